@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py — scored RANSAC hypotheses / second on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload = "p3p_5000"): BASELINE.json configs[1] — P3P LO-RANSAC on 5000 synthetic 2D-3D
+correspondences, 70 % outliers, max_iterations = 100000, with min_iterations = max_iterations so that the
+loop really evaluates 100000 iterations (with default options PoseLib stops after ~10^3).
+One "step" = one complete ransac_pnp call (sample -> P3P -> score all N -> LO -> final refinement -> inlier
+mask) on correspondences that are already resident in HBM.  A hypothesis = one minimal-solver model scored
+against all N correspondences (ransac_impl.h:112-113).  Multi-GPU: independent image pairs, one per rank
+(weak scaling, no data-path collective); RCCL is used only for the barrier and the final gather.
+
+The JSON line also carries
+  roofline     : dominant kernel k_score<ABS,5>; achieved = algorithmic bytes (hypotheses x N x 40 B, i.e. as if
+                 every hypothesis streamed the fp64 correspondence set) / HIP-event duration of the launches.
+                 NOTE the set is register/L2 resident, so physical HBM traffic is orders of magnitude lower and
+                 the real bound is the fp64 VALU; frac may therefore exceed 1.
+  cpu_baseline : the CPU oracle (port of the reference path, single thread like the reference) timed on the
+                 same workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_POINTS = 5000
+OUTLIER_RATIO = 0.7
+ITERATIONS = 100000
+MAX_ERROR_PX = 12.0
+FOCAL = 1000.0
+BYTES_PER_CORR = 40  # x, y, X, Y, Z in fp64
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iterations", type=int, default=ITERATIONS)
+    args = ap.parse_args()
+
+    import torch
+
+    import poselib_amd as P
+    from poselib_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    P.set_device(local_rank)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    # one image pair per rank (independent problems; data seed 1001 + rank)
+    scene = synth.absolute_pose_scene(N_POINTS, OUTLIER_RATIO, 1001 + rank)
+    cam = P.Camera(scene["camera"])
+    # the front-end's O(N) pre-processing (robust.cc:40-46) is done once, outside the timed region
+    import ctypes as C
+
+    from poselib_amd import _lib as L
+
+    thr = MAX_ERROR_PX / FOCAL
+    xn = (scene["p2d"] - np.array(scene["camera"]["params"][1:3])) / FOCAL  # same points the front-end feeds
+    prob = P.Problem(P.KIND_ABS, xn, scene["p3d"])  # SoA in HBM, resident from here on
+
+    def step(seed):
+        opt = {"max_error": thr, "ransac": {"max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "seed": seed}}
+        return prob.run(opt)
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(1000 + w)
+    sync()
+    t0 = time.perf_counter()
+    hyp = 0
+    kern_ms = 0.0
+    launches = 0
+    last = None
+    for s in range(args.steps):
+        pose, info = step(s)
+        hyp += info["hypotheses"]
+        kern_ms += info["score_kernel_ms"]
+        launches += info["score_kernel_launches"]
+        last = (pose, info)
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    # final gather over RCCL: [elapsed, hypotheses, kernel ms, launches, inliers, pose(7)]
+    rec = torch.tensor([elapsed, float(hyp), kern_ms, float(launches), float(last[1]["num_inliers"])]
+                       + list(last[0].q) + list(last[0].t), dtype=torch.float64, device="cuda")
+    if use_dist:
+        allrec = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        allrec = torch.stack(allrec).cpu().numpy()
+    else:
+        allrec = rec.cpu().numpy()[None]
+
+    if rank == 0:
+        t_max = float(allrec[:, 0].max())
+        total_hyp = float(allrec[:, 1].sum())
+        value = total_hyp / t_max
+        k_ms = float(allrec[0, 2])
+        k_launch = int(allrec[0, 3])
+        hyp0 = float(allrec[0, 1])
+        avg_launch_s = (k_ms / max(k_launch, 1)) * 1e-3
+        alg_bytes_per_launch = (hyp0 / max(k_launch, 1)) * N_POINTS * BYTES_PER_CORR
+        achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "scored RANSAC hypotheses/sec",
+            "value": value,
+            "unit": "hypotheses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "p3p_5000", "problem": "P3P LO-RANSAC (ransac_pnp)", "correspondences": N_POINTS,
+                       "outlier_ratio": OUTLIER_RATIO, "max_iterations": ITERATIONS, "min_iterations": ITERATIONS,
+                       "max_error_px": MAX_ERROR_PX, "problems_per_gpu_per_step": 1,
+                       "hypotheses_per_step": hyp0 / args.steps, "iterations_per_s": world * args.steps * ITERATIONS / t_max,
+                       "inliers_found": int(allrec[0, 4])},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_score<EST_ABS,5>",
+                         "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launch,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "note": "algorithmic bytes = hypotheses x N x 40 B; the set is register/L2-resident, "
+                                 "the physical bound is fp64 VALU (DESIGN.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_lib as O
+
+            o = {"max_error": thr, "ransac": {"max_iterations": args.cpu_iterations,
+                                              "min_iterations": args.cpu_iterations, "seed": 0}}
+            t1 = time.perf_counter()
+            _, _, cst = O.ransac_pnp(xn, scene["p3d"], o)
+            cpu_s = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": cst["hypotheses"] / cst["seconds"], "unit": "hypotheses/s", "cores": 1,
+                                   "kind": "port",
+                                   "sample": f"oracle ransac_pnp, same workload, {args.cpu_iterations} iterations "
+                                             f"({cst['hypotheses']} hypotheses, {cpu_s:.1f} s wall), g++ -O3 no -march, "
+                                             f"1 of {os.cpu_count()} host cores"}
+        print(json.dumps(out))
+    if use_dist:
+        dist.destroy_process_group()
+    prob.close()
+
+
+if __name__ == "__main__":
+    main()

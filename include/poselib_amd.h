@@ -1,0 +1,166 @@
+/* poselib_amd — C-ABI of the MI355X-native LO-RANSAC hot path.
+ *
+ * Drop-in boundary for the robust-estimation path of PoseLib 3.0.0 (citations relative to the
+ * reference tree, PoseLib/...).  Every entry point is `extern "C"`, takes plain pointers and sizes
+ * and is what a binding of the reference's API for this path would call:
+ *
+ *   pl_estimate_absolute_pose   <- robust.h:45-46     estimate_absolute_pose(points2D, points3D, opt, Image*, inliers*)
+ *   pl_estimate_relative_pose   <- robust.h:68-70     estimate_relative_pose(x1, x2, camera1, camera2, opt, pose*, inliers*)
+ *   pl_estimate_fundamental     <- robust.h:112-113   estimate_fundamental(x1, x2, opt, F*, inliers*)
+ *   pl_estimate_homography      <- robust.h:133-134   estimate_homography(x1, x2, opt, H*, inliers*)
+ *   pl_ransac_pnp / _relpose / _fundamental / _homography
+ *                               <- robust/ransac.h:39-40, 60-61, 85-87, 99-101
+ *   pl_p3p / pl_relpose_5pt / pl_essential_matrix_5pt / pl_relpose_7pt / pl_homography_4pt
+ *                               <- solvers/p3p.h:42, relpose_5pt.h:40-43, relpose_7pt.h:39-40, homography_4pt.h:38-39
+ *   pl_problem_* / pl_ransac_run <- the same ransac_* loop on correspondences that are already resident in
+ *                                  HBM (what bench.py times), and its batched / multi-stream form.
+ *
+ * Conventions (identical to the reference's containers):
+ *   - 2-D / 3-D points: contiguous AoS doubles, N x 2 / N x 3  (== std::vector<Eigen::Vector2d/3d>::data()).
+ *   - pose: q[4] (w, x, y, z) then t[3];  3x3 matrices: COLUMN-major (== Eigen::Matrix3d::data()).
+ *   - `inliers`: caller-allocated N bytes, 0/1 (the reference resizes a std::vector<char>).
+ *   - in/out models are the initial model when ransac.score_initial_model != 0, otherwise they are
+ *     overwritten (ransac.cc:47-50, 144-147, 252-254, 304-306).
+ *   - Algorithmic "failure" is reported through the stats exactly like the reference (e.g. too few points
+ *     => iterations == 0).  The int return value is 0 on success and a negative PL_ERR_* code for
+ *     runtime failures only.  There is NO CPU fallback: without a usable HIP device every compute entry
+ *     point returns PL_ERR_NO_DEVICE.
+ *   - Thread-safety: re-entrant; each host thread gets its own HIP stream and scratch arena.
+ */
+#ifndef POSELIB_AMD_H_
+#define POSELIB_AMD_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PL_OK 0
+#define PL_ERR_NO_DEVICE (-1)
+#define PL_ERR_HIP (-2)
+#define PL_ERR_INVALID (-3)
+#define PL_ERR_UNSUPPORTED (-4)
+
+/* types.h:39-50 */
+typedef struct {
+    uint64_t max_iterations;   /* 100000 */
+    uint64_t min_iterations;   /* 1000 */
+    double dyn_num_trials_mult; /* 3.0 */
+    double success_prob;        /* 0.9999 */
+    uint64_t seed;              /* 0 */
+    int32_t progressive_sampling; /* PROSAC: not implemented on device yet -> PL_ERR_UNSUPPORTED */
+    int32_t score_initial_model;
+    uint64_t max_prosac_iterations;
+} pl_ransac_options;
+
+/* types.h:60-95 */
+typedef struct {
+    uint64_t max_iterations; /* 100 */
+    int32_t loss_type;       /* 0 TRIVIAL, 1 TRUNCATED, 2 HUBER, 3 CAUCHY (default), 4 TRUNCATED_CAUCHY, 5 TRUNCATED_LE_ZACH */
+    int32_t lambda_update;   /* 0 NIELSEN, 1 FIXED_FACTOR */
+    int32_t damping;         /* 0 LEVENBERG, 1 MARQUARDT */
+    int32_t verbose;         /* ignored */
+    double loss_scale, gradient_tol, step_tol, relative_cost_tol, initial_lambda, min_lambda, max_lambda, lambda_factor;
+    int32_t refine_focal_length, refine_extra_params, refine_principal_point; /* must be 0 (out of scope) */
+    int32_t reserved;
+} pl_bundle_options;
+
+/* types.h:108-126, 128-145, 170-175 folded into one record; fields that do not apply are ignored */
+typedef struct {
+    pl_ransac_options ransac;
+    pl_bundle_options bundle;
+    double max_error;         /* 12.0 absolute pose, 1.0 otherwise */
+    int32_t real_focal_check; /* fundamental only */
+    int32_t tangent_sampson;  /* relative pose: must be 0 (out of scope) */
+    int32_t estimate_focal_length, estimate_extra_params; /* absolute pose: must be 0 (out of scope) */
+} pl_robust_options;
+
+/* types.h:52-58 (+ the metric numerator and timing, which the reference does not report) */
+typedef struct {
+    uint64_t refinements, iterations, num_inliers;
+    double inlier_ratio, model_score;
+    uint64_t hypotheses;          /* minimal models scored against all N points in the main loop */
+    uint64_t iterations_evaluated; /* iterations the device evaluated (>= iterations: speculative batches) */
+    double seconds;                /* host wall time of the ransac_* part */
+    double score_kernel_ms;        /* HIP-event time of the scoring kernel launches */
+    uint32_t score_kernel_launches;
+    uint32_t reserved;
+} pl_ransac_stats;
+
+/* misc/camera_models.h:56-60; supported ids: -1 NULL, 0 SIMPLE_PINHOLE, 1 PINHOLE, 4 OPENCV */
+typedef struct {
+    int32_t model_id, width, height, num_params;
+    double params[12];
+} pl_camera;
+
+typedef struct {
+    double q[4];
+    double t[3];
+} pl_camera_pose;
+
+void pl_default_ransac_options(pl_ransac_options *o);
+void pl_default_bundle_options(pl_bundle_options *o);
+/* kind: 0 absolute pose (max_error 12), 1 relative pose, 2 fundamental, 3 homography (max_error 1) */
+void pl_default_robust_options(pl_robust_options *o, int kind);
+
+/* ---- device management ---- */
+int pl_device_count(void);
+int pl_set_device(int device);      /* device used by the calling thread from now on */
+const char *pl_last_error(void);    /* thread-local description of the last failure */
+const char *pl_version(void);
+
+/* ---- robust front-ends (robust.h) ---- */
+int pl_estimate_absolute_pose(const double *points2D, const double *points3D, size_t n, const pl_robust_options *opt,
+                              pl_camera *camera, pl_camera_pose *pose, uint8_t *inliers, pl_ransac_stats *stats);
+int pl_estimate_relative_pose(const double *points2D_1, const double *points2D_2, size_t n, const pl_camera *camera1,
+                              const pl_camera *camera2, const pl_robust_options *opt, pl_camera_pose *pose,
+                              uint8_t *inliers, pl_ransac_stats *stats);
+int pl_estimate_fundamental(const double *points2D_1, const double *points2D_2, size_t n, const pl_robust_options *opt,
+                            double *F /* 9, column-major */, uint8_t *inliers, pl_ransac_stats *stats);
+int pl_estimate_homography(const double *points2D_1, const double *points2D_2, size_t n, const pl_robust_options *opt,
+                           double *H /* 9, column-major */, uint8_t *inliers, pl_ransac_stats *stats);
+
+/* ---- RANSAC entry points on normalised points (robust/ransac.h) ---- */
+int pl_ransac_pnp(const double *x, const double *X, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
+                  uint8_t *inliers, pl_ransac_stats *stats);
+int pl_ransac_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
+                      uint8_t *inliers, pl_ransac_stats *stats);
+int pl_ransac_fundamental(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *F,
+                          uint8_t *inliers, pl_ransac_stats *stats);
+int pl_ransac_homography(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *H,
+                         uint8_t *inliers, pl_ransac_stats *stats);
+
+/* ---- device-resident problems (inputs stay in HBM across calls; what bench.py times) ---- */
+typedef struct pl_problem pl_problem;
+/* kind as in pl_default_robust_options; a = first point set (N x 2), b = second (N x 3 for kind 0, else N x 2) */
+int pl_problem_create(int kind, const double *a, const double *b, size_t n, pl_problem **out);
+void pl_problem_destroy(pl_problem *p);
+/* model: pl_camera_pose for kinds 0/1, double[9] column-major for kinds 2/3 */
+int pl_ransac_run(pl_problem *p, const pl_robust_options *opt, void *model, uint8_t *inliers, pl_ransac_stats *stats);
+
+/* Score one model against the resident correspondences with the estimator's MSAC score
+ * (robust/utils.cc:36-65, 158-239, 300-329 through estimators' score_model()).  model as in pl_ransac_run. */
+int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t *inlier_count, double *score);
+/* Non-linear refinement of one model on the resident correspondences (robust/bundle.h:41-170:
+ * bundle_adjust / refine_relpose / refine_fundamental / refine_homography).  camera: absolute pose only
+ * (NULL pointer = identity camera, i.e. normalised image points).  mask: optional N bytes, refine on the
+ * flagged correspondences only. */
+int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera *camera, const uint8_t *mask,
+                    void *model, uint32_t *lm_iterations);
+
+/* ---- minimal solvers (solvers/ headers); unit bearing vectors in, solutions out; return = #solutions or <0 ---- */
+int pl_p3p(const double *x /* 3x3 */, const double *X /* 3x3 */, pl_camera_pose *out /* 4 */);
+int pl_relpose_5pt(const double *x1 /* 5x3 */, const double *x2 /* 5x3 */, pl_camera_pose *out /* 40 */);
+int pl_essential_matrix_5pt(const double *x1, const double *x2, double *E /* 10 x 9 column-major */);
+int pl_relpose_7pt(const double *x1 /* 7x3 */, const double *x2 /* 7x3 */, double *F /* 3 x 9 column-major */);
+int pl_homography_4pt(const double *x1 /* 4x3 */, const double *x2 /* 4x3 */, double *H /* 9 column-major */);
+/* batched form: `count` independent minimal problems, one GPU lane each.
+ * in: count x (2*K*3) doubles ([first set K x 3][second set K x 3]); out_models: count x max_models x 16 doubles
+ * (model records: q[4] t[3] M[9 row-major], see poselib_amd/csrc/pl_math.h); out_counts: count. */
+int pl_solve_batch(int kind, const double *in, size_t count, double *out_models, uint32_t *out_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSELIB_AMD_H_ */

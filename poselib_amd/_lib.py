@@ -1,0 +1,103 @@
+"""ctypes binding of poselib_amd/lib/libposelib_amd.so (the C-ABI in include/poselib_amd.h).
+
+The shared library is the product: hand-written HIP kernels for gfx950 plus the host driver.
+There is no Python/CPU implementation behind this module — if the library is missing or no HIP
+device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "lib", "libposelib_amd.so")
+
+u64, i32, u32, f64 = C.c_uint64, C.c_int32, C.c_uint32, C.c_double
+
+PL_OK, PL_ERR_NO_DEVICE, PL_ERR_HIP, PL_ERR_INVALID, PL_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+
+
+class RansacOptions(C.Structure):
+    _fields_ = [("max_iterations", u64), ("min_iterations", u64), ("dyn_num_trials_mult", f64), ("success_prob", f64),
+                ("seed", u64), ("progressive_sampling", i32), ("score_initial_model", i32),
+                ("max_prosac_iterations", u64)]
+
+
+class BundleOptions(C.Structure):
+    _fields_ = [("max_iterations", u64), ("loss_type", i32), ("lambda_update", i32), ("damping", i32), ("verbose", i32),
+                ("loss_scale", f64), ("gradient_tol", f64), ("step_tol", f64), ("relative_cost_tol", f64),
+                ("initial_lambda", f64), ("min_lambda", f64), ("max_lambda", f64), ("lambda_factor", f64),
+                ("refine_focal_length", i32), ("refine_extra_params", i32), ("refine_principal_point", i32),
+                ("reserved", i32)]
+
+
+class RobustOptions(C.Structure):
+    _fields_ = [("ransac", RansacOptions), ("bundle", BundleOptions), ("max_error", f64), ("real_focal_check", i32),
+                ("tangent_sampson", i32), ("estimate_focal_length", i32), ("estimate_extra_params", i32)]
+
+
+class RansacStats(C.Structure):
+    _fields_ = [("refinements", u64), ("iterations", u64), ("num_inliers", u64), ("inlier_ratio", f64),
+                ("model_score", f64), ("hypotheses", u64), ("iterations_evaluated", u64), ("seconds", f64),
+                ("score_kernel_ms", f64), ("score_kernel_launches", u32), ("reserved", u32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("model_id", i32), ("width", i32), ("height", i32), ("num_params", i32), ("params", f64 * 12)]
+
+
+class CameraPose(C.Structure):
+    _fields_ = [("q", f64 * 4), ("t", f64 * 3)]
+
+
+class PoseLibAmdError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hip", ".cc", "Makefile"))]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "poselib_amd.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        cmd = ["make", "-C", _CSRC]
+        if not verbose:
+            cmd.append("-s")
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library.  Raises if it has not been built (use poselib_amd.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PoseLibAmdError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import poselib_amd; poselib_amd.build()'` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.pl_last_error.restype = C.c_char_p
+        L.pl_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc < 0:
+        msg = lib().pl_last_error().decode()
+        raise PoseLibAmdError(f"poselib_amd error {rc}: {msg}")
+    return rc
+
+
+EXPORTED_SYMBOLS = [
+    "pl_default_ransac_options", "pl_default_bundle_options", "pl_default_robust_options", "pl_device_count",
+    "pl_set_device", "pl_last_error", "pl_version", "pl_estimate_absolute_pose", "pl_estimate_relative_pose",
+    "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
+    "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_score_model", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
+    "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch",
+]

@@ -1,0 +1,392 @@
+"""Python surface mirroring the reference's `poselib` module for the accelerated path.
+
+Signatures, option-dict keys and return shapes follow the pybind11 module of PoseLib 3.0.0:
+    estimate_absolute_pose(points2D, points3D, camera, opt={}, initial_pose=None) -> (Image, info)
+        pybind/bindings/estimators/absolute_pose.cc:15-47, 317-330
+    estimate_relative_pose(points2D_1, points2D_2, camera1, camera2, opt={}, initial_pose=None) -> (CameraPose, info)
+        pybind/bindings/estimators/relative_pose.cc:15-52, 405-420
+    estimate_fundamental(points2D_1, points2D_2, opt={}, initial_F=None) -> (3x3 ndarray, info)   (same file :221-243)
+    estimate_homography(points2D_1, points2D_2, opt={}, initial_H=None) -> (3x3 ndarray, info)
+        pybind/bindings/estimators/homography.cc:15-38, 75-77
+    p3p / relpose_5pt / essential_matrix_5pt / relpose_7pt / homography_4pt   pybind/bindings/solvers.cc:305-365
+Option dicts: nested 'ransac' / 'bundle' plus 'max_error', 'real_focal_check' (pybind/helpers.h:31-173);
+`info` holds the RansacStats fields and 'inliers' as list[bool] (helpers.h:247-253, 266-272).
+Passing an initial model sets ransac.score_initial_model (absolute_pose.cc(pybind):24-27).
+All numerical work happens in the HIP library; this file only marshals numpy arrays through the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+LOSS_TYPES = {"TRIVIAL": 0, "TRUNCATED": 1, "HUBER": 2, "CAUCHY": 3, "TRUNCATED_CAUCHY": 4, "TRUNCATED_LE_ZACH": 5}
+CAMERA_MODEL_IDS = {"NULL": -1, "SIMPLE_PINHOLE": 0, "PINHOLE": 1, "OPENCV": 4}
+_CAMERA_NAMES = {v: k for k, v in CAMERA_MODEL_IDS.items()}
+KIND_ABS, KIND_REL, KIND_FUND, KIND_HOM = 0, 1, 2, 3
+
+
+# ------------------------------------------------------------------------------------------ types
+class CameraPose:
+    """poselib.CameraPose: q (w,x,y,z), t  (pybind/bindings/types.cc:35-45)."""
+
+    def __init__(self, q=None, t=None):
+        self.q = np.array([1.0, 0.0, 0.0, 0.0]) if q is None else np.asarray(q, dtype=np.float64).copy()
+        self.t = np.zeros(3) if t is None else np.asarray(t, dtype=np.float64).copy()
+
+    @property
+    def R(self):
+        w, x, y, z = self.q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    @property
+    def Rt(self):
+        return np.concatenate([self.R, self.t[:, None]], axis=1)
+
+    def center(self):
+        return -self.R.T @ self.t
+
+    def __repr__(self):
+        return f"CameraPose(q={self.q.tolist()}, t={self.t.tolist()})"
+
+
+class Camera:
+    """poselib.Camera subset (pybind/bindings/types.cc:68-113)."""
+
+    def __init__(self, model="SIMPLE_PINHOLE", params=(), width=0, height=0):
+        if isinstance(model, dict):
+            d = model
+            model, params = d["model"], d["params"]
+            width, height = d.get("width", 0), d.get("height", 0)
+        self.model_id = CAMERA_MODEL_IDS[model] if isinstance(model, str) else int(model)
+        self.params = [float(p) for p in params]
+        self.width, self.height = int(width), int(height)
+
+    def model_name(self):
+        return _CAMERA_NAMES[self.model_id]
+
+    def focal(self):
+        if not self.params:
+            return 1.0
+        if self.model_id == 0:
+            return self.params[0]
+        if self.model_id in (1, 4):
+            return 0.5 * self.params[0] + 0.5 * self.params[1]
+        return 1.0
+
+    def todict(self):
+        return {"model": self.model_name(), "width": self.width, "height": self.height, "params": list(self.params)}
+
+    def _c(self) -> L.Camera:
+        c = L.Camera()
+        c.model_id, c.width, c.height, c.num_params = self.model_id, self.width, self.height, len(self.params)
+        for i, v in enumerate(self.params):
+            c.params[i] = v
+        return c
+
+
+class Image:
+    """poselib.Image {camera, pose} (pybind/bindings/types.cc:117-119)."""
+
+    def __init__(self, pose=None, camera=None):
+        self.pose = pose or CameraPose()
+        self.camera = camera or Camera()
+
+
+def RansacOptions():
+    return {"max_iterations": 100000, "min_iterations": 1000, "dyn_num_trials_mult": 3.0, "success_prob": 0.9999,
+            "seed": 0, "progressive_sampling": False, "max_prosac_iterations": 100000}
+
+
+def BundleOptions():
+    return {"max_iterations": 100, "loss_type": "CAUCHY", "loss_scale": 1.0, "gradient_tol": 1e-12, "step_tol": 1e-8,
+            "relative_cost_tol": 1e-10, "initial_lambda": 1e-3, "min_lambda": 1e-10, "max_lambda": 1e10,
+            "lambda_factor": 10.0, "verbose": False}
+
+
+# ------------------------------------------------------------------------------------------ marshalling
+def _robust_options(opt, kind: int, score_initial: bool) -> L.RobustOptions:
+    o = L.RobustOptions()
+    L.lib().pl_default_robust_options(C.byref(o), kind)
+    opt = opt or {}
+    r = opt.get("ransac", {})
+    for k in ("max_iterations", "min_iterations", "seed", "max_prosac_iterations"):
+        if k in r:
+            setattr(o.ransac, k, int(r[k]))
+    for k in ("dyn_num_trials_mult", "success_prob"):
+        if k in r:
+            setattr(o.ransac, k, float(r[k]))
+    if "progressive_sampling" in r:
+        o.ransac.progressive_sampling = int(bool(r["progressive_sampling"]))
+    o.ransac.score_initial_model = int(score_initial)
+    b = opt.get("bundle", {})
+    if "max_iterations" in b:
+        o.bundle.max_iterations = int(b["max_iterations"])
+    for k in ("loss_scale", "gradient_tol", "step_tol", "relative_cost_tol", "initial_lambda", "min_lambda",
+              "max_lambda", "lambda_factor"):
+        if k in b:
+            setattr(o.bundle, k, float(b[k]))
+    if "loss_type" in b:
+        lt = b["loss_type"]
+        o.bundle.loss_type = LOSS_TYPES[lt.upper()] if isinstance(lt, str) else int(lt)
+    for k in ("refine_focal_length", "refine_extra_params", "refine_principal_point"):
+        if k in b:
+            setattr(o.bundle, k, int(bool(b[k])))
+    if "max_error" in opt:
+        o.max_error = float(opt["max_error"])
+    for k in ("real_focal_check", "tangent_sampson", "estimate_focal_length", "estimate_extra_params"):
+        if k in opt:
+            setattr(o, k, int(bool(opt[k])))
+    return o
+
+
+def _pts(a, dim):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != dim:
+        raise ValueError(f"expected an (N, {dim}) array")
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _info(st: L.RansacStats, inliers: np.ndarray):
+    return {"refinements": st.refinements, "iterations": st.iterations, "num_inliers": st.num_inliers,
+            "inlier_ratio": st.inlier_ratio, "model_score": st.model_score, "inliers": inliers.astype(bool).tolist(),
+            # extras (not in the reference): metric numerator and device timing
+            "hypotheses": st.hypotheses, "iterations_evaluated": st.iterations_evaluated, "seconds": st.seconds,
+            "score_kernel_ms": st.score_kernel_ms, "score_kernel_launches": st.score_kernel_launches}
+
+
+def _cpose(p: CameraPose) -> L.CameraPose:
+    c = L.CameraPose()
+    for i in range(4):
+        c.q[i] = p.q[i]
+    for i in range(3):
+        c.t[i] = p.t[i]
+    return c
+
+
+def _pypose(c: L.CameraPose) -> CameraPose:
+    return CameraPose(np.array(c.q[:]), np.array(c.t[:]))
+
+
+def _as_camera(cam) -> Camera:
+    return cam if isinstance(cam, Camera) else Camera(cam)
+
+
+# ------------------------------------------------------------------------------------------ estimators
+def estimate_absolute_pose(points2D, points3D, camera, opt=None, initial_pose=None):
+    p2, p3 = _pts(points2D, 2), _pts(points3D, 3)
+    cam = _as_camera(camera)
+    o = _robust_options(opt, KIND_ABS, initial_pose is not None)
+    c = cam._c()
+    pose = _cpose(initial_pose if initial_pose is not None else CameraPose())
+    n = p2.shape[0]
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    st = L.RansacStats()
+    L.check(L.lib().pl_estimate_absolute_pose(_ptr(p2), _ptr(p3), C.c_size_t(n), C.byref(o), C.byref(c), C.byref(pose),
+                                              _ptr(inl), C.byref(st)))
+    out_cam = Camera(cam.model_id, list(c.params[: c.num_params]), cam.width, cam.height)
+    return Image(_pypose(pose), out_cam), _info(st, inl[:n])
+
+
+def estimate_relative_pose(points2D_1, points2D_2, camera1, camera2, opt=None, initial_pose=None):
+    a, b = _pts(points2D_1, 2), _pts(points2D_2, 2)
+    c1, c2 = _as_camera(camera1)._c(), _as_camera(camera2)._c()
+    o = _robust_options(opt, KIND_REL, initial_pose is not None)
+    pose = _cpose(initial_pose if initial_pose is not None else CameraPose())
+    n = a.shape[0]
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    st = L.RansacStats()
+    L.check(L.lib().pl_estimate_relative_pose(_ptr(a), _ptr(b), C.c_size_t(n), C.byref(c1), C.byref(c2), C.byref(o),
+                                              C.byref(pose), _ptr(inl), C.byref(st)))
+    return _pypose(pose), _info(st, inl[:n])
+
+
+def _estimate_matrix(fn, kind, points2D_1, points2D_2, opt, initial):
+    a, b = _pts(points2D_1, 2), _pts(points2D_2, 2)
+    o = _robust_options(opt, kind, initial is not None)
+    M = np.ascontiguousarray((np.eye(3) if initial is None else np.asarray(initial, dtype=np.float64)).T.reshape(9))
+    n = a.shape[0]
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    st = L.RansacStats()
+    L.check(getattr(L.lib(), fn)(_ptr(a), _ptr(b), C.c_size_t(n), C.byref(o), _ptr(M), _ptr(inl), C.byref(st)))
+    return M.reshape(3, 3).T.copy(), _info(st, inl[:n])
+
+
+def estimate_fundamental(points2D_1, points2D_2, opt=None, initial_F=None):
+    return _estimate_matrix("pl_estimate_fundamental", KIND_FUND, points2D_1, points2D_2, opt, initial_F)
+
+
+def estimate_homography(points2D_1, points2D_2, opt=None, initial_H=None):
+    return _estimate_matrix("pl_estimate_homography", KIND_HOM, points2D_1, points2D_2, opt, initial_H)
+
+
+# ------------------------------------------------------------------------------------------ ransac_* on normalised points
+def _ransac(fn, kind, a, b, dim_b, opt, initial):
+    a, b = _pts(a, 2), _pts(b, dim_b)
+    o = _robust_options(opt, kind, initial is not None)
+    n = a.shape[0]
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    st = L.RansacStats()
+    if kind in (KIND_ABS, KIND_REL):
+        pose = _cpose(initial if initial is not None else CameraPose())
+        L.check(getattr(L.lib(), fn)(_ptr(a), _ptr(b), C.c_size_t(n), C.byref(o), C.byref(pose), _ptr(inl), C.byref(st)))
+        return _pypose(pose), _info(st, inl[:n])
+    M = np.ascontiguousarray((np.eye(3) if initial is None else np.asarray(initial, dtype=np.float64)).T.reshape(9))
+    L.check(getattr(L.lib(), fn)(_ptr(a), _ptr(b), C.c_size_t(n), C.byref(o), _ptr(M), _ptr(inl), C.byref(st)))
+    return M.reshape(3, 3).T.copy(), _info(st, inl[:n])
+
+
+def ransac_pnp(x, X, opt=None, initial_pose=None):
+    return _ransac("pl_ransac_pnp", KIND_ABS, x, X, 3, opt, initial_pose)
+
+
+def ransac_relpose(x1, x2, opt=None, initial_pose=None):
+    return _ransac("pl_ransac_relpose", KIND_REL, x1, x2, 2, opt, initial_pose)
+
+
+def ransac_fundamental(x1, x2, opt=None, initial_F=None):
+    return _ransac("pl_ransac_fundamental", KIND_FUND, x1, x2, 2, opt, initial_F)
+
+
+def ransac_homography(x1, x2, opt=None, initial_H=None):
+    return _ransac("pl_ransac_homography", KIND_HOM, x1, x2, 2, opt, initial_H)
+
+
+# ------------------------------------------------------------------------------------------ device-resident problems
+class Problem:
+    """Correspondences uploaded once (SoA in HBM); `run` executes the LO-RANSAC loop on them.
+    This is the entry bench.py times: inputs are resident before the timed region starts."""
+
+    def __init__(self, kind: int, a, b):
+        self.kind = kind
+        a = _pts(a, 2)
+        b = _pts(b, 3 if kind == KIND_ABS else 2)
+        self.n = a.shape[0]
+        self._h = C.c_void_p()
+        L.check(L.lib().pl_problem_create(kind, _ptr(a), _ptr(b), C.c_size_t(self.n), C.byref(self._h)))
+
+    def run(self, opt=None, initial=None):
+        o = _robust_options(opt, self.kind, initial is not None)
+        inl = np.zeros(max(self.n, 1), dtype=np.uint8)
+        st = L.RansacStats()
+        if self.kind in (KIND_ABS, KIND_REL):
+            model = _cpose(initial if initial is not None else CameraPose())
+            L.check(L.lib().pl_ransac_run(self._h, C.byref(o), C.byref(model), _ptr(inl), C.byref(st)))
+            return _pypose(model), _info(st, inl[: self.n])
+        M = np.ascontiguousarray((np.eye(3) if initial is None else np.asarray(initial, dtype=np.float64)).T.reshape(9))
+        L.check(L.lib().pl_ransac_run(self._h, C.byref(o), _ptr(M), _ptr(inl), C.byref(st)))
+        return M.reshape(3, 3).T.copy(), _info(st, inl[: self.n])
+
+    def score(self, model, max_error):
+        """MSAC score + inlier count of one model (the estimators' score_model())."""
+        cnt = C.c_uint64(0)
+        sc = C.c_double(0.0)
+        if self.kind in (KIND_ABS, KIND_REL):
+            m = _cpose(model)
+            L.check(L.lib().pl_score_model(self._h, C.byref(m), C.c_double(max_error), C.byref(cnt), C.byref(sc)))
+        else:
+            M = np.ascontiguousarray(np.asarray(model, dtype=np.float64).T.reshape(9))
+            L.check(L.lib().pl_score_model(self._h, _ptr(M), C.c_double(max_error), C.byref(cnt), C.byref(sc)))
+        return sc.value, cnt.value
+
+    def refine(self, model, bundle_opt=None, camera=None, mask=None):
+        """bundle_adjust / refine_relpose / refine_fundamental / refine_homography on the resident points."""
+        o = _robust_options({"bundle": bundle_opt or {}}, self.kind, False).bundle
+        cam = None if camera is None else _as_camera(camera)._c()
+        it = C.c_uint32(0)
+        m8 = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        args_tail = (C.byref(cam) if cam is not None else None, None if m8 is None else _ptr(m8))
+        if self.kind in (KIND_ABS, KIND_REL):
+            m = _cpose(model)
+            L.check(L.lib().pl_refine_model(self._h, C.byref(o), *args_tail, C.byref(m), C.byref(it)))
+            return _pypose(m), it.value
+        M = np.ascontiguousarray(np.asarray(model, dtype=np.float64).T.reshape(9))
+        L.check(L.lib().pl_refine_model(self._h, C.byref(o), *args_tail, _ptr(M), C.byref(it)))
+        return M.reshape(3, 3).T.copy(), it.value
+
+    def close(self):
+        if self._h:
+            L.lib().pl_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------ minimal solvers
+def _bearings(x, k):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if x.shape != (k, 3):
+        raise ValueError(f"expected {k} bearing vectors of dimension 3")
+    return x
+
+
+def p3p(x, X):
+    x, X = _bearings(x, 3), _bearings(X, 3)
+    out = (L.CameraPose * 4)()
+    n = L.check(L.lib().pl_p3p(_ptr(x), _ptr(X), out))
+    return [_pypose(out[i]) for i in range(n)]
+
+
+def relpose_5pt(x1, x2):
+    x1, x2 = _bearings(x1, 5), _bearings(x2, 5)
+    out = (L.CameraPose * 40)()
+    n = L.check(L.lib().pl_relpose_5pt(_ptr(x1), _ptr(x2), out))
+    return [_pypose(out[i]) for i in range(n)]
+
+
+p5p = relpose_5pt  # alias named by the task statement; the reference exposes relpose_5pt / essential_matrix_5pt
+
+
+def essential_matrix_5pt(x1, x2):
+    x1, x2 = _bearings(x1, 5), _bearings(x2, 5)
+    out = np.zeros((10, 9))
+    n = L.check(L.lib().pl_essential_matrix_5pt(_ptr(x1), _ptr(x2), _ptr(out)))
+    return [out[i].reshape(3, 3).T.copy() for i in range(n)]
+
+
+def relpose_7pt(x1, x2):
+    x1, x2 = _bearings(x1, 7), _bearings(x2, 7)
+    out = np.zeros((3, 9))
+    n = L.check(L.lib().pl_relpose_7pt(_ptr(x1), _ptr(x2), _ptr(out)))
+    return [out[i].reshape(3, 3).T.copy() for i in range(n)]
+
+
+def homography_4pt(x1, x2):
+    x1, x2 = _bearings(x1, 4), _bearings(x2, 4)
+    out = np.zeros(9)
+    n = L.check(L.lib().pl_homography_4pt(_ptr(x1), _ptr(x2), _ptr(out)))
+    return [out.reshape(3, 3).T.copy()] if n else []
+
+
+def solve_batch(kind: int, first, second):
+    """Many minimal problems at once, one GPU lane each.  first/second: (B, K, 3).  Returns
+    (records (B, max_models, 16), counts (B,)) — record layout: q[4] t[3] M[9 row-major]."""
+    first = np.ascontiguousarray(first, dtype=np.float64)
+    second = np.ascontiguousarray(second, dtype=np.float64)
+    B, K = first.shape[0], first.shape[1]
+    maxm = {0: 4, 1: 40, 2: 3, 3: 1}[kind]
+    inp = np.ascontiguousarray(np.concatenate([first.reshape(B, -1), second.reshape(B, -1)], axis=1))
+    out = np.zeros((B, maxm, 16))
+    cnt = np.zeros(B, dtype=np.uint32)
+    L.check(L.lib().pl_solve_batch(kind, _ptr(inp), C.c_size_t(B), _ptr(out), _ptr(cnt)))
+    return out, cnt
+
+
+def device_count() -> int:
+    return L.lib().pl_device_count()
+
+
+def set_device(i: int):
+    L.check(L.lib().pl_set_device(int(i)))

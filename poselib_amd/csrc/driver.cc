@@ -1,0 +1,1453 @@
+// poselib_amd — host driver behind the C-ABI (include/poselib_amd.h).
+//
+// What runs where
+//   device : sample draw + minimal solve (k_generate), hypothesis scoring (k_score/k_finalize), all LM
+//            refinements (k_lm), final inlier masks (k_mask).
+//   host   : the sequential bookkeeping of LO-RANSAC, replayed over the device results so that the outcome
+//            equals the reference's single-threaded loop (PoseLib/robust/ransac_impl.h:106-201):
+//              pass 1  scan (inlier count, MSAC score) of every minimal hypothesis of a batch in
+//                      (iteration, model) order; best_minimal_* depends on minimal models only (:113-123),
+//                      so the iterations that trigger LO and their seed models are known without LO results;
+//              device  all triggered LOs of the batch run as ONE batched k_lm launch, then are re-scored;
+//              pass 2  replay stats.model_score / best_model / dynamic_max_iter and the stop rule (:182)
+//                      iteration by iteration; iterations evaluated past the stop are discarded.
+//            plus O(N) pre/post-processing of the front-ends (PoseLib/robust.cc:36-126, 242-314, 544-594,
+//            712-757): un-projection, normalisation, threshold rescaling, de-normalisation.
+// There is no CPU fallback for any device stage: without a HIP device the entry points fail.
+#include "../../include/poselib_amd.h"
+#include "pl_kernels.h"
+#include "pl_sampler.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+using namespace pl;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what, hipError_t e = hipSuccess) {
+    g_err = what;
+    if (e != hipSuccess) {
+        g_err += ": ";
+        g_err += hipGetErrorString(e);
+    }
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t _e = (expr);                                                                                        \
+        if (_e != hipSuccess)                                                                                          \
+            return fail(PL_ERR_HIP, #expr, _e);                                                                        \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+struct HostBuf { // pinned
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct Context {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // batch scratch
+    DevBuf positions, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
+    HostBuf h_positions, h_num_models, h_count, h_score, h_tasks, h_records, h_gather_idx, h_gather_out, h_mask,
+        h_small;
+};
+
+thread_local Context *g_ctx = nullptr;
+thread_local int g_requested_device = 0;
+
+int get_context(Context **out) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(PL_ERR_NO_DEVICE, "no HIP device available (poselib_amd has no CPU fallback)", e);
+    if (g_ctx && g_ctx->device == g_requested_device) {
+        HIP_TRY(hipSetDevice(g_ctx->device));
+        *out = g_ctx;
+        return PL_OK;
+    }
+    if (g_requested_device < 0 || g_requested_device >= ndev)
+        return fail(PL_ERR_INVALID, "device index out of range");
+    // (a context bound to another device is simply leaked for the lifetime of the thread)
+    Context *c = new Context();
+    c->device = g_requested_device;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    g_ctx = c;
+    *out = c;
+    return PL_OK;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+} // namespace
+
+struct pl_problem {
+    int kind;
+    int device;
+    uint32_t n;
+    double *d_pts; // SoA block: nd arrays of n doubles
+    PointSet ps;
+};
+
+namespace {
+
+LMOptions to_lm(const pl_bundle_options &b) {
+    LMOptions o;
+    o.max_iterations = (uint32_t)std::min<uint64_t>(b.max_iterations, 0xffffffffu);
+    o.loss_type = b.loss_type;
+    o.lambda_update = b.lambda_update;
+    o.damping = b.damping;
+    o.loss_scale = b.loss_scale;
+    o.gradient_tol = b.gradient_tol;
+    o.step_tol = b.step_tol;
+    o.relative_cost_tol = b.relative_cost_tol;
+    o.initial_lambda = b.initial_lambda;
+    o.min_lambda = b.min_lambda;
+    o.max_lambda = b.max_lambda;
+    o.lambda_factor = b.lambda_factor;
+    return o;
+}
+LMOptions lo_options(double max_error) { // estimators/absolute_pose.cc:61-64 (identical in the four estimators)
+    pl_bundle_options b;
+    pl_default_bundle_options(&b);
+    b.loss_type = LOSS_TRUNCATED;
+    b.loss_scale = max_error;
+    b.max_iterations = 25;
+    return to_lm(b);
+}
+CameraParams to_cam(const pl_camera *c) {
+    CameraParams r;
+    std::memset(&r, 0, sizeof(r));
+    if (!c) {
+        r.model_id = CAM_NULL;
+        return r;
+    }
+    r.model_id = c->model_id;
+    r.num_params = c->num_params;
+    for (int i = 0; i < 12; ++i)
+        r.p[i] = c->params[i];
+    return r;
+}
+bool camera_supported(const pl_camera *c) {
+    return c->model_id == CAM_NULL || (c->model_id == CAM_SIMPLE_PINHOLE && c->num_params >= 3) ||
+           (c->model_id == CAM_PINHOLE && c->num_params >= 4) || (c->model_id == CAM_OPENCV && c->num_params >= 8);
+}
+double camera_focal(const pl_camera *c) { // misc/camera_models.cc:304-323
+    if (c->num_params == 0)
+        return 1.0;
+    switch (c->model_id) {
+    case CAM_SIMPLE_PINHOLE:
+        return 0.0 + c->params[0] / 1;
+    case CAM_PINHOLE:
+    case CAM_OPENCV:
+        return 0.0 + c->params[0] / 2 + c->params[1] / 2;
+    default:
+        return 1.0;
+    }
+}
+void camera_rescale(CameraParams &c, double s) { // misc/camera_models.cc:432-455
+    if (c.num_params == 0)
+        return;
+    if (c.model_id == CAM_SIMPLE_PINHOLE) {
+        c.p[0] *= s, c.p[1] *= s, c.p[2] *= s;
+    } else if (c.model_id == CAM_PINHOLE || c.model_id == CAM_OPENCV) {
+        for (int i = 0; i < 4; ++i)
+            c.p[i] *= s;
+    }
+}
+
+// ---- model <-> parameter block <-> record conversions (host side, IEEE add/mul only) ----
+// `model` is the user-facing representation: pose = 7 doubles (q,t); matrix = 9 doubles ROW-major here.
+void params_from_record(int kind, const double *rec, double *params) {
+    for (int i = 0; i < kParamDoubles; ++i)
+        params[i] = 0.0;
+    if (kind == EST_ABS || kind == EST_REL) {
+        for (int i = 0; i < 7; ++i)
+            params[i] = rec[i];
+    } else {
+        for (int i = 0; i < 9; ++i)
+            params[i] = rec[kMatOff + i];
+    }
+}
+
+// One-sided Jacobi SVD of a 3x3 (row-major), A = U diag(s) V^T, s descending.  Used once per
+// fundamental-matrix refinement to enter the Bartoli-Sturm factorisation
+// (PoseLib/robust/optim/optim_utils.h:57-72 uses Eigen::JacobiSVD).
+void svd3(const Mat3 &A, Mat3 &U, double s[3], Mat3 &V) {
+    Mat3 B = A;
+    for (int i = 0; i < 9; ++i)
+        V.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const Vec3 bp = col(B, p), bq = col(B, q);
+                const double alpha = dot(bp, bp), beta = dot(bq, bq), gamma = dot(bp, bq);
+                if (gamma == 0.0)
+                    continue;
+                off = std::max(off, std::fabs(gamma) / std::sqrt(std::max(alpha * beta, 1e-300)));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = ((zeta >= 0) ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                set_col(B, p, c * bp - sn * bq);
+                set_col(B, q, sn * bp + c * bq);
+                const Vec3 vp = col(V, p), vq = col(V, q);
+                set_col(V, p, c * vp - sn * vq);
+                set_col(V, q, sn * vp + c * vq);
+            }
+        if (off < 1e-15)
+            break;
+    }
+    int order[3] = {0, 1, 2};
+    double sv[3];
+    for (int i = 0; i < 3; ++i)
+        sv[i] = std::sqrt(dot(col(B, i), col(B, i)));
+    std::sort(order, order + 3, [&](int a, int b) { return sv[a] > sv[b]; });
+    Mat3 Vs;
+    Vec3 u[3];
+    for (int i = 0; i < 3; ++i) {
+        s[i] = sv[order[i]];
+        set_col(Vs, i, col(V, order[i]));
+        u[i] = col(B, order[i]);
+    }
+    u[0] = u[0] / s[0];
+    if (s[1] > 1e-14 * s[0])
+        u[1] = u[1] / s[1];
+    else
+        u[1] = normalized(cross(u[0], (std::fabs(u[0].x) < 0.9) ? v3(1, 0, 0) : v3(0, 1, 0)));
+    if (s[2] > 1e-14 * s[0])
+        u[2] = u[2] / s[2];
+    else
+        u[2] = cross(u[0], u[1]);
+    for (int i = 0; i < 3; ++i)
+        set_col(U, i, u[i]);
+    V = Vs;
+}
+
+// Parameter block that enters k_lm for a model given as record.
+void lm_params_from_record(int kind, const double *rec, double *params) {
+    params_from_record(kind, rec, params);
+    if (kind == EST_FUND) { // factorise F = U diag(1, sigma, 0) V^T  (bundle.cc:318-319)
+        Mat3 F, U, V;
+        for (int i = 0; i < 9; ++i)
+            F.m[i] = rec[kMatOff + i];
+        double s[3];
+        svd3(F, U, s, V);
+        if (det3(U) < 0)
+            for (int i = 0; i < 9; ++i)
+                U.m[i] = -U.m[i];
+        if (det3(V) < 0)
+            for (int i = 0; i < 9; ++i)
+                V.m[i] = -V.m[i];
+        const Quat qU = rotmat_to_quat(U), qV = rotmat_to_quat(V);
+        for (int i = 0; i < kParamDoubles; ++i)
+            params[i] = 0.0;
+        params[0] = qU.w, params[1] = qU.x, params[2] = qU.y, params[3] = qU.z;
+        params[4] = qV.w, params[5] = qV.x, params[6] = qV.y, params[7] = qV.z;
+        params[8] = s[1] / s[0];
+    }
+}
+// Record (what k_score consumes) of a refined parameter block.
+void record_from_lm_params(int kind, const double *params, double *rec) {
+    if (kind == EST_ABS || kind == EST_REL) {
+        Quat q;
+        q.w = params[0], q.x = params[1], q.y = params[2], q.z = params[3];
+        store_pose_model_q(rec, q, v3(params[4], params[5], params[6]), kind == EST_REL);
+    } else if (kind == EST_HOM) {
+        Mat3 H;
+        for (int i = 0; i < 9; ++i)
+            H.m[i] = params[i];
+        store_matrix_model(rec, H);
+    } else {
+        Mat3 F;
+        factorized_F(params, F.m);
+        store_matrix_model(rec, F);
+    }
+}
+void identity_record(int kind, double *rec) {
+    if (kind == EST_ABS || kind == EST_REL) {
+        Quat q;
+        q.w = 1.0, q.x = q.y = q.z = 0.0;
+        store_pose_model_q(rec, q, v3(0, 0, 0), kind == EST_REL);
+    } else {
+        Mat3 I;
+        for (int i = 0; i < 9; ++i)
+            I.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        store_matrix_model(rec, I);
+    }
+}
+
+// ---- iteration bound (ransac_impl.h:43-73) ----
+double prob_all_inliers(uint64_t inl, uint64_t N, uint64_t K) {
+    if (K == 0)
+        return 1.0;
+    if (inl < K || N < K)
+        return 0.0;
+    double p = 1.0;
+    for (uint64_t i = 0; i < K; ++i)
+        p *= static_cast<double>(inl - i) / static_cast<double>(N - i);
+    return p;
+}
+uint64_t dynamic_max_iter(uint64_t inl, uint64_t N, uint64_t K, double log_fail, double mult, uint64_t min_it,
+                          uint64_t max_it) {
+    const double p = prob_all_inliers(inl, N, K);
+    if (p >= 0.9999)
+        return min_it;
+    if (p <= 0.0001)
+        return max_it;
+    const uint64_t n = static_cast<uint64_t>(std::ceil(log_fail / std::log(1.0 - p) * mult));
+    return std::max(min_it, std::min(max_it, n));
+}
+
+// Host replay of the sampler to find where each iteration's draws start (integer work, a few ns per
+// draw).  Returns the draw position after `count` iterations.
+template <int K> uint64_t sample_positions(uint64_t seed, uint64_t pos, uint64_t N, uint32_t count, uint32_t *out) {
+    uint32_t idx[K];
+    for (uint32_t i = 0; i < count; ++i) {
+        out[i] = (uint32_t)pos;
+        pos += draw_sample<K>(seed, pos, N, idx);
+    }
+    return pos;
+}
+uint64_t sample_positions_k(int K, uint64_t seed, uint64_t pos, uint64_t N, uint32_t count, uint32_t *out) {
+    switch (K) {
+    case 3:
+        return sample_positions<3>(seed, pos, N, count, out);
+    case 4:
+        return sample_positions<4>(seed, pos, N, count, out);
+    case 5:
+        return sample_positions<5>(seed, pos, N, count, out);
+    default:
+        return sample_positions<7>(seed, pos, N, count, out);
+    }
+}
+
+// Score `nrec` model records that already sit in device memory at `d_records`.  Results land in the
+// pinned h_count / h_score buffers after the caller synchronises.
+int enqueue_score_records(Context *c, const pl_problem *p, const double *d_records, uint32_t nrec, double thr2,
+                          bool time_it) {
+    const uint32_t chunks = score_chunks(p->kind, p->n);
+    HIP_TRY(c->num_hyp.ensure(sizeof(uint32_t)));
+    HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * nrec));
+    HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * nrec));
+    HIP_TRY(c->count.ensure(sizeof(uint32_t) * nrec));
+    HIP_TRY(c->score.ensure(sizeof(double) * nrec));
+    HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * nrec));
+    HIP_TRY(c->h_score.ensure(sizeof(double) * nrec));
+    HIP_TRY(hipMemcpyAsync(c->num_hyp.p, &nrec, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    ScoreArgs sa;
+    sa.pts = p->ps;
+    sa.models = d_records;
+    sa.slots = nullptr;
+    sa.num_hyp = c->num_hyp.as<uint32_t>();
+    sa.hyp_capacity = nrec;
+    sa.thr2 = thr2;
+    sa.part_count = c->part_count.as<uint32_t>();
+    sa.part_score = c->part_score.as<double>();
+    (void)time_it;
+    HIP_TRY(launch_score(p->kind, sa, std::min<uint32_t>(nrec, 1024u), c->stream));
+    FinalizeArgs fa;
+    fa.num_hyp = sa.num_hyp;
+    fa.hyp_capacity = nrec;
+    fa.chunks = chunks;
+    fa.n_points = p->n;
+    fa.thr2 = thr2;
+    fa.part_count = sa.part_count;
+    fa.part_score = sa.part_score;
+    fa.count = c->count.as<uint32_t>();
+    fa.score = c->score.as<double>();
+    HIP_TRY(launch_finalize(fa, nrec, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_count.p, c->count.p, sizeof(uint32_t) * nrec, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_score.p, c->score.p, sizeof(double) * nrec, hipMemcpyDeviceToHost, c->stream));
+    return PL_OK;
+}
+
+struct RefineJob {
+    double record_in[kModelStride]; // seed model
+    LMOptions opt;
+    CameraParams cam;
+    double point_scale = 1.0;
+    double prefilter_thr2 = 0.0;
+    const uint8_t *d_mask = nullptr;
+    // outputs
+    double record_out[kModelStride];
+    double params_out[kParamDoubles];
+    uint32_t count = 0;
+    double score = 0;
+    bool skipped = false;
+};
+
+// Runs all jobs as one batched k_lm launch, converts the refined parameters to records and (optionally)
+// re-scores them with threshold thr2.  Synchronises the stream.
+int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &jobs, bool rescore, double thr2) {
+    const uint32_t nj = (uint32_t)jobs.size();
+    if (nj == 0)
+        return PL_OK;
+    HIP_TRY(c->h_tasks.ensure(sizeof(LMTask) * nj));
+    HIP_TRY(c->lm_tasks.ensure(sizeof(LMTask) * nj));
+    HIP_TRY(c->lm_scratch.ensure((size_t)p->n * nj + 16));
+    LMTask *ht = c->h_tasks.as<LMTask>();
+    for (uint32_t j = 0; j < nj; ++j) {
+        LMTask &t = ht[j];
+        std::memset(&t, 0, sizeof(t));
+        lm_params_from_record(p->kind, jobs[j].record_in, t.params);
+        t.opt = jobs[j].opt;
+        t.cam = jobs[j].cam;
+        t.point_scale = jobs[j].point_scale;
+        t.prefilter_thr2 = jobs[j].prefilter_thr2;
+        t.mask = jobs[j].d_mask;
+        t.scratch = c->lm_scratch.as<uint8_t>() + (size_t)j * p->n;
+    }
+    HIP_TRY(hipMemcpyAsync(c->lm_tasks.p, ht, sizeof(LMTask) * nj, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_lm(p->kind, p->ps, c->lm_tasks.as<LMTask>(), nj, c->stream));
+    HIP_TRY(hipMemcpyAsync(ht, c->lm_tasks.p, sizeof(LMTask) * nj, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(c->h_records.ensure(sizeof(double) * kModelStride * nj));
+    HIP_TRY(c->lm_records.ensure(sizeof(double) * kModelStride * nj));
+    double *hr = c->h_records.as<double>();
+    for (uint32_t j = 0; j < nj; ++j) {
+        jobs[j].skipped = ht[j].skipped != 0;
+        std::memcpy(jobs[j].params_out, ht[j].params, sizeof(double) * kParamDoubles);
+        if (jobs[j].skipped) // refinement not run: model unchanged (relative_pose.cc:75-77)
+            std::memcpy(jobs[j].record_out, jobs[j].record_in, sizeof(double) * kModelStride);
+        else
+            record_from_lm_params(p->kind, ht[j].params, jobs[j].record_out);
+        std::memcpy(hr + (size_t)j * kModelStride, jobs[j].record_out, sizeof(double) * kModelStride);
+    }
+    if (!rescore)
+        return PL_OK;
+    HIP_TRY(hipMemcpyAsync(c->lm_records.p, hr, sizeof(double) * kModelStride * nj, hipMemcpyHostToDevice, c->stream));
+    int rc = enqueue_score_records(c, p, c->lm_records.as<double>(), nj, thr2, false);
+    if (rc != PL_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t j = 0; j < nj; ++j) {
+        jobs[j].count = c->h_count.as<uint32_t>()[j];
+        jobs[j].score = c->h_score.as<double>()[j];
+    }
+    return PL_OK;
+}
+
+struct Improving { // a minimal hypothesis that improved best_minimal_* (candidate for best_model)
+    uint32_t iter;   // absolute iteration index
+    uint32_t slot;   // model record index inside the batch
+    uint32_t count;
+    double score;
+    bool lo_seed;    // last improving hypothesis of its iteration
+    uint32_t gather; // index into the gathered record array
+    int job = -1;    // index of the refinement job when lo_seed
+};
+
+int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, double *best_record /* in/out */,
+                uint8_t *inliers, pl_ransac_stats *st) {
+    const int kind = p->kind;
+    const uint32_t N = p->n;
+    const int K = sample_size(kind);
+    const int MAXM = max_models(kind);
+    const pl_ransac_options &ro = o->ransac;
+    const double thr2 = o->max_error * o->max_error;
+    const LMOptions lo_opt = lo_options(o->max_error);
+    CameraParams null_cam;
+    std::memset(&null_cam, 0, sizeof(null_cam));
+    null_cam.model_id = CAM_NULL;
+
+    std::memset(st, 0, sizeof(*st));
+    st->model_score = std::numeric_limits<double>::max();
+    const double t_start = now_s();
+
+    auto make_lo_job = [&](const double *rec) {
+        RefineJob j;
+        std::memcpy(j.record_in, rec, sizeof(j.record_in));
+        j.opt = lo_opt;
+        j.cam = null_cam;
+        j.point_scale = 1.0;
+        j.prefilter_thr2 = (kind == EST_REL) ? 5 * thr2 : 0.0; // relative_pose.cc:70
+        return j;
+    };
+
+    if (N >= (uint32_t)K) { // ransac_impl.h:161-163
+        uint64_t best_min_inl = 0;
+        double best_min_score = std::numeric_limits<double>::max();
+        uint64_t dyn_max = ro.max_iterations;
+        const double log_fail = std::log(1.0 - ro.success_prob);
+        st->num_inliers = 0;
+
+        auto after_lo = [&](const RefineJob &job) { // ransac_impl.h:138-153
+            st->refinements++;
+            if (job.score < st->model_score) {
+                st->model_score = job.score;
+                st->num_inliers = job.count;
+                std::memcpy(best_record, job.record_out, sizeof(double) * kModelStride);
+            }
+            st->inlier_ratio = static_cast<double>(st->num_inliers) / static_cast<double>(N);
+            dyn_max = dynamic_max_iter(st->num_inliers, N, K, log_fail, ro.dyn_num_trials_mult, ro.min_iterations,
+                                       ro.max_iterations);
+        };
+
+        if (ro.score_initial_model) { // ransac_impl.h:174-176 : one pseudo-iteration with the supplied model
+            HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
+            HIP_TRY(hipMemcpyAsync(c->tmp_model.p, best_record, sizeof(double) * kModelStride, hipMemcpyHostToDevice,
+                                   c->stream));
+            int rc = enqueue_score_records(c, p, c->tmp_model.as<double>(), 1, thr2, false);
+            if (rc != PL_OK)
+                return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const uint32_t cnt = c->h_count.as<uint32_t>()[0];
+            const double sc = c->h_score.as<double>()[0];
+            const bool more = cnt > best_min_inl, better = sc < best_min_score;
+            if (more || better) {
+                if (more)
+                    best_min_inl = cnt;
+                if (better)
+                    best_min_score = sc;
+                if (sc < st->model_score) {
+                    st->model_score = sc;
+                    st->num_inliers = cnt;
+                }
+                std::vector<RefineJob> jobs{make_lo_job(best_record)};
+                rc = run_refinements(c, p, jobs, true, thr2);
+                if (rc != PL_OK)
+                    return rc;
+                after_lo(jobs[0]);
+            }
+        }
+
+        // batch capacity: bounded by the scratch the model records need
+        const uint32_t cap = (kind == EST_REL) ? 16384u : 131072u;
+        uint64_t grow = std::max<uint64_t>(ro.min_iterations + 2, 512);
+        grow = (grow + 63) / 64 * 64;
+        uint64_t it = 0;   // next iteration to evaluate == iterations replayed so far
+        uint64_t pos = 0;  // sampler draws consumed so far
+        bool stopped = false;
+        std::vector<Improving> imps;
+        std::vector<RefineJob> jobs;
+
+        while (!stopped && it < ro.max_iterations) {
+            if (it > ro.min_iterations && it > dyn_max) { // stop rule at the top of the next iteration (:182)
+                stopped = true;
+                break;
+            }
+            // the loop cannot stop before max(min_iterations, dynamic_max_iter) + 1 iterations
+            uint64_t needed = std::max<uint64_t>(ro.min_iterations, dyn_max) + 1;
+            needed = std::min<uint64_t>(needed, ro.max_iterations);
+            needed = (needed > it) ? needed - it : 1;
+            const uint32_t B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
+            grow = std::min<uint64_t>(grow * 2, cap);
+
+            // ---- device: generate + score the whole batch ----
+            HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * B));
+            const uint64_t pos_after = sample_positions_k(K, ro.seed, pos, N, B, c->h_positions.as<uint32_t>());
+            if (pos_after >= 0xffffffffull)
+                return fail(PL_ERR_UNSUPPORTED, "sampler draw counter exceeds 32 bits");
+            const size_t hcap = (size_t)B * MAXM;
+            const uint32_t chunks = score_chunks(kind, N);
+            HIP_TRY(c->positions.ensure(sizeof(uint32_t) * B));
+            HIP_TRY(c->models.ensure(sizeof(double) * kModelStride * hcap));
+            HIP_TRY(c->num_models.ensure(sizeof(uint32_t) * B));
+            HIP_TRY(c->slots.ensure(sizeof(uint32_t) * hcap));
+            HIP_TRY(c->num_hyp.ensure(sizeof(uint32_t)));
+            HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * hcap));
+            HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * hcap));
+            HIP_TRY(c->count.ensure(sizeof(uint32_t) * hcap));
+            HIP_TRY(c->score.ensure(sizeof(double) * hcap));
+            HIP_TRY(c->h_num_models.ensure(sizeof(uint32_t) * (B + 1)));
+            HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * hcap));
+            HIP_TRY(c->h_score.ensure(sizeof(double) * hcap));
+            HIP_TRY(hipMemcpyAsync(c->positions.p, c->h_positions.p, sizeof(uint32_t) * B, hipMemcpyHostToDevice,
+                                   c->stream));
+            GenerateArgs ga;
+            ga.pts = p->ps;
+            ga.seed = ro.seed;
+            ga.positions = c->positions.as<uint32_t>();
+            ga.num_iters = B;
+            ga.models = c->models.as<double>();
+            ga.num_models = c->num_models.as<uint32_t>();
+            ga.real_focal_check = o->real_focal_check;
+            HIP_TRY(launch_generate(kind, ga, c->stream));
+            HIP_TRY(launch_compact(ga.num_models, B, MAXM, c->slots.as<uint32_t>(), c->num_hyp.as<uint32_t>(),
+                                   c->stream));
+            ScoreArgs sa;
+            sa.pts = p->ps;
+            sa.models = ga.models;
+            sa.slots = c->slots.as<uint32_t>();
+            sa.num_hyp = c->num_hyp.as<uint32_t>();
+            sa.hyp_capacity = (uint32_t)hcap;
+            sa.thr2 = thr2;
+            sa.part_count = c->part_count.as<uint32_t>();
+            sa.part_score = c->part_score.as<double>();
+            const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, (uint32_t)hcap));
+            HIP_TRY(hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(launch_score(kind, sa, slices, c->stream));
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            FinalizeArgs fa;
+            fa.num_hyp = sa.num_hyp;
+            fa.hyp_capacity = (uint32_t)hcap;
+            fa.chunks = chunks;
+            fa.n_points = N;
+            fa.thr2 = thr2;
+            fa.part_count = sa.part_count;
+            fa.part_score = sa.part_score;
+            fa.count = c->count.as<uint32_t>();
+            fa.score = c->score.as<double>();
+            HIP_TRY(launch_finalize(fa, (uint32_t)hcap, c->stream));
+            uint32_t *h_nm = c->h_num_models.as<uint32_t>();
+            HIP_TRY(hipMemcpyAsync(h_nm, c->num_models.p, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(h_nm + B, c->num_hyp.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const uint32_t H = h_nm[B];
+            if (H) {
+                HIP_TRY(hipMemcpyAsync(c->h_count.p, c->count.p, sizeof(uint32_t) * H, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(c->h_score.p, c->score.p, sizeof(double) * H, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            st->score_kernel_ms += ms;
+            st->score_kernel_launches++;
+            st->iterations_evaluated += B;
+
+            // ---- host pass 1: which hypotheses improve best_minimal_*  (ransac_impl.h:110-133) ----
+            const uint32_t *h_cnt = c->h_count.as<uint32_t>();
+            const double *h_sc = c->h_score.as<double>();
+            imps.clear();
+            {
+                uint32_t k = 0;
+                for (uint32_t i = 0; i < B; ++i) {
+                    int last = -1;
+                    for (uint32_t m = 0; m < h_nm[i]; ++m, ++k) {
+                        const bool more = h_cnt[k] > best_min_inl;
+                        const bool better = h_sc[k] < best_min_score;
+                        if (!(more || better))
+                            continue;
+                        if (more)
+                            best_min_inl = h_cnt[k];
+                        if (better)
+                            best_min_score = h_sc[k];
+                        Improving im;
+                        im.iter = (uint32_t)(it + i);
+                        im.slot = i * MAXM + m;
+                        im.count = h_cnt[k];
+                        im.score = h_sc[k];
+                        im.lo_seed = false;
+                        im.gather = (uint32_t)imps.size();
+                        imps.push_back(im);
+                        last = (int)imps.size() - 1;
+                    }
+                    if (last >= 0)
+                        imps[last].lo_seed = true;
+                }
+            }
+
+            // ---- device: fetch the improving records, run every triggered LO of the batch at once ----
+            const uint32_t ni = (uint32_t)imps.size();
+            const double *h_rec = nullptr;
+            if (ni) {
+                HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * ni));
+                double *dst = c->h_gather_out.as<double>();
+                for (uint32_t a = 0; a < ni; ++a)
+                    HIP_TRY(hipMemcpyAsync(dst + (size_t)a * kModelStride,
+                                           c->models.as<double>() + (size_t)imps[a].slot * kModelStride,
+                                           sizeof(double) * kModelStride, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                h_rec = dst;
+                jobs.clear();
+                for (uint32_t a = 0; a < ni; ++a)
+                    if (imps[a].lo_seed) {
+                        imps[a].job = (int)jobs.size();
+                        jobs.push_back(make_lo_job(h_rec + (size_t)a * kModelStride));
+                    }
+                int rc = run_refinements(c, p, jobs, true, thr2);
+                if (rc != PL_OK)
+                    return rc;
+            }
+
+            // ---- host pass 2: replay the sequential loop over this batch (ransac_impl.h:180-188) ----
+            uint32_t a = 0; // cursor into imps
+            uint32_t hyp_cursor = 0;
+            uint64_t i = 0;
+            for (; i < B; ++i) {
+                const uint64_t iter = it + i;
+                if (iter > ro.min_iterations && iter > dyn_max) {
+                    stopped = true;
+                    break;
+                }
+                st->hypotheses += h_nm[i];
+                hyp_cursor += h_nm[i];
+                while (a < ni && imps[a].iter == iter) {
+                    const Improving &im = imps[a];
+                    if (im.score < st->model_score) { // :126-131
+                        st->model_score = im.score;
+                        st->num_inliers = im.count;
+                        std::memcpy(best_record, h_rec + (size_t)im.gather * kModelStride,
+                                    sizeof(double) * kModelStride);
+                    }
+                    if (im.lo_seed)
+                        after_lo(jobs[im.job]);
+                    ++a;
+                }
+            }
+            (void)hyp_cursor;
+            it += i;
+            pos = pos_after;
+        }
+        st->iterations = it;
+
+        // ---- final refinement of the best model (ransac_impl.h:190-198; model_score is not updated) ----
+        {
+            std::vector<RefineJob> fin{make_lo_job(best_record)};
+            int rc = run_refinements(c, p, fin, true, thr2);
+            if (rc != PL_OK)
+                return rc;
+            st->refinements++;
+            if (fin[0].score < st->model_score) {
+                std::memcpy(best_record, fin[0].record_out, sizeof(double) * kModelStride);
+                st->num_inliers = fin[0].count;
+            }
+        }
+    }
+
+    // ---- inlier mask of the returned model (ransac.cc:55, 152, 259, 311) ----
+    if (N > 0) {
+        HIP_TRY(c->mask.ensure(N));
+        HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
+        HIP_TRY(hipMemcpyAsync(c->tmp_model.p, best_record, sizeof(double) * kModelStride, hipMemcpyHostToDevice,
+                               c->stream));
+        HIP_TRY(launch_mask(kind, p->ps, c->tmp_model.as<double>(), thr2, c->mask.as<uint8_t>(), c->stream));
+        if (inliers)
+            HIP_TRY(hipMemcpyAsync(inliers, c->mask.p, N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    st->seconds = now_s() - t_start;
+    return PL_OK;
+}
+
+int validate_options(const pl_robust_options *o) {
+    if (!o)
+        return fail(PL_ERR_INVALID, "options pointer is null");
+    if (o->ransac.progressive_sampling)
+        return fail(PL_ERR_UNSUPPORTED, "PROSAC sampling is not implemented on the device path yet");
+    if (o->bundle.refine_focal_length || o->bundle.refine_extra_params || o->bundle.refine_principal_point)
+        return fail(PL_ERR_UNSUPPORTED, "intrinsics refinement is outside the accelerated hot path");
+    if (o->tangent_sampson || o->estimate_focal_length || o->estimate_extra_params)
+        return fail(PL_ERR_UNSUPPORTED, "tangent-Sampson / focal-length estimation are outside the accelerated hot path");
+    return PL_OK;
+}
+
+int make_problem(Context *c, int kind, const double *a, const double *b, size_t n, pl_problem *p) {
+    if (kind < 0 || kind > 3)
+        return fail(PL_ERR_INVALID, "unknown problem kind");
+    if (n > 0x7fffffffu)
+        return fail(PL_ERR_INVALID, "too many correspondences");
+    p->kind = kind;
+    p->device = c->device;
+    p->n = (uint32_t)n;
+    p->d_pts = nullptr;
+    const int nd = point_doubles(kind);
+    const int da = 2, db = (kind == EST_ABS) ? 3 : 2;
+    std::memset(&p->ps, 0, sizeof(p->ps));
+    p->ps.n = (uint32_t)n;
+    if (n == 0)
+        return PL_OK;
+    std::vector<double> soa((size_t)nd * n);
+    for (size_t i = 0; i < n; ++i) {
+        for (int d = 0; d < da; ++d)
+            soa[(size_t)d * n + i] = a[da * i + d];
+        for (int d = 0; d < db; ++d)
+            soa[(size_t)(da + d) * n + i] = b[db * i + d];
+    }
+    HIP_TRY(hipMalloc((void **)&p->d_pts, sizeof(double) * nd * n));
+    HIP_TRY(hipMemcpyAsync(p->d_pts, soa.data(), sizeof(double) * nd * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int d = 0; d < nd; ++d)
+        p->ps.a[d] = p->d_pts + (size_t)d * n;
+    return PL_OK;
+}
+void free_problem(pl_problem *p) {
+    if (p->d_pts)
+        (void)hipFree(p->d_pts);
+    p->d_pts = nullptr;
+}
+
+// user model <-> record
+void record_from_pose(const pl_camera_pose *pose, bool essential, double *rec) {
+    Quat q;
+    q.w = pose->q[0], q.x = pose->q[1], q.y = pose->q[2], q.z = pose->q[3];
+    store_pose_model_q(rec, q, v3(pose->t[0], pose->t[1], pose->t[2]), essential);
+}
+void pose_from_record(const double *rec, pl_camera_pose *pose) {
+    for (int i = 0; i < 4; ++i)
+        pose->q[i] = rec[i];
+    for (int i = 0; i < 3; ++i)
+        pose->t[i] = rec[4 + i];
+}
+Mat3 mat_from_colmajor(const double *m) {
+    Mat3 A;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i)
+            A.m[3 * i + j] = m[3 * j + i];
+    return A;
+}
+void mat_to_colmajor(const Mat3 &A, double *m) {
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i)
+            m[3 * j + i] = A.m[3 * i + j];
+}
+Mat3 transpose3(const Mat3 &A) {
+    Mat3 T;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            T.m[3 * i + j] = A.m[3 * j + i];
+    return T;
+}
+void normalize_frobenius(Mat3 &A) {
+    double s = 0;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i)
+            s += A.m[3 * i + j] * A.m[3 * i + j];
+    const double n = std::sqrt(s);
+    for (int i = 0; i < 9; ++i)
+        A.m[i] /= n;
+}
+
+int run_with_model(Context *c, pl_problem *p, const pl_robust_options *o, void *model, uint8_t *inliers,
+                   pl_ransac_stats *st, double *record_out = nullptr) {
+    double rec[kModelStride];
+    const bool pose_kind = (p->kind == EST_ABS || p->kind == EST_REL);
+    if (o->ransac.score_initial_model) {
+        if (pose_kind)
+            record_from_pose(static_cast<const pl_camera_pose *>(model), p->kind == EST_REL, rec);
+        else
+            store_matrix_model(rec, mat_from_colmajor(static_cast<const double *>(model)));
+    } else {
+        identity_record(p->kind, rec);
+    }
+    int rc = ransac_core(c, p, o, rec, inliers, st);
+    if (rc != PL_OK)
+        return rc;
+    if (pose_kind) {
+        pose_from_record(rec, static_cast<pl_camera_pose *>(model));
+    } else {
+        Mat3 M;
+        for (int i = 0; i < 9; ++i)
+            M.m[i] = rec[kMatOff + i];
+        mat_to_colmajor(M, static_cast<double *>(model));
+    }
+    if (record_out)
+        std::memcpy(record_out, rec, sizeof(rec));
+    return PL_OK;
+}
+
+// Final polish on the inliers (device mask from ransac_core is still in c->mask).
+int final_refine(Context *c, pl_problem *p, const double *record_in, const LMOptions &opt, const CameraParams &cam,
+                 double point_scale, double *record_out, double *params_out) {
+    RefineJob j;
+    std::memcpy(j.record_in, record_in, sizeof(j.record_in));
+    j.opt = opt;
+    j.cam = cam;
+    j.point_scale = point_scale;
+    j.prefilter_thr2 = 0.0;
+    j.d_mask = c->mask.as<uint8_t>();
+    std::vector<RefineJob> jobs{j};
+    int rc = run_refinements(c, p, jobs, false, 0.0);
+    if (rc != PL_OK)
+        return rc;
+    std::memcpy(record_out, jobs[0].record_out, sizeof(double) * kModelStride);
+    if (params_out)
+        std::memcpy(params_out, jobs[0].params_out, sizeof(double) * kParamDoubles);
+    return PL_OK;
+}
+
+// PoseLib/robust/utils.cc:584-644 with normalize_scale = shared_scale = true
+double normalize_points_shared(std::vector<double> &x1, std::vector<double> &x2, size_t n, Mat3 &T1, Mat3 &T2,
+                               bool centroid) {
+    for (int i = 0; i < 9; ++i)
+        T1.m[i] = T2.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (centroid) {
+        double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+        for (size_t k = 0; k < n; ++k) {
+            c1x += x1[2 * k], c1y += x1[2 * k + 1];
+            c2x += x2[2 * k], c2y += x2[2 * k + 1];
+        }
+        c1x /= static_cast<double>(n), c1y /= static_cast<double>(n);
+        c2x /= static_cast<double>(n), c2y /= static_cast<double>(n);
+        T1.m[2] = -c1x, T1.m[5] = -c1y;
+        T2.m[2] = -c2x, T2.m[5] = -c2y;
+        for (size_t k = 0; k < n; ++k) {
+            x1[2 * k] -= c1x, x1[2 * k + 1] -= c1y;
+            x2[2 * k] -= c2x, x2[2 * k + 1] -= c2y;
+        }
+    }
+    double scale = 0.0;
+    for (size_t k = 0; k < n; ++k) {
+        scale += std::sqrt(x1[2 * k] * x1[2 * k] + x1[2 * k + 1] * x1[2 * k + 1]);
+        scale += std::sqrt(x2[2 * k] * x2[2 * k] + x2[2 * k + 1] * x2[2 * k + 1]);
+    }
+    scale /= std::sqrt(2) * n;
+    for (size_t k = 0; k < 2 * n; ++k) {
+        x1[k] /= scale;
+        x2[k] /= scale;
+    }
+    const double f = 1.0 / scale;
+    for (int i = 0; i < 6; ++i) {
+        T1.m[i] *= f;
+        T2.m[i] *= f;
+    }
+    return scale;
+}
+
+} // namespace
+
+// =============================================================================================== C-ABI
+extern "C" {
+
+const char *pl_version(void) { return "poselib_amd 0.1 (gfx950)"; }
+const char *pl_last_error(void) { return g_err.c_str(); }
+
+void pl_default_ransac_options(pl_ransac_options *o) {
+    o->max_iterations = 100000;
+    o->min_iterations = 1000;
+    o->dyn_num_trials_mult = 3.0;
+    o->success_prob = 0.9999;
+    o->seed = 0;
+    o->progressive_sampling = 0;
+    o->score_initial_model = 0;
+    o->max_prosac_iterations = 100000;
+}
+void pl_default_bundle_options(pl_bundle_options *o) {
+    std::memset(o, 0, sizeof(*o));
+    o->max_iterations = 100;
+    o->loss_type = LOSS_CAUCHY;
+    o->lambda_update = 0;
+    o->damping = 0;
+    o->loss_scale = 1.0;
+    o->gradient_tol = 1e-12;
+    o->step_tol = 1e-8;
+    o->relative_cost_tol = 1e-10;
+    o->initial_lambda = 1e-3;
+    o->min_lambda = 1e-10;
+    o->max_lambda = 1e10;
+    o->lambda_factor = 10.0;
+}
+void pl_default_robust_options(pl_robust_options *o, int kind) {
+    std::memset(o, 0, sizeof(*o));
+    pl_default_ransac_options(&o->ransac);
+    pl_default_bundle_options(&o->bundle);
+    o->max_error = (kind == 0) ? 12.0 : 1.0;
+}
+
+int pl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+int pl_set_device(int device) {
+    g_requested_device = device;
+    Context *c;
+    return get_context(&c);
+}
+
+int pl_problem_create(int kind, const double *a, const double *b, size_t n, pl_problem **out) {
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    pl_problem *p = new pl_problem();
+    rc = make_problem(c, kind, a, b, n, p);
+    if (rc != PL_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return PL_OK;
+}
+void pl_problem_destroy(pl_problem *p) {
+    if (!p)
+        return;
+    free_problem(p);
+    delete p;
+}
+int pl_ransac_run(pl_problem *p, const pl_robust_options *opt, void *model, uint8_t *inliers, pl_ransac_stats *stats) {
+    int rc = validate_options(opt);
+    if (rc != PL_OK)
+        return rc;
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    if (p->device != c->device)
+        return fail(PL_ERR_INVALID, "problem lives on another device than the calling thread's");
+    pl_ransac_stats local;
+    return run_with_model(c, p, opt, model, inliers, stats ? stats : &local);
+}
+
+int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t *inlier_count, double *score) {
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    double rec[kModelStride];
+    if (p->kind == EST_ABS || p->kind == EST_REL)
+        record_from_pose(static_cast<const pl_camera_pose *>(model), p->kind == EST_REL, rec);
+    else
+        store_matrix_model(rec, mat_from_colmajor(static_cast<const double *>(model)));
+    HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
+    HIP_TRY(hipMemcpyAsync(c->tmp_model.p, rec, sizeof(rec), hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_score_records(c, p, c->tmp_model.as<double>(), 1, max_error * max_error, false);
+    if (rc != PL_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (inlier_count)
+        *inlier_count = c->h_count.as<uint32_t>()[0];
+    if (score)
+        *score = c->h_score.as<double>()[0];
+    return PL_OK;
+}
+
+int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera *camera, const uint8_t *mask,
+                    void *model, uint32_t *lm_iterations) {
+    if (opt->refine_focal_length || opt->refine_extra_params || opt->refine_principal_point)
+        return fail(PL_ERR_UNSUPPORTED, "intrinsics refinement is outside the accelerated hot path");
+    if (camera && !camera_supported(camera))
+        return fail(PL_ERR_UNSUPPORTED, "camera model not supported (NULL, SIMPLE_PINHOLE, PINHOLE, OPENCV)");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    RefineJob j;
+    const bool pose_kind = (p->kind == EST_ABS || p->kind == EST_REL);
+    if (pose_kind)
+        record_from_pose(static_cast<const pl_camera_pose *>(model), p->kind == EST_REL, j.record_in);
+    else
+        store_matrix_model(j.record_in, mat_from_colmajor(static_cast<const double *>(model)));
+    j.opt = to_lm(*opt);
+    j.cam = to_cam(camera);
+    j.point_scale = 1.0;
+    j.prefilter_thr2 = 0.0;
+    j.d_mask = nullptr;
+    if (mask && p->n) {
+        HIP_TRY(c->mask.ensure(p->n));
+        HIP_TRY(hipMemcpyAsync(c->mask.p, mask, p->n, hipMemcpyHostToDevice, c->stream));
+        j.d_mask = c->mask.as<uint8_t>();
+    }
+    std::vector<RefineJob> jobs{j};
+    rc = run_refinements(c, p, jobs, false, 0.0);
+    if (rc != PL_OK)
+        return rc;
+    if (lm_iterations)
+        *lm_iterations = c->h_tasks.as<LMTask>()[0].iterations;
+    if (pose_kind) {
+        pose_from_record(jobs[0].record_out, static_cast<pl_camera_pose *>(model));
+    } else {
+        Mat3 M;
+        for (int i = 0; i < 9; ++i)
+            M.m[i] = jobs[0].record_out[kMatOff + i];
+        mat_to_colmajor(M, static_cast<double *>(model));
+    }
+    return PL_OK;
+}
+
+static int ransac_oneshot(int kind, const double *a, const double *b, size_t n, const pl_robust_options *opt,
+                          void *model, uint8_t *inliers, pl_ransac_stats *stats) {
+    int rc = validate_options(opt);
+    if (rc != PL_OK)
+        return rc;
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    pl_problem p;
+    rc = make_problem(c, kind, a, b, n, &p);
+    if (rc != PL_OK)
+        return rc;
+    pl_ransac_stats local;
+    rc = run_with_model(c, &p, opt, model, inliers, stats ? stats : &local);
+    free_problem(&p);
+    return rc;
+}
+int pl_ransac_pnp(const double *x, const double *X, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
+                  uint8_t *inliers, pl_ransac_stats *stats) {
+    return ransac_oneshot(EST_ABS, x, X, n, opt, pose, inliers, stats);
+}
+int pl_ransac_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
+                      uint8_t *inliers, pl_ransac_stats *stats) {
+    return ransac_oneshot(EST_REL, x1, x2, n, opt, pose, inliers, stats);
+}
+int pl_ransac_fundamental(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *F,
+                          uint8_t *inliers, pl_ransac_stats *stats) {
+    return ransac_oneshot(EST_FUND, x1, x2, n, opt, F, inliers, stats);
+}
+int pl_ransac_homography(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *H,
+                         uint8_t *inliers, pl_ransac_stats *stats) {
+    return ransac_oneshot(EST_HOM, x1, x2, n, opt, H, inliers, stats);
+}
+
+// ---------------------------------------------------------------------------- front-ends (robust.cc)
+int pl_estimate_absolute_pose(const double *points2D, const double *points3D, size_t n, const pl_robust_options *opt,
+                              pl_camera *camera, pl_camera_pose *pose, uint8_t *inliers, pl_ransac_stats *stats) {
+    int rc = validate_options(opt);
+    if (rc != PL_OK)
+        return rc;
+    if (!camera || !camera_supported(camera))
+        return fail(PL_ERR_UNSUPPORTED, "camera model not supported (NULL, SIMPLE_PINHOLE, PINHOLE, OPENCV)");
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    // robust.cc:40-46 : un-project, rescale the threshold by 1/focal
+    const CameraParams cam = to_cam(camera);
+    std::vector<double> xn(2 * n);
+    for (size_t k = 0; k < n; ++k)
+        camera_unproject(cam, points2D[2 * k], points2D[2 * k + 1], xn[2 * k], xn[2 * k + 1]);
+    pl_robust_options scaled = *opt;
+    double scale = 1.0 / camera_focal(camera);
+    scaled.max_error *= scale;
+
+    pl_problem p;
+    rc = make_problem(c, EST_ABS, xn.data(), points3D, n, &p);
+    if (rc != PL_OK)
+        return rc;
+    pl_ransac_stats local;
+    pl_ransac_stats *st = stats ? stats : &local;
+    double rec[kModelStride];
+    rc = run_with_model(c, &p, &scaled, pose, inliers, st, rec);
+    free_problem(&p);
+    if (rc != PL_OK)
+        return rc;
+
+    if (st->num_inliers > 3) { // robust.cc:103-123 : bundle over the inliers in focal-normalised pixels
+        pl_problem pp;
+        rc = make_problem(c, EST_ABS, points2D, points3D, n, &pp);
+        if (rc != PL_OK)
+            return rc;
+        scale = 1.0 / camera_focal(camera);
+        pl_bundle_options b = opt->bundle;
+        b.loss_scale = opt->bundle.loss_scale * scale;
+        CameraParams cs = cam;
+        camera_rescale(cs, scale);
+        double out[kModelStride];
+        rc = final_refine(c, &pp, rec, to_lm(b), cs, scale, out, nullptr);
+        free_problem(&pp);
+        if (rc != PL_OK)
+            return rc;
+        pose_from_record(out, pose);
+        // camera.rescale(scale) ... rescale(1/scale) round trip of the reference (robust.cc:119-121)
+        CameraParams back = cs;
+        camera_rescale(back, 1.0 / scale);
+        for (int i = 0; i < camera->num_params && i < 12; ++i)
+            camera->params[i] = back.p[i];
+    }
+    return PL_OK;
+}
+
+int pl_estimate_relative_pose(const double *x1, const double *x2, size_t n, const pl_camera *camera1,
+                              const pl_camera *camera2, const pl_robust_options *opt, pl_camera_pose *pose,
+                              uint8_t *inliers, pl_ransac_stats *stats) {
+    int rc = validate_options(opt);
+    if (rc != PL_OK)
+        return rc;
+    if (!camera1 || !camera2 || !camera_supported(camera1) || !camera_supported(camera2))
+        return fail(PL_ERR_UNSUPPORTED, "camera model not supported (NULL, SIMPLE_PINHOLE, PINHOLE, OPENCV)");
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    // robust.cc:249-253, 286-292
+    const double scale = 0.5 * (1.0 / camera_focal(camera1) + 1.0 / camera_focal(camera2));
+    pl_robust_options scaled = *opt;
+    scaled.max_error *= scale;
+    scaled.bundle.loss_scale *= scale;
+    const CameraParams c1 = to_cam(camera1), c2 = to_cam(camera2);
+    std::vector<double> a(2 * n), b(2 * n);
+    for (size_t k = 0; k < n; ++k) {
+        camera_unproject(c1, x1[2 * k], x1[2 * k + 1], a[2 * k], a[2 * k + 1]);
+        camera_unproject(c2, x2[2 * k], x2[2 * k + 1], b[2 * k], b[2 * k + 1]);
+    }
+    pl_problem p;
+    rc = make_problem(c, EST_REL, a.data(), b.data(), n, &p);
+    if (rc != PL_OK)
+        return rc;
+    pl_ransac_stats local;
+    pl_ransac_stats *st = stats ? stats : &local;
+    double rec[kModelStride];
+    rc = run_with_model(c, &p, &scaled, pose, inliers, st, rec);
+    if (rc == PL_OK && st->num_inliers > 5) { // robust.cc:296-311
+        CameraParams nc;
+        std::memset(&nc, 0, sizeof(nc));
+        nc.model_id = CAM_NULL;
+        double out[kModelStride];
+        rc = final_refine(c, &p, rec, to_lm(scaled.bundle), nc, 1.0, out, nullptr);
+        if (rc == PL_OK)
+            pose_from_record(out, pose);
+    }
+    free_problem(&p);
+    return rc;
+}
+
+int pl_estimate_fundamental(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *F,
+                            uint8_t *inliers, pl_ransac_stats *stats) {
+    int rc = validate_options(opt);
+    if (rc != PL_OK)
+        return rc;
+    pl_ransac_stats local;
+    pl_ransac_stats *st = stats ? stats : &local;
+    if (n < 7) { // robust.cc:548-550
+        std::memset(st, 0, sizeof(*st));
+        st->model_score = std::numeric_limits<double>::max();
+        return PL_OK;
+    }
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    std::vector<double> a(x1, x1 + 2 * n), b(x2, x2 + 2 * n);
+    Mat3 T1, T2;
+    const double scale = normalize_points_shared(a, b, n, T1, T2, !opt->real_focal_check);
+    pl_robust_options scaled = *opt;
+    scaled.max_error /= scale;
+    scaled.bundle.loss_scale /= scale;
+    Mat3 Fm = mat_from_colmajor(F);
+    if (opt->ransac.score_initial_model) { // robust.cc:566-569
+        Fm = mul(mul(inverse3(transpose3(T2)), Fm), inverse3(T1));
+        normalize_frobenius(Fm);
+    }
+    double Fcm[9];
+    mat_to_colmajor(Fm, Fcm);
+    pl_problem p;
+    rc = make_problem(c, EST_FUND, a.data(), b.data(), n, &p);
+    if (rc != PL_OK)
+        return rc;
+    double rec[kModelStride];
+    rc = run_with_model(c, &p, &scaled, Fcm, inliers, st, rec);
+    if (rc == PL_OK && st->num_inliers > 7) { // robust.cc:573-588
+        CameraParams nc;
+        std::memset(&nc, 0, sizeof(nc));
+        nc.model_id = CAM_NULL;
+        double out[kModelStride];
+        rc = final_refine(c, &p, rec, to_lm(scaled.bundle), nc, 1.0, out, nullptr);
+        if (rc == PL_OK)
+            std::memcpy(rec, out, sizeof(rec));
+    }
+    free_problem(&p);
+    if (rc != PL_OK)
+        return rc;
+    for (int i = 0; i < 9; ++i)
+        Fm.m[i] = rec[kMatOff + i];
+    Fm = mul(mul(transpose3(T2), Fm), T1); // robust.cc:590-591
+    normalize_frobenius(Fm);
+    mat_to_colmajor(Fm, F);
+    return PL_OK;
+}
+
+int pl_estimate_homography(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *H,
+                           uint8_t *inliers, pl_ransac_stats *stats) {
+    int rc = validate_options(opt);
+    if (rc != PL_OK)
+        return rc;
+    pl_ransac_stats local;
+    pl_ransac_stats *st = stats ? stats : &local;
+    if (n < 4) { // robust.cc:716-718
+        std::memset(st, 0, sizeof(*st));
+        st->model_score = std::numeric_limits<double>::max();
+        return PL_OK;
+    }
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    std::vector<double> a(x1, x1 + 2 * n), b(x2, x2 + 2 * n);
+    Mat3 T1, T2;
+    const double scale = normalize_points_shared(a, b, n, T1, T2, true);
+    pl_robust_options scaled = *opt;
+    scaled.max_error /= scale;
+    scaled.bundle.loss_scale /= scale;
+    Mat3 Hm = mat_from_colmajor(H);
+    if (opt->ransac.score_initial_model) { // robust.cc:729-732
+        Hm = mul(mul(T2, Hm), inverse3(T1));
+        normalize_frobenius(Hm);
+    }
+    double Hcm[9];
+    mat_to_colmajor(Hm, Hcm);
+    pl_problem p;
+    rc = make_problem(c, EST_HOM, a.data(), b.data(), n, &p);
+    if (rc != PL_OK)
+        return rc;
+    double rec[kModelStride];
+    rc = run_with_model(c, &p, &scaled, Hcm, inliers, st, rec);
+    if (rc == PL_OK && st->num_inliers > 4) { // robust.cc:736-751
+        CameraParams nc;
+        std::memset(&nc, 0, sizeof(nc));
+        nc.model_id = CAM_NULL;
+        double out[kModelStride];
+        rc = final_refine(c, &p, rec, to_lm(scaled.bundle), nc, 1.0, out, nullptr);
+        if (rc == PL_OK)
+            std::memcpy(rec, out, sizeof(rec));
+    }
+    free_problem(&p);
+    if (rc != PL_OK)
+        return rc;
+    for (int i = 0; i < 9; ++i)
+        Hm.m[i] = rec[kMatOff + i];
+    Hm = mul(mul(inverse3(T2), Hm), T1); // robust.cc:753-754
+    normalize_frobenius(Hm);
+    mat_to_colmajor(Hm, H);
+    return PL_OK;
+}
+
+// ---------------------------------------------------------------------------- minimal solvers
+int pl_solve_batch(int kind, const double *in, size_t count, double *out_models, uint32_t *out_counts) {
+    if (kind < 0 || kind > 3)
+        return fail(PL_ERR_INVALID, "unknown solver kind");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    if (count == 0)
+        return PL_OK;
+    const int K = sample_size(kind), MAXM = max_models(kind);
+    const size_t in_bytes = sizeof(double) * 6 * K * count;
+    const size_t out_bytes = sizeof(double) * kModelStride * MAXM * count;
+    HIP_TRY(c->solve_in.ensure(in_bytes));
+    HIP_TRY(c->solve_out.ensure(out_bytes));
+    HIP_TRY(c->solve_cnt.ensure(sizeof(uint32_t) * count));
+    HIP_TRY(hipMemcpyAsync(c->solve_in.p, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_solve_batch(kind, c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<double>(),
+                               c->solve_cnt.as<uint32_t>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(out_models, c->solve_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_counts, c->solve_cnt.p, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PL_OK;
+}
+
+static int solve_one(int kind, const double *a, const double *b, double *records, uint32_t *cnt) {
+    const int K = sample_size(kind);
+    std::vector<double> in(6 * K);
+    std::memcpy(in.data(), a, sizeof(double) * 3 * K);
+    std::memcpy(in.data() + 3 * K, b, sizeof(double) * 3 * K);
+    return pl_solve_batch(kind, in.data(), 1, records, cnt);
+}
+int pl_p3p(const double *x, const double *X, pl_camera_pose *out) {
+    double rec[4 * kModelStride];
+    uint32_t n = 0;
+    int rc = solve_one(EST_ABS, x, X, rec, &n);
+    if (rc != PL_OK)
+        return rc;
+    for (uint32_t i = 0; i < n; ++i)
+        pose_from_record(rec + i * kModelStride, out + i);
+    return (int)n;
+}
+int pl_relpose_5pt(const double *x1, const double *x2, pl_camera_pose *out) {
+    std::vector<double> rec(40 * kModelStride);
+    uint32_t n = 0;
+    int rc = solve_one(EST_REL, x1, x2, rec.data(), &n);
+    if (rc != PL_OK)
+        return rc;
+    for (uint32_t i = 0; i < n; ++i)
+        pose_from_record(rec.data() + i * kModelStride, out + i);
+    return (int)n;
+}
+int pl_essential_matrix_5pt(const double *x1, const double *x2, double *E) {
+    // kind 4 (internal): essential matrices before the motion decomposition
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    std::vector<double> in(30), rec(10 * kModelStride);
+    std::memcpy(in.data(), x1, sizeof(double) * 15);
+    std::memcpy(in.data() + 15, x2, sizeof(double) * 15);
+    uint32_t n = 0;
+    HIP_TRY(c->solve_in.ensure(sizeof(double) * 30));
+    HIP_TRY(c->solve_out.ensure(sizeof(double) * kModelStride * 10));
+    HIP_TRY(c->solve_cnt.ensure(sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(c->solve_in.p, in.data(), sizeof(double) * 30, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_solve_batch(4, c->solve_in.as<double>(), 1, c->solve_out.as<double>(), c->solve_cnt.as<uint32_t>(),
+                               c->stream));
+    HIP_TRY(hipMemcpyAsync(rec.data(), c->solve_out.p, sizeof(double) * kModelStride * 10, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipMemcpyAsync(&n, c->solve_cnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        Mat3 M;
+        for (int k = 0; k < 9; ++k)
+            M.m[k] = rec[i * kModelStride + kMatOff + k];
+        mat_to_colmajor(M, E + 9 * i);
+    }
+    return (int)n;
+}
+int pl_relpose_7pt(const double *x1, const double *x2, double *F) {
+    double rec[3 * kModelStride];
+    uint32_t n = 0;
+    int rc = solve_one(EST_FUND, x1, x2, rec, &n);
+    if (rc != PL_OK)
+        return rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        Mat3 M;
+        for (int k = 0; k < 9; ++k)
+            M.m[k] = rec[i * kModelStride + kMatOff + k];
+        mat_to_colmajor(M, F + 9 * i);
+    }
+    return (int)n;
+}
+int pl_homography_4pt(const double *x1, const double *x2, double *H) {
+    double rec[kModelStride];
+    uint32_t n = 0;
+    int rc = solve_one(EST_HOM, x1, x2, rec, &n);
+    if (rc != PL_OK)
+        return rc;
+    if (n) {
+        Mat3 M;
+        for (int k = 0; k < 9; ++k)
+            M.m[k] = rec[kMatOff + k];
+        mat_to_colmajor(M, H);
+    }
+    return (int)n;
+}
+
+} // extern "C"

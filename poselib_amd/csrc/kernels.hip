@@ -1,0 +1,632 @@
+// poselib_amd — HIP kernels for gfx950 (MI355X, CDNA4, wave64).  Build: hipcc --offload-arch=gfx950
+// -O3 -std=c++17 -ffp-contract=off (fp64, no FMA contraction: residuals must round like the
+// reference's SSE2 build so that inlier decisions are identical).
+//
+// Kernel inventory (one RANSAC batch = generate -> compact -> score -> finalize):
+//   k_generate<EST>   one LANE per RANSAC iteration: counter-based sample draw, minimal solve entirely in
+//                     registers (P3P / 5-pt / 7-pt / 4-pt H), model records (128 B) written to HBM.
+//                     (reference: estimators/*::generate_models)
+//   k_compact         exclusive scan of models-per-iteration -> hypothesis list in (iteration, model) order.
+//   k_score<EST,P>    THE hot kernel.  Correspondences are stationary: every lane keeps P points in VGPRs
+//                     (loaded once, coalesced from the SoA arrays), hypotheses stream through the workgroup
+//                     as wave-uniform 128-byte records held in SGPRs.  Per hypothesis and wavefront: P
+//                     residuals per lane, inlier count by ballot+popcount on the scalar unit, MSAC sum by a
+//                     wave64 butterfly, per-workgroup combine through LDS, one (count, score) partial per
+//                     (hypothesis, point-chunk).  No atomics; summation order is fixed.
+//                     (reference: utils.cc compute_*_msac_score)
+//   k_finalize        adds the point-chunk partials in fixed order, applies the (N - inliers) * thr^2 term.
+//   k_lm<EST>         Levenberg-Marquardt refinement, ONE workgroup (16 wavefronts) per task, the whole LM
+//                     loop on device: residual / Jacobian passes over the L2-resident points, normal
+//                     equations reduced with butterflies + LDS, k x k Cholesky by one lane.
+//                     (reference: bundle.cc + optim/lm_impl.h + optim/*.h)
+//   k_mask<EST>       final inlier mask (reference: utils.cc get_inliers*).
+// MFMA is not used: there is no dense contraction in this path (fp64 VALU + L2/LDS resident data).
+#include "pl_kernels.h"
+#include "pl_sampler.h"
+#include "pl_solver_h4.h"
+#include "pl_solver_p3p.h"
+#include "pl_solver_rel.h"
+
+namespace pl {
+
+// ------------------------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------ generate
+template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs g) {
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= g.num_iters)
+        return;
+    constexpr int K = sample_size(EST);
+    constexpr int MAXM = max_models(EST);
+    uint32_t idx[K];
+    draw_sample<K>(g.seed, g.positions[it], g.pts.n, idx);
+    double *rec = g.models + (size_t)it * MAXM * kModelStride;
+    int n = 0;
+    if constexpr (EST == EST_ABS) {
+        Vec3 xb[3], Xp[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xb[k] = bearing(g.pts.a[0][idx[k]], g.pts.a[1][idx[k]]);
+            Xp[k] = v3(g.pts.a[2][idx[k]], g.pts.a[3][idx[k]], g.pts.a[4][idx[k]]);
+        }
+        P3PSolution sol[4];
+        n = p3p(xb[0], xb[1], xb[2], Xp[0], Xp[1], Xp[2], sol);
+        for (int m = 0; m < n; ++m)
+            store_pose_model(rec + m * kModelStride, sol[m].R, sol[m].t, false);
+    } else {
+        Vec3 b1[K], b2[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            b1[k] = bearing(g.pts.a[0][idx[k]], g.pts.a[1][idx[k]]);
+            b2[k] = bearing(g.pts.a[2][idx[k]], g.pts.a[3][idx[k]]);
+        }
+        if constexpr (EST == EST_HOM) {
+            Mat3 H;
+            n = homography_4pt(b1, b2, H, true);
+            if (n)
+                store_matrix_model(rec, H);
+        } else if constexpr (EST == EST_FUND) {
+            n = relpose_7pt_records(b1, b2, rec, g.real_focal_check != 0);
+        } else {
+            n = relpose_5pt_records(b1, b2, rec);
+        }
+    }
+    g.num_models[it] = (uint32_t)n;
+}
+
+// Bare solver batch: one lane per minimal problem, AoS input exactly as the reference API takes it.
+template <int EST> __global__ __launch_bounds__(64) void k_solve_batch(const double *in, uint32_t np, double *models,
+                                                                       uint32_t *num_models) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= np)
+        return;
+    constexpr int K = sample_size(EST);
+    constexpr int MAXM = max_models(EST);
+    const double *p = in + (size_t)i * 6 * K;
+    Vec3 a[K], b[K];
+    for (int k = 0; k < K; ++k) {
+        a[k] = v3(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+        b[k] = v3(p[3 * (K + k)], p[3 * (K + k) + 1], p[3 * (K + k) + 2]);
+    }
+    double *rec = models + (size_t)i * MAXM * kModelStride;
+    int n = 0;
+    if constexpr (EST == EST_ABS) {
+        P3PSolution sol[4];
+        n = p3p(a[0], a[1], a[2], b[0], b[1], b[2], sol);
+        for (int m = 0; m < n; ++m)
+            store_pose_model(rec + m * kModelStride, sol[m].R, sol[m].t, false);
+    } else if constexpr (EST == EST_HOM) {
+        Mat3 H;
+        n = homography_4pt(a, b, H, true);
+        if (n)
+            store_matrix_model(rec, H);
+    } else if constexpr (EST == EST_FUND) {
+        n = relpose_7pt_records(a, b, rec, false);
+    } else {
+        n = relpose_5pt_records(a, b, rec);
+    }
+    num_models[i] = (uint32_t)n;
+}
+
+// 5-point essential matrices without the motion decomposition (poselib.essential_matrix_5pt).
+__global__ __launch_bounds__(64) void k_solve_essential(const double *in, uint32_t np, double *models,
+                                                        uint32_t *num_models) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= np)
+        return;
+    const double *p = in + (size_t)i * 30;
+    Vec3 a[5], b[5];
+    for (int k = 0; k < 5; ++k) {
+        a[k] = v3(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+        b[k] = v3(p[3 * (5 + k)], p[3 * (5 + k) + 1], p[3 * (5 + k) + 2]);
+    }
+    Mat3 E[10];
+    const int n = essential_5pt(a, b, E);
+    for (int m = 0; m < n; ++m)
+        store_matrix_model(models + ((size_t)i * 10 + m) * kModelStride, E[m]);
+    num_models[i] = (uint32_t)n;
+}
+
+// ------------------------------------------------------------------------------------ compact
+__global__ __launch_bounds__(1024) void k_compact(const uint32_t *num_models, uint32_t num_iters, int maxm,
+                                                  uint32_t *slots, uint32_t *num_hyp) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t wave_off[16];
+    const uint32_t per = (num_iters + 1023u) / 1024u;
+    const uint32_t i0 = threadIdx.x * per;
+    const uint32_t i1 = min(num_iters, i0 + per);
+    uint32_t local = 0;
+    for (uint32_t i = i0; i < i1; ++i)
+        local += num_models[i];
+    // exclusive scan over the 1024 threads: inclusive wave scan, then wave offsets
+    uint32_t inc = local;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off, 64);
+        if (lane >= off)
+            inc += v;
+    }
+    if (lane == 63)
+        wave_tot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int w = 0; w < 16; ++w) {
+            wave_off[w] = s;
+            s += wave_tot[w];
+        }
+        *num_hyp = s;
+    }
+    __syncthreads();
+    uint32_t o = wave_off[wave] + inc - local;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t nm = num_models[i];
+        for (uint32_t m = 0; m < nm; ++m)
+            slots[o++] = i * (uint32_t)maxm + m;
+    }
+}
+
+// ------------------------------------------------------------------------------------ score
+template <int EST>
+__device__ __forceinline__ bool eval_point(const double *M, const double *pt, double thr2, double &r2) {
+    if constexpr (EST == EST_ABS)
+        return reproj_inlier(M, pt[0], pt[1], pt[2], pt[3], pt[4], thr2, r2);
+    else if constexpr (EST == EST_REL)
+        return sampson_pose_inlier(M, pt[0], pt[1], pt[2], pt[3], thr2, r2);
+    else if constexpr (EST == EST_FUND)
+        return sampson_inlier(M, pt[0], pt[1], pt[2], pt[3], thr2, r2);
+    else
+        return homography_inlier(M, pt[0], pt[1], pt[2], pt[3], thr2, r2);
+}
+
+constexpr int kScoreGroup = 32; // hypotheses between two workgroup barriers
+
+template <int EST, int P>
+__global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const double *__restrict__ models,
+                                                         const uint32_t *__restrict__ slots,
+                                                         const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
+                                                         double thr2, uint32_t *__restrict__ part_count,
+                                                         double *__restrict__ part_score) {
+    constexpr int ND = point_doubles(EST);
+    __shared__ double s_score[kScoreGroup][kScoreThreads / 64];
+    __shared__ uint32_t s_count[kScoreGroup][kScoreThreads / 64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t chunk = blockIdx.y;
+
+    // ---- stationary operand: this lane's P correspondences, coalesced loads, kept in VGPRs ----
+    double pt[P][ND];
+    bool valid[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
+        valid[p] = i < pts.n;
+        const uint32_t ic = valid[p] ? i : 0u;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+            pt[p][d] = pts.a[d][ic];
+    }
+
+    const uint32_t H = *num_hyp_ptr;
+    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
+    const uint32_t k0 = blockIdx.x * per;
+    const uint32_t k1 = min(H, k0 + per);
+
+    for (uint32_t kb = k0; kb < k1; kb += kScoreGroup) {
+        const uint32_t gn = min((uint32_t)kScoreGroup, k1 - kb);
+        for (uint32_t g = 0; g < gn; ++g) {
+            // ---- streaming operand: one hypothesis, wave-uniform (scalar loads -> SGPRs) ----
+            const uint32_t k = kb + g;
+            const uint32_t slot = __builtin_amdgcn_readfirstlane(slots ? slots[k] : k);
+            const double *Mg = models + (size_t)slot * kModelStride;
+            double M[kModelStride];
+#pragma unroll
+            for (int i = 0; i < kModelStride; ++i)
+                M[i] = Mg[i];
+
+            uint32_t cnt = 0;
+            double sc = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double r2;
+                const bool in = eval_point<EST>(M, pt[p], thr2, r2) && valid[p];
+                cnt += __popcll(__ballot(in));
+                sc += in ? r2 : 0.0;
+            }
+            sc = wave_sum(sc);
+            if (lane == 0) {
+                s_score[g][wave] = sc;
+                s_count[g][wave] = cnt;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < gn) {
+            double sc = 0.0;
+            uint32_t c = 0;
+#pragma unroll
+            for (int w = 0; w < kScoreThreads / 64; ++w) {
+                sc += s_score[threadIdx.x][w];
+                c += s_count[threadIdx.x][w];
+            }
+            const size_t o = (size_t)chunk * hyp_capacity + kb + threadIdx.x;
+            part_score[o] = sc;
+            part_count[o] = c;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs f) {
+    const uint32_t H = *f.num_hyp;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < H; k += gridDim.x * blockDim.x) {
+        uint32_t c = 0;
+        double s = 0.0;
+        for (uint32_t ch = 0; ch < f.chunks; ++ch) {
+            c += f.part_count[(size_t)ch * f.hyp_capacity + k];
+            s += f.part_score[(size_t)ch * f.hyp_capacity + k];
+        }
+        f.count[k] = c;
+        // MSAC: inlier residuals + threshold for every non-inlier (utils.cc:63 / :193-197)
+        f.score[k] = s + (double)(f.n_points - c) * f.thr2;
+    }
+}
+
+// ------------------------------------------------------------------------------------ mask
+template <int EST> __global__ __launch_bounds__(256) void k_mask(PointSet pts, const double *model, double thr2, uint8_t *mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pts.n)
+        return;
+    double M[kModelStride];
+    for (int k = 0; k < kModelStride; ++k)
+        M[k] = model[k];
+    bool in;
+    if constexpr (EST == EST_ABS) {
+        in = reproj_mask(M, pts.a[0][i], pts.a[1][i], pts.a[2][i], pts.a[3][i], pts.a[4][i], thr2);
+    } else {
+        double r2;
+        const double pt[4] = {pts.a[0][i], pts.a[1][i], pts.a[2][i], pts.a[3][i]};
+        in = eval_point<EST>(M, pt, thr2, r2);
+    }
+    mask[i] = in ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------ LM
+template <int N> struct BlockReduce {
+    // Reduces N per-thread doubles (+ one counter) over the 1024-thread workgroup.  Result in out[0..N)
+    // and *count_out (valid for every thread after the call).  Fixed order: butterfly inside each
+    // wavefront, then wavefronts 0..15 in sequence.
+    __device__ static void run(const double *v, uint32_t cnt, double (*scratch)[N + 1], double *out,
+                               uint32_t *count_out) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double s = wave_sum(v[i]);
+            if (lane == 0)
+                scratch[wave][i] = s;
+        }
+        const uint32_t c = wave_sum_u32(cnt);
+        if (lane == 0)
+            scratch[wave][N] = (double)c;
+        __syncthreads();
+        if (threadIdx.x <= N) {
+            double s = 0;
+            for (int w = 0; w < kLMThreads / 64; ++w)
+                s += scratch[w][threadIdx.x];
+            if (threadIdx.x < N)
+                out[threadIdx.x] = s;
+            else
+                *count_out = (uint32_t)s;
+        }
+        __syncthreads();
+    }
+};
+
+template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet pts, LMTask *tasks) {
+    using R = Refiner<EST>;
+    constexpr int K = R::K;
+    constexpr int NT = NormalSize<K>::kTotal;
+    LMTask &T = tasks[blockIdx.x];
+
+    __shared__ LMControl ctl;
+    __shared__ double cur[kParamDoubles], trial[kParamDoubles];
+    __shared__ RefineCtx ctx;
+    __shared__ double scratch[kLMThreads / 64][NT + 1];
+    __shared__ double normal[NT];
+    __shared__ double s_racc[1];
+    __shared__ uint32_t s_count;
+    __shared__ int s_skip;
+
+    const uint8_t *mask = T.mask;
+    const double pscale = T.point_scale;
+    const CameraParams cam = T.cam;
+
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < kParamDoubles; ++i)
+            cur[i] = T.params[i];
+        ctl.opt = T.opt;
+        ctl.loss = make_loss(T.opt.loss_type, T.opt.loss_scale);
+        ctl.done = 0;
+        s_skip = 0;
+    }
+    __syncthreads();
+
+    // ---- relative-pose LO: restrict to approximate inliers (relative_pose.cc:62-86) ----
+    if constexpr (EST == EST_REL) {
+        if (T.prefilter_thr2 > 0) {
+            double M[kModelStride];
+            {
+                Quat q;
+                q.w = cur[0], q.x = cur[1], q.y = cur[2], q.z = cur[3];
+                store_pose_model_q(M, q, v3(cur[4], cur[5], cur[6]), true);
+            }
+            uint32_t c = 0;
+            for (uint32_t i = threadIdx.x; i < pts.n; i += kLMThreads) {
+                double r2;
+                const bool in = sampson_pose_inlier(M, pts.a[0][i], pts.a[1][i], pts.a[2][i], pts.a[3][i],
+                                                    T.prefilter_thr2, r2);
+                T.scratch[i] = in ? 1 : 0;
+                c += in;
+            }
+            double dummy[1] = {0.0};
+            __shared__ double pre_scratch[kLMThreads / 64][2];
+            __shared__ double pre_out[1];
+            BlockReduce<1>::run(dummy, c, pre_scratch, pre_out, &s_count);
+            if (threadIdx.x == 0 && s_count <= 5)
+                s_skip = 1;
+            __threadfence_block();
+            __syncthreads();
+            mask = T.scratch;
+        }
+    }
+    if (s_skip) {
+        if (threadIdx.x == 0) {
+            T.skipped = 1;
+            T.iterations = 0;
+        }
+        return;
+    }
+
+    // One pass over the points.  JAC = false: robust cost only.  JAC = true: normal equations.
+    auto pass = [&](const double *p, bool jac) {
+        if (threadIdx.x == 0) {
+            R::prepare(p, ctx);
+        }
+        __syncthreads();
+        double acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            acc[i] = 0.0;
+        double racc = 0.0;
+        uint32_t cnt = 0;
+        const Loss loss = ctl.loss;
+        for (uint32_t i = threadIdx.x; i < pts.n; i += kLMThreads) {
+            if (mask && !mask[i])
+                continue;
+            if constexpr (EST == EST_ABS) {
+                const double x = pts.a[0][i] * pscale, y = pts.a[1][i] * pscale;
+                const double X = pts.a[2][i], Y = pts.a[3][i], Z = pts.a[4][i];
+                double r0, r1;
+                if (!jac) {
+                    if (R::residual(p, ctx, cam, x, y, X, Y, Z, r0, r1)) {
+                        racc += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
+                        cnt++;
+                    }
+                } else {
+                    double J[2 * K];
+                    if (R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J))
+                        accumulate2<K>(acc, loss, r0, r1, J, cnt);
+                }
+            } else if constexpr (EST == EST_HOM) {
+                const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
+                double f0, f1, g0, g1;
+                if (!jac) {
+                    R::residual(ctx, a0, a1, b0, b1, f0, f1, g0, g1);
+                    racc += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
+                    racc += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
+                    cnt += 2;
+                } else {
+                    double Jf[2 * K], Jb[2 * K];
+                    R::jacobian(ctx, a0, a1, b0, b1, f0, f1, Jf, g0, g1, Jb);
+                    accumulate2<K>(acc, loss, f0, f1, Jf, cnt);
+                    accumulate2<K>(acc, loss, g0, g1, Jb, cnt);
+                }
+            } else {
+                const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
+                if (!jac) {
+                    const double r = R::residual(ctx, a0, a1, b0, b1);
+                    racc += 1.0 * loss_value(loss, r * r);
+                    cnt++;
+                } else {
+                    double J[K];
+                    const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
+                    accumulate1<K>(acc, loss, r, J, cnt);
+                }
+            }
+        }
+        if (!jac) {
+            double v[1] = {racc};
+            BlockReduce<1>::run(v, cnt, reinterpret_cast<double(*)[2]>(&scratch[0][0]), s_racc, &s_count);
+        } else {
+            BlockReduce<NT>::run(acc, cnt, scratch, normal, &s_count);
+        }
+    };
+
+    pass(cur, false);
+    if (threadIdx.x == 0)
+        lm_begin(ctl, T.opt, s_racc[0], s_count);
+    __syncthreads();
+
+    while (!ctl.done) {
+        const bool fresh = ctl.rejac != 0;
+        if (fresh) {
+            if constexpr (EST == EST_REL) {
+                if (threadIdx.x == 0)
+                    R::prepare_params(cur);
+                __syncthreads();
+            }
+            pass(cur, true);
+        }
+        if (threadIdx.x == 0) {
+            lm_solve<K>(ctl, normal, fresh, s_count);
+            if (!ctl.done)
+                R::step(cur, ctx, ctl.sol, trial);
+        }
+        __syncthreads();
+        if (ctl.done)
+            break;
+        pass(trial, false);
+        if (threadIdx.x == 0) {
+            if (lm_update<K>(ctl, normal, s_racc[0], s_count))
+                for (int i = 0; i < kParamDoubles; ++i)
+                    cur[i] = trial[i];
+        }
+        __syncthreads();
+    }
+
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < kParamDoubles; ++i)
+            T.params[i] = cur[i];
+        T.iterations = ctl.iterations;
+        T.skipped = 0;
+        T.cost = ctl.cost;
+        T.initial_cost = ctl.initial_cost;
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+#define PL_DISPATCH_EST(est, ...)                                                                                     \
+    switch (est) {                                                                                                     \
+    case EST_ABS: {                                                                                                    \
+        constexpr int E = EST_ABS;                                                                                     \
+        __VA_ARGS__;                                                                                                    \
+    } break;                                                                                                           \
+    case EST_REL: {                                                                                                    \
+        constexpr int E = EST_REL;                                                                                     \
+        __VA_ARGS__;                                                                                                    \
+    } break;                                                                                                           \
+    case EST_FUND: {                                                                                                   \
+        constexpr int E = EST_FUND;                                                                                    \
+        __VA_ARGS__;                                                                                                    \
+    } break;                                                                                                           \
+    case EST_HOM: {                                                                                                    \
+        constexpr int E = EST_HOM;                                                                                     \
+        __VA_ARGS__;                                                                                                    \
+    } break;                                                                                                           \
+    default:                                                                                                           \
+        return hipErrorInvalidValue;                                                                                   \
+    }
+
+hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream) {
+    if (a.num_iters == 0)
+        return hipSuccess;
+    const dim3 grid((a.num_iters + 63) / 64), block(64);
+    PL_DISPATCH_EST(est, k_generate<E><<<grid, block, 0, stream>>>(a));
+    return hipGetLastError();
+}
+
+hipError_t launch_solve_batch(int est, const double *in, uint32_t np, double *models, uint32_t *num_models,
+                              hipStream_t stream) {
+    if (np == 0)
+        return hipSuccess;
+    const dim3 grid((np + 63) / 64), block(64);
+    if (est == 4) {
+        k_solve_essential<<<grid, block, 0, stream>>>(in, np, models, num_models);
+        return hipGetLastError();
+    }
+    PL_DISPATCH_EST(est, k_solve_batch<E><<<grid, block, 0, stream>>>(in, np, models, num_models));
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const uint32_t *num_models, uint32_t num_iters, int maxm, uint32_t *slots, uint32_t *num_hyp,
+                          hipStream_t stream) {
+    k_compact<<<dim3(1), dim3(1024), 0, stream>>>(num_models, num_iters, maxm, slots, num_hyp);
+    return hipGetLastError();
+}
+
+constexpr int kMaxPointsPerLane = 5;
+static void score_shape(uint32_t n, uint32_t &chunks, int &P) {
+    const uint32_t per_chunk_max = kScoreThreads * kMaxPointsPerLane;
+    chunks = (n + per_chunk_max - 1) / per_chunk_max;
+    if (chunks == 0)
+        chunks = 1;
+    P = (int)((n + kScoreThreads * chunks - 1) / (kScoreThreads * chunks));
+    if (P < 1)
+        P = 1;
+}
+uint32_t score_chunks(int, uint32_t n) {
+    uint32_t c;
+    int P;
+    score_shape(n, c, P);
+    return c;
+}
+
+template <int E>
+static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStream_t stream) {
+    uint32_t chunks;
+    int P;
+    score_shape(a.pts.n, chunks, P);
+    const dim3 grid(slices, chunks), block(kScoreThreads);
+#define PL_SCORE_CASE(PP)                                                                                              \
+    case PP:                                                                                                           \
+        k_score<E, PP><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,        \
+                                                   a.part_count, a.part_score);                                        \
+        break;
+    switch (P) {
+        PL_SCORE_CASE(1)
+        PL_SCORE_CASE(2)
+        PL_SCORE_CASE(3)
+        PL_SCORE_CASE(4)
+        PL_SCORE_CASE(5)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef PL_SCORE_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream) {
+    PL_DISPATCH_EST(est, return launch_score_est<E>(a, slices, stream));
+    return hipSuccess;
+}
+
+hipError_t launch_finalize(const FinalizeArgs &a, uint32_t max_hyp, hipStream_t stream) {
+    uint32_t blocks = (max_hyp + 255) / 256;
+    if (blocks > 1024)
+        blocks = 1024;
+    if (blocks == 0)
+        blocks = 1;
+    k_finalize<<<dim3(blocks), dim3(256), 0, stream>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
+    if (num_tasks == 0)
+        return hipSuccess;
+    PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), 0, stream>>>(pts, tasks));
+    return hipGetLastError();
+}
+
+hipError_t launch_mask(int est, const PointSet &pts, const double *model, double thr2, uint8_t *mask,
+                       hipStream_t stream) {
+    if (pts.n == 0)
+        return hipSuccess;
+    const dim3 grid((pts.n + 255) / 256), block(256);
+    PL_DISPATCH_EST(est, k_mask<E><<<grid, block, 0, stream>>>(pts, model, thr2, mask));
+    return hipGetLastError();
+}
+
+} // namespace pl

@@ -1,0 +1,89 @@
+// poselib_amd — launch interface between the host driver (driver.cc) and the HIP kernels
+// (kernels.hip).  Plain structs and pointers only.
+#pragma once
+#include "pl_refine.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pl {
+
+// Correspondences of one problem, structure-of-arrays in HBM, fp64.
+//   absolute pose : a[0..4] = x, y (normalised image plane), X, Y, Z
+//   two-view      : a[0..3] = x1, y1, x2, y2
+struct PointSet {
+    const double *a[5];
+    uint32_t n;
+};
+
+constexpr int kScoreThreads = 256; // 4 wavefronts per workgroup
+constexpr int kLMThreads = 1024;   // 16 wavefronts: one workgroup per refinement task
+
+PL_HD constexpr int sample_size(int est) { return est == EST_ABS ? 3 : est == EST_REL ? 5 : est == EST_FUND ? 7 : 4; }
+PL_HD constexpr int max_models(int est) { return est == EST_ABS ? 4 : est == EST_REL ? 40 : est == EST_FUND ? 3 : 1; }
+PL_HD constexpr int point_doubles(int est) { return est == EST_ABS ? 5 : 4; }
+
+struct GenerateArgs {
+    PointSet pts;
+    uint64_t seed;
+    const uint32_t *positions; // draws consumed before each iteration of this batch
+    uint32_t num_iters;
+    double *models;            // [num_iters * max_models] records of kModelStride doubles
+    uint32_t *num_models;      // [num_iters]
+    int32_t real_focal_check;  // fundamental only
+};
+
+struct ScoreArgs {
+    PointSet pts;
+    const double *models;
+    const uint32_t *slots;     // hypothesis k -> model record index (nullptr: identity)
+    const uint32_t *num_hyp;   // device scalar
+    uint32_t hyp_capacity;     // row pitch of the partial arrays
+    double thr2;
+    uint32_t *part_count;      // [chunks][hyp_capacity]
+    double *part_score;        // [chunks][hyp_capacity]
+};
+
+struct FinalizeArgs {
+    const uint32_t *num_hyp;
+    uint32_t hyp_capacity, chunks, n_points;
+    double thr2;
+    const uint32_t *part_count;
+    const double *part_score;
+    uint32_t *count; // [hyp_capacity]
+    double *score;   // [hyp_capacity]
+};
+
+struct LMTask {
+    double params[kParamDoubles]; // in/out (see pl_refine.h for the per-problem layout)
+    LMOptions opt;
+    CameraParams cam;      // absolute pose only
+    double point_scale;    // absolute pose: 2-D points are multiplied by this on load (final bundle)
+    double prefilter_thr2; // relative pose LO: > 0 => keep only points passing Sampson+cheirality at this
+                           // threshold; skip the refinement when <= 5 survive (relative_pose.cc:62-86)
+    const uint8_t *mask;   // optional inlier mask (final polish on inliers); nullptr = all points
+    uint8_t *scratch;      // n bytes, used by the prefilter
+    // outputs
+    uint32_t iterations, skipped;
+    double cost, initial_cost;
+};
+
+// All launchers enqueue on `stream` and return the HIP status of the launch.
+hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream);
+// chunks = ceil(n / (kScoreThreads * P)); P is chosen inside from n (returned through *chunks_out)
+uint32_t score_chunks(int est, uint32_t n_points);
+hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream);
+hipError_t launch_finalize(const FinalizeArgs &a, uint32_t max_hyp, hipStream_t stream);
+// num_models[iters] -> slots (compact list of record indices in (iteration, model) order) + count
+hipError_t launch_compact(const uint32_t *num_models, uint32_t num_iters, int max_models_per_iter, uint32_t *slots,
+                          uint32_t *num_hyp, hipStream_t stream);
+hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
+hipError_t launch_mask(int est, const PointSet &pts, const double *model, double thr2, uint8_t *mask,
+                       hipStream_t stream);
+
+// Bare solver entry points (one problem per lane); inputs/outputs in HBM.
+//   abs : in = [x0 x1 x2 X0 X1 X2] (18 doubles / problem) -> out records (4 / problem)
+hipError_t launch_solve_batch(int est, const double *in, uint32_t num_problems, double *models, uint32_t *num_models,
+                              hipStream_t stream);
+
+} // namespace pl

@@ -1,0 +1,784 @@
+// poselib_amd — two-view minimal solvers for one lane: 5-point essential (Nister) and 7-point
+// fundamental, with their helpers.
+//
+// Reference semantics (citations relative to /root/reference/PoseLib):
+//   misc/sturm.h:47-84,98-112,144-150,153-208,210-231,233-274   Sturm chain, sign variations, Cauchy bound,
+//                                     Ridders + Newton polish, interval isolation (depth-first, left first)
+//   misc/essential.cc:103-169         motion_from_essential: closed-form factorisation, 4 candidates, cheirality
+//                                     on the sample points (min depth 0)
+//   solvers/relpose_5pt.cc:101-157    trace + determinant constraints (10 x 20, Nister's monomial order)
+//   solvers/relpose_5pt.cc:159-395    null space, 10x10 LU, elimination to a 3x3 polynomial matrix, degree-10
+//                                     determinant, Sturm roots, back substitution, normalisation
+//   solvers/relpose_7pt.cc:10-60      2-D null space, cubic in the mixing parameter, <= 3 F
+//   misc/univariate.cc:48-61,94-126   real quadratic / all real cubic roots + one Newton step
+//   robust/utils.cc:646-671           real-focal-length check (evaluated in float)
+// The orthonormal null-space basis follows the algorithm of Eigen's fullPivHouseholderQr().matrixQ()
+// (pivot = largest |a_ij| of the trailing corner, first maximum in column-major order).
+#pragma once
+#include "pl_math.h"
+
+namespace pl {
+
+// =============================================================================== univariate
+PL_HD int quadratic_real_roots(double a, double b, double c, double *r) {
+    const double disc = b * b - 4 * a * c;
+    if (disc < 0)
+        return 0;
+    const double s = sqrt(disc);
+    r[0] = (b > 0) ? (2 * c) / (-b - s) : (2 * c) / (-b + s);
+    r[1] = c / (a * r[0]);
+    return 2;
+}
+PL_HD int cubic_real_roots(double c2, double c1, double c0, double *r) {
+    const double a = c1 - c2 * c2 / 3.0;
+    double b = (2.0 * c2 * c2 * c2 - 9.0 * c2 * c1) / 27.0 + c0;
+    double c = b * b / 4.0 + a * a * a / 27.0;
+    int n;
+    if (a == 0.0 && b == 0.0) {
+        r[0] = r[1] = r[2] = -c2 / 3.0;
+        n = 3;
+    } else if (c > 0) {
+        c = sqrt(c);
+        b *= -0.5;
+        r[0] = cbrt(b + c) + cbrt(b - c) - c2 / 3.0;
+        n = 1;
+    } else {
+        c = 3.0 * b / (2.0 * a) * sqrt(-3.0 / a);
+        const double d = 2.0 * sqrt(-a / 3.0);
+        r[0] = d * cos(acos(c) / 3.0) - c2 / 3.0;
+        r[1] = d * cos(acos(c) / 3.0 - 2.09439510239319526263557236234192) - c2 / 3.0;
+        r[2] = d * cos(acos(c) / 3.0 - 4.18879020478639052527114472468384) - c2 / 3.0;
+        n = 3;
+    }
+    for (int i = 0; i < n; ++i) {
+        const double x = r[i];
+        const double x2 = x * x;
+        const double x3 = x * x2;
+        const double dx = -(x3 + c2 * x2 + c1 * x + c0) / (3 * x2 + 2 * c2 * x + c1);
+        r[i] += dx;
+    }
+    return n;
+}
+
+// =============================================================================== Sturm (degree 10)
+struct Sturm10 {
+    double f[11];  // monic
+    double fp[10]; // derivative / 10, monic degree 9
+    double q0[9], q1[9], c[9];
+    double tail0, tail1, last;
+};
+
+PL_HD double horner_monic(const double *p, int deg, double x) {
+    double v = x + p[deg - 1];
+    for (int i = deg - 2; i >= 0; --i)
+        v = x * v + p[i];
+    return v;
+}
+
+PL_HD void sturm_build(Sturm10 &S) {
+    constexpr int N = 10;
+    double buf[3][11];
+    int hi = 0, lo = 1, rem = 2;
+    for (int i = 0; i <= N; ++i)
+        buf[0][i] = S.f[i];
+    for (int i = 0; i < N; ++i)
+        buf[1][i] = S.fp[i];
+    for (int i = 0; i < N - 1; ++i) {
+        const int dh = N - i, dl = N - 1 - i;
+        const double a1 = buf[hi][dh] * buf[lo][dl];
+        const double a0 = buf[hi][dh - 1] * buf[lo][dl] - buf[hi][dh] * buf[lo][dl - 1];
+        buf[rem][0] = buf[hi][0] - a0 * buf[lo][0];
+        for (int j = 1; j < dl; ++j)
+            buf[rem][j] = buf[hi][j] - a1 * buf[lo][j - 1] - a0 * buf[lo][j];
+        const double scale = -fabs(buf[rem][dl - 1]);
+        const double inv = 1.0 / scale;
+        for (int j = 0; j < dl; ++j)
+            buf[rem][j] = buf[rem][j] * inv;
+        S.q0[i] = a0;
+        S.q1[i] = a1;
+        S.c[i] = scale;
+        const int t = hi;
+        hi = lo;
+        lo = rem;
+        rem = t;
+    }
+    S.tail0 = buf[hi][0];
+    S.tail1 = buf[hi][1];
+    S.last = buf[lo][0];
+}
+
+PL_HD int sturm_variations(const Sturm10 &S, double x) {
+    constexpr int N = 10;
+    double up2 = S.last;                    // v[i+2]
+    double up1 = S.tail0 + x * S.tail1;     // v[i+1]
+    int count = ((up1 < 0) != (up2 < 0)) ? 1 : 0;
+    for (int i = N - 2; i >= 0; --i) {
+        const double v = (S.q0[i] + x * S.q1[i]) * up1 + S.c[i] * up2;
+        count += ((v < 0) != (up1 < 0)) ? 1 : 0;
+        up2 = up1;
+        up1 = v;
+    }
+    return count;
+}
+
+PL_HD void sturm_polish(const Sturm10 &S, double a, double b, double *roots, int &n, double tol) {
+    constexpr int N = 10;
+    double fa = horner_monic(S.f, N, a);
+    double fb = horner_monic(S.f, N, b);
+    if (!((fa < 0) ^ (fb < 0)))
+        return;
+    for (int it = 0; it < 30; ++it) {
+        if (fabs(a - b) < 1e-3)
+            break;
+        const double c = (a + b) * 0.5;
+        const double fc = horner_monic(S.f, N, c);
+        const double s = sqrt(fc * fc - fa * fb);
+        if (!s)
+            break;
+        const double d = (fa < fb) ? c + (a - c) * fc / s : c + (c - a) * fc / s;
+        const double fd = horner_monic(S.f, N, d);
+        if (fd >= 0 ? (fc < 0) : (fc > 0)) {
+            a = c;
+            fa = fc;
+            b = d;
+            fb = fd;
+        } else if (fd >= 0 ? (fa < 0) : (fa > 0)) {
+            b = d;
+            fb = fd;
+        } else {
+            a = d;
+            fa = fd;
+        }
+    }
+    double x = (a + b) * 0.5;
+    for (int it = 0; it < 10; ++it) {
+        const double fx = horner_monic(S.f, N, x);
+        if (fabs(fx) < tol)
+            break;
+        const double fpx = (double)N * horner_monic(S.fp, N - 1, x);
+        const double dx = fx / fpx;
+        x = x - dx;
+        if (fabs(dx) < tol)
+            break;
+    }
+    roots[n++] = x;
+}
+
+// Real roots of c[0] + c[1] z + ... + c[10] z^10, in the order the reference's recursion emits them.
+PL_HD int sturm_roots_deg10(const double *coef, double *roots) {
+    constexpr int N = 10;
+    const double tol = 1e-10;
+    if (coef[N] == 0.0)
+        return 0;
+    Sturm10 S;
+    const double lead_inv = 1.0 / coef[N];
+    for (int i = 0; i < N; ++i)
+        S.f[i] = coef[i] * lead_inv;
+    S.f[N] = 1.0;
+    for (int i = 0; i < N - 1; ++i)
+        S.fp[i] = S.f[i + 1] * ((i + 1) / (double)N);
+    S.fp[N - 1] = 1.0;
+    sturm_build(S);
+    double bound = 0;
+    for (int i = 0; i < N; ++i)
+        bound = fmax(bound, fabs(S.f[i]));
+    bound = 1.0 + bound;
+    const int sa0 = sturm_variations(S, -bound), sb0 = sturm_variations(S, bound);
+    if (sa0 - sb0 == 0)
+        return 0;
+    // explicit stack of deferred right halves (the reference recurses, depth limit 300; with fp64 an
+    // interval reaches the 1e-10 width long before 96 levels)
+    constexpr int kStack = 96;
+    double st_a[kStack], st_b[kStack];
+    int st_s[kStack]; // sa | sb << 8 | depth << 16
+    int sp = 0;
+    st_a[0] = -bound, st_b[0] = bound, st_s[0] = sa0 | (sb0 << 8);
+    sp = 1;
+    int n = 0;
+    while (sp > 0) {
+        --sp;
+        const double a = st_a[sp], b = st_b[sp];
+        const int sa = st_s[sp] & 0xff, sb = (st_s[sp] >> 8) & 0xff, depth = st_s[sp] >> 16;
+        if (depth > 300)
+            continue;
+        if (b - a < tol) {
+            if (n < N)
+                roots[n++] = b;
+            continue;
+        }
+        const int k = sa - sb;
+        if (k > 1) {
+            const double mid = (a + b) * 0.5;
+            const int sm = sturm_variations(S, mid);
+            if (sp + 2 <= kStack) {
+                st_a[sp] = mid, st_b[sp] = b, st_s[sp] = sm | (sb << 8) | ((depth + 1) << 16);
+                ++sp;
+                st_a[sp] = a, st_b[sp] = mid, st_s[sp] = sa | (sm << 8) | ((depth + 1) << 16);
+                ++sp;
+            }
+        } else if (k == 1) {
+            if (n < N)
+                sturm_polish(S, a, b, roots, n, tol);
+        }
+    }
+    return n;
+}
+
+// =============================================================================== null space
+// Orthonormal basis of the complement of span(columns of A); A is 9 x COLS column-major.
+// basis: 9 x (9-COLS), column-major.
+template <int COLS> PL_HD void complement_basis9(double *qr /* 9*COLS, destroyed */, double *basis) {
+    constexpr int ROWS = 9;
+    double tau[COLS];
+    int rowswap[COLS];
+    double biggest = 0;
+    const double precision = 2.220446049250313e-16 * COLS;
+    for (int k = 0; k < COLS; ++k) {
+        int pr = k, pc = k;
+        double best = fabs(qr[k * ROWS + k]);
+        for (int c = k; c < COLS; ++c)
+            for (int r = k; r < ROWS; ++r) {
+                const double v = fabs(qr[c * ROWS + r]);
+                if (v > best) {
+                    best = v;
+                    pr = r;
+                    pc = c;
+                }
+            }
+        if (k == 0)
+            biggest = best;
+        if (best <= biggest * precision) {
+            for (int i = k; i < COLS; ++i) {
+                rowswap[i] = i;
+                tau[i] = 0;
+            }
+            break;
+        }
+        rowswap[k] = pr;
+        if (pr != k)
+            for (int c = k; c < COLS; ++c) {
+                const double t = qr[c * ROWS + k];
+                qr[c * ROWS + k] = qr[c * ROWS + pr];
+                qr[c * ROWS + pr] = t;
+            }
+        if (pc != k)
+            for (int r = 0; r < ROWS; ++r) {
+                const double t = qr[k * ROWS + r];
+                qr[k * ROWS + r] = qr[pc * ROWS + r];
+                qr[pc * ROWS + r] = t;
+            }
+        double tail_sq = 0;
+        for (int r = k + 1; r < ROWS; ++r)
+            tail_sq += qr[k * ROWS + r] * qr[k * ROWS + r];
+        const double c0 = qr[k * ROWS + k];
+        double beta;
+        if (tail_sq <= 2.2250738585072014e-308) {
+            tau[k] = 0;
+            beta = c0;
+            for (int r = k + 1; r < ROWS; ++r)
+                qr[k * ROWS + r] = 0;
+        } else {
+            beta = sqrt(c0 * c0 + tail_sq);
+            if (c0 >= 0)
+                beta = -beta;
+            for (int r = k + 1; r < ROWS; ++r)
+                qr[k * ROWS + r] = qr[k * ROWS + r] / (c0 - beta);
+            tau[k] = (beta - c0) / beta;
+        }
+        qr[k * ROWS + k] = beta;
+        if (tau[k] != 0)
+            for (int c = k + 1; c < COLS; ++c) {
+                double t = 0;
+                for (int r = k + 1; r < ROWS; ++r)
+                    t += qr[k * ROWS + r] * qr[c * ROWS + r];
+                t += qr[c * ROWS + k];
+                qr[c * ROWS + k] -= tau[k] * t;
+                for (int r = k + 1; r < ROWS; ++r)
+                    qr[c * ROWS + r] -= tau[k] * qr[k * ROWS + r] * t;
+            }
+    }
+    // columns COLS..8 of Q = (P0 H0)(P1 H1)... applied to unit vectors
+    for (int j = 0; j < ROWS - COLS; ++j) {
+        double v[ROWS];
+        for (int r = 0; r < ROWS; ++r)
+            v[r] = (r == COLS + j) ? 1.0 : 0.0;
+        for (int k = COLS - 1; k >= 0; --k) {
+            if (tau[k] != 0) {
+                double t = 0;
+                for (int r = k + 1; r < ROWS; ++r)
+                    t += qr[k * ROWS + r] * v[r];
+                t += v[k];
+                v[k] -= tau[k] * t;
+                for (int r = k + 1; r < ROWS; ++r)
+                    v[r] -= tau[k] * qr[k * ROWS + r] * t;
+            }
+            if (rowswap[k] != k) {
+                const double t = v[k];
+                v[k] = v[rowswap[k]];
+                v[rowswap[k]] = t;
+            }
+        }
+        for (int r = 0; r < ROWS; ++r)
+            basis[j * ROWS + r] = v[r];
+    }
+}
+
+// =============================================================================== essential -> motion
+struct PoseQT {
+    Quat q;
+    Vec3 t;
+};
+
+template <int NP> PL_HD bool cheirality_all(Quat q, Vec3 t, const Vec3 *x1, const Vec3 *x2) {
+    for (int i = 0; i < NP; ++i)
+        if (!check_cheirality(q, t, x1[i], x2[i], 0.0))
+            return false;
+    return true;
+}
+
+// essential.cc:103-169.  Appends the candidates that pass cheirality on the NP sample points.
+template <int NP> PL_HD int motion_from_essential(const Mat3 &E, const Vec3 *x1, const Vec3 *x2, PoseQT *out) {
+    const Vec3 e0 = col(E, 0), e1 = col(E, 1), e2 = col(E, 2);
+    const Vec3 u12 = cross(e0, e1), u13 = cross(e0, e2), u23 = cross(e1, e2);
+    const double n12 = dot(u12, u12), n13 = dot(u13, u13), n23 = dot(u23, u23);
+    Vec3 c1, c2;
+    if (n12 > n13) {
+        if (n12 > n23) {
+            c1 = normalized(e0);
+            c2 = u12 / sqrt(n12);
+        } else {
+            c1 = normalized(e1);
+            c2 = u23 / sqrt(n23);
+        }
+    } else {
+        if (n13 > n23) {
+            c1 = normalized(e0);
+            c2 = u13 / sqrt(n13);
+        } else {
+            c1 = normalized(e1);
+            c2 = u23 / sqrt(n23);
+        }
+    }
+    const Vec3 c0 = -cross(c2, c1);
+    Vec3 r0 = mul_t(E, c1);
+    Vec3 r1 = mul_t(E, -c0);
+    r0 = normalized(r0);
+    r1 = r1 - dot(r0, r1) * r0;
+    r1 = normalized(r1);
+    const Vec3 r2 = cross(r0, r1);
+    Mat3 Vt, UW;
+    set_row(Vt, 0, r0);
+    set_row(Vt, 1, r1);
+    set_row(Vt, 2, r2);
+    set_col(UW, 0, c0);
+    set_col(UW, 1, c1);
+    set_col(UW, 2, c2);
+    int n = 0;
+    Quat q = rotmat_to_quat(mul(UW, Vt));
+    Vec3 t = c2;
+    if (cheirality_all<NP>(q, t, x1, x2)) {
+        out[n].q = q, out[n].t = t;
+        ++n;
+    }
+    t = -t;
+    if (cheirality_all<NP>(q, t, x1, x2)) {
+        out[n].q = q, out[n].t = t;
+        ++n;
+    }
+    set_col(UW, 0, -c0);
+    set_col(UW, 1, -c1);
+    q = rotmat_to_quat(mul(UW, Vt));
+    if (cheirality_all<NP>(q, t, x1, x2)) {
+        out[n].q = q, out[n].t = t;
+        ++n;
+    }
+    t = -t;
+    if (cheirality_all<NP>(q, t, x1, x2)) {
+        out[n].q = q, out[n].t = t;
+        ++n;
+    }
+    return n;
+}
+
+// =============================================================================== 5-point
+namespace detail5 {
+// monomial tables.  linear: [x y z 1]; quadratic: [x2 xy xz x y2 yz y z2 z 1];
+// cubic (Nister): [x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy xz2 xz x yz2 yz y z3 z2 z 1]
+PL_HD int quad_index(int i, int j) { // linear_i * linear_j, i <= j
+    const int t[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+    return t[i][j];
+}
+PL_HD int cubic_index(int q, int l) { // quadratic_q * linear_l
+    const int t[10][4] = {{0, 2, 4, 5},   {2, 3, 8, 9},    {4, 8, 10, 11},  {5, 9, 11, 12},  {3, 1, 6, 7},
+                          {8, 6, 13, 14}, {9, 7, 14, 15}, {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+    return t[q][l];
+}
+// acc(quadratic) += s * a(linear) * b(linear)
+PL_HD void mac_lin_lin(double *acc, double s, const double *a, const double *b) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            acc[quad_index(i, j)] += s * (a[i] * b[j]);
+}
+// acc(cubic) += a(quadratic) * b(linear)
+PL_HD void mac_quad_lin(double *acc, const double *a, const double *b) {
+    for (int q = 0; q < 10; ++q)
+        for (int l = 0; l < 4; ++l)
+            acc[cubic_index(q, l)] += a[q] * b[l];
+}
+} // namespace detail5
+
+// Returns the number of essential matrices (<= 10); E[i] row-major.
+PL_HD int essential_5pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Eout) {
+    using namespace detail5;
+    double A[45];
+    for (int i = 0; i < 5; ++i) {
+        const double a[3] = {x1[i].x, x1[i].y, x1[i].z};
+        for (int j = 0; j < 3; ++j) {
+            A[i * 9 + 3 * j + 0] = a[j] * x2[i].x;
+            A[i * 9 + 3 * j + 1] = a[j] * x2[i].y;
+            A[i * 9 + 3 * j + 2] = a[j] * x2[i].z;
+        }
+    }
+    double nb[36]; // nb[b*9 + e], e = 3*col + row of E
+    complement_basis9<5>(A, nb);
+
+    // E(i,j) as linear form l[0..3] over (x,y,z,1)
+    double L[3][3][4];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int b = 0; b < 4; ++b)
+                L[i][j][b] = nb[b * 9 + 3 * j + i];
+
+    double M[10][20];
+    for (int r = 0; r < 10; ++r)
+        for (int c = 0; c < 20; ++c)
+            M[r][c] = 0.0;
+    // (E E^T - 1/2 tr(E E^T) I) E  -> rows 0..8
+    {
+        double EEt[3][3][10];
+        for (int i = 0; i < 3; ++i)
+            for (int j = i; j < 3; ++j) {
+                for (int m = 0; m < 10; ++m)
+                    EEt[i][j][m] = 0.0;
+                for (int k = 0; k < 3; ++k)
+                    mac_lin_lin(EEt[i][j], 1.0, L[i][k], L[j][k]);
+            }
+        for (int m = 0; m < 10; ++m) {
+            const double h = 0.5 * (EEt[0][0][m] + EEt[1][1][m] + EEt[2][2][m]);
+            EEt[0][0][m] -= h;
+            EEt[1][1][m] -= h;
+            EEt[2][2][m] -= h;
+        }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k)
+                    mac_quad_lin(M[3 * i + j], (i <= k) ? EEt[i][k] : EEt[k][i], L[k][j]);
+    }
+    // det(E) -> row 9
+    {
+        double m0[10], m1[10], m2[10];
+        for (int m = 0; m < 10; ++m)
+            m0[m] = m1[m] = m2[m] = 0.0;
+        mac_lin_lin(m0, 1.0, L[0][1], L[1][2]);
+        mac_lin_lin(m0, -1.0, L[0][2], L[1][1]);
+        mac_lin_lin(m1, 1.0, L[0][2], L[1][0]);
+        mac_lin_lin(m1, -1.0, L[0][0], L[1][2]);
+        mac_lin_lin(m2, 1.0, L[0][0], L[1][1]);
+        mac_lin_lin(m2, -1.0, L[0][1], L[1][0]);
+        mac_quad_lin(M[9], m0, L[2][0]);
+        mac_quad_lin(M[9], m1, L[2][1]);
+        mac_quad_lin(M[9], m2, L[2][2]);
+    }
+
+    // X = M[:, :10]^-1 M[:, 10:]; only rows 4..9 of X are needed.  LU with partial pivoting, in place.
+    for (int k = 0; k < 10; ++k) {
+        int piv = k;
+        double best = fabs(M[k][k]);
+        for (int i = k + 1; i < 10; ++i)
+            if (fabs(M[i][k]) > best) {
+                best = fabs(M[i][k]);
+                piv = i;
+            }
+        if (piv != k)
+            for (int j = 0; j < 20; ++j) {
+                const double t = M[k][j];
+                M[k][j] = M[piv][j];
+                M[piv][j] = t;
+            }
+        if (M[k][k] != 0.0)
+            for (int i = k + 1; i < 10; ++i)
+                M[i][k] /= M[k][k];
+        for (int i = k + 1; i < 10; ++i) {
+            const double f = M[i][k];
+            for (int j = k + 1; j < 10; ++j)
+                M[i][j] -= f * M[k][j];
+        }
+    }
+    for (int c = 10; c < 20; ++c) {
+        for (int i = 1; i < 10; ++i) {
+            double s = M[i][c];
+            for (int j = 0; j < i; ++j)
+                s -= M[i][j] * M[j][c];
+            M[i][c] = s;
+        }
+        for (int i = 9; i >= 4; --i) {
+            double s = M[i][c];
+            for (int j = i + 1; j < 10; ++j)
+                s -= M[i][j] * M[j][c];
+            M[i][c] = s / M[i][i];
+        }
+    }
+
+    // px_i(z) x + py_i(z) y + pc_i(z) = 0, highest power first
+    double Az[3][13];
+    for (int i = 0; i < 3; ++i) {
+        const double *ev = &M[4 + 2 * i][10], *od = &M[5 + 2 * i][10];
+        Az[i][0] = 0.0 - od[0];
+        Az[i][1] = ev[0] - od[1];
+        Az[i][2] = ev[1] - od[2];
+        Az[i][3] = ev[2];
+        Az[i][4] = 0.0 - od[3];
+        Az[i][5] = ev[3] - od[4];
+        Az[i][6] = ev[4] - od[5];
+        Az[i][7] = ev[5];
+        Az[i][8] = 0.0 - od[6];
+        Az[i][9] = ev[6] - od[7];
+        Az[i][10] = ev[7] - od[8];
+        Az[i][11] = ev[8] - od[9];
+        Az[i][12] = ev[9];
+    }
+    // degree-10 determinant by polynomial arithmetic (ascending coefficients)
+    double c[11];
+    for (int k = 0; k <= 10; ++k)
+        c[k] = 0.0;
+    {
+        // term(sign, A_row a (deg da), B_row b (deg db), C_row d (deg dd))
+        const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+        const double sgn[6] = {1, -1, -1, 1, 1, -1};
+        for (int t = 0; t < 6; ++t) {
+            // columns: 0 = px (deg 3, Az[.][0..3]), 1 = py (deg 3, Az[.][4..7]), 2 = pc (deg 4, Az[.][8..12])
+            // row r takes column perm[t][r]
+            double prod[11];
+            for (int k = 0; k <= 10; ++k)
+                prod[k] = 0.0;
+            // first factor (row 0)
+            double p0[5], p1[5], tmp[9];
+            int d0, d1, d2;
+            double p2[5];
+            auto load = [&](int r, int colsel, double *dst, int &deg) {
+                const int off = (colsel == 0) ? 0 : (colsel == 1) ? 4 : 8;
+                deg = (colsel == 2) ? 4 : 3;
+                for (int k = 0; k <= deg; ++k)
+                    dst[k] = Az[r][off + deg - k]; // ascending
+            };
+            load(0, perm[t][0], p0, d0);
+            load(1, perm[t][1], p1, d1);
+            load(2, perm[t][2], p2, d2);
+            for (int k = 0; k <= d0 + d1; ++k)
+                tmp[k] = 0.0;
+            for (int i = 0; i <= d0; ++i)
+                for (int j = 0; j <= d1; ++j)
+                    tmp[i + j] += p0[i] * p1[j];
+            for (int i = 0; i <= d0 + d1; ++i)
+                for (int j = 0; j <= d2; ++j)
+                    prod[i + j] += tmp[i] * p2[j];
+            for (int k = 0; k <= 10; ++k)
+                c[k] += sgn[t] * prod[k];
+        }
+    }
+
+    double roots[10];
+    const int nroots = sturm_roots_deg10(c, roots);
+
+    for (int s = 0; s < nroots; ++s) {
+        const double z = roots[s];
+        const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2;
+        double B[3][2], b[3];
+        for (int i = 0; i < 3; ++i) {
+            B[i][0] = Az[i][0] * z3 + Az[i][1] * z2 + Az[i][2] * z + Az[i][3];
+            B[i][1] = Az[i][4] * z3 + Az[i][5] * z2 + Az[i][6] * z + Az[i][7];
+            b[i] = Az[i][8] * z4 + Az[i][9] * z3 + Az[i][10] * z2 + Az[i][11] * z + Az[i][12];
+        }
+        const double dt = B[0][0] * B[1][1] - B[1][0] * B[0][1];
+        const double idt = 1.0 / dt;
+        double u0 = (B[1][1] * idt) * b[0] + (-B[0][1] * idt) * b[1];
+        double u1 = (-B[1][0] * idt) * b[0] + (B[0][0] * idt) * b[1];
+        if (fabs(B[2][0] * u0 + B[2][1] * u1 - b[2]) > 1e-6) {
+            // least squares over the three rows via the 2x2 normal equations solved by a
+            // pivoted Householder QR (reference: colPivHouseholderQr, relpose_5pt.cc:381)
+            double Q[3][2] = {{B[0][0], B[0][1]}, {B[1][0], B[1][1]}, {B[2][0], B[2][1]}};
+            double rhs[3] = {b[0], b[1], b[2]};
+            const double n0 = Q[0][0] * Q[0][0] + Q[1][0] * Q[1][0] + Q[2][0] * Q[2][0];
+            const double n1 = Q[0][1] * Q[0][1] + Q[1][1] * Q[1][1] + Q[2][1] * Q[2][1];
+            const bool swapc = n1 > n0;
+            if (swapc)
+                for (int i = 0; i < 3; ++i) {
+                    const double t = Q[i][0];
+                    Q[i][0] = Q[i][1];
+                    Q[i][1] = t;
+                }
+            double Rm[2][2] = {{0, 0}, {0, 0}};
+            for (int k = 0; k < 2; ++k) {
+                double tail = 0;
+                for (int i = k + 1; i < 3; ++i)
+                    tail += Q[i][k] * Q[i][k];
+                const double c0 = Q[k][k];
+                double beta = sqrt(c0 * c0 + tail);
+                if (c0 >= 0)
+                    beta = -beta;
+                double v[3] = {0, 0, 0};
+                double tau = 0;
+                if (tail > 2.2250738585072014e-308) {
+                    v[k] = 1.0;
+                    for (int i = k + 1; i < 3; ++i)
+                        v[i] = Q[i][k] / (c0 - beta);
+                    tau = (beta - c0) / beta;
+                } else {
+                    beta = c0;
+                }
+                Rm[k][k] = beta;
+                for (int cc = k + 1; cc < 2; ++cc) {
+                    double t = 0;
+                    for (int i = k; i < 3; ++i)
+                        t += v[i] * Q[i][cc];
+                    for (int i = k; i < 3; ++i)
+                        Q[i][cc] -= tau * v[i] * t;
+                    Rm[k][cc] = Q[k][cc];
+                }
+                double t = 0;
+                for (int i = k; i < 3; ++i)
+                    t += v[i] * rhs[i];
+                for (int i = k; i < 3; ++i)
+                    rhs[i] -= tau * v[i] * t;
+            }
+            double w1 = rhs[1] / Rm[1][1];
+            double w0 = (rhs[0] - Rm[0][1] * w1) / Rm[0][0];
+            if (swapc) {
+                const double t = w0;
+                w0 = w1;
+                w1 = t;
+            }
+            u0 = w0;
+            u1 = w1;
+        }
+        const double x = -u0, y = -u1;
+        const double inv_norm = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {
+                const int e = 3 * j + i;
+                Eout[s].m[3 * i + j] = (nb[0 * 9 + e] * x + nb[1 * 9 + e] * y + nb[2 * 9 + e] * z + nb[3 * 9 + e]) * inv_norm;
+            }
+    }
+    return nroots;
+}
+
+// 5-point relative pose: writes <= 40 model records (pose + E=[t]xR(q)); returns their number.
+PL_HD int relpose_5pt_records(const Vec3 *x1, const Vec3 *x2, double *rec) {
+    Mat3 E[10];
+    const int ne = essential_5pt(x1, x2, E);
+    int n = 0;
+    for (int i = 0; i < ne; ++i) {
+        PoseQT cand[4];
+        const int nc = motion_from_essential<5>(E[i], x1, x2, cand);
+        for (int k = 0; k < nc; ++k)
+            store_pose_model_q(rec + (n++) * kModelStride, cand[k].q, cand[k].t, true);
+    }
+    return n;
+}
+
+// =============================================================================== 7-point
+PL_HD bool real_focal_check(const Mat3 &Fm) { // utils.cc:646-671
+    const double *F = Fm.m;
+#define FF(i, j) F[3 * (i) + (j)]
+    float den, num;
+    den = FF(0, 0) * FF(0, 1) * FF(2, 0) * FF(2, 2) - FF(0, 0) * FF(0, 2) * FF(2, 0) * FF(2, 1) +
+          FF(0, 1) * FF(0, 1) * FF(2, 1) * FF(2, 2) - FF(0, 1) * FF(0, 2) * FF(2, 1) * FF(2, 1) +
+          FF(1, 0) * FF(1, 1) * FF(2, 0) * FF(2, 2) - FF(1, 0) * FF(1, 2) * FF(2, 0) * FF(2, 1) +
+          FF(1, 1) * FF(1, 1) * FF(2, 1) * FF(2, 2) - FF(1, 1) * FF(1, 2) * FF(2, 1) * FF(2, 1);
+    num = -FF(2, 2) * (FF(0, 1) * FF(0, 2) * FF(2, 2) - FF(0, 2) * FF(0, 2) * FF(2, 1) +
+                       FF(1, 1) * FF(1, 2) * FF(2, 2) - FF(1, 2) * FF(1, 2) * FF(2, 1));
+    if (num * den < 0)
+        return false;
+    den = FF(0, 0) * FF(1, 0) * FF(0, 2) * FF(2, 2) - FF(0, 0) * FF(2, 0) * FF(0, 2) * FF(1, 2) +
+          FF(1, 0) * FF(1, 0) * FF(1, 2) * FF(2, 2) - FF(1, 0) * FF(2, 0) * FF(1, 2) * FF(1, 2) +
+          FF(0, 1) * FF(1, 1) * FF(0, 2) * FF(2, 2) - FF(0, 1) * FF(2, 1) * FF(0, 2) * FF(1, 2) +
+          FF(1, 1) * FF(1, 1) * FF(1, 2) * FF(2, 2) - FF(1, 1) * FF(2, 1) * FF(1, 2) * FF(1, 2);
+    num = -FF(2, 2) * (FF(1, 0) * FF(2, 0) * FF(2, 2) - FF(2, 0) * FF(2, 0) * FF(1, 2) +
+                       FF(1, 1) * FF(2, 1) * FF(2, 2) - FF(2, 1) * FF(2, 1) * FF(1, 2));
+#undef FF
+    if (num * den < 0)
+        return false;
+    return true;
+}
+
+PL_HD int relpose_7pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Fout) {
+    double A[63];
+    for (int i = 0; i < 7; ++i) {
+        const double a[3] = {x1[i].x, x1[i].y, x1[i].z};
+        for (int j = 0; j < 3; ++j) {
+            A[i * 9 + 3 * j + 0] = a[j] * x2[i].x;
+            A[i * 9 + 3 * j + 1] = a[j] * x2[i].y;
+            A[i * 9 + 3 * j + 2] = a[j] * x2[i].z;
+        }
+    }
+    double nb[18];
+    complement_basis9<7>(A, nb);
+    const double *n0 = nb, *n1 = nb + 9;
+    // det(x F0 + F1), entries (i,j) <-> vec index 3j+i; each entry = n1 + n0 x (ascending)
+    double c[4] = {0, 0, 0, 0};
+    const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    const double sgn[6] = {1, -1, -1, 1, 1, -1};
+    for (int t = 0; t < 6; ++t) {
+        const int e0 = 3 * perm[t][0] + 0, e1 = 3 * perm[t][1] + 1, e2 = 3 * perm[t][2] + 2;
+        const double a0 = n1[e0], a1 = n0[e0], b0 = n1[e1], b1 = n0[e1], d0 = n1[e2], d1 = n0[e2];
+        // (a0 + a1 x)(b0 + b1 x)
+        double q[3] = {0, 0, 0};
+        q[0] += a0 * b0;
+        q[1] += a0 * b1;
+        q[1] += a1 * b0;
+        q[2] += a1 * b1;
+        double p[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 3; ++i) {
+            p[i] += q[i] * d0;
+            p[i + 1] += q[i] * d1;
+        }
+        for (int k = 0; k < 4; ++k)
+            c[k] += sgn[t] * p[k];
+    }
+    double roots[3];
+    int nr;
+    if (fabs(c[3]) < 1e-14) {
+        nr = quadratic_real_roots(c[2], c[1], c[0], roots);
+    } else {
+        const double inv = 1.0 / c[3];
+        nr = cubic_real_roots(c[2] * inv, c[1] * inv, c[0] * inv, roots);
+    }
+    for (int s = 0; s < nr; ++s) {
+        double f[9], nn = 0;
+        for (int k = 0; k < 9; ++k) {
+            f[k] = n0[k] * roots[s] + n1[k];
+            nn += f[k] * f[k];
+        }
+        nn = sqrt(nn);
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i)
+                Fout[s].m[3 * i + j] = f[3 * j + i] / nn;
+    }
+    return nr;
+}
+
+// <= 3 records; with `rfc` the real-focal-length filter of relative_pose.cc:393-398 is applied.
+// The reference erases failing models back to front, which preserves the order of the survivors.
+PL_HD int relpose_7pt_records(const Vec3 *x1, const Vec3 *x2, double *rec, bool rfc) {
+    Mat3 F[3];
+    const int nf = relpose_7pt(x1, x2, F);
+    int n = 0;
+    for (int i = 0; i < nf; ++i) {
+        if (rfc && !real_focal_check(F[i]))
+            continue;
+        store_matrix_model(rec + (n++) * kModelStride, F[i]);
+    }
+    return n;
+}
+
+} // namespace pl

@@ -1,0 +1,289 @@
+// TEST-ONLY host compilation of the product's device math (poselib_amd/csrc/pl_*.h).
+//
+// This library exists so that the exact source that hipcc compiles into the gfx950 kernels can be
+// exercised on CPU (no GPU in the development container) and compared against the oracle before
+// GPU minutes are spent.  It is NOT a CPU fallback: nothing in poselib_amd/ loads it, the C-ABI
+// (include/poselib_amd.h) has no code path into it, and the product fails loudly without a GPU.
+// Built by tests/hostmath/Makefile with g++ -ffp-contract=off.
+#include "../../poselib_amd/csrc/pl_refine.h"
+#include "../../poselib_amd/csrc/pl_sampler.h"
+#include "../../poselib_amd/csrc/pl_score.h"
+#include "../../poselib_amd/csrc/pl_solver_h4.h"
+#include "../../poselib_amd/csrc/pl_solver_p3p.h"
+#include "../../poselib_amd/csrc/pl_solver_rel.h"
+
+#include <cstring>
+#include <vector>
+
+using namespace pl;
+
+namespace {
+
+template <int EST> int solve_records(const double *in, double *rec) {
+    constexpr int K = EST == EST_ABS ? 3 : EST == EST_REL ? 5 : EST == EST_FUND ? 7 : 4;
+    Vec3 a[K], b[K];
+    for (int k = 0; k < K; ++k) {
+        a[k] = v3(in[3 * k], in[3 * k + 1], in[3 * k + 2]);
+        b[k] = v3(in[3 * (K + k)], in[3 * (K + k) + 1], in[3 * (K + k) + 2]);
+    }
+    if constexpr (EST == EST_ABS) {
+        P3PSolution sol[4];
+        const int n = p3p(a[0], a[1], a[2], b[0], b[1], b[2], sol);
+        for (int m = 0; m < n; ++m)
+            store_pose_model(rec + m * kModelStride, sol[m].R, sol[m].t, false);
+        return n;
+    } else if constexpr (EST == EST_HOM) {
+        Mat3 H;
+        const int n = homography_4pt(a, b, H, true);
+        if (n)
+            store_matrix_model(rec, H);
+        return n;
+    } else if constexpr (EST == EST_FUND) {
+        return relpose_7pt_records(a, b, rec, false);
+    } else {
+        return relpose_5pt_records(a, b, rec);
+    }
+}
+
+// Serial evaluation of the LM kernel's algorithm (same PL_HD pieces, no block reductions).
+template <int EST>
+void lm_serial(const double *const *pa, uint32_t n, double *params, const LMOptions &opt, const CameraParams &cam,
+               double point_scale, double prefilter_thr2, const uint8_t *mask_in, uint32_t *iterations,
+               uint32_t *skipped) {
+    using R = Refiner<EST>;
+    constexpr int K = R::K;
+    constexpr int NT = NormalSize<K>::kTotal;
+    LMControl ctl;
+    ctl.opt = opt;
+    ctl.loss = make_loss(opt.loss_type, opt.loss_scale);
+    ctl.done = 0;
+    double cur[kParamDoubles], trial[kParamDoubles];
+    std::memcpy(cur, params, sizeof(cur));
+    std::vector<uint8_t> pre;
+    const uint8_t *mask = mask_in;
+    *skipped = 0;
+    if constexpr (EST == EST_REL) {
+        if (prefilter_thr2 > 0) {
+            double M[kModelStride];
+            Quat q;
+            q.w = cur[0], q.x = cur[1], q.y = cur[2], q.z = cur[3];
+            store_pose_model_q(M, q, v3(cur[4], cur[5], cur[6]), true);
+            pre.resize(n);
+            uint32_t c = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                double r2;
+                pre[i] = sampson_pose_inlier(M, pa[0][i], pa[1][i], pa[2][i], pa[3][i], prefilter_thr2, r2);
+                c += pre[i];
+            }
+            if (c <= 5) {
+                *skipped = 1;
+                *iterations = 0;
+                return;
+            }
+            mask = pre.data();
+        }
+    }
+    RefineCtx ctx;
+    double normal[NT];
+    double racc = 0;
+    uint32_t count = 0;
+    auto pass = [&](const double *p, bool jac) {
+        R::prepare(p, ctx);
+        for (int i = 0; i < NT; ++i)
+            normal[i] = 0;
+        racc = 0;
+        count = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (mask && !mask[i])
+                continue;
+            if constexpr (EST == EST_ABS) {
+                const double x = pa[0][i] * point_scale, y = pa[1][i] * point_scale;
+                double r0, r1;
+                if (!jac) {
+                    if (R::residual(p, ctx, cam, x, y, pa[2][i], pa[3][i], pa[4][i], r0, r1)) {
+                        racc += 1.0 * loss_value(ctl.loss, r0 * r0 + r1 * r1);
+                        count++;
+                    }
+                } else {
+                    double J[2 * K];
+                    if (R::jacobian(p, ctx, cam, x, y, pa[2][i], pa[3][i], pa[4][i], r0, r1, J))
+                        accumulate2<K>(normal, ctl.loss, r0, r1, J, count);
+                }
+            } else if constexpr (EST == EST_HOM) {
+                double f0, f1, g0, g1;
+                if (!jac) {
+                    R::residual(ctx, pa[0][i], pa[1][i], pa[2][i], pa[3][i], f0, f1, g0, g1);
+                    racc += 1.0 * loss_value(ctl.loss, f0 * f0 + f1 * f1);
+                    racc += 1.0 * loss_value(ctl.loss, g0 * g0 + g1 * g1);
+                    count += 2;
+                } else {
+                    double Jf[2 * K], Jb[2 * K];
+                    R::jacobian(ctx, pa[0][i], pa[1][i], pa[2][i], pa[3][i], f0, f1, Jf, g0, g1, Jb);
+                    accumulate2<K>(normal, ctl.loss, f0, f1, Jf, count);
+                    accumulate2<K>(normal, ctl.loss, g0, g1, Jb, count);
+                }
+            } else {
+                if (!jac) {
+                    const double r = R::residual(ctx, pa[0][i], pa[1][i], pa[2][i], pa[3][i]);
+                    racc += 1.0 * loss_value(ctl.loss, r * r);
+                    count++;
+                } else {
+                    double J[K];
+                    const double r = R::jacobian(ctx, pa[0][i], pa[1][i], pa[2][i], pa[3][i], J);
+                    accumulate1<K>(normal, ctl.loss, r, J, count);
+                }
+            }
+        }
+    };
+    double jac_normal[NT];
+    pass(cur, false);
+    lm_begin(ctl, opt, racc, count);
+    while (!ctl.done) {
+        const bool fresh = ctl.rejac != 0;
+        if (fresh) {
+            if constexpr (EST == EST_REL)
+                R::prepare_params(cur);
+            pass(cur, true);
+            std::memcpy(jac_normal, normal, sizeof(normal));
+        }
+        lm_solve<K>(ctl, jac_normal, fresh, count);
+        if (ctl.done)
+            break;
+        R::step(cur, ctx, ctl.sol, trial);
+        pass(trial, false);
+        if (lm_update<K>(ctl, jac_normal, racc, count))
+            std::memcpy(cur, trial, sizeof(cur));
+    }
+    std::memcpy(params, cur, sizeof(cur));
+    *iterations = ctl.iterations;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t hm_draw_samples(uint64_t seed, uint64_t N, int K, uint32_t n_iters, uint32_t *idx, uint32_t *positions) {
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < n_iters; ++i) {
+        positions[i] = (uint32_t)pos;
+        uint32_t used = 0;
+        switch (K) {
+        case 3:
+            used = draw_sample<3>(seed, pos, N, idx + (size_t)i * K);
+            break;
+        case 4:
+            used = draw_sample<4>(seed, pos, N, idx + (size_t)i * K);
+            break;
+        case 5:
+            used = draw_sample<5>(seed, pos, N, idx + (size_t)i * K);
+            break;
+        case 7:
+            used = draw_sample<7>(seed, pos, N, idx + (size_t)i * K);
+            break;
+        }
+        pos += used;
+    }
+    return (uint32_t)pos;
+}
+
+// est: 0 abs (in = 3 bearings + 3 points), 1 rel (5+5 bearings), 2 fund (7+7), 3 hom (4+4)
+int hm_solve(int est, const double *in, double *records) {
+    switch (est) {
+    case EST_ABS:
+        return solve_records<EST_ABS>(in, records);
+    case EST_REL:
+        return solve_records<EST_REL>(in, records);
+    case EST_FUND:
+        return solve_records<EST_FUND>(in, records);
+    default:
+        return solve_records<EST_HOM>(in, records);
+    }
+}
+
+int hm_essential_5pt(const double *in, double *E /* 10 x 9 row-major */) {
+    Vec3 a[5], b[5];
+    for (int k = 0; k < 5; ++k) {
+        a[k] = v3(in[3 * k], in[3 * k + 1], in[3 * k + 2]);
+        b[k] = v3(in[3 * (5 + k)], in[3 * (5 + k) + 1], in[3 * (5 + k) + 2]);
+    }
+    Mat3 Em[10];
+    const int n = essential_5pt(a, b, Em);
+    for (int i = 0; i < n; ++i)
+        std::memcpy(E + 9 * i, Em[i].m, sizeof(double) * 9);
+    return n;
+}
+
+int hm_sturm10(const double *coef, double *roots) { return sturm_roots_deg10(coef, roots); }
+
+// Build a model record from (q,t) or a row-major 3x3, as the generate kernel stores it.
+void hm_pose_record(const double *q4, const double *t3, int essential, double *rec) {
+    Quat q;
+    q.w = q4[0], q.x = q4[1], q.y = q4[2], q.z = q4[3];
+    store_pose_model_q(rec, q, v3(t3[0], t3[1], t3[2]), essential != 0);
+}
+
+// Score one model record against SoA points; per-point r2 / inlier flags are returned for bit-exact
+// comparison with the oracle.  score follows k_finalize: sum_inl r2 + (N - cnt) thr2 (serial sum).
+double hm_score(int est, const double *rec, const double *const *pa, uint32_t n, double thr2, uint32_t *count,
+                uint8_t *flags, double *r2_out) {
+    uint32_t c = 0;
+    double s = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        double r2 = 0;
+        bool in;
+        switch (est) {
+        case EST_ABS:
+            in = reproj_inlier(rec, pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], thr2, r2);
+            break;
+        case EST_REL:
+            in = sampson_pose_inlier(rec, pa[0][i], pa[1][i], pa[2][i], pa[3][i], thr2, r2);
+            break;
+        case EST_FUND:
+            in = sampson_inlier(rec, pa[0][i], pa[1][i], pa[2][i], pa[3][i], thr2, r2);
+            break;
+        default:
+            in = homography_inlier(rec, pa[0][i], pa[1][i], pa[2][i], pa[3][i], thr2, r2);
+        }
+        if (flags)
+            flags[i] = in;
+        if (r2_out)
+            r2_out[i] = r2;
+        if (in) {
+            c++;
+            s += r2;
+        }
+    }
+    *count = c;
+    return s + (double)(n - c) * thr2;
+}
+
+void hm_mask_abs(const double *rec, const double *const *pa, uint32_t n, double thr2, uint8_t *mask) {
+    for (uint32_t i = 0; i < n; ++i)
+        mask[i] = reproj_mask(rec, pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], thr2);
+}
+
+void hm_unproject(const CameraParams *cam, const double *xp, uint32_t n, double *out) {
+    for (uint32_t i = 0; i < n; ++i)
+        camera_unproject(*cam, xp[2 * i], xp[2 * i + 1], out[2 * i], out[2 * i + 1]);
+}
+
+void hm_lm(int est, const double *const *pa, uint32_t n, double *params, const LMOptions *opt, const CameraParams *cam,
+           double point_scale, double prefilter_thr2, const uint8_t *mask, uint32_t *iterations, uint32_t *skipped) {
+    switch (est) {
+    case EST_ABS:
+        lm_serial<EST_ABS>(pa, n, params, *opt, *cam, point_scale, prefilter_thr2, mask, iterations, skipped);
+        break;
+    case EST_REL:
+        lm_serial<EST_REL>(pa, n, params, *opt, *cam, point_scale, prefilter_thr2, mask, iterations, skipped);
+        break;
+    case EST_FUND:
+        lm_serial<EST_FUND>(pa, n, params, *opt, *cam, point_scale, prefilter_thr2, mask, iterations, skipped);
+        break;
+    default:
+        lm_serial<EST_HOM>(pa, n, params, *opt, *cam, point_scale, prefilter_thr2, mask, iterations, skipped);
+    }
+}
+
+void hm_factorized_F(const double *params, double *F) { factorized_F(params, F); }
+
+} // extern "C"

@@ -1,0 +1,162 @@
+"""ctypes binding of tests/hostmath/libhostmath.so — a TEST-ONLY host compilation of the product's
+device math headers (poselib_amd/csrc/pl_*.h).  Lets the CPU test-suite compare the exact source
+that hipcc compiles into the kernels against the oracle.  Never used by the product."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostmath")
+_LIB = os.path.join(_DIR, "libhostmath.so")
+EST = {"abs": 0, "rel": 1, "fund": 2, "hom": 3}
+STRIDE = 16
+MAT = 7
+
+
+class LMOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_uint32), ("loss_type", C.c_int32), ("lambda_update", C.c_int32),
+                ("damping", C.c_int32), ("loss_scale", C.c_double), ("gradient_tol", C.c_double),
+                ("step_tol", C.c_double), ("relative_cost_tol", C.c_double), ("initial_lambda", C.c_double),
+                ("min_lambda", C.c_double), ("max_lambda", C.c_double), ("lambda_factor", C.c_double)]
+
+
+class CameraParams(C.Structure):
+    _fields_ = [("model_id", C.c_int32), ("num_params", C.c_int32), ("p", C.c_double * 12)]
+
+
+def lm_options(max_iterations=100, loss_type=3, loss_scale=1.0, **kw):
+    return LMOptions(max_iterations, loss_type, kw.get("lambda_update", 0), kw.get("damping", 0), loss_scale,
+                     kw.get("gradient_tol", 1e-12), kw.get("step_tol", 1e-8), kw.get("relative_cost_tol", 1e-10),
+                     kw.get("initial_lambda", 1e-3), kw.get("min_lambda", 1e-10), kw.get("max_lambda", 1e10),
+                     kw.get("lambda_factor", 10.0))
+
+
+def camera_params(model_id=-1, params=()):
+    c = CameraParams()
+    c.model_id = model_id
+    c.num_params = len(params)
+    for i, v in enumerate(params):
+        c.p[i] = v
+    return c
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(_DIR, "hostmath.cc")]
+        csrc = os.path.join(os.path.dirname(_DIR), "..", "poselib_amd", "csrc")
+        srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.startswith("pl_") and f.endswith(".h")]
+        if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+            subprocess.check_call(["make", "-C", _DIR, "-s", "libhostmath.so"])
+        _lib = C.CDLL(_LIB)
+        _lib.hm_score.restype = C.c_double
+        _lib.hm_draw_samples.restype = C.c_uint32
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _soa(arrs):
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    return arrs, ptrs
+
+
+def draw_samples(seed, N, K, n_iters):
+    idx = np.zeros((n_iters, K), dtype=np.uint32)
+    pos = np.zeros(n_iters, dtype=np.uint32)
+    total = lib().hm_draw_samples(C.c_uint64(seed), C.c_uint64(N), K, n_iters, _p(idx), _p(pos))
+    return idx, pos, total
+
+
+def solve(est, first, second):
+    inp = np.ascontiguousarray(np.concatenate([np.asarray(first, float).ravel(), np.asarray(second, float).ravel()]))
+    maxm = {0: 4, 1: 40, 2: 3, 3: 1}[EST[est]]
+    rec = np.zeros((maxm, STRIDE))
+    n = lib().hm_solve(EST[est], _p(inp), _p(rec))
+    return rec[:n]
+
+
+def essential_5pt(x1, x2):
+    inp = np.ascontiguousarray(np.concatenate([np.asarray(x1, float).ravel(), np.asarray(x2, float).ravel()]))
+    out = np.zeros((10, 9))
+    n = lib().hm_essential_5pt(_p(inp), _p(out))
+    return [out[i].reshape(3, 3).copy() for i in range(n)]
+
+
+def sturm10(coef):
+    c = np.ascontiguousarray(coef, dtype=np.float64)
+    out = np.zeros(10)
+    n = lib().hm_sturm10(_p(c), _p(out))
+    return out[:n]
+
+
+def pose_record(q, t, essential=False):
+    rec = np.zeros(STRIDE)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    lib().hm_pose_record(_p(q), _p(t), int(essential), _p(rec))
+    return rec
+
+
+def matrix_record(M):
+    rec = np.zeros(STRIDE)
+    rec[MAT:] = np.asarray(M, float).reshape(9)
+    return rec
+
+
+def score(est, rec, cols, thr2):
+    arrs, ptrs = _soa(cols)
+    n = arrs[0].shape[0]
+    cnt = C.c_uint32(0)
+    flags = np.zeros(n, dtype=np.uint8)
+    r2 = np.zeros(n)
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    sc = lib().hm_score(EST[est], _p(rec), ptrs, C.c_uint32(n), C.c_double(thr2), C.byref(cnt), _p(flags), _p(r2))
+    return sc, cnt.value, flags.astype(bool), r2
+
+
+def mask_abs(rec, cols, thr2):
+    arrs, ptrs = _soa(cols)
+    n = arrs[0].shape[0]
+    m = np.zeros(n, dtype=np.uint8)
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    lib().hm_mask_abs(_p(rec), ptrs, C.c_uint32(n), C.c_double(thr2), _p(m))
+    return m.astype(bool)
+
+
+def unproject(cam: CameraParams, xp):
+    xp = np.ascontiguousarray(xp, dtype=np.float64)
+    out = np.zeros_like(xp)
+    lib().hm_unproject(C.byref(cam), _p(xp), C.c_uint32(xp.shape[0]), _p(out))
+    return out
+
+
+def lm(est, cols, params, opt: LMOptions, cam: CameraParams = None, point_scale=1.0, prefilter_thr2=0.0, mask=None):
+    arrs, ptrs = _soa(cols)
+    n = arrs[0].shape[0]
+    p = np.zeros(16)
+    p[: len(params)] = params
+    cam = cam or camera_params()
+    it = C.c_uint32(0)
+    sk = C.c_uint32(0)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().hm_lm(EST[est], ptrs, C.c_uint32(n), _p(p), C.byref(opt), C.byref(cam), C.c_double(point_scale),
+                C.c_double(prefilter_thr2), None if m is None else _p(m), C.byref(it), C.byref(sk))
+    return p, it.value, bool(sk.value)
+
+
+def factorized_F(params):
+    p = np.zeros(16)
+    p[: len(params)] = params
+    F = np.zeros(9)
+    lib().hm_factorized_F(_p(p), _p(F))
+    return F.reshape(3, 3)
