@@ -59,8 +59,11 @@ def quat_to_rotmat(q: np.ndarray) -> np.ndarray:
     )
 
 
-def random_pose(rs: Stream, unit_translation: bool = False):
+def random_pose(rs: Stream, unit_translation: bool = False, max_rotation: float = None):
     q = rs.normal(4)
+    if max_rotation is not None:
+        # two-view scenes: keep the relative rotation moderate so that both cameras see the scene
+        q = np.array([1.0, max_rotation * q[1], max_rotation * q[2], max_rotation * q[3]])
     q = q / np.linalg.norm(q)
     if q[0] < 0:
         q = -q
@@ -114,7 +117,11 @@ def _two_view_points(rs: Stream, n: int, R, t, s: float, planar: bool):
         if abs(nrm[2]) < 0.5:
             nrm = np.array([0.2, -0.1, -1.0]) / np.linalg.norm([0.2, -0.1, -1.0])
         dist = float(rs.uniform(1, 2.0, 6.0)[0])
+    rounds = 0
     while x1.shape[0] < n:
+        rounds += 1
+        if rounds > 1000:
+            raise RuntimeError("synthetic two-view scene: cameras share no visible points")
         m = 2 * (n - x1.shape[0]) + 16
         xy = rs.uniform(2 * m, -s, s).reshape(m, 2)
         b = np.concatenate([xy, np.ones((m, 1))], axis=1)
@@ -153,7 +160,7 @@ def relative_pose_scene(n: int, outlier_ratio: float, seed: int, noise_px: float
                         pp=(500.0, 500.0), fov_deg: float = 70.0):
     """2D-2D correspondences between two SIMPLE_PINHOLE cameras (config 2)."""
     rs = Stream(seed)
-    q, t = random_pose(rs, unit_translation=True)
+    q, t = random_pose(rs, unit_translation=True, max_rotation=0.2)
     R = quat_to_rotmat(q)
     s = _fov_scale(fov_deg)
     x1n, x2n = _two_view_points(rs, n, R, t, s, planar=False)
@@ -170,10 +177,7 @@ def homography_scene(n: int, outlier_ratio: float, seed: int, noise_px: float = 
                      pp=(500.0, 500.0), fov_deg: float = 70.0):
     """Pixel correspondences of a planar scene (config 3, homography part)."""
     rs = Stream(seed)
-    q, t = random_pose(rs, unit_translation=True)
-    # keep the rotation moderate so that the plane stays visible in both views
-    q = np.array([1.0, 0.15 * q[1], 0.15 * q[2], 0.15 * q[3]])
-    q /= np.linalg.norm(q)
+    q, t = random_pose(rs, unit_translation=True, max_rotation=0.15)
     t = 0.5 * t
     R = quat_to_rotmat(q)
     s = _fov_scale(fov_deg)

@@ -79,8 +79,8 @@ def lib():
         for name in ("orc_score_reproj", "orc_score_sampson_pose", "orc_score_sampson_F", "orc_score_homography"):
             getattr(_lib, name).restype = f64
         _lib.orc_normalize_points.restype = f64
-        _lib.orc_solve_cubic_single_real.argtypes = [f64, f64, f64, PD]
-        _lib.orc_solve_cubic_real.argtypes = [f64, f64, f64, PD]
+        _lib.orc_solve_cubic_single_real.argtypes = [f64, f64, f64, C.c_void_p]
+        _lib.orc_solve_cubic_real.argtypes = [f64, f64, f64, C.c_void_p]
     return _lib
 
 

@@ -1,0 +1,163 @@
+"""The product's device math (poselib_amd/csrc/pl_*.h), compiled for the HOST by tests/hostmath (test-only
+build of the very same headers hipcc compiles into the kernels), against the oracle — on CPU, so that
+kernel arithmetic is validated without a GPU.  With the same libm both sides must agree to the bit for
+everything except the 5-point solver (different, but equivalent, summation order of the constraint rows)."""
+import numpy as np
+
+import hostmath_lib as HM
+import oracle_lib as O
+from poselib_amd import synth
+
+
+def bear(p):
+    b = np.c_[p, np.ones(len(p))]
+    return b / np.sqrt((b * b).sum(1))[:, None]
+
+
+def test_sampler_bit_exact_and_positions():
+    for N, K in [(5000, 3), (200, 3), (10000, 7), (10000, 4), (5000, 5), (7, 7)]:
+        idx, pos, total = HM.draw_samples(3, N, K, 3000)
+        ref, state = O.sampler_draw(3, N, K, 3000)
+        assert (idx.astype(np.uint64) == ref).all()
+        assert pos[0] == 0 and (np.diff(pos.astype(np.int64)) >= K).all()
+        G = 0x9E3779B97F4A7C15
+        assert total == ((state - 3) * pow(G, -1, 2**64)) % 2**64
+
+
+def test_unproject_bit_exact():
+    rs = np.random.RandomState(0)
+    pix = rs.uniform(0, 1000, (500, 2))
+    cams = [("SIMPLE_PINHOLE", 0, [1000.0, 500.0, 480.0]), ("PINHOLE", 1, [900.0, 950.0, 500.0, 480.0]),
+            ("OPENCV", 4, [1000.0, 1010.0, 500.0, 480.0, -0.1, 0.02, 0.001, -0.002])]
+    for name, mid, params in cams:
+        a = O.unproject({"model": name, "params": params}, pix)
+        b = HM.unproject(HM.camera_params(mid, params), pix)
+        assert (a == b).all(), name
+
+
+def test_p3p_and_reprojection_score_bit_exact():
+    d = synth.absolute_pose_scene(3000, 0.6, 1001)
+    un = O.unproject(d["camera"], d["p2d"])
+    cols = [un[:, 0], un[:, 1], d["p3d"][:, 0], d["p3d"][:, 1], d["p3d"][:, 2]]
+    idx, _, _ = HM.draw_samples(0, 3000, 3, 1500)
+    thr2 = (12 / 1000.0) ** 2
+    nmodels = 0
+    for it in range(1500):
+        s = idx[it]
+        xb = bear(un[s])
+        recs = HM.solve("abs", xb, d["p3d"][s])
+        ref = O.p3p(xb, d["p3d"][s])
+        assert len(recs) == len(ref)
+        for r, o in zip(recs, ref):
+            # (a degenerate sample makes BOTH sides return a NaN model; it scores zero inliers on both)
+            assert np.array_equal(r[:7], o, equal_nan=True)
+            nmodels += 1
+            if it < 150:
+                sc, cnt, flags, r2 = HM.score("abs", r, cols, thr2)
+                osc, ocnt = O.score("reproj", o, un, d["p3d"], thr2)
+                assert cnt == ocnt
+                assert abs(sc - osc) <= 1e-12 * abs(osc)
+                # final-mask arithmetic (division form) may differ from the scoring form only at the threshold
+                m = HM.mask_abs(r, cols, thr2)
+                assert (m == O.inliers("reproj", o, un, d["p3d"], thr2)).all()
+    assert nmodels > 1500
+
+
+def test_two_view_solvers_and_scores():
+    d = synth.relative_pose_scene(2000, 0.4, 1002)
+    a = O.unproject(d["camera1"], d["x1"])
+    b = O.unproject(d["camera2"], d["x2"])
+    cols = [a[:, 0], a[:, 1], b[:, 0], b[:, 1]]
+    thr2 = 1e-6
+    # 7-point: bit exact
+    idx, _, _ = HM.draw_samples(1, 2000, 7, 400)
+    for it in range(400):
+        s = idx[it]
+        Fs = O.relpose_7pt(bear(a[s]), bear(b[s]))
+        recs = HM.solve("fund", bear(a[s]), bear(b[s]))
+        assert len(Fs) == len(recs)
+        for F, r in zip(Fs, recs):
+            assert (r[7:].reshape(3, 3) == F).all()
+            if it < 40:
+                sc, cnt, _, _ = HM.score("fund", r, cols, thr2)
+                osc, ocnt = O.score("sampson_F", F, a, b, thr2)
+                assert cnt == ocnt and abs(sc - osc) <= 1e-12 * abs(osc)
+    # homography: bit exact
+    idx, _, _ = HM.draw_samples(2, 2000, 4, 400)
+    for it in range(400):
+        s = idx[it]
+        n, H = O.homography_4pt(bear(a[s]), bear(b[s]))
+        recs = HM.solve("hom", bear(a[s]), bear(b[s]))
+        assert n == len(recs)
+        if n:
+            assert (recs[0][7:].reshape(3, 3) == H).all()
+            sc, cnt, _, _ = HM.score("hom", recs[0], cols, thr2)
+            osc, ocnt = O.score("homography", H, a, b, thr2)
+            assert cnt == ocnt and abs(sc - osc) <= 1e-12 * abs(osc)
+    # 5-point: same solution counts, rounding-level agreement for the bulk
+    idx, _, _ = HM.draw_samples(0, 2000, 5, 600)
+    diffs, mism = [], 0
+    for it in range(600):
+        s = idx[it]
+        ref = O.relpose_5pt(bear(a[s]), bear(b[s]))
+        recs = HM.solve("rel", bear(a[s]), bear(b[s]))
+        if len(ref) != len(recs):
+            mism += 1
+            continue
+        for o, r in zip(ref, recs):
+            diffs.append(np.abs(o - r[:7]).max())
+    assert mism <= 3
+    diffs = np.sort(diffs)
+    assert np.median(diffs) < 1e-12 and diffs[int(0.99 * (len(diffs) - 1))] < 1e-7
+    pose, mask, st = O.ransac_relpose(a, b, dict(max_error=1e-3))
+    rec = HM.pose_record(pose[:4], pose[4:], True)
+    sc, cnt, flags, _ = HM.score("rel", rec, cols, thr2)
+    osc, ocnt = O.score("sampson_pose", pose, a, b, thr2)
+    assert cnt == ocnt and abs(sc - osc) <= 1e-12 * abs(osc)
+    assert (flags == O.inliers("sampson_pose", pose, a, b, thr2)).all()
+
+
+def test_lm_refiners_bit_exact():
+    d = synth.absolute_pose_scene(1500, 0.5, 1000)
+    un = O.unproject(d["camera"], d["p2d"])
+    cols = [un[:, 0], un[:, 1], d["p3d"][:, 0], d["p3d"][:, 1], d["p3d"][:, 2]]
+    q = d["q_gt"] + 0.01 * np.array([0.3, -0.2, 0.5, 0.1])
+    q /= np.linalg.norm(q)
+    p0 = np.r_[q, d["t_gt"] + np.array([0.01, -0.02, 0.015])]
+    for loss, scale, mi in [(1, 0.012, 25), (3, 0.001, 100), (2, 0.002, 50), (0, 1.0, 10), (4, 0.01, 30), (5, 0.01, 30)]:
+        ref, st = O.bundle_adjust(un, d["p3d"], {"model": "NULL", "params": []}, p0,
+                                  dict(loss_type=loss, loss_scale=scale, max_iterations=mi))
+        got, it, _ = HM.lm("abs", cols, p0, HM.lm_options(mi, loss, scale))
+        assert it == st.iterations and (got[:7] == ref).all(), loss
+    # final bundle: pixel points * scale, rescaled pinhole camera, inlier mask (robust.cc:103-123)
+    scale = 1.0 / 1000
+    camp = [1000 * scale, 500 * scale, 500 * scale]
+    m = d["inlier_gt"]
+    ref, st = O.bundle_adjust(d["p2d"][m] * scale, d["p3d"][m], {"model": "SIMPLE_PINHOLE", "params": camp}, p0,
+                              dict(loss_type=3, loss_scale=scale))
+    colsp = [d["p2d"][:, 0], d["p2d"][:, 1]] + cols[2:]
+    got, it, _ = HM.lm("abs", colsp, p0, HM.lm_options(100, 3, scale), HM.camera_params(0, camp), point_scale=scale,
+                       mask=m)
+    assert it == st.iterations and (got[:7] == ref).all()
+
+    dh = synth.homography_scene(1200, 0.3, 1003, noise_px=0.2)
+    s, a, b, _, _ = O.normalize_points(dh["x1"], dh["x2"])
+    H0, _, _ = O.ransac_homography(a, b, dict(max_error=1.0 / s))
+    Hp = H0 + 1e-3 * np.arange(9).reshape(3, 3) / 9
+    ref, st = O.refine("homography", a, b, Hp, dict(loss_type=1, loss_scale=1.0 / s, max_iterations=25))
+    got, it, _ = HM.lm("hom", [a[:, 0], a[:, 1], b[:, 0], b[:, 1]], Hp.reshape(9), HM.lm_options(25, 1, 1.0 / s))
+    assert it == st.iterations and (got[:9] == ref.reshape(9)).all()
+
+    dr = synth.relative_pose_scene(1500, 0.4, 1002)
+    a = O.unproject(dr["camera1"], dr["x1"])
+    b = O.unproject(dr["camera2"], dr["x2"])
+    thr = 1e-3
+    pose, _, _ = O.ransac_relpose(a, b, dict(max_error=thr))
+    q = pose[:4] + 0.002 * np.array([0.3, -0.2, 0.5, 0.1])
+    q /= np.linalg.norm(q)
+    p0 = np.r_[q, pose[4:] + np.array([0.01, -0.005, 0.004])]
+    m5 = O.inliers("sampson_pose", p0, a, b, 5 * thr * thr)
+    ref, st = O.refine("relpose", a[m5], b[m5], p0, dict(loss_type=1, loss_scale=thr, max_iterations=25))
+    got, it, skipped = HM.lm("rel", [a[:, 0], a[:, 1], b[:, 0], b[:, 1]], p0, HM.lm_options(25, 1, thr),
+                             prefilter_thr2=5 * thr * thr)
+    assert not skipped and it == st.iterations and (got[:7] == ref).all()
