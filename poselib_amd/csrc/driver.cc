@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -92,7 +93,9 @@ struct Context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // batch scratch
     DevBuf positions, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
+    HostBuf h_rec_meta;
     HostBuf h_positions, h_num_models, h_count, h_score, h_tasks, h_records, h_gather_idx, h_gather_out, h_mask,
         h_small;
 };
@@ -409,6 +412,9 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     return PL_OK;
 }
 
+constexpr uint32_t kRecordCap = 1024;  // device record list capacity (overflow -> host scan fallback)
+constexpr uint32_t kRecordFirst = 64;  // records fetched together with the control block
+
 struct RefineJob {
     double record_in[kModelStride]; // seed model
     LMOptions opt;
@@ -568,6 +574,9 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
         bool stopped = false;
         std::vector<Improving> imps;
         std::vector<RefineJob> jobs;
+        std::vector<uint32_t> order;
+        const bool host_bookkeeping = std::getenv("POSELIB_AMD_HOST_BOOKKEEPING") != nullptr;
+        bool force_host_positions = false;
 
         while (!stopped && it < ro.max_iterations) {
             if (it > ro.min_iterations && it > dyn_max) { // stop rule at the top of the next iteration (:182)
@@ -581,43 +590,73 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             const uint32_t B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
             grow = std::min<uint64_t>(grow * 2, cap);
 
-            // ---- device: generate + score the whole batch ----
-            HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * B));
-            const uint64_t pos_after = sample_positions_k(K, ro.seed, pos, N, B, c->h_positions.as<uint32_t>());
-            if (pos_after >= 0xffffffffull)
-                return fail(PL_ERR_UNSUPPORTED, "sampler draw counter exceeds 32 bits");
+            // ---- device: positions -> generate -> compact -> score -> finalize -> records ----
             const size_t hcap = (size_t)B * MAXM;
             const uint32_t chunks = score_chunks(kind, N);
             HIP_TRY(c->positions.ensure(sizeof(uint32_t) * B));
             HIP_TRY(c->models.ensure(sizeof(double) * kModelStride * hcap));
             HIP_TRY(c->num_models.ensure(sizeof(uint32_t) * B));
             HIP_TRY(c->slots.ensure(sizeof(uint32_t) * hcap));
-            HIP_TRY(c->num_hyp.ensure(sizeof(uint32_t)));
+            HIP_TRY(c->offsets.ensure(sizeof(uint32_t) * B));
+            HIP_TRY(c->blk_tot.ensure(sizeof(uint32_t) * ((B + 1023) / 1024 + 1)));
+            HIP_TRY(c->ctl.ensure(sizeof(BatchCtl)));
             HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * hcap));
             HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * hcap));
             HIP_TRY(c->count.ensure(sizeof(uint32_t) * hcap));
             HIP_TRY(c->score.ensure(sizeof(double) * hcap));
-            HIP_TRY(c->h_num_models.ensure(sizeof(uint32_t) * (B + 1)));
-            HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * hcap));
-            HIP_TRY(c->h_score.ensure(sizeof(double) * hcap));
-            HIP_TRY(hipMemcpyAsync(c->positions.p, c->h_positions.p, sizeof(uint32_t) * B, hipMemcpyHostToDevice,
-                                   c->stream));
+            HIP_TRY(c->blk_best.ensure((sizeof(uint32_t) + sizeof(double)) * 256 + 64));
+            HIP_TRY(c->rec_meta.ensure(sizeof(RecordMeta) * kRecordCap));
+            HIP_TRY(c->rec_models.ensure(sizeof(double) * kModelStride * kRecordCap));
+            HIP_TRY(c->h_small.ensure(sizeof(BatchCtl) + 64));
+            HIP_TRY(c->h_rec_meta.ensure(sizeof(RecordMeta) * kRecordCap));
+            HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * kRecordCap));
+            BatchCtl *d_ctl = c->ctl.as<BatchCtl>();
+            HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(BatchCtl), c->stream));
+
+            uint64_t pos_after = 0;
+            bool device_positions = !host_bookkeeping && !force_host_positions;
+            if (device_positions) {
+                // window of draw positions to evaluate: expected draws per iteration (sum N/(N-i)) + slack
+                double per_it = 0;
+                for (int i = 0; i < K; ++i)
+                    per_it += static_cast<double>(N) / static_cast<double>(N - i);
+                const uint64_t M64 = (uint64_t)(B * per_it * 1.05) + 8192;
+                if (M64 > 0x7fffffffull || pos + M64 >= 0xffffffffull) {
+                    device_positions = false;
+                } else {
+                    const uint32_t M = (uint32_t)M64;
+                    HIP_TRY(c->delta.ensure(M));
+                    HIP_TRY(c->flags.ensure(sizeof(uint32_t) * (size_t)M));
+                    HIP_TRY(launch_sample_positions(K, ro.seed, pos, N, B, M, c->delta.as<uint8_t>(),
+                                                    c->flags.as<uint32_t>(), M, c->positions.as<uint32_t>(), d_ctl,
+                                                    c->stream));
+                }
+            }
+            if (!device_positions) {
+                HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * B));
+                pos_after = sample_positions_k(K, ro.seed, pos, N, B, c->h_positions.as<uint32_t>());
+                if (pos_after - pos >= 0xffffffffull)
+                    return fail(PL_ERR_UNSUPPORTED, "sampler draw window exceeds 32 bits");
+                HIP_TRY(hipMemcpyAsync(c->positions.p, c->h_positions.p, sizeof(uint32_t) * B, hipMemcpyHostToDevice,
+                                       c->stream));
+            }
             GenerateArgs ga;
             ga.pts = p->ps;
             ga.seed = ro.seed;
+            ga.pos_base = pos;
             ga.positions = c->positions.as<uint32_t>();
             ga.num_iters = B;
             ga.models = c->models.as<double>();
             ga.num_models = c->num_models.as<uint32_t>();
             ga.real_focal_check = o->real_focal_check;
             HIP_TRY(launch_generate(kind, ga, c->stream));
-            HIP_TRY(launch_compact(ga.num_models, B, MAXM, c->slots.as<uint32_t>(), c->num_hyp.as<uint32_t>(),
-                                   c->stream));
+            HIP_TRY(launch_compact2(ga.num_models, B, MAXM, c->blk_tot.as<uint32_t>(), c->slots.as<uint32_t>(),
+                                    c->offsets.as<uint32_t>(), d_ctl, c->stream));
             ScoreArgs sa;
             sa.pts = p->ps;
             sa.models = ga.models;
             sa.slots = c->slots.as<uint32_t>();
-            sa.num_hyp = c->num_hyp.as<uint32_t>();
+            sa.num_hyp = &d_ctl->num_hyp;
             sa.hyp_capacity = (uint32_t)hcap;
             sa.thr2 = thr2;
             sa.part_count = c->part_count.as<uint32_t>();
@@ -636,28 +675,88 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             fa.part_score = sa.part_score;
             fa.count = c->count.as<uint32_t>();
             fa.score = c->score.as<double>();
-            HIP_TRY(launch_finalize(fa, (uint32_t)hcap, c->stream));
-            uint32_t *h_nm = c->h_num_models.as<uint32_t>();
-            HIP_TRY(hipMemcpyAsync(h_nm, c->num_models.p, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(h_nm + B, c->num_hyp.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            uint32_t *blk_max = c->blk_best.as<uint32_t>();
+            double *blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
+            HIP_TRY(c->blk_best.ensure(1024 + sizeof(double) * 256));
+            blk_max = c->blk_best.as<uint32_t>();
+            blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
+            const uint32_t init_max = (uint32_t)std::min<uint64_t>(best_min_inl, 0xffffffffu);
+            HIP_TRY(launch_finalize_records(fa, sa.slots, ga.models, blk_max, blk_min, init_max, best_min_score,
+                                            c->rec_meta.as<RecordMeta>(), c->rec_models.as<double>(), kRecordCap, d_ctl,
+                                            c->stream));
+            BatchCtl *h_ctl = c->h_small.as<BatchCtl>();
+            RecordMeta *h_meta = c->h_rec_meta.as<RecordMeta>();
+            double *h_recm = c->h_gather_out.as<double>();
+            HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(BatchCtl), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(h_meta, c->rec_meta.p, sizeof(RecordMeta) * kRecordFirst, hipMemcpyDeviceToHost,
+                                   c->stream));
+            HIP_TRY(hipMemcpyAsync(h_recm, c->rec_models.p, sizeof(double) * kModelStride * kRecordFirst,
+                                   hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            const uint32_t H = h_nm[B];
-            if (H) {
-                HIP_TRY(hipMemcpyAsync(c->h_count.p, c->count.p, sizeof(uint32_t) * H, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipMemcpyAsync(c->h_score.p, c->score.p, sizeof(double) * H, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
+            if (device_positions) {
+                if (h_ctl->orbit_error) { // evaluated window too small / too many redraws: redo this batch
+                    force_host_positions = true;
+                    continue;
+                }
+                pos_after = h_ctl->pos_after;
             }
+            force_host_positions = false;
+            const uint32_t H = h_ctl->num_hyp;
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
             st->score_kernel_ms += ms;
             st->score_kernel_launches++;
             st->iterations_evaluated += B;
 
-            // ---- host pass 1: which hypotheses improve best_minimal_*  (ransac_impl.h:110-133) ----
-            const uint32_t *h_cnt = c->h_count.as<uint32_t>();
-            const double *h_sc = c->h_score.as<double>();
+            // ---- pass 1 result: the improving hypotheses, in (iteration, model) order ----
             imps.clear();
-            {
+            const double *h_rec = h_recm;
+            const uint32_t nrec = h_ctl->num_records;
+            if (!host_bookkeeping && nrec <= kRecordCap) {
+                if (nrec > kRecordFirst) {
+                    HIP_TRY(hipMemcpyAsync(h_meta, c->rec_meta.p, sizeof(RecordMeta) * nrec, hipMemcpyDeviceToHost,
+                                           c->stream));
+                    HIP_TRY(hipMemcpyAsync(h_recm, c->rec_models.p, sizeof(double) * kModelStride * nrec,
+                                           hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                }
+                order.resize(nrec);
+                for (uint32_t a = 0; a < nrec; ++a)
+                    order[a] = a;
+                std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_meta[x].k < h_meta[y].k; });
+                for (uint32_t a = 0; a < nrec; ++a) {
+                    const RecordMeta &m = h_meta[order[a]];
+                    Improving im;
+                    im.iter = (uint32_t)(it + m.slot / MAXM);
+                    im.slot = m.slot;
+                    im.count = m.count;
+                    im.score = m.score;
+                    im.lo_seed = false;
+                    im.gather = order[a];
+                    if (!imps.empty() && imps.back().iter != im.iter)
+                        imps.back().lo_seed = true;
+                    imps.push_back(im);
+                    best_min_inl = std::max<uint64_t>(best_min_inl, m.count);
+                    best_min_score = std::min(best_min_score, m.score);
+                }
+                if (!imps.empty())
+                    imps.back().lo_seed = true;
+            } else {
+                // fallback (record list overflow, or POSELIB_AMD_HOST_BOOKKEEPING=1): scan every score on the host
+                HIP_TRY(c->h_num_models.ensure(sizeof(uint32_t) * (B + 1)));
+                HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * hcap));
+                HIP_TRY(c->h_score.ensure(sizeof(double) * hcap));
+                uint32_t *h_nm = c->h_num_models.as<uint32_t>();
+                HIP_TRY(hipMemcpyAsync(h_nm, c->num_models.p, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, c->stream));
+                if (H) {
+                    HIP_TRY(hipMemcpyAsync(c->h_count.p, c->count.p, sizeof(uint32_t) * H, hipMemcpyDeviceToHost,
+                                           c->stream));
+                    HIP_TRY(hipMemcpyAsync(c->h_score.p, c->score.p, sizeof(double) * H, hipMemcpyDeviceToHost,
+                                           c->stream));
+                }
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                const uint32_t *h_cnt = c->h_count.as<uint32_t>();
+                const double *h_sc = c->h_score.as<double>();
                 uint32_t k = 0;
                 for (uint32_t i = 0; i < B; ++i) {
                     int last = -1;
@@ -683,58 +782,69 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                     if (last >= 0)
                         imps[last].lo_seed = true;
                 }
-            }
-
-            // ---- device: fetch the improving records, run every triggered LO of the batch at once ----
-            const uint32_t ni = (uint32_t)imps.size();
-            const double *h_rec = nullptr;
-            if (ni) {
-                HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * ni));
+                const uint32_t ni0 = (uint32_t)imps.size();
+                HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * std::max<uint32_t>(ni0, kRecordCap)));
                 double *dst = c->h_gather_out.as<double>();
-                for (uint32_t a = 0; a < ni; ++a)
+                for (uint32_t a = 0; a < ni0; ++a)
                     HIP_TRY(hipMemcpyAsync(dst + (size_t)a * kModelStride,
                                            c->models.as<double>() + (size_t)imps[a].slot * kModelStride,
                                            sizeof(double) * kModelStride, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 h_rec = dst;
-                jobs.clear();
-                for (uint32_t a = 0; a < ni; ++a)
-                    if (imps[a].lo_seed) {
-                        imps[a].job = (int)jobs.size();
-                        jobs.push_back(make_lo_job(h_rec + (size_t)a * kModelStride));
-                    }
+            }
+
+            // ---- device: every triggered LO of the batch as one batched launch, then re-scored ----
+            const uint32_t ni = (uint32_t)imps.size();
+            jobs.clear();
+            for (uint32_t a = 0; a < ni; ++a)
+                if (imps[a].lo_seed) {
+                    imps[a].job = (int)jobs.size();
+                    jobs.push_back(make_lo_job(h_rec + (size_t)imps[a].gather * kModelStride));
+                }
+            if (!jobs.empty()) {
                 int rc = run_refinements(c, p, jobs, true, thr2);
                 if (rc != PL_OK)
                     return rc;
             }
 
-            // ---- host pass 2: replay the sequential loop over this batch (ransac_impl.h:180-188) ----
-            uint32_t a = 0; // cursor into imps
-            uint32_t hyp_cursor = 0;
-            uint64_t i = 0;
-            for (; i < B; ++i) {
-                const uint64_t iter = it + i;
-                if (iter > ro.min_iterations && iter > dyn_max) {
+            // ---- host pass 2: replay the sequential loop over this batch (ransac_impl.h:180-188).  The stop
+            // rule can only change at LO events, so the replay hops from event to event. ----
+            uint64_t cursor = it;          // next iteration whose stop check has not been made yet
+            uint64_t stop_at = it + B;     // first iteration NOT replayed
+            for (uint32_t a = 0; a < ni; ++a) {
+                const Improving &im = imps[a];
+                const uint64_t first_stop = std::max<uint64_t>(std::max<uint64_t>(ro.min_iterations, dyn_max) + 1, cursor);
+                if (first_stop <= im.iter) {
                     stopped = true;
+                    stop_at = first_stop;
                     break;
                 }
-                st->hypotheses += h_nm[i];
-                hyp_cursor += h_nm[i];
-                while (a < ni && imps[a].iter == iter) {
-                    const Improving &im = imps[a];
-                    if (im.score < st->model_score) { // :126-131
-                        st->model_score = im.score;
-                        st->num_inliers = im.count;
-                        std::memcpy(best_record, h_rec + (size_t)im.gather * kModelStride,
-                                    sizeof(double) * kModelStride);
-                    }
-                    if (im.lo_seed)
-                        after_lo(jobs[im.job]);
-                    ++a;
+                if (im.score < st->model_score) { // :126-131
+                    st->model_score = im.score;
+                    st->num_inliers = im.count;
+                    std::memcpy(best_record, h_rec + (size_t)im.gather * kModelStride, sizeof(double) * kModelStride);
+                }
+                if (im.lo_seed)
+                    after_lo(jobs[im.job]);
+                cursor = (uint64_t)im.iter + 1;
+            }
+            if (!stopped) {
+                const uint64_t first_stop = std::max<uint64_t>(std::max<uint64_t>(ro.min_iterations, dyn_max) + 1, cursor);
+                if (first_stop < it + B) {
+                    stopped = true;
+                    stop_at = first_stop;
                 }
             }
-            (void)hyp_cursor;
-            it += i;
+            if (stop_at < it + B) { // hypotheses of the replayed iterations only
+                uint32_t upto = 0;
+                HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it), sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                st->hypotheses += upto;
+            } else {
+                st->hypotheses += H;
+            }
+            it = stop_at;
             pos = pos_after;
         }
         st->iterations = it;

@@ -51,7 +51,7 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs
     constexpr int K = sample_size(EST);
     constexpr int MAXM = max_models(EST);
     uint32_t idx[K];
-    draw_sample<K>(g.seed, g.positions[it], g.pts.n, idx);
+    draw_sample<K>(g.seed, g.pos_base + g.positions[it], g.pts.n, idx);
     double *rec = g.models + (size_t)it * MAXM * kModelStride;
     int n = 0;
     if constexpr (EST == EST_ABS) {

@@ -1,0 +1,388 @@
+// poselib_amd — device-side bookkeeping kernels of one RANSAC batch (gfx950).  They remove the host from
+// the per-batch critical path; everything here is integer / comparison work, deterministic, no atomics
+// on the data path (one atomic counter orders nothing: the record list is re-sorted by hypothesis index).
+//
+//   k_sample_delta<K> + k_sample_orbit
+//       Where does iteration i start in the splitmix64 draw stream?  Each iteration consumes K draws plus
+//       one more per duplicate index (PoseLib/robust/sampling.cc:46-61), so the start positions form the
+//       orbit  p -> p + delta(p)  of the function delta(p) = draws an iteration STARTING at p would consume.
+//       delta is evaluated for every position in parallel; positions with delta != K are rare ("flags",
+//       probability ~K^2/2N).  Between flags the orbit advances in strides of K, so one lane only has to hop
+//       from flag to flag (~#duplicates hops per batch) and emit (iteration, position) segments; all lanes
+//       then expand the segments into the per-iteration position table.
+//   k_count_blocks + k_compact2
+//       multi-workgroup exclusive scan of models-per-iteration -> hypothesis list in (iteration, model)
+//       order and per-iteration hypothesis offsets.
+//   k_finalize2 + k_records
+//       chunk partials -> (count, score); then the running  best_minimal_inlier_count / _msac_score  scan of
+//       PoseLib/robust/ransac_impl.h:113-123 over all hypotheses of the batch: a hypothesis is a "record"
+//       iff count > max(previous counts) or score < min(previous scores).  Records (typically O(log H)) are
+//       appended with their 128-byte model so the host fetches a few KB instead of every score.
+#include "pl_kernels.h"
+#include "pl_sampler.h"
+
+namespace pl {
+
+__device__ __forceinline__ uint32_t wsum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes of a wavefront
+__device__ __forceinline__ uint32_t wscan_add(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off, 64);
+        if (lane >= off)
+            v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wscan_max(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off, 64);
+        if (lane >= off)
+            v = max(v, u);
+    }
+    return v;
+}
+__device__ __forceinline__ double wscan_min(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double u = __shfl_up(v, off, 64);
+        if (lane >= off)
+            v = fmin(v, u);
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------ sampler orbit
+template <int K>
+__global__ __launch_bounds__(256) void k_sample_delta(uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t M,
+                                                      uint8_t *delta) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= M)
+        return;
+    uint32_t idx[K];
+    const uint32_t used = draw_sample<K>(seed, pos_base + p, N, idx);
+    delta[p] = (uint8_t)min(used, 255u);
+}
+
+constexpr int kMaxSegments = 4096;
+
+__global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, uint32_t M, int K, uint32_t B,
+                                                       uint64_t pos_base, uint32_t *flags, uint32_t flags_cap,
+                                                       uint32_t *positions, BatchCtl *ctl) {
+    __shared__ uint32_t wave_tot[16], wave_off[16];
+    __shared__ uint32_t seg_iter[kMaxSegments];
+    __shared__ uint32_t seg_pos[kMaxSegments];
+    __shared__ uint32_t s_nseg, s_nflags, s_error;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- phase 1: ordered list of the positions whose iteration would redraw (delta != K) ----
+    const uint32_t per = (M + 1023u) / 1024u;
+    const uint32_t p0 = min(M, threadIdx.x * per), p1 = min(M, p0 + per);
+    uint32_t local = 0;
+    for (uint32_t p = p0; p < p1; ++p)
+        local += (delta[p] != (uint8_t)K);
+    const uint32_t inc = wscan_add(local, lane);
+    if (lane == 63)
+        wave_tot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int w = 0; w < 16; ++w) {
+            wave_off[w] = s;
+            s += wave_tot[w];
+        }
+        s_nflags = s;
+        s_error = (s > flags_cap) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_error) {
+        uint32_t o = wave_off[wave] + inc - local;
+        for (uint32_t p = p0; p < p1; ++p)
+            if (delta[p] != (uint8_t)K)
+                flags[o++] = p;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- phase 2: one lane hops along the orbit from flag to flag ----
+    if (threadIdx.x == 0) {
+        uint32_t nseg = 1, err = s_error;
+        seg_iter[0] = 0;
+        seg_pos[0] = 0;
+        if (!err) {
+            const uint32_t F = s_nflags;
+            uint32_t cur = 0, it = 0, fi = 0;
+            while (it < B) {
+                while (fi < F && flags[fi] < cur)
+                    ++fi;
+                uint32_t j = fi;
+                while (j < F && (flags[j] - cur) % (uint32_t)K != 0)
+                    ++j;
+                if (j >= F)
+                    break; // no further redraw on this orbit: strides of K to the end
+                const uint32_t q = flags[j];
+                const uint32_t before = (q - cur) / (uint32_t)K;
+                if (it + before >= B)
+                    break; // the batch ends before that iteration
+                it += before;
+                const uint32_t d = delta[q];
+                if (d == 255u || nseg >= (uint32_t)kMaxSegments) {
+                    err = 1;
+                    break;
+                }
+                cur = q + d;
+                it += 1;
+                seg_iter[nseg] = it;
+                seg_pos[nseg] = cur;
+                ++nseg;
+            }
+        }
+        s_nseg = nseg;
+        // position of iteration B == draws consumed by the batch
+        const uint32_t s = nseg - 1;
+        const uint64_t end = (uint64_t)seg_pos[s] + (uint64_t)(B - seg_iter[s]) * (uint64_t)K;
+        if (end + 255 > M)
+            err = 1; // the window of evaluated positions was too small: the host retries with a larger one
+        ctl->pos_after = pos_base + end;
+        ctl->orbit_error = err;
+        s_error = err;
+    }
+    __syncthreads();
+
+    // ---- phase 3: expand segments to per-iteration positions (relative to pos_base) ----
+    const uint32_t nseg = s_nseg;
+    for (uint32_t i = threadIdx.x; i < B; i += 1024) {
+        uint32_t lo = 0, hi = nseg; // last segment with seg_iter <= i
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (seg_iter[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        positions[i] = seg_pos[lo] + (i - seg_iter[lo]) * (uint32_t)K;
+    }
+}
+
+// ------------------------------------------------------------------------------------ compaction
+__global__ __launch_bounds__(1024) void k_count_blocks(const uint32_t *num_models, uint32_t B, uint32_t *blk_tot) {
+    __shared__ uint32_t wt[16];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = (i < B) ? num_models[i] : 0u;
+    const uint32_t s = wsum_u32(v);
+    if ((threadIdx.x & 63) == 0)
+        wt[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w)
+            t += wt[w];
+        blk_tot[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, uint32_t B, int maxm,
+                                                   const uint32_t *blk_tot, uint32_t *slots, uint32_t *offsets,
+                                                   BatchCtl *ctl) {
+    __shared__ uint32_t wt[16], wo[16];
+    __shared__ uint32_t s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        uint32_t b = 0;
+        for (uint32_t j = 0; j < blockIdx.x; ++j)
+            b += blk_tot[j];
+        s_base = b;
+    }
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t nm = (i < B) ? num_models[i] : 0u;
+    const uint32_t inc = wscan_add(nm, lane);
+    if (lane == 63)
+        wt[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int w = 0; w < 16; ++w) {
+            wo[w] = s;
+            s += wt[w];
+        }
+        if (blockIdx.x == gridDim.x - 1)
+            ctl->num_hyp = s_base + s;
+    }
+    __syncthreads();
+    if (i < B) {
+        const uint32_t o = s_base + wo[wave] + inc - nm;
+        offsets[i] = o;
+        for (uint32_t m = 0; m < nm; ++m)
+            slots[o + m] = i * (uint32_t)maxm + m;
+    }
+}
+
+// ------------------------------------------------------------------------------------ finalize + records
+constexpr int kRecBlocks = 256; // hypothesis chunks (contiguous), shared by k_finalize2 and k_records
+
+__global__ __launch_bounds__(256) void k_finalize2(FinalizeArgs f, uint32_t *blk_max, double *blk_min) {
+    __shared__ uint32_t wmax[4];
+    __shared__ double wmin[4];
+    const uint32_t H = *f.num_hyp;
+    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
+    const uint32_t k0 = min(H, blockIdx.x * per), k1 = min(H, k0 + per);
+    uint32_t bmax = 0;
+    double bmin = 1.7976931348623157e308;
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) {
+        uint32_t c = 0;
+        double s = 0.0;
+        for (uint32_t ch = 0; ch < f.chunks; ++ch) {
+            c += f.part_count[(size_t)ch * f.hyp_capacity + k];
+            s += f.part_score[(size_t)ch * f.hyp_capacity + k];
+        }
+        const double sc = s + (double)(f.n_points - c) * f.thr2; // utils.cc:63 / :193-197
+        f.count[k] = c;
+        f.score[k] = sc;
+        bmax = max(bmax, c);
+        bmin = fmin(bmin, sc);
+    }
+    if (blk_max) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            bmax = max(bmax, (uint32_t)__shfl_xor(bmax, off, 64));
+            bmin = fmin(bmin, __shfl_xor(bmin, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            wmax[threadIdx.x >> 6] = bmax;
+            wmin[threadIdx.x >> 6] = bmin;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) {
+                bmax = max(bmax, wmax[w]);
+                bmin = fmin(bmin, wmin[w]);
+            }
+            blk_max[blockIdx.x] = bmax;
+            blk_min[blockIdx.x] = bmin;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const uint32_t *count, const double *score,
+                                                 const uint32_t *slots, const double *models, const uint32_t *blk_max,
+                                                 const double *blk_min, uint32_t init_max, double init_min,
+                                                 RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap,
+                                                 BatchCtl *ctl) {
+    __shared__ uint32_t wmax[4];
+    __shared__ double wmin[4];
+    __shared__ uint32_t s_runmax;
+    __shared__ double s_runmin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t H = *num_hyp;
+    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
+    const uint32_t k0 = min(H, blockIdx.x * per), k1 = min(H, k0 + per);
+    if (threadIdx.x == 0) { // state of the sequential loop when it reaches this chunk
+        uint32_t m = init_max;
+        double s = init_min;
+        for (uint32_t b = 0; b < blockIdx.x; ++b) {
+            m = max(m, blk_max[b]);
+            s = fmin(s, blk_min[b]);
+        }
+        s_runmax = m;
+        s_runmin = s;
+    }
+    __syncthreads();
+    for (uint32_t t0 = k0; t0 < k1; t0 += 256) {
+        const uint32_t k = t0 + threadIdx.x;
+        const bool live = k < k1;
+        const uint32_t c = live ? count[k] : 0u;
+        const double s = live ? score[k] : 1.7976931348623157e308;
+        const uint32_t imax = wscan_max(c, lane);
+        const double imin = wscan_min(s, lane);
+        if (lane == 63) {
+            wmax[wave] = imax;
+            wmin[wave] = imin;
+        }
+        __syncthreads();
+        // exclusive running values in front of this lane
+        uint32_t emax = s_runmax;
+        double emin = s_runmin;
+        for (int w = 0; w < wave; ++w) {
+            emax = max(emax, wmax[w]);
+            emin = fmin(emin, wmin[w]);
+        }
+        const uint32_t pmax = __shfl_up(imax, 1, 64);
+        const double pmin = __shfl_up(imin, 1, 64);
+        if (lane > 0) {
+            emax = max(emax, pmax);
+            emin = fmin(emin, pmin);
+        }
+        if (live && (c > emax || s < emin)) { // ransac_impl.h:114-116
+            const uint32_t r = atomicAdd(&ctl->num_records, 1u);
+            if (r < rec_cap) {
+                const uint32_t slot = slots ? slots[k] : k;
+                RecordMeta m;
+                m.k = k;
+                m.slot = slot;
+                m.count = c;
+                m.pad = 0;
+                m.score = s;
+                rec_meta[r] = m;
+                for (int i = 0; i < kModelStride; ++i)
+                    rec_models[(size_t)r * kModelStride + i] = models[(size_t)slot * kModelStride + i];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) { // carry the running state to the next tile
+            s_runmax = max(emax, c);
+            s_runmin = fmin(emin, s);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t B, uint32_t M,
+                                   uint8_t *delta, uint32_t *flags, uint32_t flags_cap, uint32_t *positions,
+                                   BatchCtl *ctl, hipStream_t stream) {
+    const dim3 grid((M + 255) / 256), block(256);
+    switch (K) {
+    case 3:
+        k_sample_delta<3><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta);
+        break;
+    case 4:
+        k_sample_delta<4><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta);
+        break;
+    case 5:
+        k_sample_delta<5><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta);
+        break;
+    case 7:
+        k_sample_delta<7><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    k_sample_orbit<<<dim3(1), dim3(1024), 0, stream>>>(delta, M, K, B, pos_base, flags, flags_cap, positions, ctl);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, uint32_t *slots,
+                           uint32_t *offsets, BatchCtl *ctl, hipStream_t stream) {
+    const uint32_t nb = (B + 1023) / 1024;
+    k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
+    k_compact2<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, maxm, blk_tot, slots, offsets, ctl);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_records(const FinalizeArgs &f, const uint32_t *slots, const double *models,
+                                   uint32_t *blk_max, double *blk_min, uint32_t init_max, double init_min,
+                                   RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap, BatchCtl *ctl,
+                                   hipStream_t stream) {
+    k_finalize2<<<dim3(kRecBlocks), dim3(256), 0, stream>>>(f, blk_max, blk_min);
+    k_records<<<dim3(kRecBlocks), dim3(256), 0, stream>>>(f.num_hyp, f.count, f.score, slots, models, blk_max, blk_min,
+                                                          init_max, init_min, rec_meta, rec_models, rec_cap, ctl);
+    return hipGetLastError();
+}
+
+} // namespace pl

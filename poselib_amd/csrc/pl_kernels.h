@@ -26,7 +26,8 @@ PL_HD constexpr int point_doubles(int est) { return est == EST_ABS ? 5 : 4; }
 struct GenerateArgs {
     PointSet pts;
     uint64_t seed;
-    const uint32_t *positions; // draws consumed before each iteration of this batch
+    uint64_t pos_base;         // draws consumed before the batch
+    const uint32_t *positions; // draws consumed before each iteration, relative to pos_base
     uint32_t num_iters;
     double *models;            // [num_iters * max_models] records of kModelStride doubles
     uint32_t *num_models;      // [num_iters]
@@ -68,6 +69,19 @@ struct LMTask {
     double cost, initial_cost;
 };
 
+// Device-resident control block of one batch (zeroed before the batch, read back after it).
+struct BatchCtl {
+    uint32_t num_hyp;     // hypotheses of the batch (k_compact2)
+    uint32_t num_records; // improving hypotheses found by k_records (may exceed the list capacity)
+    uint32_t orbit_error; // sampler position window too small / too many redraw segments
+    uint32_t pad;
+    uint64_t pos_after;   // draws consumed after the batch's last iteration
+};
+struct RecordMeta {
+    uint32_t k, slot, count, pad;
+    double score;
+};
+
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream);
 // chunks = ceil(n / (kScoreThreads * P)); P is chosen inside from n (returned through *chunks_out)
@@ -80,6 +94,17 @@ hipError_t launch_compact(const uint32_t *num_models, uint32_t num_iters, int ma
 hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
 hipError_t launch_mask(int est, const PointSet &pts, const double *model, double thr2, uint8_t *mask,
                        hipStream_t stream);
+
+// ---- device-side bookkeeping (pipeline.hip) ----
+hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t B, uint32_t M,
+                                   uint8_t *delta, uint32_t *flags, uint32_t flags_cap, uint32_t *positions,
+                                   BatchCtl *ctl, hipStream_t stream);
+hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, uint32_t *slots,
+                           uint32_t *offsets, BatchCtl *ctl, hipStream_t stream);
+hipError_t launch_finalize_records(const FinalizeArgs &f, const uint32_t *slots, const double *models,
+                                   uint32_t *blk_max, double *blk_min, uint32_t init_max, double init_min,
+                                   RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap, BatchCtl *ctl,
+                                   hipStream_t stream);
 
 // Bare solver entry points (one problem per lane); inputs/outputs in HBM.
 //   abs : in = [x0 x1 x2 X0 X1 X2] (18 doubles / problem) -> out records (4 / problem)
