@@ -7,8 +7,9 @@
 Workload (config.workload = "p3p_5000"): BASELINE.json configs[1] — P3P LO-RANSAC on 5000 synthetic 2D-3D
 correspondences, 70 % outliers, max_iterations = 100000, with min_iterations = max_iterations so that the
 loop really evaluates 100000 iterations (with default options PoseLib stops after ~10^3).
-One "step" = one complete ransac_pnp call (sample -> P3P -> score all N -> LO -> final refinement -> inlier
-mask) on correspondences that are already resident in HBM.  A hypothesis = one minimal-solver model scored
+One "step" = S (= --streams, default 4) independent, complete ransac_pnp calls in flight on the GPU (sample ->
+P3P -> score all N -> LO -> final refinement -> inlier mask; one host thread + HIP stream per problem, different
+RANSAC seeds) on correspondences that are already resident in HBM.  A hypothesis = one minimal-solver model scored
 against all N correspondences (ransac_impl.h:112-113).  Multi-GPU: independent image pairs, one per rank
 (weak scaling, no data-path collective); RCCL is used only for the barrier and the final gather.
 
@@ -46,6 +47,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent problems in flight per GPU (one host thread + HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=ITERATIONS)
     args = ap.parse_args()
@@ -72,17 +75,27 @@ def main():
     scene = synth.absolute_pose_scene(N_POINTS, OUTLIER_RATIO, 1001 + rank)
     cam = P.Camera(scene["camera"])
     # the front-end's O(N) pre-processing (robust.cc:40-46) is done once, outside the timed region
-    import ctypes as C
-
-    from poselib_amd import _lib as L
+    from concurrent.futures import ThreadPoolExecutor
 
     thr = MAX_ERROR_PX / FOCAL
-    xn = (scene["p2d"] - np.array(scene["camera"]["params"][1:3])) / FOCAL  # same points the front-end feeds
-    prob = P.Problem(P.KIND_ABS, xn, scene["p3d"])  # SoA in HBM, resident from here on
+    xn = (scene["p2d"] - np.array(scene["camera"]["params"][1:3])) / FOCAL  # normalised image points
+    S = max(1, args.streams)
+    pool = ThreadPoolExecutor(max_workers=S)
 
-    def step(seed):
+    def make_problem(_):
+        P.set_device(local_rank)  # per-thread context: own HIP stream + scratch arena
+        return P.Problem(P.KIND_ABS, xn, scene["p3d"])  # SoA in HBM, resident from here on
+
+    probs = list(pool.map(make_problem, range(S)))
+
+    def run_one(args_):
+        prob, seed = args_
         opt = {"max_error": thr, "ransac": {"max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "seed": seed}}
         return prob.run(opt)
+
+    def step(seed):
+        """One step = S independent ransac_pnp problems in flight on this GPU (different RANSAC seeds)."""
+        return list(pool.map(run_one, [(probs[j], seed * S + j) for j in range(S)]))
 
     def sync():
         torch.cuda.synchronize()
@@ -99,11 +112,11 @@ def main():
     launches = 0
     last = None
     for s in range(args.steps):
-        pose, info = step(s)
-        hyp += info["hypotheses"]
-        kern_ms += info["score_kernel_ms"]
-        launches += info["score_kernel_launches"]
-        last = (pose, info)
+        for pose, info in step(s):
+            hyp += info["hypotheses"]
+            kern_ms += info["score_kernel_ms"]
+            launches += info["score_kernel_launches"]
+            last = (pose, info)
     sync()
     elapsed = time.perf_counter() - t0
 
@@ -142,8 +155,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "p3p_5000", "problem": "P3P LO-RANSAC (ransac_pnp)", "correspondences": N_POINTS,
                        "outlier_ratio": OUTLIER_RATIO, "max_iterations": ITERATIONS, "min_iterations": ITERATIONS,
-                       "max_error_px": MAX_ERROR_PX, "problems_per_gpu_per_step": 1,
-                       "hypotheses_per_step": hyp0 / args.steps, "iterations_per_s": world * args.steps * ITERATIONS / t_max,
+                       "max_error_px": MAX_ERROR_PX, "problems_per_gpu_per_step": S,
+                       "hypotheses_per_step": hyp0 / args.steps,
+                       "iterations_per_s": world * S * args.steps * ITERATIONS / t_max,
                        "inliers_found": int(allrec[0, 4])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_score<EST_ABS,5>",
@@ -168,7 +182,9 @@ def main():
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
-    prob.close()
+    for pr in probs:
+        pr.close()
+    pool.shutdown()
 
 
 if __name__ == "__main__":

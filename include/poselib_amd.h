@@ -156,8 +156,9 @@ int pl_essential_matrix_5pt(const double *x1, const double *x2, double *E /* 10 
 int pl_relpose_7pt(const double *x1 /* 7x3 */, const double *x2 /* 7x3 */, double *F /* 3 x 9 column-major */);
 int pl_homography_4pt(const double *x1 /* 4x3 */, const double *x2 /* 4x3 */, double *H /* 9 column-major */);
 /* batched form: `count` independent minimal problems, one GPU lane each.
- * in: count x (2*K*3) doubles ([first set K x 3][second set K x 3]); out_models: count x max_models x 16 doubles
- * (model records: q[4] t[3] M[9 row-major], see poselib_amd/csrc/pl_math.h); out_counts: count. */
+ * in: count x (2*K*3) doubles ([first set K x 3][second set K x 3]); out_models: count x max_models x 24 doubles
+ * (model records of 24 doubles: q[4] t[3] M[9 row-major] + 8 doubles of internal fp32 shadow, see
+ * poselib_amd/csrc/pl_math.h); out_counts: count. */
 int pl_solve_batch(int kind, const double *in, size_t count, double *out_models, uint32_t *out_counts);
 
 #ifdef __cplusplus

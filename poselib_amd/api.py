@@ -378,10 +378,10 @@ def solve_batch(kind: int, first, second):
     B, K = first.shape[0], first.shape[1]
     maxm = {0: 4, 1: 40, 2: 3, 3: 1}[kind]
     inp = np.ascontiguousarray(np.concatenate([first.reshape(B, -1), second.reshape(B, -1)], axis=1))
-    out = np.zeros((B, maxm, 16))
+    out = np.zeros((B, maxm, 24))  # record pitch: 16 fp64 fields + fp32 shadow used by the scoring pre-filter
     cnt = np.zeros(B, dtype=np.uint32)
     L.check(L.lib().pl_solve_batch(kind, _ptr(inp), C.c_size_t(B), _ptr(out), _ptr(cnt)))
-    return out, cnt
+    return out[:, :, :16].copy(), cnt
 
 
 def device_count() -> int:

@@ -372,6 +372,20 @@ uint64_t sample_positions_k(int K, uint64_t seed, uint64_t pos, uint64_t N, uint
     }
 }
 
+// Parameters of the scoring kernel's conservative fp32 pre-filter (see kernels.hip).  Both values are
+// rounded UP; POSELIB_AMD_NO_PREFILTER=1 disables the filter (exact evaluation of every point).
+void set_prefilter(ScoreArgs &sa, const pl_problem *p, double thr2) {
+    static const bool disabled = std::getenv("POSELIB_AMD_NO_PREFILTER") != nullptr;
+    sa.pf_thr = 0.f;
+    sa.pf_gx = 0.f;
+    if (disabled || p->kind != EST_ABS || !(thr2 > 0) || !std::isfinite(thr2) || !std::isfinite(p->ps.xy_absmax))
+        return;
+    const double thr = std::sqrt(thr2);
+    const double u = 5.9604644775390625e-08; // 2^-24
+    sa.pf_thr = std::nextafter((float)thr, std::numeric_limits<float>::infinity());
+    sa.pf_gx = std::nextafter((float)(32.0 * u * (1.0 + p->ps.xy_absmax + thr)), std::numeric_limits<float>::infinity());
+}
+
 // Score `nrec` model records that already sit in device memory at `d_records`.  Results land in the
 // pinned h_count / h_score buffers after the caller synchronises.
 int enqueue_score_records(Context *c, const pl_problem *p, const double *d_records, uint32_t nrec, double thr2,
@@ -392,6 +406,7 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     sa.num_hyp = c->num_hyp.as<uint32_t>();
     sa.hyp_capacity = nrec;
     sa.thr2 = thr2;
+    set_prefilter(sa, p, thr2);
     sa.part_count = c->part_count.as<uint32_t>();
     sa.part_score = c->part_score.as<double>();
     (void)time_it;
@@ -659,6 +674,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             sa.num_hyp = &d_ctl->num_hyp;
             sa.hyp_capacity = (uint32_t)hcap;
             sa.thr2 = thr2;
+            set_prefilter(sa, p, thr2);
             sa.part_count = c->part_count.as<uint32_t>();
             sa.part_score = c->part_score.as<double>();
             const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, (uint32_t)hcap));
@@ -906,9 +922,13 @@ int make_problem(Context *c, int kind, const double *a, const double *b, size_t 
     if (n == 0)
         return PL_OK;
     std::vector<double> soa((size_t)nd * n);
+    double amax = 0;
     for (size_t i = 0; i < n; ++i) {
-        for (int d = 0; d < da; ++d)
+        for (int d = 0; d < da; ++d) {
             soa[(size_t)d * n + i] = a[da * i + d];
+            const double v = std::fabs(a[da * i + d]);
+            amax = (v > amax || v != v) ? v : amax; // NaN propagates and disables the pre-filter
+        }
         for (int d = 0; d < db; ++d)
             soa[(size_t)(da + d) * n + i] = b[db * i + d];
     }
@@ -917,6 +937,7 @@ int make_problem(Context *c, int kind, const double *a, const double *b, size_t 
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int d = 0; d < nd; ++d)
         p->ps.a[d] = p->d_pts + (size_t)d * n;
+    p->ps.xy_absmax = std::nextafter((float)amax, std::numeric_limits<float>::infinity());
     return PL_OK;
 }
 void free_problem(pl_problem *p) {

@@ -194,11 +194,23 @@ __device__ __forceinline__ bool eval_point(const double *M, const double *pt, do
 
 constexpr int kScoreGroup = 32; // hypotheses between two workgroup barriers
 
-template <int EST, int P>
+// Conservative fp32 pre-filter for the reprojection score.  It may only say "certainly NOT an inlier";
+// every point it cannot exclude is evaluated with the exact fp64 expression, so counts, inlier sets and
+// scores are unchanged.  Proof sketch (u = 2^-24):  z_i = r_i.X + t_i with |r_i| = 1, so every fp32
+// z^_i (inputs rounded to fp32, three FMAs) satisfies |z^_i - z_i| <= 8u S,  S = |X|_2 + max|t_i|.
+// An inlier has z2 > 0 and |z0 - x z2| < thr z2 (and the same in y).  With a = fl(z^0 - x^ z^2),
+// tz = fl(thr^ z^2) the accumulated error of  |a| - tz  is below  W = 32u (1 + xmax + thr) S,  hence
+// |a| - tz > W  (or z^2 < -W)  proves the point is an outlier.  Gx = 32u(1+xmax+thr) is passed rounded up.
+struct PrefilterArgs {
+    float thr;  // sqrt(thr2), rounded up
+    float gx;   // 32u (1 + max|x|,|y| + thr), rounded up; 0 disables the pre-filter
+};
+
+template <int EST, int P, bool PF>
 __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const double *__restrict__ models,
                                                          const uint32_t *__restrict__ slots,
                                                          const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
-                                                         double thr2, uint32_t *__restrict__ part_count,
+                                                         double thr2, PrefilterArgs pf, uint32_t *__restrict__ part_count,
                                                          double *__restrict__ part_score) {
     constexpr int ND = point_doubles(EST);
     __shared__ double s_score[kScoreGroup][kScoreThreads / 64];
@@ -211,6 +223,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
     // ---- stationary operand: this lane's P correspondences, coalesced loads, kept in VGPRs ----
     double pt[P][ND];
     bool valid[P];
+    float pfx[PF ? P : 1][6]; // fp32 shadow of the points: x, y, X, Y, Z, upper bound of |X|_2
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
@@ -219,6 +232,13 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
 #pragma unroll
         for (int d = 0; d < ND; ++d)
             pt[p][d] = pts.a[d][ic];
+        if constexpr (PF) {
+#pragma unroll
+            for (int d = 0; d < 5; ++d)
+                pfx[p][d] = (float)pt[p][d];
+            const double n = sqrt(pt[p][2] * pt[p][2] + pt[p][3] * pt[p][3] + pt[p][4] * pt[p][4]);
+            pfx[p][5] = (float)n * 1.000001f + 1e-30f;
+        }
     }
 
     const uint32_t H = *num_hyp_ptr;
@@ -233,19 +253,46 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
             const uint32_t k = kb + g;
             const uint32_t slot = __builtin_amdgcn_readfirstlane(slots ? slots[k] : k);
             const double *Mg = models + (size_t)slot * kModelStride;
-            double M[kModelStride];
+            double M[kModelDoubles];
 #pragma unroll
-            for (int i = 0; i < kModelStride; ++i)
+            for (int i = 0; i < kModelDoubles; ++i)
                 M[i] = Mg[i];
 
             uint32_t cnt = 0;
             double sc = 0.0;
+            if constexpr (PF) {
+                const float *Mf = reinterpret_cast<const float *>(Mg + kShadowOff);
+                float rf[13];
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                double r2;
-                const bool in = eval_point<EST>(M, pt[p], thr2, r2) && valid[p];
-                cnt += __popcll(__ballot(in));
-                sc += in ? r2 : 0.0;
+                for (int i = 0; i < 13; ++i)
+                    rf[i] = Mf[i];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const float X = pfx[p][2], Y = pfx[p][3], Z = pfx[p][4];
+                    const float z0 = fmaf(rf[0], X, fmaf(rf[1], Y, fmaf(rf[2], Z, rf[9])));
+                    const float z1 = fmaf(rf[3], X, fmaf(rf[4], Y, fmaf(rf[5], Z, rf[10])));
+                    const float z2 = fmaf(rf[6], X, fmaf(rf[7], Y, fmaf(rf[8], Z, rf[11])));
+                    const float a0 = fmaf(-pfx[p][0], z2, z0);
+                    const float a1 = fmaf(-pfx[p][1], z2, z1);
+                    const float tz = pf.thr * z2;
+                    const float W = pf.gx * (pfx[p][5] + rf[12]);
+                    const bool out = (fabsf(a0) - tz > W) | (fabsf(a1) - tz > W) | (z2 < -W);
+                    const bool cand = !out && valid[p];
+                    if (__ballot(cand)) { // wave-uniform: exact evaluation only where some lane needs it
+                        double r2;
+                        const bool in = eval_point<EST>(M, pt[p], thr2, r2) && cand;
+                        cnt += __popcll(__ballot(in));
+                        sc += in ? r2 : 0.0;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double r2;
+                    const bool in = eval_point<EST>(M, pt[p], thr2, r2) && valid[p];
+                    cnt += __popcll(__ballot(in));
+                    sc += in ? r2 : 0.0;
+                }
             }
             sc = wave_sum(sc);
             if (lane == 0) {
@@ -290,8 +337,8 @@ template <int EST> __global__ __launch_bounds__(256) void k_mask(PointSet pts, c
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pts.n)
         return;
-    double M[kModelStride];
-    for (int k = 0; k < kModelStride; ++k)
+    double M[kModelDoubles];
+    for (int k = 0; k < kModelDoubles; ++k)
         M[k] = model[k];
     bool in;
     if constexpr (EST == EST_ABS) {
@@ -580,10 +627,20 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     int P;
     score_shape(a.pts.n, chunks, P);
     const dim3 grid(slices, chunks), block(kScoreThreads);
+    PrefilterArgs pf;
+    pf.thr = a.pf_thr;
+    pf.gx = a.pf_gx;
+    constexpr bool kCanPrefilter = (E == EST_ABS);
+    const bool use_pf = kCanPrefilter && a.pf_gx > 0.f;
 #define PL_SCORE_CASE(PP)                                                                                              \
     case PP:                                                                                                           \
-        k_score<E, PP><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,        \
-                                                   a.part_count, a.part_score);                                        \
+        if (use_pf)                                                                                                    \
+            k_score<E, PP, kCanPrefilter><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp,             \
+                                                                      a.hyp_capacity, a.thr2, pf, a.part_count,       \
+                                                                      a.part_score);                                   \
+        else                                                                                                           \
+            k_score<E, PP, false><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp, a.hyp_capacity,     \
+                                                              a.thr2, pf, a.part_count, a.part_score);                 \
         break;
     switch (P) {
         PL_SCORE_CASE(1)

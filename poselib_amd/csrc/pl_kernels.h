@@ -14,6 +14,7 @@ namespace pl {
 struct PointSet {
     const double *a[5];
     uint32_t n;
+    float xy_absmax; // max(|x|, |y|) over the 2-D points (bound used by the scoring pre-filter)
 };
 
 constexpr int kScoreThreads = 256; // 4 wavefronts per workgroup
@@ -41,6 +42,8 @@ struct ScoreArgs {
     const uint32_t *num_hyp;   // device scalar
     uint32_t hyp_capacity;     // row pitch of the partial arrays
     double thr2;
+    float pf_thr, pf_gx;       // conservative fp32 pre-filter (absolute pose): sqrt(thr2) rounded up, error gain
+                               // 32u(1 + max|x|,|y| + thr) rounded up; pf_gx == 0 disables it
     uint32_t *part_count;      // [chunks][hyp_capacity]
     double *part_score;        // [chunks][hyp_capacity]
 };

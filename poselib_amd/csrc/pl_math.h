@@ -18,11 +18,17 @@
 
 namespace pl {
 
-// Layout of one hypothesis ("model record") in HBM: 16 doubles = 128 B, so that a wavefront
-// can pull a model into SGPRs with two scalar loads.
-//   [0..3]  q (w,x,y,z)        [4..6] t        [7..15] 3x3 matrix, row-major:
-//   R(q) for absolute pose, E = [t]x R(q) for relative pose, H or F for the projective models.
-constexpr int kModelStride = 16;
+// Layout of one hypothesis ("model record") in HBM: 24 doubles = 192 B, pulled into SGPRs by
+// wave-uniform scalar loads.
+//   fp64 part (kModelDoubles = 16):
+//     [0..3]  q (w,x,y,z)        [4..6] t        [7..15] 3x3 matrix, row-major:
+//     R(q) for absolute pose, E = [t]x R(q) for relative pose, H or F for the projective models.
+//   fp32 shadow (doubles 16..23 viewed as 16 floats), used ONLY by the conservative pre-filter of the
+//   scoring kernel (never by a result): f[0..8] = (float)matrix, f[9..11] = (float)t,
+//   f[12] = upper bound of max|t_i|.
+constexpr int kModelStride = 24;
+constexpr int kModelDoubles = 16;
+constexpr int kShadowOff = 16;
 constexpr int kMatOff = 7;
 
 struct Vec3 {
@@ -224,6 +230,21 @@ PL_HD bool check_cheirality(Quat q, Vec3 t, Vec3 x1, Vec3 x2, double min_depth) 
     return l1 > min_depth && l2 > min_depth;
 }
 
+// fp32 shadow of the record's matrix / translation (see the layout comment above).
+PL_HD void store_shadow(double *rec) {
+    float *f = reinterpret_cast<float *>(rec + kShadowOff);
+    for (int i = 0; i < 9; ++i)
+        f[i] = (float)rec[kMatOff + i];
+    float tmax = 0.f;
+    for (int i = 0; i < 3; ++i) {
+        f[9 + i] = (float)rec[4 + i];
+        const float a = (float)fabs(rec[4 + i]);
+        tmax = a > tmax ? a : tmax;
+    }
+    f[12] = tmax * 1.000001f + 1e-30f; // rounded-to-nearest conversions, padded upwards
+    f[13] = f[14] = f[15] = 0.f;
+}
+
 // Write a pose hypothesis (rotation given as matrix from a solver) into a 16-double record:
 // R -> q (normalised) -> R(q), exactly the round trip CameraPose(R,t) + pose.R() makes in the
 // reference (camera_pose.h:51, utils.cc:40).  `essential` selects E=[t]xR(q) for the matrix slot.
@@ -235,6 +256,7 @@ PL_HD void store_pose_model(double *rec, const Mat3 &Rsolver, Vec3 t, bool essen
     const Mat3 M = essential ? essential_from_motion(Rq, t) : Rq;
     for (int i = 0; i < 9; ++i)
         rec[kMatOff + i] = M.m[i];
+    store_shadow(rec);
 }
 PL_HD void store_pose_model_q(double *rec, Quat q, Vec3 t, bool essential) {
     const Mat3 Rq = quat_to_rotmat(q);
@@ -243,12 +265,14 @@ PL_HD void store_pose_model_q(double *rec, Quat q, Vec3 t, bool essential) {
     const Mat3 M = essential ? essential_from_motion(Rq, t) : Rq;
     for (int i = 0; i < 9; ++i)
         rec[kMatOff + i] = M.m[i];
+    store_shadow(rec);
 }
 PL_HD void store_matrix_model(double *rec, const Mat3 &M) {
     for (int i = 0; i < 7; ++i)
         rec[i] = 0.0;
     for (int i = 0; i < 9; ++i)
         rec[kMatOff + i] = M.m[i];
+    store_shadow(rec);
 }
 
 } // namespace pl

@@ -12,7 +12,7 @@ import numpy as np
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostmath")
 _LIB = os.path.join(_DIR, "libhostmath.so")
 EST = {"abs": 0, "rel": 1, "fund": 2, "hom": 3}
-STRIDE = 16
+STRIDE = 24
 MAT = 7
 
 
@@ -109,7 +109,7 @@ def pose_record(q, t, essential=False):
 
 def matrix_record(M):
     rec = np.zeros(STRIDE)
-    rec[MAT:] = np.asarray(M, float).reshape(9)
+    rec[MAT:MAT + 9] = np.asarray(M, float).reshape(9)
     return rec
 
 

@@ -166,6 +166,35 @@ def test_score_and_refine_match_oracle(gpu):
     prob.close()
 
 
+def test_prefilter_never_drops_an_inlier(gpu):
+    """The scoring kernel's conservative fp32 pre-filter may only skip points that are certainly outliers:
+    inlier counts must equal the oracle's for good, bad and borderline models, also when the world frame is
+    far from the origin (fp32 cancellation => the error bound must widen, not the result change)."""
+    d = synth.absolute_pose_scene(5000, 0.7, 1001)
+    un = O.unproject(d["camera"], d["p2d"])
+    R = rot(d["q_gt"])
+    rs = np.random.RandomState(5)
+    idx, _ = O.sampler_draw(3, 5000, 3, 150)
+    idx = idx.astype(np.int64)
+    rec, cnt = gpu.solve_batch(gpu.KIND_ABS, np.stack([bear(un[s]) for s in idx]), np.stack([d["p3d"][s] for s in idx]))
+    models = [rec[i, m, :7] for i in range(len(idx)) for m in range(cnt[i]) if np.isfinite(rec[i, m, :7]).all()]
+    for k in range(60):  # from perfect to useless
+        q = d["q_gt"] + 0.002 * k * rs.randn(4)
+        q /= np.linalg.norm(q)
+        models.append(np.r_[q, d["t_gt"] + 0.002 * k * rs.randn(3)])
+    for shift, thr in [(0.0, 0.012), (0.0, 0.001), (0.0, 0.2), (1e5, 0.012), (1e7, 0.012)]:
+        off = np.array([shift, -shift, 0.5 * shift])
+        X = d["p3d"] + off  # same scene expressed in a shifted world frame
+        prob = gpu.Problem(gpu.KIND_ABS, un, X)
+        for mdl in models:
+            t = mdl[4:] - rot(mdl[:4]) @ off
+            sc, c = prob.score(gpu.CameraPose(mdl[:4], t), thr)
+            osc, oc = O.score("reproj", np.r_[mdl[:4], t], un, X, thr * thr)
+            assert c == oc, (shift, thr, c, oc)
+            assert abs(sc - osc) <= 1e-9 * abs(osc)
+        prob.close()
+
+
 # ------------------------------------------------------------------------------------------ end to end
 ABS_CASES = [(200, 0.5, 1000, 0), (200, 0.5, 1000, 7), (5000, 0.7, 1001, 0), (5000, 0.7, 1001, 3), (1500, 0.3, 77, 1)]
 

@@ -77,7 +77,7 @@ def test_two_view_solvers_and_scores():
         recs = HM.solve("fund", bear(a[s]), bear(b[s]))
         assert len(Fs) == len(recs)
         for F, r in zip(Fs, recs):
-            assert (r[7:].reshape(3, 3) == F).all()
+            assert (r[7:16].reshape(3, 3) == F).all()
             if it < 40:
                 sc, cnt, _, _ = HM.score("fund", r, cols, thr2)
                 osc, ocnt = O.score("sampson_F", F, a, b, thr2)
@@ -90,7 +90,7 @@ def test_two_view_solvers_and_scores():
         recs = HM.solve("hom", bear(a[s]), bear(b[s]))
         assert n == len(recs)
         if n:
-            assert (recs[0][7:].reshape(3, 3) == H).all()
+            assert (recs[0][7:16].reshape(3, 3) == H).all()
             sc, cnt, _, _ = HM.score("hom", recs[0], cols, thr2)
             osc, ocnt = O.score("homography", H, a, b, thr2)
             assert cnt == ocnt and abs(sc - osc) <= 1e-12 * abs(osc)
