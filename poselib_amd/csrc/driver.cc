@@ -93,6 +93,7 @@ struct Context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // batch scratch
     DevBuf positions, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf shadow, compact64;
     DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
     HostBuf h_rec_meta;
@@ -390,7 +391,9 @@ void set_prefilter(ScoreArgs &sa, const pl_problem *p, double thr2) {
 // pinned h_count / h_score buffers after the caller synchronises.
 int enqueue_score_records(Context *c, const pl_problem *p, const double *d_records, uint32_t nrec, double thr2,
                           bool time_it) {
-    const uint32_t chunks = score_chunks(p->kind, p->n);
+    ScoreArgs sa;
+    set_prefilter(sa, p, thr2);
+    const uint32_t chunks = score_chunks(p->kind, p->n, sa.pf_gx > 0.f);
     HIP_TRY(c->num_hyp.ensure(sizeof(uint32_t)));
     HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * nrec));
     HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * nrec));
@@ -399,14 +402,14 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * nrec));
     HIP_TRY(c->h_score.ensure(sizeof(double) * nrec));
     HIP_TRY(hipMemcpyAsync(c->num_hyp.p, &nrec, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    ScoreArgs sa;
     sa.pts = p->ps;
     sa.models = d_records;
     sa.slots = nullptr;
+    sa.shadow = nullptr;
+    sa.compact64 = nullptr;
     sa.num_hyp = c->num_hyp.as<uint32_t>();
     sa.hyp_capacity = nrec;
     sa.thr2 = thr2;
-    set_prefilter(sa, p, thr2);
     sa.part_count = c->part_count.as<uint32_t>();
     sa.part_score = c->part_score.as<double>();
     (void)time_it;
@@ -607,7 +610,14 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
 
             // ---- device: positions -> generate -> compact -> score -> finalize -> records ----
             const size_t hcap = (size_t)B * MAXM;
-            const uint32_t chunks = score_chunks(kind, N);
+            ScoreArgs sa;
+            set_prefilter(sa, p, thr2);
+            const bool prefilter = sa.pf_gx > 0.f;
+            const uint32_t chunks = score_chunks(kind, N, prefilter);
+            if (prefilter) {
+                HIP_TRY(c->shadow.ensure(sizeof(float) * 16 * hcap));
+                HIP_TRY(c->compact64.ensure(sizeof(double) * kModelDoubles * hcap));
+            }
             HIP_TRY(c->positions.ensure(sizeof(uint32_t) * B));
             HIP_TRY(c->models.ensure(sizeof(double) * kModelStride * hcap));
             HIP_TRY(c->num_models.ensure(sizeof(uint32_t) * B));
@@ -666,15 +676,16 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             ga.real_focal_check = o->real_focal_check;
             HIP_TRY(launch_generate(kind, ga, c->stream));
             HIP_TRY(launch_compact2(ga.num_models, B, MAXM, c->blk_tot.as<uint32_t>(), c->slots.as<uint32_t>(),
-                                    c->offsets.as<uint32_t>(), d_ctl, c->stream));
-            ScoreArgs sa;
+                                    c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,
+                                    prefilter ? c->compact64.as<double>() : nullptr, d_ctl, c->stream));
             sa.pts = p->ps;
             sa.models = ga.models;
             sa.slots = c->slots.as<uint32_t>();
+            sa.shadow = prefilter ? c->shadow.as<float>() : nullptr;
+            sa.compact64 = prefilter ? c->compact64.as<double>() : nullptr;
             sa.num_hyp = &d_ctl->num_hyp;
             sa.hyp_capacity = (uint32_t)hcap;
             sa.thr2 = thr2;
-            set_prefilter(sa, p, thr2);
             sa.part_count = c->part_count.as<uint32_t>();
             sa.part_score = c->part_score.as<double>();
             const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, (uint32_t)hcap));

@@ -29,6 +29,17 @@
 
 namespace pl {
 
+// Wave-uniform data produced by an EARLIER kernel (model records, hypothesis lists) is read through the
+// constant address space so that the compiler emits scalar loads (s_load_*, SGPR destination, scalar cache)
+// instead of 64 identical vector loads — the kernels also store to global memory, which otherwise makes
+// LLVM fall back to vector loads.
+typedef const float __attribute__((address_space(4))) *uniform_f32_ptr;
+typedef const double __attribute__((address_space(4))) *uniform_f64_ptr;
+typedef const uint32_t __attribute__((address_space(4))) *uniform_u32_ptr;
+__device__ __forceinline__ uniform_f32_ptr as_uniform(const float *p) { return (uniform_f32_ptr)(uintptr_t)p; }
+__device__ __forceinline__ uniform_f64_ptr as_uniform(const double *p) { return (uniform_f64_ptr)(uintptr_t)p; }
+__device__ __forceinline__ uniform_u32_ptr as_uniform(const uint32_t *p) { return (uniform_u32_ptr)(uintptr_t)p; }
+
 // ------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
         }
     }
 
-    const uint32_t H = *num_hyp_ptr;
+    const uint32_t H = *as_uniform(num_hyp_ptr);
     const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
     const uint32_t k0 = blockIdx.x * per;
     const uint32_t k1 = min(H, k0 + per);
@@ -251,8 +262,8 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
         for (uint32_t g = 0; g < gn; ++g) {
             // ---- streaming operand: one hypothesis, wave-uniform (scalar loads -> SGPRs) ----
             const uint32_t k = kb + g;
-            const uint32_t slot = __builtin_amdgcn_readfirstlane(slots ? slots[k] : k);
-            const double *Mg = models + (size_t)slot * kModelStride;
+            const uint32_t slot = slots ? as_uniform(slots)[k] : k;
+            uniform_f64_ptr Mg = as_uniform(models) + (size_t)slot * kModelStride;
             double M[kModelDoubles];
 #pragma unroll
             for (int i = 0; i < kModelDoubles; ++i)
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
             uint32_t cnt = 0;
             double sc = 0.0;
             if constexpr (PF) {
-                const float *Mf = reinterpret_cast<const float *>(Mg + kShadowOff);
+                uniform_f32_ptr Mf = (uniform_f32_ptr)(Mg + kShadowOff);
                 float rf[13];
 #pragma unroll
                 for (int i = 0; i < 13; ++i)
@@ -295,6 +306,141 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
                 }
             }
             sc = wave_sum(sc);
+            if (lane == 0) {
+                s_score[g][wave] = sc;
+                s_count[g][wave] = cnt;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < gn) {
+            double sc = 0.0;
+            uint32_t c = 0;
+#pragma unroll
+            for (int w = 0; w < kScoreThreads / 64; ++w) {
+                sc += s_score[threadIdx.x][w];
+                c += s_count[threadIdx.x][w];
+            }
+            const size_t o = (size_t)chunk * hyp_capacity + kb + threadIdx.x;
+            part_score[o] = sc;
+            part_count[o] = c;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- absolute pose, pre-filtered form -----------------------------------------------------------------
+// Same results as k_score<EST_ABS>, different schedule.  Stationary operand: each lane's P correspondences in
+// fp64 (exact path) AND their fp32 shadow (filter).  Streaming operand: compact, hypothesis-ordered arrays of the
+// 64-byte fp32 model shadow (next hypothesis prefetched) and the 128-byte fp64 model (loaded at the top of the
+// hypothesis, first used after pass A) — contiguous scalar loads, no slot indirection on the critical path.
+// Pass A runs the conservative filter on all P points (branch-free fp32 FMA chains, P-way ILP).  Pass B — only
+// for the point slots where some lane survived — evaluates the exact reference expression from the fp64
+// registers.  The butterfly reduction is skipped when the wavefront found no inlier.
+template <int P>
+__global__ __launch_bounds__(kScoreThreads) void k_score_abs_pf(PointSet pts, const double *__restrict__ models,
+                                                                const float *__restrict__ shadow,
+                                                                const double *__restrict__ compact64,
+                                                                const uint32_t *__restrict__ slots,
+                                                                const uint32_t *__restrict__ num_hyp_ptr,
+                                                                uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+                                                                uint32_t *__restrict__ part_count,
+                                                                double *__restrict__ part_score) {
+    __shared__ double s_score[kScoreGroup][kScoreThreads / 64];
+    __shared__ uint32_t s_count[kScoreGroup][kScoreThreads / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t chunk = blockIdx.y;
+
+    double pt[P][5];
+    float px[P][6]; // x, y, X, Y, Z, upper bound of |X|_2  (-inf for padding slots: never a candidate)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
+        const bool valid = i < pts.n;
+        const uint32_t ic = valid ? i : 0u;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            pt[p][d] = pts.a[d][ic];
+            px[p][d] = (float)pt[p][d];
+        }
+        const float nx = (float)sqrt(pt[p][2] * pt[p][2] + pt[p][3] * pt[p][3] + pt[p][4] * pt[p][4]) * 1.000001f + 1e-30f;
+        px[p][5] = valid ? nx : -__builtin_huge_valf();
+    }
+
+    const uint32_t H = *as_uniform(num_hyp_ptr);
+    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
+    const uint32_t k0 = blockIdx.x * per;
+    const uint32_t k1 = min(H, k0 + per);
+
+    auto record_ptr = [&](uint32_t k) -> uniform_f64_ptr {
+        const uint32_t slot = slots ? as_uniform(slots)[k] : k;
+        return as_uniform(models) + (size_t)slot * kModelStride;
+    };
+    auto shadow_ptr = [&](uint32_t k) -> uniform_f32_ptr {
+        return shadow ? as_uniform(shadow) + (size_t)k * 16 : (uniform_f32_ptr)(record_ptr(k) + kShadowOff);
+    };
+
+    float rn[13];
+    if (k0 < k1) {
+        uniform_f32_ptr sp = shadow_ptr(k0);
+#pragma unroll
+        for (int i = 0; i < 13; ++i)
+            rn[i] = sp[i];
+    }
+    for (uint32_t kb = k0; kb < k1; kb += kScoreGroup) {
+        const uint32_t gn = min((uint32_t)kScoreGroup, k1 - kb);
+        for (uint32_t g = 0; g < gn; ++g) {
+            const uint32_t k = kb + g;
+            float rf[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i)
+                rf[i] = rn[i];
+            // fp64 model: issued now, consumed (if at all) after pass A
+            uniform_f64_ptr Mg = compact64 ? as_uniform(compact64) + (size_t)k * kModelDoubles : record_ptr(k);
+            double M[kModelDoubles];
+#pragma unroll
+            for (int i = 0; i < kModelDoubles; ++i)
+                M[i] = Mg[i];
+            if (k + 1 < k1) { // prefetch the next hypothesis' shadow while this one is evaluated
+                uniform_f32_ptr sp = shadow_ptr(k + 1);
+#pragma unroll
+                for (int i = 0; i < 13; ++i)
+                    rn[i] = sp[i];
+            }
+            // ---- pass A: conservative fp32 filter ----
+            uint32_t candbits = 0; // per lane
+            uint32_t need = 0;     // wave-uniform
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float X = px[p][2], Y = px[p][3], Z = px[p][4];
+                const float z0 = fmaf(rf[0], X, fmaf(rf[1], Y, fmaf(rf[2], Z, rf[9])));
+                const float z1 = fmaf(rf[3], X, fmaf(rf[4], Y, fmaf(rf[5], Z, rf[10])));
+                const float z2 = fmaf(rf[6], X, fmaf(rf[7], Y, fmaf(rf[8], Z, rf[11])));
+                const float a0 = fmaf(-px[p][0], z2, z0);
+                const float a1 = fmaf(-px[p][1], z2, z1);
+                const float tz = pf.thr * z2;
+                const float W = pf.gx * (px[p][5] + rf[12]);
+                const bool out = (fabsf(a0) - tz > W) | (fabsf(a1) - tz > W) | (z2 < -W);
+                const bool cand = !out;
+                candbits |= cand ? (1u << p) : 0u;
+                need |= __ballot(cand) ? (1u << p) : 0u;
+            }
+            // ---- pass B: exact fp64 evaluation where required ----
+            uint32_t cnt = 0;
+            double sc = 0.0;
+            if (need) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (need & (1u << p)) {
+                        double r2;
+                        const bool in = eval_point<EST_ABS>(M, pt[p], thr2, r2) && ((candbits >> p) & 1u);
+                        cnt += __popcll(__ballot(in));
+                        sc += in ? r2 : 0.0;
+                    }
+                }
+                if (cnt)
+                    sc = wave_sum(sc);
+            }
             if (lane == 0) {
                 s_score[g][wave] = sc;
                 s_count[g][wave] = cnt;
@@ -604,9 +750,10 @@ hipError_t launch_compact(const uint32_t *num_models, uint32_t num_iters, int ma
     return hipGetLastError();
 }
 
-constexpr int kMaxPointsPerLane = 5;
-static void score_shape(uint32_t n, uint32_t &chunks, int &P) {
-    const uint32_t per_chunk_max = kScoreThreads * kMaxPointsPerLane;
+constexpr int kMaxPointsPerLane = 5;    // exact kernels: fp64 points in VGPRs
+constexpr int kMaxPointsPerLanePF = 5;  // pre-filtered absolute-pose kernel: fp64 points + fp32 shadows in VGPRs
+static void score_shape(uint32_t n, bool pf, uint32_t &chunks, int &P) {
+    const uint32_t per_chunk_max = kScoreThreads * (pf ? kMaxPointsPerLanePF : kMaxPointsPerLane);
     chunks = (n + per_chunk_max - 1) / per_chunk_max;
     if (chunks == 0)
         chunks = 1;
@@ -614,10 +761,10 @@ static void score_shape(uint32_t n, uint32_t &chunks, int &P) {
     if (P < 1)
         P = 1;
 }
-uint32_t score_chunks(int, uint32_t n) {
+uint32_t score_chunks(int est, uint32_t n, bool prefilter) {
     uint32_t c;
     int P;
-    score_shape(n, c, P);
+    score_shape(n, prefilter && est == EST_ABS, c, P);
     return c;
 }
 
@@ -625,22 +772,34 @@ template <int E>
 static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStream_t stream) {
     uint32_t chunks;
     int P;
-    score_shape(a.pts.n, chunks, P);
-    const dim3 grid(slices, chunks), block(kScoreThreads);
     PrefilterArgs pf;
     pf.thr = a.pf_thr;
     pf.gx = a.pf_gx;
-    constexpr bool kCanPrefilter = (E == EST_ABS);
-    const bool use_pf = kCanPrefilter && a.pf_gx > 0.f;
+    const bool use_pf = (E == EST_ABS) && a.pf_gx > 0.f;
+    score_shape(a.pts.n, use_pf, chunks, P);
+    const dim3 grid(slices, chunks), block(kScoreThreads);
+    if (use_pf) {
+#define PL_PF_CASE(PP)                                                                                                 \
+    case PP:                                                                                                           \
+        k_score_abs_pf<PP><<<grid, block, 0, stream>>>(a.pts, a.models, a.shadow, a.compact64, a.slots, a.num_hyp,     \
+                                                       a.hyp_capacity, a.thr2, pf, a.part_count, a.part_score);        \
+        break;
+        switch (P) {
+            PL_PF_CASE(1)
+            PL_PF_CASE(2)
+            PL_PF_CASE(3)
+            PL_PF_CASE(4)
+            PL_PF_CASE(5)
+        default:
+            return hipErrorInvalidValue;
+        }
+#undef PL_PF_CASE
+        return hipGetLastError();
+    }
 #define PL_SCORE_CASE(PP)                                                                                              \
     case PP:                                                                                                           \
-        if (use_pf)                                                                                                    \
-            k_score<E, PP, kCanPrefilter><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp,             \
-                                                                      a.hyp_capacity, a.thr2, pf, a.part_count,       \
-                                                                      a.part_score);                                   \
-        else                                                                                                           \
-            k_score<E, PP, false><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp, a.hyp_capacity,     \
-                                                              a.thr2, pf, a.part_count, a.part_score);                 \
+        k_score<E, PP, false><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2, \
+                                                          pf, a.part_count, a.part_score);                             \
         break;
     switch (P) {
         PL_SCORE_CASE(1)

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(1024) void k_count_blocks(const uint32_t *num_model
 
 __global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, uint32_t B, int maxm,
                                                    const uint32_t *blk_tot, uint32_t *slots, uint32_t *offsets,
+                                                   const double *models, float *shadow_compact, double *compact64,
                                                    BatchCtl *ctl) {
     __shared__ uint32_t wt[16], wo[16];
     __shared__ uint32_t s_base;
@@ -218,8 +219,19 @@ __global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, u
     if (i < B) {
         const uint32_t o = s_base + wo[wave] + inc - nm;
         offsets[i] = o;
-        for (uint32_t m = 0; m < nm; ++m)
-            slots[o + m] = i * (uint32_t)maxm + m;
+        for (uint32_t m = 0; m < nm; ++m) {
+            const uint32_t slot = i * (uint32_t)maxm + m;
+            slots[o + m] = slot;
+            if (shadow_compact) { // fp32 model shadows in hypothesis order (streamed by the pre-filtered scorer)
+                const float4 *src = reinterpret_cast<const float4 *>(models + (size_t)slot * kModelStride + kShadowOff);
+                float4 *dst = reinterpret_cast<float4 *>(shadow_compact + (size_t)(o + m) * 16);
+                dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+                const double2 *s64 = reinterpret_cast<const double2 *>(models + (size_t)slot * kModelStride);
+                double2 *d64 = reinterpret_cast<double2 *>(compact64 + (size_t)(o + m) * kModelDoubles);
+                for (int j = 0; j < kModelDoubles / 2; ++j)
+                    d64[j] = s64[j];
+            }
+        }
     }
 }
 
@@ -368,10 +380,12 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
 }
 
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, uint32_t *slots,
-                           uint32_t *offsets, BatchCtl *ctl, hipStream_t stream) {
+                           uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,
+                           BatchCtl *ctl, hipStream_t stream) {
     const uint32_t nb = (B + 1023) / 1024;
     k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
-    k_compact2<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, maxm, blk_tot, slots, offsets, ctl);
+    k_compact2<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, maxm, blk_tot, slots, offsets, models, shadow_compact,
+                                                    compact64, ctl);
     return hipGetLastError();
 }
 

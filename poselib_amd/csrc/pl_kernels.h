@@ -39,6 +39,8 @@ struct ScoreArgs {
     PointSet pts;
     const double *models;
     const uint32_t *slots;     // hypothesis k -> model record index (nullptr: identity)
+    const float *shadow;       // optional compact [num_hyp][16] fp32 model shadows in hypothesis order (pre-filter)
+    const double *compact64;   // optional compact [num_hyp][16] fp64 model fields in hypothesis order (pre-filter)
     const uint32_t *num_hyp;   // device scalar
     uint32_t hyp_capacity;     // row pitch of the partial arrays
     double thr2;
@@ -88,7 +90,7 @@ struct RecordMeta {
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream);
 // chunks = ceil(n / (kScoreThreads * P)); P is chosen inside from n (returned through *chunks_out)
-uint32_t score_chunks(int est, uint32_t n_points);
+uint32_t score_chunks(int est, uint32_t n_points, bool prefilter);
 hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &a, uint32_t max_hyp, hipStream_t stream);
 // num_models[iters] -> slots (compact list of record indices in (iteration, model) order) + count
@@ -103,7 +105,8 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
                                    uint8_t *delta, uint32_t *flags, uint32_t flags_cap, uint32_t *positions,
                                    BatchCtl *ctl, hipStream_t stream);
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, uint32_t *slots,
-                           uint32_t *offsets, BatchCtl *ctl, hipStream_t stream);
+                           uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,
+                           BatchCtl *ctl, hipStream_t stream);
 hipError_t launch_finalize_records(const FinalizeArgs &f, const uint32_t *slots, const double *models,
                                    uint32_t *blk_max, double *blk_min, uint32_t init_max, double init_min,
                                    RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap, BatchCtl *ctl,
