@@ -33,13 +33,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-N_POINTS = 5000
-OUTLIER_RATIO = 0.7
 ITERATIONS = 100000
-MAX_ERROR_PX = 12.0
 FOCAL = 1000.0
-BYTES_PER_CORR = 40  # x, y, X, Y, Z in fp64
 HBM_PEAK_GBS = 8000.0
+# workload -> (problem kind, N, outlier ratio, max_error [px], data seed, bytes per correspondence, description)
+WORKLOADS = {
+    "p3p_5000": (0, 5000, 0.7, 12.0, 1001, 40, "P3P LO-RANSAC (ransac_pnp), BASELINE configs[1]"),
+    "relpose_5000": (1, 5000, 0.5, 1.0, 1002, 32, "5-point LO-RANSAC (ransac_relpose), BASELINE configs[2]"),
+    "fund_10000": (2, 10000, 0.5, 1.0, 1004, 32, "7-point LO-RANSAC (ransac_fundamental), BASELINE configs[3]"),
+    "hom_10000": (3, 10000, 0.5, 1.0, 1003, 32, "4-point homography LO-RANSAC (ransac_homography), BASELINE configs[3]"),
+}
 
 
 def main():
@@ -49,6 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=4,
                     help="independent problems in flight per GPU (one host thread + HIP stream each)")
+    ap.add_argument("--workload", default="p3p_5000", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=ITERATIONS)
     args = ap.parse_args()
@@ -71,20 +75,26 @@ def main():
 
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    # one image pair per rank (independent problems; data seed 1001 + rank)
-    scene = synth.absolute_pose_scene(N_POINTS, OUTLIER_RATIO, 1001 + rank)
-    cam = P.Camera(scene["camera"])
+    KIND, N_POINTS, OUTLIER_RATIO, MAX_ERROR_PX, DATA_SEED, BYTES_PER_CORR, DESCR = WORKLOADS[args.workload]
+    # one image pair per rank (independent problems; data seed + rank); pixels -> normalised image plane
+    pp = np.array([500.0, 500.0])
+    if KIND == 0:
+        scene = synth.absolute_pose_scene(N_POINTS, OUTLIER_RATIO, DATA_SEED + rank)
+        A, Bpts = (scene["p2d"] - pp) / FOCAL, scene["p3d"]
+    else:
+        gen = {1: synth.relative_pose_scene, 2: synth.fundamental_scene, 3: synth.homography_scene}[KIND]
+        scene = gen(N_POINTS, OUTLIER_RATIO, DATA_SEED + rank)
+        A, Bpts = (scene["x1"] - pp) / FOCAL, (scene["x2"] - pp) / FOCAL
     # the front-end's O(N) pre-processing (robust.cc:40-46) is done once, outside the timed region
     from concurrent.futures import ThreadPoolExecutor
 
     thr = MAX_ERROR_PX / FOCAL
-    xn = (scene["p2d"] - np.array(scene["camera"]["params"][1:3])) / FOCAL  # normalised image points
     S = max(1, args.streams)
     pool = ThreadPoolExecutor(max_workers=S)
 
     def make_problem(_):
         P.set_device(local_rank)  # per-thread context: own HIP stream + scratch arena
-        return P.Problem(P.KIND_ABS, xn, scene["p3d"])  # SoA in HBM, resident from here on
+        return P.Problem(KIND, A, Bpts)  # SoA in HBM, resident from here on
 
     probs = list(pool.map(make_problem, range(S)))
 
@@ -121,8 +131,9 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # final gather over RCCL: [elapsed, hypotheses, kernel ms, launches, inliers, pose(7)]
-    rec = torch.tensor([elapsed, float(hyp), kern_ms, float(launches), float(last[1]["num_inliers"])]
-                       + list(last[0].q) + list(last[0].t), dtype=torch.float64, device="cuda")
+    model_flat = (list(last[0].q) + list(last[0].t) + [0.0, 0.0]) if KIND in (0, 1) else list(np.asarray(last[0]).reshape(-1))
+    rec = torch.tensor([elapsed, float(hyp), kern_ms, float(launches), float(last[1]["num_inliers"])] + model_flat,
+                       dtype=torch.float64, device="cuda")
     if use_dist:
         allrec = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
@@ -153,17 +164,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "p3p_5000", "problem": "P3P LO-RANSAC (ransac_pnp)", "correspondences": N_POINTS,
+            "config": {"workload": args.workload, "problem": DESCR, "correspondences": N_POINTS,
                        "outlier_ratio": OUTLIER_RATIO, "max_iterations": ITERATIONS, "min_iterations": ITERATIONS,
                        "max_error_px": MAX_ERROR_PX, "problems_per_gpu_per_step": S,
                        "hypotheses_per_step": hyp0 / args.steps,
                        "iterations_per_s": world * S * args.steps * ITERATIONS / t_max,
                        "inliers_found": int(allrec[0, 4])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_score<EST_ABS,5>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_score_abs_pf<5>" if KIND == 0 else f"k_score<{KIND},P>",
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "note": "algorithmic bytes = hypotheses x N x 40 B; the set is register/L2-resident, "
+                         "note": f"algorithmic bytes = hypotheses x N x {BYTES_PER_CORR} B; the set is register/L2-resident, "
                                  "the physical bound is fp64 VALU (DESIGN.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -172,11 +184,12 @@ def main():
             o = {"max_error": thr, "ransac": {"max_iterations": args.cpu_iterations,
                                               "min_iterations": args.cpu_iterations, "seed": 0}}
             t1 = time.perf_counter()
-            _, _, cst = O.ransac_pnp(xn, scene["p3d"], o)
+            cpu_fn = {0: O.ransac_pnp, 1: O.ransac_relpose, 2: O.ransac_fundamental, 3: O.ransac_homography}[KIND]
+            _, _, cst = cpu_fn(A, Bpts, o)
             cpu_s = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": cst["hypotheses"] / cst["seconds"], "unit": "hypotheses/s", "cores": 1,
                                    "kind": "port",
-                                   "sample": f"oracle ransac_pnp, same workload, {args.cpu_iterations} iterations "
+                                   "sample": f"oracle {cpu_fn.__name__}, same workload, {args.cpu_iterations} iterations "
                                              f"({cst['hypotheses']} hypotheses, {cpu_s:.1f} s wall), g++ -O3 no -march, "
                                              f"1 of {os.cpu_count()} host cores"}
         print(json.dumps(out))
