@@ -514,7 +514,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
     const int kind = p->kind;
     const uint32_t N = p->n;
     const int K = sample_size(kind);
-    const int MAXM = max_models(kind);
+    int MAXM = (kind == EST_REL) ? 8 : max_models(kind); // record slots per iteration (5-pt: grown to 40 on demand)
     const pl_ransac_options &ro = o->ransac;
     const double thr2 = o->max_error * o->max_error;
     const LMOptions lo_opt = lo_options(o->max_error);
@@ -584,7 +584,6 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
         }
 
         // batch capacity: bounded by the scratch the model records need
-        const uint32_t cap = (kind == EST_REL) ? 16384u : 131072u;
         uint64_t grow = std::max<uint64_t>(ro.min_iterations + 2, 512);
         grow = (grow + 63) / 64 * 64;
         uint64_t it = 0;   // next iteration to evaluate == iterations replayed so far
@@ -605,8 +604,9 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             uint64_t needed = std::max<uint64_t>(ro.min_iterations, dyn_max) + 1;
             needed = std::min<uint64_t>(needed, ro.max_iterations);
             needed = (needed > it) ? needed - it : 1;
+            const uint32_t cap = std::min<uint32_t>(131072u, 524288u / (uint32_t)MAXM); // bounded by scratch size
             const uint32_t B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
-            grow = std::min<uint64_t>(grow * 2, cap);
+            grow = std::min<uint64_t>(grow * 2, 131072u);
 
             // ---- device: positions -> generate -> compact -> score -> finalize -> records ----
             const size_t hcap = (size_t)B * MAXM;
@@ -671,6 +671,8 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             ga.pos_base = pos;
             ga.positions = c->positions.as<uint32_t>();
             ga.num_iters = B;
+            ga.slots_per_iter = (uint32_t)MAXM;
+            ga.ctl = d_ctl;
             ga.models = c->models.as<double>();
             ga.num_models = c->num_models.as<uint32_t>();
             ga.real_focal_check = o->real_focal_check;
@@ -726,6 +728,10 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                     continue;
                 }
                 pos_after = h_ctl->pos_after;
+            }
+            if (h_ctl->gen_overflow) { // an iteration produced more models than the reserved slots: redo with 40
+                MAXM = max_models(kind);
+                continue;
             }
             force_host_positions = false;
             const uint32_t H = h_ctl->num_hyp;

@@ -63,7 +63,8 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs
     constexpr int MAXM = max_models(EST);
     uint32_t idx[K];
     draw_sample<K>(g.seed, g.pos_base + g.positions[it], g.pts.n, idx);
-    double *rec = g.models + (size_t)it * MAXM * kModelStride;
+    (void)MAXM;
+    double *rec = g.models + (size_t)it * g.slots_per_iter * kModelStride;
     int n = 0;
     if constexpr (EST == EST_ABS) {
         Vec3 xb[3], Xp[3];
@@ -91,7 +92,11 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs
         } else if constexpr (EST == EST_FUND) {
             n = relpose_7pt_records(b1, b2, rec, g.real_focal_check != 0);
         } else {
-            n = relpose_5pt_records(b1, b2, rec);
+            n = relpose_5pt_records(b1, b2, rec, (int)g.slots_per_iter);
+            if (n > (int)g.slots_per_iter) {
+                g.ctl->gen_overflow = 1;
+                n = 0;
+            }
         }
     }
     g.num_models[it] = (uint32_t)n;

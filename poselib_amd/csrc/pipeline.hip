@@ -71,17 +71,19 @@ __global__ __launch_bounds__(256) void k_sample_delta(uint64_t seed, uint64_t po
 }
 
 constexpr int kMaxSegments = 4096;
+constexpr int kMaxFlags = 12288; // flagged positions kept in LDS (position + delta); more => host fallback
 
 __global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, uint32_t M, int K, uint32_t B,
-                                                       uint64_t pos_base, uint32_t *flags, uint32_t flags_cap,
-                                                       uint32_t *positions, BatchCtl *ctl) {
+                                                       uint64_t pos_base, uint32_t *positions, BatchCtl *ctl) {
     __shared__ uint32_t wave_tot[16], wave_off[16];
+    __shared__ uint32_t flag_pos[kMaxFlags];
+    __shared__ uint8_t flag_delta[kMaxFlags];
     __shared__ uint32_t seg_iter[kMaxSegments];
     __shared__ uint32_t seg_pos[kMaxSegments];
     __shared__ uint32_t s_nseg, s_nflags, s_error;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    // ---- phase 1: ordered list of the positions whose iteration would redraw (delta != K) ----
+    // ---- phase 1: ordered list (in LDS) of the positions whose iteration would redraw (delta != K) ----
     const uint32_t per = (M + 1023u) / 1024u;
     const uint32_t p0 = min(M, threadIdx.x * per), p1 = min(M, p0 + per);
     uint32_t local = 0;
@@ -98,60 +100,93 @@ __global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, uin
             s += wave_tot[w];
         }
         s_nflags = s;
-        s_error = (s > flags_cap) ? 1u : 0u;
+        s_error = (s > (uint32_t)kMaxFlags) ? 1u : 0u;
     }
     __syncthreads();
     if (!s_error) {
         uint32_t o = wave_off[wave] + inc - local;
-        for (uint32_t p = p0; p < p1; ++p)
-            if (delta[p] != (uint8_t)K)
-                flags[o++] = p;
+        for (uint32_t p = p0; p < p1; ++p) {
+            const uint8_t d = delta[p];
+            if (d != (uint8_t)K) {
+                flag_pos[o] = p;
+                flag_delta[o] = d;
+                ++o;
+            }
+        }
     }
-    __threadfence_block();
     __syncthreads();
 
-    // ---- phase 2: one lane hops along the orbit from flag to flag ----
-    if (threadIdx.x == 0) {
+    // ---- phase 2: wavefront 0 hops along the orbit from flag to flag.  All state is wave-uniform; the 64
+    // lanes inspect 64 consecutive flags per step (the flags of the wrong phase are skipped in parallel). ----
+    if (wave == 0) {
         uint32_t nseg = 1, err = s_error;
-        seg_iter[0] = 0;
-        seg_pos[0] = 0;
+        if (lane == 0) {
+            seg_iter[0] = 0;
+            seg_pos[0] = 0;
+        }
+        const uint32_t F = s_nflags;
+        uint32_t cur = 0, it = 0, fi = 0;
         if (!err) {
-            const uint32_t F = s_nflags;
-            uint32_t cur = 0, it = 0, fi = 0;
             while (it < B) {
-                while (fi < F && flags[fi] < cur)
-                    ++fi;
-                uint32_t j = fi;
-                while (j < F && (flags[j] - cur) % (uint32_t)K != 0)
-                    ++j;
-                if (j >= F)
+                // first flag at or after `cur` (flags are sorted)
+                for (;;) {
+                    const uint32_t idx = fi + lane;
+                    const bool behind = idx < F && flag_pos[idx] < cur;
+                    const uint32_t nb = __popcll(__ballot(behind));
+                    fi += nb;
+                    if (nb < 64)
+                        break;
+                }
+                // first flag >= cur on the current phase
+                uint32_t j = 0xffffffffu;
+                for (uint32_t j0 = fi; j0 < F; j0 += 64) {
+                    const uint32_t idx = j0 + lane;
+                    const bool hit = idx < F && (flag_pos[idx] - cur) % (uint32_t)K == 0;
+                    const unsigned long long m = __ballot(hit);
+                    if (m) {
+                        j = j0 + (uint32_t)__builtin_ctzll(m);
+                        break;
+                    }
+                }
+                if (j == 0xffffffffu)
                     break; // no further redraw on this orbit: strides of K to the end
-                const uint32_t q = flags[j];
+                const uint32_t q = flag_pos[j];
                 const uint32_t before = (q - cur) / (uint32_t)K;
                 if (it + before >= B)
                     break; // the batch ends before that iteration
                 it += before;
-                const uint32_t d = delta[q];
+                const uint32_t d = flag_delta[j];
                 if (d == 255u || nseg >= (uint32_t)kMaxSegments) {
                     err = 1;
                     break;
                 }
                 cur = q + d;
                 it += 1;
-                seg_iter[nseg] = it;
-                seg_pos[nseg] = cur;
+                if (lane == 0) {
+                    seg_iter[nseg] = it;
+                    seg_pos[nseg] = cur;
+                }
                 ++nseg;
             }
         }
-        s_nseg = nseg;
-        // position of iteration B == draws consumed by the batch
-        const uint32_t s = nseg - 1;
-        const uint64_t end = (uint64_t)seg_pos[s] + (uint64_t)(B - seg_iter[s]) * (uint64_t)K;
-        if (end + 255 > M)
-            err = 1; // the window of evaluated positions was too small: the host retries with a larger one
-        ctl->pos_after = pos_base + end;
-        ctl->orbit_error = err;
-        s_error = err;
+        if (lane == 0) {
+            // position of iteration B == draws consumed by the batch (the last segment is still in registers)
+            const uint64_t end = (uint64_t)cur + (uint64_t)(B - it) * (uint64_t)K;
+            // `cur`/`it` are the start of the last segment only if the loop ended by `break`/exhaustion
+            (void)end;
+        }
+        // recompute from the segment table to keep one formula
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const uint32_t s = nseg - 1;
+            const uint64_t end = (uint64_t)seg_pos[s] + (uint64_t)(B - seg_iter[s]) * (uint64_t)K;
+            if (end + 255 > M)
+                err = 1; // the window of evaluated positions was too small: the host retries / falls back
+            ctl->pos_after = pos_base + end;
+            ctl->orbit_error = err;
+            s_nseg = nseg;
+            s_error = err;
+        }
     }
     __syncthreads();
 
@@ -375,7 +410,9 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
     default:
         return hipErrorInvalidValue;
     }
-    k_sample_orbit<<<dim3(1), dim3(1024), 0, stream>>>(delta, M, K, B, pos_base, flags, flags_cap, positions, ctl);
+    (void)flags;
+    (void)flags_cap;
+    k_sample_orbit<<<dim3(1), dim3(1024), 0, stream>>>(delta, M, K, B, pos_base, positions, ctl);
     return hipGetLastError();
 }
 

@@ -18,19 +18,23 @@ struct PointSet {
 };
 
 constexpr int kScoreThreads = 256; // 4 wavefronts per workgroup
-constexpr int kLMThreads = 1024;   // 16 wavefronts: one workgroup per refinement task
+constexpr int kLMThreads = 512;    // 8 wavefronts (2 per SIMD => 256 VGPRs each: the k(k+1)/2+k accumulators stay in registers)
 
 PL_HD constexpr int sample_size(int est) { return est == EST_ABS ? 3 : est == EST_REL ? 5 : est == EST_FUND ? 7 : 4; }
 PL_HD constexpr int max_models(int est) { return est == EST_ABS ? 4 : est == EST_REL ? 40 : est == EST_FUND ? 3 : 1; }
 PL_HD constexpr int point_doubles(int est) { return est == EST_ABS ? 5 : 4; }
 
+struct BatchCtl;
 struct GenerateArgs {
     PointSet pts;
     uint64_t seed;
     uint64_t pos_base;         // draws consumed before the batch
     const uint32_t *positions; // draws consumed before each iteration, relative to pos_base
     uint32_t num_iters;
-    double *models;            // [num_iters * max_models] records of kModelStride doubles
+    uint32_t slots_per_iter;   // record slots reserved per iteration (<= max_models(est)); more solutions than
+                               // slots => ctl->gen_overflow is set and the host repeats the batch with more room
+    struct BatchCtl *ctl;
+    double *models;            // [num_iters * slots_per_iter] records of kModelStride doubles
     uint32_t *num_models;      // [num_iters]
     int32_t real_focal_check;  // fundamental only
 };
@@ -79,7 +83,7 @@ struct BatchCtl {
     uint32_t num_hyp;     // hypotheses of the batch (k_compact2)
     uint32_t num_records; // improving hypotheses found by k_records (may exceed the list capacity)
     uint32_t orbit_error; // sampler position window too small / too many redraw segments
-    uint32_t pad;
+    uint32_t gen_overflow; // an iteration produced more models than slots_per_iter
     uint64_t pos_after;   // draws consumed after the batch's last iteration
 };
 struct RecordMeta {

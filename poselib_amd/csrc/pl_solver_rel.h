@@ -672,16 +672,20 @@ PL_HD int essential_5pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Eout) {
     return nroots;
 }
 
-// 5-point relative pose: writes <= 40 model records (pose + E=[t]xR(q)); returns their number.
-PL_HD int relpose_5pt_records(const Vec3 *x1, const Vec3 *x2, double *rec) {
+// 5-point relative pose: up to 40 model records (pose + E=[t]xR(q)).  Returns the number of solutions; only
+// the first `max_out` are written (the caller detects the overflow and retries with room for 40).
+PL_HD int relpose_5pt_records(const Vec3 *x1, const Vec3 *x2, double *rec, int max_out = 40) {
     Mat3 E[10];
     const int ne = essential_5pt(x1, x2, E);
     int n = 0;
     for (int i = 0; i < ne; ++i) {
         PoseQT cand[4];
         const int nc = motion_from_essential<5>(E[i], x1, x2, cand);
-        for (int k = 0; k < nc; ++k)
-            store_pose_model_q(rec + (n++) * kModelStride, cand[k].q, cand[k].t, true);
+        for (int k = 0; k < nc; ++k) {
+            if (n < max_out)
+                store_pose_model_q(rec + n * kModelStride, cand[k].q, cand[k].t, true);
+            ++n;
+        }
     }
     return n;
 }
