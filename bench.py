@@ -7,7 +7,7 @@
 Workload (config.workload = "p3p_5000"): BASELINE.json configs[1] — P3P LO-RANSAC on 5000 synthetic 2D-3D
 correspondences, 70 % outliers, max_iterations = 100000, with min_iterations = max_iterations so that the
 loop really evaluates 100000 iterations (with default options PoseLib stops after ~10^3).
-One "step" = S (= --streams, default 4) independent, complete ransac_pnp calls in flight on the GPU (sample ->
+One "step" = S (= --streams, default 8) independent, complete ransac_pnp calls in flight on the GPU (sample ->
 P3P -> score all N -> LO -> final refinement -> inlier mask; one host thread + HIP stream per problem, different
 RANSAC seeds) on correspondences that are already resident in HBM.  A hypothesis = one minimal-solver model scored
 against all N correspondences (ransac_impl.h:112-113).  Multi-GPU: independent image pairs, one per rank
@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="independent problems in flight per GPU (one host thread + HIP stream each)")
     ap.add_argument("--workload", default="p3p_5000", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")

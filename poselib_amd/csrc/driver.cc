@@ -650,7 +650,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                     device_positions = false;
                 } else {
                     const uint32_t M = (uint32_t)M64;
-                    HIP_TRY(c->delta.ensure(M));
+                    HIP_TRY(c->delta.ensure((size_t)M + 16384 + 64)); // k_sample_orbit reads whole 16 KiB tiles
                     HIP_TRY(c->flags.ensure(sizeof(uint32_t) * (size_t)M));
                     HIP_TRY(launch_sample_positions(K, ro.seed, pos, N, B, M, c->delta.as<uint8_t>(),
                                                     c->flags.as<uint32_t>(), M, c->positions.as<uint32_t>(), d_ctl,

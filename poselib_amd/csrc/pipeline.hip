@@ -84,37 +84,52 @@ __global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, uin
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     // ---- phase 1: ordered list (in LDS) of the positions whose iteration would redraw (delta != K) ----
-    const uint32_t per = (M + 1023u) / 1024u;
-    const uint32_t p0 = min(M, threadIdx.x * per), p1 = min(M, p0 + per);
-    uint32_t local = 0;
-    for (uint32_t p = p0; p < p1; ++p)
-        local += (delta[p] != (uint8_t)K);
-    const uint32_t inc = wscan_add(local, lane);
-    if (lane == 63)
-        wave_tot[wave] = inc;
-    __syncthreads();
+    // Tiles of 1024 x 16 positions: one coalesced 16-byte load per lane, workgroup scan of the per-lane flag
+    // counts, ordered append.  (`delta` is allocated with 16 KiB of slack, so the last tile may over-read.)
     if (threadIdx.x == 0) {
-        uint32_t s = 0;
-        for (int w = 0; w < 16; ++w) {
-            wave_off[w] = s;
-            s += wave_tot[w];
-        }
-        s_nflags = s;
-        s_error = (s > (uint32_t)kMaxFlags) ? 1u : 0u;
+        s_nflags = 0;
+        s_error = 0;
     }
     __syncthreads();
-    if (!s_error) {
-        uint32_t o = wave_off[wave] + inc - local;
-        for (uint32_t p = p0; p < p1; ++p) {
-            const uint8_t d = delta[p];
-            if (d != (uint8_t)K) {
-                flag_pos[o] = p;
-                flag_delta[o] = d;
-                ++o;
+    for (uint32_t t0 = 0; t0 < M; t0 += 16384u) {
+        const uint32_t pbase = t0 + threadIdx.x * 16u;
+        const uint4 raw = *reinterpret_cast<const uint4 *>(delta + pbase);
+        const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t local = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint32_t d = (w4[b >> 2] >> (8 * (b & 3))) & 0xffu;
+            local += (pbase + b < M && d != (uint32_t)K) ? 1u : 0u;
+        }
+        const uint32_t inc = wscan_add(local, lane);
+        if (lane == 63)
+            wave_tot[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t s = s_nflags;
+            for (int w = 0; w < 16; ++w) {
+                wave_off[w] = s;
+                s += wave_tot[w];
+            }
+            s_nflags = s;
+            if (s > (uint32_t)kMaxFlags)
+                s_error = 1u;
+        }
+        __syncthreads();
+        if (!s_error && local) {
+            uint32_t o = wave_off[wave] + inc - local;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const uint32_t d = (w4[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                if (pbase + b < M && d != (uint32_t)K) {
+                    flag_pos[o] = pbase + b;
+                    flag_delta[o] = (uint8_t)d;
+                    ++o;
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- phase 2: wavefront 0 hops along the orbit from flag to flag.  All state is wave-uniform; the 64
     // lanes inspect 64 consecutive flags per step (the flags of the wrong phase are skipped in parallel). ----
