@@ -151,6 +151,13 @@ def main():
         avg_launch_s = (k_ms / max(k_launch, 1)) * 1e-3
         alg_bytes_per_launch = (hyp0 / max(k_launch, 1)) * N_POINTS * BYTES_PER_CORR
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:  # PMC-measured HBM bytes per launch (rocprofv3 passes, committed under profiles/)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            if tr:
+                traffic, traffic_src = tr["traffic_bytes_per_launch"], tr["source"]
+        except Exception:
+            pass
         out = {
             "metric": "scored RANSAC hypotheses/sec",
             "value": value,
@@ -171,7 +178,7 @@ def main():
                        "iterations_per_s": world * S * args.steps * ITERATIONS / t_max,
                        "inliers_found": int(allrec[0, 4])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_score_abs_pf<5>" if KIND == 0 else f"k_score<{KIND},P>",
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
