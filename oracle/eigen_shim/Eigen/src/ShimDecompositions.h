@@ -1,0 +1,366 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Decompositions for the Eigen shim (see ../Core).  Algorithms restated from
+// the published descriptions of Eigen's FullPivHouseholderQR / PartialPivLU / ColPivHouseholderQR / JacobiSVD;
+// same arithmetic as oracle/src/solvers_rel.cc and refine.cc.
+#ifndef ORACLE_EIGEN_SHIM_DECOMP
+#define ORACLE_EIGEN_SHIM_DECOMP
+
+namespace Eigen {
+
+template <typename T, int R, int C> class ShimFullPivQR {
+  public:
+    template <typename D> explicit ShimFullPivQR(const Dense<D, T, R, C> &A) {
+        rows_ = A.rows();
+        cols_ = A.cols();
+        qr_.resize(rows_, cols_);
+        for (Index j = 0; j < cols_; ++j)
+            for (Index i = 0; i < rows_; ++i)
+                qr_(i, j) = A(i, j);
+        const Index size = std::min(rows_, cols_);
+        tau_.assign(static_cast<size_t>(size), T(0));
+        rowswap_.assign(static_cast<size_t>(size), 0);
+        T biggest = T(0);
+        const T precision = std::numeric_limits<T>::epsilon() * T(size);
+        for (Index k = 0; k < size; ++k) {
+            Index pr = k, pc = k;
+            T best = std::abs(qr_(k, k));
+            for (Index c = k; c < cols_; ++c)
+                for (Index r = k; r < rows_; ++r)
+                    if (std::abs(qr_(r, c)) > best) {
+                        best = std::abs(qr_(r, c));
+                        pr = r;
+                        pc = c;
+                    }
+            if (k == 0)
+                biggest = best;
+            if (best <= biggest * precision) {
+                for (Index i = k; i < size; ++i)
+                    rowswap_[static_cast<size_t>(i)] = i;
+                break;
+            }
+            rowswap_[static_cast<size_t>(k)] = pr;
+            if (pr != k)
+                for (Index c = k; c < cols_; ++c)
+                    std::swap(qr_(k, c), qr_(pr, c));
+            if (pc != k)
+                for (Index r = 0; r < rows_; ++r)
+                    std::swap(qr_(r, k), qr_(r, pc));
+            T tail_sq = T(0);
+            for (Index r = k + 1; r < rows_; ++r)
+                tail_sq += qr_(r, k) * qr_(r, k);
+            const T c0 = qr_(k, k);
+            T beta;
+            if (tail_sq <= std::numeric_limits<T>::min()) {
+                tau_[static_cast<size_t>(k)] = T(0);
+                beta = c0;
+                for (Index r = k + 1; r < rows_; ++r)
+                    qr_(r, k) = T(0);
+            } else {
+                beta = std::sqrt(c0 * c0 + tail_sq);
+                if (c0 >= T(0))
+                    beta = -beta;
+                for (Index r = k + 1; r < rows_; ++r)
+                    qr_(r, k) = qr_(r, k) / (c0 - beta);
+                tau_[static_cast<size_t>(k)] = (beta - c0) / beta;
+            }
+            qr_(k, k) = beta;
+            const T tk = tau_[static_cast<size_t>(k)];
+            if (tk != T(0))
+                for (Index c = k + 1; c < cols_; ++c) {
+                    T t = T(0);
+                    for (Index r = k + 1; r < rows_; ++r)
+                        t += qr_(r, k) * qr_(r, c);
+                    t += qr_(k, c);
+                    qr_(k, c) -= tk * t;
+                    for (Index r = k + 1; r < rows_; ++r)
+                        qr_(r, c) -= tk * qr_(r, k) * t;
+                }
+        }
+    }
+    Matrix<T, R, R> matrixQ() const {
+        Matrix<T, R, R> Q;
+        Q.resize(rows_, rows_);
+        Q.setIdentity();
+        const Index size = std::min(rows_, cols_);
+        for (Index k = size - 1; k >= 0; --k) {
+            const T tk = tau_[static_cast<size_t>(k)];
+            if (tk != T(0))
+                for (Index c = k; c < rows_; ++c) {
+                    T t = T(0);
+                    for (Index r = k + 1; r < rows_; ++r)
+                        t += qr_(r, k) * Q(r, c);
+                    t += Q(k, c);
+                    Q(k, c) -= tk * t;
+                    for (Index r = k + 1; r < rows_; ++r)
+                        Q(r, c) -= tk * qr_(r, k) * t;
+                }
+            const Index sw = rowswap_[static_cast<size_t>(k)];
+            if (sw != k)
+                for (Index c = 0; c < rows_; ++c)
+                    std::swap(Q(k, c), Q(sw, c));
+        }
+        return Q;
+    }
+
+  private:
+    Index rows_, cols_;
+    Matrix<T, Dynamic, Dynamic> qr_;
+    std::vector<T> tau_;
+    std::vector<Index> rowswap_;
+};
+
+template <typename T, int N> class ShimPartialPivLU {
+  public:
+    template <typename D> explicit ShimPartialPivLU(const Dense<D, T, N, N> &A) {
+        n_ = A.rows();
+        lu_.resize(n_, n_);
+        for (Index j = 0; j < n_; ++j)
+            for (Index i = 0; i < n_; ++i)
+                lu_(i, j) = A(i, j);
+        perm_.resize(static_cast<size_t>(n_));
+        for (Index i = 0; i < n_; ++i)
+            perm_[static_cast<size_t>(i)] = i;
+        for (Index k = 0; k < n_; ++k) {
+            Index piv = k;
+            T best = std::abs(lu_(k, k));
+            for (Index i = k + 1; i < n_; ++i)
+                if (std::abs(lu_(i, k)) > best) {
+                    best = std::abs(lu_(i, k));
+                    piv = i;
+                }
+            if (piv != k) {
+                for (Index j = 0; j < n_; ++j)
+                    std::swap(lu_(k, j), lu_(piv, j));
+                std::swap(perm_[static_cast<size_t>(k)], perm_[static_cast<size_t>(piv)]);
+            }
+            if (lu_(k, k) != T(0))
+                for (Index i = k + 1; i < n_; ++i)
+                    lu_(i, k) /= lu_(k, k);
+            for (Index i = k + 1; i < n_; ++i) {
+                const T f = lu_(i, k);
+                for (Index j = k + 1; j < n_; ++j)
+                    lu_(i, j) -= f * lu_(k, j);
+            }
+        }
+    }
+    template <typename D, int C> Matrix<T, N, C> solve(const Dense<D, T, N, C> &B) const {
+        Matrix<T, N, C> X;
+        X.resize(n_, B.cols());
+        for (Index c = 0; c < B.cols(); ++c) {
+            for (Index i = 0; i < n_; ++i)
+                X(i, c) = B(perm_[static_cast<size_t>(i)], c);
+            for (Index i = 1; i < n_; ++i) {
+                T s = X(i, c);
+                for (Index j = 0; j < i; ++j)
+                    s -= lu_(i, j) * X(j, c);
+                X(i, c) = s;
+            }
+            for (Index i = n_ - 1; i >= 0; --i) {
+                T s = X(i, c);
+                for (Index j = i + 1; j < n_; ++j)
+                    s -= lu_(i, j) * X(j, c);
+                X(i, c) = s / lu_(i, i);
+            }
+        }
+        return X;
+    }
+
+  private:
+    Index n_;
+    Matrix<T, Dynamic, Dynamic> lu_;
+    std::vector<Index> perm_;
+};
+
+// least squares through Householder QR with column pivoting (3x2 use in relpose_5pt.cc:381)
+template <typename T, int R, int C> class ShimColPivQR {
+  public:
+    template <typename D> explicit ShimColPivQR(const Dense<D, T, R, C> &A) : A_(A) {}
+    template <typename D, int C2> Matrix<T, C, C2> solve(const Dense<D, T, R, C2> &b) const {
+        const Index rows = A_.rows(), cols = A_.cols();
+        Matrix<T, Dynamic, Dynamic> Q(rows, cols);
+        std::vector<T> rhs(static_cast<size_t>(rows));
+        for (Index i = 0; i < rows; ++i) {
+            rhs[static_cast<size_t>(i)] = b(i, 0);
+            for (Index j = 0; j < cols; ++j)
+                Q(i, j) = A_(i, j);
+        }
+        std::vector<Index> colperm(static_cast<size_t>(cols));
+        for (Index j = 0; j < cols; ++j)
+            colperm[static_cast<size_t>(j)] = j;
+        Matrix<T, Dynamic, Dynamic> Rm(cols, cols);
+        for (Index k = 0; k < cols; ++k) {
+            Index best = k;
+            T bn = T(-1);
+            for (Index j = k; j < cols; ++j) {
+                T n = T(0);
+                for (Index i = k; i < rows; ++i)
+                    n += Q(i, j) * Q(i, j);
+                if (n > bn) {
+                    bn = n;
+                    best = j;
+                }
+            }
+            if (best != k) {
+                for (Index i = 0; i < rows; ++i)
+                    std::swap(Q(i, k), Q(i, best));
+                for (Index i = 0; i < k; ++i)
+                    std::swap(Rm(i, k), Rm(i, best));
+                std::swap(colperm[static_cast<size_t>(k)], colperm[static_cast<size_t>(best)]);
+            }
+            T tail = T(0);
+            for (Index i = k + 1; i < rows; ++i)
+                tail += Q(i, k) * Q(i, k);
+            const T c0 = Q(k, k);
+            T beta = std::sqrt(c0 * c0 + tail);
+            if (c0 >= T(0))
+                beta = -beta;
+            std::vector<T> v(static_cast<size_t>(rows), T(0));
+            T tau = T(0);
+            if (tail > std::numeric_limits<T>::min()) {
+                v[static_cast<size_t>(k)] = T(1);
+                for (Index i = k + 1; i < rows; ++i)
+                    v[static_cast<size_t>(i)] = Q(i, k) / (c0 - beta);
+                tau = (beta - c0) / beta;
+            } else {
+                beta = c0;
+            }
+            Rm(k, k) = beta;
+            for (Index cc = k + 1; cc < cols; ++cc) {
+                T t = T(0);
+                for (Index i = k; i < rows; ++i)
+                    t += v[static_cast<size_t>(i)] * Q(i, cc);
+                for (Index i = k; i < rows; ++i)
+                    Q(i, cc) -= tau * v[static_cast<size_t>(i)] * t;
+                Rm(k, cc) = Q(k, cc);
+            }
+            T t = T(0);
+            for (Index i = k; i < rows; ++i)
+                t += v[static_cast<size_t>(i)] * rhs[static_cast<size_t>(i)];
+            for (Index i = k; i < rows; ++i)
+                rhs[static_cast<size_t>(i)] -= tau * v[static_cast<size_t>(i)] * t;
+        }
+        std::vector<T> w(static_cast<size_t>(cols));
+        for (Index i = cols - 1; i >= 0; --i) {
+            T s = rhs[static_cast<size_t>(i)];
+            for (Index j = i + 1; j < cols; ++j)
+                s -= Rm(i, j) * w[static_cast<size_t>(j)];
+            w[static_cast<size_t>(i)] = s / Rm(i, i);
+        }
+        Matrix<T, C, C2> x;
+        x.resize(cols, 1);
+        for (Index j = 0; j < cols; ++j)
+            x(colperm[static_cast<size_t>(j)], 0) = w[static_cast<size_t>(j)];
+        return x;
+    }
+
+  private:
+    Matrix<T, R, C> A_;
+};
+
+template <typename Derived, typename T, int RT, int CT> auto Dense<Derived, T, RT, CT>::fullPivHouseholderQr() const {
+    return ShimFullPivQR<T, RT, CT>(*this);
+}
+template <typename Derived, typename T, int RT, int CT> auto Dense<Derived, T, RT, CT>::partialPivLu() const {
+    return ShimPartialPivLU<T, RT>(*this);
+}
+template <typename Derived, typename T, int RT, int CT> auto Dense<Derived, T, RT, CT>::colPivHouseholderQr() const {
+    return ShimColPivQR<T, RT, CT>(*this);
+}
+
+// 3x3 SVD by one-sided Jacobi (singular values descending); only the shape the reference needs
+template <typename MatT> class JacobiSVD {
+  public:
+    typedef typename MatT::Scalar T;
+    JacobiSVD(const MatT &A, unsigned int = 0) {
+        MatT B = A;
+        V_.setIdentity();
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            T off = T(0);
+            for (int p = 0; p < 2; ++p)
+                for (int q = p + 1; q < 3; ++q) {
+                    T alpha = 0, beta = 0, gamma = 0;
+                    for (int i = 0; i < 3; ++i) {
+                        alpha += B(i, p) * B(i, p);
+                        beta += B(i, q) * B(i, q);
+                        gamma += B(i, p) * B(i, q);
+                    }
+                    if (gamma == T(0))
+                        continue;
+                    off = std::max(off, std::abs(gamma) / std::sqrt(std::max(alpha * beta, T(1e-300))));
+                    const T zeta = (beta - alpha) / (T(2) * gamma);
+                    const T t = ((zeta >= 0) ? T(1) : T(-1)) / (std::abs(zeta) + std::sqrt(T(1) + zeta * zeta));
+                    const T c = T(1) / std::sqrt(T(1) + t * t), s = c * t;
+                    for (int i = 0; i < 3; ++i) {
+                        const T bp = B(i, p), bq = B(i, q);
+                        B(i, p) = c * bp - s * bq;
+                        B(i, q) = s * bp + c * bq;
+                        const T vp = V_(i, p), vq = V_(i, q);
+                        V_(i, p) = c * vp - s * vq;
+                        V_(i, q) = s * vp + c * vq;
+                    }
+                }
+            if (off < T(1e-15))
+                break;
+        }
+        int order[3] = {0, 1, 2};
+        T sv[3];
+        for (int j = 0; j < 3; ++j)
+            sv[j] = std::sqrt(B(0, j) * B(0, j) + B(1, j) * B(1, j) + B(2, j) * B(2, j));
+        std::sort(order, order + 3, [&](int a, int b) { return sv[a] > sv[b]; });
+        MatT Vs, Bs;
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {
+                Vs(i, j) = V_(i, order[j]);
+                Bs(i, j) = B(i, order[j]);
+            }
+        V_ = Vs;
+        for (int j = 0; j < 3; ++j)
+            s_(j) = sv[order[j]];
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i)
+                U_(i, j) = (s_(j) > T(1e-14) * s_(0)) ? Bs(i, j) / s_(j) : T(0);
+        if (!(s_(2) > T(1e-14) * s_(0))) { // complete the basis
+            U_(0, 2) = U_(1, 0) * U_(2, 1) - U_(2, 0) * U_(1, 1);
+            U_(1, 2) = U_(2, 0) * U_(0, 1) - U_(0, 0) * U_(2, 1);
+            U_(2, 2) = U_(0, 0) * U_(1, 1) - U_(1, 0) * U_(0, 1);
+        }
+    }
+    const MatT &matrixU() const { return U_; }
+    const MatT &matrixV() const { return V_; }
+    const Matrix<T, 3, 1> &singularValues() const { return s_; }
+
+  private:
+    MatT U_, V_;
+    Matrix<T, 3, 1> s_;
+};
+
+template <typename T, int N> class DiagonalMatrix {
+  public:
+    DiagonalMatrix() {}
+    DiagonalMatrix(T a, T b, T c) {
+        d_(0) = a, d_(1) = b, d_(2) = c;
+    }
+    Matrix<T, N, 1> &diagonal() { return d_; }
+    const Matrix<T, N, 1> &diagonal() const { return d_; }
+    operator Matrix<T, N, N>() const {
+        Matrix<T, N, N> m;
+        for (int i = 0; i < N; ++i)
+            m(i, i) = d_(i);
+        return m;
+    }
+
+  private:
+    Matrix<T, N, 1> d_;
+};
+template <typename T, int N, typename B, int C>
+Matrix<T, N, C> operator*(const DiagonalMatrix<T, N> &d, const Dense<B, T, N, C> &b) {
+    Matrix<T, N, C> r;
+    r.resize(b.rows(), b.cols());
+    for (Index j = 0; j < b.cols(); ++j)
+        for (Index i = 0; i < b.rows(); ++i)
+            r(i, j) = d.diagonal()(i) * b(i, j);
+    return r;
+}
+
+
+} // namespace Eigen
+#endif

@@ -1,0 +1,71 @@
+"""ctypes access to oracle/_ref/libposelib_ref.so — the REFERENCE'S OWN hot-path sources compiled in place against
+oracle/eigen_shim (recipe: oracle/Makefile.ref, adapter: oracle/ref_shim/ref_api.cc).  Test infrastructure only.
+
+The library exports the oracle's C interface under the prefix ``ref_`` instead of ``orc_``, so `reference()` simply
+swaps the handle behind tests/oracle_lib.py: inside the context every oracle_lib wrapper (sampler_draw, p3p, score,
+ransac_pnp, ...) marshals exactly as for the oracle but runs the reference's code.
+"""
+import contextlib
+import ctypes as C
+import os
+import subprocess
+
+import oracle_lib as O
+
+_ORACLE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+_REF_LIB = os.path.join(_ORACLE_DIR, "_ref", "libposelib_ref.so")
+REFERENCE_ROOT = "/root/reference"
+
+
+def build() -> str:
+    """(Re)build where the reference sources exist; elsewhere (the GPU box) use the prebuilt file if it travelled."""
+    O.build()
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "PoseLib")):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "-f", "Makefile.ref", f"REF={REFERENCE_ROOT}"])
+    return _REF_LIB
+
+
+def available() -> bool:
+    try:
+        return os.path.exists(build())
+    except (subprocess.CalledProcessError, OSError):
+        return False
+
+
+class _Proxy:
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        assert name.startswith("orc_"), name
+        return getattr(self._cdll, "ref_" + name[4:])
+
+
+_proxy = None
+
+
+def _load():
+    global _proxy
+    if _proxy is None:
+        cdll = C.CDLL(build())
+        cdll.ref_all_inlier_probability.restype = C.c_double
+        cdll.ref_all_inlier_probability.argtypes = [C.c_uint64] * 3
+        cdll.ref_dynamic_max_iter.restype = C.c_uint64
+        cdll.ref_dynamic_max_iter.argtypes = [C.c_uint64] * 3 + [C.c_double] * 2 + [C.c_uint64] * 2
+        for name in ("ref_score_reproj", "ref_score_sampson_pose", "ref_score_sampson_F", "ref_score_homography",
+                     "ref_normalize_points"):
+            getattr(cdll, name).restype = C.c_double
+        cdll.ref_solve_cubic_single_real.argtypes = [C.c_double] * 3 + [C.c_void_p]
+        cdll.ref_solve_cubic_real.argtypes = [C.c_double] * 3 + [C.c_void_p]
+        _proxy = _Proxy(cdll)
+    return _proxy
+
+
+@contextlib.contextmanager
+def reference():
+    O.lib()
+    saved, O._lib = O._lib, _load()
+    try:
+        yield O
+    finally:
+        O._lib = saved
