@@ -256,6 +256,76 @@ template <typename T, int R, int C> class ShimColPivQR {
     Matrix<T, R, C> A_;
 };
 
+// A.selfadjointView<Lower>().llt().solve(b): Cholesky of the lower triangle.  Follows the structure of Eigen's
+// unblocked LLT (per column k: x = A_kk - |A10|^2, stop if x <= 0, A21 = (A21 - A20 A10^T) / x) and of its
+// triangular solves (forward: column-oriented updates; backward with L^T: row dot product, then subtract),
+// with plain ascending sums.
+template <typename T> class ShimLLT {
+  public:
+    explicit ShimLLT(const Matrix<T, Dynamic, Dynamic> &A) : L_(A) {
+        const Index n = L_.rows();
+        for (Index k = 0; k < n; ++k) {
+            T x = L_(k, k);
+            if (k > 0) {
+                T sq = L_(k, 0) * L_(k, 0);
+                for (Index m = 1; m < k; ++m)
+                    sq += L_(k, m) * L_(k, m);
+                x -= sq;
+            }
+            if (x <= T(0))
+                break;
+            x = std::sqrt(x);
+            L_(k, k) = x;
+            for (Index r = k + 1; r < n; ++r) {
+                if (k > 0) {
+                    T d = L_(r, 0) * L_(k, 0);
+                    for (Index m = 1; m < k; ++m)
+                        d += L_(r, m) * L_(k, m);
+                    L_(r, k) -= d;
+                }
+                L_(r, k) /= x;
+            }
+        }
+    }
+    template <typename D, int R, int C> Matrix<T, Dynamic, 1> solve(const Dense<D, T, R, C> &b) const {
+        const Index n = L_.rows();
+        Matrix<T, Dynamic, 1> x(n);
+        for (Index i = 0; i < n; ++i)
+            x(i) = b(i);
+        for (Index i = 0; i < n; ++i) {
+            x(i) /= L_(i, i);
+            for (Index r = i + 1; r < n; ++r)
+                x(r) -= x(i) * L_(r, i);
+        }
+        for (Index i = n - 1; i >= 0; --i) {
+            if (i + 1 < n) {
+                T d = L_(i + 1, i) * x(i + 1);
+                for (Index j = i + 2; j < n; ++j)
+                    d += L_(j, i) * x(j);
+                x(i) -= d;
+            }
+            x(i) /= L_(i, i);
+        }
+        return x;
+    }
+
+  private:
+    Matrix<T, Dynamic, Dynamic> L_;
+};
+template <typename T> class ShimSelfAdjoint {
+  public:
+    template <typename D, int R, int C> explicit ShimSelfAdjoint(const Dense<D, T, R, C> &A) : A_(A) {}
+    ShimLLT<T> llt() const { return ShimLLT<T>(A_); }
+
+  private:
+    Matrix<T, Dynamic, Dynamic> A_;
+};
+template <typename Derived, typename T, int RT, int CT>
+template <int UpLo>
+auto Dense<Derived, T, RT, CT>::selfadjointView() const {
+    static_assert(UpLo == Lower, "only the lower view is used by the reference");
+    return ShimSelfAdjoint<T>(*this);
+}
 template <typename Derived, typename T, int RT, int CT> auto Dense<Derived, T, RT, CT>::fullPivHouseholderQr() const {
     return ShimFullPivQR<T, RT, CT>(*this);
 }
@@ -351,6 +421,15 @@ template <typename T, int N> class DiagonalMatrix {
   private:
     Matrix<T, N, 1> d_;
 };
+template <typename T, int N, typename A, int R>
+Matrix<T, R, N> operator*(const Dense<A, T, R, N> &a, const DiagonalMatrix<T, N> &d) {
+    Matrix<T, R, N> r;
+    r.resize(a.rows(), a.cols());
+    for (Index j = 0; j < a.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i)
+            r(i, j) = a(i, j) * d.diagonal()(j);
+    return r;
+}
 template <typename T, int N, typename B, int C>
 Matrix<T, N, C> operator*(const DiagonalMatrix<T, N> &d, const Dense<B, T, N, C> &b) {
     Matrix<T, N, C> r;

@@ -4,9 +4,12 @@
 // pin the oracle's restatement.  What is the reference's here: the sampler (robust/sampling.cc), the RANSAC loop
 // template (robust/ransac_impl.h), the minimal solvers (solvers/p3p.cc, relpose_5pt.cc, relpose_7pt.cc,
 // homography_4pt.cc, misc/univariate.cc, misc/sturm.h, misc/essential.cc), scoring and inlier masks
-// (robust/utils.cc), CameraPose / quaternion helpers.  What is NOT: Eigen (shim), the estimator classes'
-// refine_model() (LM, PoseLib/robust/bundle.cc — needs far more of Eigen; the oracle's LM is called instead),
-// and the robust.cc front-ends.
+// (robust/utils.cc), CameraPose / quaternion helpers, the LM refiners (robust/optim/*.h, robust_loss.h) and the
+// camera models (misc/camera_models.cc).  What is NOT: Eigen (shim), the estimator classes'
+// the estimator classes and ransac.cc / robust.cc / bundle.cc translation units themselves (they pull in every other
+// solver and refiner family): their few lines for this path are mirrored by the adapters below, which call the
+// reference's sampler, solvers, scoring, refiner classes and LM loop.  REF_USE_ORACLE_LM=1 swaps the
+// adapters' refine_model() onto the oracle's LM (to separate solver from LM differences when a test fails).
 #include <PoseLib/camera_pose.h>
 #include <PoseLib/misc/essential.h>
 #include <PoseLib/robust/ransac_impl.h>
@@ -22,22 +25,19 @@
 #include "../oracle.h"
 
 #include <PoseLib/misc/camera_models.h>
+#include <PoseLib/robust/optim/absolute.h>
+#include <PoseLib/robust/optim/fundamental.h>
+#include <PoseLib/robust/optim/homography.h>
+#include <PoseLib/robust/optim/jacobian_accumulator.h>
+#include <PoseLib/robust/optim/lm_impl.h>
+#include <PoseLib/robust/optim/relative.h>
+#include <PoseLib/robust/robust_loss.h>
 
 #include <cstdlib>
 #include <cstring>
 
 using namespace poselib;
 
-// robust/utils.cc also holds the camera-model scoring variants, which this pinning build never calls; the camera
-// models themselves (misc/camera_models.cc) are not compiled, so the two members those variants reference are
-// defined here as traps to leave the shared object without unresolved symbols.
-namespace poselib {
-void Camera::project(const Eigen::Vector3d &, Eigen::Vector2d *) const { std::abort(); }
-void Camera::unproject_with_jac(const Eigen::Vector2d &, Eigen::Vector3d *, Eigen::Matrix<double, 3, 2> *,
-                                Eigen::Matrix<double, 3, Eigen::Dynamic> *) const {
-    std::abort();
-}
-} // namespace poselib
 
 namespace {
 
@@ -114,9 +114,81 @@ std::vector<double> flat3(const std::vector<Point3D> &v) {
     return f;
 }
 
+BundleOptions bopt(const orc_bundle_opt &o) {
+    BundleOptions b;
+    b.max_iterations = o.max_iterations;
+    b.loss_type = static_cast<BundleOptions::LossType>(o.loss_type);
+    b.loss_scale = o.loss_scale;
+    b.gradient_tol = o.gradient_tol;
+    b.step_tol = o.step_tol;
+    b.relative_cost_tol = o.relative_cost_tol;
+    b.initial_lambda = o.initial_lambda;
+    b.min_lambda = o.min_lambda;
+    b.max_lambda = o.max_lambda;
+    b.lambda_update = static_cast<BundleOptions::LambdaUpdateType>(o.lambda_update);
+    b.lambda_factor = o.lambda_factor;
+    b.damping = static_cast<BundleOptions::DampingType>(o.damping);
+    return b;
+}
+void bstats_out(const BundleStats &s, orc_bundle_stats *o) {
+    if (!o)
+        return;
+    o->iterations = s.iterations;
+    o->initial_cost = s.initial_cost;
+    o->cost = s.cost;
+    o->lambda = s.lambda;
+    o->nu = s.nu;
+    o->invalid_steps = s.invalid_steps;
+    o->step_norm = s.step_norm;
+    o->grad_norm = s.grad_norm;
+}
+IterationCallback le_zach_callback(const BundleOptions &opt) { // bundle.cc:53-77, non-verbose branches
+    if (opt.loss_type == BundleOptions::TRUNCATED_LE_ZACH)
+        return [](const BundleStats &, RobustLoss *loss_fn) {
+            static_cast<TruncatedLossLeZach *>(loss_fn)->mu *= TruncatedLossLeZach::alpha;
+        };
+    return nullptr;
+}
+// The four refinement entry points as bundle.cc instantiates them for unit weights (bundle.cc:94-103, 206-213,
+// 313-323, 394-401): the REFERENCE's refiner classes, Jacobian accumulator, robust losses and LM loop
+// (robust/optim/{absolute,relative,fundamental,homography,jacobian_accumulator,lm_impl}.h, robust_loss.h,
+// misc/camera_models.cc).  bundle.cc itself is not compiled: it also instantiates every other refiner family.
+BundleStats ref_lm_abs(const std::vector<Point2D> &x, const std::vector<Point3D> &X, Image *image, const BundleOptions &opt) {
+    std::vector<size_t> camera_refine_idx = image->camera.get_param_refinement_idx(opt);
+    UniformWeightVector weights;
+    AbsolutePoseRefiner<UniformWeightVector> refiner(x, X, camera_refine_idx, weights);
+    return lm_impl<decltype(refiner)>(refiner, image, opt, le_zach_callback(opt));
+}
+BundleStats ref_lm_rel(const std::vector<Point2D> &x1, const std::vector<Point2D> &x2, CameraPose *pose, const BundleOptions &opt) {
+    UniformWeightVector weights;
+    PinholeRelativePoseRefiner<UniformWeightVector> refiner(x1, x2, weights);
+    return lm_impl<decltype(refiner)>(refiner, pose, opt, le_zach_callback(opt));
+}
+BundleStats ref_lm_fund(const std::vector<Point2D> &x1, const std::vector<Point2D> &x2, Eigen::Matrix3d *F, const BundleOptions &opt) {
+    FactorizedFundamentalMatrix factorized(*F);
+    UniformWeightVector weights;
+    PinholeFundamentalRefiner<UniformWeightVector> refiner(x1, x2, weights);
+    BundleStats stats = lm_impl<decltype(refiner)>(refiner, &factorized, opt, le_zach_callback(opt));
+    *F = factorized.F();
+    return stats;
+}
+BundleStats ref_lm_hom(const std::vector<Point2D> &x1, const std::vector<Point2D> &x2, Eigen::Matrix3d *H, const BundleOptions &opt) {
+    UniformWeightVector weights;
+    PinholeHomographyRefiner<UniformWeightVector> refiner(x1, x2, weights);
+    return lm_impl<decltype(refiner)>(refiner, H, opt, le_zach_callback(opt));
+}
+BundleOptions lo_bundle(double max_error) { // estimators/absolute_pose.cc:61-64 (same in the other three)
+    BundleOptions b;
+    b.loss_type = BundleOptions::LossType::TRUNCATED;
+    b.loss_scale = max_error;
+    b.max_iterations = 25;
+    return b;
+}
+bool use_oracle_lm() { return std::getenv("REF_USE_ORACLE_LM") != nullptr; }
+
 // Adapters with the reference's estimator concept (ransac_impl.h:77-97).  generate_models / score_model follow
 // estimators/absolute_pose.cc:46-58, relative_pose.cc:48-60 and :384-403, homography.cc:36-52 line by line and
-// call the REFERENCE's sampler, solvers and scoring; refine_model calls the oracle's LM (see file header).
+// call the REFERENCE's sampler, solvers, scoring and (refine_model) refiners + LM loop.
 struct AbsEst {
     AbsEst(const RansacOptions &ro, double max_error, const std::vector<Point2D> &x_, const std::vector<Point3D> &X_)
         : sample_sz(3), num_data(x_.size()), thr(max_error), x(x_), X(X_), sampler(num_data, sample_sz, ro),
@@ -139,6 +211,14 @@ struct AbsEst {
         return compute_msac_score(pose, x, X, thr * thr, inlier_count);
     }
     void refine_model(CameraPose *pose) const {
+        if (!use_oracle_lm()) {
+            Image image;
+            image.pose = *pose;
+            image.camera.model_id = NullCameraModel::model_id; // bundle.cc:84-92
+            ref_lm_abs(x, X, &image, lo_bundle(thr));
+            *pose = image.pose;
+            return;
+        }
         double p[7];
         pose_out(*pose, p);
         orc_camera cam;
@@ -201,6 +281,15 @@ struct RelEst : TwoViewBase {
         int num_inl = get_inliers(*pose, x1, x2, 5 * (thr * thr), &inl);
         if (num_inl <= 5)
             return;
+        if (!use_oracle_lm()) {
+            std::vector<Point2D> a, b;
+            a.reserve(num_inl), b.reserve(num_inl);
+            for (size_t k = 0; k < x1.size(); ++k)
+                if (inl[k])
+                    a.push_back(x1[k]), b.push_back(x2[k]);
+            ref_lm_rel(a, b, pose, lo_bundle(thr));
+            return;
+        }
         std::vector<double> a, b;
         for (size_t k = 0; k < x1.size(); ++k)
             if (inl[k]) {
@@ -231,6 +320,10 @@ struct FundEst : TwoViewBase {
         return compute_sampson_msac_score(F, x1, x2, thr * thr, cnt);
     }
     void refine_model(Eigen::Matrix3d *F) const {
+        if (!use_oracle_lm()) {
+            ref_lm_fund(x1, x2, F, lo_bundle(thr));
+            return;
+        }
         double m[9];
         mat_out(*F, m);
         orc_bundle_opt bo = lo_opt(thr);
@@ -253,6 +346,10 @@ struct HomEst : TwoViewBase {
         return compute_homography_msac_score(H, x1, x2, thr * thr, cnt);
     }
     void refine_model(Eigen::Matrix3d *H) const {
+        if (!use_oracle_lm()) {
+            ref_lm_hom(x1, x2, H, lo_bundle(thr));
+            return;
+        }
         double m[9];
         mat_out(*H, m);
         orc_bundle_opt bo = lo_opt(thr);
@@ -431,6 +528,38 @@ double ref_normalize_points(double *x1, double *x2, size_t n, double *T1, double
     mat_out(A, T1);
     mat_out(B, T2);
     return s;
+}
+
+void ref_bundle_adjust(const double *x, const double *X, size_t n, const orc_camera *cam, double *pose7,
+                       const orc_bundle_opt *opt, orc_bundle_stats *st) {
+    Image image;
+    image.pose = pose_in(pose7);
+    image.camera.model_id = cam ? cam->model_id : -1;
+    if (cam) {
+        image.camera.width = cam->width;
+        image.camera.height = cam->height;
+        image.camera.params.assign(cam->params, cam->params + cam->num_params);
+    }
+    bstats_out(ref_lm_abs(pts2(x, n), pts3(X, n), &image, bopt(*opt)), st);
+    pose_out(image.pose, pose7);
+}
+void ref_refine_relpose(const double *x1, const double *x2, size_t n, double *pose7, const orc_bundle_opt *opt,
+                        orc_bundle_stats *st) {
+    CameraPose pose = pose_in(pose7);
+    bstats_out(ref_lm_rel(pts2(x1, n), pts2(x2, n), &pose, bopt(*opt)), st);
+    pose_out(pose, pose7);
+}
+void ref_refine_fundamental(const double *x1, const double *x2, size_t n, double *F9, const orc_bundle_opt *opt,
+                            orc_bundle_stats *st) {
+    Eigen::Matrix3d F = mat_in(F9);
+    bstats_out(ref_lm_fund(pts2(x1, n), pts2(x2, n), &F, bopt(*opt)), st);
+    mat_out(F, F9);
+}
+void ref_refine_homography(const double *x1, const double *x2, size_t n, double *H9, const orc_bundle_opt *opt,
+                           orc_bundle_stats *st) {
+    Eigen::Matrix3d H = mat_in(H9);
+    bstats_out(ref_lm_hom(pts2(x1, n), pts2(x2, n), &H, bopt(*opt)), st);
+    mat_out(H, H9);
 }
 
 // ransac.cc:44-57, 142-154, 248-262, 300-314 with the adapters above

@@ -283,33 +283,48 @@ struct Normal { // jacobian_accumulator.h:46-166.  NB: ONE counter shared by bot
         }
         for (int i = 0; i < k; ++i)
             A[i][i] += (damping == 1) ? std::max(A[i][i] * lambda, 1e-8) : lambda;
-        // Cholesky A = L L^T (row-oriented, as Eigen's unblocked LLT), then two triangular solves
+        // Cholesky A = L L^T with the operation order of Eigen's unblocked LLT (Eigen/src/Cholesky/LLT.h,
+        // llt_inplace<Lower>::unblocked): per column c, x = A_cc - |A10|^2 (squared norm summed first),
+        // A21 = (A21 - A20 * A10^T) / x (dot product summed first); then L y = b by column-oriented updates and
+        // L^T x = y by "row dot product, then subtract" (Eigen's triangular_solve_vector, col-/row-major cases).
         for (int c = 0; c < k; ++c) {
             double d = A[c][c];
-            for (int m = 0; m < c; ++m)
-                d -= A[c][m] * A[c][m];
+            if (c > 0) {
+                double sq = A[c][0] * A[c][0];
+                for (int m = 1; m < c; ++m)
+                    sq += A[c][m] * A[c][m];
+                d -= sq;
+            }
             if (d <= 0)
                 break; // not positive definite: Eigen stops factorising and solves with what it has
             d = std::sqrt(d);
             A[c][c] = d;
             for (int r = c + 1; r < k; ++r) {
                 double s = A[r][c];
-                for (int m = 0; m < c; ++m)
-                    s -= A[r][m] * A[c][m];
+                if (c > 0) {
+                    double dot = A[r][0] * A[c][0];
+                    for (int m = 1; m < c; ++m)
+                        dot += A[r][m] * A[c][m];
+                    s -= dot;
+                }
                 A[r][c] = s / d;
             }
         }
+        for (int i = 0; i < k; ++i)
+            sol[i] = b[i];
         for (int i = 0; i < k; ++i) {
-            double s = b[i];
-            for (int j = 0; j < i; ++j)
-                s -= A[i][j] * sol[j];
-            sol[i] = s / A[i][i];
+            sol[i] /= A[i][i];
+            for (int r = i + 1; r < k; ++r)
+                sol[r] -= sol[i] * A[r][i];
         }
         for (int i = k - 1; i >= 0; --i) {
-            double s = sol[i];
-            for (int j = i + 1; j < k; ++j)
-                s -= A[j][i] * sol[j];
-            sol[i] = s / A[i][i];
+            if (i + 1 < k) {
+                double dot = A[i + 1][i] * sol[i + 1];
+                for (int j = i + 2; j < k; ++j)
+                    dot += A[j][i] * sol[j];
+                sol[i] -= dot;
+            }
+            sol[i] /= A[i][i];
         }
     }
     double predicted_decrease(const double *step, double lambda) const {

@@ -314,33 +314,46 @@ template <int K> PL_HD void lm_solve(LMControl &c, const double *normal, bool fr
     }
     for (int i = 0; i < K; ++i)
         A[i * K + i] += (c.opt.damping == 1) ? fmax(A[i * K + i] * c.lambda, 1e-8) : c.lambda;
-    // Cholesky (row-oriented like Eigen's unblocked LLT) and the two triangular solves
+    // Cholesky with the operation order of Eigen's unblocked LLT (squared norm / dot product summed first, then
+    // subtracted), forward solve by column-oriented updates, backward solve by row dot product then subtract
     for (int col = 0; col < K; ++col) {
         double d = A[col * K + col];
-        for (int m = 0; m < col; ++m)
-            d -= A[col * K + m] * A[col * K + m];
+        if (col > 0) {
+            double sq = A[col * K] * A[col * K];
+            for (int m = 1; m < col; ++m)
+                sq += A[col * K + m] * A[col * K + m];
+            d -= sq;
+        }
         if (d <= 0)
             break;
         d = sqrt(d);
         A[col * K + col] = d;
         for (int r = col + 1; r < K; ++r) {
             double s = A[r * K + col];
-            for (int m = 0; m < col; ++m)
-                s -= A[r * K + m] * A[col * K + m];
+            if (col > 0) {
+                double dot = A[r * K] * A[col * K];
+                for (int m = 1; m < col; ++m)
+                    dot += A[r * K + m] * A[col * K + m];
+                s -= dot;
+            }
             A[r * K + col] = s / d;
         }
     }
+    for (int i = 0; i < K; ++i)
+        c.sol[i] = b[i];
     for (int i = 0; i < K; ++i) {
-        double s = b[i];
-        for (int j = 0; j < i; ++j)
-            s -= A[i * K + j] * c.sol[j];
-        c.sol[i] = s / A[i * K + i];
+        c.sol[i] /= A[i * K + i];
+        for (int r = i + 1; r < K; ++r)
+            c.sol[r] -= c.sol[i] * A[r * K + i];
     }
     for (int i = K - 1; i >= 0; --i) {
-        double s = c.sol[i];
-        for (int j = i + 1; j < K; ++j)
-            s -= A[j * K + i] * c.sol[j];
-        c.sol[i] = s / A[i * K + i];
+        if (i + 1 < K) {
+            double dot = A[(i + 1) * K + i] * c.sol[i + 1];
+            for (int j = i + 2; j < K; ++j)
+                dot += A[j * K + i] * c.sol[j];
+            c.sol[i] -= dot;
+        }
+        c.sol[i] /= A[i * K + i];
     }
     double sn = 0;
     for (int i = 0; i < K; ++i)
