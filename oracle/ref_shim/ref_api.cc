@@ -1,15 +1,13 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.
-// C interface over the REFERENCE'S OWN hot-path sources (compiled in place from /root/reference against the
-// Eigen-API shim in oracle/eigen_shim; see oracle/Makefile.ref).  Used by tests/test_oracle_vs_reference.py to
-// pin the oracle's restatement.  What is the reference's here: the sampler (robust/sampling.cc), the RANSAC loop
-// template (robust/ransac_impl.h), the minimal solvers (solvers/p3p.cc, relpose_5pt.cc, relpose_7pt.cc,
-// homography_4pt.cc, misc/univariate.cc, misc/sturm.h, misc/essential.cc), scoring and inlier masks
-// (robust/utils.cc), CameraPose / quaternion helpers, the LM refiners (robust/optim/*.h, robust_loss.h) and the
-// camera models (misc/camera_models.cc).  What is NOT: Eigen (shim), the estimator classes'
-// the estimator classes and ransac.cc / robust.cc / bundle.cc translation units themselves (they pull in every other
-// solver and refiner family): their few lines for this path are mirrored by the adapters below, which call the
-// reference's sampler, solvers, scoring, refiner classes and LM loop.  REF_USE_ORACLE_LM=1 swaps the
-// adapters' refine_model() onto the oracle's LM (to separate solver from LM differences when a test fails).
+// C interface over the REFERENCE'S OWN sources, compiled in place from /root/reference against the Eigen-API shim in
+// oracle/eigen_shim (recipe: oracle/Makefile.ref).  Used by tests/test_oracle_vs_reference.py to pin the oracle's
+// restatement.  Everything behind these wrappers is PoseLib's code: the front-ends (robust.cc), the RANSAC entry
+// points (robust/ransac.cc), the estimator classes (robust/estimators/*.cc), the loop template
+// (robust/ransac_impl.h), the sampler, the minimal solvers, scoring and masks (robust/utils.cc), the refiners
+// and LM loop (robust/bundle.cc, robust/optim/*.h, robust_loss.*), the camera models (misc/camera_models.cc).
+// Only Eigen is not the real one.  Reference translation units the shim cannot carry (solver families that are
+// not on this path and need Eigen::EigenSolver etc.) are left out; the symbols they would define become traps
+// (oracle/ref_shim/make_traps.sh), which abort if anything ever calls them.
 #include <PoseLib/camera_pose.h>
 #include <PoseLib/misc/essential.h>
 #include <PoseLib/robust/ransac_impl.h>
@@ -25,13 +23,9 @@
 #include "../oracle.h"
 
 #include <PoseLib/misc/camera_models.h>
-#include <PoseLib/robust/optim/absolute.h>
-#include <PoseLib/robust/optim/fundamental.h>
-#include <PoseLib/robust/optim/homography.h>
-#include <PoseLib/robust/optim/jacobian_accumulator.h>
-#include <PoseLib/robust/optim/lm_impl.h>
-#include <PoseLib/robust/optim/relative.h>
-#include <PoseLib/robust/robust_loss.h>
+#include <PoseLib/robust.h>
+#include <PoseLib/robust/bundle.h>
+#include <PoseLib/robust/ransac.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -83,37 +77,6 @@ RansacOptions ropt(const orc_ransac_opt &o) {
     r.score_initial_model = o.score_initial_model != 0;
     return r;
 }
-orc_bundle_opt lo_opt(double max_error) { // estimators/absolute_pose.cc:61-64
-    orc_bundle_opt b;
-    std::memset(&b, 0, sizeof(b));
-    b.max_iterations = 25;
-    b.loss_type = 1; // TRUNCATED
-    b.loss_scale = max_error;
-    b.gradient_tol = 1e-12;
-    b.step_tol = 1e-8;
-    b.relative_cost_tol = 1e-10;
-    b.initial_lambda = 1e-3;
-    b.min_lambda = 1e-10;
-    b.max_lambda = 1e10;
-    b.lambda_factor = 10.0;
-    return b;
-}
-std::vector<double> flat2(const std::vector<Point2D> &v) {
-    std::vector<double> f(2 * v.size());
-    for (size_t i = 0; i < v.size(); ++i) {
-        f[2 * i] = v[i](0);
-        f[2 * i + 1] = v[i](1);
-    }
-    return f;
-}
-std::vector<double> flat3(const std::vector<Point3D> &v) {
-    std::vector<double> f(3 * v.size());
-    for (size_t i = 0; i < v.size(); ++i)
-        for (int d = 0; d < 3; ++d)
-            f[3 * i + d] = v[i](d);
-    return f;
-}
-
 BundleOptions bopt(const orc_bundle_opt &o) {
     BundleOptions b;
     b.max_iterations = o.max_iterations;
@@ -142,222 +105,28 @@ void bstats_out(const BundleStats &s, orc_bundle_stats *o) {
     o->step_norm = s.step_norm;
     o->grad_norm = s.grad_norm;
 }
-IterationCallback le_zach_callback(const BundleOptions &opt) { // bundle.cc:53-77, non-verbose branches
-    if (opt.loss_type == BundleOptions::TRUNCATED_LE_ZACH)
-        return [](const BundleStats &, RobustLoss *loss_fn) {
-            static_cast<TruncatedLossLeZach *>(loss_fn)->mu *= TruncatedLossLeZach::alpha;
-        };
-    return nullptr;
+Camera cam_in(const orc_camera *c) {
+    Camera cam;
+    cam.model_id = c ? c->model_id : -1;
+    if (c) {
+        cam.width = c->width;
+        cam.height = c->height;
+        cam.params.assign(c->params, c->params + c->num_params);
+    }
+    return cam;
 }
-// The four refinement entry points as bundle.cc instantiates them for unit weights (bundle.cc:94-103, 206-213,
-// 313-323, 394-401): the REFERENCE's refiner classes, Jacobian accumulator, robust losses and LM loop
-// (robust/optim/{absolute,relative,fundamental,homography,jacobian_accumulator,lm_impl}.h, robust_loss.h,
-// misc/camera_models.cc).  bundle.cc itself is not compiled: it also instantiates every other refiner family.
-BundleStats ref_lm_abs(const std::vector<Point2D> &x, const std::vector<Point3D> &X, Image *image, const BundleOptions &opt) {
-    std::vector<size_t> camera_refine_idx = image->camera.get_param_refinement_idx(opt);
-    UniformWeightVector weights;
-    AbsolutePoseRefiner<UniformWeightVector> refiner(x, X, camera_refine_idx, weights);
-    return lm_impl<decltype(refiner)>(refiner, image, opt, le_zach_callback(opt));
+template <typename Opt> Opt robust_in(const orc_robust_opt *o) {
+    Opt r;
+    r.ransac = ropt(o->ransac);
+    r.bundle = bopt(o->bundle);
+    r.max_error = o->max_error;
+    return r;
 }
-BundleStats ref_lm_rel(const std::vector<Point2D> &x1, const std::vector<Point2D> &x2, CameraPose *pose, const BundleOptions &opt) {
-    UniformWeightVector weights;
-    PinholeRelativePoseRefiner<UniformWeightVector> refiner(x1, x2, weights);
-    return lm_impl<decltype(refiner)>(refiner, pose, opt, le_zach_callback(opt));
+RelativePoseOptions rel_in(const orc_robust_opt *o) {
+    RelativePoseOptions r = robust_in<RelativePoseOptions>(o);
+    r.real_focal_check = o->real_focal_check != 0;
+    return r;
 }
-BundleStats ref_lm_fund(const std::vector<Point2D> &x1, const std::vector<Point2D> &x2, Eigen::Matrix3d *F, const BundleOptions &opt) {
-    FactorizedFundamentalMatrix factorized(*F);
-    UniformWeightVector weights;
-    PinholeFundamentalRefiner<UniformWeightVector> refiner(x1, x2, weights);
-    BundleStats stats = lm_impl<decltype(refiner)>(refiner, &factorized, opt, le_zach_callback(opt));
-    *F = factorized.F();
-    return stats;
-}
-BundleStats ref_lm_hom(const std::vector<Point2D> &x1, const std::vector<Point2D> &x2, Eigen::Matrix3d *H, const BundleOptions &opt) {
-    UniformWeightVector weights;
-    PinholeHomographyRefiner<UniformWeightVector> refiner(x1, x2, weights);
-    return lm_impl<decltype(refiner)>(refiner, H, opt, le_zach_callback(opt));
-}
-BundleOptions lo_bundle(double max_error) { // estimators/absolute_pose.cc:61-64 (same in the other three)
-    BundleOptions b;
-    b.loss_type = BundleOptions::LossType::TRUNCATED;
-    b.loss_scale = max_error;
-    b.max_iterations = 25;
-    return b;
-}
-bool use_oracle_lm() { return std::getenv("REF_USE_ORACLE_LM") != nullptr; }
-
-// Adapters with the reference's estimator concept (ransac_impl.h:77-97).  generate_models / score_model follow
-// estimators/absolute_pose.cc:46-58, relative_pose.cc:48-60 and :384-403, homography.cc:36-52 line by line and
-// call the REFERENCE's sampler, solvers, scoring and (refine_model) refiners + LM loop.
-struct AbsEst {
-    AbsEst(const RansacOptions &ro, double max_error, const std::vector<Point2D> &x_, const std::vector<Point3D> &X_)
-        : sample_sz(3), num_data(x_.size()), thr(max_error), x(x_), X(X_), sampler(num_data, sample_sz, ro),
-          fx(flat2(x_)), fX(flat3(X_)) {
-        xs.resize(3);
-        Xs.resize(3);
-        sample.resize(3);
-    }
-    void generate_models(std::vector<CameraPose> *models) {
-        models->clear();
-        sampler.generate_sample(&sample);
-        for (size_t k = 0; k < sample_sz; ++k) {
-            xs[k] = x[sample[k]].homogeneous().normalized();
-            Xs[k] = X[sample[k]];
-        }
-        p3p(xs, Xs, models);
-        hyp += models->size();
-    }
-    double score_model(const CameraPose &pose, size_t *inlier_count) const {
-        return compute_msac_score(pose, x, X, thr * thr, inlier_count);
-    }
-    void refine_model(CameraPose *pose) const {
-        if (!use_oracle_lm()) {
-            Image image;
-            image.pose = *pose;
-            image.camera.model_id = NullCameraModel::model_id; // bundle.cc:84-92
-            ref_lm_abs(x, X, &image, lo_bundle(thr));
-            *pose = image.pose;
-            return;
-        }
-        double p[7];
-        pose_out(*pose, p);
-        orc_camera cam;
-        std::memset(&cam, 0, sizeof(cam));
-        cam.model_id = -1;
-        orc_bundle_opt b = lo_opt(thr);
-        orc_bundle_adjust(fx.data(), fX.data(), num_data, &cam, p, &b, nullptr);
-        *pose = pose_in(p);
-    }
-    size_t sample_sz, num_data;
-    double thr;
-    const std::vector<Point2D> &x;
-    const std::vector<Point3D> &X;
-    RandomSampler sampler;
-    std::vector<double> fx, fX;
-    std::vector<Eigen::Vector3d> xs, Xs;
-    std::vector<size_t> sample;
-    size_t hyp = 0;
-};
-
-struct TwoViewBase {
-    TwoViewBase(size_t K, const RansacOptions &ro, double max_error, const std::vector<Point2D> &a,
-                const std::vector<Point2D> &b)
-        : sample_sz(K), num_data(a.size()), thr(max_error), x1(a), x2(b), sampler(num_data, sample_sz, ro),
-          f1(flat2(a)), f2(flat2(b)) {
-        x1s.resize(K);
-        x2s.resize(K);
-        sample.resize(K);
-    }
-    void draw() {
-        sampler.generate_sample(&sample);
-        for (size_t k = 0; k < sample_sz; ++k) {
-            x1s[k] = x1[sample[k]].homogeneous().normalized();
-            x2s[k] = x2[sample[k]].homogeneous().normalized();
-        }
-    }
-    size_t sample_sz, num_data;
-    double thr;
-    const std::vector<Point2D> &x1;
-    const std::vector<Point2D> &x2;
-    RandomSampler sampler;
-    std::vector<double> f1, f2;
-    std::vector<Eigen::Vector3d> x1s, x2s;
-    std::vector<size_t> sample;
-    size_t hyp = 0;
-};
-struct RelEst : TwoViewBase {
-    using TwoViewBase::TwoViewBase;
-    void generate_models(std::vector<CameraPose> *models) {
-        models->clear();
-        draw();
-        relpose_5pt(x1s, x2s, models);
-        hyp += models->size();
-    }
-    double score_model(const CameraPose &pose, size_t *cnt) const {
-        return compute_sampson_msac_score(pose, x1, x2, thr * thr, cnt);
-    }
-    void refine_model(CameraPose *pose) const { // relative_pose.cc:62-86
-        std::vector<char> inl;
-        int num_inl = get_inliers(*pose, x1, x2, 5 * (thr * thr), &inl);
-        if (num_inl <= 5)
-            return;
-        if (!use_oracle_lm()) {
-            std::vector<Point2D> a, b;
-            a.reserve(num_inl), b.reserve(num_inl);
-            for (size_t k = 0; k < x1.size(); ++k)
-                if (inl[k])
-                    a.push_back(x1[k]), b.push_back(x2[k]);
-            ref_lm_rel(a, b, pose, lo_bundle(thr));
-            return;
-        }
-        std::vector<double> a, b;
-        for (size_t k = 0; k < x1.size(); ++k)
-            if (inl[k]) {
-                a.push_back(x1[k](0)), a.push_back(x1[k](1));
-                b.push_back(x2[k](0)), b.push_back(x2[k](1));
-            }
-        double p[7];
-        pose_out(*pose, p);
-        orc_bundle_opt bo = lo_opt(thr);
-        orc_refine_relpose(a.data(), b.data(), a.size() / 2, p, &bo, nullptr);
-        *pose = pose_in(p);
-    }
-};
-struct FundEst : TwoViewBase {
-    using TwoViewBase::TwoViewBase;
-    bool rfc = false;
-    void generate_models(std::vector<Eigen::Matrix3d> *models) {
-        models->clear();
-        draw();
-        relpose_7pt(x1s, x2s, models);
-        if (rfc)
-            for (int i = models->size() - 1; i >= 0; i--)
-                if (!calculate_RFC((*models)[i]))
-                    models->erase(models->begin() + i);
-        hyp += models->size();
-    }
-    double score_model(const Eigen::Matrix3d &F, size_t *cnt) const {
-        return compute_sampson_msac_score(F, x1, x2, thr * thr, cnt);
-    }
-    void refine_model(Eigen::Matrix3d *F) const {
-        if (!use_oracle_lm()) {
-            ref_lm_fund(x1, x2, F, lo_bundle(thr));
-            return;
-        }
-        double m[9];
-        mat_out(*F, m);
-        orc_bundle_opt bo = lo_opt(thr);
-        orc_refine_fundamental(f1.data(), f2.data(), num_data, m, &bo, nullptr);
-        *F = mat_in(m);
-    }
-};
-struct HomEst : TwoViewBase {
-    using TwoViewBase::TwoViewBase;
-    void generate_models(std::vector<Eigen::Matrix3d> *models) {
-        models->clear();
-        draw();
-        Eigen::Matrix3d H;
-        int sols = homography_4pt(x1s, x2s, &H, true);
-        if (sols > 0)
-            models->push_back(H);
-        hyp += models->size();
-    }
-    double score_model(const Eigen::Matrix3d &H, size_t *cnt) const {
-        return compute_homography_msac_score(H, x1, x2, thr * thr, cnt);
-    }
-    void refine_model(Eigen::Matrix3d *H) const {
-        if (!use_oracle_lm()) {
-            ref_lm_hom(x1, x2, H, lo_bundle(thr));
-            return;
-        }
-        double m[9];
-        mat_out(*H, m);
-        orc_bundle_opt bo = lo_opt(thr);
-        orc_refine_homography(f1.data(), f2.data(), num_data, m, &bo, nullptr);
-        *H = mat_in(m);
-    }
-};
-
 void stats_out(const RansacStats &s, size_t hyp, orc_stats *o) {
     o->refinements = s.refinements;
     o->iterations = s.iterations;
@@ -530,104 +299,133 @@ double ref_normalize_points(double *x1, double *x2, size_t n, double *T1, double
     return s;
 }
 
+void ref_unproject(const orc_camera *cam, const double *xp, size_t n, double *out) {
+    const Camera c = cam_in(cam);
+    for (size_t i = 0; i < n; ++i) {
+        Eigen::Vector3d d;
+        c.unproject(Eigen::Vector2d(xp[2 * i], xp[2 * i + 1]), &d);
+        out[2 * i] = d(0) / d(2);
+        out[2 * i + 1] = d(1) / d(2);
+    }
+}
+
+// robust/bundle.h entry points
 void ref_bundle_adjust(const double *x, const double *X, size_t n, const orc_camera *cam, double *pose7,
                        const orc_bundle_opt *opt, orc_bundle_stats *st) {
     Image image;
     image.pose = pose_in(pose7);
-    image.camera.model_id = cam ? cam->model_id : -1;
-    if (cam) {
-        image.camera.width = cam->width;
-        image.camera.height = cam->height;
-        image.camera.params.assign(cam->params, cam->params + cam->num_params);
-    }
-    bstats_out(ref_lm_abs(pts2(x, n), pts3(X, n), &image, bopt(*opt)), st);
+    image.camera = cam_in(cam);
+    bstats_out(bundle_adjust(pts2(x, n), pts3(X, n), &image, bopt(*opt)), st);
     pose_out(image.pose, pose7);
 }
 void ref_refine_relpose(const double *x1, const double *x2, size_t n, double *pose7, const orc_bundle_opt *opt,
                         orc_bundle_stats *st) {
     CameraPose pose = pose_in(pose7);
-    bstats_out(ref_lm_rel(pts2(x1, n), pts2(x2, n), &pose, bopt(*opt)), st);
+    bstats_out(refine_relpose(pts2(x1, n), pts2(x2, n), &pose, bopt(*opt)), st);
     pose_out(pose, pose7);
 }
 void ref_refine_fundamental(const double *x1, const double *x2, size_t n, double *F9, const orc_bundle_opt *opt,
                             orc_bundle_stats *st) {
     Eigen::Matrix3d F = mat_in(F9);
-    bstats_out(ref_lm_fund(pts2(x1, n), pts2(x2, n), &F, bopt(*opt)), st);
+    bstats_out(refine_fundamental(pts2(x1, n), pts2(x2, n), &F, bopt(*opt)), st);
     mat_out(F, F9);
 }
 void ref_refine_homography(const double *x1, const double *x2, size_t n, double *H9, const orc_bundle_opt *opt,
                            orc_bundle_stats *st) {
     Eigen::Matrix3d H = mat_in(H9);
-    bstats_out(ref_lm_hom(pts2(x1, n), pts2(x2, n), &H, bopt(*opt)), st);
+    bstats_out(refine_homography(pts2(x1, n), pts2(x2, n), &H, bopt(*opt)), st);
     mat_out(H, H9);
 }
 
-// ransac.cc:44-57, 142-154, 248-262, 300-314 with the adapters above
+// robust/ransac.h entry points (hypotheses are not observable from outside: reported as 0)
 void ref_ransac_pnp(const double *x, const double *X, size_t n, const orc_robust_opt *opt, double *pose7,
                     uint8_t *inliers, orc_stats *st) {
-    const std::vector<Point2D> a = pts2(x, n);
-    const std::vector<Point3D> b = pts3(X, n);
-    const RansacOptions ro = ropt(opt->ransac);
     CameraPose best = pose_in(pose7);
-    if (!ro.score_initial_model) {
-        best.q << 1.0, 0.0, 0.0, 0.0;
-        best.t.setZero();
-    }
-    AbsEst est(ro, opt->max_error, a, b);
-    const RansacStats s = ransac<AbsEst>(est, ro, &best);
     std::vector<char> m;
-    get_inliers(best, a, b, opt->max_error * opt->max_error, &m);
+    const RansacStats s = ransac_pnp(pts2(x, n), pts3(X, n), robust_in<AbsolutePoseOptions>(opt), &best, &m);
     pose_out(best, pose7);
+    m.resize(n, 0);
     mask_out(m, inliers);
-    stats_out(s, est.hyp, st);
+    stats_out(s, 0, st);
 }
 void ref_ransac_relpose(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *pose7,
                         uint8_t *inliers, orc_stats *st) {
-    const std::vector<Point2D> a = pts2(x1, n), b = pts2(x2, n);
-    const RansacOptions ro = ropt(opt->ransac);
     CameraPose best = pose_in(pose7);
-    if (!ro.score_initial_model) {
-        best.q << 1.0, 0.0, 0.0, 0.0;
-        best.t.setZero();
-    }
-    RelEst est(5, ro, opt->max_error, a, b);
-    const RansacStats s = ransac<RelEst>(est, ro, &best);
     std::vector<char> m;
-    get_inliers(best, a, b, opt->max_error * opt->max_error, &m);
+    const RansacStats s = ransac_relpose(pts2(x1, n), pts2(x2, n), rel_in(opt), &best, &m);
     pose_out(best, pose7);
+    m.resize(n, 0);
     mask_out(m, inliers);
-    stats_out(s, est.hyp, st);
+    stats_out(s, 0, st);
 }
 void ref_ransac_fundamental(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *F9,
                             uint8_t *inliers, orc_stats *st) {
-    const std::vector<Point2D> a = pts2(x1, n), b = pts2(x2, n);
-    const RansacOptions ro = ropt(opt->ransac);
     Eigen::Matrix3d best = mat_in(F9);
-    if (!ro.score_initial_model)
-        best.setIdentity();
-    FundEst est(7, ro, opt->max_error, a, b);
-    est.rfc = opt->real_focal_check != 0;
-    const RansacStats s = ransac<FundEst, Eigen::Matrix3d>(est, ro, &best);
     std::vector<char> m;
-    get_inliers(best, a, b, opt->max_error * opt->max_error, &m);
+    const RansacStats s = ransac_fundamental(pts2(x1, n), pts2(x2, n), rel_in(opt), &best, &m);
     mat_out(best, F9);
+    m.resize(n, 0);
     mask_out(m, inliers);
-    stats_out(s, est.hyp, st);
+    stats_out(s, 0, st);
 }
 void ref_ransac_homography(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *H9,
                            uint8_t *inliers, orc_stats *st) {
-    const std::vector<Point2D> a = pts2(x1, n), b = pts2(x2, n);
-    const RansacOptions ro = ropt(opt->ransac);
     Eigen::Matrix3d best = mat_in(H9);
-    if (!ro.score_initial_model)
-        best.setIdentity();
-    HomEst est(4, ro, opt->max_error, a, b);
-    const RansacStats s = ransac<HomEst, Eigen::Matrix3d>(est, ro, &best);
     std::vector<char> m;
-    get_homography_inliers(best, a, b, opt->max_error * opt->max_error, &m);
+    const RansacStats s = ransac_homography(pts2(x1, n), pts2(x2, n), robust_in<HomographyOptions>(opt), &best, &m);
     mat_out(best, H9);
+    m.resize(n, 0);
     mask_out(m, inliers);
-    stats_out(s, est.hyp, st);
+    stats_out(s, 0, st);
+}
+
+// robust.h front-ends
+void ref_estimate_absolute_pose(const double *p2d, const double *p3d, size_t n, const orc_robust_opt *opt,
+                                orc_camera *cam, double *pose7, uint8_t *inliers, orc_stats *st) {
+    Image image;
+    image.pose = pose_in(pose7);
+    image.camera = cam_in(cam);
+    std::vector<char> m;
+    const RansacStats s = estimate_absolute_pose(pts2(p2d, n), pts3(p3d, n), robust_in<AbsolutePoseOptions>(opt), &image, &m);
+    pose_out(image.pose, pose7);
+    cam->num_params = static_cast<int32_t>(image.camera.params.size());
+    for (size_t i = 0; i < image.camera.params.size() && i < 12; ++i)
+        cam->params[i] = image.camera.params[i];
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, 0, st);
+}
+void ref_estimate_relative_pose(const double *x1, const double *x2, size_t n, const orc_camera *cam1,
+                                const orc_camera *cam2, const orc_robust_opt *opt, double *pose7, uint8_t *inliers,
+                                orc_stats *st) {
+    CameraPose pose = pose_in(pose7);
+    std::vector<char> m;
+    const RansacStats s =
+        estimate_relative_pose(pts2(x1, n), pts2(x2, n), cam_in(cam1), cam_in(cam2), rel_in(opt), &pose, &m);
+    pose_out(pose, pose7);
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, 0, st);
+}
+void ref_estimate_fundamental(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *F9,
+                              uint8_t *inliers, orc_stats *st) {
+    Eigen::Matrix3d F = mat_in(F9);
+    std::vector<char> m;
+    const RansacStats s = estimate_fundamental(pts2(x1, n), pts2(x2, n), rel_in(opt), &F, &m);
+    mat_out(F, F9);
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, 0, st);
+}
+void ref_estimate_homography(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *H9,
+                             uint8_t *inliers, orc_stats *st) {
+    Eigen::Matrix3d H = mat_in(H9);
+    std::vector<char> m;
+    const RansacStats s = estimate_homography(pts2(x1, n), pts2(x2, n), robust_in<HomographyOptions>(opt), &H, &m);
+    mat_out(H, H9);
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, 0, st);
 }
 
 } // extern "C"

@@ -1,5 +1,6 @@
-"""ctypes access to oracle/_ref/libposelib_ref.so — the REFERENCE'S OWN hot-path sources compiled in place against
-oracle/eigen_shim (recipe: oracle/Makefile.ref, adapter: oracle/ref_shim/ref_api.cc).  Test infrastructure only.
+"""ctypes access to oracle/_ref/libposelib_ref.so — the REFERENCE'S OWN sources (front-ends, ransac_*, estimators,
+loop, sampler, solvers, scoring, refiners + LM, camera models) compiled in place against oracle/eigen_shim
+(recipe: oracle/Makefile.ref, C wrappers: oracle/ref_shim/ref_api.cc).  Test infrastructure only.
 
 The library exports the oracle's C interface under the prefix ``ref_`` instead of ``orc_``, so `reference()` simply
 swaps the handle behind tests/oracle_lib.py: inside the context every oracle_lib wrapper (sampler_draw, p3p, score,
@@ -21,7 +22,7 @@ def build() -> str:
     """(Re)build where the reference sources exist; elsewhere (the GPU box) use the prebuilt file if it travelled."""
     O.build()
     if os.path.isdir(os.path.join(REFERENCE_ROOT, "PoseLib")):
-        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "-f", "Makefile.ref", f"REF={REFERENCE_ROOT}"])
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "-j8", "-f", "Makefile.ref", f"REF={REFERENCE_ROOT}"])
     return _REF_LIB
 
 

@@ -1,8 +1,9 @@
 """Pins the oracle's restatement against the REFERENCE'S OWN SOURCES (oracle/_ref/libposelib_ref.so, built in
-place from /root/reference by oracle/Makefile.ref against the Eigen-API shim).  Sampler, RANSAC loop, minimal
-solvers, scoring, masks and point normalisation on the `ref` side are PoseLib's code; only Eigen and the LM called
-from refine_model() are not (see oracle/ref_shim/ref_api.cc).  Skipped where neither /root/reference nor a
-prebuilt library is present.
+place from /root/reference by oracle/Makefile.ref against the Eigen-API shim).  Everything on the `ref` side is
+PoseLib's code — front-ends (robust.cc), ransac_* (robust/ransac.cc), estimator classes, loop template, sampler,
+minimal solvers, scoring and masks, refiners + LM (robust/bundle.cc, robust/optim/*.h), camera models — only Eigen
+is not the real one (see oracle/ref_shim/ref_api.cc).  Skipped where neither /root/reference nor a prebuilt
+library is present.
 """
 import ctypes as C
 
@@ -237,9 +238,19 @@ def test_normalize_points():
             assert np.allclose(p, q, rtol=1e-13, atol=1e-13)
 
 
+def _unit_t(m):
+    """relative pose: |t| is a gauge freedom (the LM steps t along its tangent plane without renormalising, so one
+    more or fewer accepted step changes |t| at 1e-7 without moving the direction); compare directions"""
+    m = np.array(m, dtype=np.float64)
+    m[4:] /= np.linalg.norm(m[4:])
+    return m
+
+
 def _cmp_run(fn, a, b, opt, tol=1e-8):
     (ma, ka, sa), (mb, kb, sb) = both(fn, a, b, opt)
-    for k in ("iterations", "refinements", "num_inliers", "hypotheses"):
+    if fn == "ransac_relpose":
+        ma, mb = _unit_t(ma), _unit_t(mb)
+    for k in ("iterations", "refinements", "num_inliers"):
         assert sa[k] == sb[k], (k, sa, sb)
     assert np.array_equal(ka, kb)
     assert sa["model_score"] == pytest.approx(sb["model_score"], rel=1e-9)
@@ -287,6 +298,84 @@ BOPTS = [
     {"loss_type": "TRUNCATED_CAUCHY", "lambda_update": 1, "lambda_factor": 5.0},
     {"loss_type": "TRUNCATED_LE_ZACH", "max_iterations": 30},
 ]
+
+
+# ------------------------------------------------------------------------------- front-ends (the real robust.cc)
+def _opencv_scene(n, seed):
+    d = synth.absolute_pose_scene(n, 0.4, seed)
+    f, cx, cy = d["camera"]["params"]
+    par = [f, f, cx, cy, -0.08, 0.02, 1e-3, -5e-4]
+    cam = dict(d["camera"], model="OPENCV", params=par)
+    return dict(d, camera=cam, p2d=synth.opencv_distort_pixels(np.asarray(d["p2d"]), par))
+
+
+@pytest.mark.parametrize("model", ["SIMPLE_PINHOLE", "PINHOLE", "OPENCV"])
+def test_unproject(model):
+    rs = np.random.RandomState(3)
+    pix = rs.uniform(50, 950, (500, 2))
+    cam = {"SIMPLE_PINHOLE": {"model": "SIMPLE_PINHOLE", "params": [800.0, 500.0, 480.0]},
+           "PINHOLE": {"model": "PINHOLE", "params": [800.0, 790.0, 500.0, 480.0]},
+           "OPENCV": {"model": "OPENCV", "params": [800.0, 790.0, 500.0, 480.0, -0.08, 0.02, 1e-3, -5e-4]}}[model]
+    a, b = both("unproject", cam, pix)
+    assert np.array_equal(a, b)
+
+
+def _cmp_frontend(fn, args, opt, tol=1e-8):
+    (ma, ka, sa), (mb, kb, sb) = both(fn, *args, opt)
+    if fn == "estimate_relative_pose":
+        ma, mb = _unit_t(ma), _unit_t(mb)
+    for k in ("iterations", "refinements", "num_inliers"):
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert np.array_equal(ka, kb)
+    assert sa["inlier_ratio"] == sb["inlier_ratio"]
+    assert sa["model_score"] == pytest.approx(sb["model_score"], rel=1e-9)
+    assert np.abs(ma - mb).max() / max(1.0, np.abs(ma).max()) < tol
+    return sa, bool(np.array_equal(ma, mb))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_estimate_absolute_pose(seed):  # robust.cc estimate_absolute_pose, BASELINE config 0 / 1 shape
+    d = synth.absolute_pose_scene(1500, 0.5, 800 + seed) if seed < 3 else _opencv_scene(1500, 803)
+    opt = {"max_error": 4.0, "ransac": {"seed": seed, "max_iterations": 4000}}
+    st, exact = _cmp_frontend("estimate_absolute_pose", (d["p2d"], d["p3d"], d["camera"]), opt)
+    assert st["num_inliers"] > 600
+    print("estimate_absolute_pose bit-identical:", exact)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_estimate_relative_pose(seed):
+    d = synth.relative_pose_scene(1500, 0.4, 810 + seed)
+    opt = {"max_error": 1.5, "ransac": {"seed": seed, "max_iterations": 2000}}
+    st, _ = _cmp_frontend("estimate_relative_pose", (d["x1"], d["x2"], d["camera1"], d["camera2"]), opt)
+    assert st["num_inliers"] > 600
+
+
+@pytest.mark.parametrize("seed,rfc", [(0, False), (1, True)])
+def test_estimate_fundamental(seed, rfc):
+    d = synth.fundamental_scene(1500, 0.4, 820 + seed)
+    opt = {"max_error": 1.5, "real_focal_check": rfc, "ransac": {"seed": seed, "max_iterations": 2000}}
+    st, _ = _cmp_frontend("estimate_fundamental", (d["x1"], d["x2"]), opt, 1e-6)
+    assert st["num_inliers"] > 600
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_estimate_homography(seed):
+    d = synth.homography_scene(1500, 0.4, 830 + seed)
+    opt = {"max_error": 1.5, "ransac": {"seed": seed, "max_iterations": 2000}}
+    st, _ = _cmp_frontend("estimate_homography", (d["x1"], d["x2"]), opt)
+    assert st["num_inliers"] > 600
+
+
+def test_estimate_with_prosac_and_initial_model():
+    d = synth.absolute_pose_scene(1200, 0.5, 840)
+    opt = {"max_error": 4.0, "ransac": {"seed": 5, "max_iterations": 3000, "progressive_sampling": True,
+                                        "max_prosac_iterations": 500}}
+    _cmp_frontend("estimate_absolute_pose", (d["p2d"], d["p3d"], d["camera"]), opt)
+    opt = {"max_error": 4.0, "ransac": {"seed": 6, "max_iterations": 3000, "score_initial_model": True}}
+    init = np.r_[d["q_gt"], d["t_gt"]]
+    (ma, ka, sa), (mb, kb, sb) = both("estimate_absolute_pose", d["p2d"], d["p3d"], d["camera"], opt, init)
+    assert sa["iterations"] == sb["iterations"] and sa["num_inliers"] == sb["num_inliers"] and np.array_equal(ka, kb)
+    assert np.abs(ma - mb).max() < 1e-9
 
 
 EXACT = []  # per LM comparison: parameters and final cost bit-identical?
