@@ -179,7 +179,7 @@ def main():
                        "inliers_found": int(allrec[0, 4])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_score_abs_pf<5>" if KIND == 0 else f"k_score<{KIND},P>",
+                         "kernel": "k_score_abs_stream<5>" if KIND == 0 else f"k_score<{KIND},P>",
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "note": f"algorithmic bytes = hypotheses x N x {BYTES_PER_CORR} B; the set is register/L2-resident, "

@@ -22,6 +22,7 @@
 //   k_mask<EST>       final inlier mask (reference: utils.cc get_inliers*).
 // MFMA is not used: there is no dense contraction in this path (fp64 VALU + L2/LDS resident data).
 #include "pl_kernels.h"
+#include <cstdlib>
 #include "pl_sampler.h"
 #include "pl_solver_h4.h"
 #include "pl_solver_p3p.h"
@@ -468,6 +469,171 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_abs_pf(PointSet pts, co
     }
 }
 
+// Streaming variant of the pre-filtered reprojection score for the batched main loop (hypotheses compacted by
+// k_compact2: 16 floats of shadow and 16 doubles of model per hypothesis, consecutive).  Same arithmetic and the
+// same summation tree as k_score_abs_pf; what changes is the bookkeeping around it:
+//   * the candidate sets of pass A stay wave masks in SGPRs (v_cmp results, no per-lane bit vectors);
+//   * W = gx*|X| + gx*tmax is split into a per-point and a per-hypothesis part, and the outlier test is
+//     max(|a0|,|a1|) > fma(thr, z2, W)  (one rounding less than |a| - thr*z2 > W; covered by the 32u margin);
+//   * the fp64 model is only fetched when some point survives pass A;
+//   * results are parked in lane g of a VGPR and written once per 64 hypotheses, so a hypothesis
+//     without candidates costs no result traffic at all;
+//   * the shadow is double-buffered by unrolling two hypotheses per trip (no SGPR copies);
+//   * models flagged NaN by store_shadow are skipped: they have no inliers by construction.
+#ifdef PL_EXPERIMENT_NO_EXACT_PASS
+constexpr bool kExactPass = false; // timing experiments only (scripts/gpu_job_*.sh): results are wrong
+#else
+constexpr bool kExactPass = true;
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f bc(float s) { return v2f{s, s}; }
+
+template <int P>
+__global__ __launch_bounds__(kScoreThreads) void k_score_abs_stream(PointSet pts, const float *__restrict__ shadow,
+                                                                     const double *__restrict__ compact64,
+                                                                     const uint32_t *__restrict__ num_hyp_ptr,
+                                                                     uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+                                                                     uint32_t *__restrict__ part_count,
+                                                                     double *__restrict__ part_score) {
+    constexpr int kWaves = kScoreThreads / 64;
+    __shared__ double s_score[kWaves][64];
+    __shared__ uint32_t s_count[kWaves][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t chunk = blockIdx.y;
+
+    double pt[P][5];
+    float fx[P], fy[P], fX[P], fY[P], fZ[P], fw[P]; // fw = gx * upper bound of |X|_2 (-inf for padding slots)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
+        const bool valid = i < pts.n;
+        const uint32_t ic = valid ? i : 0u;
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+            pt[p][d] = pts.a[d][ic];
+        fx[p] = (float)pt[p][0], fy[p] = (float)pt[p][1];
+        fX[p] = (float)pt[p][2], fY[p] = (float)pt[p][3], fZ[p] = (float)pt[p][4];
+        const float nx = (float)sqrt(pt[p][2] * pt[p][2] + pt[p][3] * pt[p][3] + pt[p][4] * pt[p][4]) * 1.000001f + 1e-30f;
+        fw[p] = valid ? pf.gx * nx * 1.000001f : -__builtin_huge_valf();
+    }
+
+    const uint32_t H = *as_uniform(num_hyp_ptr);
+    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
+    const uint32_t k0 = blockIdx.x * per;
+    const uint32_t k1 = min(H, k0 + per);
+    const uniform_f32_ptr sh = as_uniform(shadow);
+    const uniform_f64_ptr md = as_uniform(compact64);
+
+    for (uint32_t kb = k0; kb < k1; kb += 64) {
+        const uint32_t gn = min(64u, k1 - kb);
+        double acc_s = 0.0; // lane g: score of hypothesis kb + g (this wave's points)
+        uint32_t acc_c = 0; // lane g: inlier count
+
+        auto step = [&](const float(&r)[14], uint32_t g) {
+            if (__float_as_uint(r[13]) != 0u)
+                return; // NaN model: zero inliers (pl_math.h store_shadow)
+            const float gt = pf.gx * r[12] * 1.000001f;
+            uint64_t m[P];
+            uint64_t any = 0;
+            // two points per packed fp32 instruction (v_pk_fma_f32); the comparisons feed the ballots directly
+#pragma unroll
+            for (int p = 0; p + 1 < P; p += 2) {
+                const v2f X = {fX[p], fX[p + 1]}, Y = {fY[p], fY[p + 1]}, Z = {fZ[p], fZ[p + 1]};
+                const v2f x = {fx[p], fx[p + 1]}, y = {fy[p], fy[p + 1]}, w = {fw[p], fw[p + 1]};
+                const v2f z0 = pk_fma(bc(r[0]), X, pk_fma(bc(r[1]), Y, pk_fma(bc(r[2]), Z, bc(r[9]))));
+                const v2f z1 = pk_fma(bc(r[3]), X, pk_fma(bc(r[4]), Y, pk_fma(bc(r[5]), Z, bc(r[10]))));
+                const v2f z2 = pk_fma(bc(r[6]), X, pk_fma(bc(r[7]), Y, pk_fma(bc(r[8]), Z, bc(r[11]))));
+                const v2f a0 = pk_fma(-x, z2, z0);
+                const v2f a1 = pk_fma(-y, z2, z1);
+                const v2f W = w + bc(gt);
+                const v2f B = pk_fma(bc(pf.thr), z2, W);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const uint64_t far = __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a0[e]), fabsf(a1[e])) > B[e]);
+                    const uint64_t behind = __builtin_amdgcn_ballot_w64(z2[e] < -W[e]);
+                    m[p + e] = ~(far | behind);
+                    any |= m[p + e];
+                }
+            }
+            if constexpr (P & 1) {
+                constexpr int p = P - 1;
+                const float z0 = fmaf(r[0], fX[p], fmaf(r[1], fY[p], fmaf(r[2], fZ[p], r[9])));
+                const float z1 = fmaf(r[3], fX[p], fmaf(r[4], fY[p], fmaf(r[5], fZ[p], r[10])));
+                const float z2 = fmaf(r[6], fX[p], fmaf(r[7], fY[p], fmaf(r[8], fZ[p], r[11])));
+                const float a0 = fmaf(-fx[p], z2, z0);
+                const float a1 = fmaf(-fy[p], z2, z1);
+                const float W = fw[p] + gt;
+                const float B = fmaf(pf.thr, z2, W);
+                const uint64_t far = __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a0), fabsf(a1)) > B);
+                const uint64_t behind = __builtin_amdgcn_ballot_w64(z2 < -W);
+                m[p] = ~(far | behind);
+                any |= m[p];
+            }
+            if (kExactPass && any) { // wave-uniform; rare for a wrong hypothesis
+                double M[kModelDoubles];
+#pragma unroll
+                for (int i = 0; i < kModelDoubles; ++i)
+                    M[i] = md[(size_t)(kb + g) * kModelDoubles + i];
+                uint32_t cnt = 0;
+                double sc = 0.0;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (m[p]) {
+                        double r2;
+                        const bool in = eval_point<EST_ABS>(M, pt[p], thr2, r2) && ((m[p] >> lane) & 1u);
+                        cnt += __popcll(__builtin_amdgcn_ballot_w64(in));
+                        sc += in ? r2 : 0.0;
+                    }
+                }
+                if (cnt) {
+                    sc = wave_sum(sc);
+                    const bool mine = (uint32_t)lane == g;
+                    acc_s = mine ? sc : acc_s;
+                    acc_c = mine ? cnt : acc_c;
+                }
+            }
+        };
+        auto fetch = [&](float(&r)[14], uint32_t g) {
+            const uniform_f32_ptr sp = sh + (size_t)(kb + g) * 16;
+#pragma unroll
+            for (int i = 0; i < 14; ++i)
+                r[i] = sp[i];
+        };
+
+        float ra[14], rb[14];
+        fetch(ra, 0);
+        for (uint32_t g = 0; g < gn; g += 2) {
+            const bool two = g + 1 < gn;
+            if (two)
+                fetch(rb, g + 1);
+            step(ra, g);
+            if (two) {
+                if (g + 2 < gn)
+                    fetch(ra, g + 2);
+                step(rb, g + 1);
+            }
+        }
+        s_score[wave][lane] = acc_s;
+        s_count[wave][lane] = acc_c;
+        __syncthreads();
+        if (threadIdx.x < gn) {
+            double sc = 0.0;
+            uint32_t c = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                sc += s_score[w][threadIdx.x];
+                c += s_count[w][threadIdx.x];
+            }
+            const size_t o = (size_t)chunk * hyp_capacity + kb + threadIdx.x;
+            part_score[o] = sc;
+            part_count[o] = c;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs f) {
     const uint32_t H = *f.num_hyp;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < H; k += gridDim.x * blockDim.x) {
@@ -756,9 +922,17 @@ hipError_t launch_compact(const uint32_t *num_models, uint32_t num_iters, int ma
 }
 
 constexpr int kMaxPointsPerLane = 5;    // exact kernels: fp64 points in VGPRs
-constexpr int kMaxPointsPerLanePF = 5;  // pre-filtered absolute-pose kernel: fp64 points + fp32 shadows in VGPRs
+// pre-filtered absolute-pose kernels: fp64 points + fp32 shadows in VGPRs (POSELIB_AMD_PF_P overrides, 1..6)
+static int max_points_per_lane_pf() {
+    static const int v = [] {
+        const char *e = std::getenv("POSELIB_AMD_PF_P");
+        const int x = e ? std::atoi(e) : 5;
+        return x < 1 ? 1 : (x > 6 ? 6 : x);
+    }();
+    return v;
+}
 static void score_shape(uint32_t n, bool pf, uint32_t &chunks, int &P) {
-    const uint32_t per_chunk_max = kScoreThreads * (pf ? kMaxPointsPerLanePF : kMaxPointsPerLane);
+    const uint32_t per_chunk_max = kScoreThreads * (pf ? max_points_per_lane_pf() : kMaxPointsPerLane);
     chunks = (n + per_chunk_max - 1) / per_chunk_max;
     if (chunks == 0)
         chunks = 1;
@@ -783,6 +957,25 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     const bool use_pf = (E == EST_ABS) && a.pf_gx > 0.f;
     score_shape(a.pts.n, use_pf, chunks, P);
     const dim3 grid(slices, chunks), block(kScoreThreads);
+    if (use_pf && a.shadow && a.compact64) {
+#define PL_ST_CASE(PP)                                                                                                 \
+    case PP:                                                                                                           \
+        k_score_abs_stream<PP><<<grid, block, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,    \
+                                                           a.thr2, pf, a.part_count, a.part_score);                    \
+        break;
+        switch (P) {
+            PL_ST_CASE(1)
+            PL_ST_CASE(2)
+            PL_ST_CASE(3)
+            PL_ST_CASE(4)
+            PL_ST_CASE(5)
+            PL_ST_CASE(6)
+        default:
+            return hipErrorInvalidValue;
+        }
+#undef PL_ST_CASE
+        return hipGetLastError();
+    }
     if (use_pf) {
 #define PL_PF_CASE(PP)                                                                                                 \
     case PP:                                                                                                           \
@@ -795,6 +988,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
             PL_PF_CASE(3)
             PL_PF_CASE(4)
             PL_PF_CASE(5)
+            PL_PF_CASE(6)
         default:
             return hipErrorInvalidValue;
         }

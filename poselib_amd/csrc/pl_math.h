@@ -242,7 +242,15 @@ PL_HD void store_shadow(double *rec) {
         tmax = a > tmax ? a : tmax;
     }
     f[12] = tmax * 1.000001f + 1e-30f; // rounded-to-nearest conversions, padded upwards
-    f[13] = f[14] = f[15] = 0.f;
+    // f[13] != 0: some entry of t or of the matrix is NaN.  Every residual of the four scores then is NaN (each
+    // point's residual involves every entry, and 0 * NaN = NaN), no comparison r2 < thr2 succeeds, and the
+    // reference counts zero inliers (utils.cc:37-130): scorers may return (0, 0) for such a model unseen.  The
+    // reference's P3P does emit such poses for inconsistent samples (about 13 % at 70 % outliers).
+    bool any_nan = false;
+    for (int i = 4; i < kModelDoubles; ++i)
+        any_nan = any_nan || (rec[i] != rec[i]);
+    f[13] = any_nan ? 1.f : 0.f;
+    f[14] = f[15] = 0.f;
 }
 
 // Write a pose hypothesis (rotation given as matrix from a solver) into a 16-double record:
