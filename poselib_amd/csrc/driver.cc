@@ -373,18 +373,13 @@ uint64_t sample_positions_k(int K, uint64_t seed, uint64_t pos, uint64_t N, uint
     }
 }
 
-// Parameters of the scoring kernel's conservative fp32 pre-filter (see kernels.hip).  Both values are
-// rounded UP; POSELIB_AMD_NO_PREFILTER=1 disables the filter (exact evaluation of every point).
+// Parameters of the scoring kernels' conservative fp32 pre-filters (pl_prefilter.h).  Every value is rounded UP;
+// POSELIB_AMD_NO_PREFILTER=1 disables the filters (exact evaluation of every point).
 void set_prefilter(ScoreArgs &sa, const pl_problem *p, double thr2) {
     static const bool disabled = std::getenv("POSELIB_AMD_NO_PREFILTER") != nullptr;
-    sa.pf_thr = 0.f;
-    sa.pf_gx = 0.f;
-    if (disabled || p->kind != EST_ABS || !(thr2 > 0) || !std::isfinite(thr2) || !std::isfinite(p->ps.xy_absmax))
-        return;
-    const double thr = std::sqrt(thr2);
-    const double u = 5.9604644775390625e-08; // 2^-24
-    sa.pf_thr = std::nextafter((float)thr, std::numeric_limits<float>::infinity());
-    sa.pf_gx = std::nextafter((float)(32.0 * u * (1.0 + p->ps.xy_absmax + thr)), std::numeric_limits<float>::infinity());
+    sa.pf = make_prefilter_args(p->kind, thr2, p->ps.xy_absmax);
+    if (disabled)
+        sa.pf.enabled = 0;
 }
 
 // Score `nrec` model records that already sit in device memory at `d_records`.  Results land in the
@@ -393,7 +388,7 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
                           bool time_it) {
     ScoreArgs sa;
     set_prefilter(sa, p, thr2);
-    const uint32_t chunks = score_chunks(p->kind, p->n, sa.pf_gx > 0.f);
+    const uint32_t chunks = score_chunks(p->kind, p->n, false);
     HIP_TRY(c->num_hyp.ensure(sizeof(uint32_t)));
     HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * nrec));
     HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * nrec));
@@ -612,7 +607,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             const size_t hcap = (size_t)B * MAXM;
             ScoreArgs sa;
             set_prefilter(sa, p, thr2);
-            const bool prefilter = sa.pf_gx > 0.f;
+            const bool prefilter = true; // compact hypothesis stream for the streaming scorer (all estimators)
             const uint32_t chunks = score_chunks(kind, N, prefilter);
             if (prefilter) {
                 HIP_TRY(c->shadow.ensure(sizeof(float) * 16 * hcap));

@@ -22,6 +22,7 @@
 //   k_mask<EST>       final inlier mask (reference: utils.cc get_inliers*).
 // MFMA is not used: there is no dense contraction in this path (fp64 VALU + L2/LDS resident data).
 #include "pl_kernels.h"
+#include "pl_prefilter.h"
 #include <cstdlib>
 #include "pl_sampler.h"
 #include "pl_solver_h4.h"
@@ -218,10 +219,6 @@ constexpr int kScoreGroup = 32; // hypotheses between two workgroup barriers
 // An inlier has z2 > 0 and |z0 - x z2| < thr z2 (and the same in y).  With a = fl(z^0 - x^ z^2),
 // tz = fl(thr^ z^2) the accumulated error of  |a| - tz  is below  W = 32u (1 + xmax + thr) S,  hence
 // |a| - tz > W  (or z^2 < -W)  proves the point is an outlier.  Gx = 32u(1+xmax+thr) is passed rounded up.
-struct PrefilterArgs {
-    float thr;  // sqrt(thr2), rounded up
-    float gx;   // 32u (1 + max|x|,|y| + thr), rounded up; 0 disables the pre-filter
-};
 
 template <int EST, int P, bool PF>
 __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const double *__restrict__ models,
@@ -469,54 +466,83 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_abs_pf(PointSet pts, co
     }
 }
 
-// Streaming variant of the pre-filtered reprojection score for the batched main loop (hypotheses compacted by
-// k_compact2: 16 floats of shadow and 16 doubles of model per hypothesis, consecutive).  Same arithmetic and the
-// same summation tree as k_score_abs_pf; what changes is the bookkeeping around it:
-//   * the candidate sets of pass A stay wave masks in SGPRs (v_cmp results, no per-lane bit vectors);
-//   * W = gx*|X| + gx*tmax is split into a per-point and a per-hypothesis part, and the outlier test is
-//     max(|a0|,|a1|) > fma(thr, z2, W)  (one rounding less than |a| - thr*z2 > W; covered by the 32u margin);
-//   * the fp64 model is only fetched when some point survives pass A;
-//   * results are parked in lane g of a VGPR and written once per 64 hypotheses, so a hypothesis
-//     without candidates costs no result traffic at all;
-//   * the shadow is double-buffered by unrolling two hypotheses per trip (no SGPR copies);
-//   * models flagged NaN by store_shadow are skipped: they have no inliers by construction.
+// Streaming scorer of the batched main loop for all four estimators (hypotheses compacted by k_compact2: 16 floats
+// of shadow and 16 doubles of model per hypothesis, consecutive).
+//   pass A  conservative fp32 pre-filter (pl_prefilter.h) on the register-resident points; its results stay wave
+//           masks in SGPRs (v_cmp -> ballot), no per-lane bookkeeping;
+//   pass B  exact fp64 evaluation (pl_score.h) of the slots in which some lane survived; the fp64 model is only
+//           fetched then.  Same arithmetic and summation tree as the non-streaming kernels.
+// Results are parked in lane g of a VGPR and written once per 64 hypotheses, so a hypothesis without candidates
+// costs no result traffic; the shadow is double-buffered by unrolling two hypotheses per trip (no SGPR copies);
+// models flagged NaN by store_shadow are skipped (no inliers by construction).
 #ifdef PL_EXPERIMENT_NO_EXACT_PASS
 constexpr bool kExactPass = false; // timing experiments only (scripts/gpu_job_*.sh): results are wrong
 #else
 constexpr bool kExactPass = true;
 #endif
+#ifdef PL_SCALAR_ABS_FILTER
+constexpr bool kPackedAbsFilter = false;
+#else
+constexpr bool kPackedAbsFilter = true; // v_pk_fma_f32 pairs in the absolute-pose filter
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f bc(float s) { return v2f{s, s}; }
 
-template <int P>
-__global__ __launch_bounds__(kScoreThreads) void k_score_abs_stream(PointSet pts, const float *__restrict__ shadow,
-                                                                     const double *__restrict__ compact64,
-                                                                     const uint32_t *__restrict__ num_hyp_ptr,
-                                                                     uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
-                                                                     uint32_t *__restrict__ part_count,
-                                                                     double *__restrict__ part_score) {
+// sum over the wave of a value that is non-zero in `cnt` lanes only (`lanes` = their mask): with one such lane the
+// butterfly would add 63 zeros to it, so the value is simply broadcast
+__device__ __forceinline__ double wave_sum_sparse(double v, uint32_t cnt, uint64_t lanes) {
+    if (cnt == 1) {
+        const int src = __builtin_ctzll(lanes);
+        const uint64_t bits = (uint64_t)__double_as_longlong(v);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, src);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bits >> 32), src);
+        return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+    }
+    return wave_sum(v);
+}
+
+template <int EST, int P>
+__global__ __launch_bounds__(kScoreThreads) void k_score_stream(PointSet pts, const float *__restrict__ shadow,
+                                                                 const double *__restrict__ compact64,
+                                                                 const uint32_t *__restrict__ num_hyp_ptr,
+                                                                 uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+                                                                 uint32_t *__restrict__ part_count,
+                                                                 double *__restrict__ part_score) {
     constexpr int kWaves = kScoreThreads / 64;
+    constexpr int ND = point_doubles(EST);
+    constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 3); // bound terms per point
     __shared__ double s_score[kWaves][64];
     __shared__ uint32_t s_count[kWaves][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t chunk = blockIdx.y;
 
-    double pt[P][5];
-    float fx[P], fy[P], fX[P], fY[P], fZ[P], fw[P]; // fw = gx * upper bound of |X|_2 (-inf for padding slots)
+    double pt[P][ND];
+    float pf32[P][ND]; // the point in fp32
+    float bnd[P][NB];  // per-point bound terms of the pre-filter
+    uint64_t vmask[P]; // lanes of slot p that hold a real correspondence (wave-uniform)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
         const bool valid = i < pts.n;
         const uint32_t ic = valid ? i : 0u;
+        vmask[p] = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
-        for (int d = 0; d < 5; ++d)
+        for (int d = 0; d < ND; ++d) {
             pt[p][d] = pts.a[d][ic];
-        fx[p] = (float)pt[p][0], fy[p] = (float)pt[p][1];
-        fX[p] = (float)pt[p][2], fY[p] = (float)pt[p][3], fZ[p] = (float)pt[p][4];
-        const float nx = (float)sqrt(pt[p][2] * pt[p][2] + pt[p][3] * pt[p][3] + pt[p][4] * pt[p][4]) * 1.000001f + 1e-30f;
-        fw[p] = valid ? pf.gx * nx * 1.000001f : -__builtin_huge_valf();
+            pf32[p][d] = (float)pt[p][d];
+        }
+        if constexpr (EST == EST_ABS) {
+            bnd[p][0] = pf_point_abs(pt[p][2], pt[p][3], pt[p][4], pf.gx);
+        } else {
+            float na, nb, nanb, nanb_thr;
+            pf_point_two_view(pt[p][0], pt[p][1], pt[p][2], pt[p][3], pf.thr, na, nb, nanb, nanb_thr);
+            if constexpr (EST == EST_HOM)
+                bnd[p][0] = nanb_thr;
+            else
+                bnd[p][0] = na, bnd[p][1] = nb, bnd[p][2] = nanb;
+        }
     }
 
     const uint32_t H = *as_uniform(num_hyp_ptr);
@@ -531,45 +557,73 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_abs_stream(PointSet pts
         double acc_s = 0.0; // lane g: score of hypothesis kb + g (this wave's points)
         uint32_t acc_c = 0; // lane g: inlier count
 
-        auto step = [&](const float(&r)[14], uint32_t g) {
+        auto step = [&](const float(&r)[15], uint32_t g) {
             if (__float_as_uint(r[13]) != 0u)
                 return; // NaN model: zero inliers (pl_math.h store_shadow)
-            const float gt = pf.gx * r[12] * 1.000001f;
             uint64_t m[P];
             uint64_t any = 0;
-            // two points per packed fp32 instruction (v_pk_fma_f32); the comparisons feed the ballots directly
+            if (!pf.enabled) {
 #pragma unroll
-            for (int p = 0; p + 1 < P; p += 2) {
-                const v2f X = {fX[p], fX[p + 1]}, Y = {fY[p], fY[p + 1]}, Z = {fZ[p], fZ[p + 1]};
-                const v2f x = {fx[p], fx[p + 1]}, y = {fy[p], fy[p + 1]}, w = {fw[p], fw[p + 1]};
-                const v2f z0 = pk_fma(bc(r[0]), X, pk_fma(bc(r[1]), Y, pk_fma(bc(r[2]), Z, bc(r[9]))));
-                const v2f z1 = pk_fma(bc(r[3]), X, pk_fma(bc(r[4]), Y, pk_fma(bc(r[5]), Z, bc(r[10]))));
-                const v2f z2 = pk_fma(bc(r[6]), X, pk_fma(bc(r[7]), Y, pk_fma(bc(r[8]), Z, bc(r[11]))));
-                const v2f a0 = pk_fma(-x, z2, z0);
-                const v2f a1 = pk_fma(-y, z2, z1);
-                const v2f W = w + bc(gt);
-                const v2f B = pk_fma(bc(pf.thr), z2, W);
+                for (int p = 0; p < P; ++p)
+                    m[p] = vmask[p], any |= m[p];
+            } else if constexpr (EST == EST_ABS && kPackedAbsFilter) {
+                const float gt = pf_up(pf.gx * r[12]);
+                // two points per packed fp32 instruction; the comparisons feed the ballots directly
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const uint64_t far = __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a0[e]), fabsf(a1[e])) > B[e]);
-                    const uint64_t behind = __builtin_amdgcn_ballot_w64(z2[e] < -W[e]);
-                    m[p + e] = ~(far | behind);
-                    any |= m[p + e];
+                for (int p = 0; p + 1 < P; p += 2) {
+                    const v2f X = {pf32[p][2], pf32[p + 1][2]}, Y = {pf32[p][3], pf32[p + 1][3]};
+                    const v2f Z = {pf32[p][4], pf32[p + 1][4]};
+                    const v2f x = {pf32[p][0], pf32[p + 1][0]}, y = {pf32[p][1], pf32[p + 1][1]};
+                    const v2f w = {bnd[p][0], bnd[p + 1][0]};
+                    const v2f z0 = pk_fma(bc(r[0]), X, pk_fma(bc(r[1]), Y, pk_fma(bc(r[2]), Z, bc(r[9]))));
+                    const v2f z1 = pk_fma(bc(r[3]), X, pk_fma(bc(r[4]), Y, pk_fma(bc(r[5]), Z, bc(r[10]))));
+                    const v2f z2 = pk_fma(bc(r[6]), X, pk_fma(bc(r[7]), Y, pk_fma(bc(r[8]), Z, bc(r[11]))));
+                    const v2f a0 = pk_fma(-x, z2, z0);
+                    const v2f a1 = pk_fma(-y, z2, z1);
+                    const v2f W = w + bc(gt);
+                    const v2f B = pk_fma(bc(pf.thr), z2, W);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint64_t far = __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a0[e]), fabsf(a1[e])) > B[e]);
+                        const uint64_t behind = __builtin_amdgcn_ballot_w64(z2[e] < -W[e]);
+                        m[p + e] = vmask[p + e] & ~(far | behind);
+                        any |= m[p + e];
+                    }
                 }
-            }
-            if constexpr (P & 1) {
-                constexpr int p = P - 1;
-                const float z0 = fmaf(r[0], fX[p], fmaf(r[1], fY[p], fmaf(r[2], fZ[p], r[9])));
-                const float z1 = fmaf(r[3], fX[p], fmaf(r[4], fY[p], fmaf(r[5], fZ[p], r[10])));
-                const float z2 = fmaf(r[6], fX[p], fmaf(r[7], fY[p], fmaf(r[8], fZ[p], r[11])));
-                const float a0 = fmaf(-fx[p], z2, z0);
-                const float a1 = fmaf(-fy[p], z2, z1);
-                const float W = fw[p] + gt;
-                const float B = fmaf(pf.thr, z2, W);
-                const uint64_t far = __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a0), fabsf(a1)) > B);
-                const uint64_t behind = __builtin_amdgcn_ballot_w64(z2 < -W);
-                m[p] = ~(far | behind);
-                any |= m[p];
+                if constexpr (P & 1) {
+                    constexpr int p = P - 1;
+                    const bool out = pf_abs_outlier(r, gt, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
+                                                    pf32[p][4], bnd[p][0]);
+                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
+                    any |= m[p];
+                }
+            } else if constexpr (EST == EST_ABS) {
+                const float gt = pf_up(pf.gx * r[12]);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool out = pf_abs_outlier(r, gt, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
+                                                    pf32[p][4], bnd[p][0]);
+                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
+                    any |= m[p];
+                }
+            } else if constexpr (EST == EST_HOM) {
+                const float gh = (32.f * kPfU) * r[14];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool out = pf_hom_outlier(r, gh, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
+                                                    bnd[p][0]);
+                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
+                    any |= m[p];
+                }
+            } else {
+                const float gf = (16.f * kPfU) * r[14];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool out = pf_sampson_outlier(r, gf, pf.thr2_up, pf32[p][0], pf32[p][1], pf32[p][2],
+                                                        pf32[p][3], bnd[p][0], bnd[p][1], bnd[p][2]);
+                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
+                    any |= m[p];
+                }
             }
             if (kExactPass && any) { // wave-uniform; rare for a wrong hypothesis
                 double M[kModelDoubles];
@@ -577,32 +631,35 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_abs_stream(PointSet pts
                 for (int i = 0; i < kModelDoubles; ++i)
                     M[i] = md[(size_t)(kb + g) * kModelDoubles + i];
                 uint32_t cnt = 0;
+                uint64_t lanes = 0;
                 double sc = 0.0;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     if (m[p]) {
                         double r2;
-                        const bool in = eval_point<EST_ABS>(M, pt[p], thr2, r2) && ((m[p] >> lane) & 1u);
-                        cnt += __popcll(__builtin_amdgcn_ballot_w64(in));
+                        const bool in = eval_point<EST>(M, pt[p], thr2, r2) && ((m[p] >> lane) & 1u);
+                        const uint64_t im = __builtin_amdgcn_ballot_w64(in);
+                        cnt += __popcll(im);
+                        lanes |= im;
                         sc += in ? r2 : 0.0;
                     }
                 }
                 if (cnt) {
-                    sc = wave_sum(sc);
+                    sc = wave_sum_sparse(sc, cnt, lanes);
                     const bool mine = (uint32_t)lane == g;
                     acc_s = mine ? sc : acc_s;
                     acc_c = mine ? cnt : acc_c;
                 }
             }
         };
-        auto fetch = [&](float(&r)[14], uint32_t g) {
+        auto fetch = [&](float(&r)[15], uint32_t g) {
             const uniform_f32_ptr sp = sh + (size_t)(kb + g) * 16;
 #pragma unroll
-            for (int i = 0; i < 14; ++i)
+            for (int i = 0; i < 15; ++i)
                 r[i] = sp[i];
         };
 
-        float ra[14], rb[14];
+        float ra[15], rb[15];
         fetch(ra, 0);
         for (uint32_t g = 0; g < gn; g += 2) {
             const bool two = g + 1 < gn;
@@ -631,6 +688,243 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_abs_stream(PointSet pts
             part_count[o] = c;
         }
         __syncthreads();
+    }
+}
+
+// ---- deferred exact evaluation ----------------------------------------------------------------------------------
+// k_score_queue: the scorer of the batched main loop.  One wavefront = 64*P register-resident correspondences (fp32
+// copies + bound terms) x a stream of hypotheses; the four waves of a workgroup share the same correspondences
+// (fp64 copies in LDS) and split the hypotheses between them, so nothing in the loop needs a workgroup barrier.
+//   pass A   conservative fp32 pre-filter (pl_prefilter.h), results = wave masks in SGPRs;
+//   queue    the (hypothesis, correspondence) pairs that survive are appended to a wave-private LDS ring
+//            (ballot + mbcnt compaction) instead of being evaluated on the spot - a wrong hypothesis leaves a
+//            handful of survivors, and evaluating a 64-lane slot for one of them would cost as much as pass A;
+//   drain    whenever 64 pairs are waiting (and at the end of each group of 64 hypotheses) every lane takes one
+//            pair: its fp64 correspondence from LDS, its fp64 model from the compact stream, the exact expression
+//            of pl_score.h.  Pairs are ordered by (hypothesis, correspondence), so a segmented inclusive scan over
+//            the lanes (keys = hypothesis) yields per-hypothesis sums in a fixed order; the last lane of every
+//            segment adds them to the wave's per-hypothesis accumulators in LDS.
+// Everything is deterministic (no atomics); the summation tree differs from the non-streaming kernels, i.e. scores
+// agree with them to rounding, counts exactly.
+constexpr int kQueueCap = 512; // >= 63 + 64 * 6 entries can be waiting at most
+
+template <int EST, int P>
+__global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, const float *__restrict__ shadow,
+                                                                const double *__restrict__ compact64,
+                                                                const uint32_t *__restrict__ num_hyp_ptr,
+                                                                uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+                                                                uint32_t *__restrict__ part_count,
+                                                                double *__restrict__ part_score) {
+    constexpr int kWaves = kScoreThreads / 64;
+    constexpr int ND = point_doubles(EST);
+    constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 3); // bound terms per point
+    constexpr int NPW = 64 * P;                                         // correspondences per chunk
+    __shared__ double s_pts[ND][NPW];
+    __shared__ uint32_t s_queue[kWaves][kQueueCap];
+    __shared__ double s_acc_s[kWaves][64];
+    __shared__ uint32_t s_acc_c[kWaves][64];
+    const int lane = threadIdx.x & 63;
+    // readfirstlane: the wave index is uniform, and the compiler has to know it for the scalar (s_load) shadow stream
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t chunk = blockIdx.y;
+
+    float pf32[P][ND]; // the correspondences in fp32
+    float bnd[P][NB];  // per-point bound terms of the pre-filter
+    uint64_t vmask[P]; // lanes of slot p that hold a real correspondence (wave-uniform)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t i = chunk * NPW + p * 64 + lane;
+        const bool valid = i < pts.n;
+        const uint32_t ic = valid ? i : 0u;
+        vmask[p] = __builtin_amdgcn_ballot_w64(valid);
+        double x[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            x[d] = pts.a[d][ic];
+            pf32[p][d] = (float)x[d];
+            if (wave == 0)
+                s_pts[d][p * 64 + lane] = x[d];
+        }
+        if constexpr (EST == EST_ABS) {
+            bnd[p][0] = pf_point_abs(x[2], x[3], x[4], pf.gx);
+        } else {
+            float na, nb, nanb, nanb_thr;
+            pf_point_two_view(x[0], x[1], x[2], x[3], pf.thr, na, nb, nanb, nanb_thr);
+            if constexpr (EST == EST_HOM)
+                bnd[p][0] = nanb_thr;
+            else
+                bnd[p][0] = na, bnd[p][1] = nb, bnd[p][2] = nanb;
+        }
+    }
+    __syncthreads(); // the only workgroup barrier: fp64 correspondences are in LDS
+
+    const uint32_t H = *as_uniform(num_hyp_ptr);
+    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
+    const uint32_t k0 = blockIdx.x * per;
+    const uint32_t k1 = min(H, k0 + per);
+    const uniform_f32_ptr sh = as_uniform(shadow);
+    uint32_t *const queue = s_queue[wave];
+    double *const acc_s = s_acc_s[wave];
+    uint32_t *const acc_c = s_acc_c[wave];
+
+    for (uint32_t kb = k0 + 64u * wave; kb < k1; kb += 64u * kWaves) {
+        const uint32_t gn = min(64u, k1 - kb);
+        acc_s[lane] = 0.0;
+        acc_c[lane] = 0;
+        uint32_t qhead = 0, qtail = 0; // wave-uniform ring positions
+
+        auto drain = [&](uint32_t n) { // n <= 64 waiting pairs, one per lane
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool act = (uint32_t)lane < n;
+            const uint32_t e = act ? queue[(qhead + lane) & (kQueueCap - 1)] : 0xffffffffu;
+            const uint32_t g = e >> 16, pi = act ? (e & 0xffffu) : 0u;
+            double x[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                x[d] = s_pts[d][pi];
+            const double *Mp = compact64 + (size_t)(kb + (act ? g : 0u)) * kModelDoubles;
+            double M[kModelDoubles];
+#pragma unroll
+            for (int i = 0; i < kModelDoubles; ++i)
+                M[i] = Mp[i];
+            double r2;
+            const bool in = eval_point<EST>(M, x, thr2, r2) && act;
+            double v = in ? r2 : 0.0;
+            uint32_t c = in ? 1u : 0u;
+            if (__builtin_amdgcn_ballot_w64(in)) {
+                // segmented inclusive scan; keys (hypothesis) ascend with the lane, so "same key `off` lanes below"
+                // implies the whole stretch in between belongs to the segment
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double vv = __shfl_up(v, off, 64);
+                    const uint32_t cc = __shfl_up(c, off, 64);
+                    const uint32_t gg = __shfl_up(g, off, 64);
+                    if (lane >= off && gg == g) {
+                        v += vv;
+                        c += cc;
+                    }
+                }
+                const uint32_t gnext = __shfl_down(g, 1, 64);
+                const bool tail = act && ((uint32_t)lane + 1 == n || gnext != g);
+                if (tail && c) {
+                    acc_s[g] += v;
+                    acc_c[g] += c;
+                }
+            }
+            qhead += n;
+        };
+
+        auto step = [&](const float(&r)[15], uint32_t g) {
+            if (__float_as_uint(r[13]) != 0u)
+                return; // NaN model: zero inliers (pl_math.h store_shadow)
+            uint64_t m[P];
+            uint64_t any = 0;
+            if (!pf.enabled) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    m[p] = vmask[p], any |= m[p];
+            } else if constexpr (EST == EST_ABS && kPackedAbsFilter) {
+                const float gt = pf_up(pf.gx * r[12]);
+                // two points per packed fp32 instruction; the comparisons feed the ballots directly
+#pragma unroll
+                for (int p = 0; p + 1 < P; p += 2) {
+                    const v2f X = {pf32[p][2], pf32[p + 1][2]}, Y = {pf32[p][3], pf32[p + 1][3]};
+                    const v2f Z = {pf32[p][4], pf32[p + 1][4]};
+                    const v2f x = {pf32[p][0], pf32[p + 1][0]}, y = {pf32[p][1], pf32[p + 1][1]};
+                    const v2f w = {bnd[p][0], bnd[p + 1][0]};
+                    const v2f z0 = pk_fma(bc(r[0]), X, pk_fma(bc(r[1]), Y, pk_fma(bc(r[2]), Z, bc(r[9]))));
+                    const v2f z1 = pk_fma(bc(r[3]), X, pk_fma(bc(r[4]), Y, pk_fma(bc(r[5]), Z, bc(r[10]))));
+                    const v2f z2 = pk_fma(bc(r[6]), X, pk_fma(bc(r[7]), Y, pk_fma(bc(r[8]), Z, bc(r[11]))));
+                    const v2f a0 = pk_fma(-x, z2, z0);
+                    const v2f a1 = pk_fma(-y, z2, z1);
+                    const v2f W = w + bc(gt);
+                    const v2f B = pk_fma(bc(pf.thr), z2, W);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint64_t far = __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a0[e]), fabsf(a1[e])) > B[e]);
+                        const uint64_t behind = __builtin_amdgcn_ballot_w64(z2[e] < -W[e]);
+                        m[p + e] = vmask[p + e] & ~(far | behind);
+                        any |= m[p + e];
+                    }
+                }
+                if constexpr (P & 1) {
+                    constexpr int p = P - 1;
+                    const bool out = pf_abs_outlier(r, gt, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
+                                                    pf32[p][4], bnd[p][0]);
+                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
+                    any |= m[p];
+                }
+            } else if constexpr (EST == EST_ABS) {
+                const float gt = pf_up(pf.gx * r[12]);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool out = pf_abs_outlier(r, gt, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
+                                                    pf32[p][4], bnd[p][0]);
+                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
+                    any |= m[p];
+                }
+            } else if constexpr (EST == EST_HOM) {
+                const float gh = (32.f * kPfU) * r[14];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool out = pf_hom_outlier(r, gh, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
+                                                    bnd[p][0]);
+                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
+                    any |= m[p];
+                }
+            } else {
+                const float gf = (16.f * kPfU) * r[14];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool out = pf_sampson_outlier(r, gf, pf.thr2_up, pf32[p][0], pf32[p][1], pf32[p][2],
+                                                        pf32[p][3], bnd[p][0], bnd[p][1], bnd[p][2]);
+                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
+                    any |= m[p];
+                }
+            }
+            if (any) { // wave-uniform: append the survivors, ordered by (slot, lane)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (m[p]) {
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[p] >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)m[p], 0u));
+                        if ((m[p] >> lane) & 1u)
+                            queue[(qtail + below) & (kQueueCap - 1)] = (g << 16) | (uint32_t)(p * 64 + lane);
+                        qtail += (uint32_t)__popcll(m[p]);
+                    }
+                }
+                while (qtail - qhead >= 64u)
+                    drain(64u);
+            }
+        };
+        auto fetch = [&](float(&r)[15], uint32_t g) {
+            const uniform_f32_ptr sp = sh + (size_t)(kb + g) * 16;
+#pragma unroll
+            for (int i = 0; i < 15; ++i)
+                r[i] = sp[i];
+        };
+
+        float ra[15], rb[15];
+        fetch(ra, 0);
+        for (uint32_t g = 0; g < gn; g += 2) {
+            const bool two = g + 1 < gn;
+            if (two)
+                fetch(rb, g + 1);
+            step(ra, g);
+            if (two) {
+                if (g + 2 < gn)
+                    fetch(ra, g + 2);
+                step(rb, g + 1);
+            }
+        }
+        while (qtail != qhead)
+            drain(min(64u, qtail - qhead));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((uint32_t)lane < gn) {
+            const size_t o = (size_t)chunk * hyp_capacity + kb + lane;
+            part_score[o] = acc_s[lane];
+            part_count[o] = acc_c[lane];
+        }
     }
 }
 
@@ -931,19 +1225,30 @@ static int max_points_per_lane_pf() {
     }();
     return v;
 }
-static void score_shape(uint32_t n, bool pf, uint32_t &chunks, int &P) {
-    const uint32_t per_chunk_max = kScoreThreads * (pf ? max_points_per_lane_pf() : kMaxPointsPerLane);
+// `streaming`: launches of the batched main loop (k_score_queue: 64 * P correspondences per chunk, every wave of a
+// workgroup sees the same chunk); otherwise the non-streaming kernels (256 * P correspondences per chunk).
+static void score_shape(uint32_t n, bool streaming, uint32_t &chunks, int &P) {
+    const uint32_t lanes = streaming ? 64u : (uint32_t)kScoreThreads;
+    const uint32_t per_chunk_max = lanes * (uint32_t)max_points_per_lane_pf();
     chunks = (n + per_chunk_max - 1) / per_chunk_max;
     if (chunks == 0)
         chunks = 1;
-    P = (int)((n + kScoreThreads * chunks - 1) / (kScoreThreads * chunks));
+    P = (int)((n + lanes * chunks - 1) / (lanes * chunks));
     if (P < 1)
         P = 1;
 }
-uint32_t score_chunks(int est, uint32_t n, bool prefilter) {
+static bool use_queue_scorer() {
+    static const bool v = [] {
+        const char *e = std::getenv("POSELIB_AMD_SCORER"); // "stream": the per-slot evaluating scorer (A/B runs)
+        return !(e && e[0] == 's');
+    }();
+    return v;
+}
+uint32_t score_chunks(int est, uint32_t n, bool streaming) {
+    (void)est;
     uint32_t c;
     int P;
-    score_shape(n, prefilter && est == EST_ABS, c, P);
+    score_shape(n, streaming && use_queue_scorer(), c, P);
     return c;
 }
 
@@ -951,16 +1256,34 @@ template <int E>
 static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStream_t stream) {
     uint32_t chunks;
     int P;
-    PrefilterArgs pf;
-    pf.thr = a.pf_thr;
-    pf.gx = a.pf_gx;
-    const bool use_pf = (E == EST_ABS) && a.pf_gx > 0.f;
-    score_shape(a.pts.n, use_pf, chunks, P);
+    const PrefilterArgs pf = a.pf;
+    const bool use_pf = (E == EST_ABS) && pf.enabled && pf.gx > 0.f; // non-streaming launches: absolute pose only
+    const bool streaming = a.shadow && a.compact64; // batched main loop: compact hypothesis stream
+    score_shape(a.pts.n, streaming && use_queue_scorer(), chunks, P);
     const dim3 grid(slices, chunks), block(kScoreThreads);
-    if (use_pf && a.shadow && a.compact64) {
+    if (streaming && use_queue_scorer()) {
+#define PL_Q_CASE(PP)                                                                                                  \
+    case PP:                                                                                                           \
+        k_score_queue<E, PP><<<grid, block, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,      \
+                                                         a.thr2, pf, a.part_count, a.part_score);                      \
+        break;
+        switch (P) {
+            PL_Q_CASE(1)
+            PL_Q_CASE(2)
+            PL_Q_CASE(3)
+            PL_Q_CASE(4)
+            PL_Q_CASE(5)
+            PL_Q_CASE(6)
+        default:
+            return hipErrorInvalidValue;
+        }
+#undef PL_Q_CASE
+        return hipGetLastError();
+    }
+    if (streaming) {
 #define PL_ST_CASE(PP)                                                                                                 \
     case PP:                                                                                                           \
-        k_score_abs_stream<PP><<<grid, block, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,    \
+        k_score_stream<E, PP><<<grid, block, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,    \
                                                            a.thr2, pf, a.part_count, a.part_score);                    \
         break;
         switch (P) {

@@ -1,6 +1,7 @@
 // poselib_amd — launch interface between the host driver (driver.cc) and the HIP kernels
 // (kernels.hip).  Plain structs and pointers only.
 #pragma once
+#include "pl_prefilter.h"
 #include "pl_refine.h"
 
 #include <hip/hip_runtime.h>
@@ -48,8 +49,7 @@ struct ScoreArgs {
     const uint32_t *num_hyp;   // device scalar
     uint32_t hyp_capacity;     // row pitch of the partial arrays
     double thr2;
-    float pf_thr, pf_gx;       // conservative fp32 pre-filter (absolute pose): sqrt(thr2) rounded up, error gain
-                               // 32u(1 + max|x|,|y| + thr) rounded up; pf_gx == 0 disables it
+    PrefilterArgs pf;          // conservative fp32 pre-filter (pl_prefilter.h); pf.enabled == 0: exact evaluation
     uint32_t *part_count;      // [chunks][hyp_capacity]
     double *part_score;        // [chunks][hyp_capacity]
 };

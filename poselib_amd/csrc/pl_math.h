@@ -231,6 +231,19 @@ PL_HD bool check_cheirality(Quat q, Vec3 t, Vec3 x1, Vec3 x2, double min_depth) 
 }
 
 // fp32 shadow of the record's matrix / translation (see the layout comment above).
+// max-abs entry of the 3x3 matrix as fp32 (padded up), or +inf when it lies outside the range in which the fp32
+// pre-filters keep their relative accuracy (pl_prefilter.h)
+PL_HD float model_scale_f32(const double *M9) {
+    double m = 0.0;
+    for (int i = 0; i < 9; ++i) {
+        const double a = fabs(M9[i]);
+        m = a > m ? a : m;
+    }
+    if (!(m >= 1e-18 && m <= 1e18))
+        return __builtin_huge_valf();
+    return (float)m * 1.000001f + 1e-30f;
+}
+
 PL_HD void store_shadow(double *rec) {
     float *f = reinterpret_cast<float *>(rec + kShadowOff);
     for (int i = 0; i < 9; ++i)
@@ -250,7 +263,8 @@ PL_HD void store_shadow(double *rec) {
     for (int i = 4; i < kModelDoubles; ++i)
         any_nan = any_nan || (rec[i] != rec[i]);
     f[13] = any_nan ? 1.f : 0.f;
-    f[14] = f[15] = 0.f;
+    f[14] = model_scale_f32(rec + kMatOff);
+    f[15] = 0.f;
 }
 
 // Write a pose hypothesis (rotation given as matrix from a solver) into a 16-double record:

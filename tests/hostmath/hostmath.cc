@@ -5,6 +5,7 @@
 // GPU minutes are spent.  It is NOT a CPU fallback: nothing in poselib_amd/ loads it, the C-ABI
 // (include/poselib_amd.h) has no code path into it, and the product fails loudly without a GPU.
 // Built by tests/hostmath/Makefile with g++ -ffp-contract=off.
+#include "../../poselib_amd/csrc/pl_prefilter.h"
 #include "../../poselib_amd/csrc/pl_refine.h"
 #include "../../poselib_amd/csrc/pl_sampler.h"
 #include "../../poselib_amd/csrc/pl_score.h"
@@ -255,6 +256,48 @@ double hm_score(int est, const double *rec, const double *const *pa, uint32_t n,
     }
     *count = c;
     return s + (double)(n - c) * thr2;
+}
+
+void hm_matrix_record(const double *M9, double *rec) {
+    Mat3 M;
+    for (int i = 0; i < 9; ++i)
+        M.m[i] = M9[i];
+    store_matrix_model(rec, M);
+}
+
+// The scoring kernels' conservative fp32 pre-filter, operation for operation (kernels.hip k_score_stream pass A):
+// out[i] = 1 when correspondence i is PROVEN not to be an inlier of the model.  Returns 0 when the filter is
+// disabled for these parameters (every point is then evaluated exactly).
+int hm_prefilter(int est, const double *rec, const double *const *pa, uint32_t n, double thr2, float xy_absmax,
+                 uint8_t *out) {
+    const PrefilterArgs pf = make_prefilter_args(est, thr2, xy_absmax);
+    const float *r = reinterpret_cast<const float *>(rec + kShadowOff);
+    std::memset(out, 0, n);
+    if (!pf.enabled)
+        return 0;
+    uint32_t flag;
+    std::memcpy(&flag, &r[13], 4);
+    if (flag != 0u) { // NaN model: no inliers at all
+        std::memset(out, 1, n);
+        return 1;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (est == EST_ABS) {
+            const float fw = pf_point_abs(pa[2][i], pa[3][i], pa[4][i], pf.gx);
+            const float gt = pf_up(pf.gx * r[12]);
+            out[i] = pf_abs_outlier(r, gt, pf.thr, (float)pa[0][i], (float)pa[1][i], (float)pa[2][i], (float)pa[3][i],
+                                    (float)pa[4][i], fw);
+        } else {
+            float na, nb, nanb, nanb_thr;
+            pf_point_two_view(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pf.thr, na, nb, nanb, nanb_thr);
+            const float a0 = (float)pa[0][i], a1 = (float)pa[1][i], b0 = (float)pa[2][i], b1 = (float)pa[3][i];
+            if (est == EST_HOM)
+                out[i] = pf_hom_outlier(r, (32.f * kPfU) * r[14], pf.thr, a0, a1, b0, b1, nanb_thr);
+            else
+                out[i] = pf_sampson_outlier(r, (16.f * kPfU) * r[14], pf.thr2_up, a0, a1, b0, b1, na, nb, nanb);
+        }
+    }
+    return 1;
 }
 
 void hm_mask_abs(const double *rec, const double *const *pa, uint32_t n, double thr2, uint8_t *mask) {

@@ -109,8 +109,19 @@ def pose_record(q, t, essential=False):
 
 def matrix_record(M):
     rec = np.zeros(STRIDE)
-    rec[MAT:MAT + 9] = np.asarray(M, float).reshape(9)
+    M = np.ascontiguousarray(np.asarray(M, float).reshape(9))
+    lib().hm_matrix_record(_p(M), _p(rec))
     return rec
+
+
+def prefilter(est, rec, cols, thr2, xy_absmax=0.0):
+    """the scoring kernels' fp32 pre-filter: (enabled, mask of correspondences PROVEN not to be inliers)"""
+    arrs, ptrs = _soa(cols)
+    n = arrs[0].shape[0]
+    out = np.zeros(n, dtype=np.uint8)
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    en = lib().hm_prefilter(EST[est], _p(rec), ptrs, C.c_uint32(n), C.c_double(thr2), C.c_float(xy_absmax), _p(out))
+    return bool(en), out.astype(bool)
 
 
 def score(est, rec, cols, thr2):

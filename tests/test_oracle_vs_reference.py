@@ -118,6 +118,24 @@ def test_p3p_matches_reference():
     print(f"p3p: {exact}/{total} problems bit-identical, worst |diff| {worst:.2e}")
 
 
+def test_p3p_on_outlier_contaminated_samples_incl_nan_poses():
+    """samples drawn from a 70 %-outlier scene (BASELINE config 1): inconsistent triplets make p3p.cc emit NaN poses
+    (about 13 % of all hypotheses); the oracle must emit exactly the same ones, the scorers rely on it"""
+    sc = synth.absolute_pose_scene(5000, 0.7, 1001)
+    x = (np.asarray(sc["p2d"]) - 500.0) / 1000.0
+    X = np.asarray(sc["p3d"])
+    idx, _ = O.sampler_draw(0, 5000, 3, 1500)
+    nan = total = 0
+    for s in idx.astype(int):
+        xb = np.c_[x[s], np.ones(3)]
+        xb /= np.linalg.norm(xb, axis=1, keepdims=True)
+        a, b = both("p3p", xb, X[s])
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+        total += len(a)
+        nan += int(np.isnan(a).any(axis=1).sum()) if len(a) else 0
+    assert 0.05 < nan / total < 0.25
+
+
 def _two_view(rs, n):
     Rm, t = _rot(rs) if rs.rand() < 0.3 else synth_small_rot(rs), rs.randn(3)
     x1 = _bearing(rs, n)

@@ -1,0 +1,209 @@
+"""The scoring kernels' conservative fp32 pre-filter (poselib_amd/csrc/pl_prefilter.h) may only exclude
+correspondences that are NOT inliers under the reference's exact fp64 test.  The kernels and this test run the very
+same inline functions (tests/hostmath compiles the device headers for the host), so the property is checked here
+on the CPU against exact inlier flags that tests/test_hostmath_vs_oracle.py pins bit-for-bit to the oracle:
+
+    for every (model, correspondence):   proven_outlier  =>  not inlier
+
+over good, perturbed and random models; normalised and pixel-scale coordinates; thresholds from 1e-9 to 1e+2;
+correspondences planted exactly at the threshold; rescaled matrices (Sampson / homography are scale invariant);
+models with NaN / inf / out-of-range entries.  It also reports how selective the filter is.
+"""
+import numpy as np
+import pytest
+
+import hostmath_lib as HM
+from poselib_amd import synth
+
+
+def _rot(rs, s=1.0):
+    w = rs.randn(3) * s
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def _quat(R):
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    return np.array([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
+
+
+def _check(est, rec, cols, thr2, xy_absmax=0.0, stats=None):
+    _, _, inl, _ = HM.score(est, rec, cols, thr2)
+    en, out = HM.prefilter(est, rec, cols, thr2, xy_absmax)
+    bad = inl & out
+    assert not bad.any(), (est, thr2, np.flatnonzero(bad)[:5])
+    if stats is not None and en:
+        stats[0] += int((~inl).sum())
+        stats[1] += int((~inl & ~out).sum())
+    return en
+
+
+def test_absolute_pose_filter_never_drops_an_inlier():
+    rs = np.random.RandomState(1)
+    stats = [0, 0]
+    for trial in range(60):
+        scale = [1.0, 1.0, 50.0, 1e-3, 1e4][trial % 5]  # scene scale
+        d = synth.absolute_pose_scene(1500, 0.5, 100 + trial)
+        par = d["camera"]["params"]
+        x = (np.asarray(d["p2d"]) - par[-2:]) / par[0]
+        X = np.asarray(d["p3d"]) * scale
+        q, t = np.asarray(d["q_gt"], float), np.asarray(d["t_gt"], float) * scale
+        cols = [x[:, 0], x[:, 1], X[:, 0], X[:, 1], X[:, 2]]
+        xy = float(np.abs(x).max())
+        for thr in (1e-4, 2e-3, 1.2e-2, 0.3, 5.0):
+            for model in range(4):
+                if model == 0:
+                    qq, tt = q, t
+                elif model == 1:
+                    qq = q + 1e-3 * rs.randn(4)
+                    qq /= np.linalg.norm(qq)
+                    tt = t + 1e-3 * scale * rs.randn(3)
+                elif model == 2:
+                    qq = rs.randn(4)
+                    qq /= np.linalg.norm(qq)
+                    tt = rs.randn(3) * scale * 3
+                else:  # camera centre next to a scene point: depths around zero
+                    qq = q
+                    R = np.array(HM.pose_record(q, t)[HM.MAT:HM.MAT + 9]).reshape(3, 3)
+                    tt = -R @ X[trial] + 1e-6 * scale * rs.randn(3)
+                _check("abs", HM.pose_record(qq, tt), cols, thr * thr, xy, stats)
+    print(f"abs: {stats[1]}/{stats[0]} non-inliers pass the filter ({100.0 * stats[1] / stats[0]:.3f} %)")
+    assert stats[1] < 0.02 * stats[0]
+
+
+def _plant_at_threshold_abs(rec, X, thr, rs):
+    """2-D points whose reprojection error is thr * (1 +- 1e-7 ... 1e-3)"""
+    R = rec[HM.MAT:HM.MAT + 9].reshape(3, 3)
+    Z = X @ R.T + rec[4:7]
+    ok = Z[:, 2] > 1e-3
+    ang = rs.uniform(0, 2 * np.pi, len(X))
+    eps = 10.0 ** rs.uniform(-9, -3, len(X)) * rs.choice([-1, 1], len(X))
+    rad = thr * (1 + eps)
+    x = Z[:, :2] / Z[:, 2:3] + np.c_[rad * np.cos(ang), rad * np.sin(ang)]
+    return x[ok], X[ok]
+
+
+def test_absolute_pose_filter_at_the_threshold():
+    rs = np.random.RandomState(2)
+    for trial in range(20):
+        d = synth.absolute_pose_scene(2000, 0.0, 300 + trial)
+        rec = HM.pose_record(d["q_gt"], d["t_gt"])
+        for thr in (1e-5, 1e-3, 1.2e-2, 0.5):
+            x, X = _plant_at_threshold_abs(rec, np.asarray(d["p3d"]), thr, rs)
+            cols = [x[:, 0], x[:, 1], X[:, 0], X[:, 1], X[:, 2]]
+            _check("abs", rec, cols, thr * thr, float(np.abs(x).max()))
+
+
+def _two_view_cols(d, pixel):
+    x1, x2 = np.asarray(d["x1"], float), np.asarray(d["x2"], float)
+    if not pixel:
+        x1, x2 = (x1 - 500.0) / 1000.0, (x2 - 500.0) / 1000.0
+    return [x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1]]
+
+
+def _essential(q, t):
+    return HM.pose_record(q, t, essential=True)
+
+
+@pytest.mark.parametrize("est", ["fund", "rel"])
+def test_sampson_filter_never_drops_an_inlier(est):
+    rs = np.random.RandomState(3)
+    stats = [0, 0]
+    for trial in range(40):
+        d = synth.relative_pose_scene(1500, 0.5, 400 + trial)
+        q, t = np.asarray(d["q_gt"], float), np.asarray(d["t_gt"], float)
+        pixel = est == "fund" and trial % 2 == 0
+        cols = _two_view_cols(d, pixel)
+        recE = _essential(q, t)
+        E = recE[HM.MAT:HM.MAT + 9].reshape(3, 3)
+        if pixel:
+            Kinv = np.array([[1e-3, 0, -0.5], [0, 1e-3, -0.5], [0, 0, 1.0]])
+            Fgt = Kinv.T @ E @ Kinv
+        else:
+            Fgt = E
+        for thr in ((0.3, 1.0, 3.0, 20.0) if pixel else (1e-5, 1e-3, 3e-3, 0.1)):
+            for model in range(5):
+                if est == "rel":
+                    if model == 0:
+                        rec = recE
+                    elif model < 3:
+                        qq = q + 10.0 ** -(model + 1) * rs.randn(4)
+                        qq /= np.linalg.norm(qq)
+                        tt = t + 10.0 ** -(model + 1) * rs.randn(3)
+                        rec = _essential(qq, tt * rs.choice([1.0, 1e-3, 1e3]))
+                    else:
+                        qq = rs.randn(4)
+                        rec = _essential(qq / np.linalg.norm(qq), rs.randn(3))
+                else:
+                    if model == 0:
+                        F = Fgt
+                    elif model < 3:
+                        F = Fgt + 10.0 ** -(2 * model) * np.abs(Fgt).max() * rs.randn(3, 3)
+                    else:
+                        F = rs.randn(3, 3) * (1e-3 if pixel else 1.0) ** rs.randint(0, 3, (3, 3))
+                    F = F * 10.0 ** rs.choice([-12, -3, 0, 0, 4, 15])  # Sampson is scale invariant
+                    rec = HM.matrix_record(F)
+                _check(est, rec, cols, thr * thr, 0.0, stats)
+    print(f"{est}: {stats[1]}/{stats[0]} non-inliers pass the filter ({100.0 * stats[1] / stats[0]:.3f} %)")
+    # rel: correspondences that satisfy the Sampson test but fail the cheirality test are non-inliers the Sampson
+    # filter cannot (and must not) exclude
+    assert stats[1] < (0.15 if est == "rel" else 0.05) * stats[0]
+
+
+def test_homography_filter_never_drops_an_inlier():
+    rs = np.random.RandomState(4)
+    stats = [0, 0]
+    for trial in range(40):
+        pixel = trial % 2 == 0
+        d = synth.homography_scene(1500, 0.5, 500 + trial)
+        cols = _two_view_cols(d, pixel)
+        # a homography close to the truth: fit to a handful of inlier correspondences
+        inl = np.flatnonzero(d["inlier_gt"])[:40]
+        a = np.c_[cols[0][inl], cols[1][inl], np.ones(len(inl))]
+        b = np.c_[cols[2][inl], cols[3][inl]]
+        A = []
+        for p, (u, v) in zip(a, b):
+            A.append(np.r_[p, 0, 0, 0, -u * p])
+            A.append(np.r_[0, 0, 0, p, -v * p])
+        Hgt = np.linalg.svd(np.array(A))[2][-1].reshape(3, 3)
+        for thr in ((0.3, 1.0, 3.0, 30.0) if pixel else (1e-5, 1e-3, 3e-3, 0.1)):
+            for model in range(5):
+                if model == 0:
+                    Hm = Hgt
+                elif model < 3:
+                    Hm = Hgt + 10.0 ** -(2 * model) * np.abs(Hgt).max() * rs.randn(3, 3)
+                elif model == 3:
+                    Hm = rs.randn(3, 3)
+                else:  # third row nearly orthogonal to many points: denominators around zero
+                    Hm = Hgt.copy()
+                    Hm[2] = [1.0, -1.0, 1e-9] if not pixel else [1e-3, -1e-3, 1e-9]
+                Hm = Hm * 10.0 ** rs.choice([-12, -3, 0, 0, 4, 15]) * rs.choice([-1, 1])
+                _check("hom", HM.matrix_record(Hm), cols, thr * thr, 0.0, stats)
+    print(f"hom: {stats[1]}/{stats[0]} non-inliers pass the filter ({100.0 * stats[1] / stats[0]:.3f} %)")
+    assert stats[1] < 0.10 * stats[0]
+
+
+def test_degenerate_models():
+    d = synth.homography_scene(500, 0.3, 7)
+    cols = _two_view_cols(d, True)
+    for est in ("fund", "hom"):
+        for M in (np.zeros((3, 3)), np.full((3, 3), np.nan), np.eye(3) * 1e-30, np.eye(3) * 1e30,
+                  np.array([[1, 0, 0], [0, np.inf, 0], [0, 0, 1.0]]), np.array([[1, 0, 0], [0, 1, 0], [np.nan, 0, 1.0]])):
+            rec = HM.matrix_record(M)
+            _, _, inl, _ = HM.score(est, rec, cols, 4.0)
+            en, out = HM.prefilter(est, rec, cols, 4.0)
+            assert not (inl & out).any()
+            if np.isnan(M).any():
+                assert not inl.any() and out.all()  # the NaN shortcut is exact
+    a = synth.absolute_pose_scene(500, 0.3, 8)
+    x = (np.asarray(a["p2d"]) - 500.0) / 1000.0
+    X = np.asarray(a["p3d"])
+    cols = [x[:, 0], x[:, 1], X[:, 0], X[:, 1], X[:, 2]]
+    for t in ([np.nan, 0, 0], [0, 0, np.inf], [1e30, 0, 1e30], [0, 0, 0]):
+        rec = HM.pose_record(a["q_gt"], np.array(t, float))
+        _, _, inl, _ = HM.score("abs", rec, cols, 1e-4)
+        en, out = HM.prefilter("abs", rec, cols, 1e-4, float(np.abs(x).max()))
+        assert not (inl & out).any()
+    # thresholds outside the range fp32 can carry switch the filter off
+    assert not HM.prefilter("fund", HM.matrix_record(np.eye(3)), _two_view_cols(d, True), 1e-40)[0]
