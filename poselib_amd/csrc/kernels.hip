@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_stream(PointSet pts, co
                                                                  double *__restrict__ part_score) {
     constexpr int kWaves = kScoreThreads / 64;
     constexpr int ND = point_doubles(EST);
-    constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 3); // bound terms per point
+    constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 2); // bound terms per point
     __shared__ double s_score[kWaves][64];
     __shared__ uint32_t s_count[kWaves][64];
     const int lane = threadIdx.x & 63;
@@ -536,12 +536,12 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_stream(PointSet pts, co
         if constexpr (EST == EST_ABS) {
             bnd[p][0] = pf_point_abs(pt[p][2], pt[p][3], pt[p][4], pf.gx);
         } else {
-            float na, nb, nanb, nanb_thr;
-            pf_point_two_view(pt[p][0], pt[p][1], pt[p][2], pt[p][3], pf.thr, na, nb, nanb, nanb_thr);
+            float nanb, nsq, nanb_thr;
+            pf_point_two_view(pt[p][0], pt[p][1], pt[p][2], pt[p][3], pf.thr, nanb, nsq, nanb_thr);
             if constexpr (EST == EST_HOM)
                 bnd[p][0] = nanb_thr;
             else
-                bnd[p][0] = na, bnd[p][1] = nb, bnd[p][2] = nanb;
+                bnd[p][0] = nanb, bnd[p][1] = nsq;
         }
     }
 
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_stream(PointSet pts, co
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const bool out = pf_sampson_outlier(r, gf, pf.thr2_up, pf32[p][0], pf32[p][1], pf32[p][2],
-                                                        pf32[p][3], bnd[p][0], bnd[p][1], bnd[p][2]);
+                                                        pf32[p][3], bnd[p][0], bnd[p][1]);
                     m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
                     any |= m[p];
                 }
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
                                                                 double *__restrict__ part_score) {
     constexpr int kWaves = kScoreThreads / 64;
     constexpr int ND = point_doubles(EST);
-    constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 3); // bound terms per point
+    constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 2); // bound terms per point
     constexpr int NPW = 64 * P;                                         // correspondences per chunk
     __shared__ double s_pts[ND][NPW];
     __shared__ uint32_t s_queue[kWaves][kQueueCap];
@@ -748,12 +748,12 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
         if constexpr (EST == EST_ABS) {
             bnd[p][0] = pf_point_abs(x[2], x[3], x[4], pf.gx);
         } else {
-            float na, nb, nanb, nanb_thr;
-            pf_point_two_view(x[0], x[1], x[2], x[3], pf.thr, na, nb, nanb, nanb_thr);
+            float nanb, nsq, nanb_thr;
+            pf_point_two_view(x[0], x[1], x[2], x[3], pf.thr, nanb, nsq, nanb_thr);
             if constexpr (EST == EST_HOM)
                 bnd[p][0] = nanb_thr;
             else
-                bnd[p][0] = na, bnd[p][1] = nb, bnd[p][2] = nanb;
+                bnd[p][0] = nanb, bnd[p][1] = nsq;
         }
     }
     __syncthreads(); // the only workgroup barrier: fp64 correspondences are in LDS
@@ -874,10 +874,36 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
                 }
             } else {
                 const float gf = (16.f * kPfU) * r[14];
+                const float gf2 = gf * gf, gfx2 = gf + gf;
+                // two points per packed fp32 instruction, operation for operation pf_sampson_outlier
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
+                for (int p = 0; p + 1 < P; p += 2) {
+                    const v2f a0 = {pf32[p][0], pf32[p + 1][0]}, a1 = {pf32[p][1], pf32[p + 1][1]};
+                    const v2f b0 = {pf32[p][2], pf32[p + 1][2]}, b1 = {pf32[p][3], pf32[p + 1][3]};
+                    const v2f nanb = {bnd[p][0], bnd[p + 1][0]}, nsq = {bnd[p][1], bnd[p + 1][1]};
+                    const v2f Ea0 = pk_fma(bc(r[0]), a0, pk_fma(bc(r[1]), a1, bc(r[2])));
+                    const v2f Ea1 = pk_fma(bc(r[3]), a0, pk_fma(bc(r[4]), a1, bc(r[5])));
+                    const v2f Ea2 = pk_fma(bc(r[6]), a0, pk_fma(bc(r[7]), a1, bc(r[8])));
+                    const v2f Eb0 = pk_fma(bc(r[0]), b0, pk_fma(bc(r[3]), b1, bc(r[6])));
+                    const v2f Eb1 = pk_fma(bc(r[1]), b0, pk_fma(bc(r[4]), b1, bc(r[7])));
+                    const v2f C = pk_fma(b0, Ea0, pk_fma(b1, Ea1, Ea2));
+                    const v2f S = pk_fma(Eb1, Eb1, pk_fma(Eb0, Eb0, pk_fma(Ea1, Ea1, Ea0 * Ea0)));
+                    const v2f D = pk_fma(S, bc(1.015625f), bc(gf2) * nsq);
+                    const v2f eC = bc(gfx2) * nanb;
+                    const v2f R = bc(pf.thr2_up) * D;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float c = fabsf(C[e]) - eC[e];
+                        const uint64_t pos = __builtin_amdgcn_ballot_w64(c > 0.f);
+                        const uint64_t big = __builtin_amdgcn_ballot_w64(c * c > R[e]);
+                        m[p + e] = vmask[p + e] & ~(pos & big);
+                        any |= m[p + e];
+                    }
+                }
+                if constexpr (P & 1) {
+                    constexpr int p = P - 1;
                     const bool out = pf_sampson_outlier(r, gf, pf.thr2_up, pf32[p][0], pf32[p][1], pf32[p][2],
-                                                        pf32[p][3], bnd[p][0], bnd[p][1], bnd[p][2]);
+                                                        pf32[p][3], bnd[p][0], bnd[p][1]);
                     m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
                     any |= m[p];
                 }
@@ -1225,18 +1251,6 @@ static int max_points_per_lane_pf() {
     }();
     return v;
 }
-// `streaming`: launches of the batched main loop (k_score_queue: 64 * P correspondences per chunk, every wave of a
-// workgroup sees the same chunk); otherwise the non-streaming kernels (256 * P correspondences per chunk).
-static void score_shape(uint32_t n, bool streaming, uint32_t &chunks, int &P) {
-    const uint32_t lanes = streaming ? 64u : (uint32_t)kScoreThreads;
-    const uint32_t per_chunk_max = lanes * (uint32_t)max_points_per_lane_pf();
-    chunks = (n + per_chunk_max - 1) / per_chunk_max;
-    if (chunks == 0)
-        chunks = 1;
-    P = (int)((n + lanes * chunks - 1) / (lanes * chunks));
-    if (P < 1)
-        P = 1;
-}
 static bool use_queue_scorer() {
     static const bool v = [] {
         const char *e = std::getenv("POSELIB_AMD_SCORER"); // "stream": the per-slot evaluating scorer (A/B runs)
@@ -1244,11 +1258,41 @@ static bool use_queue_scorer() {
     }();
     return v;
 }
+// `streaming`: launches of the batched main loop (k_score_queue: 64 * P correspondences per chunk, every wave of a
+// workgroup sees the same chunk); otherwise the non-streaming kernels (256 * P correspondences per chunk).
+// For the Sampson scores P is chosen to minimise  chunks(P) * (VALU issue slots of the pre-filter for P points + a
+// per-hypothesis overhead): pairs of points share packed instructions, an odd point costs as much as a pair.
+static void score_shape(int est, uint32_t n, bool streaming, uint32_t &chunks, int &P) {
+    const uint32_t lanes = streaming ? 64u : (uint32_t)kScoreThreads;
+    const int pmax = max_points_per_lane_pf();
+    if (streaming && (est == EST_REL || est == EST_FUND) && std::getenv("POSELIB_AMD_PF_P") == nullptr) {
+        // Sampson filter: 27 issue slots per pair of points, 29 for an odd one, ~30 per hypothesis around them
+        // (measured on MI355X: P = 6 beats P = 5 by 25 % at N = 10000; for the cheaper reprojection and
+        // homography filters the smaller register footprint of P = 5 wins)
+        uint64_t best = ~0ull;
+        for (int q = 1; q <= 6; ++q) {
+            const uint64_t c = (n + lanes * q - 1) / (lanes * q);
+            const uint64_t cost = (c ? c : 1) * (uint64_t)((q / 2) * 27 + (q & 1) * 29 + 30);
+            if (cost < best)
+                best = cost, P = q;
+        }
+        chunks = (n + lanes * P - 1) / (lanes * P);
+        if (chunks == 0)
+            chunks = 1;
+        return;
+    }
+    const uint32_t per_chunk_max = lanes * (uint32_t)pmax;
+    chunks = (n + per_chunk_max - 1) / per_chunk_max;
+    if (chunks == 0)
+        chunks = 1;
+    P = (int)((n + lanes * chunks - 1) / (lanes * chunks));
+    if (P < 1)
+        P = 1;
+}
 uint32_t score_chunks(int est, uint32_t n, bool streaming) {
-    (void)est;
     uint32_t c;
     int P;
-    score_shape(n, streaming && use_queue_scorer(), c, P);
+    score_shape(est, n, streaming && use_queue_scorer(), c, P);
     return c;
 }
 
@@ -1259,7 +1303,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     const PrefilterArgs pf = a.pf;
     const bool use_pf = (E == EST_ABS) && pf.enabled && pf.gx > 0.f; // non-streaming launches: absolute pose only
     const bool streaming = a.shadow && a.compact64; // batched main loop: compact hypothesis stream
-    score_shape(a.pts.n, streaming && use_queue_scorer(), chunks, P);
+    score_shape(E, a.pts.n, streaming && use_queue_scorer(), chunks, P);
     const dim3 grid(slices, chunks), block(kScoreThreads);
     if (streaming && use_queue_scorer()) {
 #define PL_Q_CASE(PP)                                                                                                  \

@@ -21,11 +21,13 @@
 //    max(|a^0|, |a^1|) > fma(thr^, |h^2|, W).
 //  * Sampson (fundamental / essential), model F, point (a; b):  inlier => C^2 < thr2 (Cx + Cy) with
 //    C = b^T F a,  Cx + Cy = (Fa)_0^2 + (Fa)_1^2 + (F^T b)_0^2 + (F^T b)_1^2.  With fm >= max|F_ij|,
-//    na = 1 + |a0| + |a1|, nb = 1 + |b0| + |b1|:  every (Fa)^_i is within 5u fm na, every (F^T b)^_j within
-//    5u fm nb and C^ within 10u fm na nb of the exact value.  With e_a = 16u fm na, e_b = 16u fm nb,
-//    e_C = 32u fm na nb:   D_up = sum (|E^_k| + e_k)^2 >= Cx + Cy   and   |C| >= |C^| - e_C,   so
-//    |C^| > e_C  and  (|C^| - e_C)^2 > thr2 (1 + 64u) D_up   proves an outlier (the 64u absorbs the roundings of
-//    the test itself).
+//    na = 1 + |a0| + |a1|, nb = 1 + |b0| + |b1|:  every (Fa)^_i is within e_a = 16u fm na, every (F^T b)^_j within
+//    e_b = 16u fm nb (the bound is 5u) and C^ within e_C = 32u fm na nb (bound 10u) of the exact value.  By
+//    (|E| + e)^2 <= (1 + d) E^2 + (1 + 1/d) e^2  with d = 1/64:
+//        D_up = (1 + d) sum E^_k^2 + 130 (e_a^2 + e_b^2)  >=  Cx + Cy,      |C| >= |C^| - e_C,
+//    so  |C^| > e_C  and  (|C^| - e_C)^2 > thr2 (1 + 64u) D_up  proves an outlier (the 64u absorbs the roundings
+//    of the test itself).  This form needs no absolute values inside the sums and packs two points per
+//    v_pk_* instruction.
 //  * models with a NaN entry have no inliers at all (see store_shadow); models or thresholds outside the range in
 //    which fp32 keeps its relative accuracy (max-abs entry outside [1e-18, 1e18]) get an infinite slack, i.e. every
 //    point is evaluated exactly.
@@ -73,11 +75,12 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
 PL_HD float pf_point_abs(double X, double Y, double Z, float gx) { // gx * upper bound of |X|_2
     return pf_up(gx * pf_up((float)sqrt(X * X + Y * Y + Z * Z)));
 }
-PL_HD void pf_point_two_view(double a0, double a1, double b0, double b1, float thr, float &na, float &nb, float &nanb,
+PL_HD void pf_point_two_view(double a0, double a1, double b0, double b1, float thr, float &nanb, float &nsq,
                              float &nanb_thr) {
-    na = pf_up((float)(1.0 + fabs(a0) + fabs(a1)));
-    nb = pf_up((float)(1.0 + fabs(b0) + fabs(b1)));
-    nanb = pf_up(na * nb);                          // Sampson: e_C = gf * 2 * na * nb
+    const float na = pf_up((float)(1.0 + fabs(a0) + fabs(a1)));
+    const float nb = pf_up((float)(1.0 + fabs(b0) + fabs(b1)));
+    nanb = pf_up(na * nb);                          // Sampson: e_C = 2 gf * na * nb
+    nsq = pf_up(130.f * pf_up(na * na + nb * nb));  // Sampson: 130 (e_a^2 + e_b^2) = gf^2 * nsq
     nanb_thr = pf_up(na * pf_up(nb + thr));         // homography: W = gh * na * (nb + thr)
 }
 
@@ -111,18 +114,16 @@ PL_HD bool pf_hom_outlier(const float *r, float gh /* 32u * hm */, float thr, fl
 }
 
 PL_HD bool pf_sampson_outlier(const float *r, float gf /* 16u * fm */, float thr2_up, float a0, float a1, float b0,
-                              float b1, float na, float nb, float nanb) {
+                              float b1, float nanb, float nsq) {
     const float Ea0 = fmaf(r[0], a0, fmaf(r[1], a1, r[2]));
     const float Ea1 = fmaf(r[3], a0, fmaf(r[4], a1, r[5]));
     const float Ea2 = fmaf(r[6], a0, fmaf(r[7], a1, r[8]));
     const float Eb0 = fmaf(r[0], b0, fmaf(r[3], b1, r[6]));
     const float Eb1 = fmaf(r[1], b0, fmaf(r[4], b1, r[7]));
     const float C = fmaf(b0, Ea0, fmaf(b1, Ea1, Ea2));
-    const float ea = gf * na, eb = gf * nb;
-    const float eC = (gf + gf) * nanb;
-    const float s0 = fabsf(Ea0) + ea, s1 = fabsf(Ea1) + ea, s2 = fabsf(Eb0) + eb, s3 = fabsf(Eb1) + eb;
-    const float D = fmaf(s3, s3, fmaf(s2, s2, fmaf(s1, s1, s0 * s0)));
-    const float c = fabsf(C) - eC;
+    const float S = fmaf(Eb1, Eb1, fmaf(Eb0, Eb0, fmaf(Ea1, Ea1, Ea0 * Ea0)));
+    const float D = fmaf(S, 1.015625f, (gf * gf) * nsq);
+    const float c = fabsf(C) - (gf + gf) * nanb;
     return (c > 0.f) & (c * c > thr2_up * D);
 }
 

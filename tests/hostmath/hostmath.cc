@@ -288,13 +288,13 @@ int hm_prefilter(int est, const double *rec, const double *const *pa, uint32_t n
             out[i] = pf_abs_outlier(r, gt, pf.thr, (float)pa[0][i], (float)pa[1][i], (float)pa[2][i], (float)pa[3][i],
                                     (float)pa[4][i], fw);
         } else {
-            float na, nb, nanb, nanb_thr;
-            pf_point_two_view(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pf.thr, na, nb, nanb, nanb_thr);
+            float nanb, nsq, nanb_thr;
+            pf_point_two_view(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pf.thr, nanb, nsq, nanb_thr);
             const float a0 = (float)pa[0][i], a1 = (float)pa[1][i], b0 = (float)pa[2][i], b1 = (float)pa[3][i];
             if (est == EST_HOM)
                 out[i] = pf_hom_outlier(r, (32.f * kPfU) * r[14], pf.thr, a0, a1, b0, b1, nanb_thr);
             else
-                out[i] = pf_sampson_outlier(r, (16.f * kPfU) * r[14], pf.thr2_up, a0, a1, b0, b1, na, nb, nanb);
+                out[i] = pf_sampson_outlier(r, (16.f * kPfU) * r[14], pf.thr2_up, a0, a1, b0, b1, nanb, nsq);
         }
     }
     return 1;
