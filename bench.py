@@ -24,6 +24,11 @@ The JSON line also carries
 import argparse
 import json
 import os
+
+# one HIP stream per in-flight problem: let the runtime map them onto 8 hardware queues instead of the default 4
+# (must be set before the HIP runtime initialises; measured +5..15 % whole-job throughput on MI355X; 16 queues were
+# another few % faster but ran a mixed-estimator batch out of queue resources, so 8 it is)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 import time
 
@@ -50,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=16,
                     help="independent problems in flight per GPU (one host thread + HIP stream each)")
     ap.add_argument("--workload", default="p3p_5000", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -49,6 +49,27 @@ __device__ __forceinline__ double wave_sum(double v) {
         v += __shfl_xor(v, off, 64);
     return v;
 }
+// Wave reduction through the DPP cross-lane paths (no LDS round trips as in __shfl_xor): quads, half rows, rows of
+// 16, then row broadcasts; the total is read from lane 63.  The pairing differs from wave_sum's xor butterfly, so
+// the two agree to rounding only - the LM normal equations use this one, the MSAC scores keep wave_sum.
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ double dpp_move(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v); // row_half_mirror
+    v += dpp_move<0x140>(v); // row_mirror: every lane holds the sum of its row of 16
+    v += dpp_move<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3 (other rows add 0)
+    v += dpp_move<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
@@ -998,7 +1019,7 @@ template <int N> struct BlockReduce {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const double s = wave_sum(v[i]);
+            const double s = wave_sum_dpp(v[i]);
             if (lane == 0)
                 scratch[wave][i] = s;
         }
