@@ -49,7 +49,7 @@ typedef struct {
     double dyn_num_trials_mult; /* 3.0 */
     double success_prob;        /* 0.9999 */
     uint64_t seed;              /* 0 */
-    int32_t progressive_sampling; /* PROSAC: not implemented on device yet -> PL_ERR_UNSUPPORTED */
+    int32_t progressive_sampling; /* PROSAC (sampling.cc:85-136): samples drawn on the host, models on the device */
     int32_t score_initial_model;
     uint64_t max_prosac_iterations;
 } pl_ransac_options;

@@ -92,7 +92,7 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // batch scratch
-    DevBuf positions, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf positions, samples, models, num_models, slots, num_hyp, part_count, part_score, count, score;
     DevBuf shadow, compact64;
     DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
@@ -373,6 +373,65 @@ uint64_t sample_positions_k(int K, uint64_t seed, uint64_t pos, uint64_t N, uint
     }
 }
 
+// PROSAC sampling (PoseLib/robust/sampling.cc:85-136): the size of the subset the sample is drawn from follows a
+// serial recurrence over the iteration counter, so the samples of a batch are drawn on the host - one splitmix64
+// draw (pl_sampler.h draw_at) per index - and handed to k_generate explicitly.  After max_prosac_iterations the
+// sampler is the uniform one again (sampling.cc:101-102).
+struct ProsacSampler {
+    uint64_t seed = 0, N = 0, max_it = 0;
+    int K = 0;
+    uint64_t pos = 0;        // splitmix draws consumed
+    uint64_t sample_k = 1;   // sampling.cc:133
+    uint64_t subset_sz = 0;  // sampling.cc:134
+    std::vector<uint64_t> growth;
+
+    void init(uint64_t seed_, uint64_t N_, int K_, uint64_t max_prosac_iterations) { // sampling.cc:105-135
+        seed = seed_, N = N_, K = K_, max_it = max_prosac_iterations;
+        growth.assign(std::max<uint64_t>(N, (uint64_t)K), 0);
+        double T_n = (double)max_it;
+        for (int i = 0; i < K; ++i)
+            T_n *= static_cast<double>(K - i) / static_cast<double>(N - i);
+        for (int n = 0; n < K; ++n)
+            growth[n] = 1;
+        uint64_t T_np = 1;
+        for (uint64_t n = K; n < N; ++n) {
+            const double T_n_next = T_n * (n + 1.0) / (n + 1.0 - K);
+            T_np += (uint64_t)std::ceil(T_n_next - T_n);
+            growth[n] = T_np;
+            T_n = T_n_next;
+        }
+        sample_k = 1;
+        subset_sz = (uint64_t)K;
+        pos = 0;
+    }
+    void draw(int count, uint64_t range, uint32_t *out) { // sampling.cc:46-61
+        for (int i = 0; i < count; ++i) {
+            for (;;) {
+                const uint32_t v = (uint32_t)draw_at(seed, ++pos, range);
+                bool fresh = true;
+                for (int j = 0; j < i; ++j)
+                    fresh = fresh && out[j] != v;
+                if (fresh) {
+                    out[i] = v;
+                    break;
+                }
+            }
+        }
+    }
+    void generate(uint32_t *sample) { // sampling.cc:85-103
+        if (sample_k < max_it) {
+            draw(K - 1, subset_sz - 1, sample);
+            sample[K - 1] = (uint32_t)(subset_sz - 1);
+            sample_k++;
+            if (sample_k < max_it && sample_k > growth[subset_sz - 1])
+                if (++subset_sz > N)
+                    subset_sz = N;
+        } else {
+            draw(K, N, sample);
+        }
+    }
+};
+
 // Parameters of the scoring kernels' conservative fp32 pre-filters (pl_prefilter.h).  Every value is rounded UP;
 // POSELIB_AMD_NO_PREFILTER=1 disables the filters (exact evaluation of every point).
 void set_prefilter(ScoreArgs &sa, const pl_problem *p, double thr2) {
@@ -589,6 +648,10 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
         std::vector<uint32_t> order;
         const bool host_bookkeeping = std::getenv("POSELIB_AMD_HOST_BOOKKEEPING") != nullptr;
         bool force_host_positions = false;
+        const bool prosac = ro.progressive_sampling != 0;
+        ProsacSampler prosac_sampler;
+        if (prosac)
+            prosac_sampler.init(ro.seed, N, K, ro.max_prosac_iterations);
 
         while (!stopped && it < ro.max_iterations) {
             if (it > ro.min_iterations && it > dyn_max) { // stop rule at the top of the next iteration (:182)
@@ -634,7 +697,18 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(BatchCtl), c->stream));
 
             uint64_t pos_after = 0;
-            bool device_positions = !host_bookkeeping && !force_host_positions;
+            bool device_positions = !host_bookkeeping && !force_host_positions && !prosac;
+            const ProsacSampler prosac_at_batch_start = prosac_sampler; // a repeated batch draws the same samples
+            if (prosac) {
+                HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * (size_t)B * K));
+                HIP_TRY(c->samples.ensure(sizeof(uint32_t) * (size_t)B * K));
+                uint32_t *hs = c->h_positions.as<uint32_t>();
+                for (uint32_t b = 0; b < B; ++b)
+                    prosac_sampler.generate(hs + (size_t)b * K);
+                pos_after = prosac_sampler.pos;
+                HIP_TRY(hipMemcpyAsync(c->samples.p, hs, sizeof(uint32_t) * (size_t)B * K, hipMemcpyHostToDevice,
+                                       c->stream));
+            }
             if (device_positions) {
                 // window of draw positions to evaluate: expected draws per iteration (sum N/(N-i)) + slack
                 double per_it = 0;
@@ -652,7 +726,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                                                     c->stream));
                 }
             }
-            if (!device_positions) {
+            if (!device_positions && !prosac) {
                 HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * B));
                 pos_after = sample_positions_k(K, ro.seed, pos, N, B, c->h_positions.as<uint32_t>());
                 if (pos_after - pos >= 0xffffffffull)
@@ -665,6 +739,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             ga.seed = ro.seed;
             ga.pos_base = pos;
             ga.positions = c->positions.as<uint32_t>();
+            ga.samples = prosac ? c->samples.as<uint32_t>() : nullptr;
             ga.num_iters = B;
             ga.slots_per_iter = (uint32_t)MAXM;
             ga.ctl = d_ctl;
@@ -726,6 +801,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             }
             if (h_ctl->gen_overflow) { // an iteration produced more models than the reserved slots: redo with 40
                 MAXM = max_models(kind);
+                prosac_sampler = prosac_at_batch_start;
                 continue;
             }
             force_host_positions = false;
@@ -909,8 +985,6 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
 int validate_options(const pl_robust_options *o) {
     if (!o)
         return fail(PL_ERR_INVALID, "options pointer is null");
-    if (o->ransac.progressive_sampling)
-        return fail(PL_ERR_UNSUPPORTED, "PROSAC sampling is not implemented on the device path yet");
     if (o->bundle.refine_focal_length || o->bundle.refine_extra_params || o->bundle.refine_principal_point)
         return fail(PL_ERR_UNSUPPORTED, "intrinsics refinement is outside the accelerated hot path");
     if (o->tangent_sampson || o->estimate_focal_length || o->estimate_extra_params)

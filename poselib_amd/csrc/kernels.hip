@@ -85,7 +85,13 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs
     constexpr int K = sample_size(EST);
     constexpr int MAXM = max_models(EST);
     uint32_t idx[K];
-    draw_sample<K>(g.seed, g.pos_base + g.positions[it], g.pts.n, idx);
+    if (g.samples) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            idx[k] = g.samples[(size_t)it * K + k];
+    } else {
+        draw_sample<K>(g.seed, g.pos_base + g.positions[it], g.pts.n, idx);
+    }
     (void)MAXM;
     double *rec = g.models + (size_t)it * g.slots_per_iter * kModelStride;
     int n = 0;

@@ -31,6 +31,8 @@ struct GenerateArgs {
     uint64_t seed;
     uint64_t pos_base;         // draws consumed before the batch
     const uint32_t *positions; // draws consumed before each iteration, relative to pos_base
+    const uint32_t *samples;   // optional explicit minimal samples [num_iters][K] (PROSAC: drawn on the host,
+                               // the subset schedule is a serial recurrence); nullptr => draw from `positions`
     uint32_t num_iters;
     uint32_t slots_per_iter;   // record slots reserved per iteration (<= max_models(est)); more solutions than
                                // slots => ctl->gen_overflow is set and the host repeats the batch with more room

@@ -195,9 +195,12 @@ PL_HD void camera_project_jac(const CameraParams &c, Vec3 Z, double &ox, double 
         double du, dv, Jd[4];
         opencv_distort(c.p[4], c.p[5], c.p[6], c.p[7], u, v, du, dv, Jd);
         const double P[6] = {1.0 / Z.z, 0.0, -u / Z.z, 0.0, 1.0 / Z.z, -v / Z.z};
+        PL_UNROLL
         for (int a = 0; a < 2; ++a)
+            PL_UNROLL
             for (int b = 0; b < 3; ++b)
                 J[3 * a + b] = Jd[2 * a] * P[b] + Jd[2 * a + 1] * P[3 + b];
+        PL_UNROLL
         for (int b = 0; b < 3; ++b) {
             J[b] *= c.p[0];
             J[3 + b] *= c.p[1];
@@ -230,10 +233,13 @@ template <int K> PL_HD void accumulate2(double *acc, const Loss &loss, double r0
     if (w == 0)
         return;
     int o = 0;
+    PL_UNROLL
     for (int i = 0; i < K; ++i)
+        PL_UNROLL
         for (int j = 0; j <= i; ++j)
             acc[o++] += w * (J[i] * J[j] + J[K + i] * J[K + j]);
     const double wr0 = w * r0, wr1 = w * r1;
+    PL_UNROLL
     for (int i = 0; i < K; ++i)
         acc[o + i] += J[i] * wr0 + J[K + i] * wr1;
     count++;
@@ -244,10 +250,13 @@ template <int K> PL_HD void accumulate1(double *acc, const Loss &loss, double r,
     if (w == 0)
         return;
     int o = 0;
+    PL_UNROLL
     for (int i = 0; i < K; ++i)
+        PL_UNROLL
         for (int j = 0; j <= i; ++j)
             acc[o++] += w * (J[i] * J[j]);
     const double wr = w * r;
+    PL_UNROLL
     for (int i = 0; i < K; ++i)
         acc[o + i] += wr * J[i];
     count++;
@@ -297,6 +306,7 @@ template <int K> PL_HD void lm_solve(LMControl &c, const double *normal, bool fr
     if (fresh_jacobian) {
         c.count = jac_count;
         double s = 0;
+        PL_UNROLL
         for (int i = 0; i < K; ++i)
             s += normal[T + i] * normal[T + i];
         c.grad_norm = lm_scale(c.count) * sqrt(s);
@@ -307,19 +317,24 @@ template <int K> PL_HD void lm_solve(LMControl &c, const double *normal, bool fr
     }
     const double sc = lm_scale(c.count);
     double A[K * K], b[K];
+    PL_UNROLL
     for (int i = 0; i < K; ++i) {
+        PL_UNROLL
         for (int j = 0; j <= i; ++j)
             A[i * K + j] = sc * normal[i * (i + 1) / 2 + j];
         b[i] = -(sc * normal[T + i]);
     }
+    PL_UNROLL
     for (int i = 0; i < K; ++i)
         A[i * K + i] += (c.opt.damping == 1) ? fmax(A[i * K + i] * c.lambda, 1e-8) : c.lambda;
     // Cholesky with the operation order of Eigen's unblocked LLT (squared norm / dot product summed first, then
     // subtracted), forward solve by column-oriented updates, backward solve by row dot product then subtract
+    PL_UNROLL
     for (int col = 0; col < K; ++col) {
         double d = A[col * K + col];
         if (col > 0) {
             double sq = A[col * K] * A[col * K];
+            PL_UNROLL
             for (int m = 1; m < col; ++m)
                 sq += A[col * K + m] * A[col * K + m];
             d -= sq;
@@ -328,10 +343,12 @@ template <int K> PL_HD void lm_solve(LMControl &c, const double *normal, bool fr
             break;
         d = sqrt(d);
         A[col * K + col] = d;
+        PL_UNROLL
         for (int r = col + 1; r < K; ++r) {
             double s = A[r * K + col];
             if (col > 0) {
                 double dot = A[r * K] * A[col * K];
+                PL_UNROLL
                 for (int m = 1; m < col; ++m)
                     dot += A[r * K + m] * A[col * K + m];
                 s -= dot;
@@ -339,16 +356,21 @@ template <int K> PL_HD void lm_solve(LMControl &c, const double *normal, bool fr
             A[r * K + col] = s / d;
         }
     }
+    PL_UNROLL
     for (int i = 0; i < K; ++i)
         c.sol[i] = b[i];
+    PL_UNROLL
     for (int i = 0; i < K; ++i) {
         c.sol[i] /= A[i * K + i];
+        PL_UNROLL
         for (int r = i + 1; r < K; ++r)
             c.sol[r] -= c.sol[i] * A[r * K + i];
     }
+    PL_UNROLL
     for (int i = K - 1; i >= 0; --i) {
         if (i + 1 < K) {
             double dot = A[(i + 1) * K + i] * c.sol[i + 1];
+            PL_UNROLL
             for (int j = i + 2; j < K; ++j)
                 dot += A[j * K + i] * c.sol[j];
             c.sol[i] -= dot;
@@ -356,6 +378,7 @@ template <int K> PL_HD void lm_solve(LMControl &c, const double *normal, bool fr
         c.sol[i] /= A[i * K + i];
     }
     double sn = 0;
+    PL_UNROLL
     for (int i = 0; i < K; ++i)
         sn += c.sol[i] * c.sol[i];
     c.step_norm = sqrt(sn);
@@ -378,6 +401,7 @@ template <int K> PL_HD bool lm_update(LMControl &c, const double *normal, double
         if (c.opt.lambda_update == 0) {
             const double sc = lm_scale(c.count);
             double s = 0;
+            PL_UNROLL
             for (int i = 0; i < K; ++i)
                 s += c.sol[i] * (c.lambda * c.sol[i] + sc * normal[T + i]);
             const double pred = -s;
@@ -435,6 +459,7 @@ template <> struct Refiner<EST_ABS> {
         Quat q;
         q.w = p[0], q.x = p[1], q.y = p[2], q.z = p[3];
         const Mat3 R = quat_to_rotmat(q);
+        PL_UNROLL
         for (int i = 0; i < 9; ++i)
             c.M[i] = R.m[i];
     }
@@ -463,6 +488,7 @@ template <> struct Refiner<EST_ABS> {
         camera_project_jac(cam, Zc, px, py, Jp);
         r0 = px - x;
         r1 = py - y;
+        PL_UNROLL
         for (int a = 0; a < 2; ++a) {
             const double d0 = Jp[3 * a] * R[0] + Jp[3 * a + 1] * R[3] + Jp[3 * a + 2] * R[6];
             const double d1 = Jp[3 * a] * R[1] + Jp[3 * a + 1] * R[4] + Jp[3 * a + 2] * R[7];
@@ -481,6 +507,7 @@ template <> struct Refiner<EST_ABS> {
         q.w = p[0], q.x = p[1], q.y = p[2], q.z = p[3];
         const Quat qn = quat_step_post(q, v3(dp[0], dp[1], dp[2]));
         const Vec3 dt = quat_rotate(q, v3(dp[3], dp[4], dp[5]));
+        PL_UNROLL
         for (int i = 0; i < kParamDoubles; ++i)
             out[i] = p[i];
         out[0] = qn.w, out[1] = qn.x, out[2] = qn.y, out[3] = qn.z;
@@ -523,6 +550,7 @@ PL_HD double sampson_residual_grad(const double *E, double a0, double a1, double
     dF[5] -= s * (J1);
     dF[6] -= s * (J2);
     dF[7] -= s * (J3);
+    PL_UNROLL
     for (int i = 0; i < 9; ++i)
         dF[i] *= inv;
     return r;
@@ -550,6 +578,7 @@ template <> struct Refiner<EST_REL> {
         const Mat3 R = quat_to_rotmat(q);
         const Vec3 t = v3(p[4], p[5], p[6]);
         const Mat3 E = essential_from_motion(R, t);
+        PL_UNROLL
         for (int i = 0; i < 9; ++i)
             c.M[i] = E.m[i];
         // D[m][0..2] = d vec(E)/d rot, D[m][3..4] = d vec(E)/d tangent   (relative.h:39-61)
@@ -557,7 +586,9 @@ template <> struct Refiner<EST_REL> {
         const Vec3 zero = v3(0, 0, 0);
         const Vec3 blocks[3][3] = {{zero, -e2, e1}, {e2, zero, -e0}, {-e1, e0, zero}};
         const Vec3 tb0 = v3(p[7], p[8], p[9]), tb1 = v3(p[10], p[11], p[12]);
+        PL_UNROLL
         for (int cb = 0; cb < 3; ++cb) {
+            PL_UNROLL
             for (int k = 0; k < 3; ++k) {
                 const Vec3 v = blocks[cb][k];
                 c.D[(3 * cb + 0) * 7 + k] = v.x;
@@ -575,8 +606,10 @@ template <> struct Refiner<EST_REL> {
     PL_HD static double jacobian(const RefineCtx &c, double a0, double a1, double b0, double b1, double *J) {
         double dF[9];
         const double r = sampson_residual_grad(c.M, a0, a1, b0, b1, dF);
+        PL_UNROLL
         for (int k = 0; k < 5; ++k) {
             double s = 0;
+            PL_UNROLL
             for (int m = 0; m < 9; ++m)
                 s += dF[m] * c.D[m * 7 + k];
             J[k] = s;
@@ -587,6 +620,7 @@ template <> struct Refiner<EST_REL> {
         Quat q;
         q.w = p[0], q.x = p[1], q.y = p[2], q.z = p[3];
         const Quat qn = quat_step_post(q, v3(dp[0], dp[1], dp[2]));
+        PL_UNROLL
         for (int i = 0; i < kParamDoubles; ++i)
             out[i] = p[i];
         out[0] = qn.w, out[1] = qn.x, out[2] = qn.y, out[3] = qn.z;
@@ -601,6 +635,7 @@ template <> struct Refiner<EST_HOM> {
     static constexpr int K = 8;
     PL_HD static void prepare(const double *p, RefineCtx &c) {
         const double *H = p;
+        PL_UNROLL
         for (int i = 0; i < 9; ++i)
             c.M[i] = H[i];
         c.G[0] = H[4] * H[8] - H[5] * H[7];
@@ -636,6 +671,7 @@ template <> struct Refiner<EST_HOM> {
         transfer(H, a0, a1, z0, z1, inv);
         f0 = z0 - b0, f1 = z1 - b1;
         const double jf[16] = {a0, 0.0, -a0 * z0, a1, 0.0, -a1 * z0, 1.0, 0.0, 0.0, a0, -a0 * z1, 0.0, a1, -a1 * z1, 0.0, 1.0};
+        PL_UNROLL
         for (int i = 0; i < 16; ++i)
             Jf[i] = jf[i] * inv;
         double y0, y1, ginv;
@@ -660,13 +696,16 @@ template <> struct Refiner<EST_HOM> {
                                H00 * y1b1 - H10 * y1b0,
                                H10 - H20 * b1,
                                H20 * b0 - H00};
+        PL_UNROLL
         for (int i = 0; i < 16; ++i)
             Jb[i] = jb[i] * ginv;
     }
     PL_HD static void step(const double *p, const RefineCtx &, const double *dp, double *out) {
+        PL_UNROLL
         for (int i = 0; i < kParamDoubles; ++i)
             out[i] = p[i];
         // parameters = first 8 entries of column-major H: e -> (row e%3, col e/3)
+        PL_UNROLL
         for (int e = 0; e < 8; ++e)
             out[3 * (e % 3) + (e / 3)] = p[3 * (e % 3) + (e / 3)] + dp[e];
     }
@@ -679,7 +718,9 @@ PL_HD void factorized_F(const double *p, double *F) { // optim_utils.h:73-77
     qV.w = p[4], qV.x = p[5], qV.y = p[6], qV.z = p[7];
     const Mat3 U = quat_to_rotmat(qU), V = quat_to_rotmat(qV);
     const double sigma = p[8];
+    PL_UNROLL
     for (int i = 0; i < 3; ++i)
+        PL_UNROLL
         for (int j = 0; j < 3; ++j)
             F[3 * i + j] = U.m[3 * i] * V.m[3 * j] + (sigma * U.m[3 * i + 1]) * V.m[3 * j + 1];
 }
@@ -692,24 +733,31 @@ template <> struct Refiner<EST_FUND> {
         qV.w = p[4], qV.x = p[5], qV.y = p[6], qV.z = p[7];
         const Mat3 U = quat_to_rotmat(qU), V = quat_to_rotmat(qV);
         Mat3 F;
+        PL_UNROLL
         for (int i = 0; i < 9; ++i)
             F.m[i] = c.M[i];
         const Vec3 axes[3] = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+        PL_UNROLL
         for (int cb = 0; cb < 3; ++cb) {
             const Vec3 f = col(F, cb);
+            PL_UNROLL
             for (int k = 0; k < 3; ++k) {
                 const Vec3 d = cross(axes[k], f);
                 c.D[(3 * cb + 0) * 7 + k] = d.x, c.D[(3 * cb + 1) * 7 + k] = d.y, c.D[(3 * cb + 2) * 7 + k] = d.z;
             }
         }
+        PL_UNROLL
         for (int r = 0; r < 3; ++r) {
             const Vec3 f = row(F, r);
+            PL_UNROLL
             for (int k = 0; k < 3; ++k) {
                 const Vec3 d = cross(axes[k], f);
                 c.D[(0 + r) * 7 + 3 + k] = d.x, c.D[(3 + r) * 7 + 3 + k] = d.y, c.D[(6 + r) * 7 + 3 + k] = d.z;
             }
         }
+        PL_UNROLL
         for (int j = 0; j < 3; ++j)
+            PL_UNROLL
             for (int i = 0; i < 3; ++i)
                 c.D[(3 * j + i) * 7 + 6] = U.m[3 * i + 1] * V.m[3 * j + 1];
     }
@@ -719,8 +767,10 @@ template <> struct Refiner<EST_FUND> {
     PL_HD static double jacobian(const RefineCtx &c, double a0, double a1, double b0, double b1, double *J) {
         double dF[9];
         const double r = sampson_residual_grad(c.M, a0, a1, b0, b1, dF);
+        PL_UNROLL
         for (int k = 0; k < 7; ++k) {
             double s = 0;
+            PL_UNROLL
             for (int m = 0; m < 9; ++m)
                 s += dF[m] * c.D[m * 7 + k];
             J[k] = s;
@@ -733,6 +783,7 @@ template <> struct Refiner<EST_FUND> {
         qV.w = p[4], qV.x = p[5], qV.y = p[6], qV.z = p[7];
         const Quat u = quat_step_pre(qU, v3(dp[0], dp[1], dp[2]));
         const Quat v = quat_step_pre(qV, v3(dp[3], dp[4], dp[5]));
+        PL_UNROLL
         for (int i = 0; i < kParamDoubles; ++i)
             out[i] = p[i];
         out[0] = u.w, out[1] = u.x, out[2] = u.y, out[3] = u.z;

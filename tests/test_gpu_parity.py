@@ -267,6 +267,31 @@ def test_estimate_fundamental_parity(gpu, n, outl, dseed, rseed):
     assert ok, err
 
 
+@pytest.mark.parametrize("max_prosac", [100000, 300])
+def test_prosac_sampling_parity(gpu, max_prosac):
+    """progressive sampling (sampling.cc:85-136): correspondences sorted by quality, samples from a growing
+    prefix; with max_prosac_iterations = 300 the run crosses over to uniform sampling half way"""
+    d = synth.absolute_pose_scene(2000, 0.6, 91)
+    order = np.argsort(~d["inlier_gt"], kind="stable")  # "best" matches first
+    p2d, p3d = d["p2d"][order], d["p3d"][order]
+    opt = {"ransac": {"seed": 4, "progressive_sampling": True, "max_prosac_iterations": max_prosac}}
+    img, info = gpu.estimate_absolute_pose(p2d, p3d, d["camera"], opt)
+    pose, mask, st = O.estimate_absolute_pose(p2d, p3d, d["camera"], opt)
+    assert info["iterations"] == st["iterations"] and info["refinements"] == st["refinements"]
+    assert info["num_inliers"] == st["num_inliers"] and (np.array(info["inliers"]) == mask).all()
+    ok, err = pose_close(img.pose, pose)
+    assert ok, err
+    h = synth.homography_scene(3000, 0.5, 92)
+    order = np.argsort(~h["inlier_gt"], kind="stable")
+    x1, x2 = h["x1"][order], h["x2"][order]
+    Hg, info = gpu.estimate_homography(x1, x2, opt)
+    Ho, mask, st = O.estimate_homography(x1, x2, opt)
+    assert info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+    assert (np.array(info["inliers"]) == mask).all()
+    ok, err = mat_close(Hg, Ho)
+    assert ok, err
+
+
 def test_edge_cases(gpu):
     d = synth.absolute_pose_scene(200, 0.5, 1000)
     # fewer points than the sample size: default stats, identity pose, mask computed for it (ransac_impl.h:161-163)
