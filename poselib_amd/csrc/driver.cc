@@ -461,6 +461,7 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     sa.slots = nullptr;
     sa.shadow = nullptr;
     sa.compact64 = nullptr;
+
     sa.num_hyp = c->num_hyp.as<uint32_t>();
     sa.hyp_capacity = nrec;
     sa.thr2 = thr2;

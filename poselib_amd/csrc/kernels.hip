@@ -750,6 +750,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
     __shared__ uint32_t s_queue[kWaves][kQueueCap];
     __shared__ double s_acc_s[kWaves][64];
     __shared__ uint32_t s_acc_c[kWaves][64];
+    __shared__ uint32_t s_next_group;
     const int lane = threadIdx.x & 63;
     // readfirstlane: the wave index is uniform, and the compiler has to know it for the scalar (s_load) shadow stream
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -783,18 +784,34 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
                 bnd[p][0] = nanb, bnd[p][1] = nsq;
         }
     }
+    if (threadIdx.x == 0)
+        s_next_group = 0;
     __syncthreads(); // the only workgroup barrier: fp64 correspondences are in LDS
 
     const uint32_t H = *as_uniform(num_hyp_ptr);
-    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
-    const uint32_t k0 = blockIdx.x * per;
-    const uint32_t k1 = min(H, k0 + per);
     const uniform_f32_ptr sh = as_uniform(shadow);
     uint32_t *const queue = s_queue[wave];
     double *const acc_s = s_acc_s[wave];
     uint32_t *const acc_c = s_acc_c[wave];
 
-    for (uint32_t kb = k0 + 64u * wave; kb < k1; kb += 64u * kWaves) {
+    // The workgroup owns a contiguous range of 64-hypothesis groups; its four waves take them one at a time from
+    // a counter in LDS, so they finish together (a static split leaves one wave a whole group behind).  Which wave
+    // evaluates a group has no influence on its results.
+    const uint32_t G = (H + 63u) / 64u;
+    const uint32_t gper = (G + gridDim.x - 1) / gridDim.x;
+    const uint32_t g0 = blockIdx.x * gper;
+    const uint32_t g1 = min(G, g0 + gper);
+    auto request_ticket = [&]() -> uint32_t { // per-lane value; lane 0 holds the ticket
+        uint32_t t = 0;
+        if (lane == 0)
+            t = atomicAdd(&s_next_group, 1u);
+        return t;
+    };
+    uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)request_ticket());
+    while (g0 + ticket < g1) {
+        const uint32_t kb = (g0 + ticket) * 64u;
+        const uint32_t k1 = H;
+        const uint32_t pending = request_ticket(); // the next ticket travels while this group is evaluated
         const uint32_t gn = min(64u, k1 - kb);
         acc_s[lane] = 0.0;
         acc_c[lane] = 0;
@@ -978,6 +995,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
             part_score[o] = acc_s[lane];
             part_count[o] = acc_c[lane];
         }
+        ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
     }
 }
 

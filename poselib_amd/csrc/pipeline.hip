@@ -272,17 +272,25 @@ __global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, u
         for (uint32_t m = 0; m < nm; ++m) {
             const uint32_t slot = i * (uint32_t)maxm + m;
             slots[o + m] = slot;
-            if (shadow_compact) { // fp32 model shadows in hypothesis order (streamed by the pre-filtered scorer)
-                const float4 *src = reinterpret_cast<const float4 *>(models + (size_t)slot * kModelStride + kShadowOff);
-                float4 *dst = reinterpret_cast<float4 *>(shadow_compact + (size_t)(o + m) * 16);
-                dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
-                const double2 *s64 = reinterpret_cast<const double2 *>(models + (size_t)slot * kModelStride);
-                double2 *d64 = reinterpret_cast<double2 *>(compact64 + (size_t)(o + m) * kModelDoubles);
-                for (int j = 0; j < kModelDoubles / 2; ++j)
-                    d64[j] = s64[j];
-            }
         }
     }
+}
+
+// Hypothesis-ordered copies of the records for the streaming scorer: 12 lanes move the 192 bytes of one record
+// (16 B each, contiguous on both sides): bytes 0..127 = the fp64 model -> compact64, 128..191 = the fp32 shadow.
+__global__ __launch_bounds__(256) void k_gather_models(const uint32_t *num_hyp, const uint32_t *slots,
+                                                       const double *models, float *shadow_compact, double *compact64) {
+    static_assert(kModelStride == 24 && kModelDoubles == 16 && kShadowOff == 16, "record layout");
+    const uint32_t H = *num_hyp;
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t k = (uint32_t)(t / 12), part = (uint32_t)(t % 12);
+    if (k >= H)
+        return;
+    const uint4 v = reinterpret_cast<const uint4 *>(models + (size_t)slots[k] * kModelStride)[part];
+    if (part < 8)
+        reinterpret_cast<uint4 *>(compact64 + (size_t)k * kModelDoubles)[part] = v;
+    else
+        reinterpret_cast<uint4 *>(shadow_compact + (size_t)k * 16)[part - 8] = v;
 }
 
 // ------------------------------------------------------------------------------------ finalize + records
@@ -438,6 +446,11 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
     k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
     k_compact2<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, maxm, blk_tot, slots, offsets, models, shadow_compact,
                                                     compact64, ctl);
+    if (shadow_compact && compact64) {
+        const uint64_t threads = (uint64_t)B * (uint64_t)maxm * 12u; // capacity; lanes beyond num_hyp return at once
+        k_gather_models<<<dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream>>>(&ctl->num_hyp, slots, models,
+                                                                                          shadow_compact, compact64);
+    }
     return hipGetLastError();
 }
 
