@@ -7,17 +7,18 @@
 Workload (config.workload = "p3p_5000"): BASELINE.json configs[1] — P3P LO-RANSAC on 5000 synthetic 2D-3D
 correspondences, 70 % outliers, max_iterations = 100000, with min_iterations = max_iterations so that the
 loop really evaluates 100000 iterations (with default options PoseLib stops after ~10^3).
-One "step" = S (= --streams, default 8) independent, complete ransac_pnp calls in flight on the GPU (sample ->
+One "step" = S (= --streams, default 16) independent, complete ransac_pnp calls in flight on the GPU (sample ->
 P3P -> score all N -> LO -> final refinement -> inlier mask; one host thread + HIP stream per problem, different
 RANSAC seeds) on correspondences that are already resident in HBM.  A hypothesis = one minimal-solver model scored
 against all N correspondences (ransac_impl.h:112-113).  Multi-GPU: independent image pairs, one per rank
 (weak scaling, no data-path collective); RCCL is used only for the barrier and the final gather.
 
 The JSON line also carries
-  roofline     : dominant kernel k_score<ABS,5>; achieved = algorithmic bytes (hypotheses x N x 40 B, i.e. as if
+  roofline     : dominant kernel k_score_queue<ABS,5>; achieved = algorithmic bytes (hypotheses x N x 40 B, i.e. as if
                  every hypothesis streamed the fp64 correspondence set) / HIP-event duration of the launches.
-                 NOTE the set is register/L2 resident, so physical HBM traffic is orders of magnitude lower and
-                 the real bound is the fp64 VALU; frac may therefore exceed 1.
+                 NOTE the set is register/LDS resident, so physical HBM traffic (roofline.traffic, from the committed
+                 PMC passes) is orders of magnitude lower and the real bound is the vector ALU (see DESIGN.md);
+                 frac may therefore exceed 1.
   cpu_baseline : the CPU oracle (port of the reference path, single thread like the reference) timed on the
                  same workload on this box's host cores (rank 0, N=1 only).
 """
@@ -156,11 +157,12 @@ def main():
         avg_launch_s = (k_ms / max(k_launch, 1)) * 1e-3
         alg_bytes_per_launch = (hyp0 / max(k_launch, 1)) * N_POINTS * BYTES_PER_CORR
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src, kernel_name, valu_busy = None, None, f"k_score_queue<{KIND}, P>", None
         try:  # PMC-measured HBM bytes per launch (rocprofv3 passes, committed under profiles/)
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
             if tr:
                 traffic, traffic_src = tr["traffic_bytes_per_launch"], tr["source"]
+                kernel_name, valu_busy = tr.get("kernel", kernel_name), tr.get("valu_busy")
         except Exception:
             pass
         out = {
@@ -184,11 +186,13 @@ def main():
                        "inliers_found": int(allrec[0, 4])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_score_abs_stream<5>" if KIND == 0 else f"k_score<{KIND},P>",
-                         "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "note": f"algorithmic bytes = hypotheses x N x {BYTES_PER_CORR} B; the set is register/L2-resident, "
-                                 "the physical bound is fp64 VALU (DESIGN.md)"},
+                         "kernel": kernel_name, "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launch,
+                         "launches_in_flight": S, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "point_hypotheses_per_s": value * N_POINTS, "valu_busy_pmc": valu_busy,
+                         "note": f"algorithmic bytes = hypotheses x N x {BYTES_PER_CORR} B (SURVEY 8d); the set is "
+                                 "register/LDS-resident, so frac > 1 is expected: the binding unit is the vector ALU "
+                                 "(fp32 filter + fp64 exact pass, DESIGN.md 4); avg_launch_ms is the HIP-event time of "
+                                 "one launch while launches_in_flight problems share the device"},
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle_lib as O
