@@ -7,9 +7,10 @@
 Workload (config.workload = "p3p_5000"): BASELINE.json configs[1] — P3P LO-RANSAC on 5000 synthetic 2D-3D
 correspondences, 70 % outliers, max_iterations = 100000, with min_iterations = max_iterations so that the
 loop really evaluates 100000 iterations (with default options PoseLib stops after ~10^3).
-One "step" = S (= --streams, default 16) independent, complete ransac_pnp calls in flight on the GPU (sample ->
-P3P -> score all N -> LO -> final refinement -> inlier mask; one host thread + HIP stream per problem, different
-RANSAC seeds) on correspondences that are already resident in HBM.  A hypothesis = one minimal-solver model scored
+One "step" = one batch of 8 x S (default 128) independent, complete ransac_pnp problems (sample -> P3P -> score all N -> LO ->
+final refinement -> inlier mask; different RANSAC seeds) worked through by S (= --streams, default 16) host
+threads with one HIP stream each, i.e. S problems in flight on the GPU, on correspondences that are already
+resident in HBM.  A hypothesis = one minimal-solver model scored
 against all N correspondences (ransac_impl.h:112-113).  Multi-GPU: independent image pairs, one per rank
 (weak scaling, no data-path collective); RCCL is used only for the barrier and the final gather.
 
@@ -54,10 +55,12 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=16,
                     help="independent problems in flight per GPU (one host thread + HIP stream each)")
+    ap.add_argument("--problems-per-step", type=int, default=0,
+                    help="independent problems per step and GPU (default 8 x streams): the batch one step works through")
     ap.add_argument("--workload", default="p3p_5000", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=ITERATIONS)
@@ -109,9 +112,12 @@ def main():
         opt = {"max_error": thr, "ransac": {"max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "seed": seed}}
         return prob.run(opt)
 
+    PPS = args.problems_per_step if args.problems_per_step > 0 else 8 * S
+
     def step(seed):
-        """One step = S independent ransac_pnp problems in flight on this GPU (different RANSAC seeds)."""
-        return list(pool.map(run_one, [(probs[j], seed * S + j) for j in range(S)]))
+        """One step = a batch of PPS independent ransac_pnp problems (different RANSAC seeds) worked through by S
+        host threads / HIP streams, i.e. S problems in flight on this GPU at any time."""
+        return list(pool.map(run_one, [(probs[j % S], seed * PPS + j) for j in range(PPS)]))
 
     def sync():
         torch.cuda.synchronize()
@@ -180,9 +186,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "problem": DESCR, "correspondences": N_POINTS,
                        "outlier_ratio": OUTLIER_RATIO, "max_iterations": ITERATIONS, "min_iterations": ITERATIONS,
-                       "max_error_px": MAX_ERROR_PX, "problems_per_gpu_per_step": S,
+                       "max_error_px": MAX_ERROR_PX, "problems_per_gpu_per_step": PPS, "problems_in_flight_per_gpu": S,
                        "hypotheses_per_step": hyp0 / args.steps,
-                       "iterations_per_s": world * S * args.steps * ITERATIONS / t_max,
+                       "iterations_per_s": world * PPS * args.steps * ITERATIONS / t_max,
                        "inliers_found": int(allrec[0, 4])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
