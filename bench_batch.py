@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench_batch.py — BASELINE.json configs[4]: a batch of independent image-pair problems (mixed P3P / 5-point /
 homography, N ~ U{500..5000}, 30-70 % outliers, default options = the reference's ~10^3-iteration regime),
-sharded round-robin over the GPUs of one node (poselib_amd/sharding.py), S problems in flight per GPU,
-RCCL only for the final gather of the result records.
+sharded round-robin over the GPUs of one node (poselib_amd/sharding.py); each rank hands its whole shard to ONE
+call of the batched C-ABI entry point pl_estimate_batch (S problems in flight per GPU, host threads inside the
+library); RCCL only for the final gather of the result records.
 
     python bench_batch.py --problems 4096 --gpus 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench_batch.py --gpus 8
@@ -95,15 +96,34 @@ def main():
     mine = sharding.owned(args.problems, rank, world)
     problems = {i: make_problem(i) for i in mine}  # synthetic data, generated outside the timed region
     S = max(1, args.streams)
-    pool = ThreadPoolExecutor(max_workers=S, initializer=lambda: P.set_device(local_rank))
+    P.set_device(local_rank)
+
+    def batch_args(i):
+        kind, n, d = problems[i]
+        opt = {"ransac": {"seed": i}}
+        if kind == "abs":
+            return ("abs", d["p2d"], d["p3d"], d["camera"], opt)
+        if kind == "rel":
+            return ("rel", d["x1"], d["x2"], d["camera1"], d["camera2"], opt)
+        return ("hom", d["x1"], d["x2"], opt)
+
+    shard_args = [batch_args(i) for i in mine]
 
     def run_shard():
-        def one(i):
+        """the whole shard in ONE library call: pl_estimate_batch keeps S problems in flight (its own host threads,
+        one HIP stream each)"""
+        res = P.estimate_batch(shard_args, max_in_flight=S)
+        out = []
+        for i, (model, info) in zip(mine, res):
             kind, n, d = problems[i]
-            info, model = solve(P, i, kind, d)
-            return sharding.pack_record(i, info, model), info["hypotheses"], n
-
-        return list(pool.map(one, mine))
+            if kind == "abs":
+                flat = np.r_[model.pose.q, model.pose.t]
+            elif kind == "rel":
+                flat = np.r_[model.q, model.t]
+            else:
+                flat = model.reshape(-1)
+            out.append((sharding.pack_record(i, info, flat), info["hypotheses"], n))
+        return out
 
     def sync():
         torch.cuda.synchronize()
@@ -164,7 +184,6 @@ def main():
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
-    pool.shutdown()
 
 
 if __name__ == "__main__":

@@ -121,6 +121,27 @@ int pl_estimate_fundamental(const double *points2D_1, const double *points2D_2, 
 int pl_estimate_homography(const double *points2D_1, const double *points2D_2, size_t n, const pl_robust_options *opt,
                            double *H /* 9, column-major */, uint8_t *inliers, pl_ransac_stats *stats);
 
+/* ---- batched front-end: an array of independent problems (BASELINE config 4: many image pairs) ----
+ * Every item is one call of the matching pl_estimate_* above; `max_in_flight` problems (<= 0: 8) are worked on
+ * concurrently by an internal pool of host threads, each with its own HIP stream and scratch arena, on the device the
+ * calling thread selected with pl_set_device().  The reference has no such call: a PoseLib user loops over
+ * estimate_*() (robust.h) from a thread pool, the Python wrappers release the GIL for that purpose. */
+typedef struct {
+    int32_t kind;            /* 0 absolute pose, 1 relative pose, 2 fundamental, 3 homography */
+    int32_t status;          /* out: PL_OK or the error of this item */
+    const double *a;         /* points2D (kind 0) / points2D_1: N x 2 */
+    const double *b;         /* points3D: N x 3 (kind 0) / points2D_2: N x 2 */
+    size_t n;
+    const pl_robust_options *opt;
+    pl_camera *camera1;      /* kind 0: in/out camera; kind 1: first camera; otherwise NULL */
+    const pl_camera *camera2; /* kind 1: second camera; otherwise NULL */
+    void *model;             /* in/out: pl_camera_pose (kinds 0, 1) or double[9] column-major (kinds 2, 3) */
+    uint8_t *inliers;        /* n bytes */
+    pl_ransac_stats *stats;
+} pl_batch_item;
+/* returns PL_OK if every item succeeded, otherwise the status of the first failing item */
+int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight);
+
 /* ---- RANSAC entry points on normalised points (robust/ransac.h) ---- */
 int pl_ransac_pnp(const double *x, const double *X, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
                   uint8_t *inliers, pl_ransac_stats *stats);

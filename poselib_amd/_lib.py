@@ -44,12 +44,21 @@ class RansacStats(C.Structure):
                 ("score_kernel_ms", f64), ("score_kernel_launches", u32), ("reserved", u32)]
 
 
+class BatchItem(C.Structure):
+    pass  # fields set below (needs Camera / RobustOptions)
+
+
 class Camera(C.Structure):
     _fields_ = [("model_id", i32), ("width", i32), ("height", i32), ("num_params", i32), ("params", f64 * 12)]
 
 
 class CameraPose(C.Structure):
     _fields_ = [("q", f64 * 4), ("t", f64 * 3)]
+
+
+BatchItem._fields_ = [("kind", i32), ("status", i32), ("a", C.c_void_p), ("b", C.c_void_p), ("n", C.c_size_t),
+                      ("opt", C.POINTER(RobustOptions)), ("camera1", C.POINTER(Camera)), ("camera2", C.POINTER(Camera)),
+                      ("model", C.c_void_p), ("inliers", C.c_void_p), ("stats", C.POINTER(RansacStats))]
 
 
 class PoseLibAmdError(RuntimeError):
@@ -99,5 +108,5 @@ EXPORTED_SYMBOLS = [
     "pl_set_device", "pl_last_error", "pl_version", "pl_estimate_absolute_pose", "pl_estimate_relative_pose",
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
     "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_score_model", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
-    "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch",
+    "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch",
 ]

@@ -19,13 +19,17 @@
 #include "pl_sampler.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace pl;
@@ -92,7 +96,7 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // batch scratch
-    DevBuf positions, samples, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf positions, samples, lm2_states, lm2_partials, models, num_models, slots, num_hyp, part_count, part_score, count, score;
     DevBuf shadow, compact64;
     DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
@@ -102,6 +106,7 @@ struct Context {
 };
 
 thread_local Context *g_ctx = nullptr;
+
 thread_local int g_requested_device = 0;
 
 int get_context(Context **out) {
@@ -525,7 +530,33 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         t.scratch = c->lm_scratch.as<uint8_t>() + (size_t)j * p->n;
     }
     HIP_TRY(hipMemcpyAsync(c->lm_tasks.p, ht, sizeof(LMTask) * nj, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_lm(p->kind, p->ps, c->lm_tasks.as<LMTask>(), nj, c->stream));
+    // Large point sets with 6..8 parameters saturate the single CU k_lm gives a task: spread every task over several
+    // workgroups (k_lm2).  Only for short, bounded runs (the LO: 25 iterations) - k_lm2 costs 2 * max_iterations + 3
+    // launches whatever the iteration count turns out to be.
+    // k_lm2 trades launches for latency (2 * max_iterations + 3 small launches instead of one long kernel on one CU):
+    // 1.6x shorter homography problems at N = 10^4 when the device serves one problem at a time, but with a dozen
+    // problems in flight the long kernels overlap anyway and the launch traffic congests the hardware queues
+    // (measured: -30 % throughput).  The two kernels sum the normal equations in different orders, so the choice
+    // must not depend on load: it is an explicit, process-wide setting (POSELIB_AMD_LATENCY_MODE=1), off by default.
+    static const bool latency_mode = std::getenv("POSELIB_AMD_LATENCY_MODE") != nullptr;
+    const bool lm2_off = false;
+    uint32_t max_it = 0;
+    bool same_it = true;
+    for (uint32_t j = 0; j < nj; ++j) {
+        same_it = same_it && (j == 0 || jobs[j].opt.max_iterations == max_it);
+        max_it = std::max(max_it, jobs[j].opt.max_iterations);
+    }
+    const uint32_t lm2_min_points = (p->kind == EST_ABS) ? 8192u : 2560u;
+    if (!lm2_off && latency_mode && p->kind != EST_REL && same_it && max_it >= 1 && max_it <= 32 &&
+        p->n >= lm2_min_points) {
+        const uint32_t slices = std::min<uint32_t>(16u, std::max<uint32_t>(2u, p->n / 512u));
+        HIP_TRY(c->lm2_states.ensure(lm2_state_bytes(nj)));
+        HIP_TRY(c->lm2_partials.ensure(lm2_partial_bytes(nj, slices)));
+        HIP_TRY(launch_lm2(p->kind, p->ps, c->lm_tasks.as<LMTask>(), nj, slices, max_it, c->lm2_states.p,
+                           c->lm2_partials.as<double>(), c->stream));
+    } else {
+        HIP_TRY(launch_lm(p->kind, p->ps, c->lm_tasks.as<LMTask>(), nj, c->stream));
+    }
     HIP_TRY(hipMemcpyAsync(ht, c->lm_tasks.p, sizeof(LMTask) * nj, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(c->h_records.ensure(sizeof(double) * kModelStride * nj));
@@ -1666,6 +1697,105 @@ int pl_homography_4pt(const double *x1, const double *x2, double *H) {
         mat_to_colmajor(M, H);
     }
     return (int)n;
+}
+
+// ---------------------------------------------------------------------------- batched front-end
+// A persistent pool of host threads (each owns a Context: HIP stream + scratch arena, created on first use and kept
+// for later batches) pulls items from a shared counter.  The threads are detached and live until the process ends.
+namespace {
+struct BatchPool {
+    std::mutex mu;
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    // current job
+    pl_batch_item *items = nullptr;
+    size_t count = 0;
+    std::atomic<size_t> next{0};
+    int device = 0;
+    uint64_t generation = 0;
+    int wanted = 0;   // workers that should take part in the current job
+    int joined = 0;   // workers that have picked the current job up
+    int running = 0;  // workers still inside the current job
+
+    static int run_item(pl_batch_item &it) {
+        switch (it.kind) {
+        case EST_ABS:
+            return pl_estimate_absolute_pose(it.a, it.b, it.n, it.opt, it.camera1, static_cast<pl_camera_pose *>(it.model),
+                                             it.inliers, it.stats);
+        case EST_REL:
+            return pl_estimate_relative_pose(it.a, it.b, it.n, it.camera1, it.camera2, it.opt,
+                                             static_cast<pl_camera_pose *>(it.model), it.inliers, it.stats);
+        case EST_FUND:
+            return pl_estimate_fundamental(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
+        case EST_HOM:
+            return pl_estimate_homography(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
+        default:
+            return fail(PL_ERR_INVALID, "pl_batch_item.kind must be 0..3");
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                wake.wait(lk, [&] { return generation != seen && joined < wanted; });
+                seen = generation;
+                joined++;
+                running++;
+            }
+            g_requested_device = device;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= count)
+                    break;
+                items[i].status = run_item(items[i]);
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--running == 0 && joined == wanted)
+                    done.notify_all();
+            }
+        }
+    }
+    int run(pl_batch_item *its, size_t n, int in_flight, int dev) {
+        std::unique_lock<std::mutex> lk(mu); // one batch at a time per process
+        while ((int)threads.size() < in_flight) {
+            threads.emplace_back([this] { worker(); });
+            threads.back().detach();
+        }
+        items = its, count = n, device = dev;
+        next.store(0);
+        wanted = in_flight, joined = 0, running = 0;
+        generation++;
+        wake.notify_all();
+        done.wait(lk, [&] { return joined == wanted && running == 0; });
+        items = nullptr;
+        wanted = 0;
+        return PL_OK;
+    }
+};
+BatchPool &batch_pool() {
+    static BatchPool *pool = new BatchPool(); // never destroyed: its detached workers may outlive static destructors
+    return *pool;
+}
+} // namespace
+
+int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
+    if (count == 0)
+        return PL_OK;
+    if (!items)
+        return fail(PL_ERR_INVALID, "items pointer is null");
+    Context *c;
+    int rc = get_context(&c); // fails loudly without a HIP device, and pins the device for the workers
+    if (rc != PL_OK)
+        return rc;
+    int w = max_in_flight <= 0 ? 8 : std::min(max_in_flight, 64);
+    w = (int)std::min<size_t>((size_t)w, count);
+    batch_pool().run(items, count, w, g_requested_device);
+    for (size_t i = 0; i < count; ++i)
+        if (items[i].status != PL_OK)
+            return fail(items[i].status, ("pl_estimate_batch: item " + std::to_string(i) + " failed").c_str());
+    return PL_OK;
 }
 
 } // extern "C"

@@ -95,6 +95,10 @@ struct RecordMeta {
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream);
+size_t lm2_state_bytes(uint32_t num_tasks);
+size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices);
+hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, uint32_t slices,
+                      uint32_t max_iterations, void *states, double *partials, hipStream_t stream);
 // chunks = ceil(n / (kScoreThreads * P)); P is chosen inside from n (returned through *chunks_out)
 uint32_t score_chunks(int est, uint32_t n_points, bool prefilter);
 hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream);

@@ -292,6 +292,70 @@ def test_prosac_sampling_parity(gpu, max_prosac):
     assert ok, err
 
 
+def test_estimate_batch_matches_single_calls(gpu):
+    """pl_estimate_batch (array of problem descriptors, BASELINE config 4) = the single-problem entry points"""
+    probs, singles = [], []
+    for i in range(12):
+        n = 300 + 137 * i
+        opt = {"ransac": {"seed": i}}
+        if i % 3 == 0:
+            d = synth.absolute_pose_scene(n, 0.4, 600 + i)
+            probs.append(("abs", d["p2d"], d["p3d"], d["camera"], opt))
+            img, info = gpu.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], opt)
+            singles.append((np.r_[img.pose.q, img.pose.t], info))
+        elif i % 3 == 1:
+            d = synth.relative_pose_scene(n, 0.4, 600 + i)
+            probs.append(("rel", d["x1"], d["x2"], d["camera1"], d["camera2"], opt))
+            pose, info = gpu.estimate_relative_pose(d["x1"], d["x2"], d["camera1"], d["camera2"], opt)
+            singles.append((np.r_[pose.q, pose.t], info))
+        else:
+            d = synth.homography_scene(n, 0.4, 600 + i)
+            probs.append(("hom", d["x1"], d["x2"], opt))
+            H, info = gpu.estimate_homography(d["x1"], d["x2"], opt)
+            singles.append((H.reshape(-1), info))
+    for in_flight in (1, 5):
+        res = gpu.estimate_batch(probs, max_in_flight=in_flight)
+        assert len(res) == len(probs)
+        for (model, info), (ref_model, ref_info), pr in zip(res, singles, probs):
+            flat = (np.r_[model.pose.q, model.pose.t] if pr[0] == "abs" else
+                    np.r_[model.q, model.t] if pr[0] == "rel" else model.reshape(-1))
+            assert np.array_equal(flat, ref_model)  # same kernels, same order of operations: bit-identical
+            for k in ("iterations", "refinements", "num_inliers", "model_score"):
+                assert info[k] == ref_info[k]
+            assert info["inliers"] == ref_info["inliers"]
+
+
+def test_latency_mode_multi_workgroup_lm(gpu):
+    """POSELIB_AMD_LATENCY_MODE=1 runs the LO of large homography / fundamental problems through k_lm2 (one task
+    spread over several workgroups, one launch per LM half-step).  It has to reproduce the oracle like the default
+    single-workgroup LM; run in a subprocess because the setting is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import poselib_amd as P, oracle_lib as O
+from poselib_amd import synth
+for gen, fn, ofn, seed in ((synth.homography_scene, P.estimate_homography, O.estimate_homography, 1003),
+                           (synth.fundamental_scene, P.estimate_fundamental, O.estimate_fundamental, 1004)):
+    d = gen(10000, 0.5, seed)
+    opt = {"ransac": {"seed": 0}}
+    M, info = fn(d["x1"], d["x2"], opt)
+    Mo, mask, st = ofn(d["x1"], d["x2"], opt)
+    assert info["iterations"] == st["iterations"] and info["refinements"] == st["refinements"], (info, st)
+    assert info["num_inliers"] == st["num_inliers"] and (np.array(info["inliers"]) == mask).all()
+    A, B = M / np.linalg.norm(M), Mo / np.linalg.norm(Mo)
+    assert min(np.linalg.norm(A - B), np.linalg.norm(A + B)) < 1e-6
+print("latency mode ok")
+"""
+    env = dict(os.environ, POSELIB_AMD_LATENCY_MODE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "latency mode ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_edge_cases(gpu):
     d = synth.absolute_pose_scene(200, 0.5, 1000)
     # fewer points than the sample size: default stats, identity pose, mask computed for it (ransac_impl.h:161-163)
