@@ -694,7 +694,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             uint64_t needed = std::max<uint64_t>(ro.min_iterations, dyn_max) + 1;
             needed = std::min<uint64_t>(needed, ro.max_iterations);
             needed = (needed > it) ? needed - it : 1;
-            const uint32_t cap = std::min<uint32_t>(131072u, 524288u / (uint32_t)MAXM); // bounded by scratch size
+            const uint32_t cap = std::min<uint32_t>(131072u, 1048576u / (uint32_t)MAXM); // bounded by scratch size (<= 200 MB of records)
             const uint32_t B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
             grow = std::min<uint64_t>(grow * 2, 131072u);
 

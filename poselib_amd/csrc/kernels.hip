@@ -2,25 +2,22 @@
 // -O3 -std=c++17 -ffp-contract=off (fp64, no FMA contraction: residuals must round like the
 // reference's SSE2 build so that inlier decisions are identical).
 //
-// Kernel inventory (one RANSAC batch = generate -> compact -> score -> finalize):
-//   k_generate<EST>   one LANE per RANSAC iteration: counter-based sample draw, minimal solve entirely in
-//                     registers (P3P / 5-pt / 7-pt / 4-pt H), model records (128 B) written to HBM.
-//                     (reference: estimators/*::generate_models)
-//   k_compact         exclusive scan of models-per-iteration -> hypothesis list in (iteration, model) order.
-//   k_score<EST,P>    THE hot kernel.  Correspondences are stationary: every lane keeps P points in VGPRs
-//                     (loaded once, coalesced from the SoA arrays), hypotheses stream through the workgroup
-//                     as wave-uniform 128-byte records held in SGPRs.  Per hypothesis and wavefront: P
-//                     residuals per lane, inlier count by ballot+popcount on the scalar unit, MSAC sum by a
-//                     wave64 butterfly, per-workgroup combine through LDS, one (count, score) partial per
-//                     (hypothesis, point-chunk).  No atomics; summation order is fixed.
-//                     (reference: utils.cc compute_*_msac_score)
-//   k_finalize        adds the point-chunk partials in fixed order, applies the (N - inliers) * thr^2 term.
-//   k_lm<EST>         Levenberg-Marquardt refinement, ONE workgroup (16 wavefronts) per task, the whole LM
-//                     loop on device: residual / Jacobian passes over the L2-resident points, normal
-//                     equations reduced with butterflies + LDS, k x k Cholesky by one lane.
-//                     (reference: bundle.cc + optim/lm_impl.h + optim/*.h)
-//   k_mask<EST>       final inlier mask (reference: utils.cc get_inliers*).
-// MFMA is not used: there is no dense contraction in this path (fp64 VALU + L2/LDS resident data).
+// Kernel inventory (one RANSAC batch = positions [pipeline.hip] -> generate -> compact/gather [pipeline.hip] ->
+// score -> finalize/records [pipeline.hip] -> LM of the improving hypotheses -> re-score):
+//   k_generate<EST>       one LANE per RANSAC iteration: counter-based sample draw (or explicit PROSAC sample), minimal
+//                         solve entirely in registers (P3P / 5-pt / 7-pt / 4-pt H), model records (192 B incl. fp32
+//                         shadow) written to HBM.  (reference: estimators/*::generate_models)
+//   k_score_queue<EST,P>  THE hot kernel: streaming scorer of the batched main loop - conservative fp32 pre-filter on
+//                         register-resident points, survivors queued in LDS and evaluated exactly in fp64 by full
+//                         wavefronts.  (reference: utils.cc compute_*_msac_score)
+//   k_score<EST,P>        exact scorer for the handful of refined / initial models (no filter, 256 * P points per
+//                         chunk, hypotheses as wave-uniform records in SGPRs), k_finalize adds its chunk partials.
+//   k_lm<EST>             Levenberg-Marquardt refinement, ONE workgroup (8 wavefronts) per task, the whole LM loop on
+//                         device; k_lm2<EST>: the same spread over several workgroups per task, one launch per LM
+//                         half-step (opt-in latency mode).  (reference: bundle.cc + optim/lm_impl.h + optim/*.h)
+//   k_mask<EST>           final inlier mask (reference: utils.cc get_inliers*).
+//   k_solve_batch<EST>    the bare minimal solvers, one lane per problem.
+// MFMA is not used: there is no dense contraction in this path.
 #include "pl_kernels.h"
 #include "pl_prefilter.h"
 #include <cstdlib>
@@ -184,46 +181,6 @@ __global__ __launch_bounds__(64) void k_solve_essential(const double *in, uint32
     num_models[i] = (uint32_t)n;
 }
 
-// ------------------------------------------------------------------------------------ compact
-__global__ __launch_bounds__(1024) void k_compact(const uint32_t *num_models, uint32_t num_iters, int maxm,
-                                                  uint32_t *slots, uint32_t *num_hyp) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t wave_off[16];
-    const uint32_t per = (num_iters + 1023u) / 1024u;
-    const uint32_t i0 = threadIdx.x * per;
-    const uint32_t i1 = min(num_iters, i0 + per);
-    uint32_t local = 0;
-    for (uint32_t i = i0; i < i1; ++i)
-        local += num_models[i];
-    // exclusive scan over the 1024 threads: inclusive wave scan, then wave offsets
-    uint32_t inc = local;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off, 64);
-        if (lane >= off)
-            inc += v;
-    }
-    if (lane == 63)
-        wave_tot[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t s = 0;
-        for (int w = 0; w < 16; ++w) {
-            wave_off[w] = s;
-            s += wave_tot[w];
-        }
-        *num_hyp = s;
-    }
-    __syncthreads();
-    uint32_t o = wave_off[wave] + inc - local;
-    for (uint32_t i = i0; i < i1; ++i) {
-        const uint32_t nm = num_models[i];
-        for (uint32_t m = 0; m < nm; ++m)
-            slots[o++] = i * (uint32_t)maxm + m;
-    }
-}
-
 // ------------------------------------------------------------------------------------ score
 template <int EST>
 __device__ __forceinline__ bool eval_point(const double *M, const double *pt, double thr2, double &r2) {
@@ -239,19 +196,11 @@ __device__ __forceinline__ bool eval_point(const double *M, const double *pt, do
 
 constexpr int kScoreGroup = 32; // hypotheses between two workgroup barriers
 
-// Conservative fp32 pre-filter for the reprojection score.  It may only say "certainly NOT an inlier";
-// every point it cannot exclude is evaluated with the exact fp64 expression, so counts, inlier sets and
-// scores are unchanged.  Proof sketch (u = 2^-24):  z_i = r_i.X + t_i with |r_i| = 1, so every fp32
-// z^_i (inputs rounded to fp32, three FMAs) satisfies |z^_i - z_i| <= 8u S,  S = |X|_2 + max|t_i|.
-// An inlier has z2 > 0 and |z0 - x z2| < thr z2 (and the same in y).  With a = fl(z^0 - x^ z^2),
-// tz = fl(thr^ z^2) the accumulated error of  |a| - tz  is below  W = 32u (1 + xmax + thr) S,  hence
-// |a| - tz > W  (or z^2 < -W)  proves the point is an outlier.  Gx = 32u(1+xmax+thr) is passed rounded up.
-
-template <int EST, int P, bool PF>
+template <int EST, int P>
 __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const double *__restrict__ models,
                                                          const uint32_t *__restrict__ slots,
                                                          const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
-                                                         double thr2, PrefilterArgs pf, uint32_t *__restrict__ part_count,
+                                                         double thr2, uint32_t *__restrict__ part_count,
                                                          double *__restrict__ part_score) {
     constexpr int ND = point_doubles(EST);
     __shared__ double s_score[kScoreGroup][kScoreThreads / 64];
@@ -264,7 +213,6 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
     // ---- stationary operand: this lane's P correspondences, coalesced loads, kept in VGPRs ----
     double pt[P][ND];
     bool valid[P];
-    float pfx[PF ? P : 1][6]; // fp32 shadow of the points: x, y, X, Y, Z, upper bound of |X|_2
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
@@ -273,13 +221,6 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
 #pragma unroll
         for (int d = 0; d < ND; ++d)
             pt[p][d] = pts.a[d][ic];
-        if constexpr (PF) {
-#pragma unroll
-            for (int d = 0; d < 5; ++d)
-                pfx[p][d] = (float)pt[p][d];
-            const double n = sqrt(pt[p][2] * pt[p][2] + pt[p][3] * pt[p][3] + pt[p][4] * pt[p][4]);
-            pfx[p][5] = (float)n * 1.000001f + 1e-30f;
-        }
     }
 
     const uint32_t H = *as_uniform(num_hyp_ptr);
@@ -301,39 +242,12 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
 
             uint32_t cnt = 0;
             double sc = 0.0;
-            if constexpr (PF) {
-                uniform_f32_ptr Mf = (uniform_f32_ptr)(Mg + kShadowOff);
-                float rf[13];
 #pragma unroll
-                for (int i = 0; i < 13; ++i)
-                    rf[i] = Mf[i];
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const float X = pfx[p][2], Y = pfx[p][3], Z = pfx[p][4];
-                    const float z0 = fmaf(rf[0], X, fmaf(rf[1], Y, fmaf(rf[2], Z, rf[9])));
-                    const float z1 = fmaf(rf[3], X, fmaf(rf[4], Y, fmaf(rf[5], Z, rf[10])));
-                    const float z2 = fmaf(rf[6], X, fmaf(rf[7], Y, fmaf(rf[8], Z, rf[11])));
-                    const float a0 = fmaf(-pfx[p][0], z2, z0);
-                    const float a1 = fmaf(-pfx[p][1], z2, z1);
-                    const float tz = pf.thr * z2;
-                    const float W = pf.gx * (pfx[p][5] + rf[12]);
-                    const bool out = (fabsf(a0) - tz > W) | (fabsf(a1) - tz > W) | (z2 < -W);
-                    const bool cand = !out && valid[p];
-                    if (__ballot(cand)) { // wave-uniform: exact evaluation only where some lane needs it
-                        double r2;
-                        const bool in = eval_point<EST>(M, pt[p], thr2, r2) && cand;
-                        cnt += __popcll(__ballot(in));
-                        sc += in ? r2 : 0.0;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    double r2;
-                    const bool in = eval_point<EST>(M, pt[p], thr2, r2) && valid[p];
-                    cnt += __popcll(__ballot(in));
-                    sc += in ? r2 : 0.0;
-                }
+            for (int p = 0; p < P; ++p) {
+                double r2;
+                const bool in = eval_point<EST>(M, pt[p], thr2, r2) && valid[p];
+                cnt += __popcll(__ballot(in));
+                sc += in ? r2 : 0.0;
             }
             sc = wave_sum(sc);
             if (lane == 0) {
@@ -358,155 +272,6 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const dou
     }
 }
 
-// ---- absolute pose, pre-filtered form -----------------------------------------------------------------
-// Same results as k_score<EST_ABS>, different schedule.  Stationary operand: each lane's P correspondences in
-// fp64 (exact path) AND their fp32 shadow (filter).  Streaming operand: compact, hypothesis-ordered arrays of the
-// 64-byte fp32 model shadow (next hypothesis prefetched) and the 128-byte fp64 model (loaded at the top of the
-// hypothesis, first used after pass A) — contiguous scalar loads, no slot indirection on the critical path.
-// Pass A runs the conservative filter on all P points (branch-free fp32 FMA chains, P-way ILP).  Pass B — only
-// for the point slots where some lane survived — evaluates the exact reference expression from the fp64
-// registers.  The butterfly reduction is skipped when the wavefront found no inlier.
-template <int P>
-__global__ __launch_bounds__(kScoreThreads) void k_score_abs_pf(PointSet pts, const double *__restrict__ models,
-                                                                const float *__restrict__ shadow,
-                                                                const double *__restrict__ compact64,
-                                                                const uint32_t *__restrict__ slots,
-                                                                const uint32_t *__restrict__ num_hyp_ptr,
-                                                                uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
-                                                                uint32_t *__restrict__ part_count,
-                                                                double *__restrict__ part_score) {
-    __shared__ double s_score[kScoreGroup][kScoreThreads / 64];
-    __shared__ uint32_t s_count[kScoreGroup][kScoreThreads / 64];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t chunk = blockIdx.y;
-
-    double pt[P][5];
-    float px[P][6]; // x, y, X, Y, Z, upper bound of |X|_2  (-inf for padding slots: never a candidate)
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
-        const bool valid = i < pts.n;
-        const uint32_t ic = valid ? i : 0u;
-#pragma unroll
-        for (int d = 0; d < 5; ++d) {
-            pt[p][d] = pts.a[d][ic];
-            px[p][d] = (float)pt[p][d];
-        }
-        const float nx = (float)sqrt(pt[p][2] * pt[p][2] + pt[p][3] * pt[p][3] + pt[p][4] * pt[p][4]) * 1.000001f + 1e-30f;
-        px[p][5] = valid ? nx : -__builtin_huge_valf();
-    }
-
-    const uint32_t H = *as_uniform(num_hyp_ptr);
-    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
-    const uint32_t k0 = blockIdx.x * per;
-    const uint32_t k1 = min(H, k0 + per);
-
-    auto record_ptr = [&](uint32_t k) -> uniform_f64_ptr {
-        const uint32_t slot = slots ? as_uniform(slots)[k] : k;
-        return as_uniform(models) + (size_t)slot * kModelStride;
-    };
-    auto shadow_ptr = [&](uint32_t k) -> uniform_f32_ptr {
-        return shadow ? as_uniform(shadow) + (size_t)k * 16 : (uniform_f32_ptr)(record_ptr(k) + kShadowOff);
-    };
-
-    float rn[13];
-    if (k0 < k1) {
-        uniform_f32_ptr sp = shadow_ptr(k0);
-#pragma unroll
-        for (int i = 0; i < 13; ++i)
-            rn[i] = sp[i];
-    }
-    for (uint32_t kb = k0; kb < k1; kb += kScoreGroup) {
-        const uint32_t gn = min((uint32_t)kScoreGroup, k1 - kb);
-        for (uint32_t g = 0; g < gn; ++g) {
-            const uint32_t k = kb + g;
-            float rf[13];
-#pragma unroll
-            for (int i = 0; i < 13; ++i)
-                rf[i] = rn[i];
-            // fp64 model: issued now, consumed (if at all) after pass A
-            uniform_f64_ptr Mg = compact64 ? as_uniform(compact64) + (size_t)k * kModelDoubles : record_ptr(k);
-            double M[kModelDoubles];
-#pragma unroll
-            for (int i = 0; i < kModelDoubles; ++i)
-                M[i] = Mg[i];
-            if (k + 1 < k1) { // prefetch the next hypothesis' shadow while this one is evaluated
-                uniform_f32_ptr sp = shadow_ptr(k + 1);
-#pragma unroll
-                for (int i = 0; i < 13; ++i)
-                    rn[i] = sp[i];
-            }
-            // ---- pass A: conservative fp32 filter ----
-            uint32_t candbits = 0; // per lane
-            uint32_t need = 0;     // wave-uniform
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const float X = px[p][2], Y = px[p][3], Z = px[p][4];
-                const float z0 = fmaf(rf[0], X, fmaf(rf[1], Y, fmaf(rf[2], Z, rf[9])));
-                const float z1 = fmaf(rf[3], X, fmaf(rf[4], Y, fmaf(rf[5], Z, rf[10])));
-                const float z2 = fmaf(rf[6], X, fmaf(rf[7], Y, fmaf(rf[8], Z, rf[11])));
-                const float a0 = fmaf(-px[p][0], z2, z0);
-                const float a1 = fmaf(-px[p][1], z2, z1);
-                const float tz = pf.thr * z2;
-                const float W = pf.gx * (px[p][5] + rf[12]);
-                const bool out = (fabsf(a0) - tz > W) | (fabsf(a1) - tz > W) | (z2 < -W);
-                const bool cand = !out;
-                candbits |= cand ? (1u << p) : 0u;
-                need |= __ballot(cand) ? (1u << p) : 0u;
-            }
-            // ---- pass B: exact fp64 evaluation where required ----
-            uint32_t cnt = 0;
-            double sc = 0.0;
-            if (need) {
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (need & (1u << p)) {
-                        double r2;
-                        const bool in = eval_point<EST_ABS>(M, pt[p], thr2, r2) && ((candbits >> p) & 1u);
-                        cnt += __popcll(__ballot(in));
-                        sc += in ? r2 : 0.0;
-                    }
-                }
-                if (cnt)
-                    sc = wave_sum(sc);
-            }
-            if (lane == 0) {
-                s_score[g][wave] = sc;
-                s_count[g][wave] = cnt;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < gn) {
-            double sc = 0.0;
-            uint32_t c = 0;
-#pragma unroll
-            for (int w = 0; w < kScoreThreads / 64; ++w) {
-                sc += s_score[threadIdx.x][w];
-                c += s_count[threadIdx.x][w];
-            }
-            const size_t o = (size_t)chunk * hyp_capacity + kb + threadIdx.x;
-            part_score[o] = sc;
-            part_count[o] = c;
-        }
-        __syncthreads();
-    }
-}
-
-// Streaming scorer of the batched main loop for all four estimators (hypotheses compacted by k_compact2: 16 floats
-// of shadow and 16 doubles of model per hypothesis, consecutive).
-//   pass A  conservative fp32 pre-filter (pl_prefilter.h) on the register-resident points; its results stay wave
-//           masks in SGPRs (v_cmp -> ballot), no per-lane bookkeeping;
-//   pass B  exact fp64 evaluation (pl_score.h) of the slots in which some lane survived; the fp64 model is only
-//           fetched then.  Same arithmetic and summation tree as the non-streaming kernels.
-// Results are parked in lane g of a VGPR and written once per 64 hypotheses, so a hypothesis without candidates
-// costs no result traffic; the shadow is double-buffered by unrolling two hypotheses per trip (no SGPR copies);
-// models flagged NaN by store_shadow are skipped (no inliers by construction).
-#ifdef PL_EXPERIMENT_NO_EXACT_PASS
-constexpr bool kExactPass = false; // timing experiments only (scripts/gpu_job_*.sh): results are wrong
-#else
-constexpr bool kExactPass = true;
-#endif
 #ifdef PL_SCALAR_ABS_FILTER
 constexpr bool kPackedAbsFilter = false;
 #else
@@ -515,208 +280,6 @@ constexpr bool kPackedAbsFilter = true; // v_pk_fma_f32 pairs in the absolute-po
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f bc(float s) { return v2f{s, s}; }
-
-// sum over the wave of a value that is non-zero in `cnt` lanes only (`lanes` = their mask): with one such lane the
-// butterfly would add 63 zeros to it, so the value is simply broadcast
-__device__ __forceinline__ double wave_sum_sparse(double v, uint32_t cnt, uint64_t lanes) {
-    if (cnt == 1) {
-        const int src = __builtin_ctzll(lanes);
-        const uint64_t bits = (uint64_t)__double_as_longlong(v);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, src);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bits >> 32), src);
-        return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-    }
-    return wave_sum(v);
-}
-
-template <int EST, int P>
-__global__ __launch_bounds__(kScoreThreads) void k_score_stream(PointSet pts, const float *__restrict__ shadow,
-                                                                 const double *__restrict__ compact64,
-                                                                 const uint32_t *__restrict__ num_hyp_ptr,
-                                                                 uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
-                                                                 uint32_t *__restrict__ part_count,
-                                                                 double *__restrict__ part_score) {
-    constexpr int kWaves = kScoreThreads / 64;
-    constexpr int ND = point_doubles(EST);
-    constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 2); // bound terms per point
-    __shared__ double s_score[kWaves][64];
-    __shared__ uint32_t s_count[kWaves][64];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t chunk = blockIdx.y;
-
-    double pt[P][ND];
-    float pf32[P][ND]; // the point in fp32
-    float bnd[P][NB];  // per-point bound terms of the pre-filter
-    uint64_t vmask[P]; // lanes of slot p that hold a real correspondence (wave-uniform)
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
-        const bool valid = i < pts.n;
-        const uint32_t ic = valid ? i : 0u;
-        vmask[p] = __builtin_amdgcn_ballot_w64(valid);
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            pt[p][d] = pts.a[d][ic];
-            pf32[p][d] = (float)pt[p][d];
-        }
-        if constexpr (EST == EST_ABS) {
-            bnd[p][0] = pf_point_abs(pt[p][2], pt[p][3], pt[p][4], pf.gx);
-        } else {
-            float nanb, nsq, nanb_thr;
-            pf_point_two_view(pt[p][0], pt[p][1], pt[p][2], pt[p][3], pf.thr, nanb, nsq, nanb_thr);
-            if constexpr (EST == EST_HOM)
-                bnd[p][0] = nanb_thr;
-            else
-                bnd[p][0] = nanb, bnd[p][1] = nsq;
-        }
-    }
-
-    const uint32_t H = *as_uniform(num_hyp_ptr);
-    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
-    const uint32_t k0 = blockIdx.x * per;
-    const uint32_t k1 = min(H, k0 + per);
-    const uniform_f32_ptr sh = as_uniform(shadow);
-    const uniform_f64_ptr md = as_uniform(compact64);
-
-    for (uint32_t kb = k0; kb < k1; kb += 64) {
-        const uint32_t gn = min(64u, k1 - kb);
-        double acc_s = 0.0; // lane g: score of hypothesis kb + g (this wave's points)
-        uint32_t acc_c = 0; // lane g: inlier count
-
-        auto step = [&](const float(&r)[15], uint32_t g) {
-            if (__float_as_uint(r[13]) != 0u)
-                return; // NaN model: zero inliers (pl_math.h store_shadow)
-            uint64_t m[P];
-            uint64_t any = 0;
-            if (!pf.enabled) {
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    m[p] = vmask[p], any |= m[p];
-            } else if constexpr (EST == EST_ABS && kPackedAbsFilter) {
-                const float gt = pf_up(pf.gx * r[12]);
-                // two points per packed fp32 instruction; the comparisons feed the ballots directly
-#pragma unroll
-                for (int p = 0; p + 1 < P; p += 2) {
-                    const v2f X = {pf32[p][2], pf32[p + 1][2]}, Y = {pf32[p][3], pf32[p + 1][3]};
-                    const v2f Z = {pf32[p][4], pf32[p + 1][4]};
-                    const v2f x = {pf32[p][0], pf32[p + 1][0]}, y = {pf32[p][1], pf32[p + 1][1]};
-                    const v2f w = {bnd[p][0], bnd[p + 1][0]};
-                    const v2f z0 = pk_fma(bc(r[0]), X, pk_fma(bc(r[1]), Y, pk_fma(bc(r[2]), Z, bc(r[9]))));
-                    const v2f z1 = pk_fma(bc(r[3]), X, pk_fma(bc(r[4]), Y, pk_fma(bc(r[5]), Z, bc(r[10]))));
-                    const v2f z2 = pk_fma(bc(r[6]), X, pk_fma(bc(r[7]), Y, pk_fma(bc(r[8]), Z, bc(r[11]))));
-                    const v2f a0 = pk_fma(-x, z2, z0);
-                    const v2f a1 = pk_fma(-y, z2, z1);
-                    const v2f W = w + bc(gt);
-                    const v2f B = pk_fma(bc(pf.thr), z2, W);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const uint64_t far = __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a0[e]), fabsf(a1[e])) > B[e]);
-                        const uint64_t behind = __builtin_amdgcn_ballot_w64(z2[e] < -W[e]);
-                        m[p + e] = vmask[p + e] & ~(far | behind);
-                        any |= m[p + e];
-                    }
-                }
-                if constexpr (P & 1) {
-                    constexpr int p = P - 1;
-                    const bool out = pf_abs_outlier(r, gt, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
-                                                    pf32[p][4], bnd[p][0]);
-                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
-                    any |= m[p];
-                }
-            } else if constexpr (EST == EST_ABS) {
-                const float gt = pf_up(pf.gx * r[12]);
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const bool out = pf_abs_outlier(r, gt, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
-                                                    pf32[p][4], bnd[p][0]);
-                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
-                    any |= m[p];
-                }
-            } else if constexpr (EST == EST_HOM) {
-                const float gh = (32.f * kPfU) * r[14];
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const bool out = pf_hom_outlier(r, gh, pf.thr, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
-                                                    bnd[p][0]);
-                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
-                    any |= m[p];
-                }
-            } else {
-                const float gf = (16.f * kPfU) * r[14];
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const bool out = pf_sampson_outlier(r, gf, pf.thr2_up, pf32[p][0], pf32[p][1], pf32[p][2],
-                                                        pf32[p][3], bnd[p][0], bnd[p][1]);
-                    m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
-                    any |= m[p];
-                }
-            }
-            if (kExactPass && any) { // wave-uniform; rare for a wrong hypothesis
-                double M[kModelDoubles];
-#pragma unroll
-                for (int i = 0; i < kModelDoubles; ++i)
-                    M[i] = md[(size_t)(kb + g) * kModelDoubles + i];
-                uint32_t cnt = 0;
-                uint64_t lanes = 0;
-                double sc = 0.0;
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (m[p]) {
-                        double r2;
-                        const bool in = eval_point<EST>(M, pt[p], thr2, r2) && ((m[p] >> lane) & 1u);
-                        const uint64_t im = __builtin_amdgcn_ballot_w64(in);
-                        cnt += __popcll(im);
-                        lanes |= im;
-                        sc += in ? r2 : 0.0;
-                    }
-                }
-                if (cnt) {
-                    sc = wave_sum_sparse(sc, cnt, lanes);
-                    const bool mine = (uint32_t)lane == g;
-                    acc_s = mine ? sc : acc_s;
-                    acc_c = mine ? cnt : acc_c;
-                }
-            }
-        };
-        auto fetch = [&](float(&r)[15], uint32_t g) {
-            const uniform_f32_ptr sp = sh + (size_t)(kb + g) * 16;
-#pragma unroll
-            for (int i = 0; i < 15; ++i)
-                r[i] = sp[i];
-        };
-
-        float ra[15], rb[15];
-        fetch(ra, 0);
-        for (uint32_t g = 0; g < gn; g += 2) {
-            const bool two = g + 1 < gn;
-            if (two)
-                fetch(rb, g + 1);
-            step(ra, g);
-            if (two) {
-                if (g + 2 < gn)
-                    fetch(ra, g + 2);
-                step(rb, g + 1);
-            }
-        }
-        s_score[wave][lane] = acc_s;
-        s_count[wave][lane] = acc_c;
-        __syncthreads();
-        if (threadIdx.x < gn) {
-            double sc = 0.0;
-            uint32_t c = 0;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-                sc += s_score[w][threadIdx.x];
-                c += s_count[w][threadIdx.x];
-            }
-            const size_t o = (size_t)chunk * hyp_capacity + kb + threadIdx.x;
-            part_score[o] = sc;
-            part_count[o] = c;
-        }
-        __syncthreads();
-    }
-}
 
 // ---- deferred exact evaluation ----------------------------------------------------------------------------------
 // k_score_queue: the scorer of the batched main loop.  One wavefront = 64*P register-resident correspondences (fp32
@@ -1500,26 +1063,12 @@ hipError_t launch_solve_batch(int est, const double *in, uint32_t np, double *mo
     return hipGetLastError();
 }
 
-hipError_t launch_compact(const uint32_t *num_models, uint32_t num_iters, int maxm, uint32_t *slots, uint32_t *num_hyp,
-                          hipStream_t stream) {
-    k_compact<<<dim3(1), dim3(1024), 0, stream>>>(num_models, num_iters, maxm, slots, num_hyp);
-    return hipGetLastError();
-}
-
-constexpr int kMaxPointsPerLane = 5;    // exact kernels: fp64 points in VGPRs
-// pre-filtered absolute-pose kernels: fp64 points + fp32 shadows in VGPRs (POSELIB_AMD_PF_P overrides, 1..6)
+// points per lane of the scorers (POSELIB_AMD_PF_P overrides, 1..6)
 static int max_points_per_lane_pf() {
     static const int v = [] {
         const char *e = std::getenv("POSELIB_AMD_PF_P");
         const int x = e ? std::atoi(e) : 5;
         return x < 1 ? 1 : (x > 6 ? 6 : x);
-    }();
-    return v;
-}
-static bool use_queue_scorer() {
-    static const bool v = [] {
-        const char *e = std::getenv("POSELIB_AMD_SCORER"); // "stream": the per-slot evaluating scorer (A/B runs)
-        return !(e && e[0] == 's');
     }();
     return v;
 }
@@ -1557,7 +1106,7 @@ static void score_shape(int est, uint32_t n, bool streaming, uint32_t &chunks, i
 uint32_t score_chunks(int est, uint32_t n, bool streaming) {
     uint32_t c;
     int P;
-    score_shape(est, n, streaming && use_queue_scorer(), c, P);
+    score_shape(est, n, streaming, c, P);
     return c;
 }
 
@@ -1566,11 +1115,10 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     uint32_t chunks;
     int P;
     const PrefilterArgs pf = a.pf;
-    const bool use_pf = (E == EST_ABS) && pf.enabled && pf.gx > 0.f; // non-streaming launches: absolute pose only
     const bool streaming = a.shadow && a.compact64; // batched main loop: compact hypothesis stream
-    score_shape(E, a.pts.n, streaming && use_queue_scorer(), chunks, P);
+    score_shape(E, a.pts.n, streaming, chunks, P);
     const dim3 grid(slices, chunks), block(kScoreThreads);
-    if (streaming && use_queue_scorer()) {
+    if (streaming) {
 #define PL_Q_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \
         k_score_queue<E, PP><<<grid, block, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,      \
@@ -1589,48 +1137,10 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
 #undef PL_Q_CASE
         return hipGetLastError();
     }
-    if (streaming) {
-#define PL_ST_CASE(PP)                                                                                                 \
-    case PP:                                                                                                           \
-        k_score_stream<E, PP><<<grid, block, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,    \
-                                                           a.thr2, pf, a.part_count, a.part_score);                    \
-        break;
-        switch (P) {
-            PL_ST_CASE(1)
-            PL_ST_CASE(2)
-            PL_ST_CASE(3)
-            PL_ST_CASE(4)
-            PL_ST_CASE(5)
-            PL_ST_CASE(6)
-        default:
-            return hipErrorInvalidValue;
-        }
-#undef PL_ST_CASE
-        return hipGetLastError();
-    }
-    if (use_pf) {
-#define PL_PF_CASE(PP)                                                                                                 \
-    case PP:                                                                                                           \
-        k_score_abs_pf<PP><<<grid, block, 0, stream>>>(a.pts, a.models, a.shadow, a.compact64, a.slots, a.num_hyp,     \
-                                                       a.hyp_capacity, a.thr2, pf, a.part_count, a.part_score);        \
-        break;
-        switch (P) {
-            PL_PF_CASE(1)
-            PL_PF_CASE(2)
-            PL_PF_CASE(3)
-            PL_PF_CASE(4)
-            PL_PF_CASE(5)
-            PL_PF_CASE(6)
-        default:
-            return hipErrorInvalidValue;
-        }
-#undef PL_PF_CASE
-        return hipGetLastError();
-    }
 #define PL_SCORE_CASE(PP)                                                                                              \
     case PP:                                                                                                           \
-        k_score<E, PP, false><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2, \
-                                                          pf, a.part_count, a.part_score);                             \
+        k_score<E, PP><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,      \
+                                                   a.part_count, a.part_score);                                       \
         break;
     switch (P) {
         PL_SCORE_CASE(1)

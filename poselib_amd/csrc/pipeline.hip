@@ -184,13 +184,7 @@ __global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, uin
                 ++nseg;
             }
         }
-        if (lane == 0) {
-            // position of iteration B == draws consumed by the batch (the last segment is still in registers)
-            const uint64_t end = (uint64_t)cur + (uint64_t)(B - it) * (uint64_t)K;
-            // `cur`/`it` are the start of the last segment only if the loop ended by `break`/exhaustion
-            (void)end;
-        }
-        // recompute from the segment table to keep one formula
+        // position of iteration B == draws consumed by the batch, from the last segment of the table
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             const uint32_t s = nseg - 1;

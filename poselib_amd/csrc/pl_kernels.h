@@ -104,8 +104,6 @@ uint32_t score_chunks(int est, uint32_t n_points, bool prefilter);
 hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &a, uint32_t max_hyp, hipStream_t stream);
 // num_models[iters] -> slots (compact list of record indices in (iteration, model) order) + count
-hipError_t launch_compact(const uint32_t *num_models, uint32_t num_iters, int max_models_per_iter, uint32_t *slots,
-                          uint32_t *num_hyp, hipStream_t stream);
 hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
 hipError_t launch_mask(int est, const PointSet &pts, const double *model, double thr2, uint8_t *mask,
                        hipStream_t stream);
