@@ -76,13 +76,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    P.set_device(local_rank)
+    # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_DEVICE=1: rehearsal of the multi-rank path on a box with ONE GPU (all
+    # ranks use device 0, the collectives run on CPU tensors).  Never used for reported numbers.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    device_index = 0 if os.environ.get("BENCH_SHARE_DEVICE") else local_rank
+    torch.cuda.set_device(device_index)
+    P.set_device(device_index)
     use_dist = world > 1
+    coll_device = "cuda" if backend == "nccl" else "cpu"
     if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     KIND, N_POINTS, OUTLIER_RATIO, MAX_ERROR_PX, DATA_SEED, BYTES_PER_CORR, DESCR = WORKLOADS[args.workload]
     # one image pair per rank (independent problems; data seed + rank); pixels -> normalised image plane
@@ -99,10 +104,10 @@ def main():
 
     thr = MAX_ERROR_PX / FOCAL
     S = max(1, args.streams)
-    pool = ThreadPoolExecutor(max_workers=S)
+    # every worker thread selects this rank's GPU before its first call (per-thread context: HIP stream + scratch)
+    pool = ThreadPoolExecutor(max_workers=S, initializer=lambda: P.set_device(device_index))
 
     def make_problem(_):
-        P.set_device(local_rank)  # per-thread context: own HIP stream + scratch arena
         return P.Problem(KIND, A, Bpts)  # SoA in HBM, resident from here on
 
     probs = list(pool.map(make_problem, range(S)))
@@ -145,7 +150,7 @@ def main():
     # final gather over RCCL: [elapsed, hypotheses, kernel ms, launches, inliers, pose(7)]
     model_flat = (list(last[0].q) + list(last[0].t) + [0.0, 0.0]) if KIND in (0, 1) else list(np.asarray(last[0]).reshape(-1))
     rec = torch.tensor([elapsed, float(hyp), kern_ms, float(launches), float(last[1]["num_inliers"])] + model_flat,
-                       dtype=torch.float64, device="cuda")
+                       dtype=torch.float64, device=coll_device)
     if use_dist:
         allrec = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)

@@ -346,17 +346,32 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
     const uint32_t H = *num_hyp;
     const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
     const uint32_t k0 = min(H, blockIdx.x * per), k1 = min(H, k0 + per);
-    if (threadIdx.x == 0) { // state of the sequential loop when it reaches this chunk
-        uint32_t m = init_max;
-        double s = init_min;
-        for (uint32_t b = 0; b < blockIdx.x; ++b) {
-            m = max(m, blk_max[b]);
-            s = fmin(s, blk_min[b]);
+    { // state of the sequential loop when it reaches this chunk: max / min over the chunks in front of it
+        static_assert(kRecBlocks == 256, "one earlier chunk per thread");
+        uint32_t m = (threadIdx.x < blockIdx.x) ? blk_max[threadIdx.x] : 0u;
+        double s = (threadIdx.x < blockIdx.x) ? blk_min[threadIdx.x] : 1.7976931348623157e308;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+            s = fmin(s, __shfl_xor(s, off, 64));
         }
-        s_runmax = m;
-        s_runmin = s;
+        if (lane == 0) {
+            wmax[wave] = m;
+            wmin[wave] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t mm = init_max;
+            double ss = init_min;
+            for (int w = 0; w < 4; ++w) {
+                mm = max(mm, wmax[w]);
+                ss = fmin(ss, wmin[w]);
+            }
+            s_runmax = mm;
+            s_runmin = ss;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (uint32_t t0 = k0; t0 < k1; t0 += 256) {
         const uint32_t k = t0 + threadIdx.x;
         const bool live = k < k1;
