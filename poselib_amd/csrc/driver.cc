@@ -96,12 +96,12 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // batch scratch
-    DevBuf positions, samples, lm2_states, lm2_partials, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf positions, samples, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
     DevBuf shadow, compact64;
     DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
     HostBuf h_rec_meta;
-    HostBuf h_positions, h_num_models, h_count, h_score, h_tasks, h_records, h_gather_idx, h_gather_out, h_mask,
+    HostBuf h_absmax, h_positions, h_num_models, h_count, h_score, h_tasks, h_records, h_gather_idx, h_gather_out, h_mask,
         h_small;
 };
 
@@ -143,6 +143,7 @@ struct pl_problem {
     uint32_t n;
     double *d_pts; // SoA block: nd arrays of n doubles
     PointSet ps;
+    bool borrowed = false; // d_pts lives in the calling thread's context arena (one-shot front-ends): not freed
 };
 
 namespace {
@@ -1059,9 +1060,60 @@ int make_problem(Context *c, int kind, const double *a, const double *b, size_t 
     return PL_OK;
 }
 void free_problem(pl_problem *p) {
-    if (p->d_pts)
+    if (p->d_pts && !p->borrowed)
         (void)hipFree(p->d_pts);
     p->d_pts = nullptr;
+}
+
+// One-shot front-ends: the user's AoS buffers go to the device as they are and k_prepare (pipeline.hip) writes the SoA
+// block into the context's arena - per-point un-projection / normalisation on the GPU, no
+// hipMalloc / hipFree per call.  The problem is valid until the next make_problem_prepared on this thread.
+int make_problem_prepared(Context *c, int kind, const double *a, const double *b, size_t n, const PrepareArgs &pa,
+                          pl_problem *p) {
+    if (kind < 0 || kind > 3)
+        return fail(PL_ERR_INVALID, "unknown problem kind");
+    if (n > 0x7fffffffu)
+        return fail(PL_ERR_INVALID, "too many correspondences");
+    p->kind = kind;
+    p->device = c->device;
+    p->n = (uint32_t)n;
+    p->d_pts = nullptr;
+    p->borrowed = true;
+    std::memset(&p->ps, 0, sizeof(p->ps));
+    p->ps.n = (uint32_t)n;
+    if (n == 0)
+        return PL_OK;
+    const int nd = point_doubles(kind);
+    const int db = (kind == EST_ABS) ? 3 : 2;
+    HIP_TRY(c->raw_a.ensure(sizeof(double) * 2 * n));
+    HIP_TRY(c->raw_b.ensure(sizeof(double) * db * n));
+    HIP_TRY(c->pts_arena.ensure(sizeof(double) * nd * n));
+    HIP_TRY(c->absmax.ensure(sizeof(unsigned long long)));
+    HIP_TRY(c->h_absmax.ensure(sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->absmax.p, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->raw_a.p, a, sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->raw_b.p, b, sizeof(double) * db * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_prepare(c->raw_a.as<double>(), c->raw_b.as<double>(), (uint32_t)n, pa, c->pts_arena.as<double>(),
+                           c->absmax.as<unsigned long long>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_absmax.p, c->absmax.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    p->d_pts = c->pts_arena.as<double>();
+    for (int d = 0; d < nd; ++d)
+        p->ps.a[d] = p->d_pts + (size_t)d * n;
+    double amax;
+    std::memcpy(&amax, c->h_absmax.p, sizeof(double));
+    p->ps.xy_absmax = std::nextafter((float)amax, std::numeric_limits<float>::infinity());
+    return PL_OK;
+}
+PrepareArgs prepare_unproject(const CameraParams &c1, const CameraParams *c2) {
+    PrepareArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.mode = c2 ? 1 : 0;
+    pa.cam1 = c1;
+    if (c2)
+        pa.cam2 = *c2;
+    pa.scale = 1.0;
+    return pa;
 }
 
 // user model <-> record
@@ -1153,13 +1205,15 @@ int final_refine(Context *c, pl_problem *p, const double *record_in, const LMOpt
     return PL_OK;
 }
 
-// PoseLib/robust/utils.cc:584-644 with normalize_scale = shared_scale = true
-double normalize_points_shared(std::vector<double> &x1, std::vector<double> &x2, size_t n, Mat3 &T1, Mat3 &T2,
-                               bool centroid) {
+// PoseLib/robust/utils.cc:584-644 with normalize_scale = shared_scale = true.  Only the two order-dependent reductions
+// (centroids, mean distance) are summed here, sequentially like the reference; the per-point part - subtract the
+// centroid, divide by the scale - is applied by k_prepare on the device with the same two operations per coordinate.
+double normalization_of(const double *x1, const double *x2, size_t n, bool centroid, Mat3 &T1, Mat3 &T2,
+                        PrepareArgs &pa) {
     for (int i = 0; i < 9; ++i)
         T1.m[i] = T2.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
     if (centroid) {
-        double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
         for (size_t k = 0; k < n; ++k) {
             c1x += x1[2 * k], c1y += x1[2 * k + 1];
             c2x += x2[2 * k], c2y += x2[2 * k + 1];
@@ -1168,26 +1222,26 @@ double normalize_points_shared(std::vector<double> &x1, std::vector<double> &x2,
         c2x /= static_cast<double>(n), c2y /= static_cast<double>(n);
         T1.m[2] = -c1x, T1.m[5] = -c1y;
         T2.m[2] = -c2x, T2.m[5] = -c2y;
-        for (size_t k = 0; k < n; ++k) {
-            x1[2 * k] -= c1x, x1[2 * k + 1] -= c1y;
-            x2[2 * k] -= c2x, x2[2 * k + 1] -= c2y;
-        }
     }
     double scale = 0.0;
     for (size_t k = 0; k < n; ++k) {
-        scale += std::sqrt(x1[2 * k] * x1[2 * k] + x1[2 * k + 1] * x1[2 * k + 1]);
-        scale += std::sqrt(x2[2 * k] * x2[2 * k] + x2[2 * k + 1] * x2[2 * k + 1]);
+        double a0 = x1[2 * k], a1 = x1[2 * k + 1], b0 = x2[2 * k], b1 = x2[2 * k + 1];
+        if (centroid)
+            a0 -= c1x, a1 -= c1y, b0 -= c2x, b1 -= c2y;
+        scale += std::sqrt(a0 * a0 + a1 * a1);
+        scale += std::sqrt(b0 * b0 + b1 * b1);
     }
     scale /= std::sqrt(2) * n;
-    for (size_t k = 0; k < 2 * n; ++k) {
-        x1[k] /= scale;
-        x2[k] /= scale;
-    }
     const double f = 1.0 / scale;
     for (int i = 0; i < 6; ++i) {
         T1.m[i] *= f;
         T2.m[i] *= f;
     }
+    std::memset(&pa, 0, sizeof(pa));
+    pa.mode = 2;
+    pa.centred = centroid ? 1 : 0;
+    pa.c1x = c1x, pa.c1y = c1y, pa.c2x = c2x, pa.c2y = c2y;
+    pa.scale = scale;
     return scale;
 }
 
@@ -1392,15 +1446,12 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
         return rc;
     // robust.cc:40-46 : un-project, rescale the threshold by 1/focal
     const CameraParams cam = to_cam(camera);
-    std::vector<double> xn(2 * n);
-    for (size_t k = 0; k < n; ++k)
-        camera_unproject(cam, points2D[2 * k], points2D[2 * k + 1], xn[2 * k], xn[2 * k + 1]);
     pl_robust_options scaled = *opt;
     double scale = 1.0 / camera_focal(camera);
     scaled.max_error *= scale;
 
     pl_problem p;
-    rc = make_problem(c, EST_ABS, xn.data(), points3D, n, &p);
+    rc = make_problem_prepared(c, EST_ABS, points2D, points3D, n, prepare_unproject(cam, nullptr), &p);
     if (rc != PL_OK)
         return rc;
     pl_ransac_stats local;
@@ -1413,7 +1464,10 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
 
     if (st->num_inliers > 3) { // robust.cc:103-123 : bundle over the inliers in focal-normalised pixels
         pl_problem pp;
-        rc = make_problem(c, EST_ABS, points2D, points3D, n, &pp);
+        CameraParams raw_cam;
+        std::memset(&raw_cam, 0, sizeof(raw_cam));
+        raw_cam.model_id = CAM_NULL; // pixels as they are
+        rc = make_problem_prepared(c, EST_ABS, points2D, points3D, n, prepare_unproject(raw_cam, nullptr), &pp);
         if (rc != PL_OK)
             return rc;
         scale = 1.0 / camera_focal(camera);
@@ -1454,13 +1508,8 @@ int pl_estimate_relative_pose(const double *x1, const double *x2, size_t n, cons
     scaled.max_error *= scale;
     scaled.bundle.loss_scale *= scale;
     const CameraParams c1 = to_cam(camera1), c2 = to_cam(camera2);
-    std::vector<double> a(2 * n), b(2 * n);
-    for (size_t k = 0; k < n; ++k) {
-        camera_unproject(c1, x1[2 * k], x1[2 * k + 1], a[2 * k], a[2 * k + 1]);
-        camera_unproject(c2, x2[2 * k], x2[2 * k + 1], b[2 * k], b[2 * k + 1]);
-    }
     pl_problem p;
-    rc = make_problem(c, EST_REL, a.data(), b.data(), n, &p);
+    rc = make_problem_prepared(c, EST_REL, x1, x2, n, prepare_unproject(c1, &c2), &p);
     if (rc != PL_OK)
         return rc;
     pl_ransac_stats local;
@@ -1496,9 +1545,9 @@ int pl_estimate_fundamental(const double *x1, const double *x2, size_t n, const 
     rc = get_context(&c);
     if (rc != PL_OK)
         return rc;
-    std::vector<double> a(x1, x1 + 2 * n), b(x2, x2 + 2 * n);
     Mat3 T1, T2;
-    const double scale = normalize_points_shared(a, b, n, T1, T2, !opt->real_focal_check);
+    PrepareArgs prep;
+    const double scale = normalization_of(x1, x2, n, !opt->real_focal_check, T1, T2, prep);
     pl_robust_options scaled = *opt;
     scaled.max_error /= scale;
     scaled.bundle.loss_scale /= scale;
@@ -1510,7 +1559,7 @@ int pl_estimate_fundamental(const double *x1, const double *x2, size_t n, const 
     double Fcm[9];
     mat_to_colmajor(Fm, Fcm);
     pl_problem p;
-    rc = make_problem(c, EST_FUND, a.data(), b.data(), n, &p);
+    rc = make_problem_prepared(c, EST_FUND, x1, x2, n, prep, &p);
     if (rc != PL_OK)
         return rc;
     double rec[kModelStride];
@@ -1551,9 +1600,9 @@ int pl_estimate_homography(const double *x1, const double *x2, size_t n, const p
     rc = get_context(&c);
     if (rc != PL_OK)
         return rc;
-    std::vector<double> a(x1, x1 + 2 * n), b(x2, x2 + 2 * n);
     Mat3 T1, T2;
-    const double scale = normalize_points_shared(a, b, n, T1, T2, true);
+    PrepareArgs prep;
+    const double scale = normalization_of(x1, x2, n, true, T1, T2, prep);
     pl_robust_options scaled = *opt;
     scaled.max_error /= scale;
     scaled.bundle.loss_scale /= scale;
@@ -1565,7 +1614,7 @@ int pl_estimate_homography(const double *x1, const double *x2, size_t n, const p
     double Hcm[9];
     mat_to_colmajor(Hm, Hcm);
     pl_problem p;
-    rc = make_problem(c, EST_HOM, a.data(), b.data(), n, &p);
+    rc = make_problem_prepared(c, EST_HOM, x1, x2, n, prep, &p);
     if (rc != PL_OK)
         return rc;
     double rec[kModelStride];

@@ -421,7 +421,66 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
     }
 }
 
+// ------------------------------------------------------------------------------------ front-end pre-processing
+__global__ __launch_bounds__(256) void k_prepare(const double *__restrict__ a_raw, const double *__restrict__ b_raw,
+                                                 uint32_t n, PrepareArgs g, double *__restrict__ soa,
+                                                 unsigned long long *absmax_bits) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    double m = 0.0;
+    if (i < n) {
+        double a0 = a_raw[2 * (size_t)i], a1 = a_raw[2 * (size_t)i + 1];
+        if (g.mode == 2) {
+            if (g.centred)
+                a0 -= g.c1x, a1 -= g.c1y;
+            a0 /= g.scale, a1 /= g.scale;
+        } else {
+            double u, v;
+            camera_unproject(g.cam1, a0, a1, u, v);
+            a0 = u, a1 = v;
+        }
+        soa[i] = a0;
+        soa[(size_t)n + i] = a1;
+        const double f0 = fabs(a0), f1 = fabs(a1);
+        m = (f0 > m || f0 != f0) ? f0 : m; // NaN propagates (and disables the pre-filter), like the host loop
+        m = (f1 > m || f1 != f1) ? f1 : m;
+        if (g.mode == 0) {
+            for (int d = 0; d < 3; ++d)
+                soa[(size_t)(2 + d) * n + i] = b_raw[3 * (size_t)i + d];
+        } else {
+            double b0 = b_raw[2 * (size_t)i], b1 = b_raw[2 * (size_t)i + 1];
+            if (g.mode == 2) {
+                if (g.centred)
+                    b0 -= g.c2x, b1 -= g.c2y;
+                b0 /= g.scale, b1 /= g.scale;
+            } else {
+                double u, v;
+                camera_unproject(g.cam2, b0, b1, u, v);
+                b0 = u, b1 = v;
+            }
+            soa[(size_t)2 * n + i] = b0;
+            soa[(size_t)3 * n + i] = b1;
+        }
+    }
+    // non-negative doubles (and NaN, whose pattern is above +inf) order like their bit patterns
+    unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(bits, off, 64);
+        bits = o > bits ? o : bits;
+    }
+    if ((threadIdx.x & 63) == 0 && bits)
+        atomicMax(absmax_bits, bits);
+}
+
 // ------------------------------------------------------------------------------------ launchers
+hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, const PrepareArgs &args, double *soa,
+                          unsigned long long *absmax_bits, hipStream_t stream) {
+    if (n == 0)
+        return hipSuccess;
+    k_prepare<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(a_raw, b_raw, n, args, soa, absmax_bits);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t B, uint32_t M,
                                    uint8_t *delta, uint32_t *flags, uint32_t flags_cap, uint32_t *positions,
                                    BatchCtl *ctl, hipStream_t stream) {

@@ -95,6 +95,20 @@ struct RecordMeta {
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream);
+// Front-end pre-processing on the device (robust.cc:40-46, 286-292; utils.cc:584-644 per-point part): AoS user
+// buffers -> the problem's SoA block, with per-point un-projection (modes 0, 1) or the affine normalisation whose
+// centroid / scale the host has summed sequentially (mode 2; the two reductions of normalize_points are order
+// dependent and stay on the host to remain bit-identical).  absmax_bits: max(|x|, |y|) of the first point set as the
+// bit pattern of a non-negative double (NaN propagates), zeroed by the caller.
+struct PrepareArgs {
+    int32_t mode;          // 0: a -> unproject(cam1), b = N x 3 copied; 1: a -> unproject(cam1), b -> unproject(cam2);
+                           // 2: a -> (a - c1) / scale, b -> (b - c2) / scale   (subtract only if `centred`)
+    int32_t centred;
+    CameraParams cam1, cam2;
+    double c1x, c1y, c2x, c2y, scale;
+};
+hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, const PrepareArgs &args, double *soa,
+                          unsigned long long *absmax_bits, hipStream_t stream);
 size_t lm2_state_bytes(uint32_t num_tasks);
 size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices);
 hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, uint32_t slices,
