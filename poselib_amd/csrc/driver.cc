@@ -96,7 +96,7 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // batch scratch
-    DevBuf positions, samples, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf positions, samples, lm_records_in, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
     DevBuf shadow, compact64;
     DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
@@ -304,23 +304,6 @@ void lm_params_from_record(int kind, const double *rec, double *params) {
         params[8] = s[1] / s[0];
     }
 }
-// Record (what k_score consumes) of a refined parameter block.
-void record_from_lm_params(int kind, const double *params, double *rec) {
-    if (kind == EST_ABS || kind == EST_REL) {
-        Quat q;
-        q.w = params[0], q.x = params[1], q.y = params[2], q.z = params[3];
-        store_pose_model_q(rec, q, v3(params[4], params[5], params[6]), kind == EST_REL);
-    } else if (kind == EST_HOM) {
-        Mat3 H;
-        for (int i = 0; i < 9; ++i)
-            H.m[i] = params[i];
-        store_matrix_model(rec, H);
-    } else {
-        Mat3 F;
-        factorized_F(params, F.m);
-        store_matrix_model(rec, F);
-    }
-}
 void identity_record(int kind, double *rec) {
     if (kind == EST_ABS || kind == EST_REL) {
         Quat q;
@@ -509,16 +492,31 @@ struct RefineJob {
     bool skipped = false;
 };
 
-// Runs all jobs as one batched k_lm launch, converts the refined parameters to records and (optionally)
-// re-scores them with threshold thr2.  Synchronises the stream.
-int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &jobs, bool rescore, double thr2) {
+// Optional tail of a single-job refinement: pick "refined if its score beats the incumbent's, else the incumbent"
+// on the device (ransac_impl.h:190-198) and compute that model's inlier mask, all behind the same synchronisation.
+struct MaskTail {
+    double incumbent_score;      // stats.model_score
+    const double *incumbent_rec; // host record of the incumbent (best model so far)
+    double thr2;
+    uint8_t *host_mask;          // N bytes or nullptr
+};
+
+// Runs all jobs as one batched LM launch; the refined parameters become records ON THE DEVICE (k_task_records),
+// which are (optionally) re-scored with threshold thr2, and (optionally, single job) followed by the mask tail.
+// One stream synchronisation for the whole chain.
+int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &jobs, bool rescore, double thr2,
+                    const MaskTail *tail = nullptr) {
     const uint32_t nj = (uint32_t)jobs.size();
     if (nj == 0)
         return PL_OK;
     HIP_TRY(c->h_tasks.ensure(sizeof(LMTask) * nj));
     HIP_TRY(c->lm_tasks.ensure(sizeof(LMTask) * nj));
     HIP_TRY(c->lm_scratch.ensure((size_t)p->n * nj + 16));
+    HIP_TRY(c->h_records.ensure(sizeof(double) * kModelStride * (nj + 1)));
+    HIP_TRY(c->lm_records_in.ensure(sizeof(double) * kModelStride * (nj + 1)));
+    HIP_TRY(c->lm_records.ensure(sizeof(double) * kModelStride * nj));
     LMTask *ht = c->h_tasks.as<LMTask>();
+    double *hr = c->h_records.as<double>();
     for (uint32_t j = 0; j < nj; ++j) {
         LMTask &t = ht[j];
         std::memset(&t, 0, sizeof(t));
@@ -529,8 +527,13 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         t.prefilter_thr2 = jobs[j].prefilter_thr2;
         t.mask = jobs[j].d_mask;
         t.scratch = c->lm_scratch.as<uint8_t>() + (size_t)j * p->n;
+        std::memcpy(hr + (size_t)j * kModelStride, jobs[j].record_in, sizeof(double) * kModelStride);
     }
+    if (tail)
+        std::memcpy(hr + (size_t)nj * kModelStride, tail->incumbent_rec, sizeof(double) * kModelStride);
     HIP_TRY(hipMemcpyAsync(c->lm_tasks.p, ht, sizeof(LMTask) * nj, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->lm_records_in.p, hr, sizeof(double) * kModelStride * (nj + (tail ? 1 : 0)),
+                           hipMemcpyHostToDevice, c->stream));
     // Large point sets with 6..8 parameters saturate the single CU k_lm gives a task: spread every task over several
     // workgroups (k_lm2).  Only for short, bounded runs (the LO: 25 iterations) - k_lm2 costs 2 * max_iterations + 3
     // launches whatever the iteration count turns out to be.
@@ -540,7 +543,6 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     // (measured: -30 % throughput).  The two kernels sum the normal equations in different orders, so the choice
     // must not depend on load: it is an explicit, process-wide setting (POSELIB_AMD_LATENCY_MODE=1), off by default.
     static const bool latency_mode = std::getenv("POSELIB_AMD_LATENCY_MODE") != nullptr;
-    const bool lm2_off = false;
     uint32_t max_it = 0;
     bool same_it = true;
     for (uint32_t j = 0; j < nj; ++j) {
@@ -548,8 +550,7 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         max_it = std::max(max_it, jobs[j].opt.max_iterations);
     }
     const uint32_t lm2_min_points = (p->kind == EST_ABS) ? 8192u : 2560u;
-    if (!lm2_off && latency_mode && p->kind != EST_REL && same_it && max_it >= 1 && max_it <= 32 &&
-        p->n >= lm2_min_points) {
+    if (latency_mode && p->kind != EST_REL && same_it && max_it >= 1 && max_it <= 32 && p->n >= lm2_min_points) {
         const uint32_t slices = std::min<uint32_t>(16u, std::max<uint32_t>(2u, p->n / 512u));
         HIP_TRY(c->lm2_states.ensure(lm2_state_bytes(nj)));
         HIP_TRY(c->lm2_partials.ensure(lm2_partial_bytes(nj, slices)));
@@ -558,30 +559,36 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     } else {
         HIP_TRY(launch_lm(p->kind, p->ps, c->lm_tasks.as<LMTask>(), nj, c->stream));
     }
+    HIP_TRY(launch_task_records(p->kind, c->lm_tasks.as<LMTask>(), c->lm_records_in.as<double>(),
+                                c->lm_records.as<double>(), nj, c->stream));
     HIP_TRY(hipMemcpyAsync(ht, c->lm_tasks.p, sizeof(LMTask) * nj, hipMemcpyDeviceToHost, c->stream));
+    if (rescore || tail) {
+        int rc = enqueue_score_records(c, p, c->lm_records.as<double>(), nj, tail ? tail->thr2 : thr2, false);
+        if (rc != PL_OK)
+            return rc;
+    }
+    if (tail) { // single job: choose refined / incumbent on the device, then the inlier mask of the choice
+        HIP_TRY(c->mask.ensure(std::max<uint32_t>(p->n, 1u)));
+        HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
+        HIP_TRY(launch_select_record(c->score.as<double>(), tail->incumbent_score, c->lm_records.as<double>(),
+                                     c->lm_records_in.as<double>() + (size_t)nj * kModelStride,
+                                     c->tmp_model.as<double>(), c->stream));
+        HIP_TRY(launch_mask(p->kind, p->ps, c->tmp_model.as<double>(), tail->thr2, c->mask.as<uint8_t>(), c->stream));
+        if (tail->host_mask && p->n)
+            HIP_TRY(hipMemcpyAsync(tail->host_mask, c->mask.p, p->n, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(c->h_records.ensure(sizeof(double) * kModelStride * nj));
-    HIP_TRY(c->lm_records.ensure(sizeof(double) * kModelStride * nj));
-    double *hr = c->h_records.as<double>();
     for (uint32_t j = 0; j < nj; ++j) {
         jobs[j].skipped = ht[j].skipped != 0;
         std::memcpy(jobs[j].params_out, ht[j].params, sizeof(double) * kParamDoubles);
         if (jobs[j].skipped) // refinement not run: model unchanged (relative_pose.cc:75-77)
             std::memcpy(jobs[j].record_out, jobs[j].record_in, sizeof(double) * kModelStride);
         else
-            record_from_lm_params(p->kind, ht[j].params, jobs[j].record_out);
-        std::memcpy(hr + (size_t)j * kModelStride, jobs[j].record_out, sizeof(double) * kModelStride);
-    }
-    if (!rescore)
-        return PL_OK;
-    HIP_TRY(hipMemcpyAsync(c->lm_records.p, hr, sizeof(double) * kModelStride * nj, hipMemcpyHostToDevice, c->stream));
-    int rc = enqueue_score_records(c, p, c->lm_records.as<double>(), nj, thr2, false);
-    if (rc != PL_OK)
-        return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (uint32_t j = 0; j < nj; ++j) {
-        jobs[j].count = c->h_count.as<uint32_t>()[j];
-        jobs[j].score = c->h_score.as<double>()[j];
+            record_from_lm_params(p->kind, ht[j].params, jobs[j].record_out); // same inline function as the device
+        if (rescore || tail) {
+            jobs[j].count = c->h_count.as<uint32_t>()[j];
+            jobs[j].score = c->h_score.as<double>()[j];
+        }
     }
     return PL_OK;
 }
@@ -623,6 +630,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
         return j;
     };
 
+    bool mask_done = false;
     if (N >= (uint32_t)K) { // ransac_impl.h:161-163
         uint64_t best_min_inl = 0;
         double best_min_score = std::numeric_limits<double>::max();
@@ -986,10 +994,17 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
         }
         st->iterations = it;
 
-        // ---- final refinement of the best model (ransac_impl.h:190-198; model_score is not updated) ----
+        // ---- final refinement of the best model (ransac_impl.h:190-198; model_score is not updated), chained on the
+        // device with the choice refined / incumbent and the inlier mask of the returned model (ransac.cc:55, 152,
+        // 259, 311): one synchronisation ----
         {
             std::vector<RefineJob> fin{make_lo_job(best_record)};
-            int rc = run_refinements(c, p, fin, true, thr2);
+            MaskTail tail;
+            tail.incumbent_score = st->model_score;
+            tail.incumbent_rec = best_record;
+            tail.thr2 = thr2;
+            tail.host_mask = inliers;
+            int rc = run_refinements(c, p, fin, true, thr2, &tail);
             if (rc != PL_OK)
                 return rc;
             st->refinements++;
@@ -997,11 +1012,12 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                 std::memcpy(best_record, fin[0].record_out, sizeof(double) * kModelStride);
                 st->num_inliers = fin[0].count;
             }
+            mask_done = true;
         }
     }
 
-    // ---- inlier mask of the returned model (ransac.cc:55, 152, 259, 311) ----
-    if (N > 0) {
+    // ---- inlier mask of the returned model when the loop did not run (too few points: ransac_impl.h:161-163) ----
+    if (N > 0 && !mask_done) {
         HIP_TRY(c->mask.ensure(N));
         HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
         HIP_TRY(hipMemcpyAsync(c->tmp_model.p, best_record, sizeof(double) * kModelStride, hipMemcpyHostToDevice,

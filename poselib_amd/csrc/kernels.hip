@@ -1177,6 +1177,38 @@ hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_t
     return hipGetLastError();
 }
 
+__global__ void k_task_records(int est, const LMTask *tasks, const double *records_in, double *records_out,
+                               uint32_t num_tasks) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_tasks)
+        return;
+    double *out = records_out + (size_t)j * kModelStride;
+    if (tasks[j].skipped) { // refinement not run: model unchanged (relative_pose.cc:75-77)
+        for (int i = 0; i < kModelStride; ++i)
+            out[i] = records_in[(size_t)j * kModelStride + i];
+    } else {
+        record_from_lm_params(est, tasks[j].params, out);
+    }
+}
+__global__ void k_select_record(const double *score_refined, double incumbent_score, const double *rec_refined,
+                                const double *rec_incumbent, double *out) {
+    const double *src = (*score_refined < incumbent_score) ? rec_refined : rec_incumbent;
+    if (threadIdx.x < kModelStride)
+        out[threadIdx.x] = src[threadIdx.x];
+}
+hipError_t launch_task_records(int est, const LMTask *tasks, const double *records_in, double *records_out,
+                               uint32_t num_tasks, hipStream_t stream) {
+    if (num_tasks == 0)
+        return hipSuccess;
+    k_task_records<<<dim3((num_tasks + 63) / 64), dim3(64), 0, stream>>>(est, tasks, records_in, records_out, num_tasks);
+    return hipGetLastError();
+}
+hipError_t launch_select_record(const double *score_refined, double incumbent_score, const double *rec_refined,
+                                const double *rec_incumbent, double *out, hipStream_t stream) {
+    k_select_record<<<dim3(1), dim3(64), 0, stream>>>(score_refined, incumbent_score, rec_refined, rec_incumbent, out);
+    return hipGetLastError();
+}
+
 // Multi-workgroup LM (k_lm2): `slices` workgroups per task, 2 * max_iterations + 3 launches.
 size_t lm2_state_bytes(uint32_t num_tasks) { return sizeof(LM2State) * 2 * (size_t)num_tasks; }
 size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices) { return sizeof(double) * 2 * (size_t)num_tasks * slices * 46; }

@@ -109,6 +109,13 @@ struct PrepareArgs {
 };
 hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, const PrepareArgs &args, double *soa,
                           unsigned long long *absmax_bits, hipStream_t stream);
+// After the LM kernels: records of the refined models on the device (skipped tasks keep their input record), and the
+// choice "refined model if its score beats `incumbent_score`, else the incumbent" of the final refinement
+// (ransac_impl.h:190-198) so that the inlier mask can follow without a host round trip.
+hipError_t launch_task_records(int est, const LMTask *tasks, const double *records_in, double *records_out,
+                               uint32_t num_tasks, hipStream_t stream);
+hipError_t launch_select_record(const double *score_refined, double incumbent_score, const double *rec_refined,
+                                const double *rec_incumbent, double *out, hipStream_t stream);
 size_t lm2_state_bytes(uint32_t num_tasks);
 size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices);
 hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, uint32_t slices,

@@ -792,4 +792,23 @@ template <> struct Refiner<EST_FUND> {
     }
 };
 
+// Record (what the scorers consume) of a refined parameter block: pose (q, t) for the absolute / relative problems,
+// H row-major, or the Bartoli-Sturm factorisation of F (optim_utils.h:73-77).  est: pl_score.h Estimator.
+PL_HD void record_from_lm_params(int est, const double *params, double *rec) {
+    if (est == 0 || est == 1) {
+        Quat q;
+        q.w = params[0], q.x = params[1], q.y = params[2], q.z = params[3];
+        store_pose_model_q(rec, q, v3(params[4], params[5], params[6]), est == 1);
+    } else if (est == 3) {
+        Mat3 H;
+        for (int i = 0; i < 9; ++i)
+            H.m[i] = params[i];
+        store_matrix_model(rec, H);
+    } else {
+        Mat3 F;
+        factorized_F(params, F.m);
+        store_matrix_model(rec, F);
+    }
+}
+
 } // namespace pl
