@@ -627,11 +627,24 @@ template <int N> struct BlockReduce {
     }
 };
 
-template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet pts, LMTask *tasks) {
+// `lds_points` != 0: the correspondences are staged once into dynamic LDS (nd * n doubles) and every residual /
+// Jacobian pass reads them from there - a task makes 30..50 passes over the same points, and for the small problems
+// of the default-options regime the L2 round trip of every pass is a visible part of the 8 us an LM iteration takes.
+template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet pts_global, LMTask *tasks, int lds_points) {
     using R = Refiner<EST>;
     constexpr int K = R::K;
     constexpr int NT = NormalSize<K>::kTotal;
+    constexpr int ND = point_doubles(EST);
     LMTask &T = tasks[blockIdx.x];
+    extern __shared__ double s_lm_points[];
+    PointSet pts = pts_global;
+    if (lds_points) {
+        for (int d = 0; d < ND; ++d) {
+            for (uint32_t i = threadIdx.x; i < pts_global.n; i += kLMThreads)
+                s_lm_points[(size_t)d * pts_global.n + i] = pts_global.a[d][i];
+            pts.a[d] = s_lm_points + (size_t)d * pts_global.n;
+        }
+    }
 
     __shared__ LMControl ctl;
     __shared__ double cur[kParamDoubles], trial[kParamDoubles];
@@ -1173,7 +1186,19 @@ hipError_t launch_finalize(const FinalizeArgs &a, uint32_t max_hyp, hipStream_t 
 hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
-    PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), 0, stream>>>(pts, tasks));
+    // stage the points in LDS when they fit next to the kernel's static LDS (160 KB per CU, one workgroup per CU)
+    const size_t bytes = sizeof(double) * point_doubles(est) * (size_t)pts.n;
+    const bool lds = bytes <= 128 * 1024 && std::getenv("POSELIB_AMD_LM_NO_LDS") == nullptr;
+    static bool attr_set[4] = {false, false, false, false};
+    if (lds && bytes > 48 * 1024 && est >= 0 && est < 4 && !attr_set[est]) {
+        hipError_t e = hipSuccess;
+        PL_DISPATCH_EST(est, e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm<E>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        if (e != hipSuccess)
+            return e;
+        attr_set[est] = true;
+    }
+    PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), lds ? bytes : 0, stream>>>(pts, tasks, lds ? 1 : 0));
     return hipGetLastError();
 }
 

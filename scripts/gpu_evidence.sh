@@ -2,7 +2,7 @@
 # commands, PMC passes (VALU/issue counters, FETCH_SIZE, WRITE_SIZE in separate passes), multi-stream occupancy.
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r1z
+O=$R/gpurun_out/evidence
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.log
 timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
