@@ -382,6 +382,54 @@ def test_edge_cases(gpu):
         assert (np.array(info["inliers"]) == mask).all()
 
 
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 63, 64, 65, 319, 320, 321, 383, 384, 385, 640, 1281])
+def test_point_counts_around_the_chunk_boundaries(gpu, n):
+    """ragged inputs: the streaming scorer holds 64 * P correspondences per wavefront (P = 1..6, chosen from N), the
+    small scorers 256 * P - every size class, exact multiples and off-by-ones, for all four estimators"""
+    opt = {"ransac": {"seed": n, "max_iterations": 400, "min_iterations": 100}}
+    d = synth.absolute_pose_scene(max(n, 3), 0.3, 40 + n)
+    img, info = gpu.estimate_absolute_pose(d["p2d"][:n], d["p3d"][:n], d["camera"], opt)
+    pose, mask, st = O.estimate_absolute_pose(d["p2d"][:n], d["p3d"][:n], d["camera"], opt)
+    assert info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+    assert (np.array(info["inliers"]) == mask).all()
+    h = synth.homography_scene(max(n, 4), 0.3, 41 + n)
+    H, info = gpu.estimate_homography(h["x1"][:n], h["x2"][:n], opt)
+    Ho, mask, st = O.estimate_homography(h["x1"][:n], h["x2"][:n], opt)
+    assert info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+    assert (np.array(info["inliers"]) == mask).all()
+    r = synth.relative_pose_scene(max(n, 7), 0.3, 42 + n)
+    pg, info = gpu.estimate_relative_pose(r["x1"][:n], r["x2"][:n], r["camera1"], r["camera2"], opt)
+    po, mask, st = O.estimate_relative_pose(r["x1"][:n], r["x2"][:n], r["camera1"], r["camera2"], opt)
+    assert info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+    assert (np.array(info["inliers"]) == mask).all()
+    F, info = gpu.estimate_fundamental(r["x1"][:n], r["x2"][:n], opt)
+    Fo, mask, st = O.estimate_fundamental(r["x1"][:n], r["x2"][:n], opt)
+    assert info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+    assert (np.array(info["inliers"]) == mask).all()
+
+
+def test_non_finite_inputs_do_not_hang_or_crash(gpu):
+    """NaN / inf correspondences: the reference happily computes with them (comparisons fail, the point is an
+    outlier); the device path must do the same - same counts and masks as the oracle, no hang"""
+    d = synth.absolute_pose_scene(600, 0.3, 77)
+    p2d, p3d = d["p2d"].copy(), d["p3d"].copy()
+    p2d[5] = [np.nan, 10.0]
+    p3d[9] = [np.inf, 0.0, 1.0]
+    p2d[17] = [1e300, -1e300]
+    opt = {"ransac": {"seed": 2, "max_iterations": 500, "min_iterations": 100}}
+    img, info = gpu.estimate_absolute_pose(p2d, p3d, d["camera"], opt)
+    pose, mask, st = O.estimate_absolute_pose(p2d, p3d, d["camera"], opt)
+    assert info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+    assert (np.array(info["inliers"]) == mask).all()
+    h = synth.homography_scene(600, 0.3, 78)
+    x1, x2 = h["x1"].copy(), h["x2"].copy()
+    x1[3] = [np.nan, np.nan]
+    H, info = gpu.estimate_homography(x1, x2, opt)
+    Ho, mask, st = O.estimate_homography(x1, x2, opt)
+    assert info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+    assert (np.array(info["inliers"]) == mask).all()
+
+
 def test_throughput_mode_full_size_properties(gpu):
     """BASELINE config 1 at full size (100k iterations): size-independent properties — the run is
     deterministic, the reported best score is reproduced by re-scoring the returned model, and the
