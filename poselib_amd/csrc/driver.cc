@@ -96,7 +96,7 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // batch scratch
-    DevBuf positions, samples, lm_records_in, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf positions, samples, shadow16, lm_records_in, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
     DevBuf shadow, compact64;
     DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
@@ -449,6 +449,7 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     sa.models = d_records;
     sa.slots = nullptr;
     sa.shadow = nullptr;
+    sa.shadow16 = nullptr;
     sa.compact64 = nullptr;
 
     sa.num_hyp = c->num_hyp.as<uint32_t>();
@@ -794,6 +795,13 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             sa.pts = p->ps;
             sa.models = ga.models;
             sa.slots = c->slots.as<uint32_t>();
+            sa.shadow16 = nullptr;
+            if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores
+                HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
+                HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), (uint32_t)hcap, sa.pf.g16, sa.pf.c16,
+                                        c->shadow16.p, c->stream));
+                sa.shadow16 = c->shadow16.p;
+            }
             sa.shadow = prefilter ? c->shadow.as<float>() : nullptr;
             sa.compact64 = prefilter ? c->compact64.as<double>() : nullptr;
             sa.num_hyp = &d_ctl->num_hyp;

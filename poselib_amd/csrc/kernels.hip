@@ -67,6 +67,20 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
+// Inclusive prefix sum over the 64 lanes through the DPP paths (Hillis-Steele inside each row of 16 with zero fill,
+// then the row totals are broadcast downwards): no LDS round trips.
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ uint32_t dpp_shift_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v += dpp_shift_u32<0x111>(v); // row_shr:1
+    v += dpp_shift_u32<0x112>(v); // row_shr:2
+    v += dpp_shift_u32<0x114>(v); // row_shr:4
+    v += dpp_shift_u32<0x118>(v); // row_shr:8
+    v += dpp_shift_u32<0x142, 0xa>(v); // row_bcast:15 -> rows 1, 3
+    v += dpp_shift_u32<0x143, 0xc>(v); // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
@@ -548,6 +562,219 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
                 if (g + 2 < gn)
                     fetch(ra, g + 2);
                 step(rb, g + 1);
+            }
+        }
+        while (qtail != qhead)
+            drain(min(64u, qtail - qhead));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((uint32_t)lane < gn) {
+            const size_t o = (size_t)chunk * hyp_capacity + kb + lane;
+            part_score[o] = acc_s[lane];
+            part_count[o] = acc_c[lane];
+        }
+        ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
+    }
+}
+
+// ---- absolute pose: the pre-filter on the matrix cores ----------------------------------------------------------
+// k_score_mfma: same contract and same exact pass as k_score_queue, but pass A evaluates z = R X + t for 8 hypotheses
+// x 32 correspondences per v_mfma_f32_32x32x8_f16 (operands: k_shadow16's blocks and fp16 hi/lo pairs of the points;
+// bound derivation in pl_prefilter.h).  The projection products - 9 of the 13 FMAs per pair of the VALU filter -
+// leave the vector ALU, which keeps the per-pair tail: a = z0 - x z2 (fp32, exact x), the slack-widened threshold,
+// one subtraction whose SIGN BIT is the verdict (no compare, no SGPR mask per pair: the bit is shifted into a
+// per-lane, per-hypothesis bit field over the point groups).  After the PG tiles of a group of 8 hypotheses the bit
+// fields are expanded into the wave's LDS queue, hypothesis by hypothesis in ascending order (prefix sum over the
+// lanes), so the drain's segmented scan sees every hypothesis as one run, exactly as in k_score_queue.
+// Register layout of one tile (32 rows x 32 columns, 16 accumulator registers per lane; lane l: column l % 32, rows
+// 8 (v / 4) + 4 (l / 32) + v % 4 for register v): lanes 0..31 hold hypothesis slots 0, 2, 4, 6 of the group, lanes
+// 32..63 slots 1, 3, 5, 7; registers (0,1) = z0 of two slots, (2,3) = z2, (4,5) = z1, (6,7) = their slack W, and
+// (8..15) the same for the other two slots - pairs of adjacent registers, so the tail runs as packed fp32.
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+constexpr int kMfmaQueueCap = 1024; // >= 63 waiting + 64 lanes * 10 point groups appended by one round
+
+template <int PG>
+__global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma(PointSet pts, const uint2 *__restrict__ shadow16,
+                                                               const double *__restrict__ compact64,
+                                                               const uint32_t *__restrict__ num_hyp_ptr,
+                                                               uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+                                                               uint32_t *__restrict__ part_count,
+                                                               double *__restrict__ part_score) {
+    constexpr int kWaves = kScoreThreads / 64;
+    constexpr int NPW = 32 * PG; // correspondences per chunk
+    __shared__ double s_pts[5][NPW];
+    __shared__ uint32_t s_queue[kWaves][kMfmaQueueCap];
+    __shared__ double s_acc_s[kWaves][64];
+    __shared__ uint32_t s_acc_c[kWaves][64];
+    __shared__ uint32_t s_next_group;
+    __shared__ uint2 s_bop[PG][64];  // B operands of the point groups (lane-specific: high / low fp16 parts)
+    __shared__ float4 s_xyw[PG][32]; // fp32 x, y and the point's share of the slack, per column
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = lane & 31, half = lane >> 5;
+    const uint32_t chunk = blockIdx.y;
+
+    // ---- stationary operand: PG groups of 32 correspondences; lane l carries column l % 32 of every group ----
+    // The per-point data of the PG tiles live in LDS, not in registers: the tile loop below is a real loop (an
+    // unrolled one makes the register allocator give every tile its own 16 accumulators and spill the rest).
+    uint32_t validbits = 0; // bit (PG - 1 - g): group g holds a real correspondence in this column
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+        const uint32_t i = chunk * NPW + g * 32 + col;
+        const bool valid = i < pts.n;
+        const uint32_t ic = valid ? i : 0u;
+        double x[5];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            x[d] = pts.a[d][ic];
+            if (wave == 0 && half == 0)
+                s_pts[d][g * 32 + col] = x[d];
+        }
+        const double n1 = fabs(x[2]) + fabs(x[3]) + fabs(x[4]);
+        const bool in_range = n1 < 3.0e4; // fp16 carries it (NaN fails the test too)
+        const bool use = valid && in_range;
+        _Float16 h[3], l[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = use ? (float)x[2 + d] : 0.f;
+            h[d] = (_Float16)v;
+            l[d] = (_Float16)(v - (float)h[d]);
+        }
+        if (wave == 0) {
+            const half4_t b = half ? half4_t{l[0], l[1], l[2], (_Float16)1.0f} : half4_t{h[0], h[1], h[2], (_Float16)1.0f};
+            uint2 raw;
+            __builtin_memcpy(&raw, &b, 8);
+            s_bop[g][lane] = raw;
+            if (half == 0) // out-of-range points: zero operand + infinite slack = always evaluated exactly
+                s_xyw[g][col] = make_float4(use ? (float)x[0] : 0.f, use ? (float)x[1] : 0.f,
+                                            use ? pf_up(pf.g16 * pf_up((float)n1)) : __builtin_huge_valf(), 0.f);
+        }
+        validbits |= valid ? (1u << (PG - 1 - g)) : 0u;
+    }
+    if (threadIdx.x == 0)
+        s_next_group = 0;
+    __syncthreads(); // the only workgroup barrier
+
+    const uint32_t H = *as_uniform(num_hyp_ptr);
+    uint32_t *const queue = s_queue[wave];
+    double *const acc_s = s_acc_s[wave];
+    uint32_t *const acc_c = s_acc_c[wave];
+    const uint32_t G = (H + 63u) / 64u;
+    const uint32_t gper = (G + gridDim.x - 1) / gridDim.x;
+    const uint32_t g0 = blockIdx.x * gper;
+    const uint32_t g1 = min(G, g0 + gper);
+    auto request_ticket = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (lane == 0)
+            t = atomicAdd(&s_next_group, 1u);
+        return t;
+    };
+    uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)request_ticket());
+    while (g0 + ticket < g1) {
+        const uint32_t kb = (g0 + ticket) * 64u;
+        const uint32_t pending = request_ticket();
+        const uint32_t gn = min(64u, H - kb);
+        acc_s[lane] = 0.0;
+        acc_c[lane] = 0;
+        uint32_t qhead = 0, qtail = 0;
+
+        auto drain = [&](uint32_t n) { // identical to k_score_queue's
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool act = (uint32_t)lane < n;
+            const uint32_t e = act ? queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffffffu;
+            const uint32_t g = e >> 16, pi = act ? (e & 0xffffu) : 0u;
+            double x[5];
+#pragma unroll
+            for (int d = 0; d < 5; ++d)
+                x[d] = s_pts[d][pi];
+            const double *Mp = compact64 + (size_t)(kb + (act ? g : 0u)) * kModelDoubles;
+            double M[kModelDoubles];
+#pragma unroll
+            for (int i = 0; i < kModelDoubles; ++i)
+                M[i] = Mp[i];
+            double r2;
+            const bool in = eval_point<EST_ABS>(M, x, thr2, r2) && act;
+            double v = in ? r2 : 0.0;
+            uint32_t c = in ? 1u : 0u;
+            if (__builtin_amdgcn_ballot_w64(in)) {
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double vv = __shfl_up(v, off, 64);
+                    const uint32_t cc = __shfl_up(c, off, 64);
+                    const uint32_t gg = __shfl_up(g, off, 64);
+                    if (lane >= off && gg == g) {
+                        v += vv;
+                        c += cc;
+                    }
+                }
+                const uint32_t gnext = __shfl_down(g, 1, 64);
+                const bool tail = act && ((uint32_t)lane + 1 == n || gnext != g);
+                if (tail && c) {
+                    acc_s[g] += v;
+                    acc_c[g] += c;
+                }
+            }
+            qhead += n;
+        };
+
+        const uint32_t ngroups8 = (gn + 7u) / 8u;
+        uint2 Araw = shadow16[((size_t)(kb >> 3)) * 64 + half * 32 + col];
+        for (uint32_t hg = 0; hg < ngroups8; ++hg) {
+            half4_t Aop;
+            __builtin_memcpy(&Aop, &Araw, 8);
+            if (hg + 1 < ngroups8) // next group's operand travels while this one is evaluated
+                Araw = shadow16[((size_t)(kb >> 3) + hg + 1) * 64 + half * 32 + col];
+            uint32_t out[4] = {0u, 0u, 0u, 0u}; // slot 2 r + half: bit (PG - 1 - g) = point group g is a proven outlier
+            const float16_t kZero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+            for (int g = 0; g < PG; ++g) {
+                half4_t Bop;
+                const uint2 braw = s_bop[g][lane];
+                __builtin_memcpy(&Bop, &braw, 8);
+                const float4 xyw = s_xyw[g][col];
+                const float16_t D = __builtin_amdgcn_mfma_f32_32x32x8f16(Aop, Bop, kZero, 0, 0, 0);
+#pragma unroll
+                for (int P2 = 0; P2 < 2; ++P2) {
+                    const int b = 8 * P2;
+                    const v2f z0 = {D[b], D[b + 1]}, z2 = {D[b + 2], D[b + 3]};
+                    const v2f z1 = {D[b + 4], D[b + 5]}, Wt = {D[b + 6], D[b + 7]};
+                    const v2f a0 = pk_fma(bc(-xyw.x), z2, z0);
+                    const v2f a1 = pk_fma(bc(-xyw.y), z2, z1);
+                    const v2f W = Wt + bc(xyw.z);
+                    const v2f Bv = pk_fma(bc(pf.thr), z2, W);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        // proven outlier <=> max(|a0|, |a1|) > B <=> B - max < 0: the sign bit of the difference
+                        // is shifted into the bit field by one v_alignbit (B is never -0.0: the slack is positive)
+                        const float d = Bv[e] - fmaxf(fabsf(a0[e]), fabsf(a1[e]));
+                        out[2 * P2 + e] = __builtin_amdgcn_alignbit(out[2 * P2 + e], __float_as_uint(d), 31);
+                    }
+                }
+            }
+            // ---- expansion: four rounds, round r = slots 2 r (lanes 0..31) and 2 r + 1 (lanes 32..63) ----
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t slot = hg * 8u + 2u * r + half; // hypothesis index inside the group of 64
+                uint32_t bits = ~out[r] & validbits;
+                if (slot >= gn)
+                    bits = 0u;
+                if (__builtin_amdgcn_ballot_w64(bits != 0u)) { // wave-uniform
+                    const uint32_t cnt = (uint32_t)__popc(bits);
+                    const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = lower slot first)
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint32_t pos = qtail + incl - cnt;
+                    uint32_t rest = bits;
+                    while (rest) { // point groups in ascending order = bits from the top
+                        const int hi = 31 - __clz((int)rest);
+                        rest &= ~(1u << hi);
+                        const uint32_t g = (uint32_t)(PG - 1 - hi);
+                        queue[pos & (kMfmaQueueCap - 1)] = (slot << 16) | (g * 32u + (uint32_t)col);
+                        ++pos;
+                    }
+                    qtail += total;
+                    while (qtail - qhead >= 64u)
+                        drain(64u);
+                }
             }
         }
         while (qtail != qhead)
@@ -1116,6 +1343,10 @@ static void score_shape(int est, uint32_t n, bool streaming, uint32_t &chunks, i
     if (P < 1)
         P = 1;
 }
+bool score_uses_mfma(int est, uint32_t n_points, const PrefilterArgs &pf) {
+    static const bool off = std::getenv("POSELIB_AMD_NO_MFMA") != nullptr;
+    return !off && est == EST_ABS && pf.enabled && pf.g16 > 0.f && n_points >= 1024u;
+}
 uint32_t score_chunks(int est, uint32_t n, bool streaming) {
     uint32_t c;
     int P;
@@ -1131,6 +1362,28 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     const bool streaming = a.shadow && a.compact64; // batched main loop: compact hypothesis stream
     score_shape(E, a.pts.n, streaming, chunks, P);
     const dim3 grid(slices, chunks), block(kScoreThreads);
+    if constexpr (E == EST_ABS) {
+        if (streaming && a.shadow16) { // pre-filter on the matrix cores (PG = 2 P groups of 32 points per wave)
+#define PL_M_CASE(PP)                                                                                                  \
+    case PP:                                                                                                           \
+        k_score_mfma<2 * PP><<<grid, block, 0, stream>>>(a.pts, static_cast<const uint2 *>(a.shadow16), a.compact64,   \
+                                                         a.num_hyp, a.hyp_capacity, a.thr2, pf, a.part_count,          \
+                                                         a.part_score);                                                \
+        break;
+            switch (P) {
+                PL_M_CASE(1)
+                PL_M_CASE(2)
+                PL_M_CASE(3)
+                PL_M_CASE(4)
+                PL_M_CASE(5)
+                PL_M_CASE(6)
+            default:
+                return hipErrorInvalidValue;
+            }
+#undef PL_M_CASE
+            return hipGetLastError();
+        }
+    }
     if (streaming) {
 #define PL_Q_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \

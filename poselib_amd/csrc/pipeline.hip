@@ -421,6 +421,95 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
     }
 }
 
+// ------------------------------------------------------------------------------------ fp16 hypothesis operands
+// A-operand blocks of v_mfma_f32_32x32x8_f16 for k_score_mfma (kernels.hip).  One block = 8 hypotheses = 32 rows x 8
+// halfs, stored [k-block 0: rows 0..31, 4 halfs each][k-block 1: rows 0..31] so that lane l of a wave loads its
+// operand (row l % 32, k-block l / 32) with one coalesced 8-byte load.  Hypothesis slot s = k % 8 sits in lane half
+// s & 1, round r = s >> 1 (register pair P = r >> 1, element e = r & 1), rows  z0: b, z2: b + 2, z1: b + 8, W: b + 10
+// with b = 16 P + 4 (s & 1) + e;  row of z_c = (R_c0, R_c1, R_c2, t_c hi | R_c0, R_c1, R_c2, t_c lo), row of
+// W = (0, 0, 0, g | 0, 0, 0, 0) with the hypothesis' slack g = g16 max|t_c| + c16 rounded up to fp16 (pl_prefilter.h;
+// +inf: evaluate every point exactly, -inf: NaN model, no inliers).
+__device__ __forceinline__ unsigned short half_bits_rn(float v) {
+    const _Float16 h = (_Float16)v;
+    unsigned short b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+}
+__device__ __forceinline__ unsigned short half_bits_up(float v) { // v >= 0: smallest fp16 >= v
+    _Float16 h = (_Float16)v;
+    unsigned short b;
+    __builtin_memcpy(&b, &h, 2);
+    if ((float)h < v)
+        b = (unsigned short)(b + 1); // next fp16 above (b < 0x7c00 here; 0x7bff + 1 = +inf)
+    return b;
+}
+__global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const float *__restrict__ shadow,
+                                                  uint32_t capacity8, float g16, float c16, uint2 *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= capacity8)
+        return;
+    const uint32_t H = *num_hyp;
+    if (k >= ((H + 7u) & ~7u))
+        return; // blocks past the last hypothesis are never read
+    const uint32_t s = k & 7u, half = s & 1u, r = s >> 1, P = r >> 1, e = r & 1u;
+    const uint32_t b = 16u * P + 4u * half + e;
+    uint2 *blk = out + (size_t)(k >> 3) * 64; // 512 B = 64 x 8 B
+    const uint32_t rows[4] = {b, b + 8, b + 2, b + 10}; // z0, z1, z2, W
+    float R[9], t[3];
+    float slack; // +inf / -inf / finite
+    if (k >= H) {
+        slack = -__builtin_huge_valf(); // not a hypothesis: never a candidate
+        for (int i = 0; i < 9; ++i)
+            R[i] = 0.f;
+        t[0] = t[1] = t[2] = 0.f;
+    } else {
+        const float *f = shadow + (size_t)k * 16;
+        float rmax = 0.f;
+        for (int i = 0; i < 9; ++i) {
+            R[i] = f[i];
+            rmax = fmaxf(rmax, fabsf(f[i]));
+        }
+        for (int i = 0; i < 3; ++i)
+            t[i] = f[9 + i];
+        const float tmax = f[12];
+        uint32_t nanflag;
+        __builtin_memcpy(&nanflag, &f[13], 4);
+        if (nanflag != 0u) {
+            slack = -__builtin_huge_valf();
+            for (int i = 0; i < 9; ++i)
+                R[i] = 0.f;
+            t[0] = t[1] = t[2] = 0.f;
+        } else if (!(tmax < 3.0e4f) || !(rmax <= 1.0001f)) {
+            slack = __builtin_huge_valf(); // outside what fp16 carries: every point is evaluated exactly
+            for (int i = 0; i < 9; ++i)
+                R[i] = 0.f;
+            t[0] = t[1] = t[2] = 0.f;
+        } else {
+            slack = fmaf(g16, tmax, c16) * 1.000001f + 6.2e-5f; // >= the smallest normal fp16 (no flush to zero)
+        }
+    }
+    unsigned short sb;
+    if (slack == __builtin_huge_valf())
+        sb = 0x7c00;
+    else if (slack == -__builtin_huge_valf())
+        sb = 0xfc00;
+    else
+        sb = half_bits_up(slack);
+    for (int c = 0; c < 3; ++c) {
+        const unsigned short r0 = half_bits_rn(R[3 * c]), r1 = half_bits_rn(R[3 * c + 1]), r2 = half_bits_rn(R[3 * c + 2]);
+        const _Float16 thi = (_Float16)t[c];
+        const _Float16 tlo = (_Float16)(t[c] - (float)thi);
+        unsigned short th, tl;
+        __builtin_memcpy(&th, &thi, 2);
+        __builtin_memcpy(&tl, &tlo, 2);
+        const uint32_t w0 = (uint32_t)r0 | ((uint32_t)r1 << 16);
+        blk[rows[c]] = make_uint2(w0, (uint32_t)r2 | ((uint32_t)th << 16));
+        blk[32 + rows[c]] = make_uint2(w0, (uint32_t)r2 | ((uint32_t)tl << 16));
+    }
+    blk[rows[3]] = make_uint2(0u, (uint32_t)sb << 16);
+    blk[32 + rows[3]] = make_uint2(0u, 0u);
+}
+
 // ------------------------------------------------------------------------------------ front-end pre-processing
 __global__ __launch_bounds__(256) void k_prepare(const double *__restrict__ a_raw, const double *__restrict__ b_raw,
                                                  uint32_t n, PrepareArgs g, double *__restrict__ soa,
@@ -473,6 +562,16 @@ __global__ __launch_bounds__(256) void k_prepare(const double *__restrict__ a_ra
 }
 
 // ------------------------------------------------------------------------------------ launchers
+hipError_t launch_shadow16(const uint32_t *num_hyp, const float *shadow_compact, uint32_t hyp_capacity, float g16,
+                           float c16, void *shadow16, hipStream_t stream) {
+    const uint32_t cap8 = (hyp_capacity + 7u) & ~7u;
+    if (cap8 == 0)
+        return hipSuccess;
+    k_shadow16<<<dim3((cap8 + 255) / 256), dim3(256), 0, stream>>>(num_hyp, shadow_compact, cap8, g16, c16,
+                                                                   static_cast<uint2 *>(shadow16));
+    return hipGetLastError();
+}
+
 hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, const PrepareArgs &args, double *soa,
                           unsigned long long *absmax_bits, hipStream_t stream) {
     if (n == 0)

@@ -48,6 +48,8 @@ struct ScoreArgs {
     const uint32_t *slots;     // hypothesis k -> model record index (nullptr: identity)
     const float *shadow;       // optional compact [num_hyp][16] fp32 model shadows in hypothesis order (pre-filter)
     const double *compact64;   // optional compact [num_hyp][16] fp64 model fields in hypothesis order (pre-filter)
+    const void *shadow16;      // optional fp16 MFMA operand blocks of the hypotheses (absolute pose, k_score_mfma):
+                               // 512 B per 8 hypotheses, see k_shadow16 in pipeline.hip
     const uint32_t *num_hyp;   // device scalar
     uint32_t hyp_capacity;     // row pitch of the partial arrays
     double thr2;
@@ -116,6 +118,11 @@ hipError_t launch_task_records(int est, const LMTask *tasks, const double *recor
                                uint32_t num_tasks, hipStream_t stream);
 hipError_t launch_select_record(const double *score_refined, double incumbent_score, const double *rec_refined,
                                 const double *rec_incumbent, double *out, hipStream_t stream);
+// fp16 A-operand blocks for k_score_mfma from the compact fp32 shadows (absolute pose); capacity = hypotheses rounded
+// up to a multiple of 8, 64 B each.
+hipError_t launch_shadow16(const uint32_t *num_hyp, const float *shadow_compact, uint32_t hyp_capacity, float g16,
+                           float c16, void *shadow16, hipStream_t stream);
+bool score_uses_mfma(int est, uint32_t n_points, const PrefilterArgs &pf);
 size_t lm2_state_bytes(uint32_t num_tasks);
 size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices);
 hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, uint32_t slices,

@@ -28,6 +28,15 @@
 //    so  |C^| > e_C  and  (|C^| - e_C)^2 > thr2 (1 + 64u) D_up  proves an outlier (the 64u absorbs the roundings
 //    of the test itself).  This form needs no absolute values inside the sums and packs two points per
 //    v_pk_* instruction.
+//  * reprojection, fp16 / MFMA form (k_score_mfma): z = R X + t is evaluated by v_mfma_f32_32x32x8_f16 as
+//    rn16(R) (X_hi + X_lo) + (t_hi + t_lo) with X_hi = rn16(X), X_lo = rn16(X - X_hi) (same for t) and fp32
+//    accumulation.  |R_ck| <= 1 gives |rn16(R_ck) - R_ck| <= 2^-12; the hi/lo pairs leave 2^-22 |X| (+ 3e-8 once the
+//    low part is subnormal); the products are exact in fp32 and eight accumulations add <= 2^-21 (|X|_1 + |t_c|):
+//    |z^_c - z_c| <= 2^-12 |X|_1 + 2^-20 (|X|_1 + |t_c|) + 1e-7.  The test  max(|a^0|, |a^1|) > fma(thr^, z^2, W)
+//    with  W = (1 + max|x|,|y| + thr) (2^-11 (|X|_1 + max|t_c|) + 2e-7)  (twice the bound, every factor rounded up)
+//    proves an outlier; the "behind the camera" test is left to the exact pass.  Points or translations beyond 3e4
+//    (fp16 range) and rotation rows that are not unit-bounded get W = +inf (always evaluated exactly), NaN models
+//    W = -inf (never).
 //  * models with a NaN entry have no inliers at all (see store_shadow); models or thresholds outside the range in
 //    which fp32 keeps its relative accuracy (max-abs entry outside [1e-18, 1e18]) get an infinite slack, i.e. every
 //    point is evaluated exactly.
@@ -45,6 +54,8 @@ struct PrefilterArgs {
     float gx;      // absolute pose: 32u (1 + max|x|,|y| + thr), rounded up
     float thr2_up; // Sampson: thr2 (1 + 64u), rounded up
     int enabled;   // 0: exact evaluation of every point
+    float g16;     // absolute pose, fp16 / MFMA form of the filter: 2^-11 (1 + max|x|,|y| + thr), rounded up
+    float c16;     //   and the absolute part 2e-7 (1 + max|x|,|y| + thr)
 };
 
 PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-negative bound upwards
@@ -54,7 +65,7 @@ PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-nega
 // the range fp32 can carry.
 inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) {
     PrefilterArgs a;
-    a.thr = a.gx = a.thr2_up = 0.f;
+    a.thr = a.gx = a.thr2_up = a.g16 = a.c16 = 0.f;
     a.enabled = 0;
     if (!(thr2 >= 1e-30 && thr2 <= 1e30))
         return a;
@@ -65,8 +76,11 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
     const double u = 5.9604644775390625e-08;
     a.thr = nextafterf((float)thr, inf);
     a.thr2_up = nextafterf((float)(thr2 * (1.0 + 64.0 * u)), inf);
-    if (est == 0)
+    if (est == 0) {
         a.gx = nextafterf((float)(32.0 * u * (1.0 + (double)xy_absmax + thr)), inf);
+        a.g16 = nextafterf((float)(4.8828125e-4 * (1.0 + (double)xy_absmax + thr)), inf); // 2^-11
+        a.c16 = nextafterf((float)(2e-7 * (1.0 + (double)xy_absmax + thr)), inf);
+    }
     a.enabled = 1;
     return a;
 }
