@@ -799,7 +799,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores
                 HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
                 HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), (uint32_t)hcap, sa.pf.g16, sa.pf.c16,
-                                        c->shadow16.p, c->stream));
+                                        sa.pf.thr, c->shadow16.p, c->stream));
                 sa.shadow16 = c->shadow16.p;
             }
             sa.shadow = prefilter ? c->shadow.as<float>() : nullptr;

@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4
     __shared__ uint32_t s_acc_c[kWaves][64];
     __shared__ uint32_t s_next_group;
     __shared__ uint2 s_bop[PG][64];  // B operands of the point groups (lane-specific: high / low fp16 parts)
-    __shared__ float4 s_xyw[PG][32]; // fp32 x, y and the point's share of the slack, per column
+    __shared__ float2 s_xy[PG][32];  // fp32 x, y per column
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int col = lane & 31, half = lane >> 5;
@@ -641,13 +641,22 @@ __global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4
             l[d] = (_Float16)(v - (float)h[d]);
         }
         if (wave == 0) {
-            const half4_t b = half ? half4_t{l[0], l[1], l[2], (_Float16)1.0f} : half4_t{h[0], h[1], h[2], (_Float16)1.0f};
+            // the point's share of the slack, rounded up to fp16 (out-of-range points: zero operand + infinite slack =
+            // always evaluated exactly); it rides in the last k slot of the low half
+            const float wv = use ? pf_up(pf.g16 * pf_up((float)n1)) + 6.2e-5f : __builtin_huge_valf();
+            _Float16 wh = (_Float16)wv;
+            if ((float)wh < wv) {
+                unsigned short bits;
+                __builtin_memcpy(&bits, &wh, 2);
+                bits = (unsigned short)(bits + 1);
+                __builtin_memcpy(&wh, &bits, 2);
+            }
+            const half4_t b = half ? half4_t{l[0], l[1], l[2], wh} : half4_t{h[0], h[1], h[2], (_Float16)1.0f};
             uint2 raw;
             __builtin_memcpy(&raw, &b, 8);
             s_bop[g][lane] = raw;
-            if (half == 0) // out-of-range points: zero operand + infinite slack = always evaluated exactly
-                s_xyw[g][col] = make_float4(use ? (float)x[0] : 0.f, use ? (float)x[1] : 0.f,
-                                            use ? pf_up(pf.g16 * pf_up((float)n1)) : __builtin_huge_valf(), 0.f);
+            if (half == 0)
+                s_xy[g][col] = make_float2(use ? (float)x[0] : 0.f, use ? (float)x[1] : 0.f);
         }
         validbits |= valid ? (1u << (PG - 1 - g)) : 0u;
     }
@@ -731,22 +740,20 @@ __global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4
                 half4_t Bop;
                 const uint2 braw = s_bop[g][lane];
                 __builtin_memcpy(&Bop, &braw, 8);
-                const float4 xyw = s_xyw[g][col];
+                const float2 xy = s_xy[g][col];
                 const float16_t D = __builtin_amdgcn_mfma_f32_32x32x8f16(Aop, Bop, kZero, 0, 0, 0);
 #pragma unroll
                 for (int P2 = 0; P2 < 2; ++P2) {
                     const int b = 8 * P2;
                     const v2f z0 = {D[b], D[b + 1]}, z2 = {D[b + 2], D[b + 3]};
-                    const v2f z1 = {D[b + 4], D[b + 5]}, Wt = {D[b + 6], D[b + 7]};
-                    const v2f a0 = pk_fma(bc(-xyw.x), z2, z0);
-                    const v2f a1 = pk_fma(bc(-xyw.y), z2, z1);
-                    const v2f W = Wt + bc(xyw.z);
-                    const v2f Bv = pk_fma(bc(pf.thr), z2, W);
+                    const v2f z1 = {D[b + 4], D[b + 5]}, Bt = {D[b + 6], D[b + 7]}; // Bt = thr z2 + slack
+                    const v2f a0 = pk_fma(bc(-xy.x), z2, z0);
+                    const v2f a1 = pk_fma(bc(-xy.y), z2, z1);
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         // proven outlier <=> max(|a0|, |a1|) > B <=> B - max < 0: the sign bit of the difference
-                        // is shifted into the bit field by one v_alignbit (B is never -0.0: the slack is positive)
-                        const float d = Bv[e] - fmaxf(fabsf(a0[e]), fabsf(a1[e]));
+                        // is shifted into the bit field by one v_alignbit
+                        const float d = Bt[e] - fmaxf(fabsf(a0[e]), fabsf(a1[e]));
                         out[2 * P2 + e] = __builtin_amdgcn_alignbit(out[2 * P2 + e], __float_as_uint(d), 31);
                     }
                 }

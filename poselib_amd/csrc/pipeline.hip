@@ -425,10 +425,14 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
 // A-operand blocks of v_mfma_f32_32x32x8_f16 for k_score_mfma (kernels.hip).  One block = 8 hypotheses = 32 rows x 8
 // halfs, stored [k-block 0: rows 0..31, 4 halfs each][k-block 1: rows 0..31] so that lane l of a wave loads its
 // operand (row l % 32, k-block l / 32) with one coalesced 8-byte load.  Hypothesis slot s = k % 8 sits in lane half
-// s & 1, round r = s >> 1 (register pair P = r >> 1, element e = r & 1), rows  z0: b, z2: b + 2, z1: b + 8, W: b + 10
-// with b = 16 P + 4 (s & 1) + e;  row of z_c = (R_c0, R_c1, R_c2, t_c hi | R_c0, R_c1, R_c2, t_c lo), row of
-// W = (0, 0, 0, g | 0, 0, 0, 0) with the hypothesis' slack g = g16 max|t_c| + c16 rounded up to fp16 (pl_prefilter.h;
-// +inf: evaluate every point exactly, -inf: NaN model, no inliers).
+// s & 1, round r = s >> 1 (register pair P = r >> 1, element e = r & 1), rows  z0: b, z2: b + 2, z1: b + 8, B: b + 10
+// with b = 16 P + 4 (s & 1) + e.  The point operand is (X, Y, Z, 1 | X_lo, Y_lo, Z_lo, w) with w the point's share
+// of the slack, so
+//   row of z_c = (R_c0, R_c1, R_c2, t_c | R_c0, R_c1, R_c2, 0)                         ->  z_c = R_c (X + X_lo) + t_c
+//   row of B   = (thr R_20, thr R_21, thr R_22, thr t_2 + g | thr R_20, thr R_21, thr R_22, 1)  ->  thr z_2 + g + w
+// i.e. the slack-widened threshold of the test comes out of the matrix pipe as well; g = g16 max|t_c| + c16 is the
+// hypothesis' share of the slack (pl_prefilter.h; +inf: evaluate every point exactly, -inf: NaN model, no inliers),
+// and the constant term is rounded UP to fp16.
 __device__ __forceinline__ unsigned short half_bits_rn(float v) {
     const _Float16 h = (_Float16)v;
     unsigned short b;
@@ -444,7 +448,8 @@ __device__ __forceinline__ unsigned short half_bits_up(float v) { // v >= 0: sma
     return b;
 }
 __global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const float *__restrict__ shadow,
-                                                  uint32_t capacity8, float g16, float c16, uint2 *__restrict__ out) {
+                                                  uint32_t capacity8, float g16, float c16, float thr,
+                                                  uint2 *__restrict__ out) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= capacity8)
         return;
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const
     const uint32_t s = k & 7u, half = s & 1u, r = s >> 1, P = r >> 1, e = r & 1u;
     const uint32_t b = 16u * P + 4u * half + e;
     uint2 *blk = out + (size_t)(k >> 3) * 64; // 512 B = 64 x 8 B
-    const uint32_t rows[4] = {b, b + 8, b + 2, b + 10}; // z0, z1, z2, W
+    const uint32_t rows[4] = {b, b + 8, b + 2, b + 10}; // z0, z1, z2, B
     float R[9], t[3];
     float slack; // +inf / -inf / finite
     if (k >= H) {
@@ -485,29 +490,40 @@ __global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const
                 R[i] = 0.f;
             t[0] = t[1] = t[2] = 0.f;
         } else {
-            slack = fmaf(g16, tmax, c16) * 1.000001f + 6.2e-5f; // >= the smallest normal fp16 (no flush to zero)
+            slack = fmaf(g16, tmax, c16) * 1.000001f + 6.2e-5f;
         }
     }
-    unsigned short sb;
-    if (slack == __builtin_huge_valf())
-        sb = 0x7c00;
-    else if (slack == -__builtin_huge_valf())
-        sb = 0xfc00;
-    else
-        sb = half_bits_up(slack);
     for (int c = 0; c < 3; ++c) {
         const unsigned short r0 = half_bits_rn(R[3 * c]), r1 = half_bits_rn(R[3 * c + 1]), r2 = half_bits_rn(R[3 * c + 2]);
-        const _Float16 thi = (_Float16)t[c];
-        const _Float16 tlo = (_Float16)(t[c] - (float)thi);
-        unsigned short th, tl;
-        __builtin_memcpy(&th, &thi, 2);
-        __builtin_memcpy(&tl, &tlo, 2);
+        const unsigned short th = half_bits_rn(t[c]);
         const uint32_t w0 = (uint32_t)r0 | ((uint32_t)r1 << 16);
         blk[rows[c]] = make_uint2(w0, (uint32_t)r2 | ((uint32_t)th << 16));
-        blk[32 + rows[c]] = make_uint2(w0, (uint32_t)r2 | ((uint32_t)tl << 16));
+        blk[32 + rows[c]] = make_uint2(w0, (uint32_t)r2);
     }
-    blk[rows[3]] = make_uint2(0u, (uint32_t)sb << 16);
-    blk[32 + rows[3]] = make_uint2(0u, 0u);
+    {
+        const unsigned short r0 = half_bits_rn(thr * R[6]), r1 = half_bits_rn(thr * R[7]), r2 = half_bits_rn(thr * R[8]);
+        unsigned short cb;
+        if (slack == __builtin_huge_valf())
+            cb = 0x7c00;
+        else if (slack == -__builtin_huge_valf())
+            cb = 0xfc00;
+        else { // constant term thr t_2 + g, rounded up (it may be negative: round towards +inf)
+            const float cval = fmaf(thr, t[2], slack);
+            _Float16 h = (_Float16)cval;
+            if ((float)h < cval) { // next fp16 above
+                unsigned short bits;
+                __builtin_memcpy(&bits, &h, 2);
+                bits = (bits & 0x8000u) ? (unsigned short)(bits - 1) : (unsigned short)(bits + 1);
+                if (bits == 0x8000u)
+                    bits = 0; // -0 -> +0
+                __builtin_memcpy(&h, &bits, 2);
+            }
+            __builtin_memcpy(&cb, &h, 2);
+        }
+        const uint32_t w0 = (uint32_t)r0 | ((uint32_t)r1 << 16);
+        blk[rows[3]] = make_uint2(w0, (uint32_t)r2 | ((uint32_t)cb << 16));
+        blk[32 + rows[3]] = make_uint2(w0, (uint32_t)r2 | (0x3c00u << 16)); // k7 = 1.0
+    }
 }
 
 // ------------------------------------------------------------------------------------ front-end pre-processing
@@ -563,11 +579,11 @@ __global__ __launch_bounds__(256) void k_prepare(const double *__restrict__ a_ra
 
 // ------------------------------------------------------------------------------------ launchers
 hipError_t launch_shadow16(const uint32_t *num_hyp, const float *shadow_compact, uint32_t hyp_capacity, float g16,
-                           float c16, void *shadow16, hipStream_t stream) {
+                           float c16, float thr, void *shadow16, hipStream_t stream) {
     const uint32_t cap8 = (hyp_capacity + 7u) & ~7u;
     if (cap8 == 0)
         return hipSuccess;
-    k_shadow16<<<dim3((cap8 + 255) / 256), dim3(256), 0, stream>>>(num_hyp, shadow_compact, cap8, g16, c16,
+    k_shadow16<<<dim3((cap8 + 255) / 256), dim3(256), 0, stream>>>(num_hyp, shadow_compact, cap8, g16, c16, thr,
                                                                    static_cast<uint2 *>(shadow16));
     return hipGetLastError();
 }

@@ -121,7 +121,7 @@ hipError_t launch_select_record(const double *score_refined, double incumbent_sc
 // fp16 A-operand blocks for k_score_mfma from the compact fp32 shadows (absolute pose); capacity = hypotheses rounded
 // up to a multiple of 8, 64 B each.
 hipError_t launch_shadow16(const uint32_t *num_hyp, const float *shadow_compact, uint32_t hyp_capacity, float g16,
-                           float c16, void *shadow16, hipStream_t stream);
+                           float c16, float thr, void *shadow16, hipStream_t stream);
 bool score_uses_mfma(int est, uint32_t n_points, const PrefilterArgs &pf);
 size_t lm2_state_bytes(uint32_t num_tasks);
 size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices);

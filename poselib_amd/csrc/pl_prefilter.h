@@ -28,15 +28,18 @@
 //    so  |C^| > e_C  and  (|C^| - e_C)^2 > thr2 (1 + 64u) D_up  proves an outlier (the 64u absorbs the roundings
 //    of the test itself).  This form needs no absolute values inside the sums and packs two points per
 //    v_pk_* instruction.
-//  * reprojection, fp16 / MFMA form (k_score_mfma): z = R X + t is evaluated by v_mfma_f32_32x32x8_f16 as
-//    rn16(R) (X_hi + X_lo) + (t_hi + t_lo) with X_hi = rn16(X), X_lo = rn16(X - X_hi) (same for t) and fp32
-//    accumulation.  |R_ck| <= 1 gives |rn16(R_ck) - R_ck| <= 2^-12; the hi/lo pairs leave 2^-22 |X| (+ 3e-8 once the
-//    low part is subnormal); the products are exact in fp32 and eight accumulations add <= 2^-21 (|X|_1 + |t_c|):
-//    |z^_c - z_c| <= 2^-12 |X|_1 + 2^-20 (|X|_1 + |t_c|) + 1e-7.  The test  max(|a^0|, |a^1|) > fma(thr^, z^2, W)
-//    with  W = (1 + max|x|,|y| + thr) (2^-11 (|X|_1 + max|t_c|) + 2e-7)  (twice the bound, every factor rounded up)
-//    proves an outlier; the "behind the camera" test is left to the exact pass.  Points or translations beyond 3e4
-//    (fp16 range) and rotation rows that are not unit-bounded get W = +inf (always evaluated exactly), NaN models
-//    W = -inf (never).
+//  * reprojection, fp16 / MFMA form (k_score_mfma): v_mfma_f32_32x32x8_f16 evaluates, with fp32 accumulation,
+//        z^_c = rn16(R_c) (X_hi + X_lo) + rn16(t_c)          X_hi = rn16(X), X_lo = rn16(X - X_hi)
+//        B^   = rn16(thr R_2) (X_hi + X_lo) + up16(thr t_2 + g) + up16(w)
+//    |R_ck| <= 1 gives |rn16(R_ck) - R_ck| <= 2^-12 and |rn16(t_c) - t_c| <= 2^-12 |t_c|; the hi/lo pair leaves
+//    2^-22 |X| (+ 3e-8 once the low part is subnormal); products are exact in fp32 and eight accumulations add
+//    <= 2^-21 (|X|_1 + |t_c|):  |z^_c - z_c| <= 2^-12 (|X|_1 + |t_c|) (1 + 2^-8) + 1e-7,  hence
+//    |a^ - a| <= (1 + |x|) of that for a^ = fl(z^0 - x z^2) (fp32, exact x), and B^ >= thr z_2 - 2^-11 thr |X|_1
+//    + g + w.  With  g = G max|t_c| + c,  w = G |X|_1,  G = 2^-11 (1 + max|x|,|y| + thr),  c = 2e-7 (1 + max|x|,|y|
+//    + thr) + 6e-5 (every factor rounded up) the slack is twice the error of a^ plus the error of B^ itself, so
+//    max(|a^0|, |a^1|) > B^  proves an outlier; the "behind the camera" test is left to the exact pass.  Points or
+//    translations beyond 3e4 (fp16 range) and rotation rows that are not unit-bounded get an infinite slack
+//    (always evaluated exactly), NaN models -inf (never).
 //  * models with a NaN entry have no inliers at all (see store_shadow); models or thresholds outside the range in
 //    which fp32 keeps its relative accuracy (max-abs entry outside [1e-18, 1e18]) get an infinite slack, i.e. every
 //    point is evaluated exactly.
