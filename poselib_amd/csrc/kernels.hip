@@ -641,9 +641,11 @@ __global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4
             l[d] = (_Float16)(v - (float)h[d]);
         }
         if (wave == 0) {
-            // the point's share of the slack, rounded up to fp16 (out-of-range points: zero operand + infinite slack =
-            // always evaluated exactly); it rides in the last k slot of the low half
-            const float wv = use ? pf_up(pf.g16 * pf_up((float)n1)) + 6.2e-5f : __builtin_huge_valf();
+            // the point's share of the slack, rounded up to fp16; it rides in the last k slot of the low half
+            // (out-of-range points: zero operand and the largest finite fp16, not +inf - an infinite entry would turn the z rows, whose
+            // matching k slot is 0, into NaN; 65504 exceeds every |a| a zero point operand can produce, since
+            // hypotheses with |t| >= 3e4 carry an infinite slack of their own and thr <= 1 on this path)
+            const float wv = use ? fminf(pf_up(pf.g16 * pf_up((float)n1)) + 6.2e-5f, 65504.f) : 65504.f;
             _Float16 wh = (_Float16)wv;
             if ((float)wh < wv) {
                 unsigned short bits;
@@ -1352,7 +1354,7 @@ static void score_shape(int est, uint32_t n, bool streaming, uint32_t &chunks, i
 }
 bool score_uses_mfma(int est, uint32_t n_points, const PrefilterArgs &pf) {
     static const bool off = std::getenv("POSELIB_AMD_NO_MFMA") != nullptr;
-    return !off && est == EST_ABS && pf.enabled && pf.g16 > 0.f && n_points >= 1024u;
+    return !off && est == EST_ABS && pf.enabled && pf.g16 > 0.f && pf.thr <= 1.0f && n_points >= 1024u;
 }
 uint32_t score_chunks(int est, uint32_t n, bool streaming) {
     uint32_t c;

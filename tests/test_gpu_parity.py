@@ -195,6 +195,57 @@ def test_prefilter_never_drops_an_inlier(gpu):
         prob.close()
 
 
+def test_streaming_filters_do_not_change_any_result(gpu):
+    """The main-loop scorers (fp16 / MFMA filter for absolute pose, fp32 filters for the two-view scores) against the
+    same runs with the filters switched off (POSELIB_AMD_NO_PREFILTER=1: every pair evaluated exactly) and with the
+    fp32 filter instead of the MFMA one (POSELIB_AMD_NO_MFMA=1): iterations, refinements, inlier counts, masks AND
+    the final MSAC score must be bit-identical - the filters only remove exact evaluations of proven non-inliers.
+    Scenes include a world frame shifted by 1e5 (beyond fp16: the MFMA path must fall back to exact evaluation per
+    point), tiny and huge thresholds.  The settings are read once per process, hence subprocesses."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+import poselib_amd as P
+from poselib_amd import synth
+out = []
+def rec(info, model):
+    out.append([info["iterations"], info["refinements"], info["num_inliers"], repr(info["model_score"]),
+                int(np.packbits(np.array(info["inliers"], dtype=np.uint8)).sum()), [repr(float(v)) for v in np.ravel(model)]])
+for seed, n, outl, err, shift in ((1, 5000, 0.7, 12.0, 0.0), (2, 3000, 0.4, 1.0, 0.0), (3, 2000, 0.5, 200.0, 0.0),
+                                  (4, 4000, 0.6, 12.0, 1e5), (5, 1500, 0.2, 0.05, 0.0)):
+    d = synth.absolute_pose_scene(n, outl, 900 + seed)
+    par = d["camera"]["params"]
+    x = (d["p2d"] - par[-2:]) / par[0]
+    X = d["p3d"] + np.array([shift, -shift, 0.5 * shift])
+    pose, info = P.ransac_pnp(x, X, {"max_error": err / par[0], "ransac": {"seed": seed, "max_iterations": 6000, "min_iterations": 6000}})
+    rec(info, np.r_[pose.q, pose.t])
+for seed, gen, fn in ((6, synth.relative_pose_scene, P.ransac_relpose), (7, synth.fundamental_scene, P.ransac_fundamental),
+                      (8, synth.homography_scene, P.ransac_homography)):
+    d = gen(4000, 0.5, 900 + seed)
+    x1, x2 = (d["x1"] - 500.0) / 1000.0, (d["x2"] - 500.0) / 1000.0
+    for err in (1e-3, 3e-2):
+        m, info = fn(x1, x2, {"max_error": err, "ransac": {"seed": seed, "max_iterations": 3000, "min_iterations": 3000}})
+        rec(info, np.r_[m.q, m.t] if hasattr(m, "q") else m)
+print("RESULT " + json.dumps(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = {}
+    for tag, extra in (("mfma", {}), ("fp32", {"POSELIB_AMD_NO_MFMA": "1"}), ("exact", {"POSELIB_AMD_NO_PREFILTER": "1"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        results[tag] = json.loads(line[7:])
+    assert results["mfma"] == results["exact"]
+    assert results["fp32"] == results["exact"]
+    assert all(row[2] > 100 for row in results["exact"][:3])  # the runs found their models
+
+
 # ------------------------------------------------------------------------------------------ end to end
 ABS_CASES = [(200, 0.5, 1000, 0), (200, 0.5, 1000, 7), (5000, 0.7, 1001, 0), (5000, 0.7, 1001, 3), (1500, 0.3, 77, 1)]
 
