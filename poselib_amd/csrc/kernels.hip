@@ -7,9 +7,12 @@
 //   k_generate<EST>       one LANE per RANSAC iteration: counter-based sample draw (or explicit PROSAC sample), minimal
 //                         solve entirely in registers (P3P / 5-pt / 7-pt / 4-pt H), model records (192 B incl. fp32
 //                         shadow) written to HBM.  (reference: estimators/*::generate_models)
-//   k_score_queue<EST,P>  THE hot kernel: streaming scorer of the batched main loop - conservative fp32 pre-filter on
-//                         register-resident points, survivors queued in LDS and evaluated exactly in fp64 by full
-//                         wavefronts.  (reference: utils.cc compute_*_msac_score)
+//   k_score_mfma<PG>      THE hot kernel (absolute pose): streaming scorer of the batched main loop - conservative
+//                         pre-filter with R X + t on the matrix cores (v_mfma_f32_32x32x8_f16, fp16 hi/lo operands,
+//                         8 hypotheses x 32 points per tile), survivors queued in LDS and evaluated exactly in fp64 by
+//                         full wavefronts.  (reference: utils.cc compute_msac_score)
+//   k_score_queue<EST,P>  the same with an fp32 pre-filter on the vector ALU: Sampson and homography scores, and the
+//                         absolute-pose fallback (small N, out-of-range thresholds).
 //   k_score<EST,P>        exact scorer for the handful of refined / initial models (no filter, 256 * P points per
 //                         chunk, hypotheses as wave-uniform records in SGPRs), k_finalize adds its chunk partials.
 //   k_lm<EST>             Levenberg-Marquardt refinement, ONE workgroup (8 wavefronts) per task, the whole LM loop on
@@ -17,7 +20,8 @@
 //                         half-step (opt-in latency mode).  (reference: bundle.cc + optim/lm_impl.h + optim/*.h)
 //   k_mask<EST>           final inlier mask (reference: utils.cc get_inliers*).
 //   k_solve_batch<EST>    the bare minimal solvers, one lane per problem.
-// MFMA is not used: there is no dense contraction in this path.
+// Exact arithmetic (fp64, reference association order) never runs on the matrix cores; only the filter's projection
+// products do.
 #include "pl_kernels.h"
 #include "pl_prefilter.h"
 #include <cstdlib>
