@@ -649,7 +649,7 @@ __global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4
             // (out-of-range points: zero operand and the largest finite fp16, not +inf - an infinite entry would turn the z rows, whose
             // matching k slot is 0, into NaN; 65504 exceeds every |a| a zero point operand can produce, since
             // hypotheses with |t| >= 3e4 carry an infinite slack of their own and thr <= 1 on this path)
-            const float wv = use ? fminf(pf_up(pf.g16 * pf_up((float)n1)) + 6.2e-5f, 65504.f) : 65504.f;
+            const float wv = use ? fminf(pf_up(pf.g16 * pf_up((float)n1)) + 1.3e-4f, 65504.f) : 65504.f;
             _Float16 wh = (_Float16)wv;
             if ((float)wh < wv) {
                 unsigned short bits;

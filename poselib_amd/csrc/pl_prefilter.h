@@ -35,8 +35,10 @@
 //    2^-22 |X| (+ 3e-8 once the low part is subnormal); products are exact in fp32 and eight accumulations add
 //    <= 2^-21 (|X|_1 + |t_c|):  |z^_c - z_c| <= 2^-12 (|X|_1 + |t_c|) (1 + 2^-8) + 1e-7,  hence
 //    |a^ - a| <= (1 + |x|) of that for a^ = fl(z^0 - x z^2) (fp32, exact x), and B^ >= thr z_2 - 2^-11 thr |X|_1
-//    + g + w.  With  g = G max|t_c| + c,  w = G |X|_1,  G = 2^-11 (1 + max|x|,|y| + thr),  c = 2e-7 (1 + max|x|,|y|
-//    + thr) + 6e-5 (every factor rounded up) the slack is twice the error of a^ plus the error of B^ itself, so
+//    + g + w.  With  g = G max|t_c| + c,  w = G |X|_1 + 1.3e-4,  G = 2^-11 (1 + max|x|,|y| + thr),  c = 2.5e-4 (1 +
+//    max|x|,|y| + thr) + 6e-5 (every factor rounded up; the absolute parts also cover fp16 subnormal inputs - X_lo
+//    below |X| = 0.25, small t, small thr R_2 - being flushed to zero by the matrix pipe) the slack is twice the
+//    error of a^ plus the error of B^ itself, so
 //    max(|a^0|, |a^1|) > B^  proves an outlier; the "behind the camera" test is left to the exact pass.  Points or
 //    translations beyond 3e4 (fp16 range) and rotation rows that are not unit-bounded get an infinite slack
 //    (always evaluated exactly), NaN models -inf (never).
@@ -58,7 +60,7 @@ struct PrefilterArgs {
     float thr2_up; // Sampson: thr2 (1 + 64u), rounded up
     int enabled;   // 0: exact evaluation of every point
     float g16;     // absolute pose, fp16 / MFMA form of the filter: 2^-11 (1 + max|x|,|y| + thr), rounded up
-    float c16;     //   and the absolute part 2e-7 (1 + max|x|,|y| + thr)
+    float c16;     //   and the absolute part (2e-7 + 2.5e-4) (1 + max|x|,|y| + thr)
 };
 
 PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-negative bound upwards
@@ -82,7 +84,9 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
     if (est == 0) {
         a.gx = nextafterf((float)(32.0 * u * (1.0 + (double)xy_absmax + thr)), inf);
         a.g16 = nextafterf((float)(4.8828125e-4 * (1.0 + (double)xy_absmax + thr)), inf); // 2^-11
-        a.c16 = nextafterf((float)(2e-7 * (1.0 + (double)xy_absmax + thr)), inf);
+        // 2e-7: fp32 accumulation; 2.5e-4: four fp16 inputs per row (X_lo, t) may be subnormal, i.e. below 6.1e-5 - the
+        // bound holds even if the matrix pipe flushes them to zero
+        a.c16 = nextafterf((float)((2e-7 + 2.5e-4) * (1.0 + (double)xy_absmax + thr)), inf);
     }
     a.enabled = 1;
     return a;

@@ -201,7 +201,7 @@ def test_streaming_filters_do_not_change_any_result(gpu):
     fp32 filter instead of the MFMA one (POSELIB_AMD_NO_MFMA=1): iterations, refinements, inlier counts, masks AND
     the final MSAC score must be bit-identical - the filters only remove exact evaluations of proven non-inliers.
     Scenes include a world frame shifted by 1e5 (beyond fp16: the MFMA path must fall back to exact evaluation per
-    point), tiny and huge thresholds.  The settings are read once per process, hence subprocesses."""
+    point), worlds scaled by 1e-2 / 1e-4 (fp16 subnormal operands), tiny and huge thresholds.  The settings are read once per process, hence subprocesses."""
     import json
     import os
     import subprocess
@@ -216,12 +216,13 @@ out = []
 def rec(info, model):
     out.append([info["iterations"], info["refinements"], info["num_inliers"], repr(info["model_score"]),
                 int(np.packbits(np.array(info["inliers"], dtype=np.uint8)).sum()), [repr(float(v)) for v in np.ravel(model)]])
-for seed, n, outl, err, shift in ((1, 5000, 0.7, 12.0, 0.0), (2, 3000, 0.4, 1.0, 0.0), (3, 2000, 0.5, 200.0, 0.0),
-                                  (4, 4000, 0.6, 12.0, 1e5), (5, 1500, 0.2, 0.05, 0.0)):
+for seed, n, outl, err, shift, scale in ((1, 5000, 0.7, 12.0, 0.0, 1.0), (2, 3000, 0.4, 1.0, 0.0, 1.0), (3, 2000, 0.5, 200.0, 0.0, 1.0),
+                                         (4, 4000, 0.6, 12.0, 1e5, 1.0), (5, 1500, 0.2, 0.05, 0.0, 1.0),
+                                         (9, 3000, 0.5, 2.0, 0.0, 0.01), (10, 3000, 0.5, 12.0, 0.0, 1e-4)):
     d = synth.absolute_pose_scene(n, outl, 900 + seed)
     par = d["camera"]["params"]
     x = (d["p2d"] - par[-2:]) / par[0]
-    X = d["p3d"] + np.array([shift, -shift, 0.5 * shift])
+    X = d["p3d"] * scale + np.array([shift, -shift, 0.5 * shift])
     pose, info = P.ransac_pnp(x, X, {"max_error": err / par[0], "ransac": {"seed": seed, "max_iterations": 6000, "min_iterations": 6000}})
     rec(info, np.r_[pose.q, pose.t])
 for seed, gen, fn in ((6, synth.relative_pose_scene, P.ransac_relpose), (7, synth.fundamental_scene, P.ransac_fundamental),
