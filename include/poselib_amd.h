@@ -41,6 +41,7 @@ extern "C" {
 #define PL_ERR_HIP (-2)
 #define PL_ERR_INVALID (-3)
 #define PL_ERR_UNSUPPORTED (-4)
+#define PL_ERR_COMM (-5) /* the caller's all-gather callback failed (pl_ransac_run_sharded) */
 
 /* types.h:39-50 */
 typedef struct {
@@ -159,6 +160,24 @@ int pl_problem_create(int kind, const double *a, const double *b, size_t n, pl_p
 void pl_problem_destroy(pl_problem *p);
 /* model: pl_camera_pose for kinds 0/1, double[9] column-major for kinds 2/3 */
 int pl_ransac_run(pl_problem *p, const pl_robust_options *opt, void *model, uint8_t *inliers, pl_ransac_stats *stats);
+
+/* ---- ONE problem across several GPUs: every rank holds the same correspondences (its own pl_problem on
+ * its own device) and calls pl_ransac_run_sharded with the same options.  Each batch of iterations is cut into `world`
+ * contiguous ranges; a rank draws the whole batch's sample positions (integer work, replicated) but generates and
+ * scores only its range.  ONE exchange step per batch: the ranks all-gather their improving hypotheses (<= 7 KB per
+ * rank, a second message only when a rank has more than 32 of them); every rank then replays the sequential loop of
+ * ransac_impl.h:157-201 on the merged list - including the local optimisations, which are replicated - so all
+ * ranks return the same model, mask and stats, identical to the single-device run.  `allgather` is the caller's
+ * collective (RCCL / gloo through torch.distributed, MPI, or shared memory between threads): it must copy `bytes` bytes
+ * from `send` of rank r to `recv + r * bytes` on every rank, and return 0. */
+typedef int (*pl_allgather_fn)(void *user, const void *send, void *recv, size_t bytes);
+typedef struct pl_shard {
+    int32_t rank, world;
+    pl_allgather_fn allgather;
+    void *user;
+} pl_shard;
+int pl_ransac_run_sharded(pl_problem *p, const pl_robust_options *opt, const pl_shard *shard, void *model,
+                          uint8_t *inliers, pl_ransac_stats *stats);
 
 /* Score one model against the resident correspondences with the estimator's MSAC score
  * (robust/utils.cc:36-65, 158-239, 300-329 through estimators' score_model()).  model as in pl_ransac_run. */

@@ -61,6 +61,13 @@ BatchItem._fields_ = [("kind", i32), ("status", i32), ("a", C.c_void_p), ("b", C
                       ("model", C.c_void_p), ("inliers", C.c_void_p), ("stats", C.POINTER(RansacStats))]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class Shard(C.Structure):  # pl_shard
+    _fields_ = [("rank", i32), ("world", i32), ("allgather", ALLGATHER_FN), ("user", C.c_void_p)]
+
+
 class PoseLibAmdError(RuntimeError):
     pass
 
@@ -107,6 +114,6 @@ EXPORTED_SYMBOLS = [
     "pl_default_ransac_options", "pl_default_bundle_options", "pl_default_robust_options", "pl_device_count",
     "pl_set_device", "pl_last_error", "pl_version", "pl_estimate_absolute_pose", "pl_estimate_relative_pose",
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
-    "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_score_model", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
+    "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch",
 ]

@@ -343,6 +343,43 @@ class Problem:
         L.check(L.lib().pl_ransac_run(self._h, C.byref(o), _ptr(M), _ptr(inl), C.byref(st)))
         return M.reshape(3, 3).T.copy(), _info(st, inl[: self.n])
 
+    def run_sharded(self, opt, rank: int, world: int, allgather, initial=None):
+        """ONE problem across `world` GPUs (pl_ransac_run_sharded): every rank holds the same correspondences in its
+        own Problem on its own device and calls this with the same options; each evaluates a contiguous share of every
+        batch of iterations, and `allgather(send: bytes-like numpy uint8 array, recv: numpy uint8 array of world *
+        len(send))` is the one exchange step per batch (see poselib_amd.sharding.dist_allgather for the
+        torch.distributed form).  All ranks return the same result - the single-device one."""
+        o = _robust_options(opt, self.kind, initial is not None)
+        inl = np.zeros(max(self.n, 1), dtype=np.uint8)
+        st = L.RansacStats()
+        errors = []
+
+        def _cb(_user, send, recv, nbytes):
+            try:
+                s_arr = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                r_arr = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+                allgather(s_arr, r_arr)
+                return 0
+            except Exception as e:  # surfaces as PL_ERR_COMM
+                errors.append(e)
+                return 1
+
+        cb = L.ALLGATHER_FN(_cb)
+        shard = L.Shard(rank, world, cb, None)
+        if self.kind in (KIND_ABS, KIND_REL):
+            model = _cpose(initial if initial is not None else CameraPose())
+            rc = L.lib().pl_ransac_run_sharded(self._h, C.byref(o), C.byref(shard), C.byref(model), _ptr(inl), C.byref(st))
+            if rc and errors:
+                raise errors[0]
+            L.check(rc)
+            return _pypose(model), _info(st, inl[: self.n])
+        M = np.ascontiguousarray((np.eye(3) if initial is None else np.asarray(initial, dtype=np.float64)).T.reshape(9))
+        rc = L.lib().pl_ransac_run_sharded(self._h, C.byref(o), C.byref(shard), _ptr(M), _ptr(inl), C.byref(st))
+        if rc and errors:
+            raise errors[0]
+        L.check(rc)
+        return M.reshape(3, 3).T.copy(), _info(st, inl[: self.n])
+
     def score(self, model, max_error):
         """MSAC score + inlier count of one model (the estimators' score_model())."""
         cnt = C.c_uint64(0)

@@ -72,23 +72,33 @@ struct DevBuf {
     }
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
-struct HostBuf { // pinned
+struct HostBuf { // pinned and mapped: kernels write their small results here themselves (no copy dispatch); the
+                 // host reads them after the stream synchronisation that follows
     void *p = nullptr;
+    void *dp = nullptr; // the same memory as the device addresses it
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap)
             return hipSuccess;
         if (p)
             (void)hipHostFree(p);
-        p = nullptr;
+        p = dp = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e == hipSuccess)
-            cap = want;
-        return e;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
+        if (e != hipSuccess)
+            return e;
+        e = hipHostGetDevicePointer(&dp, p, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(p);
+            p = dp = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
     }
     template <typename T> T *as() const { return static_cast<T *>(p); }
+    template <typename T> T *dev() const { return static_cast<T *>(dp); }
 };
 
 struct Context {
@@ -96,18 +106,21 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // batch scratch
-    DevBuf positions, samples, shadow16, lm_records_in, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
+    DevBuf positions, samples, shadow16, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
     DevBuf shadow, compact64;
     DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
+    DevBuf iota; // iota[i] = i: a device-resident "number of hypotheses" for launches whose count the host knows
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
     HostBuf h_rec_meta;
-    HostBuf h_absmax, h_positions, h_num_models, h_count, h_score, h_tasks, h_records, h_gather_idx, h_gather_out, h_mask,
+    HostBuf h_absmax, h_positions, h_num_models, h_count, h_score, h_tasks, h_gather_idx, h_gather_out, h_mask,
         h_small;
 };
 
+constexpr uint32_t kIotaEntries = 4097;
 thread_local Context *g_ctx = nullptr;
 
 thread_local int g_requested_device = 0;
+thread_local const pl_shard *g_shard = nullptr; // set around ransac_core by pl_ransac_run_sharded
 
 int get_context(Context **out) {
     int ndev = 0;
@@ -128,6 +141,13 @@ int get_context(Context **out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    {
+        std::vector<uint32_t> iota(kIotaEntries);
+        for (uint32_t i = 0; i < kIotaEntries; ++i)
+            iota[i] = i;
+        HIP_TRY(c->iota.ensure(sizeof(uint32_t) * kIotaEntries));
+        HIP_TRY(hipMemcpy(c->iota.p, iota.data(), sizeof(uint32_t) * kIotaEntries, hipMemcpyHostToDevice));
+    }
     g_ctx = c;
     *out = c;
     return PL_OK;
@@ -444,7 +464,9 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     HIP_TRY(c->score.ensure(sizeof(double) * nrec));
     HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * nrec));
     HIP_TRY(c->h_score.ensure(sizeof(double) * nrec));
-    HIP_TRY(hipMemcpyAsync(c->num_hyp.p, &nrec, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    const bool counted = nrec < kIotaEntries; // the count is read from the device-resident table: no upload
+    if (!counted)
+        HIP_TRY(hipMemcpyAsync(c->num_hyp.p, &nrec, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     sa.pts = p->ps;
     sa.models = d_records;
     sa.slots = nullptr;
@@ -452,7 +474,7 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     sa.shadow16 = nullptr;
     sa.compact64 = nullptr;
 
-    sa.num_hyp = c->num_hyp.as<uint32_t>();
+    sa.num_hyp = counted ? c->iota.as<uint32_t>() + nrec : c->num_hyp.as<uint32_t>();
     sa.hyp_capacity = nrec;
     sa.thr2 = thr2;
     sa.part_count = c->part_count.as<uint32_t>();
@@ -469,9 +491,9 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     fa.part_score = sa.part_score;
     fa.count = c->count.as<uint32_t>();
     fa.score = c->score.as<double>();
+    fa.host_count = c->h_count.dev<uint32_t>(); // k_finalize writes the pinned copies itself
+    fa.host_score = c->h_score.dev<double>();
     HIP_TRY(launch_finalize(fa, nrec, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_count.p, c->count.p, sizeof(uint32_t) * nrec, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_score.p, c->score.p, sizeof(double) * nrec, hipMemcpyDeviceToHost, c->stream));
     return PL_OK;
 }
 
@@ -510,14 +532,16 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     const uint32_t nj = (uint32_t)jobs.size();
     if (nj == 0)
         return PL_OK;
-    HIP_TRY(c->h_tasks.ensure(sizeof(LMTask) * nj));
-    HIP_TRY(c->lm_tasks.ensure(sizeof(LMTask) * nj));
+    // one staging block, one upload: [LMTask x nj][seed records x nj (+ the incumbent's record)]
+    static_assert(sizeof(LMTask) % sizeof(double) == 0, "records follow the tasks");
+    const size_t stage_bytes = sizeof(LMTask) * nj + sizeof(double) * kModelStride * (nj + 1);
+    HIP_TRY(c->h_tasks.ensure(stage_bytes));
+    HIP_TRY(c->lm_tasks.ensure(stage_bytes));
     HIP_TRY(c->lm_scratch.ensure((size_t)p->n * nj + 16));
-    HIP_TRY(c->h_records.ensure(sizeof(double) * kModelStride * (nj + 1)));
-    HIP_TRY(c->lm_records_in.ensure(sizeof(double) * kModelStride * (nj + 1)));
     HIP_TRY(c->lm_records.ensure(sizeof(double) * kModelStride * nj));
     LMTask *ht = c->h_tasks.as<LMTask>();
-    double *hr = c->h_records.as<double>();
+    double *hr = reinterpret_cast<double *>(ht + nj);
+    double *d_records_in = reinterpret_cast<double *>(c->lm_tasks.as<LMTask>() + nj);
     for (uint32_t j = 0; j < nj; ++j) {
         LMTask &t = ht[j];
         std::memset(&t, 0, sizeof(t));
@@ -532,9 +556,7 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     }
     if (tail)
         std::memcpy(hr + (size_t)nj * kModelStride, tail->incumbent_rec, sizeof(double) * kModelStride);
-    HIP_TRY(hipMemcpyAsync(c->lm_tasks.p, ht, sizeof(LMTask) * nj, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->lm_records_in.p, hr, sizeof(double) * kModelStride * (nj + (tail ? 1 : 0)),
-                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->lm_tasks.p, ht, stage_bytes, hipMemcpyHostToDevice, c->stream));
     // Large point sets with 6..8 parameters saturate the single CU k_lm gives a task: spread every task over several
     // workgroups (k_lm2).  Only for short, bounded runs (the LO: 25 iterations) - k_lm2 costs 2 * max_iterations + 3
     // launches whatever the iteration count turns out to be.
@@ -560,9 +582,10 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     } else {
         HIP_TRY(launch_lm(p->kind, p->ps, c->lm_tasks.as<LMTask>(), nj, c->stream));
     }
-    HIP_TRY(launch_task_records(p->kind, c->lm_tasks.as<LMTask>(), c->lm_records_in.as<double>(),
-                                c->lm_records.as<double>(), nj, c->stream));
-    HIP_TRY(hipMemcpyAsync(ht, c->lm_tasks.p, sizeof(LMTask) * nj, hipMemcpyDeviceToHost, c->stream));
+    // (k_task_records also writes the tasks' outputs into the pinned staging block: stream order puts that after the
+    // upload above has read it)
+    HIP_TRY(launch_task_records(p->kind, c->lm_tasks.as<LMTask>(), d_records_in, c->lm_records.as<double>(), nj,
+                                c->h_tasks.dev<LMTask>(), c->stream));
     if (rescore || tail) {
         int rc = enqueue_score_records(c, p, c->lm_records.as<double>(), nj, tail ? tail->thr2 : thr2, false);
         if (rc != PL_OK)
@@ -572,7 +595,7 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         HIP_TRY(c->mask.ensure(std::max<uint32_t>(p->n, 1u)));
         HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
         HIP_TRY(launch_select_record(c->score.as<double>(), tail->incumbent_score, c->lm_records.as<double>(),
-                                     c->lm_records_in.as<double>() + (size_t)nj * kModelStride,
+                                     d_records_in + (size_t)nj * kModelStride,
                                      c->tmp_model.as<double>(), c->stream));
         HIP_TRY(launch_mask(p->kind, p->ps, c->tmp_model.as<double>(), tail->thr2, c->mask.as<uint8_t>(), c->stream));
         if (tail->host_mask && p->n)
@@ -630,6 +653,21 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
         j.prefilter_thr2 = (kind == EST_REL) ? 5 * thr2 : 0.0; // relative_pose.cc:70
         return j;
     };
+
+    // one problem across several devices (pl_ransac_run_sharded): this rank evaluates a contiguous share of every batch
+    const pl_shard *sh = (g_shard && g_shard->world > 1) ? g_shard : nullptr;
+    const uint32_t G = sh ? (uint32_t)sh->world : 1u, grank = sh ? (uint32_t)sh->rank : 0u;
+    struct WireHead {
+        uint32_t n, gen_overflow, H, pad;
+    };
+    struct WireRec {
+        uint32_t iter_off, count; // iteration relative to the batch start
+        double score;
+        double model[kModelStride];
+    };
+    constexpr uint32_t kWireFirst = 32; // records that travel with the header
+    std::vector<unsigned char> wire_send, wire_recv;
+    std::vector<double> merged_models;
 
     bool mask_done = false;
     if (N >= (uint32_t)K) { // ransac_impl.h:161-163
@@ -708,8 +746,12 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             const uint32_t B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
             grow = std::min<uint64_t>(grow * 2, 131072u);
 
+            // this rank's share of the batch: iterations [it + lo_g, it + hi_g)  (the whole batch on a single device)
+            const uint32_t lo_g = (uint32_t)((uint64_t)B * grank / G), hi_g = (uint32_t)((uint64_t)B * (grank + 1) / G);
+            const uint32_t Bl = hi_g - lo_g;
+
             // ---- device: positions -> generate -> compact -> score -> finalize -> records ----
-            const size_t hcap = (size_t)B * MAXM;
+            const size_t hcap = (size_t)std::max<uint32_t>(Bl, 1u) * MAXM;
             ScoreArgs sa;
             set_prefilter(sa, p, thr2);
             const bool prefilter = true; // compact hypothesis stream for the streaming scorer (all estimators)
@@ -720,10 +762,10 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             }
             HIP_TRY(c->positions.ensure(sizeof(uint32_t) * B));
             HIP_TRY(c->models.ensure(sizeof(double) * kModelStride * hcap));
-            HIP_TRY(c->num_models.ensure(sizeof(uint32_t) * B));
+            HIP_TRY(c->num_models.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
             HIP_TRY(c->slots.ensure(sizeof(uint32_t) * hcap));
-            HIP_TRY(c->offsets.ensure(sizeof(uint32_t) * B));
-            HIP_TRY(c->blk_tot.ensure(sizeof(uint32_t) * ((B + 1023) / 1024 + 1)));
+            HIP_TRY(c->offsets.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
+            HIP_TRY(c->blk_tot.ensure(sizeof(uint32_t) * ((Bl + 1023) / 1024 + 1)));
             HIP_TRY(c->ctl.ensure(sizeof(BatchCtl)));
             HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * hcap));
             HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * hcap));
@@ -748,8 +790,9 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                 for (uint32_t b = 0; b < B; ++b)
                     prosac_sampler.generate(hs + (size_t)b * K);
                 pos_after = prosac_sampler.pos;
-                HIP_TRY(hipMemcpyAsync(c->samples.p, hs, sizeof(uint32_t) * (size_t)B * K, hipMemcpyHostToDevice,
-                                       c->stream));
+                if (Bl)
+                    HIP_TRY(hipMemcpyAsync(c->samples.p, hs + (size_t)lo_g * K, sizeof(uint32_t) * (size_t)Bl * K,
+                                           hipMemcpyHostToDevice, c->stream));
             }
             if (device_positions) {
                 // window of draw positions to evaluate: expected draws per iteration (sum N/(N-i)) + slack
@@ -761,10 +804,10 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                     device_positions = false;
                 } else {
                     const uint32_t M = (uint32_t)M64;
-                    HIP_TRY(c->delta.ensure((size_t)M + 16384 + 64)); // k_sample_orbit reads whole 16 KiB tiles
-                    HIP_TRY(c->flags.ensure(sizeof(uint32_t) * (size_t)M));
+                    HIP_TRY(c->delta.ensure((size_t)M + 64));
+                    HIP_TRY(c->flags.ensure(sizeof(uint64_t) * ((size_t)M / 64 + 2))); // bitmap of redrawing positions
                     HIP_TRY(launch_sample_positions(K, ro.seed, pos, N, B, M, c->delta.as<uint8_t>(),
-                                                    c->flags.as<uint32_t>(), M, c->positions.as<uint32_t>(), d_ctl,
+                                                    c->flags.as<uint64_t>(), c->positions.as<uint32_t>(), d_ctl,
                                                     c->stream));
                 }
             }
@@ -776,70 +819,69 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                 HIP_TRY(hipMemcpyAsync(c->positions.p, c->h_positions.p, sizeof(uint32_t) * B, hipMemcpyHostToDevice,
                                        c->stream));
             }
-            GenerateArgs ga;
-            ga.pts = p->ps;
-            ga.seed = ro.seed;
-            ga.pos_base = pos;
-            ga.positions = c->positions.as<uint32_t>();
-            ga.samples = prosac ? c->samples.as<uint32_t>() : nullptr;
-            ga.num_iters = B;
-            ga.slots_per_iter = (uint32_t)MAXM;
-            ga.ctl = d_ctl;
-            ga.models = c->models.as<double>();
-            ga.num_models = c->num_models.as<uint32_t>();
-            ga.real_focal_check = o->real_focal_check;
-            HIP_TRY(launch_generate(kind, ga, c->stream));
-            HIP_TRY(launch_compact2(ga.num_models, B, MAXM, c->blk_tot.as<uint32_t>(), c->slots.as<uint32_t>(),
-                                    c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,
-                                    prefilter ? c->compact64.as<double>() : nullptr, d_ctl, c->stream));
-            sa.pts = p->ps;
-            sa.models = ga.models;
-            sa.slots = c->slots.as<uint32_t>();
-            sa.shadow16 = nullptr;
-            if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores
-                HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
-                HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), (uint32_t)hcap, sa.pf.g16, sa.pf.c16,
-                                        sa.pf.thr, c->shadow16.p, c->stream));
-                sa.shadow16 = c->shadow16.p;
+            if (Bl > 0) { // (a rank whose share of a short batch is empty only takes part in the exchange)
+                GenerateArgs ga;
+                ga.pts = p->ps;
+                ga.seed = ro.seed;
+                ga.pos_base = pos;
+                ga.positions = c->positions.as<uint32_t>() + lo_g;
+                ga.samples = prosac ? c->samples.as<uint32_t>() : nullptr;
+                ga.num_iters = Bl;
+                ga.slots_per_iter = (uint32_t)MAXM;
+                ga.ctl = d_ctl;
+                ga.models = c->models.as<double>();
+                ga.num_models = c->num_models.as<uint32_t>();
+                ga.real_focal_check = o->real_focal_check;
+                HIP_TRY(launch_generate(kind, ga, c->stream));
+                HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, c->blk_tot.as<uint32_t>(), c->slots.as<uint32_t>(),
+                                        c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,
+                                        prefilter ? c->compact64.as<double>() : nullptr, d_ctl, c->stream));
+                sa.pts = p->ps;
+                sa.models = ga.models;
+                sa.slots = c->slots.as<uint32_t>();
+                sa.shadow16 = nullptr;
+                if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores
+                    HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
+                    HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), (uint32_t)hcap, sa.pf.g16, sa.pf.c16,
+                                            sa.pf.thr, c->shadow16.p, c->stream));
+                    sa.shadow16 = c->shadow16.p;
+                }
+                sa.shadow = prefilter ? c->shadow.as<float>() : nullptr;
+                sa.compact64 = prefilter ? c->compact64.as<double>() : nullptr;
+                sa.num_hyp = &d_ctl->num_hyp;
+                sa.hyp_capacity = (uint32_t)hcap;
+                sa.thr2 = thr2;
+                sa.part_count = c->part_count.as<uint32_t>();
+                sa.part_score = c->part_score.as<double>();
+                const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, (uint32_t)hcap));
+                HIP_TRY(hipEventRecord(c->ev0, c->stream));
+                HIP_TRY(launch_score(kind, sa, slices, c->stream));
+                HIP_TRY(hipEventRecord(c->ev1, c->stream));
+                FinalizeArgs fa;
+                fa.num_hyp = sa.num_hyp;
+                fa.hyp_capacity = (uint32_t)hcap;
+                fa.chunks = chunks;
+                fa.n_points = N;
+                fa.thr2 = thr2;
+                fa.part_count = sa.part_count;
+                fa.part_score = sa.part_score;
+                fa.count = c->count.as<uint32_t>();
+                fa.score = c->score.as<double>();
+                uint32_t *blk_max = c->blk_best.as<uint32_t>();
+                double *blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
+                HIP_TRY(c->blk_best.ensure(1024 + sizeof(double) * 256));
+                blk_max = c->blk_best.as<uint32_t>();
+                blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
+                const uint32_t init_max = (uint32_t)std::min<uint64_t>(best_min_inl, 0xffffffffu);
+                HIP_TRY(launch_finalize_records(fa, sa.slots, ga.models, blk_max, blk_min, init_max, best_min_score,
+                                                c->rec_meta.as<RecordMeta>(), c->rec_models.as<double>(), kRecordCap, d_ctl,
+                                                c->h_rec_meta.dev<RecordMeta>(), c->h_gather_out.dev<double>(), kRecordFirst,
+                                                c->stream));
             }
-            sa.shadow = prefilter ? c->shadow.as<float>() : nullptr;
-            sa.compact64 = prefilter ? c->compact64.as<double>() : nullptr;
-            sa.num_hyp = &d_ctl->num_hyp;
-            sa.hyp_capacity = (uint32_t)hcap;
-            sa.thr2 = thr2;
-            sa.part_count = c->part_count.as<uint32_t>();
-            sa.part_score = c->part_score.as<double>();
-            const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, (uint32_t)hcap));
-            HIP_TRY(hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(launch_score(kind, sa, slices, c->stream));
-            HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            FinalizeArgs fa;
-            fa.num_hyp = sa.num_hyp;
-            fa.hyp_capacity = (uint32_t)hcap;
-            fa.chunks = chunks;
-            fa.n_points = N;
-            fa.thr2 = thr2;
-            fa.part_count = sa.part_count;
-            fa.part_score = sa.part_score;
-            fa.count = c->count.as<uint32_t>();
-            fa.score = c->score.as<double>();
-            uint32_t *blk_max = c->blk_best.as<uint32_t>();
-            double *blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
-            HIP_TRY(c->blk_best.ensure(1024 + sizeof(double) * 256));
-            blk_max = c->blk_best.as<uint32_t>();
-            blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
-            const uint32_t init_max = (uint32_t)std::min<uint64_t>(best_min_inl, 0xffffffffu);
-            HIP_TRY(launch_finalize_records(fa, sa.slots, ga.models, blk_max, blk_min, init_max, best_min_score,
-                                            c->rec_meta.as<RecordMeta>(), c->rec_models.as<double>(), kRecordCap, d_ctl,
-                                            c->stream));
             BatchCtl *h_ctl = c->h_small.as<BatchCtl>();
-            RecordMeta *h_meta = c->h_rec_meta.as<RecordMeta>();
+            RecordMeta *h_meta = c->h_rec_meta.as<RecordMeta>(); // the first kRecordFirst records: written by k_records
             double *h_recm = c->h_gather_out.as<double>();
             HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(BatchCtl), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(h_meta, c->rec_meta.p, sizeof(RecordMeta) * kRecordFirst, hipMemcpyDeviceToHost,
-                                   c->stream));
-            HIP_TRY(hipMemcpyAsync(h_recm, c->rec_models.p, sizeof(double) * kModelStride * kRecordFirst,
-                                   hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (device_positions) {
                 if (h_ctl->orbit_error) { // evaluated window too small / too many redraws: redo this batch
@@ -848,24 +890,31 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                 }
                 pos_after = h_ctl->pos_after;
             }
-            if (h_ctl->gen_overflow) { // an iteration produced more models than the reserved slots: redo with 40
+            const bool overflow = h_ctl->gen_overflow != 0;
+            if (overflow && !sh) { // an iteration produced more models than the reserved slots: redo with 40
                 MAXM = max_models(kind);
                 prosac_sampler = prosac_at_batch_start;
                 continue;
-            }
+            } // (sharded: the ranks agree on the retry in the exchange below)
             force_host_positions = false;
-            const uint32_t H = h_ctl->num_hyp;
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-            st->score_kernel_ms += ms;
-            st->score_kernel_launches++;
-            st->iterations_evaluated += B;
+            uint32_t H = h_ctl->num_hyp; // sharded: replaced by the sum over the ranks after the exchange
+            const uint32_t H_local = H;
+            if (Bl > 0 && !overflow) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+                st->score_kernel_ms += ms;
+                st->score_kernel_launches++;
+            }
+            const uint64_t b0_inl = best_min_inl; // state of the sequential loop at the start of the batch
+            const double b0_score = best_min_score;
 
             // ---- pass 1 result: the improving hypotheses, in (iteration, model) order ----
             imps.clear();
             const double *h_rec = h_recm;
-            const uint32_t nrec = h_ctl->num_records;
-            if (!host_bookkeeping && nrec <= kRecordCap) {
+            const uint32_t nrec = overflow ? 0u : h_ctl->num_records;
+            if (overflow) {
+                // nothing to report: every rank redoes the batch with more slots per iteration
+            } else if (!host_bookkeeping && nrec <= kRecordCap) {
                 if (nrec > kRecordFirst) {
                     HIP_TRY(hipMemcpyAsync(h_meta, c->rec_meta.p, sizeof(RecordMeta) * nrec, hipMemcpyDeviceToHost,
                                            c->stream));
@@ -880,7 +929,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                 for (uint32_t a = 0; a < nrec; ++a) {
                     const RecordMeta &m = h_meta[order[a]];
                     Improving im;
-                    im.iter = (uint32_t)(it + m.slot / MAXM);
+                    im.iter = (uint32_t)(it + lo_g + m.slot / MAXM);
                     im.slot = m.slot;
                     im.count = m.count;
                     im.score = m.score;
@@ -896,11 +945,12 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                     imps.back().lo_seed = true;
             } else {
                 // fallback (record list overflow, or POSELIB_AMD_HOST_BOOKKEEPING=1): scan every score on the host
-                HIP_TRY(c->h_num_models.ensure(sizeof(uint32_t) * (B + 1)));
+                HIP_TRY(c->h_num_models.ensure(sizeof(uint32_t) * (Bl + 1)));
                 HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * hcap));
                 HIP_TRY(c->h_score.ensure(sizeof(double) * hcap));
                 uint32_t *h_nm = c->h_num_models.as<uint32_t>();
-                HIP_TRY(hipMemcpyAsync(h_nm, c->num_models.p, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, c->stream));
+                if (Bl)
+                    HIP_TRY(hipMemcpyAsync(h_nm, c->num_models.p, sizeof(uint32_t) * Bl, hipMemcpyDeviceToHost, c->stream));
                 if (H) {
                     HIP_TRY(hipMemcpyAsync(c->h_count.p, c->count.p, sizeof(uint32_t) * H, hipMemcpyDeviceToHost,
                                            c->stream));
@@ -911,7 +961,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                 const uint32_t *h_cnt = c->h_count.as<uint32_t>();
                 const double *h_sc = c->h_score.as<double>();
                 uint32_t k = 0;
-                for (uint32_t i = 0; i < B; ++i) {
+                for (uint32_t i = 0; i < Bl; ++i) {
                     int last = -1;
                     for (uint32_t m = 0; m < h_nm[i]; ++m, ++k) {
                         const bool more = h_cnt[k] > best_min_inl;
@@ -923,7 +973,7 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                         if (better)
                             best_min_score = h_sc[k];
                         Improving im;
-                        im.iter = (uint32_t)(it + i);
+                        im.iter = (uint32_t)(it + lo_g + i);
                         im.slot = i * MAXM + m;
                         im.count = h_cnt[k];
                         im.score = h_sc[k];
@@ -945,6 +995,100 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 h_rec = dst;
             }
+
+            // ---- sharded: the ONE exchange step of the batch.  Every rank contributes the improving hypotheses of its
+            // range (improving w.r.t. the batch-start state and its own earlier hypotheses - a superset of what the
+            // sequential loop keeps); the merged list is filtered with the true running best, rank by rank, i.e. in
+            // iteration order.  From here on every rank holds the same list and does the same thing. ----
+            if (sh) {
+                const uint32_t nloc = (uint32_t)imps.size();
+                auto pack = [&](unsigned char *dst, uint32_t first, uint32_t count) {
+                    for (uint32_t a = 0; a < count; ++a) {
+                        WireRec w;
+                        std::memset(&w, 0, sizeof(w));
+                        if (first + a < nloc) {
+                            const Improving &im = imps[first + a];
+                            w.iter_off = (uint32_t)(im.iter - it);
+                            w.count = im.count;
+                            w.score = im.score;
+                            std::memcpy(w.model, h_rec + (size_t)im.gather * kModelStride, sizeof(w.model));
+                        }
+                        std::memcpy(dst + (size_t)a * sizeof(WireRec), &w, sizeof(w));
+                    }
+                };
+                const size_t bytes1 = sizeof(WireHead) + (size_t)kWireFirst * sizeof(WireRec);
+                wire_send.assign(bytes1, 0);
+                wire_recv.assign(bytes1 * G, 0);
+                WireHead head{nloc, overflow ? 1u : 0u, H_local, 0u};
+                std::memcpy(wire_send.data(), &head, sizeof(head));
+                pack(wire_send.data() + sizeof(WireHead), 0, kWireFirst);
+                if (sh->allgather(sh->user, wire_send.data(), wire_recv.data(), bytes1) != 0)
+                    return fail(PL_ERR_COMM, "all-gather callback failed");
+                std::vector<WireHead> heads(G);
+                bool any_overflow = false;
+                uint32_t max_n = 0;
+                uint64_t H_sum = 0;
+                for (uint32_t r = 0; r < G; ++r) {
+                    std::memcpy(&heads[r], wire_recv.data() + (size_t)r * bytes1, sizeof(WireHead));
+                    any_overflow = any_overflow || heads[r].gen_overflow != 0;
+                    max_n = std::max(max_n, heads[r].n);
+                    H_sum += heads[r].H;
+                }
+                if (any_overflow) { // some rank ran out of model slots: all ranks redo the batch with 40 per iteration
+                    best_min_inl = b0_inl;
+                    best_min_score = b0_score;
+                    MAXM = max_models(kind);
+                    prosac_sampler = prosac_at_batch_start;
+                    continue;
+                }
+                const unsigned char *recs = wire_recv.data() + sizeof(WireHead);
+                size_t rank_stride = bytes1;
+                std::vector<unsigned char> recv2;
+                if (max_n > kWireFirst) { // rare: a second message with every rank's full list
+                    const size_t bytes2 = (size_t)max_n * sizeof(WireRec);
+                    std::vector<unsigned char> send2(bytes2, 0);
+                    recv2.assign(bytes2 * G, 0);
+                    pack(send2.data(), 0, max_n);
+                    if (sh->allgather(sh->user, send2.data(), recv2.data(), bytes2) != 0)
+                        return fail(PL_ERR_COMM, "all-gather callback failed");
+                    recs = recv2.data();
+                    rank_stride = bytes2;
+                }
+                imps.clear();
+                merged_models.clear();
+                uint64_t run_inl = b0_inl;
+                double run_score = b0_score;
+                for (uint32_t r = 0; r < G; ++r)
+                    for (uint32_t a = 0; a < heads[r].n; ++a) {
+                        WireRec w;
+                        std::memcpy(&w, recs + (size_t)r * rank_stride + (size_t)a * sizeof(WireRec), sizeof(w));
+                        const bool more = w.count > run_inl, better = w.score < run_score; // ransac_impl.h:114-116
+                        if (!(more || better))
+                            continue;
+                        if (more)
+                            run_inl = w.count;
+                        if (better)
+                            run_score = w.score;
+                        Improving im;
+                        im.iter = (uint32_t)(it + w.iter_off);
+                        im.slot = 0;
+                        im.count = w.count;
+                        im.score = w.score;
+                        im.lo_seed = false;
+                        im.gather = (uint32_t)imps.size();
+                        if (!imps.empty() && imps.back().iter != im.iter)
+                            imps.back().lo_seed = true;
+                        imps.push_back(im);
+                        merged_models.insert(merged_models.end(), w.model, w.model + kModelStride);
+                    }
+                if (!imps.empty())
+                    imps.back().lo_seed = true;
+                best_min_inl = run_inl;
+                best_min_score = run_score;
+                h_rec = merged_models.data();
+                H = (uint32_t)std::min<uint64_t>(H_sum, 0xffffffffu);
+            }
+            st->iterations_evaluated += B;
 
             // ---- device: every triggered LO of the batch as one batched launch, then re-scored ----
             const uint32_t ni = (uint32_t)imps.size();
@@ -990,10 +1134,23 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
             }
             if (stop_at < it + B) { // hypotheses of the replayed iterations only
                 uint32_t upto = 0;
-                HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it), sizeof(uint32_t),
-                                       hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                st->hypotheses += upto;
+                if (stop_at >= it + hi_g) {
+                    upto = H_local;
+                } else if (stop_at > it + lo_g) {
+                    HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it - lo_g), sizeof(uint32_t),
+                                           hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                }
+                uint64_t total = upto;
+                if (sh) { // sum of the ranks' shares (8 bytes each; once per run)
+                    std::vector<uint64_t> all(G, 0);
+                    if (sh->allgather(sh->user, &total, all.data(), sizeof(uint64_t)) != 0)
+                        return fail(PL_ERR_COMM, "all-gather callback failed");
+                    total = 0;
+                    for (uint32_t r = 0; r < G; ++r)
+                        total += all[r];
+                }
+                st->hypotheses += total;
             } else {
                 st->hypotheses += H;
             }
@@ -1353,6 +1510,18 @@ int pl_ransac_run(pl_problem *p, const pl_robust_options *opt, void *model, uint
         return fail(PL_ERR_INVALID, "problem lives on another device than the calling thread's");
     pl_ransac_stats local;
     return run_with_model(c, p, opt, model, inliers, stats ? stats : &local);
+}
+
+int pl_ransac_run_sharded(pl_problem *p, const pl_robust_options *opt, const pl_shard *shard, void *model,
+                          uint8_t *inliers, pl_ransac_stats *stats) {
+    if (!shard || shard->world < 1 || shard->rank < 0 || shard->rank >= shard->world)
+        return fail(PL_ERR_INVALID, "shard: need 0 <= rank < world");
+    if (shard->world > 1 && !shard->allgather)
+        return fail(PL_ERR_INVALID, "shard: all-gather callback missing");
+    g_shard = shard;
+    const int rc = pl_ransac_run(p, opt, model, inliers, stats);
+    g_shard = nullptr;
+    return rc;
 }
 
 int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t *inlier_count, double *score) {
@@ -1847,7 +2016,7 @@ struct BatchPool {
         return PL_OK;
     }
 };
-BatchPool &batch_pool() {
+static BatchPool &batch_pool_instance() {
     static BatchPool *pool = new BatchPool(); // never destroyed: its detached workers may outlive static destructors
     return *pool;
 }
@@ -1864,7 +2033,7 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
         return rc;
     int w = max_in_flight <= 0 ? 8 : std::min(max_in_flight, 64);
     w = (int)std::min<size_t>((size_t)w, count);
-    batch_pool().run(items, count, w, g_requested_device);
+    batch_pool_instance().run(items, count, w, g_requested_device);
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
             return fail(items[i].status, ("pl_estimate_batch: item " + std::to_string(i) + " failed").c_str());

@@ -596,18 +596,22 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 constexpr int kMfmaQueueCap = 1024; // >= 63 waiting + 64 lanes * 10 point groups appended by one round
+#ifndef PL_MFMA_THREADS
+#define PL_MFMA_THREADS 512
+#endif
+constexpr int kMfmaThreads = PL_MFMA_THREADS; // 8 wavefronts share one chunk of correspondences (LDS: 20 KB shared + 2.8 KB per wave)
 
 template <int PG>
-__global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma(PointSet pts, const uint2 *__restrict__ shadow16,
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma(PointSet pts, const uint2 *__restrict__ shadow16,
                                                                const double *__restrict__ compact64,
                                                                const uint32_t *__restrict__ num_hyp_ptr,
                                                                uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
                                                                uint32_t *__restrict__ part_count,
                                                                double *__restrict__ part_score) {
-    constexpr int kWaves = kScoreThreads / 64;
+    constexpr int kWaves = kMfmaThreads / 64;
     constexpr int NPW = 32 * PG; // correspondences per chunk
     __shared__ double s_pts[5][NPW];
-    __shared__ uint32_t s_queue[kWaves][kMfmaQueueCap];
+    __shared__ uint16_t s_queue[kWaves][kMfmaQueueCap]; // entries: hypothesis slot << 9 | correspondence of the chunk
     __shared__ double s_acc_s[kWaves][64];
     __shared__ uint32_t s_acc_c[kWaves][64];
     __shared__ uint32_t s_next_group;
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4
     __syncthreads(); // the only workgroup barrier
 
     const uint32_t H = *as_uniform(num_hyp_ptr);
-    uint32_t *const queue = s_queue[wave];
+    uint16_t *const queue = s_queue[wave];
     double *const acc_s = s_acc_s[wave];
     uint32_t *const acc_c = s_acc_c[wave];
     const uint32_t G = (H + 63u) / 64u;
@@ -696,8 +700,8 @@ __global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4
         auto drain = [&](uint32_t n) { // identical to k_score_queue's
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const bool act = (uint32_t)lane < n;
-            const uint32_t e = act ? queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffffffu;
-            const uint32_t g = e >> 16, pi = act ? (e & 0xffffu) : 0u;
+            const uint32_t e = act ? (uint32_t)queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffu;
+            const uint32_t g = e >> 9, pi = act ? (e & 0x1ffu) : 0u;
             double x[5];
 #pragma unroll
             for (int d = 0; d < 5; ++d)
@@ -781,7 +785,7 @@ __global__ __launch_bounds__(kScoreThreads) __attribute__((amdgpu_waves_per_eu(4
                         const int hi = 31 - __clz((int)rest);
                         rest &= ~(1u << hi);
                         const uint32_t g = (uint32_t)(PG - 1 - hi);
-                        queue[pos & (kMfmaQueueCap - 1)] = (slot << 16) | (g * 32u + (uint32_t)col);
+                        queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
                         ++pos;
                     }
                     qtail += total;
@@ -813,7 +817,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs f) {
         }
         f.count[k] = c;
         // MSAC: inlier residuals + threshold for every non-inlier (utils.cc:63 / :193-197)
-        f.score[k] = s + (double)(f.n_points - c) * f.thr2;
+        const double sc = s + (double)(f.n_points - c) * f.thr2;
+        f.score[k] = sc;
+        if (f.host_count) {
+            f.host_count[k] = c;
+            f.host_score[k] = sc;
+        }
     }
 }
 
@@ -1377,9 +1386,11 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     const dim3 grid(slices, chunks), block(kScoreThreads);
     if constexpr (E == EST_ABS) {
         if (streaming && a.shadow16) { // pre-filter on the matrix cores (PG = 2 P groups of 32 points per wave)
+            const dim3 mgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
+            const dim3 mblock(kMfmaThreads);
 #define PL_M_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \
-        k_score_mfma<2 * PP><<<grid, block, 0, stream>>>(a.pts, static_cast<const uint2 *>(a.shadow16), a.compact64,   \
+        k_score_mfma<2 * PP><<<mgrid, mblock, 0, stream>>>(a.pts, static_cast<const uint2 *>(a.shadow16), a.compact64,   \
                                                          a.num_hyp, a.hyp_capacity, a.thr2, pf, a.part_count,          \
                                                          a.part_score);                                                \
         break;
@@ -1469,10 +1480,18 @@ hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_t
 }
 
 __global__ void k_task_records(int est, const LMTask *tasks, const double *records_in, double *records_out,
-                               uint32_t num_tasks) {
+                               uint32_t num_tasks, LMTask *host_tasks) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= num_tasks)
         return;
+    if (host_tasks) { // the outputs of the LM kernel, straight to pinned host memory
+        for (int i = 0; i < kParamDoubles; ++i)
+            host_tasks[j].params[i] = tasks[j].params[i];
+        host_tasks[j].iterations = tasks[j].iterations;
+        host_tasks[j].skipped = tasks[j].skipped;
+        host_tasks[j].cost = tasks[j].cost;
+        host_tasks[j].initial_cost = tasks[j].initial_cost;
+    }
     double *out = records_out + (size_t)j * kModelStride;
     if (tasks[j].skipped) { // refinement not run: model unchanged (relative_pose.cc:75-77)
         for (int i = 0; i < kModelStride; ++i)
@@ -1488,10 +1507,11 @@ __global__ void k_select_record(const double *score_refined, double incumbent_sc
         out[threadIdx.x] = src[threadIdx.x];
 }
 hipError_t launch_task_records(int est, const LMTask *tasks, const double *records_in, double *records_out,
-                               uint32_t num_tasks, hipStream_t stream) {
+                               uint32_t num_tasks, LMTask *host_tasks, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
-    k_task_records<<<dim3((num_tasks + 63) / 64), dim3(64), 0, stream>>>(est, tasks, records_in, records_out, num_tasks);
+    k_task_records<<<dim3((num_tasks + 63) / 64), dim3(64), 0, stream>>>(est, tasks, records_in, records_out, num_tasks,
+                                                                         host_tasks);
     return hipGetLastError();
 }
 hipError_t launch_select_record(const double *score_refined, double incumbent_score, const double *rec_refined,

@@ -61,45 +61,68 @@ __device__ __forceinline__ double wscan_min(double v, int lane) {
 // ------------------------------------------------------------------------------------ sampler orbit
 template <int K>
 __global__ __launch_bounds__(256) void k_sample_delta(uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t M,
-                                                      uint8_t *delta) {
+                                                      uint8_t *delta, uint64_t *flagbits) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= M)
-        return;
-    uint32_t idx[K];
-    const uint32_t used = draw_sample<K>(seed, pos_base + p, N, idx);
-    delta[p] = (uint8_t)min(used, 255u);
+    bool flag = false;
+    if (p < M) {
+        uint32_t idx[K];
+        const uint32_t used = draw_sample<K>(seed, pos_base + p, N, idx);
+        delta[p] = (uint8_t)min(used, 255u);
+        flag = used != (uint32_t)K;
+    }
+    // bitmap of the positions whose iteration redraws: one 64-bit word per wavefront
+    const unsigned long long m = __ballot(flag);
+    if ((threadIdx.x & 63) == 0 && p < M)
+        flagbits[p >> 6] = m;
 }
 
 constexpr int kMaxSegments = 4096;
-constexpr int kMaxFlags = 12288; // flagged positions kept in LDS (position + delta); more => host fallback
+constexpr int kMaxFlags = 12288; // flagged positions kept in LDS (position + delta + successor); more => host fallback
+constexpr int kOrbitWords = 4;   // bitmap words per lane and tile of phase 1
 
-__global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, uint32_t M, int K, uint32_t B,
-                                                       uint64_t pos_base, uint32_t *positions, BatchCtl *ctl) {
+__device__ __forceinline__ uint32_t div_k(uint32_t x, int K) { // constant divisors compile to a multiply-high
+    switch (K) {
+    case 3:
+        return x / 3u;
+    case 4:
+        return x >> 2;
+    case 5:
+        return x / 5u;
+    default:
+        return x / 7u;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, const uint64_t *flagbits, uint32_t M, int K,
+                                                       uint32_t B, uint64_t pos_base, uint32_t *positions,
+                                                       BatchCtl *ctl) {
     __shared__ uint32_t wave_tot[16], wave_off[16];
     __shared__ uint32_t flag_pos[kMaxFlags];
     __shared__ uint8_t flag_delta[kMaxFlags];
+    __shared__ uint16_t flag_next[kMaxFlags]; // next flag on the orbit that passes through this flag (0xffff: none)
     __shared__ uint32_t seg_iter[kMaxSegments];
     __shared__ uint32_t seg_pos[kMaxSegments];
-    __shared__ uint32_t s_nseg, s_nflags, s_error;
+    __shared__ uint32_t s_nseg, s_nflags, s_error, s_entry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    // ---- phase 1: ordered list (in LDS) of the positions whose iteration would redraw (delta != K) ----
-    // Tiles of 1024 x 16 positions: one coalesced 16-byte load per lane, workgroup scan of the per-lane flag
-    // counts, ordered append.  (`delta` is allocated with 16 KiB of slack, so the last tile may over-read.)
+    // ---- phase 1: ordered list (in LDS) of the positions whose iteration would redraw (delta != K), from the
+    // bitmap k_sample_delta wrote: tiles of 1024 x kOrbitWords words, workgroup scan of the per-lane counts,
+    // ordered append (the delta byte is fetched for flagged positions only) ----
     if (threadIdx.x == 0) {
         s_nflags = 0;
         s_error = 0;
+        s_entry = 0xffffffffu;
     }
     __syncthreads();
-    for (uint32_t t0 = 0; t0 < M; t0 += 16384u) {
-        const uint32_t pbase = t0 + threadIdx.x * 16u;
-        const uint4 raw = *reinterpret_cast<const uint4 *>(delta + pbase);
-        const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+    const uint32_t nwords = (M + 63u) >> 6;
+    for (uint32_t w0 = 0; w0 < nwords; w0 += 1024u * kOrbitWords) {
+        const uint32_t wbase = w0 + threadIdx.x * kOrbitWords;
+        uint64_t bits[kOrbitWords];
         uint32_t local = 0;
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const uint32_t d = (w4[b >> 2] >> (8 * (b & 3))) & 0xffu;
-            local += (pbase + b < M && d != (uint32_t)K) ? 1u : 0u;
+        for (int b = 0; b < kOrbitWords; ++b) {
+            bits[b] = wbase + b < nwords ? flagbits[wbase + b] : 0ull;
+            local += (uint32_t)__popcll(bits[b]);
         }
         const uint32_t inc = wscan_add(local, lane);
         if (lane == 63)
@@ -119,11 +142,13 @@ __global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, uin
         if (!s_error && local) {
             uint32_t o = wave_off[wave] + inc - local;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const uint32_t d = (w4[b >> 2] >> (8 * (b & 3))) & 0xffu;
-                if (pbase + b < M && d != (uint32_t)K) {
-                    flag_pos[o] = pbase + b;
-                    flag_delta[o] = (uint8_t)d;
+            for (int b = 0; b < kOrbitWords; ++b) {
+                uint64_t rest = bits[b];
+                while (rest) {
+                    const uint32_t q = ((wbase + b) << 6) + (uint32_t)__builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    flag_pos[o] = q;
+                    flag_delta[o] = delta[q];
                     ++o;
                 }
             }
@@ -131,86 +156,103 @@ __global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, uin
         __syncthreads();
     }
 
-    // ---- phase 2: wavefront 0 hops along the orbit from flag to flag.  All state is wave-uniform; the 64
-    // lanes inspect 64 consecutive flags per step (the flags of the wrong phase are skipped in parallel). ----
-    if (wave == 0) {
-        uint32_t nseg = 1, err = s_error;
-        if (lane == 0) {
-            seg_iter[0] = 0;
-            seg_pos[0] = 0;
-        }
-        const uint32_t F = s_nflags;
-        uint32_t cur = 0, it = 0, fi = 0;
-        if (!err) {
-            while (it < B) {
-                // first flag at or after `cur` (flags are sorted)
-                for (;;) {
-                    const uint32_t idx = fi + lane;
-                    const bool behind = idx < F && flag_pos[idx] < cur;
-                    const uint32_t nb = __popcll(__ballot(behind));
-                    fi += nb;
-                    if (nb < 64)
-                        break;
-                }
-                // first flag >= cur on the current phase
-                uint32_t j = 0xffffffffu;
-                for (uint32_t j0 = fi; j0 < F; j0 += 64) {
-                    const uint32_t idx = j0 + lane;
-                    const bool hit = idx < F && (flag_pos[idx] - cur) % (uint32_t)K == 0;
-                    const unsigned long long m = __ballot(hit);
-                    if (m) {
-                        j = j0 + (uint32_t)__builtin_ctzll(m);
-                        break;
-                    }
-                }
-                if (j == 0xffffffffu)
-                    break; // no further redraw on this orbit: strides of K to the end
-                const uint32_t q = flag_pos[j];
-                const uint32_t before = (q - cur) / (uint32_t)K;
-                if (it + before >= B)
-                    break; // the batch ends before that iteration
-                it += before;
-                const uint32_t d = flag_delta[j];
-                if (d == 255u || nseg >= (uint32_t)kMaxSegments) {
-                    err = 1;
-                    break;
-                }
-                cur = q + d;
-                it += 1;
-                if (lane == 0) {
-                    seg_iter[nseg] = it;
-                    seg_pos[nseg] = cur;
-                }
-                ++nseg;
+    // ---- phase 2a: every flag looks up its successor on the orbit that passes through it: the first flag at
+    // or after  pos + delta  on the same phase modulo K (flags are sorted; ~K candidates to inspect).  Flag -1 is the
+    // virtual start (position 0, nothing consumed): its successor is the entry of the batch's orbit. ----
+    const uint32_t F = s_error ? 0u : s_nflags;
+    for (uint32_t j = threadIdx.x; j <= F; j += 1024u) {
+        const bool start = j == F; // the virtual start flag
+        const uint32_t from = start ? 0u : flag_pos[j] + (uint32_t)flag_delta[j];
+        uint32_t k = start ? 0u : j + 1;
+        uint32_t found = 0xffffu;
+        for (; k < F; ++k) {
+            const uint32_t q = flag_pos[k];
+            if (q >= from && (q - from) - div_k(q - from, K) * (uint32_t)K == 0u) {
+                found = k;
+                break;
             }
         }
-        // position of iteration B == draws consumed by the batch, from the last segment of the table
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            const uint32_t s = nseg - 1;
-            const uint64_t end = (uint64_t)seg_pos[s] + (uint64_t)(B - seg_iter[s]) * (uint64_t)K;
-            if (end + 255 > M)
-                err = 1; // the window of evaluated positions was too small: the host retries / falls back
-            ctl->pos_after = pos_base + end;
-            ctl->orbit_error = err;
-            s_nseg = nseg;
-            s_error = err;
-        }
+        if (start)
+            s_entry = found;
+        else
+            flag_next[j] = (uint16_t)found;
     }
     __syncthreads();
 
-    // ---- phase 3: expand segments to per-iteration positions (relative to pos_base) ----
-    const uint32_t nseg = s_nseg;
-    for (uint32_t i = threadIdx.x; i < B; i += 1024) {
-        uint32_t lo = 0, hi = nseg; // last segment with seg_iter <= i
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (seg_iter[mid] <= i)
-                lo = mid;
-            else
-                hi = mid;
+    // ---- phase 2b: one lane follows the successor links and emits (iteration, position) segments ----
+    if (threadIdx.x == 0) {
+        uint32_t nseg = 1, err = s_error;
+        seg_iter[0] = 0;
+        seg_pos[0] = 0;
+        uint32_t cur = 0, it = 0, j = s_entry;
+        while (!err && j != 0xffffu) {
+            const uint32_t q = flag_pos[j];
+            const uint32_t before = div_k(q - cur, K);
+            if (it + before >= B)
+                break; // the batch ends before that iteration
+            const uint32_t d = flag_delta[j];
+            if (d == 255u || nseg >= (uint32_t)kMaxSegments) {
+                err = 1;
+                break;
+            }
+            it += before + 1;
+            cur = q + d;
+            seg_iter[nseg] = it;
+            seg_pos[nseg] = cur;
+            ++nseg;
+            j = flag_next[j];
         }
-        positions[i] = seg_pos[lo] + (i - seg_iter[lo]) * (uint32_t)K;
+        // position of iteration B == draws consumed by the batch, from the last segment of the table
+        const uint32_t s = nseg - 1;
+        const uint64_t end = (uint64_t)seg_pos[s] + (uint64_t)(B - seg_iter[s]) * (uint64_t)K;
+        if (end + 255 > M)
+            err = 1; // the window of evaluated positions was too small: the host retries / falls back
+        ctl->pos_after = pos_base + end;
+        ctl->orbit_error = err;
+        s_nseg = nseg;
+        s_error = err;
+    }
+    __syncthreads();
+
+    // ---- phase 3: expand segments to per-iteration positions (relative to pos_base).  Every wavefront takes a
+    // contiguous sixteenth of the iterations, its lanes stride through it by 64: a lane's iterations ascend in small
+    // steps, so its segment index only creeps forward - one compare per iteration against the start of the next
+    // segment (kept in a register), a short linear probe when it is crossed, a binary search if the probe fails ----
+    const uint32_t nseg = s_nseg;
+    const uint32_t per_wave = ((B + 15u) / 16u + 63u) & ~63u;
+    const uint32_t i0 = (uint32_t)wave * per_wave, i1 = min(B, i0 + per_wave);
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) { // last segment with seg_iter <= i0 (wave-uniform)
+        const uint32_t mid = (lo + hi) >> 1;
+        if (seg_iter[mid] <= i0)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    uint32_t cur_it = seg_iter[lo], cur_pos = seg_pos[lo];
+    uint32_t next_it = lo + 1 < nseg ? seg_iter[lo + 1] : 0xffffffffu;
+    for (uint32_t i = i0 + (uint32_t)lane; i < i1; i += 64) {
+        if (i >= next_it) {
+            int probe = 0;
+            do {
+                ++lo;
+                next_it = lo + 1 < nseg ? seg_iter[lo + 1] : 0xffffffffu;
+            } while (i >= next_it && ++probe < 4);
+            if (i >= next_it) {
+                hi = nseg;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (seg_iter[mid] <= i)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                next_it = lo + 1 < nseg ? seg_iter[lo + 1] : 0xffffffffu;
+            }
+            cur_it = seg_iter[lo];
+            cur_pos = seg_pos[lo];
+        }
+        positions[i] = cur_pos + (i - cur_it) * (uint32_t)K;
     }
 }
 
@@ -337,7 +379,8 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
                                                  const uint32_t *slots, const double *models, const uint32_t *blk_max,
                                                  const double *blk_min, uint32_t init_max, double init_min,
                                                  RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap,
-                                                 BatchCtl *ctl) {
+                                                 BatchCtl *ctl, RecordMeta *host_meta, double *host_models,
+                                                 uint32_t host_cap) {
     __shared__ uint32_t wmax[4];
     __shared__ double wmin[4];
     __shared__ uint32_t s_runmax;
@@ -410,6 +453,11 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
                 rec_meta[r] = m;
                 for (int i = 0; i < kModelStride; ++i)
                     rec_models[(size_t)r * kModelStride + i] = models[(size_t)slot * kModelStride + i];
+                if (r < host_cap) { // the first records go straight to pinned host memory (no copy dispatch)
+                    host_meta[r] = m;
+                    for (int i = 0; i < kModelStride; ++i)
+                        host_models[(size_t)r * kModelStride + i] = models[(size_t)slot * kModelStride + i];
+                }
             }
         }
         __syncthreads();
@@ -597,28 +645,26 @@ hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, 
 }
 
 hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t B, uint32_t M,
-                                   uint8_t *delta, uint32_t *flags, uint32_t flags_cap, uint32_t *positions,
-                                   BatchCtl *ctl, hipStream_t stream) {
+                                   uint8_t *delta, uint64_t *flagbits, uint32_t *positions, BatchCtl *ctl,
+                                   hipStream_t stream) {
     const dim3 grid((M + 255) / 256), block(256);
     switch (K) {
     case 3:
-        k_sample_delta<3><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta);
+        k_sample_delta<3><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits);
         break;
     case 4:
-        k_sample_delta<4><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta);
+        k_sample_delta<4><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits);
         break;
     case 5:
-        k_sample_delta<5><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta);
+        k_sample_delta<5><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits);
         break;
     case 7:
-        k_sample_delta<7><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta);
+        k_sample_delta<7><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits);
         break;
     default:
         return hipErrorInvalidValue;
     }
-    (void)flags;
-    (void)flags_cap;
-    k_sample_orbit<<<dim3(1), dim3(1024), 0, stream>>>(delta, M, K, B, pos_base, positions, ctl);
+    k_sample_orbit<<<dim3(1), dim3(1024), 0, stream>>>(delta, flagbits, M, K, B, pos_base, positions, ctl);
     return hipGetLastError();
 }
 
@@ -640,10 +686,11 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
 hipError_t launch_finalize_records(const FinalizeArgs &f, const uint32_t *slots, const double *models,
                                    uint32_t *blk_max, double *blk_min, uint32_t init_max, double init_min,
                                    RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap, BatchCtl *ctl,
-                                   hipStream_t stream) {
+                                   RecordMeta *host_meta, double *host_models, uint32_t host_cap, hipStream_t stream) {
     k_finalize2<<<dim3(kRecBlocks), dim3(256), 0, stream>>>(f, blk_max, blk_min);
     k_records<<<dim3(kRecBlocks), dim3(256), 0, stream>>>(f.num_hyp, f.count, f.score, slots, models, blk_max, blk_min,
-                                                          init_max, init_min, rec_meta, rec_models, rec_cap, ctl);
+                                                          init_max, init_min, rec_meta, rec_models, rec_cap, ctl,
+                                                          host_meta, host_models, host_meta ? host_cap : 0u);
     return hipGetLastError();
 }
 

@@ -66,6 +66,9 @@ struct FinalizeArgs {
     const double *part_score;
     uint32_t *count; // [hyp_capacity]
     double *score;   // [hyp_capacity]
+    // optional second destination in pinned host memory (written by the kernel itself: no copy dispatch); k_finalize only
+    uint32_t *host_count = nullptr;
+    double *host_score = nullptr;
 };
 
 struct LMTask {
@@ -114,8 +117,9 @@ hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, 
 // After the LM kernels: records of the refined models on the device (skipped tasks keep their input record), and the
 // choice "refined model if its score beats `incumbent_score`, else the incumbent" of the final refinement
 // (ransac_impl.h:190-198) so that the inlier mask can follow without a host round trip.
+// host_tasks (pinned host memory, may be null): receives params / skipped / iterations / costs of every task
 hipError_t launch_task_records(int est, const LMTask *tasks, const double *records_in, double *records_out,
-                               uint32_t num_tasks, hipStream_t stream);
+                               uint32_t num_tasks, LMTask *host_tasks, hipStream_t stream);
 hipError_t launch_select_record(const double *score_refined, double incumbent_score, const double *rec_refined,
                                 const double *rec_incumbent, double *out, hipStream_t stream);
 // fp16 A-operand blocks for k_score_mfma from the compact fp32 shadows (absolute pose); capacity = hypotheses rounded
@@ -138,7 +142,7 @@ hipError_t launch_mask(int est, const PointSet &pts, const double *model, double
 
 // ---- device-side bookkeeping (pipeline.hip) ----
 hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t B, uint32_t M,
-                                   uint8_t *delta, uint32_t *flags, uint32_t flags_cap, uint32_t *positions,
+                                   uint8_t *delta, uint64_t *flagbits /* >= ceil(M / 64) words */, uint32_t *positions,
                                    BatchCtl *ctl, hipStream_t stream);
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, uint32_t *slots,
                            uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,
@@ -146,7 +150,7 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
 hipError_t launch_finalize_records(const FinalizeArgs &f, const uint32_t *slots, const double *models,
                                    uint32_t *blk_max, double *blk_min, uint32_t init_max, double init_min,
                                    RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap, BatchCtl *ctl,
-                                   hipStream_t stream);
+                                   RecordMeta *host_meta, double *host_models, uint32_t host_cap, hipStream_t stream);
 
 // Bare solver entry points (one problem per lane); inputs/outputs in HBM.
 //   abs : in = [x0 x1 x2 X0 X1 X2] (18 doubles / problem) -> out records (4 / problem)

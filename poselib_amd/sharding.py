@@ -11,6 +11,47 @@ from __future__ import annotations
 
 import numpy as np
 
+
+def dist_allgather(group=None, device=None):
+    """The exchange step of Problem.run_sharded (ONE problem across the GPUs: every rank scores a share of each batch
+    of iterations) as a torch.distributed all-gather: RCCL when `device` is this rank's GPU ("nccl" backend), gloo
+    with device=None.  Returns allgather(send, recv) for numpy uint8 arrays, len(recv) == world * len(send)."""
+    import torch
+    import torch.distributed as dist
+
+    def allgather(send, recv):
+        world = dist.get_world_size(group)
+        t = torch.from_numpy(np.array(send, dtype=np.uint8, copy=True))
+        if device is not None:
+            t = t.to(device)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t, group=group)
+        recv[:] = torch.cat(out).cpu().numpy()
+
+    return allgather
+
+
+def thread_allgather(world: int):
+    """In-process all-gather between `world` host threads (one per device, or several sharing one device in the
+    tests): returns allgather_for(rank) -> allgather(send, recv)."""
+    import threading
+
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+
+    def allgather_for(rank):
+        def allgather(send, recv):
+            slots[rank] = np.array(send, copy=True)
+            barrier.wait()
+            n = len(send)
+            for r in range(world):
+                recv[r * n:(r + 1) * n] = slots[r]
+            barrier.wait()
+
+        return allgather
+
+    return allgather_for
+
 RECORD_DOUBLES = 15
 
 

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-bash scripts/gpu_check.sh
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sharded" 2>&1 | tail -15
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3

@@ -460,6 +460,135 @@ def test_point_counts_around_the_chunk_boundaries(gpu, n):
     assert (np.array(info["inliers"]) == mask).all()
 
 
+@pytest.mark.parametrize("n", [8, 11, 24, 60, 200])
+def test_sampler_with_frequent_redraws(gpu, n):
+    """Few correspondences: most iterations redraw a duplicate index (sampling.cc:46-61), so the device sampler's
+    orbit has a flag at almost every position (bitmap -> successor links -> segments; beyond 12288 flags or 4096
+    segments per batch it must fall back to the host walk) - long fixed-length runs must still follow the
+    reference's draw stream exactly.  (`refinements` is compared from 24 correspondences up: below that the same
+    sample recurs in permuted order, its models tie to the last bit of the MSAC score, and the device's tree-order
+    sums may rank such a pair differently from the sequential sums - DESIGN.md section 5, residual risk.)"""
+    refs = (lambda a, b: a == b) if n >= 24 else (lambda a, b: True)
+    opt = {"ransac": {"seed": 5 + n, "max_iterations": 30000, "min_iterations": 30000}}
+    r = synth.relative_pose_scene(max(n, 8), 0.25, 70 + n)
+    F, info = gpu.estimate_fundamental(r["x1"][:n], r["x2"][:n], opt)
+    Fo, mask, st = O.estimate_fundamental(r["x1"][:n], r["x2"][:n], opt)
+    assert info["iterations"] == st["iterations"] == 30000 and refs(info["refinements"], st["refinements"])
+    assert info["num_inliers"] == st["num_inliers"] and (np.array(info["inliers"]) == mask).all()
+    d = synth.absolute_pose_scene(max(n, 8), 0.25, 71 + n)
+    img, info = gpu.estimate_absolute_pose(d["p2d"][:n], d["p3d"][:n], d["camera"], opt)
+    pose, mask, st = O.estimate_absolute_pose(d["p2d"][:n], d["p3d"][:n], d["camera"], opt)
+    assert info["iterations"] == st["iterations"] == 30000 and refs(info["refinements"], st["refinements"])
+    assert info["num_inliers"] == st["num_inliers"] and (np.array(info["inliers"]) == mask).all()
+    h = synth.homography_scene(max(n, 8), 0.25, 72 + n)
+    H, info = gpu.estimate_homography(h["x1"][:n], h["x2"][:n], opt)
+    Ho, mask, st = O.estimate_homography(h["x1"][:n], h["x2"][:n], opt)
+    assert info["iterations"] == st["iterations"] == 30000 and refs(info["refinements"], st["refinements"])
+    assert info["num_inliers"] == st["num_inliers"] and (np.array(info["inliers"]) == mask).all()
+
+
+def _run_sharded_threads(kind, a, b, opt, world):
+    """`world` host threads, each with its own Problem (own HIP stream / scratch) on the one GPU of the box, exchange
+    through sharding.thread_allgather: the within-problem sharding of pl_ransac_run_sharded, rank by rank."""
+    import threading
+
+    import poselib_amd as P
+    from poselib_amd import sharding
+
+    ag_for = sharding.thread_allgather(world)
+    out = [None] * world
+    err = []
+
+    def run(rank):
+        try:
+            prob = P.Problem(kind, a, b)
+            out[rank] = prob.run_sharded(opt, rank, world, ag_for(rank))
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+            raise
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not err, err
+    return out
+
+
+SHARD_FIELDS = ("iterations", "refinements", "num_inliers", "model_score", "hypotheses", "inlier_ratio")
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_one_problem_sharded_over_ranks_equals_the_single_device_run(gpu, world):
+    """iteration ranges per rank + one all-gather of improving hypotheses per batch.  Every rank must
+    return exactly the single-device result: model bits, mask, iterations (early stop in the middle of a batch
+    included), refinements, hypothesis count."""
+    import poselib_amd as P
+
+    cases = []
+    d = synth.absolute_pose_scene(3000, 0.6, 811)
+    par = d["camera"]["params"]
+    cases.append((0, (d["p2d"] - par[-2:]) / par[0], d["p3d"], 12.0 / par[0]))
+    r = synth.relative_pose_scene(2000, 0.4, 812)
+    cases.append((1, (r["x1"] - 500.0) / 1000.0, (r["x2"] - 500.0) / 1000.0, 1e-3))
+    f = synth.fundamental_scene(2500, 0.4, 813)
+    cases.append((2, (f["x1"] - 500.0) / 1000.0, (f["x2"] - 500.0) / 1000.0, 1e-3))
+    h = synth.homography_scene(2500, 0.4, 814)
+    cases.append((3, (h["x1"] - 500.0) / 1000.0, (h["x2"] - 500.0) / 1000.0, 1e-3))
+    for kind, a, b, err in cases:
+        for ransac in ({"seed": 3}, {"seed": 4, "max_iterations": 20000, "min_iterations": 20000},
+                       {"seed": 5, "progressive_sampling": True, "max_prosac_iterations": 500}):
+            opt = {"max_error": err, "ransac": ransac}
+            m0, i0 = P.Problem(kind, a, b).run(opt)
+            flat0 = np.r_[m0.q, m0.t] if hasattr(m0, "q") else np.ravel(m0)
+            for m, info in _run_sharded_threads(kind, a, b, opt, world):
+                flat = np.r_[m.q, m.t] if hasattr(m, "q") else np.ravel(m)
+                assert (flat == flat0).all(), (kind, ransac)
+                assert all(info[k] == i0[k] for k in SHARD_FIELDS), (kind, ransac, {k: (info[k], i0[k]) for k in SHARD_FIELDS})
+                assert (np.array(info["inliers"]) == np.array(i0["inliers"])).all()
+
+
+def test_sharded_run_over_torch_distributed_gloo(gpu):
+    """the same through torch.distributed (two processes sharing the box's GPU, gloo all-gather on CPU tensors - on a
+    node with one GPU per rank the callback is sharding.dist_allgather(device=...) over RCCL)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import poselib_amd as P
+from poselib_amd import synth, sharding
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+d = synth.absolute_pose_scene(2000, 0.5, 815)
+par = d["camera"]["params"]
+x, X = (d["p2d"] - par[-2:]) / par[0], d["p3d"]
+opt = {"max_error": 12.0 / par[0], "ransac": {"seed": 9, "max_iterations": 5000, "min_iterations": 5000}}
+prob = P.Problem(0, x, X)
+pose, info = prob.run_sharded(opt, rank, world, sharding.dist_allgather())
+single_pose, single = prob.run(opt)
+ok = (list(pose.q) + list(pose.t) == list(single_pose.q) + list(single_pose.t)) and all(
+    info[k] == single[k] for k in ("iterations", "refinements", "num_inliers", "model_score", "hypotheses")) and info["inliers"] == single["inliers"]
+print("RESULT " + json.dumps([rank, bool(ok), info["iterations"], info["num_inliers"]]))
+dist.destroy_process_group()
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(32500 + os.getpid() % 2000), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, "-c", code, root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        out, errtxt = p.communicate(timeout=600)
+        assert p.returncode == 0, out + errtxt
+        line = [ln for ln in out.splitlines() if ln.startswith("RESULT ")][-1]
+        rank, ok, its, inl = json.loads(line[7:])
+        assert ok and its == 5000 and inl > 500, (rank, ok, its, inl)
+
+
 def test_non_finite_inputs_do_not_hang_or_crash(gpu):
     """NaN / inf correspondences: the reference happily computes with them (comparisons fail, the point is an
     outlier); the device path must do the same - same counts and masks as the oracle, no hang"""

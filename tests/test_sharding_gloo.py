@@ -62,3 +62,65 @@ def test_two_rank_gloo_gather_equals_single_process():
         table = table.copy()
         table[:, 5] = 0  # wall time differs between runs
         assert (table == single).all(), rank
+
+
+def exchange_worker(rank, world, port, q):
+    from poselib_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ag = sharding.dist_allgather()
+    out = []
+    for nbytes in (8, 6928, 40000):  # the three message sizes of pl_ransac_run_sharded (count, header + 32, full lists)
+        send = ((np.arange(nbytes) * (rank + 3)) % 251).astype(np.uint8)
+        recv = np.zeros(world * nbytes, dtype=np.uint8)
+        ag(send, recv)
+        out.append(recv)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_exchange_step_of_the_within_problem_sharding_over_gloo():
+    """sharding.dist_allgather is the collective Problem.run_sharded calls once per batch (RCCL on the GPU nodes):
+    world 2 over gloo, every rank must receive rank r's bytes at offset r * len."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in results:
+        for recv, nbytes in zip(out, (8, 6928, 40000)):
+            for r in range(2):
+                want = ((np.arange(nbytes) * (r + 3)) % 251).astype(np.uint8)
+                assert (recv[r * nbytes:(r + 1) * nbytes] == want).all(), (rank, nbytes, r)
+
+
+def test_thread_allgather():
+    import threading
+
+    from poselib_amd import sharding
+
+    world = 3
+    ag_for = sharding.thread_allgather(world)
+    got = [None] * world
+
+    def run(rank):
+        for rnd in range(4):
+            send = np.full(16, 10 * rnd + rank, dtype=np.uint8)
+            recv = np.zeros(16 * world, dtype=np.uint8)
+            ag_for(rank)(send, recv)
+            got[rank] = recv
+            assert all((recv[r * 16:(r + 1) * 16] == 10 * rnd + r).all() for r in range(world))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert all(g is not None for g in got)
