@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--problems-per-step", type=int, default=0,
                     help="independent problems per step and GPU (default 8 x streams): the batch one step works through")
     ap.add_argument("--workload", default="p3p_5000", choices=sorted(WORKLOADS))
+    ap.add_argument("--shard-problem", action="store_true",
+                    help="strong-scaling mode (SURVEY 8e-ii): ONE problem at a time, its iterations sharded over the "
+                         "ranks (pl_ransac_run_sharded, one all-gather per batch); default is independent problems per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=ITERATIONS)
     args = ap.parse_args()
@@ -92,18 +95,20 @@ def main():
     KIND, N_POINTS, OUTLIER_RATIO, MAX_ERROR_PX, DATA_SEED, BYTES_PER_CORR, DESCR = WORKLOADS[args.workload]
     # one image pair per rank (independent problems; data seed + rank); pixels -> normalised image plane
     pp = np.array([500.0, 500.0])
+    shard_problem = bool(args.shard_problem)
+    data_rank = 0 if shard_problem else rank  # sharded problem: every rank holds the same correspondences
     if KIND == 0:
-        scene = synth.absolute_pose_scene(N_POINTS, OUTLIER_RATIO, DATA_SEED + rank)
+        scene = synth.absolute_pose_scene(N_POINTS, OUTLIER_RATIO, DATA_SEED + data_rank)
         A, Bpts = (scene["p2d"] - pp) / FOCAL, scene["p3d"]
     else:
         gen = {1: synth.relative_pose_scene, 2: synth.fundamental_scene, 3: synth.homography_scene}[KIND]
-        scene = gen(N_POINTS, OUTLIER_RATIO, DATA_SEED + rank)
+        scene = gen(N_POINTS, OUTLIER_RATIO, DATA_SEED + data_rank)
         A, Bpts = (scene["x1"] - pp) / FOCAL, (scene["x2"] - pp) / FOCAL
     # the front-end's O(N) pre-processing (robust.cc:40-46) is done once, outside the timed region
     from concurrent.futures import ThreadPoolExecutor
 
     thr = MAX_ERROR_PX / FOCAL
-    S = max(1, args.streams)
+    S = 1 if shard_problem else max(1, args.streams)  # collectives of one process group must be issued in one order
     # every worker thread selects this rank's GPU before its first call (per-thread context: HIP stream + scratch)
     pool = ThreadPoolExecutor(max_workers=S, initializer=lambda: P.set_device(device_index))
 
@@ -112,9 +117,17 @@ def main():
 
     probs = list(pool.map(make_problem, range(S)))
 
+    exchange = None
+    if shard_problem and use_dist:
+        from poselib_amd import sharding
+
+        exchange = sharding.dist_allgather(device=(f"cuda:{device_index}" if backend == "nccl" else None))
+
     def run_one(args_):
         prob, seed = args_
         opt = {"max_error": thr, "ransac": {"max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "seed": seed}}
+        if exchange is not None:
+            return prob.run_sharded(opt, rank, world, exchange)
         return prob.run(opt)
 
     PPS = args.problems_per_step if args.problems_per_step > 0 else 8 * S
@@ -160,7 +173,8 @@ def main():
 
     if rank == 0:
         t_max = float(allrec[:, 0].max())
-        total_hyp = float(allrec[:, 1].sum())
+        # sharded problem: every rank reports the job's total; independent problems: the ranks' sums add up
+        total_hyp = float(allrec[0, 1]) if shard_problem else float(allrec[:, 1].sum())
         value = total_hyp / t_max
         k_ms = float(allrec[0, 2])
         k_launch = int(allrec[0, 3])
@@ -185,7 +199,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard_problem else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -193,7 +207,8 @@ def main():
                        "outlier_ratio": OUTLIER_RATIO, "max_iterations": ITERATIONS, "min_iterations": ITERATIONS,
                        "max_error_px": MAX_ERROR_PX, "problems_per_gpu_per_step": PPS, "problems_in_flight_per_gpu": S,
                        "hypotheses_per_step": hyp0 / args.steps,
-                       "iterations_per_s": world * PPS * args.steps * ITERATIONS / t_max,
+                       "iterations_per_s": (1 if shard_problem else world) * PPS * args.steps * ITERATIONS / t_max,
+                       "sharding": "one problem over the ranks (iteration ranges, one all-gather per batch)" if shard_problem else "independent problems per rank",
                        "inliers_found": int(allrec[0, 4])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sharded" 2>&1 | tail -15
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+export BENCH_DIST_BACKEND=gloo BENCH_SHARE_DEVICE=1
+timeout 300 python bench.py --no-cpu-baseline --streams 1 --steps 3 2>&1 | tail -1 | cut -c1-330
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --shard-problem --no-cpu-baseline 2>&1 | tail -2 | cut -c1-900
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330
