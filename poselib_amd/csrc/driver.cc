@@ -558,14 +558,16 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         std::memcpy(hr + (size_t)nj * kModelStride, tail->incumbent_rec, sizeof(double) * kModelStride);
     HIP_TRY(hipMemcpyAsync(c->lm_tasks.p, ht, stage_bytes, hipMemcpyHostToDevice, c->stream));
     // Large point sets with 6..8 parameters saturate the single CU k_lm gives a task: spread every task over several
-    // workgroups (k_lm2).  Only for short, bounded runs (the LO: 25 iterations) - k_lm2 costs 2 * max_iterations + 3
-    // launches whatever the iteration count turns out to be.
-    // k_lm2 trades launches for latency (2 * max_iterations + 3 small launches instead of one long kernel on one CU):
-    // 1.6x shorter homography problems at N = 10^4 when the device serves one problem at a time, but with a dozen
-    // problems in flight the long kernels overlap anyway and the launch traffic congests the hardware queues
-    // (measured: -30 % throughput).  The two kernels sum the normal equations in different orders, so the choice
-    // must not depend on load: it is an explicit, process-wide setting (POSELIB_AMD_LATENCY_MODE=1), off by default.
-    static const bool latency_mode = std::getenv("POSELIB_AMD_LATENCY_MODE") != nullptr;
+    // workgroups (k_lm2, one launch per LM iteration).  Only for short, bounded runs (the LO: 25 iterations) - k_lm2
+    // costs max_iterations + 2 launches whatever the iteration count turns out to be.  Measured on MI355X at
+    // N = 10^4: homography problems 2.2x, fundamental 1.5x shorter when the device serves one problem at a time; with
+    // 16 problems in flight the long single-CU kernels overlap anyway and the extra launches cost 4..8 % throughput.
+    // The two kernels sum the normal equations in different orders, so the choice must not depend on load: it is a
+    // process-wide setting, on by default, POSELIB_AMD_LATENCY_MODE=0 switches it off.
+    static const bool latency_mode = [] {
+        const char *e = std::getenv("POSELIB_AMD_LATENCY_MODE");
+        return !(e && e[0] == '0');
+    }();
     uint32_t max_it = 0;
     bool same_it = true;
     for (uint32_t j = 0; j < nj; ++j) {

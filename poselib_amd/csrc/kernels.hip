@@ -1064,21 +1064,23 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet p
 // ---- LM across several workgroups ---------------------------------------------------------------------------------
 // k_lm keeps one refinement task on one CU; at N = 10^4 with 7 or 8 parameters that CU is VALU-saturated for ~70 us per
 // LM iteration.  k_lm2 spreads the point range of every task over gridDim.x workgroups and turns the LM loop inside
-// out: one launch = "advance the LM state with the partial sums the previous launch left, then run the next pass
-// (residuals or normal equations) over my slice".  Every workgroup of a task reduces the same partials in the same
-// order and runs the same scalar state machine (pl_refine.h lm_begin / lm_solve / lm_update), so all of them arrive at
-// the same state without talking to each other; slice 0 stores it.  States and partials are double-buffered by launch
-// parity.  The host enqueues 2 * max_iterations + 3 launches; workgroups of finished tasks return at once.
-// No spinning, no inter-workgroup synchronisation inside a launch.
+// out: one launch = "advance the LM state with the partial sums the previous launch left, then run the next pass over
+// my slice".  A pass evaluates the robust cost AND the normal equations at the same parameters (the trial point): if
+// the step is accepted these are exactly the normal equations lm_impl.h would compute next, if it is rejected they are
+// dropped and the previous ones are re-solved with the larger damping - so ONE launch per LM iteration.  Every
+// workgroup of a task reduces the same partials in the same order and runs the same scalar state machine
+// (pl_refine.h lm_begin / lm_solve / lm_update), so all of them arrive at the same state without talking to each
+// other; slice 0 stores it.  States and partials are double-buffered by launch parity.  The host enqueues
+// max_iterations + 2 launches; workgroups of finished tasks return at once.  No spinning, no inter-workgroup
+// synchronisation inside a launch.
 constexpr int kLM2Threads = 256;
 
 struct LM2State {
     LMControl ctl;
     double cur[kParamDoubles], trial[kParamDoubles];
-    double normal[44]; // reduced [tri | Jtr] of the last Jacobian pass
-    uint32_t count;
-    int32_t phase;    // partials waiting for the next launch: 0 none, 1 residuals(cur) of the start, 2 normal
-                      // equations(cur), 3 residuals(trial)
+    double normal[44]; // reduced [tri | Jtr] at `cur`
+    uint32_t count;    // residuals with non-zero weight behind `normal`
+    int32_t phase;     // partials waiting for the next launch: 0 none, 1 pass at the start point, 3 pass at `trial`
     int32_t finished;
     int32_t pad;
 };
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
     using R = Refiner<EST>;
     constexpr int K = R::K;
     constexpr int NT = NormalSize<K>::kTotal;
-    constexpr int NV = NT + 2; // + robust cost, + residual count
+    constexpr int NV = NT + 3; // + robust cost, + residual count, + count of non-zero weights
     constexpr int kWaves = kLM2Threads / 64;
     const uint32_t S = gridDim.x, T = gridDim.y, s = blockIdx.x, t = blockIdx.y;
     LMTask &task = tasks[t];
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
     __shared__ RefineCtx ctx;
     __shared__ double sums[NV];
     __shared__ double scratch[kWaves][NV];
-    __shared__ int s_pass; // 0 nothing, 1 residuals(cur), 2 normal equations(cur), 3 residuals(trial)
+    __shared__ int s_pass; // 0 nothing, 1 pass at cur, 3 pass at trial
 
     if (threadIdx.x == 0) {
         if (first) {
@@ -1131,7 +1133,13 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
     if (threadIdx.x == 0) {
         int next = 0;
         bool finish = false;
-        const uint32_t cnt = (st.phase != 0) ? (uint32_t)sums[NT + 1] : 0u;
+        const uint32_t cnt_res = (st.phase != 0) ? (uint32_t)sums[NT + 1] : 0u;
+        const uint32_t cnt_jac = (st.phase != 0) ? (uint32_t)sums[NT + 2] : 0u;
+        auto take_normal = [&]() {
+            for (int i = 0; i < NT; ++i)
+                st.normal[i] = sums[i];
+            st.count = cnt_jac;
+        };
         auto solve_and_step = [&](bool fresh) {
             lm_solve<K>(st.ctl, st.normal, fresh, st.count);
             if (st.ctl.done) {
@@ -1147,30 +1155,28 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
             next = 1;
             st.phase = 1;
             break;
-        case 1:
-            lm_begin(st.ctl, task.opt, sums[NT], cnt);
-            if (st.ctl.done)
+        case 1: // cost and normal equations at the start point
+            lm_begin(st.ctl, task.opt, sums[NT], cnt_res);
+            if (st.ctl.done) {
                 finish = true;
-            else
-                next = 2, st.phase = 2;
+            } else {
+                take_normal();
+                solve_and_step(true);
+            }
             break;
-        case 2:
-            for (int i = 0; i < NT; ++i)
-                st.normal[i] = sums[i];
-            st.count = cnt;
-            solve_and_step(true);
-            break;
-        default:
-            if (lm_update<K>(st.ctl, st.normal, sums[NT], cnt))
+        default: { // cost and (speculative) normal equations at the trial point
+            const bool accepted = lm_update<K>(st.ctl, st.normal, sums[NT], cnt_res); // gradient of the OLD point
+            if (accepted) {
                 for (int i = 0; i < kParamDoubles; ++i)
                     st.cur[i] = st.trial[i];
+                take_normal();
+            }
             if (st.ctl.done)
                 finish = true;
-            else if (st.ctl.rejac)
-                next = 2, st.phase = 2;
             else
-                solve_and_step(false);
+                solve_and_step(accepted);
             break;
+        }
         }
         if (finish) {
             st.finished = 1;
@@ -1196,7 +1202,6 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
     if (pass == 0)
         return;
     const double *p = (pass == 3) ? st.trial : st.cur;
-    const bool jac = pass == 2;
     const uint8_t *mask = task.mask;
     const double pscale = task.point_scale;
     const CameraParams cam = task.cam;
@@ -1206,7 +1211,7 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
     for (int i = 0; i < NT; ++i)
         acc[i] = 0.0;
     double racc = 0.0;
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, cntj = 0;
     const uint32_t per = (pts.n + S - 1) / S;
     const uint32_t i0 = s * per, i1 = min(pts.n, i0 + per);
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += kLM2Threads) {
@@ -1215,68 +1220,53 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
         if constexpr (EST == EST_ABS) {
             const double x = pts.a[0][i] * pscale, y = pts.a[1][i] * pscale;
             const double X = pts.a[2][i], Y = pts.a[3][i], Z = pts.a[4][i];
-            double r0, r1;
-            if (!jac) {
-                if (R::residual(p, ctx, cam, x, y, X, Y, Z, r0, r1)) {
-                    racc += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
-                    cnt++;
-                }
-            } else {
-                double J[2 * K];
-                if (R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J))
-                    accumulate2<K>(acc, loss, r0, r1, J, cnt);
+            double r0, r1, J[2 * K];
+            if (R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J)) {
+                racc += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
+                cnt++;
+                accumulate2<K>(acc, loss, r0, r1, J, cntj);
             }
         } else if constexpr (EST == EST_HOM) {
             const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
-            double f0, f1, g0, g1;
-            if (!jac) {
-                R::residual(ctx, a0, a1, b0, b1, f0, f1, g0, g1);
-                racc += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
-                racc += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
-                cnt += 2;
-            } else {
-                double Jf[2 * K], Jb[2 * K];
-                R::jacobian(ctx, a0, a1, b0, b1, f0, f1, Jf, g0, g1, Jb);
-                accumulate2<K>(acc, loss, f0, f1, Jf, cnt);
-                accumulate2<K>(acc, loss, g0, g1, Jb, cnt);
-            }
+            double f0, f1, g0, g1, Jf[2 * K], Jb[2 * K];
+            R::jacobian(ctx, a0, a1, b0, b1, f0, f1, Jf, g0, g1, Jb);
+            racc += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
+            racc += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
+            cnt += 2;
+            accumulate2<K>(acc, loss, f0, f1, Jf, cntj);
+            accumulate2<K>(acc, loss, g0, g1, Jb, cntj);
         } else {
             const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
-            if (!jac) {
-                const double r = R::residual(ctx, a0, a1, b0, b1);
-                racc += 1.0 * loss_value(loss, r * r);
-                cnt++;
-            } else {
-                double J[K];
-                const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
-                accumulate1<K>(acc, loss, r, J, cnt);
-            }
+            double J[K];
+            const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
+            racc += 1.0 * loss_value(loss, r * r);
+            cnt++;
+            accumulate1<K>(acc, loss, r, J, cntj);
         }
     }
     // workgroup reduction in fixed order (DPP inside the wave, waves 0..3 in sequence), then this slice's partial
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (jac) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const double v = wave_sum_dpp(acc[i]);
-            if (lane == 0)
-                scratch[wave][i] = v;
-        }
+    for (int i = 0; i < NT; ++i) {
+        const double v = wave_sum_dpp(acc[i]);
+        if (lane == 0)
+            scratch[wave][i] = v;
     }
     {
         const double v = wave_sum_dpp(racc);
         const uint32_t c = wave_sum_u32(cnt);
+        const uint32_t cj = wave_sum_u32(cntj);
         if (lane == 0) {
             scratch[wave][NT] = v;
             scratch[wave][NT + 1] = (double)c;
+            scratch[wave][NT + 2] = (double)cj;
         }
     }
     __syncthreads();
     if (threadIdx.x < NV) {
         double v = 0.0;
-        if (jac || threadIdx.x >= NT)
-            for (int w = 0; w < kWaves; ++w)
-                v += scratch[w][threadIdx.x];
+        for (int w = 0; w < kWaves; ++w)
+            v += scratch[w][threadIdx.x];
         pout[threadIdx.x] = v;
     }
 }
@@ -1520,9 +1510,9 @@ hipError_t launch_select_record(const double *score_refined, double incumbent_sc
     return hipGetLastError();
 }
 
-// Multi-workgroup LM (k_lm2): `slices` workgroups per task, 2 * max_iterations + 3 launches.
+// Multi-workgroup LM (k_lm2): `slices` workgroups per task, max_iterations + 2 launches.
 size_t lm2_state_bytes(uint32_t num_tasks) { return sizeof(LM2State) * 2 * (size_t)num_tasks; }
-size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices) { return sizeof(double) * 2 * (size_t)num_tasks * slices * 46; }
+size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices) { return sizeof(double) * 2 * (size_t)num_tasks * slices * 48; }
 hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, uint32_t slices,
                       uint32_t max_iterations, void *states, double *partials, hipStream_t stream) {
     if (num_tasks == 0)
@@ -1530,7 +1520,7 @@ hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_
     if (est == EST_REL)
         return hipErrorInvalidValue; // the relative-pose LO (pre-filter, tangent basis) stays on k_lm
     const dim3 grid(slices, num_tasks), block(kLM2Threads);
-    const uint32_t launches = 2 * max_iterations + 3;
+    const uint32_t launches = max_iterations + 2;
     for (uint32_t l = 0; l < launches; ++l) {
         switch (est) {
         case EST_ABS:

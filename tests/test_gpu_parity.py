@@ -377,10 +377,11 @@ def test_estimate_batch_matches_single_calls(gpu):
             assert info["inliers"] == ref_info["inliers"]
 
 
-def test_latency_mode_multi_workgroup_lm(gpu):
-    """POSELIB_AMD_LATENCY_MODE=1 runs the LO of large homography / fundamental problems through k_lm2 (one task
-    spread over several workgroups, one launch per LM half-step).  It has to reproduce the oracle like the default
-    single-workgroup LM; run in a subprocess because the setting is read once per process."""
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_multi_workgroup_and_single_workgroup_lm(gpu, mode):
+    """The LO of large homography / fundamental problems runs through k_lm2 by default (one task spread over several
+    workgroups, one launch per LM iteration); POSELIB_AMD_LATENCY_MODE=0 keeps every task on one workgroup (k_lm).
+    Both have to reproduce the oracle; run in subprocesses because the setting is read once per process."""
     import os
     import subprocess
     import sys
@@ -402,7 +403,7 @@ for gen, fn, ofn, seed in ((synth.homography_scene, P.estimate_homography, O.est
     assert min(np.linalg.norm(A - B), np.linalg.norm(A + B)) < 1e-6
 print("latency mode ok")
 """
-    env = dict(os.environ, POSELIB_AMD_LATENCY_MODE="1")
+    env = dict(os.environ, POSELIB_AMD_LATENCY_MODE=mode)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "latency mode ok" in out.stdout, out.stdout + out.stderr
