@@ -109,6 +109,7 @@ struct Context {
     DevBuf positions, samples, shadow16, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
     DevBuf shadow, compact64;
     DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
+    DevBuf gen_stage; // workspace of the staged 5-point generator
     DevBuf iota; // iota[i] = i: a device-resident "number of hypotheses" for launches whose count the host knows
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
     HostBuf h_rec_meta;
@@ -834,6 +835,10 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
                 ga.models = c->models.as<double>();
                 ga.num_models = c->num_models.as<uint32_t>();
                 ga.real_focal_check = o->real_focal_check;
+                if (const size_t sb = generate_stage_bytes(kind, Bl)) {
+                    HIP_TRY(c->gen_stage.ensure(sb));
+                    ga.stage = c->gen_stage.p;
+                }
                 HIP_TRY(launch_generate(kind, ga, c->stream));
                 HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, c->blk_tot.as<uint32_t>(), c->slots.as<uint32_t>(),
                                         c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,

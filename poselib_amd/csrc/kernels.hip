@@ -146,6 +146,130 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs
     g.num_models[it] = (uint32_t)n;
 }
 
+// ---- 5-point generator in three stages (relative pose) -------------------------------------------------------------
+// One lane per iteration in every stage; the stages hand their results over in a structure-of-arrays workspace
+// (rel_stage: [field][iteration], coalesced), so that no kernel carries the live state of another: the 10 x 20
+// elimination of the front end, the Sturm chain of the root finder and the pose recovery each get the register file
+// to themselves.  The root finder keeps its per-level notes in LDS (one column per lane).
+constexpr int kRelNb = 36, kRelAz = 39, kRelRoots = 10;
+__host__ __device__ inline size_t rel_stage_doubles(size_t cap) { return (size_t)(kRelNb + kRelAz + kRelRoots) * cap; }
+
+template <int K> __device__ __forceinline__ void sample_of_iteration(const GenerateArgs &g, uint32_t it, uint32_t *idx) {
+    if (g.samples) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            idx[k] = g.samples[(size_t)it * K + k];
+    } else {
+        draw_sample<K>(g.seed, g.pos_base + g.positions[it], g.pts.n, idx);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rel_front(GenerateArgs g, double *stage, uint32_t cap) {
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= g.num_iters)
+        return;
+    uint32_t idx[5];
+    sample_of_iteration<5>(g, it, idx);
+    Vec3 b1[5], b2[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        b1[k] = bearing(g.pts.a[0][idx[k]], g.pts.a[1][idx[k]]);
+        b2[k] = bearing(g.pts.a[2][idx[k]], g.pts.a[3][idx[k]]);
+    }
+    double nb[36], Az[3][13];
+    rel5_front(b1, b2, nb, Az);
+    double *snb = stage, *saz = stage + (size_t)kRelNb * cap;
+#pragma unroll
+    for (int e = 0; e < 36; ++e)
+        snb[(size_t)e * cap + it] = nb[e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 13; ++k)
+            saz[(size_t)(i * 13 + k) * cap + it] = Az[i][k];
+}
+
+struct SturmWorkLds { // one column per lane of [slot][64] LDS arrays
+    double *sa, *sb, *la, *lb;
+    unsigned *si;
+    __device__ void push(int i, double a, double b, unsigned info) { sa[i * 64] = a, sb[i * 64] = b, si[i * 64] = info; }
+    __device__ void pop(int i, double &a, double &b, unsigned &info) const { a = sa[i * 64], b = sb[i * 64], info = si[i * 64]; }
+    __device__ void leaf_set(int i, double a, double b) { la[i * 64] = a, lb[i * 64] = b; }
+    __device__ void leaf_get(int i, double &a, double &b) const { a = la[i * 64], b = lb[i * 64]; }
+};
+
+__global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *stage, uint32_t cap, uint32_t *nroots_out) {
+    __shared__ double s_stack_a[kSturmSlots][64], s_stack_b[kSturmSlots][64], s_leaf_a[kSturmSlots][64],
+        s_leaf_b[kSturmSlots][64];
+    __shared__ unsigned s_stack_i[kSturmSlots][64];
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= num_iters)
+        return;
+    const double *saz = stage + (size_t)kRelNb * cap;
+    double Az[3][13];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 13; ++k)
+            Az[i][k] = saz[(size_t)(i * 13 + k) * cap + it];
+    double c[11];
+    rel5_poly(Az, c);
+    double roots[10];
+    SturmWorkLds work{&s_stack_a[0][threadIdx.x], &s_stack_b[0][threadIdx.x], &s_leaf_a[0][threadIdx.x],
+                      &s_leaf_b[0][threadIdx.x], &s_stack_i[0][threadIdx.x]};
+    const int n = sturm_roots_deg10(c, roots, work);
+    double *sroots = stage + (size_t)(kRelNb + kRelAz) * cap;
+#pragma unroll
+    for (int r = 0; r < 10; ++r)
+        if (r < n)
+            sroots[(size_t)r * cap + it] = roots[r];
+    nroots_out[it] = (uint32_t)n;
+}
+
+__global__ __launch_bounds__(64) void k_rel_poses(GenerateArgs g, const double *stage, uint32_t cap, const uint32_t *nroots_in) {
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= g.num_iters)
+        return;
+    uint32_t idx[5];
+    sample_of_iteration<5>(g, it, idx);
+    Vec3 b1[5], b2[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        b1[k] = bearing(g.pts.a[0][idx[k]], g.pts.a[1][idx[k]]);
+        b2[k] = bearing(g.pts.a[2][idx[k]], g.pts.a[3][idx[k]]);
+    }
+    const double *snb = stage, *saz = stage + (size_t)kRelNb * cap, *sroots = stage + (size_t)(kRelNb + kRelAz) * cap;
+    double nb[36], Az[3][13];
+#pragma unroll
+    for (int e = 0; e < 36; ++e)
+        nb[e] = snb[(size_t)e * cap + it];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 13; ++k)
+            Az[i][k] = saz[(size_t)(i * 13 + k) * cap + it];
+    const int ne = (int)nroots_in[it];
+    double *rec = g.models + (size_t)it * g.slots_per_iter * kModelStride;
+    const int max_out = (int)g.slots_per_iter;
+    int n = 0;
+    for (int s = 0; s < ne; ++s) { // relpose_5pt_records, root by root
+        Mat3 E;
+        rel5_essential_at_root(nb, Az, sroots[(size_t)s * cap + it], E);
+        PoseQT cand[4];
+        const int nc = motion_from_essential<5>(E, b1, b2, cand);
+        for (int k = 0; k < nc; ++k) {
+            if (n < max_out)
+                store_pose_model_q(rec + n * kModelStride, cand[k].q, cand[k].t, true);
+            ++n;
+        }
+    }
+    if (n > max_out) {
+        g.ctl->gen_overflow = 1;
+        n = 0;
+    }
+    g.num_models[it] = (uint32_t)n;
+}
+
 // Bare solver batch: one lane per minimal problem, AoS input exactly as the reference API takes it.
 template <int EST> __global__ __launch_bounds__(64) void k_solve_batch(const double *in, uint32_t np, double *models,
                                                                        uint32_t *num_models) {
@@ -1294,10 +1418,21 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
         return hipErrorInvalidValue;                                                                                   \
     }
 
+size_t generate_stage_bytes(int est, uint32_t num_iters) {
+    return est == EST_REL ? sizeof(double) * rel_stage_doubles(num_iters) + sizeof(uint32_t) * (size_t)num_iters : 0;
+}
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream) {
     if (a.num_iters == 0)
         return hipSuccess;
     const dim3 grid((a.num_iters + 63) / 64), block(64);
+    if (est == EST_REL && a.stage) { // three stages over a structure-of-arrays workspace
+        double *stage = static_cast<double *>(a.stage);
+        uint32_t *nroots = reinterpret_cast<uint32_t *>(stage + rel_stage_doubles(a.num_iters));
+        k_rel_front<<<grid, block, 0, stream>>>(a, stage, a.num_iters);
+        k_rel_roots<<<grid, block, 0, stream>>>(a.num_iters, stage, a.num_iters, nroots);
+        k_rel_poses<<<grid, block, 0, stream>>>(a, stage, a.num_iters, nroots);
+        return hipGetLastError();
+    }
     PL_DISPATCH_EST(est, k_generate<E><<<grid, block, 0, stream>>>(a));
     return hipGetLastError();
 }

@@ -40,6 +40,7 @@ struct GenerateArgs {
     double *models;            // [num_iters * slots_per_iter] records of kModelStride doubles
     uint32_t *num_models;      // [num_iters]
     int32_t real_focal_check;  // fundamental only
+    void *stage = nullptr;     // relative pose: workspace of generate_stage_bytes(); nullptr = single-kernel generator
 };
 
 struct ScoreArgs {
@@ -100,6 +101,7 @@ struct RecordMeta {
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream);
+size_t generate_stage_bytes(int est, uint32_t num_iters); // workspace of the staged 5-point generator (0: none)
 // Front-end pre-processing on the device (robust.cc:40-46, 286-292; utils.cc:584-644 per-point part): AoS user
 // buffers -> the problem's SoA block, with per-point un-projection (modes 0, 1) or the affine normalisation whose
 // centroid / scale the host has summed sequentially (mode 2; the two reductions of normalize_points are order

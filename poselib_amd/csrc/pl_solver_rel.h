@@ -164,79 +164,147 @@ PL_HD void sturm_polish(const Sturm10 &S, double a, double b, double *roots, int
     roots[n++] = x;
 }
 
-// Real roots of c[0] + c[1] z + ... + c[10] z^10, in the order the reference's recursion emits them.
-PL_HD int sturm_roots_deg10(const double *coef, double *roots) {
+// Work space of the root isolation: a stack of deferred right halves and the list of leaf intervals, both tiny (a
+// deferred half is kept only if it can still produce a root, so at most ten are alive).  The host build and the bare
+// solver entry points keep it in local arrays; the batched generator keeps it in LDS, one column per lane
+// (kernels.hip), so that nothing of the root finder lives in scratch memory.
+constexpr int kSturmSlots = 12;
+struct SturmWorkLocal {
+    double sa[kSturmSlots], sb[kSturmSlots], la[kSturmSlots], lb[kSturmSlots];
+    unsigned si[kSturmSlots];
+    PL_HD void push(int i, double a, double b, unsigned info) { sa[i] = a, sb[i] = b, si[i] = info; }
+    PL_HD void pop(int i, double &a, double &b, unsigned &info) const { a = sa[i], b = sb[i], info = si[i]; }
+    PL_HD void leaf_set(int i, double a, double b) { la[i] = a, lb[i] = b; }
+    PL_HD void leaf_get(int i, double &a, double &b) const { a = la[i], b = lb[i]; }
+};
+
+// Real roots of c[0] + c[1] z + ... + c[10] z^10, in the order the reference's recursion emits them (depth first,
+// left half first: sturm.h:210-231).  Two phases so that the lanes of a wavefront stay together: (1) the bisection
+// only records its leaves - intervals narrower than tol (the reference reports their right end as a root whatever
+// the sign-variation count says) and intervals holding exactly one root - in recursion order; (2) the leaves are
+// turned into roots one after the other (Ridders + Newton polish for the isolating intervals).  A right half without
+// a sign variation is deferred only if it is narrower than tol (the one case in which visiting it has an effect).
+template <class Work> PL_HD int sturm_roots_deg10(const double *coef, double *roots, Work &w) {
     constexpr int N = 10;
     const double tol = 1e-10;
     if (coef[N] == 0.0)
         return 0;
     Sturm10 S;
     const double lead_inv = 1.0 / coef[N];
+    PL_UNROLL
     for (int i = 0; i < N; ++i)
         S.f[i] = coef[i] * lead_inv;
     S.f[N] = 1.0;
+    PL_UNROLL
     for (int i = 0; i < N - 1; ++i)
         S.fp[i] = S.f[i + 1] * ((i + 1) / (double)N);
     S.fp[N - 1] = 1.0;
     sturm_build(S);
     double bound = 0;
+    PL_UNROLL
     for (int i = 0; i < N; ++i)
         bound = fmax(bound, fabs(S.f[i]));
     bound = 1.0 + bound;
     const int sa0 = sturm_variations(S, -bound), sb0 = sturm_variations(S, bound);
     if (sa0 - sb0 == 0)
         return 0;
-    // explicit stack of deferred right halves (the reference recurses, depth limit 300; with fp64 an
-    // interval reaches the 1e-10 width long before 96 levels)
-    constexpr int kStack = 96;
-    double st_a[kStack], st_b[kStack];
-    int st_s[kStack]; // sa | sb << 8 | depth << 16
-    int sp = 0;
-    st_a[0] = -bound, st_b[0] = bound, st_s[0] = sa0 | (sb0 << 8);
-    sp = 1;
-    int n = 0;
-    while (sp > 0) {
-        --sp;
-        const double a = st_a[sp], b = st_b[sp];
-        const int sa = st_s[sp] & 0xff, sb = (st_s[sp] >> 8) & 0xff, depth = st_s[sp] >> 16;
-        if (depth > 300)
-            continue;
-        if (b - a < tol) {
-            if (n < N)
-                roots[n++] = b;
-            continue;
-        }
-        const int k = sa - sb;
-        if (k > 1) {
-            const double mid = (a + b) * 0.5;
-            const int sm = sturm_variations(S, mid);
-            if (sp + 2 <= kStack) {
-                st_a[sp] = mid, st_b[sp] = b, st_s[sp] = sm | (sb << 8) | ((depth + 1) << 16);
-                ++sp;
-                st_a[sp] = a, st_b[sp] = mid, st_s[sp] = sa | (sm << 8) | ((depth + 1) << 16);
-                ++sp;
+    // ---- phase 1: leaves in recursion order ----
+    double a = -bound, b = bound;
+    int sa = sa0, sb = sb0, depth = 0;
+    int sp = 0, nleaf = 0;
+    unsigned tiny = 0; // bit i: leaf i is a narrow interval (root = its right end)
+    for (;;) {
+        bool descend = false;
+        if (depth <= 300) { // MAX_STURM_RECURSION_DEPTH_LIMIT
+            if (b - a < tol) {
+                if (nleaf < kSturmSlots) {
+                    w.leaf_set(nleaf, a, b);
+                    tiny |= 1u << nleaf;
+                    ++nleaf;
+                }
+            } else {
+                const int k = sa - sb;
+                if (k > 1) {
+                    const double mid = (a + b) * 0.5;
+                    const int sm = sturm_variations(S, mid);
+                    if ((sm - sb >= 1 || b - mid < tol) && sp < kSturmSlots) { // right half (mid, b): later
+                        w.push(sp, mid, b, (unsigned)sm | ((unsigned)sb << 4) | ((unsigned)(depth + 1) << 8));
+                        ++sp;
+                    }
+                    b = mid; // left half (a, mid): now
+                    sb = sm;
+                    depth += 1;
+                    descend = true;
+                } else if (k == 1) {
+                    if (nleaf < kSturmSlots) {
+                        w.leaf_set(nleaf, a, b);
+                        ++nleaf;
+                    }
+                }
             }
-        } else if (k == 1) {
-            if (n < N)
-                sturm_polish(S, a, b, roots, n, tol);
+        }
+        if (descend)
+            continue;
+        if (sp == 0)
+            break;
+        --sp;
+        unsigned info;
+        w.pop(sp, a, b, info);
+        sa = (int)(info & 0xfu);
+        sb = (int)((info >> 4) & 0xfu);
+        depth = (int)(info >> 8);
+    }
+    // ---- phase 2: leaves -> roots ----
+    int n = 0;
+    for (int i = 0; i < nleaf; ++i) {
+        double la, lb;
+        w.leaf_get(i, la, lb);
+        if (n < N) {
+            if ((tiny >> i) & 1u)
+                roots[n++] = lb;
+            else
+                sturm_polish(S, la, lb, roots, n, tol);
         }
     }
     return n;
+}
+PL_HD int sturm_roots_deg10(const double *coef, double *roots) {
+    SturmWorkLocal w;
+    return sturm_roots_deg10(coef, roots, w);
 }
 
 // =============================================================================== null space
 // Orthonormal basis of the complement of span(columns of A); A is 9 x COLS column-major.
 // basis: 9 x (9-COLS), column-major.
+// Every array index below is a compile-time constant once the loops are unrolled - pivot rows / columns are swapped
+// by comparison-selected exchanges, never through a run-time index - so that the device keeps the matrix in
+// registers instead of scratch memory.
+PL_HD void cswap(bool sw, double &a, double &b) {
+    const double x = a, y = b;
+    a = sw ? y : x;
+    b = sw ? x : y;
+}
 template <int COLS> PL_HD void complement_basis9(double *qr /* 9*COLS, destroyed */, double *basis) {
     constexpr int ROWS = 9;
     double tau[COLS];
     int rowswap[COLS];
+    PL_UNROLL
+    for (int i = 0; i < COLS; ++i) {
+        tau[i] = 0;
+        rowswap[i] = i;
+    }
     double biggest = 0;
     const double precision = 2.220446049250313e-16 * COLS;
+    bool live = true; // false once the remaining corner is negligible (the reference breaks out of the loop)
+    PL_UNROLL
     for (int k = 0; k < COLS; ++k) {
+        if (!live)
+            continue;
         int pr = k, pc = k;
         double best = fabs(qr[k * ROWS + k]);
+        PL_UNROLL
         for (int c = k; c < COLS; ++c)
+            PL_UNROLL
             for (int r = k; r < ROWS; ++r) {
                 const double v = fabs(qr[c * ROWS + r]);
                 if (v > best) {
@@ -248,26 +316,26 @@ template <int COLS> PL_HD void complement_basis9(double *qr /* 9*COLS, destroyed
         if (k == 0)
             biggest = best;
         if (best <= biggest * precision) {
-            for (int i = k; i < COLS; ++i) {
-                rowswap[i] = i;
-                tau[i] = 0;
-            }
-            break;
+            live = false;
+            continue;
         }
         rowswap[k] = pr;
-        if (pr != k)
-            for (int c = k; c < COLS; ++c) {
-                const double t = qr[c * ROWS + k];
-                qr[c * ROWS + k] = qr[c * ROWS + pr];
-                qr[c * ROWS + pr] = t;
-            }
-        if (pc != k)
-            for (int r = 0; r < ROWS; ++r) {
-                const double t = qr[k * ROWS + r];
-                qr[k * ROWS + r] = qr[pc * ROWS + r];
-                qr[pc * ROWS + r] = t;
-            }
+        PL_UNROLL
+        for (int r = k + 1; r < ROWS; ++r) {
+            const bool sw = pr == r;
+            PL_UNROLL
+            for (int c = k; c < COLS; ++c)
+                cswap(sw, qr[c * ROWS + k], qr[c * ROWS + r]);
+        }
+        PL_UNROLL
+        for (int cc = k + 1; cc < COLS; ++cc) {
+            const bool sw = pc == cc;
+            PL_UNROLL
+            for (int r = 0; r < ROWS; ++r)
+                cswap(sw, qr[k * ROWS + r], qr[cc * ROWS + r]);
+        }
         double tail_sq = 0;
+        PL_UNROLL
         for (int r = k + 1; r < ROWS; ++r)
             tail_sq += qr[k * ROWS + r] * qr[k * ROWS + r];
         const double c0 = qr[k * ROWS + k];
@@ -275,49 +343,59 @@ template <int COLS> PL_HD void complement_basis9(double *qr /* 9*COLS, destroyed
         if (tail_sq <= 2.2250738585072014e-308) {
             tau[k] = 0;
             beta = c0;
+            PL_UNROLL
             for (int r = k + 1; r < ROWS; ++r)
                 qr[k * ROWS + r] = 0;
         } else {
             beta = sqrt(c0 * c0 + tail_sq);
             if (c0 >= 0)
                 beta = -beta;
+            PL_UNROLL
             for (int r = k + 1; r < ROWS; ++r)
                 qr[k * ROWS + r] = qr[k * ROWS + r] / (c0 - beta);
             tau[k] = (beta - c0) / beta;
         }
         qr[k * ROWS + k] = beta;
-        if (tau[k] != 0)
+        if (tau[k] != 0) {
+            PL_UNROLL
             for (int c = k + 1; c < COLS; ++c) {
                 double t = 0;
+                PL_UNROLL
                 for (int r = k + 1; r < ROWS; ++r)
                     t += qr[k * ROWS + r] * qr[c * ROWS + r];
                 t += qr[c * ROWS + k];
                 qr[c * ROWS + k] -= tau[k] * t;
+                PL_UNROLL
                 for (int r = k + 1; r < ROWS; ++r)
                     qr[c * ROWS + r] -= tau[k] * qr[k * ROWS + r] * t;
             }
+        }
     }
     // columns COLS..8 of Q = (P0 H0)(P1 H1)... applied to unit vectors
+    PL_UNROLL
     for (int j = 0; j < ROWS - COLS; ++j) {
         double v[ROWS];
+        PL_UNROLL
         for (int r = 0; r < ROWS; ++r)
             v[r] = (r == COLS + j) ? 1.0 : 0.0;
+        PL_UNROLL
         for (int k = COLS - 1; k >= 0; --k) {
             if (tau[k] != 0) {
                 double t = 0;
+                PL_UNROLL
                 for (int r = k + 1; r < ROWS; ++r)
                     t += qr[k * ROWS + r] * v[r];
                 t += v[k];
                 v[k] -= tau[k] * t;
+                PL_UNROLL
                 for (int r = k + 1; r < ROWS; ++r)
                     v[r] -= tau[k] * qr[k * ROWS + r] * t;
             }
-            if (rowswap[k] != k) {
-                const double t = v[k];
-                v[k] = v[rowswap[k]];
-                v[rowswap[k]] = t;
-            }
+            PL_UNROLL
+            for (int r = k + 1; r < ROWS; ++r)
+                cswap(rowswap[k] == r, v[k], v[r]);
         }
+        PL_UNROLL
         for (int r = 0; r < ROWS; ++r)
             basis[j * ROWS + r] = v[r];
     }
@@ -415,68 +493,94 @@ PL_HD int cubic_index(int q, int l) { // quadratic_q * linear_l
 }
 // acc(quadratic) += s * a(linear) * b(linear)
 PL_HD void mac_lin_lin(double *acc, double s, const double *a, const double *b) {
+    PL_UNROLL
     for (int i = 0; i < 4; ++i)
+        PL_UNROLL
         for (int j = 0; j < 4; ++j)
             acc[quad_index(i, j)] += s * (a[i] * b[j]);
 }
 // acc(cubic) += a(quadratic) * b(linear)
 PL_HD void mac_quad_lin(double *acc, const double *a, const double *b) {
+    PL_UNROLL
     for (int q = 0; q < 10; ++q)
+        PL_UNROLL
         for (int l = 0; l < 4; ++l)
             acc[cubic_index(q, l)] += a[q] * b[l];
 }
 } // namespace detail5
 
-// Returns the number of essential matrices (<= 10); E[i] row-major.
-PL_HD int essential_5pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Eout) {
+// The 5-point solver in three stages (the batched generator runs them as three kernels so that no stage carries the
+// state of another; the bare solver entry points call them back to back):
+//   rel5_front   bearings -> null-space basis nb[36] + the 3 x 3 polynomial matrix Az[3][13]
+//   rel5_poly    Az -> coefficients of the degree-10 determinant      (then sturm_roots_deg10)
+//   rel5_essential_at_root   one real root z -> one essential matrix
+// All array indices are compile-time constants after unrolling (pivot rows are exchanged by comparison-selected
+// swaps): the 10 x 20 elimination stays in registers.
+PL_HD void rel5_front(const Vec3 *x1, const Vec3 *x2, double *nb /* 36: nb[b*9 + e], e = 3*col + row of E */,
+                      double (*Az)[13]) {
     using namespace detail5;
     double A[45];
+    PL_UNROLL
     for (int i = 0; i < 5; ++i) {
         const double a[3] = {x1[i].x, x1[i].y, x1[i].z};
+        PL_UNROLL
         for (int j = 0; j < 3; ++j) {
             A[i * 9 + 3 * j + 0] = a[j] * x2[i].x;
             A[i * 9 + 3 * j + 1] = a[j] * x2[i].y;
             A[i * 9 + 3 * j + 2] = a[j] * x2[i].z;
         }
     }
-    double nb[36]; // nb[b*9 + e], e = 3*col + row of E
     complement_basis9<5>(A, nb);
 
     // E(i,j) as linear form l[0..3] over (x,y,z,1)
     double L[3][3][4];
+    PL_UNROLL
     for (int i = 0; i < 3; ++i)
+        PL_UNROLL
         for (int j = 0; j < 3; ++j)
+            PL_UNROLL
             for (int b = 0; b < 4; ++b)
                 L[i][j][b] = nb[b * 9 + 3 * j + i];
 
     double M[10][20];
+    PL_UNROLL
     for (int r = 0; r < 10; ++r)
+        PL_UNROLL
         for (int c = 0; c < 20; ++c)
             M[r][c] = 0.0;
     // (E E^T - 1/2 tr(E E^T) I) E  -> rows 0..8
     {
         double EEt[3][3][10];
+        PL_UNROLL
         for (int i = 0; i < 3; ++i)
+            PL_UNROLL
             for (int j = i; j < 3; ++j) {
+                PL_UNROLL
                 for (int m = 0; m < 10; ++m)
                     EEt[i][j][m] = 0.0;
+                PL_UNROLL
                 for (int k = 0; k < 3; ++k)
                     mac_lin_lin(EEt[i][j], 1.0, L[i][k], L[j][k]);
             }
+        PL_UNROLL
         for (int m = 0; m < 10; ++m) {
             const double h = 0.5 * (EEt[0][0][m] + EEt[1][1][m] + EEt[2][2][m]);
             EEt[0][0][m] -= h;
             EEt[1][1][m] -= h;
             EEt[2][2][m] -= h;
         }
+        PL_UNROLL
         for (int i = 0; i < 3; ++i)
+            PL_UNROLL
             for (int j = 0; j < 3; ++j)
+                PL_UNROLL
                 for (int k = 0; k < 3; ++k)
                     mac_quad_lin(M[3 * i + j], (i <= k) ? EEt[i][k] : EEt[k][i], L[k][j]);
     }
     // det(E) -> row 9
     {
         double m0[10], m1[10], m2[10];
+        PL_UNROLL
         for (int m = 0; m < 10; ++m)
             m0[m] = m1[m] = m2[m] = 0.0;
         mac_lin_lin(m0, 1.0, L[0][1], L[1][2]);
@@ -491,38 +595,50 @@ PL_HD int essential_5pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Eout) {
     }
 
     // X = M[:, :10]^-1 M[:, 10:]; only rows 4..9 of X are needed.  LU with partial pivoting, in place.
+    PL_UNROLL
     for (int k = 0; k < 10; ++k) {
         int piv = k;
         double best = fabs(M[k][k]);
+        PL_UNROLL
         for (int i = k + 1; i < 10; ++i)
             if (fabs(M[i][k]) > best) {
                 best = fabs(M[i][k]);
                 piv = i;
             }
-        if (piv != k)
-            for (int j = 0; j < 20; ++j) {
-                const double t = M[k][j];
-                M[k][j] = M[piv][j];
-                M[piv][j] = t;
-            }
-        if (M[k][k] != 0.0)
+        PL_UNROLL
+        for (int i = k + 1; i < 10; ++i) {
+            const bool sw = piv == i;
+            PL_UNROLL
+            for (int j = 0; j < 20; ++j)
+                cswap(sw, M[k][j], M[i][j]);
+        }
+        if (M[k][k] != 0.0) {
+            PL_UNROLL
             for (int i = k + 1; i < 10; ++i)
                 M[i][k] /= M[k][k];
+        }
+        PL_UNROLL
         for (int i = k + 1; i < 10; ++i) {
             const double f = M[i][k];
+            PL_UNROLL
             for (int j = k + 1; j < 10; ++j)
                 M[i][j] -= f * M[k][j];
         }
     }
+    PL_UNROLL
     for (int c = 10; c < 20; ++c) {
+        PL_UNROLL
         for (int i = 1; i < 10; ++i) {
             double s = M[i][c];
+            PL_UNROLL
             for (int j = 0; j < i; ++j)
                 s -= M[i][j] * M[j][c];
             M[i][c] = s;
         }
+        PL_UNROLL
         for (int i = 9; i >= 4; --i) {
             double s = M[i][c];
+            PL_UNROLL
             for (int j = i + 1; j < 10; ++j)
                 s -= M[i][j] * M[j][c];
             M[i][c] = s / M[i][i];
@@ -530,7 +646,7 @@ PL_HD int essential_5pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Eout) {
     }
 
     // px_i(z) x + py_i(z) y + pc_i(z) = 0, highest power first
-    double Az[3][13];
+    PL_UNROLL
     for (int i = 0; i < 3; ++i) {
         const double *ev = &M[4 + 2 * i][10], *od = &M[5 + 2 * i][10];
         Az[i][0] = 0.0 - od[0];
@@ -547,128 +663,146 @@ PL_HD int essential_5pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Eout) {
         Az[i][11] = ev[8] - od[9];
         Az[i][12] = ev[9];
     }
-    // degree-10 determinant by polynomial arithmetic (ascending coefficients)
-    double c[11];
+}
+
+// degree-10 determinant of the 3 x 3 polynomial matrix by polynomial arithmetic (ascending coefficients)
+PL_HD void rel5_poly(const double (*Az)[13], double *c /* 11 */) {
+    PL_UNROLL
     for (int k = 0; k <= 10; ++k)
         c[k] = 0.0;
-    {
-        // term(sign, A_row a (deg da), B_row b (deg db), C_row d (deg dd))
+    // term t: row r takes column perm[t][r]; columns: 0 = px (deg 3, Az[.][0..3]), 1 = py (deg 3, Az[.][4..7]),
+    // 2 = pc (deg 4, Az[.][8..12])
+    PL_UNROLL
+    for (int t = 0; t < 6; ++t) {
         const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
         const double sgn[6] = {1, -1, -1, 1, 1, -1};
-        for (int t = 0; t < 6; ++t) {
-            // columns: 0 = px (deg 3, Az[.][0..3]), 1 = py (deg 3, Az[.][4..7]), 2 = pc (deg 4, Az[.][8..12])
-            // row r takes column perm[t][r]
-            double prod[11];
-            for (int k = 0; k <= 10; ++k)
-                prod[k] = 0.0;
-            // first factor (row 0)
-            double p0[5], p1[5], tmp[9];
-            int d0, d1, d2;
-            double p2[5];
-            auto load = [&](int r, int colsel, double *dst, int &deg) {
-                const int off = (colsel == 0) ? 0 : (colsel == 1) ? 4 : 8;
-                deg = (colsel == 2) ? 4 : 3;
-                for (int k = 0; k <= deg; ++k)
-                    dst[k] = Az[r][off + deg - k]; // ascending
-            };
-            load(0, perm[t][0], p0, d0);
-            load(1, perm[t][1], p1, d1);
-            load(2, perm[t][2], p2, d2);
-            for (int k = 0; k <= d0 + d1; ++k)
-                tmp[k] = 0.0;
-            for (int i = 0; i <= d0; ++i)
-                for (int j = 0; j <= d1; ++j)
+        double prod[11];
+        PL_UNROLL
+        for (int k = 0; k <= 10; ++k)
+            prod[k] = 0.0;
+        double p0[5], p1[5], p2[5], tmp[9];
+        const int s0 = perm[t][0], s1 = perm[t][1], s2 = perm[t][2];
+        const int d0 = (s0 == 2) ? 4 : 3, d1 = (s1 == 2) ? 4 : 3, d2 = (s2 == 2) ? 4 : 3;
+        const int o0 = 4 * s0, o1 = 4 * s1, o2 = 4 * s2; // column offsets 0, 4, 8
+        PL_UNROLL
+        for (int k = 0; k < 5; ++k) {
+            p0[k] = (k <= d0) ? Az[0][o0 + d0 - k] : 0.0; // ascending
+            p1[k] = (k <= d1) ? Az[1][o1 + d1 - k] : 0.0;
+            p2[k] = (k <= d2) ? Az[2][o2 + d2 - k] : 0.0;
+        }
+        PL_UNROLL
+        for (int k = 0; k < 9; ++k)
+            tmp[k] = 0.0;
+        PL_UNROLL
+        for (int i = 0; i < 5; ++i)
+            PL_UNROLL
+            for (int j = 0; j < 5; ++j)
+                if (i <= d0 && j <= d1)
                     tmp[i + j] += p0[i] * p1[j];
-            for (int i = 0; i <= d0 + d1; ++i)
-                for (int j = 0; j <= d2; ++j)
+        PL_UNROLL
+        for (int i = 0; i < 9; ++i)
+            PL_UNROLL
+            for (int j = 0; j < 5; ++j)
+                if (i <= d0 + d1 && j <= d2)
                     prod[i + j] += tmp[i] * p2[j];
-            for (int k = 0; k <= 10; ++k)
-                c[k] += sgn[t] * prod[k];
-        }
+        PL_UNROLL
+        for (int k = 0; k <= 10; ++k)
+            c[k] += sgn[t] * prod[k];
     }
+}
 
-    double roots[10];
-    const int nroots = sturm_roots_deg10(c, roots);
-
-    for (int s = 0; s < nroots; ++s) {
-        const double z = roots[s];
-        const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2;
-        double B[3][2], b[3];
-        for (int i = 0; i < 3; ++i) {
-            B[i][0] = Az[i][0] * z3 + Az[i][1] * z2 + Az[i][2] * z + Az[i][3];
-            B[i][1] = Az[i][4] * z3 + Az[i][5] * z2 + Az[i][6] * z + Az[i][7];
-            b[i] = Az[i][8] * z4 + Az[i][9] * z3 + Az[i][10] * z2 + Az[i][11] * z + Az[i][12];
-        }
-        const double dt = B[0][0] * B[1][1] - B[1][0] * B[0][1];
-        const double idt = 1.0 / dt;
-        double u0 = (B[1][1] * idt) * b[0] + (-B[0][1] * idt) * b[1];
-        double u1 = (-B[1][0] * idt) * b[0] + (B[0][0] * idt) * b[1];
-        if (fabs(B[2][0] * u0 + B[2][1] * u1 - b[2]) > 1e-6) {
-            // least squares over the three rows via the 2x2 normal equations solved by a
-            // pivoted Householder QR (reference: colPivHouseholderQr, relpose_5pt.cc:381)
-            double Q[3][2] = {{B[0][0], B[0][1]}, {B[1][0], B[1][1]}, {B[2][0], B[2][1]}};
-            double rhs[3] = {b[0], b[1], b[2]};
-            const double n0 = Q[0][0] * Q[0][0] + Q[1][0] * Q[1][0] + Q[2][0] * Q[2][0];
-            const double n1 = Q[0][1] * Q[0][1] + Q[1][1] * Q[1][1] + Q[2][1] * Q[2][1];
-            const bool swapc = n1 > n0;
-            if (swapc)
-                for (int i = 0; i < 3; ++i) {
-                    const double t = Q[i][0];
-                    Q[i][0] = Q[i][1];
-                    Q[i][1] = t;
-                }
-            double Rm[2][2] = {{0, 0}, {0, 0}};
-            for (int k = 0; k < 2; ++k) {
-                double tail = 0;
+// one real root of the determinant -> (x, y) by back substitution -> E = normalised null-space combination
+PL_HD void rel5_essential_at_root(const double *nb, const double (*Az)[13], double z, Mat3 &Eout) {
+    const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2;
+    double B[3][2], b[3];
+    PL_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        B[i][0] = Az[i][0] * z3 + Az[i][1] * z2 + Az[i][2] * z + Az[i][3];
+        B[i][1] = Az[i][4] * z3 + Az[i][5] * z2 + Az[i][6] * z + Az[i][7];
+        b[i] = Az[i][8] * z4 + Az[i][9] * z3 + Az[i][10] * z2 + Az[i][11] * z + Az[i][12];
+    }
+    const double dt = B[0][0] * B[1][1] - B[1][0] * B[0][1];
+    const double idt = 1.0 / dt;
+    double u0 = (B[1][1] * idt) * b[0] + (-B[0][1] * idt) * b[1];
+    double u1 = (-B[1][0] * idt) * b[0] + (B[0][0] * idt) * b[1];
+    if (fabs(B[2][0] * u0 + B[2][1] * u1 - b[2]) > 1e-6) {
+        // least squares over the three rows via the 2x2 normal equations solved by a
+        // pivoted Householder QR (reference: colPivHouseholderQr, relpose_5pt.cc:381)
+        double Q[3][2] = {{B[0][0], B[0][1]}, {B[1][0], B[1][1]}, {B[2][0], B[2][1]}};
+        double rhs[3] = {b[0], b[1], b[2]};
+        const double n0 = Q[0][0] * Q[0][0] + Q[1][0] * Q[1][0] + Q[2][0] * Q[2][0];
+        const double n1 = Q[0][1] * Q[0][1] + Q[1][1] * Q[1][1] + Q[2][1] * Q[2][1];
+        const bool swapc = n1 > n0;
+        PL_UNROLL
+        for (int i = 0; i < 3; ++i)
+            cswap(swapc, Q[i][0], Q[i][1]);
+        double Rm[2][2] = {{0, 0}, {0, 0}};
+        PL_UNROLL
+        for (int k = 0; k < 2; ++k) {
+            double tail = 0;
+            PL_UNROLL
+            for (int i = k + 1; i < 3; ++i)
+                tail += Q[i][k] * Q[i][k];
+            const double c0 = Q[k][k];
+            double beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0)
+                beta = -beta;
+            double v[3] = {0, 0, 0};
+            double tau = 0;
+            if (tail > 2.2250738585072014e-308) {
+                v[k] = 1.0;
+                PL_UNROLL
                 for (int i = k + 1; i < 3; ++i)
-                    tail += Q[i][k] * Q[i][k];
-                const double c0 = Q[k][k];
-                double beta = sqrt(c0 * c0 + tail);
-                if (c0 >= 0)
-                    beta = -beta;
-                double v[3] = {0, 0, 0};
-                double tau = 0;
-                if (tail > 2.2250738585072014e-308) {
-                    v[k] = 1.0;
-                    for (int i = k + 1; i < 3; ++i)
-                        v[i] = Q[i][k] / (c0 - beta);
-                    tau = (beta - c0) / beta;
-                } else {
-                    beta = c0;
-                }
-                Rm[k][k] = beta;
-                for (int cc = k + 1; cc < 2; ++cc) {
-                    double t = 0;
-                    for (int i = k; i < 3; ++i)
-                        t += v[i] * Q[i][cc];
-                    for (int i = k; i < 3; ++i)
-                        Q[i][cc] -= tau * v[i] * t;
-                    Rm[k][cc] = Q[k][cc];
-                }
+                    v[i] = Q[i][k] / (c0 - beta);
+                tau = (beta - c0) / beta;
+            } else {
+                beta = c0;
+            }
+            Rm[k][k] = beta;
+            PL_UNROLL
+            for (int cc = k + 1; cc < 2; ++cc) {
                 double t = 0;
+                PL_UNROLL
                 for (int i = k; i < 3; ++i)
-                    t += v[i] * rhs[i];
+                    t += v[i] * Q[i][cc];
+                PL_UNROLL
                 for (int i = k; i < 3; ++i)
-                    rhs[i] -= tau * v[i] * t;
+                    Q[i][cc] -= tau * v[i] * t;
+                Rm[k][cc] = Q[k][cc];
             }
-            double w1 = rhs[1] / Rm[1][1];
-            double w0 = (rhs[0] - Rm[0][1] * w1) / Rm[0][0];
-            if (swapc) {
-                const double t = w0;
-                w0 = w1;
-                w1 = t;
-            }
-            u0 = w0;
-            u1 = w1;
+            double t = 0;
+            PL_UNROLL
+            for (int i = k; i < 3; ++i)
+                t += v[i] * rhs[i];
+            PL_UNROLL
+            for (int i = k; i < 3; ++i)
+                rhs[i] -= tau * v[i] * t;
         }
-        const double x = -u0, y = -u1;
-        const double inv_norm = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) {
-                const int e = 3 * j + i;
-                Eout[s].m[3 * i + j] = (nb[0 * 9 + e] * x + nb[1 * 9 + e] * y + nb[2 * 9 + e] * z + nb[3 * 9 + e]) * inv_norm;
-            }
+        double w1 = rhs[1] / Rm[1][1];
+        double w0 = (rhs[0] - Rm[0][1] * w1) / Rm[0][0];
+        cswap(swapc, w0, w1);
+        u0 = w0;
+        u1 = w1;
     }
+    const double x = -u0, y = -u1;
+    const double inv_norm = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
+    PL_UNROLL
+    for (int j = 0; j < 3; ++j)
+        PL_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            const int e = 3 * j + i;
+            Eout.m[3 * i + j] = (nb[0 * 9 + e] * x + nb[1 * 9 + e] * y + nb[2 * 9 + e] * z + nb[3 * 9 + e]) * inv_norm;
+        }
+}
+
+// Returns the number of essential matrices (<= 10); E[i] row-major.
+PL_HD int essential_5pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Eout) {
+    double nb[36], Az[3][13], c[11], roots[10];
+    rel5_front(x1, x2, nb, Az);
+    rel5_poly(Az, c);
+    const int nroots = sturm_roots_deg10(c, roots);
+    for (int s = 0; s < nroots; ++s)
+        rel5_essential_at_root(nb, Az, roots[s], Eout[s]);
     return nroots;
 }
 
