@@ -630,36 +630,46 @@ struct Improving { // a minimal hypothesis that improved best_minimal_* (candida
     int job = -1;    // index of the refinement job when lo_seed
 };
 
-int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, double *best_record /* in/out */,
-                uint8_t *inliers, pl_ransac_stats *st) {
-    const int kind = p->kind;
-    const uint32_t N = p->n;
-    const int K = sample_size(kind);
-    int MAXM = (kind == EST_REL) ? 8 : max_models(kind); // record slots per iteration (5-pt: grown to 40 on demand)
-    const pl_ransac_options &ro = o->ransac;
-    const double thr2 = o->max_error * o->max_error;
-    const LMOptions lo_opt = lo_options(o->max_error);
-    CameraParams null_cam;
-    std::memset(&null_cam, 0, sizeof(null_cam));
-    null_cam.model_id = CAM_NULL;
+// One LO-RANSAC run (ransac_impl.h:157-201) as batches: `enqueue_batch` puts the whole device pipeline of a batch of
+// iterations on the stream, `collect_improving` synchronises once and lists the hypotheses that improved the running
+// best, `exchange_improving` (sharded runs only) merges the ranks' lists, `refine_and_replay` runs the triggered local
+// optimisations as one batched launch and replays the sequential loop over the batch, event by event.
+struct RansacRun {
+    static constexpr int kRedoBatch = 1; // positive: not an error, the batch has to be evaluated again
 
-    std::memset(st, 0, sizeof(*st));
-    st->model_score = std::numeric_limits<double>::max();
-    const double t_start = now_s();
-
-    auto make_lo_job = [&](const double *rec) {
-        RefineJob j;
-        std::memcpy(j.record_in, rec, sizeof(j.record_in));
-        j.opt = lo_opt;
-        j.cam = null_cam;
-        j.point_scale = 1.0;
-        j.prefilter_thr2 = (kind == EST_REL) ? 5 * thr2 : 0.0; // relative_pose.cc:70
-        return j;
+    // what one batch hands from step to step
+    struct Batch {
+        uint32_t B = 0;                      // iterations of the batch (all ranks)
+        uint32_t lo_g = 0, hi_g = 0, Bl = 0; // this rank's share: iterations [it + lo_g, it + hi_g)
+        size_t hcap = 0;                     // hypothesis capacity of the share
+        BatchCtl *d_ctl = nullptr;
+        uint64_t pos_after = 0; // sampler draws consumed after the batch
+        bool device_positions = false;
+        ProsacSampler prosac_at_batch_start; // a repeated batch draws the same samples
+        bool overflow = false;               // an iteration of the share produced more models than slots
+        uint32_t H = 0, H_local = 0;         // hypotheses of the batch (sharded: over all ranks) / of the share
+        uint64_t b0_inl = 0;                 // state of the sequential loop at the start of the batch
+        double b0_score = 0;
+        const double *h_rec = nullptr; // model records of `imps`, indexed by Improving::gather
     };
 
+    Context *c;
+    const pl_problem *p;
+    const pl_robust_options *o;
+    double *best_record; // in/out
+    uint8_t *inliers;
+    pl_ransac_stats *st;
+    const int kind;
+    const uint32_t N;
+    const int K;
+    int MAXM; // record slots per iteration (5-pt: grown to 40 on demand)
+    const pl_ransac_options &ro;
+    const double thr2;
+    const LMOptions lo_opt;
+    CameraParams null_cam;
     // one problem across several devices (pl_ransac_run_sharded): this rank evaluates a contiguous share of every batch
-    const pl_shard *sh = (g_shard && g_shard->world > 1) ? g_shard : nullptr;
-    const uint32_t G = sh ? (uint32_t)sh->world : 1u, grank = sh ? (uint32_t)sh->rank : 0u;
+    const pl_shard *sh;
+    const uint32_t G, grank;
     struct WireHead {
         uint32_t n, gen_overflow, H, pad;
     };
@@ -668,539 +678,640 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
         double score;
         double model[kModelStride];
     };
-    constexpr uint32_t kWireFirst = 32; // records that travel with the header
+    static constexpr uint32_t kWireFirst = 32; // records that travel with the header
     std::vector<unsigned char> wire_send, wire_recv;
     std::vector<double> merged_models;
+    // state of the sequential loop
+    uint64_t best_min_inl = 0;
+    double best_min_score = std::numeric_limits<double>::max();
+    uint64_t dyn_max;
+    const double log_fail;
+    uint64_t it = 0;  // next iteration to evaluate == iterations replayed so far
+    uint64_t pos = 0; // sampler draws consumed so far
+    bool stopped = false;
+    std::vector<Improving> imps;
+    std::vector<RefineJob> jobs;
+    std::vector<uint32_t> order;
+    const bool host_bookkeeping = std::getenv("POSELIB_AMD_HOST_BOOKKEEPING") != nullptr;
+    bool force_host_positions = false;
+    const bool prosac;
+    ProsacSampler prosac_sampler;
 
-    bool mask_done = false;
-    if (N >= (uint32_t)K) { // ransac_impl.h:161-163
-        uint64_t best_min_inl = 0;
-        double best_min_score = std::numeric_limits<double>::max();
-        uint64_t dyn_max = ro.max_iterations;
-        const double log_fail = std::log(1.0 - ro.success_prob);
-        st->num_inliers = 0;
-
-        auto after_lo = [&](const RefineJob &job) { // ransac_impl.h:138-153
-            st->refinements++;
-            if (job.score < st->model_score) {
-                st->model_score = job.score;
-                st->num_inliers = job.count;
-                std::memcpy(best_record, job.record_out, sizeof(double) * kModelStride);
-            }
-            st->inlier_ratio = static_cast<double>(st->num_inliers) / static_cast<double>(N);
-            dyn_max = dynamic_max_iter(st->num_inliers, N, K, log_fail, ro.dyn_num_trials_mult, ro.min_iterations,
-                                       ro.max_iterations);
-        };
-
-        if (ro.score_initial_model) { // ransac_impl.h:174-176 : one pseudo-iteration with the supplied model
-            HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
-            HIP_TRY(hipMemcpyAsync(c->tmp_model.p, best_record, sizeof(double) * kModelStride, hipMemcpyHostToDevice,
-                                   c->stream));
-            int rc = enqueue_score_records(c, p, c->tmp_model.as<double>(), 1, thr2, false);
-            if (rc != PL_OK)
-                return rc;
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            const uint32_t cnt = c->h_count.as<uint32_t>()[0];
-            const double sc = c->h_score.as<double>()[0];
-            const bool more = cnt > best_min_inl, better = sc < best_min_score;
-            if (more || better) {
-                if (more)
-                    best_min_inl = cnt;
-                if (better)
-                    best_min_score = sc;
-                if (sc < st->model_score) {
-                    st->model_score = sc;
-                    st->num_inliers = cnt;
-                }
-                std::vector<RefineJob> jobs{make_lo_job(best_record)};
-                rc = run_refinements(c, p, jobs, true, thr2);
-                if (rc != PL_OK)
-                    return rc;
-                after_lo(jobs[0]);
-            }
-        }
-
-        // batch capacity: bounded by the scratch the model records need
-        uint64_t grow = std::max<uint64_t>(ro.min_iterations + 2, 512);
-        grow = (grow + 63) / 64 * 64;
-        uint64_t it = 0;   // next iteration to evaluate == iterations replayed so far
-        uint64_t pos = 0;  // sampler draws consumed so far
-        bool stopped = false;
-        std::vector<Improving> imps;
-        std::vector<RefineJob> jobs;
-        std::vector<uint32_t> order;
-        const bool host_bookkeeping = std::getenv("POSELIB_AMD_HOST_BOOKKEEPING") != nullptr;
-        bool force_host_positions = false;
-        const bool prosac = ro.progressive_sampling != 0;
-        ProsacSampler prosac_sampler;
-        if (prosac)
-            prosac_sampler.init(ro.seed, N, K, ro.max_prosac_iterations);
-
-        while (!stopped && it < ro.max_iterations) {
-            if (it > ro.min_iterations && it > dyn_max) { // stop rule at the top of the next iteration (:182)
-                stopped = true;
-                break;
-            }
-            // the loop cannot stop before max(min_iterations, dynamic_max_iter) + 1 iterations
-            uint64_t needed = std::max<uint64_t>(ro.min_iterations, dyn_max) + 1;
-            needed = std::min<uint64_t>(needed, ro.max_iterations);
-            needed = (needed > it) ? needed - it : 1;
-            const uint32_t cap = std::min<uint32_t>(131072u, 1048576u / (uint32_t)MAXM); // bounded by scratch size (<= 200 MB of records)
-            const uint32_t B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
-            grow = std::min<uint64_t>(grow * 2, 131072u);
-
-            // this rank's share of the batch: iterations [it + lo_g, it + hi_g)  (the whole batch on a single device)
-            const uint32_t lo_g = (uint32_t)((uint64_t)B * grank / G), hi_g = (uint32_t)((uint64_t)B * (grank + 1) / G);
-            const uint32_t Bl = hi_g - lo_g;
-
-            // ---- device: positions -> generate -> compact -> score -> finalize -> records ----
-            const size_t hcap = (size_t)std::max<uint32_t>(Bl, 1u) * MAXM;
-            ScoreArgs sa;
-            set_prefilter(sa, p, thr2);
-            const bool prefilter = true; // compact hypothesis stream for the streaming scorer (all estimators)
-            const uint32_t chunks = score_chunks(kind, N, prefilter);
-            if (prefilter) {
-                HIP_TRY(c->shadow.ensure(sizeof(float) * 16 * hcap));
-                HIP_TRY(c->compact64.ensure(sizeof(double) * kModelDoubles * hcap));
-            }
-            HIP_TRY(c->positions.ensure(sizeof(uint32_t) * B));
-            HIP_TRY(c->models.ensure(sizeof(double) * kModelStride * hcap));
-            HIP_TRY(c->num_models.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
-            HIP_TRY(c->slots.ensure(sizeof(uint32_t) * hcap));
-            HIP_TRY(c->offsets.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
-            HIP_TRY(c->blk_tot.ensure(sizeof(uint32_t) * ((Bl + 1023) / 1024 + 1)));
-            HIP_TRY(c->ctl.ensure(sizeof(BatchCtl)));
-            HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * hcap));
-            HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * hcap));
-            HIP_TRY(c->count.ensure(sizeof(uint32_t) * hcap));
-            HIP_TRY(c->score.ensure(sizeof(double) * hcap));
-            HIP_TRY(c->blk_best.ensure((sizeof(uint32_t) + sizeof(double)) * 256 + 64));
-            HIP_TRY(c->rec_meta.ensure(sizeof(RecordMeta) * kRecordCap));
-            HIP_TRY(c->rec_models.ensure(sizeof(double) * kModelStride * kRecordCap));
-            HIP_TRY(c->h_small.ensure(sizeof(BatchCtl) + 64));
-            HIP_TRY(c->h_rec_meta.ensure(sizeof(RecordMeta) * kRecordCap));
-            HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * kRecordCap));
-            BatchCtl *d_ctl = c->ctl.as<BatchCtl>();
-            HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(BatchCtl), c->stream));
-
-            uint64_t pos_after = 0;
-            bool device_positions = !host_bookkeeping && !force_host_positions && !prosac;
-            const ProsacSampler prosac_at_batch_start = prosac_sampler; // a repeated batch draws the same samples
-            if (prosac) {
-                HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * (size_t)B * K));
-                HIP_TRY(c->samples.ensure(sizeof(uint32_t) * (size_t)B * K));
-                uint32_t *hs = c->h_positions.as<uint32_t>();
-                for (uint32_t b = 0; b < B; ++b)
-                    prosac_sampler.generate(hs + (size_t)b * K);
-                pos_after = prosac_sampler.pos;
-                if (Bl)
-                    HIP_TRY(hipMemcpyAsync(c->samples.p, hs + (size_t)lo_g * K, sizeof(uint32_t) * (size_t)Bl * K,
-                                           hipMemcpyHostToDevice, c->stream));
-            }
-            if (device_positions) {
-                // window of draw positions to evaluate: expected draws per iteration (sum N/(N-i)) + slack
-                double per_it = 0;
-                for (int i = 0; i < K; ++i)
-                    per_it += static_cast<double>(N) / static_cast<double>(N - i);
-                const uint64_t M64 = (uint64_t)(B * per_it * 1.05) + 8192;
-                if (M64 > 0x7fffffffull || pos + M64 >= 0xffffffffull) {
-                    device_positions = false;
-                } else {
-                    const uint32_t M = (uint32_t)M64;
-                    HIP_TRY(c->delta.ensure((size_t)M + 64));
-                    HIP_TRY(c->flags.ensure(sizeof(uint64_t) * ((size_t)M / 64 + 2))); // bitmap of redrawing positions
-                    HIP_TRY(launch_sample_positions(K, ro.seed, pos, N, B, M, c->delta.as<uint8_t>(),
-                                                    c->flags.as<uint64_t>(), c->positions.as<uint32_t>(), d_ctl,
-                                                    c->stream));
-                }
-            }
-            if (!device_positions && !prosac) {
-                HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * B));
-                pos_after = sample_positions_k(K, ro.seed, pos, N, B, c->h_positions.as<uint32_t>());
-                if (pos_after - pos >= 0xffffffffull)
-                    return fail(PL_ERR_UNSUPPORTED, "sampler draw window exceeds 32 bits");
-                HIP_TRY(hipMemcpyAsync(c->positions.p, c->h_positions.p, sizeof(uint32_t) * B, hipMemcpyHostToDevice,
-                                       c->stream));
-            }
-            if (Bl > 0) { // (a rank whose share of a short batch is empty only takes part in the exchange)
-                GenerateArgs ga;
-                ga.pts = p->ps;
-                ga.seed = ro.seed;
-                ga.pos_base = pos;
-                ga.positions = c->positions.as<uint32_t>() + lo_g;
-                ga.samples = prosac ? c->samples.as<uint32_t>() : nullptr;
-                ga.num_iters = Bl;
-                ga.slots_per_iter = (uint32_t)MAXM;
-                ga.ctl = d_ctl;
-                ga.models = c->models.as<double>();
-                ga.num_models = c->num_models.as<uint32_t>();
-                ga.real_focal_check = o->real_focal_check;
-                if (const size_t sb = generate_stage_bytes(kind, Bl)) {
-                    HIP_TRY(c->gen_stage.ensure(sb));
-                    ga.stage = c->gen_stage.p;
-                }
-                HIP_TRY(launch_generate(kind, ga, c->stream));
-                HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, c->blk_tot.as<uint32_t>(), c->slots.as<uint32_t>(),
-                                        c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,
-                                        prefilter ? c->compact64.as<double>() : nullptr, d_ctl, c->stream));
-                sa.pts = p->ps;
-                sa.models = ga.models;
-                sa.slots = c->slots.as<uint32_t>();
-                sa.shadow16 = nullptr;
-                if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores
-                    HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
-                    HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), (uint32_t)hcap, sa.pf.g16, sa.pf.c16,
-                                            sa.pf.thr, c->shadow16.p, c->stream));
-                    sa.shadow16 = c->shadow16.p;
-                }
-                sa.shadow = prefilter ? c->shadow.as<float>() : nullptr;
-                sa.compact64 = prefilter ? c->compact64.as<double>() : nullptr;
-                sa.num_hyp = &d_ctl->num_hyp;
-                sa.hyp_capacity = (uint32_t)hcap;
-                sa.thr2 = thr2;
-                sa.part_count = c->part_count.as<uint32_t>();
-                sa.part_score = c->part_score.as<double>();
-                const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, (uint32_t)hcap));
-                HIP_TRY(hipEventRecord(c->ev0, c->stream));
-                HIP_TRY(launch_score(kind, sa, slices, c->stream));
-                HIP_TRY(hipEventRecord(c->ev1, c->stream));
-                FinalizeArgs fa;
-                fa.num_hyp = sa.num_hyp;
-                fa.hyp_capacity = (uint32_t)hcap;
-                fa.chunks = chunks;
-                fa.n_points = N;
-                fa.thr2 = thr2;
-                fa.part_count = sa.part_count;
-                fa.part_score = sa.part_score;
-                fa.count = c->count.as<uint32_t>();
-                fa.score = c->score.as<double>();
-                uint32_t *blk_max = c->blk_best.as<uint32_t>();
-                double *blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
-                HIP_TRY(c->blk_best.ensure(1024 + sizeof(double) * 256));
-                blk_max = c->blk_best.as<uint32_t>();
-                blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
-                const uint32_t init_max = (uint32_t)std::min<uint64_t>(best_min_inl, 0xffffffffu);
-                HIP_TRY(launch_finalize_records(fa, sa.slots, ga.models, blk_max, blk_min, init_max, best_min_score,
-                                                c->rec_meta.as<RecordMeta>(), c->rec_models.as<double>(), kRecordCap, d_ctl,
-                                                c->h_rec_meta.dev<RecordMeta>(), c->h_gather_out.dev<double>(), kRecordFirst,
-                                                c->stream));
-            }
-            BatchCtl *h_ctl = c->h_small.as<BatchCtl>();
-            RecordMeta *h_meta = c->h_rec_meta.as<RecordMeta>(); // the first kRecordFirst records: written by k_records
-            double *h_recm = c->h_gather_out.as<double>();
-            HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(BatchCtl), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (device_positions) {
-                if (h_ctl->orbit_error) { // evaluated window too small / too many redraws: redo this batch
-                    force_host_positions = true;
-                    continue;
-                }
-                pos_after = h_ctl->pos_after;
-            }
-            const bool overflow = h_ctl->gen_overflow != 0;
-            if (overflow && !sh) { // an iteration produced more models than the reserved slots: redo with 40
-                MAXM = max_models(kind);
-                prosac_sampler = prosac_at_batch_start;
-                continue;
-            } // (sharded: the ranks agree on the retry in the exchange below)
-            force_host_positions = false;
-            uint32_t H = h_ctl->num_hyp; // sharded: replaced by the sum over the ranks after the exchange
-            const uint32_t H_local = H;
-            if (Bl > 0 && !overflow) {
-                float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-                st->score_kernel_ms += ms;
-                st->score_kernel_launches++;
-            }
-            const uint64_t b0_inl = best_min_inl; // state of the sequential loop at the start of the batch
-            const double b0_score = best_min_score;
-
-            // ---- pass 1 result: the improving hypotheses, in (iteration, model) order ----
-            imps.clear();
-            const double *h_rec = h_recm;
-            const uint32_t nrec = overflow ? 0u : h_ctl->num_records;
-            if (overflow) {
-                // nothing to report: every rank redoes the batch with more slots per iteration
-            } else if (!host_bookkeeping && nrec <= kRecordCap) {
-                if (nrec > kRecordFirst) {
-                    HIP_TRY(hipMemcpyAsync(h_meta, c->rec_meta.p, sizeof(RecordMeta) * nrec, hipMemcpyDeviceToHost,
-                                           c->stream));
-                    HIP_TRY(hipMemcpyAsync(h_recm, c->rec_models.p, sizeof(double) * kModelStride * nrec,
-                                           hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(hipStreamSynchronize(c->stream));
-                }
-                order.resize(nrec);
-                for (uint32_t a = 0; a < nrec; ++a)
-                    order[a] = a;
-                std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_meta[x].k < h_meta[y].k; });
-                for (uint32_t a = 0; a < nrec; ++a) {
-                    const RecordMeta &m = h_meta[order[a]];
-                    Improving im;
-                    im.iter = (uint32_t)(it + lo_g + m.slot / MAXM);
-                    im.slot = m.slot;
-                    im.count = m.count;
-                    im.score = m.score;
-                    im.lo_seed = false;
-                    im.gather = order[a];
-                    if (!imps.empty() && imps.back().iter != im.iter)
-                        imps.back().lo_seed = true;
-                    imps.push_back(im);
-                    best_min_inl = std::max<uint64_t>(best_min_inl, m.count);
-                    best_min_score = std::min(best_min_score, m.score);
-                }
-                if (!imps.empty())
-                    imps.back().lo_seed = true;
-            } else {
-                // fallback (record list overflow, or POSELIB_AMD_HOST_BOOKKEEPING=1): scan every score on the host
-                HIP_TRY(c->h_num_models.ensure(sizeof(uint32_t) * (Bl + 1)));
-                HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * hcap));
-                HIP_TRY(c->h_score.ensure(sizeof(double) * hcap));
-                uint32_t *h_nm = c->h_num_models.as<uint32_t>();
-                if (Bl)
-                    HIP_TRY(hipMemcpyAsync(h_nm, c->num_models.p, sizeof(uint32_t) * Bl, hipMemcpyDeviceToHost, c->stream));
-                if (H) {
-                    HIP_TRY(hipMemcpyAsync(c->h_count.p, c->count.p, sizeof(uint32_t) * H, hipMemcpyDeviceToHost,
-                                           c->stream));
-                    HIP_TRY(hipMemcpyAsync(c->h_score.p, c->score.p, sizeof(double) * H, hipMemcpyDeviceToHost,
-                                           c->stream));
-                }
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                const uint32_t *h_cnt = c->h_count.as<uint32_t>();
-                const double *h_sc = c->h_score.as<double>();
-                uint32_t k = 0;
-                for (uint32_t i = 0; i < Bl; ++i) {
-                    int last = -1;
-                    for (uint32_t m = 0; m < h_nm[i]; ++m, ++k) {
-                        const bool more = h_cnt[k] > best_min_inl;
-                        const bool better = h_sc[k] < best_min_score;
-                        if (!(more || better))
-                            continue;
-                        if (more)
-                            best_min_inl = h_cnt[k];
-                        if (better)
-                            best_min_score = h_sc[k];
-                        Improving im;
-                        im.iter = (uint32_t)(it + lo_g + i);
-                        im.slot = i * MAXM + m;
-                        im.count = h_cnt[k];
-                        im.score = h_sc[k];
-                        im.lo_seed = false;
-                        im.gather = (uint32_t)imps.size();
-                        imps.push_back(im);
-                        last = (int)imps.size() - 1;
-                    }
-                    if (last >= 0)
-                        imps[last].lo_seed = true;
-                }
-                const uint32_t ni0 = (uint32_t)imps.size();
-                HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * std::max<uint32_t>(ni0, kRecordCap)));
-                double *dst = c->h_gather_out.as<double>();
-                for (uint32_t a = 0; a < ni0; ++a)
-                    HIP_TRY(hipMemcpyAsync(dst + (size_t)a * kModelStride,
-                                           c->models.as<double>() + (size_t)imps[a].slot * kModelStride,
-                                           sizeof(double) * kModelStride, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                h_rec = dst;
-            }
-
-            // ---- sharded: the ONE exchange step of the batch.  Every rank contributes the improving hypotheses of its
-            // range (improving w.r.t. the batch-start state and its own earlier hypotheses - a superset of what the
-            // sequential loop keeps); the merged list is filtered with the true running best, rank by rank, i.e. in
-            // iteration order.  From here on every rank holds the same list and does the same thing. ----
-            if (sh) {
-                const uint32_t nloc = (uint32_t)imps.size();
-                auto pack = [&](unsigned char *dst, uint32_t first, uint32_t count) {
-                    for (uint32_t a = 0; a < count; ++a) {
-                        WireRec w;
-                        std::memset(&w, 0, sizeof(w));
-                        if (first + a < nloc) {
-                            const Improving &im = imps[first + a];
-                            w.iter_off = (uint32_t)(im.iter - it);
-                            w.count = im.count;
-                            w.score = im.score;
-                            std::memcpy(w.model, h_rec + (size_t)im.gather * kModelStride, sizeof(w.model));
-                        }
-                        std::memcpy(dst + (size_t)a * sizeof(WireRec), &w, sizeof(w));
-                    }
-                };
-                const size_t bytes1 = sizeof(WireHead) + (size_t)kWireFirst * sizeof(WireRec);
-                wire_send.assign(bytes1, 0);
-                wire_recv.assign(bytes1 * G, 0);
-                WireHead head{nloc, overflow ? 1u : 0u, H_local, 0u};
-                std::memcpy(wire_send.data(), &head, sizeof(head));
-                pack(wire_send.data() + sizeof(WireHead), 0, kWireFirst);
-                if (sh->allgather(sh->user, wire_send.data(), wire_recv.data(), bytes1) != 0)
-                    return fail(PL_ERR_COMM, "all-gather callback failed");
-                std::vector<WireHead> heads(G);
-                bool any_overflow = false;
-                uint32_t max_n = 0;
-                uint64_t H_sum = 0;
-                for (uint32_t r = 0; r < G; ++r) {
-                    std::memcpy(&heads[r], wire_recv.data() + (size_t)r * bytes1, sizeof(WireHead));
-                    any_overflow = any_overflow || heads[r].gen_overflow != 0;
-                    max_n = std::max(max_n, heads[r].n);
-                    H_sum += heads[r].H;
-                }
-                if (any_overflow) { // some rank ran out of model slots: all ranks redo the batch with 40 per iteration
-                    best_min_inl = b0_inl;
-                    best_min_score = b0_score;
-                    MAXM = max_models(kind);
-                    prosac_sampler = prosac_at_batch_start;
-                    continue;
-                }
-                const unsigned char *recs = wire_recv.data() + sizeof(WireHead);
-                size_t rank_stride = bytes1;
-                std::vector<unsigned char> recv2;
-                if (max_n > kWireFirst) { // rare: a second message with every rank's full list
-                    const size_t bytes2 = (size_t)max_n * sizeof(WireRec);
-                    std::vector<unsigned char> send2(bytes2, 0);
-                    recv2.assign(bytes2 * G, 0);
-                    pack(send2.data(), 0, max_n);
-                    if (sh->allgather(sh->user, send2.data(), recv2.data(), bytes2) != 0)
-                        return fail(PL_ERR_COMM, "all-gather callback failed");
-                    recs = recv2.data();
-                    rank_stride = bytes2;
-                }
-                imps.clear();
-                merged_models.clear();
-                uint64_t run_inl = b0_inl;
-                double run_score = b0_score;
-                for (uint32_t r = 0; r < G; ++r)
-                    for (uint32_t a = 0; a < heads[r].n; ++a) {
-                        WireRec w;
-                        std::memcpy(&w, recs + (size_t)r * rank_stride + (size_t)a * sizeof(WireRec), sizeof(w));
-                        const bool more = w.count > run_inl, better = w.score < run_score; // ransac_impl.h:114-116
-                        if (!(more || better))
-                            continue;
-                        if (more)
-                            run_inl = w.count;
-                        if (better)
-                            run_score = w.score;
-                        Improving im;
-                        im.iter = (uint32_t)(it + w.iter_off);
-                        im.slot = 0;
-                        im.count = w.count;
-                        im.score = w.score;
-                        im.lo_seed = false;
-                        im.gather = (uint32_t)imps.size();
-                        if (!imps.empty() && imps.back().iter != im.iter)
-                            imps.back().lo_seed = true;
-                        imps.push_back(im);
-                        merged_models.insert(merged_models.end(), w.model, w.model + kModelStride);
-                    }
-                if (!imps.empty())
-                    imps.back().lo_seed = true;
-                best_min_inl = run_inl;
-                best_min_score = run_score;
-                h_rec = merged_models.data();
-                H = (uint32_t)std::min<uint64_t>(H_sum, 0xffffffffu);
-            }
-            st->iterations_evaluated += B;
-
-            // ---- device: every triggered LO of the batch as one batched launch, then re-scored ----
-            const uint32_t ni = (uint32_t)imps.size();
-            jobs.clear();
-            for (uint32_t a = 0; a < ni; ++a)
-                if (imps[a].lo_seed) {
-                    imps[a].job = (int)jobs.size();
-                    jobs.push_back(make_lo_job(h_rec + (size_t)imps[a].gather * kModelStride));
-                }
-            if (!jobs.empty()) {
-                int rc = run_refinements(c, p, jobs, true, thr2);
-                if (rc != PL_OK)
-                    return rc;
-            }
-
-            // ---- host pass 2: replay the sequential loop over this batch (ransac_impl.h:180-188).  The stop
-            // rule can only change at LO events, so the replay hops from event to event. ----
-            uint64_t cursor = it;          // next iteration whose stop check has not been made yet
-            uint64_t stop_at = it + B;     // first iteration NOT replayed
-            for (uint32_t a = 0; a < ni; ++a) {
-                const Improving &im = imps[a];
-                const uint64_t first_stop = std::max<uint64_t>(std::max<uint64_t>(ro.min_iterations, dyn_max) + 1, cursor);
-                if (first_stop <= im.iter) {
-                    stopped = true;
-                    stop_at = first_stop;
-                    break;
-                }
-                if (im.score < st->model_score) { // :126-131
-                    st->model_score = im.score;
-                    st->num_inliers = im.count;
-                    std::memcpy(best_record, h_rec + (size_t)im.gather * kModelStride, sizeof(double) * kModelStride);
-                }
-                if (im.lo_seed)
-                    after_lo(jobs[im.job]);
-                cursor = (uint64_t)im.iter + 1;
-            }
-            if (!stopped) {
-                const uint64_t first_stop = std::max<uint64_t>(std::max<uint64_t>(ro.min_iterations, dyn_max) + 1, cursor);
-                if (first_stop < it + B) {
-                    stopped = true;
-                    stop_at = first_stop;
-                }
-            }
-            if (stop_at < it + B) { // hypotheses of the replayed iterations only
-                uint32_t upto = 0;
-                if (stop_at >= it + hi_g) {
-                    upto = H_local;
-                } else if (stop_at > it + lo_g) {
-                    HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it - lo_g), sizeof(uint32_t),
-                                           hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(hipStreamSynchronize(c->stream));
-                }
-                uint64_t total = upto;
-                if (sh) { // sum of the ranks' shares (8 bytes each; once per run)
-                    std::vector<uint64_t> all(G, 0);
-                    if (sh->allgather(sh->user, &total, all.data(), sizeof(uint64_t)) != 0)
-                        return fail(PL_ERR_COMM, "all-gather callback failed");
-                    total = 0;
-                    for (uint32_t r = 0; r < G; ++r)
-                        total += all[r];
-                }
-                st->hypotheses += total;
-            } else {
-                st->hypotheses += H;
-            }
-            it = stop_at;
-            pos = pos_after;
-        }
-        st->iterations = it;
-
-        // ---- final refinement of the best model (ransac_impl.h:190-198; model_score is not updated), chained on the
-        // device with the choice refined / incumbent and the inlier mask of the returned model (ransac.cc:55, 152,
-        // 259, 311): one synchronisation ----
-        {
-            std::vector<RefineJob> fin{make_lo_job(best_record)};
-            MaskTail tail;
-            tail.incumbent_score = st->model_score;
-            tail.incumbent_rec = best_record;
-            tail.thr2 = thr2;
-            tail.host_mask = inliers;
-            int rc = run_refinements(c, p, fin, true, thr2, &tail);
-            if (rc != PL_OK)
-                return rc;
-            st->refinements++;
-            if (fin[0].score < st->model_score) {
-                std::memcpy(best_record, fin[0].record_out, sizeof(double) * kModelStride);
-                st->num_inliers = fin[0].count;
-            }
-            mask_done = true;
-        }
+    RansacRun(Context *c_, const pl_problem *p_, const pl_robust_options *o_, double *best_record_, uint8_t *inliers_,
+              pl_ransac_stats *st_)
+        : c(c_), p(p_), o(o_), best_record(best_record_), inliers(inliers_), st(st_), kind(p_->kind), N(p_->n),
+          K(sample_size(p_->kind)), MAXM((p_->kind == EST_REL) ? 8 : max_models(p_->kind)), ro(o_->ransac),
+          thr2(o_->max_error * o_->max_error), lo_opt(lo_options(o_->max_error)),
+          sh((g_shard && g_shard->world > 1) ? g_shard : nullptr), G(sh ? (uint32_t)sh->world : 1u),
+          grank(sh ? (uint32_t)sh->rank : 0u), dyn_max(o_->ransac.max_iterations),
+          log_fail(std::log(1.0 - o_->ransac.success_prob)), prosac(o_->ransac.progressive_sampling != 0) {
+        std::memset(&null_cam, 0, sizeof(null_cam));
+        null_cam.model_id = CAM_NULL;
     }
 
-    // ---- inlier mask of the returned model when the loop did not run (too few points: ransac_impl.h:161-163) ----
-    if (N > 0 && !mask_done) {
-        HIP_TRY(c->mask.ensure(N));
+    RefineJob make_lo_job(const double *rec) const {
+        RefineJob j;
+        std::memcpy(j.record_in, rec, sizeof(j.record_in));
+        j.opt = lo_opt;
+        j.cam = null_cam;
+        j.point_scale = 1.0;
+        j.prefilter_thr2 = (kind == EST_REL) ? 5 * thr2 : 0.0; // relative_pose.cc:70
+        return j;
+    }
+    void after_lo(const RefineJob &job) { // ransac_impl.h:138-153
+        st->refinements++;
+        if (job.score < st->model_score) {
+            st->model_score = job.score;
+            st->num_inliers = job.count;
+            std::memcpy(best_record, job.record_out, sizeof(double) * kModelStride);
+        }
+        st->inlier_ratio = static_cast<double>(st->num_inliers) / static_cast<double>(N);
+        dyn_max = dynamic_max_iter(st->num_inliers, N, K, log_fail, ro.dyn_num_trials_mult, ro.min_iterations,
+                                   ro.max_iterations);
+    }
+
+    int score_initial_model() {
         HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
         HIP_TRY(hipMemcpyAsync(c->tmp_model.p, best_record, sizeof(double) * kModelStride, hipMemcpyHostToDevice,
                                c->stream));
-        HIP_TRY(launch_mask(kind, p->ps, c->tmp_model.as<double>(), thr2, c->mask.as<uint8_t>(), c->stream));
-        if (inliers)
-            HIP_TRY(hipMemcpyAsync(inliers, c->mask.p, N, hipMemcpyDeviceToHost, c->stream));
+        int rc = enqueue_score_records(c, p, c->tmp_model.as<double>(), 1, thr2, false);
+        if (rc != PL_OK)
+            return rc;
         HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint32_t cnt = c->h_count.as<uint32_t>()[0];
+        const double sc = c->h_score.as<double>()[0];
+        const bool more = cnt > best_min_inl, better = sc < best_min_score;
+        if (more || better) {
+            if (more)
+                best_min_inl = cnt;
+            if (better)
+                best_min_score = sc;
+            if (sc < st->model_score) {
+                st->model_score = sc;
+                st->num_inliers = cnt;
+            }
+            std::vector<RefineJob> jobs{make_lo_job(best_record)};
+            rc = run_refinements(c, p, jobs, true, thr2);
+            if (rc != PL_OK)
+                return rc;
+            after_lo(jobs[0]);
+        }
+        return PL_OK;
     }
-    st->seconds = now_s() - t_start;
-    return PL_OK;
+
+    // ---- device: positions -> generate -> compact -> score -> finalize -> records, all on the stream ----
+    int enqueue_batch(Batch &b) {
+        const uint32_t B = b.B, lo_g = b.lo_g, hi_g = b.hi_g, Bl = b.Bl;
+        (void)B, (void)lo_g, (void)hi_g, (void)Bl;
+        // ---- device: positions -> generate -> compact -> score -> finalize -> records ----
+        const size_t hcap = (size_t)std::max<uint32_t>(Bl, 1u) * MAXM;
+        ScoreArgs sa;
+        set_prefilter(sa, p, thr2);
+        const bool prefilter = true; // compact hypothesis stream for the streaming scorer (all estimators)
+        const uint32_t chunks = score_chunks(kind, N, prefilter);
+        if (prefilter) {
+            HIP_TRY(c->shadow.ensure(sizeof(float) * 16 * hcap));
+            HIP_TRY(c->compact64.ensure(sizeof(double) * kModelDoubles * hcap));
+        }
+        HIP_TRY(c->positions.ensure(sizeof(uint32_t) * B));
+        HIP_TRY(c->models.ensure(sizeof(double) * kModelStride * hcap));
+        HIP_TRY(c->num_models.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
+        HIP_TRY(c->slots.ensure(sizeof(uint32_t) * hcap));
+        HIP_TRY(c->offsets.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
+        HIP_TRY(c->blk_tot.ensure(sizeof(uint32_t) * ((Bl + 1023) / 1024 + 1)));
+        HIP_TRY(c->ctl.ensure(sizeof(BatchCtl)));
+        HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * hcap));
+        HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * hcap));
+        HIP_TRY(c->count.ensure(sizeof(uint32_t) * hcap));
+        HIP_TRY(c->score.ensure(sizeof(double) * hcap));
+        HIP_TRY(c->blk_best.ensure((sizeof(uint32_t) + sizeof(double)) * 256 + 64));
+        HIP_TRY(c->rec_meta.ensure(sizeof(RecordMeta) * kRecordCap));
+        HIP_TRY(c->rec_models.ensure(sizeof(double) * kModelStride * kRecordCap));
+        HIP_TRY(c->h_small.ensure(sizeof(BatchCtl) + 64));
+        HIP_TRY(c->h_rec_meta.ensure(sizeof(RecordMeta) * kRecordCap));
+        HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * kRecordCap));
+        BatchCtl *d_ctl = c->ctl.as<BatchCtl>();
+        HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(BatchCtl), c->stream));
+
+        uint64_t pos_after = 0;
+        bool device_positions = !host_bookkeeping && !force_host_positions && !prosac;
+        const ProsacSampler prosac_at_batch_start = prosac_sampler; // a repeated batch draws the same samples
+        if (prosac) {
+            HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * (size_t)B * K));
+            HIP_TRY(c->samples.ensure(sizeof(uint32_t) * (size_t)B * K));
+            uint32_t *hs = c->h_positions.as<uint32_t>();
+            for (uint32_t b = 0; b < B; ++b)
+                prosac_sampler.generate(hs + (size_t)b * K);
+            pos_after = prosac_sampler.pos;
+            if (Bl)
+                HIP_TRY(hipMemcpyAsync(c->samples.p, hs + (size_t)lo_g * K, sizeof(uint32_t) * (size_t)Bl * K,
+                                       hipMemcpyHostToDevice, c->stream));
+        }
+        if (device_positions) {
+            // window of draw positions to evaluate: expected draws per iteration (sum N/(N-i)) + slack
+            double per_it = 0;
+            for (int i = 0; i < K; ++i)
+                per_it += static_cast<double>(N) / static_cast<double>(N - i);
+            const uint64_t M64 = (uint64_t)(B * per_it * 1.05) + 8192;
+            if (M64 > 0x7fffffffull || pos + M64 >= 0xffffffffull) {
+                device_positions = false;
+            } else {
+                const uint32_t M = (uint32_t)M64;
+                HIP_TRY(c->delta.ensure((size_t)M + 64));
+                HIP_TRY(c->flags.ensure(sizeof(uint64_t) * ((size_t)M / 64 + 2))); // bitmap of redrawing positions
+                HIP_TRY(launch_sample_positions(K, ro.seed, pos, N, B, M, c->delta.as<uint8_t>(),
+                                                c->flags.as<uint64_t>(), c->positions.as<uint32_t>(), d_ctl,
+                                                c->stream));
+            }
+        }
+        if (!device_positions && !prosac) {
+            HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * B));
+            pos_after = sample_positions_k(K, ro.seed, pos, N, B, c->h_positions.as<uint32_t>());
+            if (pos_after - pos >= 0xffffffffull)
+                return fail(PL_ERR_UNSUPPORTED, "sampler draw window exceeds 32 bits");
+            HIP_TRY(hipMemcpyAsync(c->positions.p, c->h_positions.p, sizeof(uint32_t) * B, hipMemcpyHostToDevice,
+                                   c->stream));
+        }
+        if (Bl > 0) { // (a rank whose share of a short batch is empty only takes part in the exchange)
+            GenerateArgs ga;
+            ga.pts = p->ps;
+            ga.seed = ro.seed;
+            ga.pos_base = pos;
+            ga.positions = c->positions.as<uint32_t>() + lo_g;
+            ga.samples = prosac ? c->samples.as<uint32_t>() : nullptr;
+            ga.num_iters = Bl;
+            ga.slots_per_iter = (uint32_t)MAXM;
+            ga.ctl = d_ctl;
+            ga.models = c->models.as<double>();
+            ga.num_models = c->num_models.as<uint32_t>();
+            ga.real_focal_check = o->real_focal_check;
+            if (const size_t sb = generate_stage_bytes(kind, Bl)) {
+                HIP_TRY(c->gen_stage.ensure(sb));
+                ga.stage = c->gen_stage.p;
+            }
+            HIP_TRY(launch_generate(kind, ga, c->stream));
+            HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, c->blk_tot.as<uint32_t>(), c->slots.as<uint32_t>(),
+                                    c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,
+                                    prefilter ? c->compact64.as<double>() : nullptr, d_ctl, c->stream));
+            sa.pts = p->ps;
+            sa.models = ga.models;
+            sa.slots = c->slots.as<uint32_t>();
+            sa.shadow16 = nullptr;
+            if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores
+                HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
+                HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), (uint32_t)hcap, sa.pf.g16, sa.pf.c16,
+                                        sa.pf.thr, c->shadow16.p, c->stream));
+                sa.shadow16 = c->shadow16.p;
+            }
+            sa.shadow = prefilter ? c->shadow.as<float>() : nullptr;
+            sa.compact64 = prefilter ? c->compact64.as<double>() : nullptr;
+            sa.num_hyp = &d_ctl->num_hyp;
+            sa.hyp_capacity = (uint32_t)hcap;
+            sa.thr2 = thr2;
+            sa.part_count = c->part_count.as<uint32_t>();
+            sa.part_score = c->part_score.as<double>();
+            const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, (uint32_t)hcap));
+            HIP_TRY(hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(launch_score(kind, sa, slices, c->stream));
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            FinalizeArgs fa;
+            fa.num_hyp = sa.num_hyp;
+            fa.hyp_capacity = (uint32_t)hcap;
+            fa.chunks = chunks;
+            fa.n_points = N;
+            fa.thr2 = thr2;
+            fa.part_count = sa.part_count;
+            fa.part_score = sa.part_score;
+            fa.count = c->count.as<uint32_t>();
+            fa.score = c->score.as<double>();
+            uint32_t *blk_max = c->blk_best.as<uint32_t>();
+            double *blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
+            HIP_TRY(c->blk_best.ensure(1024 + sizeof(double) * 256));
+            blk_max = c->blk_best.as<uint32_t>();
+            blk_min = reinterpret_cast<double *>(c->blk_best.as<char>() + 1024);
+            const uint32_t init_max = (uint32_t)std::min<uint64_t>(best_min_inl, 0xffffffffu);
+            HIP_TRY(launch_finalize_records(fa, sa.slots, ga.models, blk_max, blk_min, init_max, best_min_score,
+                                            c->rec_meta.as<RecordMeta>(), c->rec_models.as<double>(), kRecordCap, d_ctl,
+                                            c->h_rec_meta.dev<RecordMeta>(), c->h_gather_out.dev<double>(), kRecordFirst,
+                                            c->stream));
+        }
+        b.pos_after = pos_after;
+        b.device_positions = device_positions;
+        b.hcap = hcap;
+        b.d_ctl = d_ctl;
+        b.prosac_at_batch_start = prosac_at_batch_start;
+        return PL_OK;
+    }
+
+    // ---- the one synchronisation of the batch; retry decisions; improving hypotheses of this rank's share ----
+    int collect_improving(Batch &b) {
+        const uint32_t B = b.B, lo_g = b.lo_g, hi_g = b.hi_g, Bl = b.Bl;
+        (void)B, (void)lo_g, (void)hi_g, (void)Bl;
+        const size_t hcap = b.hcap;
+        BatchCtl *const d_ctl = b.d_ctl;
+        uint64_t &pos_after = b.pos_after;
+        const bool device_positions = b.device_positions;
+        const ProsacSampler &prosac_at_batch_start = b.prosac_at_batch_start;
+        (void)hcap;
+        BatchCtl *h_ctl = c->h_small.as<BatchCtl>();
+        RecordMeta *h_meta = c->h_rec_meta.as<RecordMeta>(); // the first kRecordFirst records: written by k_records
+        double *h_recm = c->h_gather_out.as<double>();
+        HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(BatchCtl), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (device_positions) {
+            if (h_ctl->orbit_error) { // evaluated window too small / too many redraws: redo this batch
+                force_host_positions = true;
+                return kRedoBatch;
+            }
+            pos_after = h_ctl->pos_after;
+        }
+        const bool overflow = h_ctl->gen_overflow != 0;
+        if (overflow && !sh) { // an iteration produced more models than the reserved slots: redo with 40
+            MAXM = max_models(kind);
+            prosac_sampler = prosac_at_batch_start;
+            return kRedoBatch;
+        } // (sharded: the ranks agree on the retry in the exchange below)
+        force_host_positions = false;
+        uint32_t H = h_ctl->num_hyp; // sharded: replaced by the sum over the ranks after the exchange
+        const uint32_t H_local = H;
+        if (Bl > 0 && !overflow) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            st->score_kernel_ms += ms;
+            st->score_kernel_launches++;
+        }
+        const uint64_t b0_inl = best_min_inl; // state of the sequential loop at the start of the batch
+        const double b0_score = best_min_score;
+
+        // ---- pass 1 result: the improving hypotheses, in (iteration, model) order ----
+        imps.clear();
+        const double *h_rec = h_recm;
+        const uint32_t nrec = overflow ? 0u : h_ctl->num_records;
+        if (overflow) {
+            // nothing to report: every rank redoes the batch with more slots per iteration
+        } else if (!host_bookkeeping && nrec <= kRecordCap) {
+            if (nrec > kRecordFirst) {
+                HIP_TRY(hipMemcpyAsync(h_meta, c->rec_meta.p, sizeof(RecordMeta) * nrec, hipMemcpyDeviceToHost,
+                                       c->stream));
+                HIP_TRY(hipMemcpyAsync(h_recm, c->rec_models.p, sizeof(double) * kModelStride * nrec,
+                                       hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            order.resize(nrec);
+            for (uint32_t a = 0; a < nrec; ++a)
+                order[a] = a;
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_meta[x].k < h_meta[y].k; });
+            for (uint32_t a = 0; a < nrec; ++a) {
+                const RecordMeta &m = h_meta[order[a]];
+                Improving im;
+                im.iter = (uint32_t)(it + lo_g + m.slot / MAXM);
+                im.slot = m.slot;
+                im.count = m.count;
+                im.score = m.score;
+                im.lo_seed = false;
+                im.gather = order[a];
+                if (!imps.empty() && imps.back().iter != im.iter)
+                    imps.back().lo_seed = true;
+                imps.push_back(im);
+                best_min_inl = std::max<uint64_t>(best_min_inl, m.count);
+                best_min_score = std::min(best_min_score, m.score);
+            }
+            if (!imps.empty())
+                imps.back().lo_seed = true;
+        } else {
+            // fallback (record list overflow, or POSELIB_AMD_HOST_BOOKKEEPING=1): scan every score on the host
+            HIP_TRY(c->h_num_models.ensure(sizeof(uint32_t) * (Bl + 1)));
+            HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * hcap));
+            HIP_TRY(c->h_score.ensure(sizeof(double) * hcap));
+            uint32_t *h_nm = c->h_num_models.as<uint32_t>();
+            if (Bl)
+                HIP_TRY(hipMemcpyAsync(h_nm, c->num_models.p, sizeof(uint32_t) * Bl, hipMemcpyDeviceToHost, c->stream));
+            if (H) {
+                HIP_TRY(hipMemcpyAsync(c->h_count.p, c->count.p, sizeof(uint32_t) * H, hipMemcpyDeviceToHost,
+                                       c->stream));
+                HIP_TRY(hipMemcpyAsync(c->h_score.p, c->score.p, sizeof(double) * H, hipMemcpyDeviceToHost,
+                                       c->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const uint32_t *h_cnt = c->h_count.as<uint32_t>();
+            const double *h_sc = c->h_score.as<double>();
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < Bl; ++i) {
+                int last = -1;
+                for (uint32_t m = 0; m < h_nm[i]; ++m, ++k) {
+                    const bool more = h_cnt[k] > best_min_inl;
+                    const bool better = h_sc[k] < best_min_score;
+                    if (!(more || better))
+                        continue;
+                    if (more)
+                        best_min_inl = h_cnt[k];
+                    if (better)
+                        best_min_score = h_sc[k];
+                    Improving im;
+                    im.iter = (uint32_t)(it + lo_g + i);
+                    im.slot = i * MAXM + m;
+                    im.count = h_cnt[k];
+                    im.score = h_sc[k];
+                    im.lo_seed = false;
+                    im.gather = (uint32_t)imps.size();
+                    imps.push_back(im);
+                    last = (int)imps.size() - 1;
+                }
+                if (last >= 0)
+                    imps[last].lo_seed = true;
+            }
+            const uint32_t ni0 = (uint32_t)imps.size();
+            HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * std::max<uint32_t>(ni0, kRecordCap)));
+            double *dst = c->h_gather_out.as<double>();
+            for (uint32_t a = 0; a < ni0; ++a)
+                HIP_TRY(hipMemcpyAsync(dst + (size_t)a * kModelStride,
+                                       c->models.as<double>() + (size_t)imps[a].slot * kModelStride,
+                                       sizeof(double) * kModelStride, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            h_rec = dst;
+        }
+
+        b.overflow = overflow;
+        b.H = H;
+        b.H_local = H_local;
+        b.b0_inl = b0_inl;
+        b.b0_score = b0_score;
+        b.h_rec = h_rec;
+        return PL_OK;
+    }
+
+    // ---- sharded runs: the ONE exchange step of the batch (all-gather of the ranks' improving hypotheses) ----
+    int exchange_improving(Batch &b) {
+        const bool overflow = b.overflow;
+        const uint32_t H_local = b.H_local;
+        const uint64_t b0_inl = b.b0_inl;
+        const double b0_score = b.b0_score;
+        const ProsacSampler &prosac_at_batch_start = b.prosac_at_batch_start;
+        uint32_t &H = b.H;
+        const double *&h_rec = b.h_rec;
+        // ---- sharded: the ONE exchange step of the batch.  Every rank contributes the improving hypotheses of its
+        // range (improving w.r.t. the batch-start state and its own earlier hypotheses - a superset of what the
+        // sequential loop keeps); the merged list is filtered with the true running best, rank by rank, i.e. in
+        // iteration order.  From here on every rank holds the same list and does the same thing. ----
+        if (sh) {
+            const uint32_t nloc = (uint32_t)imps.size();
+            auto pack = [&](unsigned char *dst, uint32_t first, uint32_t count) {
+                for (uint32_t a = 0; a < count; ++a) {
+                    WireRec w;
+                    std::memset(&w, 0, sizeof(w));
+                    if (first + a < nloc) {
+                        const Improving &im = imps[first + a];
+                        w.iter_off = (uint32_t)(im.iter - it);
+                        w.count = im.count;
+                        w.score = im.score;
+                        std::memcpy(w.model, h_rec + (size_t)im.gather * kModelStride, sizeof(w.model));
+                    }
+                    std::memcpy(dst + (size_t)a * sizeof(WireRec), &w, sizeof(w));
+                }
+            };
+            const size_t bytes1 = sizeof(WireHead) + (size_t)kWireFirst * sizeof(WireRec);
+            wire_send.assign(bytes1, 0);
+            wire_recv.assign(bytes1 * G, 0);
+            WireHead head{nloc, overflow ? 1u : 0u, H_local, 0u};
+            std::memcpy(wire_send.data(), &head, sizeof(head));
+            pack(wire_send.data() + sizeof(WireHead), 0, kWireFirst);
+            if (sh->allgather(sh->user, wire_send.data(), wire_recv.data(), bytes1) != 0)
+                return fail(PL_ERR_COMM, "all-gather callback failed");
+            std::vector<WireHead> heads(G);
+            bool any_overflow = false;
+            uint32_t max_n = 0;
+            uint64_t H_sum = 0;
+            for (uint32_t r = 0; r < G; ++r) {
+                std::memcpy(&heads[r], wire_recv.data() + (size_t)r * bytes1, sizeof(WireHead));
+                any_overflow = any_overflow || heads[r].gen_overflow != 0;
+                max_n = std::max(max_n, heads[r].n);
+                H_sum += heads[r].H;
+            }
+            if (any_overflow) { // some rank ran out of model slots: all ranks redo the batch with 40 per iteration
+                best_min_inl = b0_inl;
+                best_min_score = b0_score;
+                MAXM = max_models(kind);
+                prosac_sampler = prosac_at_batch_start;
+                return kRedoBatch;
+            }
+            const unsigned char *recs = wire_recv.data() + sizeof(WireHead);
+            size_t rank_stride = bytes1;
+            std::vector<unsigned char> recv2;
+            if (max_n > kWireFirst) { // rare: a second message with every rank's full list
+                const size_t bytes2 = (size_t)max_n * sizeof(WireRec);
+                std::vector<unsigned char> send2(bytes2, 0);
+                recv2.assign(bytes2 * G, 0);
+                pack(send2.data(), 0, max_n);
+                if (sh->allgather(sh->user, send2.data(), recv2.data(), bytes2) != 0)
+                    return fail(PL_ERR_COMM, "all-gather callback failed");
+                recs = recv2.data();
+                rank_stride = bytes2;
+            }
+            imps.clear();
+            merged_models.clear();
+            uint64_t run_inl = b0_inl;
+            double run_score = b0_score;
+            for (uint32_t r = 0; r < G; ++r)
+                for (uint32_t a = 0; a < heads[r].n; ++a) {
+                    WireRec w;
+                    std::memcpy(&w, recs + (size_t)r * rank_stride + (size_t)a * sizeof(WireRec), sizeof(w));
+                    const bool more = w.count > run_inl, better = w.score < run_score; // ransac_impl.h:114-116
+                    if (!(more || better))
+                        continue;
+                    if (more)
+                        run_inl = w.count;
+                    if (better)
+                        run_score = w.score;
+                    Improving im;
+                    im.iter = (uint32_t)(it + w.iter_off);
+                    im.slot = 0;
+                    im.count = w.count;
+                    im.score = w.score;
+                    im.lo_seed = false;
+                    im.gather = (uint32_t)imps.size();
+                    if (!imps.empty() && imps.back().iter != im.iter)
+                        imps.back().lo_seed = true;
+                    imps.push_back(im);
+                    merged_models.insert(merged_models.end(), w.model, w.model + kModelStride);
+                }
+            if (!imps.empty())
+                imps.back().lo_seed = true;
+            best_min_inl = run_inl;
+            best_min_score = run_score;
+            h_rec = merged_models.data();
+            H = (uint32_t)std::min<uint64_t>(H_sum, 0xffffffffu);
+        }
+        return PL_OK;
+    }
+
+    // ---- batched local optimisations of the batch, then the replay of the sequential loop over it ----
+    int refine_and_replay(Batch &b) {
+        const uint32_t B = b.B, lo_g = b.lo_g, hi_g = b.hi_g, Bl = b.Bl;
+        (void)B, (void)lo_g, (void)hi_g, (void)Bl;
+        const uint32_t H = b.H, H_local = b.H_local;
+        const double *const h_rec = b.h_rec;
+        const uint64_t pos_after = b.pos_after;
+        st->iterations_evaluated += B;
+
+        // ---- device: every triggered LO of the batch as one batched launch, then re-scored ----
+        const uint32_t ni = (uint32_t)imps.size();
+        jobs.clear();
+        for (uint32_t a = 0; a < ni; ++a)
+            if (imps[a].lo_seed) {
+                imps[a].job = (int)jobs.size();
+                jobs.push_back(make_lo_job(h_rec + (size_t)imps[a].gather * kModelStride));
+            }
+        if (!jobs.empty()) {
+            int rc = run_refinements(c, p, jobs, true, thr2);
+            if (rc != PL_OK)
+                return rc;
+        }
+
+        // ---- host pass 2: replay the sequential loop over this batch (ransac_impl.h:180-188).  The stop
+        // rule can only change at LO events, so the replay hops from event to event. ----
+        uint64_t cursor = it;          // next iteration whose stop check has not been made yet
+        uint64_t stop_at = it + B;     // first iteration NOT replayed
+        for (uint32_t a = 0; a < ni; ++a) {
+            const Improving &im = imps[a];
+            const uint64_t first_stop = std::max<uint64_t>(std::max<uint64_t>(ro.min_iterations, dyn_max) + 1, cursor);
+            if (first_stop <= im.iter) {
+                stopped = true;
+                stop_at = first_stop;
+                break;
+            }
+            if (im.score < st->model_score) { // :126-131
+                st->model_score = im.score;
+                st->num_inliers = im.count;
+                std::memcpy(best_record, h_rec + (size_t)im.gather * kModelStride, sizeof(double) * kModelStride);
+            }
+            if (im.lo_seed)
+                after_lo(jobs[im.job]);
+            cursor = (uint64_t)im.iter + 1;
+        }
+        if (!stopped) {
+            const uint64_t first_stop = std::max<uint64_t>(std::max<uint64_t>(ro.min_iterations, dyn_max) + 1, cursor);
+            if (first_stop < it + B) {
+                stopped = true;
+                stop_at = first_stop;
+            }
+        }
+        if (stop_at < it + B) { // hypotheses of the replayed iterations only
+            uint32_t upto = 0;
+            if (stop_at >= it + hi_g) {
+                upto = H_local;
+            } else if (stop_at > it + lo_g) {
+                HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it - lo_g), sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            uint64_t total = upto;
+            if (sh) { // sum of the ranks' shares (8 bytes each; once per run)
+                std::vector<uint64_t> all(G, 0);
+                if (sh->allgather(sh->user, &total, all.data(), sizeof(uint64_t)) != 0)
+                    return fail(PL_ERR_COMM, "all-gather callback failed");
+                total = 0;
+                for (uint32_t r = 0; r < G; ++r)
+                    total += all[r];
+            }
+            st->hypotheses += total;
+        } else {
+            st->hypotheses += H;
+        }
+        it = stop_at;
+        pos = pos_after;
+        return PL_OK;
+    }
+
+    int run() {
+        std::memset(st, 0, sizeof(*st));
+        st->model_score = std::numeric_limits<double>::max();
+        const double t_start = now_s();
+        bool mask_done = false;
+        if (N >= (uint32_t)K) { // ransac_impl.h:161-163
+            st->num_inliers = 0;
+            if (ro.score_initial_model) {
+                const int rc = score_initial_model();
+                if (rc != PL_OK)
+                    return rc;
+            }
+            // batch capacity: bounded by the scratch the model records need
+            uint64_t grow = std::max<uint64_t>(ro.min_iterations + 2, 512);
+            grow = (grow + 63) / 64 * 64;
+            if (prosac)
+                prosac_sampler.init(ro.seed, N, K, ro.max_prosac_iterations);
+            while (!stopped && it < ro.max_iterations) {
+                if (it > ro.min_iterations && it > dyn_max) { // stop rule at the top of the next iteration (:182)
+                    stopped = true;
+                    break;
+                }
+                // the loop cannot stop before max(min_iterations, dynamic_max_iter) + 1 iterations
+                uint64_t needed = std::max<uint64_t>(ro.min_iterations, dyn_max) + 1;
+                needed = std::min<uint64_t>(needed, ro.max_iterations);
+                needed = (needed > it) ? needed - it : 1;
+                const uint32_t cap = std::min<uint32_t>(131072u, 1048576u / (uint32_t)MAXM); // scratch size (<= 200 MB of records)
+                Batch b;
+                b.B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
+                grow = std::min<uint64_t>(grow * 2, 131072u);
+                // this rank's share of the batch (the whole batch on a single device)
+                b.lo_g = (uint32_t)((uint64_t)b.B * grank / G);
+                b.hi_g = (uint32_t)((uint64_t)b.B * (grank + 1) / G);
+                b.Bl = b.hi_g - b.lo_g;
+                int rc = enqueue_batch(b);
+                if (rc == PL_OK)
+                    rc = collect_improving(b);
+                if (rc == PL_OK && sh)
+                    rc = exchange_improving(b);
+                if (rc == kRedoBatch)
+                    continue;
+                if (rc == PL_OK)
+                    rc = refine_and_replay(b);
+                if (rc != PL_OK)
+                    return rc;
+            }
+            st->iterations = it;
+
+            // ---- final refinement of the best model (ransac_impl.h:190-198; model_score is not updated), chained on the
+            // device with the choice refined / incumbent and the inlier mask of the returned model (ransac.cc:55, 152,
+            // 259, 311): one synchronisation ----
+            {
+                std::vector<RefineJob> fin{make_lo_job(best_record)};
+                MaskTail tail;
+                tail.incumbent_score = st->model_score;
+                tail.incumbent_rec = best_record;
+                tail.thr2 = thr2;
+                tail.host_mask = inliers;
+                int rc = run_refinements(c, p, fin, true, thr2, &tail);
+                if (rc != PL_OK)
+                    return rc;
+                st->refinements++;
+                if (fin[0].score < st->model_score) {
+                    std::memcpy(best_record, fin[0].record_out, sizeof(double) * kModelStride);
+                    st->num_inliers = fin[0].count;
+                }
+                mask_done = true;
+            }
+        }
+
+        // ---- inlier mask of the returned model when the loop did not run (too few points: ransac_impl.h:161-163) ----
+        if (N > 0 && !mask_done) {
+            HIP_TRY(c->mask.ensure(N));
+            HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
+            HIP_TRY(hipMemcpyAsync(c->tmp_model.p, best_record, sizeof(double) * kModelStride, hipMemcpyHostToDevice,
+                                   c->stream));
+            HIP_TRY(launch_mask(kind, p->ps, c->tmp_model.as<double>(), thr2, c->mask.as<uint8_t>(), c->stream));
+            if (inliers)
+                HIP_TRY(hipMemcpyAsync(inliers, c->mask.p, N, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        st->seconds = now_s() - t_start;
+        return PL_OK;
+    }
+};
+
+int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, double *best_record /* in/out */,
+                uint8_t *inliers, pl_ransac_stats *st) {
+    RansacRun run(c, p, o, best_record, inliers, st);
+    return run.run();
 }
 
 int validate_options(const pl_robust_options *o) {
