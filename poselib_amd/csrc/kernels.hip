@@ -151,8 +151,10 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs
 // (rel_stage: [field][iteration], coalesced), so that no kernel carries the live state of another: the 10 x 20
 // elimination of the front end, the Sturm chain of the root finder and the pose recovery each get the register file
 // to themselves.  The root finder keeps its per-level notes in LDS (one column per lane).
-constexpr int kRelNb = 36, kRelAz = 39, kRelRoots = 10;
-__host__ __device__ inline size_t rel_stage_doubles(size_t cap) { return (size_t)(kRelNb + kRelAz + kRelRoots) * cap; }
+constexpr int kRelNb = 36, kRelAz = 39, kRelRoots = 10, kRelLeaves = 2 * kSturmSlots;
+__host__ __device__ inline size_t rel_stage_doubles(size_t cap) {
+    return (size_t)(kRelNb + kRelAz + kRelRoots + kRelLeaves) * cap;
+}
 
 template <int K> __device__ __forceinline__ void sample_of_iteration(const GenerateArgs &g, uint32_t it, uint32_t *idx) {
     if (g.samples) {
@@ -189,18 +191,19 @@ __global__ __launch_bounds__(64) void k_rel_front(GenerateArgs g, double *stage,
             saz[(size_t)(i * 13 + k) * cap + it] = Az[i][k];
 }
 
-struct SturmWorkLds { // one column per lane of [slot][64] LDS arrays
-    double *sa, *sb, *la, *lb;
-    unsigned *si;
+struct SturmWorkDev { // deferred halves: one column per lane of [slot][64] LDS arrays; leaves: the workspace
+    double *sa, *sb;  // LDS
+    unsigned *si;     // LDS
+    double *leaves;   // global, [2 * slot + {0, 1}][cap], this iteration's column
+    size_t cap;
     __device__ void push(int i, double a, double b, unsigned info) { sa[i * 64] = a, sb[i * 64] = b, si[i * 64] = info; }
     __device__ void pop(int i, double &a, double &b, unsigned &info) const { a = sa[i * 64], b = sb[i * 64], info = si[i * 64]; }
-    __device__ void leaf_set(int i, double a, double b) { la[i * 64] = a, lb[i * 64] = b; }
-    __device__ void leaf_get(int i, double &a, double &b) const { a = la[i * 64], b = lb[i * 64]; }
+    __device__ void leaf_set(int i, double a, double b) { leaves[(size_t)(2 * i) * cap] = a, leaves[(size_t)(2 * i + 1) * cap] = b; }
+    __device__ void leaf_get(int i, double &a, double &b) const { a = leaves[(size_t)(2 * i) * cap], b = leaves[(size_t)(2 * i + 1) * cap]; }
 };
 
 __global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *stage, uint32_t cap, uint32_t *nroots_out) {
-    __shared__ double s_stack_a[kSturmSlots][64], s_stack_b[kSturmSlots][64], s_leaf_a[kSturmSlots][64],
-        s_leaf_b[kSturmSlots][64];
+    __shared__ double s_stack_a[kSturmSlots][64], s_stack_b[kSturmSlots][64];
     __shared__ unsigned s_stack_i[kSturmSlots][64];
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     if (it >= num_iters)
@@ -215,8 +218,8 @@ __global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *st
     double c[11];
     rel5_poly(Az, c);
     double roots[10];
-    SturmWorkLds work{&s_stack_a[0][threadIdx.x], &s_stack_b[0][threadIdx.x], &s_leaf_a[0][threadIdx.x],
-                      &s_leaf_b[0][threadIdx.x], &s_stack_i[0][threadIdx.x]};
+    SturmWorkDev work{&s_stack_a[0][threadIdx.x], &s_stack_b[0][threadIdx.x], &s_stack_i[0][threadIdx.x],
+                      stage + (size_t)(kRelNb + kRelAz + kRelRoots) * cap + it, cap};
     const int n = sturm_roots_deg10(c, roots, work);
     double *sroots = stage + (size_t)(kRelNb + kRelAz) * cap;
 #pragma unroll
