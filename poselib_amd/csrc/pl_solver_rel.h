@@ -401,6 +401,105 @@ template <int COLS> PL_HD void complement_basis9(double *qr /* 9*COLS, destroyed
     }
 }
 
+// The same algorithm with run-time row / column indices: fewer instructions (no comparison-selected exchanges), but
+// the matrix lives in scratch memory on the device.  Used by the 7-point solver, whose 9 x 7 matrix would cost more
+// in exchanges than the scratch accesses do (measured: 295 vs 165 us per 100 k samples).
+template <int COLS> PL_HD void complement_basis9_indexed(double *qr /* 9*COLS, destroyed */, double *basis) {
+    constexpr int ROWS = 9;
+    double tau[COLS];
+    int rowswap[COLS];
+    double biggest = 0;
+    const double precision = 2.220446049250313e-16 * COLS;
+    for (int k = 0; k < COLS; ++k) {
+        int pr = k, pc = k;
+        double best = fabs(qr[k * ROWS + k]);
+        for (int c = k; c < COLS; ++c)
+            for (int r = k; r < ROWS; ++r) {
+                const double v = fabs(qr[c * ROWS + r]);
+                if (v > best) {
+                    best = v;
+                    pr = r;
+                    pc = c;
+                }
+            }
+        if (k == 0)
+            biggest = best;
+        if (best <= biggest * precision) {
+            for (int i = k; i < COLS; ++i) {
+                rowswap[i] = i;
+                tau[i] = 0;
+            }
+            break;
+        }
+        rowswap[k] = pr;
+        if (pr != k)
+            for (int c = k; c < COLS; ++c) {
+                const double t = qr[c * ROWS + k];
+                qr[c * ROWS + k] = qr[c * ROWS + pr];
+                qr[c * ROWS + pr] = t;
+            }
+        if (pc != k)
+            for (int r = 0; r < ROWS; ++r) {
+                const double t = qr[k * ROWS + r];
+                qr[k * ROWS + r] = qr[pc * ROWS + r];
+                qr[pc * ROWS + r] = t;
+            }
+        double tail_sq = 0;
+        for (int r = k + 1; r < ROWS; ++r)
+            tail_sq += qr[k * ROWS + r] * qr[k * ROWS + r];
+        const double c0 = qr[k * ROWS + k];
+        double beta;
+        if (tail_sq <= 2.2250738585072014e-308) {
+            tau[k] = 0;
+            beta = c0;
+            for (int r = k + 1; r < ROWS; ++r)
+                qr[k * ROWS + r] = 0;
+        } else {
+            beta = sqrt(c0 * c0 + tail_sq);
+            if (c0 >= 0)
+                beta = -beta;
+            for (int r = k + 1; r < ROWS; ++r)
+                qr[k * ROWS + r] = qr[k * ROWS + r] / (c0 - beta);
+            tau[k] = (beta - c0) / beta;
+        }
+        qr[k * ROWS + k] = beta;
+        if (tau[k] != 0)
+            for (int c = k + 1; c < COLS; ++c) {
+                double t = 0;
+                for (int r = k + 1; r < ROWS; ++r)
+                    t += qr[k * ROWS + r] * qr[c * ROWS + r];
+                t += qr[c * ROWS + k];
+                qr[c * ROWS + k] -= tau[k] * t;
+                for (int r = k + 1; r < ROWS; ++r)
+                    qr[c * ROWS + r] -= tau[k] * qr[k * ROWS + r] * t;
+            }
+    }
+    // columns COLS..8 of Q = (P0 H0)(P1 H1)... applied to unit vectors
+    for (int j = 0; j < ROWS - COLS; ++j) {
+        double v[ROWS];
+        for (int r = 0; r < ROWS; ++r)
+            v[r] = (r == COLS + j) ? 1.0 : 0.0;
+        for (int k = COLS - 1; k >= 0; --k) {
+            if (tau[k] != 0) {
+                double t = 0;
+                for (int r = k + 1; r < ROWS; ++r)
+                    t += qr[k * ROWS + r] * v[r];
+                t += v[k];
+                v[k] -= tau[k] * t;
+                for (int r = k + 1; r < ROWS; ++r)
+                    v[r] -= tau[k] * qr[k * ROWS + r] * t;
+            }
+            if (rowswap[k] != k) {
+                const double t = v[k];
+                v[k] = v[rowswap[k]];
+                v[rowswap[k]] = t;
+            }
+        }
+        for (int r = 0; r < ROWS; ++r)
+            basis[j * ROWS + r] = v[r];
+    }
+}
+
 // =============================================================================== essential -> motion
 struct PoseQT {
     Quat q;
@@ -860,7 +959,7 @@ PL_HD int relpose_7pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Fout) {
         }
     }
     double nb[18];
-    complement_basis9<7>(A, nb);
+    complement_basis9_indexed<7>(A, nb);
     const double *n0 = nb, *n1 = nb + 9;
     // det(x F0 + F1), entries (i,j) <-> vec index 3j+i; each entry = n1 + n0 x (ascending)
     double c[4] = {0, 0, 0, 0};
