@@ -108,7 +108,7 @@ struct Context {
     // batch scratch
     DevBuf positions, samples, shadow16, lm2_states, lm2_partials, raw_a, raw_b, pts_arena, absmax, models, num_models, slots, num_hyp, part_count, part_score, count, score;
     DevBuf shadow, compact64;
-    DevBuf offsets, blk_tot, ctl, blk_best, rec_meta, rec_models, delta, flags;
+    DevBuf offsets, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf gen_stage; // workspace of the staged 5-point generator
     DevBuf iota; // iota[i] = i: a device-resident "number of hypotheses" for launches whose count the host knows
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
@@ -778,8 +778,9 @@ struct RansacRun {
         HIP_TRY(c->num_models.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
         HIP_TRY(c->slots.ensure(sizeof(uint32_t) * hcap));
         HIP_TRY(c->offsets.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
-        HIP_TRY(c->blk_tot.ensure(sizeof(uint32_t) * ((Bl + 1023) / 1024 + 1)));
-        HIP_TRY(c->ctl.ensure(sizeof(BatchCtl)));
+        // control block + models per 1024 iterations (zeroed together, filled by the generator)
+        const size_t ctl_bytes = sizeof(BatchCtl) + sizeof(uint32_t) * ((Bl + 1023) / 1024 + 1);
+        HIP_TRY(c->ctl.ensure(ctl_bytes));
         HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * hcap));
         HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * hcap));
         HIP_TRY(c->count.ensure(sizeof(uint32_t) * hcap));
@@ -791,7 +792,8 @@ struct RansacRun {
         HIP_TRY(c->h_rec_meta.ensure(sizeof(RecordMeta) * kRecordCap));
         HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * kRecordCap));
         BatchCtl *d_ctl = c->ctl.as<BatchCtl>();
-        HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(BatchCtl), c->stream));
+        HIP_TRY(hipMemsetAsync(d_ctl, 0, ctl_bytes, c->stream));
+        uint32_t *const blk_tot = reinterpret_cast<uint32_t *>(d_ctl + 1);
 
         uint64_t pos_after = 0;
         bool device_positions = !host_bookkeeping && !force_host_positions && !prosac;
@@ -845,12 +847,13 @@ struct RansacRun {
             ga.models = c->models.as<double>();
             ga.num_models = c->num_models.as<uint32_t>();
             ga.real_focal_check = o->real_focal_check;
+            ga.blk_tot = blk_tot;
             if (const size_t sb = generate_stage_bytes(kind, Bl)) {
                 HIP_TRY(c->gen_stage.ensure(sb));
                 ga.stage = c->gen_stage.p;
             }
             HIP_TRY(launch_generate(kind, ga, c->stream));
-            HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, c->blk_tot.as<uint32_t>(), c->slots.as<uint32_t>(),
+            HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, blk_tot, true, c->slots.as<uint32_t>(),
                                     c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,
                                     prefilter ? c->compact64.as<double>() : nullptr, d_ctl, c->stream));
             sa.pts = p->ps;

@@ -93,10 +93,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------ generate
-template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs g) {
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
-    if (it >= g.num_iters)
+// Models per block of 1024 iterations (the first level of k_compact2's scan), accumulated by the generators themselves:
+// one integer atomic per wavefront into a table the batch's control-block memset has zeroed.
+__device__ __forceinline__ void count_models_of_wave(const GenerateArgs &g, uint32_t it, uint32_t n) {
+    if (!g.blk_tot)
         return;
+    const uint32_t s = wave_sum_u32(n);
+    if ((threadIdx.x & 63) == 0 && s)
+        atomicAdd(&g.blk_tot[it >> 10], s);
+}
+
+template <int EST> __device__ __forceinline__ uint32_t generate_one(const GenerateArgs &g, uint32_t it) {
     constexpr int K = sample_size(EST);
     constexpr int MAXM = max_models(EST);
     uint32_t idx[K];
@@ -144,7 +151,14 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs
         }
     }
     g.num_models[it] = (uint32_t)n;
+    return (uint32_t)n;
 }
+template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs g) {
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t n = (it < g.num_iters) ? generate_one<EST>(g, it) : 0u;
+    count_models_of_wave(g, it, n); // one call site: the lanes past the last iteration take part with n = 0
+}
+
 
 // ---- 5-point generator in three stages (relative pose) -------------------------------------------------------------
 // One lane per iteration in every stage; the stages hand their results over in a structure-of-arrays workspace
@@ -229,10 +243,8 @@ __global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *st
     nroots_out[it] = (uint32_t)n;
 }
 
-__global__ __launch_bounds__(64) void k_rel_poses(GenerateArgs g, const double *stage, uint32_t cap, const uint32_t *nroots_in) {
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
-    if (it >= g.num_iters)
-        return;
+__device__ __forceinline__ uint32_t rel_poses_one(const GenerateArgs &g, const double *stage, uint32_t cap, const uint32_t *nroots_in,
+                                                  uint32_t it) {
     uint32_t idx[5];
     sample_of_iteration<5>(g, it, idx);
     Vec3 b1[5], b2[5];
@@ -271,6 +283,12 @@ __global__ __launch_bounds__(64) void k_rel_poses(GenerateArgs g, const double *
         n = 0;
     }
     g.num_models[it] = (uint32_t)n;
+    return (uint32_t)n;
+}
+__global__ __launch_bounds__(64) void k_rel_poses(GenerateArgs g, const double *stage, uint32_t cap, const uint32_t *nroots_in) {
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, cap, nroots_in, it) : 0u;
+    count_models_of_wave(g, it, n);
 }
 
 // Bare solver batch: one lane per minimal problem, AoS input exactly as the reference API takes it.

@@ -668,11 +668,12 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
     return hipGetLastError();
 }
 
-hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, uint32_t *slots,
+hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, bool counted, uint32_t *slots,
                            uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,
                            BatchCtl *ctl, hipStream_t stream) {
     const uint32_t nb = (B + 1023) / 1024;
-    k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
+    if (!counted)
+        k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
     k_compact2<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, maxm, blk_tot, slots, offsets, models, shadow_compact,
                                                     compact64, ctl);
     if (shadow_compact && compact64) {

@@ -40,6 +40,7 @@ struct GenerateArgs {
     double *models;            // [num_iters * slots_per_iter] records of kModelStride doubles
     uint32_t *num_models;      // [num_iters]
     int32_t real_focal_check;  // fundamental only
+    uint32_t *blk_tot = nullptr; // optional, zeroed: models per block of 1024 iterations, accumulated by the generator
     void *stage = nullptr;     // relative pose: workspace of generate_stage_bytes(); nullptr = single-kernel generator
 };
 
@@ -146,7 +147,8 @@ hipError_t launch_mask(int est, const PointSet &pts, const double *model, double
 hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t B, uint32_t M,
                                    uint8_t *delta, uint64_t *flagbits /* >= ceil(M / 64) words */, uint32_t *positions,
                                    BatchCtl *ctl, hipStream_t stream);
-hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, uint32_t *slots,
+// counted: blk_tot already holds the per-block model counts (GenerateArgs.blk_tot); otherwise they are counted first
+hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, bool counted, uint32_t *slots,
                            uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,
                            BatchCtl *ctl, hipStream_t stream);
 hipError_t launch_finalize_records(const FinalizeArgs &f, const uint32_t *slots, const double *models,
