@@ -460,20 +460,21 @@ __device__ __forceinline__ v2f bc(float s) { return v2f{s, s}; }
 // Everything is deterministic (no atomics); the summation tree differs from the non-streaming kernels, i.e. scores
 // agree with them to rounding, counts exactly.
 constexpr int kQueueCap = 512; // >= 63 + 64 * 6 entries can be waiting at most
+constexpr int kQueueThreads = 512; // 8 wavefronts share one chunk of correspondences
 
 template <int EST, int P>
-__global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, const float *__restrict__ shadow,
+__global__ __launch_bounds__(kQueueThreads) void k_score_queue(PointSet pts, const float *__restrict__ shadow,
                                                                 const double *__restrict__ compact64,
                                                                 const uint32_t *__restrict__ num_hyp_ptr,
                                                                 uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
                                                                 uint32_t *__restrict__ part_count,
                                                                 double *__restrict__ part_score) {
-    constexpr int kWaves = kScoreThreads / 64;
+    constexpr int kWaves = kQueueThreads / 64;
     constexpr int ND = point_doubles(EST);
     constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 2); // bound terms per point
     constexpr int NPW = 64 * P;                                         // correspondences per chunk
     __shared__ double s_pts[ND][NPW];
-    __shared__ uint32_t s_queue[kWaves][kQueueCap];
+    __shared__ uint16_t s_queue[kWaves][kQueueCap]; // entries: hypothesis of the group << 9 | correspondence of the chunk
     __shared__ double s_acc_s[kWaves][64];
     __shared__ uint32_t s_acc_c[kWaves][64];
     __shared__ uint32_t s_next_group;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
 
     const uint32_t H = *as_uniform(num_hyp_ptr);
     const uniform_f32_ptr sh = as_uniform(shadow);
-    uint32_t *const queue = s_queue[wave];
+    uint16_t *const queue = s_queue[wave];
     double *const acc_s = s_acc_s[wave];
     uint32_t *const acc_c = s_acc_c[wave];
 
@@ -546,8 +547,8 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
         auto drain = [&](uint32_t n) { // n <= 64 waiting pairs, one per lane
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const bool act = (uint32_t)lane < n;
-            const uint32_t e = act ? queue[(qhead + lane) & (kQueueCap - 1)] : 0xffffffffu;
-            const uint32_t g = e >> 16, pi = act ? (e & 0xffffu) : 0u;
+            const uint32_t e = act ? (uint32_t)queue[(qhead + lane) & (kQueueCap - 1)] : 0xffffu;
+            const uint32_t g = e >> 9, pi = act ? (e & 0x1ffu) : 0u;
             double x[ND];
 #pragma unroll
             for (int d = 0; d < ND; ++d)
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_queue(PointSet pts, con
                         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[p] >> 32),
                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m[p], 0u));
                         if ((m[p] >> lane) & 1u)
-                            queue[(qtail + below) & (kQueueCap - 1)] = (g << 16) | (uint32_t)(p * 64 + lane);
+                            queue[(qtail + below) & (kQueueCap - 1)] = (uint16_t)((g << 9) | (uint32_t)(p * 64 + lane));
                         qtail += (uint32_t)__popcll(m[p]);
                     }
                 }
@@ -1555,9 +1556,11 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
         }
     }
     if (streaming) {
+        const dim3 qgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kQueueThreads), chunks);
+        const dim3 qblock(kQueueThreads);
 #define PL_Q_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \
-        k_score_queue<E, PP><<<grid, block, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,      \
+        k_score_queue<E, PP><<<qgrid, qblock, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,      \
                                                          a.thr2, pf, a.part_count, a.part_score);                      \
         break;
         switch (P) {
