@@ -10,7 +10,7 @@
 //       probability ~K^2/2N).  Between flags the orbit advances in strides of K, so one lane only has to hop
 //       from flag to flag (~#duplicates hops per batch) and emit (iteration, position) segments; all lanes
 //       then expand the segments into the per-iteration position table.
-//   k_count_blocks + k_compact2
+//   (k_count_blocks +) k_compact2   [the batched generators count per block themselves: GenerateArgs.blk_tot]
 //       multi-workgroup exclusive scan of models-per-iteration -> hypothesis list in (iteration, model)
 //       order and per-iteration hypothesis offsets.
 //   k_finalize2 + k_records
