@@ -1,4 +1,10 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
-timeout 300 python bench.py --no-cpu-baseline --workload hom_10000 --streams 16 --steps 5 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('hom streams 16 value %.4g launch_ms %.3f'%(d['value'], d['roofline']['avg_launch_ms']))"
+R=$GRAFT_REPO_ROOT
+cp poselib_amd/lib/libposelib_amd.so /tmp/lib_base.so
+cd /tmp && export TMPDIR=/tmp
+for T in base pipe base pipe; do
+  if [ $T != base ]; then cp $R/poselib_amd/lib/variants/lib_$T.so $R/poselib_amd/lib/libposelib_amd.so; else cp /tmp/lib_base.so $R/poselib_amd/lib/libposelib_amd.so; fi
+  rm -rf /tmp/pv; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pv -o p -- python $R/bench.py --no-cpu-baseline --streams 1 --steps 3 > /dev/null 2>&1
+  echo "== $T"; python $R/scripts/rocprof_summary.py $(find /tmp/pv -name "*.db" | head -1) | grep -E "k_score_mfma"
 done
+cp /tmp/lib_base.so $R/poselib_amd/lib/libposelib_amd.so
