@@ -361,11 +361,13 @@ uint64_t dynamic_max_iter(uint64_t inl, uint64_t N, uint64_t K, double log_fail,
 }
 
 // Host replay of the sampler to find where each iteration's draws start (integer work, a few ns per
-// draw).  Returns the draw position after `count` iterations.
+// draw): out[i] = draws consumed before iteration i, RELATIVE to `pos` (like the device's k_sample_orbit; the
+// generators add GenerateArgs.pos_base).  Returns the absolute draw position after `count` iterations.
 template <int K> uint64_t sample_positions(uint64_t seed, uint64_t pos, uint64_t N, uint32_t count, uint32_t *out) {
     uint32_t idx[K];
+    const uint64_t pos0 = pos;
     for (uint32_t i = 0; i < count; ++i) {
-        out[i] = (uint32_t)pos;
+        out[i] = (uint32_t)(pos - pos0);
         pos += draw_sample<K>(seed, pos, N, idx);
     }
     return pos;
@@ -692,7 +694,11 @@ struct RansacRun {
     std::vector<Improving> imps;
     std::vector<RefineJob> jobs;
     std::vector<uint32_t> order;
+    // diagnostics: POSELIB_AMD_HOST_BOOKKEEPING=1 (both), POSELIB_AMD_HOST_POSITIONS=1 (sampler positions walked on the
+    // host), POSELIB_AMD_HOST_RECORDS=1 (improving hypotheses found by a host scan over all scores)
     const bool host_bookkeeping = std::getenv("POSELIB_AMD_HOST_BOOKKEEPING") != nullptr;
+    const bool host_positions = host_bookkeeping || std::getenv("POSELIB_AMD_HOST_POSITIONS") != nullptr;
+    const bool host_records = host_bookkeeping || std::getenv("POSELIB_AMD_HOST_RECORDS") != nullptr;
     bool force_host_positions = false;
     const bool prosac;
     ProsacSampler prosac_sampler;
@@ -796,7 +802,7 @@ struct RansacRun {
         uint32_t *const blk_tot = reinterpret_cast<uint32_t *>(d_ctl + 1);
 
         uint64_t pos_after = 0;
-        bool device_positions = !host_bookkeeping && !force_host_positions && !prosac;
+        bool device_positions = !host_positions && !force_host_positions && !prosac;
         const ProsacSampler prosac_at_batch_start = prosac_sampler; // a repeated batch draws the same samples
         if (prosac) {
             HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * (size_t)B * K));
@@ -927,6 +933,23 @@ struct RansacRun {
                 return kRedoBatch;
             }
             pos_after = h_ctl->pos_after;
+            static const bool check_positions = std::getenv("POSELIB_AMD_CHECK_POSITIONS") != nullptr;
+            if (check_positions) { // diagnostic: the device's orbit walk against the sequential walk on the host
+                std::vector<uint32_t> dev(B), host(B);
+                HIP_TRY(hipMemcpy(dev.data(), c->positions.p, sizeof(uint32_t) * B, hipMemcpyDeviceToHost));
+                const uint64_t after = sample_positions_k(K, ro.seed, pos, N, B, host.data());
+                for (uint32_t i = 0; i < B; ++i)
+                    if (dev[i] != host[i]) {
+                        std::fprintf(stderr, "poselib_amd: sampler position mismatch: N %u K %d batch %u at draw %llu, iteration %u: device %u host %u\n",
+                                     N, K, B, (unsigned long long)pos, i, dev[i], host[i]);
+                        return fail(PL_ERR_HIP, "device sampler positions differ from the sequential walk");
+                    }
+                if (after != pos_after) {
+                    std::fprintf(stderr, "poselib_amd: sampler end position mismatch: device %llu host %llu\n",
+                                 (unsigned long long)pos_after, (unsigned long long)after);
+                    return fail(PL_ERR_HIP, "device sampler end position differs from the sequential walk");
+                }
+            }
         }
         const bool overflow = h_ctl->gen_overflow != 0;
         if (overflow && !sh) { // an iteration produced more models than the reserved slots: redo with 40
@@ -952,7 +975,7 @@ struct RansacRun {
         const uint32_t nrec = overflow ? 0u : h_ctl->num_records;
         if (overflow) {
             // nothing to report: every rank redoes the batch with more slots per iteration
-        } else if (!host_bookkeeping && nrec <= kRecordCap) {
+        } else if (!host_records && nrec <= kRecordCap) {
             if (nrec > kRecordFirst) {
                 HIP_TRY(hipMemcpyAsync(h_meta, c->rec_meta.p, sizeof(RecordMeta) * nrec, hipMemcpyDeviceToHost,
                                        c->stream));

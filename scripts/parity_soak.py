@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Parity soak on a GPU box: many random problems per estimator, product (through the C-ABI) vs oracle.
+Compares iterations, refinements, inlier count, inlier mask and the model (1e-6).  Prints one summary line per
+estimator and every disagreement.   python scripts/parity_soak.py [problems per estimator] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import oracle_lib as O  # noqa: E402
+import poselib_amd as P  # noqa: E402
+from poselib_amd import synth  # noqa: E402
+
+
+def model_diff(kind, a, b):
+    if kind in ("abs", "rel"):
+        qa, qb = np.asarray(a.q), np.asarray(b[:4])
+        dq = min(np.abs(qa - qb).max(), np.abs(qa + qb).max())
+        ta, tb = np.asarray(a.t), np.asarray(b[4:7])
+        if kind == "rel":  # translation up to scale: compare directions
+            ta, tb = ta / (np.linalg.norm(ta) + 1e-300), tb / (np.linalg.norm(tb) + 1e-300)
+        return max(dq, np.abs(ta - tb).max())
+    A, B = np.asarray(a) / np.linalg.norm(a), np.asarray(b) / np.linalg.norm(b)
+    return min(np.abs(A - B).max(), np.abs(A + B).max())
+
+
+def main(count=100, seed=1):
+    rng = np.random.default_rng(seed)
+    total_bad = 0
+    for kind in ("abs", "rel", "fund", "hom"):
+        bad = ref_only = 0
+        worst = 0.0
+        t0 = time.time()
+        for i in range(count):
+            n = int(rng.integers(12, 3000))
+            outl = float(rng.uniform(0.1, 0.7))
+            dseed, rseed = int(rng.integers(1, 1 << 30)), int(rng.integers(0, 1 << 30))
+            opt = {"ransac": {"seed": rseed}}
+            if rng.uniform() < 0.3:
+                opt["ransac"].update(max_iterations=3000, min_iterations=int(rng.integers(100, 3000)))
+            if kind == "abs":
+                d = synth.absolute_pose_scene(n, outl, dseed)
+                got, info = P.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], opt)
+                want, mask, st = O.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], opt)
+                got = got.pose
+            elif kind == "rel":
+                d = synth.relative_pose_scene(n, outl, dseed)
+                got, info = P.estimate_relative_pose(d["x1"], d["x2"], d["camera1"], d["camera2"], opt)
+                want, mask, st = O.estimate_relative_pose(d["x1"], d["x2"], d["camera1"], d["camera2"], opt)
+            elif kind == "fund":
+                d = synth.fundamental_scene(n, outl, dseed)
+                got, info = P.estimate_fundamental(d["x1"], d["x2"], opt)
+                want, mask, st = O.estimate_fundamental(d["x1"], d["x2"], opt)
+            else:
+                d = synth.homography_scene(n, outl, dseed)
+                got, info = P.estimate_homography(d["x1"], d["x2"], opt)
+                want, mask, st = O.estimate_homography(d["x1"], d["x2"], opt)
+            same = (info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+                    and (np.array(info["inliers"]) == mask).all())
+            diff = model_diff(kind, got, want) if st["num_inliers"] > 0 else 0.0
+            worst = max(worst, diff if same else 0.0)
+            if not same or diff > 1e-6:
+                bad += 1
+                print(f"  MISMATCH {kind} n={n} outl={outl:.2f} dseed={dseed} rseed={rseed} opt={opt['ransac']}: "
+                      f"iterations {info['iterations']}/{st['iterations']} refinements {info['refinements']}/{st['refinements']} "
+                      f"inliers {info['num_inliers']}/{st['num_inliers']} model diff {diff:.2e}")
+            elif info["refinements"] != st["refinements"]:
+                ref_only += 1
+        total_bad += bad
+        print(f"{kind}: {count} problems, {bad} disagreements, {ref_only} with a different refinement count only, "
+              f"worst model difference among the agreeing {worst:.2e}, {time.time() - t0:.1f} s")
+    return total_bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(*(int(a) for a in sys.argv[1:3])) else 0)

@@ -247,6 +247,44 @@ print("RESULT " + json.dumps(out))
     assert all(row[2] > 100 for row in results["exact"][:3])  # the runs found their models
 
 
+def test_host_fallbacks_of_the_bookkeeping_agree_with_the_device_path(gpu):
+    """The sampler's orbit walk and the scan for improving hypotheses run on the device; both have host fall-backs
+    (orbit window too small / too many redraws; record list overflow).  Forced through the diagnostic switches they
+    must reproduce the device path on runs of several batches (draw positions of a later batch are relative to its
+    start), and POSELIB_AMD_CHECK_POSITIONS=1 compares the two position tables batch by batch."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+import poselib_amd as P
+from poselib_amd import synth
+out = []
+for gen, fn, n, seed in ((synth.fundamental_scene, P.estimate_fundamental, 2000, 3), (synth.homography_scene, P.estimate_homography, 40, 4),
+                         (synth.fundamental_scene, P.estimate_fundamental, 30, 5)):
+    d = gen(n, 0.4, 70 + seed)
+    M, info = fn(d["x1"], d["x2"], {"ransac": {"seed": seed, "min_iterations": 2500}})
+    out.append([info["iterations"], info["refinements"], info["num_inliers"], repr(info["model_score"]), [repr(float(v)) for v in np.ravel(M)]])
+d = synth.absolute_pose_scene(25, 0.3, 99)
+img, info = P.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], {"ransac": {"seed": 6, "min_iterations": 5000}})
+out.append([info["iterations"], info["refinements"], info["num_inliers"], repr(info["model_score"]), [repr(float(v)) for v in list(img.pose.q) + list(img.pose.t)]])
+print("RESULT " + json.dumps(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = {}
+    for tag, extra in (("device", {"POSELIB_AMD_CHECK_POSITIONS": "1"}), ("host_positions", {"POSELIB_AMD_HOST_POSITIONS": "1"}),
+                       ("host_records", {"POSELIB_AMD_HOST_RECORDS": "1"}), ("host_both", {"POSELIB_AMD_HOST_BOOKKEEPING": "1"})):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        results[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert all(row[0] > 2500 for row in results["device"])  # several batches each
+    for tag in ("host_positions", "host_records", "host_both"):
+        assert results[tag] == results["device"], tag
+
+
 # ------------------------------------------------------------------------------------------ end to end
 ABS_CASES = [(200, 0.5, 1000, 0), (200, 0.5, 1000, 7), (5000, 0.7, 1001, 0), (5000, 0.7, 1001, 3), (1500, 0.3, 77, 1)]
 
