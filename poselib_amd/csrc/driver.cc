@@ -453,16 +453,13 @@ void set_prefilter(ScoreArgs &sa, const pl_problem *p, double thr2) {
         sa.pf.enabled = 0;
 }
 
-// Score `nrec` model records that already sit in device memory at `d_records`.  Results land in the
-// pinned h_count / h_score buffers after the caller synchronises.
+// Score `nrec` model records that already sit in device memory at `d_records`, in the reference's summation order
+// (k_score_seq).  Results land in c->count / c->score and in the pinned h_count / h_score buffers after the caller
+// synchronises.
 int enqueue_score_records(Context *c, const pl_problem *p, const double *d_records, uint32_t nrec, double thr2,
                           bool time_it) {
-    ScoreArgs sa;
-    set_prefilter(sa, p, thr2);
-    const uint32_t chunks = score_chunks(p->kind, p->n, false);
+    (void)time_it;
     HIP_TRY(c->num_hyp.ensure(sizeof(uint32_t)));
-    HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * nrec));
-    HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * nrec));
     HIP_TRY(c->count.ensure(sizeof(uint32_t) * nrec));
     HIP_TRY(c->score.ensure(sizeof(double) * nrec));
     HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * nrec));
@@ -470,33 +467,20 @@ int enqueue_score_records(Context *c, const pl_problem *p, const double *d_recor
     const bool counted = nrec < kIotaEntries; // the count is read from the device-resident table: no upload
     if (!counted)
         HIP_TRY(hipMemcpyAsync(c->num_hyp.p, &nrec, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    SeqScoreArgs sa;
     sa.pts = p->ps;
     sa.models = d_records;
-    sa.slots = nullptr;
-    sa.shadow = nullptr;
-    sa.shadow16 = nullptr;
-    sa.compact64 = nullptr;
-
-    sa.num_hyp = counted ? c->iota.as<uint32_t>() + nrec : c->num_hyp.as<uint32_t>();
-    sa.hyp_capacity = nrec;
+    sa.cand = nullptr;
+    sa.num = counted ? c->iota.as<uint32_t>() + nrec : c->num_hyp.as<uint32_t>();
+    sa.cap = nrec;
     sa.thr2 = thr2;
-    sa.part_count = c->part_count.as<uint32_t>();
-    sa.part_score = c->part_score.as<double>();
-    (void)time_it;
-    HIP_TRY(launch_score(p->kind, sa, std::min<uint32_t>(nrec, 1024u), c->stream));
-    FinalizeArgs fa;
-    fa.num_hyp = sa.num_hyp;
-    fa.hyp_capacity = nrec;
-    fa.chunks = chunks;
-    fa.n_points = p->n;
-    fa.thr2 = thr2;
-    fa.part_count = sa.part_count;
-    fa.part_score = sa.part_score;
-    fa.count = c->count.as<uint32_t>();
-    fa.score = c->score.as<double>();
-    fa.host_count = c->h_count.dev<uint32_t>(); // k_finalize writes the pinned copies itself
-    fa.host_score = c->h_score.dev<double>();
-    HIP_TRY(launch_finalize(fa, nrec, c->stream));
+    sa.count = c->count.as<uint32_t>();
+    sa.score = c->score.as<double>();
+    sa.host_count = c->h_count.dev<uint32_t>(); // the kernel writes the pinned copies itself
+    sa.host_score = c->h_score.dev<double>();
+    sa.host_cand = nullptr;
+    sa.host_cap = 0;
+    HIP_TRY(launch_score_seq(p->kind, sa, c->stream));
     return PL_OK;
 }
 
@@ -903,6 +887,21 @@ struct RansacRun {
                                             c->rec_meta.as<RecordMeta>(), c->rec_models.as<double>(), kRecordCap, d_ctl,
                                             c->h_rec_meta.dev<RecordMeta>(), c->h_gather_out.dev<double>(), kRecordFirst,
                                             c->stream));
+            // the listed candidates once more, summed like the reference sums them (decisions are taken on these)
+            SeqScoreArgs qa;
+            qa.pts = p->ps;
+            qa.models = ga.models;
+            qa.cand = c->rec_meta.as<RecordMeta>();
+            qa.num = &d_ctl->num_records;
+            qa.cap = kRecordCap;
+            qa.thr2 = thr2;
+            qa.count = nullptr;
+            qa.score = nullptr;
+            qa.host_count = nullptr;
+            qa.host_score = nullptr;
+            qa.host_cand = c->h_rec_meta.dev<RecordMeta>();
+            qa.host_cap = kRecordFirst;
+            HIP_TRY(launch_score_seq(kind, qa, c->stream));
         }
         b.pos_after = pos_after;
         b.device_positions = device_positions;
@@ -910,6 +909,34 @@ struct RansacRun {
         b.d_ctl = d_ctl;
         b.prosac_at_batch_start = prosac_at_batch_start;
         return PL_OK;
+    }
+
+    // The candidates (sorted by hypothesis index, scores summed in the reference's order) through the rule of
+    // ransac_impl.h:113-123: those that improve the running best become `imps`; the last one of an iteration seeds
+    // the local optimisation.
+    void keep_improving(const RecordMeta *meta, const uint32_t *order_, uint32_t n, uint32_t first_iteration) {
+        for (uint32_t a = 0; a < n; ++a) {
+            const RecordMeta &m = meta[order_[a]];
+            const bool more = m.count > best_min_inl, better = m.score < best_min_score;
+            if (!(more || better))
+                continue;
+            if (more)
+                best_min_inl = m.count;
+            if (better)
+                best_min_score = m.score;
+            Improving im;
+            im.iter = first_iteration + m.slot / (uint32_t)MAXM;
+            im.slot = m.slot;
+            im.count = m.count;
+            im.score = m.score;
+            im.lo_seed = false;
+            im.gather = order_[a];
+            if (!imps.empty() && imps.back().iter != im.iter)
+                imps.back().lo_seed = true;
+            imps.push_back(im);
+        }
+        if (!imps.empty())
+            imps.back().lo_seed = true;
     }
 
     // ---- the one synchronisation of the batch; retry decisions; improving hypotheses of this rank's share ----
@@ -923,7 +950,7 @@ struct RansacRun {
         const ProsacSampler &prosac_at_batch_start = b.prosac_at_batch_start;
         (void)hcap;
         BatchCtl *h_ctl = c->h_small.as<BatchCtl>();
-        RecordMeta *h_meta = c->h_rec_meta.as<RecordMeta>(); // the first kRecordFirst records: written by k_records
+        RecordMeta *h_meta = c->h_rec_meta.as<RecordMeta>(); // the first kRecordFirst candidates: written by k_score_seq
         double *h_recm = c->h_gather_out.as<double>();
         HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(BatchCtl), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -987,25 +1014,11 @@ struct RansacRun {
             for (uint32_t a = 0; a < nrec; ++a)
                 order[a] = a;
             std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_meta[x].k < h_meta[y].k; });
-            for (uint32_t a = 0; a < nrec; ++a) {
-                const RecordMeta &m = h_meta[order[a]];
-                Improving im;
-                im.iter = (uint32_t)(it + lo_g + m.slot / MAXM);
-                im.slot = m.slot;
-                im.count = m.count;
-                im.score = m.score;
-                im.lo_seed = false;
-                im.gather = order[a];
-                if (!imps.empty() && imps.back().iter != im.iter)
-                    imps.back().lo_seed = true;
-                imps.push_back(im);
-                best_min_inl = std::max<uint64_t>(best_min_inl, m.count);
-                best_min_score = std::min(best_min_score, m.score);
-            }
-            if (!imps.empty())
-                imps.back().lo_seed = true;
+            keep_improving(h_meta, order.data(), nrec, (uint32_t)(it + lo_g));
         } else {
-            // fallback (record list overflow, or POSELIB_AMD_HOST_BOOKKEEPING=1): scan every score on the host
+            // fallback (candidate list overflow, or POSELIB_AMD_HOST_RECORDS=1): scan every (tree-order) score on the
+            // host with the same margin as k_records, have the candidates re-scored in the reference's summation
+            // order, then apply the exact rule like above
             HIP_TRY(c->h_num_models.ensure(sizeof(uint32_t) * (Bl + 1)));
             HIP_TRY(c->h_count.ensure(sizeof(uint32_t) * hcap));
             HIP_TRY(c->h_score.ensure(sizeof(double) * hcap));
@@ -1021,39 +1034,60 @@ struct RansacRun {
             HIP_TRY(hipStreamSynchronize(c->stream));
             const uint32_t *h_cnt = c->h_count.as<uint32_t>();
             const double *h_sc = c->h_score.as<double>();
+            std::vector<RecordMeta> cand;
+            uint64_t run_inl = best_min_inl;
+            double run_score = best_min_score;
             uint32_t k = 0;
-            for (uint32_t i = 0; i < Bl; ++i) {
-                int last = -1;
+            for (uint32_t i = 0; i < Bl; ++i)
                 for (uint32_t m = 0; m < h_nm[i]; ++m, ++k) {
-                    const bool more = h_cnt[k] > best_min_inl;
-                    const bool better = h_sc[k] < best_min_score;
-                    if (!(more || better))
+                    if (!(h_cnt[k] > run_inl || h_sc[k] < run_score * (1.0 + 1e-9)))
                         continue;
-                    if (more)
-                        best_min_inl = h_cnt[k];
-                    if (better)
-                        best_min_score = h_sc[k];
-                    Improving im;
-                    im.iter = (uint32_t)(it + lo_g + i);
-                    im.slot = i * MAXM + m;
-                    im.count = h_cnt[k];
-                    im.score = h_sc[k];
-                    im.lo_seed = false;
-                    im.gather = (uint32_t)imps.size();
-                    imps.push_back(im);
-                    last = (int)imps.size() - 1;
+                    run_inl = std::max<uint64_t>(run_inl, h_cnt[k]);
+                    run_score = std::min(run_score, h_sc[k]);
+                    RecordMeta rm;
+                    rm.k = k;
+                    rm.slot = i * MAXM + m;
+                    rm.count = h_cnt[k];
+                    rm.pad = 0;
+                    rm.score = h_sc[k];
+                    cand.push_back(rm);
                 }
-                if (last >= 0)
-                    imps[last].lo_seed = true;
-            }
-            const uint32_t ni0 = (uint32_t)imps.size();
-            HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * std::max<uint32_t>(ni0, kRecordCap)));
+            const uint32_t nc = (uint32_t)cand.size();
+            HIP_TRY(c->h_rec_meta.ensure(sizeof(RecordMeta) * std::max<uint32_t>(nc, kRecordCap)));
+            HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * std::max<uint32_t>(nc, kRecordCap)));
+            h_meta = c->h_rec_meta.as<RecordMeta>();
             double *dst = c->h_gather_out.as<double>();
-            for (uint32_t a = 0; a < ni0; ++a)
-                HIP_TRY(hipMemcpyAsync(dst + (size_t)a * kModelStride,
-                                       c->models.as<double>() + (size_t)imps[a].slot * kModelStride,
-                                       sizeof(double) * kModelStride, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (nc) {
+                HIP_TRY(c->rec_meta.ensure(sizeof(RecordMeta) * std::max<uint32_t>(nc, kRecordCap)));
+                HIP_TRY(c->num_hyp.ensure(sizeof(uint32_t)));
+                std::memcpy(h_meta, cand.data(), sizeof(RecordMeta) * nc);
+                HIP_TRY(hipMemcpyAsync(c->rec_meta.p, h_meta, sizeof(RecordMeta) * nc, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(c->num_hyp.p, &nc, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                SeqScoreArgs qa;
+                qa.pts = p->ps;
+                qa.models = c->models.as<double>();
+                qa.cand = c->rec_meta.as<RecordMeta>();
+                qa.num = c->num_hyp.as<uint32_t>();
+                qa.cap = nc;
+                qa.thr2 = thr2;
+                qa.count = nullptr;
+                qa.score = nullptr;
+                qa.host_count = nullptr;
+                qa.host_score = nullptr;
+                qa.host_cand = nullptr;
+                qa.host_cap = 0;
+                HIP_TRY(launch_score_seq(kind, qa, c->stream));
+                HIP_TRY(hipMemcpyAsync(h_meta, c->rec_meta.p, sizeof(RecordMeta) * nc, hipMemcpyDeviceToHost, c->stream));
+                for (uint32_t a = 0; a < nc; ++a)
+                    HIP_TRY(hipMemcpyAsync(dst + (size_t)a * kModelStride,
+                                           c->models.as<double>() + (size_t)cand[a].slot * kModelStride,
+                                           sizeof(double) * kModelStride, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            order.resize(nc);
+            for (uint32_t a = 0; a < nc; ++a)
+                order[a] = a;
+            keep_improving(h_meta, order.data(), nc, (uint32_t)(it + lo_g));
             h_rec = dst;
         }
 

@@ -13,11 +13,11 @@
 //                         full wavefronts.  (reference: utils.cc compute_msac_score)
 //   k_score_queue<EST,P>  the same with an fp32 pre-filter on the vector ALU: Sampson and homography scores, and the
 //                         absolute-pose fallback (small N, out-of-range thresholds).
-//   k_score<EST,P>        exact scorer for the handful of refined / initial models (no filter, 256 * P points per
-//                         chunk, hypotheses as wave-uniform records in SGPRs), k_finalize adds its chunk partials.
+//   k_score_seq<EST>      the MSAC score in the reference's summation order for every model a decision is taken on
+//                         (candidates of the record scan, refined / initial models): one workgroup per model.
 //   k_lm<EST>             Levenberg-Marquardt refinement, ONE workgroup (8 wavefronts) per task, the whole LM loop on
 //                         device; k_lm2<EST>: the same spread over several workgroups per task, one launch per LM
-//                         half-step (opt-in latency mode).  (reference: bundle.cc + optim/lm_impl.h + optim/*.h)
+//                         iteration (default for large two-view LO).  (reference: bundle.cc + optim/lm_impl.h + optim/*.h)
 //   k_mask<EST>           final inlier mask (reference: utils.cc get_inliers*).
 //   k_solve_batch<EST>    the bare minimal solvers, one lane per problem.
 // Exact arithmetic (fp64, reference association order) never runs on the matrix cores; only the filter's projection
@@ -355,84 +355,6 @@ __device__ __forceinline__ bool eval_point(const double *M, const double *pt, do
         return sampson_inlier(M, pt[0], pt[1], pt[2], pt[3], thr2, r2);
     else
         return homography_inlier(M, pt[0], pt[1], pt[2], pt[3], thr2, r2);
-}
-
-constexpr int kScoreGroup = 32; // hypotheses between two workgroup barriers
-
-template <int EST, int P>
-__global__ __launch_bounds__(kScoreThreads) void k_score(PointSet pts, const double *__restrict__ models,
-                                                         const uint32_t *__restrict__ slots,
-                                                         const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
-                                                         double thr2, uint32_t *__restrict__ part_count,
-                                                         double *__restrict__ part_score) {
-    constexpr int ND = point_doubles(EST);
-    __shared__ double s_score[kScoreGroup][kScoreThreads / 64];
-    __shared__ uint32_t s_count[kScoreGroup][kScoreThreads / 64];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t chunk = blockIdx.y;
-
-    // ---- stationary operand: this lane's P correspondences, coalesced loads, kept in VGPRs ----
-    double pt[P][ND];
-    bool valid[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const uint32_t i = (chunk * P + p) * kScoreThreads + threadIdx.x;
-        valid[p] = i < pts.n;
-        const uint32_t ic = valid[p] ? i : 0u;
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-            pt[p][d] = pts.a[d][ic];
-    }
-
-    const uint32_t H = *as_uniform(num_hyp_ptr);
-    const uint32_t per = (H + gridDim.x - 1) / gridDim.x;
-    const uint32_t k0 = blockIdx.x * per;
-    const uint32_t k1 = min(H, k0 + per);
-
-    for (uint32_t kb = k0; kb < k1; kb += kScoreGroup) {
-        const uint32_t gn = min((uint32_t)kScoreGroup, k1 - kb);
-        for (uint32_t g = 0; g < gn; ++g) {
-            // ---- streaming operand: one hypothesis, wave-uniform (scalar loads -> SGPRs) ----
-            const uint32_t k = kb + g;
-            const uint32_t slot = slots ? as_uniform(slots)[k] : k;
-            uniform_f64_ptr Mg = as_uniform(models) + (size_t)slot * kModelStride;
-            double M[kModelDoubles];
-#pragma unroll
-            for (int i = 0; i < kModelDoubles; ++i)
-                M[i] = Mg[i];
-
-            uint32_t cnt = 0;
-            double sc = 0.0;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                double r2;
-                const bool in = eval_point<EST>(M, pt[p], thr2, r2) && valid[p];
-                cnt += __popcll(__ballot(in));
-                sc += in ? r2 : 0.0;
-            }
-            sc = wave_sum(sc);
-            if (lane == 0) {
-                s_score[g][wave] = sc;
-                s_count[g][wave] = cnt;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < gn) {
-            double sc = 0.0;
-            uint32_t c = 0;
-#pragma unroll
-            for (int w = 0; w < kScoreThreads / 64; ++w) {
-                sc += s_score[threadIdx.x][w];
-                c += s_count[threadIdx.x][w];
-            }
-            const size_t o = (size_t)chunk * hyp_capacity + kb + threadIdx.x;
-            part_score[o] = sc;
-            part_count[o] = c;
-        }
-        __syncthreads();
-    }
 }
 
 #ifdef PL_SCALAR_ABS_FILTER
@@ -952,23 +874,107 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
     }
 }
 
-__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs f) {
-    const uint32_t H = *f.num_hyp;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < H; k += gridDim.x * blockDim.x) {
-        uint32_t c = 0;
-        double s = 0.0;
-        for (uint32_t ch = 0; ch < f.chunks; ++ch) {
-            c += f.part_count[(size_t)ch * f.hyp_capacity + k];
-            s += f.part_score[(size_t)ch * f.hyp_capacity + k];
+// ---- MSAC score in the reference's summation order ------------------------------------------------------------------
+// The streaming scorers add the inlier residuals of a hypothesis in tree order; the reference adds them one after the
+// other in correspondence order (utils.cc:52-63).  The two sums differ in the last bits, which only matters when two
+// hypotheses tie - but then it decides `score < best` (ransac_impl.h:114-116, 142-146).  So every score a decision
+// is taken on - the candidates k_records lists (improving hypotheses plus anything within 1e-9 of the running
+// minimum) and the re-scored refined models - is recomputed here exactly like the reference does it: one workgroup per
+// model; the threads evaluate the correspondences of a chunk in parallel and compact the inliers' squared residuals
+// in index order into LDS (block scan), one lane adds them sequentially.
+constexpr int kSeqThreads = 1024, kSeqPerThread = 8, kSeqChunk = kSeqThreads * kSeqPerThread; // 64 KB of LDS
+
+template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(SeqScoreArgs a) {
+    constexpr int ND = point_doubles(EST);
+    __shared__ double s_list[kSeqChunk + 8];
+    __shared__ uint32_t s_wave_tot[kSeqThreads / 64], s_total;
+    __shared__ double s_sum;
+    const uint32_t nrec = min(*a.num, a.cap);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t r = blockIdx.x; r < nrec; r += gridDim.x) {
+        const double *Mp = a.models + (size_t)(a.cand ? a.cand[r].slot : r) * kModelStride;
+        double M[kModelDoubles];
+#pragma unroll
+        for (int i = 0; i < kModelDoubles; ++i)
+            M[i] = Mp[i];
+        if (threadIdx.x == 0)
+            s_sum = 0.0;
+        uint32_t count = 0; // (thread 0 keeps the total)
+        for (uint32_t base = 0; base < a.pts.n; base += kSeqChunk) {
+            double r2v[kSeqPerThread];
+            uint32_t flags = 0, cnt = 0;
+#pragma unroll
+            for (int j = 0; j < kSeqPerThread; ++j) {
+                const uint32_t i = base + threadIdx.x * kSeqPerThread + j; // contiguous per thread: index order
+                r2v[j] = 0.0;
+                if (i < a.pts.n) {
+                    double x[ND];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        x[d] = a.pts.a[d][i];
+                    double r2;
+                    if (eval_point<EST>(M, x, a.thr2, r2)) {
+                        r2v[j] = r2;
+                        flags |= 1u << j;
+                        ++cnt;
+                    }
+                }
+            }
+            const uint32_t incl = wave_scan_u32(cnt);
+            if (lane == 63)
+                s_wave_tot[wave] = incl;
+            __syncthreads(); // (also: the previous chunk's list has been consumed)
+            uint32_t off = incl - cnt;
+            for (int w = 0; w < wave; ++w)
+                off += s_wave_tot[w];
+#pragma unroll
+            for (int j = 0; j < kSeqPerThread; ++j)
+                if ((flags >> j) & 1u)
+                    s_list[off++] = r2v[j];
+            if (threadIdx.x == kSeqThreads - 1) {
+                s_total = off;
+                for (int z = 0; z < 8; ++z) // pad to a multiple of 8 with +0.0 (x + 0.0 == x: the sum never is -0.0)
+                    s_list[off + z] = 0.0;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t total = s_total;
+                double sum = s_sum;
+                // utils.cc:59 / :193 / :233 / :323, in correspondence order; eight values per step so that the LDS reads
+                // of the next step travel while this step's dependent additions run
+                for (uint32_t j = 0; j < total; j += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        v[t] = s_list[j + t];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        sum += v[t];
+                }
+                s_sum = sum;
+                count += total;
+            }
+            __syncthreads();
         }
-        f.count[k] = c;
-        // MSAC: inlier residuals + threshold for every non-inlier (utils.cc:63 / :193-197)
-        const double sc = s + (double)(f.n_points - c) * f.thr2;
-        f.score[k] = sc;
-        if (f.host_count) {
-            f.host_count[k] = c;
-            f.host_score[k] = sc;
+        if (threadIdx.x == 0) {
+            const double score = s_sum + (double)(a.pts.n - count) * a.thr2; // utils.cc:63
+            if (a.cand) {
+                a.cand[r].count = count;
+                a.cand[r].score = score;
+                if (r < a.host_cap) {
+                    RecordMeta m = a.cand[r];
+                    a.host_cand[r] = m;
+                }
+            } else {
+                a.count[r] = count;
+                a.score[r] = score;
+                if (a.host_count) {
+                    a.host_count[r] = count;
+                    a.host_score[r] = score;
+                }
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -1530,7 +1536,6 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     const PrefilterArgs pf = a.pf;
     const bool streaming = a.shadow && a.compact64; // batched main loop: compact hypothesis stream
     score_shape(E, a.pts.n, streaming, chunks, P);
-    const dim3 grid(slices, chunks), block(kScoreThreads);
     if constexpr (E == EST_ABS) {
         if (streaming && a.shadow16) { // pre-filter on the matrix cores (PG = 2 P groups of 32 points per wave)
             const dim3 mgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
@@ -1576,38 +1581,21 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
 #undef PL_Q_CASE
         return hipGetLastError();
     }
-#define PL_SCORE_CASE(PP)                                                                                              \
-    case PP:                                                                                                           \
-        k_score<E, PP><<<grid, block, 0, stream>>>(a.pts, a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,      \
-                                                   a.part_count, a.part_score);                                       \
-        break;
-    switch (P) {
-        PL_SCORE_CASE(1)
-        PL_SCORE_CASE(2)
-        PL_SCORE_CASE(3)
-        PL_SCORE_CASE(4)
-        PL_SCORE_CASE(5)
-    default:
-        return hipErrorInvalidValue;
-    }
-#undef PL_SCORE_CASE
-    return hipGetLastError();
+    return hipErrorInvalidValue; // only the streaming form exists (models decisions are taken on: k_score_seq)
 }
 
+hipError_t launch_score_seq(int est, const SeqScoreArgs &a, hipStream_t stream) {
+    if (a.cap == 0)
+        return hipSuccess;
+    const dim3 grid(std::min<uint32_t>(a.cap, 128u)), block(kSeqThreads); // (candidate lists hold a few dozen entries)
+    PL_DISPATCH_EST(est, k_score_seq<E><<<grid, block, 0, stream>>>(a));
+    return hipGetLastError();
+}
 hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream) {
     PL_DISPATCH_EST(est, return launch_score_est<E>(a, slices, stream));
     return hipSuccess;
 }
 
-hipError_t launch_finalize(const FinalizeArgs &a, uint32_t max_hyp, hipStream_t stream) {
-    uint32_t blocks = (max_hyp + 255) / 256;
-    if (blocks > 1024)
-        blocks = 1024;
-    if (blocks == 0)
-        blocks = 1;
-    k_finalize<<<dim3(blocks), dim3(256), 0, stream>>>(a);
-    return hipGetLastError();
-}
 
 hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
     if (num_tasks == 0)

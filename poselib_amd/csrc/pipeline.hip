@@ -440,7 +440,9 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
             emax = max(emax, pmax);
             emin = fmin(emin, pmin);
         }
-        if (live && (c > emax || s < emin)) { // ransac_impl.h:114-116
+        // ransac_impl.h:114-116 with a margin on the score: these sums are in tree order, the decision is taken on the
+        // sequentially summed scores k_score_seq computes for the listed candidates (the host applies the exact rule)
+        if (live && (c > emax || s < emin * (1.0 + 1e-9))) {
             const uint32_t r = atomicAdd(&ctl->num_records, 1u);
             if (r < rec_cap) {
                 const uint32_t slot = slots ? slots[k] : k;
@@ -453,8 +455,8 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
                 rec_meta[r] = m;
                 for (int i = 0; i < kModelStride; ++i)
                     rec_models[(size_t)r * kModelStride + i] = models[(size_t)slot * kModelStride + i];
-                if (r < host_cap) { // the first records go straight to pinned host memory (no copy dispatch)
-                    host_meta[r] = m;
+                if (r < host_cap) { // the first models go straight to pinned host memory (no copy dispatch); their
+                                    // (count, score) follow from k_score_seq
                     for (int i = 0; i < kModelStride; ++i)
                         host_models[(size_t)r * kModelStride + i] = models[(size_t)slot * kModelStride + i];
                 }

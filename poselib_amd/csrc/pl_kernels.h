@@ -68,9 +68,6 @@ struct FinalizeArgs {
     const double *part_score;
     uint32_t *count; // [hyp_capacity]
     double *score;   // [hyp_capacity]
-    // optional second destination in pinned host memory (written by the kernel itself: no copy dispatch); k_finalize only
-    uint32_t *host_count = nullptr;
-    double *host_score = nullptr;
 };
 
 struct LMTask {
@@ -99,6 +96,24 @@ struct RecordMeta {
     uint32_t k, slot, count, pad;
     double score;
 };
+
+// k_score_seq: scores in the reference's (sequential) summation order for the models decisions are taken on.
+struct SeqScoreArgs {
+    PointSet pts;
+    const double *models;   // records of kModelStride doubles
+    RecordMeta *cand;       // candidate list: model of candidate r = models + cand[r].slot; count / score are rewritten.
+                            // nullptr: model r = models + r, results go to count[] / score[]
+    const uint32_t *num;    // number of candidates / models (device memory)
+    uint32_t cap;           // upper bound of *num
+    double thr2;
+    uint32_t *count;        // plain mode: [cap]
+    double *score;          // plain mode: [cap]
+    uint32_t *host_count;   // plain mode: optional pinned mirrors
+    double *host_score;
+    RecordMeta *host_cand;  // candidate mode: pinned mirror of the first host_cap candidates
+    uint32_t host_cap;
+};
+hipError_t launch_score_seq(int est, const SeqScoreArgs &a, hipStream_t stream);
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream);
@@ -137,7 +152,6 @@ hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_
 // chunks = ceil(n / (kScoreThreads * P)); P is chosen inside from n (returned through *chunks_out)
 uint32_t score_chunks(int est, uint32_t n_points, bool prefilter);
 hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream);
-hipError_t launch_finalize(const FinalizeArgs &a, uint32_t max_hyp, hipStream_t stream);
 // num_models[iters] -> slots (compact list of record indices in (iteration, model) order) + count
 hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
 hipError_t launch_mask(int est, const PointSet &pts, const double *model, double thr2, uint8_t *mask,

@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "host_fallbacks or frequent_redraws" 2>&1 | tail -8
+for i in 1 2 3; do
+timeout 300 python bench.py --no-cpu-baseline --steps 20 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('p3p 16 streams value %.4g'%d['value'])"
+done
+timeout 300 python bench.py --no-cpu-baseline --streams 1 --steps 20 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('p3p 1 stream value %.4g'%d['value'])"

@@ -504,20 +504,24 @@ def test_sampler_with_frequent_redraws(gpu, n):
     """Few correspondences: most iterations redraw a duplicate index (sampling.cc:46-61), so the device sampler's
     orbit has a flag at almost every position (bitmap -> successor links -> segments; beyond 12288 flags or 4096
     segments per batch it must fall back to the host walk) - long fixed-length runs must still follow the
-    reference's draw stream exactly.  (`refinements` is compared from 24 correspondences up: below that the same
-    sample recurs in permuted order, its models tie to the last bit of the MSAC score, and the device's tree-order
-    sums may rank such a pair differently from the sequential sums - DESIGN.md section 5, residual risk.)"""
-    refs = (lambda a, b: a == b) if n >= 24 else (lambda a, b: True)
+    reference's draw stream exactly.  With so few correspondences the same sample recurs in permuted order and its
+    models tie to the last bits of the MSAC score: `refinements` (and the score's bits) only agree because every score
+    a decision is taken on is summed in the reference's order (k_score_seq).  For P3P the tie can still break
+    differently below 24 correspondences: the device's cbrt / acos / cos (ocml) round differently from glibc's, so the
+    tied models themselves differ in their last bits."""
+    refs = lambda a, b: a == b  # noqa: E731
+    refs_p3p = refs if n >= 24 else (lambda a, b: True)
     opt = {"ransac": {"seed": 5 + n, "max_iterations": 30000, "min_iterations": 30000}}
     r = synth.relative_pose_scene(max(n, 8), 0.25, 70 + n)
     F, info = gpu.estimate_fundamental(r["x1"][:n], r["x2"][:n], opt)
     Fo, mask, st = O.estimate_fundamental(r["x1"][:n], r["x2"][:n], opt)
     assert info["iterations"] == st["iterations"] == 30000 and refs(info["refinements"], st["refinements"])
+    assert info["model_score"] == st["model_score"]  # to the bit
     assert info["num_inliers"] == st["num_inliers"] and (np.array(info["inliers"]) == mask).all()
     d = synth.absolute_pose_scene(max(n, 8), 0.25, 71 + n)
     img, info = gpu.estimate_absolute_pose(d["p2d"][:n], d["p3d"][:n], d["camera"], opt)
     pose, mask, st = O.estimate_absolute_pose(d["p2d"][:n], d["p3d"][:n], d["camera"], opt)
-    assert info["iterations"] == st["iterations"] == 30000 and refs(info["refinements"], st["refinements"])
+    assert info["iterations"] == st["iterations"] == 30000 and refs_p3p(info["refinements"], st["refinements"])
     assert info["num_inliers"] == st["num_inliers"] and (np.array(info["inliers"]) == mask).all()
     h = synth.homography_scene(max(n, 8), 0.25, 72 + n)
     H, info = gpu.estimate_homography(h["x1"][:n], h["x2"][:n], opt)
