@@ -632,6 +632,19 @@ dist.destroy_process_group()
         assert ok and its == 5000 and inl > 500, (rank, ok, its, inl)
 
 
+def test_random_problem_soak(gpu):
+    """scripts/parity_soak.py in small: 4 x 40 random problems (12..3000 correspondences, 10..70 % outliers, default and
+    fixed-length option sets) against the oracle - iterations, inlier count, mask, model."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "parity_soak.py")
+    spec = importlib.util.spec_from_file_location("parity_soak", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(40, 2024) == 0
+
+
 def test_non_finite_inputs_do_not_hang_or_crash(gpu):
     """NaN / inf correspondences: the reference happily computes with them (comparisons fail, the point is an
     outlier); the device path must do the same - same counts and masks as the oracle, no hang"""
