@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -q -k soak 2>&1 | tail -3
+SOAK_NMIN=7 SOAK_NMAX=40 timeout 1500 python scripts/parity_soak.py 150 31 2>&1 | tail -14
+timeout 1500 python scripts/parity_soak.py 100 32 2>&1 | tail -6

@@ -36,12 +36,14 @@ def main(count=100, seed=1):
         worst = 0.0
         t0 = time.time()
         for i in range(count):
-            n = int(rng.integers(12, 3000))
+            n = int(rng.integers(int(os.environ.get("SOAK_NMIN", 12)), int(os.environ.get("SOAK_NMAX", 3000))))
             outl = float(rng.uniform(0.1, 0.7))
             dseed, rseed = int(rng.integers(1, 1 << 30)), int(rng.integers(0, 1 << 30))
             opt = {"ransac": {"seed": rseed}}
             if rng.uniform() < 0.3:
                 opt["ransac"].update(max_iterations=3000, min_iterations=int(rng.integers(100, 3000)))
+            if rng.uniform() < 0.15:
+                opt["ransac"].update(progressive_sampling=True, max_prosac_iterations=int(rng.integers(50, 2000)))
             if kind == "abs":
                 d = synth.absolute_pose_scene(n, outl, dseed)
                 got, info = P.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], opt)
