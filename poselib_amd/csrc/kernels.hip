@@ -886,7 +886,7 @@ constexpr int kSeqThreads = 1024, kSeqPerThread = 8, kSeqChunk = kSeqThreads * k
 
 template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(SeqScoreArgs a) {
     constexpr int ND = point_doubles(EST);
-    __shared__ double s_list[kSeqChunk + 8];
+    __shared__ double s_list[kSeqChunk + 32];
     __shared__ uint32_t s_wave_tot[kSeqThreads / 64], s_total;
     __shared__ double s_sum;
     const uint32_t nrec = min(*a.num, a.cap);
@@ -933,7 +933,7 @@ template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(Se
                     s_list[off++] = r2v[j];
             if (threadIdx.x == kSeqThreads - 1) {
                 s_total = off;
-                for (int z = 0; z < 8; ++z) // pad to a multiple of 8 with +0.0 (x + 0.0 == x: the sum never is -0.0)
+                for (int z = 0; z < 32; ++z) // pad with +0.0 (x + 0.0 == x: the sum never is -0.0)
                     s_list[off + z] = 0.0;
             }
             __syncthreads();
@@ -942,14 +942,24 @@ template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(Se
                 double sum = s_sum;
                 // utils.cc:59 / :193 / :233 / :323, in correspondence order; eight values per step so that the LDS reads
                 // of the next step travel while this step's dependent additions run
-                for (uint32_t j = 0; j < total; j += 8) {
-                    double v[8];
+                // (the reads of the next eight values are issued before this step's dependent additions)
+                double v[8], w[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    v[t] = s_list[t];
+                for (uint32_t j = 0; j < total; j += 16) {
 #pragma unroll
                     for (int t = 0; t < 8; ++t)
-                        v[t] = s_list[j + t];
+                        w[t] = s_list[j + 8 + t];
 #pragma unroll
                     for (int t = 0; t < 8; ++t)
                         sum += v[t];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        v[t] = s_list[j + 16 + t];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        sum += w[t]; // (+0.0 beyond `total`)
                 }
                 s_sum = sum;
                 count += total;
