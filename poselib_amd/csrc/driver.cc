@@ -1427,8 +1427,10 @@ void free_problem(pl_problem *p) {
 // One-shot front-ends: the user's AoS buffers go to the device as they are and k_prepare (pipeline.hip) writes the SoA
 // block into the context's arena - per-point un-projection / normalisation on the GPU, no
 // hipMalloc / hipFree per call.  The problem is valid until the next make_problem_prepared on this thread.
+// resident: the raw correspondences of this call are already in c->raw_a / raw_b (second preparation of the same
+// inputs: no upload); lm_only: the problem is only refined on, never scored - no max|x| read-back, no synchronisation
 int make_problem_prepared(Context *c, int kind, const double *a, const double *b, size_t n, const PrepareArgs &pa,
-                          pl_problem *p) {
+                          pl_problem *p, bool resident = false, bool lm_only = false) {
     if (kind < 0 || kind > 3)
         return fail(PL_ERR_INVALID, "unknown problem kind");
     if (n > 0x7fffffffu)
@@ -1450,15 +1452,21 @@ int make_problem_prepared(Context *c, int kind, const double *a, const double *b
     HIP_TRY(c->absmax.ensure(sizeof(unsigned long long)));
     HIP_TRY(c->h_absmax.ensure(sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->absmax.p, 0, sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipMemcpyAsync(c->raw_a.p, a, sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->raw_b.p, b, sizeof(double) * db * n, hipMemcpyHostToDevice, c->stream));
+    if (!resident) {
+        HIP_TRY(hipMemcpyAsync(c->raw_a.p, a, sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->raw_b.p, b, sizeof(double) * db * n, hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(launch_prepare(c->raw_a.as<double>(), c->raw_b.as<double>(), (uint32_t)n, pa, c->pts_arena.as<double>(),
                            c->absmax.as<unsigned long long>(), c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_absmax.p, c->absmax.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     p->d_pts = c->pts_arena.as<double>();
     for (int d = 0; d < nd; ++d)
         p->ps.a[d] = p->d_pts + (size_t)d * n;
+    if (lm_only) { // (stream order puts the refinement behind k_prepare)
+        p->ps.xy_absmax = std::numeric_limits<float>::infinity();
+        return PL_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_absmax.p, c->absmax.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     double amax;
     std::memcpy(&amax, c->h_absmax.p, sizeof(double));
     p->ps.xy_absmax = std::nextafter((float)amax, std::numeric_limits<float>::infinity());
@@ -1838,7 +1846,8 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
         CameraParams raw_cam;
         std::memset(&raw_cam, 0, sizeof(raw_cam));
         raw_cam.model_id = CAM_NULL; // pixels as they are
-        rc = make_problem_prepared(c, EST_ABS, points2D, points3D, n, prepare_unproject(raw_cam, nullptr), &pp);
+        rc = make_problem_prepared(c, EST_ABS, points2D, points3D, n, prepare_unproject(raw_cam, nullptr), &pp,
+                                   /*resident=*/true, /*lm_only=*/true);
         if (rc != PL_OK)
             return rc;
         scale = 1.0 / camera_focal(camera);
