@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -2
-timeout 300 python scripts/latency_probe.py 2>&1 | tail -3
-timeout 300 python bench_batch.py --problems 4096 2>&1 | tail -1 | cut -c1-120
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o k -- python $R/scripts/_lat.py > /tmp/kt.log 2>&1
+python $R/scripts/timeline.py $(find /tmp/kt -name "*kernel_trace.csv") k_prepare 20 | cut -c1-110
