@@ -27,10 +27,12 @@ import argparse
 import json
 import os
 
-# one HIP stream per in-flight problem: let the runtime map them onto 8 hardware queues instead of the default 4
-# (must be set before the HIP runtime initialises; measured +5..15 % whole-job throughput on MI355X; 16 queues were
-# another few % faster but ran a mixed-estimator batch out of queue resources, so 8 it is)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# one HIP stream per in-flight problem: let the runtime map the 16 streams onto 16 hardware queues instead of the
+# default 4 (must be set before the HIP runtime initialises).  Measured on MI355X, whole-job throughput of the
+# default workload: 4 queues 3.4e8, 8 queues 3.9e8, 12 queues 4.0e8, 16 queues 4.2e8 hypotheses/s - two streams sharing
+# a queue block each other behind their long single-CU kernels (LM, sampler orbit).  (bench_batch.py keeps the
+# runtime default: with its library-side thread pool on top 16 queues once ran out of queue resources.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import sys
 import time
 
