@@ -147,6 +147,13 @@ def main():
 
     for w in range(args.warmup):
         step(1000 + w)
+    # the dominant kernel with the device to itself (4 problems one after the other, outside the timed region): the
+    # per-launch time the timed region reports is that of S launches sharing the device
+    solo_ms, solo_launches = 0.0, 0
+    for j in range(4):
+        _, info = pool.submit(run_one, (probs[0], 7000 + j)).result()
+        solo_ms += info["score_kernel_ms"]
+        solo_launches += info["score_kernel_launches"]
     sync()
     t0 = time.perf_counter()
     hyp = 0
@@ -216,11 +223,16 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launch,
                          "launches_in_flight": S, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "solo_avg_launch_ms": solo_ms / max(solo_launches, 1),
+                         "solo_frac": (alg_bytes_per_launch / (1e-3 * solo_ms / max(solo_launches, 1)) / 1e9 / HBM_PEAK_GBS)
+                         if solo_ms > 0 else None,
                          "point_hypotheses_per_s": value * N_POINTS, "valu_busy_pmc": valu_busy,
                          "note": f"algorithmic bytes = hypotheses x N x {BYTES_PER_CORR} B (SURVEY 8d); the set is "
                                  "register/LDS-resident, so frac > 1 is expected: the binding unit is the vector ALU "
                                  "(fp32 filter + fp64 exact pass, DESIGN.md 4); avg_launch_ms is the HIP-event time of "
-                                 "one launch while launches_in_flight problems share the device"},
+                                 "one launch while launches_in_flight problems share the device (throughput-optimal, but every "
+                                 "launch takes longer); solo_* is the same kernel with the device to itself, measured "
+                                 "before the timed region"},
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle_lib as O
