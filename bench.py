@@ -33,6 +33,10 @@ import os
 # a queue block each other behind their long single-CU kernels (LM, sampler orbit).  (bench_batch.py keeps the
 # runtime default: with its library-side thread pool on top 16 queues once ran out of queue resources.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# throughput benchmark: every LO task on one workgroup (k_lm) instead of spread over several with one launch per LM
+# iteration (k_lm2, the library's default for large homography / fundamental problems: 1.5-2.2x shorter single
+# problems, but -10..-25 % throughput with 16 problems in flight).  No effect on the default workload.
+os.environ.setdefault("POSELIB_AMD_LATENCY_MODE", "0")
 import sys
 import time
 
