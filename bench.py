@@ -26,6 +26,7 @@ The JSON line also carries
 import argparse
 import json
 import os
+import sys
 
 # one HIP stream per in-flight problem: let the runtime map the 16 streams onto 16 hardware queues instead of the
 # default 4 (must be set before the HIP runtime initialises).  Measured on MI355X, whole-job throughput of the
@@ -36,8 +37,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # throughput benchmark: every LO task on one workgroup (k_lm) instead of spread over several with one launch per LM
 # iteration (k_lm2, the library's default for large homography / fundamental problems: 1.5-2.2x shorter single
 # problems, but -10..-25 % throughput with 16 problems in flight).  No effect on the default workload.
-os.environ.setdefault("POSELIB_AMD_LATENCY_MODE", "0")
-import sys
+if not ("--streams" in sys.argv and sys.argv[sys.argv.index("--streams") + 1:][:1] == ["1"]):  # (one at a time: keep it)
+    os.environ.setdefault("POSELIB_AMD_LATENCY_MODE", "0")
 import time
 
 import numpy as np
