@@ -1,14 +1,14 @@
 #!/usr/bin/env python
-"""Parity soak on a GPU box: many random problems per estimator, product (through the C-ABI) vs oracle.
+"""Test infrastructure (uses the oracle).  Parity soak on a GPU box: many random problems per estimator, product (through the C-ABI) vs oracle.
 Compares iterations, refinements, inlier count, inlier mask and the model (1e-6).  Prints one summary line per
-estimator and every disagreement.   python scripts/parity_soak.py [problems per estimator] [seed]"""
+estimator and every disagreement.   python tests/parity_soak.py [problems per estimator] [seed]"""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 
 import oracle_lib as O  # noqa: E402

@@ -633,12 +633,12 @@ dist.destroy_process_group()
 
 
 def test_random_problem_soak(gpu):
-    """scripts/parity_soak.py in small: 4 x 40 random problems (12..3000 correspondences, 10..70 % outliers, default and
+    """tests/parity_soak.py in small: 4 x 40 random problems (12..3000 correspondences, 10..70 % outliers, default and
     fixed-length option sets) against the oracle - iterations, inlier count, mask, model."""
     import importlib.util
     import os
 
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "parity_soak.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "parity_soak.py")
     spec = importlib.util.spec_from_file_location("parity_soak", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
