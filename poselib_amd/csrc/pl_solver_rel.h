@@ -184,12 +184,11 @@ struct SturmWorkLocal {
 // the sign-variation count says) and intervals holding exactly one root - in recursion order; (2) the leaves are
 // turned into roots one after the other (Ridders + Newton polish for the isolating intervals).  A right half without
 // a sign variation is deferred only if it is narrower than tol (the one case in which visiting it has an effect).
-template <class Work> PL_HD int sturm_roots_deg10(const double *coef, double *roots, Work &w) {
+// f (monic) and f' / N of the Sturm chain from the coefficients; false when the leading coefficient is zero
+PL_HD bool sturm_monic(const double *coef, Sturm10 &S) {
     constexpr int N = 10;
-    const double tol = 1e-10;
     if (coef[N] == 0.0)
-        return 0;
-    Sturm10 S;
+        return false;
     const double lead_inv = 1.0 / coef[N];
     PL_UNROLL
     for (int i = 0; i < N; ++i)
@@ -199,6 +198,17 @@ template <class Work> PL_HD int sturm_roots_deg10(const double *coef, double *ro
     for (int i = 0; i < N - 1; ++i)
         S.fp[i] = S.f[i + 1] * ((i + 1) / (double)N);
     S.fp[N - 1] = 1.0;
+    return true;
+}
+
+// phase 1: the leaves of the bisection in recursion order (w.leaf_*); bit i of `tiny`: leaf i is narrower than tol
+template <class Work> PL_HD int sturm_isolate(const double *coef, Work &w, unsigned &tiny) {
+    constexpr int N = 10;
+    const double tol = 1e-10;
+    tiny = 0;
+    Sturm10 S;
+    if (!sturm_monic(coef, S))
+        return 0;
     sturm_build(S);
     double bound = 0;
     PL_UNROLL
@@ -208,11 +218,9 @@ template <class Work> PL_HD int sturm_roots_deg10(const double *coef, double *ro
     const int sa0 = sturm_variations(S, -bound), sb0 = sturm_variations(S, bound);
     if (sa0 - sb0 == 0)
         return 0;
-    // ---- phase 1: leaves in recursion order ----
     double a = -bound, b = bound;
     int sa = sa0, sb = sb0, depth = 0;
     int sp = 0, nleaf = 0;
-    unsigned tiny = 0; // bit i: leaf i is a narrow interval (root = its right end)
     for (;;) {
         bool descend = false;
         if (depth <= 300) { // MAX_STURM_RECURSION_DEPTH_LIMIT
@@ -254,17 +262,35 @@ template <class Work> PL_HD int sturm_roots_deg10(const double *coef, double *ro
         sb = (int)((info >> 4) & 0xfu);
         depth = (int)(info >> 8);
     }
-    // ---- phase 2: leaves -> roots ----
+    return nleaf;
+}
+
+// phase 2, one leaf: its root (the right end of a narrow leaf; Ridders + Newton on an isolating one, which reports
+// nothing when the end points do not bracket a sign change).  Returns the number of roots written (0 or 1).
+PL_HD int sturm_leaf_root(const Sturm10 &S, double la, double lb, bool is_tiny, double *root) {
+    if (is_tiny) {
+        *root = lb;
+        return 1;
+    }
+    int n = 0;
+    sturm_polish(S, la, lb, root, n, 1e-10);
+    return n;
+}
+
+template <class Work> PL_HD int sturm_roots_deg10(const double *coef, double *roots, Work &w) {
+    constexpr int N = 10;
+    unsigned tiny;
+    const int nleaf = sturm_isolate(coef, w, tiny);
+    if (nleaf == 0)
+        return 0;
+    Sturm10 S;
+    sturm_monic(coef, S);
     int n = 0;
     for (int i = 0; i < nleaf; ++i) {
         double la, lb;
         w.leaf_get(i, la, lb);
-        if (n < N) {
-            if ((tiny >> i) & 1u)
-                roots[n++] = lb;
-            else
-                sturm_polish(S, la, lb, roots, n, tol);
-        }
+        if (n < N)
+            n += sturm_leaf_root(S, la, lb, (tiny >> i) & 1u, roots + n);
     }
     return n;
 }
