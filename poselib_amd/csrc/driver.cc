@@ -1,18 +1,20 @@
 // poselib_amd — host driver behind the C-ABI (include/poselib_amd.h).
 //
 // What runs where
-//   device : sample draw + minimal solve (k_generate), hypothesis scoring (k_score/k_finalize), all LM
-//            refinements (k_lm), final inlier masks (k_mask).
-//   host   : the sequential bookkeeping of LO-RANSAC, replayed over the device results so that the outcome
+//   device : sampler positions (k_sample_delta / k_sample_orbit), sample draw + minimal solve (k_generate, k_rel_*),
+//            hypothesis scoring (k_score_mfma / k_score_queue), the running-best scan (k_finalize2 / k_records), the
+//            decision-relevant scores in the reference's summation order (k_score_seq), all LM refinements
+//            (k_lm / k_lm2), final inlier masks (k_mask), the per-point pre-processing of the front-ends (k_prepare).
+//   host   : the sequential bookkeeping of LO-RANSAC (RansacRun), replayed over the device results so that the outcome
 //            equals the reference's single-threaded loop (PoseLib/robust/ransac_impl.h:106-201):
-//              pass 1  scan (inlier count, MSAC score) of every minimal hypothesis of a batch in
-//                      (iteration, model) order; best_minimal_* depends on minimal models only (:113-123),
-//                      so the iterations that trigger LO and their seed models are known without LO results;
-//              device  all triggered LOs of the batch run as ONE batched k_lm launch, then are re-scored;
+//              pass 1  the candidate list of a batch - hypotheses that improve the running (inlier count, MSAC score)
+//                      in (iteration, model) order - through the exact rule; best_minimal_* depends on minimal models
+//                      only (:113-123), so the iterations that trigger LO and their seeds are known without LO results;
+//              device  all triggered LOs of the batch run as ONE batched LM launch, then are re-scored;
 //              pass 2  replay stats.model_score / best_model / dynamic_max_iter and the stop rule (:182)
 //                      iteration by iteration; iterations evaluated past the stop are discarded.
-//            plus O(N) pre/post-processing of the front-ends (PoseLib/robust.cc:36-126, 242-314, 544-594,
-//            712-757): un-projection, normalisation, threshold rescaling, de-normalisation.
+//            plus, of the front-ends (PoseLib/robust.cc:36-126, 242-314, 544-594, 712-757), the two order-dependent
+//            reductions of normalize_points, threshold rescaling and de-normalisation; PROSAC's serial sample schedule.
 // There is no CPU fallback for any device stage: without a HIP device the entry points fail.
 #include "../../include/poselib_amd.h"
 #include "pl_kernels.h"
