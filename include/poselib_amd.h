@@ -164,10 +164,11 @@ int pl_ransac_run(pl_problem *p, const pl_robust_options *opt, void *model, uint
 /* ---- ONE problem across several GPUs: every rank holds the same correspondences (its own pl_problem on
  * its own device) and calls pl_ransac_run_sharded with the same options.  Each batch of iterations is cut into `world`
  * contiguous ranges; a rank draws the whole batch's sample positions (integer work, replicated) but generates and
- * scores only its range.  ONE exchange step per batch: the ranks all-gather their improving hypotheses (<= 7 KB per
- * rank, a second message only when a rank has more than 32 of them); every rank then replays the sequential loop of
- * ransac_impl.h:157-201 on the merged list - including the local optimisations, which are replicated - so all
- * ranks return the same model, mask and stats, identical to the single-device run.  `allgather` is the caller's
+ * scores only its range.  Two exchange steps per batch: the ranks all-gather their improving hypotheses (<= 7 KB per
+ * rank, another message only when a rank has more than 32 of them), deal the triggered local optimisations out
+ * among themselves (job j on rank j mod world) and all-gather the refined models (0.2 KB per job); every rank then
+ * replays the sequential loop of ransac_impl.h:157-201 on the merged data, so all ranks return the same model, mask
+ * and stats, identical to the single-device run.  `allgather` is the caller's
  * collective (RCCL / gloo through torch.distributed, MPI, or shared memory between threads): it must copy `bytes` bytes
  * from `send` of rank r to `recv + r * bytes` on every rank, and return 0. */
 typedef int (*pl_allgather_fn)(void *user, const void *send, void *recv, size_t bytes);

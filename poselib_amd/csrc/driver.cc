@@ -1206,6 +1206,50 @@ struct RansacRun {
         return PL_OK;
     }
 
+    // Sharded runs: the local optimisations of a batch are dealt out to the ranks (job j to rank j mod world; the
+    // kernels are deterministic, so it does not matter which device refines a seed) and their results - refined record,
+    // inlier count, score - are all-gathered: the second (and last) exchange step of a batch, ~0.2 KB per job.
+    int run_refinements_sharded() {
+        struct WireJob {
+            double record_out[kModelStride];
+            double score;
+            uint32_t count, skipped;
+        };
+        const uint32_t nj = (uint32_t)jobs.size();
+        const uint32_t per_rank = (nj + G - 1) / G;
+        std::vector<RefineJob> mine;
+        for (uint32_t j = grank; j < nj; j += G)
+            mine.push_back(jobs[j]);
+        if (!mine.empty()) {
+            const int rc = run_refinements(c, p, mine, true, thr2);
+            if (rc != PL_OK)
+                return rc;
+        }
+        const size_t bytes = (size_t)per_rank * sizeof(WireJob);
+        wire_send.assign(bytes, 0);
+        wire_recv.assign(bytes * G, 0);
+        for (uint32_t a = 0; a < (uint32_t)mine.size(); ++a) {
+            WireJob w;
+            std::memset(&w, 0, sizeof(w));
+            std::memcpy(w.record_out, mine[a].record_out, sizeof(w.record_out));
+            w.score = mine[a].score;
+            w.count = mine[a].count;
+            w.skipped = mine[a].skipped ? 1u : 0u;
+            std::memcpy(wire_send.data() + (size_t)a * sizeof(WireJob), &w, sizeof(w));
+        }
+        if (sh->allgather(sh->user, wire_send.data(), wire_recv.data(), bytes) != 0)
+            return fail(PL_ERR_COMM, "all-gather callback failed");
+        for (uint32_t j = 0; j < nj; ++j) {
+            WireJob w;
+            std::memcpy(&w, wire_recv.data() + (size_t)(j % G) * bytes + (size_t)(j / G) * sizeof(WireJob), sizeof(w));
+            std::memcpy(jobs[j].record_out, w.record_out, sizeof(w.record_out));
+            jobs[j].score = w.score;
+            jobs[j].count = w.count;
+            jobs[j].skipped = w.skipped != 0;
+        }
+        return PL_OK;
+    }
+
     // ---- batched local optimisations of the batch, then the replay of the sequential loop over it ----
     int refine_and_replay(Batch &b) {
         const uint32_t B = b.B, lo_g = b.lo_g, hi_g = b.hi_g, Bl = b.Bl;
@@ -1224,7 +1268,7 @@ struct RansacRun {
                 jobs.push_back(make_lo_job(h_rec + (size_t)imps[a].gather * kModelStride));
             }
         if (!jobs.empty()) {
-            int rc = run_refinements(c, p, jobs, true, thr2);
+            const int rc = sh ? run_refinements_sharded() : run_refinements(c, p, jobs, true, thr2);
             if (rc != PL_OK)
                 return rc;
         }
