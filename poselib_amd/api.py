@@ -347,7 +347,7 @@ class Problem:
         """ONE problem across `world` GPUs (pl_ransac_run_sharded): every rank holds the same correspondences in its
         own Problem on its own device and calls this with the same options; each evaluates a contiguous share of every
         batch of iterations, and `allgather(send: bytes-like numpy uint8 array, recv: numpy uint8 array of world *
-        len(send))` is the one exchange step per batch (see poselib_amd.sharding.dist_allgather for the
+        len(send))` is the collective of the two exchange steps per batch (see poselib_amd.sharding.dist_allgather for the
         torch.distributed form).  All ranks return the same result - the single-device one."""
         o = _robust_options(opt, self.kind, initial is not None)
         inl = np.zeros(max(self.n, 1), dtype=np.uint8)

@@ -1102,7 +1102,7 @@ struct RansacRun {
         return PL_OK;
     }
 
-    // ---- sharded runs: the ONE exchange step of the batch (all-gather of the ranks' improving hypotheses) ----
+    // ---- sharded runs: first exchange step of the batch (all-gather of the ranks' improving hypotheses) ----
     int exchange_improving(Batch &b) {
         const bool overflow = b.overflow;
         const uint32_t H_local = b.H_local;
@@ -1111,7 +1111,7 @@ struct RansacRun {
         const ProsacSampler &prosac_at_batch_start = b.prosac_at_batch_start;
         uint32_t &H = b.H;
         const double *&h_rec = b.h_rec;
-        // ---- sharded: the ONE exchange step of the batch.  Every rank contributes the improving hypotheses of its
+        // ---- sharded: the first exchange step of the batch.  Every rank contributes the improving hypotheses of its
         // range (improving w.r.t. the batch-start state and its own earlier hypotheses - a superset of what the
         // sequential loop keeps); the merged list is filtered with the true running best, rank by rank, i.e. in
         // iteration order.  From here on every rank holds the same list and does the same thing. ----

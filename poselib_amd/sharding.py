@@ -13,7 +13,7 @@ import numpy as np
 
 
 def dist_allgather(group=None, device=None):
-    """The exchange step of Problem.run_sharded (ONE problem across the GPUs: every rank scores a share of each batch
+    """The collective of Problem.run_sharded's exchange steps (ONE problem across the GPUs: every rank scores a share of each batch
     of iterations) as a torch.distributed all-gather: RCCL when `device` is this rank's GPU ("nccl" backend), gloo
     with device=None.  Returns allgather(send, recv) for numpy uint8 arrays, len(recv) == world * len(send)."""
     import torch
