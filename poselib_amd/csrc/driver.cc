@@ -1507,8 +1507,28 @@ int make_problem_prepared(Context *c, int kind, const double *a, const double *b
     p->d_pts = c->pts_arena.as<double>();
     for (int d = 0; d < nd; ++d)
         p->ps.a[d] = p->d_pts + (size_t)d * n;
-    if (lm_only) { // (stream order puts the refinement behind k_prepare)
+    if (lm_only || kind != EST_ABS) { // (stream order puts the next kernels behind k_prepare)
+        // max|x| only parameterises the absolute-pose pre-filter
         p->ps.xy_absmax = std::numeric_limits<float>::infinity();
+        return PL_OK;
+    }
+    if (pa.mode == 0 && pa.cam1.model_id != CAM_OPENCV) {
+        // linear cameras: an upper bound of max(|x|, |y|) after un-projection from the raw pixels on the host - no
+        // read-back, no synchronisation (the un-projected coordinate is (px - c) / f up to one rounding)
+        const CameraParams &cam = pa.cam1;
+        double cx = 0, cy = 0, fx = 1, fy = 1;
+        if (cam.model_id == CAM_SIMPLE_PINHOLE)
+            fx = fy = cam.p[0], cx = cam.p[1], cy = cam.p[2];
+        else if (cam.model_id == CAM_PINHOLE)
+            fx = cam.p[0], fy = cam.p[1], cx = cam.p[2], cy = cam.p[3];
+        double m = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            const double u = std::fabs((a[2 * i] - cx) / fx), v = std::fabs((a[2 * i + 1] - cy) / fy);
+            m = (u > m || u != u) ? u : m; // NaN propagates (and disables the pre-filter)
+            m = (v > m || v != v) ? v : m;
+        }
+        m = m * (1.0 + 1e-12);
+        p->ps.xy_absmax = std::nextafter((float)m, std::numeric_limits<float>::infinity());
         return PL_OK;
     }
     HIP_TRY(hipMemcpyAsync(c->h_absmax.p, c->absmax.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
