@@ -358,7 +358,17 @@ uint64_t dynamic_max_iter(uint64_t inl, uint64_t N, uint64_t K, double log_fail,
         return min_it;
     if (p <= 0.0001)
         return max_it;
-    const uint64_t n = static_cast<uint64_t>(std::ceil(log_fail / std::log(1.0 - p) * mult));
+    // The reference converts the double to size_t with a plain static_cast (ransac_impl.h:70-71), which is undefined
+    // for values that do not fit - success_prob = 1 gives log(0) = -inf and hence +inf here.  Its de-facto behaviour
+    // (gcc, x86-64: cvttsd2si on x - 2^63 and a sign-bit flip for x >= 2^63) is spelled out so that it does not depend
+    // on the compiler of this file: +inf and everything >= 2^64 become 0, NaN becomes 2^63.
+    const double v = std::ceil(log_fail / std::log(1.0 - p) * mult);
+    const double two63 = 9223372036854775808.0;
+    auto cvttsd2si = [&](double x) -> int64_t {
+        return (x >= -two63 && x < two63) ? static_cast<int64_t>(x) : std::numeric_limits<int64_t>::min();
+    };
+    const uint64_t n = (v >= two63) ? (static_cast<uint64_t>(cvttsd2si(v - two63)) ^ 0x8000000000000000ull)
+                                    : static_cast<uint64_t>(cvttsd2si(v));
     return std::max(min_it, std::min(max_it, n));
 }
 
@@ -410,7 +420,7 @@ struct ProsacSampler {
         uint64_t T_np = 1;
         for (uint64_t n = K; n < N; ++n) {
             const double T_n_next = T_n * (n + 1.0) / (n + 1.0 - K);
-            T_np += (uint64_t)std::ceil(T_n_next - T_n);
+            T_np = (uint64_t)((double)T_np + std::ceil(T_n_next - T_n)); // `size_t += double` of sampling.cc:129
             growth[n] = T_np;
             T_n = T_n_next;
         }

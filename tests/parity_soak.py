@@ -44,6 +44,12 @@ def main(count=100, seed=1):
                 opt["ransac"].update(max_iterations=3000, min_iterations=int(rng.integers(100, 3000)))
             if rng.uniform() < 0.15:
                 opt["ransac"].update(progressive_sampling=True, max_prosac_iterations=int(rng.integers(50, 2000)))
+            if os.environ.get("SOAK_FUZZ"):  # odd option values
+                opt["ransac"].update(max_iterations=int(rng.choice([0, 1, 7, 300, 5000])),
+                                     min_iterations=int(rng.choice([0, 5, 400, 9000])),
+                                     success_prob=float(rng.choice([0.5, 0.99, 0.9999, 1.0])),
+                                     dyn_num_trials_mult=float(rng.choice([0.5, 3.0, 10.0])))
+                opt["max_error"] = float(rng.choice([0.05, 1.0, 12.0, 100.0]))
             if kind == "abs":
                 d = synth.absolute_pose_scene(n, outl, dseed)
                 got, info = P.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], opt)
