@@ -28,6 +28,25 @@ def model_diff(kind, a, b):
     return min(np.abs(A - B).max(), np.abs(A + B).max())
 
 
+def degrade(rng, d, keys):
+    """SOAK_FUZZ3: duplicated correspondences, a block of identical points, a few wildly scaled outliers"""
+    n = d[keys[0]].shape[0]
+    if n < 12:
+        return d
+    idx = np.arange(n)
+    dup = rng.integers(0, n, size=max(1, n // 5))
+    idx[rng.integers(0, n, size=dup.size)] = dup  # duplicates
+    blk = rng.integers(0, n, size=max(1, n // 10))
+    idx[blk] = idx[blk[0]]  # a block of identical correspondences
+    out = dict(d)
+    for k in keys:
+        out[k] = np.ascontiguousarray(d[k][idx])
+    wild = rng.integers(0, n, size=3)
+    out[keys[0]] = out[keys[0]].copy()
+    out[keys[0]][wild] *= np.array([1e4, -1e3])[: out[keys[0]].shape[1]] if out[keys[0]].shape[1] == 2 else 1.0
+    return out
+
+
 def main(count=100, seed=1):
     rng = np.random.default_rng(seed)
     total_bad = 0
@@ -50,21 +69,47 @@ def main(count=100, seed=1):
                                      success_prob=float(rng.choice([0.5, 0.99, 0.9999, 1.0])),
                                      dyn_num_trials_mult=float(rng.choice([0.5, 3.0, 10.0])))
                 opt["max_error"] = float(rng.choice([0.05, 1.0, 12.0, 100.0]))
+            cam_fuzz = None
+            if os.environ.get("SOAK_FUZZ2"):  # final-refinement options and camera models
+                opt["bundle"] = {"loss_type": str(rng.choice(["TRIVIAL", "TRUNCATED", "HUBER", "CAUCHY", "TRUNCATED_LE_ZACH"])),
+                                 "loss_scale": float(rng.choice([0.3, 1.0, 5.0])),
+                                 "max_iterations": int(rng.choice([0, 3, 100]))}
+                which = int(rng.integers(0, 3))
+                if which == 1:
+                    cam_fuzz = {"model": "PINHOLE", "width": 1000, "height": 1000,
+                                "params": [float(rng.uniform(900, 1100)), float(rng.uniform(900, 1100)),
+                                           float(rng.uniform(480, 520)), float(rng.uniform(480, 520))]}
+                elif which == 2:
+                    cam_fuzz = {"model": "OPENCV", "width": 1000, "height": 1000,
+                                "params": [float(rng.uniform(900, 1100)), float(rng.uniform(900, 1100)),
+                                           float(rng.uniform(480, 520)), float(rng.uniform(480, 520)),
+                                           float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-0.02, 0.02)),
+                                           float(rng.uniform(-0.002, 0.002)), float(rng.uniform(-0.002, 0.002))]}
             if kind == "abs":
                 d = synth.absolute_pose_scene(n, outl, dseed)
-                got, info = P.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], opt)
-                want, mask, st = O.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], opt)
+                if os.environ.get("SOAK_FUZZ3"):
+                    d = degrade(rng, d, ("p2d", "p3d"))
+                cam = cam_fuzz or d["camera"]
+                got, info = P.estimate_absolute_pose(d["p2d"], d["p3d"], cam, opt)
+                want, mask, st = O.estimate_absolute_pose(d["p2d"], d["p3d"], cam, opt)
                 got = got.pose
             elif kind == "rel":
                 d = synth.relative_pose_scene(n, outl, dseed)
-                got, info = P.estimate_relative_pose(d["x1"], d["x2"], d["camera1"], d["camera2"], opt)
-                want, mask, st = O.estimate_relative_pose(d["x1"], d["x2"], d["camera1"], d["camera2"], opt)
+                if os.environ.get("SOAK_FUZZ3"):
+                    d = degrade(rng, d, ("x1", "x2"))
+                c1, c2 = cam_fuzz or d["camera1"], cam_fuzz or d["camera2"]
+                got, info = P.estimate_relative_pose(d["x1"], d["x2"], c1, c2, opt)
+                want, mask, st = O.estimate_relative_pose(d["x1"], d["x2"], c1, c2, opt)
             elif kind == "fund":
                 d = synth.fundamental_scene(n, outl, dseed)
+                if os.environ.get("SOAK_FUZZ3"):
+                    d = degrade(rng, d, ("x1", "x2"))
                 got, info = P.estimate_fundamental(d["x1"], d["x2"], opt)
                 want, mask, st = O.estimate_fundamental(d["x1"], d["x2"], opt)
             else:
                 d = synth.homography_scene(n, outl, dseed)
+                if os.environ.get("SOAK_FUZZ3"):
+                    d = degrade(rng, d, ("x1", "x2"))
                 got, info = P.estimate_homography(d["x1"], d["x2"], opt)
                 want, mask, st = O.estimate_homography(d["x1"], d["x2"], opt)
             same = (info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
