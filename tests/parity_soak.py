@@ -90,8 +90,15 @@ def main(count=100, seed=1):
                 if os.environ.get("SOAK_FUZZ3"):
                     d = degrade(rng, d, ("p2d", "p3d"))
                 cam = cam_fuzz or d["camera"]
-                got, info = P.estimate_absolute_pose(d["p2d"], d["p3d"], cam, opt)
-                want, mask, st = O.estimate_absolute_pose(d["p2d"], d["p3d"], cam, opt)
+                init_p = init_o = None
+                if os.environ.get("SOAK_FUZZ4") and rng.uniform() < 0.7:  # warm start (score_initial_model)
+                    q = np.asarray(d["q_gt"]) + rng.normal(0, float(rng.choice([1e-4, 1e-2, 0.5])), 4)
+                    q /= np.linalg.norm(q)
+                    t = np.asarray(d["t_gt"]) + rng.normal(0, 0.01, 3)
+                    init_p, init_o = P.CameraPose(q, t), np.r_[q, t]
+                oo = dict(opt, ransac=dict(opt["ransac"], score_initial_model=init_o is not None))
+                got, info = P.estimate_absolute_pose(d["p2d"], d["p3d"], cam, opt, init_p)
+                want, mask, st = O.estimate_absolute_pose(d["p2d"], d["p3d"], cam, oo, init_o)
                 got = got.pose
             elif kind == "rel":
                 d = synth.relative_pose_scene(n, outl, dseed)
@@ -104,14 +111,24 @@ def main(count=100, seed=1):
                 d = synth.fundamental_scene(n, outl, dseed)
                 if os.environ.get("SOAK_FUZZ3"):
                     d = degrade(rng, d, ("x1", "x2"))
-                got, info = P.estimate_fundamental(d["x1"], d["x2"], opt)
-                want, mask, st = O.estimate_fundamental(d["x1"], d["x2"], opt)
+                init_m = None
+                if os.environ.get("SOAK_FUZZ4"):
+                    opt["real_focal_check"] = bool(rng.uniform() < 0.5)
+                    if rng.uniform() < 0.5:
+                        init_m = rng.normal(size=(3, 3))
+                oo = dict(opt, ransac=dict(opt["ransac"], score_initial_model=init_m is not None))
+                got, info = P.estimate_fundamental(d["x1"], d["x2"], opt, init_m)
+                want, mask, st = O.estimate_fundamental(d["x1"], d["x2"], oo, init_m)
             else:
                 d = synth.homography_scene(n, outl, dseed)
                 if os.environ.get("SOAK_FUZZ3"):
                     d = degrade(rng, d, ("x1", "x2"))
-                got, info = P.estimate_homography(d["x1"], d["x2"], opt)
-                want, mask, st = O.estimate_homography(d["x1"], d["x2"], opt)
+                init_m = None
+                if os.environ.get("SOAK_FUZZ4") and rng.uniform() < 0.5:
+                    init_m = np.eye(3) + rng.normal(0, 0.05, (3, 3))
+                oo = dict(opt, ransac=dict(opt["ransac"], score_initial_model=init_m is not None))
+                got, info = P.estimate_homography(d["x1"], d["x2"], opt, init_m)
+                want, mask, st = O.estimate_homography(d["x1"], d["x2"], oo, init_m)
             same = (info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
                     and (np.array(info["inliers"]) == mask).all())
             diff = model_diff(kind, got, want) if st["num_inliers"] > 0 else 0.0
