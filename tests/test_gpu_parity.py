@@ -632,17 +632,23 @@ dist.destroy_process_group()
         assert ok and its == 5000 and inl > 500, (rank, ok, its, inl)
 
 
-def test_random_problem_soak(gpu):
-    """tests/parity_soak.py in small: 4 x 40 random problems (12..3000 correspondences, 10..70 % outliers, default and
-    fixed-length option sets) against the oracle - iterations, inlier count, mask, model."""
+@pytest.mark.parametrize("mode,count", [("", 40), ("SOAK_FUZZ", 20), ("SOAK_FUZZ2", 12), ("SOAK_FUZZ3", 20), ("SOAK_FUZZ4", 20)])
+def test_random_problem_soak(gpu, monkeypatch, mode, count):
+    """tests/parity_soak.py in small: 4 x `count` random problems against the oracle - iterations, inlier count, mask,
+    model.  Modes: plain (12..3000 correspondences, 10..70 % outliers, default / fixed-length / PROSAC option sets), odd
+    option values (SOAK_FUZZ: success_prob = 1, max < min iterations, ...), final-refinement options and camera
+    models (SOAK_FUZZ2), degraded data (SOAK_FUZZ3), warm starts and real_focal_check (SOAK_FUZZ4)."""
     import importlib.util
     import os
 
+    if mode:
+        monkeypatch.setenv(mode, "1")
+        monkeypatch.setenv("SOAK_NMAX", "800")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "parity_soak.py")
     spec = importlib.util.spec_from_file_location("parity_soak", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.main(40, 2024) == 0
+    assert mod.main(count, 2024) == 0
 
 
 def test_non_finite_inputs_do_not_hang_or_crash(gpu):
