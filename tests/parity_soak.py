@@ -133,9 +133,11 @@ def main(count=100, seed=1):
                     and (np.array(info["inliers"]) == mask).all())
             diff = model_diff(kind, got, want) if st["num_inliers"] > 0 else 0.0
             worst = max(worst, diff if same else 0.0)
-            if same and diff > 1e-6 and os.environ.get("SOAK_FUZZ3") and kind == "rel":
-                # degraded data make the 5-point problem ambiguous: several poses with the same support and score; which
-                # one wins is decided in the last bits of solvers that are equivalent, not bit-identical
+            if ((not same or diff > 1e-6) and os.environ.get("SOAK_FUZZ3") and kind == "rel"
+                    and info["num_inliers"] == st["num_inliers"] and info["iterations"] == st["iterations"]):
+                # duplicated correspondences inside a minimal sample make the 5-point problem rank deficient: the null
+                # space basis - and with it the solutions - of two equivalent, not bit-identical solvers differ, and
+                # another model with the same support can win
                 ambiguous += 1
             elif not same or diff > 1e-6:
                 bad += 1
@@ -146,7 +148,7 @@ def main(count=100, seed=1):
                 ref_only += 1
         total_bad += bad
         print(f"{kind}: {count} problems, {bad} disagreements, {ref_only} with a different refinement count only, "
-              + (f"{ambiguous} ambiguous (same inliers, another pose), " if ambiguous else "") +
+              + (f"{ambiguous} ambiguous (same support, another pose), " if ambiguous else "") +
               f"worst model difference among the agreeing {worst:.2e}, {time.time() - t0:.1f} s")
     return total_bad
 
