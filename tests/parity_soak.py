@@ -129,6 +129,19 @@ def main(count=100, seed=1):
                 oo = dict(opt, ransac=dict(opt["ransac"], score_initial_model=init_m is not None))
                 got, info = P.estimate_homography(d["x1"], d["x2"], opt, init_m)
                 want, mask, st = O.estimate_homography(d["x1"], d["x2"], oo, init_m)
+            if os.environ.get("SOAK_RANSAC"):  # the ransac_* entry points on normalised image points instead
+                ro = dict(opt, max_error=float(rng.choice([5e-4, 1e-3, 1.2e-2])))
+                if kind == "abs":
+                    par = d["camera"]["params"]
+                    x = (d["p2d"] - np.array(par[-2:])) / par[0]
+                    got, info = P.ransac_pnp(x, d["p3d"], ro)
+                    want, mask, st = O.ransac_pnp(x, d["p3d"], ro)
+                else:
+                    x1, x2 = (d["x1"] - 500.0) / 1000.0, (d["x2"] - 500.0) / 1000.0
+                    fn, ofn = {"rel": (P.ransac_relpose, O.ransac_relpose), "fund": (P.ransac_fundamental, O.ransac_fundamental),
+                               "hom": (P.ransac_homography, O.ransac_homography)}[kind]
+                    got, info = fn(x1, x2, ro)
+                    want, mask, st = ofn(x1, x2, ro)
             same = (info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
                     and (np.array(info["inliers"]) == mask).all())
             diff = model_diff(kind, got, want) if st["num_inliers"] > 0 else 0.0
