@@ -396,6 +396,22 @@ def test_estimate_with_prosac_and_initial_model():
     assert np.abs(ma - mb).max() < 1e-9
 
 
+@pytest.mark.parametrize("ransac", [{"success_prob": 1.0, "min_iterations": 5, "max_iterations": 300},
+                                    {"success_prob": 1.0, "min_iterations": 400, "max_iterations": 5000, "dyn_num_trials_mult": 0.5},
+                                    {"min_iterations": 9000, "max_iterations": 300}, {"max_iterations": 0}, {"max_iterations": 1},
+                                    {"success_prob": 0.5, "dyn_num_trials_mult": 10.0, "min_iterations": 0}])
+def test_odd_loop_control_options(ransac):
+    """Loop control outside the usual range.  success_prob = 1 makes ransac_impl.h:70-71 cast +inf to size_t - undefined
+    behaviour that this toolchain (gcc, x86-64) resolves to 0, i.e. the run stops right after min_iterations: the
+    oracle (same literal code, same compiler) and the reference's sources must agree, and the product spells the
+    conversion out (driver.cc dynamic_max_iter; GPU soak with SOAK_FUZZ)."""
+    d = synth.homography_scene(400, 0.3, 850)
+    opt = {"max_error": 1.5, "ransac": dict(ransac, seed=3)}
+    st, _ = _cmp_frontend("estimate_homography", (d["x1"], d["x2"]), opt)
+    if ransac.get("success_prob") == 1.0 and st["num_inliers"] > 0:
+        assert st["iterations"] <= ransac["min_iterations"] + 2 < ransac["max_iterations"]  # stops right after min_iterations
+
+
 EXACT = []  # per LM comparison: parameters and final cost bit-identical?
 
 
