@@ -607,30 +607,42 @@ template <int NP> PL_HD int motion_from_essential(const Mat3 &E, const Vec3 *x1,
 namespace detail5 {
 // monomial tables.  linear: [x y z 1]; quadratic: [x2 xy xz x y2 yz y z2 z 1];
 // cubic (Nister): [x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy xz2 xz x yz2 yz y z3 z2 z 1]
-PL_HD int quad_index(int i, int j) { // linear_i * linear_j, i <= j
-    const int t[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
-    return t[i][j];
-}
-PL_HD int cubic_index(int q, int l) { // quadratic_q * linear_l
-    const int t[10][4] = {{0, 2, 4, 5},   {2, 3, 8, 9},    {4, 8, 10, 11},  {5, 9, 11, 12},  {3, 1, 6, 7},
-                          {8, 6, 13, 14}, {9, 7, 14, 15}, {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}};
-    return t[q][l];
-}
-// acc(quadratic) += s * a(linear) * b(linear)
+// (namespace-scope constexpr tables: with the loops unrolled every look-up folds to a constant on host and device)
+constexpr int kQuadIndex[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+constexpr int kCubicIndex[10][4] = {{0, 2, 4, 5},   {2, 3, 8, 9},    {4, 8, 10, 11},  {5, 9, 11, 12},  {3, 1, 6, 7},
+                                    {8, 6, 13, 14}, {9, 7, 14, 15}, {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+PL_HD constexpr int quad_index(int i, int j) { return kQuadIndex[i][j]; }   // linear_i * linear_j (symmetric)
+PL_HD constexpr int cubic_index(int q, int l) { return kCubicIndex[q][l]; } // quadratic_q * linear_l
+// acc(quadratic) += s * (a(linear) * b(linear)).  Every coefficient of the product is formed on its own first - its
+// terms in the order "constant towards x" (descending index) of a, then of b (the oracle skips exact zeros of `a`:
+// adding their +-0 products changes no bit of a finite sum, which never is -0) - and then added: the association order of the oracle's polynomial arithmetic (oracle/src/solvers_rel.cc mul / axpy), so that
+// both produce the same bits.  (Monomial by monomial: one scalar temporary instead of a whole product in registers.)
 PL_HD void mac_lin_lin(double *acc, double s, const double *a, const double *b) {
     PL_UNROLL
-    for (int i = 0; i < 4; ++i)
+    for (int m = 0; m < 10; ++m) {
+        double t = 0.0;
         PL_UNROLL
-        for (int j = 0; j < 4; ++j)
-            acc[quad_index(i, j)] += s * (a[i] * b[j]);
+        for (int i = 3; i >= 0; --i)
+            PL_UNROLL
+            for (int j = 3; j >= 0; --j)
+                if (quad_index(i, j) == m)
+                    t += a[i] * b[j];
+        acc[m] += s * t;
+    }
 }
-// acc(cubic) += a(quadratic) * b(linear)
+// acc(cubic) += a(quadratic) * b(linear), same order
 PL_HD void mac_quad_lin(double *acc, const double *a, const double *b) {
     PL_UNROLL
-    for (int q = 0; q < 10; ++q)
+    for (int m = 0; m < 20; ++m) {
+        double t = 0.0;
         PL_UNROLL
-        for (int l = 0; l < 4; ++l)
-            acc[cubic_index(q, l)] += a[q] * b[l];
+        for (int q = 9; q >= 0; --q)
+            PL_UNROLL
+            for (int l = 3; l >= 0; --l)
+                if (cubic_index(q, l) == m)
+                    t += a[q] * b[l];
+        acc[m] += 1.0 * t;
+    }
 }
 } // namespace detail5
 
@@ -689,10 +701,12 @@ PL_HD void rel5_front(const Vec3 *x1, const Vec3 *x2, double *nb /* 36: nb[b*9 +
             }
         PL_UNROLL
         for (int m = 0; m < 10; ++m) {
-            const double h = 0.5 * (EEt[0][0][m] + EEt[1][1][m] + EEt[2][2][m]);
-            EEt[0][0][m] -= h;
-            EEt[1][1][m] -= h;
-            EEt[2][2][m] -= h;
+            double h = 0.0 + 0.5 * EEt[0][0][m]; // half the trace, summed like the oracle's axpy chain
+            h += 0.5 * EEt[1][1][m];
+            h += 0.5 * EEt[2][2][m];
+            EEt[0][0][m] += -1.0 * h;
+            EEt[1][1][m] += -1.0 * h;
+            EEt[2][2][m] += -1.0 * h;
         }
         PL_UNROLL
         for (int i = 0; i < 3; ++i)

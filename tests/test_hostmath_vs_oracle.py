@@ -94,21 +94,19 @@ def test_two_view_solvers_and_scores():
             sc, cnt, _, _ = HM.score("hom", recs[0], cols, thr2)
             osc, ocnt = O.score("homography", H, a, b, thr2)
             assert cnt == ocnt and abs(sc - osc) <= 1e-12 * abs(osc)
-    # 5-point: same solution counts, rounding-level agreement for the bulk
+    # 5-point: the constraint polynomials are accumulated in the oracle's association order (pl_solver_rel.h
+    # mac_lin_lin / mac_quad_lin), everything downstream is the same sequence of operations: bit-identical poses
     idx, _, _ = HM.draw_samples(0, 2000, 5, 600)
-    diffs, mism = [], 0
+    total = 0
     for it in range(600):
         s = idx[it]
         ref = O.relpose_5pt(bear(a[s]), bear(b[s]))
         recs = HM.solve("rel", bear(a[s]), bear(b[s]))
-        if len(ref) != len(recs):
-            mism += 1
-            continue
+        assert len(ref) == len(recs), it
         for o, r in zip(ref, recs):
-            diffs.append(np.abs(o - r[:7]).max())
-    assert mism <= 3
-    diffs = np.sort(diffs)
-    assert np.median(diffs) < 1e-12 and diffs[int(0.99 * (len(diffs) - 1))] < 1e-7
+            assert (o == r[:7]).all(), (it, o, r[:7])
+        total += len(ref)
+    assert total > 300
     pose, mask, st = O.ransac_relpose(a, b, dict(max_error=1e-3))
     rec = HM.pose_record(pose[:4], pose[4:], True)
     sc, cnt, flags, _ = HM.score("rel", rec, cols, thr2)
