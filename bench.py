@@ -64,7 +64,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=16,
                     help="independent problems in flight per GPU (one host thread + HIP stream each)")
     ap.add_argument("--problems-per-step", type=int, default=0,
