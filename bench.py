@@ -1,43 +1,53 @@
 #!/usr/bin/env python
-"""bench.py — scored RANSAC hypotheses / second on MI355X (BASELINE.json metric).
+"""bench.py — scored RANSAC hypotheses / second on MI355X (BASELINE.json metric: P3P@5k corrs, 5pt@5k corrs).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+        N > 1 and no WORLD_SIZE in the environment: bench.py starts the N ranks ITSELF (re-exec under
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), one process per
+        GPU; launched under torchrun by someone else it uses the ranks it finds.  It never prints n_gpus = 1 for
+        --gpus 8: too few devices is an error.
 
-Workload (config.workload = "p3p_5000"): BASELINE.json configs[1] — P3P LO-RANSAC on 5000 synthetic 2D-3D
-correspondences, 70 % outliers, max_iterations = 100000, with min_iterations = max_iterations so that the
-loop really evaluates 100000 iterations (with default options PoseLib stops after ~10^3).
-One "step" = one batch of 8 x S (default 128) independent, complete ransac_pnp problems (sample -> P3P -> score all N -> LO ->
-final refinement -> inlier mask; different RANSAC seeds) worked through by S (= --streams, default 16) host
-threads with one HIP stream each, i.e. S problems in flight on the GPU, on correspondences that are already
-resident in HBM.  A hypothesis = one minimal-solver model scored
-against all N correspondences (ransac_impl.h:112-113).  Multi-GPU: independent image pairs, one per rank
-(weak scaling, no data-path collective); RCCL is used only for the barrier and the final gather.
+Primary workload (value / ms_per_step; config.workload = "p3p_5000"): BASELINE.json configs[1] - P3P LO-RANSAC on
+5000 synthetic 2D-3D correspondences, 70 % outliers, max_iterations = min_iterations = 100000 (with default options
+PoseLib stops after ~10^3 iterations).  One "step" = a batch of independent, complete ransac_pnp problems
+(sample -> P3P -> score all N -> LO -> final refinement -> inlier mask; different RANSAC seeds) worked through by S
+(= --streams, default 16) host threads with one HIP stream each, on correspondences already resident in HBM.
+A hypothesis = one minimal-solver model scored against all N correspondences (ransac_impl.h:112-113).
+The same K steps are then run for the metric's second half and the other BASELINE configs (config.secondary:
+relpose_5000 = configs[2], fund_10000 / hom_10000 = configs[3]), each with its own value / roofline / parity / CPU
+baseline.  Multi-GPU: independent image pairs, one set per rank (weak scaling, no data-path collective); RCCL is used
+for the barrier and the final gather only.
 
 The JSON line also carries
-  roofline     : dominant kernel k_score_queue<ABS,5>; achieved = algorithmic bytes (hypotheses x N x 40 B, i.e. as if
-                 every hypothesis streamed the fp64 correspondence set) / HIP-event duration of the launches.
-                 NOTE the set is register/LDS resident, so physical HBM traffic (roofline.traffic, from the committed
-                 PMC passes) is orders of magnitude lower and the real bound is the vector ALU;
-                 frac may therefore exceed 1.
-  cpu_baseline : the CPU oracle (port of the reference path, single thread like the reference) timed on the
-                 same workload on this box's host cores (rank 0, N=1 only).
+  parity       : the GPU results of RANSAC seeds 0..7 of the first timed step against the CPU oracle's runs of the same
+                 seeds (the runs that also give cpu_baseline): iterations, refinements, hypotheses, inlier count and
+                 mask must be identical, models within 1e-6.  A mismatch makes the exit code non-zero.
+  roofline     : dominant kernel (k_score_mfma / k_score_queue).  bound = "valu_issue": the correspondences are
+                 register/LDS-resident, so the kernel is limited by vector-ALU issue, not by HBM.
+                 achieved = VALU wave-instructions per launch (PMC-measured instructions per (hypothesis, point chunk),
+                 committed in profiles/pmc_traffic.json, x hypotheses x chunks of the launch) / launch duration (HIP
+                 events, launching stream); peak = 1024 SIMDs x clock / 4 cycles per wave64 instruction; frac < 1 by
+                 construction.  The SURVEY 8d "as if streamed" byte count is kept as algorithmic_hbm_x_peak, the PMC
+                 traffic as hbm_frac_physical.
+  cpu_baseline : oracle/_ref (the reference's own sources, kind "reference") and the oracle restatement ("port") timed
+                 on the same workload on this box's host cores (rank 0, N = 1 only; single-threaded per problem like the
+                 reference, several problems on separate cores at once, rate quoted per core).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 
 # one HIP stream per in-flight problem: let the runtime map the 16 streams onto 16 hardware queues instead of the
 # default 4 (must be set before the HIP runtime initialises).  Measured on MI355X, whole-job throughput of the
 # default workload: 4 queues 3.4e8, 8 queues 3.9e8, 12 queues 4.0e8, 16 queues 4.2e8 hypotheses/s - two streams sharing
-# a queue block each other behind their long single-CU kernels (LM, sampler orbit).  (bench_batch.py keeps the
-# runtime default of 4, which is best for its short default-option problems.)
-# (stress-tested with 32 queues and 40 streams in one process: no resource failures)
+# a queue block each other behind their long single-CU kernels (LM, sampler orbit).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # throughput benchmark: every LO task on one workgroup (k_lm) instead of spread over several with one launch per LM
 # iteration (k_lm2, the library's default for large homography / fundamental problems: 1.5-2.2x shorter single
-# problems, but -10..-25 % throughput with 16 problems in flight).  No effect on the default workload.
+# problems, but -10..-25 % throughput with 16 problems in flight).  No effect on the primary workload.
 if not ("--streams" in sys.argv and sys.argv[sys.argv.index("--streams") + 1:][:1] == ["1"]):  # (one at a time: keep it)
     os.environ.setdefault("POSELIB_AMD_LATENCY_MODE", "0")
 import time
@@ -51,13 +61,353 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ITERATIONS = 100000
 FOCAL = 1000.0
 HBM_PEAK_GBS = 8000.0
-# workload -> (problem kind, N, outlier ratio, max_error [px], data seed, bytes per correspondence, description)
+SIMDS = 1024            # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+PEAK_CLOCK_GHZ = 2.4    # peak engine clock; a wave64 VALU instruction occupies its SIMD for 4 cycles
+VALU_PEAK_GINST_S = SIMDS * PEAK_CLOCK_GHZ / 4.0  # 614.4 G wave-instructions / s
+PARITY_SEEDS = 8
+POSE_TOL = 1e-6
+# workload -> (kind, N, outlier ratio, max_error [px], data seed, bytes per correspondence, problems per step and
+#              in-flight stream, description)
 WORKLOADS = {
-    "p3p_5000": (0, 5000, 0.7, 12.0, 1001, 40, "P3P LO-RANSAC (ransac_pnp), BASELINE configs[1]"),
-    "relpose_5000": (1, 5000, 0.5, 1.0, 1002, 32, "5-point LO-RANSAC (ransac_relpose), BASELINE configs[2]"),
-    "fund_10000": (2, 10000, 0.5, 1.0, 1004, 32, "7-point LO-RANSAC (ransac_fundamental), BASELINE configs[3]"),
-    "hom_10000": (3, 10000, 0.5, 1.0, 1003, 32, "4-point homography LO-RANSAC (ransac_homography), BASELINE configs[3]"),
+    "p3p_5000": (0, 5000, 0.7, 12.0, 1001, 40, 64, "P3P LO-RANSAC (ransac_pnp), BASELINE configs[1]"),
+    "relpose_5000": (1, 5000, 0.5, 1.0, 1002, 32, 10, "5-point LO-RANSAC (ransac_relpose), BASELINE configs[2]"),
+    "fund_10000": (2, 10000, 0.5, 1.0, 1004, 32, 4, "7-point LO-RANSAC (ransac_fundamental), BASELINE configs[3]"),
+    "hom_10000": (3, 10000, 0.5, 1.0, 1003, 32, 12, "4-point homography LO-RANSAC (ransac_homography), BASELINE configs[3]"),
 }
+SECONDARY = ["relpose_5000", "fund_10000", "hom_10000"]
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run ourselves."""
+    if not os.environ.get("BENCH_SHARE_DEVICE") and "--rehearse-distributed" not in sys.argv:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible; refusing to run a smaller job "
+                  "under that label", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def model_vec(kind, model):
+    if kind in (0, 1):
+        return np.r_[np.asarray(model.q, dtype=np.float64), np.asarray(model.t, dtype=np.float64)]
+    return np.asarray(model, dtype=np.float64).reshape(-1)
+
+
+def model_diff(kind, got, ref):
+    """rotation + translation difference for poses (BASELINE: 1e-6 each), sign-free normalised difference for F / H"""
+    if kind in (0, 1):
+        from poselib_amd import synth
+
+        dr = float(np.linalg.norm(synth.quat_to_rotmat(got[:4]) - synth.quat_to_rotmat(ref[:4])))
+        return max(dr, float(np.linalg.norm(got[4:] - ref[4:])))
+    a, b = got / np.linalg.norm(got), ref / np.linalg.norm(ref)
+    return float(min(np.linalg.norm(a - b), np.linalg.norm(a + b)))
+
+
+class Ranks:
+    """rank bookkeeping + the two collectives the bench needs (barrier, final gather)"""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_DEVICE=1: rehearsal of the multi-rank path on a box with ONE GPU (all
+        # ranks use device 0, the collectives run on CPU tensors).  Never used for reported numbers.
+        self.backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        self.device_index = 0 if os.environ.get("BENCH_SHARE_DEVICE") else self.local_rank
+        self.coll_device = "cuda" if self.backend == "nccl" else "cpu"
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self, cuda=True):
+        if cuda:
+            import torch
+
+            torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            if cuda:
+                import torch
+
+                torch.cuda.synchronize()
+
+    def gather(self, values):
+        """every rank contributes a vector of doubles; returns the (world, len) table on every rank"""
+        import torch
+
+        rec = torch.tensor(values, dtype=torch.float64, device=self.coll_device)
+        if self.dist is None:
+            return rec.cpu().numpy()[None]
+        out = [torch.zeros_like(rec) for _ in range(self.world)]
+        self.dist.all_gather(out, rec)
+        return torch.stack(out).cpu().numpy()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def rehearse(args):
+    """--rehearse-distributed: the launch / rendezvous / barrier / gather path of a multi-rank run WITHOUT any GPU work
+    (tests/test_bench_distributed.py runs it with the gloo backend on CPU).  Prints a line that cannot be mistaken for a
+    measurement: no metric, no value."""
+    ranks = Ranks(args)
+    ranks.barrier(cuda=False)
+    table = ranks.gather([float(ranks.rank), float(os.getpid()), 1.0])
+    ranks.barrier(cuda=False)
+    if ranks.rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": ranks.world, "backend": ranks.backend,
+                          "ranks_seen": [int(r) for r in table[:, 0]], "distinct_processes": len(set(table[:, 1])),
+                          "metric": None, "value": None}))
+    ranks.close()
+    return 0
+
+
+def run_workload(name, args, ranks, P, synth, pool_factory, primary):
+    """K timed steps of one workload on this rank; returns the per-rank record and (rank 0) the data the report needs"""
+    KIND, N_POINTS, OUTLIER_RATIO, MAX_ERROR_PX, DATA_SEED, BYTES_PER_CORR, PPS_PER_STREAM, DESCR = WORKLOADS[name]
+    shard_problem = bool(args.shard_problem)
+    pp = np.array([500.0, 500.0])
+    data_rank = 0 if shard_problem else ranks.rank  # one image pair per rank; sharded problem: the same on every rank
+    if KIND == 0:
+        scene = synth.absolute_pose_scene(N_POINTS, OUTLIER_RATIO, DATA_SEED + data_rank)
+        A, Bpts = (scene["p2d"] - pp) / FOCAL, scene["p3d"]
+    else:
+        gen = {1: synth.relative_pose_scene, 2: synth.fundamental_scene, 3: synth.homography_scene}[KIND]
+        scene = gen(N_POINTS, OUTLIER_RATIO, DATA_SEED + data_rank)
+        A, Bpts = (scene["x1"] - pp) / FOCAL, (scene["x2"] - pp) / FOCAL
+    thr = MAX_ERROR_PX / FOCAL
+    S = 1 if shard_problem else max(1, args.streams)  # collectives of one process group must be issued in one order
+    pool = pool_factory(S)
+    # the front-end's O(N) pre-processing (robust.cc:40-46) is done once, outside the timed region
+    probs = list(pool.map(lambda _: P.Problem(KIND, A, Bpts), range(S)))  # SoA in HBM, resident from here on
+
+    exchange = None
+    if shard_problem and ranks.dist is not None:
+        from poselib_amd import sharding
+
+        exchange = sharding.dist_allgather(device=(f"cuda:{ranks.device_index}" if ranks.backend == "nccl" else None))
+
+    def run_one(a):
+        prob, seed = a
+        opt = {"max_error": thr, "ransac": {"max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "seed": seed}}
+        if exchange is not None:
+            return prob.run_sharded(opt, ranks.rank, ranks.world, exchange)
+        return prob.run(opt)
+
+    if primary and args.problems_per_step > 0:
+        PPS = args.problems_per_step
+    else:
+        PPS = max(PARITY_SEEDS, PPS_PER_STREAM * S if primary else max(1, int(PPS_PER_STREAM * S * args.secondary_scale)))
+
+    def step(seed):
+        """a batch of PPS independent problems (RANSAC seeds seed * PPS + j) worked through by S host threads / HIP
+        streams, i.e. S problems in flight on this GPU at any time"""
+        return list(pool.map(run_one, [(probs[j % S], seed * PPS + j) for j in range(PPS)]))
+
+    for w in range(args.warmup):
+        step(1000 + w)
+    # the dominant kernel with the device to itself (4 problems one after the other, outside the timed region)
+    ranks.barrier()
+    solo_ms, solo_launches, solo_hyp = 0.0, 0, 0
+    for j in range(4):
+        _, info = pool.submit(run_one, (probs[0], 7000 + j)).result()
+        solo_ms += info["score_kernel_ms"]
+        solo_launches += info["score_kernel_launches"]
+        solo_hyp += info["hypotheses"]
+    ranks.barrier()
+    t0 = time.perf_counter()
+    hyp = nan_hyp = launches = 0
+    kern_ms = 0.0
+    first, last = None, None
+    for s in range(args.steps):
+        res = step(s)
+        if s == 0:
+            first = res[:PARITY_SEEDS]  # RANSAC seeds 0..7: the ones the oracle runs below
+        for _, info in res:
+            hyp += info["hypotheses"]
+            nan_hyp += info["nan_hypotheses"]
+            kern_ms += info["score_kernel_ms"]
+            launches += info["score_kernel_launches"]
+        last = res[-1]
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    for pr in probs:
+        pr.close()
+    pool.shutdown()
+    rec = [elapsed, float(hyp), kern_ms, float(launches), float(last[1]["num_inliers"]), float(nan_hyp), solo_ms,
+           float(solo_launches), float(solo_hyp)]
+    ctx = {"A": A, "B": Bpts, "thr": thr, "first": first, "PPS": PPS, "S": S, "kind": KIND, "n": N_POINTS,
+           "bytes_per_corr": BYTES_PER_CORR, "descr": DESCR, "outliers": OUTLIER_RATIO, "max_error_px": MAX_ERROR_PX,
+           "shard_problem": shard_problem}
+    return rec, ctx
+
+
+def cpu_runs(kind, A, Bpts, thr, iterations, nseeds, use_reference):
+    """RANSAC seeds 0..nseeds-1 of the workload on the host: single-threaded per problem like the reference, the
+    problems on separate cores (ctypes releases the GIL).  use_reference: oracle/_ref/libposelib_ref.so (the reference's
+    own sources) instead of the oracle restatement.  Test infrastructure used as the CHECKER and the CPU baseline only."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import oracle_lib as O
+
+    fn_name = {0: "ransac_pnp", 1: "ransac_relpose", 2: "ransac_fundamental", 3: "ransac_homography"}[kind]
+
+    def one(seed):
+        o = {"max_error": thr, "ransac": {"max_iterations": iterations, "min_iterations": iterations, "seed": seed}}
+        return getattr(O, fn_name)(A, Bpts, o)
+
+    def run_all():
+        workers = max(1, min(nseeds, (os.cpu_count() or 2) // 2))
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            return list(ex.map(one, range(nseeds))), workers
+
+    t1 = time.perf_counter()
+    if use_reference:
+        import ref_lib
+
+        with ref_lib.reference():
+            out, workers = run_all()
+    else:
+        out, workers = run_all()
+    return out, time.perf_counter() - t1, workers, fn_name
+
+
+def parity_block(kind, gpu_first, cpu_out):
+    checked = min(len(gpu_first), len(cpu_out))
+    same = {"iterations": 0, "refinements": 0, "hypotheses": 0, "num_inliers": 0, "masks": 0}
+    worst = 0.0
+    for (gm, gi), (cm, cmask, cst) in zip(gpu_first[:checked], cpu_out[:checked]):
+        for k in ("iterations", "refinements", "hypotheses", "num_inliers"):
+            same[k] += int(gi[k] == cst[k])
+        same["masks"] += int(bool((np.array(gi["inliers"], dtype=bool) == np.asarray(cmask, dtype=bool)).all()))
+        ref = np.asarray(cm, dtype=np.float64).reshape(-1)
+        worst = max(worst, model_diff(kind, model_vec(kind, gm), ref))
+    ok = all(v == checked for v in same.values()) and worst <= POSE_TOL and checked > 0
+    return {"checked": checked, "identical_iterations": same["iterations"], "identical_refinements": same["refinements"],
+            "identical_hypotheses": same["hypotheses"], "identical_inlier_counts": same["num_inliers"],
+            "identical_masks": same["masks"], "max_model_diff": worst, "tolerance": POSE_TOL, "ok": bool(ok),
+            "against": "oracle (CPU restatement, pinned to the reference's sources), RANSAC seeds 0..%d of the first timed "
+                       "step, full size (%d iterations)" % (checked - 1, ITERATIONS)}
+
+
+def report_workload(name, table, ctx, args, world):
+    """rank 0: value, roofline, parity, cpu baseline of one workload from the gathered per-rank records"""
+    kind, n_points = ctx["kind"], ctx["n"]
+    shard_problem = ctx["shard_problem"]
+    t_max = float(table[:, 0].max())
+    total_hyp = float(table[0, 1]) if shard_problem else float(table[:, 1].sum())
+    value = total_hyp / t_max
+    hyp0, k_ms, k_launch = float(table[0, 1]), float(table[0, 2]), int(table[0, 3])
+    nan0 = float(table[0, 5])
+    solo_ms, solo_launches, solo_hyp = float(table[0, 6]), int(table[0, 7]), float(table[0, 8])
+    avg_launch_s = (k_ms / max(k_launch, 1)) * 1e-3
+    solo_launch_s = (solo_ms / max(solo_launches, 1)) * 1e-3
+    hyp_per_launch = hyp0 / max(k_launch, 1)
+    alg_bytes_per_launch = hyp_per_launch * n_points * ctx["bytes_per_corr"]
+    pmc = {}
+    try:  # PMC-measured constants of the dominant kernel (rocprofv3 passes, committed under profiles/)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(name) or {}
+    except Exception:
+        pass
+    kernel_name = pmc.get("kernel", "k_score_mfma<PG>" if kind == 0 else f"k_score_queue<{kind}, P>")
+    traffic = pmc.get("traffic_bytes_per_launch")
+    roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST_S,
+            "peak_basis": f"{SIMDS} SIMDs x {PEAK_CLOCK_GHZ} GHz / 4 cycles per wave64 VALU instruction",
+            "kernel": kernel_name, "launches": k_launch, "launches_in_flight": ctx["S"],
+            "avg_launch_ms": 1e3 * avg_launch_s, "solo_avg_launch_ms": 1e3 * solo_launch_s,
+            "hypotheses_per_launch": hyp_per_launch, "point_hypotheses_per_s": value * n_points,
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            "algorithmic_hbm_x_peak": (alg_bytes_per_launch / solo_launch_s / 1e9 / HBM_PEAK_GBS) if solo_launch_s > 0 else None,
+            "traffic": traffic, "traffic_source": pmc.get("source"),
+            "hbm_frac_physical": (traffic / solo_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and solo_launch_s > 0) else None}
+    per_hc = pmc.get("valu_insts_per_hypothesis_chunk")
+    chunk_pts = pmc.get("points_per_chunk")
+    if per_hc and chunk_pts and solo_launch_s > 0:
+        chunks = (n_points + chunk_pts - 1) // chunk_pts
+        insts_solo = per_hc * (solo_hyp / max(solo_launches, 1)) * chunks
+        achieved = insts_solo / solo_launch_s / 1e9
+        insts_all = per_hc * hyp0 * chunks  # every scoring launch of the timed region on rank 0
+        roof.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINST_S,
+                     "frac_basis": "the kernel with the device to itself (4 problems one after the other right before "
+                                   "the timed region; HIP events on the launching stream) - in the timed region "
+                                   f"{ctx['S']} launches share the device, see device_frac_timed_region",
+                     "valu_insts_per_hypothesis_chunk": per_hc, "points_per_chunk": chunk_pts,
+                     "valu_insts_per_launch": insts_solo,
+                     "device_frac_timed_region": insts_all / 1e9 / VALU_PEAK_GINST_S / float(table[0, 0]),
+                     "valu_busy_pmc": pmc.get("valu_busy"), "mfma_busy_pmc": pmc.get("mfma_busy")})
+    else:
+        roof.update({"achieved": None, "frac": None,
+                     "frac_basis": "no PMC instruction count committed for this kernel (profiles/pmc_traffic.json)"})
+    roof["note"] = ("the correspondences are register/LDS-resident: physical HBM traffic per launch (traffic, PMC) is "
+                    "orders of magnitude below the SURVEY 8d 'as if every hypothesis streamed the set' count "
+                    "(algorithmic_bytes_per_launch), so the binding roof is vector-ALU issue, not HBM")
+    out = {"value": value, "unit": "hypotheses/s", "ms_per_step": 1e3 * t_max / args.steps,
+           "problem": ctx["descr"], "correspondences": n_points, "outlier_ratio": ctx["outliers"],
+           "max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "max_error_px": ctx["max_error_px"],
+           "problems_per_gpu_per_step": ctx["PPS"], "problems_in_flight_per_gpu": ctx["S"],
+           "timed_region_s": t_max, "hypotheses_per_step": hyp0 / args.steps,
+           "iterations_per_s": (1 if shard_problem else world) * ctx["PPS"] * args.steps * ITERATIONS / t_max,
+           "nan_model_share": (nan0 / hyp0) if hyp0 else None,
+           "nan_model_note": "share of the counted hypotheses whose model has a NaN entry (the reference's P3P emits "
+                             "them for inconsistent samples; ransac_impl.h:112-113 counts them, utils.cc:36-65 scores "
+                             "them at full price on the CPU, the device scorer skips them: no inliers possible)",
+           "inliers_found": int(table[0, 4]), "roofline": roof}
+    # ---- the oracle on RANSAC seeds 0..7 of the same problem: parity of the timed configuration + CPU baseline ----
+    ok = True
+    if not args.no_parity and not shard_problem:
+        cpu_out, wall, workers, fn_name = cpu_runs(kind, ctx["A"], ctx["B"], ctx["thr"], ITERATIONS, PARITY_SEEDS, False)
+        out["parity"] = parity_block(kind, ctx["first"], cpu_out)
+        ok = out["parity"]["ok"]
+        if world == 1 and not args.no_cpu_baseline:
+            hyp_c = sum(c[2]["hypotheses"] for c in cpu_out)
+            sec_c = sum(c[2]["seconds"] for c in cpu_out)
+            port = {"value": hyp_c / sec_c, "unit": "hypotheses/s", "cores": 1, "kind": "port",
+                    "sample": f"oracle {fn_name}, RANSAC seeds 0..{PARITY_SEEDS - 1} of the same workload ({ITERATIONS} "
+                              f"iterations each, {hyp_c} hypotheses, {sec_c:.1f} core-seconds; {workers} problems at a "
+                              f"time on separate cores, {wall:.1f} s wall), g++ -O3 no -march, rate per core, "
+                              f"{os.cpu_count()} host cores"}
+            base = port
+            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libposelib_ref.so")):
+                try:
+                    ref_out, rwall, rworkers, _ = cpu_runs(kind, ctx["A"], ctx["B"], ctx["thr"], ITERATIONS, PARITY_SEEDS, True)
+                    # (ransac_* does not report its model count; the oracle's run of the same seed counts the same
+                    # sample stream and agrees in iterations / inliers / mask, see agrees_with_port)
+                    hyp_r = hyp_c
+                    sec_r = sum(c[2]["seconds"] for c in ref_out)
+                    same = sum(int(r[2]["iterations"] == c[2]["iterations"] and r[2]["num_inliers"] == c[2]["num_inliers"]
+                                   and bool((r[1] == c[1]).all())) for r, c in zip(ref_out, cpu_out))
+                    base = {"value": hyp_r / sec_r, "unit": "hypotheses/s", "cores": 1, "kind": "reference",
+                            "sample": f"oracle/_ref/libposelib_ref.so = the reference's own sources (robust/ransac.cc, "
+                                      f"ransac_impl.h, estimators, solvers, utils.cc, bundle.cc, ...) compiled in place "
+                                      f"against oracle/eigen_shim (real Eigen is not in this image): {fn_name}, RANSAC "
+                                      f"seeds 0..{PARITY_SEEDS - 1} of the same workload ({ITERATIONS} iterations each, "
+                                      f"{hyp_r} hypotheses as counted by the oracle's runs of the same seeds, {sec_r:.1f} core-seconds; {rworkers} problems at a time on "
+                                      f"separate cores, {rwall:.1f} s wall), g++ -O2, rate per core, {os.cpu_count()} host cores",
+                            "agrees_with_port": f"{same}/{len(ref_out)} runs identical in iterations / inliers / mask",
+                            "port": port}
+                except Exception as e:  # the prebuilt file did not travel / does not load: the port alone
+                    port["reference_unavailable"] = repr(e)
+            out["cpu_baseline"] = base
+    return out, ok
 
 
 def main():
@@ -68,203 +418,80 @@ def main():
     ap.add_argument("--streams", type=int, default=16,
                     help="independent problems in flight per GPU (one host thread + HIP stream each)")
     ap.add_argument("--problems-per-step", type=int, default=0,
-                    help="independent problems per step and GPU (default 8 x streams): the batch one step works through")
+                    help="independent problems per step and GPU of the primary workload (default 64 x streams)")
     ap.add_argument("--workload", default="p3p_5000", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-secondary", action="store_true", help="only the primary workload")
+    ap.add_argument("--secondary-scale", type=float, default=1.0, help="scales the secondary workloads' step size")
     ap.add_argument("--shard-problem", action="store_true",
                     help="strong-scaling mode (SURVEY 8e-ii): ONE problem at a time, its iterations sharded over the "
                          "ranks (pl_ransac_run_sharded, one all-gather per batch); default is independent problems per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iterations", type=int, default=ITERATIONS)
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle runs (profiling)")
+    ap.add_argument("--rehearse-distributed", action="store_true",
+                    help="launch / rendezvous / gather path only, no GPU work, prints no measurement (CPU test)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.rehearse_distributed:
+        sys.exit(rehearse(args))
+
     import torch
+    from concurrent.futures import ThreadPoolExecutor
 
     import poselib_amd as P
     from poselib_amd import synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_DEVICE=1: rehearsal of the multi-rank path on a box with ONE GPU (all
-    # ranks use device 0, the collectives run on CPU tensors).  Never used for reported numbers.
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    device_index = 0 if os.environ.get("BENCH_SHARE_DEVICE") else local_rank
-    torch.cuda.set_device(device_index)
-    P.set_device(device_index)
-    use_dist = world > 1
-    coll_device = "cuda" if backend == "nccl" else "cpu"
-    if use_dist:
-        import torch.distributed as dist
+    ranks = Ranks(args)
+    torch.cuda.set_device(ranks.device_index)
+    P.set_device(ranks.device_index)
 
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    def pool_factory(S):
+        # every worker thread selects this rank's GPU before its first call (per-thread context: HIP stream + scratch)
+        return ThreadPoolExecutor(max_workers=S, initializer=lambda: P.set_device(ranks.device_index))
 
-    KIND, N_POINTS, OUTLIER_RATIO, MAX_ERROR_PX, DATA_SEED, BYTES_PER_CORR, DESCR = WORKLOADS[args.workload]
-    # one image pair per rank (independent problems; data seed + rank); pixels -> normalised image plane
-    pp = np.array([500.0, 500.0])
-    shard_problem = bool(args.shard_problem)
-    data_rank = 0 if shard_problem else rank  # sharded problem: every rank holds the same correspondences
-    if KIND == 0:
-        scene = synth.absolute_pose_scene(N_POINTS, OUTLIER_RATIO, DATA_SEED + data_rank)
-        A, Bpts = (scene["p2d"] - pp) / FOCAL, scene["p3d"]
-    else:
-        gen = {1: synth.relative_pose_scene, 2: synth.fundamental_scene, 3: synth.homography_scene}[KIND]
-        scene = gen(N_POINTS, OUTLIER_RATIO, DATA_SEED + data_rank)
-        A, Bpts = (scene["x1"] - pp) / FOCAL, (scene["x2"] - pp) / FOCAL
-    # the front-end's O(N) pre-processing (robust.cc:40-46) is done once, outside the timed region
-    from concurrent.futures import ThreadPoolExecutor
+    names = [args.workload] + ([] if (args.no_secondary or args.shard_problem) else [w for w in SECONDARY if w != args.workload])
+    reports, all_ok = {}, True
+    for i, name in enumerate(names):
+        rec, ctx = run_workload(name, args, ranks, P, synth, pool_factory, primary=(i == 0))
+        table = ranks.gather(rec)  # final gather over RCCL
+        if ranks.rank == 0:
+            reports[name], ok = report_workload(name, table, ctx, args, ranks.world)
+            all_ok = all_ok and ok
 
-    thr = MAX_ERROR_PX / FOCAL
-    S = 1 if shard_problem else max(1, args.streams)  # collectives of one process group must be issued in one order
-    # every worker thread selects this rank's GPU before its first call (per-thread context: HIP stream + scratch)
-    pool = ThreadPoolExecutor(max_workers=S, initializer=lambda: P.set_device(device_index))
-
-    def make_problem(_):
-        return P.Problem(KIND, A, Bpts)  # SoA in HBM, resident from here on
-
-    probs = list(pool.map(make_problem, range(S)))
-
-    exchange = None
-    if shard_problem and use_dist:
-        from poselib_amd import sharding
-
-        exchange = sharding.dist_allgather(device=(f"cuda:{device_index}" if backend == "nccl" else None))
-
-    def run_one(args_):
-        prob, seed = args_
-        opt = {"max_error": thr, "ransac": {"max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "seed": seed}}
-        if exchange is not None:
-            return prob.run_sharded(opt, rank, world, exchange)
-        return prob.run(opt)
-
-    PPS = args.problems_per_step if args.problems_per_step > 0 else 8 * S
-
-    def step(seed):
-        """One step = a batch of PPS independent ransac_pnp problems (different RANSAC seeds) worked through by S
-        host threads / HIP streams, i.e. S problems in flight on this GPU at any time."""
-        return list(pool.map(run_one, [(probs[j % S], seed * PPS + j) for j in range(PPS)]))
-
-    def sync():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for w in range(args.warmup):
-        step(1000 + w)
-    # the dominant kernel with the device to itself (4 problems one after the other, outside the timed region): the
-    # per-launch time the timed region reports is that of S launches sharing the device
-    solo_ms, solo_launches = 0.0, 0
-    for j in range(4):
-        _, info = pool.submit(run_one, (probs[0], 7000 + j)).result()
-        solo_ms += info["score_kernel_ms"]
-        solo_launches += info["score_kernel_launches"]
-    sync()
-    t0 = time.perf_counter()
-    hyp = 0
-    kern_ms = 0.0
-    launches = 0
-    last = None
-    for s in range(args.steps):
-        for pose, info in step(s):
-            hyp += info["hypotheses"]
-            kern_ms += info["score_kernel_ms"]
-            launches += info["score_kernel_launches"]
-            last = (pose, info)
-    sync()
-    elapsed = time.perf_counter() - t0
-
-    # final gather over RCCL: [elapsed, hypotheses, kernel ms, launches, inliers, pose(7)]
-    model_flat = (list(last[0].q) + list(last[0].t) + [0.0, 0.0]) if KIND in (0, 1) else list(np.asarray(last[0]).reshape(-1))
-    rec = torch.tensor([elapsed, float(hyp), kern_ms, float(launches), float(last[1]["num_inliers"])] + model_flat,
-                       dtype=torch.float64, device=coll_device)
-    if use_dist:
-        allrec = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        allrec = torch.stack(allrec).cpu().numpy()
-    else:
-        allrec = rec.cpu().numpy()[None]
-
-    if rank == 0:
-        t_max = float(allrec[:, 0].max())
-        # sharded problem: every rank reports the job's total; independent problems: the ranks' sums add up
-        total_hyp = float(allrec[0, 1]) if shard_problem else float(allrec[:, 1].sum())
-        value = total_hyp / t_max
-        k_ms = float(allrec[0, 2])
-        k_launch = int(allrec[0, 3])
-        hyp0 = float(allrec[0, 1])
-        avg_launch_s = (k_ms / max(k_launch, 1)) * 1e-3
-        alg_bytes_per_launch = (hyp0 / max(k_launch, 1)) * N_POINTS * BYTES_PER_CORR
-        achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic, traffic_src, kernel_name, valu_busy = None, None, f"k_score_queue<{KIND}, P>", None
-        try:  # PMC-measured HBM bytes per launch (rocprofv3 passes, committed under profiles/)
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-            if tr:
-                traffic, traffic_src = tr["traffic_bytes_per_launch"], tr["source"]
-                kernel_name, valu_busy = tr.get("kernel", kernel_name), tr.get("valu_busy")
-        except Exception:
-            pass
+    if ranks.rank == 0:
+        prim = reports[args.workload]
         out = {
-            "metric": "scored RANSAC hypotheses/sec",
-            "value": value,
+            "metric": "scored RANSAC hypotheses/sec (P3P@5k corrs, 5pt@5k corrs)",
+            "value": prim["value"],
             "unit": "hypotheses/s",
-            "n_gpus": world,
+            "n_gpus": ranks.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * t_max / args.steps,
+            "ms_per_step": prim["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "strong" if shard_problem else "weak",
+            "scaling": "strong" if args.shard_problem else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": args.workload, "problem": DESCR, "correspondences": N_POINTS,
-                       "outlier_ratio": OUTLIER_RATIO, "max_iterations": ITERATIONS, "min_iterations": ITERATIONS,
-                       "max_error_px": MAX_ERROR_PX, "problems_per_gpu_per_step": PPS, "problems_in_flight_per_gpu": S,
-                       "hypotheses_per_step": hyp0 / args.steps,
-                       "iterations_per_s": (1 if shard_problem else world) * PPS * args.steps * ITERATIONS / t_max,
-                       "sharding": "one problem over the ranks (iteration ranges, one all-gather per batch)" if shard_problem else "independent problems per rank",
-                       "inliers_found": int(allrec[0, 4])},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_name, "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launch,
-                         "launches_in_flight": S, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "solo_avg_launch_ms": solo_ms / max(solo_launches, 1),
-                         "solo_frac": (alg_bytes_per_launch / (1e-3 * solo_ms / max(solo_launches, 1)) / 1e9 / HBM_PEAK_GBS)
-                         if solo_ms > 0 else None,
-                         "point_hypotheses_per_s": value * N_POINTS, "valu_busy_pmc": valu_busy,
-                         "note": f"algorithmic bytes = hypotheses x N x {BYTES_PER_CORR} B (SURVEY 8d); the set is "
-                                 "register/LDS-resident, so frac > 1 is expected: the binding unit is the vector ALU "
-                                 "(fp32 filter + fp64 exact pass, DESIGN.md 4); avg_launch_ms is the HIP-event time of "
-                                 "one launch while launches_in_flight problems share the device (throughput-optimal, but every "
-                                 "launch takes longer); solo_* is the same kernel with the device to itself, measured "
-                                 "before the timed region"},
+            "config": {"workload": args.workload,
+                       **{k: prim[k] for k in ("problem", "correspondences", "outlier_ratio", "max_iterations",
+                                               "min_iterations", "max_error_px", "problems_per_gpu_per_step",
+                                               "problems_in_flight_per_gpu", "timed_region_s", "hypotheses_per_step",
+                                               "iterations_per_s", "nan_model_share", "nan_model_note", "inliers_found")},
+                       "sharding": "one problem over the ranks (iteration ranges, one all-gather per batch)"
+                       if args.shard_problem else "independent problems per rank, RCCL for the barrier and the final gather only",
+                       "secondary": {n: reports[n] for n in names[1:]}},
+            "roofline": prim["roofline"],
+            "parity": prim.get("parity"),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            import oracle_lib as O
-
-            # bounded sample of the same workload: whole problems (different RANSAC seeds) until ~12 s of CPU time
-            cpu_fn = {0: O.ransac_pnp, 1: O.ransac_relpose, 2: O.ransac_fundamental, 3: O.ransac_homography}[KIND]
-            t1 = time.perf_counter()
-            cpu_hyp, cpu_sec, cpu_n = 0, 0.0, 0
-            while cpu_n < 64 and time.perf_counter() - t1 < 12.0:
-                o = {"max_error": thr, "ransac": {"max_iterations": args.cpu_iterations,
-                                                  "min_iterations": args.cpu_iterations, "seed": cpu_n}}
-                _, _, cst = cpu_fn(A, Bpts, o)
-                cpu_hyp += cst["hypotheses"]
-                cpu_sec += cst["seconds"]
-                cpu_n += 1
-            cpu_s = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": cpu_hyp / cpu_sec, "unit": "hypotheses/s", "cores": 1, "kind": "port",
-                                   "sample": f"oracle {cpu_fn.__name__}, {cpu_n} problems of the same workload "
-                                             f"({args.cpu_iterations} iterations each, {cpu_hyp} hypotheses, "
-                                             f"{cpu_s:.1f} s wall), g++ -O3 no -march, 1 of {os.cpu_count()} host cores"}
+        if "cpu_baseline" in prim:
+            out["cpu_baseline"] = prim["cpu_baseline"]
         print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
-    for pr in probs:
-        pr.close()
-    pool.shutdown()
+    ranks.close()
+    if ranks.rank == 0 and not all_ok:
+        print("bench.py: PARITY MISMATCH between the GPU results and the oracle (see the parity blocks)", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -86,7 +86,8 @@ typedef struct {
     double seconds;                /* host wall time of the ransac_* part */
     double score_kernel_ms;        /* HIP-event time of the scoring kernel launches */
     uint32_t score_kernel_launches;
-    uint32_t reserved;
+    uint32_t nan_hypotheses;       /* of the hypotheses the device evaluated: models with a NaN entry (the reference's
+                                      P3P emits them for inconsistent samples; they have no inliers, utils.cc:36-65) */
 } pl_ransac_stats;
 
 /* misc/camera_models.h:56-60; supported ids: -1 NULL, 0 SIMPLE_PINHOLE, 1 PINHOLE, 4 OPENCV */
@@ -183,6 +184,15 @@ int pl_ransac_run_sharded(pl_problem *p, const pl_robust_options *opt, const pl_
 /* Score one model against the resident correspondences with the estimator's MSAC score
  * (robust/utils.cc:36-65, 158-239, 300-329 through estimators' score_model()).  model as in pl_ransac_run. */
 int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t *inlier_count, double *score);
+/* Diagnostic entry (no counterpart in the reference): `n` models - pl_camera_pose[n] for kinds 0/1, double[n][9]
+ * column-major for kinds 2/3 - through the STREAMING scorer of the batched main loop, i.e. through the conservative
+ * pre-filters (fp16/MFMA or fp32) in front of the exact fp64 evaluation, instead of the sequential scorer behind
+ * pl_score_model.  counts / scores: n entries each (scores summed in tree order: equal to pl_score_model's to rounding,
+ * counts exactly).  path_used: 2 = matrix-core filter (k_score_mfma), 1 = fp32 filter (k_score_queue), 0 = no filter
+ * (threshold / coordinates outside the filters' range, or POSELIB_AMD_NO_PREFILTER).  tests/ plants adversarial
+ * models and correspondences here to check that a filter never drops an inlier. */
+int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double max_error, uint32_t *counts,
+                          double *scores, int32_t *path_used);
 /* Non-linear refinement of one model on the resident correspondences (robust/bundle.h:41-170:
  * bundle_adjust / refine_relpose / refine_fundamental / refine_homography).  camera: absolute pose only
  * (NULL pointer = identity camera, i.e. normalised image points).  mask: optional N bytes, refine on the

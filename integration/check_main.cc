@@ -1,0 +1,108 @@
+// Executes the reference-side binding (integration/robust_amd.cc): a PoseLib user's program - the reference's own
+// types (std::vector<Eigen::Vector2d>, Camera, Image, CameraPose, AbsolutePoseOptions, ...) and the reference's own
+// entry-point signatures (PoseLib/robust.h:45-46, 68-70, 112-113, 133-134) - linked against robust_amd.o INSTEAD of
+// the reference's robust.cc, so every poselib::estimate_* call below lands in libposelib_amd.so.
+//
+//   robust_amd_check <in.bin> <out.bin>
+//     in : doubles [kind, n, seed, max_error, model_id, num_params, params[12], A (n x 2), B (n x 3 | n x 2)]
+//     out: doubles [iterations, refinements, num_inliers, model_score, model (7: q t | 9: column-major 3x3),
+//                   camera params[12] (kind 0), inliers (n)]
+// tests/test_integration_shim.py (-m gpu) feeds it the scenes of the parity tests and compares the output with the
+// ctypes path bit for bit.  Built by integration/Makefile against the reference's headers (oracle/eigen_shim stands in
+// for Eigen, which this image lacks) where /root/reference exists; the binary travels to the GPU box.
+#include <PoseLib/robust.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace poselib;
+
+int main(int argc, char **argv) {
+    if (argc != 3) {
+        std::fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]);
+        return 2;
+    }
+    std::FILE *f = std::fopen(argv[1], "rb");
+    if (!f)
+        return 2;
+    std::fseek(f, 0, SEEK_END);
+    const long bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<double> in(bytes / sizeof(double));
+    if (std::fread(in.data(), sizeof(double), in.size(), f) != in.size())
+        return 2;
+    std::fclose(f);
+
+    const int kind = (int)in[0];
+    const size_t n = (size_t)in[1];
+    RansacOptions ransac;
+    ransac.seed = (size_t)in[2];
+    const double max_error = in[3];
+    std::vector<double> cam_params(in.begin() + 6, in.begin() + 6 + (size_t)in[5]);
+    const Camera camera((int)in[4], cam_params);
+    const double *a = in.data() + 18, *b = a + 2 * n;
+    std::vector<Point2D> x1(n), x2d(n);
+    std::vector<Point3D> X(n);
+    for (size_t i = 0; i < n; ++i) {
+        x1[i] = Point2D(a[2 * i], a[2 * i + 1]);
+        if (kind == 0)
+            X[i] = Point3D(b[3 * i], b[3 * i + 1], b[3 * i + 2]);
+        else
+            x2d[i] = Point2D(b[2 * i], b[2 * i + 1]);
+    }
+
+    std::vector<char> inliers;
+    RansacStats st;
+    std::vector<double> model;
+    std::vector<double> cam_out(12, 0.0);
+    if (kind == 0) {
+        AbsolutePoseOptions opt;
+        opt.ransac = ransac;
+        opt.max_error = max_error;
+        Image image;
+        image.camera = camera;
+        st = estimate_absolute_pose(x1, X, opt, &image, &inliers);
+        for (int i = 0; i < 4; ++i)
+            model.push_back(image.pose.q(i));
+        for (int i = 0; i < 3; ++i)
+            model.push_back(image.pose.t(i));
+        for (size_t i = 0; i < image.camera.params.size() && i < 12; ++i)
+            cam_out[i] = image.camera.params[i];
+    } else if (kind == 1) {
+        RelativePoseOptions opt;
+        opt.ransac = ransac;
+        opt.max_error = max_error;
+        CameraPose pose;
+        st = estimate_relative_pose(x1, x2d, camera, camera, opt, &pose, &inliers);
+        for (int i = 0; i < 4; ++i)
+            model.push_back(pose.q(i));
+        for (int i = 0; i < 3; ++i)
+            model.push_back(pose.t(i));
+    } else if (kind == 2) {
+        RelativePoseOptions opt;
+        opt.ransac = ransac;
+        opt.max_error = max_error;
+        Eigen::Matrix3d F;
+        st = estimate_fundamental(x1, x2d, opt, &F, &inliers);
+        model.assign(F.data(), F.data() + 9);
+    } else {
+        HomographyOptions opt;
+        opt.ransac = ransac;
+        opt.max_error = max_error;
+        Eigen::Matrix3d H;
+        st = estimate_homography(x1, x2d, opt, &H, &inliers);
+        model.assign(H.data(), H.data() + 9);
+    }
+
+    std::vector<double> out = {(double)st.iterations, (double)st.refinements, (double)st.num_inliers, st.model_score};
+    out.insert(out.end(), model.begin(), model.end());
+    out.insert(out.end(), cam_out.begin(), cam_out.end());
+    for (size_t i = 0; i < n; ++i)
+        out.push_back(i < inliers.size() && inliers[i] ? 1.0 : 0.0);
+    f = std::fopen(argv[2], "wb");
+    if (!f || std::fwrite(out.data(), sizeof(double), out.size(), f) != out.size())
+        return 2;
+    std::fclose(f);
+    return 0;
+}

@@ -61,6 +61,10 @@ RansacStats from_pl(const pl_ransac_stats &s) {
 }
 
 pl_camera to_pl(const Camera &c) {
+    // pl_camera carries at most 12 parameters (the supported models need <= 8); the reference has models with more
+    // (RadTanThinPrismFisheye: 16) - reject them here instead of overrunning the array
+    if (c.params.size() > sizeof(pl_camera::params) / sizeof(double))
+        throw std::runtime_error("poselib_amd: camera model not supported (NULL, SIMPLE_PINHOLE, PINHOLE, OPENCV)");
     pl_camera cam{c.model_id, c.width, c.height, static_cast<int32_t>(c.params.size()), {}};
     std::copy(c.params.begin(), c.params.end(), cam.params);
     return cam;

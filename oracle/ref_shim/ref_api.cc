@@ -27,6 +27,7 @@
 #include <PoseLib/robust/bundle.h>
 #include <PoseLib/robust/ransac.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -337,46 +338,63 @@ void ref_refine_homography(const double *x1, const double *x2, size_t n, double 
     mat_out(H, H9);
 }
 
-// robust/ransac.h entry points (hypotheses are not observable from outside: reported as 0)
+// robust/ransac.h entry points (hypotheses are not observable from outside: reported as 0; `seconds` is the wall time of
+// the reference's ransac_* call itself, measured here the way the oracle measures its own loop)
+struct CallTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 void ref_ransac_pnp(const double *x, const double *X, size_t n, const orc_robust_opt *opt, double *pose7,
                     uint8_t *inliers, orc_stats *st) {
     CameraPose best = pose_in(pose7);
     std::vector<char> m;
+    const CallTimer timer;
     const RansacStats s = ransac_pnp(pts2(x, n), pts3(X, n), robust_in<AbsolutePoseOptions>(opt), &best, &m);
+    const double call_seconds = timer.seconds();
     pose_out(best, pose7);
     m.resize(n, 0);
     mask_out(m, inliers);
     stats_out(s, 0, st);
+    st->seconds = call_seconds;
 }
 void ref_ransac_relpose(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *pose7,
                         uint8_t *inliers, orc_stats *st) {
     CameraPose best = pose_in(pose7);
     std::vector<char> m;
+    const CallTimer timer;
     const RansacStats s = ransac_relpose(pts2(x1, n), pts2(x2, n), rel_in(opt), &best, &m);
+    const double call_seconds = timer.seconds();
     pose_out(best, pose7);
     m.resize(n, 0);
     mask_out(m, inliers);
     stats_out(s, 0, st);
+    st->seconds = call_seconds;
 }
 void ref_ransac_fundamental(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *F9,
                             uint8_t *inliers, orc_stats *st) {
     Eigen::Matrix3d best = mat_in(F9);
     std::vector<char> m;
+    const CallTimer timer;
     const RansacStats s = ransac_fundamental(pts2(x1, n), pts2(x2, n), rel_in(opt), &best, &m);
+    const double call_seconds = timer.seconds();
     mat_out(best, F9);
     m.resize(n, 0);
     mask_out(m, inliers);
     stats_out(s, 0, st);
+    st->seconds = call_seconds;
 }
 void ref_ransac_homography(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *H9,
                            uint8_t *inliers, orc_stats *st) {
     Eigen::Matrix3d best = mat_in(H9);
     std::vector<char> m;
+    const CallTimer timer;
     const RansacStats s = ransac_homography(pts2(x1, n), pts2(x2, n), robust_in<HomographyOptions>(opt), &best, &m);
+    const double call_seconds = timer.seconds();
     mat_out(best, H9);
     m.resize(n, 0);
     mask_out(m, inliers);
     stats_out(s, 0, st);
+    st->seconds = call_seconds;
 }
 
 // robust.h front-ends

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libposelib_amd.so")
 
 u64, i32, u32, f64 = C.c_uint64, C.c_int32, C.c_uint32, C.c_double
 
-PL_OK, PL_ERR_NO_DEVICE, PL_ERR_HIP, PL_ERR_INVALID, PL_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+PL_OK, PL_ERR_NO_DEVICE, PL_ERR_HIP, PL_ERR_INVALID, PL_ERR_UNSUPPORTED, PL_ERR_COMM = 0, -1, -2, -3, -4, -5
 
 
 class RansacOptions(C.Structure):
@@ -41,7 +41,7 @@ class RobustOptions(C.Structure):
 class RansacStats(C.Structure):
     _fields_ = [("refinements", u64), ("iterations", u64), ("num_inliers", u64), ("inlier_ratio", f64),
                 ("model_score", f64), ("hypotheses", u64), ("iterations_evaluated", u64), ("seconds", f64),
-                ("score_kernel_ms", f64), ("score_kernel_launches", u32), ("reserved", u32)]
+                ("score_kernel_ms", f64), ("score_kernel_launches", u32), ("nan_hypotheses", u32)]
 
 
 class BatchItem(C.Structure):
@@ -97,10 +97,54 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import poselib_amd; poselib_amd.build()'` "
                 "(there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
-        L.pl_last_error.restype = C.c_char_p
-        L.pl_version.restype = C.c_char_p
+        _declare(L)
         _lib = L
     return _lib
+
+
+def _declare(L):
+    """argtypes / restype of every C-ABI function (include/poselib_amd.h), so that a bare Python int or None is
+    converted to the declared width instead of ctypes' default c_int."""
+    vp, sz, dbl, cint = C.c_void_p, C.c_size_t, C.c_double, C.c_int
+    P = C.POINTER
+    opt, stats, cam, pose = P(RobustOptions), P(RansacStats), P(Camera), P(CameraPose)
+    sig = {
+        "pl_default_ransac_options": (None, [P(RansacOptions)]),
+        "pl_default_bundle_options": (None, [P(BundleOptions)]),
+        "pl_default_robust_options": (None, [opt, cint]),
+        "pl_device_count": (cint, []),
+        "pl_set_device": (cint, [cint]),
+        "pl_last_error": (C.c_char_p, []),
+        "pl_version": (C.c_char_p, []),
+        "pl_estimate_absolute_pose": (cint, [vp, vp, sz, opt, cam, pose, vp, stats]),
+        "pl_estimate_relative_pose": (cint, [vp, vp, sz, cam, cam, opt, pose, vp, stats]),
+        "pl_estimate_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
+        "pl_estimate_homography": (cint, [vp, vp, sz, opt, vp, vp, stats]),
+        "pl_estimate_batch": (cint, [P(BatchItem), sz, cint]),
+        "pl_ransac_pnp": (cint, [vp, vp, sz, opt, pose, vp, stats]),
+        "pl_ransac_relpose": (cint, [vp, vp, sz, opt, pose, vp, stats]),
+        "pl_ransac_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
+        "pl_ransac_homography": (cint, [vp, vp, sz, opt, vp, vp, stats]),
+        "pl_problem_create": (cint, [cint, vp, vp, sz, P(vp)]),
+        "pl_problem_destroy": (None, [vp]),
+        "pl_ransac_run": (cint, [vp, opt, vp, vp, stats]),
+        "pl_ransac_run_sharded": (cint, [vp, opt, P(Shard), vp, vp, stats]),
+        "pl_score_model": (cint, [vp, vp, dbl, P(C.c_uint64), P(dbl)]),
+        "pl_debug_score_stream": (cint, [vp, vp, sz, dbl, vp, vp, P(C.c_int32)]),
+        "pl_refine_model": (cint, [vp, P(BundleOptions), cam, vp, vp, P(C.c_uint32)]),
+        "pl_p3p": (cint, [vp, vp, P(CameraPose)]),
+        "pl_relpose_5pt": (cint, [vp, vp, P(CameraPose)]),
+        "pl_essential_matrix_5pt": (cint, [vp, vp, vp]),
+        "pl_relpose_7pt": (cint, [vp, vp, vp]),
+        "pl_homography_4pt": (cint, [vp, vp, vp]),
+        "pl_solve_batch": (cint, [cint, vp, sz, vp, vp]),
+    }
+    missing = [name for name in EXPORTED_SYMBOLS if name not in sig]
+    assert not missing, f"no signature declared for {missing}"
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
 
 
 def check(rc: int):
@@ -114,6 +158,6 @@ EXPORTED_SYMBOLS = [
     "pl_default_ransac_options", "pl_default_bundle_options", "pl_default_robust_options", "pl_device_count",
     "pl_set_device", "pl_last_error", "pl_version", "pl_estimate_absolute_pose", "pl_estimate_relative_pose",
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
-    "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
+    "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch",
 ]

@@ -22,6 +22,8 @@ import numpy as np
 
 from . import _lib as L
 
+LAMBDA_UPDATES = {"NIELSEN": 0, "FIXED_FACTOR": 1}
+DAMPINGS = {"LEVENBERG": 0, "MARQUARDT": 1}
 LOSS_TYPES = {"TRIVIAL": 0, "TRUNCATED": 1, "HUBER": 2, "CAUCHY": 3, "TRUNCATED_CAUCHY": 4, "TRUNCATED_LE_ZACH": 5}
 CAMERA_MODEL_IDS = {"NULL": -1, "SIMPLE_PINHOLE": 0, "PINHOLE": 1, "OPENCV": 4}
 _CAMERA_NAMES = {v: k for k, v in CAMERA_MODEL_IDS.items()}
@@ -105,14 +107,35 @@ def RansacOptions():
 def BundleOptions():
     return {"max_iterations": 100, "loss_type": "CAUCHY", "loss_scale": 1.0, "gradient_tol": 1e-12, "step_tol": 1e-8,
             "relative_cost_tol": 1e-10, "initial_lambda": 1e-3, "min_lambda": 1e-10, "max_lambda": 1e10,
-            "lambda_factor": 10.0, "verbose": False}
+            "lambda_factor": 10.0, "lambda_update": "NIELSEN", "damping": "LEVENBERG", "verbose": False}
 
 
 # ------------------------------------------------------------------------------------------ marshalling
+_RANSAC_KEYS = {"max_iterations", "min_iterations", "dyn_num_trials_mult", "success_prob", "seed",
+                "progressive_sampling", "max_prosac_iterations", "score_initial_model"}
+_BUNDLE_KEYS = {"max_iterations", "loss_type", "loss_scale", "gradient_tol", "step_tol", "relative_cost_tol",
+                "initial_lambda", "min_lambda", "max_lambda", "lambda_factor", "lambda_update", "damping", "verbose",
+                "refine_focal_length", "refine_extra_params", "refine_principal_point"}
+_TOP_KEYS = {"ransac", "bundle", "max_error", "real_focal_check", "tangent_sampson", "estimate_focal_length",
+             "estimate_extra_params", "min_fov"}
+
+
+def _warn_unknown(d, known, where):
+    # the reference's pybind ignores unknown keys silently (helpers.h:21-29); say so instead
+    extra = sorted(set(d) - known)
+    if extra:
+        import warnings
+
+        warnings.warn(f"poselib_amd: unknown {where} option(s) {extra} ignored", stacklevel=4)
+
+
 def _robust_options(opt, kind: int, score_initial: bool) -> L.RobustOptions:
     o = L.RobustOptions()
     L.lib().pl_default_robust_options(C.byref(o), kind)
     opt = opt or {}
+    _warn_unknown(opt, _TOP_KEYS, "top-level")
+    _warn_unknown(opt.get("ransac", {}), _RANSAC_KEYS, "'ransac'")
+    _warn_unknown(opt.get("bundle", {}), _BUNDLE_KEYS, "'bundle'")
     r = opt.get("ransac", {})
     for k in ("max_iterations", "min_iterations", "seed", "max_prosac_iterations"):
         if k in r:
@@ -130,9 +153,11 @@ def _robust_options(opt, kind: int, score_initial: bool) -> L.RobustOptions:
               "max_lambda", "lambda_factor"):
         if k in b:
             setattr(o.bundle, k, float(b[k]))
-    if "loss_type" in b:
-        lt = b["loss_type"]
-        o.bundle.loss_type = LOSS_TYPES[lt.upper()] if isinstance(lt, str) else int(lt)
+    # enumerations: case-insensitive names like the reference's pybind (helpers.h:54-92), or the integer value
+    for key, table in (("loss_type", LOSS_TYPES), ("lambda_update", LAMBDA_UPDATES), ("damping", DAMPINGS)):
+        if key in b:
+            v = b[key]
+            setattr(o.bundle, key, table[v.upper()] if isinstance(v, str) else int(v))
     for k in ("refine_focal_length", "refine_extra_params", "refine_principal_point"):
         if k in b:
             setattr(o.bundle, k, int(bool(b[k])))
@@ -160,7 +185,8 @@ def _info(st: L.RansacStats, inliers: np.ndarray):
             "inlier_ratio": st.inlier_ratio, "model_score": st.model_score, "inliers": inliers.astype(bool).tolist(),
             # extras (not in the reference): metric numerator and device timing
             "hypotheses": st.hypotheses, "iterations_evaluated": st.iterations_evaluated, "seconds": st.seconds,
-            "score_kernel_ms": st.score_kernel_ms, "score_kernel_launches": st.score_kernel_launches}
+            "score_kernel_ms": st.score_kernel_ms, "score_kernel_launches": st.score_kernel_launches,
+            "nan_hypotheses": st.nan_hypotheses}
 
 
 def _cpose(p: CameraPose) -> L.CameraPose:
@@ -391,6 +417,26 @@ class Problem:
             M = np.ascontiguousarray(np.asarray(model, dtype=np.float64).T.reshape(9))
             L.check(L.lib().pl_score_model(self._h, _ptr(M), C.c_double(max_error), C.byref(cnt), C.byref(sc)))
         return sc.value, cnt.value
+
+    def score_stream(self, models, max_error):
+        """Diagnostic (pl_debug_score_stream): a list of models through the streaming scorer of the main loop, i.e.
+        through the conservative pre-filter in front of the exact evaluation.  models: (n, 7) array of q, t for pose
+        problems, (n, 3, 3) matrices otherwise.  Returns (counts, scores, path) with path 2 = matrix-core filter,
+        1 = fp32 filter, 0 = no filter."""
+        m = np.ascontiguousarray(models, dtype=np.float64)
+        n = m.shape[0]
+        if self.kind in (KIND_ABS, KIND_REL):
+            assert m.shape == (n, 7)
+            flat = np.ascontiguousarray(m.reshape(-1))  # pl_camera_pose = 7 packed doubles
+        else:
+            assert m.shape == (n, 3, 3)
+            flat = np.ascontiguousarray(np.transpose(m, (0, 2, 1)).reshape(-1))  # column-major
+        cnt = np.zeros(max(n, 1), dtype=np.uint32)
+        sc = np.zeros(max(n, 1), dtype=np.float64)
+        path = C.c_int32(0)
+        L.check(L.lib().pl_debug_score_stream(self._h, _ptr(flat), C.c_size_t(n), C.c_double(max_error), _ptr(cnt),
+                                              _ptr(sc), C.byref(path)))
+        return cnt[:n], sc[:n], path.value
 
     def refine(self, model, bundle_opt=None, camera=None, mask=None):
         """bundle_adjust / refine_relpose / refine_fundamental / refine_homography on the resident points."""

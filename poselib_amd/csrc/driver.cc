@@ -138,7 +138,35 @@ int get_context(Context **out) {
     if (g_requested_device < 0 || g_requested_device >= ndev)
         return fail(PL_ERR_INVALID, "device index out of range");
     // (a context bound to another device is simply leaked for the lifetime of the thread)
-    Context *c = new Context();
+    {
+        // the kernels are built for gfx950 only (k_sample_orbit alone keeps ~116 KB of static LDS): say so instead of
+        // failing with "invalid device function" at the first launch
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, g_requested_device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            static thread_local std::string msg;
+            msg = std::string("device architecture ") + prop.gcnArchName +
+                  " is not supported: poselib_amd is built for gfx950 (MI355X) only";
+            return fail(PL_ERR_UNSUPPORTED, msg.c_str());
+        }
+    }
+    struct Guard { // releases a half-built context on the failure paths
+        Context *c;
+        ~Guard() {
+            if (!c)
+                return;
+            if (c->ev0)
+                (void)hipEventDestroy(c->ev0);
+            if (c->ev1)
+                (void)hipEventDestroy(c->ev1);
+            if (c->stream)
+                (void)hipStreamDestroy(c->stream);
+            if (c->iota.p)
+                (void)hipFree(c->iota.p);
+            delete c;
+        }
+    } guard{new Context()};
+    Context *c = guard.c;
     c->device = g_requested_device;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -151,6 +179,7 @@ int get_context(Context **out) {
         HIP_TRY(c->iota.ensure(sizeof(uint32_t) * kIotaEntries));
         HIP_TRY(hipMemcpy(c->iota.p, iota.data(), sizeof(uint32_t) * kIotaEntries, hipMemcpyHostToDevice));
     }
+    guard.c = nullptr;
     g_ctx = c;
     *out = c;
     return PL_OK;
@@ -1004,6 +1033,7 @@ struct RansacRun {
             HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
             st->score_kernel_ms += ms;
             st->score_kernel_launches++;
+            st->nan_hypotheses += h_ctl->nan_hyp;
         }
         const uint64_t b0_inl = best_min_inl; // state of the sequential loop at the start of the batch
         const double b0_score = best_min_score;
@@ -1467,8 +1497,14 @@ int make_problem(Context *c, int kind, const double *a, const double *b, size_t 
             soa[(size_t)(da + d) * n + i] = b[db * i + d];
     }
     HIP_TRY(hipMalloc((void **)&p->d_pts, sizeof(double) * nd * n));
-    HIP_TRY(hipMemcpyAsync(p->d_pts, soa.data(), sizeof(double) * nd * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipError_t up = hipMemcpyAsync(p->d_pts, soa.data(), sizeof(double) * nd * n, hipMemcpyHostToDevice, c->stream);
+    if (up == hipSuccess)
+        up = hipStreamSynchronize(c->stream);
+    if (up != hipSuccess) {
+        (void)hipFree(p->d_pts);
+        p->d_pts = nullptr;
+        return fail(PL_ERR_HIP, "upload of the correspondences", up);
+    }
     for (int d = 0; d < nd; ++d)
         p->ps.a[d] = p->d_pts + (size_t)d * n;
     p->ps.xy_absmax = std::nextafter((float)amax, std::numeric_limits<float>::infinity());
@@ -1761,6 +1797,8 @@ void pl_problem_destroy(pl_problem *p) {
     delete p;
 }
 int pl_ransac_run(pl_problem *p, const pl_robust_options *opt, void *model, uint8_t *inliers, pl_ransac_stats *stats) {
+    if (!p || !model)
+        return fail(PL_ERR_INVALID, "problem / model pointer is null");
     int rc = validate_options(opt);
     if (rc != PL_OK)
         return rc;
@@ -1787,10 +1825,14 @@ int pl_ransac_run_sharded(pl_problem *p, const pl_robust_options *opt, const pl_
 }
 
 int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t *inlier_count, double *score) {
+    if (!p || !model)
+        return fail(PL_ERR_INVALID, "problem / model pointer is null");
     Context *c;
     int rc = get_context(&c);
     if (rc != PL_OK)
         return rc;
+    if (p->device != c->device)
+        return fail(PL_ERR_INVALID, "problem lives on another device than the calling thread's");
     double rec[kModelStride];
     if (p->kind == EST_ABS || p->kind == EST_REL)
         record_from_pose(static_cast<const pl_camera_pose *>(model), p->kind == EST_REL, rec);
@@ -1809,8 +1851,104 @@ int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t 
     return PL_OK;
 }
 
+// Diagnostic: an arbitrary list of models through the STREAMING scorer of the main loop (k_gather_models -> k_shadow16 ->
+// k_score_mfma / k_score_queue -> k_finalize2), i.e. through the conservative pre-filters, instead of the sequential
+// scorer pl_score_model uses.  Lets tests feed adversarial models / points to the filters on the device.
+int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double max_error, uint32_t *counts,
+                          double *scores, int32_t *path_used) {
+    if (!p || (!models && n))
+        return fail(PL_ERR_INVALID, "problem / models pointer is null");
+    if (n > (1u << 22))
+        return fail(PL_ERR_INVALID, "too many models");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    if (p->device != c->device)
+        return fail(PL_ERR_INVALID, "problem lives on another device than the calling thread's");
+    if (path_used)
+        *path_used = 0;
+    if (n == 0)
+        return PL_OK;
+    const uint32_t H = (uint32_t)n;
+    const bool pose_kind = (p->kind == EST_ABS || p->kind == EST_REL);
+    std::vector<double> recs((size_t)H * kModelStride);
+    std::vector<uint32_t> ident(H);
+    for (uint32_t k = 0; k < H; ++k) {
+        ident[k] = k;
+        if (pose_kind)
+            record_from_pose(static_cast<const pl_camera_pose *>(models) + k, p->kind == EST_REL, &recs[(size_t)k * kModelStride]);
+        else
+            store_matrix_model(&recs[(size_t)k * kModelStride], mat_from_colmajor(static_cast<const double *>(models) + 9 * (size_t)k));
+    }
+    const double thr2 = max_error * max_error;
+    ScoreArgs sa;
+    set_prefilter(sa, p, thr2);
+    const uint32_t chunks = score_chunks(p->kind, p->n, true);
+    HIP_TRY(c->models.ensure(sizeof(double) * kModelStride * H));
+    HIP_TRY(c->slots.ensure(sizeof(uint32_t) * H));
+    HIP_TRY(c->shadow.ensure(sizeof(float) * 16 * H));
+    HIP_TRY(c->compact64.ensure(sizeof(double) * kModelDoubles * H));
+    HIP_TRY(c->ctl.ensure(sizeof(BatchCtl) + 64));
+    HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * H));
+    HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * H));
+    HIP_TRY(c->count.ensure(sizeof(uint32_t) * H));
+    HIP_TRY(c->score.ensure(sizeof(double) * H));
+    BatchCtl hc;
+    std::memset(&hc, 0, sizeof(hc));
+    hc.num_hyp = H;
+    BatchCtl *d_ctl = c->ctl.as<BatchCtl>();
+    HIP_TRY(hipMemcpyAsync(d_ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->models.p, recs.data(), sizeof(double) * recs.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->slots.p, ident.data(), sizeof(uint32_t) * H, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_gather_models(d_ctl, c->slots.as<uint32_t>(), c->models.as<double>(), H, c->shadow.as<float>(),
+                                 c->compact64.as<double>(), c->stream));
+    sa.pts = p->ps;
+    sa.models = c->models.as<double>();
+    sa.slots = c->slots.as<uint32_t>();
+    sa.shadow16 = nullptr;
+    int path = sa.pf.enabled ? 1 : 0;
+    if (score_uses_mfma(p->kind, p->n, sa.pf)) {
+        HIP_TRY(c->shadow16.ensure(((size_t)H + 8) * 64));
+        HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), H, sa.pf.g16, sa.pf.c16, sa.pf.thr,
+                                c->shadow16.p, c->stream));
+        sa.shadow16 = c->shadow16.p;
+        path = 2;
+    }
+    sa.shadow = c->shadow.as<float>();
+    sa.compact64 = c->compact64.as<double>();
+    sa.num_hyp = &d_ctl->num_hyp;
+    sa.hyp_capacity = H;
+    sa.thr2 = thr2;
+    sa.part_count = c->part_count.as<uint32_t>();
+    sa.part_score = c->part_score.as<double>();
+    const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, H));
+    HIP_TRY(launch_score(p->kind, sa, slices, c->stream));
+    FinalizeArgs fa;
+    fa.num_hyp = sa.num_hyp;
+    fa.hyp_capacity = H;
+    fa.chunks = chunks;
+    fa.n_points = p->n;
+    fa.thr2 = thr2;
+    fa.part_count = sa.part_count;
+    fa.part_score = sa.part_score;
+    fa.count = c->count.as<uint32_t>();
+    fa.score = c->score.as<double>();
+    HIP_TRY(launch_finalize(fa, c->stream));
+    if (counts)
+        HIP_TRY(hipMemcpyAsync(counts, c->count.p, sizeof(uint32_t) * H, hipMemcpyDeviceToHost, c->stream));
+    if (scores)
+        HIP_TRY(hipMemcpyAsync(scores, c->score.p, sizeof(double) * H, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (path_used)
+        *path_used = path;
+    return PL_OK;
+}
+
 int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera *camera, const uint8_t *mask,
                     void *model, uint32_t *lm_iterations) {
+    if (!p || !model || !opt)
+        return fail(PL_ERR_INVALID, "problem / options / model pointer is null");
     if (opt->refine_focal_length || opt->refine_extra_params || opt->refine_principal_point)
         return fail(PL_ERR_UNSUPPORTED, "intrinsics refinement is outside the accelerated hot path");
     if (camera && !camera_supported(camera))
@@ -1819,6 +1957,8 @@ int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera
     int rc = get_context(&c);
     if (rc != PL_OK)
         return rc;
+    if (p->device != c->device)
+        return fail(PL_ERR_INVALID, "problem lives on another device than the calling thread's");
     RefineJob j;
     const bool pose_kind = (p->kind == EST_ABS || p->kind == EST_REL);
     if (pose_kind)
@@ -2209,6 +2349,7 @@ int pl_homography_4pt(const double *x1, const double *x2, double *H) {
 // for later batches) pulls items from a shared counter.  The threads are detached and live until the process ends.
 namespace {
 struct BatchPool {
+    std::mutex run_mu; // held for the whole of run(): one batch at a time per process (concurrent callers queue up)
     std::mutex mu;
     std::condition_variable wake, done;
     std::vector<std::thread> threads;
@@ -2263,7 +2404,10 @@ struct BatchPool {
         }
     }
     int run(pl_batch_item *its, size_t n, int in_flight, int dev) {
-        std::unique_lock<std::mutex> lk(mu); // one batch at a time per process
+        // `mu` alone is not enough: done.wait() releases it, and a second caller would overwrite the job state while
+        // the first batch's workers are still running
+        std::lock_guard<std::mutex> one_batch(run_mu);
+        std::unique_lock<std::mutex> lk(mu);
         while ((int)threads.size() < in_flight) {
             threads.emplace_back([this] { worker(); });
             threads.back().detach();

@@ -314,19 +314,25 @@ __global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, u
 
 // Hypothesis-ordered copies of the records for the streaming scorer: 12 lanes move the 192 bytes of one record
 // (16 B each, contiguous on both sides): bytes 0..127 = the fp64 model -> compact64, 128..191 = the fp32 shadow.
-__global__ __launch_bounds__(256) void k_gather_models(const uint32_t *num_hyp, const uint32_t *slots,
+__global__ __launch_bounds__(256) void k_gather_models(BatchCtl *ctl, const uint32_t *slots,
                                                        const double *models, float *shadow_compact, double *compact64) {
     static_assert(kModelStride == 24 && kModelDoubles == 16 && kShadowOff == 16, "record layout");
-    const uint32_t H = *num_hyp;
+    const uint32_t H = ctl->num_hyp;
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t k = (uint32_t)(t / 12), part = (uint32_t)(t % 12);
-    if (k >= H)
-        return;
-    const uint4 v = reinterpret_cast<const uint4 *>(models + (size_t)slots[k] * kModelStride)[part];
-    if (part < 8)
-        reinterpret_cast<uint4 *>(compact64 + (size_t)k * kModelDoubles)[part] = v;
-    else
-        reinterpret_cast<uint4 *>(shadow_compact + (size_t)k * 16)[part - 8] = v;
+    bool nan_model = false;
+    if (k < H) {
+        const uint4 v = reinterpret_cast<const uint4 *>(models + (size_t)slots[k] * kModelStride)[part];
+        if (part < 8)
+            reinterpret_cast<uint4 *>(compact64 + (size_t)k * kModelDoubles)[part] = v;
+        else
+            reinterpret_cast<uint4 *>(shadow_compact + (size_t)k * 16)[part - 8] = v;
+        nan_model = part == 11 && v.y != 0u; // shadow float 13: the record's NaN flag (pl_math.h store_shadow)
+    }
+    // statistics only (pl_ransac_stats.nan_hypotheses): one integer atomic per wavefront that saw a NaN model
+    const unsigned long long m = __ballot(nan_model);
+    if (m && (threadIdx.x & 63) == 0)
+        atomicAdd(&ctl->nan_hyp, (uint32_t)__popcll(m));
 }
 
 // ------------------------------------------------------------------------------------ finalize + records
@@ -680,9 +686,23 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
                                                     compact64, ctl);
     if (shadow_compact && compact64) {
         const uint64_t threads = (uint64_t)B * (uint64_t)maxm * 12u; // capacity; lanes beyond num_hyp return at once
-        k_gather_models<<<dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream>>>(&ctl->num_hyp, slots, models,
+        k_gather_models<<<dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream>>>(ctl, slots, models,
                                                                                           shadow_compact, compact64);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_models(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t capacity,
+                                float *shadow_compact, double *compact64, hipStream_t stream) {
+    if (capacity == 0)
+        return hipSuccess;
+    const uint64_t threads = (uint64_t)capacity * 12u;
+    k_gather_models<<<dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream>>>(ctl, slots, models, shadow_compact,
+                                                                                      compact64);
+    return hipGetLastError();
+}
+hipError_t launch_finalize(const FinalizeArgs &f, hipStream_t stream) {
+    k_finalize2<<<dim3(kRecBlocks), dim3(256), 0, stream>>>(f, nullptr, nullptr);
     return hipGetLastError();
 }
 

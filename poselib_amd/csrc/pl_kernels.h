@@ -91,6 +91,8 @@ struct BatchCtl {
     uint32_t orbit_error; // sampler position window too small / too many redraw segments
     uint32_t gen_overflow; // an iteration produced more models than slots_per_iter
     uint64_t pos_after;   // draws consumed after the batch's last iteration
+    uint32_t nan_hyp;     // hypotheses of the batch with a NaN entry (k_gather_models; the scorers skip them: no inliers)
+    uint32_t pad;
 };
 struct RecordMeta {
     uint32_t k, slot, count, pad;
@@ -165,6 +167,11 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, bool counted, uint32_t *slots,
                            uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,
                            BatchCtl *ctl, hipStream_t stream);
+// the two halves on their own (diagnostic entry pl_debug_score_stream): hypothesis-ordered copies of records that already
+// sit in `models` in list order `slots`, and the chunk partials -> (count, score) without the record scan
+hipError_t launch_gather_models(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t capacity,
+                                float *shadow_compact, double *compact64, hipStream_t stream);
+hipError_t launch_finalize(const FinalizeArgs &f, hipStream_t stream);
 hipError_t launch_finalize_records(const FinalizeArgs &f, const uint32_t *slots, const double *models,
                                    uint32_t *blk_max, double *blk_min, uint32_t init_max, double init_min,
                                    RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap, BatchCtl *ctl,

@@ -5,9 +5,12 @@
 // (PoseLib/solvers/p3p_common.h:31-71), each line gives a quadratic in the depth ratio
 // (PoseLib/solvers/p3p.cc:129-195), depths are polished by <= 5 Newton steps
 // (p3p_common.h:74-94) and R = Y * X^-1 (p3p.cc:121-122,162-164).  All branches are kept so the
-// set and ORDER of returned solutions equals the reference's; only cbrt/acos/cos (ocml vs glibc)
-// can differ in the last ulp.
+// set and ORDER of returned solutions equals the reference's; cbrt is glibc's algorithm (pl_libm.h,
+// bit-identical to the host's), only acos/cos (ocml vs glibc) can differ in the last ulp.
+// The coefficient block of p3p() below follows PoseLib/solvers/p3p.cc:77-101 operation for operation (BSD-3 source):
+// the arithmetic ORDER is what bit-parity with the reference requires, so that part is a transliteration by design.
 #pragma once
+#include "pl_libm.h"
 #include "pl_math.h"
 
 namespace pl {
@@ -21,7 +24,7 @@ PL_HD bool cubic_one_real_root(double c2, double c1, double c0, double &root) {
         if (c > 0) {
             c = sqrt(c);
             b *= -0.5;
-            root = cbrt(b + c) + cbrt(b - c) - c2 / 3.0;
+            root = pl_cbrt(b + c) + pl_cbrt(b - c) - c2 / 3.0;
             return true;
         }
         c = 3.0 * b / (2.0 * a) * sqrt(-3.0 / a);

@@ -15,6 +15,7 @@
 // The orthonormal null-space basis follows the algorithm of Eigen's fullPivHouseholderQr().matrixQ()
 // (pivot = largest |a_ij| of the trailing corner, first maximum in column-major order).
 #pragma once
+#include "pl_libm.h"
 #include "pl_math.h"
 
 namespace pl {
@@ -40,7 +41,7 @@ PL_HD int cubic_real_roots(double c2, double c1, double c0, double *r) {
     } else if (c > 0) {
         c = sqrt(c);
         b *= -0.5;
-        r[0] = cbrt(b + c) + cbrt(b - c) - c2 / 3.0;
+        r[0] = pl_cbrt(b + c) + pl_cbrt(b - c) - c2 / 3.0;
         n = 1;
     } else {
         c = 3.0 * b / (2.0 * a) * sqrt(-3.0 / a);

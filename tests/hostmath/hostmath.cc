@@ -13,6 +13,7 @@
 #include "../../poselib_amd/csrc/pl_solver_p3p.h"
 #include "../../poselib_amd/csrc/pl_solver_rel.h"
 
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -328,5 +329,39 @@ void hm_lm(int est, const double *const *pa, uint32_t n, double *params, const L
 }
 
 void hm_factorized_F(const double *params, double *F) { factorized_F(params, F); }
+
+// pl_libm.h against the host's libm (glibc): number of arguments on which pl_cbrt and cbrt differ in any bit.
+// mode 0: any bit pattern; 1: uniform in [-10, 10]; 2: log-uniform magnitudes 2^-60..2^60, both signs; 3: subnormals
+uint64_t hm_cbrt_mismatches(uint64_t count, uint64_t seed, int mode, double *first_bad) {
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 88172645463325252ull, bad = 0;
+    auto rnd = [&]() {
+        s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+        return s;
+    };
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint64_t r = rnd();
+        double x;
+        if (mode == 0) {
+            std::memcpy(&x, &r, 8);
+        } else if (mode == 1) {
+            x = ((double)(r >> 11) / 9007199254740992.0 - 0.5) * 20.0;
+        } else if (mode == 2) {
+            x = std::ldexp((double)(r >> 11) / 9007199254740992.0 + 0.5, (int)(rnd() % 121) - 60);
+            if (r & 1)
+                x = -x;
+        } else {
+            const uint64_t b = r & 0x800fffffffffffffull;
+            std::memcpy(&x, &b, 8);
+        }
+        const double mine = pl_cbrt(x), host = std::cbrt(x);
+        if (std::memcmp(&mine, &host, 8) != 0 && !(mine != mine && host != host)) {
+            if (!bad && first_bad)
+                *first_bad = x;
+            ++bad;
+        }
+    }
+    return bad;
+}
+double hm_cbrt(double x) { return pl_cbrt(x); }
 
 } // extern "C"

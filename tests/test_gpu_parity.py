@@ -51,7 +51,9 @@ def test_p3p_batch_matches_oracle(gpu):
         for m in range(len(ref)):
             worst = max(worst, np.abs(rec[i, m, :7] - ref[m]).max())
     print("p3p: max |pose diff| device vs oracle =", worst)
-    assert worst < 1e-9
+    # cbrt is glibc's algorithm on the device (pl_libm.h, bit-identical); acos / cos of the three-real-root branch of the
+    # cubic are ocml's and may differ from glibc's in the last bit, amplified by the conditioning of the sample
+    assert worst < 1e-11, worst
 
 
 def test_single_solver_entry_points(gpu):
@@ -128,15 +130,15 @@ def test_two_view_solver_batches(gpu, kind, name, K):
     p99 = diffs[int(0.99 * (len(diffs) - 1))] if len(diffs) else 0.0
     print(f"{name}: solution-count mismatches {mismatched}/{len(idx)}, max |diff| {worst}, median "
           f"{np.median(diffs) if len(diffs) else 0}, p99 {p99}")
-    assert mismatched <= len(idx) // 200  # ill-conditioned samples may gain/lose a root at the 1e-10 tolerances
-    if name == "rel":
-        # the degree-10 polynomial amplifies rounding (different summation order of the constraint rows on
-        # device vs oracle) for ill-conditioned (outlier-contaminated) samples: bound the bulk tightly and the
-        # tail loosely
-        assert p99 < 1e-7 and worst < 1e-2
+    # The device solvers are the oracle's arithmetic operation for operation (tests/test_hostmath_vs_oracle.py checks the
+    # same headers bit for bit on the host): -ffp-contract=off on both sides, IEEE division and square root.  The 5-point
+    # and the homography solvers call nothing but sqrt from libm, so they must agree to the bit; the 7-point solver's
+    # cubic goes through cbrt (pl_libm.h: glibc's algorithm, bit-identical) or acos / cos (ocml).
+    assert mismatched == 0
+    if name == "fund":
+        assert worst < 1e-11, worst  # the cubic's acos / cos branch (ocml vs glibc: last bit), see test_p3p_batch_matches_oracle
     else:
-        assert worst < 1e-8
-
+        assert worst == 0.0, worst
 
 # ------------------------------------------------------------------------------------------ scoring / refinement
 def test_score_and_refine_match_oracle(gpu):
