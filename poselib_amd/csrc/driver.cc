@@ -560,31 +560,15 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     const uint32_t nj = (uint32_t)jobs.size();
     if (nj == 0)
         return PL_OK;
-    // one staging block, one upload: [LMTask x nj][seed records x nj (+ the incumbent's record)]
+    // one staging block in pinned, device-mapped host memory: [LMTask x nj][seed records x nj (+ the incumbent's record)].
+    // k_lm fetches its task from there itself (one cooperative read over the bus) and writes the outputs back, so the
+    // single-workgroup path needs no upload dispatch; the multi-launch k_lm2 path reads its tasks every launch and keeps
+    // a device copy.
     static_assert(sizeof(LMTask) % sizeof(double) == 0, "records follow the tasks");
     const size_t stage_bytes = sizeof(LMTask) * nj + sizeof(double) * kModelStride * (nj + 1);
     HIP_TRY(c->h_tasks.ensure(stage_bytes));
-    HIP_TRY(c->lm_tasks.ensure(stage_bytes));
     HIP_TRY(c->lm_scratch.ensure((size_t)p->n * nj + 16));
     HIP_TRY(c->lm_records.ensure(sizeof(double) * kModelStride * nj));
-    LMTask *ht = c->h_tasks.as<LMTask>();
-    double *hr = reinterpret_cast<double *>(ht + nj);
-    double *d_records_in = reinterpret_cast<double *>(c->lm_tasks.as<LMTask>() + nj);
-    for (uint32_t j = 0; j < nj; ++j) {
-        LMTask &t = ht[j];
-        std::memset(&t, 0, sizeof(t));
-        lm_params_from_record(p->kind, jobs[j].record_in, t.params);
-        t.opt = jobs[j].opt;
-        t.cam = jobs[j].cam;
-        t.point_scale = jobs[j].point_scale;
-        t.prefilter_thr2 = jobs[j].prefilter_thr2;
-        t.mask = jobs[j].d_mask;
-        t.scratch = c->lm_scratch.as<uint8_t>() + (size_t)j * p->n;
-        std::memcpy(hr + (size_t)j * kModelStride, jobs[j].record_in, sizeof(double) * kModelStride);
-    }
-    if (tail)
-        std::memcpy(hr + (size_t)nj * kModelStride, tail->incumbent_rec, sizeof(double) * kModelStride);
-    HIP_TRY(hipMemcpyAsync(c->lm_tasks.p, ht, stage_bytes, hipMemcpyHostToDevice, c->stream));
     // Large point sets with 6..8 parameters saturate the single CU k_lm gives a task: spread every task over several
     // workgroups (k_lm2, one launch per LM iteration).  Only for short, bounded runs (the LO: 25 iterations) - k_lm2
     // costs max_iterations + 2 launches whatever the iteration count turns out to be.  Measured on MI355X at
@@ -603,19 +587,44 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         max_it = std::max(max_it, jobs[j].opt.max_iterations);
     }
     const uint32_t lm2_min_points = (p->kind == EST_ABS) ? 8192u : 2560u;
-    if (latency_mode && p->kind != EST_REL && same_it && max_it >= 1 && max_it <= 32 && p->n >= lm2_min_points) {
+    const bool use_lm2 = latency_mode && p->kind != EST_REL && same_it && max_it >= 1 && max_it <= 32 && p->n >= lm2_min_points;
+    if (use_lm2)
+        HIP_TRY(c->lm_tasks.ensure(stage_bytes));
+    LMTask *ht = c->h_tasks.as<LMTask>();
+    double *hr = reinterpret_cast<double *>(ht + nj);
+    // where the kernels see the staging block: the device copy (k_lm2) or the pinned block itself (k_lm)
+    LMTask *d_tasks = use_lm2 ? c->lm_tasks.as<LMTask>() : c->h_tasks.dev<LMTask>();
+    double *d_records_in = reinterpret_cast<double *>(d_tasks + nj);
+    for (uint32_t j = 0; j < nj; ++j) {
+        LMTask &t = ht[j];
+        std::memset(&t, 0, sizeof(t));
+        lm_params_from_record(p->kind, jobs[j].record_in, t.params);
+        t.opt = jobs[j].opt;
+        t.cam = jobs[j].cam;
+        t.point_scale = jobs[j].point_scale;
+        t.prefilter_thr2 = jobs[j].prefilter_thr2;
+        t.mask = jobs[j].d_mask;
+        t.scratch = c->lm_scratch.as<uint8_t>() + (size_t)j * p->n;
+        t.record_in = d_records_in + (size_t)j * kModelStride;
+        t.record_out = use_lm2 ? nullptr : c->lm_records.as<double>() + (size_t)j * kModelStride;
+        std::memcpy(hr + (size_t)j * kModelStride, jobs[j].record_in, sizeof(double) * kModelStride);
+    }
+    if (tail)
+        std::memcpy(hr + (size_t)nj * kModelStride, tail->incumbent_rec, sizeof(double) * kModelStride);
+    if (use_lm2) {
+        HIP_TRY(hipMemcpyAsync(c->lm_tasks.p, ht, stage_bytes, hipMemcpyHostToDevice, c->stream));
         const uint32_t slices = std::min<uint32_t>(16u, std::max<uint32_t>(2u, p->n / 512u));
         HIP_TRY(c->lm2_states.ensure(lm2_state_bytes(nj)));
         HIP_TRY(c->lm2_partials.ensure(lm2_partial_bytes(nj, slices)));
-        HIP_TRY(launch_lm2(p->kind, p->ps, c->lm_tasks.as<LMTask>(), nj, slices, max_it, c->lm2_states.p,
-                           c->lm2_partials.as<double>(), c->stream));
+        HIP_TRY(launch_lm2(p->kind, p->ps, d_tasks, nj, slices, max_it, c->lm2_states.p, c->lm2_partials.as<double>(),
+                           c->stream));
+        // (k_task_records also writes the tasks' outputs into the pinned staging block: stream order puts that after the
+        // upload above has read it)
+        HIP_TRY(launch_task_records(p->kind, d_tasks, d_records_in, c->lm_records.as<double>(), nj,
+                                    c->h_tasks.dev<LMTask>(), c->stream));
     } else {
-        HIP_TRY(launch_lm(p->kind, p->ps, c->lm_tasks.as<LMTask>(), nj, c->stream));
+        HIP_TRY(launch_lm(p->kind, p->ps, d_tasks, nj, c->stream)); // outputs + refined records: written by k_lm itself
     }
-    // (k_task_records also writes the tasks' outputs into the pinned staging block: stream order puts that after the
-    // upload above has read it)
-    HIP_TRY(launch_task_records(p->kind, c->lm_tasks.as<LMTask>(), d_records_in, c->lm_records.as<double>(), nj,
-                                c->h_tasks.dev<LMTask>(), c->stream));
     if (rescore || tail) {
         int rc = enqueue_score_records(c, p, c->lm_records.as<double>(), nj, tail ? tail->thr2 : thr2, false);
         if (rc != PL_OK)
@@ -627,11 +636,13 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         HIP_TRY(launch_select_record(c->score.as<double>(), tail->incumbent_score, c->lm_records.as<double>(),
                                      d_records_in + (size_t)nj * kModelStride,
                                      c->tmp_model.as<double>(), c->stream));
-        HIP_TRY(launch_mask(p->kind, p->ps, c->tmp_model.as<double>(), tail->thr2, c->mask.as<uint8_t>(), c->stream));
-        if (tail->host_mask && p->n)
-            HIP_TRY(hipMemcpyAsync(tail->host_mask, c->mask.p, p->n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c->h_mask.ensure(std::max<uint32_t>(p->n, 1u)));
+        HIP_TRY(launch_mask(p->kind, p->ps, c->tmp_model.as<double>(), tail->thr2, c->mask.as<uint8_t>(),
+                            tail->host_mask ? c->h_mask.dev<uint8_t>() : nullptr, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (tail && tail->host_mask && p->n) // the kernel wrote the pinned copy itself
+        std::memcpy(tail->host_mask, c->h_mask.p, p->n);
     for (uint32_t j = 0; j < nj; ++j) {
         jobs[j].skipped = ht[j].skipped != 0;
         std::memcpy(jobs[j].params_out, ht[j].params, sizeof(double) * kParamDoubles);
@@ -678,6 +689,7 @@ struct RansacRun {
         uint64_t b0_inl = 0;                 // state of the sequential loop at the start of the batch
         double b0_score = 0;
         const double *h_rec = nullptr; // model records of `imps`, indexed by Improving::gather
+        bool ctl_mirrored = false;     // k_score_seq has written the control block to pinned host memory
     };
 
     Context *c;
@@ -810,7 +822,8 @@ struct RansacRun {
         HIP_TRY(c->slots.ensure(sizeof(uint32_t) * hcap));
         HIP_TRY(c->offsets.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
         // control block + models per 1024 iterations (zeroed together, filled by the generator)
-        const size_t ctl_bytes = sizeof(BatchCtl) + sizeof(uint32_t) * ((Bl + 1023) / 1024 + 1);
+        const uint32_t nblk = (Bl + 1023) / 1024; // (two tables: models and NaN models per 1024 iterations)
+        const size_t ctl_bytes = sizeof(BatchCtl) + sizeof(uint32_t) * (2 * (size_t)nblk + 2);
         HIP_TRY(c->ctl.ensure(ctl_bytes));
         HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * hcap));
         HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * hcap));
@@ -823,12 +836,13 @@ struct RansacRun {
         HIP_TRY(c->h_rec_meta.ensure(sizeof(RecordMeta) * kRecordCap));
         HIP_TRY(c->h_gather_out.ensure(sizeof(double) * kModelStride * kRecordCap));
         BatchCtl *d_ctl = c->ctl.as<BatchCtl>();
-        HIP_TRY(hipMemsetAsync(d_ctl, 0, ctl_bytes, c->stream));
+        bool ctl_zeroed = false; // (the device sampler's first kernel clears the block; otherwise a memset does)
         uint32_t *const blk_tot = reinterpret_cast<uint32_t *>(d_ctl + 1);
 
         uint64_t pos_after = 0;
         bool device_positions = !host_positions && !force_host_positions && !prosac;
         const ProsacSampler prosac_at_batch_start = prosac_sampler; // a repeated batch draws the same samples
+        static_assert(sizeof(BatchCtl) % 4 == 0, "zeroed as 32-bit words");
         if (prosac) {
             HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * (size_t)B * K));
             HIP_TRY(c->samples.ensure(sizeof(uint32_t) * (size_t)B * K));
@@ -854,9 +868,12 @@ struct RansacRun {
                 HIP_TRY(c->flags.ensure(sizeof(uint64_t) * ((size_t)M / 64 + 2))); // bitmap of redrawing positions
                 HIP_TRY(launch_sample_positions(K, ro.seed, pos, N, B, M, c->delta.as<uint8_t>(),
                                                 c->flags.as<uint64_t>(), c->positions.as<uint32_t>(), d_ctl,
-                                                c->stream));
+                                                (uint32_t)(ctl_bytes / 4), c->stream));
+                ctl_zeroed = true;
             }
         }
+        if (!ctl_zeroed)
+            HIP_TRY(hipMemsetAsync(d_ctl, 0, ctl_bytes, c->stream));
         if (!device_positions && !prosac) {
             HIP_TRY(c->h_positions.ensure(sizeof(uint32_t) * B));
             pos_after = sample_positions_k(K, ro.seed, pos, N, B, c->h_positions.as<uint32_t>());
@@ -879,24 +896,27 @@ struct RansacRun {
             ga.num_models = c->num_models.as<uint32_t>();
             ga.real_focal_check = o->real_focal_check;
             ga.blk_tot = blk_tot;
+            ga.blk_nan = blk_tot + nblk;
             if (const size_t sb = generate_stage_bytes(kind, Bl)) {
                 HIP_TRY(c->gen_stage.ensure(sb));
                 ga.stage = c->gen_stage.p;
             }
             HIP_TRY(launch_generate(kind, ga, c->stream));
-            HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, blk_tot, true, c->slots.as<uint32_t>(),
-                                    c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,
-                                    prefilter ? c->compact64.as<double>() : nullptr, d_ctl, c->stream));
             sa.pts = p->ps;
             sa.models = ga.models;
             sa.slots = c->slots.as<uint32_t>();
             sa.shadow16 = nullptr;
-            if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores
+            Shadow16Params s16;
+            if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores: built
+                                                    // in the same launch as the hypothesis-ordered copies
                 HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
-                HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), (uint32_t)hcap, sa.pf.g16, sa.pf.c16,
-                                        sa.pf.thr, c->shadow16.p, c->stream));
+                s16.out = c->shadow16.p;
+                s16.g16 = sa.pf.g16, s16.c16 = sa.pf.c16, s16.thr = sa.pf.thr;
                 sa.shadow16 = c->shadow16.p;
             }
+            HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, blk_tot, true, c->slots.as<uint32_t>(),
+                                    c->offsets.as<uint32_t>(), ga.models, prefilter ? c->shadow.as<float>() : nullptr,
+                                    prefilter ? c->compact64.as<double>() : nullptr, d_ctl, s16, c->stream));
             sa.shadow = prefilter ? c->shadow.as<float>() : nullptr;
             sa.compact64 = prefilter ? c->compact64.as<double>() : nullptr;
             sa.num_hyp = &d_ctl->num_hyp;
@@ -942,7 +962,10 @@ struct RansacRun {
             qa.host_score = nullptr;
             qa.host_cand = c->h_rec_meta.dev<RecordMeta>();
             qa.host_cap = kRecordFirst;
+            qa.ctl_src = d_ctl; // the last kernel of the batch mirrors the control block into pinned host memory
+            qa.ctl_host = c->h_small.dev<BatchCtl>();
             HIP_TRY(launch_score_seq(kind, qa, c->stream));
+            b.ctl_mirrored = true;
         }
         b.pos_after = pos_after;
         b.device_positions = device_positions;
@@ -993,7 +1016,8 @@ struct RansacRun {
         BatchCtl *h_ctl = c->h_small.as<BatchCtl>();
         RecordMeta *h_meta = c->h_rec_meta.as<RecordMeta>(); // the first kRecordFirst candidates: written by k_score_seq
         double *h_recm = c->h_gather_out.as<double>();
-        HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(BatchCtl), hipMemcpyDeviceToHost, c->stream));
+        if (!b.ctl_mirrored)
+            HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(BatchCtl), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (device_positions) {
             if (h_ctl->orbit_error) { // evaluated window too small / too many redraws: redo this batch
@@ -1444,10 +1468,12 @@ struct RansacRun {
             HIP_TRY(c->tmp_model.ensure(sizeof(double) * kModelStride));
             HIP_TRY(hipMemcpyAsync(c->tmp_model.p, best_record, sizeof(double) * kModelStride, hipMemcpyHostToDevice,
                                    c->stream));
-            HIP_TRY(launch_mask(kind, p->ps, c->tmp_model.as<double>(), thr2, c->mask.as<uint8_t>(), c->stream));
-            if (inliers)
-                HIP_TRY(hipMemcpyAsync(inliers, c->mask.p, N, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c->h_mask.ensure(N));
+            HIP_TRY(launch_mask(kind, p->ps, c->tmp_model.as<double>(), thr2, c->mask.as<uint8_t>(),
+                                inliers ? c->h_mask.dev<uint8_t>() : nullptr, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            if (inliers)
+                std::memcpy(inliers, c->h_mask.p, N);
         }
         st->seconds = now_s() - t_start;
         return PL_OK;

@@ -95,15 +95,26 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // ------------------------------------------------------------------------------------ generate
 // Models per block of 1024 iterations (the first level of k_compact2's scan), accumulated by the generators themselves:
 // one integer atomic per wavefront into a table the batch's control-block memset has zeroed.
-__device__ __forceinline__ void count_models_of_wave(const GenerateArgs &g, uint32_t it, uint32_t n) {
+// (n_nan: models with a NaN entry - statistics only, pl_ransac_stats.nan_hypotheses - go into a second table of the
+// same shape; the atomics are spread over the blocks' table entries, one hot counter would serialise them)
+__device__ __forceinline__ void count_models_of_wave(const GenerateArgs &g, uint32_t it, uint32_t n, uint32_t n_nan) {
     if (!g.blk_tot)
         return;
     const uint32_t s = wave_sum_u32(n);
     if ((threadIdx.x & 63) == 0 && s)
         atomicAdd(&g.blk_tot[it >> 10], s);
+    if (g.blk_nan && __builtin_amdgcn_ballot_w64(n_nan != 0u)) {
+        const uint32_t sn = wave_sum_u32(n_nan);
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd(&g.blk_nan[it >> 10], sn);
+    }
+}
+// NaN flag of a record that has been written (pl_math.h store_shadow)
+__device__ __forceinline__ uint32_t record_is_nan(const double *rec) {
+    return reinterpret_cast<const uint32_t *>(rec + kShadowOff)[13] != 0u ? 1u : 0u;
 }
 
-template <int EST> __device__ __forceinline__ uint32_t generate_one(const GenerateArgs &g, uint32_t it) {
+template <int EST> __device__ __forceinline__ uint32_t generate_one(const GenerateArgs &g, uint32_t it, uint32_t &n_nan) {
     constexpr int K = sample_size(EST);
     constexpr int MAXM = max_models(EST);
     uint32_t idx[K];
@@ -127,7 +138,7 @@ template <int EST> __device__ __forceinline__ uint32_t generate_one(const Genera
         P3PSolution sol[4];
         n = p3p(xb[0], xb[1], xb[2], Xp[0], Xp[1], Xp[2], sol);
         for (int m = 0; m < n; ++m)
-            store_pose_model(rec + m * kModelStride, sol[m].R, sol[m].t, false);
+            n_nan += store_pose_model(rec + m * kModelStride, sol[m].R, sol[m].t, false) ? 1u : 0u;
     } else {
         Vec3 b1[K], b2[K];
 #pragma unroll
@@ -139,15 +150,19 @@ template <int EST> __device__ __forceinline__ uint32_t generate_one(const Genera
             Mat3 H;
             n = homography_4pt(b1, b2, H, true);
             if (n)
-                store_matrix_model(rec, H);
+                n_nan += store_matrix_model(rec, H) ? 1u : 0u;
         } else if constexpr (EST == EST_FUND) {
             n = relpose_7pt_records(b1, b2, rec, g.real_focal_check != 0);
+            for (int m = 0; m < n; ++m)
+                n_nan += record_is_nan(rec + m * kModelStride);
         } else {
             n = relpose_5pt_records(b1, b2, rec, (int)g.slots_per_iter);
             if (n > (int)g.slots_per_iter) {
                 g.ctl->gen_overflow = 1;
                 n = 0;
             }
+            for (int m = 0; m < n; ++m)
+                n_nan += record_is_nan(rec + m * kModelStride);
         }
     }
     g.num_models[it] = (uint32_t)n;
@@ -155,8 +170,9 @@ template <int EST> __device__ __forceinline__ uint32_t generate_one(const Genera
 }
 template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs g) {
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t n = (it < g.num_iters) ? generate_one<EST>(g, it) : 0u;
-    count_models_of_wave(g, it, n); // one call site: the lanes past the last iteration take part with n = 0
+    uint32_t n_nan = 0;
+    const uint32_t n = (it < g.num_iters) ? generate_one<EST>(g, it, n_nan) : 0u;
+    count_models_of_wave(g, it, n, n_nan); // one call site: the lanes past the last iteration take part with n = 0
 }
 
 
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *st
 }
 
 __device__ __forceinline__ uint32_t rel_poses_one(const GenerateArgs &g, const double *stage, uint32_t cap, const uint32_t *nroots_in,
-                                                  uint32_t it) {
+                                                  uint32_t it, uint32_t &n_nan) {
     uint32_t idx[5];
     sample_of_iteration<5>(g, it, idx);
     Vec3 b1[5], b2[5];
@@ -274,21 +290,23 @@ __device__ __forceinline__ uint32_t rel_poses_one(const GenerateArgs &g, const d
         const int nc = motion_from_essential<5>(E, b1, b2, cand);
         for (int k = 0; k < nc; ++k) {
             if (n < max_out)
-                store_pose_model_q(rec + n * kModelStride, cand[k].q, cand[k].t, true);
+                n_nan += store_pose_model_q(rec + n * kModelStride, cand[k].q, cand[k].t, true) ? 1u : 0u;
             ++n;
         }
     }
     if (n > max_out) {
         g.ctl->gen_overflow = 1;
         n = 0;
+        n_nan = 0;
     }
     g.num_models[it] = (uint32_t)n;
     return (uint32_t)n;
 }
 __global__ __launch_bounds__(64) void k_rel_poses(GenerateArgs g, const double *stage, uint32_t cap, const uint32_t *nroots_in) {
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, cap, nroots_in, it) : 0u;
-    count_models_of_wave(g, it, n);
+    uint32_t n_nan = 0;
+    const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, cap, nroots_in, it, n_nan) : 0u;
+    count_models_of_wave(g, it, n, n_nan);
 }
 
 // Bare solver batch: one lane per minimal problem, AoS input exactly as the reference API takes it.
@@ -891,6 +909,10 @@ template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(Se
     __shared__ double s_sum;
     const uint32_t nrec = min(*a.num, a.cap);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.ctl_host && blockIdx.x == 0 && threadIdx.x == 0) {
+        const BatchCtl c = *a.ctl_src; // final: every kernel that writes it is an earlier launch of the stream
+        *a.ctl_host = c;
+    }
     for (uint32_t r = blockIdx.x; r < nrec; r += gridDim.x) {
         const double *Mp = a.models + (size_t)(a.cand ? a.cand[r].slot : r) * kModelStride;
         double M[kModelDoubles];
@@ -989,7 +1011,8 @@ template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(Se
 }
 
 // ------------------------------------------------------------------------------------ mask
-template <int EST> __global__ __launch_bounds__(256) void k_mask(PointSet pts, const double *model, double thr2, uint8_t *mask) {
+template <int EST> __global__ __launch_bounds__(256) void k_mask(PointSet pts, const double *model, double thr2, uint8_t *mask,
+                                                                 uint8_t *host_mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pts.n)
         return;
@@ -1005,6 +1028,8 @@ template <int EST> __global__ __launch_bounds__(256) void k_mask(PointSet pts, c
         in = eval_point<EST>(M, pt, thr2, r2);
     }
     mask[i] = in ? 1 : 0;
+    if (host_mask)
+        host_mask[i] = in ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------ LM
@@ -1046,7 +1071,36 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet p
     constexpr int K = R::K;
     constexpr int NT = NormalSize<K>::kTotal;
     constexpr int ND = point_doubles(EST);
-    LMTask &T = tasks[blockIdx.x];
+    // The task may live in pinned host memory the device reads over the bus (no upload dispatch): ONE cooperative
+    // fetch into LDS; the outputs go back to the task (and the refined model's record to device memory) at the end.
+    __shared__ LMTask s_task;
+    LMTask &Tout = tasks[blockIdx.x];
+    {
+        static_assert(sizeof(LMTask) % 8 == 0, "copied as 64-bit words");
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(&Tout);
+        uint64_t *dst = reinterpret_cast<uint64_t *>(&s_task);
+        for (uint32_t w = threadIdx.x; w < sizeof(LMTask) / 8; w += kLMThreads)
+            dst[w] = src[w];
+        __syncthreads();
+    }
+    const LMTask &T = s_task;
+    auto finish = [&](const double *params, bool skipped, uint32_t iterations, double cost, double initial_cost) {
+        // (thread 0 only)
+        for (int i = 0; i < kParamDoubles; ++i)
+            Tout.params[i] = params[i];
+        Tout.iterations = iterations;
+        Tout.skipped = skipped ? 1u : 0u;
+        Tout.cost = cost;
+        Tout.initial_cost = initial_cost;
+        if (T.record_out) {
+            if (skipped) { // refinement not run: model unchanged (relative_pose.cc:75-77)
+                for (int i = 0; i < kModelStride; ++i)
+                    T.record_out[i] = T.record_in[i];
+            } else {
+                record_from_lm_params(EST, params, T.record_out);
+            }
+        }
+    };
     extern __shared__ double s_lm_points[];
     PointSet pts = pts_global;
     if (lds_points) {
@@ -1109,10 +1163,8 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet p
         }
     }
     if (s_skip) {
-        if (threadIdx.x == 0) {
-            T.skipped = 1;
-            T.iterations = 0;
-        }
+        if (threadIdx.x == 0)
+            finish(cur, true, 0u, 0.0, 0.0);
         return;
     }
 
@@ -1213,14 +1265,8 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet p
         __syncthreads();
     }
 
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < kParamDoubles; ++i)
-            T.params[i] = cur[i];
-        T.iterations = ctl.iterations;
-        T.skipped = 0;
-        T.cost = ctl.cost;
-        T.initial_cost = ctl.initial_cost;
-    }
+    if (threadIdx.x == 0)
+        finish(cur, false, ctl.iterations, ctl.cost, ctl.initial_cost);
 }
 
 // ---- LM across several workgroups ---------------------------------------------------------------------------------
@@ -1695,11 +1741,11 @@ hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_
 }
 
 hipError_t launch_mask(int est, const PointSet &pts, const double *model, double thr2, uint8_t *mask,
-                       hipStream_t stream) {
+                       uint8_t *host_mask, hipStream_t stream) {
     if (pts.n == 0)
         return hipSuccess;
     const dim3 grid((pts.n + 255) / 256), block(256);
-    PL_DISPATCH_EST(est, k_mask<E><<<grid, block, 0, stream>>>(pts, model, thr2, mask));
+    PL_DISPATCH_EST(est, k_mask<E><<<grid, block, 0, stream>>>(pts, model, thr2, mask, host_mask));
     return hipGetLastError();
 }
 

@@ -61,7 +61,13 @@ __device__ __forceinline__ double wscan_min(double v, int lane) {
 // ------------------------------------------------------------------------------------ sampler orbit
 template <int K>
 __global__ __launch_bounds__(256) void k_sample_delta(uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t M,
-                                                      uint8_t *delta, uint64_t *flagbits) {
+                                                      uint8_t *delta, uint64_t *flagbits, uint32_t *zero,
+                                                      uint32_t zero_words) {
+    // the batch's control block and the generators' per-block model counts start at zero: the first kernel of the
+    // batch clears them (everything that writes them is a later launch on the same stream) - no memset dispatch
+    if (blockIdx.x == 0)
+        for (uint32_t w = threadIdx.x; w < zero_words; w += 256)
+            zero[w] = 0u;
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     bool flag = false;
     if (p < M) {
@@ -298,8 +304,14 @@ __global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, u
             wo[w] = s;
             s += wt[w];
         }
-        if (blockIdx.x == gridDim.x - 1)
+        if (blockIdx.x == gridDim.x - 1) {
             ctl->num_hyp = s_base + s;
+            uint32_t nan = 0; // the generators' NaN-model counts (second table behind blk_tot; statistics)
+            const uint32_t *blk_nan = blk_tot + gridDim.x;
+            for (uint32_t j = 0; j < gridDim.x; ++j)
+                nan += blk_nan[j];
+            ctl->nan_hyp = nan;
+        }
     }
     __syncthreads();
     if (i < B) {
@@ -314,11 +326,10 @@ __global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, u
 
 // Hypothesis-ordered copies of the records for the streaming scorer: 12 lanes move the 192 bytes of one record
 // (16 B each, contiguous on both sides): bytes 0..127 = the fp64 model -> compact64, 128..191 = the fp32 shadow.
-__global__ __launch_bounds__(256) void k_gather_models(BatchCtl *ctl, const uint32_t *slots,
-                                                       const double *models, float *shadow_compact, double *compact64) {
+__device__ __forceinline__ void gather_one(BatchCtl *ctl, const uint32_t *slots, const double *models,
+                                           float *shadow_compact, double *compact64, uint64_t t) {
     static_assert(kModelStride == 24 && kModelDoubles == 16 && kShadowOff == 16, "record layout");
     const uint32_t H = ctl->num_hyp;
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t k = (uint32_t)(t / 12), part = (uint32_t)(t % 12);
     bool nan_model = false;
     if (k < H) {
@@ -327,12 +338,12 @@ __global__ __launch_bounds__(256) void k_gather_models(BatchCtl *ctl, const uint
             reinterpret_cast<uint4 *>(compact64 + (size_t)k * kModelDoubles)[part] = v;
         else
             reinterpret_cast<uint4 *>(shadow_compact + (size_t)k * 16)[part - 8] = v;
-        nan_model = part == 11 && v.y != 0u; // shadow float 13: the record's NaN flag (pl_math.h store_shadow)
     }
-    // statistics only (pl_ransac_stats.nan_hypotheses): one integer atomic per wavefront that saw a NaN model
-    const unsigned long long m = __ballot(nan_model);
-    if (m && (threadIdx.x & 63) == 0)
-        atomicAdd(&ctl->nan_hyp, (uint32_t)__popcll(m));
+    (void)nan_model;
+}
+__global__ __launch_bounds__(256) void k_gather_models(BatchCtl *ctl, const uint32_t *slots,
+                                                       const double *models, float *shadow_compact, double *compact64) {
+    gather_one(ctl, slots, models, shadow_compact, compact64, (uint64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ finalize + records
@@ -503,13 +514,10 @@ __device__ __forceinline__ unsigned short half_bits_up(float v) { // v >= 0: sma
         b = (unsigned short)(b + 1); // next fp16 above (b < 0x7c00 here; 0x7bff + 1 = +inf)
     return b;
 }
-__global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const float *__restrict__ shadow,
-                                                  uint32_t capacity8, float g16, float c16, float thr,
-                                                  uint2 *__restrict__ out) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= capacity8)
-        return;
-    const uint32_t H = *num_hyp;
+// shadow_of(k): the fp32 shadow (16 floats) of hypothesis k < H
+template <typename ShadowOf>
+__device__ __forceinline__ void shadow16_one(uint32_t k, uint32_t H, ShadowOf shadow_of, float g16, float c16, float thr,
+                                             uint2 *__restrict__ out) {
     if (k >= ((H + 7u) & ~7u))
         return; // blocks past the last hypothesis are never read
     const uint32_t s = k & 7u, half = s & 1u, r = s >> 1, P = r >> 1, e = r & 1u;
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const
             R[i] = 0.f;
         t[0] = t[1] = t[2] = 0.f;
     } else {
-        const float *f = shadow + (size_t)k * 16;
+        const float *f = shadow_of(k);
         float rmax = 0.f;
         for (int i = 0; i < 9; ++i) {
             R[i] = f[i];
@@ -580,6 +588,33 @@ __global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const
         blk[rows[3]] = make_uint2(w0, (uint32_t)r2 | ((uint32_t)cb << 16));
         blk[32 + rows[3]] = make_uint2(w0, (uint32_t)r2 | (0x3c00u << 16)); // k7 = 1.0
     }
+}
+
+__global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const float *__restrict__ shadow,
+                                                  uint32_t capacity8, float g16, float c16, float thr,
+                                                  uint2 *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= capacity8)
+        return;
+    shadow16_one(k, *num_hyp, [&](uint32_t kk) { return shadow + (size_t)kk * 16; }, g16, c16, thr, out);
+}
+
+// k_gather_models and k_shadow16 as ONE launch (both only depend on k_compact2's hypothesis list): blocks below
+// `gather_blocks` copy the records, the blocks above build the fp16 operand blocks straight from the records' shadows.
+__global__ __launch_bounds__(256) void k_gather_shadow16(BatchCtl *ctl, const uint32_t *slots, const double *models,
+                                                         float *shadow_compact, double *compact64,
+                                                         uint32_t gather_blocks, uint32_t capacity8, float g16, float c16,
+                                                         float thr, uint2 *__restrict__ out16) {
+    if (blockIdx.x < gather_blocks) {
+        gather_one(ctl, slots, models, shadow_compact, compact64, (uint64_t)blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
+    const uint32_t k = (blockIdx.x - gather_blocks) * 256 + threadIdx.x;
+    if (k >= capacity8)
+        return;
+    shadow16_one(k, ctl->num_hyp,
+                 [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
+                 g16, c16, thr, out16);
 }
 
 // ------------------------------------------------------------------------------------ front-end pre-processing
@@ -654,20 +689,21 @@ hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, 
 
 hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t B, uint32_t M,
                                    uint8_t *delta, uint64_t *flagbits, uint32_t *positions, BatchCtl *ctl,
-                                   hipStream_t stream) {
+                                   uint32_t zero_words, hipStream_t stream) {
+    uint32_t *const zero = reinterpret_cast<uint32_t *>(ctl);
     const dim3 grid((M + 255) / 256), block(256);
     switch (K) {
     case 3:
-        k_sample_delta<3><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits);
+        k_sample_delta<3><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits, zero, zero_words);
         break;
     case 4:
-        k_sample_delta<4><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits);
+        k_sample_delta<4><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits, zero, zero_words);
         break;
     case 5:
-        k_sample_delta<5><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits);
+        k_sample_delta<5><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits, zero, zero_words);
         break;
     case 7:
-        k_sample_delta<7><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits);
+        k_sample_delta<7><<<grid, block, 0, stream>>>(seed, pos_base, N, M, delta, flagbits, zero, zero_words);
         break;
     default:
         return hipErrorInvalidValue;
@@ -678,7 +714,7 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
 
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, bool counted, uint32_t *slots,
                            uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,
-                           BatchCtl *ctl, hipStream_t stream) {
+                           BatchCtl *ctl, const Shadow16Params &s16, hipStream_t stream) {
     const uint32_t nb = (B + 1023) / 1024;
     if (!counted)
         k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
@@ -686,8 +722,15 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
                                                     compact64, ctl);
     if (shadow_compact && compact64) {
         const uint64_t threads = (uint64_t)B * (uint64_t)maxm * 12u; // capacity; lanes beyond num_hyp return at once
-        k_gather_models<<<dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream>>>(ctl, slots, models,
-                                                                                          shadow_compact, compact64);
+        const uint32_t gblocks = (uint32_t)((threads + 255) / 256);
+        if (s16.out) {
+            const uint32_t cap8 = (uint32_t)(((uint64_t)B * (uint64_t)maxm + 7u) & ~7ull);
+            k_gather_shadow16<<<dim3(gblocks + (cap8 + 255) / 256), dim3(256), 0, stream>>>(
+                ctl, slots, models, shadow_compact, compact64, gblocks, cap8, s16.g16, s16.c16, s16.thr,
+                static_cast<uint2 *>(s16.out));
+        } else {
+            k_gather_models<<<dim3(gblocks), dim3(256), 0, stream>>>(ctl, slots, models, shadow_compact, compact64);
+        }
     }
     return hipGetLastError();
 }

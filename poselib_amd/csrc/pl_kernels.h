@@ -41,6 +41,7 @@ struct GenerateArgs {
     uint32_t *num_models;      // [num_iters]
     int32_t real_focal_check;  // fundamental only
     uint32_t *blk_tot = nullptr; // optional, zeroed: models per block of 1024 iterations, accumulated by the generator
+    uint32_t *blk_nan = nullptr; // optional, zeroed: NaN models per block of 1024 iterations (statistics)
     void *stage = nullptr;     // relative pose: workspace of generate_stage_bytes(); nullptr = single-kernel generator
 };
 
@@ -79,6 +80,8 @@ struct LMTask {
                            // threshold; skip the refinement when <= 5 survive (relative_pose.cc:62-86)
     const uint8_t *mask;   // optional inlier mask (final polish on inliers); nullptr = all points
     uint8_t *scratch;      // n bytes, used by the prefilter
+    const double *record_in; // k_lm: the seed's model record (kept when the refinement is skipped) ...
+    double *record_out;      // ... and where the refined model's record goes (device memory); nullptr: no record
     // outputs
     uint32_t iterations, skipped;
     double cost, initial_cost;
@@ -91,7 +94,8 @@ struct BatchCtl {
     uint32_t orbit_error; // sampler position window too small / too many redraw segments
     uint32_t gen_overflow; // an iteration produced more models than slots_per_iter
     uint64_t pos_after;   // draws consumed after the batch's last iteration
-    uint32_t nan_hyp;     // hypotheses of the batch with a NaN entry (k_gather_models; the scorers skip them: no inliers)
+    uint32_t nan_hyp;     // hypotheses of the batch with a NaN entry (counted by the generators, summed by k_compact2;
+                          // the scorers skip them: no inliers)
     uint32_t pad;
 };
 struct RecordMeta {
@@ -114,6 +118,8 @@ struct SeqScoreArgs {
     double *host_score;
     RecordMeta *host_cand;  // candidate mode: pinned mirror of the first host_cap candidates
     uint32_t host_cap;
+    const BatchCtl *ctl_src = nullptr; // optional: the batch's control block, final when this kernel starts, is copied
+    BatchCtl *ctl_host = nullptr;      // to pinned host memory by the kernel itself (no copy dispatch)
 };
 hipError_t launch_score_seq(int est, const SeqScoreArgs &a, hipStream_t stream);
 
@@ -156,17 +162,27 @@ uint32_t score_chunks(int est, uint32_t n_points, bool prefilter);
 hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream);
 // num_models[iters] -> slots (compact list of record indices in (iteration, model) order) + count
 hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
+// host_mask (pinned, device-mapped; may be null): the kernel writes a second copy there itself - no copy dispatch
 hipError_t launch_mask(int est, const PointSet &pts, const double *model, double thr2, uint8_t *mask,
-                       hipStream_t stream);
+                       uint8_t *host_mask, hipStream_t stream);
 
 // ---- device-side bookkeeping (pipeline.hip) ----
+// zero_words: 32-bit words starting at `ctl` (control block + the generators' per-block model counts) that the first
+// kernel zeroes itself (0: the caller has done it)
 hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t B, uint32_t M,
                                    uint8_t *delta, uint64_t *flagbits /* >= ceil(M / 64) words */, uint32_t *positions,
-                                   BatchCtl *ctl, hipStream_t stream);
+                                   BatchCtl *ctl, uint32_t zero_words, hipStream_t stream);
 // counted: blk_tot already holds the per-block model counts (GenerateArgs.blk_tot); otherwise they are counted first
+// shadow16 != nullptr: the fp16 operand blocks of k_score_mfma are built in the same launch as the hypothesis-ordered
+// copies (Shadow16Params; see k_shadow16)
+struct Shadow16Params {
+    void *out = nullptr;
+    float g16 = 0.f, c16 = 0.f, thr = 0.f;
+};
+// blk_tot is followed by the generators' NaN-model table of the same length (nb = ceil(B / 1024) entries each)
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, bool counted, uint32_t *slots,
                            uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,
-                           BatchCtl *ctl, hipStream_t stream);
+                           BatchCtl *ctl, const Shadow16Params &s16, hipStream_t stream);
 // the two halves on their own (diagnostic entry pl_debug_score_stream): hypothesis-ordered copies of records that already
 // sit in `models` in list order `slots`, and the chunk partials -> (count, score) without the record scan
 hipError_t launch_gather_models(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t capacity,

@@ -246,7 +246,7 @@ PL_HD float model_scale_f32(const double *M9) {
     return (float)m * 1.000001f + 1e-30f;
 }
 
-PL_HD void store_shadow(double *rec) {
+PL_HD bool store_shadow(double *rec) { // returns the record's NaN flag
     float *f = reinterpret_cast<float *>(rec + kShadowOff);
     for (int i = 0; i < 9; ++i)
         f[i] = (float)rec[kMatOff + i];
@@ -267,12 +267,13 @@ PL_HD void store_shadow(double *rec) {
     f[13] = any_nan ? 1.f : 0.f;
     f[14] = model_scale_f32(rec + kMatOff);
     f[15] = 0.f;
+    return any_nan;
 }
 
 // Write a pose hypothesis (rotation given as matrix from a solver) into a 16-double record:
 // R -> q (normalised) -> R(q), exactly the round trip CameraPose(R,t) + pose.R() makes in the
 // reference (camera_pose.h:51, utils.cc:40).  `essential` selects E=[t]xR(q) for the matrix slot.
-PL_HD void store_pose_model(double *rec, const Mat3 &Rsolver, Vec3 t, bool essential) {
+PL_HD bool store_pose_model(double *rec, const Mat3 &Rsolver, Vec3 t, bool essential) {
     const Quat q = rotmat_to_quat(Rsolver);
     const Mat3 Rq = quat_to_rotmat(q);
     rec[0] = q.w, rec[1] = q.x, rec[2] = q.y, rec[3] = q.z;
@@ -280,23 +281,23 @@ PL_HD void store_pose_model(double *rec, const Mat3 &Rsolver, Vec3 t, bool essen
     const Mat3 M = essential ? essential_from_motion(Rq, t) : Rq;
     for (int i = 0; i < 9; ++i)
         rec[kMatOff + i] = M.m[i];
-    store_shadow(rec);
+    return store_shadow(rec);
 }
-PL_HD void store_pose_model_q(double *rec, Quat q, Vec3 t, bool essential) {
+PL_HD bool store_pose_model_q(double *rec, Quat q, Vec3 t, bool essential) {
     const Mat3 Rq = quat_to_rotmat(q);
     rec[0] = q.w, rec[1] = q.x, rec[2] = q.y, rec[3] = q.z;
     rec[4] = t.x, rec[5] = t.y, rec[6] = t.z;
     const Mat3 M = essential ? essential_from_motion(Rq, t) : Rq;
     for (int i = 0; i < 9; ++i)
         rec[kMatOff + i] = M.m[i];
-    store_shadow(rec);
+    return store_shadow(rec);
 }
-PL_HD void store_matrix_model(double *rec, const Mat3 &M) {
+PL_HD bool store_matrix_model(double *rec, const Mat3 &M) {
     for (int i = 0; i < 7; ++i)
         rec[i] = 0.0;
     for (int i = 0; i < 9; ++i)
         rec[kMatOff + i] = M.m[i];
-    store_shadow(rec);
+    return store_shadow(rec);
 }
 
 } // namespace pl
