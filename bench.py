@@ -45,11 +45,6 @@ import sys
 # default workload: 4 queues 3.4e8, 8 queues 3.9e8, 12 queues 4.0e8, 16 queues 4.2e8 hypotheses/s - two streams sharing
 # a queue block each other behind their long single-CU kernels (LM, sampler orbit).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-# throughput benchmark: every LO task on one workgroup (k_lm) instead of spread over several with one launch per LM
-# iteration (k_lm2, the library's default for large homography / fundamental problems: 1.5-2.2x shorter single
-# problems, but -10..-25 % throughput with 16 problems in flight).  No effect on the primary workload.
-if not ("--streams" in sys.argv and sys.argv[sys.argv.index("--streams") + 1:][:1] == ["1"]):  # (one at a time: keep it)
-    os.environ.setdefault("POSELIB_AMD_LATENCY_MODE", "0")
 import time
 
 import numpy as np

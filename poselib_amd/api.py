@@ -246,6 +246,72 @@ def _estimate_matrix(fn, kind, points2D_1, points2D_2, opt, initial):
     return M.reshape(3, 3).T.copy(), _info(st, inl[:n])
 
 
+class Batch:
+    """An array of pl_batch_item descriptors (include/poselib_amd.h) marshalled once: `run()` is the C-ABI call
+    pl_estimate_batch and nothing else (what bench_batch.py times), `results()` turns the outputs into the objects the
+    single-problem functions return."""
+
+    def __init__(self, problems):
+        kinds = {"abs": KIND_ABS, "rel": KIND_REL, "fund": KIND_FUND, "hom": KIND_HOM}
+        self.items = (L.BatchItem * len(problems))()
+        self.keep = []
+        for it, pr in zip(self.items, problems):
+            kind = kinds[pr[0]]
+            it.kind = kind
+            if kind == KIND_ABS:
+                _, a, b, cam, opt = pr
+                a, b = _pts(a, 2), _pts(b, 3)
+                cam = _as_camera(cam)
+                c1, c2 = cam._c(), None
+                model = _cpose(CameraPose())
+            elif kind == KIND_REL:
+                _, a, b, cam1, cam2, opt = pr
+                a, b = _pts(a, 2), _pts(b, 2)
+                cam = None
+                c1, c2 = _as_camera(cam1)._c(), _as_camera(cam2)._c()
+                model = _cpose(CameraPose())
+            else:
+                _, a, b, opt = pr
+                a, b = _pts(a, 2), _pts(b, 2)
+                cam, c1, c2 = None, None, None
+                model = np.ascontiguousarray(np.eye(3).reshape(9))
+            o = _robust_options(opt, kind, False)
+            n = a.shape[0]
+            inl = np.zeros(max(n, 1), dtype=np.uint8)
+            st = L.RansacStats()
+            it.a, it.b, it.n = _ptr(a), _ptr(b), n
+            it.opt = C.pointer(o)
+            it.camera1 = C.pointer(c1) if c1 is not None else None
+            it.camera2 = C.pointer(c2) if c2 is not None else None
+            it.model = C.cast(C.pointer(model), C.c_void_p) if kind in (KIND_ABS, KIND_REL) else _ptr(model)
+            it.inliers = _ptr(inl)
+            it.stats = C.pointer(st)
+            self.keep.append((kind, a, b, o, cam, c1, c2, model, inl, st, n))
+
+    def run(self, max_in_flight=8):
+        L.check(L.lib().pl_estimate_batch(self.items, C.c_size_t(len(self.keep)), C.c_int(int(max_in_flight))))
+
+    def stats(self):
+        """(iterations, num_inliers, hypotheses) arrays without building the per-problem Python objects"""
+        it = np.array([k[9].iterations for k in self.keep], dtype=np.int64)
+        ni = np.array([k[9].num_inliers for k in self.keep], dtype=np.int64)
+        hy = np.array([k[9].hypotheses for k in self.keep], dtype=np.int64)
+        return it, ni, hy
+
+    def results(self):
+        out = []
+        for kind, a, b, o, cam, c1, c2, model, inl, st, n in self.keep:
+            info = _info(st, inl[:n])
+            if kind == KIND_ABS:
+                out_cam = Camera(cam.model_id, list(c1.params[: c1.num_params]), cam.width, cam.height)
+                out.append((Image(_pypose(model), out_cam), info))
+            elif kind == KIND_REL:
+                out.append((_pypose(model), info))
+            else:
+                out.append((model.reshape(3, 3).T.copy(), info))
+        return out
+
+
 def estimate_batch(problems, max_in_flight=8):
     """Many independent problems in one call (include/poselib_amd.h pl_estimate_batch; BASELINE config 4).
 
@@ -253,55 +319,12 @@ def estimate_batch(problems, max_in_flight=8):
         ("abs", points2D, points3D, camera, opt)            -> (Image, info)
         ("rel", points2D_1, points2D_2, camera1, camera2, opt) -> (CameraPose, info)
         ("fund", points2D_1, points2D_2, opt) / ("hom", points2D_1, points2D_2, opt) -> (3x3 ndarray, info)
-    Returns the list of results in the same order.  `max_in_flight` problems are processed concurrently, each on
-    its own HIP stream (host threads inside the library, no GIL involved)."""
-    kinds = {"abs": KIND_ABS, "rel": KIND_REL, "fund": KIND_FUND, "hom": KIND_HOM}
-    items = (L.BatchItem * len(problems))()
-    keep = []
-    for it, pr in zip(items, problems):
-        kind = kinds[pr[0]]
-        it.kind = kind
-        if kind == KIND_ABS:
-            _, a, b, cam, opt = pr
-            a, b = _pts(a, 2), _pts(b, 3)
-            cam = _as_camera(cam)
-            c1, c2 = cam._c(), None
-            model = _cpose(CameraPose())
-        elif kind == KIND_REL:
-            _, a, b, cam1, cam2, opt = pr
-            a, b = _pts(a, 2), _pts(b, 2)
-            cam = None
-            c1, c2 = _as_camera(cam1)._c(), _as_camera(cam2)._c()
-            model = _cpose(CameraPose())
-        else:
-            _, a, b, opt = pr
-            a, b = _pts(a, 2), _pts(b, 2)
-            cam, c1, c2 = None, None, None
-            model = np.ascontiguousarray(np.eye(3).reshape(9))
-        o = _robust_options(opt, kind, False)
-        n = a.shape[0]
-        inl = np.zeros(max(n, 1), dtype=np.uint8)
-        st = L.RansacStats()
-        it.a, it.b, it.n = _ptr(a), _ptr(b), n
-        it.opt = C.pointer(o)
-        it.camera1 = C.pointer(c1) if c1 is not None else None
-        it.camera2 = C.pointer(c2) if c2 is not None else None
-        it.model = C.cast(C.pointer(model), C.c_void_p) if kind in (KIND_ABS, KIND_REL) else _ptr(model)
-        it.inliers = _ptr(inl)
-        it.stats = C.pointer(st)
-        keep.append((kind, a, b, o, cam, c1, c2, model, inl, st, n))
-    L.check(L.lib().pl_estimate_batch(items, C.c_size_t(len(problems)), C.c_int(int(max_in_flight))))
-    out = []
-    for kind, a, b, o, cam, c1, c2, model, inl, st, n in keep:
-        info = _info(st, inl[:n])
-        if kind == KIND_ABS:
-            out_cam = Camera(cam.model_id, list(c1.params[: c1.num_params]), cam.width, cam.height)
-            out.append((Image(_pypose(model), out_cam), info))
-        elif kind == KIND_REL:
-            out.append((_pypose(model), info))
-        else:
-            out.append((model.reshape(3, 3).T.copy(), info))
-    return out
+    Returns the list of results in the same order.  Problems of the same kind advance in groups through ONE launch
+    sequence (the problem index is a grid dimension of every kernel); `max_in_flight` host threads inside the library
+    work on groups concurrently, each with its own HIP stream."""
+    b = Batch(problems)
+    b.run(max_in_flight)
+    return b.results()
 
 
 def estimate_fundamental(points2D_1, points2D_2, opt=None, initial_F=None):

@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -569,16 +570,18 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     HIP_TRY(c->h_tasks.ensure(stage_bytes));
     HIP_TRY(c->lm_scratch.ensure((size_t)p->n * nj + 16));
     HIP_TRY(c->lm_records.ensure(sizeof(double) * kModelStride * nj));
-    // Large point sets with 6..8 parameters saturate the single CU k_lm gives a task: spread every task over several
-    // workgroups (k_lm2, one launch per LM iteration).  Only for short, bounded runs (the LO: 25 iterations) - k_lm2
-    // costs max_iterations + 2 launches whatever the iteration count turns out to be.  Measured on MI355X at
-    // N = 10^4: homography problems 2.2x, fundamental 1.5x shorter when the device serves one problem at a time; with
-    // 16 problems in flight the long single-CU kernels overlap anyway and the extra launches cost 4..8 % throughput.
-    // The two kernels sum the normal equations in different orders, so the choice must not depend on load: it is a
-    // process-wide setting, on by default, POSELIB_AMD_LATENCY_MODE=0 switches it off.
+    // Large point sets with 6..8 parameters saturate the single CU k_lm gives a task; k_lm2 spreads every task over
+    // several workgroups (one launch per LM iteration; only for short, bounded runs - the LO: 25 iterations - since it
+    // costs max_iterations + 2 launches whatever the iteration count turns out to be).  Measured on MI355X at N = 10^4:
+    // homography problems 2.2x, fundamental 1.5x shorter when the device serves one problem at a time; with many
+    // problems in flight the long single-CU kernels overlap anyway and the extra launches cost throughput.  The two
+    // kernels sum the normal equations in different orders (results agree to rounding, not to the bit), so the choice
+    // must not depend on load or on the entry point: it is a process-wide setting, OFF by default - the grouped launches
+    // of pl_estimate_batch refine with k_lm, and a problem gives the same bits whichever way it is submitted -,
+    // POSELIB_AMD_LATENCY_MODE=1 switches it on for single large two-view problems.
     static const bool latency_mode = [] {
         const char *e = std::getenv("POSELIB_AMD_LATENCY_MODE");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     uint32_t max_it = 0;
     bool same_it = true;
@@ -598,6 +601,7 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     for (uint32_t j = 0; j < nj; ++j) {
         LMTask &t = ht[j];
         std::memset(&t, 0, sizeof(t));
+        t.pts = p->ps;
         lm_params_from_record(p->kind, jobs[j].record_in, t.params);
         t.opt = jobs[j].opt;
         t.cam = jobs[j].cam;
@@ -1314,31 +1318,43 @@ struct RansacRun {
         return PL_OK;
     }
 
+    // ---- the local optimisations the batch's improving hypotheses trigger (ransac_impl.h:127-131: the last improving
+    // hypothesis of an iteration seeds one) ----
+    void make_jobs(const Batch &b) {
+        const uint32_t ni = (uint32_t)imps.size();
+        jobs.clear();
+        for (uint32_t a = 0; a < ni; ++a)
+            if (imps[a].lo_seed) {
+                imps[a].job = (int)jobs.size();
+                jobs.push_back(make_lo_job(b.h_rec + (size_t)imps[a].gather * kModelStride));
+            }
+    }
+
     // ---- batched local optimisations of the batch, then the replay of the sequential loop over it ----
     int refine_and_replay(Batch &b) {
+        // ---- device: every triggered LO of the batch as one batched launch, then re-scored ----
+        make_jobs(b);
+        if (!jobs.empty()) {
+            const int rc = sh ? run_refinements_sharded() : run_refinements(c, p, jobs, true, thr2);
+            if (rc != PL_OK)
+                return rc;
+        }
+        return replay(b, nullptr);
+    }
+
+    // ---- host pass 2: replay the sequential loop over this batch (ransac_impl.h:180-188) with the refined and
+    // re-scored models in `jobs`.  host_offsets: pinned mirror of the per-iteration hypothesis offsets of the batch (group
+    // launches write one); nullptr: the one entry that is needed is fetched from the device ----
+    int replay(Batch &b, const uint32_t *host_offsets) {
         const uint32_t B = b.B, lo_g = b.lo_g, hi_g = b.hi_g, Bl = b.Bl;
         (void)B, (void)lo_g, (void)hi_g, (void)Bl;
         const uint32_t H = b.H, H_local = b.H_local;
         const double *const h_rec = b.h_rec;
         const uint64_t pos_after = b.pos_after;
         st->iterations_evaluated += B;
-
-        // ---- device: every triggered LO of the batch as one batched launch, then re-scored ----
         const uint32_t ni = (uint32_t)imps.size();
-        jobs.clear();
-        for (uint32_t a = 0; a < ni; ++a)
-            if (imps[a].lo_seed) {
-                imps[a].job = (int)jobs.size();
-                jobs.push_back(make_lo_job(h_rec + (size_t)imps[a].gather * kModelStride));
-            }
-        if (!jobs.empty()) {
-            const int rc = sh ? run_refinements_sharded() : run_refinements(c, p, jobs, true, thr2);
-            if (rc != PL_OK)
-                return rc;
-        }
 
-        // ---- host pass 2: replay the sequential loop over this batch (ransac_impl.h:180-188).  The stop
-        // rule can only change at LO events, so the replay hops from event to event. ----
+        // The stop rule can only change at LO events, so the replay hops from event to event.
         uint64_t cursor = it;          // next iteration whose stop check has not been made yet
         uint64_t stop_at = it + B;     // first iteration NOT replayed
         for (uint32_t a = 0; a < ni; ++a) {
@@ -1370,9 +1386,13 @@ struct RansacRun {
             if (stop_at >= it + hi_g) {
                 upto = H_local;
             } else if (stop_at > it + lo_g) {
-                HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it - lo_g), sizeof(uint32_t),
-                                       hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (host_offsets) {
+                    upto = host_offsets[stop_at - it - lo_g];
+                } else {
+                    HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it - lo_g), sizeof(uint32_t),
+                                           hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                }
             }
             uint64_t total = upto;
             if (sh) { // sum of the ranks' shares (8 bytes each; once per run)
@@ -1392,6 +1412,37 @@ struct RansacRun {
         return PL_OK;
     }
 
+    // ---- size of the next batch (false: the loop is over) ----
+    uint64_t grow = 0;
+    void begin_loop() {
+        // batch capacity: bounded by the scratch the model records need
+        grow = std::max<uint64_t>(ro.min_iterations + 2, 512);
+        grow = (grow + 63) / 64 * 64;
+        if (prosac)
+            prosac_sampler.init(ro.seed, N, K, ro.max_prosac_iterations);
+    }
+    bool plan_batch(Batch &b) {
+        if (stopped || it >= ro.max_iterations)
+            return false;
+        if (it > ro.min_iterations && it > dyn_max) { // stop rule at the top of the next iteration (:182)
+            stopped = true;
+            return false;
+        }
+        // the loop cannot stop before max(min_iterations, dynamic_max_iter) + 1 iterations
+        uint64_t needed = std::max<uint64_t>(ro.min_iterations, dyn_max) + 1;
+        needed = std::min<uint64_t>(needed, ro.max_iterations);
+        needed = (needed > it) ? needed - it : 1;
+        const uint32_t cap = std::min<uint32_t>(131072u, 1048576u / (uint32_t)MAXM); // scratch size (<= 200 MB of records)
+        b = Batch();
+        b.B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
+        grow = std::min<uint64_t>(grow * 2, 131072u);
+        // this rank's share of the batch (the whole batch on a single device)
+        b.lo_g = (uint32_t)((uint64_t)b.B * grank / G);
+        b.hi_g = (uint32_t)((uint64_t)b.B * (grank + 1) / G);
+        b.Bl = b.hi_g - b.lo_g;
+        return true;
+    }
+
     int run() {
         std::memset(st, 0, sizeof(*st));
         st->model_score = std::numeric_limits<double>::max();
@@ -1404,28 +1455,9 @@ struct RansacRun {
                 if (rc != PL_OK)
                     return rc;
             }
-            // batch capacity: bounded by the scratch the model records need
-            uint64_t grow = std::max<uint64_t>(ro.min_iterations + 2, 512);
-            grow = (grow + 63) / 64 * 64;
-            if (prosac)
-                prosac_sampler.init(ro.seed, N, K, ro.max_prosac_iterations);
-            while (!stopped && it < ro.max_iterations) {
-                if (it > ro.min_iterations && it > dyn_max) { // stop rule at the top of the next iteration (:182)
-                    stopped = true;
-                    break;
-                }
-                // the loop cannot stop before max(min_iterations, dynamic_max_iter) + 1 iterations
-                uint64_t needed = std::max<uint64_t>(ro.min_iterations, dyn_max) + 1;
-                needed = std::min<uint64_t>(needed, ro.max_iterations);
-                needed = (needed > it) ? needed - it : 1;
-                const uint32_t cap = std::min<uint32_t>(131072u, 1048576u / (uint32_t)MAXM); // scratch size (<= 200 MB of records)
-                Batch b;
-                b.B = (uint32_t)std::min<uint64_t>({needed, (uint64_t)cap, grow, ro.max_iterations - it});
-                grow = std::min<uint64_t>(grow * 2, 131072u);
-                // this rank's share of the batch (the whole batch on a single device)
-                b.lo_g = (uint32_t)((uint64_t)b.B * grank / G);
-                b.hi_g = (uint32_t)((uint64_t)b.B * (grank + 1) / G);
-                b.Bl = b.hi_g - b.lo_g;
+            begin_loop();
+            Batch b;
+            while (plan_batch(b)) {
                 int rc = enqueue_batch(b);
                 if (rc == PL_OK)
                     rc = collect_improving(b);
@@ -1749,6 +1781,8 @@ double normalization_of(const double *x1, const double *x2, size_t n, bool centr
     pa.scale = scale;
     return scale;
 }
+
+#include "driver_group.inc"
 
 } // namespace
 
@@ -2379,48 +2413,33 @@ struct BatchPool {
     std::mutex mu;
     std::condition_variable wake, done;
     std::vector<std::thread> threads;
-    // current job
-    pl_batch_item *items = nullptr;
-    size_t count = 0;
+    // current batch: a list of jobs (a group of problems, or one problem on its own)
+    std::vector<std::function<void()>> *jobs = nullptr;
     std::atomic<size_t> next{0};
     int device = 0;
     uint64_t generation = 0;
-    int wanted = 0;   // workers that should take part in the current job
-    int joined = 0;   // workers that have picked the current job up
-    int running = 0;  // workers still inside the current job
+    int wanted = 0;   // workers that should take part in the current batch
+    int joined = 0;   // workers that have picked the current batch up
+    int running = 0;  // workers still inside the current batch
 
-    static int run_item(pl_batch_item &it) {
-        switch (it.kind) {
-        case EST_ABS:
-            return pl_estimate_absolute_pose(it.a, it.b, it.n, it.opt, it.camera1, static_cast<pl_camera_pose *>(it.model),
-                                             it.inliers, it.stats);
-        case EST_REL:
-            return pl_estimate_relative_pose(it.a, it.b, it.n, it.camera1, it.camera2, it.opt,
-                                             static_cast<pl_camera_pose *>(it.model), it.inliers, it.stats);
-        case EST_FUND:
-            return pl_estimate_fundamental(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
-        case EST_HOM:
-            return pl_estimate_homography(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
-        default:
-            return fail(PL_ERR_INVALID, "pl_batch_item.kind must be 0..3");
-        }
-    }
     void worker() {
         uint64_t seen = 0;
         for (;;) {
+            std::vector<std::function<void()>> *mine;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 wake.wait(lk, [&] { return generation != seen && joined < wanted; });
                 seen = generation;
                 joined++;
                 running++;
+                mine = jobs;
             }
             g_requested_device = device;
             for (;;) {
                 const size_t i = next.fetch_add(1);
-                if (i >= count)
+                if (i >= mine->size())
                     break;
-                items[i].status = run_item(items[i]);
+                (*mine)[i]();
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -2429,7 +2448,7 @@ struct BatchPool {
             }
         }
     }
-    int run(pl_batch_item *its, size_t n, int in_flight, int dev) {
+    int run(std::vector<std::function<void()>> &js, int in_flight, int dev) {
         // `mu` alone is not enough: done.wait() releases it, and a second caller would overwrite the job state while
         // the first batch's workers are still running
         std::lock_guard<std::mutex> one_batch(run_mu);
@@ -2438,13 +2457,13 @@ struct BatchPool {
             threads.emplace_back([this] { worker(); });
             threads.back().detach();
         }
-        items = its, count = n, device = dev;
+        jobs = &js, device = dev;
         next.store(0);
         wanted = in_flight, joined = 0, running = 0;
         generation++;
         wake.notify_all();
         done.wait(lk, [&] { return joined == wanted && running == 0; });
-        items = nullptr;
+        jobs = nullptr;
         wanted = 0;
         return PL_OK;
     }
@@ -2452,6 +2471,39 @@ struct BatchPool {
 static BatchPool &batch_pool_instance() {
     static BatchPool *pool = new BatchPool(); // never destroyed: its detached workers may outlive static destructors
     return *pool;
+}
+
+int run_item(pl_batch_item &it) {
+    switch (it.kind) {
+    case EST_ABS:
+        return pl_estimate_absolute_pose(it.a, it.b, it.n, it.opt, it.camera1, static_cast<pl_camera_pose *>(it.model),
+                                         it.inliers, it.stats);
+    case EST_REL:
+        return pl_estimate_relative_pose(it.a, it.b, it.n, it.camera1, it.camera2, it.opt,
+                                         static_cast<pl_camera_pose *>(it.model), it.inliers, it.stats);
+    case EST_FUND:
+        return pl_estimate_fundamental(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
+    case EST_HOM:
+        return pl_estimate_homography(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
+    default:
+        return fail(PL_ERR_INVALID, "pl_batch_item.kind must be 0..3");
+    }
+}
+
+// one group of same-kind problems through the group launches; whatever it could not finish goes through the
+// single-problem entry points
+void run_group_job(std::vector<GroupItem> &items) {
+    Context *c;
+    int rc = get_context(&c);
+    if (rc == PL_OK) {
+        for (GroupItem &g : items)
+            group_prepare_item(g);
+        rc = run_group(c, items.data(), (uint32_t)items.size());
+    }
+    for (GroupItem &g : items) {
+        if (rc != PL_OK || g.fallback)
+            g.item->status = run_item(*g.item);
+    }
 }
 } // namespace
 
@@ -2464,9 +2516,39 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     int rc = get_context(&c); // fails loudly without a HIP device, and pins the device for the workers
     if (rc != PL_OK)
         return rc;
+    static const bool no_groups = std::getenv("POSELIB_AMD_NO_GROUPS") != nullptr; // diagnostic: every item on its own
+    // problems the group launches cover, by kind and in descending size (neighbours in a group then have similar
+    // grids); everything else is a job of its own
+    std::vector<size_t> by_kind[4], solo;
+    std::vector<std::function<void()>> jobs;
+    for (size_t i = 0; i < count; ++i) {
+        items[i].status = PL_OK;
+        if (!no_groups && group_eligible(items[i]))
+            by_kind[items[i].kind].push_back(i);
+        else
+            solo.push_back(i);
+    }
+    std::vector<std::vector<GroupItem>> groups;
+    for (int k = 0; k < 4; ++k) {
+        std::vector<size_t> &v = by_kind[k];
+        std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].n > items[b].n; });
+        for (size_t at = 0; at < v.size(); at += kGroupMax) {
+            groups.emplace_back();
+            for (size_t j = at; j < std::min(v.size(), at + kGroupMax); ++j) {
+                GroupItem g;
+                g.item = &items[v[j]];
+                g.kind = k;
+                groups.back().push_back(g);
+            }
+        }
+    }
+    for (auto &grp : groups) // (the long jobs first)
+        jobs.emplace_back([&grp] { run_group_job(grp); });
+    for (size_t i : solo)
+        jobs.emplace_back([items, i] { items[i].status = run_item(items[i]); });
     int w = max_in_flight <= 0 ? 8 : std::min(max_in_flight, 64);
-    w = (int)std::min<size_t>((size_t)w, count);
-    batch_pool_instance().run(items, count, w, g_requested_device);
+    w = (int)std::min<size_t>((size_t)w, jobs.size());
+    batch_pool_instance().run(jobs, w, g_requested_device);
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
             return fail(items[i].status, ("pl_estimate_batch: item " + std::to_string(i) + " failed").c_str());

@@ -175,6 +175,16 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs
     count_models_of_wave(g, it, n, n_nan); // one call site: the lanes past the last iteration take part with n = 0
 }
 
+template <int EST> __global__ __launch_bounds__(64) void k_generate_g(const GroupArgs *ga) {
+    const GroupArgs &gg = ga[blockIdx.z];
+    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
+        return;
+    const GenerateArgs &g = gg.gen;
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    uint32_t n_nan = 0;
+    const uint32_t n = (it < g.num_iters) ? generate_one<EST>(g, it, n_nan) : 0u;
+    count_models_of_wave(g, it, n, n_nan);
+}
 
 // ---- 5-point generator in three stages (relative pose) -------------------------------------------------------------
 // One lane per iteration in every stage; the stages hand their results over in a structure-of-arrays workspace
@@ -196,7 +206,7 @@ template <int K> __device__ __forceinline__ void sample_of_iteration(const Gener
     }
 }
 
-__global__ __launch_bounds__(64) void k_rel_front(GenerateArgs g, double *stage, uint32_t cap) {
+__device__ __forceinline__ void rel_front_body(const GenerateArgs &g, double *stage, uint32_t cap) {
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     if (it >= g.num_iters)
         return;
@@ -220,6 +230,13 @@ __global__ __launch_bounds__(64) void k_rel_front(GenerateArgs g, double *stage,
         for (int k = 0; k < 13; ++k)
             saz[(size_t)(i * 13 + k) * cap + it] = Az[i][k];
 }
+__global__ __launch_bounds__(64) void k_rel_front(GenerateArgs g, double *stage, uint32_t cap) { rel_front_body(g, stage, cap); }
+__global__ __launch_bounds__(64) void k_rel_front_g(const GroupArgs *ga) {
+    const GroupArgs &gg = ga[blockIdx.z];
+    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
+        return;
+    rel_front_body(gg.gen, static_cast<double *>(gg.gen.stage), gg.gen.num_iters);
+}
 
 struct SturmWorkDev { // deferred halves: one column per lane of [slot][64] LDS arrays; leaves: the workspace
     double *sa, *sb;  // LDS
@@ -232,7 +249,7 @@ struct SturmWorkDev { // deferred halves: one column per lane of [slot][64] LDS 
     __device__ void leaf_get(int i, double &a, double &b) const { a = leaves[(size_t)(2 * i) * cap], b = leaves[(size_t)(2 * i + 1) * cap]; }
 };
 
-__global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *stage, uint32_t cap, uint32_t *nroots_out) {
+__device__ __forceinline__ void rel_roots_body(uint32_t num_iters, double *stage, uint32_t cap, uint32_t *nroots_out) {
     __shared__ double s_stack_a[kSturmSlots][64], s_stack_b[kSturmSlots][64];
     __shared__ unsigned s_stack_i[kSturmSlots][64];
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
@@ -257,6 +274,17 @@ __global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *st
         if (r < n)
             sroots[(size_t)r * cap + it] = roots[r];
     nroots_out[it] = (uint32_t)n;
+}
+__global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *stage, uint32_t cap, uint32_t *nroots_out) {
+    rel_roots_body(num_iters, stage, cap, nroots_out);
+}
+__global__ __launch_bounds__(64) void k_rel_roots_g(const GroupArgs *ga) {
+    const GroupArgs &gg = ga[blockIdx.z];
+    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
+        return;
+    double *stage = static_cast<double *>(gg.gen.stage);
+    rel_roots_body(gg.gen.num_iters, stage, gg.gen.num_iters,
+                   reinterpret_cast<uint32_t *>(stage + rel_stage_doubles(gg.gen.num_iters)));
 }
 
 __device__ __forceinline__ uint32_t rel_poses_one(const GenerateArgs &g, const double *stage, uint32_t cap, const uint32_t *nroots_in,
@@ -306,6 +334,20 @@ __global__ __launch_bounds__(64) void k_rel_poses(GenerateArgs g, const double *
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     uint32_t n_nan = 0;
     const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, cap, nroots_in, it, n_nan) : 0u;
+    count_models_of_wave(g, it, n, n_nan);
+}
+__global__ __launch_bounds__(64) void k_rel_poses_g(const GroupArgs *ga) {
+    const GroupArgs &gg = ga[blockIdx.z];
+    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
+        return;
+    const GenerateArgs &g = gg.gen;
+    const double *stage = static_cast<const double *>(g.stage);
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    uint32_t n_nan = 0;
+    const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, g.num_iters,
+                                                          reinterpret_cast<const uint32_t *>(stage + rel_stage_doubles(g.num_iters)),
+                                                          it, n_nan)
+                                          : 0u;
     count_models_of_wave(g, it, n, n_nan);
 }
 
@@ -403,12 +445,12 @@ constexpr int kQueueCap = 512; // >= 63 + 64 * 6 entries can be waiting at most
 constexpr int kQueueThreads = 512; // 8 wavefronts share one chunk of correspondences
 
 template <int EST, int P>
-__global__ __launch_bounds__(kQueueThreads) void k_score_queue(PointSet pts, const float *__restrict__ shadow,
-                                                                const double *__restrict__ compact64,
-                                                                const uint32_t *__restrict__ num_hyp_ptr,
-                                                                uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
-                                                                uint32_t *__restrict__ part_count,
-                                                                double *__restrict__ part_score) {
+__device__ __forceinline__ void score_queue_body(const PointSet &pts, const float *__restrict__ shadow,
+                                                 const double *__restrict__ compact64,
+                                                 const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
+                                                 double thr2, const PrefilterArgs &pf, uint32_t *__restrict__ part_count,
+                                                 double *__restrict__ part_score, uint32_t slice, uint32_t chunk,
+                                                 uint32_t nslices) {
     constexpr int kWaves = kQueueThreads / 64;
     constexpr int ND = point_doubles(EST);
     constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 2); // bound terms per point
@@ -421,7 +463,6 @@ __global__ __launch_bounds__(kQueueThreads) void k_score_queue(PointSet pts, con
     const int lane = threadIdx.x & 63;
     // readfirstlane: the wave index is uniform, and the compiler has to know it for the scalar (s_load) shadow stream
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t chunk = blockIdx.y;
 
     float pf32[P][ND]; // the correspondences in fp32
     float bnd[P][NB];  // per-point bound terms of the pre-filter
@@ -465,8 +506,8 @@ __global__ __launch_bounds__(kQueueThreads) void k_score_queue(PointSet pts, con
     // a counter in LDS, so they finish together (a static split leaves one wave a whole group behind).  Which wave
     // evaluates a group has no influence on its results.
     const uint32_t G = (H + 63u) / 64u;
-    const uint32_t gper = (G + gridDim.x - 1) / gridDim.x;
-    const uint32_t g0 = blockIdx.x * gper;
+    const uint32_t gper = (G + nslices - 1) / nslices;
+    const uint32_t g0 = slice * gper;
     const uint32_t g1 = min(G, g0 + gper);
     auto request_ticket = [&]() -> uint32_t { // per-lane value; lane 0 holds the ticket
         uint32_t t = 0;
@@ -666,6 +707,25 @@ __global__ __launch_bounds__(kQueueThreads) void k_score_queue(PointSet pts, con
     }
 }
 
+template <int EST, int P>
+__global__ __launch_bounds__(kQueueThreads) void k_score_queue(PointSet pts, const float *__restrict__ shadow,
+                                                                const double *__restrict__ compact64,
+                                                                const uint32_t *__restrict__ num_hyp_ptr,
+                                                                uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+                                                                uint32_t *__restrict__ part_count,
+                                                                double *__restrict__ part_score) {
+    score_queue_body<EST, P>(pts, shadow, compact64, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score,
+                             blockIdx.x, blockIdx.y, gridDim.x);
+}
+template <int EST, int P> __global__ __launch_bounds__(kQueueThreads) void k_score_queue_g(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active || g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
+        return;
+    const ScoreArgs &a = g.score;
+    score_queue_body<EST, P>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity, a.thr2, a.pf, a.part_count,
+                             a.part_score, blockIdx.x, blockIdx.y, g.slices);
+}
+
 // ---- absolute pose: the pre-filter on the matrix cores ----------------------------------------------------------
 // k_score_mfma: same contract and same exact pass as k_score_queue, but pass A evaluates z = R X + t for 8 hypotheses
 // x 32 correspondences per v_mfma_f32_32x32x8_f16 (operands: k_shadow16's blocks and fp16 hi/lo pairs of the points;
@@ -688,12 +748,12 @@ constexpr int kMfmaQueueCap = 1024; // >= 63 waiting + 64 lanes * 10 point group
 constexpr int kMfmaThreads = PL_MFMA_THREADS; // 8 wavefronts share one chunk of correspondences (LDS: 20 KB shared + 2.8 KB per wave)
 
 template <int PG>
-__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma(PointSet pts, const uint2 *__restrict__ shadow16,
-                                                               const double *__restrict__ compact64,
-                                                               const uint32_t *__restrict__ num_hyp_ptr,
-                                                               uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
-                                                               uint32_t *__restrict__ part_count,
-                                                               double *__restrict__ part_score) {
+__device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2 *__restrict__ shadow16,
+                                                const double *__restrict__ compact64,
+                                                const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
+                                                double thr2, const PrefilterArgs &pf, uint32_t *__restrict__ part_count,
+                                                double *__restrict__ part_score, uint32_t slice, uint32_t chunk,
+                                                uint32_t nslices) {
     constexpr int kWaves = kMfmaThreads / 64;
     constexpr int NPW = 32 * PG; // correspondences per chunk
     __shared__ double s_pts[5][NPW];
@@ -706,7 +766,6 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int col = lane & 31, half = lane >> 5;
-    const uint32_t chunk = blockIdx.y;
 
     // ---- stationary operand: PG groups of 32 correspondences; lane l carries column l % 32 of every group ----
     // The per-point data of the PG tiles live in LDS, not in registers: the tile loop below is a real loop (an
@@ -765,8 +824,8 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
     double *const acc_s = s_acc_s[wave];
     uint32_t *const acc_c = s_acc_c[wave];
     const uint32_t G = (H + 63u) / 64u;
-    const uint32_t gper = (G + gridDim.x - 1) / gridDim.x;
-    const uint32_t g0 = blockIdx.x * gper;
+    const uint32_t gper = (G + nslices - 1) / nslices;
+    const uint32_t g0 = slice * gper;
     const uint32_t g1 = min(G, g0 + gper);
     auto request_ticket = [&]() -> uint32_t {
         uint32_t t = 0;
@@ -892,6 +951,26 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
     }
 }
 
+template <int PG>
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma(PointSet pts, const uint2 *__restrict__ shadow16,
+                                                               const double *__restrict__ compact64,
+                                                               const uint32_t *__restrict__ num_hyp_ptr,
+                                                               uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+                                                               uint32_t *__restrict__ part_count,
+                                                               double *__restrict__ part_score) {
+    score_mfma_body<PG>(pts, shadow16, compact64, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score, blockIdx.x,
+                        blockIdx.y, gridDim.x);
+}
+template <int PG>
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma_g(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active || !g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
+        return;
+    const ScoreArgs &a = g.score;
+    score_mfma_body<PG>(a.pts, static_cast<const uint2 *>(a.shadow16), a.compact64, a.num_hyp, a.hyp_capacity, a.thr2, a.pf,
+                        a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
+}
+
 // ---- MSAC score in the reference's summation order ------------------------------------------------------------------
 // The streaming scorers add the inlier residuals of a hypothesis in tree order; the reference adds them one after the
 // other in correspondence order (utils.cc:52-63).  The two sums differ in the last bits, which only matters when two
@@ -902,7 +981,7 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
 // in index order into LDS (block scan), one lane adds them sequentially.
 constexpr int kSeqThreads = 1024, kSeqPerThread = 8, kSeqChunk = kSeqThreads * kSeqPerThread; // 64 KB of LDS
 
-template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(SeqScoreArgs a) {
+template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScoreArgs &a) {
     constexpr int ND = point_doubles(EST);
     __shared__ double s_list[kSeqChunk + 32];
     __shared__ uint32_t s_wave_tot[kSeqThreads / 64], s_total;
@@ -1009,10 +1088,24 @@ template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(Se
         __syncthreads();
     }
 }
+template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq(SeqScoreArgs a) { score_seq_body<EST>(a); }
+template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq_g(const SeqScoreArgs *arr) {
+    const SeqScoreArgs &a = arr[blockIdx.z];
+    if (a.cap == 0 || a.num == nullptr)
+        return;
+    score_seq_body<EST>(a);
+}
+// (the candidate re-scoring of a group's batch step: arguments inside the GroupArgs table)
+template <int EST> __global__ __launch_bounds__(kSeqThreads) void k_score_seq_gb(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active)
+        return;
+    score_seq_body<EST>(g.seq);
+}
 
 // ------------------------------------------------------------------------------------ mask
-template <int EST> __global__ __launch_bounds__(256) void k_mask(PointSet pts, const double *model, double thr2, uint8_t *mask,
-                                                                 uint8_t *host_mask) {
+template <int EST>
+__device__ __forceinline__ void mask_body(const PointSet &pts, const double *model, double thr2, uint8_t *mask, uint8_t *host_mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pts.n)
         return;
@@ -1030,6 +1123,16 @@ template <int EST> __global__ __launch_bounds__(256) void k_mask(PointSet pts, c
     mask[i] = in ? 1 : 0;
     if (host_mask)
         host_mask[i] = in ? 1 : 0;
+}
+template <int EST> __global__ __launch_bounds__(256) void k_mask(PointSet pts, const double *model, double thr2, uint8_t *mask,
+                                                                 uint8_t *host_mask) {
+    mask_body<EST>(pts, model, thr2, mask, host_mask);
+}
+template <int EST> __global__ __launch_bounds__(256) void k_mask_g(const MaskArgs *arr) {
+    const MaskArgs &a = arr[blockIdx.z];
+    if (blockIdx.x * 256u >= a.pts.n)
+        return;
+    mask_body<EST>(a.pts, a.model, a.thr2, a.mask, a.host_mask);
 }
 
 // ------------------------------------------------------------------------------------ LM
@@ -1066,7 +1169,7 @@ template <int N> struct BlockReduce {
 // `lds_points` != 0: the correspondences are staged once into dynamic LDS (nd * n doubles) and every residual /
 // Jacobian pass reads them from there - a task makes 30..50 passes over the same points, and for the small problems
 // of the default-options regime the L2 round trip of every pass is a visible part of the 8 us an LM iteration takes.
-template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet pts_global, LMTask *tasks, int lds_points) {
+template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *tasks, uint32_t lds_bytes) {
     using R = Refiner<EST>;
     constexpr int K = R::K;
     constexpr int NT = NormalSize<K>::kTotal;
@@ -1102,7 +1205,10 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(PointSet p
         }
     };
     extern __shared__ double s_lm_points[];
+    const PointSet pts_global = T.pts;
     PointSet pts = pts_global;
+    // (tasks of several problems may share a launch: each stages its own points if they fit the launch's dynamic LDS)
+    const bool lds_points = sizeof(double) * ND * (size_t)pts_global.n <= (size_t)lds_bytes;
     if (lds_points) {
         for (int d = 0; d < ND; ++d) {
             for (uint32_t i = threadIdx.x; i < pts_global.n; i += kLMThreads)
@@ -1654,11 +1760,18 @@ hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_
 
 
 hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
+    // (every task carries its correspondences: LMTask.pts; here they all are this problem's)
+    const size_t want = sizeof(double) * point_doubles(est) * (size_t)pts.n;
+    return launch_lm_tasks(est, tasks, num_tasks, want <= 128 * 1024 ? pts.n : 0u, stream);
+}
+hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
-    // stage the points in LDS when they fit next to the kernel's static LDS (160 KB per CU, one workgroup per CU)
-    const size_t bytes = sizeof(double) * point_doubles(est) * (size_t)pts.n;
-    const bool lds = bytes <= 128 * 1024 && std::getenv("POSELIB_AMD_LM_NO_LDS") == nullptr;
+    // stage the points in LDS when they fit next to the kernel's static LDS (160 KB per CU, one workgroup per CU); tasks
+    // of a mixed launch whose points do not fit the launch's dynamic LDS read them from L2
+    const size_t want = sizeof(double) * point_doubles(est) * (size_t)max_points;
+    const size_t bytes = std::min<size_t>(want, 128 * 1024);
+    const bool lds = std::getenv("POSELIB_AMD_LM_NO_LDS") == nullptr;
     static bool attr_set[4] = {false, false, false, false};
     if (lds && bytes > 48 * 1024 && est >= 0 && est < 4 && !attr_set[est]) {
         hipError_t e = hipSuccess;
@@ -1668,7 +1781,7 @@ hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_t
             return e;
         attr_set[est] = true;
     }
-    PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), lds ? bytes : 0, stream>>>(pts, tasks, lds ? 1 : 0));
+    PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), lds ? bytes : 0, stream>>>(tasks, lds ? (uint32_t)bytes : 0u));
     return hipGetLastError();
 }
 
@@ -1699,6 +1812,81 @@ __global__ void k_select_record(const double *score_refined, double incumbent_sc
     if (threadIdx.x < kModelStride)
         out[threadIdx.x] = src[threadIdx.x];
 }
+__global__ void k_select_record_g(const SelectArgs *arr) {
+    const SelectArgs &a = arr[blockIdx.z];
+    if (!a.out)
+        return;
+    const double *src = (*a.score_refined < a.incumbent_score) ? a.rec_refined : a.rec_incumbent;
+    if (threadIdx.x < kModelStride)
+        a.out[threadIdx.x] = src[threadIdx.x];
+}
+hipError_t launch_group_select(const SelectArgs *args, uint32_t G, hipStream_t stream) {
+    if (G == 0)
+        return hipSuccess;
+    k_select_record_g<<<dim3(1, 1, G), dim3(64), 0, stream>>>(args);
+    return hipGetLastError();
+}
+hipError_t launch_group_mask(int est, const MaskArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream) {
+    if (G == 0 || max_n == 0)
+        return hipSuccess;
+    const dim3 grid((max_n + 255) / 256, 1, G), block(256);
+    PL_DISPATCH_EST(est, k_mask_g<E><<<grid, block, 0, stream>>>(args));
+    return hipGetLastError();
+}
+hipError_t launch_group_score_seq(int est, const SeqScoreArgs *args, uint32_t G, uint32_t max_cap, hipStream_t stream) {
+    if (G == 0 || max_cap == 0)
+        return hipSuccess;
+    const dim3 grid(std::min<uint32_t>(max_cap, 128u), 1, G), block(kSeqThreads);
+    PL_DISPATCH_EST(est, k_score_seq_g<E><<<grid, block, 0, stream>>>(args));
+    return hipGetLastError();
+}
+
+// ---- one batch step of a whole group of problems ----
+int group_points_per_lane(int est) { return (est == EST_REL || est == EST_FUND) ? 6 : 5; }
+
+template <int E> static hipError_t launch_group_score_est(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
+    const dim3 grid(std::max<uint32_t>(1u, d.max_slices), std::max<uint32_t>(1u, d.max_chunks), d.G);
+    if constexpr (E == EST_ABS) {
+        if (d.any_mfma)
+            k_score_mfma_g<10><<<grid, dim3(kMfmaThreads), 0, stream>>>(args);
+        if (d.any_queue)
+            k_score_queue_g<EST_ABS, 5><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
+    } else if constexpr (E == EST_HOM) {
+        k_score_queue_g<EST_HOM, 5><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
+    } else {
+        k_score_queue_g<E, 6><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
+    if (d.G == 0)
+        return hipSuccess;
+    hipError_t e = launch_group_positions(sample_size(est), args, d, stream);
+    if (e != hipSuccess)
+        return e;
+    const dim3 ggrid((d.max_B + 63) / 64, 1, d.G), gblock(64);
+    if (est == EST_REL) {
+        k_rel_front_g<<<ggrid, gblock, 0, stream>>>(args);
+        k_rel_roots_g<<<ggrid, gblock, 0, stream>>>(args);
+        k_rel_poses_g<<<ggrid, gblock, 0, stream>>>(args);
+    } else {
+        PL_DISPATCH_EST(est, k_generate_g<E><<<ggrid, gblock, 0, stream>>>(args));
+    }
+    e = launch_group_compact(args, d, stream);
+    if (e != hipSuccess)
+        return e;
+    PL_DISPATCH_EST(est, e = launch_group_score_est<E>(args, d, stream));
+    if (e != hipSuccess)
+        return e;
+    e = launch_group_finalize_records(args, d, stream);
+    if (e != hipSuccess)
+        return e;
+    const dim3 sgrid(128, 1, d.G), sblock(kSeqThreads);
+    PL_DISPATCH_EST(est, k_score_seq_gb<E><<<sgrid, sblock, 0, stream>>>(args));
+    return hipGetLastError();
+}
+
 hipError_t launch_task_records(int est, const LMTask *tasks, const double *records_in, double *records_out,
                                uint32_t num_tasks, LMTask *host_tasks, hipStream_t stream) {
     if (num_tasks == 0)

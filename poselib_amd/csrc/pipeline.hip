@@ -60,9 +60,9 @@ __device__ __forceinline__ double wscan_min(double v, int lane) {
 
 // ------------------------------------------------------------------------------------ sampler orbit
 template <int K>
-__global__ __launch_bounds__(256) void k_sample_delta(uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t M,
-                                                      uint8_t *delta, uint64_t *flagbits, uint32_t *zero,
-                                                      uint32_t zero_words) {
+__device__ __forceinline__ void sample_delta_body(uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t M,
+                                                  uint8_t *delta, uint64_t *flagbits, uint32_t *zero,
+                                                  uint32_t zero_words) {
     // the batch's control block and the generators' per-block model counts start at zero: the first kernel of the
     // batch clears them (everything that writes them is a later launch on the same stream) - no memset dispatch
     if (blockIdx.x == 0)
@@ -80,6 +80,20 @@ __global__ __launch_bounds__(256) void k_sample_delta(uint64_t seed, uint64_t po
     const unsigned long long m = __ballot(flag);
     if ((threadIdx.x & 63) == 0 && p < M)
         flagbits[p >> 6] = m;
+}
+template <int K>
+__global__ __launch_bounds__(256) void k_sample_delta(uint64_t seed, uint64_t pos_base, uint64_t N, uint32_t M,
+                                                      uint8_t *delta, uint64_t *flagbits, uint32_t *zero,
+                                                      uint32_t zero_words) {
+    sample_delta_body<K>(seed, pos_base, N, M, delta, flagbits, zero, zero_words);
+}
+// group form: problem = blockIdx.z, arguments from the group's table
+template <int K> __global__ __launch_bounds__(256) void k_sample_delta_g(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active || blockIdx.x * 256u >= ((g.samp.M + 255u) & ~255u))
+        return;
+    sample_delta_body<K>(g.samp.seed, g.samp.pos_base, g.samp.N, g.samp.M, g.samp.delta, g.samp.flagbits,
+                         reinterpret_cast<uint32_t *>(g.samp.ctl), g.samp.zero_words);
 }
 
 constexpr int kMaxSegments = 4096;
@@ -99,9 +113,8 @@ __device__ __forceinline__ uint32_t div_k(uint32_t x, int K) { // constant divis
     }
 }
 
-__global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, const uint64_t *flagbits, uint32_t M, int K,
-                                                       uint32_t B, uint64_t pos_base, uint32_t *positions,
-                                                       BatchCtl *ctl) {
+__device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const uint64_t *flagbits, uint32_t M, int K,
+                                                  uint32_t B, uint64_t pos_base, uint32_t *positions, BatchCtl *ctl) {
     __shared__ uint32_t wave_tot[16], wave_off[16];
     __shared__ uint32_t flag_pos[kMaxFlags];
     __shared__ uint8_t flag_delta[kMaxFlags];
@@ -261,6 +274,18 @@ __global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, con
         positions[i] = cur_pos + (i - cur_it) * (uint32_t)K;
     }
 }
+__global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, const uint64_t *flagbits, uint32_t M, int K,
+                                                       uint32_t B, uint64_t pos_base, uint32_t *positions,
+                                                       BatchCtl *ctl) {
+    sample_orbit_body(delta, flagbits, M, K, B, pos_base, positions, ctl);
+}
+__global__ __launch_bounds__(1024) void k_sample_orbit_g(const GroupArgs *ga, int K) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active)
+        return;
+    sample_orbit_body(g.samp.delta, g.samp.flagbits, g.samp.M, K, g.samp.B, g.samp.pos_base, g.samp.positions,
+                      g.samp.ctl);
+}
 
 // ------------------------------------------------------------------------------------ compaction
 __global__ __launch_bounds__(1024) void k_count_blocks(const uint32_t *num_models, uint32_t B, uint32_t *blk_tot) {
@@ -279,10 +304,9 @@ __global__ __launch_bounds__(1024) void k_count_blocks(const uint32_t *num_model
     }
 }
 
-__global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, uint32_t B, int maxm,
-                                                   const uint32_t *blk_tot, uint32_t *slots, uint32_t *offsets,
-                                                   const double *models, float *shadow_compact, double *compact64,
-                                                   BatchCtl *ctl) {
+__device__ __forceinline__ void compact2_body(const uint32_t *num_models, uint32_t B, int maxm,
+                                              const uint32_t *blk_tot, uint32_t *slots, uint32_t *offsets,
+                                              BatchCtl *ctl, uint32_t nblocks, uint32_t *host_offsets) {
     __shared__ uint32_t wt[16], wo[16];
     __shared__ uint32_t s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -304,11 +328,11 @@ __global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, u
             wo[w] = s;
             s += wt[w];
         }
-        if (blockIdx.x == gridDim.x - 1) {
+        if (blockIdx.x == nblocks - 1) {
             ctl->num_hyp = s_base + s;
             uint32_t nan = 0; // the generators' NaN-model counts (second table behind blk_tot; statistics)
-            const uint32_t *blk_nan = blk_tot + gridDim.x;
-            for (uint32_t j = 0; j < gridDim.x; ++j)
+            const uint32_t *blk_nan = blk_tot + nblocks;
+            for (uint32_t j = 0; j < nblocks; ++j)
                 nan += blk_nan[j];
             ctl->nan_hyp = nan;
         }
@@ -317,11 +341,28 @@ __global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, u
     if (i < B) {
         const uint32_t o = s_base + wo[wave] + inc - nm;
         offsets[i] = o;
+        if (host_offsets)
+            host_offsets[i] = o;
         for (uint32_t m = 0; m < nm; ++m) {
             const uint32_t slot = i * (uint32_t)maxm + m;
             slots[o + m] = slot;
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_compact2(const uint32_t *num_models, uint32_t B, int maxm,
+                                                   const uint32_t *blk_tot, uint32_t *slots, uint32_t *offsets,
+                                                   const double *models, float *shadow_compact, double *compact64,
+                                                   BatchCtl *ctl) {
+    compact2_body(num_models, B, maxm, blk_tot, slots, offsets, ctl, gridDim.x, nullptr);
+}
+__global__ __launch_bounds__(1024) void k_compact2_g(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    const uint32_t nb = (g.comp.B + 1023u) / 1024u;
+    if (!g.active || blockIdx.x >= nb)
+        return;
+    compact2_body(g.comp.num_models, g.comp.B, g.comp.maxm, g.comp.blk_tot, g.comp.slots, g.comp.offsets, g.comp.ctl, nb,
+                  g.comp.host_offsets);
 }
 
 // Hypothesis-ordered copies of the records for the streaming scorer: 12 lanes move the 192 bytes of one record
@@ -349,7 +390,7 @@ __global__ __launch_bounds__(256) void k_gather_models(BatchCtl *ctl, const uint
 // ------------------------------------------------------------------------------------ finalize + records
 constexpr int kRecBlocks = 256; // hypothesis chunks (contiguous), shared by k_finalize2 and k_records
 
-__global__ __launch_bounds__(256) void k_finalize2(FinalizeArgs f, uint32_t *blk_max, double *blk_min) {
+__device__ __forceinline__ void finalize2_body(const FinalizeArgs &f, uint32_t *blk_max, double *blk_min) {
     __shared__ uint32_t wmax[4];
     __shared__ double wmin[4];
     const uint32_t H = *f.num_hyp;
@@ -391,13 +432,22 @@ __global__ __launch_bounds__(256) void k_finalize2(FinalizeArgs f, uint32_t *blk
         }
     }
 }
+__global__ __launch_bounds__(256) void k_finalize2(FinalizeArgs f, uint32_t *blk_max, double *blk_min) {
+    finalize2_body(f, blk_max, blk_min);
+}
+__global__ __launch_bounds__(256) void k_finalize2_g(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active)
+        return;
+    finalize2_body(g.rec.f, g.rec.blk_max, g.rec.blk_min);
+}
 
-__global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const uint32_t *count, const double *score,
-                                                 const uint32_t *slots, const double *models, const uint32_t *blk_max,
-                                                 const double *blk_min, uint32_t init_max, double init_min,
-                                                 RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap,
-                                                 BatchCtl *ctl, RecordMeta *host_meta, double *host_models,
-                                                 uint32_t host_cap) {
+__device__ __forceinline__ void records_body(const uint32_t *num_hyp, const uint32_t *count, const double *score,
+                                             const uint32_t *slots, const double *models, const uint32_t *blk_max,
+                                             const double *blk_min, uint32_t init_max, double init_min,
+                                             RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap,
+                                             BatchCtl *ctl, RecordMeta *host_meta, double *host_models,
+                                             uint32_t host_cap) {
     __shared__ uint32_t wmax[4];
     __shared__ double wmin[4];
     __shared__ uint32_t s_runmax;
@@ -486,6 +536,24 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const 
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void k_records(const uint32_t *num_hyp, const uint32_t *count, const double *score,
+                                                 const uint32_t *slots, const double *models, const uint32_t *blk_max,
+                                                 const double *blk_min, uint32_t init_max, double init_min,
+                                                 RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap,
+                                                 BatchCtl *ctl, RecordMeta *host_meta, double *host_models,
+                                                 uint32_t host_cap) {
+    records_body(num_hyp, count, score, slots, models, blk_max, blk_min, init_max, init_min, rec_meta, rec_models, rec_cap,
+                 ctl, host_meta, host_models, host_cap);
+}
+__global__ __launch_bounds__(256) void k_records_g(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active)
+        return;
+    const RecordsArgs &r = g.rec;
+    records_body(r.f.num_hyp, r.f.count, r.f.score, r.slots, r.models, r.blk_max, r.blk_min, r.init_max, r.init_min,
+                 r.rec_meta, r.rec_models, r.rec_cap, r.ctl, r.host_meta, r.host_models, r.host_meta ? r.host_cap : 0u);
 }
 
 // ------------------------------------------------------------------------------------ fp16 hypothesis operands
@@ -617,10 +685,34 @@ __global__ __launch_bounds__(256) void k_gather_shadow16(BatchCtl *ctl, const ui
                  g16, c16, thr, out16);
 }
 
+__global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, uint32_t gather_blocks_max) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active)
+        return;
+    const uint64_t cap = (uint64_t)g.comp.B * (uint64_t)g.comp.maxm;
+    if (blockIdx.x < gather_blocks_max) {
+        const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+        if (t < cap * 12u)
+            gather_one(g.comp.ctl, g.comp.slots, g.comp.models, g.comp.shadow, g.comp.compact64, t);
+        return;
+    }
+    if (!g.comp.s16.out)
+        return;
+    const uint32_t cap8 = (uint32_t)((cap + 7u) & ~7ull);
+    const uint32_t k = (blockIdx.x - gather_blocks_max) * 256 + threadIdx.x;
+    if (k >= cap8)
+        return;
+    const uint32_t *slots = g.comp.slots;
+    const double *models = g.comp.models;
+    shadow16_one(k, g.comp.ctl->num_hyp,
+                 [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
+                 g.comp.s16.g16, g.comp.s16.c16, g.comp.s16.thr, static_cast<uint2 *>(g.comp.s16.out));
+}
+
 // ------------------------------------------------------------------------------------ front-end pre-processing
-__global__ __launch_bounds__(256) void k_prepare(const double *__restrict__ a_raw, const double *__restrict__ b_raw,
-                                                 uint32_t n, PrepareArgs g, double *__restrict__ soa,
-                                                 unsigned long long *absmax_bits) {
+__device__ __forceinline__ void prepare_body(const double *__restrict__ a_raw, const double *__restrict__ b_raw,
+                                             uint32_t n, const PrepareArgs &g, double *__restrict__ soa,
+                                             unsigned long long *absmax_bits) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     double m = 0.0;
     if (i < n) {
@@ -664,8 +756,19 @@ __global__ __launch_bounds__(256) void k_prepare(const double *__restrict__ a_ra
         const unsigned long long o = __shfl_xor(bits, off, 64);
         bits = o > bits ? o : bits;
     }
-    if ((threadIdx.x & 63) == 0 && bits)
+    if ((threadIdx.x & 63) == 0 && bits && absmax_bits)
         atomicMax(absmax_bits, bits);
+}
+__global__ __launch_bounds__(256) void k_prepare(const double *__restrict__ a_raw, const double *__restrict__ b_raw,
+                                                 uint32_t n, PrepareArgs g, double *__restrict__ soa,
+                                                 unsigned long long *absmax_bits) {
+    prepare_body(a_raw, b_raw, n, g, soa, absmax_bits);
+}
+__global__ __launch_bounds__(256) void k_prepare_g(const PrepareGroupArgs *pa) {
+    const PrepareGroupArgs &g = pa[blockIdx.z];
+    if (blockIdx.x * 256u >= g.n)
+        return;
+    prepare_body(g.a_raw, g.b_raw, g.n, g.args, g.soa, g.absmax_bits);
 }
 
 // ------------------------------------------------------------------------------------ launchers
@@ -746,6 +849,47 @@ hipError_t launch_gather_models(BatchCtl *ctl, const uint32_t *slots, const doub
 }
 hipError_t launch_finalize(const FinalizeArgs &f, hipStream_t stream) {
     k_finalize2<<<dim3(kRecBlocks), dim3(256), 0, stream>>>(f, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+// ---- group launches (problem = blockIdx.z) ----
+hipError_t launch_group_positions(int K, const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
+    const dim3 grid((d.max_M + 255) / 256, 1, d.G), block(256);
+    switch (K) {
+    case 3:
+        k_sample_delta_g<3><<<grid, block, 0, stream>>>(args);
+        break;
+    case 4:
+        k_sample_delta_g<4><<<grid, block, 0, stream>>>(args);
+        break;
+    case 5:
+        k_sample_delta_g<5><<<grid, block, 0, stream>>>(args);
+        break;
+    case 7:
+        k_sample_delta_g<7><<<grid, block, 0, stream>>>(args);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    k_sample_orbit_g<<<dim3(1, 1, d.G), dim3(1024), 0, stream>>>(args, K);
+    return hipGetLastError();
+}
+hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
+    k_compact2_g<<<dim3((d.max_B + 1023) / 1024, 1, d.G), dim3(1024), 0, stream>>>(args);
+    const uint32_t gblocks = (uint32_t)(((uint64_t)d.max_hcap * 12u + 255) / 256);
+    const uint32_t sblocks = d.any_mfma ? (((d.max_hcap + 7u) & ~7u) + 255) / 256 : 0u;
+    k_gather_shadow16_g<<<dim3(gblocks + sblocks, 1, d.G), dim3(256), 0, stream>>>(args, gblocks);
+    return hipGetLastError();
+}
+hipError_t launch_group_finalize_records(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
+    k_finalize2_g<<<dim3(kRecBlocks, 1, d.G), dim3(256), 0, stream>>>(args);
+    k_records_g<<<dim3(kRecBlocks, 1, d.G), dim3(256), 0, stream>>>(args);
+    return hipGetLastError();
+}
+hipError_t launch_group_prepare(const PrepareGroupArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream) {
+    if (G == 0 || max_n == 0)
+        return hipSuccess;
+    k_prepare_g<<<dim3((max_n + 255) / 256, 1, G), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
 

@@ -72,6 +72,7 @@ struct FinalizeArgs {
 };
 
 struct LMTask {
+    PointSet pts;                 // the correspondences the task refines on
     double params[kParamDoubles]; // in/out (see pl_refine.h for the per-problem layout)
     LMOptions opt;
     CameraParams cam;      // absolute pose only
@@ -192,6 +193,100 @@ hipError_t launch_finalize_records(const FinalizeArgs &f, const uint32_t *slots,
                                    uint32_t *blk_max, double *blk_min, uint32_t init_max, double init_min,
                                    RecordMeta *rec_meta, double *rec_models, uint32_t rec_cap, BatchCtl *ctl,
                                    RecordMeta *host_meta, double *host_models, uint32_t host_cap, hipStream_t stream);
+
+// ---- groups of problems: one launch sequence for MANY independent problems (BASELINE config 4) ----------------------
+// The problem index is a grid dimension (blockIdx.z) and every kernel fetches its arguments from a device-resident
+// table with one entry per problem of the group - the same kernel bodies as the single-problem launches above, so a
+// batch of 64 default-option problems costs the ~10 launches of one problem instead of 64 x 10.
+struct SampleArgs {
+    uint64_t seed, pos_base, N;
+    uint32_t B, M;
+    uint8_t *delta;
+    uint64_t *flagbits;
+    uint32_t *positions;
+    BatchCtl *ctl;
+    uint32_t zero_words, pad;
+};
+struct CompactArgs {
+    const uint32_t *num_models;
+    uint32_t B;
+    int32_t maxm;
+    uint32_t *blk_tot, *slots, *offsets;
+    const double *models;
+    float *shadow;
+    double *compact64;
+    BatchCtl *ctl;
+    Shadow16Params s16;
+    uint32_t *host_offsets; // optional pinned mirror of `offsets` (the host needs offsets[stop] after its replay)
+};
+struct RecordsArgs {
+    FinalizeArgs f;
+    const uint32_t *slots;
+    const double *models;
+    uint32_t *blk_max;
+    double *blk_min;
+    uint32_t init_max, rec_cap;
+    double init_min;
+    RecordMeta *rec_meta;
+    double *rec_models;
+    BatchCtl *ctl;
+    RecordMeta *host_meta;
+    double *host_models;
+    uint32_t host_cap, pad;
+};
+struct MaskArgs {
+    PointSet pts;
+    const double *model;
+    double thr2;
+    uint8_t *mask, *host_mask;
+};
+struct SelectArgs {
+    const double *score_refined;
+    double incumbent_score;
+    const double *rec_refined, *rec_incumbent;
+    double *out;
+};
+struct GroupArgs { // everything the kernels of one batch step need for ONE problem of the group
+    uint32_t active;   // 0: the slot takes no part in this step
+    uint32_t use_mfma; // absolute pose: scored by k_score_mfma (otherwise k_score_queue)
+    uint32_t chunks, slices;
+    SampleArgs samp;
+    GenerateArgs gen;
+    CompactArgs comp;
+    ScoreArgs score;
+    RecordsArgs rec;
+    SeqScoreArgs seq;
+};
+struct GroupDims { // grid extents: maxima over the active problems of the group
+    uint32_t G;          // problems (grid.z)
+    uint32_t max_M;      // sampler window
+    uint32_t max_B;      // iterations per batch
+    uint32_t max_hcap;   // hypothesis slots
+    uint32_t max_chunks, max_slices;
+    uint32_t any_mfma, any_queue;
+    int P;               // points per lane of the scorers (chunk = 64 P correspondences)
+};
+// positions -> generate -> compact/gather(/fp16 operands) -> score -> finalize/records -> candidates re-scored: the
+// whole batch step of every active problem of the group, one launch per kernel
+hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &dims, hipStream_t stream);
+hipError_t launch_group_score_seq(int est, const SeqScoreArgs *args, uint32_t G, uint32_t max_cap, hipStream_t stream);
+hipError_t launch_group_select(const SelectArgs *args, uint32_t G, hipStream_t stream);
+hipError_t launch_group_mask(int est, const MaskArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream);
+struct PrepareGroupArgs {
+    const double *a_raw, *b_raw;
+    uint32_t n, pad;
+    PrepareArgs args;
+    double *soa;
+    unsigned long long *absmax_bits;
+};
+hipError_t launch_group_prepare(const PrepareGroupArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream);
+// (pieces of launch_group_batch that live in pipeline.hip)
+hipError_t launch_group_positions(int K, const GroupArgs *args, const GroupDims &d, hipStream_t stream);
+hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipStream_t stream);
+hipError_t launch_group_finalize_records(const GroupArgs *args, const GroupDims &d, hipStream_t stream);
+// LM over the tasks of many problems: every task carries its own correspondences (LMTask.pts)
+hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream);
+int group_points_per_lane(int est); // P of the group launches (fixed per estimator)
 
 // Bare solver entry points (one problem per lane); inputs/outputs in HBM.
 //   abs : in = [x0 x1 x2 X0 X1 X2] (18 doubles / problem) -> out records (4 / problem)

@@ -1,0 +1,130 @@
+"""pl_estimate_batch through the GROUP launches (BASELINE config 4): problems of the same kind advance in lock-step, the
+problem index is a grid dimension of every kernel.  The results must be those of the single-problem entry points bit
+for bit (same kernel bodies, same host replay), and those match the oracle (tests/test_gpu_parity.py)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from poselib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems(count, base, opts):
+    probs = []
+    for i in range(count):
+        n = [9, 40, 320, 321, 700, 1023, 1024, 1500, 2750, 5000, 64, 12000][i % 12] + (i // 12)
+        outl = 0.3 + 0.04 * (i % 10)
+        opt = dict(opts[i % len(opts)])
+        opt["ransac"] = dict(opt.get("ransac", {}), seed=base + i)
+        k = i % 4
+        if k == 0:
+            d = synth.absolute_pose_scene(n, outl, base + i)
+            probs.append(("abs", d["p2d"], d["p3d"], d["camera"], opt))
+        elif k == 1:
+            d = synth.relative_pose_scene(n, outl, base + i)
+            probs.append(("rel", d["x1"], d["x2"], d["camera1"], d["camera2"], opt))
+        elif k == 2:
+            d = synth.homography_scene(n, outl, base + i, noise_px=0.3)
+            probs.append(("hom", d["x1"], d["x2"], opt))
+        else:
+            d = synth.fundamental_scene(n, outl, base + i)
+            probs.append(("fund", d["x1"], d["x2"], opt))
+    return probs
+
+
+def _single(gpu, pr):
+    if pr[0] == "abs":
+        img, info = gpu.estimate_absolute_pose(pr[1], pr[2], pr[3], pr[4])
+        return np.r_[img.pose.q, img.pose.t, img.camera.params], info
+    if pr[0] == "rel":
+        pose, info = gpu.estimate_relative_pose(pr[1], pr[2], pr[3], pr[4], pr[5])
+        return np.r_[pose.q, pose.t], info
+    fn = gpu.estimate_homography if pr[0] == "hom" else gpu.estimate_fundamental
+    M, info = fn(pr[1], pr[2], pr[3])
+    return M.reshape(-1), info
+
+
+def _flat(pr, model):
+    if pr[0] == "abs":
+        return np.r_[model.pose.q, model.pose.t, model.camera.params]
+    if pr[0] == "rel":
+        return np.r_[model.q, model.t]
+    return model.reshape(-1)
+
+
+OPTS = [{}, {}, {"ransac": {"min_iterations": 1500}}, {"ransac": {"max_iterations": 300, "min_iterations": 100}},
+        {"bundle": {"loss_type": "HUBER", "loss_scale": 0.7}}, {"ransac": {"min_iterations": 2500, "success_prob": 0.99}}]
+
+
+def test_group_launches_equal_the_single_problem_entry_points(gpu):
+    probs = _problems(96, 31000, OPTS)
+    singles = [_single(gpu, pr) for pr in probs]
+    for in_flight in (1, 3):
+        res = gpu.estimate_batch(probs, max_in_flight=in_flight)
+        assert len(res) == len(probs)
+        for (model, info), (ref_model, ref_info), pr in zip(res, singles, probs):
+            assert np.array_equal(_flat(pr, model), ref_model), (pr[0], len(pr[1]))  # bit for bit
+            for k in ("iterations", "refinements", "num_inliers", "model_score", "hypotheses", "inlier_ratio"):
+                assert info[k] == ref_info[k], (pr[0], len(pr[1]), k, info[k], ref_info[k])
+            assert info["inliers"] == ref_info["inliers"]
+
+
+def test_grouped_problems_match_the_oracle(gpu):
+    probs = _problems(36, 32000, [{}])
+    res = gpu.estimate_batch(probs, max_in_flight=2)
+    for (model, info), pr in zip(res, probs):
+        if pr[0] == "abs":
+            ref, mask, st = O.estimate_absolute_pose(pr[1], pr[2], pr[3], pr[4])
+        elif pr[0] == "rel":
+            ref, mask, st = O.estimate_relative_pose(pr[1], pr[2], pr[3], pr[4], pr[5])
+        elif pr[0] == "hom":
+            ref, mask, st = O.estimate_homography(pr[1], pr[2], pr[3])
+        else:
+            ref, mask, st = O.estimate_fundamental(pr[1], pr[2], pr[3])
+        assert info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"], (pr[0], len(pr[1]))
+        assert (np.array(info["inliers"]) == mask).all()
+
+
+def test_items_outside_the_group_path_take_the_single_problem_path(gpu):
+    """PROSAC, OPENCV cameras, fewer points than a sample, long fixed-length runs: same call, same results"""
+    d = synth.absolute_pose_scene(800, 0.4, 33001)
+    order = np.argsort(~d["inlier_gt"], kind="stable")
+    h = synth.homography_scene(3, 0.0, 33002)
+    r = synth.relative_pose_scene(900, 0.4, 33003)
+    ocv = {"model": "OPENCV", "width": 1000, "height": 1000, "params": [1000.0, 1000.0, 500.0, 500.0, 0.01, -0.002, 1e-4, -1e-4]}
+    probs = [("abs", d["p2d"][order], d["p3d"][order], d["camera"], {"ransac": {"seed": 1, "progressive_sampling": True}}),
+             ("hom", h["x1"], h["x2"], {"ransac": {"seed": 2}}),
+             ("rel", r["x1"], r["x2"], ocv, ocv, {"ransac": {"seed": 3}}),
+             ("abs", d["p2d"], d["p3d"], d["camera"], {"ransac": {"seed": 4, "min_iterations": 20000, "max_iterations": 20000}}),
+             ("abs", d["p2d"], d["p3d"], d["camera"], {"ransac": {"seed": 5}})]
+    singles = [_single(gpu, pr) for pr in probs]
+    res = gpu.estimate_batch(probs, max_in_flight=2)
+    for (model, info), (ref_model, ref_info), pr in zip(res, singles, probs):
+        assert np.array_equal(_flat(pr, model), ref_model)
+        assert info["iterations"] == ref_info["iterations"] and info["inliers"] == ref_info["inliers"]
+
+
+def test_group_path_can_be_switched_off(gpu):
+    """POSELIB_AMD_NO_GROUPS=1 (diagnostic): every item on its own - same results"""
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import poselib_amd as P
+import test_gpu_group as T
+probs = T._problems(24, 34000, [{}])
+res = P.estimate_batch(probs, max_in_flight=2)
+print("RESULT " + json.dumps([[repr(float(v)) for v in T._flat(pr, m)] + [i["iterations"], i["num_inliers"]] for (m, i), pr in zip(res, probs)]))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ({}, {"POSELIB_AMD_NO_GROUPS": "1"}):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, **extra), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1])
+    assert outs[0] == outs[1]

@@ -419,8 +419,8 @@ def test_estimate_batch_matches_single_calls(gpu):
 
 @pytest.mark.parametrize("mode", ["1", "0"])
 def test_multi_workgroup_and_single_workgroup_lm(gpu, mode):
-    """The LO of large homography / fundamental problems runs through k_lm2 by default (one task spread over several
-    workgroups, one launch per LM iteration); POSELIB_AMD_LATENCY_MODE=0 keeps every task on one workgroup (k_lm).
+    """POSELIB_AMD_LATENCY_MODE=1 sends the LO of large homography / fundamental problems through k_lm2 (one task
+    spread over several workgroups, one launch per LM iteration); the default keeps every task on one workgroup (k_lm).
     Both have to reproduce the oracle; run in subprocesses because the setting is read once per process."""
     import os
     import subprocess
