@@ -405,6 +405,84 @@ def report_workload(name, table, ctx, args, world):
     return out, ok
 
 
+def run_batch_mixed(args, ranks, P, synth):
+    """BASELINE configs[4]: a batch of independent image pairs (P3P / 5-point / homography cycling, N ~ U{500..5000},
+    30-70 % outliers, DEFAULT options = the reference's ~10^3-iteration regime), host-resident inputs, one
+    pl_estimate_batch call per step (problems of a kind advance in groups through one launch sequence; PCIe- and
+    front-end-inclusive).  Problem i of the global batch lives on rank i mod world (sharding.owned)."""
+    from poselib_amd import sharding
+
+    per_rank = args.batch_problems
+    total = per_rank * ranks.world
+    mine = sharding.owned(total, ranks.rank, ranks.world)
+    kinds = ("abs", "rel", "hom")
+    problems = {}
+    for i in mine:
+        rs = synth.Stream(900000 + i)
+        n = int(rs.uniform(1, 500, 5001)[0])
+        outl = float(rs.uniform(1, 0.3, 0.7)[0])
+        kind = kinds[i % 3]
+        opt = {"ransac": {"seed": i}}
+        if kind == "abs":
+            d = synth.absolute_pose_scene(n, outl, 2000 + i)
+            problems[i] = ("abs", d["p2d"], d["p3d"], d["camera"], opt)
+        elif kind == "rel":
+            d = synth.relative_pose_scene(n, outl, 2000 + i)
+            problems[i] = ("rel", d["x1"], d["x2"], d["camera1"], d["camera2"], opt)
+        else:
+            d = synth.homography_scene(n, outl, 2000 + i, noise_px=0.3)
+            problems[i] = ("hom", d["x1"], d["x2"], opt)
+    batch = P.Batch([problems[i] for i in mine])  # descriptors marshalled once, outside the timed region
+    for _ in range(max(1, args.warmup)):
+        batch.run(max_in_flight=args.batch_threads)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    hyp = 0
+    for _ in range(args.steps):
+        batch.run(max_in_flight=args.batch_threads)
+        hyp += int(batch.stats()[2].sum())
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    table = ranks.gather([elapsed, float(hyp), float(len(mine))])
+    if ranks.rank != 0:
+        return None, True
+    t_max = float(table[:, 0].max())
+    out = {"value": float(table[:, 1].sum()) / t_max, "unit": "hypotheses/s",
+           "problems_per_s": float(table[:, 2].sum()) * args.steps / t_max, "ms_per_step": 1e3 * t_max / args.steps,
+           "problem": "BASELINE configs[4]: P3P / 5-point / homography cycling, N in [500,5000], 30-70 % outliers, default "
+                      "options, host-resident inputs (PCIe- and front-end-inclusive), one pl_estimate_batch call per step",
+           "problems_per_gpu_per_step": per_rank, "host_threads_per_gpu": args.batch_threads, "timed_region_s": t_max,
+           "sharding": "problem i on rank i mod world; RCCL for the barrier and the final gather only"}
+    ok = True
+    if not args.no_parity:  # a sample of rank 0's problems against the oracle's front-ends
+        import oracle_lib as O
+
+        res = batch.results()
+        sample = list(range(0, len(mine), max(1, len(mine) // 24)))[:24]
+        same = 0
+        t1 = time.perf_counter()
+        for j in sample:
+            pr = problems[mine[j]]
+            if pr[0] == "abs":
+                ref, mask, st = O.estimate_absolute_pose(pr[1], pr[2], pr[3], pr[4])
+            elif pr[0] == "rel":
+                ref, mask, st = O.estimate_relative_pose(pr[1], pr[2], pr[3], pr[4], pr[5])
+            else:
+                ref, mask, st = O.estimate_homography(pr[1], pr[2], pr[3])
+            info = res[j][1]
+            same += int(info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"]
+                        and bool((np.array(info["inliers"], dtype=bool) == mask).all()))
+        cpu_s = time.perf_counter() - t1
+        ok = same == len(sample)
+        out["parity"] = {"checked": len(sample), "identical_iterations_inliers_masks": same, "ok": ok,
+                         "against": "oracle estimate_* (complete front-ends) on a sample of the batch"}
+        if ranks.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = {"value": len(sample) / cpu_s, "unit": "problems/s", "cores": 1, "kind": "port",
+                                   "sample": f"oracle estimate_* on {len(sample)} problems of the batch, one after the other "
+                                             f"({cpu_s:.1f} s, 1 of {os.cpu_count()} host cores)"}
+    return out, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -422,6 +500,9 @@ def main():
                          "ranks (pl_ransac_run_sharded, one all-gather per batch); default is independent problems per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle runs (profiling)")
+    ap.add_argument("--batch-problems", type=int, default=2048,
+                    help="configs[4] leg: problems per GPU and step of the mixed default-options batch (0: skip)")
+    ap.add_argument("--batch-threads", type=int, default=8, help="host threads inside pl_estimate_batch")
     ap.add_argument("--rehearse-distributed", action="store_true",
                     help="launch / rendezvous / gather path only, no GPU work, prints no measurement (CPU test)")
     args = ap.parse_args()
@@ -452,6 +533,13 @@ def main():
         table = ranks.gather(rec)  # final gather over RCCL
         if ranks.rank == 0:
             reports[name], ok = report_workload(name, table, ctx, args, ranks.world)
+            all_ok = all_ok and ok
+
+    if args.batch_problems > 0 and not args.no_secondary and not args.shard_problem:
+        rep, ok = run_batch_mixed(args, ranks, P, synth)
+        if ranks.rank == 0:
+            reports["batch_mixed"] = rep
+            names = names + ["batch_mixed"]
             all_ok = all_ok and ok
 
     if ranks.rank == 0:

@@ -453,7 +453,7 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
                                                  uint32_t nslices) {
     constexpr int kWaves = kQueueThreads / 64;
     constexpr int ND = point_doubles(EST);
-    constexpr int NB = (EST == EST_ABS) ? 1 : (EST == EST_HOM ? 1 : 2); // bound terms per point
+    constexpr int NB = 1; // bound terms per point
     constexpr int NPW = 64 * P;                                         // correspondences per chunk
     __shared__ double s_pts[ND][NPW];
     __shared__ uint16_t s_queue[kWaves][kQueueCap]; // entries: hypothesis of the group << 9 | correspondence of the chunk
@@ -489,7 +489,7 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
             if constexpr (EST == EST_HOM)
                 bnd[p][0] = nanb_thr;
             else
-                bnd[p][0] = nanb, bnd[p][1] = nsq;
+                bnd[p][0] = pf_point_sampson_w(nanb, nsq, pf);
         }
     }
     if (threadIdx.x == 0)
@@ -626,13 +626,14 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
                 }
             } else {
                 const float gf = (16.f * kPfU) * r[14];
-                const float gf2 = gf * gf, gfx2 = gf + gf;
-                // two points per packed fp32 instruction, operation for operation pf_sampson_outlier
+                const float gf2 = gf * gf;
+                // two points per packed fp32 instruction, operation for operation pf_sampson_outlier: ONE comparison per
+                // point (pl_prefilter.h), its result is the wave mask
 #pragma unroll
                 for (int p = 0; p + 1 < P; p += 2) {
                     const v2f a0 = {pf32[p][0], pf32[p + 1][0]}, a1 = {pf32[p][1], pf32[p + 1][1]};
                     const v2f b0 = {pf32[p][2], pf32[p + 1][2]}, b1 = {pf32[p][3], pf32[p + 1][3]};
-                    const v2f nanb = {bnd[p][0], bnd[p + 1][0]}, nsq = {bnd[p][1], bnd[p + 1][1]};
+                    const v2f w = {bnd[p][0], bnd[p + 1][0]};
                     const v2f Ea0 = pk_fma(bc(r[0]), a0, pk_fma(bc(r[1]), a1, bc(r[2])));
                     const v2f Ea1 = pk_fma(bc(r[3]), a0, pk_fma(bc(r[4]), a1, bc(r[5])));
                     const v2f Ea2 = pk_fma(bc(r[6]), a0, pk_fma(bc(r[7]), a1, bc(r[8])));
@@ -640,22 +641,18 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
                     const v2f Eb1 = pk_fma(bc(r[1]), b0, pk_fma(bc(r[4]), b1, bc(r[7])));
                     const v2f C = pk_fma(b0, Ea0, pk_fma(b1, Ea1, Ea2));
                     const v2f S = pk_fma(Eb1, Eb1, pk_fma(Eb0, Eb0, pk_fma(Ea1, Ea1, Ea0 * Ea0)));
-                    const v2f D = pk_fma(S, bc(1.015625f), bc(gf2) * nsq);
-                    const v2f eC = bc(gfx2) * nanb;
-                    const v2f R = bc(pf.thr2_up) * D;
+                    const v2f L = C * C;
+                    const v2f R = pk_fma(bc(pf.t1), S, bc(gf2) * w);
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const float c = fabsf(C[e]) - eC[e];
-                        const uint64_t pos = __builtin_amdgcn_ballot_w64(c > 0.f);
-                        const uint64_t big = __builtin_amdgcn_ballot_w64(c * c > R[e]);
-                        m[p + e] = vmask[p + e] & ~(pos & big);
+                        m[p + e] = vmask[p + e] & ~__builtin_amdgcn_ballot_w64(L[e] > R[e]);
                         any |= m[p + e];
                     }
                 }
                 if constexpr (P & 1) {
                     constexpr int p = P - 1;
-                    const bool out = pf_sampson_outlier(r, gf, pf.thr2_up, pf32[p][0], pf32[p][1], pf32[p][2],
-                                                        pf32[p][3], bnd[p][0], bnd[p][1]);
+                    const bool out = pf_sampson_outlier(r, gf, pf.t1, pf32[p][0], pf32[p][1], pf32[p][2], pf32[p][3],
+                                                        bnd[p][0]);
                     m[p] = vmask[p] & ~__builtin_amdgcn_ballot_w64(out);
                     any |= m[p];
                 }

@@ -26,8 +26,14 @@
 //    (|E| + e)^2 <= (1 + d) E^2 + (1 + 1/d) e^2  with d = 1/64:
 //        D_up = (1 + d) sum E^_k^2 + 130 (e_a^2 + e_b^2)  >=  Cx + Cy,      |C| >= |C^| - e_C,
 //    so  |C^| > e_C  and  (|C^| - e_C)^2 > thr2 (1 + 64u) D_up  proves an outlier (the 64u absorbs the roundings
-//    of the test itself).  This form needs no absolute values inside the sums and packs two points per
-//    v_pk_* instruction.
+//    of the test itself).  The kernels evaluate a slightly weaker sufficient condition that needs ONE comparison and
+//    no absolute value: for every a, b >= 0 and h in (0, 1),  (a - b)^2 >= (1 - h) a^2 - (1 / h - 1) b^2,  so with h = 1/16
+//        C^^2  >  T1 * sum E^_k^2  +  gf^2 * w                                  (gf = 16u fm per model, w per point)
+//        T1 = (16/15) (1 + d) thr2 (1 + 96u),    w = (16/15) (1 + 96u) (thr2 (1 + 64u) 130 (na^2 + nb^2) + 60 (na nb)^2)
+//    implies the condition above (e_C^2 = 4 gf^2 (na nb)^2; the right-hand side is non-negative, so the inequality also
+//    forces |C^| > 3.8 e_C > e_C); the extra 32u covers the roundings of C^ C^, gf^2 w and the final FMA.  The acceptance
+//    band is 4 % wider than with the two-comparison form (h trades that against the weight of e_C, which matters for
+//    un-normalised pixel coordinates); 20 instead of 24 operations per pair.
 //  * reprojection, fp16 / MFMA form (k_score_mfma): v_mfma_f32_32x32x8_f16 evaluates, with fp32 accumulation,
 //        z^_c = rn16(R_c) (X_hi + X_lo) + rn16(t_c)          X_hi = rn16(X), X_lo = rn16(X - X_hi)
 //        B^   = rn16(thr R_2) (X_hi + X_lo) + up16(thr t_2 + g) + up16(w)
@@ -61,6 +67,8 @@ struct PrefilterArgs {
     int enabled;   // 0: exact evaluation of every point
     float g16;     // absolute pose, fp16 / MFMA form of the filter: 2^-11 (1 + max|x|,|y| + thr), rounded up
     float c16;     //   and the absolute part (2e-7 + 2.5e-4) (1 + max|x|,|y| + thr)
+    float t1;      // Sampson, one-comparison form: (16/15) (1 + 1/64) thr2 (1 + 96u), rounded up
+    float w252;    //   and (16/15) (1 + 96u) 60, rounded up (factor of (na nb)^2 in the per-point term w)
 };
 
 PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-negative bound upwards
@@ -70,7 +78,7 @@ PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-nega
 // the range fp32 can carry.
 inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) {
     PrefilterArgs a;
-    a.thr = a.gx = a.thr2_up = a.g16 = a.c16 = 0.f;
+    a.thr = a.gx = a.thr2_up = a.g16 = a.c16 = a.t1 = a.w252 = 0.f;
     a.enabled = 0;
     if (!(thr2 >= 1e-30 && thr2 <= 1e30))
         return a;
@@ -81,6 +89,8 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
     const double u = 5.9604644775390625e-08;
     a.thr = nextafterf((float)thr, inf);
     a.thr2_up = nextafterf((float)(thr2 * (1.0 + 64.0 * u)), inf);
+    a.t1 = nextafterf((float)((16.0 / 15.0) * (1.0 + 1.0 / 64.0) * thr2 * (1.0 + 96.0 * u)), inf);
+    a.w252 = nextafterf((float)((16.0 / 15.0) * (1.0 + 96.0 * u) * 60.0), inf);
     if (est == 0) {
         a.gx = nextafterf((float)(32.0 * u * (1.0 + (double)xy_absmax + thr)), inf);
         a.g16 = nextafterf((float)(4.8828125e-4 * (1.0 + (double)xy_absmax + thr)), inf); // 2^-11
@@ -103,6 +113,11 @@ PL_HD void pf_point_two_view(double a0, double a1, double b0, double b1, float t
     nanb = pf_up(na * nb);                          // Sampson: e_C = 2 gf * na * nb
     nsq = pf_up(130.f * pf_up(na * na + nb * nb));  // Sampson: 130 (e_a^2 + e_b^2) = gf^2 * nsq
     nanb_thr = pf_up(na * pf_up(nb + thr));         // homography: W = gh * na * (nb + thr)
+}
+// Sampson, one-comparison form: the per-point term w (header comment), every factor rounded up
+PL_HD float pf_point_sampson_w(float nanb, float nsq, const PrefilterArgs &pf) {
+    // (16/15) (1 + 96u) thr2_up nsq <= t1 nsq  (t1 carries the larger factor (1 + 1/64) as well)
+    return pf_up(pf_up(pf.t1 * nsq) + pf_up(pf.w252 * pf_up(nanb * nanb)));
 }
 
 // ---- per-model terms: shadow[12] = padded max|t_i| (absolute pose), shadow[13] = NaN flag, shadow[14] = padded
@@ -134,8 +149,9 @@ PL_HD bool pf_hom_outlier(const float *r, float gh /* 32u * hm */, float thr, fl
     return fmaxf(fabsf(e0), fabsf(e1)) > B;
 }
 
-PL_HD bool pf_sampson_outlier(const float *r, float gf /* 16u * fm */, float thr2_up, float a0, float a1, float b0,
-                              float b1, float nanb, float nsq) {
+// w: pf_point_sampson_w of the correspondence; t1: PrefilterArgs.t1
+PL_HD bool pf_sampson_outlier(const float *r, float gf /* 16u * fm */, float t1, float a0, float a1, float b0,
+                              float b1, float w) {
     const float Ea0 = fmaf(r[0], a0, fmaf(r[1], a1, r[2]));
     const float Ea1 = fmaf(r[3], a0, fmaf(r[4], a1, r[5]));
     const float Ea2 = fmaf(r[6], a0, fmaf(r[7], a1, r[8]));
@@ -143,9 +159,7 @@ PL_HD bool pf_sampson_outlier(const float *r, float gf /* 16u * fm */, float thr
     const float Eb1 = fmaf(r[1], b0, fmaf(r[4], b1, r[7]));
     const float C = fmaf(b0, Ea0, fmaf(b1, Ea1, Ea2));
     const float S = fmaf(Eb1, Eb1, fmaf(Eb0, Eb0, fmaf(Ea1, Ea1, Ea0 * Ea0)));
-    const float D = fmaf(S, 1.015625f, (gf * gf) * nsq);
-    const float c = fabsf(C) - (gf + gf) * nanb;
-    return (c > 0.f) & (c * c > thr2_up * D);
+    return C * C > fmaf(t1, S, (gf * gf) * w);
 }
 
 } // namespace pl

@@ -295,7 +295,7 @@ int hm_prefilter(int est, const double *rec, const double *const *pa, uint32_t n
             if (est == EST_HOM)
                 out[i] = pf_hom_outlier(r, (32.f * kPfU) * r[14], pf.thr, a0, a1, b0, b1, nanb_thr);
             else
-                out[i] = pf_sampson_outlier(r, (16.f * kPfU) * r[14], pf.thr2_up, a0, a1, b0, b1, nanb, nsq);
+                out[i] = pf_sampson_outlier(r, (16.f * kPfU) * r[14], pf.t1, a0, a1, b0, b1, pf_point_sampson_w(nanb, nsq, pf));
         }
     }
     return 1;

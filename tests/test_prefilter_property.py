@@ -148,7 +148,10 @@ def test_sampson_filter_never_drops_an_inlier(est):
     print(f"{est}: {stats[1]}/{stats[0]} non-inliers pass the filter ({100.0 * stats[1] / stats[0]:.3f} %)")
     # rel: correspondences that satisfy the Sampson test but fail the cheirality test are non-inliers the Sampson
     # filter cannot (and must not) exclude
-    assert stats[1] < (0.15 if est == "rel" else 0.05) * stats[0]
+    # fund: half of the trials are raw pixel coordinates with matrices rescaled by 1e-12 .. 1e15, where the rounding slack
+    # e_C carries weight; the one-comparison form of the filter (pl_prefilter.h) trades 3 points of selectivity there
+    # for 4 fewer operations per pair everywhere
+    assert stats[1] < (0.15 if est == "rel" else 0.08) * stats[0]
 
 
 def test_homography_filter_never_drops_an_inlier():
