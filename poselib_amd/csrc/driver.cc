@@ -826,8 +826,10 @@ struct RansacRun {
         HIP_TRY(c->slots.ensure(sizeof(uint32_t) * hcap));
         HIP_TRY(c->offsets.ensure(sizeof(uint32_t) * std::max<uint32_t>(Bl, 1u)));
         // control block + models per 1024 iterations (zeroed together, filled by the generator)
-        const uint32_t nblk = (Bl + 1023) / 1024; // (two tables: models and NaN models per 1024 iterations)
-        const size_t ctl_bytes = sizeof(BatchCtl) + sizeof(uint32_t) * (2 * (size_t)nblk + 2);
+        // behind the control block, zeroed with it: models and NaN models per 1024 iterations (two tables of nblk + 1
+        // entries), the scorer's work counters (one per chunk of correspondences)
+        const uint32_t nblk = (Bl + 1023) / 1024;
+        const size_t ctl_bytes = sizeof(BatchCtl) + sizeof(uint32_t) * (2 * (size_t)nblk + 2 + chunks);
         HIP_TRY(c->ctl.ensure(ctl_bytes));
         HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * hcap));
         HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * hcap));
@@ -928,6 +930,7 @@ struct RansacRun {
             sa.thr2 = thr2;
             sa.part_count = c->part_count.as<uint32_t>();
             sa.part_score = c->part_score.as<double>();
+            sa.tickets = blk_tot + 2 * (size_t)nblk + 2;
             const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, (uint32_t)hcap));
             HIP_TRY(hipEventRecord(c->ev0, c->stream));
             HIP_TRY(launch_score(kind, sa, slices, c->stream));
@@ -1949,7 +1952,7 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
     HIP_TRY(c->slots.ensure(sizeof(uint32_t) * H));
     HIP_TRY(c->shadow.ensure(sizeof(float) * 16 * H));
     HIP_TRY(c->compact64.ensure(sizeof(double) * kModelDoubles * H));
-    HIP_TRY(c->ctl.ensure(sizeof(BatchCtl) + 64));
+    HIP_TRY(c->ctl.ensure(sizeof(BatchCtl) + 64 + sizeof(uint32_t) * chunks));
     HIP_TRY(c->part_count.ensure(sizeof(uint32_t) * chunks * H));
     HIP_TRY(c->part_score.ensure(sizeof(double) * chunks * H));
     HIP_TRY(c->count.ensure(sizeof(uint32_t) * H));
@@ -1958,6 +1961,7 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
     std::memset(&hc, 0, sizeof(hc));
     hc.num_hyp = H;
     BatchCtl *d_ctl = c->ctl.as<BatchCtl>();
+    HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(BatchCtl) + 64 + sizeof(uint32_t) * chunks, c->stream));
     HIP_TRY(hipMemcpyAsync(d_ctl, &hc, sizeof(hc), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->models.p, recs.data(), sizeof(double) * recs.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->slots.p, ident.data(), sizeof(uint32_t) * H, hipMemcpyHostToDevice, c->stream));
@@ -1982,6 +1986,7 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
     sa.thr2 = thr2;
     sa.part_count = c->part_count.as<uint32_t>();
     sa.part_score = c->part_score.as<double>();
+    sa.tickets = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(d_ctl) + sizeof(BatchCtl) + 64);
     const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(1536u / chunks, H));
     HIP_TRY(launch_score(p->kind, sa, slices, c->stream));
     FinalizeArgs fa;

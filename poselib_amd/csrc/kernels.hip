@@ -426,6 +426,32 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f bc(float s) { return v2f{s, s}; }
 
+// ---- work distribution of the streaming scorers ---------------------------------------------------------------------
+// The waves that hold the same chunk of correspondences (all workgroups of the launch with that chunk index) share the
+// hypothesis stream by a fixed stride: workgroup b of B owns the units 8 b + j + 8 B r (j < 8 waves, r = 0, 1, ...) and
+// its waves take them one at a time from a counter in LDS, so they finish together.  Units are 64 hypotheses while
+// whole rounds remain (every wave gets the same number of them), then the remainder is cut into units of 32 or 16 so
+// that the last round is short as well - with 2025 groups for 384 waves (config 1) contiguous ranges per workgroup
+// cost 6 rounds, this costs 5.5; with 918 for 432 (config 2) 2.25 instead of 3.  (A counter in global memory shared by
+// the waves of all XCDs was measured: 2.2x SLOWER - contended device-scope atomics.)  Which wave evaluates a unit has
+// no influence on its results.
+__device__ __forceinline__ bool unit_of_ticket(uint32_t t, uint32_t H, uint32_t waves_per_chunk, uint32_t &kb, uint32_t &gn) {
+    const uint32_t G = (H + 63u) / 64u;
+    const uint32_t full = (G / waves_per_chunk) * waves_per_chunk; // 64-hypothesis units of the whole rounds
+    if (t < full) {
+        kb = t * 64u;
+        gn = min(64u, H - kb);
+        return true;
+    }
+    const uint32_t rest = G - full; // < waves_per_chunk groups left
+    const uint32_t sub = (rest * 4u <= waves_per_chunk) ? 16u : (rest * 2u <= waves_per_chunk) ? 32u : 64u;
+    kb = full * 64u + (t - full) * sub;
+    if (kb >= H)
+        return false;
+    gn = min(sub, H - kb);
+    return true;
+}
+
 // ---- deferred exact evaluation ----------------------------------------------------------------------------------
 // k_score_queue: the scorer of the batched main loop.  One wavefront = 64*P register-resident correspondences (fp32
 // copies + bound terms) x a stream of hypotheses; the four waves of a workgroup share the same correspondences
@@ -459,7 +485,7 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
     __shared__ uint16_t s_queue[kWaves][kQueueCap]; // entries: hypothesis of the group << 9 | correspondence of the chunk
     __shared__ double s_acc_s[kWaves][64];
     __shared__ uint32_t s_acc_c[kWaves][64];
-    __shared__ uint32_t s_next_group;
+    __shared__ uint32_t s_next_unit;
     const int lane = threadIdx.x & 63;
     // readfirstlane: the wave index is uniform, and the compiler has to know it for the scalar (s_load) shadow stream
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -493,7 +519,7 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
         }
     }
     if (threadIdx.x == 0)
-        s_next_group = 0;
+        s_next_unit = 0;
     __syncthreads(); // the only workgroup barrier: fp64 correspondences are in LDS
 
     const uint32_t H = *as_uniform(num_hyp_ptr);
@@ -502,25 +528,19 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
     double *const acc_s = s_acc_s[wave];
     uint32_t *const acc_c = s_acc_c[wave];
 
-    // The workgroup owns a contiguous range of 64-hypothesis groups; its four waves take them one at a time from
-    // a counter in LDS, so they finish together (a static split leaves one wave a whole group behind).  Which wave
-    // evaluates a group has no influence on its results.
-    const uint32_t G = (H + 63u) / 64u;
-    const uint32_t gper = (G + nslices - 1) / nslices;
-    const uint32_t g0 = slice * gper;
-    const uint32_t g1 = min(G, g0 + gper);
-    auto request_ticket = [&]() -> uint32_t { // per-lane value; lane 0 holds the ticket
+    const uint32_t waves_per_chunk = nslices * kWaves;
+    auto request_ticket = [&]() -> uint32_t { // per-lane value; lane 0 holds the workgroup's next unit
         uint32_t t = 0;
-        if (lane == 0)
-            t = atomicAdd(&s_next_group, 1u);
+        if (lane == 0) {
+            const uint32_t k = atomicAdd(&s_next_unit, 1u);
+            t = slice * kWaves + (k % kWaves) + (k / kWaves) * waves_per_chunk;
+        }
         return t;
     };
     uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)request_ticket());
-    while (g0 + ticket < g1) {
-        const uint32_t kb = (g0 + ticket) * 64u;
-        const uint32_t k1 = H;
-        const uint32_t pending = request_ticket(); // the next ticket travels while this group is evaluated
-        const uint32_t gn = min(64u, k1 - kb);
+    uint32_t kb, gn;
+    while (unit_of_ticket(ticket, H, waves_per_chunk, kb, gn)) {
+        const uint32_t pending = request_ticket(); // the next unit's index travels while this one is evaluated
         acc_s[lane] = 0.0;
         acc_c[lane] = 0;
         uint32_t qhead = 0, qtail = 0; // wave-uniform ring positions
@@ -710,7 +730,9 @@ __global__ __launch_bounds__(kQueueThreads) void k_score_queue(PointSet pts, con
                                                                 const uint32_t *__restrict__ num_hyp_ptr,
                                                                 uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
                                                                 uint32_t *__restrict__ part_count,
-                                                                double *__restrict__ part_score) {
+                                                                double *__restrict__ part_score,
+                                                                uint32_t *__restrict__ tickets) {
+    (void)tickets;
     score_queue_body<EST, P>(pts, shadow, compact64, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score,
                              blockIdx.x, blockIdx.y, gridDim.x);
 }
@@ -757,7 +779,7 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
     __shared__ uint16_t s_queue[kWaves][kMfmaQueueCap]; // entries: hypothesis slot << 9 | correspondence of the chunk
     __shared__ double s_acc_s[kWaves][64];
     __shared__ uint32_t s_acc_c[kWaves][64];
-    __shared__ uint32_t s_next_group;
+    __shared__ uint32_t s_next_unit;
     __shared__ uint2 s_bop[PG][64];  // B operands of the point groups (lane-specific: high / low fp16 parts)
     __shared__ float2 s_xy[PG][32];  // fp32 x, y per column
     const int lane = threadIdx.x & 63;
@@ -813,28 +835,26 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
         validbits |= valid ? (1u << (PG - 1 - g)) : 0u;
     }
     if (threadIdx.x == 0)
-        s_next_group = 0;
+        s_next_unit = 0;
     __syncthreads(); // the only workgroup barrier
 
     const uint32_t H = *as_uniform(num_hyp_ptr);
     uint16_t *const queue = s_queue[wave];
     double *const acc_s = s_acc_s[wave];
     uint32_t *const acc_c = s_acc_c[wave];
-    const uint32_t G = (H + 63u) / 64u;
-    const uint32_t gper = (G + nslices - 1) / nslices;
-    const uint32_t g0 = slice * gper;
-    const uint32_t g1 = min(G, g0 + gper);
-    auto request_ticket = [&]() -> uint32_t {
+    const uint32_t waves_per_chunk = nslices * kWaves;
+    auto request_ticket = [&]() -> uint32_t { // per-lane value; lane 0 holds the workgroup's next unit
         uint32_t t = 0;
-        if (lane == 0)
-            t = atomicAdd(&s_next_group, 1u);
+        if (lane == 0) {
+            const uint32_t k = atomicAdd(&s_next_unit, 1u);
+            t = slice * kWaves + (k % kWaves) + (k / kWaves) * waves_per_chunk;
+        }
         return t;
     };
     uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)request_ticket());
-    while (g0 + ticket < g1) {
-        const uint32_t kb = (g0 + ticket) * 64u;
-        const uint32_t pending = request_ticket();
-        const uint32_t gn = min(64u, H - kb);
+    uint32_t kb, gn;
+    while (unit_of_ticket(ticket, H, waves_per_chunk, kb, gn)) {
+        const uint32_t pending = request_ticket(); // the next unit's index travels while this one is evaluated
         acc_s[lane] = 0.0;
         acc_c[lane] = 0;
         uint32_t qhead = 0, qtail = 0;
@@ -954,7 +974,9 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
                                                                const uint32_t *__restrict__ num_hyp_ptr,
                                                                uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
                                                                uint32_t *__restrict__ part_count,
-                                                               double *__restrict__ part_score) {
+                                                               double *__restrict__ part_score,
+                                                               uint32_t *__restrict__ tickets) {
+    (void)tickets;
     score_mfma_body<PG>(pts, shadow16, compact64, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score, blockIdx.x,
                         blockIdx.y, gridDim.x);
 }
@@ -1703,7 +1725,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     case PP:                                                                                                           \
         k_score_mfma<2 * PP><<<mgrid, mblock, 0, stream>>>(a.pts, static_cast<const uint2 *>(a.shadow16), a.compact64,   \
                                                          a.num_hyp, a.hyp_capacity, a.thr2, pf, a.part_count,          \
-                                                         a.part_score);                                                \
+                                                         a.part_score, a.tickets);                                     \
         break;
             switch (P) {
                 PL_M_CASE(1)
@@ -1725,7 +1747,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
 #define PL_Q_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \
         k_score_queue<E, PP><<<qgrid, qblock, 0, stream>>>(a.pts, a.shadow, a.compact64, a.num_hyp, a.hyp_capacity,      \
-                                                         a.thr2, pf, a.part_count, a.part_score);                      \
+                                                         a.thr2, pf, a.part_count, a.part_score, a.tickets);           \
         break;
         switch (P) {
             PL_Q_CASE(1)

@@ -59,7 +59,9 @@ struct ScoreArgs {
     PrefilterArgs pf;          // conservative fp32 pre-filter (pl_prefilter.h); pf.enabled == 0: exact evaluation
     uint32_t *part_count;      // [chunks][hyp_capacity]
     double *part_score;        // [chunks][hyp_capacity]
+    uint32_t *tickets;         // [chunks], zeroed before the launch: work counters of the waves that share a chunk
 };
+constexpr uint32_t kMaxScoreChunks = 4096; // (2^31 correspondences / 64 P would be more; the driver rejects such sets)
 
 struct FinalizeArgs {
     const uint32_t *num_hyp;
