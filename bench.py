@@ -483,6 +483,45 @@ def run_batch_mixed(args, ranks, P, synth):
     return out, ok
 
 
+def run_undistort_stage(args, ranks, P, synth):
+    """BASELINE configs[3] "OPENCV camera model": the pre-processing stage in front of the homography / 7-point
+    estimators (which take no camera) - 2 x 10000 pixels of an OPENCV camera through Camera::unproject on the device
+    (pl_undistort_points; host-resident in and out, PCIe-inclusive), checked against the oracle's unproject."""
+    cam = {"model": "OPENCV", "width": 1000, "height": 1000, "params": [1000.0, 1010.0, 500.0, 505.0, 0.04, -0.015, 8e-4, -6e-4]}
+    d = synth.homography_scene(10000, 0.5, 1003 + ranks.rank)
+    fx, fy, cx, cy = cam["params"][:4]
+    pix = [synth.opencv_distort_pixels(np.c_[fx * (d[k][:, 0] - 500.0) / FOCAL + cx, fy * (d[k][:, 1] - 500.0) / FOCAL + cy],
+                                       cam["params"]) for k in ("x1", "x2")]
+    for _ in range(max(1, args.warmup)):
+        out = [P.undistort_points(cam, p) for p in pix]
+    ranks.barrier()
+    t0 = time.perf_counter()
+    reps = 10 * args.steps
+    for _ in range(reps):
+        out = [P.undistort_points(cam, p) for p in pix]
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    table = ranks.gather([elapsed])
+    if ranks.rank != 0:
+        return None, True
+    t_max = float(table[:, 0].max())
+    rep = {"value": ranks.world * reps * 2 * 10000 / t_max, "unit": "points/s", "calls": reps * 2, "points_per_call": 10000,
+           "ms_per_call": 1e3 * t_max / (reps * 2),
+           "problem": "configs[3] pre-processing: pixels of an OPENCV camera -> Camera::unproject (iterative inverse, "
+                      "camera_models.cc:972-990) -> pixels of the distortion-free camera; host-resident in / out"}
+    ok = True
+    if not args.no_parity:
+        import oracle_lib as O
+
+        worst = 0.0
+        for p, o in zip(pix, out):
+            un = O.unproject(cam, p)
+            worst = max(worst, float(np.abs(o - np.c_[fx * un[:, 0] + cx, fy * un[:, 1] + cy]).max()))
+        ok = worst == 0.0
+        rep["parity"] = {"checked_points": 20000, "max_abs_diff_px": worst, "ok": ok, "against": "oracle unproject + fx u + cx"}
+    return rep, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -535,6 +574,12 @@ def main():
             reports[name], ok = report_workload(name, table, ctx, args, ranks.world)
             all_ok = all_ok and ok
 
+    if not args.no_secondary and not args.shard_problem:
+        rep, ok = run_undistort_stage(args, ranks, P, synth)
+        if ranks.rank == 0:
+            reports["opencv_undistort"] = rep
+            names = names + ["opencv_undistort"]
+            all_ok = all_ok and ok
     if args.batch_problems > 0 and not args.no_secondary and not args.shard_problem:
         rep, ok = run_batch_mixed(args, ranks, P, synth)
         if ranks.rank == 0:

@@ -123,6 +123,12 @@ int pl_estimate_fundamental(const double *points2D_1, const double *points2D_2, 
 int pl_estimate_homography(const double *points2D_1, const double *points2D_2, size_t n, const pl_robust_options *opt,
                            double *H /* 9, column-major */, uint8_t *inliers, pl_ransac_stats *stats);
 
+/* ---- un-distortion as a stage of its own (BASELINE config 3: pixels of an OPENCV camera in front of the homography /
+ * 7-point estimators, which take no camera).  Every point goes through Camera::unproject (misc/camera_models.h:98-102;
+ * OPENCV: the iterative inverse of misc/camera_models.cc:972-990) and comes back as the pixel of the distortion-free
+ * camera with the same focal lengths and principal point: out = (fx u + cx, fy v + cy).  points2D, out: N x 2. ---- */
+int pl_undistort_points(const pl_camera *camera, const double *points2D, size_t n, double *out);
+
 /* ---- batched front-end: an array of independent problems (BASELINE config 4: many image pairs) ----
  * Every item is one call of the matching pl_estimate_* above; `max_in_flight` problems (<= 0: 8) are worked on
  * concurrently by an internal pool of host threads, each with its own HIP stream and scratch arena, on the device the

@@ -121,6 +121,7 @@ def _declare(L):
         "pl_estimate_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
         "pl_estimate_homography": (cint, [vp, vp, sz, opt, vp, vp, stats]),
         "pl_estimate_batch": (cint, [P(BatchItem), sz, cint]),
+        "pl_undistort_points": (cint, [cam, vp, sz, vp]),
         "pl_ransac_pnp": (cint, [vp, vp, sz, opt, pose, vp, stats]),
         "pl_ransac_relpose": (cint, [vp, vp, sz, opt, pose, vp, stats]),
         "pl_ransac_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
@@ -159,5 +160,5 @@ EXPORTED_SYMBOLS = [
     "pl_set_device", "pl_last_error", "pl_version", "pl_estimate_absolute_pose", "pl_estimate_relative_pose",
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
     "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
-    "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch",
+    "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
 ]

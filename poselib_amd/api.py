@@ -548,6 +548,17 @@ def solve_batch(kind: int, first, second):
     return out[:, :, :16].copy(), cnt
 
 
+def undistort_points(camera, points2D):
+    """Pixels of a distorting camera -> pixels of the distortion-free camera with the same focal lengths and principal
+    point (pl_undistort_points: Camera::unproject per point on the device, then fx u + cx, fy v + cy).  The stage in
+    front of estimate_homography / estimate_fundamental, which take no camera."""
+    a = _pts(points2D, 2)
+    out = np.zeros_like(a)
+    c = _as_camera(camera)._c()
+    L.check(L.lib().pl_undistort_points(C.byref(c), _ptr(a), C.c_size_t(a.shape[0]), _ptr(out)))
+    return out
+
+
 def device_count() -> int:
     return L.lib().pl_device_count()
 

@@ -2300,6 +2300,35 @@ int pl_estimate_homography(const double *x1, const double *x2, size_t n, const p
     return PL_OK;
 }
 
+// ---------------------------------------------------------------------------- un-distortion stage
+int pl_undistort_points(const pl_camera *camera, const double *points2D, size_t n, double *out) {
+    if (!camera || !camera_supported(camera) || camera->model_id == CAM_NULL)
+        return fail(PL_ERR_UNSUPPORTED, "camera model not supported (SIMPLE_PINHOLE, PINHOLE, OPENCV)");
+    if (n > 0x7fffffffu)
+        return fail(PL_ERR_INVALID, "too many points");
+    if (n && (!points2D || !out))
+        return fail(PL_ERR_INVALID, "points pointer is null");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    if (n == 0)
+        return PL_OK;
+    const CameraParams cam = to_cam(camera);
+    double fx, fy, cx, cy;
+    if (camera->model_id == CAM_SIMPLE_PINHOLE)
+        fx = fy = cam.p[0], cx = cam.p[1], cy = cam.p[2];
+    else
+        fx = cam.p[0], fy = cam.p[1], cx = cam.p[2], cy = cam.p[3];
+    HIP_TRY(c->raw_a.ensure(sizeof(double) * 2 * n));
+    HIP_TRY(c->raw_b.ensure(sizeof(double) * 2 * n));
+    HIP_TRY(hipMemcpyAsync(c->raw_a.p, points2D, sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_undistort(c->raw_a.as<double>(), (uint32_t)n, cam, fx, fy, cx, cy, c->raw_b.as<double>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->raw_b.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PL_OK;
+}
+
 // ---------------------------------------------------------------------------- minimal solvers
 int pl_solve_batch(int kind, const double *in, size_t count, double *out_models, uint32_t *out_counts) {
     if (kind < 0 || kind > 3)

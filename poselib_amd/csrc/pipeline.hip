@@ -771,6 +771,27 @@ __global__ __launch_bounds__(256) void k_prepare_g(const PrepareGroupArgs *pa) {
     prepare_body(g.a_raw, g.b_raw, g.n, g.args, g.soa, g.absmax_bits);
 }
 
+// Un-distortion as a stage of its own (BASELINE config 3: "OPENCV camera model" in front of the homography / 7-point
+// estimators, which take no camera): pixel -> Camera::unproject (misc/camera_models.cc:1025-1032, the iterative
+// OPENCV inverse :972-990) -> pixel of the distortion-free camera with the same focal lengths and principal point.
+__global__ __launch_bounds__(256) void k_undistort(const double *__restrict__ in, uint32_t n, CameraParams cam, double fx,
+                                                   double fy, double cx, double cy, double *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    double u, v;
+    camera_unproject(cam, in[2 * (size_t)i], in[2 * (size_t)i + 1], u, v);
+    out[2 * (size_t)i] = fx * u + cx;
+    out[2 * (size_t)i + 1] = fy * v + cy;
+}
+hipError_t launch_undistort(const double *in, uint32_t n, const CameraParams &cam, double fx, double fy, double cx,
+                            double cy, double *out, hipStream_t stream) {
+    if (n == 0)
+        return hipSuccess;
+    k_undistort<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(in, n, cam, fx, fy, cx, cy, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------ launchers
 hipError_t launch_shadow16(const uint32_t *num_hyp, const float *shadow_compact, uint32_t hyp_capacity, float g16,
                            float c16, float thr, void *shadow16, hipStream_t stream) {

@@ -143,6 +143,9 @@ struct PrepareArgs {
 };
 hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, const PrepareArgs &args, double *soa,
                           unsigned long long *absmax_bits, hipStream_t stream);
+// pixels of a distorting camera -> pixels of the distortion-free camera with the same focal lengths / principal point
+hipError_t launch_undistort(const double *in, uint32_t n, const CameraParams &cam, double fx, double fy, double cx,
+                            double cy, double *out, hipStream_t stream);
 // After the LM kernels: records of the refined models on the device (skipped tasks keep their input record), and the
 // choice "refined model if its score beats `incumbent_score`, else the incumbent" of the final refinement
 // (ransac_impl.h:190-198) so that the inlier mask can follow without a host round trip.

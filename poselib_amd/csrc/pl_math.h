@@ -6,17 +6,8 @@
 // Reference semantics followed: PoseLib/misc/quaternion.h:36-104 (R<->q through Eigen's
 // Quaterniond, real part first), PoseLib/camera_pose.h:40-68.
 #pragma once
-#include <math.h>
-#include <stdint.h>
-
-#if defined(__HIPCC__)
-#include <hip/hip_runtime.h>
-#define PL_HD __host__ __device__ __forceinline__
-#define PL_UNROLL _Pragma("unroll") // small constant-trip loops over register arrays: no dynamic indexing -> no scratch
-#else
-#define PL_HD inline
-#define PL_UNROLL
-#endif
+#include "pl_defs.h"
+#include "pl_libm.h"
 
 namespace pl {
 
@@ -194,8 +185,8 @@ PL_HD Quat quat_exp(Vec3 w) { // quaternion.h:73-96
     const double th = sqrt(th2);
     double re, im;
     if (th > 1e-6) {
-        re = cos(0.5 * th);
-        im = sin(0.5 * th) / th;
+        re = pl_cos(0.5 * th); // (pl_libm.h: rounds like the reference's host libm)
+        im = pl_sin(0.5 * th) / th;
     } else {
         const double th4 = th2 * th2;
         re = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;

@@ -10,7 +10,6 @@
 // The coefficient block of p3p() below follows PoseLib/solvers/p3p.cc:77-101 operation for operation (BSD-3 source):
 // the arithmetic ORDER is what bit-parity with the reference requires, so that part is a transliteration by design.
 #pragma once
-#include "pl_libm.h"
 #include "pl_math.h"
 
 namespace pl {
@@ -28,7 +27,7 @@ PL_HD bool cubic_one_real_root(double c2, double c1, double c0, double &root) {
             return true;
         }
         c = 3.0 * b / (2.0 * a) * sqrt(-3.0 / a);
-        root = 2.0 * sqrt(-a / 3.0) * cos(acos(c) / 3.0) - c2 / 3.0;
+        root = 2.0 * sqrt(-a / 3.0) * pl_cos(pl_acos(c) / 3.0) - c2 / 3.0;
         return false;
     }
     root = -c2 / 3.0 + (a != 0 ? (3.0 * b / a) : 0);

@@ -15,7 +15,6 @@
 // The orthonormal null-space basis follows the algorithm of Eigen's fullPivHouseholderQr().matrixQ()
 // (pivot = largest |a_ij| of the trailing corner, first maximum in column-major order).
 #pragma once
-#include "pl_libm.h"
 #include "pl_math.h"
 
 namespace pl {
@@ -46,9 +45,9 @@ PL_HD int cubic_real_roots(double c2, double c1, double c0, double *r) {
     } else {
         c = 3.0 * b / (2.0 * a) * sqrt(-3.0 / a);
         const double d = 2.0 * sqrt(-a / 3.0);
-        r[0] = d * cos(acos(c) / 3.0) - c2 / 3.0;
-        r[1] = d * cos(acos(c) / 3.0 - 2.09439510239319526263557236234192) - c2 / 3.0;
-        r[2] = d * cos(acos(c) / 3.0 - 4.18879020478639052527114472468384) - c2 / 3.0;
+        r[0] = d * pl_cos(pl_acos(c) / 3.0) - c2 / 3.0;
+        r[1] = d * pl_cos(pl_acos(c) / 3.0 - 2.09439510239319526263557236234192) - c2 / 3.0;
+        r[2] = d * pl_cos(pl_acos(c) / 3.0 - 4.18879020478639052527114472468384) - c2 / 3.0;
         n = 3;
     }
     for (int i = 0; i < n; ++i) {

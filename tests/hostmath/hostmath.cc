@@ -364,4 +364,55 @@ uint64_t hm_cbrt_mismatches(uint64_t count, uint64_t seed, int mode, double *fir
 }
 double hm_cbrt(double x) { return pl_cbrt(x); }
 
+// which: 0 acos on (-1, 1) incl. the interval edges of its piecewise expansion, 1 cos on [-6, 6] and tiny arguments,
+// 2 sin on [-2.4, 2.4] and tiny arguments: arguments on which pl_libm.h and the host's libm differ in any bit
+uint64_t hm_libm_mismatches(int which, uint64_t count, uint64_t seed, double *first_bad) {
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 88172645463325252ull, bad = 0;
+    auto rnd = [&]() {
+        s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+        return s;
+    };
+    static const uint64_t edges[] = {0x3fc00000, 0x3fd00000, 0x3fe00000, 0x3fe80000, 0x3fed8000, 0x3fee8000, 0x3fef0000, 0x3ff00000};
+    for (uint64_t i = 0; i < count; ++i) {
+        const double u = (double)(rnd() >> 11) / 9007199254740992.0;
+        double x, mine, host;
+        if (which == 0) {
+            switch (i % 5) {
+            case 0:
+                x = 2 * u - 1;
+                break;
+            case 1:
+                x = (u < 0.5 ? -1 : 1) * (1 - std::ldexp(u, -(int)(rnd() % 40)));
+                break;
+            case 2:
+                x = std::ldexp(2 * u - 1, -(int)(rnd() % 60));
+                break;
+            case 3:
+                x = (0.96875 + u * 0.03125) * ((rnd() & 1) ? 1 : -1);
+                break;
+            default: {
+                uint64_t b = edges[rnd() % 8] << 32;
+                b += (int64_t)(rnd() % 2000) - 1000;
+                std::memcpy(&x, &b, 8);
+                if (rnd() & 1)
+                    x = -x;
+            }
+            }
+            mine = pl_acos(x), host = std::acos(x);
+        } else if (which == 1) {
+            x = (i % 3 == 0) ? (u * 12 - 6) : (i % 3 == 1) ? u * 1.0472 : std::ldexp(2 * u - 1, -(int)(rnd() % 40));
+            mine = pl_cos(x), host = std::cos(x);
+        } else {
+            x = (i % 3 == 0) ? (u * 4.8 - 2.4) : (i % 3 == 1) ? u * 0.5 : std::ldexp(2 * u - 1, -(int)(rnd() % 40));
+            mine = pl_sin(x), host = std::sin(x);
+        }
+        if (std::memcmp(&mine, &host, 8) != 0 && !(mine != mine && host != host)) {
+            if (!bad && first_bad)
+                *first_bad = x;
+            ++bad;
+        }
+    }
+    return bad;
+}
+
 } // extern "C"

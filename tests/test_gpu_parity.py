@@ -51,9 +51,9 @@ def test_p3p_batch_matches_oracle(gpu):
         for m in range(len(ref)):
             worst = max(worst, np.abs(rec[i, m, :7] - ref[m]).max())
     print("p3p: max |pose diff| device vs oracle =", worst)
-    # cbrt is glibc's algorithm on the device (pl_libm.h, bit-identical); acos / cos of the three-real-root branch of the
-    # cubic are ocml's and may differ from glibc's in the last bit, amplified by the conditioning of the sample
-    assert worst < 1e-11, worst
+    # bit for bit: cbrt / acos / cos of the cubic are glibc's algorithms on the device (pl_libm.h), everything else is
+    # IEEE add / mul / div / sqrt in the oracle's order
+    assert worst == 0.0, worst
 
 
 def test_single_solver_entry_points(gpu):
@@ -133,12 +133,9 @@ def test_two_view_solver_batches(gpu, kind, name, K):
     # The device solvers are the oracle's arithmetic operation for operation (tests/test_hostmath_vs_oracle.py checks the
     # same headers bit for bit on the host): -ffp-contract=off on both sides, IEEE division and square root.  The 5-point
     # and the homography solvers call nothing but sqrt from libm, so they must agree to the bit; the 7-point solver's
-    # cubic goes through cbrt (pl_libm.h: glibc's algorithm, bit-identical) or acos / cos (ocml).
+    # cubic goes through cbrt or acos / cos, which pl_libm.h restates from glibc (bit-identical to the host's libm).
     assert mismatched == 0
-    if name == "fund":
-        assert worst < 1e-11, worst  # the cubic's acos / cos branch (ocml vs glibc: last bit), see test_p3p_batch_matches_oracle
-    else:
-        assert worst == 0.0, worst
+    assert worst == 0.0, worst
 
 # ------------------------------------------------------------------------------------------ scoring / refinement
 def test_score_and_refine_match_oracle(gpu):
@@ -508,11 +505,10 @@ def test_sampler_with_frequent_redraws(gpu, n):
     segments per batch it must fall back to the host walk) - long fixed-length runs must still follow the
     reference's draw stream exactly.  With so few correspondences the same sample recurs in permuted order and its
     models tie to the last bits of the MSAC score: `refinements` only agrees because every score
-    a decision is taken on is summed in the reference's order (k_score_seq).  For P3P the tie can still break
-    differently below 24 correspondences: the device's cbrt / acos / cos (ocml) round differently from glibc's, so the
-    tied models themselves differ in their last bits."""
+    a decision is taken on is summed in the reference's order (k_score_seq) and because the tied models themselves are
+    bit-identical to the oracle's - the device's cbrt / acos / cos are glibc's algorithms (pl_libm.h)."""
     refs = lambda a, b: a == b  # noqa: E731
-    refs_p3p = refs if n >= 24 else (lambda a, b: True)
+    refs_p3p = refs
     opt = {"ransac": {"seed": 5 + n, "max_iterations": 30000, "min_iterations": 30000}}
     r = synth.relative_pose_scene(max(n, 8), 0.25, 70 + n)
     F, info = gpu.estimate_fundamental(r["x1"][:n], r["x2"][:n], opt)

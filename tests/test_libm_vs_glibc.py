@@ -1,8 +1,11 @@
-"""poselib_amd/csrc/pl_libm.h against the host's libm (glibc 2.35 in this image): the device's cbrt is glibc's algorithm
-(sysdeps/ieee754/dbl-64/s_cbrt.c) restated as plain IEEE operations, so that the cubic of the P3P / 7-point solvers
-(PoseLib/misc/univariate.cc:82, 86, 107) rounds like the reference's host library.  The very header hipcc compiles is
-compiled for the host (tests/hostmath) and compared bit for bit on 1.2e7 arguments: every bit pattern class, the
-range the solvers use, 120 binades, subnormals."""
+"""poselib_amd/csrc/pl_libm.h against the host's libm (glibc 2.35 in this image): cbrt, acos, cos (and sin) on the device
+are glibc's algorithms (sysdeps/ieee754/dbl-64/s_cbrt.c, e_asin.c, s_sin.c) restated as explicit IEEE operation sequences,
+so that the cubics of the P3P / 7-point solvers (PoseLib/misc/univariate.cc:82, 86, 107-124) and the quaternion
+exponential of the refiners round like the reference's host library.  The very header hipcc compiles is compiled for the
+host (tests/hostmath) and compared BIT FOR BIT with libm: cbrt on 1.2e7 arguments (every bit pattern class, 120 binades,
+subnormals), acos on 2e7 (all of (-1, 1), the neighbourhoods of +-1 and of 0, the edges of its piecewise expansion),
+cos and sin on 1.5e7 each.  acos / cos / sin follow the variant glibc selects on hosts with FMA (as this image's and the
+GPU box's hosts are): on a host without FMA libm itself takes another code path and the last bit may differ."""
 import ctypes as C
 import math
 
@@ -26,3 +29,24 @@ def test_cbrt_is_bit_identical_to_glibc():
         assert L.hm_cbrt(x) == libm.cbrt(x), x
     assert math.copysign(1.0, L.hm_cbrt(-0.0)) == -1.0 and L.hm_cbrt(0.0) == 0.0
     assert L.hm_cbrt(math.inf) == math.inf and L.hm_cbrt(-math.inf) == -math.inf and math.isnan(L.hm_cbrt(math.nan))
+
+
+def _has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return True
+
+
+def test_acos_cos_sin_are_bit_identical_to_glibc():
+    import pytest
+
+    if not _has_fma():
+        pytest.skip("host without FMA: glibc runs its sse2 variants of acos / cos / sin here")
+    L = HM.lib()
+    L.hm_libm_mismatches.restype = C.c_uint64
+    L.hm_libm_mismatches.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
+    for which, name, count in ((0, "acos", 20_000_000), (1, "cos", 15_000_000), (2, "sin", 15_000_000)):
+        bad_x = C.c_double(0.0)
+        bad = L.hm_libm_mismatches(which, count, 3 + which, C.byref(bad_x))
+        assert bad == 0, (name, bad, bad_x.value.hex())
