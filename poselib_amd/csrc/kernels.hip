@@ -768,7 +768,7 @@ constexpr int kMfmaThreads = PL_MFMA_THREADS; // 8 wavefronts share one chunk of
 
 template <int PG>
 __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2 *__restrict__ shadow16,
-                                                const double *__restrict__ compact64,
+                                                const double *__restrict__ models, const uint32_t *__restrict__ slots,
                                                 const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
                                                 double thr2, const PrefilterArgs &pf, uint32_t *__restrict__ part_count,
                                                 double *__restrict__ part_score, uint32_t slice, uint32_t chunk,
@@ -868,7 +868,9 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
 #pragma unroll
             for (int d = 0; d < 5; ++d)
                 x[d] = s_pts[d][pi];
-            const double *Mp = compact64 + (size_t)(kb + (act ? g : 0u)) * kModelDoubles;
+            // the fp64 model straight from its record (hypothesis k lives in slot slots[k]; the records of consecutive
+            // hypotheses are neighbours in memory): no hypothesis-ordered copy of the models is needed on this path
+            const double *Mp = models + (size_t)slots[kb + (act ? g : 0u)] * kModelStride;
             double M[kModelDoubles];
 #pragma unroll
             for (int i = 0; i < kModelDoubles; ++i)
@@ -970,15 +972,16 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
 
 template <int PG>
 __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma(PointSet pts, const uint2 *__restrict__ shadow16,
-                                                               const double *__restrict__ compact64,
+                                                               const double *__restrict__ models,
+                                                               const uint32_t *__restrict__ slots,
                                                                const uint32_t *__restrict__ num_hyp_ptr,
                                                                uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
                                                                uint32_t *__restrict__ part_count,
                                                                double *__restrict__ part_score,
                                                                uint32_t *__restrict__ tickets) {
     (void)tickets;
-    score_mfma_body<PG>(pts, shadow16, compact64, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score, blockIdx.x,
-                        blockIdx.y, gridDim.x);
+    score_mfma_body<PG>(pts, shadow16, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score,
+                        blockIdx.x, blockIdx.y, gridDim.x);
 }
 template <int PG>
 __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma_g(const GroupArgs *ga) {
@@ -986,8 +989,8 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
     if (!g.active || !g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
         return;
     const ScoreArgs &a = g.score;
-    score_mfma_body<PG>(a.pts, static_cast<const uint2 *>(a.shadow16), a.compact64, a.num_hyp, a.hyp_capacity, a.thr2, a.pf,
-                        a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
+    score_mfma_body<PG>(a.pts, static_cast<const uint2 *>(a.shadow16), a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,
+                        a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
 }
 
 // ---- MSAC score in the reference's summation order ------------------------------------------------------------------
@@ -1715,7 +1718,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     uint32_t chunks;
     int P;
     const PrefilterArgs pf = a.pf;
-    const bool streaming = a.shadow && a.compact64; // batched main loop: compact hypothesis stream
+    const bool streaming = (a.shadow && a.compact64) || a.shadow16; // batched main loop: hypothesis stream
     score_shape(E, a.pts.n, streaming, chunks, P);
     if constexpr (E == EST_ABS) {
         if (streaming && a.shadow16) { // pre-filter on the matrix cores (PG = 2 P groups of 32 points per wave)
@@ -1723,9 +1726,9 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
             const dim3 mblock(kMfmaThreads);
 #define PL_M_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \
-        k_score_mfma<2 * PP><<<mgrid, mblock, 0, stream>>>(a.pts, static_cast<const uint2 *>(a.shadow16), a.compact64,   \
-                                                         a.num_hyp, a.hyp_capacity, a.thr2, pf, a.part_count,          \
-                                                         a.part_score, a.tickets);                                     \
+        k_score_mfma<2 * PP><<<mgrid, mblock, 0, stream>>>(a.pts, static_cast<const uint2 *>(a.shadow16), a.models,      \
+                                                         a.slots, a.num_hyp, a.hyp_capacity, a.thr2, pf,               \
+                                                         a.part_count, a.part_score, a.tickets);                       \
         break;
             switch (P) {
                 PL_M_CASE(1)

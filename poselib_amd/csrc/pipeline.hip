@@ -97,7 +97,8 @@ template <int K> __global__ __launch_bounds__(256) void k_sample_delta_g(const G
 }
 
 constexpr int kMaxSegments = 4096;
-constexpr int kMaxFlags = 12288; // flagged positions kept in LDS (position + delta + successor); more => host fallback
+constexpr int kMaxFlags = 8192;  // flagged positions kept in LDS (position + delta + successor); more => host fallback
+constexpr int kParFlags = 4096;  // up to this many flags the orbit is followed by pointer doubling (all lanes)
 constexpr int kOrbitWords = 4;   // bitmap words per lane and tile of phase 1
 
 __device__ __forceinline__ uint32_t div_k(uint32_t x, int K) { // constant divisors compile to a multiply-high
@@ -122,6 +123,10 @@ __device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const ui
     __shared__ uint32_t seg_iter[kMaxSegments];
     __shared__ uint32_t seg_pos[kMaxSegments];
     __shared__ uint32_t s_nseg, s_nflags, s_error, s_entry;
+    // pointer doubling over the flags (phase 2b, parallel form)
+    __shared__ uint32_t pj_w[kParFlags], pj_rank[kParFlags];
+    __shared__ uint16_t pj_next[kParFlags], pj_hops[kParFlags];
+    __shared__ uint8_t pj_mark[kParFlags];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     // ---- phase 1: ordered list (in LDS) of the positions whose iteration would redraw (delta != K), from the
@@ -198,8 +203,84 @@ __device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const ui
     }
     __syncthreads();
 
-    // ---- phase 2b: one lane follows the successor links and emits (iteration, position) segments ----
-    if (threadIdx.x == 0) {
+    // ---- phase 2b: the orbit through the flags, as (iteration, position) segments.  A flag j visited by the orbit
+    // starts a segment at iteration it_j = it_prev + (q_j - cur_prev) / K + 1 with position cur_j = q_j + delta_j.
+    // Up to kParFlags flags the successor links are followed by POINTER DOUBLING: every flag carries its 2^k-th successor
+    // and the iterations that lie between; the flags reachable from the entry are marked round by round (after round k
+    // all flags within 2^(k+1) hops) and receive their iteration index and hop count on the way - 12 rounds of all
+    // lanes instead of one lane hopping ~300 times through LDS (22 us -> 4 us at config 1).  Beyond that: one lane. ----
+    if (!s_error && F <= (uint32_t)kParFlags) {
+        constexpr int kPer = kParFlags / 1024;
+        const uint32_t entry = s_entry;
+        for (uint32_t j = threadIdx.x; j < F; j += 1024u) {
+            const uint32_t nj = flag_next[j];
+            pj_next[j] = (uint16_t)nj;
+            pj_w[j] = nj != 0xffffu ? div_k(flag_pos[nj] - (flag_pos[j] + (uint32_t)flag_delta[j]), K) + 1u : 0u;
+            pj_mark[j] = j == entry ? 1 : 0;
+            pj_rank[j] = j == entry ? div_k(flag_pos[j], K) + 1u : 0u;
+            pj_hops[j] = 0;
+        }
+        if (threadIdx.x == 0) {
+            s_nseg = 1;
+            seg_iter[0] = 0;
+            seg_pos[0] = 0;
+        }
+        __syncthreads();
+        for (uint32_t step = 1; step < F; step <<= 1) { // (wave-uniform trip count)
+            uint32_t nj[kPer], wj[kPer], nn[kPer], wn[kPer], rk[kPer], hp[kPer];
+            bool mk[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const uint32_t j = threadIdx.x + 1024u * u;
+                nj[u] = 0xffffu;
+                if (j < F) {
+                    nj[u] = pj_next[j], wj[u] = pj_w[j], mk[u] = pj_mark[j] != 0, rk[u] = pj_rank[j], hp[u] = pj_hops[j];
+                    if (nj[u] != 0xffffu)
+                        nn[u] = pj_next[nj[u]], wn[u] = pj_w[nj[u]];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const uint32_t j = threadIdx.x + 1024u * u;
+                if (j < F && nj[u] != 0xffffu) {
+                    if (mk[u]) { // (the marked flags lie on one path: their successors are distinct)
+                        pj_mark[nj[u]] = 1;
+                        pj_rank[nj[u]] = rk[u] + wj[u];
+                        pj_hops[nj[u]] = (uint16_t)(hp[u] + step);
+                    }
+                    pj_next[j] = (uint16_t)nn[u];
+                    pj_w[j] = wj[u] + wn[u];
+                }
+            }
+            __syncthreads();
+        }
+        // segments of the visited flags whose iteration still belongs to the batch (the serial walk stops at the first
+        // one that does not); their hop count is their place in the table
+        for (uint32_t j = threadIdx.x; j < F; j += 1024u) {
+            if (!pj_mark[j] || pj_rank[j] > B)
+                continue;
+            const uint32_t idx = (uint32_t)pj_hops[j] + 1u;
+            if (flag_delta[j] == 255u || idx >= (uint32_t)kMaxSegments) {
+                s_error = 1;
+                continue;
+            }
+            seg_iter[idx] = pj_rank[j];
+            seg_pos[idx] = flag_pos[j] + (uint32_t)flag_delta[j];
+            atomicMax(&s_nseg, idx + 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t err = s_error;
+            const uint32_t s = s_nseg - 1;
+            const uint64_t end = (uint64_t)seg_pos[s] + (uint64_t)(B - seg_iter[s]) * (uint64_t)K;
+            if (end + 255 > M)
+                err = 1; // the window of evaluated positions was too small: the host retries / falls back
+            ctl->pos_after = pos_base + end;
+            ctl->orbit_error = err;
+            s_error = err;
+        }
+    } else if (threadIdx.x == 0) {
         uint32_t nseg = 1, err = s_error;
         seg_iter[0] = 0;
         seg_pos[0] = 0;
@@ -692,7 +773,7 @@ __global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, 
     const uint64_t cap = (uint64_t)g.comp.B * (uint64_t)g.comp.maxm;
     if (blockIdx.x < gather_blocks_max) {
         const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-        if (t < cap * 12u)
+        if (!g.comp.s16.out && t < cap * 12u) // (the matrix-core scorer reads the records themselves)
             gather_one(g.comp.ctl, g.comp.slots, g.comp.models, g.comp.shadow, g.comp.compact64, t);
         return;
     }
@@ -844,17 +925,17 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
         k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
     k_compact2<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, maxm, blk_tot, slots, offsets, models, shadow_compact,
                                                     compact64, ctl);
-    if (shadow_compact && compact64) {
+    if (s16.out) {
+        // matrix-core scorer: its fp16 operand blocks are built straight from the records, and its exact pass reads the
+        // fp64 models from the records as well - no hypothesis-ordered copies
+        const uint32_t cap8 = (uint32_t)(((uint64_t)B * (uint64_t)maxm + 7u) & ~7ull);
+        k_gather_shadow16<<<dim3((cap8 + 255) / 256), dim3(256), 0, stream>>>(ctl, slots, models, nullptr, nullptr, 0u, cap8,
+                                                                            s16.g16, s16.c16, s16.thr,
+                                                                            static_cast<uint2 *>(s16.out));
+    } else if (shadow_compact && compact64) {
         const uint64_t threads = (uint64_t)B * (uint64_t)maxm * 12u; // capacity; lanes beyond num_hyp return at once
-        const uint32_t gblocks = (uint32_t)((threads + 255) / 256);
-        if (s16.out) {
-            const uint32_t cap8 = (uint32_t)(((uint64_t)B * (uint64_t)maxm + 7u) & ~7ull);
-            k_gather_shadow16<<<dim3(gblocks + (cap8 + 255) / 256), dim3(256), 0, stream>>>(
-                ctl, slots, models, shadow_compact, compact64, gblocks, cap8, s16.g16, s16.c16, s16.thr,
-                static_cast<uint2 *>(s16.out));
-        } else {
-            k_gather_models<<<dim3(gblocks), dim3(256), 0, stream>>>(ctl, slots, models, shadow_compact, compact64);
-        }
+        k_gather_models<<<dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream>>>(ctl, slots, models,
+                                                                                          shadow_compact, compact64);
     }
     return hipGetLastError();
 }
