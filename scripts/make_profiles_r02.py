@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Assemble the committed profiles/r02_* summaries from the outputs of scripts/gpu_evidence_r02.sh
+(gpurun_out/evidence_r02) and refresh profiles/pmc_traffic.json (the PMC constants bench.py's roofline uses)."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EV = os.path.join(ROOT, "gpurun_out", "evidence_r02")
+PR = os.path.join(ROOT, "profiles")
+TAG = "r02"
+WORK = {"p3p_5000": ("k_score_mfma<10>", 320, 5000), "relpose_5000": ("k_score_queue<1, 6>", 384, 5000),
+        "fund_10000": ("k_score_queue<2, 6>", 384, 10000), "hom_10000": ("k_score_queue<3, 5>", 320, 10000)}
+
+
+def rd(name):
+    return open(os.path.join(EV, name)).read()
+
+
+def bench(name):
+    return json.loads(rd(name + ".json").strip().splitlines()[-1])
+
+
+def rows(md):
+    lines = [ln for ln in md.splitlines() if ln.startswith("|")]
+    cols = [c.strip() for c in lines[0].strip().strip("|").split("|")]
+    out = []
+    for ln in lines[2:]:
+        cells = [c.strip() for c in ln.strip().strip("|").split("|")]
+        out.append(dict(zip(cols, cells)))
+    return out
+
+
+def find(rws, kernel, launches=None):
+    for r in rws:
+        if r["kernel"].strip("`").replace("pl::", "") == kernel and (launches is None or r.get("launches") == launches):
+            return r
+    return None
+
+
+def main():
+    d = bench("bench_default")
+    s1 = bench("bench_s1")
+    out = {}
+    line = dict(d)
+    out[f"{TAG}_bench_line.json"] = json.dumps(line, indent=1) + "\n"
+    reports = {"p3p_5000": {"roofline": d["roofline"], "value": d["value"]}}
+    reports.update({k: v for k, v in d["config"]["secondary"].items()})
+    # ---- kernel-trace summaries ----
+    p16 = rd("prof_default.md")
+    r16 = find(rows(p16), "k_score_mfma<10>", "full batch")
+    out[f"{TAG}_bench_default_16streams_kernel_trace.md"] = (
+        f"# {TAG} — `python bench.py` (primary workload p3p_5000, 16 problems in flight, 1024 per step) under rocprofv3 --kernel-trace --stats\n\n"
+        "Command (GPU box, from /tmp): `rocprofv3 --kernel-trace --stats -d ... -- python bench.py --no-parity --no-cpu-baseline "
+        "--no-secondary --steps 5` (scripts/gpu_evidence_r02.sh).\n"
+        f"bench.py of the same configuration (full default run, profiles/{TAG}_bench_line.json): {d['value']:.4g} hypotheses/s, "
+        f"roofline.avg_launch_ms = {d['roofline']['avg_launch_ms']:.3f} (HIP events, 16 launches sharing the device); rocprof average "
+        f"of the same kernel below: {float(r16['avg us']) / 1e3:.3f} ms.\n\n" + p16 +
+        "\n## Device occupancy of the same configuration (scripts/busy.py on the csv kernel trace)\n\n```\n" + rd("busy_default.txt") + "```\n")
+    p1 = rd("prof_s1.md")
+    r1 = find(rows(p1), "k_score_mfma<10>", "full batch")
+    hpl = s1["roofline"]["hypotheses_per_launch"]
+    out[f"{TAG}_bench_p3p5000_1stream_kernel_trace.md"] = (
+        f"# {TAG} — `python bench.py --streams 1` under rocprofv3 --kernel-trace --stats (one problem at a time)\n\n"
+        f"bench.py of the same configuration: {s1['value']:.4g} hypotheses/s = {1e3 * hpl / s1['value']:.3f} ms per 100000-iteration "
+        f"problem (Python call overhead included), roofline.solo_avg_launch_ms = {s1['roofline']['solo_avg_launch_ms']:.4f}; rocprof "
+        f"average of k_score_mfma<10> below: {float(r1['avg us']) / 1e3:.4f} ms ({hpl / 1e3:.1f} k hypotheses x 5000 correspondences per "
+        f"launch = {hpl * 5000 / (float(r1['avg us']) * 1e-6):.3g} point-hypotheses/s).\n\n" + p1 +
+        "\n## One problem in time order (scripts/timeline.py: start offset, duration, gap to the previous kernel's end)\n\n```\n" + rd("timeline_s1.txt") + "```\n")
+    for w in ("relpose_5000", "fund_10000", "hom_10000"):
+        b = reports[w]
+        out[f"{TAG}_bench_{w}_1stream_kernel_trace.md"] = (
+            f"# {TAG} — `python bench.py --workload {w} --streams 1 --steps 3` under rocprofv3 --kernel-trace --stats\n\n"
+            f"bench.py (16 problems in flight, profiles/{TAG}_bench_line.json config.secondary.{w}): {b['value']:.4g} hypotheses/s, "
+            f"{b['iterations_per_s']:.4g} iterations/s; dominant kernel with the device to itself {b['roofline']['solo_avg_launch_ms']:.4f} ms "
+            f"per {b['roofline']['hypotheses_per_launch'] / 1e3:.1f} k hypotheses.\n\n" + rd(f"prof_{w}.md"))
+    bm = reports.get("batch_mixed", {})
+    out[f"{TAG}_bench_batch_mixed_kernel_trace.md"] = (
+        f"# {TAG} — `python bench_batch.py --problems 4096 --streams 8 --steps 2` (configs[4], grouped launches) under rocprofv3 --kernel-trace --stats\n\n"
+        f"bench.py's batch_mixed leg of the default run: {bm.get('problems_per_s', 0):.5g} problems/s ({bm.get('value', 0):.4g} hypotheses/s, "
+        f"2048 problems per step, 8 host threads).  Kernels with the suffix _g are the group launches (problem index = blockIdx.z); "
+        "the others serve the few problems that leave the group path.\n\n" + rd("prof_batch.md") +
+        "\n## Device occupancy (scripts/busy.py)\n\n```\n" + rd("busy_batch.txt") + "```\n")
+    # ---- PMC ----
+    traffic = {"_comment": "PMC constants of the dominant kernels (the streaming scorers), measured with rocprofv3 --pmc in separate passes "
+               "(scripts/gpu_evidence_r02.sh; summaries in profiles/r02_pmc_*.md), one problem at a time. FETCH_SIZE (KB) is doubled per "
+               "MI355X_MICROARCH.md (gfx950 under-reports wide streaming reads by 2x); WRITE_SIZE (KB) is taken as is. "
+               "valu_insts_per_hypothesis_chunk = SQ_INSTS_VALU of one launch / (hypotheses x point chunks of the launch): bench.py's "
+               "valu_issue roofline multiplies it back with the hypotheses and chunks of its own launches; it cannot re-measure it "
+               "(PMC needs the profiler)."}
+    for w, (kernel, chunk_pts, n) in WORK.items():
+        md = rd(f"pmc_{w}.md")
+        r = find(rows(md), kernel, "full batch")
+        f = lambda k: float(r[k])
+        hyp = reports[w]["roofline"]["hypotheses_per_launch"]
+        chunks = (n + chunk_pts - 1) // chunk_pts
+        cycles = f("GRBM_GUI_ACTIVE") / 8
+        valu_busy = f("SQ_ACTIVE_INST_VALU") * 4 / 1024 / cycles
+        mfma_busy = f("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / cycles if "SQ_VALU_MFMA_BUSY_CYCLES" in r and r["SQ_VALU_MFMA_BUSY_CYCLES"] else 0.0
+        traffic[w] = {"kernel": kernel, "fetch_size_kb": f("FETCH_SIZE"), "write_size_kb": f("WRITE_SIZE"),
+                      "traffic_bytes_per_launch": (2 * f("FETCH_SIZE") + f("WRITE_SIZE")) * 1024.0, "hypotheses_per_launch": hyp,
+                      "points_per_chunk": chunk_pts, "valu_insts_per_launch": f("SQ_INSTS_VALU"),
+                      "valu_insts_per_hypothesis_chunk": f("SQ_INSTS_VALU") / (hyp * chunks), "valu_busy": round(valu_busy, 3),
+                      "mfma_busy": round(mfma_busy, 3), "kernel_cycles": cycles, "source": f"profiles/{TAG}_pmc_{w}.md"}
+        out[f"{TAG}_pmc_{w}.md"] = (
+            f"# {TAG} — PMC counters, workload {w} (`python bench.py --workload {w} --streams 1 --steps 2 --warmup 1 --no-parity "
+            "--no-cpu-baseline --no-secondary`; counters in separate rocprofv3 --pmc passes with --kernel-trace only)\n\n"
+            f"Dominant kernel `{kernel}`: {hyp / 1e3:.1f} k hypotheses x {n} correspondences per launch in {chunks} chunks of {chunk_pts}; "
+            f"GRBM_GUI_ACTIVE / 8 = {cycles:.4g} cycles; SQ_INSTS_VALU = {f('SQ_INSTS_VALU'):.4g} = "
+            f"{f('SQ_INSTS_VALU') / (hyp * chunks):.1f} per (hypothesis, chunk); SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs = "
+            f"{f('SQ_ACTIVE_INST_VALU') * 4 / 1024:.4g} cycles = {100 * valu_busy:.0f} % VALU-busy"
+            + (f"; matrix pipe {100 * mfma_busy:.0f} % busy" if mfma_busy else "") +
+            f"; HBM: FETCH_SIZE {f('FETCH_SIZE') / 1024:.1f} MB (x2 on gfx950) + WRITE_SIZE {f('WRITE_SIZE') / 1024:.1f} MB = "
+            f"{(2 * f('FETCH_SIZE') + f('WRITE_SIZE')) / 1024:.0f} MB per launch.\n\nPer-launch averages of every kernel of the pass:\n\n" + md)
+    for name, text in out.items():
+        open(os.path.join(PR, name), "w").write(text)
+        print("wrote", name)
+    json.dump(traffic, open(os.path.join(PR, "pmc_traffic.json"), "w"), indent=1)
+    for w in WORK:
+        t = traffic[w]
+        print(w, "valu/hyp-chunk", round(t["valu_insts_per_hypothesis_chunk"], 2), "valu_busy", t["valu_busy"], "mfma", t["mfma_busy"],
+              "traffic MB", round(t["traffic_bytes_per_launch"] / 1e6, 1))
+
+
+if __name__ == "__main__":
+    main()
