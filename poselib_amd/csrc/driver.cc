@@ -118,6 +118,8 @@ struct Context {
     HostBuf h_rec_meta;
     HostBuf h_absmax, h_positions, h_num_models, h_count, h_score, h_tasks, h_gather_idx, h_gather_out, h_mask,
         h_small;
+    HostBuf h_flag;        // completion flag of wait_stream(): the stream writes a sequence number, the host spins on it
+    uint32_t flag_seq = 0;
 };
 
 constexpr uint32_t kIotaEntries = 4097;
@@ -180,6 +182,10 @@ int get_context(Context **out) {
         HIP_TRY(c->iota.ensure(sizeof(uint32_t) * kIotaEntries));
         HIP_TRY(hipMemcpy(c->iota.p, iota.data(), sizeof(uint32_t) * kIotaEntries, hipMemcpyHostToDevice));
     }
+    if (c->h_flag.ensure(64) == hipSuccess)
+        *c->h_flag.as<uint32_t>() = 0;
+    else
+        (void)hipGetLastError(); // (wait_stream falls back to hipStreamSynchronize)
     guard.c = nullptr;
     g_ctx = c;
     *out = c;
@@ -187,6 +193,43 @@ int get_context(Context **out) {
 }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Wait for everything enqueued on the context's stream.  Default: hipStreamSynchronize.  POSELIB_AMD_SPIN_SYNC=1: the
+// stream itself writes a sequence number into pinned host memory behind the work (hipStreamWriteValue32: ordered like a
+// kernel) and the host spins on that word (after 2 ms without progress it yields between polls, after 5 s it falls back
+// to hipStreamSynchronize, which also reports a device fault instead of spinning for ever).  Measured on MI355X: one
+// problem at a time 0.768 -> 0.743 ms per 100000-iteration P3P problem (three synchronisations each), but -13 % on the
+// grouped batch (8 host threads) and -1 % with 16 problems in flight - the runtime's own wait already polls - so it is
+// opt-in for latency-bound single-problem use.
+hipError_t wait_stream(Context *c) {
+    static const bool spin = std::getenv("POSELIB_AMD_SPIN_SYNC") != nullptr;
+    if (!spin || !c->h_flag.p)
+        return hipStreamSynchronize(c->stream);
+    const uint32_t seq = ++c->flag_seq;
+    hipError_t e = hipStreamWriteValue32(c->stream, c->h_flag.dp, seq, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return hipStreamSynchronize(c->stream);
+    }
+    volatile uint32_t *flag = c->h_flag.as<volatile uint32_t>();
+    const double t0 = now_s();
+    for (uint64_t spins = 0;; ++spins) {
+        if (*flag == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire); // (what the kernels wrote to pinned memory is read after this)
+            return hipSuccess;
+        }
+        if ((spins & 0xfff) == 0xfff) {
+            const double dt = now_s() - t0;
+            if (dt > 5.0)
+                return hipStreamSynchronize(c->stream);
+            if (dt > 2e-3)
+                std::this_thread::yield();
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
 
 } // namespace
 
@@ -644,7 +687,7 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         HIP_TRY(launch_mask(p->kind, p->ps, c->tmp_model.as<double>(), tail->thr2, c->mask.as<uint8_t>(),
                             tail->host_mask ? c->h_mask.dev<uint8_t>() : nullptr, c->stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(wait_stream(c));
     if (tail && tail->host_mask && p->n) // the kernel wrote the pinned copy itself
         std::memcpy(tail->host_mask, c->h_mask.p, p->n);
     for (uint32_t j = 0; j < nj; ++j) {
@@ -784,7 +827,7 @@ struct RansacRun {
         int rc = enqueue_score_records(c, p, c->tmp_model.as<double>(), 1, thr2, false);
         if (rc != PL_OK)
             return rc;
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(wait_stream(c));
         const uint32_t cnt = c->h_count.as<uint32_t>()[0];
         const double sc = c->h_score.as<double>()[0];
         const bool more = cnt > best_min_inl, better = sc < best_min_score;
@@ -1025,7 +1068,7 @@ struct RansacRun {
         double *h_recm = c->h_gather_out.as<double>();
         if (!b.ctl_mirrored)
             HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(BatchCtl), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(wait_stream(c));
         if (device_positions) {
             if (h_ctl->orbit_error) { // evaluated window too small / too many redraws: redo this batch
                 force_host_positions = true;
@@ -1081,7 +1124,7 @@ struct RansacRun {
                                        c->stream));
                 HIP_TRY(hipMemcpyAsync(h_recm, c->rec_models.p, sizeof(double) * kModelStride * nrec,
                                        hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(wait_stream(c));
             }
             order.resize(nrec);
             for (uint32_t a = 0; a < nrec; ++a)
@@ -1104,7 +1147,7 @@ struct RansacRun {
                 HIP_TRY(hipMemcpyAsync(c->h_score.p, c->score.p, sizeof(double) * H, hipMemcpyDeviceToHost,
                                        c->stream));
             }
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(wait_stream(c));
             const uint32_t *h_cnt = c->h_count.as<uint32_t>();
             const double *h_sc = c->h_score.as<double>();
             std::vector<RecordMeta> cand;
@@ -1155,7 +1198,7 @@ struct RansacRun {
                     HIP_TRY(hipMemcpyAsync(dst + (size_t)a * kModelStride,
                                            c->models.as<double>() + (size_t)cand[a].slot * kModelStride,
                                            sizeof(double) * kModelStride, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(wait_stream(c));
             }
             order.resize(nc);
             for (uint32_t a = 0; a < nc; ++a)
@@ -1394,7 +1437,7 @@ struct RansacRun {
                 } else {
                     HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it - lo_g), sizeof(uint32_t),
                                            hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    HIP_TRY(wait_stream(c));
                 }
             }
             uint64_t total = upto;
@@ -1506,7 +1549,7 @@ struct RansacRun {
             HIP_TRY(c->h_mask.ensure(N));
             HIP_TRY(launch_mask(kind, p->ps, c->tmp_model.as<double>(), thr2, c->mask.as<uint8_t>(),
                                 inliers ? c->h_mask.dev<uint8_t>() : nullptr, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(wait_stream(c));
             if (inliers)
                 std::memcpy(inliers, c->h_mask.p, N);
         }
@@ -1639,7 +1682,7 @@ int make_problem_prepared(Context *c, int kind, const double *a, const double *b
         return PL_OK;
     }
     HIP_TRY(hipMemcpyAsync(c->h_absmax.p, c->absmax.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(wait_stream(c));
     double amax;
     std::memcpy(&amax, c->h_absmax.p, sizeof(double));
     p->ps.xy_absmax = std::nextafter((float)amax, std::numeric_limits<float>::infinity());
@@ -1906,7 +1949,7 @@ int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t 
     rc = enqueue_score_records(c, p, c->tmp_model.as<double>(), 1, max_error * max_error, false);
     if (rc != PL_OK)
         return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(wait_stream(c));
     if (inlier_count)
         *inlier_count = c->h_count.as<uint32_t>()[0];
     if (score)
@@ -2004,7 +2047,7 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
         HIP_TRY(hipMemcpyAsync(counts, c->count.p, sizeof(uint32_t) * H, hipMemcpyDeviceToHost, c->stream));
     if (scores)
         HIP_TRY(hipMemcpyAsync(scores, c->score.p, sizeof(double) * H, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(wait_stream(c));
     if (path_used)
         *path_used = path;
     return PL_OK;
@@ -2325,7 +2368,7 @@ int pl_undistort_points(const pl_camera *camera, const double *points2D, size_t 
     HIP_TRY(hipMemcpyAsync(c->raw_a.p, points2D, sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_undistort(c->raw_a.as<double>(), (uint32_t)n, cam, fx, fy, cx, cy, c->raw_b.as<double>(), c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->raw_b.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(wait_stream(c));
     return PL_OK;
 }
 
@@ -2350,7 +2393,7 @@ int pl_solve_batch(int kind, const double *in, size_t count, double *out_models,
                                c->solve_cnt.as<uint32_t>(), c->stream));
     HIP_TRY(hipMemcpyAsync(out_models, c->solve_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out_counts, c->solve_cnt.p, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(wait_stream(c));
     return PL_OK;
 }
 
@@ -2400,7 +2443,7 @@ int pl_essential_matrix_5pt(const double *x1, const double *x2, double *E) {
     HIP_TRY(hipMemcpyAsync(rec.data(), c->solve_out.p, sizeof(double) * kModelStride * 10, hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipMemcpyAsync(&n, c->solve_cnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(wait_stream(c));
     for (uint32_t i = 0; i < n; ++i) {
         Mat3 M;
         for (int k = 0; k < 9; ++k)
