@@ -482,6 +482,10 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
     constexpr int NB = 1; // bound terms per point
     constexpr int NPW = 64 * P;                                         // correspondences per chunk
     __shared__ double s_pts[ND][NPW];
+    // relative pose: the unit bearings of the cheirality test (utils.cc:183-185) depend on the correspondence only -
+    // computed once per chunk instead of once per exact evaluation (2 square roots + 6 divisions, 40 % of a drain)
+    constexpr int NBR = (EST == EST_REL) ? 6 : 1;
+    __shared__ double s_bear[NBR][(EST == EST_REL) ? NPW : 1];
     __shared__ uint16_t s_queue[kWaves][kQueueCap]; // entries: hypothesis of the group << 9 | correspondence of the chunk
     __shared__ double s_acc_s[kWaves][64];
     __shared__ uint32_t s_acc_c[kWaves][64];
@@ -506,6 +510,13 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
             pf32[p][d] = (float)x[d];
             if (wave == 0)
                 s_pts[d][p * 64 + lane] = x[d];
+        }
+        if constexpr (EST == EST_REL) {
+            if (wave == 1 + (p % (kWaves - 1))) {
+                const Vec3 u1 = bearing(x[0], x[1]), u2 = bearing(x[2], x[3]);
+                s_bear[0][p * 64 + lane] = u1.x, s_bear[1][p * 64 + lane] = u1.y, s_bear[2][p * 64 + lane] = u1.z;
+                s_bear[3][p * 64 + lane] = u2.x, s_bear[4][p * 64 + lane] = u2.y, s_bear[5][p * 64 + lane] = u2.z;
+            }
         }
         if constexpr (EST == EST_ABS) {
             bnd[p][0] = pf_point_abs(x[2], x[3], x[4], pf.gx);
@@ -560,10 +571,33 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
             for (int i = 0; i < kModelDoubles; ++i)
                 M[i] = Mp[i];
             double r2;
-            const bool in = eval_point<EST>(M, x, thr2, r2) && act;
+            bool in;
+            if constexpr (EST == EST_REL) {
+                r2 = sampson_sq(M + kMatOff, x[0], x[1], x[2], x[3]);
+                in = r2 < thr2;
+                if (in) {
+                    Quat q;
+                    q.w = M[0], q.x = M[1], q.y = M[2], q.z = M[3];
+                    in = check_cheirality(q, v3(M[4], M[5], M[6]), v3(s_bear[0][pi], s_bear[1][pi], s_bear[2][pi]),
+                                          v3(s_bear[3][pi], s_bear[4][pi], s_bear[5][pi]), 0.01);
+                }
+                in = in && act;
+            } else {
+                in = eval_point<EST>(M, x, thr2, r2) && act;
+            }
             double v = in ? r2 : 0.0;
             uint32_t c = in ? 1u : 0u;
-            if (__builtin_amdgcn_ballot_w64(in)) {
+            const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
+            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) {
+                // all waiting pairs belong to one hypothesis (the usual case when a good model's inliers arrive): a plain
+                // wave sum over the DPP paths
+                const double tot = wave_sum_dpp(v);
+                if (lane == 0) {
+                    acc_s[g0] += tot;
+                    acc_c[g0] += (uint32_t)__popcll(inmask);
+                }
+            } else if (inmask) {
                 // segmented inclusive scan; keys (hypothesis) ascend with the lane, so "same key `off` lanes below"
                 // implies the whole stretch in between belongs to the segment
 #pragma unroll
@@ -879,7 +913,15 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
             const bool in = eval_point<EST_ABS>(M, x, thr2, r2) && act;
             double v = in ? r2 : 0.0;
             uint32_t c = in ? 1u : 0u;
-            if (__builtin_amdgcn_ballot_w64(in)) {
+            const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
+            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) { // one hypothesis: plain wave sum (k_score_queue)
+                const double tot = wave_sum_dpp(v);
+                if (lane == 0) {
+                    acc_s[g0] += tot;
+                    acc_c[g0] += (uint32_t)__popcll(inmask);
+                }
+            } else if (inmask) {
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const double vv = __shfl_up(v, off, 64);

@@ -43,6 +43,17 @@ PL_HD double sampson_sq(const double *E /*row-major 3x3*/, double a0, double a1,
 }
 
 // relative pose: Sampson below threshold AND positive depth in both views (min depth 0.01)
+// u1 = bearing(a0, a1), u2 = bearing(b0, b1): they depend on the correspondence only, so a scorer that sees the same
+// correspondence for many models passes them in (same function, same bits)
+PL_HD bool sampson_pose_inlier_b(const double *M, double a0, double a1, double b0, double b1, Vec3 u1, Vec3 u2,
+                                 double thr2, double &r2) {
+    r2 = sampson_sq(M + kMatOff, a0, a1, b0, b1);
+    if (!(r2 < thr2))
+        return false;
+    Quat q;
+    q.w = M[0], q.x = M[1], q.y = M[2], q.z = M[3];
+    return check_cheirality(q, v3(M[4], M[5], M[6]), u1, u2, 0.01);
+}
 PL_HD bool sampson_pose_inlier(const double *M, double a0, double a1, double b0, double b1, double thr2, double &r2) {
     r2 = sampson_sq(M + kMatOff, a0, a1, b0, b1);
     if (!(r2 < thr2))
