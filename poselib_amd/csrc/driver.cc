@@ -858,7 +858,8 @@ struct RansacRun {
         ScoreArgs sa;
         set_prefilter(sa, p, thr2);
         const bool prefilter = true; // compact hypothesis stream for the streaming scorer (all estimators)
-        const uint32_t chunks = score_chunks(kind, N, prefilter);
+        const bool on_mfma = score_uses_mfma(kind, N, sa.pf);
+        const uint32_t chunks = score_chunks(kind, N, prefilter, on_mfma);
         if (prefilter) {
             HIP_TRY(c->shadow.ensure(sizeof(float) * 16 * hcap));
             HIP_TRY(c->compact64.ensure(sizeof(double) * kModelDoubles * hcap));
@@ -956,11 +957,16 @@ struct RansacRun {
             sa.slots = c->slots.as<uint32_t>();
             sa.shadow16 = nullptr;
             Shadow16Params s16;
-            if (score_uses_mfma(kind, N, sa.pf)) { // fp16 operand blocks of the hypotheses for the matrix cores: built
-                                                    // in the same launch as the hypothesis-ordered copies
+            if (on_mfma && kind == EST_ABS) { // fp16 operand blocks of the hypotheses for the matrix cores: built
+                                              // in the same launch as the hypothesis-ordered copies
                 HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
                 s16.out = c->shadow16.p;
                 s16.g16 = sa.pf.g16, s16.c16 = sa.pf.c16, s16.thr = sa.pf.thr;
+                sa.shadow16 = c->shadow16.p;
+            } else if (on_mfma) { // two-view: operands of the Sampson forms (k_sampson16 / k_score_mfma2)
+                HIP_TRY(c->shadow16.ensure((hcap + kSampson16Pad) * kSampson16Bytes));
+                s16.out = c->shadow16.p;
+                s16.sampson = 1;
                 sa.shadow16 = c->shadow16.p;
             }
             HIP_TRY(launch_compact2(ga.num_models, Bl, MAXM, blk_tot, true, c->slots.as<uint32_t>(),
@@ -1597,8 +1603,13 @@ int make_problem(Context *c, int kind, const double *a, const double *b, size_t 
             const double v = std::fabs(a[da * i + d]);
             amax = (v > amax || v != v) ? v : amax; // NaN propagates and disables the pre-filter
         }
-        for (int d = 0; d < db; ++d)
+        for (int d = 0; d < db; ++d) {
             soa[(size_t)(da + d) * n + i] = b[db * i + d];
+            if (kind != EST_ABS) { // two-view: the bound covers all four coordinates (pl_prefilter.h, fp16 Sampson form)
+                const double v = std::fabs(b[db * i + d]);
+                amax = (v > amax || v != v) ? v : amax;
+            }
+        }
     }
     HIP_TRY(hipMalloc((void **)&p->d_pts, sizeof(double) * nd * n));
     hipError_t up = hipMemcpyAsync(p->d_pts, soa.data(), sizeof(double) * nd * n, hipMemcpyHostToDevice, c->stream);
@@ -1990,7 +2001,8 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
     const double thr2 = max_error * max_error;
     ScoreArgs sa;
     set_prefilter(sa, p, thr2);
-    const uint32_t chunks = score_chunks(p->kind, p->n, true);
+    const bool on_mfma = score_uses_mfma(p->kind, p->n, sa.pf);
+    const uint32_t chunks = score_chunks(p->kind, p->n, true, on_mfma);
     HIP_TRY(c->models.ensure(sizeof(double) * kModelStride * H));
     HIP_TRY(c->slots.ensure(sizeof(uint32_t) * H));
     HIP_TRY(c->shadow.ensure(sizeof(float) * 16 * H));
@@ -2015,10 +2027,15 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
     sa.slots = c->slots.as<uint32_t>();
     sa.shadow16 = nullptr;
     int path = sa.pf.enabled ? 1 : 0;
-    if (score_uses_mfma(p->kind, p->n, sa.pf)) {
+    if (on_mfma && p->kind == EST_ABS) {
         HIP_TRY(c->shadow16.ensure(((size_t)H + 8) * 64));
         HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), H, sa.pf.g16, sa.pf.c16, sa.pf.thr,
                                 c->shadow16.p, c->stream));
+        sa.shadow16 = c->shadow16.p;
+        path = 2;
+    } else if (on_mfma) {
+        HIP_TRY(c->shadow16.ensure(((size_t)H + kSampson16Pad) * kSampson16Bytes));
+        HIP_TRY(launch_sampson16(d_ctl, c->slots.as<uint32_t>(), c->models.as<double>(), H, c->shadow16.p, c->stream));
         sa.shadow16 = c->shadow16.p;
         path = 2;
     }

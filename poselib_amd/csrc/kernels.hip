@@ -1035,6 +1035,247 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
                         a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
 }
 
+// ---- two-view Sampson scores: the pre-filter on the matrix cores ----------------------------------------------------
+// k_score_mfma2<EST, PG> (EST = relative pose / fundamental matrix): same contract, same queue and the same exact pass as
+// k_score_queue, but pass A is three v_mfma_f32_32x32x16_f16 per 32 hypotheses x 32 correspondences: two accumulate the
+// bilinear form C~ = b^T F a over fp16 high / low splits of both factors, one the quadratic forms S~ = Cx + Cy plus the
+// slack (operands and error bounds: pl_prefilter.h "Sampson, fp16 / MFMA form"; hypothesis side built by k_sampson16,
+// correspondence side here, once per workgroup, into LDS).  What is left for the vector ALU per pair is one
+// multiplication and one FMA whose sign bit is the verdict (19 packed + 2 compares per PAIR of pairs in the fp32 filter).
+// Accumulator layout (both tiles): lane l = correspondence l % 32 of the group, register v = hypothesis row
+// 8 (v / 4) + 4 (l / 32) + v % 4.  The sign bits are shifted into one bit field per register over the PG groups of the
+// chunk, then expanded into the wave's LDS queue register by register - lanes 0..31 (one hypothesis) before lanes 32..63
+// (another), so every hypothesis is one run of the queue, which is all the drain's segmented sum needs.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+template <int EST, int PG>
+__device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint4 *__restrict__ hypop,
+                                                 const double *__restrict__ models, const uint32_t *__restrict__ slots,
+                                                 const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
+                                                 double thr2, const PrefilterArgs &pf, uint32_t *__restrict__ part_count,
+                                                 double *__restrict__ part_score, uint32_t slice, uint32_t chunk,
+                                                 uint32_t nslices) {
+    static_assert(EST == EST_REL || EST == EST_FUND, "Sampson scores");
+    constexpr int kWaves = kMfmaThreads / 64;
+    constexpr int NPW = 32 * PG; // correspondences per chunk
+    constexpr int NBR = (EST == EST_REL) ? 6 : 1;
+    __shared__ double s_pts[4][NPW];
+    __shared__ double s_bear[NBR][(EST == EST_REL) ? NPW : 1];
+    __shared__ uint16_t s_queue[kWaves][kMfmaQueueCap]; // entries: hypothesis slot << 9 | correspondence of the chunk
+    __shared__ double s_acc_s[kWaves][64];
+    __shared__ uint32_t s_acc_c[kWaves][64];
+    __shared__ uint32_t s_next_unit;
+    __shared__ uint4 s_bop[PG][3][64]; // B operands: group, instruction, lane (column l % 32, k block l / 32)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = lane & 31, half = lane >> 5;
+
+    // ---- stationary side: the chunk's correspondences (fp64 for the exact pass, fp16 operands for the filter) ----
+    for (uint32_t j = threadIdx.x; j < (uint32_t)NPW; j += kMfmaThreads) {
+        const uint32_t i = chunk * NPW + j;
+        const uint32_t ic = i < pts.n ? i : 0u;
+        const double a0 = pts.a[0][ic], a1 = pts.a[1][ic], b0 = pts.a[2][ic], b1 = pts.a[3][ic];
+        s_pts[0][j] = a0, s_pts[1][j] = a1, s_pts[2][j] = b0, s_pts[3][j] = b1;
+        if constexpr (EST == EST_REL) {
+            const Vec3 u1 = bearing(a0, a1), u2 = bearing(b0, b1);
+            s_bear[0][j] = u1.x, s_bear[1][j] = u1.y, s_bear[2][j] = u1.z;
+            s_bear[3][j] = u2.x, s_bear[4][j] = u2.y, s_bear[5][j] = u2.z;
+        }
+    }
+    uint32_t validbits = 0; // bit (PG - 1 - g): group g holds a real correspondence in this column
+#pragma unroll
+    for (int g = 0; g < PG; ++g)
+        validbits |= (chunk * NPW + g * 32 + col < pts.n) ? (1u << (PG - 1 - g)) : 0u;
+    for (int g = wave; g < PG; g += kWaves) {
+        const uint32_t i = chunk * NPW + g * 32 + col;
+        const bool valid = i < pts.n;
+        const uint32_t ic = valid ? i : 0u;
+        Sampson16Operand o;
+        pf16_sampson_point(pts.a[0][ic], pts.a[1][ic], pts.a[2][ic], pts.a[3][ic], valid, pf.t16, o);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // k block 2 j + half of the operand: both candidates are built, the lane keeps its own
+            uint32_t w[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int b = 2 * j + hh;
+                const uint16_t *h = b < 4 ? o.c + 8 * b : o.s + 8 * (b - 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    w[hh][q] = (uint32_t)h[2 * q] | ((uint32_t)h[2 * q + 1] << 16);
+            }
+            s_bop[g][j][lane] = make_uint4(half ? w[1][0] : w[0][0], half ? w[1][1] : w[0][1], half ? w[1][2] : w[0][2],
+                                           half ? w[1][3] : w[0][3]);
+        }
+    }
+    if (threadIdx.x == 0)
+        s_next_unit = 0;
+    __syncthreads(); // the only workgroup barrier
+
+    const uint32_t H = *as_uniform(num_hyp_ptr);
+    const float t16 = pf.t16;
+    uint16_t *const queue = s_queue[wave];
+    double *const acc_s = s_acc_s[wave];
+    uint32_t *const acc_c = s_acc_c[wave];
+    const uint32_t waves_per_chunk = nslices * kWaves;
+    auto request_ticket = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (lane == 0) {
+            const uint32_t k = atomicAdd(&s_next_unit, 1u);
+            t = slice * kWaves + (k % kWaves) + (k / kWaves) * waves_per_chunk;
+        }
+        return t;
+    };
+    uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)request_ticket());
+    uint32_t kb, gn;
+    while (unit_of_ticket(ticket, H, waves_per_chunk, kb, gn)) {
+        const uint32_t pending = request_ticket();
+        acc_s[lane] = 0.0;
+        acc_c[lane] = 0;
+        uint32_t qhead = 0, qtail = 0;
+
+        auto drain = [&](uint32_t n) { // k_score_queue's exact pass; the fp64 models straight from their records
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool act = (uint32_t)lane < n;
+            const uint32_t e = act ? (uint32_t)queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffu;
+            const uint32_t g = e >> 9, pi = act ? (e & 0x1ffu) : 0u;
+            const double x0 = s_pts[0][pi], x1 = s_pts[1][pi], x2 = s_pts[2][pi], x3 = s_pts[3][pi];
+            const double *Mp = models + (size_t)slots[kb + (act ? g : 0u)] * kModelStride;
+            double M[kModelDoubles];
+#pragma unroll
+            for (int i = 0; i < kModelDoubles; ++i)
+                M[i] = Mp[i];
+            double r2 = sampson_sq(M + kMatOff, x0, x1, x2, x3);
+            bool in = r2 < thr2;
+            if constexpr (EST == EST_REL) {
+                if (in) {
+                    Quat q;
+                    q.w = M[0], q.x = M[1], q.y = M[2], q.z = M[3];
+                    in = check_cheirality(q, v3(M[4], M[5], M[6]), v3(s_bear[0][pi], s_bear[1][pi], s_bear[2][pi]),
+                                          v3(s_bear[3][pi], s_bear[4][pi], s_bear[5][pi]), 0.01);
+                }
+            }
+            in = in && act;
+            double v = in ? r2 : 0.0;
+            uint32_t c = in ? 1u : 0u;
+            const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
+            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) {
+                const double tot = wave_sum_dpp(v);
+                if (lane == 0) {
+                    acc_s[g0] += tot;
+                    acc_c[g0] += (uint32_t)__popcll(inmask);
+                }
+            } else if (inmask) {
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double vv = __shfl_up(v, off, 64);
+                    const uint32_t cc = __shfl_up(c, off, 64);
+                    const uint32_t gg = __shfl_up(g, off, 64);
+                    if (lane >= off && gg == g) {
+                        v += vv;
+                        c += cc;
+                    }
+                }
+                const uint32_t gnext = __shfl_down(g, 1, 64);
+                const bool tail = act && ((uint32_t)lane + 1 == n || gnext != g);
+                if (tail && c) {
+                    acc_s[g] += v;
+                    acc_c[g] += c;
+                }
+            }
+            qhead += n;
+        };
+
+        const uint32_t ngroups32 = (gn + 31u) / 32u;
+        auto load_a = [&](uint32_t hg, uint4 (&A)[3]) {
+            const uint4 *row = hypop + (size_t)(kb + 32u * hg + (uint32_t)col) * 6;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                A[j] = row[2 * j + half];
+        };
+        uint4 Araw[3];
+        load_a(0, Araw);
+        for (uint32_t hg = 0; hg < ngroups32; ++hg) {
+            half8_t Aop[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                __builtin_memcpy(&Aop[j], &Araw[j], 16);
+            if (hg + 1 < ngroups32) // next group's operands travel while this one is evaluated
+                load_a(hg + 1, Araw);
+            uint32_t out[16]; // register v: bit (PG - 1 - g) = point group g is a proven outlier of hypothesis row(v)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                out[v] = 0u;
+            const float16_t kZero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+            for (int g = 0; g < PG; ++g) {
+                half8_t Bop[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint4 braw = s_bop[g][j][lane];
+                    __builtin_memcpy(&Bop[j], &braw, 16);
+                }
+                float16_t C = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[0], Bop[0], kZero, 0, 0, 0);
+                C = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[1], Bop[1], C, 0, 0, 0);
+                const float16_t S = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[2], Bop[2], kZero, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    // proven outlier <=> C^2 > t16 S' <=> t16 S' - C^2 < 0: the sign bit goes into the bit field
+                    const float d = fmaf(t16, S[v], -(C[v] * C[v]));
+                    out[v] = __builtin_amdgcn_alignbit(out[v], __float_as_uint(d), 31);
+                }
+            }
+            // ---- expansion: register v = hypothesis rows 8 (v / 4) + v % 4 (lanes 0..31) and + 4 (lanes 32..63) ----
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const uint32_t slot = hg * 32u + 8u * (uint32_t)(v >> 2) + 4u * (uint32_t)half + (uint32_t)(v & 3);
+                uint32_t bits = ~out[v] & validbits;
+                if (slot >= gn)
+                    bits = 0u;
+                if (__builtin_amdgcn_ballot_w64(bits != 0u)) { // wave-uniform
+                    const uint32_t cnt = (uint32_t)__popc(bits);
+                    const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint32_t pos = qtail + incl - cnt;
+                    uint32_t rest = bits;
+                    while (rest) { // point groups in ascending order = bits from the top
+                        const int hi = 31 - __clz((int)rest);
+                        rest &= ~(1u << hi);
+                        const uint32_t g = (uint32_t)(PG - 1 - hi);
+                        queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
+                        ++pos;
+                    }
+                    qtail += total;
+                    while (qtail - qhead >= 64u)
+                        drain(64u);
+                }
+            }
+        }
+        while (qtail != qhead)
+            drain(min(64u, qtail - qhead));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((uint32_t)lane < gn) {
+            const size_t o = (size_t)chunk * hyp_capacity + kb + lane;
+            part_score[o] = acc_s[lane];
+            part_count[o] = acc_c[lane];
+        }
+        ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
+    }
+}
+
+template <int EST, int PG>
+__global__ __launch_bounds__(kMfmaThreads) void k_score_mfma2(PointSet pts, const uint4 *__restrict__ hypop,
+                                                              const double *__restrict__ models,
+                                                              const uint32_t *__restrict__ slots,
+                                                              const uint32_t *__restrict__ num_hyp_ptr,
+                                                              uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+                                                              uint32_t *__restrict__ part_count,
+                                                              double *__restrict__ part_score) {
+    score_mfma2_body<EST, PG>(pts, hypop, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score,
+                              blockIdx.x, blockIdx.y, gridDim.x);
+}
+
 // ---- MSAC score in the reference's summation order ------------------------------------------------------------------
 // The streaming scorers add the inlier residuals of a hypothesis in tree order; the reference adds them one after the
 // other in correspondence order (utils.cc:52-63).  The two sums differ in the last bits, which only matters when two
@@ -1717,9 +1958,17 @@ static int max_points_per_lane_pf() {
 // workgroup sees the same chunk); otherwise the non-streaming kernels (256 * P correspondences per chunk).
 // For the Sampson scores P is chosen to minimise  chunks(P) * (VALU issue slots of the pre-filter for P points + a
 // per-hypothesis overhead): pairs of points share packed instructions, an odd point costs as much as a pair.
-static void score_shape(int est, uint32_t n, bool streaming, uint32_t &chunks, int &P) {
+static void score_shape(int est, uint32_t n, bool streaming, bool mfma, uint32_t &chunks, int &P) {
     const uint32_t lanes = streaming ? 64u : (uint32_t)kScoreThreads;
     const int pmax = max_points_per_lane_pf();
+    if (streaming && mfma && (est == EST_REL || est == EST_FUND)) {
+        // k_score_mfma2: PG = 2 P groups of 32 correspondences per chunk; relative pose keeps the bearings in LDS as
+        // well and stops at 320 correspondences per workgroup (two workgroups per CU)
+        const uint32_t per_chunk_max = lanes * (est == EST_REL ? 5u : 6u);
+        chunks = std::max<uint32_t>(1u, (n + per_chunk_max - 1) / per_chunk_max);
+        P = std::max<int>(1, (int)((n + lanes * chunks - 1) / (lanes * chunks)));
+        return;
+    }
     if (streaming && (est == EST_REL || est == EST_FUND) && std::getenv("POSELIB_AMD_PF_P") == nullptr) {
         // Sampson filter: 27 issue slots per pair of points, 29 for an odd one, ~30 per hypothesis around them
         // (measured on MI355X: P = 6 beats P = 5 by 25 % at N = 10000; for the cheaper reprojection and
@@ -1746,12 +1995,19 @@ static void score_shape(int est, uint32_t n, bool streaming, uint32_t &chunks, i
 }
 bool score_uses_mfma(int est, uint32_t n_points, const PrefilterArgs &pf) {
     static const bool off = std::getenv("POSELIB_AMD_NO_MFMA") != nullptr;
-    return !off && est == EST_ABS && pf.enabled && pf.g16 > 0.f && pf.thr <= 1.0f && n_points >= 1024u;
+    static const bool off2 = std::getenv("POSELIB_AMD_NO_MFMA2") != nullptr;
+    if (off || !pf.enabled || n_points < 1024u)
+        return false;
+    if (est == EST_ABS)
+        return pf.g16 > 0.f && pf.thr <= 1.0f;
+    if (est == EST_REL || est == EST_FUND)
+        return !off2 && pf.t16 > 0.f; // (coordinates bounded by 8, threshold in range: make_prefilter_args)
+    return false;
 }
-uint32_t score_chunks(int est, uint32_t n, bool streaming) {
+uint32_t score_chunks(int est, uint32_t n, bool streaming, bool mfma) {
     uint32_t c;
     int P;
-    score_shape(est, n, streaming, c, P);
+    score_shape(est, n, streaming, mfma, c, P);
     return c;
 }
 
@@ -1761,7 +2017,31 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     int P;
     const PrefilterArgs pf = a.pf;
     const bool streaming = (a.shadow && a.compact64) || a.shadow16; // batched main loop: hypothesis stream
-    score_shape(E, a.pts.n, streaming, chunks, P);
+    score_shape(E, a.pts.n, streaming, a.shadow16 != nullptr, chunks, P);
+    if constexpr (E == EST_REL || E == EST_FUND) {
+        if (streaming && a.shadow16) { // Sampson pre-filter on the matrix cores
+            const dim3 mgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
+            const dim3 mblock(kMfmaThreads);
+#define PL_M2_CASE(PP)                                                                                                 \
+    case PP:                                                                                                           \
+        k_score_mfma2<E, 2 * PP><<<mgrid, mblock, 0, stream>>>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models, \
+                                                              a.slots, a.num_hyp, a.hyp_capacity, a.thr2, pf,          \
+                                                              a.part_count, a.part_score);                             \
+        break;
+            switch (P) {
+                PL_M2_CASE(1)
+                PL_M2_CASE(2)
+                PL_M2_CASE(3)
+                PL_M2_CASE(4)
+                PL_M2_CASE(5)
+                PL_M2_CASE(6)
+            default:
+                return hipErrorInvalidValue;
+            }
+#undef PL_M2_CASE
+            return hipGetLastError();
+        }
+    }
     if constexpr (E == EST_ABS) {
         if (streaming && a.shadow16) { // pre-filter on the matrix cores (PG = 2 P groups of 32 points per wave)
             const dim3 mgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);

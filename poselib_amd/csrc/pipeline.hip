@@ -739,6 +739,39 @@ __device__ __forceinline__ void shadow16_one(uint32_t k, uint32_t H, ShadowOf sh
     }
 }
 
+// Operands of k_score_mfma2 (Sampson scores on the matrix cores): 96 B per hypothesis = six 16-byte k blocks
+// [C~ k0-7][k8-15][k16-23][k24-31][S~ k0-7][k8-15], built from the fp64 record (pl_prefilter.h pf16_sampson_model).
+__device__ __forceinline__ void sampson16_one(uint32_t k, uint32_t H, uint32_t cap, const uint32_t *__restrict__ slots,
+                                              const double *__restrict__ models, uint4 *__restrict__ out) {
+    if (k >= cap)
+        return;
+    Sampson16Operand o;
+    if (k < H) {
+        const double *rec = models + (size_t)slots[k] * kModelStride;
+        const bool nan_model = reinterpret_cast<const uint32_t *>(rec + kShadowOff)[13] != 0u;
+        pf16_sampson_model(rec + kMatOff, nan_model, o);
+    } else { // not a hypothesis: never a candidate
+        const double zero[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        pf16_sampson_model(zero, true, o);
+    }
+    uint4 *dst = out + (size_t)k * 6;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const uint16_t *h = b < 4 ? o.c + 8 * b : o.s + 8 * (b - 4);
+        dst[b] = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                            (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+    }
+}
+__global__ __launch_bounds__(256) void k_sampson16(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t cap,
+                                                   uint4 *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t H = ctl->num_hyp;
+    // (rows past the last hypothesis of the last unit: one pad of kSampson16Pad rows is all a partial group can reach)
+    if (k >= min(cap, (H + (uint32_t)kSampson16Pad)))
+        return;
+    sampson16_one(k, H, cap, slots, models, out);
+}
+
 __global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const float *__restrict__ shadow,
                                                   uint32_t capacity8, float g16, float c16, float thr,
                                                   uint2 *__restrict__ out) {
@@ -925,7 +958,10 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
         k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
     k_compact2<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, maxm, blk_tot, slots, offsets, models, shadow_compact,
                                                     compact64, ctl);
-    if (s16.out) {
+    if (s16.out && s16.sampson) {
+        const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)B * (uint64_t)maxm + kSampson16Pad, 0xffffff00ull);
+        k_sampson16<<<dim3((cap + 255) / 256), dim3(256), 0, stream>>>(ctl, slots, models, cap, static_cast<uint4 *>(s16.out));
+    } else if (s16.out) {
         // matrix-core scorer: its fp16 operand blocks are built straight from the records, and its exact pass reads the
         // fp64 models from the records as well - no hypothesis-ordered copies
         const uint32_t cap8 = (uint32_t)(((uint64_t)B * (uint64_t)maxm + 7u) & ~7ull);
@@ -937,6 +973,13 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
         k_gather_models<<<dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream>>>(ctl, slots, models,
                                                                                           shadow_compact, compact64);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_sampson16(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t capacity, void *out,
+                            hipStream_t stream) {
+    const uint32_t cap = capacity + (uint32_t)kSampson16Pad;
+    k_sampson16<<<dim3((cap + 255) / 256), dim3(256), 0, stream>>>(ctl, slots, models, cap, static_cast<uint4 *>(out));
     return hipGetLastError();
 }
 

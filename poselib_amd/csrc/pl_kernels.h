@@ -15,7 +15,8 @@ namespace pl {
 struct PointSet {
     const double *a[5];
     uint32_t n;
-    float xy_absmax; // max(|x|, |y|) over the 2-D points (bound used by the scoring pre-filter)
+    float xy_absmax; // absolute pose: max(|x|, |y|) over the 2-D points; two-view: max over all four coordinates, +inf
+                     // when unknown (bounds used by the scoring pre-filters)
 };
 
 constexpr int kScoreThreads = 256; // 4 wavefronts per workgroup
@@ -159,12 +160,15 @@ hipError_t launch_select_record(const double *score_refined, double incumbent_sc
 hipError_t launch_shadow16(const uint32_t *num_hyp, const float *shadow_compact, uint32_t hyp_capacity, float g16,
                            float c16, float thr, void *shadow16, hipStream_t stream);
 bool score_uses_mfma(int est, uint32_t n_points, const PrefilterArgs &pf);
+// operands of k_score_mfma2 for `capacity` hypotheses listed in `slots` (+ the pad rows behind them)
+hipError_t launch_sampson16(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t capacity, void *out,
+                            hipStream_t stream);
 size_t lm2_state_bytes(uint32_t num_tasks);
 size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices);
 hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, uint32_t slices,
                       uint32_t max_iterations, void *states, double *partials, hipStream_t stream);
 // chunks = ceil(n / (kScoreThreads * P)); P is chosen inside from n (returned through *chunks_out)
-uint32_t score_chunks(int est, uint32_t n_points, bool prefilter);
+uint32_t score_chunks(int est, uint32_t n_points, bool prefilter, bool mfma = false);
 hipError_t launch_score(int est, const ScoreArgs &a, uint32_t slices, hipStream_t stream);
 // num_models[iters] -> slots (compact list of record indices in (iteration, model) order) + count
 hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
@@ -184,7 +188,10 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
 struct Shadow16Params {
     void *out = nullptr;
     float g16 = 0.f, c16 = 0.f, thr = 0.f;
+    int sampson = 0; // 1: two-view, operands of k_score_mfma2 (96 B per hypothesis, pl_prefilter.h Sampson16Operand)
 };
+constexpr size_t kSampson16Bytes = 96;
+constexpr size_t kSampson16Pad = 64; // operand rows a partial group of 32 may read past the last hypothesis
 // blk_tot is followed by the generators' NaN-model table of the same length (nb = ceil(B / 1024) entries each)
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, bool counted, uint32_t *slots,
                            uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,

@@ -48,6 +48,32 @@
 //    max(|a^0|, |a^1|) > B^  proves an outlier; the "behind the camera" test is left to the exact pass.  Points or
 //    translations beyond 3e4 (fp16 range) and rotation rows that are not unit-bounded get an infinite slack
 //    (always evaluated exactly), NaN models -inf (never).
+//  * Sampson, fp16 / MFMA form (k_score_mfma2; two-view problems whose coordinates are bounded by 8, i.e. normalised image
+//    points): the matrix pipe evaluates the two FORMS of the test directly, for 32 models x 32 correspondences per
+//    instruction (v_mfma_f32_32x32x16_f16, fp32 accumulation):
+//        C~ = sum_ij F~_ij phi~_ij          F~ = F cF, cF the power of two with max|F~_ij| in [2^9, 2^10),  phi~_ij = 2^8 b_i a_j
+//        S~ = sum_k g~_k psi~_k             g~ = 2^-7 coefficients of  a^T G1 a + b^T G2 b,  G1 = F~_0 F~_0^T + F~_1 F~_1^T (rows),
+//                                           G2 likewise from the first two columns;  psi~ = 2^8 (a0^2, a0 a1, a1^2, a0, a1, 1, b0^2, ...)
+//    so C~ = 2^8 cF C and S~ = 2 cF^2 (Cx + Cy):  C^2 > T (Cx + Cy)  <=>  C~^2 > 2^15 T S~.  C~ has to resolve a cancellation
+//    (|C| << sum |F_ij phi_ij| near the epipolar line): both operands are split into fp16 high / low parts and three of the
+//    four partial products are kept (27 of the 32 k slots: hi*hi, hi*lo, lo*hi); S~ is a sum of squares and runs on the
+//    high parts only (11 slots + one slot that adds the slack).  Error bounds, in the scaled units, per correspondence only
+//    (|F~_ij| <= 2^10 whatever the model):
+//      - split: |v - hi - lo| <= 2^-22 |v| (+ 2^-14 absolute once a part is below the fp16 normal range - that also covers a
+//        matrix pipe that flushes subnormal inputs); the dropped lo*lo product is <= 2^-22 |F~ phi~|; products of two fp16
+//        numbers are exact in fp32; 32 accumulations at <= 2^-23 each (truncation assumed, not round-to-nearest):
+//            |C^ - C~| <= 2^-17 sum |F~ phi~| + 2^-14 (sum |F~| + sum |phi~|) <= E_C = 2.1 na nb + 0.6
+//        (sum_ij |phi_ij| = na nb exactly, na = 1 + |a0| + |a1|, nb = 1 + |b0| + |b1|)
+//      - S^: both factors rounded to fp16 (2^-11 each), 12 accumulations:
+//            |S^ - S~| <= 2^-9.9 sum |g~ psi~| + 2^-14 (sum |g~| + sum |psi~|) <= E_S = 4401 (na^2 + nb^2) + 24
+//        (|g~_k| <= 2^15, sum over the 11 monomials with their multiplicities <= 2^22 (na^2 + nb^2))
+//    With (|C^| - E_C)^2 >= (15/16) C^^2 - 15 E_C^2:   C^^2 > t16 (S^ + w),  w >= E_S + 16 E_C^2 / t16,
+//    t16 = (16/15) 2^15 thr2 (1 + 256u)  implies  C~^2 > 2^15 thr2 (1 + 256u) S~, i.e. a certain outlier (the 256u absorb the
+//    fp32 roundings of C^ C^ and of the final FMA and the reference's own fp64 roundings).  w rides in the twelfth k slot
+//    (model side 2^14, correspondence side w 2^-14 rounded UP to fp16, a normal number), so the kernel's tail per pair is
+//    one multiplication and one FMA whose SIGN is the verdict.  Model side of that slot = -inf: NaN model (no inliers);
+//    +inf: matrix outside [1e-18, 1e18] (every point evaluated exactly).  Correspondences with a coordinate beyond 8 (or
+//    NaN) carry zero operands and the largest finite slack: never excluded.
 //  * models with a NaN entry have no inliers at all (see store_shadow); models or thresholds outside the range in
 //    which fp32 keeps its relative accuracy (max-abs entry outside [1e-18, 1e18]) get an infinite slack, i.e. every
 //    point is evaluated exactly.
@@ -69,6 +95,7 @@ struct PrefilterArgs {
     float c16;     //   and the absolute part (2e-7 + 2.5e-4) (1 + max|x|,|y| + thr)
     float t1;      // Sampson, one-comparison form: (16/15) (1 + 1/64) thr2 (1 + 96u), rounded up
     float w252;    //   and (16/15) (1 + 96u) 60, rounded up (factor of (na nb)^2 in the per-point term w)
+    float t16;     // Sampson, fp16 / MFMA form: (16/15) 2^15 thr2 (1 + 256u), rounded up; 0 = that form is not available
 };
 
 PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-negative bound upwards
@@ -78,7 +105,7 @@ PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-nega
 // the range fp32 can carry.
 inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) {
     PrefilterArgs a;
-    a.thr = a.gx = a.thr2_up = a.g16 = a.c16 = a.t1 = a.w252 = 0.f;
+    a.thr = a.gx = a.thr2_up = a.g16 = a.c16 = a.t1 = a.w252 = a.t16 = 0.f;
     a.enabled = 0;
     if (!(thr2 >= 1e-30 && thr2 <= 1e30))
         return a;
@@ -97,6 +124,12 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
         // 2e-7: fp32 accumulation; 2.5e-4: four fp16 inputs per row (X_lo, t) may be subnormal, i.e. below 6.1e-5 - the
         // bound holds even if the matrix pipe flushes them to zero
         a.c16 = nextafterf((float)((2e-7 + 2.5e-4) * (1.0 + (double)xy_absmax + thr)), inf);
+    }
+    if (est == 1 || est == 2) {
+        // xy_absmax of a two-view problem: max over all four coordinates (driver.cc make_problem; +inf when unknown).
+        // thr2 range: t16 and 16 E_C^2 / t16 have to stay inside fp32 / fp16 with room to spare
+        if (xy_absmax <= 8.0f && thr2 >= 1e-12 && thr2 <= 1e4)
+            a.t16 = nextafterf((float)((16.0 / 15.0) * 32768.0 * thr2 * (1.0 + 256.0 * u)), inf);
     }
     a.enabled = 1;
     return a;
@@ -160,6 +193,150 @@ PL_HD bool pf_sampson_outlier(const float *r, float gf /* 16u * fm */, float t1,
     const float C = fmaf(b0, Ea0, fmaf(b1, Ea1, Ea2));
     const float S = fmaf(Eb1, Eb1, fmaf(Eb0, Eb0, fmaf(Ea1, Ea1, Ea0 * Ea0)));
     return C * C > fmaf(t1, S, (gf * gf) * w);
+}
+
+// ---- Sampson, fp16 / MFMA form: operands (header comment).  Portable fp16 conversions: the kernels, the operand builder
+// of the hypotheses (pipeline.hip) and the test-only host build run the same integer code ------------------------------
+PL_HD uint16_t pf_half_rn(float f) { // round to nearest even; overflow -> inf
+    uint32_t x;
+    __builtin_memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u)
+        return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x >= 0x477ff000u) // >= 65520
+        return (uint16_t)(sign | 0x7c00u);
+    if (x < 0x38800000u) { // below 2^-14: multiples of 2^-24
+        float af;
+        __builtin_memcpy(&af, &x, 4);
+        const float scaled = af * 16777216.0f;                // exact
+        const float r = (scaled + 8388608.0f) - 8388608.0f;   // nearest-even integer, 0 <= scaled < 2^10
+        return (uint16_t)(sign | (uint32_t)r);
+    }
+    x += 0x0fffu + ((x >> 13) & 1u);
+    return (uint16_t)(sign | ((x - 0x38000000u) >> 13));
+}
+PL_HD float pf_half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t x;
+    if (e == 0) {
+        const float v = (float)m * 5.9604644775390625e-08f;
+        __builtin_memcpy(&x, &v, 4);
+        x |= sign;
+    } else if (e == 31) {
+        x = sign | 0x7f800000u | (m << 13);
+    } else {
+        x = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    __builtin_memcpy(&f, &x, 4);
+    return f;
+}
+PL_HD uint16_t pf_half_up(float v) { // v >= 0: the smallest fp16 >= v (+inf beyond 65504)
+    uint16_t b = pf_half_rn(v);
+    if (b < 0x7c00u && pf_half_to_float(b) < v)
+        b = (uint16_t)(b + 1);
+    return b;
+}
+PL_HD void pf_split16(double v, uint16_t &hi, uint16_t &lo) { // |v| < 65504
+    hi = pf_half_rn((float)v);
+    lo = pf_half_rn((float)(v - (double)pf_half_to_float(hi)));
+}
+
+struct Sampson16Operand { // one model or one correspondence: k slots of the three matrix instructions
+    uint16_t c[32];       // C~: slots 0..8 / 9..17 / 18..26, 27..31 = 0
+    uint16_t s[16];       // S~: slots 0..10, slack in 11, 12..15 = 0
+};
+constexpr double kS16PointMax = 8.0; // largest |coordinate| the fp16 operands carry
+
+// model side.  F: row-major 3x3; nan_model: the record's NaN flag (pl_math.h store_shadow)
+PL_HD void pf16_sampson_model(const double *F, bool nan_model, Sampson16Operand &o) {
+    for (int k = 0; k < 32; ++k)
+        o.c[k] = 0;
+    for (int k = 0; k < 16; ++k)
+        o.s[k] = 0;
+    double fm = 0.0;
+    bool bad = nan_model;
+    for (int k = 0; k < 9; ++k) {
+        const double a = fabs(F[k]);
+        bad |= (a != a);
+        fm = a > fm ? a : fm;
+    }
+    if (bad) {
+        o.s[11] = 0xfc00u; // -inf: no inliers
+        return;
+    }
+    if (!(fm >= 1e-18 && fm <= 1e18)) {
+        o.s[11] = 0x7c00u; // +inf: every correspondence is evaluated exactly
+        return;
+    }
+    int e;
+    (void)frexp(fm, &e);                  // fm in [2^(e-1), 2^e)
+    const double cF = ldexp(1.0, 10 - e); // max |F~| in [2^9, 2^10)
+    double Ft[9];
+    for (int k = 0; k < 9; ++k) {
+        Ft[k] = F[k] * cF;
+        uint16_t h, l;
+        pf_split16(Ft[k], h, l);
+        o.c[k] = h, o.c[9 + k] = h, o.c[18 + k] = l;
+    }
+    // G1 from rows 0, 1 (quadratic form in a), G2 from columns 0, 1 (in b)
+    const double *r0 = Ft, *r1 = Ft + 3;
+    const double c0[3] = {Ft[0], Ft[3], Ft[6]}, c1[3] = {Ft[1], Ft[4], Ft[7]};
+    auto g1 = [&](int i, int j) { return r0[i] * r0[j] + r1[i] * r1[j]; };
+    auto g2 = [&](int i, int j) { return c0[i] * c0[j] + c1[i] * c1[j]; };
+    const double sc = 0.0078125; // 2^-7
+    const double g[11] = {g1(0, 0) * sc, 2.0 * g1(0, 1) * sc, g1(1, 1) * sc, 2.0 * g1(0, 2) * sc, 2.0 * g1(1, 2) * sc,
+                          (g1(2, 2) + g2(2, 2)) * sc,
+                          g2(0, 0) * sc, 2.0 * g2(0, 1) * sc, g2(1, 1) * sc, 2.0 * g2(0, 2) * sc, 2.0 * g2(1, 2) * sc};
+    for (int k = 0; k < 11; ++k)
+        o.s[k] = pf_half_rn((float)g[k]);
+    o.s[11] = 0x7400u; // 2^14
+}
+
+// correspondence side.  Returns false (zero operands, largest finite slack) for points the operands cannot carry.
+PL_HD bool pf16_sampson_point(double a0, double a1, double b0, double b1, bool valid, float t16, Sampson16Operand &o) {
+    for (int k = 0; k < 32; ++k)
+        o.c[k] = 0;
+    for (int k = 0; k < 16; ++k)
+        o.s[k] = 0;
+    const double m = fmax(fmax(fabs(a0), fabs(a1)), fmax(fabs(b0), fabs(b1)));
+    const bool finite = (a0 == a0) & (a1 == a1) & (b0 == b0) & (b1 == b1);
+    if (!(valid && finite && m <= kS16PointMax)) {
+        o.s[11] = 0x7bffu; // 65504
+        return false;
+    }
+    const double al[3] = {a0, a1, 1.0}, be[3] = {b0, b1, 1.0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            uint16_t h, l;
+            pf_split16(be[i] * al[j] * 256.0, h, l);
+            o.c[3 * i + j] = h, o.c[9 + 3 * i + j] = l, o.c[18 + 3 * i + j] = h;
+        }
+    const double psi[11] = {a0 * a0, a0 * a1, a1 * a1, a0, a1, 1.0, b0 * b0, b0 * b1, b1 * b1, b0, b1};
+    for (int k = 0; k < 11; ++k)
+        o.s[k] = pf_half_rn((float)(psi[k] * 256.0));
+    const double na = 1.0 + fabs(a0) + fabs(a1), nb = 1.0 + fabs(b0) + fabs(b1);
+    const double EC = 2.1 * na * nb + 0.6;
+    const double ES = 4401.0 * (na * na + nb * nb) + 24.0;
+    const double w = (ES + 16.0 * EC * EC / (double)t16) * 1.000001;
+    o.s[11] = pf_half_up((float)(w * 6.103515625e-05) * 1.000001f); // 2^-14; >= 2^-14 * 8826: a normal fp16
+    return true;
+}
+
+// The verdict as the kernel computes it, with one particular accumulation order (the bound holds for any order):
+// true = certainly not an inlier.  Test-only host build and documentation of the device tail.
+PL_HD bool pf16_sampson_outlier(const Sampson16Operand &model, const Sampson16Operand &point, float t16) {
+    float C = 0.f, S = 0.f;
+    for (int k = 0; k < 32; ++k)
+        C = fmaf(pf_half_to_float(model.c[k]), pf_half_to_float(point.c[k]), C);
+    for (int k = 0; k < 16; ++k)
+        S = fmaf(pf_half_to_float(model.s[k]), pf_half_to_float(point.s[k]), S);
+    const float d = fmaf(t16, S, -(C * C));
+    uint32_t bits;
+    __builtin_memcpy(&bits, &d, 4);
+    return (bits >> 31) != 0u;
 }
 
 } // namespace pl

@@ -301,6 +301,63 @@ int hm_prefilter(int est, const double *rec, const double *const *pa, uint32_t n
     return 1;
 }
 
+// The Sampson pre-filter in its fp16 / matrix-core form (k_score_mfma2; pl_prefilter.h): the same operand builders as the
+// kernels, the two forms accumulated in fp32 in k-slot order.  Returns 0 when that form is not available for these
+// parameters (coordinates beyond 8, threshold out of range).  random_order != 0: the products are accumulated in a
+// pseudo-random order instead (the bound must hold for any order the matrix pipe may use).
+int hm_prefilter16(int est, const double *rec, const double *const *pa, uint32_t n, double thr2, float uv_absmax,
+                   uint32_t random_order, uint8_t *out) {
+    const PrefilterArgs pf = make_prefilter_args(est, thr2, uv_absmax);
+    std::memset(out, 0, n);
+    if (!pf.enabled || !(pf.t16 > 0.f) || (est != EST_REL && est != EST_FUND))
+        return 0;
+    const float *r = reinterpret_cast<const float *>(rec + kShadowOff);
+    uint32_t flag;
+    std::memcpy(&flag, &r[13], 4);
+    Sampson16Operand m;
+    pf16_sampson_model(rec + kMatOff, flag != 0u, m);
+    uint64_t rng = 0x9e3779b97f4a7c15ull * (random_order + 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        Sampson16Operand p;
+        pf16_sampson_point(pa[0][i], pa[1][i], pa[2][i], pa[3][i], true, pf.t16, p);
+        if (!random_order) {
+            out[i] = pf16_sampson_outlier(m, p, pf.t16);
+            continue;
+        }
+        int oc[32], os[16];
+        for (int k = 0; k < 32; ++k)
+            oc[k] = k;
+        for (int k = 0; k < 16; ++k)
+            os[k] = k;
+        auto next = [&]() {
+            rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17;
+            return (uint32_t)(rng >> 33);
+        };
+        for (int k = 31; k > 0; --k)
+            std::swap(oc[k], oc[next() % (k + 1)]);
+        for (int k = 15; k > 0; --k)
+            std::swap(os[k], os[next() % (k + 1)]);
+        float Cc = 0.f, S = 0.f;
+        for (int k = 0; k < 32; ++k)
+            Cc = fmaf(pf_half_to_float(m.c[oc[k]]), pf_half_to_float(p.c[oc[k]]), Cc);
+        for (int k = 0; k < 16; ++k)
+            S = fmaf(pf_half_to_float(m.s[os[k]]), pf_half_to_float(p.s[os[k]]), S);
+        const float d = fmaf(pf.t16, S, -(Cc * Cc));
+        uint32_t bits;
+        std::memcpy(&bits, &d, 4);
+        out[i] = (uint8_t)(bits >> 31);
+    }
+    return 1;
+}
+
+// fp16 conversions of pl_prefilter.h (checked against numpy's float16 by the tests)
+void hm_half_rn(const float *v, uint64_t n, uint16_t *bits, float *back) {
+    for (uint64_t i = 0; i < n; ++i) {
+        bits[i] = pf_half_rn(v[i]);
+        back[i] = pf_half_to_float(bits[i]);
+    }
+}
+
 void hm_mask_abs(const double *rec, const double *const *pa, uint32_t n, double thr2, uint8_t *mask) {
     for (uint32_t i = 0; i < n; ++i)
         mask[i] = reproj_mask(rec, pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], thr2);

@@ -124,6 +124,26 @@ def prefilter(est, rec, cols, thr2, xy_absmax=0.0):
     return bool(en), out.astype(bool)
 
 
+def prefilter16(est, rec, cols, thr2, uv_absmax, random_order=0):
+    """the Sampson pre-filter in its fp16 / matrix-core form: (available, mask of PROVEN non-inliers)"""
+    arrs, ptrs = _soa(cols)
+    n = arrs[0].shape[0]
+    out = np.zeros(n, dtype=np.uint8)
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    en = lib().hm_prefilter16(EST[est], _p(rec), ptrs, C.c_uint32(n), C.c_double(thr2), C.c_float(uv_absmax),
+                              C.c_uint32(random_order), _p(out))
+    return bool(en), out.astype(bool)
+
+
+def half_rn(v):
+    """pl_prefilter.h's float -> fp16 conversion: (bits, value of those bits as float32)"""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    bits = np.zeros(v.size, dtype=np.uint16)
+    back = np.zeros(v.size, dtype=np.float32)
+    lib().hm_half_rn(_p(v), C.c_uint64(v.size), _p(bits), _p(back))
+    return bits, back
+
+
 def score(est, rec, cols, thr2):
     arrs, ptrs = _soa(cols)
     n = arrs[0].shape[0]

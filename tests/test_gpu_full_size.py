@@ -169,10 +169,13 @@ def test_fp32_filters_never_drop_an_inlier_on_the_device(gpu, kind):
     okind = {1: "sampson_pose", 2: "sampson_F", 3: "homography"}[kind]
     for trial in range(8):
         pixel = kind != 1 and trial % 2 == 0  # F / H also on raw pixel coordinates (entries spanning 1e-6 .. 1)
+        # (fewer than 1024 normalised correspondences, or pixel coordinates: the fp32 form; otherwise Sampson scores take
+        # the matrix-core form, which has its own test below)
+        npts = 1000 if (kind != 3 and not pixel and trial % 4 == 1) else 3000
         if kind == 3:
-            d = synth.homography_scene(3000, 0.5, 6000 + trial)
+            d = synth.homography_scene(npts, 0.5, 6000 + trial)
         else:
-            d = synth.relative_pose_scene(3000, 0.5, 6100 + trial)
+            d = synth.relative_pose_scene(npts, 0.5, 6100 + trial)
         x1, x2 = np.asarray(d["x1"], float), np.asarray(d["x2"], float)
         if not pixel:
             x1, x2 = (x1 - 500.0) / FOCAL, (x2 - 500.0) / FOCAL
@@ -233,7 +236,7 @@ def test_fp32_filters_never_drop_an_inlier_on_the_device(gpu, kind):
             prob = gpu.Problem(kind, x1, x2)
             cnt, sc, path = prob.score_stream(M, thr)
             prob.close()
-            assert path == 1
+            assert path == (2 if (kind != 3 and not pixel and npts >= 1024) else 1), (kind, pixel, npts, thr, path)
             for k in range(len(M)):
                 osc, ocnt = O.score(okind, M[k], x1, x2, thr * thr)
                 pairs += len(x1)
@@ -243,7 +246,93 @@ def test_fp32_filters_never_drop_an_inlier_on_the_device(gpu, kind):
                 elif np.isfinite(osc):
                     assert abs(sc[k] - osc) <= 1e-9 * abs(osc) + 1e-300
     print(f"kind {kind}: {pairs} pairs through the device filter, count differences {diff}")
-    assert pairs >= 1_000_000 and diff == 0
+    assert pairs >= 900_000 and diff == 0
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_matrix_core_sampson_filter_never_drops_an_inlier_on_the_device(gpu, kind):
+    """k_score_mfma2: fp16 high / low operands, two quadratic forms per pair out of the matrix pipe (pl_prefilter.h).
+    Correspondences planted around the decision boundary, coordinates up to the operand bound of 8, matrices rescaled
+    over 27 decades, NaN / zero / rank-deficient models; counts must equal the oracle's exact evaluation."""
+    rs = np.random.RandomState(90 + kind)
+    pairs = diff = 0
+    okind = {1: "sampson_pose", 2: "sampson_F"}[kind]
+    for trial in range(10):
+        d = synth.relative_pose_scene(4000, 0.5, 6300 + trial)
+        sc = 1.0 if kind == 1 else [1.0, 1.0, 7.5, 3.0, 0.05][trial % 5]
+        x1, x2 = (np.asarray(d["x1"], float) - 500.0) / FOCAL * sc, (np.asarray(d["x2"], float) - 500.0) / FOCAL * sc
+        q, t = np.asarray(d["q_gt"], float), np.asarray(d["t_gt"], float)
+        S = np.diag([1 / sc, 1 / sc, 1.0])
+        gt = S @ _essential(q, t) @ S
+        models = []
+        for k in range(14):
+            if kind == 1:
+                if k == 0:
+                    qq, tt = q, t
+                elif k < 7:
+                    qq = q + 10.0 ** (-k) * rs.randn(4)
+                    qq /= np.linalg.norm(qq)
+                    tt = (t + 10.0 ** (-k) * rs.randn(3)) * rs.choice([1.0, 1e-3, 1e3])
+                elif k < 12:
+                    qq = rs.randn(4)
+                    qq /= np.linalg.norm(qq)
+                    tt = rs.randn(3)
+                elif k == 12:
+                    qq, tt = q, np.array([np.nan, 0.0, 1.0])
+                else:
+                    qq, tt = q, np.zeros(3)
+                models.append(np.r_[qq, tt])
+            else:
+                if k == 0:
+                    Mk = gt
+                elif k < 7:
+                    Mk = gt + 10.0 ** (-2 * k) * np.abs(gt).max() * rs.randn(3, 3)
+                elif k < 10:
+                    Mk = rs.randn(3, 3) * (1e-3 ** rs.randint(0, 3, (3, 3)))
+                elif k == 10:
+                    Mk = np.outer(rs.randn(3), rs.randn(3))  # rank one
+                elif k == 11:
+                    Mk = gt.copy()
+                    Mk[1, 1] = np.nan
+                elif k == 12:
+                    Mk = np.zeros((3, 3))
+                else:
+                    Mk = np.diag([0.0, 0.0, 1.0])  # Cx + Cy = 0 for every correspondence
+                models.append(Mk * 10.0 ** rs.choice([-12, -3, 0, 0, 4, 15]) * rs.choice([-1.0, 1.0]))
+        M = np.array(models)
+        # half of the second-image points moved onto the decision boundary of the first model: along the normal of the
+        # epipolar line, to k thr (1 +- 1e-9 .. 1e-3) for a few k around the Sampson / point-line ratio
+        a = np.c_[x1, np.ones(len(x1))]
+        l = a @ gt.T
+        nrm = np.linalg.norm(l[:, :2], axis=1)
+        dist = np.einsum("ij,ij->i", np.c_[x2, np.ones(len(x2))], l) / nrm
+        foot = x2 - dist[:, None] * l[:, :2] / nrm[:, None]
+        for thr in (1e-5 * sc, 1e-3 * sc, 3e-3 * sc, 0.1 * sc):
+            eps = 10.0 ** rs.uniform(-9, -3, len(x2)) * rs.choice([-1, 1], len(x2))
+            kk = rs.choice([0.9, 1.0, 1.2, 1.41, 1.42, 1.6], len(x2))
+            planted = foot + (kk * thr * (1 + eps))[:, None] * l[:, :2] / nrm[:, None]
+            b = x2.copy()
+            sel = rs.rand(len(x2)) < 0.5
+            b[sel] = planted[sel]
+            if trial == 1:
+                b[::9] *= 30.0  # correspondences beyond the operand bound: the problem falls back to the fp32 form
+            if trial == 2 and kind == 2:
+                b[::11] = np.clip(b[::11] * 1.05, -7.99, 7.99)
+            prob = gpu.Problem(kind, x1, b)
+            cnt, scv, path = prob.score_stream(M, thr)
+            prob.close()
+            in_range = max(np.abs(x1).max(), np.abs(b).max()) <= 8.0 and 1e-12 <= thr * thr <= 1e4
+            assert path == (2 if in_range else 1), (kind, trial, thr, path)
+            for k in range(len(M)):
+                osc, ocnt = O.score(okind, M[k], x1, b, thr * thr)
+                pairs += len(x1)
+                if cnt[k] != ocnt:
+                    diff += abs(int(cnt[k]) - int(ocnt))
+                    print("MISMATCH kind", kind, "trial", trial, "thr", thr, "model", k, cnt[k], ocnt)
+                elif np.isfinite(osc):
+                    assert abs(scv[k] - osc) <= 1e-9 * abs(osc) + 1e-300
+    print(f"kind {kind}: {pairs} pairs through the matrix-core Sampson filter, count differences {diff}")
+    assert pairs >= 2_000_000 and diff == 0
 
 
 # ------------------------------------------------------------------------------------------ concurrency of the batch entry

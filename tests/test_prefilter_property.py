@@ -210,3 +210,122 @@ def test_degenerate_models():
         assert not (inl & out).any()
     # thresholds outside the range fp32 can carry switch the filter off
     assert not HM.prefilter("fund", HM.matrix_record(np.eye(3)), _two_view_cols(d, True), 1e-40)[0]
+
+
+# ---- Sampson, fp16 / matrix-core form (k_score_mfma2) ---------------------------------------------------------------
+def _check16(est, rec, cols, thr2, uv, stats=None, order=0):
+    _, _, inl, _ = HM.score(est, rec, cols, thr2)
+    en, out = HM.prefilter16(est, rec, cols, thr2, uv, order)
+    bad = inl & out
+    assert not bad.any(), (est, thr2, np.flatnonzero(bad)[:5])
+    if stats is not None and en:
+        stats[0] += int((~inl).sum())
+        stats[1] += int((~inl & ~out).sum())
+    return en
+
+
+def test_fp16_conversions_match_ieee_half():
+    rs = np.random.RandomState(11)
+    v = np.concatenate([rs.randn(400000) * 10.0 ** rs.uniform(-9, 5, 400000),
+                        [0, -0.0, 65504, 65519.9, 65520, 1e9, -1e9, np.inf, -np.inf, 6.1e-5, 6.0e-5, 5.96e-8, 2.98e-8,
+                         2.99e-8, 1e-10, 2.0 ** -14, 2.0 ** -24, 2.0 ** -25, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11]]).astype(np.float32)
+    bits, back = HM.half_rn(v)
+    with np.errstate(over="ignore"):
+        want = v.astype(np.float16)
+    assert (bits == want.view(np.uint16)).all()
+    assert (back == want.astype(np.float32)).all()
+
+
+@pytest.mark.parametrize("est", ["fund", "rel"])
+def test_sampson_fp16_form_never_drops_an_inlier(est):
+    rs = np.random.RandomState(5)
+    stats = [0, 0]
+    enabled = 0
+    for trial in range(40):
+        d = synth.relative_pose_scene(1500, 0.5, 600 + trial)
+        q, t = np.asarray(d["q_gt"], float), np.asarray(d["t_gt"], float)
+        cols = _two_view_cols(d, False)
+        # coordinate scales the operands must carry: normalised image points, points near the bound of 8, tiny ones
+        sc = [1.0, 1.0, 7.9, 1e-3, 3.0][trial % 5]
+        cols = [c * sc for c in cols]
+        uv = float(max(np.abs(c).max() for c in cols))
+        recE = _essential(q, t)
+        E = recE[HM.MAT:HM.MAT + 9].reshape(3, 3)
+        for thr in (1e-5 * sc, 1e-3 * sc, 3e-3 * sc, 0.1 * sc):
+            for model in range(5):
+                if est == "rel":
+                    if model == 0:
+                        rec = recE
+                    elif model < 3:
+                        qq = q + 10.0 ** -(model + 1) * rs.randn(4)
+                        qq /= np.linalg.norm(qq)
+                        tt = t + 10.0 ** -(model + 1) * rs.randn(3)
+                        rec = _essential(qq, tt * rs.choice([1.0, 1e-3, 1e3]))
+                    else:
+                        qq = rs.randn(4)
+                        rec = _essential(qq / np.linalg.norm(qq), rs.randn(3))
+                else:
+                    S = np.diag([1 / sc, 1 / sc, 1.0])
+                    Fgt = S @ E @ S
+                    if model == 0:
+                        F = Fgt
+                    elif model < 3:
+                        F = Fgt + 10.0 ** -(2 * model) * np.abs(Fgt).max() * rs.randn(3, 3)
+                    else:
+                        F = rs.randn(3, 3) * 1e-3 ** rs.randint(0, 3, (3, 3))
+                    F = F * 10.0 ** rs.choice([-12, -3, 0, 0, 4, 15])
+                    rec = HM.matrix_record(F)
+                if est == "rel" and sc != 1.0:
+                    continue  # (an essential matrix lives on normalised coordinates)
+                # selectivity is reported for the regime the form is meant for (coordinates of order one, thresholds of
+                # a pixel at focal lengths of 10^2..10^4); the never-drops property is checked everywhere
+                typical = sc in (1.0, 3.0) and thr >= 1e-3 * sc
+                enabled += _check16(est, rec, cols, thr * thr, uv, stats if typical else None, order=trial % 3)
+    assert enabled > 100
+    print(f"{est} (fp16 form): {stats[1]}/{stats[0]} non-inliers pass the filter ({100.0 * stats[1] / stats[0]:.3f} %)")
+    assert stats[1] < (0.15 if est == "rel" else 0.05) * stats[0]
+
+
+def test_sampson_fp16_form_at_the_threshold_and_degenerate():
+    rs = np.random.RandomState(6)
+    for trial in range(12):
+        d = synth.relative_pose_scene(3000, 0.0, 700 + trial)
+        cols = _two_view_cols(d, False)
+        rec = _essential(d["q_gt"], d["t_gt"])
+        E = rec[HM.MAT:HM.MAT + 9].reshape(3, 3)
+        # move the second point along the epipolar normal until the Sampson error is thr (1 +- eps)
+        a = np.c_[cols[0], cols[1], np.ones(len(cols[0]))]
+        l = a @ E.T  # epipolar lines in image 2
+        nrm = np.linalg.norm(l[:, :2], axis=1)
+        b = np.c_[cols[2], cols[3]]
+        dist = (np.einsum("ij,ij->i", np.c_[b, np.ones(len(b))], l)) / nrm
+        foot = b - (dist / nrm)[:, None] * l[:, :2]
+        for thr in (1e-4, 1e-3, 1e-2):
+            eps = 10.0 ** rs.uniform(-9, -3, len(b)) * rs.choice([-1, 1], len(b))
+            # (first order: the Sampson distance is close to the point-line distance / sqrt(2) here; scan a band around it)
+            for k in (0.9, 1.0, 1.2, 1.41, 1.6):
+                bb = foot + (k * thr * (1 + eps) / nrm)[:, None] * l[:, :2]
+                c2 = [cols[0], cols[1], bb[:, 0], bb[:, 1]]
+                uv = float(max(np.abs(c).max() for c in c2))
+                _check16("fund", rec, c2, thr * thr, uv)
+                _check16("rel", rec, c2, thr * thr, uv)
+    d = synth.homography_scene(500, 0.3, 7)
+    cols = _two_view_cols(d, False)
+    uv = float(max(np.abs(c).max() for c in cols))
+    for M in (np.zeros((3, 3)), np.full((3, 3), np.nan), np.eye(3) * 1e-30, np.eye(3) * 1e30, np.eye(3) * 1e-17,
+              np.array([[1, 0, 0], [0, np.inf, 0], [0, 0, 1.0]]), np.array([[1, 0, 0], [0, 1, 0], [np.nan, 0, 1.0]]),
+              np.array([[0, 0, 0], [0, 0, 0], [0, 0, 1.0]]), np.array([[1e-9, 0, 0], [0, 1e-9, 0], [0, 0, 1.0]])):
+        rec = HM.matrix_record(M)
+        _, _, inl, _ = HM.score("fund", rec, cols, 1e-4)
+        en, out = HM.prefilter16("fund", rec, cols, 1e-4, uv)
+        assert en and not (inl & out).any()
+        if np.isnan(M).any():
+            assert out.all()
+    # points with NaN / huge coordinates are never excluded; the form is off beyond the coordinate bound
+    bad = [c.copy() for c in cols]
+    bad[0][:5] = np.nan
+    bad[2][5:10] = 7.99
+    en, out = HM.prefilter16("fund", HM.matrix_record(np.eye(3)), bad, 1e-4, 7.99)
+    assert en and not out[:5].any()
+    assert not HM.prefilter16("fund", HM.matrix_record(np.eye(3)), cols, 1e-4, 8.5)[0]
+    assert not HM.prefilter16("fund", HM.matrix_record(np.eye(3)), cols, 1e-14, uv)[0]
