@@ -201,22 +201,42 @@ def run_workload(name, args, ranks, P, synth, pool_factory, primary):
 
         exchange = sharding.dist_allgather(device=(f"cuda:{ranks.device_index}" if ranks.backend == "nccl" else None))
 
+    def options(seed):
+        return {"max_error": thr, "ransac": {"max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "seed": seed}}
+
     def run_one(a):
         prob, seed = a
-        opt = {"max_error": thr, "ransac": {"max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "seed": seed}}
         if exchange is not None:
-            return prob.run_sharded(opt, ranks.rank, ranks.world, exchange)
-        return prob.run(opt)
+            return prob.run_sharded(options(seed), ranks.rank, ranks.world, exchange)
+        return prob.run(options(seed))
 
     if primary and args.problems_per_step > 0:
         PPS = args.problems_per_step
     else:
         PPS = max(PARITY_SEEDS, PPS_PER_STREAM * S if primary else max(1, int(PPS_PER_STREAM * S * args.secondary_scale)))
+    grouped = args.mode == "groups" and not shard_problem
+    G, T = max(1, args.group_size), max(1, args.group_threads)
+
+    # grouped mode (default): one C-ABI call per step, pl_ransac_batch - the PPS problems advance in lock-step groups of
+    # G through ONE launch sequence per group and batch of iterations, T host threads inside the library work on
+    # different groups.  The descriptors (options structs, output buffers) of every step are marshalled before the
+    # timed region: what is timed is the library call.
+    batches = {}
+    if grouped:
+        for sd in [1000 + w for w in range(args.warmup)] + list(range(args.steps)):
+            batches[sd] = P.RansacBatch([probs[j % S] for j in range(PPS)], [options(sd * PPS + j) for j in range(PPS)])
 
     def step(seed):
-        """a batch of PPS independent problems (RANSAC seeds seed * PPS + j) worked through by S host threads / HIP
-        streams, i.e. S problems in flight on this GPU at any time"""
-        return list(pool.map(run_one, [(probs[j % S], seed * PPS + j) for j in range(PPS)]))
+        """a batch of PPS independent problems (RANSAC seeds seed * PPS + j).  Grouped: see above; --mode streams: worked
+        through by S host threads / HIP streams, i.e. S problems in flight on this GPU at any time.
+        Returns the pl_ransac_stats of the problems"""
+        if grouped:
+            batches[seed].run(T, G)
+            return batches[seed].stats()
+        return [info for _, info in pool.map(run_one, [(probs[j % S], seed * PPS + j) for j in range(PPS)])]
+
+    def field(st, name):
+        return st[name] if isinstance(st, dict) else getattr(st, name)
 
     for w in range(args.warmup):
         step(1000 + w)
@@ -232,27 +252,34 @@ def run_workload(name, args, ranks, P, synth, pool_factory, primary):
     t0 = time.perf_counter()
     hyp = nan_hyp = launches = 0
     kern_ms = 0.0
-    first, last = None, None
+    last_inliers = 0
+    first_streams = None
     for s in range(args.steps):
         res = step(s)
-        if s == 0:
-            first = res[:PARITY_SEEDS]  # RANSAC seeds 0..7: the ones the oracle runs below
-        for _, info in res:
-            hyp += info["hypotheses"]
-            nan_hyp += info["nan_hypotheses"]
-            kern_ms += info["score_kernel_ms"]
-            launches += info["score_kernel_launches"]
-        last = res[-1]
+        if s == 0 and not grouped:
+            first_streams = res[:PARITY_SEEDS]
+        for st in res:
+            hyp += field(st, "hypotheses")
+            nan_hyp += field(st, "nan_hypotheses")
+            kern_ms += field(st, "score_kernel_ms")
+            launches += field(st, "score_kernel_launches")
+        last_inliers = field(res[-1], "num_inliers")
     ranks.barrier()
     elapsed = time.perf_counter() - t0
+    # RANSAC seeds 0..7 of the first timed step: the ones the oracle runs below
+    if grouped:
+        first = batches[0].results()[:PARITY_SEEDS]
+    else:
+        first = [pool.submit(run_one, (probs[j % S], j)).result() for j in range(PARITY_SEEDS)] if first_streams is not None else None
+    batches.clear()
     for pr in probs:
         pr.close()
     pool.shutdown()
-    rec = [elapsed, float(hyp), kern_ms, float(launches), float(last[1]["num_inliers"]), float(nan_hyp), solo_ms,
+    rec = [elapsed, float(hyp), kern_ms, float(launches), float(last_inliers), float(nan_hyp), solo_ms,
            float(solo_launches), float(solo_hyp)]
     ctx = {"A": A, "B": Bpts, "thr": thr, "first": first, "PPS": PPS, "S": S, "kind": KIND, "n": N_POINTS,
            "bytes_per_corr": BYTES_PER_CORR, "descr": DESCR, "outliers": OUTLIER_RATIO, "max_error_px": MAX_ERROR_PX,
-           "shard_problem": shard_problem}
+           "shard_problem": shard_problem, "grouped": grouped, "G": G, "T": T}
     return rec, ctx
 
 
@@ -327,7 +354,8 @@ def report_workload(name, table, ctx, args, world):
     traffic = pmc.get("traffic_bytes_per_launch")
     roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST_S,
             "peak_basis": f"{SIMDS} SIMDs x {PEAK_CLOCK_GHZ} GHz / 4 cycles per wave64 VALU instruction",
-            "kernel": kernel_name, "launches": k_launch, "launches_in_flight": ctx["S"],
+            "kernel": kernel_name, "launches": k_launch,
+            "launches_in_flight": ctx["T"] if ctx["grouped"] else ctx["S"],
             "avg_launch_ms": 1e3 * avg_launch_s, "solo_avg_launch_ms": 1e3 * solo_launch_s,
             "hypotheses_per_launch": hyp_per_launch, "point_hypotheses_per_s": value * n_points,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
@@ -344,7 +372,8 @@ def report_workload(name, table, ctx, args, world):
         roof.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINST_S,
                      "frac_basis": "the kernel with the device to itself (4 problems one after the other right before "
                                    "the timed region; HIP events on the launching stream) - in the timed region "
-                                   f"{ctx['S']} launches share the device, see device_frac_timed_region",
+                                   "several launches share the device (grouped mode: every launch serves a group of "
+                                   "problems, avg_launch_ms is one problem's share), see device_frac_timed_region",
                      "valu_insts_per_hypothesis_chunk": per_hc, "points_per_chunk": chunk_pts,
                      "valu_insts_per_launch": insts_solo,
                      "device_frac_timed_region": insts_all / 1e9 / VALU_PEAK_GINST_S / float(table[0, 0]),
@@ -358,7 +387,11 @@ def report_workload(name, table, ctx, args, world):
     out = {"value": value, "unit": "hypotheses/s", "ms_per_step": 1e3 * t_max / args.steps,
            "problem": ctx["descr"], "correspondences": n_points, "outlier_ratio": ctx["outliers"],
            "max_iterations": ITERATIONS, "min_iterations": ITERATIONS, "max_error_px": ctx["max_error_px"],
-           "problems_per_gpu_per_step": ctx["PPS"], "problems_in_flight_per_gpu": ctx["S"],
+           "problems_per_gpu_per_step": ctx["PPS"],
+           "problems_in_flight_per_gpu": (ctx["G"] * ctx["T"]) if ctx["grouped"] else ctx["S"],
+           "execution": (f"pl_ransac_batch: lock-step groups of {ctx['G']} problems (one launch sequence per group and batch "
+                         f"of iterations), {ctx['T']} groups in flight") if ctx["grouped"] else
+                        f"pl_ransac_run from {ctx['S']} host threads, one HIP stream each",
            "timed_region_s": t_max, "hypotheses_per_step": hyp0 / args.steps,
            "iterations_per_s": (1 if shard_problem else world) * ctx["PPS"] * args.steps * ITERATIONS / t_max,
            "nan_model_share": (nan0 / hyp0) if hyp0 else None,
@@ -527,8 +560,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", default="groups", choices=["groups", "streams"],
+                    help="groups (default): every step is ONE pl_ransac_batch call, problems advance in lock-step groups; "
+                         "streams: pl_ransac_run from --streams host threads (round 1's form)")
+    ap.add_argument("--group-size", type=int, default=16, help="problems per lock-step group (pl_ransac_batch)")
+    ap.add_argument("--group-threads", type=int, default=4, help="groups in flight (host threads inside pl_ransac_batch)")
     ap.add_argument("--streams", type=int, default=16,
-                    help="independent problems in flight per GPU (one host thread + HIP stream each)")
+                    help="--mode streams: independent problems in flight per GPU (one host thread + HIP stream each); "
+                         "also sets the default step size (64 x streams problems)")
     ap.add_argument("--problems-per-step", type=int, default=0,
                     help="independent problems per step and GPU of the primary workload (default 64 x streams)")
     ap.add_argument("--workload", default="p3p_5000", choices=sorted(WORKLOADS))

@@ -168,6 +168,25 @@ void pl_problem_destroy(pl_problem *p);
 /* model: pl_camera_pose for kinds 0/1, double[9] column-major for kinds 2/3 */
 int pl_ransac_run(pl_problem *p, const pl_robust_options *opt, void *model, uint8_t *inliers, pl_ransac_stats *stats);
 
+/* ---- many device-resident problems at once: every item is one pl_ransac_run (a loop over ransac_pnp / ransac_relpose /
+ * ransac_fundamental / ransac_homography of robust/ransac.h:45-66 on the reference side), same results bit for bit.
+ * Items of the same kind advance in lock-step groups of `group_size` problems (<= 0: 16, at most 64): one launch sequence
+ * per group and batch of iterations instead of one per problem, which is what keeps the device busy when thousands of
+ * problems are queued (bench.py's throughput mode).  `max_in_flight` host threads (<= 0: 4), each with its own stream,
+ * work on different groups.  Items a group cannot take (PROSAC, warm starts, fewer correspondences than sample size + 4,
+ * more than 16384) run through pl_ransac_run. ---- */
+typedef struct {
+    pl_problem *problem;
+    const pl_robust_options *opt;
+    void *model;            /* out: pl_camera_pose (kinds 0, 1) or double[9] column-major (kinds 2, 3); in as well when
+                               opt->ransac.score_initial_model is set */
+    uint8_t *inliers;       /* optional, problem size bytes */
+    pl_ransac_stats *stats; /* optional */
+    int32_t status;         /* out: PL_OK or the error of this item */
+    int32_t reserved;
+} pl_ransac_item;
+int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int group_size);
+
 /* ---- ONE problem across several GPUs: every rank holds the same correspondences (its own pl_problem on
  * its own device) and calls pl_ransac_run_sharded with the same options.  Each batch of iterations is cut into `world`
  * contiguous ranges; a rank draws the whole batch's sample positions (integer work, replicated) but generates and

@@ -61,6 +61,11 @@ BatchItem._fields_ = [("kind", i32), ("status", i32), ("a", C.c_void_p), ("b", C
                       ("model", C.c_void_p), ("inliers", C.c_void_p), ("stats", C.POINTER(RansacStats))]
 
 
+class RansacItem(C.Structure):  # pl_ransac_item
+    _fields_ = [("problem", C.c_void_p), ("opt", C.POINTER(RobustOptions)), ("model", C.c_void_p), ("inliers", C.c_void_p),
+                ("stats", C.POINTER(RansacStats)), ("status", i32), ("reserved", i32)]
+
+
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
@@ -121,6 +126,7 @@ def _declare(L):
         "pl_estimate_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
         "pl_estimate_homography": (cint, [vp, vp, sz, opt, vp, vp, stats]),
         "pl_estimate_batch": (cint, [P(BatchItem), sz, cint]),
+        "pl_ransac_batch": (cint, [P(RansacItem), sz, cint, cint]),
         "pl_undistort_points": (cint, [cam, vp, sz, vp]),
         "pl_ransac_pnp": (cint, [vp, vp, sz, opt, pose, vp, stats]),
         "pl_ransac_relpose": (cint, [vp, vp, sz, opt, pose, vp, stats]),
@@ -161,4 +167,5 @@ EXPORTED_SYMBOLS = [
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
     "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
+    "pl_ransac_batch",
 ]

@@ -327,6 +327,54 @@ def estimate_batch(problems, max_in_flight=8):
     return b.results()
 
 
+class RansacBatch:
+    """pl_ransac_item descriptors for device-resident problems (`Problem`), marshalled once: `run()` is the C-ABI call
+    pl_ransac_batch and nothing else (what bench.py times), `results()` returns what `Problem.run` returns per item."""
+
+    def __init__(self, problems, opts):
+        assert len(problems) == len(opts)
+        self.items = (L.RansacItem * len(problems))()
+        self.keep = []
+        for it, pr, opt in zip(self.items, problems, opts):
+            o = _robust_options(opt, pr.kind, False)
+            inl = np.zeros(max(pr.n, 1), dtype=np.uint8)
+            st = L.RansacStats()
+            if pr.kind in (KIND_ABS, KIND_REL):
+                model = _cpose(CameraPose())
+                it.model = C.cast(C.pointer(model), C.c_void_p)
+            else:
+                model = np.ascontiguousarray(np.eye(3).reshape(9))
+                it.model = _ptr(model)
+            it.problem = pr._h
+            it.opt = C.pointer(o)
+            it.inliers = _ptr(inl)
+            it.stats = C.pointer(st)
+            self.keep.append((pr, o, model, inl, st))
+
+    def run(self, max_in_flight=4, group_size=16):
+        L.check(L.lib().pl_ransac_batch(self.items, C.c_size_t(len(self.items)), int(max_in_flight), int(group_size)))
+
+    def stats(self):
+        return [k[4] for k in self.keep]
+
+    def results(self):
+        out = []
+        for pr, o, model, inl, st in self.keep:
+            if pr.kind in (KIND_ABS, KIND_REL):
+                out.append((_pypose(model), _info(st, inl[: pr.n])))
+            else:
+                out.append((model.reshape(3, 3).T.copy(), _info(st, inl[: pr.n])))
+        return out
+
+
+def ransac_batch(problems, opts, max_in_flight=4, group_size=16):
+    """Many device-resident problems in one call (pl_ransac_batch): results of `problems[i].run(opts[i])`, bit for bit.
+    Problems of the same kind advance in lock-step groups of `group_size` through one launch sequence."""
+    b = RansacBatch(problems, opts)
+    b.run(max_in_flight, group_size)
+    return b.results()
+
+
 def estimate_fundamental(points2D_1, points2D_2, opt=None, initial_F=None):
     return _estimate_matrix("pl_estimate_fundamental", KIND_FUND, points2D_1, points2D_2, opt, initial_F)
 

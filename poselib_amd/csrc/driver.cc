@@ -2601,6 +2601,67 @@ void run_group_job(std::vector<GroupItem> &items) {
 }
 } // namespace
 
+int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int group_size) {
+    if (count == 0)
+        return PL_OK;
+    if (!items)
+        return fail(PL_ERR_INVALID, "items pointer is null");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    static const bool no_groups = std::getenv("POSELIB_AMD_NO_GROUPS") != nullptr;
+    const size_t gsz = (size_t)(group_size <= 0 ? 16 : std::min<int>(group_size, (int)kGroupMax));
+    auto run_solo = [](pl_ransac_item &it) {
+        it.status = pl_ransac_run(it.problem, it.opt, it.model, it.inliers, it.stats);
+    };
+    std::vector<size_t> by_kind[4], solo;
+    for (size_t i = 0; i < count; ++i) {
+        items[i].status = PL_OK;
+        if (!no_groups && group_eligible_resident(items[i]) && items[i].problem->device == c->device)
+            by_kind[items[i].problem->kind].push_back(i);
+        else
+            solo.push_back(i);
+    }
+    std::vector<std::vector<GroupItem>> groups;
+    for (int k = 0; k < 4; ++k) {
+        std::vector<size_t> &v = by_kind[k];
+        std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].problem->n > items[b].problem->n; });
+        for (size_t at = 0; at < v.size(); at += gsz) {
+            groups.emplace_back();
+            for (size_t j = at; j < std::min(v.size(), at + gsz); ++j) {
+                GroupItem g;
+                g.ritem = &items[v[j]];
+                g.kind = k;
+                groups.back().push_back(g);
+            }
+        }
+    }
+    std::vector<std::function<void()>> jobs;
+    for (auto &grp : groups)
+        jobs.emplace_back([&grp, run_solo] {
+            Context *cc;
+            int r = get_context(&cc);
+            if (r == PL_OK) {
+                for (GroupItem &g : grp)
+                    group_prepare_resident(g);
+                r = run_group(cc, grp.data(), (uint32_t)grp.size(), true);
+            }
+            for (GroupItem &g : grp)
+                if (r != PL_OK || g.fallback)
+                    run_solo(*g.ritem);
+        });
+    for (size_t i : solo)
+        jobs.emplace_back([items, i, run_solo] { run_solo(items[i]); });
+    int w = max_in_flight <= 0 ? 4 : std::min(max_in_flight, 64);
+    w = (int)std::min<size_t>((size_t)w, jobs.size());
+    batch_pool_instance().run(jobs, w, g_requested_device);
+    for (size_t i = 0; i < count; ++i)
+        if (items[i].status != PL_OK)
+            return fail(items[i].status, ("pl_ransac_batch: item " + std::to_string(i) + " failed").c_str());
+    return PL_OK;
+}
+
 int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     if (count == 0)
         return PL_OK;

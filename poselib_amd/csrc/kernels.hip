@@ -1276,6 +1276,15 @@ __global__ __launch_bounds__(kMfmaThreads) void k_score_mfma2(PointSet pts, cons
                               blockIdx.x, blockIdx.y, gridDim.x);
 }
 
+template <int EST, int PG> __global__ __launch_bounds__(kMfmaThreads) void k_score_mfma2_g(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active || !g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
+        return;
+    const ScoreArgs &a = g.score;
+    score_mfma2_body<EST, PG>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models, a.slots, a.num_hyp, a.hyp_capacity,
+                              a.thr2, a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
+}
+
 // ---- MSAC score in the reference's summation order ------------------------------------------------------------------
 // The streaming scorers add the inlier residuals of a hypothesis in tree order; the reference adds them one after the
 // other in correspondence order (utils.cc:52-63).  The two sums differ in the last bits, which only matters when two
@@ -2020,7 +2029,11 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     score_shape(E, a.pts.n, streaming, a.shadow16 != nullptr, chunks, P);
     if constexpr (E == EST_REL || E == EST_FUND) {
         if (streaming && a.shadow16) { // Sampson pre-filter on the matrix cores
-            const dim3 mgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
+            // two workgroups fit a CU (LDS): one resident round of 512 workgroups - a second, half-empty round would cost
+            // as much as the first, and every workgroup pays the fp16 split of its chunk before its first hypothesis
+            const uint32_t mslices = std::min<uint32_t>(slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads,
+                                                        std::max<uint32_t>(1u, 512u / chunks));
+            const dim3 mgrid(std::max<uint32_t>(1u, mslices), chunks);
             const dim3 mblock(kMfmaThreads);
 #define PL_M2_CASE(PP)                                                                                                 \
     case PP:                                                                                                           \
@@ -2198,12 +2211,18 @@ template <int E> static hipError_t launch_group_score_est(const GroupArgs *args,
     } else if constexpr (E == EST_HOM) {
         k_score_queue_g<EST_HOM, 5><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
     } else {
-        k_score_queue_g<E, 6><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
+        // (problems on the matrix-core form cut their correspondences into chunks of 32 PG, the others into 64 * 6: the
+        // grid covers the larger chunk count, every block checks its own problem's)
+        if (d.any_mfma)
+            k_score_mfma2_g<E, 2 * group_mfma2_points_per_lane(E)><<<grid, dim3(kMfmaThreads), 0, stream>>>(args);
+        if (d.any_queue)
+            k_score_queue_g<E, 6><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
+hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &d, hipStream_t stream, hipEvent_t ev0,
+                              hipEvent_t ev1) {
     if (d.G == 0)
         return hipSuccess;
     hipError_t e = launch_group_positions(sample_size(est), args, d, stream);
@@ -2220,8 +2239,12 @@ hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &d
     e = launch_group_compact(args, d, stream);
     if (e != hipSuccess)
         return e;
+    if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess)
+        return e;
     PL_DISPATCH_EST(est, e = launch_group_score_est<E>(args, d, stream));
     if (e != hipSuccess)
+        return e;
+    if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess)
         return e;
     e = launch_group_finalize_records(args, d, stream);
     if (e != hipSuccess)

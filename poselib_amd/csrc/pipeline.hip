@@ -812,8 +812,15 @@ __global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, 
     }
     if (!g.comp.s16.out)
         return;
-    const uint32_t cap8 = (uint32_t)((cap + 7u) & ~7ull);
     const uint32_t k = (blockIdx.x - gather_blocks_max) * 256 + threadIdx.x;
+    if (g.comp.s16.sampson) {
+        const uint32_t H = g.comp.ctl->num_hyp;
+        const uint32_t capp = (uint32_t)std::min<uint64_t>(cap + kSampson16Pad, 0xffffff00ull);
+        if (k < min(capp, H + (uint32_t)kSampson16Pad))
+            sampson16_one(k, H, capp, g.comp.slots, g.comp.models, static_cast<uint4 *>(g.comp.s16.out));
+        return;
+    }
+    const uint32_t cap8 = (uint32_t)((cap + 7u) & ~7ull);
     if (k >= cap8)
         return;
     const uint32_t *slots = g.comp.slots;
@@ -1022,7 +1029,7 @@ hipError_t launch_group_positions(int K, const GroupArgs *args, const GroupDims 
 hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
     k_compact2_g<<<dim3((d.max_B + 1023) / 1024, 1, d.G), dim3(1024), 0, stream>>>(args);
     const uint32_t gblocks = (uint32_t)(((uint64_t)d.max_hcap * 12u + 255) / 256);
-    const uint32_t sblocks = d.any_mfma ? (((d.max_hcap + 7u) & ~7u) + 255) / 256 : 0u;
+    const uint32_t sblocks = d.any_mfma ? (((d.max_hcap + 7u) & ~7u) + (uint32_t)kSampson16Pad + 255) / 256 : 0u;
     k_gather_shadow16_g<<<dim3(gblocks + sblocks, 1, d.G), dim3(256), 0, stream>>>(args, gblocks);
     return hipGetLastError();
 }

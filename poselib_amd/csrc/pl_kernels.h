@@ -269,6 +269,8 @@ struct GroupArgs { // everything the kernels of one batch step need for ONE prob
     RecordsArgs rec;
     SeqScoreArgs seq;
 };
+// chunk = 64 * this many correspondences for two-view problems scored by k_score_mfma2 in a group (score_shape's bound)
+constexpr int group_mfma2_points_per_lane(int est) { return est == EST_REL ? 5 : 6; }
 struct GroupDims { // grid extents: maxima over the active problems of the group
     uint32_t G;          // problems (grid.z)
     uint32_t max_M;      // sampler window
@@ -280,7 +282,9 @@ struct GroupDims { // grid extents: maxima over the active problems of the group
 };
 // positions -> generate -> compact/gather(/fp16 operands) -> score -> finalize/records -> candidates re-scored: the
 // whole batch step of every active problem of the group, one launch per kernel
-hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &dims, hipStream_t stream);
+// ev0 / ev1 (optional): recorded around the scoring launch(es)
+hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &dims, hipStream_t stream,
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_group_score_seq(int est, const SeqScoreArgs *args, uint32_t G, uint32_t max_cap, hipStream_t stream);
 hipError_t launch_group_select(const SelectArgs *args, uint32_t G, hipStream_t stream);
 hipError_t launch_group_mask(int est, const MaskArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream);

@@ -128,3 +128,79 @@ print("RESULT " + json.dumps([[repr(float(v)) for v in T._flat(pr, m)] + [i["ite
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1])
     assert outs[0] == outs[1]
+
+
+# ---- pl_ransac_batch: device-resident problems in lock-step groups ------------------------------------------------------
+def _resident_set(gpu, base):
+    """(Problem, options) pairs of all four kinds: default-length runs, long fixed-length runs (several batches of a group
+    with a small arena, one fat batch otherwise), sizes on both sides of the matrix-core scorers' thresholds"""
+    out = []
+    for i in range(24):
+        kind = i % 4
+        n = [30, 700, 1500, 5000, 2300, 10000][(i // 4) % 6]
+        outl = 0.3 + 0.05 * (i % 7)
+        if kind == 0:
+            d = synth.absolute_pose_scene(n, outl, base + i)
+            a, b = (np.asarray(d["p2d"]) - 500.0) / 1000.0, d["p3d"]
+            thr = 12.0 / 1000.0
+        else:
+            gen = {1: synth.relative_pose_scene, 2: synth.fundamental_scene, 3: synth.homography_scene}[kind]
+            d = gen(n, outl, base + i)
+            a, b = (np.asarray(d["x1"]) - 500.0) / 1000.0, (np.asarray(d["x2"]) - 500.0) / 1000.0
+            thr = 1.0 / 1000.0
+        its = [None, 3000, 20000, None, 9000, 700][(i // 4) % 6]
+        ro = {"seed": base + i}
+        if its:
+            ro.update(max_iterations=its, min_iterations=its)
+        out.append((gpu.Problem(kind, a, b), {"max_error": thr, "ransac": ro}))
+    return out
+
+
+def _same(kind, got, info, want, winfo):
+    assert info["iterations"] == winfo["iterations"]
+    assert info["refinements"] == winfo["refinements"]
+    assert info["num_inliers"] == winfo["num_inliers"]
+    assert info["hypotheses"] == winfo["hypotheses"]
+    assert info["model_score"] == winfo["model_score"]
+    assert (np.array(info["inliers"]) == np.array(winfo["inliers"])).all()
+    g = np.r_[got.q, got.t] if hasattr(got, "q") else np.ravel(got)
+    w = np.r_[want.q, want.t] if hasattr(want, "q") else np.ravel(want)
+    assert (g == w).all(), (kind, g, w)
+
+
+@pytest.mark.parametrize("group_size,in_flight", [(16, 4), (3, 2), (64, 1)])
+def test_ransac_batch_matches_single_runs_bit_for_bit(gpu, group_size, in_flight):
+    items = _resident_set(gpu, 4200 + group_size)
+    want = [p.run(o) for p, o in items]
+    got = gpu.ransac_batch([p for p, _ in items], [o for _, o in items], in_flight, group_size)
+    for (p, _), (m, info), (wm, winfo) in zip(items, got, want):
+        _same(p.kind, m, info, wm, winfo)
+    # ... and the oracle agrees on a sample (the single runs are held to it in test_gpu_parity.py)
+    for p, _ in items:
+        p.close()
+
+
+def test_ransac_batch_small_arena_cuts_long_runs_into_several_batches(gpu):
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import poselib_amd as P
+from test_gpu_group import _resident_set
+items = _resident_set(P, 4300)
+got = P.ransac_batch([p for p, _ in items], [o for _, o in items], 2, 8)
+out = []
+for m, info in got:
+    v = np.r_[m.q, m.t] if hasattr(m, "q") else np.ravel(m)
+    out.append([info["iterations"], info["refinements"], info["num_inliers"], info["hypotheses"], repr(info["model_score"]),
+                [repr(float(x)) for x in v]])
+print("RESULT " + json.dumps(out))
+"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("groups", {}), ("small_arena", {"POSELIB_AMD_GROUP_ARENA_MB": "256"}), ("solo", {"POSELIB_AMD_NO_GROUPS": "1"})):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["groups"] == res["solo"]
+    assert res["small_arena"] == res["solo"]
