@@ -564,7 +564,7 @@ def main():
                     help="groups (default): every step is ONE pl_ransac_batch call, problems advance in lock-step groups; "
                          "streams: pl_ransac_run from --streams host threads (round 1's form)")
     ap.add_argument("--group-size", type=int, default=16, help="problems per lock-step group (pl_ransac_batch)")
-    ap.add_argument("--group-threads", type=int, default=4, help="groups in flight (host threads inside pl_ransac_batch)")
+    ap.add_argument("--group-threads", type=int, default=8, help="groups in flight (host threads inside pl_ransac_batch)")
     ap.add_argument("--streams", type=int, default=16,
                     help="--mode streams: independent problems in flight per GPU (one host thread + HIP stream each); "
                          "also sets the default step size (64 x streams problems)")

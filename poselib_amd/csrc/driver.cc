@@ -1631,6 +1631,48 @@ void free_problem(pl_problem *p) {
     p->d_pts = nullptr;
 }
 
+// Upper bound of the largest |coordinate| the prepared two-view points will have (pl_prefilter.h, fp16 Sampson form), from
+// the raw points on the host: linear cameras / the normalisation (x - c) / scale round at most once per operation.
+// +inf when it cannot be told without the device (OPENCV un-projection) or a coordinate is NaN.
+float host_two_view_absmax(const PrepareArgs &pa, const double *a, const double *b, size_t n) {
+    const float inf = std::numeric_limits<float>::infinity();
+    double m = 0.0;
+    auto take = [&](double v) { m = (v > m || v != v) ? v : m; };
+    if (pa.mode == 1) {
+        const CameraParams *cams[2] = {&pa.cam1, &pa.cam2};
+        const double *pts[2] = {a, b};
+        for (int k = 0; k < 2; ++k) {
+            const CameraParams &cam = *cams[k];
+            double cx = 0, cy = 0, fx = 1, fy = 1;
+            if (cam.model_id == CAM_SIMPLE_PINHOLE)
+                fx = fy = cam.p[0], cx = cam.p[1], cy = cam.p[2];
+            else if (cam.model_id == CAM_PINHOLE)
+                fx = cam.p[0], fy = cam.p[1], cx = cam.p[2], cy = cam.p[3];
+            else if (cam.model_id != CAM_NULL)
+                return inf;
+            for (size_t i = 0; i < n; ++i) {
+                take(std::fabs((pts[k][2 * i] - cx) / fx));
+                take(std::fabs((pts[k][2 * i + 1] - cy) / fy));
+            }
+        }
+    } else if (pa.mode == 2) {
+        const double c1x = pa.centred ? pa.c1x : 0.0, c1y = pa.centred ? pa.c1y : 0.0;
+        const double c2x = pa.centred ? pa.c2x : 0.0, c2y = pa.centred ? pa.c2y : 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            take(std::fabs((a[2 * i] - c1x) / pa.scale));
+            take(std::fabs((a[2 * i + 1] - c1y) / pa.scale));
+            take(std::fabs((b[2 * i] - c2x) / pa.scale));
+            take(std::fabs((b[2 * i + 1] - c2y) / pa.scale));
+        }
+    } else {
+        return inf;
+    }
+    if (m != m)
+        return inf;
+    m = m * (1.0 + 1e-12);
+    return std::nextafter((float)m, inf);
+}
+
 // One-shot front-ends: the user's AoS buffers go to the device as they are and k_prepare (pipeline.hip) writes the SoA
 // block into the context's arena - per-point un-projection / normalisation on the GPU, no
 // hipMalloc / hipFree per call.  The problem is valid until the next make_problem_prepared on this thread.
@@ -1669,8 +1711,11 @@ int make_problem_prepared(Context *c, int kind, const double *a, const double *b
     for (int d = 0; d < nd; ++d)
         p->ps.a[d] = p->d_pts + (size_t)d * n;
     if (lm_only || kind != EST_ABS) { // (stream order puts the next kernels behind k_prepare)
-        // max|x| only parameterises the absolute-pose pre-filter
+        // two-view: the coordinate bound that admits the matrix-core form of the Sampson filter (large problems only: the
+        // O(N) host pass is not worth it below the size that form starts at)
         p->ps.xy_absmax = std::numeric_limits<float>::infinity();
+        if (!lm_only && (kind == EST_REL || kind == EST_FUND) && n >= 1024 && a && b)
+            p->ps.xy_absmax = host_two_view_absmax(pa, a, b, n);
         return PL_OK;
     }
     if (pa.mode == 0 && pa.cam1.model_id != CAM_OPENCV) {

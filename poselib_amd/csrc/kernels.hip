@@ -206,6 +206,9 @@ template <int K> __device__ __forceinline__ void sample_of_iteration(const Gener
     }
 }
 
+#ifndef PL_FRONT_ATTR
+#define PL_FRONT_ATTR
+#endif
 __device__ __forceinline__ void rel_front_body(const GenerateArgs &g, double *stage, uint32_t cap) {
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     if (it >= g.num_iters)
@@ -230,8 +233,8 @@ __device__ __forceinline__ void rel_front_body(const GenerateArgs &g, double *st
         for (int k = 0; k < 13; ++k)
             saz[(size_t)(i * 13 + k) * cap + it] = Az[i][k];
 }
-__global__ __launch_bounds__(64) void k_rel_front(GenerateArgs g, double *stage, uint32_t cap) { rel_front_body(g, stage, cap); }
-__global__ __launch_bounds__(64) void k_rel_front_g(const GroupArgs *ga) {
+__global__ __launch_bounds__(64) PL_FRONT_ATTR void k_rel_front(GenerateArgs g, double *stage, uint32_t cap) { rel_front_body(g, stage, cap); }
+__global__ __launch_bounds__(64) PL_FRONT_ATTR void k_rel_front_g(const GroupArgs *ga) {
     const GroupArgs &gg = ga[blockIdx.z];
     if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
         return;
@@ -2126,8 +2129,9 @@ hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t 
         return hipSuccess;
     // stage the points in LDS when they fit next to the kernel's static LDS (160 KB per CU, one workgroup per CU); tasks
     // of a mixed launch whose points do not fit the launch's dynamic LDS read them from L2
+    // (a request the points do not fit into would only keep every other workgroup off the CU: no staging then)
     const size_t want = sizeof(double) * point_doubles(est) * (size_t)max_points;
-    const size_t bytes = std::min<size_t>(want, 128 * 1024);
+    const size_t bytes = want <= 128 * 1024 ? want : 0;
     const bool lds = std::getenv("POSELIB_AMD_LM_NO_LDS") == nullptr;
     static bool attr_set[4] = {false, false, false, false};
     if (lds && bytes > 48 * 1024 && est >= 0 && est < 4 && !attr_set[est]) {
