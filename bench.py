@@ -9,9 +9,13 @@
 
 Primary workload (value / ms_per_step; config.workload = "p3p_5000"): BASELINE.json configs[1] - P3P LO-RANSAC on
 5000 synthetic 2D-3D correspondences, 70 % outliers, max_iterations = min_iterations = 100000 (with default options
-PoseLib stops after ~10^3 iterations).  One "step" = a batch of independent, complete ransac_pnp problems
-(sample -> P3P -> score all N -> LO -> final refinement -> inlier mask; different RANSAC seeds) worked through by S
-(= --streams, default 16) host threads with one HIP stream each, on correspondences already resident in HBM.
+PoseLib stops after ~10^3 iterations).  One "step" = a batch of 1024 independent, complete ransac_pnp
+problems (sample -> P3P -> score all N -> LO -> final refinement -> inlier mask; different RANSAC seeds) on
+correspondences already resident in HBM, handed to the library as ONE C-ABI call, pl_ransac_batch: the problems advance
+in lock-step groups of 16 (one launch sequence per group and batch of iterations - the problem index is a grid dimension
+of every kernel), 8 groups in flight on separate streams.  Every result is that of the single-problem call pl_ransac_run,
+bit for bit (tests/test_gpu_group.py).  --mode streams is round 1's form of the same work: pl_ransac_run from 16 host
+threads with one HIP stream each (about 15 % slower: ~15 small launches per problem compete on 16 hardware queues).
 A hypothesis = one minimal-solver model scored against all N correspondences (ransac_impl.h:112-113).
 The same K steps are then run for the metric's second half and the other BASELINE configs (config.secondary:
 relpose_5000 = configs[2], fund_10000 / hom_10000 = configs[3]), each with its own value / roofline / parity / CPU
@@ -22,7 +26,7 @@ The JSON line also carries
   parity       : the GPU results of RANSAC seeds 0..7 of the first timed step against the CPU oracle's runs of the same
                  seeds (the runs that also give cpu_baseline): iterations, refinements, hypotheses, inlier count and
                  mask must be identical, models within 1e-6.  A mismatch makes the exit code non-zero.
-  roofline     : dominant kernel (k_score_mfma / k_score_queue).  bound = "valu_issue": the correspondences are
+  roofline     : dominant kernel (k_score_mfma / k_score_mfma2 / k_score_queue).  bound = "valu_issue": the correspondences are
                  register/LDS-resident, so the kernel is limited by vector-ALU issue, not by HBM.
                  achieved = VALU wave-instructions per launch (PMC-measured instructions per (hypothesis, point chunk),
                  committed in profiles/pmc_traffic.json, x hypotheses x chunks of the launch) / launch duration (HIP

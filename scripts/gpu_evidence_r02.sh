@@ -7,20 +7,22 @@ O=$R/gpurun_out/evidence_r02
 rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 300 python bench.py --streams 1 --no-secondary --no-cpu-baseline --steps 10 > $O/bench_s1.json 2> $O/bench_s1.err
+timeout 300 python bench.py --mode streams --streams 1 --no-secondary --no-cpu-baseline --steps 10 > $O/bench_s1.json 2> $O/bench_s1.err
+timeout 600 python bench.py --mode streams --no-cpu-baseline --no-parity --steps 10 > $O/bench_streams16.json 2> $O/bench_streams16.err
 cd /tmp && export TMPDIR=/tmp
 Q="--no-parity --no-cpu-baseline --no-secondary"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_default -o r -- python $R/bench.py $Q --steps 5 > $O/prof_default.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_s1 -o r -- python $R/bench.py $Q --streams 1 --steps 5 > $O/prof_s1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_s1 -o r -- python $R/bench.py $Q --mode streams --streams 1 --steps 5 > $O/prof_s1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_default -o k -- python $R/bench.py $Q --steps 3 > $O/kt_default.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_s1 -o k -- python $R/bench.py $Q --streams 1 --steps 3 > $O/kt_s1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_s1 -o k -- python $R/bench.py $Q --mode streams --streams 1 --steps 3 > $O/kt_s1.log 2>&1
 for w in relpose_5000 fund_10000 hom_10000; do
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$w -o r -- python $R/bench.py $Q --workload $w --streams 1 --steps 3 > $O/prof_$w.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$w -o r -- python $R/bench.py $Q --workload $w --mode streams --streams 1 --steps 3 > $O/prof_$w.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/profg_$w -o r -- python $R/bench.py $Q --workload $w --steps 3 > $O/profg_$w.log 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_batch -o r -- python $R/bench_batch.py --problems 4096 --streams 8 --steps 2 --no-cpu-baseline > $O/prof_batch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_batch -o k -- python $R/bench_batch.py --problems 4096 --streams 8 --steps 2 --no-cpu-baseline > $O/kt_batch.log 2>&1
 for w in p3p_5000 relpose_5000 fund_10000 hom_10000; do
-  B1="python $R/bench.py $Q --workload $w --streams 1 --steps 2 --warmup 1"
+  B1="python $R/bench.py $Q --workload $w --mode streams --streams 1 --steps 2 --warmup 1"
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq_$w -o p -- $B1 > $O/pmc_sq_$w.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq2_$w -o p -- $B1 > $O/pmc_sq2_$w.log 2>&1
   timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_grbm_$w -o p -- $B1 > $O/pmc_grbm_$w.log 2>&1
@@ -28,7 +30,7 @@ for w in p3p_5000 relpose_5000 fund_10000 hom_10000; do
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$w -o p -- $B1 > $O/pmc_write_$w.log 2>&1
 done
 cd $R
-for d in prof_default prof_s1 prof_relpose_5000 prof_fund_10000 prof_hom_10000 prof_batch; do f=$(find $O/$d -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/$d.md; done
+for d in prof_default prof_s1 prof_relpose_5000 prof_fund_10000 prof_hom_10000 profg_relpose_5000 profg_fund_10000 profg_hom_10000 prof_batch; do f=$(find $O/$d -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/$d.md; done
 python scripts/busy.py $(find $O/kt_default -name "*kernel_trace.csv") > $O/busy_default.txt
 python scripts/busy.py $(find $O/kt_batch -name "*kernel_trace.csv") > $O/busy_batch.txt
 python scripts/timeline.py $(find $O/kt_s1 -name "*kernel_trace.csv") k_sample_delta 30 > $O/timeline_s1.txt

@@ -8,8 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "evidence_r02")
 PR = os.path.join(ROOT, "profiles")
 TAG = "r02"
-WORK = {"p3p_5000": ("k_score_mfma<10>", 320, 5000), "relpose_5000": ("k_score_queue<1, 6>", 384, 5000),
-        "fund_10000": ("k_score_queue<2, 6>", 384, 10000), "hom_10000": ("k_score_queue<3, 5>", 320, 10000)}
+WORK = {"p3p_5000": ("k_score_mfma<10>", 320, 5000), "relpose_5000": ("k_score_mfma2<1, 10>", 320, 5000),
+        "fund_10000": ("k_score_mfma2<2, 12>", 384, 10000), "hom_10000": ("k_score_queue<3, 5>", 320, 10000)}
 
 
 def rd(name):
@@ -47,20 +47,26 @@ def main():
     reports.update({k: v for k, v in d["config"]["secondary"].items()})
     # ---- kernel-trace summaries ----
     p16 = rd("prof_default.md")
-    r16 = find(rows(p16), "k_score_mfma<10>", "full batch")
-    out[f"{TAG}_bench_default_16streams_kernel_trace.md"] = (
-        f"# {TAG} — `python bench.py` (primary workload p3p_5000, 16 problems in flight, 1024 per step) under rocprofv3 --kernel-trace --stats\n\n"
+    r16 = find(rows(p16), "k_score_mfma_g<10>", "full batch") or find(rows(p16), "k_score_mfma_g<10>")
+    s16 = bench("bench_streams16")
+    out[f"{TAG}_bench_default_groups_kernel_trace.md"] = (
+        f"# {TAG} — `python bench.py` (primary workload p3p_5000: 1024 problems per step through pl_ransac_batch, lock-step groups of "
+        f"{d['config'].get('group_size', 16)}, {d['config'].get('group_threads', 8)} groups in flight) under rocprofv3 --kernel-trace --stats\n\n"
         "Command (GPU box, from /tmp): `rocprofv3 --kernel-trace --stats -d ... -- python bench.py --no-parity --no-cpu-baseline "
-        "--no-secondary --steps 5` (scripts/gpu_evidence_r02.sh).\n"
-        f"bench.py of the same configuration (full default run, profiles/{TAG}_bench_line.json): {d['value']:.4g} hypotheses/s, "
-        f"roofline.avg_launch_ms = {d['roofline']['avg_launch_ms']:.3f} (HIP events, 16 launches sharing the device); rocprof average "
-        f"of the same kernel below: {float(r16['avg us']) / 1e3:.3f} ms.\n\n" + p16 +
+        "--no-secondary --steps 5` (scripts/gpu_evidence_r02.sh).  Kernels with the suffix _g are group launches (problem index = "
+        "blockIdx.z): one launch serves 16 problems.\n"
+        f"bench.py of the same configuration (full default run, profiles/{TAG}_bench_line.json): {d['value']:.4g} hypotheses/s; "
+        f"roofline.avg_launch_ms = {d['roofline']['avg_launch_ms']:.3f} is ONE problem's share of a group's scoring launch (HIP events on "
+        f"the group's stream, several groups sharing the device); rocprof average of the whole group launch below: "
+        f"{float(r16['avg us']) / 1e3:.3f} ms.  The same workload as round 1 ran it (`--mode streams`: pl_ransac_run from 16 host threads, "
+        f"one stream each): {s16['value']:.4g} hypotheses/s"
+        + "".join(f", {k} {v['value']:.4g}" for k, v in s16["config"]["secondary"].items() if "value" in v and k in WORK) + ".\n\n" + p16 +
         "\n## Device occupancy of the same configuration (scripts/busy.py on the csv kernel trace)\n\n```\n" + rd("busy_default.txt") + "```\n")
     p1 = rd("prof_s1.md")
     r1 = find(rows(p1), "k_score_mfma<10>", "full batch")
     hpl = s1["roofline"]["hypotheses_per_launch"]
     out[f"{TAG}_bench_p3p5000_1stream_kernel_trace.md"] = (
-        f"# {TAG} — `python bench.py --streams 1` under rocprofv3 --kernel-trace --stats (one problem at a time)\n\n"
+        f"# {TAG} — `python bench.py --mode streams --streams 1` under rocprofv3 --kernel-trace --stats (one problem at a time)\n\n"
         f"bench.py of the same configuration: {s1['value']:.4g} hypotheses/s = {1e3 * hpl / s1['value']:.3f} ms per 100000-iteration "
         f"problem (Python call overhead included), roofline.solo_avg_launch_ms = {s1['roofline']['solo_avg_launch_ms']:.4f}; rocprof "
         f"average of k_score_mfma<10> below: {float(r1['avg us']) / 1e3:.4f} ms ({hpl / 1e3:.1f} k hypotheses x 5000 correspondences per "
@@ -69,10 +75,12 @@ def main():
     for w in ("relpose_5000", "fund_10000", "hom_10000"):
         b = reports[w]
         out[f"{TAG}_bench_{w}_1stream_kernel_trace.md"] = (
-            f"# {TAG} — `python bench.py --workload {w} --streams 1 --steps 3` under rocprofv3 --kernel-trace --stats\n\n"
-            f"bench.py (16 problems in flight, profiles/{TAG}_bench_line.json config.secondary.{w}): {b['value']:.4g} hypotheses/s, "
+            f"# {TAG} — `python bench.py --workload {w} --mode streams --streams 1 --steps 3` under rocprofv3 --kernel-trace --stats\n\n"
+            f"One problem at a time (every kernel with the device to itself).  bench.py default (grouped, profiles/{TAG}_bench_line.json "
+            f"config.secondary.{w}): {b['value']:.4g} hypotheses/s, "
             f"{b['iterations_per_s']:.4g} iterations/s; dominant kernel with the device to itself {b['roofline']['solo_avg_launch_ms']:.4f} ms "
-            f"per {b['roofline']['hypotheses_per_launch'] / 1e3:.1f} k hypotheses.\n\n" + rd(f"prof_{w}.md"))
+            f"per launch.\n\n" + rd(f"prof_{w}.md") +
+            f"\n## The same workload as bench.py runs it by default (`--workload {w} --steps 3`: pl_ransac_batch, groups of 16)\n\n" + rd(f"profg_{w}.md"))
     bm = reports.get("batch_mixed", {})
     out[f"{TAG}_bench_batch_mixed_kernel_trace.md"] = (
         f"# {TAG} — `python bench_batch.py --problems 4096 --streams 8 --steps 2` (configs[4], grouped launches) under rocprofv3 --kernel-trace --stats\n\n"
@@ -102,7 +110,7 @@ def main():
                       "valu_insts_per_hypothesis_chunk": f("SQ_INSTS_VALU") / (hyp * chunks), "valu_busy": round(valu_busy, 3),
                       "mfma_busy": round(mfma_busy, 3), "kernel_cycles": cycles, "source": f"profiles/{TAG}_pmc_{w}.md"}
         out[f"{TAG}_pmc_{w}.md"] = (
-            f"# {TAG} — PMC counters, workload {w} (`python bench.py --workload {w} --streams 1 --steps 2 --warmup 1 --no-parity "
+            f"# {TAG} — PMC counters, workload {w} (`python bench.py --workload {w} --mode streams --streams 1 --steps 2 --warmup 1 --no-parity "
             "--no-cpu-baseline --no-secondary`; counters in separate rocprofv3 --pmc passes with --kernel-trace only)\n\n"
             f"Dominant kernel `{kernel}`: {hyp / 1e3:.1f} k hypotheses x {n} correspondences per launch in {chunks} chunks of {chunk_pts}; "
             f"GRBM_GUI_ACTIVE / 8 = {cycles:.4g} cycles; SQ_INSTS_VALU = {f('SQ_INSTS_VALU'):.4g} = "
