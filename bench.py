@@ -361,7 +361,8 @@ def report_workload(name, table, ctx, args, world):
             "kernel": kernel_name, "launches": k_launch,
             "launches_in_flight": ctx["T"] if ctx["grouped"] else ctx["S"],
             "avg_launch_ms": 1e3 * avg_launch_s, "solo_avg_launch_ms": 1e3 * solo_launch_s,
-            "hypotheses_per_launch": hyp_per_launch, "point_hypotheses_per_s": value * n_points,
+            "hypotheses_per_launch": hyp_per_launch,
+            "solo_hypotheses_per_launch": solo_hyp / max(solo_launches, 1), "point_hypotheses_per_s": value * n_points,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             "algorithmic_hbm_x_peak": (alg_bytes_per_launch / solo_launch_s / 1e9 / HBM_PEAK_GBS) if solo_launch_s > 0 else None,
             "traffic": traffic, "traffic_source": pmc.get("source"),

@@ -99,7 +99,9 @@ def main():
         md = rd(f"pmc_{w}.md")
         r = find(rows(md), kernel, "full batch")
         f = lambda k: float(r[k])
-        hyp = reports[w]["roofline"]["hypotheses_per_launch"]
+        # hypotheses of one launch of the PMC pass = one problem's whole run (--mode streams: one batch of 100000
+        # iterations); the grouped default run cuts long runs into several batches when the arena budget asks for it
+        hyp = (s16["roofline"] if w == "p3p_5000" else s16["config"]["secondary"][w]["roofline"])["hypotheses_per_launch"]
         chunks = (n + chunk_pts - 1) // chunk_pts
         cycles = f("GRBM_GUI_ACTIVE") / 8
         valu_busy = f("SQ_ACTIVE_INST_VALU") * 4 / 1024 / cycles
