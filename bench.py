@@ -9,7 +9,7 @@
 
 Primary workload (value / ms_per_step; config.workload = "p3p_5000"): BASELINE.json configs[1] - P3P LO-RANSAC on
 5000 synthetic 2D-3D correspondences, 70 % outliers, max_iterations = min_iterations = 100000 (with default options
-PoseLib stops after ~10^3 iterations).  One "step" = a batch of 1024 independent, complete ransac_pnp
+PoseLib stops after ~10^3 iterations).  One "step" = a batch of 1536 independent, complete ransac_pnp
 problems (sample -> P3P -> score all N -> LO -> final refinement -> inlier mask; different RANSAC seeds) on
 correspondences already resident in HBM, handed to the library as ONE C-ABI call, pl_ransac_batch: the problems advance
 in lock-step groups of 16 (one launch sequence per group and batch of iterations - the problem index is a grid dimension
@@ -68,10 +68,10 @@ POSE_TOL = 1e-6
 # workload -> (kind, N, outlier ratio, max_error [px], data seed, bytes per correspondence, problems per step and
 #              in-flight stream, description)
 WORKLOADS = {
-    "p3p_5000": (0, 5000, 0.7, 12.0, 1001, 40, 64, "P3P LO-RANSAC (ransac_pnp), BASELINE configs[1]"),
-    "relpose_5000": (1, 5000, 0.5, 1.0, 1002, 32, 10, "5-point LO-RANSAC (ransac_relpose), BASELINE configs[2]"),
-    "fund_10000": (2, 10000, 0.5, 1.0, 1004, 32, 4, "7-point LO-RANSAC (ransac_fundamental), BASELINE configs[3]"),
-    "hom_10000": (3, 10000, 0.5, 1.0, 1003, 32, 12, "4-point homography LO-RANSAC (ransac_homography), BASELINE configs[3]"),
+    "p3p_5000": (0, 5000, 0.7, 12.0, 1001, 40, 96, "P3P LO-RANSAC (ransac_pnp), BASELINE configs[1]"),
+    "relpose_5000": (1, 5000, 0.5, 1.0, 1002, 32, 24, "5-point LO-RANSAC (ransac_relpose), BASELINE configs[2]"),
+    "fund_10000": (2, 10000, 0.5, 1.0, 1004, 32, 8, "7-point LO-RANSAC (ransac_fundamental), BASELINE configs[3]"),
+    "hom_10000": (3, 10000, 0.5, 1.0, 1003, 32, 32, "4-point homography LO-RANSAC (ransac_homography), BASELINE configs[3]"),
 }
 SECONDARY = ["relpose_5000", "fund_10000", "hom_10000"]
 
@@ -572,9 +572,9 @@ def main():
     ap.add_argument("--group-threads", type=int, default=8, help="groups in flight (host threads inside pl_ransac_batch)")
     ap.add_argument("--streams", type=int, default=16,
                     help="--mode streams: independent problems in flight per GPU (one host thread + HIP stream each); "
-                         "also sets the default step size (64 x streams problems)")
+                         "also sets the default step size (96 x streams problems)")
     ap.add_argument("--problems-per-step", type=int, default=0,
-                    help="independent problems per step and GPU of the primary workload (default 64 x streams)")
+                    help="independent problems per step and GPU of the primary workload (default 96 x streams = 1536)")
     ap.add_argument("--workload", default="p3p_5000", choices=sorted(WORKLOADS))
     ap.add_argument("--no-secondary", action="store_true", help="only the primary workload")
     ap.add_argument("--secondary-scale", type=float, default=1.0, help="scales the secondary workloads' step size")
