@@ -333,25 +333,52 @@ __device__ __forceinline__ uint32_t rel_poses_one(const GenerateArgs &g, const d
     g.num_models[it] = (uint32_t)n;
     return (uint32_t)n;
 }
-__global__ __launch_bounds__(64) void k_rel_poses(GenerateArgs g, const double *stage, uint32_t cap, const uint32_t *nroots_in) {
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+// Lane assignment of the pose stage: the work of an iteration is proportional to its number of real roots (0, 2, 4, ...,
+// 10; 4.2 on average, but the maximum over 64 neighbouring iterations is 6.8), so the 256 iterations of a workgroup are
+// bucketed by root count in LDS and every lane takes the iteration at its position of the sorted list: the lanes of a
+// wavefront then loop over the same number of roots.  Which lane works on which iteration has no influence on any result
+// (records, counts and flags are addressed by iteration; the per-1024 block totals are sums).
+constexpr int kPosesThreads = 256;
+__device__ __forceinline__ uint32_t rel_poses_sorted_iteration(const uint32_t *nroots_in, uint32_t num_iters) {
+    __shared__ uint32_t s_cnt[12];
+    __shared__ uint16_t s_perm[kPosesThreads];
+    const uint32_t it0 = blockIdx.x * kPosesThreads, tid = threadIdx.x;
+    const uint32_t it = it0 + tid;
+    const uint32_t ne = it < num_iters ? min(nroots_in[it], 10u) : 11u; // 11: not an iteration (sorted to the end)
+    if (tid < 12)
+        s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t rank = atomicAdd(&s_cnt[ne], 1u);
+    __syncthreads();
+    uint32_t base = 0; // iterations with more roots first
+    for (uint32_t k = 0; k < 12; ++k) {
+        const uint32_t key = (k == 11) ? 11u : 10u - k; // order of the buckets: 10, 9, ..., 0, then the padding
+        if (key == ne)
+            break;
+        base += s_cnt[key];
+    }
+    s_perm[base + rank] = (uint16_t)tid;
+    __syncthreads();
+    return it0 + s_perm[tid];
+}
+__global__ __launch_bounds__(kPosesThreads) void k_rel_poses(GenerateArgs g, const double *stage, uint32_t cap,
+                                                              const uint32_t *nroots_in) {
+    const uint32_t it = rel_poses_sorted_iteration(nroots_in, g.num_iters);
     uint32_t n_nan = 0;
     const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, cap, nroots_in, it, n_nan) : 0u;
-    count_models_of_wave(g, it, n, n_nan);
+    count_models_of_wave(g, blockIdx.x * kPosesThreads, n, n_nan);
 }
-__global__ __launch_bounds__(64) void k_rel_poses_g(const GroupArgs *ga) {
+__global__ __launch_bounds__(kPosesThreads) void k_rel_poses_g(const GroupArgs *ga) {
     const GroupArgs &gg = ga[blockIdx.z];
-    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
+    if (!gg.active || blockIdx.x * (uint32_t)kPosesThreads >= gg.gen.num_iters)
         return;
     const GenerateArgs &g = gg.gen;
     const double *stage = static_cast<const double *>(g.stage);
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t *nroots_in = reinterpret_cast<const uint32_t *>(stage + rel_stage_doubles(g.num_iters));
+    const uint32_t it = rel_poses_sorted_iteration(nroots_in, g.num_iters);
     uint32_t n_nan = 0;
-    const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, g.num_iters,
-                                                          reinterpret_cast<const uint32_t *>(stage + rel_stage_doubles(g.num_iters)),
-                                                          it, n_nan)
-                                          : 0u;
-    count_models_of_wave(g, it, n, n_nan);
+    const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, g.num_iters, nroots_in, it, n_nan) : 0u;
+    count_models_of_wave(g, blockIdx.x * kPosesThreads, n, n_nan);
 }
 
 // Bare solver batch: one lane per minimal problem, AoS input exactly as the reference API takes it.
@@ -1937,7 +1964,7 @@ hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream) {
         uint32_t *nroots = reinterpret_cast<uint32_t *>(stage + rel_stage_doubles(a.num_iters));
         k_rel_front<<<grid, block, 0, stream>>>(a, stage, a.num_iters);
         k_rel_roots<<<grid, block, 0, stream>>>(a.num_iters, stage, a.num_iters, nroots);
-        k_rel_poses<<<grid, block, 0, stream>>>(a, stage, a.num_iters, nroots);
+        k_rel_poses<<<dim3((a.num_iters + kPosesThreads - 1) / kPosesThreads), dim3(kPosesThreads), 0, stream>>>(a, stage, a.num_iters, nroots);
         return hipGetLastError();
     }
     PL_DISPATCH_EST(est, k_generate<E><<<grid, block, 0, stream>>>(a));
@@ -2236,7 +2263,7 @@ hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &d
     if (est == EST_REL) {
         k_rel_front_g<<<ggrid, gblock, 0, stream>>>(args);
         k_rel_roots_g<<<ggrid, gblock, 0, stream>>>(args);
-        k_rel_poses_g<<<ggrid, gblock, 0, stream>>>(args);
+        k_rel_poses_g<<<dim3((d.max_B + kPosesThreads - 1) / kPosesThreads, 1, d.G), dim3(kPosesThreads), 0, stream>>>(args);
     } else {
         PL_DISPATCH_EST(est, k_generate_g<E><<<ggrid, gblock, 0, stream>>>(args));
     }

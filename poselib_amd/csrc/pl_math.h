@@ -212,13 +212,18 @@ PL_HD Mat3 essential_from_motion(const Mat3 &R, Vec3 t) {
 }
 
 // Two-view cheirality test for unit bearings (essential.cc:40-57).
-PL_HD bool check_cheirality(Quat q, Vec3 t, Vec3 x1, Vec3 x2, double min_depth) {
+// the two (scaled) depths and the factor of the depth bound
+PL_HD void cheirality_depths(Quat q, Vec3 t, Vec3 x1, Vec3 x2, double &l1, double &l2, double &a) {
     const Vec3 Rx1 = quat_rotate(q, x1);
-    const double a = -dot(Rx1, x2);
+    a = -dot(Rx1, x2);
     const double b1 = -dot(Rx1, t);
     const double b2 = dot(x2, t);
-    const double l1 = b1 - a * b2;
-    const double l2 = -a * b1 + b2;
+    l1 = b1 - a * b2;
+    l2 = -a * b1 + b2;
+}
+PL_HD bool check_cheirality(Quat q, Vec3 t, Vec3 x1, Vec3 x2, double min_depth) {
+    double l1, l2, a;
+    cheirality_depths(q, t, x1, x2, l1, l2, a);
     min_depth = min_depth * (1 - a * a);
     return l1 > min_depth && l2 > min_depth;
 }

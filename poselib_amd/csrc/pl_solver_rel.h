@@ -538,6 +538,20 @@ template <int NP> PL_HD bool cheirality_all(Quat q, Vec3 t, const Vec3 *x1, cons
             return false;
     return true;
 }
+// cheirality_all for t (pos) and for -t (neg) in one pass.  With t negated b1, b2 and with them l1, l2 change sign
+// exactly (every product and sum is the negated one, IEEE rounding is symmetric), and the depth bound is +-0: the test of
+// (q, -t) is "l1 < 0 and l2 < 0" on the numbers computed for (q, t).
+template <int NP> PL_HD void cheirality_pair(Quat q, Vec3 t, const Vec3 *x1, const Vec3 *x2, bool &pos, bool &neg) {
+    pos = neg = true;
+    for (int i = 0; i < NP; ++i) {
+        double l1, l2, a;
+        cheirality_depths(q, t, x1[i], x2[i], l1, l2, a);
+        pos = pos && (l1 > 0.0 && l2 > 0.0);
+        neg = neg && (l1 < 0.0 && l2 < 0.0);
+        if (!pos && !neg)
+            return;
+    }
+}
 
 // essential.cc:103-169.  Appends the candidates that pass cheirality on the NP sample points.
 template <int NP> PL_HD int motion_from_essential(const Mat3 &E, const Vec3 *x1, const Vec3 *x2, PoseQT *out) {
@@ -578,25 +592,26 @@ template <int NP> PL_HD int motion_from_essential(const Mat3 &E, const Vec3 *x1,
     set_col(UW, 2, c2);
     int n = 0;
     Quat q = rotmat_to_quat(mul(UW, Vt));
-    Vec3 t = c2;
-    if (cheirality_all<NP>(q, t, x1, x2)) {
+    const Vec3 t = c2, tn = -c2;
+    bool pos, neg;
+    cheirality_pair<NP>(q, t, x1, x2, pos, neg); // essential.cc:152-157: (q, t), (q, -t) ...
+    if (pos) {
         out[n].q = q, out[n].t = t;
         ++n;
     }
-    t = -t;
-    if (cheirality_all<NP>(q, t, x1, x2)) {
-        out[n].q = q, out[n].t = t;
+    if (neg) {
+        out[n].q = q, out[n].t = tn;
         ++n;
     }
     set_col(UW, 0, -c0);
     set_col(UW, 1, -c1);
     q = rotmat_to_quat(mul(UW, Vt));
-    if (cheirality_all<NP>(q, t, x1, x2)) {
-        out[n].q = q, out[n].t = t;
+    cheirality_pair<NP>(q, t, x1, x2, pos, neg); // ... then (q', -t), (q', t)  (:160-167)
+    if (neg) {
+        out[n].q = q, out[n].t = tn;
         ++n;
     }
-    t = -t;
-    if (cheirality_all<NP>(q, t, x1, x2)) {
+    if (pos) {
         out[n].q = q, out[n].t = t;
         ++n;
     }
