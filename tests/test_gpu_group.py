@@ -204,3 +204,31 @@ print("RESULT " + json.dumps(out))
         res[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["groups"] == res["solo"]
     assert res["small_arena"] == res["solo"]
+
+
+def test_ransac_batch_items_outside_the_group_path(gpu):
+    """PROSAC, a warm start, fewer correspondences than sample size + 4: those items run through pl_ransac_run inside the
+    same call; the others still go through groups.  Every result equals the single run."""
+    items, initial = [], []
+    for i in range(12):
+        kind = i % 4
+        n = [6, 2000, 300][i % 3]
+        if kind == 0:
+            d = synth.absolute_pose_scene(n, 0.4, 4500 + i)
+            a, b = (np.asarray(d["p2d"]) - 500.0) / 1000.0, d["p3d"]
+            thr = 12.0 / 1000.0
+        else:
+            gen = {1: synth.relative_pose_scene, 2: synth.fundamental_scene, 3: synth.homography_scene}[kind]
+            d = gen(n, 0.4, 4500 + i)
+            a, b = (np.asarray(d["x1"]) - 500.0) / 1000.0, (np.asarray(d["x2"]) - 500.0) / 1000.0
+            thr = 1.0 / 1000.0
+        ro = {"seed": 4500 + i}
+        if i % 5 == 1:
+            ro.update(progressive_sampling=True, max_prosac_iterations=500)
+        items.append((gpu.Problem(kind, a, b), {"max_error": thr, "ransac": ro}))
+    want = [p.run(o) for p, o in items]
+    got = gpu.ransac_batch([p for p, _ in items], [o for _, o in items], 3, 4)
+    for (p, _), (m, info), (wm, winfo) in zip(items, got, want):
+        _same(p.kind, m, info, wm, winfo)
+    for p, _ in items:
+        p.close()
