@@ -5,8 +5,8 @@
 // (PoseLib/solvers/p3p_common.h:31-71), each line gives a quadratic in the depth ratio
 // (PoseLib/solvers/p3p.cc:129-195), depths are polished by <= 5 Newton steps
 // (p3p_common.h:74-94) and R = Y * X^-1 (p3p.cc:121-122,162-164).  All branches are kept so the
-// set and ORDER of returned solutions equals the reference's; cbrt is glibc's algorithm (pl_libm.h,
-// bit-identical to the host's), only acos/cos (ocml vs glibc) can differ in the last ulp.
+// set and ORDER of returned solutions equals the reference's; cbrt / acos / cos are glibc's algorithms (pl_libm.h,
+// bit-identical to the host's libm), so the device models equal the CPU path's to the bit.
 // The coefficient block of p3p() below follows PoseLib/solvers/p3p.cc:77-101 operation for operation (BSD-3 source):
 // the arithmetic ORDER is what bit-parity with the reference requires, so that part is a transliteration by design.
 #pragma once
