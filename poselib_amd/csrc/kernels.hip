@@ -1569,6 +1569,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
     __shared__ double s_racc[1];
     __shared__ uint32_t s_count;
     __shared__ int s_skip;
+    __shared__ uint32_t s_queue[kLMThreads / 64][128]; // per wavefront: correspondences waiting for their Jacobian
 
     const uint8_t *mask = T.mask;
     const double pscale = T.point_scale;
@@ -1631,14 +1632,13 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         double racc = 0.0;
         uint32_t cnt = 0;
         const Loss loss = ctl.loss;
-        for (uint32_t i = threadIdx.x; i < pts.n; i += kLMThreads) {
-            if (mask && !mask[i])
-                continue;
+        // One correspondence into the normal equations (jac) or into the robust cost (!jac)
+        auto point = [&](uint32_t i, bool jacobian_pass) {
             if constexpr (EST == EST_ABS) {
                 const double x = pts.a[0][i] * pscale, y = pts.a[1][i] * pscale;
                 const double X = pts.a[2][i], Y = pts.a[3][i], Z = pts.a[4][i];
                 double r0, r1;
-                if (!jac) {
+                if (!jacobian_pass) {
                     if (R::residual(p, ctx, cam, x, y, X, Y, Z, r0, r1)) {
                         racc += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
                         cnt++;
@@ -1651,7 +1651,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
             } else if constexpr (EST == EST_HOM) {
                 const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
                 double f0, f1, g0, g1;
-                if (!jac) {
+                if (!jacobian_pass) {
                     R::residual(ctx, a0, a1, b0, b1, f0, f1, g0, g1);
                     racc += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
                     racc += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
@@ -1664,7 +1664,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                 }
             } else {
                 const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
-                if (!jac) {
+                if (!jacobian_pass) {
                     const double r = R::residual(ctx, a0, a1, b0, b1);
                     racc += 1.0 * loss_value(loss, r * r);
                     cnt++;
@@ -1673,6 +1673,63 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                     const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
                     accumulate1<K>(acc, loss, r, J, cnt);
                 }
+            }
+        };
+        // Truncated losses (the LO's: bundle.cc TRUNCATED at max_error) give weight zero to every correspondence beyond the
+        // threshold - 70 % of them in config 1 - but a Jacobian costs 10x a residual and a wavefront pays for it as soon as
+        // ONE lane holds an inlier.  So the Jacobian pass first evaluates the residuals only, queues the correspondences
+        // with a non-zero weight per wavefront (ballot + prefix, ascending order) and runs Jacobian + accumulation on full
+        // wavefronts of them.  Which lane accumulates a correspondence changes, the set of terms does not; the reduction
+        // over lanes and wavefronts below is in fixed order as before.
+        const bool zero_weights = loss.type == LOSS_TRUNCATED || loss.type == LOSS_TRUNCATED_CAUCHY;
+        if (jac && zero_weights && !(EST == EST_REL && mask)) {
+            const int lane = threadIdx.x & 63;
+            uint32_t *const q = s_queue[threadIdx.x >> 6];
+            uint32_t qn = 0; // wave-uniform: correspondences waiting, q[0 .. qn)
+            for (uint32_t base = (threadIdx.x >> 6) * 64u; base < pts.n; base += kLMThreads) {
+                const uint32_t i = base + (uint32_t)lane;
+                bool keep = false;
+                if (i < pts.n && !(mask && !mask[i])) {
+                    if constexpr (EST == EST_ABS) {
+                        double r0, r1;
+                        keep = R::residual(p, ctx, cam, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
+                                           pts.a[4][i], r0, r1) &&
+                               loss_weight(loss, r0 * r0 + r1 * r1) != 0;
+                    } else if constexpr (EST == EST_HOM) {
+                        double f0, f1, g0, g1;
+                        R::residual(ctx, pts.a[0][i], pts.a[1][i], pts.a[2][i], pts.a[3][i], f0, f1, g0, g1);
+                        keep = loss_weight(loss, f0 * f0 + f1 * f1) != 0 || loss_weight(loss, g0 * g0 + g1 * g1) != 0;
+                    } else {
+                        const double r = R::residual(ctx, pts.a[0][i], pts.a[1][i], pts.a[2][i], pts.a[3][i]);
+                        keep = loss_weight(loss, r * r) != 0;
+                    }
+                }
+                const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+                if (m) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (keep)
+                        q[qn + below] = i;
+                    qn += (uint32_t)__popcll(m);
+                    if (qn >= 64u) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        point(q[lane], true);
+                        const uint32_t rest = qn - 64u;
+                        const uint32_t moved = ((uint32_t)lane < rest) ? q[64 + lane] : 0u;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if ((uint32_t)lane < rest)
+                            q[lane] = moved;
+                        qn = rest;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if ((uint32_t)lane < qn)
+                point(q[lane], true);
+        } else {
+            for (uint32_t i = threadIdx.x; i < pts.n; i += kLMThreads) {
+                if (mask && !mask[i])
+                    continue;
+                point(i, jac);
             }
         }
         if (!jac) {
