@@ -218,6 +218,10 @@ int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t 
  * models and correspondences here to check that a filter never drops an inlier. */
 int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double max_error, uint32_t *counts,
                           double *scores, int32_t *path_used);
+/* Diagnostic entry: the scalar math of the device kernels, element-wise on `n` doubles - fn 0: the cube of the LM's
+ * Nielsen update (optim/lm_impl.h:124 std::pow(., 3)), 1: sqrt, 2: reciprocal, 3 .. 6: cbrt / cos / sin / acos of
+ * pl_libm.h.  tests/ compares them with the host's libm bit for bit. */
+int pl_debug_device_math(int fn, const double *x, size_t n, double *out);
 /* Non-linear refinement of one model on the resident correspondences (robust/bundle.h:41-170:
  * bundle_adjust / refine_relpose / refine_fundamental / refine_homography).  camera: absolute pose only
  * (NULL pointer = identity camera, i.e. normalised image points).  mask: optional N bytes, refine on the

@@ -138,6 +138,7 @@ def _declare(L):
         "pl_ransac_run_sharded": (cint, [vp, opt, P(Shard), vp, vp, stats]),
         "pl_score_model": (cint, [vp, vp, dbl, P(C.c_uint64), P(dbl)]),
         "pl_debug_score_stream": (cint, [vp, vp, sz, dbl, vp, vp, P(C.c_int32)]),
+        "pl_debug_device_math": (cint, [cint, vp, sz, vp]),
         "pl_refine_model": (cint, [vp, P(BundleOptions), cam, vp, vp, P(C.c_uint32)]),
         "pl_p3p": (cint, [vp, vp, P(CameraPose)]),
         "pl_relpose_5pt": (cint, [vp, vp, P(CameraPose)]),
@@ -167,5 +168,5 @@ EXPORTED_SYMBOLS = [
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
     "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
-    "pl_ransac_batch",
+    "pl_ransac_batch", "pl_debug_device_math",
 ]

@@ -367,6 +367,15 @@ class RansacBatch:
         return out
 
 
+def device_math(fn: int, x):
+    """Diagnostic (pl_debug_device_math): the device kernels' scalar math on an array - 0: cube of the LM's Nielsen update,
+    1: sqrt, 2: reciprocal, 3: cbrt, 4: cos, 5: sin, 6: acos."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    L.check(L.lib().pl_debug_device_math(int(fn), _ptr(x), C.c_size_t(x.size), _ptr(out)))
+    return out
+
+
 def ransac_batch(problems, opts, max_in_flight=4, group_size=16):
     """Many device-resident problems in one call (pl_ransac_batch): results of `problems[i].run(opts[i])`, bit for bit.
     Problems of the same kind advance in lock-step groups of `group_size` through one launch sequence."""

@@ -2115,6 +2115,33 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
     return PL_OK;
 }
 
+int pl_debug_device_math(int fn, const double *x, size_t n, double *out) {
+    if ((!x || !out) && n)
+        return fail(PL_ERR_INVALID, "null pointer");
+    if (n > (1u << 28))
+        return fail(PL_ERR_INVALID, "too many values");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    if (n == 0)
+        return PL_OK;
+    struct Scratch { // freed on every path
+        void *p = nullptr;
+        ~Scratch() {
+            if (p)
+                (void)hipFree(p);
+        }
+    } din, dout;
+    HIP_TRY(hipMalloc(&din.p, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&dout.p, sizeof(double) * n));
+    HIP_TRY(hipMemcpyAsync(din.p, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_device_math(fn, static_cast<const double *>(din.p), (uint32_t)n, static_cast<double *>(dout.p), c->stream));
+    HIP_TRY(hipMemcpyAsync(out, dout.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PL_OK;
+}
+
 int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera *camera, const uint8_t *mask,
                     void *model, uint32_t *lm_iterations) {
     if (!p || !model || !opt)

@@ -23,6 +23,7 @@
 // Exact arithmetic (fp64, reference association order) never runs on the matrix cores; only the filter's projection
 // products do.
 #include "pl_kernels.h"
+#include <atomic>
 #include "pl_prefilter.h"
 #include <cstdlib>
 #include "pl_sampler.h"
@@ -1330,6 +1331,7 @@ template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScore
     __shared__ double s_list[kSeqChunk + 32];
     __shared__ uint32_t s_wave_tot[kSeqThreads / 64], s_total;
     __shared__ double s_sum;
+    __shared__ uint32_t s_inliers;
     const uint32_t nrec = min(*a.num, a.cap);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (a.ctl_host && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1342,12 +1344,14 @@ template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScore
 #pragma unroll
         for (int i = 0; i < kModelDoubles; ++i)
             M[i] = Mp[i];
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             s_sum = 0.0;
+            s_inliers = 0;
+        }
         uint32_t count = 0; // (thread 0 keeps the total)
         for (uint32_t base = 0; base < a.pts.n; base += kSeqChunk) {
             double r2v[kSeqPerThread];
-            uint32_t flags = 0, cnt = 0;
+            uint32_t flags = 0, cnt = 0, inl = 0; // cnt: terms this thread contributes to the list; inl: inliers among them
 #pragma unroll
             for (int j = 0; j < kSeqPerThread; ++j) {
                 const uint32_t i = base + threadIdx.x * kSeqPerThread + j; // contiguous per thread: index order
@@ -1358,10 +1362,20 @@ template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScore
                     for (int d = 0; d < ND; ++d)
                         x[d] = a.pts.a[d][i];
                     double r2;
-                    if (eval_point<EST>(M, x, a.thr2, r2)) {
-                        r2v[j] = r2;
+                    const bool in = eval_point<EST>(M, x, a.thr2, r2);
+                    if constexpr (EST == EST_ABS) {
+                        if (in) { // utils.cc:57-60: the inliers' residuals, the outliers' share in one product at the end (:63)
+                            r2v[j] = r2;
+                            flags |= 1u << j;
+                            ++cnt;
+                        }
+                    } else {
+                        // utils.cc:188-198, 230-235, 320-325: the two-view scores add r^2 OR the squared threshold for
+                        // every correspondence, in correspondence order - one term per correspondence in the list
+                        r2v[j] = in ? r2 : a.thr2;
                         flags |= 1u << j;
                         ++cnt;
+                        inl += in ? 1u : 0u;
                     }
                 }
             }
@@ -1407,12 +1421,20 @@ template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScore
                         sum += w[t]; // (+0.0 beyond `total`)
                 }
                 s_sum = sum;
-                count += total;
+                if constexpr (EST == EST_ABS)
+                    count += total;
+            }
+            if constexpr (EST != EST_ABS) { // inliers of the chunk (an integer: any order)
+                const uint32_t wi = wave_sum_u32(inl);
+                if (lane == 0 && wi)
+                    atomicAdd(&s_inliers, wi);
             }
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            const double score = s_sum + (double)(a.pts.n - count) * a.thr2; // utils.cc:63
+            if constexpr (EST != EST_ABS)
+                count = s_inliers;
+            const double score = (EST == EST_ABS) ? s_sum + (double)(a.pts.n - count) * a.thr2 /* utils.cc:63 */ : s_sum;
             if (a.cand) {
                 a.cand[r].count = count;
                 a.cand[r].score = score;
@@ -1570,6 +1592,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
     __shared__ uint32_t s_count;
     __shared__ int s_skip;
     __shared__ uint32_t s_queue[kLMThreads / 64][128]; // per wavefront: correspondences waiting for their Jacobian
+    __shared__ double s_terms[128][NT + 1];           // small problems: the terms of 64 correspondences (x 2 for H) + cost
 
     const uint8_t *mask = T.mask;
     const double pscale = T.point_scale;
@@ -1632,49 +1655,108 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         double racc = 0.0;
         uint32_t cnt = 0;
         const Loss loss = ctl.loss;
-        // One correspondence into the normal equations (jac) or into the robust cost (!jac)
-        auto point = [&](uint32_t i, bool jacobian_pass) {
+        // One correspondence into the normal equations (jac) or into the robust cost (!jac).  A0 / c0: target of the
+        // (first) residual block, A1 / c1: of the homography's backward block (the same target in the streaming passes).
+        auto point_into = [&](uint32_t i, bool jacobian_pass, double *A0, double *A1, double &c0, double &c1, uint32_t &cn) {
             if constexpr (EST == EST_ABS) {
                 const double x = pts.a[0][i] * pscale, y = pts.a[1][i] * pscale;
                 const double X = pts.a[2][i], Y = pts.a[3][i], Z = pts.a[4][i];
                 double r0, r1;
                 if (!jacobian_pass) {
                     if (R::residual(p, ctx, cam, x, y, X, Y, Z, r0, r1)) {
-                        racc += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
-                        cnt++;
+                        c0 += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
+                        cn++;
                     }
                 } else {
                     double J[2 * K];
                     if (R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J))
-                        accumulate2<K>(acc, loss, r0, r1, J, cnt);
+                        accumulate2<K>(A0, loss, r0, r1, J, cn);
                 }
             } else if constexpr (EST == EST_HOM) {
                 const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
                 double f0, f1, g0, g1;
                 if (!jacobian_pass) {
                     R::residual(ctx, a0, a1, b0, b1, f0, f1, g0, g1);
-                    racc += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
-                    racc += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
-                    cnt += 2;
+                    c0 += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
+                    c1 += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
+                    cn += 2;
                 } else {
                     double Jf[2 * K], Jb[2 * K];
                     R::jacobian(ctx, a0, a1, b0, b1, f0, f1, Jf, g0, g1, Jb);
-                    accumulate2<K>(acc, loss, f0, f1, Jf, cnt);
-                    accumulate2<K>(acc, loss, g0, g1, Jb, cnt);
+                    accumulate2<K>(A0, loss, f0, f1, Jf, cn);
+                    accumulate2<K>(A1, loss, g0, g1, Jb, cn);
                 }
             } else {
                 const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
                 if (!jacobian_pass) {
                     const double r = R::residual(ctx, a0, a1, b0, b1);
-                    racc += 1.0 * loss_value(loss, r * r);
-                    cnt++;
+                    c0 += 1.0 * loss_value(loss, r * r);
+                    cn++;
                 } else {
                     double J[K];
                     const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
-                    accumulate1<K>(acc, loss, r, J, cnt);
+                    accumulate1<K>(A0, loss, r, J, cn);
                 }
             }
         };
+        auto point = [&](uint32_t i, bool jacobian_pass) { point_into(i, jacobian_pass, acc, acc, racc, racc, cnt); };
+        // Small problems (n <= kLMSeqPoints): the sums in the REFERENCE's order.  With a handful of correspondences the
+        // models of a run tie exactly in their MSAC score (minimal support: every inlier is a sample point, the residuals
+        // vanish against (N - count) thr^2), and which of two tied LO results wins is decided by the last bit of the refined
+        // model - i.e. by the order the normal equations are summed in.  The reference adds correspondence after
+        // correspondence (jacobian_accumulator.h:82-97); here every thread forms its correspondence's terms, and thread a
+        // adds term a of all correspondences one after the other, 64 correspondences per round through LDS.  (x + 0.0 = x:
+        // the terms of skipped correspondences are zeros.)
+        if (pts.n <= (uint32_t)kLMSeqPoints) {
+            constexpr int SUB = (EST == EST_HOM) ? 2 : 1;
+            double term[SUB][NT], cterm[SUB];
+#pragma unroll
+            for (int u = 0; u < SUB; ++u) {
+                cterm[u] = 0.0;
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+                    term[u][a] = 0.0;
+            }
+            uint32_t cn = 0;
+            if (threadIdx.x < pts.n && !(mask && !mask[threadIdx.x]))
+                point_into(threadIdx.x, jac, term[0], term[SUB - 1], cterm[0], cterm[SUB - 1], cn);
+            if (threadIdx.x == 0)
+                s_count = 0;
+            __syncthreads();
+            if (cn)
+                atomicAdd(&s_count, cn);
+            double tot = 0.0;
+            const uint32_t rounds = (pts.n + 63u) / 64u;
+            for (uint32_t rd = 0; rd < rounds; ++rd) {
+                if ((threadIdx.x >> 6) == rd) {
+#pragma unroll
+                    for (int u = 0; u < SUB; ++u) {
+                        double *dst = s_terms[SUB * (threadIdx.x & 63) + u];
+                        if (jac) {
+#pragma unroll
+                            for (int a = 0; a < NT; ++a)
+                                dst[a] = term[u][a];
+                        } else {
+                            dst[NT] = cterm[u];
+                        }
+                    }
+                }
+                __syncthreads();
+                const uint32_t slots = min(64u, pts.n - 64u * rd) * SUB;
+                if (jac ? threadIdx.x < NT : threadIdx.x == NT)
+                    for (uint32_t q = 0; q < slots; ++q)
+                        tot += s_terms[q][threadIdx.x];
+                __syncthreads();
+            }
+            if (jac) {
+                if (threadIdx.x < NT)
+                    normal[threadIdx.x] = tot;
+            } else if (threadIdx.x == NT) {
+                s_racc[0] = tot;
+            }
+            __syncthreads();
+            return;
+        }
         // Truncated losses (the LO's: bundle.cc TRUNCATED at max_error) give weight zero to every correspondence beyond the
         // threshold - 70 % of them in config 1 - but a Jacobian costs 10x a residual and a wavefront pays for it as soon as
         // ONE lane holds an inlier.  So the Jacobian pass first evaluates the residuals only, queues the correspondences
@@ -2211,22 +2293,33 @@ hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_t
 hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
+    if (est < 0 || est > 3)
+        return hipErrorInvalidValue;
     // stage the points in LDS when they fit next to the kernel's static LDS (160 KB per CU, one workgroup per CU); tasks
     // of a mixed launch whose points do not fit the launch's dynamic LDS read them from L2
     // (a request the points do not fit into would only keep every other workgroup off the CU: no staging then)
-    const size_t want = sizeof(double) * point_doubles(est) * (size_t)max_points;
-    const size_t bytes = want <= 128 * 1024 ? want : 0;
-    const bool lds = std::getenv("POSELIB_AMD_LM_NO_LDS") == nullptr;
-    static bool attr_set[4] = {false, false, false, false};
-    if (lds && bytes > 48 * 1024 && est >= 0 && est < 4 && !attr_set[est]) {
+    static std::atomic<int> dyn_limit[4] = {{-1}, {-1}, {-1}, {-1}}; // bytes of dynamic LDS the kernel may ask for
+    int limit = dyn_limit[est].load(std::memory_order_acquire);
+    if (limit < 0) {
+        hipFuncAttributes fa;
         hipError_t e = hipSuccess;
-        PL_DISPATCH_EST(est, e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm<E>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        PL_DISPATCH_EST(est, e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_lm<E>)));
         if (e != hipSuccess)
             return e;
-        attr_set[est] = true;
+        limit = std::max<int>(0, 160 * 1024 - (int)fa.sharedSizeBytes - 1024);
+        limit = std::min<int>(limit, 128 * 1024);
+        if (limit > 48 * 1024) {
+            PL_DISPATCH_EST(est, e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm<E>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, limit));
+            if (e != hipSuccess)
+                return e;
+        }
+        dyn_limit[est].store(limit, std::memory_order_release);
     }
-    PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), lds ? bytes : 0, stream>>>(tasks, lds ? (uint32_t)bytes : 0u));
+    const size_t want = sizeof(double) * point_doubles(est) * (size_t)max_points;
+    const bool lds = std::getenv("POSELIB_AMD_LM_NO_LDS") == nullptr;
+    const size_t bytes = (lds && want <= (size_t)limit) ? want : 0;
+    PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), bytes, stream>>>(tasks, (uint32_t)bytes));
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@
 //       iff count > max(previous counts) or score < min(previous scores).  Records (typically O(log H)) are
 //       appended with their 128-byte model so the host fetches a few KB instead of every score.
 #include "pl_kernels.h"
+#include "pl_refine.h"
 #include "pl_sampler.h"
 
 namespace pl {
@@ -905,6 +906,32 @@ __global__ __launch_bounds__(256) void k_undistort(const double *__restrict__ in
     out[2 * (size_t)i] = fx * u + cx;
     out[2 * (size_t)i + 1] = fy * v + cy;
 }
+// Diagnostic: the device's scalar math as the kernels call it, element-wise (pl_debug_device_math)
+__global__ __launch_bounds__(256) void k_device_math(int fn, const double *__restrict__ x, uint32_t n, double *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const double v = x[i];
+    double r;
+    switch (fn) {
+    case 0: r = lm_cube(v); break; // the cube of the Nielsen update (pl_refine.h)
+    case 1: r = sqrt(v); break;
+    case 2: r = 1.0 / v; break;
+    case 3: r = pl_cbrt(v); break;
+    case 4: r = pl_cos(v); break;
+    case 5: r = pl_sin(v); break;
+    case 6: r = pl_acos(v); break;
+    default: r = v; break;
+    }
+    out[i] = r;
+}
+hipError_t launch_device_math(int fn, const double *x, uint32_t n, double *out, hipStream_t stream) {
+    if (n == 0)
+        return hipSuccess;
+    k_device_math<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(fn, x, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_undistort(const double *in, uint32_t n, const CameraParams &cam, double fx, double fy, double cx,
                             double cy, double *out, hipStream_t stream) {
     if (n == 0)

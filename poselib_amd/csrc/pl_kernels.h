@@ -20,6 +20,7 @@ struct PointSet {
 };
 
 constexpr int kScoreThreads = 256; // 4 wavefronts per workgroup
+constexpr int kLMSeqPoints = 256; // up to this many correspondences k_lm sums in the reference's order (one thread per correspondence)
 constexpr int kLMThreads = 512;    // 8 wavefronts (2 per SIMD => 256 VGPRs each: the k(k+1)/2+k accumulators stay in registers)
 
 PL_HD constexpr int sample_size(int est) { return est == EST_ABS ? 3 : est == EST_REL ? 5 : est == EST_FUND ? 7 : 4; }
@@ -145,6 +146,8 @@ struct PrepareArgs {
 hipError_t launch_prepare(const double *a_raw, const double *b_raw, uint32_t n, const PrepareArgs &args, double *soa,
                           unsigned long long *absmax_bits, hipStream_t stream);
 // pixels of a distorting camera -> pixels of the distortion-free camera with the same focal lengths / principal point
+// diagnostic: fn 0 cube of the LM's Nielsen update, 1 sqrt, 2 reciprocal, 3 cbrt, 4 cos, 5 sin, 6 acos - as the kernels evaluate them
+hipError_t launch_device_math(int fn, const double *x, uint32_t n, double *out, hipStream_t stream);
 hipError_t launch_undistort(const double *in, uint32_t n, const CameraParams &cam, double fx, double fy, double cx,
                             double cy, double *out, hipStream_t stream);
 // After the LM kernels: records of the refined models on the device (skipped tasks keep their input record), and the

@@ -699,3 +699,77 @@ def test_throughput_mode_full_size_properties(gpu):
     print("throughput: hyp", info1["hypotheses"], "seconds", info1["seconds"], "score kernel ms",
           info1["score_kernel_ms"], "=> hyp/s", info1["hypotheses"] / info1["seconds"])
     prob.close()
+
+
+def test_decision_scores_and_small_problem_refinements_equal_the_oracle_bit_for_bit(gpu):
+    """Every score a RANSAC decision is taken on comes from k_score_seq, which adds the terms in the reference's order:
+    the inliers' r^2 and one product for the outliers (absolute pose, utils.cc:57-63), r^2 OR thr^2 correspondence by
+    correspondence (two-view scores, utils.cc:188-198, 230-235, 320-325).  pl_score_model must therefore EQUAL the
+    oracle's score, not approximate it - with a handful of correspondences whole runs hinge on exact ties.  Likewise the
+    LM of problems up to 256 correspondences sums its normal equations correspondence by correspondence: the refined
+    models equal the oracle's to the bit (the one libm call of the LM loop, pow(., 3), is a correctly rounded cube on the
+    device: equal to glibc's for 99.9 % of the arguments, hence the few exceptions allowed below)."""
+    rs = np.random.RandomState(17)
+    checked = 0
+    for trial in range(24):
+        n = [8, 40, 200, 256, 257, 3000][trial % 6]
+        outl = [0.3, 0.6][trial % 2]
+        # ---- absolute pose
+        d = synth.absolute_pose_scene(n, outl, 7000 + trial)
+        par = d["camera"]["params"]
+        x = (np.asarray(d["p2d"]) - np.array(par[-2:])) / par[0]
+        X = np.asarray(d["p3d"])
+        prob = gpu.Problem(gpu.KIND_ABS, x, X)
+        for k in range(3):
+            q = np.asarray(d["q_gt"]) + 0.01 * k * rs.randn(4)
+            q /= np.linalg.norm(q)
+            t = np.asarray(d["t_gt"]) + 0.01 * k * rs.randn(3)
+            sc, cnt = prob.score(gpu.CameraPose(q, t), 0.012)
+            osc, ocnt = O.score("reproj", np.r_[q, t], x, X, 0.012 ** 2)
+            assert (sc, cnt) == (osc, ocnt), ("abs", n, k, sc, osc)
+            checked += 1
+        prob.close()
+        # ---- two-view
+        r = synth.relative_pose_scene(n, outl, 7100 + trial)
+        x1, x2 = (np.asarray(r["x1"]) - 500.0) / 1000.0, (np.asarray(r["x2"]) - 500.0) / 1000.0
+        h = synth.homography_scene(n, outl, 7200 + trial)
+        y1, y2 = (np.asarray(h["x1"]) - 500.0) / 1000.0, (np.asarray(h["x2"]) - 500.0) / 1000.0
+        pr, pf, ph = gpu.Problem(gpu.KIND_REL, x1, x2), gpu.Problem(gpu.KIND_FUND, x1, x2), gpu.Problem(gpu.KIND_HOM, y1, y2)
+        Hm, _ = gpu.ransac_homography(y1, y2, {"max_error": 1e-3, "ransac": {"seed": trial, "max_iterations": 300}})
+        for k in range(3):
+            q = np.asarray(r["q_gt"]) + 0.003 * k * rs.randn(4)
+            q /= np.linalg.norm(q)
+            t = np.asarray(r["t_gt"]) + 0.003 * k * rs.randn(3)
+            for thr in (1e-3, 5e-2):
+                sc, cnt = pr.score(gpu.CameraPose(q, t), thr)
+                osc, ocnt = O.score("sampson_pose", np.r_[q, t], x1, x2, thr * thr)
+                assert (sc, cnt) == (osc, ocnt), ("rel", n, k, thr, sc, osc)
+                tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+                F = tx @ rot(q) * 10.0 ** rs.randint(-3, 4)
+                sc, cnt = pf.score(F, thr)
+                osc, ocnt = O.score("sampson_F", F, x1, x2, thr * thr)
+                assert (sc, cnt) == (osc, ocnt), ("fund", n, k, thr, sc, osc)
+                Hk = Hm + 1e-4 * k * np.abs(Hm).max() * rs.randn(3, 3)
+                sc, cnt = ph.score(Hk, thr)
+                osc, ocnt = O.score("homography", Hk, y1, y2, thr * thr)
+                assert (sc, cnt) == (osc, ocnt), ("hom", n, k, thr, sc, osc)
+                checked += 3
+        # ---- LM on small problems: bit-identical refined models
+        if n <= 256:
+            exact = total = 0
+            for loss in ("TRUNCATED", "CAUCHY", "TRIVIAL"):
+                bo = {"loss_type": loss, "loss_scale": 1e-3, "max_iterations": 25}
+                q = np.asarray(r["q_gt"]) + 1e-3 * rs.randn(4)
+                q /= np.linalg.norm(q)
+                t = np.asarray(r["t_gt"]) + 1e-3 * rs.randn(3)
+                got, it = pr.refine(gpu.CameraPose(q, t), bo)
+                want, st = O.refine("relpose", x1, x2, np.r_[q, t], bo)
+                exact += int((np.r_[got.q, got.t] == want).all() and it == st.iterations)
+                M = Hm + 1e-4 * np.abs(Hm).max() * rs.randn(3, 3)
+                got, it = ph.refine(M, bo)
+                want, st = O.refine("homography", y1, y2, M, bo)
+                exact += int((np.ravel(got) == np.ravel(want)).all() and it == st.iterations)
+                total += 2
+            assert exact >= total - 1, (n, exact, total)
+        pr.close(), pf.close(), ph.close()
+    assert checked > 500
