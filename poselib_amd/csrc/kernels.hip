@@ -1655,51 +1655,50 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         double racc = 0.0;
         uint32_t cnt = 0;
         const Loss loss = ctl.loss;
-        // One correspondence into the normal equations (jac) or into the robust cost (!jac).  A0 / c0: target of the
-        // (first) residual block, A1 / c1: of the homography's backward block (the same target in the streaming passes).
-        auto point_into = [&](uint32_t i, bool jacobian_pass, double *A0, double *A1, double &c0, double &c1, uint32_t &cn) {
+        // One correspondence into the normal equations (jac) or into the robust cost (!jac) of this thread's accumulators
+        // (named directly - handed over as pointers they would live in scratch memory)
+        auto point = [&](uint32_t i, bool jacobian_pass) {
             if constexpr (EST == EST_ABS) {
                 const double x = pts.a[0][i] * pscale, y = pts.a[1][i] * pscale;
                 const double X = pts.a[2][i], Y = pts.a[3][i], Z = pts.a[4][i];
                 double r0, r1;
                 if (!jacobian_pass) {
                     if (R::residual(p, ctx, cam, x, y, X, Y, Z, r0, r1)) {
-                        c0 += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
-                        cn++;
+                        racc += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
+                        cnt++;
                     }
                 } else {
                     double J[2 * K];
                     if (R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J))
-                        accumulate2<K>(A0, loss, r0, r1, J, cn);
+                        accumulate2<K>(acc, loss, r0, r1, J, cnt);
                 }
             } else if constexpr (EST == EST_HOM) {
                 const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
                 double f0, f1, g0, g1;
                 if (!jacobian_pass) {
                     R::residual(ctx, a0, a1, b0, b1, f0, f1, g0, g1);
-                    c0 += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
-                    c1 += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
-                    cn += 2;
+                    racc += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
+                    racc += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
+                    cnt += 2;
                 } else {
                     double Jf[2 * K], Jb[2 * K];
                     R::jacobian(ctx, a0, a1, b0, b1, f0, f1, Jf, g0, g1, Jb);
-                    accumulate2<K>(A0, loss, f0, f1, Jf, cn);
-                    accumulate2<K>(A1, loss, g0, g1, Jb, cn);
+                    accumulate2<K>(acc, loss, f0, f1, Jf, cnt);
+                    accumulate2<K>(acc, loss, g0, g1, Jb, cnt);
                 }
             } else {
                 const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
                 if (!jacobian_pass) {
                     const double r = R::residual(ctx, a0, a1, b0, b1);
-                    c0 += 1.0 * loss_value(loss, r * r);
-                    cn++;
+                    racc += 1.0 * loss_value(loss, r * r);
+                    cnt++;
                 } else {
                     double J[K];
                     const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
-                    accumulate1<K>(A0, loss, r, J, cn);
+                    accumulate1<K>(acc, loss, r, J, cnt);
                 }
             }
         };
-        auto point = [&](uint32_t i, bool jacobian_pass) { point_into(i, jacobian_pass, acc, acc, racc, racc, cnt); };
         // Small problems (n <= kLMSeqPoints): the sums in the REFERENCE's order.  With a handful of correspondences the
         // models of a run tie exactly in their MSAC score (minimal support: every inlier is a sample point, the residuals
         // vanish against (N - count) thr^2), and which of two tied LO results wins is decided by the last bit of the refined
@@ -1718,8 +1717,51 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                     term[u][a] = 0.0;
             }
             uint32_t cn = 0;
+            // (the same expressions as `point`, into this correspondence's own terms; the homography's backward block apart)
+                auto point_terms = [&](uint32_t i, bool jacobian_pass) {
+                if constexpr (EST == EST_ABS) {
+                    const double x = pts.a[0][i] * pscale, y = pts.a[1][i] * pscale;
+                    const double X = pts.a[2][i], Y = pts.a[3][i], Z = pts.a[4][i];
+                    double r0, r1;
+                    if (!jacobian_pass) {
+                        if (R::residual(p, ctx, cam, x, y, X, Y, Z, r0, r1)) {
+                            cterm[0] += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
+                            cn++;
+                        }
+                    } else {
+                        double J[2 * K];
+                        if (R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J))
+                            accumulate2<K>(term[0], loss, r0, r1, J, cn);
+                    }
+                } else if constexpr (EST == EST_HOM) {
+                    const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
+                    double f0, f1, g0, g1;
+                    if (!jacobian_pass) {
+                        R::residual(ctx, a0, a1, b0, b1, f0, f1, g0, g1);
+                        cterm[0] += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
+                        cterm[SUB - 1] += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
+                        cn += 2;
+                    } else {
+                        double Jf[2 * K], Jb[2 * K];
+                        R::jacobian(ctx, a0, a1, b0, b1, f0, f1, Jf, g0, g1, Jb);
+                        accumulate2<K>(term[0], loss, f0, f1, Jf, cn);
+                        accumulate2<K>(term[SUB - 1], loss, g0, g1, Jb, cn);
+                    }
+                } else {
+                    const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
+                    if (!jacobian_pass) {
+                        const double r = R::residual(ctx, a0, a1, b0, b1);
+                        cterm[0] += 1.0 * loss_value(loss, r * r);
+                        cn++;
+                    } else {
+                        double J[K];
+                        const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
+                        accumulate1<K>(term[0], loss, r, J, cn);
+                    }
+                }
+            };
             if (threadIdx.x < pts.n && !(mask && !mask[threadIdx.x]))
-                point_into(threadIdx.x, jac, term[0], term[SUB - 1], cterm[0], cterm[SUB - 1], cn);
+                point_terms(threadIdx.x, jac);
             if (threadIdx.x == 0)
                 s_count = 0;
             __syncthreads();
