@@ -1,3 +1,5 @@
+"""The device kernels' scalar math against the host libm (pl_debug_device_math): cube of the LM's Nielsen update vs pow(x, 3),
+sqrt, reciprocal.  Run on a GPU box."""
 import sys, math, numpy as np
 sys.path.insert(0,'/root/repo')
 import poselib_amd as P

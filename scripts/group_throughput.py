@@ -1,3 +1,5 @@
+"""Throughput of pl_ransac_batch on one bench workload:  python scripts/group_throughput.py {p3p|rel|fund|hom} <group size>
+<groups in flight> <problems>  (100 000-iteration problems on device-resident correspondences, as bench.py runs them)"""
 import sys, time, numpy as np
 sys.path.insert(0,'/root/repo')
 import poselib_amd as P
