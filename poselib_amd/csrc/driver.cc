@@ -959,7 +959,7 @@ struct RansacRun {
             Shadow16Params s16;
             if (on_mfma && kind == EST_ABS) { // fp16 operand blocks of the hypotheses for the matrix cores: built
                                               // in the same launch as the hypothesis-ordered copies
-                HIP_TRY(c->shadow16.ensure((hcap + 8) * 64));
+                HIP_TRY(c->shadow16.ensure((hcap + kAbs16Pad) * kAbs16Bytes));
                 s16.out = c->shadow16.p;
                 s16.g16 = sa.pf.g16, s16.c16 = sa.pf.c16, s16.thr = sa.pf.thr;
                 sa.shadow16 = c->shadow16.p;
@@ -2073,7 +2073,7 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
     sa.shadow16 = nullptr;
     int path = sa.pf.enabled ? 1 : 0;
     if (on_mfma && p->kind == EST_ABS) {
-        HIP_TRY(c->shadow16.ensure(((size_t)H + 8) * 64));
+        HIP_TRY(c->shadow16.ensure(((size_t)H + kAbs16Pad) * kAbs16Bytes));
         HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), H, sa.pf.g16, sa.pf.c16, sa.pf.thr,
                                 c->shadow16.p, c->stream));
         sa.shadow16 = c->shadow16.p;

@@ -811,19 +811,20 @@ template <int EST, int P> __global__ __launch_bounds__(kQueueThreads) void k_sco
 }
 
 // ---- absolute pose: the pre-filter on the matrix cores ----------------------------------------------------------
-// k_score_mfma: same contract and same exact pass as k_score_queue, but pass A evaluates z = R X + t for 8 hypotheses
-// x 32 correspondences per v_mfma_f32_32x32x8_f16 (operands: k_shadow16's blocks and fp16 hi/lo pairs of the points;
-// bound derivation in pl_prefilter.h).  The projection products - 9 of the 13 FMAs per pair of the VALU filter -
-// leave the vector ALU, which keeps the per-pair tail: a = z0 - x z2 (fp32, exact x), the slack-widened threshold,
-// one subtraction whose SIGN BIT is the verdict (no compare, no SGPR mask per pair: the bit is shifted into a
-// per-lane, per-hypothesis bit field over the point groups).  After the PG tiles of a group of 8 hypotheses the bit
-// fields are expanded into the wave's LDS queue, hypothesis by hypothesis in ascending order (prefix sum over the
-// lanes), so the drain's segmented scan sees every hypothesis as one run, exactly as in k_score_queue.
-// Register layout of one tile (32 rows x 32 columns, 16 accumulator registers per lane; lane l: column l % 32, rows
-// 8 (v / 4) + 4 (l / 32) + v % 4 for register v): lanes 0..31 hold hypothesis slots 0, 2, 4, 6 of the group, lanes
-// 32..63 slots 1, 3, 5, 7; registers (0,1) = z0 of two slots, (2,3) = z2, (4,5) = z1, (6,7) = their slack W, and
-// (8..15) the same for the other two slots - pairs of adjacent registers, so the tail runs as packed fp32.
+// k_score_mfma: same contract and same exact pass as k_score_queue, but pass A comes out of the matrix pipe whole: the
+// reprojection test is four half-planes per pair, each linear in sixteen numbers of the correspondence (X high / low,
+// 1, slack | x X high / low, x), so two v_mfma_f32_32x32x16_f16 - one with the x-, one with the y-products - deliver
+// B - a0, B + a0, B - a1, B + a1 (B = thr z2 + slack) for 16 hypotheses x 32 correspondences (operand rows: k_shadow16 in
+// pipeline.hip; bound derivation in pl_prefilter.h).  The vector ALU ORs the four sign bits of a pair (one v_or3, one
+// v_or) and shifts the result into a per-lane, per-hypothesis bit field over the point groups (v_alignbit): 3
+// instructions per pair instead of 4 with the z rows of round 1.  After the PG tiles of a group of 16 hypotheses the bit
+// fields are expanded into the wave's LDS queue, hypothesis by hypothesis (prefix sum over the lanes), so the drain's
+// segmented scan sees every hypothesis as one run, exactly as in k_score_queue.
+// Register layout of a tile (32 rows x 32 columns, 16 accumulator registers per lane; lane l: column l % 32, rows
+// 8 (v / 4) + 4 (l / 32) + v % 4 for register v; row 2 j + f = hypothesis j of the group, f = 0: B - a, 1: B + a):
+// register 4 q + 2 e + f of a lane belongs to hypothesis 4 q + 2 (l / 32) + e.
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 constexpr int kMfmaQueueCap = 1024; // >= 63 waiting + 64 lanes * 10 point groups appended by one round
 #ifndef PL_MFMA_THREADS
@@ -832,7 +833,7 @@ constexpr int kMfmaQueueCap = 1024; // >= 63 waiting + 64 lanes * 10 point group
 constexpr int kMfmaThreads = PL_MFMA_THREADS; // 8 wavefronts share one chunk of correspondences (LDS: 20 KB shared + 2.8 KB per wave)
 
 template <int PG>
-__device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2 *__restrict__ shadow16,
+__device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4 *__restrict__ shadow16,
                                                 const double *__restrict__ models, const uint32_t *__restrict__ slots,
                                                 const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
                                                 double thr2, const PrefilterArgs &pf, uint32_t *__restrict__ part_count,
@@ -845,8 +846,9 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
     __shared__ double s_acc_s[kWaves][64];
     __shared__ uint32_t s_acc_c[kWaves][64];
     __shared__ uint32_t s_next_unit;
-    __shared__ uint2 s_bop[PG][64];  // B operands of the point groups (lane-specific: high / low fp16 parts)
-    __shared__ float2 s_xy[PG][32];  // fp32 x, y per column
+    __shared__ uint4 s_b0[PG][32]; // B operands, first k block: (X_hi, X_lo, 1, w) - shared by the x- and the y-instruction
+    __shared__ uint4 s_bx[PG][32]; // second k block of the x-instruction: (x X)_hi, (x X)_lo, x, 0
+    __shared__ uint4 s_by[PG][32]; // ... of the y-instruction
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int col = lane & 31, half = lane >> 5;
@@ -868,34 +870,41 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
                 s_pts[d][g * 32 + col] = x[d];
         }
         const double n1 = fabs(x[2]) + fabs(x[3]) + fabs(x[4]);
-        const bool in_range = n1 < 3.0e4; // fp16 carries it (NaN fails the test too)
+        // fp16 carries the coordinates and their products with x, y (NaN fails the tests too)
+        const bool in_range = n1 < 3.0e4 && fabs(x[0]) * n1 < 3.0e4 && fabs(x[1]) * n1 < 3.0e4 && fabs(x[0]) < 3.0e4 && fabs(x[1]) < 3.0e4;
         const bool use = valid && in_range;
-        _Float16 h[3], l[3];
+        if (wave == 0 && half == 0) {
+            auto split = [](double v, unsigned short &hi, unsigned short &lo) {
+                const float f = (float)v;
+                const _Float16 h = (_Float16)f;
+                const _Float16 l = (_Float16)(float)(v - (double)(float)h);
+                __builtin_memcpy(&hi, &h, 2);
+                __builtin_memcpy(&lo, &l, 2);
+            };
+            unsigned short Xh[3], Xl[3], xh[3], xl[3], yh[3], yl[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float v = use ? (float)x[2 + d] : 0.f;
-            h[d] = (_Float16)v;
-            l[d] = (_Float16)(v - (float)h[d]);
-        }
-        if (wave == 0) {
-            // the point's share of the slack, rounded up to fp16; it rides in the last k slot of the low half
-            // (out-of-range points: zero operand and the largest finite fp16, not +inf - an infinite entry would turn the z rows, whose
-            // matching k slot is 0, into NaN; 65504 exceeds every |a| a zero point operand can produce, since
-            // hypotheses with |t| >= 3e4 carry an infinite slack of their own and thr <= 1 on this path)
+            for (int d = 0; d < 3; ++d) {
+                split(use ? x[2 + d] : 0.0, Xh[d], Xl[d]);
+                split(use ? x[0] * x[2 + d] : 0.0, xh[d], xl[d]);
+                split(use ? x[1] * x[2 + d] : 0.0, yh[d], yl[d]);
+            }
+            // the point's share of the slack, rounded up to fp16; it rides in the last slot of the first k block
+            // (out-of-range points: zero operands and the largest finite fp16, not +inf: hypotheses with |t| >= 3e4 carry an
+            // infinite slack of their own, so 65504 exceeds every |a| a zero operand can produce, thr <= 1 on this path)
             const float wv = use ? fminf(pf_up(pf.g16 * pf_up((float)n1)) + 1.3e-4f, 65504.f) : 65504.f;
             _Float16 wh = (_Float16)wv;
-            if ((float)wh < wv) {
-                unsigned short bits;
-                __builtin_memcpy(&bits, &wh, 2);
-                bits = (unsigned short)(bits + 1);
-                __builtin_memcpy(&wh, &bits, 2);
-            }
-            const half4_t b = half ? half4_t{l[0], l[1], l[2], wh} : half4_t{h[0], h[1], h[2], (_Float16)1.0f};
-            uint2 raw;
-            __builtin_memcpy(&raw, &b, 8);
-            s_bop[g][lane] = raw;
-            if (half == 0)
-                s_xy[g][col] = make_float2(use ? (float)x[0] : 0.f, use ? (float)x[1] : 0.f);
+            unsigned short wbits;
+            __builtin_memcpy(&wbits, &wh, 2);
+            if ((float)wh < wv)
+                wbits = (unsigned short)(wbits + 1);
+            const _Float16 x16 = (_Float16)(use ? (float)x[0] : 0.f), y16 = (_Float16)(use ? (float)x[1] : 0.f);
+            unsigned short xb, yb;
+            __builtin_memcpy(&xb, &x16, 2);
+            __builtin_memcpy(&yb, &y16, 2);
+            auto pack = [](unsigned short a, unsigned short b) { return (uint32_t)a | ((uint32_t)b << 16); };
+            s_b0[g][col] = make_uint4(pack(Xh[0], Xh[1]), pack(Xh[2], Xl[0]), pack(Xl[1], Xl[2]), pack(0x3c00, wbits));
+            s_bx[g][col] = make_uint4(pack(xh[0], xh[1]), pack(xh[2], xl[0]), pack(xl[1], xl[2]), pack(xb, 0));
+            s_by[g][col] = make_uint4(pack(yh[0], yh[1]), pack(yh[2], yl[0]), pack(yl[1], yl[2]), pack(yb, 0));
         }
         validbits |= valid ? (1u << (PG - 1 - g)) : 0u;
     }
@@ -973,48 +982,55 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
             qhead += n;
         };
 
-        const uint32_t ngroups8 = (gn + 7u) / 8u;
-        uint2 Araw = shadow16[((size_t)(kb >> 3)) * 64 + half * 32 + col];
-        for (uint32_t hg = 0; hg < ngroups8; ++hg) {
-            half4_t Aop;
-            __builtin_memcpy(&Aop, &Araw, 8);
-            if (hg + 1 < ngroups8) // next group's operand travels while this one is evaluated
-                Araw = shadow16[((size_t)(kb >> 3) + hg + 1) * 64 + half * 32 + col];
-            uint32_t out[4] = {0u, 0u, 0u, 0u}; // slot 2 r + half: bit (PG - 1 - g) = point group g is a proven outlier
+        const uint32_t ngroups16 = (gn + 15u) / 16u;
+        // lane l: row l % 32 of the group's blocks; lanes 0..31 carry the first k block (x rows / y rows), lanes 32..63
+        // the second one (the same for both instructions)
+        auto load_a = [&](uint32_t hg, uint4 &ax, uint4 &ay) {
+            const uint4 *grp = shadow16 + ((size_t)(kb >> 4) + hg) * 96;
+            ax = grp[(half ? 64 : 0) + col];
+            ay = grp[(half ? 64 : 32) + col];
+        };
+        uint4 Axr, Ayr;
+        load_a(0, Axr, Ayr);
+        for (uint32_t hg = 0; hg < ngroups16; ++hg) {
+            half8_t Ax, Ay;
+            __builtin_memcpy(&Ax, &Axr, 16);
+            __builtin_memcpy(&Ay, &Ayr, 16);
+            if (hg + 1 < ngroups16) // next group's operands travel while this one is evaluated
+                load_a(hg + 1, Axr, Ayr);
+            uint32_t out[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; // hypothesis 4 q + 2 half + e -> out[2 q + e]: bit (PG - 1 - g) = point group g is a proven outlier
             const float16_t kZero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 2
+#pragma unroll 1
             for (int g = 0; g < PG; ++g) {
-                half4_t Bop;
-                const uint2 braw = s_bop[g][lane];
-                __builtin_memcpy(&Bop, &braw, 8);
-                const float2 xy = s_xy[g][col];
-                const float16_t D = __builtin_amdgcn_mfma_f32_32x32x8f16(Aop, Bop, kZero, 0, 0, 0);
+                const uint4 bxr = half ? s_bx[g][col] : s_b0[g][col];
+                const uint4 byr = half ? s_by[g][col] : s_b0[g][col];
+                half8_t Bx, By;
+                __builtin_memcpy(&Bx, &bxr, 16);
+                __builtin_memcpy(&By, &byr, 16);
+                const float16_t Dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ax, Bx, kZero, 0, 0, 0);
+                const float16_t Dy = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ay, By, kZero, 0, 0, 0);
 #pragma unroll
-                for (int P2 = 0; P2 < 2; ++P2) {
-                    const int b = 8 * P2;
-                    const v2f z0 = {D[b], D[b + 1]}, z2 = {D[b + 2], D[b + 3]};
-                    const v2f z1 = {D[b + 4], D[b + 5]}, Bt = {D[b + 6], D[b + 7]}; // Bt = thr z2 + slack
-                    const v2f a0 = pk_fma(bc(-xy.x), z2, z0);
-                    const v2f a1 = pk_fma(bc(-xy.y), z2, z1);
+                for (int q = 0; q < 4; ++q) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        // proven outlier <=> max(|a0|, |a1|) > B <=> B - max < 0: the sign bit of the difference
-                        // is shifted into the bit field by one v_alignbit
-                        const float d = Bt[e] - fmaxf(fabsf(a0[e]), fabsf(a1[e]));
-                        out[2 * P2 + e] = __builtin_amdgcn_alignbit(out[2 * P2 + e], __float_as_uint(d), 31);
+                        // proven outlier <=> one of B - a0, B + a0, B - a1, B + a1 is negative: OR of the four sign bits
+                        const int b = 4 * q + 2 * e;
+                        const uint32_t sg = __float_as_uint(Dx[b]) | __float_as_uint(Dx[b + 1]) | __float_as_uint(Dy[b]) |
+                                            __float_as_uint(Dy[b + 1]);
+                        out[2 * q + e] = __builtin_amdgcn_alignbit(out[2 * q + e], sg, 31);
                     }
                 }
             }
-            // ---- expansion: four rounds, round r = slots 2 r (lanes 0..31) and 2 r + 1 (lanes 32..63) ----
+            // ---- expansion: eight rounds, round (q, e) = hypothesis 4 q + e (lanes 0..31) and 4 q + 2 + e (lanes 32..63) ----
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t slot = hg * 8u + 2u * r + half; // hypothesis index inside the group of 64
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t slot = hg * 16u + 4u * (uint32_t)(r >> 1) + 2u * (uint32_t)half + (uint32_t)(r & 1); // hypothesis index inside the unit
                 uint32_t bits = ~out[r] & validbits;
                 if (slot >= gn)
                     bits = 0u;
                 if (__builtin_amdgcn_ballot_w64(bits != 0u)) { // wave-uniform
                     const uint32_t cnt = (uint32_t)__popc(bits);
-                    const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = lower slot first)
+                    const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
                     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     uint32_t pos = qtail + incl - cnt;
                     uint32_t rest = bits;
@@ -1044,7 +1060,7 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint2
 }
 
 template <int PG>
-__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma(PointSet pts, const uint2 *__restrict__ shadow16,
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_score_mfma(PointSet pts, const uint4 *__restrict__ shadow16,
                                                                const double *__restrict__ models,
                                                                const uint32_t *__restrict__ slots,
                                                                const uint32_t *__restrict__ num_hyp_ptr,
@@ -1057,12 +1073,12 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
                         blockIdx.x, blockIdx.y, gridDim.x);
 }
 template <int PG>
-__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_score_mfma_g(const GroupArgs *ga) {
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_score_mfma_g(const GroupArgs *ga) {
     const GroupArgs &g = ga[blockIdx.z];
     if (!g.active || !g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
         return;
     const ScoreArgs &a = g.score;
-    score_mfma_body<PG>(a.pts, static_cast<const uint2 *>(a.shadow16), a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,
+    score_mfma_body<PG>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,
                         a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
 }
 
@@ -1077,7 +1093,6 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(4,
 // 8 (v / 4) + 4 (l / 32) + v % 4.  The sign bits are shifted into one bit field per register over the PG groups of the
 // chunk, then expanded into the wave's LDS queue register by register - lanes 0..31 (one hypothesis) before lanes 32..63
 // (another), so every hypothesis is one run of the queue, which is all the drain's segmented sum needs.
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
 template <int EST, int PG>
 __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint4 *__restrict__ hypop,
@@ -2272,7 +2287,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
             const dim3 mblock(kMfmaThreads);
 #define PL_M_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \
-        k_score_mfma<2 * PP><<<mgrid, mblock, 0, stream>>>(a.pts, static_cast<const uint2 *>(a.shadow16), a.models,      \
+        k_score_mfma<2 * PP><<<mgrid, mblock, 0, stream>>>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models,      \
                                                          a.slots, a.num_hyp, a.hyp_capacity, a.thr2, pf,               \
                                                          a.part_count, a.part_score, a.tickets);                       \
         break;

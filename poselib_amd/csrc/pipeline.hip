@@ -639,17 +639,20 @@ __global__ __launch_bounds__(256) void k_records_g(const GroupArgs *ga) {
 }
 
 // ------------------------------------------------------------------------------------ fp16 hypothesis operands
-// A-operand blocks of v_mfma_f32_32x32x8_f16 for k_score_mfma (kernels.hip).  One block = 8 hypotheses = 32 rows x 8
-// halfs, stored [k-block 0: rows 0..31, 4 halfs each][k-block 1: rows 0..31] so that lane l of a wave loads its
-// operand (row l % 32, k-block l / 32) with one coalesced 8-byte load.  Hypothesis slot s = k % 8 sits in lane half
-// s & 1, round r = s >> 1 (register pair P = r >> 1, element e = r & 1), rows  z0: b, z2: b + 2, z1: b + 8, B: b + 10
-// with b = 16 P + 4 (s & 1) + e.  The point operand is (X, Y, Z, 1 | X_lo, Y_lo, Z_lo, w) with w the point's share
-// of the slack, so
-//   row of z_c = (R_c0, R_c1, R_c2, t_c | R_c0, R_c1, R_c2, 0)                         ->  z_c = R_c (X + X_lo) + t_c
-//   row of B   = (thr R_20, thr R_21, thr R_22, thr t_2 + g | thr R_20, thr R_21, thr R_22, 1)  ->  thr z_2 + g + w
-// i.e. the slack-widened threshold of the test comes out of the matrix pipe as well; g = g16 max|t_c| + c16 is the
-// hypothesis' share of the slack (pl_prefilter.h; +inf: evaluate every point exactly, -inf: NaN model, no inliers),
-// and the constant term is rounded UP to fp16.
+// A-operand rows of v_mfma_f32_32x32x16_f16 for k_score_mfma (kernels.hip; bounds in pl_prefilter.h).  The reprojection
+// test |z0 - x z2| <= thr z2 and |z1 - y z2| <= thr z2 is four half-planes, each LINEAR in the sixteen per-correspondence
+// numbers  (X, X_lo, 1, w | xX, (xX)_lo, x, 0)  resp. the same with y:
+//     F-  =  (thr R_2 - R_a) . X  +  (thr t_2 - t_a + g)  +  x (R_2 . X)  +  x t_2  +  w      ( = B - a,  a = z_a - x z_2 )
+//     F+  =  (thr R_2 + R_a) . X  +  (thr t_2 + t_a + g)  -  x (R_2 . X)  -  x t_2  +  w      ( = B + a )
+// so the matrix pipe delivers the four signed distances of a pair directly, slack included, and the vector ALU only
+// ORs four sign bits.  One instruction = 16 hypotheses x 2 rows (F-, F+) x 32 correspondences; the x- and the y-instruction
+// share the first k block of the correspondence side and the second k block of the hypothesis side.  Stored per group of
+// 16 hypotheses as three blocks of 32 rows x 16 B:  [block 0 of the x rows][block 0 of the y rows][block 1 (both)],
+// row 2 j + f for hypothesis j of the group and f = 0 (F-) / 1 (F+):
+//     block 0 = (c_0, c_1, c_2, c_0, c_1, c_2, const, 1),  c = thr R_2 -+ R_a,  const = thr t_2 -+ t_a + g  rounded UP
+//     block 1 = +-(R_20, R_21, R_22, R_20, R_21, R_22, t_2, 0)
+// g = g16 max|t_c| + c16 is the hypothesis' share of the slack (+inf: evaluate every point exactly, -inf: NaN model, no
+// inliers; the other entries are zero then).
 __device__ __forceinline__ unsigned short half_bits_rn(float v) {
     const _Float16 h = (_Float16)v;
     unsigned short b;
@@ -664,80 +667,107 @@ __device__ __forceinline__ unsigned short half_bits_up(float v) { // v >= 0: sma
         b = (unsigned short)(b + 1); // next fp16 above (b < 0x7c00 here; 0x7bff + 1 = +inf)
     return b;
 }
+__device__ __forceinline__ unsigned short half_bits_toward_plus_inf(float v) { // any sign: smallest fp16 >= v
+    _Float16 h = (_Float16)v;
+    unsigned short bits;
+    __builtin_memcpy(&bits, &h, 2);
+    if ((float)h < v) {
+        bits = (bits & 0x8000u) ? (unsigned short)(bits - 1) : (unsigned short)(bits + 1);
+        if (bits == 0x8000u)
+            bits = 0; // -0 -> +0
+    }
+    return bits;
+}
 // shadow_of(k): the fp32 shadow (16 floats) of hypothesis k < H
 template <typename ShadowOf>
 __device__ __forceinline__ void shadow16_one(uint32_t k, uint32_t H, ShadowOf shadow_of, float g16, float c16, float thr,
-                                             uint2 *__restrict__ out) {
-    if (k >= ((H + 7u) & ~7u))
-        return; // blocks past the last hypothesis are never read
-    const uint32_t s = k & 7u, half = s & 1u, r = s >> 1, P = r >> 1, e = r & 1u;
-    const uint32_t b = 16u * P + 4u * half + e;
-    uint2 *blk = out + (size_t)(k >> 3) * 64; // 512 B = 64 x 8 B
-    const uint32_t rows[4] = {b, b + 8, b + 2, b + 10}; // z0, z1, z2, B
+                                             uint4 *__restrict__ out) {
+    if (k >= ((H + 15u) & ~15u))
+        return; // groups past the last hypothesis are never read
     float R[9], t[3];
     float slack; // +inf / -inf / finite
+    for (int i = 0; i < 9; ++i)
+        R[i] = 0.f;
+    t[0] = t[1] = t[2] = 0.f;
     if (k >= H) {
         slack = -__builtin_huge_valf(); // not a hypothesis: never a candidate
-        for (int i = 0; i < 9; ++i)
-            R[i] = 0.f;
-        t[0] = t[1] = t[2] = 0.f;
     } else {
         const float *f = shadow_of(k);
         float rmax = 0.f;
-        for (int i = 0; i < 9; ++i) {
-            R[i] = f[i];
+        for (int i = 0; i < 9; ++i)
             rmax = fmaxf(rmax, fabsf(f[i]));
-        }
-        for (int i = 0; i < 3; ++i)
-            t[i] = f[9 + i];
         const float tmax = f[12];
         uint32_t nanflag;
         __builtin_memcpy(&nanflag, &f[13], 4);
         if (nanflag != 0u) {
             slack = -__builtin_huge_valf();
-            for (int i = 0; i < 9; ++i)
-                R[i] = 0.f;
-            t[0] = t[1] = t[2] = 0.f;
         } else if (!(tmax < 3.0e4f) || !(rmax <= 1.0001f)) {
             slack = __builtin_huge_valf(); // outside what fp16 carries: every point is evaluated exactly
-            for (int i = 0; i < 9; ++i)
-                R[i] = 0.f;
-            t[0] = t[1] = t[2] = 0.f;
         } else {
+            for (int i = 0; i < 9; ++i)
+                R[i] = f[i];
+            for (int i = 0; i < 3; ++i)
+                t[i] = f[9 + i];
             slack = fmaf(g16, tmax, c16) * 1.000001f + 6.2e-5f;
         }
     }
-    for (int c = 0; c < 3; ++c) {
-        const unsigned short r0 = half_bits_rn(R[3 * c]), r1 = half_bits_rn(R[3 * c + 1]), r2 = half_bits_rn(R[3 * c + 2]);
-        const unsigned short th = half_bits_rn(t[c]);
-        const uint32_t w0 = (uint32_t)r0 | ((uint32_t)r1 << 16);
-        blk[rows[c]] = make_uint2(w0, (uint32_t)r2 | ((uint32_t)th << 16));
-        blk[32 + rows[c]] = make_uint2(w0, (uint32_t)r2);
-    }
-    {
-        const unsigned short r0 = half_bits_rn(thr * R[6]), r1 = half_bits_rn(thr * R[7]), r2 = half_bits_rn(thr * R[8]);
-        unsigned short cb;
-        if (slack == __builtin_huge_valf())
-            cb = 0x7c00;
-        else if (slack == -__builtin_huge_valf())
-            cb = 0xfc00;
-        else { // constant term thr t_2 + g, rounded up (it may be negative: round towards +inf)
-            const float cval = fmaf(thr, t[2], slack);
-            _Float16 h = (_Float16)cval;
-            if ((float)h < cval) { // next fp16 above
-                unsigned short bits;
-                __builtin_memcpy(&bits, &h, 2);
-                bits = (bits & 0x8000u) ? (unsigned short)(bits - 1) : (unsigned short)(bits + 1);
-                if (bits == 0x8000u)
-                    bits = 0; // -0 -> +0
-                __builtin_memcpy(&h, &bits, 2);
-            }
-            __builtin_memcpy(&cb, &h, 2);
+    uint4 *grp = out + (size_t)(k >> 4) * 96; // 3 blocks x 32 rows
+    const uint32_t j = k & 15u;
+    const bool finite = slack != __builtin_huge_valf() && slack != -__builtin_huge_valf();
+    for (int a = 0; a < 2; ++a) {      // a = 0: the x rows (R_0, t_0), a = 1: the y rows (R_1, t_1)
+        for (int f = 0; f < 2; ++f) {  // f = 0: F- = B - a, f = 1: F+ = B + a
+            const float sg = f ? 1.f : -1.f;
+            unsigned short c[3];
+            for (int d = 0; d < 3; ++d)
+                c[d] = half_bits_rn(fmaf(thr, R[6 + d], sg * R[3 * a + d]));
+            unsigned short cb;
+            if (!finite)
+                cb = slack > 0 ? 0x7c00 : 0xfc00;
+            else
+                cb = half_bits_toward_plus_inf(fmaf(thr, t[2], sg * t[a]) + slack);
+            const uint32_t w0 = (uint32_t)c[0] | ((uint32_t)c[1] << 16);
+            const uint32_t w1 = (uint32_t)c[2] | ((uint32_t)c[0] << 16);
+            const uint32_t w2 = (uint32_t)c[1] | ((uint32_t)c[2] << 16);
+            const uint32_t w3 = (uint32_t)cb | (0x3c00u << 16); // const, 1.0
+            grp[a * 32 + 2 * j + f] = make_uint4(w0, w1, w2, w3);
         }
-        const uint32_t w0 = (uint32_t)r0 | ((uint32_t)r1 << 16);
-        blk[rows[3]] = make_uint2(w0, (uint32_t)r2 | ((uint32_t)cb << 16));
-        blk[32 + rows[3]] = make_uint2(w0, (uint32_t)r2 | (0x3c00u << 16)); // k7 = 1.0
     }
+    for (int f = 0; f < 2; ++f) { // block 1: the products with x (or y): + for F-, - for F+
+        const float sg = f ? -1.f : 1.f;
+        unsigned short r[3];
+        for (int d = 0; d < 3; ++d)
+            r[d] = half_bits_rn(sg * R[6 + d]);
+        const unsigned short t2 = half_bits_rn(sg * t[2]);
+        grp[64 + 2 * j + f] = make_uint4((uint32_t)r[0] | ((uint32_t)r[1] << 16), (uint32_t)r[2] | ((uint32_t)r[0] << 16),
+                                         (uint32_t)r[1] | ((uint32_t)r[2] << 16), (uint32_t)t2);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const float *__restrict__ shadow,
+                                                  uint32_t capacity16, float g16, float c16, float thr,
+                                                  uint4 *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= capacity16)
+        return;
+    shadow16_one(k, *num_hyp, [&](uint32_t kk) { return shadow + (size_t)kk * 16; }, g16, c16, thr, out);
+}
+
+// k_gather_models and k_shadow16 as ONE launch (both only depend on k_compact2's hypothesis list): blocks below
+// `gather_blocks` copy the records, the blocks above build the fp16 operand blocks straight from the records' shadows.
+__global__ __launch_bounds__(256) void k_gather_shadow16(BatchCtl *ctl, const uint32_t *slots, const double *models,
+                                                         float *shadow_compact, double *compact64,
+                                                         uint32_t gather_blocks, uint32_t capacity16, float g16, float c16,
+                                                         float thr, uint4 *__restrict__ out16) {
+    if (blockIdx.x < gather_blocks) {
+        gather_one(ctl, slots, models, shadow_compact, compact64, (uint64_t)blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
+    const uint32_t k = (blockIdx.x - gather_blocks) * 256 + threadIdx.x;
+    if (k >= capacity16)
+        return;
+    shadow16_one(k, ctl->num_hyp,
+                 [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
+                 g16, c16, thr, out16);
 }
 
 // Operands of k_score_mfma2 (Sampson scores on the matrix cores): 96 B per hypothesis = six 16-byte k blocks
@@ -773,33 +803,6 @@ __global__ __launch_bounds__(256) void k_sampson16(BatchCtl *ctl, const uint32_t
     sampson16_one(k, H, cap, slots, models, out);
 }
 
-__global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const float *__restrict__ shadow,
-                                                  uint32_t capacity8, float g16, float c16, float thr,
-                                                  uint2 *__restrict__ out) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= capacity8)
-        return;
-    shadow16_one(k, *num_hyp, [&](uint32_t kk) { return shadow + (size_t)kk * 16; }, g16, c16, thr, out);
-}
-
-// k_gather_models and k_shadow16 as ONE launch (both only depend on k_compact2's hypothesis list): blocks below
-// `gather_blocks` copy the records, the blocks above build the fp16 operand blocks straight from the records' shadows.
-__global__ __launch_bounds__(256) void k_gather_shadow16(BatchCtl *ctl, const uint32_t *slots, const double *models,
-                                                         float *shadow_compact, double *compact64,
-                                                         uint32_t gather_blocks, uint32_t capacity8, float g16, float c16,
-                                                         float thr, uint2 *__restrict__ out16) {
-    if (blockIdx.x < gather_blocks) {
-        gather_one(ctl, slots, models, shadow_compact, compact64, (uint64_t)blockIdx.x * 256 + threadIdx.x);
-        return;
-    }
-    const uint32_t k = (blockIdx.x - gather_blocks) * 256 + threadIdx.x;
-    if (k >= capacity8)
-        return;
-    shadow16_one(k, ctl->num_hyp,
-                 [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
-                 g16, c16, thr, out16);
-}
-
 __global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, uint32_t gather_blocks_max) {
     const GroupArgs &g = ga[blockIdx.z];
     if (!g.active)
@@ -821,14 +824,14 @@ __global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, 
             sampson16_one(k, H, capp, g.comp.slots, g.comp.models, static_cast<uint4 *>(g.comp.s16.out));
         return;
     }
-    const uint32_t cap8 = (uint32_t)((cap + 7u) & ~7ull);
-    if (k >= cap8)
+    const uint32_t cap16 = (uint32_t)((cap + 15u) & ~15ull);
+    if (k >= cap16)
         return;
     const uint32_t *slots = g.comp.slots;
     const double *models = g.comp.models;
     shadow16_one(k, g.comp.ctl->num_hyp,
                  [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
-                 g.comp.s16.g16, g.comp.s16.c16, g.comp.s16.thr, static_cast<uint2 *>(g.comp.s16.out));
+                 g.comp.s16.g16, g.comp.s16.c16, g.comp.s16.thr, static_cast<uint4 *>(g.comp.s16.out));
 }
 
 // ------------------------------------------------------------------------------------ front-end pre-processing
@@ -943,11 +946,11 @@ hipError_t launch_undistort(const double *in, uint32_t n, const CameraParams &ca
 // ------------------------------------------------------------------------------------ launchers
 hipError_t launch_shadow16(const uint32_t *num_hyp, const float *shadow_compact, uint32_t hyp_capacity, float g16,
                            float c16, float thr, void *shadow16, hipStream_t stream) {
-    const uint32_t cap8 = (hyp_capacity + 7u) & ~7u;
+    const uint32_t cap8 = (hyp_capacity + 15u) & ~15u;
     if (cap8 == 0)
         return hipSuccess;
     k_shadow16<<<dim3((cap8 + 255) / 256), dim3(256), 0, stream>>>(num_hyp, shadow_compact, cap8, g16, c16, thr,
-                                                                   static_cast<uint2 *>(shadow16));
+                                                                   static_cast<uint4 *>(shadow16));
     return hipGetLastError();
 }
 
@@ -998,10 +1001,10 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
     } else if (s16.out) {
         // matrix-core scorer: its fp16 operand blocks are built straight from the records, and its exact pass reads the
         // fp64 models from the records as well - no hypothesis-ordered copies
-        const uint32_t cap8 = (uint32_t)(((uint64_t)B * (uint64_t)maxm + 7u) & ~7ull);
+        const uint32_t cap8 = (uint32_t)(((uint64_t)B * (uint64_t)maxm + 15u) & ~15ull);
         k_gather_shadow16<<<dim3((cap8 + 255) / 256), dim3(256), 0, stream>>>(ctl, slots, models, nullptr, nullptr, 0u, cap8,
                                                                             s16.g16, s16.c16, s16.thr,
-                                                                            static_cast<uint2 *>(s16.out));
+                                                                            static_cast<uint4 *>(s16.out));
     } else if (shadow_compact && compact64) {
         const uint64_t threads = (uint64_t)B * (uint64_t)maxm * 12u; // capacity; lanes beyond num_hyp return at once
         k_gather_models<<<dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream>>>(ctl, slots, models,
@@ -1056,7 +1059,7 @@ hipError_t launch_group_positions(int K, const GroupArgs *args, const GroupDims 
 hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
     k_compact2_g<<<dim3((d.max_B + 1023) / 1024, 1, d.G), dim3(1024), 0, stream>>>(args);
     const uint32_t gblocks = (uint32_t)(((uint64_t)d.max_hcap * 12u + 255) / 256);
-    const uint32_t sblocks = d.any_mfma ? (((d.max_hcap + 7u) & ~7u) + (uint32_t)kSampson16Pad + 255) / 256 : 0u;
+    const uint32_t sblocks = d.any_mfma ? (((d.max_hcap + 15u) & ~15u) + (uint32_t)kSampson16Pad + 255) / 256 : 0u;
     k_gather_shadow16_g<<<dim3(gblocks + sblocks, 1, d.G), dim3(256), 0, stream>>>(args, gblocks);
     return hipGetLastError();
 }

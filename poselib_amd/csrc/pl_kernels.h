@@ -54,7 +54,7 @@ struct ScoreArgs {
     const float *shadow;       // optional compact [num_hyp][16] fp32 model shadows in hypothesis order (pre-filter)
     const double *compact64;   // optional compact [num_hyp][16] fp64 model fields in hypothesis order (pre-filter)
     const void *shadow16;      // optional fp16 MFMA operand blocks of the hypotheses (absolute pose, k_score_mfma):
-                               // 512 B per 8 hypotheses, see k_shadow16 in pipeline.hip
+                               // 96 B per hypothesis in groups of 16, see k_shadow16 in pipeline.hip
     const uint32_t *num_hyp;   // device scalar
     uint32_t hyp_capacity;     // row pitch of the partial arrays
     double thr2;
@@ -194,6 +194,8 @@ struct Shadow16Params {
     int sampson = 0; // 1: two-view, operands of k_score_mfma2 (96 B per hypothesis, pl_prefilter.h Sampson16Operand)
 };
 constexpr size_t kSampson16Bytes = 96;
+constexpr size_t kAbs16Bytes = 96;  // absolute pose (k_score_mfma): 2 rows x 3 k blocks x 16 B per hypothesis
+constexpr size_t kAbs16Pad = 16;    // the last group of 16 is filled up
 constexpr size_t kSampson16Pad = 64; // operand rows a partial group of 32 may read past the last hypothesis
 // blk_tot is followed by the generators' NaN-model table of the same length (nb = ceil(B / 1024) entries each)
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, bool counted, uint32_t *slots,

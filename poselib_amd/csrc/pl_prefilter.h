@@ -34,20 +34,24 @@
 //    forces |C^| > 3.8 e_C > e_C); the extra 32u covers the roundings of C^ C^, gf^2 w and the final FMA.  The acceptance
 //    band is 4 % wider than with the two-comparison form (h trades that against the weight of e_C, which matters for
 //    un-normalised pixel coordinates); 20 instead of 24 operations per pair.
-//  * reprojection, fp16 / MFMA form (k_score_mfma): v_mfma_f32_32x32x8_f16 evaluates, with fp32 accumulation,
-//        z^_c = rn16(R_c) (X_hi + X_lo) + rn16(t_c)          X_hi = rn16(X), X_lo = rn16(X - X_hi)
-//        B^   = rn16(thr R_2) (X_hi + X_lo) + up16(thr t_2 + g) + up16(w)
-//    |R_ck| <= 1 gives |rn16(R_ck) - R_ck| <= 2^-12 and |rn16(t_c) - t_c| <= 2^-12 |t_c|; the hi/lo pair leaves
-//    2^-22 |X| (+ 3e-8 once the low part is subnormal); products are exact in fp32 and eight accumulations add
-//    <= 2^-21 (|X|_1 + |t_c|):  |z^_c - z_c| <= 2^-12 (|X|_1 + |t_c|) (1 + 2^-8) + 1e-7,  hence
-//    |a^ - a| <= (1 + |x|) of that for a^ = fl(z^0 - x z^2) (fp32, exact x), and B^ >= thr z_2 - 2^-11 thr |X|_1
-//    + g + w.  With  g = G max|t_c| + c,  w = G |X|_1 + 1.3e-4,  G = 2^-11 (1 + max|x|,|y| + thr),  c = 2.5e-4 (1 +
-//    max|x|,|y| + thr) + 6e-5 (every factor rounded up; the absolute parts also cover fp16 subnormal inputs - X_lo
-//    below |X| = 0.25, small t, small thr R_2 - being flushed to zero by the matrix pipe) the slack is twice the
-//    error of a^ plus the error of B^ itself, so
-//    max(|a^0|, |a^1|) > B^  proves an outlier; the "behind the camera" test is left to the exact pass.  Points or
-//    translations beyond 3e4 (fp16 range) and rotation rows that are not unit-bounded get an infinite slack
-//    (always evaluated exactly), NaN models -inf (never).
+//  * reprojection, fp16 / MFMA form (k_score_mfma, round 2): the test is four half-planes per pair,
+//        F(-+, a) = thr z_2 -+ (z_a - p z_2) + slack >= 0        a = 0, 1;  p = x (a = 0) or y (a = 1)
+//    and each is LINEAR in sixteen numbers of the correspondence, so v_mfma_f32_32x32x16_f16 evaluates, with fp32
+//    accumulation,
+//        F^ = rn16(thr R_2 -+ R_a) (X_hi + X_lo) + up16(thr t_2 -+ t_a + g) + up16(w)
+//             +- rn16(R_2) ((p X)_hi + (p X)_lo) +- rn16(t_2) rn16(p)
+//    (X_hi = rn16(X), X_lo = rn16(X - X_hi); the products p X are formed in fp64 and split the same way; p itself enters
+//    with its high part only).  |R_ck| <= 1 and thr <= 1 give coefficients bounded by 1 + thr, rounded with relative error
+//    2^-12; the splits leave 2^-22 (+ 6.1e-5 absolute once a part is subnormal - also when the matrix pipe flushes it);
+//    products are exact in fp32 and sixteen accumulations add <= 2^-19 of the sum of magnitudes:
+//        |F^ - F| <= 2^-12 (1 + thr + |p|) |X|_1 (1 + 2^-6)  +  2^-12 (2 |p| + 2^-7 (1 + thr)) max|t_c|  +  absolute terms
+//    (the 2 |p|: rounded t_2 and the dropped low part of p).  With  g = G max|t_c| + c,  w = G |X|_1 + 1.3e-4,
+//    G = 2^-11 (1 + max|x|,|y| + thr),  c = 4e-4 (1 + max|x|,|y| + thr) + 6e-5 (every factor rounded up; the absolute
+//    parts cover the subnormal operands: six low parts and p per row, and coefficients below 6.1e-5 against the margin
+//    of G) the slack exceeds the error with a factor of two to spare, and the constant is rounded towards +inf, so
+//    F^ >= F:  a NEGATIVE F^ proves |z_a - p z_2| > thr z_2, i.e. an outlier (z_2 <= 0: not an inlier either way).  The
+//    kernel ORs the four sign bits.  Points or translations beyond 3e4 (fp16 range; also |p| |X|_1) and rotation rows that
+//    are not unit-bounded get an infinite slack (always evaluated exactly), NaN models -inf (never).
 //  * Sampson, fp16 / MFMA form (k_score_mfma2; two-view problems whose coordinates are bounded by 8, i.e. normalised image
 //    points): the matrix pipe evaluates the two FORMS of the test directly, for 32 models x 32 correspondences per
 //    instruction (v_mfma_f32_32x32x16_f16, fp32 accumulation):
@@ -123,7 +127,8 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
         a.g16 = nextafterf((float)(4.8828125e-4 * (1.0 + (double)xy_absmax + thr)), inf); // 2^-11
         // 2e-7: fp32 accumulation; 2.5e-4: four fp16 inputs per row (X_lo, t) may be subnormal, i.e. below 6.1e-5 - the
         // bound holds even if the matrix pipe flushes them to zero
-        a.c16 = nextafterf((float)((2e-7 + 2.5e-4) * (1.0 + (double)xy_absmax + thr)), inf);
+        // (round 2, half-plane rows: six low parts - X_lo, (x X)_lo - and x itself may be subnormal per row: 4e-4)
+        a.c16 = nextafterf((float)((2e-7 + 4.0e-4) * (1.0 + (double)xy_absmax + thr)), inf);
     }
     if (est == 1 || est == 2) {
         // xy_absmax of a two-view problem: max over all four coordinates (driver.cc make_problem; +inf when unknown).
