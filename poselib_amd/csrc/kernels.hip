@@ -858,55 +858,29 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
     // unrolled one makes the register allocator give every tile its own 16 accumulators and spill the rest).
     uint32_t validbits = 0; // bit (PG - 1 - g): group g holds a real correspondence in this column
 #pragma unroll
-    for (int g = 0; g < PG; ++g) {
-        const uint32_t i = chunk * NPW + g * 32 + col;
+    for (int g = 0; g < PG; ++g)
+        validbits |= (chunk * NPW + g * 32 + col < pts.n) ? (1u << (PG - 1 - g)) : 0u;
+    // one thread per correspondence of the chunk: fp64 copy for the exact pass, fp16 operands for the filter
+    // (pl_prefilter.h pf16_abs_point: the host test build runs the same function)
+    for (uint32_t j = threadIdx.x; j < (uint32_t)NPW; j += kMfmaThreads) {
+        const uint32_t i = chunk * NPW + j;
         const bool valid = i < pts.n;
         const uint32_t ic = valid ? i : 0u;
         double x[5];
 #pragma unroll
         for (int d = 0; d < 5; ++d) {
             x[d] = pts.a[d][ic];
-            if (wave == 0 && half == 0)
-                s_pts[d][g * 32 + col] = x[d];
+            s_pts[d][j] = x[d];
         }
-        const double n1 = fabs(x[2]) + fabs(x[3]) + fabs(x[4]);
-        // fp16 carries the coordinates and their products with x, y (NaN fails the tests too)
-        const bool in_range = n1 < 3.0e4 && fabs(x[0]) * n1 < 3.0e4 && fabs(x[1]) * n1 < 3.0e4 && fabs(x[0]) < 3.0e4 && fabs(x[1]) < 3.0e4;
-        const bool use = valid && in_range;
-        if (wave == 0 && half == 0) {
-            auto split = [](double v, unsigned short &hi, unsigned short &lo) {
-                const float f = (float)v;
-                const _Float16 h = (_Float16)f;
-                const _Float16 l = (_Float16)(float)(v - (double)(float)h);
-                __builtin_memcpy(&hi, &h, 2);
-                __builtin_memcpy(&lo, &l, 2);
-            };
-            unsigned short Xh[3], Xl[3], xh[3], xl[3], yh[3], yl[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                split(use ? x[2 + d] : 0.0, Xh[d], Xl[d]);
-                split(use ? x[0] * x[2 + d] : 0.0, xh[d], xl[d]);
-                split(use ? x[1] * x[2 + d] : 0.0, yh[d], yl[d]);
-            }
-            // the point's share of the slack, rounded up to fp16; it rides in the last slot of the first k block
-            // (out-of-range points: zero operands and the largest finite fp16, not +inf: hypotheses with |t| >= 3e4 carry an
-            // infinite slack of their own, so 65504 exceeds every |a| a zero operand can produce, thr <= 1 on this path)
-            const float wv = use ? fminf(pf_up(pf.g16 * pf_up((float)n1)) + 1.3e-4f, 65504.f) : 65504.f;
-            _Float16 wh = (_Float16)wv;
-            unsigned short wbits;
-            __builtin_memcpy(&wbits, &wh, 2);
-            if ((float)wh < wv)
-                wbits = (unsigned short)(wbits + 1);
-            const _Float16 x16 = (_Float16)(use ? (float)x[0] : 0.f), y16 = (_Float16)(use ? (float)x[1] : 0.f);
-            unsigned short xb, yb;
-            __builtin_memcpy(&xb, &x16, 2);
-            __builtin_memcpy(&yb, &y16, 2);
-            auto pack = [](unsigned short a, unsigned short b) { return (uint32_t)a | ((uint32_t)b << 16); };
-            s_b0[g][col] = make_uint4(pack(Xh[0], Xh[1]), pack(Xh[2], Xl[0]), pack(Xl[1], Xl[2]), pack(0x3c00, wbits));
-            s_bx[g][col] = make_uint4(pack(xh[0], xh[1]), pack(xh[2], xl[0]), pack(xl[1], xl[2]), pack(xb, 0));
-            s_by[g][col] = make_uint4(pack(yh[0], yh[1]), pack(yh[2], yl[0]), pack(yl[1], yl[2]), pack(yb, 0));
-        }
-        validbits |= valid ? (1u << (PG - 1 - g)) : 0u;
+        Abs16Point o;
+        pf16_abs_point(x[0], x[1], x[2], x[3], x[4], valid, pf.g16, o);
+        auto row = [](const uint16_t *h) {
+            return make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                              (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+        };
+        s_b0[j >> 5][j & 31] = row(o.b0);
+        s_bx[j >> 5][j & 31] = row(o.bx);
+        s_by[j >> 5][j & 31] = row(o.by);
     }
     if (threadIdx.x == 0)
         s_next_unit = 0;
@@ -1132,26 +1106,19 @@ __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint
 #pragma unroll
     for (int g = 0; g < PG; ++g)
         validbits |= (chunk * NPW + g * 32 + col < pts.n) ? (1u << (PG - 1 - g)) : 0u;
-    for (int g = wave; g < PG; g += kWaves) {
-        const uint32_t i = chunk * NPW + g * 32 + col;
+    // one thread per correspondence: its fp16 operand blocks (block 2 j + h of the operand = instruction j, lane half h)
+    for (uint32_t j = threadIdx.x; j < (uint32_t)NPW; j += kMfmaThreads) {
+        const uint32_t i = chunk * NPW + j;
         const bool valid = i < pts.n;
         const uint32_t ic = valid ? i : 0u;
         Sampson16Operand o;
         pf16_sampson_point(pts.a[0][ic], pts.a[1][ic], pts.a[2][ic], pts.a[3][ic], valid, pf.t16, o);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            // k block 2 j + half of the operand: both candidates are built, the lane keeps its own
-            uint32_t w[2][4];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int b = 2 * j + hh;
-                const uint16_t *h = b < 4 ? o.c + 8 * b : o.s + 8 * (b - 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    w[hh][q] = (uint32_t)h[2 * q] | ((uint32_t)h[2 * q + 1] << 16);
-            }
-            s_bop[g][j][lane] = make_uint4(half ? w[1][0] : w[0][0], half ? w[1][1] : w[0][1], half ? w[1][2] : w[0][2],
-                                           half ? w[1][3] : w[0][3]);
+        for (int b = 0; b < 6; ++b) {
+            const uint16_t *h = b < 4 ? o.c + 8 * b : o.s + 8 * (b - 4);
+            s_bop[j >> 5][b >> 1][(j & 31) + 32 * (b & 1)] =
+                make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                           (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
         }
     }
     if (threadIdx.x == 0)

@@ -653,93 +653,24 @@ __global__ __launch_bounds__(256) void k_records_g(const GroupArgs *ga) {
 //     block 1 = +-(R_20, R_21, R_22, R_20, R_21, R_22, t_2, 0)
 // g = g16 max|t_c| + c16 is the hypothesis' share of the slack (+inf: evaluate every point exactly, -inf: NaN model, no
 // inliers; the other entries are zero then).
-__device__ __forceinline__ unsigned short half_bits_rn(float v) {
-    const _Float16 h = (_Float16)v;
-    unsigned short b;
-    __builtin_memcpy(&b, &h, 2);
-    return b;
-}
-__device__ __forceinline__ unsigned short half_bits_up(float v) { // v >= 0: smallest fp16 >= v
-    _Float16 h = (_Float16)v;
-    unsigned short b;
-    __builtin_memcpy(&b, &h, 2);
-    if ((float)h < v)
-        b = (unsigned short)(b + 1); // next fp16 above (b < 0x7c00 here; 0x7bff + 1 = +inf)
-    return b;
-}
-__device__ __forceinline__ unsigned short half_bits_toward_plus_inf(float v) { // any sign: smallest fp16 >= v
-    _Float16 h = (_Float16)v;
-    unsigned short bits;
-    __builtin_memcpy(&bits, &h, 2);
-    if ((float)h < v) {
-        bits = (bits & 0x8000u) ? (unsigned short)(bits - 1) : (unsigned short)(bits + 1);
-        if (bits == 0x8000u)
-            bits = 0; // -0 -> +0
-    }
-    return bits;
-}
 // shadow_of(k): the fp32 shadow (16 floats) of hypothesis k < H
 template <typename ShadowOf>
 __device__ __forceinline__ void shadow16_one(uint32_t k, uint32_t H, ShadowOf shadow_of, float g16, float c16, float thr,
                                              uint4 *__restrict__ out) {
     if (k >= ((H + 15u) & ~15u))
         return; // groups past the last hypothesis are never read
-    float R[9], t[3];
-    float slack; // +inf / -inf / finite
-    for (int i = 0; i < 9; ++i)
-        R[i] = 0.f;
-    t[0] = t[1] = t[2] = 0.f;
-    if (k >= H) {
-        slack = -__builtin_huge_valf(); // not a hypothesis: never a candidate
-    } else {
-        const float *f = shadow_of(k);
-        float rmax = 0.f;
-        for (int i = 0; i < 9; ++i)
-            rmax = fmaxf(rmax, fabsf(f[i]));
-        const float tmax = f[12];
-        uint32_t nanflag;
-        __builtin_memcpy(&nanflag, &f[13], 4);
-        if (nanflag != 0u) {
-            slack = -__builtin_huge_valf();
-        } else if (!(tmax < 3.0e4f) || !(rmax <= 1.0001f)) {
-            slack = __builtin_huge_valf(); // outside what fp16 carries: every point is evaluated exactly
-        } else {
-            for (int i = 0; i < 9; ++i)
-                R[i] = f[i];
-            for (int i = 0; i < 3; ++i)
-                t[i] = f[9 + i];
-            slack = fmaf(g16, tmax, c16) * 1.000001f + 6.2e-5f;
-        }
-    }
+    Abs16Model m;
+    pf16_abs_model(k < H ? shadow_of(k) : nullptr, g16, c16, thr, m); // (pl_prefilter.h: the host test build runs the same)
     uint4 *grp = out + (size_t)(k >> 4) * 96; // 3 blocks x 32 rows
     const uint32_t j = k & 15u;
-    const bool finite = slack != __builtin_huge_valf() && slack != -__builtin_huge_valf();
-    for (int a = 0; a < 2; ++a) {      // a = 0: the x rows (R_0, t_0), a = 1: the y rows (R_1, t_1)
-        for (int f = 0; f < 2; ++f) {  // f = 0: F- = B - a, f = 1: F+ = B + a
-            const float sg = f ? 1.f : -1.f;
-            unsigned short c[3];
-            for (int d = 0; d < 3; ++d)
-                c[d] = half_bits_rn(fmaf(thr, R[6 + d], sg * R[3 * a + d]));
-            unsigned short cb;
-            if (!finite)
-                cb = slack > 0 ? 0x7c00 : 0xfc00;
-            else
-                cb = half_bits_toward_plus_inf(fmaf(thr, t[2], sg * t[a]) + slack);
-            const uint32_t w0 = (uint32_t)c[0] | ((uint32_t)c[1] << 16);
-            const uint32_t w1 = (uint32_t)c[2] | ((uint32_t)c[0] << 16);
-            const uint32_t w2 = (uint32_t)c[1] | ((uint32_t)c[2] << 16);
-            const uint32_t w3 = (uint32_t)cb | (0x3c00u << 16); // const, 1.0
-            grp[a * 32 + 2 * j + f] = make_uint4(w0, w1, w2, w3);
-        }
-    }
-    for (int f = 0; f < 2; ++f) { // block 1: the products with x (or y): + for F-, - for F+
-        const float sg = f ? -1.f : 1.f;
-        unsigned short r[3];
-        for (int d = 0; d < 3; ++d)
-            r[d] = half_bits_rn(sg * R[6 + d]);
-        const unsigned short t2 = half_bits_rn(sg * t[2]);
-        grp[64 + 2 * j + f] = make_uint4((uint32_t)r[0] | ((uint32_t)r[1] << 16), (uint32_t)r[2] | ((uint32_t)r[0] << 16),
-                                         (uint32_t)r[1] | ((uint32_t)r[2] << 16), (uint32_t)t2);
+    auto row = [](const uint16_t *h) {
+        return make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                          (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+    };
+    for (int f = 0; f < 2; ++f) {
+        grp[2 * j + f] = row(m.x0[f]);
+        grp[32 + 2 * j + f] = row(m.y0[f]);
+        grp[64 + 2 * j + f] = row(m.b1[f]);
     }
 }
 

@@ -203,6 +203,14 @@ PL_HD bool pf_sampson_outlier(const float *r, float gf /* 16u * fm */, float t1,
 // ---- Sampson, fp16 / MFMA form: operands (header comment).  Portable fp16 conversions: the kernels, the operand builder
 // of the hypotheses (pipeline.hip) and the test-only host build run the same integer code ------------------------------
 PL_HD uint16_t pf_half_rn(float f) { // round to nearest even; overflow -> inf
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the conversion instruction does exactly this (v_cvt_f16_f32: IEEE round-to-nearest-even, subnormal results kept);
+    // the integer form below is what the host test build runs, checked bit for bit against IEEE half on 4e5 values
+    const _Float16 h = (_Float16)f;
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+#endif
     uint32_t x;
     __builtin_memcpy(&x, &f, 4);
     const uint32_t sign = (x >> 16) & 0x8000u;
@@ -222,6 +230,11 @@ PL_HD uint16_t pf_half_rn(float f) { // round to nearest even; overflow -> inf
     return (uint16_t)(sign | ((x - 0x38000000u) >> 13));
 }
 PL_HD float pf_half_to_float(uint16_t h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    _Float16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return (float)v;
+#endif
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
     const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
     uint32_t x;
@@ -342,6 +355,114 @@ PL_HD bool pf16_sampson_outlier(const Sampson16Operand &model, const Sampson16Op
     uint32_t bits;
     __builtin_memcpy(&bits, &d, 4);
     return (bits >> 31) != 0u;
+}
+
+// ---- reprojection, fp16 / MFMA form: operands (header comment).  The kernels (k_shadow16, k_score_mfma) and the test-only
+// host build run these very functions ---------------------------------------------------------------------------------
+PL_HD uint16_t pf_half_toward_plus_inf(float v) { // any sign: the smallest fp16 >= v
+    uint16_t b = pf_half_rn(v);
+    if ((b & 0x7fffu) < 0x7c00u && pf_half_to_float(b) < v) {
+        b = (b & 0x8000u) ? (uint16_t)(b - 1) : (uint16_t)(b + 1);
+        if (b == 0x8000u)
+            b = 0; // -0 -> +0
+    }
+    return b;
+}
+struct Abs16Model { // rows of one hypothesis: [f = 0: B - a, f = 1: B + a][8 k slots]
+    uint16_t x0[2][8]; // first k block of the x rows:  (c_0, c_1, c_2, c_0, c_1, c_2, const, 1)
+    uint16_t y0[2][8]; // ... of the y rows
+    uint16_t b1[2][8]; // second k block (both):        +-(R_20, R_21, R_22, R_20, R_21, R_22, t_2, 0)
+};
+// shadow: the record's fp32 shadow (R row-major at 0..8, t at 9..11, padded max|t_c| at 12, NaN flag at 13) or nullptr for
+// a row that is not a hypothesis
+PL_HD void pf16_abs_model(const float *shadow, float g16, float c16, float thr, Abs16Model &o) {
+    const float inf = __builtin_huge_valf();
+    float R[9], t[3], slack;
+    for (int i = 0; i < 9; ++i)
+        R[i] = 0.f;
+    t[0] = t[1] = t[2] = 0.f;
+    if (!shadow) {
+        slack = -inf; // never a candidate
+    } else {
+        float rmax = 0.f;
+        for (int i = 0; i < 9; ++i)
+            rmax = fmaxf(rmax, fabsf(shadow[i]));
+        const float tmax = shadow[12];
+        uint32_t nanflag;
+        __builtin_memcpy(&nanflag, &shadow[13], 4);
+        if (nanflag != 0u) {
+            slack = -inf; // NaN model: no inliers
+        } else if (!(tmax < 3.0e4f) || !(rmax <= 1.0001f)) {
+            slack = inf; // outside what fp16 carries: every point is evaluated exactly
+        } else {
+            for (int i = 0; i < 9; ++i)
+                R[i] = shadow[i];
+            for (int i = 0; i < 3; ++i)
+                t[i] = shadow[9 + i];
+            slack = fmaf(g16, tmax, c16) * 1.000001f + 6.2e-5f;
+        }
+    }
+    const bool finite = slack != inf && slack != -inf;
+    for (int a = 0; a < 2; ++a)
+        for (int f = 0; f < 2; ++f) {
+            const float sg = f ? 1.f : -1.f;
+            uint16_t *row = a ? o.y0[f] : o.x0[f];
+            for (int d = 0; d < 3; ++d)
+                row[d] = row[3 + d] = pf_half_rn(fmaf(thr, R[6 + d], sg * R[3 * a + d]));
+            row[6] = finite ? pf_half_toward_plus_inf(fmaf(thr, t[2], sg * t[a]) + slack) : (uint16_t)(slack > 0 ? 0x7c00u : 0xfc00u);
+            row[7] = 0x3c00u; // 1.0
+        }
+    for (int f = 0; f < 2; ++f) {
+        const float sg = f ? -1.f : 1.f;
+        for (int d = 0; d < 3; ++d)
+            o.b1[f][d] = o.b1[f][3 + d] = pf_half_rn(sg * R[6 + d]);
+        o.b1[f][6] = pf_half_rn(sg * t[2]);
+        o.b1[f][7] = 0;
+    }
+}
+struct Abs16Point {
+    uint16_t b0[8]; // (X_hi, X_lo, 1, w)
+    uint16_t bx[8]; // ((x X)_hi, (x X)_lo, x, 0)
+    uint16_t by[8];
+};
+// returns false (zero operands, largest finite slack) for correspondences the operands cannot carry
+PL_HD bool pf16_abs_point(double x, double y, double X, double Y, double Z, bool valid, float g16, Abs16Point &o) {
+    const double n1 = fabs(X) + fabs(Y) + fabs(Z);
+    const bool use = valid && n1 < 3.0e4 && fabs(x) * n1 < 3.0e4 && fabs(y) * n1 < 3.0e4 && fabs(x) < 3.0e4 && fabs(y) < 3.0e4;
+    const double P[3] = {X, Y, Z};
+    for (int d = 0; d < 3; ++d) {
+        pf_split16(use ? P[d] : 0.0, o.b0[d], o.b0[3 + d]);
+        pf_split16(use ? x * P[d] : 0.0, o.bx[d], o.bx[3 + d]);
+        pf_split16(use ? y * P[d] : 0.0, o.by[d], o.by[3 + d]);
+    }
+    // the point's share of the slack, rounded up (out of range: the largest finite fp16, not +inf - hypotheses with
+    // |t| >= 3e4 carry an infinite slack of their own, so 65504 exceeds every |a| a zero operand can produce; thr <= 1)
+    const float wv = use ? fminf(pf_up(g16 * pf_up((float)n1)) + 1.3e-4f, 65504.f) : 65504.f;
+    o.b0[6] = 0x3c00u;
+    o.b0[7] = pf_half_up(wv);
+    o.bx[6] = pf_half_rn(use ? (float)x : 0.f);
+    o.by[6] = pf_half_rn(use ? (float)y : 0.f);
+    o.bx[7] = o.by[7] = 0;
+    return use;
+}
+// The verdict as the kernel computes it (one particular accumulation order; `order` permutes it): true = certainly not an
+// inlier.  Test-only host build and documentation of the device tail.
+PL_HD bool pf16_abs_outlier(const Abs16Model &m, const Abs16Point &p, const int *order /* 16 slots or nullptr */) {
+    uint32_t sign = 0;
+    for (int a = 0; a < 2; ++a)
+        for (int f = 0; f < 2; ++f) {
+            float acc = 0.f;
+            for (int q = 0; q < 16; ++q) {
+                const int k = order ? order[q] : q;
+                const uint16_t av = k < 8 ? (a ? m.y0[f][k] : m.x0[f][k]) : m.b1[f][k - 8];
+                const uint16_t bv = k < 8 ? p.b0[k] : (a ? p.by[k - 8] : p.bx[k - 8]);
+                acc = fmaf(pf_half_to_float(av), pf_half_to_float(bv), acc);
+            }
+            uint32_t bits;
+            __builtin_memcpy(&bits, &acc, 4);
+            sign |= bits;
+        }
+    return (sign >> 31) != 0u;
 }
 
 } // namespace pl

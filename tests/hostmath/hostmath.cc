@@ -350,6 +350,34 @@ int hm_prefilter16(int est, const double *rec, const double *const *pa, uint32_t
     return 1;
 }
 
+// The reprojection pre-filter in its fp16 / matrix-core form (k_shadow16 + k_score_mfma; pl_prefilter.h): the same operand
+// builders as the kernels, the four half-plane forms accumulated in fp32 in k-slot order or (random_order != 0) in a
+// pseudo-random order.  Returns 0 when that form is not available (threshold above 1, coordinates out of range).
+int hm_prefilter16_abs(const double *rec, const double *const *pa, uint32_t n, double thr2, float xy_absmax,
+                       uint32_t random_order, uint8_t *out) {
+    const PrefilterArgs pf = make_prefilter_args(EST_ABS, thr2, xy_absmax);
+    std::memset(out, 0, n);
+    if (!pf.enabled || !(pf.g16 > 0.f) || !(pf.thr <= 1.0f))
+        return 0;
+    Abs16Model m;
+    pf16_abs_model(reinterpret_cast<const float *>(rec + kShadowOff), pf.g16, pf.c16, pf.thr, m);
+    uint64_t rng = 0x9e3779b97f4a7c15ull * (random_order + 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        Abs16Point p;
+        pf16_abs_point(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], true, pf.g16, p);
+        int order[16];
+        for (int k = 0; k < 16; ++k)
+            order[k] = k;
+        if (random_order)
+            for (int k = 15; k > 0; --k) {
+                rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17;
+                std::swap(order[k], order[(rng >> 33) % (uint64_t)(k + 1)]);
+            }
+        out[i] = pf16_abs_outlier(m, p, random_order ? order : nullptr);
+    }
+    return 1;
+}
+
 // fp16 conversions of pl_prefilter.h (checked against numpy's float16 by the tests)
 void hm_half_rn(const float *v, uint64_t n, uint16_t *bits, float *back) {
     for (uint64_t i = 0; i < n; ++i) {

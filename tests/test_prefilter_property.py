@@ -329,3 +329,76 @@ def test_sampson_fp16_form_at_the_threshold_and_degenerate():
     assert en and not out[:5].any()
     assert not HM.prefilter16("fund", HM.matrix_record(np.eye(3)), cols, 1e-4, 8.5)[0]
     assert not HM.prefilter16("fund", HM.matrix_record(np.eye(3)), cols, 1e-14, uv)[0]
+
+
+# ---- reprojection, fp16 / matrix-core form (k_shadow16 + k_score_mfma) ------------------------------------------------
+def _check16_abs(rec, cols, thr2, xy, stats=None, order=0):
+    _, _, inl, _ = HM.score("abs", rec, cols, thr2)
+    en, out = HM.prefilter16_abs(rec, cols, thr2, xy, order)
+    bad = inl & out
+    assert not bad.any(), (thr2, np.flatnonzero(bad)[:5])
+    if stats is not None and en:
+        stats[0] += int((~inl).sum())
+        stats[1] += int((~inl & ~out).sum())
+    return en
+
+
+def test_absolute_pose_fp16_form_never_drops_an_inlier():
+    """The four half-plane forms of the headline kernel's filter, built by the very operand functions the kernels call
+    (pf16_abs_model / pf16_abs_point) and accumulated in fp32 in several orders: scenes scaled by 1e-6 .. 300, world frames
+    shifted up to and beyond the fp16 range, camera centres next to scene points, thresholds 1e-5 .. 1, correspondences
+    planted at the decision boundary, NaN / inf / huge translations, non-unit quaternions."""
+    rs = np.random.RandomState(21)
+    stats = [0, 0]
+    enabled = 0
+    for trial in range(48):
+        scale, shift = [(1.0, 0.0), (1.0, 0.0), (50.0, 0.0), (1e-3, 0.0), (1e-6, 0.0), (300.0, 0.0), (1.0, 1e3), (1.0, 2.9e4),
+                        (1.0, 3.1e4), (0.25, 0.0), (1.0, 0.0), (1.0, 1e5)][trial % 12]
+        d = synth.absolute_pose_scene(1500, 0.5, 800 + trial)
+        par = d["camera"]["params"]
+        x = (np.asarray(d["p2d"]) - par[-2:]) / par[0]
+        off = np.array([shift, -shift, 0.5 * shift])
+        X = np.asarray(d["p3d"]) * scale + off
+        q = np.asarray(d["q_gt"], float)
+        R = np.array(HM.pose_record(q, np.zeros(3))[HM.MAT:HM.MAT + 9]).reshape(3, 3)
+        t = np.asarray(d["t_gt"], float) * scale - R @ off
+        if trial % 12 == 10:
+            x = x.copy()
+            x[::7] *= 40.0  # image points far outside the field of view
+        for thr in (1e-5, 1e-3, 1.2e-2, 0.3, 1.0):
+            rec0 = HM.pose_record(q, t)
+            xp, Xp = _plant_at_threshold_abs(rec0, X, thr, rs)
+            if len(xp) < 100:  # (tiny scenes: depths below the helper's cut) the scene as it is
+                xx, Xp = x, X
+            else:
+                sel = rs.rand(len(xp)) < 0.5
+                xx = np.where(sel[:, None], xp, x[:len(xp)])
+            cols = [xx[:, 0], xx[:, 1], Xp[:, 0], Xp[:, 1], Xp[:, 2]]
+            xy = float(np.abs(xx).max())
+            for model in range(6):
+                if model == 0:
+                    qq, tt = q, t
+                elif model == 1:
+                    qq = q + 1e-3 * rs.randn(4)
+                    qq /= np.linalg.norm(qq)
+                    tt = t + 1e-3 * scale * rs.randn(3)
+                elif model == 2:
+                    qq = rs.randn(4)
+                    qq /= np.linalg.norm(qq)
+                    tt = rs.randn(3) * scale * 3 - np.array(HM.pose_record(qq, np.zeros(3))[HM.MAT:HM.MAT + 9]).reshape(3, 3) @ off
+                elif model == 3:  # camera centre next to a scene point: depths around zero
+                    qq, tt = q, -R @ X[trial] + 1e-6 * scale * rs.randn(3)
+                elif model == 4:
+                    qq, tt = q, np.array([[2.9e4, 0, 1.0], [0, -3.1e4, 2.0], [np.nan, 0, 1], [0, np.inf, 1]][trial % 4])
+                else:
+                    qq, tt = 2.0 * q, t  # rows not unit-bounded
+                # (selectivity: random models at the thresholds the form is meant for; planted boundary points and tiny
+                # thresholds - below the fp16 slack - pass the filter by design)
+                typical = model == 2 and scale == 1.0 and shift == 0.0 and thr >= 1.2e-2
+                en = _check16_abs(HM.pose_record(qq, tt), cols, thr * thr, xy, stats if typical else None, order=trial % 3)
+                enabled += en
+    assert enabled > 500
+    print(f"abs (fp16 form): {stats[1]}/{stats[0]} non-inliers pass the filter ({100.0 * stats[1] / stats[0]:.3f} %)")
+    assert stats[1] < 0.05 * stats[0]
+    # above thr = 1 the form hands over to the fp32 one
+    assert not HM.prefilter16_abs(HM.pose_record(q, t), cols, 1.0000001 ** 2, 0.5)[0]
