@@ -213,7 +213,8 @@ int pl_score_model(pl_problem *p, const void *model, double max_error, uint64_t 
  * column-major for kinds 2/3 - through the STREAMING scorer of the batched main loop, i.e. through the conservative
  * pre-filters (fp16/MFMA or fp32) in front of the exact fp64 evaluation, instead of the sequential scorer behind
  * pl_score_model.  counts / scores: n entries each (scores summed in tree order: equal to pl_score_model's to rounding,
- * counts exactly).  path_used: 2 = matrix-core filter (k_score_mfma), 1 = fp32 filter (k_score_queue), 0 = no filter
+ * counts exactly).  path_used: 2 = matrix-core filter (k_score_mfma: absolute pose; k_score_mfma2: Sampson scores on
+ * coordinates bounded by 8), 1 = fp32 filter (k_score_queue), 0 = no filter
  * (threshold / coordinates outside the filters' range, or POSELIB_AMD_NO_PREFILTER).  tests/ plants adversarial
  * models and correspondences here to check that a filter never drops an inlier. */
 int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double max_error, uint32_t *counts,
