@@ -274,7 +274,7 @@ def run_workload(name, args, ranks, P, synth, pool_factory, primary):
     elapsed = time.perf_counter() - t0
     # RANSAC seeds 0..7 of the first timed step: the ones the oracle runs below
     if grouped:
-        first = batches[0].results()[:PARITY_SEEDS]
+        first = batches[0].results(PARITY_SEEDS)
     else:
         first = [pool.submit(run_one, (probs[j % S], j)).result() for j in range(PARITY_SEEDS)] if first_streams is not None else None
     batches.clear()

@@ -357,9 +357,10 @@ class RansacBatch:
     def stats(self):
         return [k[4] for k in self.keep]
 
-    def results(self):
+    def results(self, first=None):
+        """what `Problem.run` returns, per item (`first`: only the first so many items)"""
         out = []
-        for pr, o, model, inl, st in self.keep:
+        for pr, o, model, inl, st in (self.keep if first is None else self.keep[:first]):
             if pr.kind in (KIND_ABS, KIND_REL):
                 out.append((_pypose(model), _info(st, inl[: pr.n])))
             else:
