@@ -250,13 +250,18 @@ double hm_score(int est, const double *rec, const double *const *pa, uint32_t n,
             flags[i] = in;
         if (r2_out)
             r2_out[i] = r2;
+        // the reference's summation orders (robust/utils.cc): the reprojection score adds the inliers' r^2 and the
+        // outliers' share in one product at the end (:57-63); the two-view scores add r^2 OR thr^2 correspondence by
+        // correspondence (:188-198, 230-235, 320-325) - k_score_seq does the same on the device
         if (in) {
             c++;
             s += r2;
+        } else if (est != EST_ABS) {
+            s += thr2;
         }
     }
     *count = c;
-    return s + (double)(n - c) * thr2;
+    return est == EST_ABS ? s + (double)(n - c) * thr2 : s;
 }
 
 void hm_matrix_record(const double *M9, double *rec) {

@@ -56,7 +56,7 @@ def test_p3p_and_reprojection_score_bit_exact():
                 sc, cnt, flags, r2 = HM.score("abs", r, cols, thr2)
                 osc, ocnt = O.score("reproj", o, un, d["p3d"], thr2)
                 assert cnt == ocnt
-                assert abs(sc - osc) <= 1e-12 * abs(osc)
+                assert sc == osc  # same summation order: the same bits
                 # final-mask arithmetic (division form) may differ from the scoring form only at the threshold
                 m = HM.mask_abs(r, cols, thr2)
                 assert (m == O.inliers("reproj", o, un, d["p3d"], thr2)).all()
@@ -81,7 +81,7 @@ def test_two_view_solvers_and_scores():
             if it < 40:
                 sc, cnt, _, _ = HM.score("fund", r, cols, thr2)
                 osc, ocnt = O.score("sampson_F", F, a, b, thr2)
-                assert cnt == ocnt and abs(sc - osc) <= 1e-12 * abs(osc)
+                assert cnt == ocnt and sc == osc  # (r^2 or thr^2 per correspondence, in order: the same bits)
     # homography: bit exact
     idx, _, _ = HM.draw_samples(2, 2000, 4, 400)
     for it in range(400):
@@ -93,7 +93,7 @@ def test_two_view_solvers_and_scores():
             assert (recs[0][7:16].reshape(3, 3) == H).all()
             sc, cnt, _, _ = HM.score("hom", recs[0], cols, thr2)
             osc, ocnt = O.score("homography", H, a, b, thr2)
-            assert cnt == ocnt and abs(sc - osc) <= 1e-12 * abs(osc)
+            assert cnt == ocnt and sc == osc
     # 5-point: the constraint polynomials are accumulated in the oracle's association order (pl_solver_rel.h
     # mac_lin_lin / mac_quad_lin), everything downstream is the same sequence of operations: bit-identical poses
     idx, _, _ = HM.draw_samples(0, 2000, 5, 600)
@@ -111,7 +111,7 @@ def test_two_view_solvers_and_scores():
     rec = HM.pose_record(pose[:4], pose[4:], True)
     sc, cnt, flags, _ = HM.score("rel", rec, cols, thr2)
     osc, ocnt = O.score("sampson_pose", pose, a, b, thr2)
-    assert cnt == ocnt and abs(sc - osc) <= 1e-12 * abs(osc)
+    assert cnt == ocnt and sc == osc
     assert (flags == O.inliers("sampson_pose", pose, a, b, thr2)).all()
 
 
