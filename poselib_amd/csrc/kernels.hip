@@ -8,20 +8,26 @@
 //                         solve entirely in registers (P3P / 5-pt / 7-pt / 4-pt H), model records (192 B incl. fp32
 //                         shadow) written to HBM.  (reference: estimators/*::generate_models)
 //   k_score_mfma<PG>      THE hot kernel (absolute pose): streaming scorer of the batched main loop - conservative
-//                         pre-filter with R X + t on the matrix cores (v_mfma_f32_32x32x8_f16, fp16 hi/lo operands,
-//                         8 hypotheses x 32 points per tile), survivors queued in LDS and evaluated exactly in fp64 by
-//                         full wavefronts.  (reference: utils.cc compute_msac_score)
-//   k_score_queue<EST,P>  the same with an fp32 pre-filter on the vector ALU: Sampson and homography scores, and the
-//                         absolute-pose fallback (small N, out-of-range thresholds).
+//                         pre-filter on the matrix cores: the four half-planes of the reprojection test as linear forms
+//                         of fp16 hi/lo operands (v_mfma_f32_32x32x16_f16, 16 hypotheses x 32 correspondences per pair
+//                         of instructions), survivors queued in LDS and evaluated exactly in fp64 by full wavefronts.
+//                         (reference: utils.cc compute_msac_score)
+//   k_score_mfma2<EST,PG> the same for the Sampson scores (relative pose, fundamental matrix) on coordinates bounded by
+//                         8: the bilinear form b'Fa and the quadratic forms Cx + Cy out of the matrix pipe.
+//   k_score_queue<EST,P>  the same with an fp32 pre-filter on the vector ALU: homography score, and the fallback of the
+//                         others (small N, thresholds / coordinates outside the matrix-core forms' range).
 //   k_score_seq<EST>      the MSAC score in the reference's summation order for every model a decision is taken on
 //                         (candidates of the record scan, refined / initial models): one workgroup per model.
 //   k_lm<EST>             Levenberg-Marquardt refinement, ONE workgroup (8 wavefronts) per task, the whole LM loop on
-//                         device; k_lm2<EST>: the same spread over several workgroups per task, one launch per LM
-//                         iteration (default for large two-view LO).  (reference: bundle.cc + optim/lm_impl.h + optim/*.h)
+//                         device (up to 256 correspondences: sums in the reference's order); k_lm2<EST>: the same spread
+//                         over several workgroups per task, one launch per LM iteration (opt-in).
+//                         (reference: bundle.cc + optim/lm_impl.h + optim/*.h)
+//   k_*_g                 group forms of the batch kernels: the same bodies, problem index = blockIdx.z, arguments from
+//                         a device table (pl_estimate_batch / pl_ransac_batch, driver_group.inc).
 //   k_mask<EST>           final inlier mask (reference: utils.cc get_inliers*).
 //   k_solve_batch<EST>    the bare minimal solvers, one lane per problem.
-// Exact arithmetic (fp64, reference association order) never runs on the matrix cores; only the filter's projection
-// products do.
+// Exact arithmetic (fp64, reference association order) never runs on the matrix cores; only the filters' linear and
+// quadratic forms do.
 #include "pl_kernels.h"
 #include <atomic>
 #include "pl_prefilter.h"
