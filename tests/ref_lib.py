@@ -15,20 +15,24 @@ import oracle_lib as O
 
 _ORACLE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
 _REF_LIB = os.path.join(_ORACLE_DIR, "_ref", "libposelib_ref.so")
+_REF_LIB_FMA = os.path.join(_ORACLE_DIR, "_ref", "fma", "libposelib_ref.so")
 REFERENCE_ROOT = "/root/reference"
 
 
-def build() -> str:
-    """(Re)build where the reference sources exist; elsewhere (the GPU box) use the prebuilt file if it travelled."""
+def build(variant: str = "") -> str:
+    """(Re)build where the reference sources exist; elsewhere (the GPU box) use the prebuilt file if it travelled.
+    variant "": the reference's Release flags (-O3, SSE2, no contraction); "fma": its MARCH_NATIVE option restated
+    portably (-O3 -march=x86-64-v3) - the second build of the reference-against-itself measurements."""
     O.build()
     if os.path.isdir(os.path.join(REFERENCE_ROOT, "PoseLib")):
-        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "-j8", "-f", "Makefile.ref", f"REF={REFERENCE_ROOT}"])
-    return _REF_LIB
+        cmd = ["make", "-C", _ORACLE_DIR, "-s", "-j8", "-f", "Makefile.ref", f"REF={REFERENCE_ROOT}"]
+        subprocess.check_call(cmd + ([f"VARIANT={variant}"] if variant else []))
+    return _REF_LIB_FMA if variant == "fma" else _REF_LIB
 
 
-def available() -> bool:
+def available(variant: str = "") -> bool:
     try:
-        return os.path.exists(build())
+        return os.path.exists(build(variant))
     except (subprocess.CalledProcessError, OSError):
         return False
 
@@ -42,13 +46,13 @@ class _Proxy:
         return getattr(self._cdll, "ref_" + name[4:])
 
 
-_proxy = None
+_proxies = {}
 
 
-def _load():
-    global _proxy
+def _load(variant: str = ""):
+    _proxy = _proxies.get(variant)
     if _proxy is None:
-        cdll = C.CDLL(build())
+        cdll = C.CDLL(build(variant))
         cdll.ref_all_inlier_probability.restype = C.c_double
         cdll.ref_all_inlier_probability.argtypes = [C.c_uint64] * 3
         cdll.ref_dynamic_max_iter.restype = C.c_uint64
@@ -58,14 +62,14 @@ def _load():
             getattr(cdll, name).restype = C.c_double
         cdll.ref_solve_cubic_single_real.argtypes = [C.c_double] * 3 + [C.c_void_p]
         cdll.ref_solve_cubic_real.argtypes = [C.c_double] * 3 + [C.c_void_p]
-        _proxy = _Proxy(cdll)
+        _proxy = _proxies[variant] = _Proxy(cdll)
     return _proxy
 
 
 @contextlib.contextmanager
-def reference():
+def reference(variant: str = ""):
     O.lib()
-    saved, O._lib = O._lib, _load()
+    saved, O._lib = O._lib, _load(variant)
     try:
         yield O
     finally:

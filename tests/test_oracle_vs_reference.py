@@ -256,22 +256,30 @@ def test_normalize_points():
             assert np.allclose(p, q, rtol=1e-13, atol=1e-13)
 
 
-def _unit_t(m):
-    """relative pose: |t| is a gauge freedom (the LM steps t along its tangent plane without renormalising, so one
-    more or fewer accepted step changes |t| at 1e-7 without moving the direction); compare directions"""
-    m = np.array(m, dtype=np.float64)
-    m[4:] /= np.linalg.norm(m[4:])
-    return m
+def _rel_parts(a, b):
+    """relative pose, component by component: dR, d(t/|t|) and d|t|.  |t| is a gauge freedom (the reference's LM steps t
+    along its tangent plane without renormalising, optim/relative.h:94-152): the reference does not reproduce it
+    across its own builds (tests/golden/make_gauge.py), so it gets its own, wider bound - stated, not hidden."""
+    from golden.make_gauge import parts
+
+    return parts(a, b)
+
+
+REL_DT_LEN_BOUND = 10.0 * __import__("json").load(open(__import__("os").path.join(
+    __import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "relpose_gauge_v1.json")))["measured"]["max_dt_len"]
 
 
 def _cmp_run(fn, a, b, opt, tol=1e-8):
     (ma, ka, sa), (mb, kb, sb) = both(fn, a, b, opt)
-    if fn == "ransac_relpose":
-        ma, mb = _unit_t(ma), _unit_t(mb)
     for k in ("iterations", "refinements", "num_inliers"):
         assert sa[k] == sb[k], (k, sa, sb)
     assert np.array_equal(ka, kb)
     assert sa["model_score"] == pytest.approx(sb["model_score"], rel=1e-9)
+    if fn == "ransac_relpose":
+        p = _rel_parts(ma, mb)
+        assert p["dR"] < tol and p["dt_dir"] < tol, p
+        assert p["dt_len"] <= REL_DT_LEN_BOUND, p
+        return sa
     sc = max(1.0, np.abs(ma).max())
     assert np.abs(ma - mb).max() / sc < tol
     return sa
@@ -340,14 +348,17 @@ def test_unproject(model):
 
 def _cmp_frontend(fn, args, opt, tol=1e-8):
     (ma, ka, sa), (mb, kb, sb) = both(fn, *args, opt)
-    if fn == "estimate_relative_pose":
-        ma, mb = _unit_t(ma), _unit_t(mb)
     for k in ("iterations", "refinements", "num_inliers"):
         assert sa[k] == sb[k], (k, sa, sb)
     assert np.array_equal(ka, kb)
     assert sa["inlier_ratio"] == sb["inlier_ratio"]
     assert sa["model_score"] == pytest.approx(sb["model_score"], rel=1e-9)
-    assert np.abs(ma - mb).max() / max(1.0, np.abs(ma).max()) < tol
+    if fn == "estimate_relative_pose":
+        p = _rel_parts(ma, mb)
+        assert p["dR"] < tol and p["dt_dir"] < tol, p
+        assert p["dt_len"] <= REL_DT_LEN_BOUND, p
+    else:
+        assert np.abs(ma - mb).max() / max(1.0, np.abs(ma).max()) < tol
     return sa, bool(np.array_equal(ma, mb))
 
 
