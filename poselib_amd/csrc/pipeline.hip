@@ -734,35 +734,44 @@ __global__ __launch_bounds__(256) void k_sampson16(BatchCtl *ctl, const uint32_t
     sampson16_one(k, H, cap, slots, models, out);
 }
 
-__global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, uint32_t gather_blocks_max) {
+// Group form.  The grid is NOT sized by the record capacity (B x slots per iteration: 1.6 M slots for a 100 k-iteration
+// 5-point batch of which ~60 k hold a hypothesis - a capacity-sized grid was ~80 k empty workgroups per problem, whose
+// dispatch alone cost 8 % of the grouped 5-point step): a bounded number of workgroups per problem strides over the
+// hypotheses the device-side count names.  blockIdx.x < gather_blocks: record copies of the problems on the fp32 / exact
+// scorers; above: fp16 operand blocks of the problems on the matrix-core scorers.
+__global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, uint32_t gather_blocks) {
     const GroupArgs &g = ga[blockIdx.z];
     if (!g.active)
         return;
     const uint64_t cap = (uint64_t)g.comp.B * (uint64_t)g.comp.maxm;
-    if (blockIdx.x < gather_blocks_max) {
-        const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-        if (!g.comp.s16.out && t < cap * 12u) // (the matrix-core scorer reads the records themselves)
+    const uint32_t H = g.comp.ctl->num_hyp;
+    if (blockIdx.x < gather_blocks) {
+        if (g.comp.s16.out) // (the matrix-core scorer reads the records themselves)
+            return;
+        const uint64_t end = std::min<uint64_t>(cap, H) * 12u;
+        for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < end; t += (uint64_t)gather_blocks * 256)
             gather_one(g.comp.ctl, g.comp.slots, g.comp.models, g.comp.shadow, g.comp.compact64, t);
         return;
     }
     if (!g.comp.s16.out)
         return;
-    const uint32_t k = (blockIdx.x - gather_blocks_max) * 256 + threadIdx.x;
+    const uint32_t nb = gridDim.x - gather_blocks;
+    const uint32_t k0 = (blockIdx.x - gather_blocks) * 256 + threadIdx.x;
     if (g.comp.s16.sampson) {
-        const uint32_t H = g.comp.ctl->num_hyp;
         const uint32_t capp = (uint32_t)std::min<uint64_t>(cap + kSampson16Pad, 0xffffff00ull);
-        if (k < min(capp, H + (uint32_t)kSampson16Pad))
+        const uint32_t end = min(capp, H + (uint32_t)kSampson16Pad);
+        for (uint32_t k = k0; k < end; k += nb * 256)
             sampson16_one(k, H, capp, g.comp.slots, g.comp.models, static_cast<uint4 *>(g.comp.s16.out));
         return;
     }
-    const uint32_t cap16 = (uint32_t)((cap + 15u) & ~15ull);
-    if (k >= cap16)
-        return;
+    // (shadow16_one fills the last group of 16 up and ignores everything behind it)
+    const uint32_t end = (uint32_t)std::min<uint64_t>((cap + 15u) & ~15ull, ((uint64_t)H + 15u) & ~15ull);
     const uint32_t *slots = g.comp.slots;
     const double *models = g.comp.models;
-    shadow16_one(k, g.comp.ctl->num_hyp,
-                 [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
-                 g.comp.s16.g16, g.comp.s16.c16, g.comp.s16.thr, static_cast<uint4 *>(g.comp.s16.out));
+    for (uint32_t k = k0; k < end; k += nb * 256)
+        shadow16_one(k, H,
+                     [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
+                     g.comp.s16.g16, g.comp.s16.c16, g.comp.s16.thr, static_cast<uint4 *>(g.comp.s16.out));
 }
 
 // ------------------------------------------------------------------------------------ front-end pre-processing
@@ -989,9 +998,11 @@ hipError_t launch_group_positions(int K, const GroupArgs *args, const GroupDims 
 }
 hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
     k_compact2_g<<<dim3((d.max_B + 1023) / 1024, 1, d.G), dim3(1024), 0, stream>>>(args);
-    const uint32_t gblocks = (uint32_t)(((uint64_t)d.max_hcap * 12u + 255) / 256);
-    const uint32_t sblocks = d.any_mfma ? (((d.max_hcap + 15u) & ~15u) + (uint32_t)kSampson16Pad + 255) / 256 : 0u;
-    k_gather_shadow16_g<<<dim3(gblocks + sblocks, 1, d.G), dim3(256), 0, stream>>>(args, gblocks);
+    // bounded grids (see k_gather_shadow16_g): at most 1024 + 512 workgroups per problem, none where nobody needs them
+    const uint32_t gblocks = d.any_queue ? (uint32_t)std::min<uint64_t>(((uint64_t)d.max_hcap * 12u + 255) / 256, 1024u) : 0u;
+    const uint32_t sblocks = d.any_mfma ? std::min<uint32_t>((((d.max_hcap + 15u) & ~15u) + (uint32_t)kSampson16Pad + 255) / 256, 512u) : 0u;
+    if (gblocks + sblocks)
+        k_gather_shadow16_g<<<dim3(gblocks + sblocks, 1, d.G), dim3(256), 0, stream>>>(args, gblocks);
     return hipGetLastError();
 }
 hipError_t launch_group_finalize_records(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
