@@ -29,6 +29,7 @@
 // Exact arithmetic (fp64, reference association order) never runs on the matrix cores; only the filters' linear and
 // quadratic forms do.
 #include "pl_kernels.h"
+#include "pl_device.h"
 #include <atomic>
 #include "pl_prefilter.h"
 #include <cstdlib>
@@ -92,35 +93,7 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
     v += dpp_shift_u32<0x143, 0xc>(v); // row_bcast:31 -> rows 2, 3
     return v;
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // ------------------------------------------------------------------------------------ generate
-// Models per block of 1024 iterations (the first level of k_compact2's scan), accumulated by the generators themselves:
-// one integer atomic per wavefront into a table the batch's control-block memset has zeroed.
-// (n_nan: models with a NaN entry - statistics only, pl_ransac_stats.nan_hypotheses - go into a second table of the
-// same shape; the atomics are spread over the blocks' table entries, one hot counter would serialise them)
-__device__ __forceinline__ void count_models_of_wave(const GenerateArgs &g, uint32_t it, uint32_t n, uint32_t n_nan) {
-    if (!g.blk_tot)
-        return;
-    const uint32_t s = wave_sum_u32(n);
-    if ((threadIdx.x & 63) == 0 && s)
-        atomicAdd(&g.blk_tot[it >> 10], s);
-    if (g.blk_nan && __builtin_amdgcn_ballot_w64(n_nan != 0u)) {
-        const uint32_t sn = wave_sum_u32(n_nan);
-        if ((threadIdx.x & 63) == 0)
-            atomicAdd(&g.blk_nan[it >> 10], sn);
-    }
-}
-// NaN flag of a record that has been written (pl_math.h store_shadow)
-__device__ __forceinline__ uint32_t record_is_nan(const double *rec) {
-    return reinterpret_cast<const uint32_t *>(rec + kShadowOff)[13] != 0u ? 1u : 0u;
-}
-
 template <int EST> __device__ __forceinline__ uint32_t generate_one(const GenerateArgs &g, uint32_t it, uint32_t &n_nan) {
     constexpr int K = sample_size(EST);
     constexpr int MAXM = max_models(EST);
@@ -191,201 +164,6 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate_g(const Grou
     uint32_t n_nan = 0;
     const uint32_t n = (it < g.num_iters) ? generate_one<EST>(g, it, n_nan) : 0u;
     count_models_of_wave(g, it, n, n_nan);
-}
-
-// ---- 5-point generator in three stages (relative pose) -------------------------------------------------------------
-// One lane per iteration in every stage; the stages hand their results over in a structure-of-arrays workspace
-// (rel_stage: [field][iteration], coalesced), so that no kernel carries the live state of another: the 10 x 20
-// elimination of the front end, the Sturm chain of the root finder and the pose recovery each get the register file
-// to themselves.  The root finder keeps its per-level notes in LDS (one column per lane).
-constexpr int kRelNb = 36, kRelAz = 39, kRelRoots = 10, kRelLeaves = 2 * kSturmSlots;
-__host__ __device__ inline size_t rel_stage_doubles(size_t cap) {
-    return (size_t)(kRelNb + kRelAz + kRelRoots + kRelLeaves) * cap;
-}
-
-template <int K> __device__ __forceinline__ void sample_of_iteration(const GenerateArgs &g, uint32_t it, uint32_t *idx) {
-    if (g.samples) {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            idx[k] = g.samples[(size_t)it * K + k];
-    } else {
-        draw_sample<K>(g.seed, g.pos_base + g.positions[it], g.pts.n, idx);
-    }
-}
-
-#ifndef PL_FRONT_ATTR
-#define PL_FRONT_ATTR
-#endif
-__device__ __forceinline__ void rel_front_body(const GenerateArgs &g, double *stage, uint32_t cap) {
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
-    if (it >= g.num_iters)
-        return;
-    uint32_t idx[5];
-    sample_of_iteration<5>(g, it, idx);
-    Vec3 b1[5], b2[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        b1[k] = bearing(g.pts.a[0][idx[k]], g.pts.a[1][idx[k]]);
-        b2[k] = bearing(g.pts.a[2][idx[k]], g.pts.a[3][idx[k]]);
-    }
-    double nb[36], Az[3][13];
-    rel5_front(b1, b2, nb, Az);
-    double *snb = stage, *saz = stage + (size_t)kRelNb * cap;
-#pragma unroll
-    for (int e = 0; e < 36; ++e)
-        snb[(size_t)e * cap + it] = nb[e];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 13; ++k)
-            saz[(size_t)(i * 13 + k) * cap + it] = Az[i][k];
-}
-__global__ __launch_bounds__(64) PL_FRONT_ATTR void k_rel_front(GenerateArgs g, double *stage, uint32_t cap) { rel_front_body(g, stage, cap); }
-__global__ __launch_bounds__(64) PL_FRONT_ATTR void k_rel_front_g(const GroupArgs *ga) {
-    const GroupArgs &gg = ga[blockIdx.z];
-    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
-        return;
-    rel_front_body(gg.gen, static_cast<double *>(gg.gen.stage), gg.gen.num_iters);
-}
-
-struct SturmWorkDev { // deferred halves: one column per lane of [slot][64] LDS arrays; leaves: the workspace
-    double *sa, *sb;  // LDS
-    unsigned *si;     // LDS
-    double *leaves;   // global, [2 * slot + {0, 1}][cap], this iteration's column
-    size_t cap;
-    __device__ void push(int i, double a, double b, unsigned info) { sa[i * 64] = a, sb[i * 64] = b, si[i * 64] = info; }
-    __device__ void pop(int i, double &a, double &b, unsigned &info) const { a = sa[i * 64], b = sb[i * 64], info = si[i * 64]; }
-    __device__ void leaf_set(int i, double a, double b) { leaves[(size_t)(2 * i) * cap] = a, leaves[(size_t)(2 * i + 1) * cap] = b; }
-    __device__ void leaf_get(int i, double &a, double &b) const { a = leaves[(size_t)(2 * i) * cap], b = leaves[(size_t)(2 * i + 1) * cap]; }
-};
-
-__device__ __forceinline__ void rel_roots_body(uint32_t num_iters, double *stage, uint32_t cap, uint32_t *nroots_out) {
-    __shared__ double s_stack_a[kSturmSlots][64], s_stack_b[kSturmSlots][64];
-    __shared__ unsigned s_stack_i[kSturmSlots][64];
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
-    if (it >= num_iters)
-        return;
-    const double *saz = stage + (size_t)kRelNb * cap;
-    double Az[3][13];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 13; ++k)
-            Az[i][k] = saz[(size_t)(i * 13 + k) * cap + it];
-    double c[11];
-    rel5_poly(Az, c);
-    double roots[10];
-    SturmWorkDev work{&s_stack_a[0][threadIdx.x], &s_stack_b[0][threadIdx.x], &s_stack_i[0][threadIdx.x],
-                      stage + (size_t)(kRelNb + kRelAz + kRelRoots) * cap + it, cap};
-    const int n = sturm_roots_deg10(c, roots, work);
-    double *sroots = stage + (size_t)(kRelNb + kRelAz) * cap;
-#pragma unroll
-    for (int r = 0; r < 10; ++r)
-        if (r < n)
-            sroots[(size_t)r * cap + it] = roots[r];
-    nroots_out[it] = (uint32_t)n;
-}
-__global__ __launch_bounds__(64) void k_rel_roots(uint32_t num_iters, double *stage, uint32_t cap, uint32_t *nroots_out) {
-    rel_roots_body(num_iters, stage, cap, nroots_out);
-}
-__global__ __launch_bounds__(64) void k_rel_roots_g(const GroupArgs *ga) {
-    const GroupArgs &gg = ga[blockIdx.z];
-    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
-        return;
-    double *stage = static_cast<double *>(gg.gen.stage);
-    rel_roots_body(gg.gen.num_iters, stage, gg.gen.num_iters,
-                   reinterpret_cast<uint32_t *>(stage + rel_stage_doubles(gg.gen.num_iters)));
-}
-
-__device__ __forceinline__ uint32_t rel_poses_one(const GenerateArgs &g, const double *stage, uint32_t cap, const uint32_t *nroots_in,
-                                                  uint32_t it, uint32_t &n_nan) {
-    uint32_t idx[5];
-    sample_of_iteration<5>(g, it, idx);
-    Vec3 b1[5], b2[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        b1[k] = bearing(g.pts.a[0][idx[k]], g.pts.a[1][idx[k]]);
-        b2[k] = bearing(g.pts.a[2][idx[k]], g.pts.a[3][idx[k]]);
-    }
-    const double *snb = stage, *saz = stage + (size_t)kRelNb * cap, *sroots = stage + (size_t)(kRelNb + kRelAz) * cap;
-    double nb[36], Az[3][13];
-#pragma unroll
-    for (int e = 0; e < 36; ++e)
-        nb[e] = snb[(size_t)e * cap + it];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 13; ++k)
-            Az[i][k] = saz[(size_t)(i * 13 + k) * cap + it];
-    const int ne = (int)nroots_in[it];
-    double *rec = g.models + (size_t)it * g.slots_per_iter * kModelStride;
-    const int max_out = (int)g.slots_per_iter;
-    int n = 0;
-    for (int s = 0; s < ne; ++s) { // relpose_5pt_records, root by root
-        Mat3 E;
-        rel5_essential_at_root(nb, Az, sroots[(size_t)s * cap + it], E);
-        PoseQT cand[4];
-        const int nc = motion_from_essential<5>(E, b1, b2, cand);
-        for (int k = 0; k < nc; ++k) {
-            if (n < max_out)
-                n_nan += store_pose_model_q(rec + n * kModelStride, cand[k].q, cand[k].t, true) ? 1u : 0u;
-            ++n;
-        }
-    }
-    if (n > max_out) {
-        g.ctl->gen_overflow = 1;
-        n = 0;
-        n_nan = 0;
-    }
-    g.num_models[it] = (uint32_t)n;
-    return (uint32_t)n;
-}
-// Lane assignment of the pose stage: the work of an iteration is proportional to its number of real roots (0, 2, 4, ...,
-// 10; 4.2 on average, but the maximum over 64 neighbouring iterations is 6.8), so the 256 iterations of a workgroup are
-// bucketed by root count in LDS and every lane takes the iteration at its position of the sorted list: the lanes of a
-// wavefront then loop over the same number of roots.  Which lane works on which iteration has no influence on any result
-// (records, counts and flags are addressed by iteration; the per-1024 block totals are sums).
-constexpr int kPosesThreads = 256;
-__device__ __forceinline__ uint32_t rel_poses_sorted_iteration(const uint32_t *nroots_in, uint32_t num_iters) {
-    __shared__ uint32_t s_cnt[12];
-    __shared__ uint16_t s_perm[kPosesThreads];
-    const uint32_t it0 = blockIdx.x * kPosesThreads, tid = threadIdx.x;
-    const uint32_t it = it0 + tid;
-    const uint32_t ne = it < num_iters ? min(nroots_in[it], 10u) : 11u; // 11: not an iteration (sorted to the end)
-    if (tid < 12)
-        s_cnt[tid] = 0;
-    __syncthreads();
-    const uint32_t rank = atomicAdd(&s_cnt[ne], 1u);
-    __syncthreads();
-    uint32_t base = 0; // iterations with more roots first
-    for (uint32_t k = 0; k < 12; ++k) {
-        const uint32_t key = (k == 11) ? 11u : 10u - k; // order of the buckets: 10, 9, ..., 0, then the padding
-        if (key == ne)
-            break;
-        base += s_cnt[key];
-    }
-    s_perm[base + rank] = (uint16_t)tid;
-    __syncthreads();
-    return it0 + s_perm[tid];
-}
-__global__ __launch_bounds__(kPosesThreads) void k_rel_poses(GenerateArgs g, const double *stage, uint32_t cap,
-                                                              const uint32_t *nroots_in) {
-    const uint32_t it = rel_poses_sorted_iteration(nroots_in, g.num_iters);
-    uint32_t n_nan = 0;
-    const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, cap, nroots_in, it, n_nan) : 0u;
-    count_models_of_wave(g, blockIdx.x * kPosesThreads, n, n_nan);
-}
-__global__ __launch_bounds__(kPosesThreads) void k_rel_poses_g(const GroupArgs *ga) {
-    const GroupArgs &gg = ga[blockIdx.z];
-    if (!gg.active || blockIdx.x * (uint32_t)kPosesThreads >= gg.gen.num_iters)
-        return;
-    const GenerateArgs &g = gg.gen;
-    const double *stage = static_cast<const double *>(g.stage);
-    const uint32_t *nroots_in = reinterpret_cast<const uint32_t *>(stage + rel_stage_doubles(g.num_iters));
-    const uint32_t it = rel_poses_sorted_iteration(nroots_in, g.num_iters);
-    uint32_t n_nan = 0;
-    const uint32_t n = (it < g.num_iters) ? rel_poses_one(g, stage, g.num_iters, nroots_in, it, n_nan) : 0u;
-    count_models_of_wave(g, blockIdx.x * kPosesThreads, n, n_nan);
 }
 
 // Bare solver batch: one lane per minimal problem, AoS input exactly as the reference API takes it.
@@ -2121,21 +1899,13 @@ __global__ __launch_bounds__(kLM2Threads) void k_lm2(PointSet pts, LMTask *tasks
         return hipErrorInvalidValue;                                                                                   \
     }
 
-size_t generate_stage_bytes(int est, uint32_t num_iters) {
-    return est == EST_REL ? sizeof(double) * rel_stage_doubles(num_iters) + sizeof(uint32_t) * (size_t)num_iters : 0;
-}
+size_t generate_stage_bytes(int est, uint32_t num_iters) { return est == EST_REL ? rel_stage_bytes(num_iters) : 0; }
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream) {
     if (a.num_iters == 0)
         return hipSuccess;
     const dim3 grid((a.num_iters + 63) / 64), block(64);
-    if (est == EST_REL && a.stage) { // three stages over a structure-of-arrays workspace
-        double *stage = static_cast<double *>(a.stage);
-        uint32_t *nroots = reinterpret_cast<uint32_t *>(stage + rel_stage_doubles(a.num_iters));
-        k_rel_front<<<grid, block, 0, stream>>>(a, stage, a.num_iters);
-        k_rel_roots<<<grid, block, 0, stream>>>(a.num_iters, stage, a.num_iters, nroots);
-        k_rel_poses<<<dim3((a.num_iters + kPosesThreads - 1) / kPosesThreads), dim3(kPosesThreads), 0, stream>>>(a, stage, a.num_iters, nroots);
-        return hipGetLastError();
-    }
+    if (est == EST_REL && a.stage) // four stages over a structure-of-arrays workspace (gen_rel.hip)
+        return launch_generate_rel(a, stream);
     PL_DISPATCH_EST(est, k_generate<E><<<grid, block, 0, stream>>>(a));
     return hipGetLastError();
 }
@@ -2441,9 +2211,9 @@ hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &d
         return e;
     const dim3 ggrid((d.max_B + 63) / 64, 1, d.G), gblock(64);
     if (est == EST_REL) {
-        k_rel_front_g<<<ggrid, gblock, 0, stream>>>(args);
-        k_rel_roots_g<<<ggrid, gblock, 0, stream>>>(args);
-        k_rel_poses_g<<<dim3((d.max_B + kPosesThreads - 1) / kPosesThreads, 1, d.G), dim3(kPosesThreads), 0, stream>>>(args);
+        e = launch_group_generate_rel(args, d.max_B, d.G, stream);
+        if (e != hipSuccess)
+            return e;
     } else {
         PL_DISPATCH_EST(est, k_generate_g<E><<<ggrid, gblock, 0, stream>>>(args));
     }

