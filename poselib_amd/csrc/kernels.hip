@@ -1963,7 +1963,8 @@ static void score_shape(int est, uint32_t n, bool streaming, bool mfma, uint32_t
             chunks = 1;
         return;
     }
-    const uint32_t per_chunk_max = lanes * (uint32_t)pmax;
+    // (absolute pose on the matrix-core form: at most 10 groups of 32 correspondences per chunk, see launch_score_est)
+    const uint32_t per_chunk_max = lanes * (uint32_t)((streaming && mfma && est == EST_ABS) ? std::min(pmax, 5) : pmax);
     chunks = (n + per_chunk_max - 1) / per_chunk_max;
     if (chunks == 0)
         chunks = 1;
@@ -2040,8 +2041,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
                 PL_M_CASE(3)
                 PL_M_CASE(4)
                 PL_M_CASE(5)
-                PL_M_CASE(6)
-            default:
+            default: // (PG = 12 does not fit three workgroups into a CU's LDS - 4 instead of 6 wavefronts per SIMD: not built)
                 return hipErrorInvalidValue;
             }
 #undef PL_M_CASE
