@@ -2666,9 +2666,14 @@ void run_group_job(std::vector<GroupItem> &items) {
             group_prepare_item(g);
         rc = run_group(c, items.data(), (uint32_t)items.size());
     }
+    if (rc != PL_OK)
+        note_worker_error(); // (the items are retried one by one below; the reason is kept for the caller)
     for (GroupItem &g : items) {
-        if (rc != PL_OK || g.fallback)
+        if (rc != PL_OK || g.fallback) {
             g.item->status = run_item(*g.item);
+            if (g.item->status != PL_OK)
+                note_worker_error();
+        }
     }
 }
 } // namespace
@@ -2686,6 +2691,8 @@ int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int 
     const size_t gsz = (size_t)(group_size <= 0 ? 16 : std::min<int>(group_size, (int)kGroupMax));
     auto run_solo = [](pl_ransac_item &it) {
         it.status = pl_ransac_run(it.problem, it.opt, it.model, it.inliers, it.stats);
+        if (it.status != PL_OK)
+            note_worker_error();
     };
     std::vector<size_t> by_kind[4], solo;
     for (size_t i = 0; i < count; ++i) {
@@ -2719,6 +2726,8 @@ int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int 
                     group_prepare_resident(g);
                 r = run_group(cc, grp.data(), (uint32_t)grp.size(), true);
             }
+            if (r != PL_OK)
+                note_worker_error();
             for (GroupItem &g : grp)
                 if (r != PL_OK || g.fallback)
                     run_solo(*g.ritem);
@@ -2727,10 +2736,13 @@ int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int 
         jobs.emplace_back([items, i, run_solo] { run_solo(items[i]); });
     int w = max_in_flight <= 0 ? 4 : std::min(max_in_flight, 64);
     w = (int)std::min<size_t>((size_t)w, jobs.size());
+    (void)take_worker_error();
+    g_group_workers.store(std::max(w, 1));
     batch_pool_instance().run(jobs, w, g_requested_device);
+    const std::string werr = take_worker_error();
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
-            return fail(items[i].status, ("pl_ransac_batch: item " + std::to_string(i) + " failed").c_str());
+            return fail(items[i].status, ("pl_ransac_batch: item " + std::to_string(i) + " failed" + (werr.empty() ? "" : ": " + werr)).c_str());
     return PL_OK;
 }
 
@@ -2772,13 +2784,20 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     for (auto &grp : groups) // (the long jobs first)
         jobs.emplace_back([&grp] { run_group_job(grp); });
     for (size_t i : solo)
-        jobs.emplace_back([items, i] { items[i].status = run_item(items[i]); });
+        jobs.emplace_back([items, i] {
+            items[i].status = run_item(items[i]);
+            if (items[i].status != PL_OK)
+                note_worker_error();
+        });
     int w = max_in_flight <= 0 ? 8 : std::min(max_in_flight, 64);
     w = (int)std::min<size_t>((size_t)w, jobs.size());
+    (void)take_worker_error();
+    g_group_workers.store(std::max(w, 1));
     batch_pool_instance().run(jobs, w, g_requested_device);
+    const std::string werr = take_worker_error();
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
-            return fail(items[i].status, ("pl_estimate_batch: item " + std::to_string(i) + " failed").c_str());
+            return fail(items[i].status, ("pl_estimate_batch: item " + std::to_string(i) + " failed" + (werr.empty() ? "" : ": " + werr)).c_str());
     return PL_OK;
 }
 
