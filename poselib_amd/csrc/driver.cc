@@ -963,6 +963,12 @@ struct RansacRun {
                 s16.out = c->shadow16.p;
                 s16.g16 = sa.pf.g16, s16.c16 = sa.pf.c16, s16.thr = sa.pf.thr;
                 sa.shadow16 = c->shadow16.p;
+            } else if (on_mfma && kind == EST_HOM) { // homography: operands of k_score_mfmah (k_hom16)
+                HIP_TRY(c->shadow16.ensure((hcap + kHom16Pad) * kHom16Bytes));
+                s16.out = c->shadow16.p;
+                s16.sampson = 2;
+                s16.thr = sa.pf.h16;
+                sa.shadow16 = c->shadow16.p;
             } else if (on_mfma) { // two-view: operands of the Sampson forms (k_sampson16 / k_score_mfma2)
                 HIP_TRY(c->shadow16.ensure((hcap + kSampson16Pad) * kSampson16Bytes));
                 s16.out = c->shadow16.p;
@@ -1714,7 +1720,7 @@ int make_problem_prepared(Context *c, int kind, const double *a, const double *b
         // two-view: the coordinate bound that admits the matrix-core form of the Sampson filter (large problems only: the
         // O(N) host pass is not worth it below the size that form starts at)
         p->ps.xy_absmax = std::numeric_limits<float>::infinity();
-        if (!lm_only && (kind == EST_REL || kind == EST_FUND) && n >= 1024 && a && b)
+        if (!lm_only && n >= 1024 && a && b) // (relative pose, fundamental matrix, homography)
             p->ps.xy_absmax = host_two_view_absmax(pa, a, b, n);
         return PL_OK;
     }
@@ -2076,6 +2082,11 @@ int pl_debug_score_stream(pl_problem *p, const void *models, size_t n, double ma
         HIP_TRY(c->shadow16.ensure(((size_t)H + kAbs16Pad) * kAbs16Bytes));
         HIP_TRY(launch_shadow16(&d_ctl->num_hyp, c->shadow.as<float>(), H, sa.pf.g16, sa.pf.c16, sa.pf.thr,
                                 c->shadow16.p, c->stream));
+        sa.shadow16 = c->shadow16.p;
+        path = 2;
+    } else if (on_mfma && p->kind == EST_HOM) {
+        HIP_TRY(c->shadow16.ensure(((size_t)H + kHom16Pad) * kHom16Bytes));
+        HIP_TRY(launch_hom16(d_ctl, c->slots.as<uint32_t>(), c->models.as<double>(), H, sa.pf.h16, c->shadow16.p, c->stream));
         sa.shadow16 = c->shadow16.p;
         path = 2;
     } else if (on_mfma) {

@@ -1082,6 +1082,217 @@ template <int EST, int PG> __global__ __launch_bounds__(kMfmaThreads) void k_sco
                               a.thr2, a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
 }
 
+// ---- homography: the pre-filter on the matrix cores (round 3) ------------------------------------------------------------
+// k_score_mfmah<PG>: same contract, same queue and the same exact pass as k_score_queue<EST_HOM>, pass A out of the matrix
+// pipe: TWO chained v_mfma_f32_32x32x16_f16 (32 k slots: fp16 high / low splits of both factors) per 8 hypotheses x 32
+// correspondences deliver, for every pair, the four linear forms V_0 = h_0 - b_0 h_2, V_1 = h_1 - b_1 h_2, U = thr h_2 and
+// the slack S (rows 4 j + r of hypothesis j; operands and error budget: pl_prefilter.h "homography, fp16 / MFMA form";
+// hypothesis side built by k_hom16, correspondence side here, once per workgroup, into LDS).  The sign of h_2 is not fixed over an image, so the inlier region is a double cone and the
+// verdict is  max(|V_0|, |V_1|) > |U| + S:  four vector instructions per pair (v_max with |.| modifiers, v_add, v_sub,
+// v_alignbit into the per-lane bit field), against 84 per (hypothesis, 320 correspondences) of the fp32 form.
+// Accumulator layout: lane l = correspondence l % 32 of the group, register 4 q + r = row r of hypothesis 2 q + l / 32.
+template <int PG>
+__device__ __forceinline__ void score_mfmah_body(const PointSet &pts, const uint4 *__restrict__ hypop,
+                                                 const double *__restrict__ models, const uint32_t *__restrict__ slots,
+                                                 const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity,
+                                                 double thr2, const PrefilterArgs &pf, uint32_t *__restrict__ part_count,
+                                                 double *__restrict__ part_score, uint32_t slice, uint32_t chunk,
+                                                 uint32_t nslices) {
+    constexpr int kWaves = kMfmaThreads / 64;
+    constexpr int NPW = 32 * PG; // correspondences per chunk
+    __shared__ double s_pts[4][NPW];
+    __shared__ uint16_t s_queue[kWaves][kMfmaQueueCap]; // entries: hypothesis slot << 9 | correspondence of the chunk
+    __shared__ double s_acc_s[kWaves][64];
+    __shared__ uint32_t s_acc_c[kWaves][64];
+    __shared__ uint32_t s_next_unit;
+    __shared__ uint4 s_bop[PG][4][32]; // B operand: group, k block (8 slots each), column
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = lane & 31, half = lane >> 5;
+
+    uint32_t validbits = 0; // bit (PG - 1 - g): group g holds a real correspondence in this column
+#pragma unroll
+    for (int g = 0; g < PG; ++g)
+        validbits |= (chunk * NPW + g * 32 + col < pts.n) ? (1u << (PG - 1 - g)) : 0u;
+    // one thread per correspondence of the chunk: fp64 copy for the exact pass, fp16 operands for the filter
+    for (uint32_t j = threadIdx.x; j < (uint32_t)NPW; j += kMfmaThreads) {
+        const uint32_t i = chunk * NPW + j;
+        const bool valid = i < pts.n;
+        const uint32_t ic = valid ? i : 0u;
+        const double a0 = pts.a[0][ic], a1 = pts.a[1][ic], b0 = pts.a[2][ic], b1 = pts.a[3][ic];
+        s_pts[0][j] = a0, s_pts[1][j] = a1, s_pts[2][j] = b0, s_pts[3][j] = b1;
+        Hom16Point o;
+        pf16_hom_point(a0, a1, b0, b1, valid, pf.h16, o);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint16_t *h = o.k + 8 * b;
+            s_bop[j >> 5][b][j & 31] = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                                                  (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+        }
+    }
+    if (threadIdx.x == 0)
+        s_next_unit = 0;
+    __syncthreads(); // the only workgroup barrier
+
+    const uint32_t H = *as_uniform(num_hyp_ptr);
+    uint16_t *const queue = s_queue[wave];
+    double *const acc_s = s_acc_s[wave];
+    uint32_t *const acc_c = s_acc_c[wave];
+    const uint32_t waves_per_chunk = nslices * kWaves;
+    auto request_ticket = [&]() -> uint32_t { // per-lane value; lane 0 holds the workgroup's next unit
+        uint32_t t = 0;
+        if (lane == 0) {
+            const uint32_t k = atomicAdd(&s_next_unit, 1u);
+            t = slice * kWaves + (k % kWaves) + (k / kWaves) * waves_per_chunk;
+        }
+        return t;
+    };
+    uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)request_ticket());
+    uint32_t kb, gn;
+    while (unit_of_ticket(ticket, H, waves_per_chunk, kb, gn)) {
+        const uint32_t pending = request_ticket(); // the next unit's index travels while this one is evaluated
+        acc_s[lane] = 0.0;
+        acc_c[lane] = 0;
+        uint32_t qhead = 0, qtail = 0;
+
+        auto drain = [&](uint32_t n) { // k_score_queue's exact pass; the fp64 models straight from their records
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool act = (uint32_t)lane < n;
+            const uint32_t e = act ? (uint32_t)queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffu;
+            const uint32_t g = e >> 9, pi = act ? (e & 0x1ffu) : 0u;
+            double x[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                x[d] = s_pts[d][pi];
+            const double *Mp = models + (size_t)slots[kb + (act ? g : 0u)] * kModelStride;
+            double M[kModelDoubles];
+#pragma unroll
+            for (int i = 0; i < kModelDoubles; ++i)
+                M[i] = Mp[i];
+            double r2;
+            const bool in = eval_point<EST_HOM>(M, x, thr2, r2) && act;
+            double v = in ? r2 : 0.0;
+            uint32_t c = in ? 1u : 0u;
+            const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
+            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) { // one hypothesis: plain wave sum
+                const double tot = wave_sum_dpp(v);
+                if (lane == 0) {
+                    acc_s[g0] += tot;
+                    acc_c[g0] += (uint32_t)__popcll(inmask);
+                }
+            } else if (inmask) {
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double vv = __shfl_up(v, off, 64);
+                    const uint32_t cc = __shfl_up(c, off, 64);
+                    const uint32_t gg = __shfl_up(g, off, 64);
+                    if (lane >= off && gg == g) {
+                        v += vv;
+                        c += cc;
+                    }
+                }
+                const uint32_t gnext = __shfl_down(g, 1, 64);
+                const bool tail = act && ((uint32_t)lane + 1 == n || gnext != g);
+                if (tail && c) {
+                    acc_s[g] += v;
+                    acc_c[g] += c;
+                }
+            }
+            qhead += n;
+        };
+
+        const uint32_t ngroups8 = (gn + 7u) / 8u;
+        // lane l: row l % 32 of the group's k blocks l / 32 (first instruction) and 2 + l / 32 (second)
+        auto load_a = [&](uint32_t hg, uint4 (&A)[2]) {
+            const uint4 *grp = hypop + ((size_t)(kb >> 3) + hg) * 128;
+            A[0] = grp[32 * half + col];
+            A[1] = grp[64 + 32 * half + col];
+        };
+        uint4 Araw[2];
+        load_a(0, Araw);
+        for (uint32_t hg = 0; hg < ngroups8; ++hg) {
+            half8_t Aop[2];
+            __builtin_memcpy(&Aop[0], &Araw[0], 16);
+            __builtin_memcpy(&Aop[1], &Araw[1], 16);
+            if (hg + 1 < ngroups8) // next group's operands travel while this one is evaluated
+                load_a(hg + 1, Araw);
+            uint32_t out[4] = {0u, 0u, 0u, 0u}; // hypothesis 2 q + half: bit (PG - 1 - g) = point group g is a proven outlier
+            const float16_t kZero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+            for (int g = 0; g < PG; ++g) {
+                const uint4 b0raw = s_bop[g][half][col], b1raw = s_bop[g][2 + half][col];
+                half8_t Bop0, Bop1;
+                __builtin_memcpy(&Bop0, &b0raw, 16);
+                __builtin_memcpy(&Bop1, &b1raw, 16);
+                float16_t D = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[0], Bop0, kZero, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[1], Bop1, D, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // proven outlier <=> max(|V_0|, |V_1|) > |U| + S: the sign bit of the difference goes into the bit field
+                    // (v_med3_f32 |a|, |b|, 3e38 = the larger magnitude in ONE instruction - the forms stay below 2^20; fmaxf,
+                    // or a median with +inf that the compiler folds into it, canonicalises both inputs first: two more
+                    // instructions per pair.  No NaNs here: NaN models carry zero rows)
+                    const float t = __builtin_amdgcn_fmed3f(__builtin_fabsf(D[4 * q]), __builtin_fabsf(D[4 * q + 1]), 3.0e38f);
+                    const float d = (__builtin_fabsf(D[4 * q + 2]) + D[4 * q + 3]) - t;
+                    out[q] = __builtin_amdgcn_alignbit(out[q], __float_as_uint(d), 31);
+                }
+            }
+            // ---- expansion: four rounds, round q = hypothesis 2 q (lanes 0..31) and 2 q + 1 (lanes 32..63) ----
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t slot = hg * 8u + 2u * (uint32_t)q + (uint32_t)half; // hypothesis index inside the unit
+                uint32_t bits = ~out[q] & validbits;
+                if (slot >= gn)
+                    bits = 0u;
+                if (__builtin_amdgcn_ballot_w64(bits != 0u)) { // wave-uniform
+                    const uint32_t cnt = (uint32_t)__popc(bits);
+                    const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint32_t pos = qtail + incl - cnt;
+                    uint32_t rest = bits;
+                    while (rest) { // point groups in ascending order = bits from the top
+                        const int hi = 31 - __clz((int)rest);
+                        rest &= ~(1u << hi);
+                        const uint32_t g = (uint32_t)(PG - 1 - hi);
+                        queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
+                        ++pos;
+                    }
+                    qtail += total;
+                    while (qtail - qhead >= 64u)
+                        drain(64u);
+                }
+            }
+        }
+        while (qtail != qhead)
+            drain(min(64u, qtail - qhead));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((uint32_t)lane < gn) {
+            const size_t o = (size_t)chunk * hyp_capacity + kb + lane;
+            part_score[o] = acc_s[lane];
+            part_count[o] = acc_c[lane];
+        }
+        ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
+    }
+}
+template <int PG>
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_score_mfmah(
+    PointSet pts, const uint4 *__restrict__ hypop, const double *__restrict__ models, const uint32_t *__restrict__ slots,
+    const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
+    uint32_t *__restrict__ part_count, double *__restrict__ part_score) {
+    score_mfmah_body<PG>(pts, hypop, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score, blockIdx.x,
+                         blockIdx.y, gridDim.x);
+}
+template <int PG>
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_score_mfmah_g(const GroupArgs *ga) {
+    const GroupArgs &g = ga[blockIdx.z];
+    if (!g.active || !g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
+        return;
+    const ScoreArgs &a = g.score;
+    score_mfmah_body<PG>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,
+                         a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
+}
+
 // ---- MSAC score in the reference's summation order ------------------------------------------------------------------
 // The streaming scorers add the inlier residuals of a hypothesis in tree order; the reference adds them one after the
 // other in correspondence order (utils.cc:52-63).  The two sums differ in the last bits, which only matters when two
@@ -1964,7 +2175,7 @@ static void score_shape(int est, uint32_t n, bool streaming, bool mfma, uint32_t
         return;
     }
     // (absolute pose on the matrix-core form: at most 10 groups of 32 correspondences per chunk, see launch_score_est)
-    const uint32_t per_chunk_max = lanes * (uint32_t)((streaming && mfma && est == EST_ABS) ? std::min(pmax, 5) : pmax);
+    const uint32_t per_chunk_max = lanes * (uint32_t)((streaming && mfma && (est == EST_ABS || est == EST_HOM)) ? std::min(pmax, 5) : pmax);
     chunks = (n + per_chunk_max - 1) / per_chunk_max;
     if (chunks == 0)
         chunks = 1;
@@ -1981,7 +2192,8 @@ bool score_uses_mfma(int est, uint32_t n_points, const PrefilterArgs &pf) {
         return pf.g16 > 0.f && pf.thr <= 1.0f;
     if (est == EST_REL || est == EST_FUND)
         return !off2 && pf.t16 > 0.f; // (coordinates bounded by 8, threshold in range: make_prefilter_args)
-    return false;
+    static const bool offh = std::getenv("POSELIB_AMD_NO_MFMAH") != nullptr;
+    return !offh && pf.h16 > 0.f; // homography: the same conditions
 }
 uint32_t score_chunks(int est, uint32_t n, bool streaming, bool mfma) {
     uint32_t c;
@@ -2022,6 +2234,29 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
                 return hipErrorInvalidValue;
             }
 #undef PL_M2_CASE
+            return hipGetLastError();
+        }
+    }
+    if constexpr (E == EST_HOM) {
+        if (streaming && a.shadow16) { // homography pre-filter on the matrix cores (PG = 2 P groups of 32 points per chunk)
+            const dim3 mgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
+            const dim3 mblock(kMfmaThreads);
+#define PL_MH_CASE(PP)                                                                                                 \
+    case PP:                                                                                                           \
+        k_score_mfmah<2 * PP><<<mgrid, mblock, 0, stream>>>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models,    \
+                                                          a.slots, a.num_hyp, a.hyp_capacity, a.thr2, pf, a.part_count, \
+                                                          a.part_score);                                                \
+        break;
+            switch (P) {
+                PL_MH_CASE(1)
+                PL_MH_CASE(2)
+                PL_MH_CASE(3)
+                PL_MH_CASE(4)
+                PL_MH_CASE(5)
+            default:
+                return hipErrorInvalidValue;
+            }
+#undef PL_MH_CASE
             return hipGetLastError();
         }
     }
@@ -2190,7 +2425,10 @@ template <int E> static hipError_t launch_group_score_est(const GroupArgs *args,
         if (d.any_queue)
             k_score_queue_g<EST_ABS, 5><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
     } else if constexpr (E == EST_HOM) {
-        k_score_queue_g<EST_HOM, 5><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
+        if (d.any_mfma)
+            k_score_mfmah_g<10><<<grid, dim3(kMfmaThreads), 0, stream>>>(args);
+        if (d.any_queue)
+            k_score_queue_g<EST_HOM, 5><<<grid, dim3(kQueueThreads), 0, stream>>>(args);
     } else {
         // (problems on the matrix-core form cut their correspondences into chunks of 32 PG, the others into 64 * 6: the
         // grid covers the larger chunk count, every block checks its own problem's)

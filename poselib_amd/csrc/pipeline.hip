@@ -734,6 +734,41 @@ __global__ __launch_bounds__(256) void k_sampson16(BatchCtl *ctl, const uint32_t
     sampson16_one(k, H, cap, slots, models, out);
 }
 
+// Operands of k_score_mfmah (homography on the matrix cores): four rows (V_0, V_1, U, S) of 32 k slots per hypothesis,
+// built from the fp64 record (pl_prefilter.h pf16_hom_model).  Stored per group of 8 hypotheses as four blocks of 32 rows x
+// 16 B: [k slots 0..7][8..15][16..23][24..31], row 4 j + r for hypothesis j of the group.
+__device__ __forceinline__ void hom16_one(uint32_t k, uint32_t H, const uint32_t *__restrict__ slots,
+                                          const double *__restrict__ models, float thr, uint4 *__restrict__ out) {
+    if (k >= ((H + 7u) & ~7u))
+        return; // groups past the last hypothesis are never read
+    Hom16Model o;
+    if (k < H) {
+        const double *rec = models + (size_t)slots[k] * kModelStride;
+        const bool nan_model = reinterpret_cast<const uint32_t *>(rec + kShadowOff)[13] != 0u;
+        pf16_hom_model(rec + kMatOff, nan_model, thr, o);
+    } else { // not a hypothesis: never a candidate
+        const double zero[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        pf16_hom_model(zero, true, thr, o);
+    }
+    uint4 *grp = out + (size_t)(k >> 3) * 128;
+    const uint32_t j = k & 7u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint16_t *h = o.r[r] + 8 * b;
+            grp[32 * b + 4 * j + r] = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                                                 (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+        }
+}
+__global__ __launch_bounds__(256) void k_hom16(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t cap,
+                                               float thr, uint4 *__restrict__ out) {
+    const uint32_t H = ctl->num_hyp;
+    const uint32_t end = min(cap, (H + 7u) & ~7u);
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < end; k += gridDim.x * 256)
+        hom16_one(k, H, slots, models, thr, out);
+}
+
 // Group form.  The grid is NOT sized by the record capacity (B x slots per iteration: 1.6 M slots for a 100 k-iteration
 // 5-point batch of which ~60 k hold a hypothesis - a capacity-sized grid was ~80 k empty workgroups per problem, whose
 // dispatch alone cost 8 % of the grouped 5-point step): a bounded number of workgroups per problem strides over the
@@ -757,6 +792,12 @@ __global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, 
         return;
     const uint32_t nb = gridDim.x - gather_blocks;
     const uint32_t k0 = (blockIdx.x - gather_blocks) * 256 + threadIdx.x;
+    if (g.comp.s16.sampson == 2) {
+        const uint32_t end = (uint32_t)std::min<uint64_t>((cap + 7u) & ~7ull, ((uint64_t)H + 7u) & ~7ull);
+        for (uint32_t k = k0; k < end; k += nb * 256)
+            hom16_one(k, H, g.comp.slots, g.comp.models, g.comp.s16.thr, static_cast<uint4 *>(g.comp.s16.out));
+        return;
+    }
     if (g.comp.s16.sampson) {
         const uint32_t capp = (uint32_t)std::min<uint64_t>(cap + kSampson16Pad, 0xffffff00ull);
         const uint32_t end = min(capp, H + (uint32_t)kSampson16Pad);
@@ -935,7 +976,11 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
         k_count_blocks<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, blk_tot);
     k_compact2<<<dim3(nb), dim3(1024), 0, stream>>>(num_models, B, maxm, blk_tot, slots, offsets, models, shadow_compact,
                                                     compact64, ctl);
-    if (s16.out && s16.sampson) {
+    if (s16.out && s16.sampson == 2) {
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)B * (uint64_t)maxm + 7u) & ~7ull, 0xffffff00ull);
+        k_hom16<<<dim3(std::min<uint32_t>((cap + 255) / 256, 1024u)), dim3(256), 0, stream>>>(ctl, slots, models, cap, s16.thr,
+                                                                                          static_cast<uint4 *>(s16.out));
+    } else if (s16.out && s16.sampson) {
         const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)B * (uint64_t)maxm + kSampson16Pad, 0xffffff00ull);
         k_sampson16<<<dim3((cap + 255) / 256), dim3(256), 0, stream>>>(ctl, slots, models, cap, static_cast<uint4 *>(s16.out));
     } else if (s16.out) {
@@ -957,6 +1002,14 @@ hipError_t launch_sampson16(BatchCtl *ctl, const uint32_t *slots, const double *
                             hipStream_t stream) {
     const uint32_t cap = capacity + (uint32_t)kSampson16Pad;
     k_sampson16<<<dim3((cap + 255) / 256), dim3(256), 0, stream>>>(ctl, slots, models, cap, static_cast<uint4 *>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_hom16(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t capacity, float thr, void *out,
+                        hipStream_t stream) {
+    const uint32_t cap = (capacity + 7u) & ~7u;
+    k_hom16<<<dim3(std::min<uint32_t>((cap + 255) / 256, 1024u)), dim3(256), 0, stream>>>(ctl, slots, models, cap, thr,
+                                                                                      static_cast<uint4 *>(out));
     return hipGetLastError();
 }
 

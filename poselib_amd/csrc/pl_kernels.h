@@ -171,6 +171,9 @@ bool score_uses_mfma(int est, uint32_t n_points, const PrefilterArgs &pf);
 // operands of k_score_mfma2 for `capacity` hypotheses listed in `slots` (+ the pad rows behind them)
 hipError_t launch_sampson16(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t capacity, void *out,
                             hipStream_t stream);
+// operands of k_score_mfmah for `capacity` hypotheses listed in `slots` (the last group of 8 is filled up)
+hipError_t launch_hom16(BatchCtl *ctl, const uint32_t *slots, const double *models, uint32_t capacity, float thr, void *out,
+                        hipStream_t stream);
 size_t lm2_state_bytes(uint32_t num_tasks);
 size_t lm2_partial_bytes(uint32_t num_tasks, uint32_t slices);
 hipError_t launch_lm2(int est, const PointSet &pts, LMTask *tasks, uint32_t num_tasks, uint32_t slices,
@@ -196,12 +199,15 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
 struct Shadow16Params {
     void *out = nullptr;
     float g16 = 0.f, c16 = 0.f, thr = 0.f;
-    int sampson = 0; // 1: two-view, operands of k_score_mfma2 (96 B per hypothesis, pl_prefilter.h Sampson16Operand)
+    int sampson = 0; // 1: two-view, operands of k_score_mfma2 (96 B per hypothesis, pl_prefilter.h Sampson16Operand);
+                     // 2: homography, operands of k_score_mfmah (256 B per hypothesis, Hom16Model; thr = PrefilterArgs.h16)
 };
 constexpr size_t kSampson16Bytes = 96;
 constexpr size_t kAbs16Bytes = 96;  // absolute pose (k_score_mfma): 2 rows x 3 k blocks x 16 B per hypothesis
 constexpr size_t kAbs16Pad = 16;    // the last group of 16 is filled up
 constexpr size_t kSampson16Pad = 64; // operand rows a partial group of 32 may read past the last hypothesis
+constexpr size_t kHom16Bytes = 256; // homography (k_score_mfmah): 4 rows x 4 k blocks x 16 B per hypothesis, groups of 8
+constexpr size_t kHom16Pad = 8;     // the last group of 8 is filled up
 // blk_tot is followed by the generators' NaN-model table of the same length (nb = ceil(B / 1024) entries each)
 hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uint32_t *blk_tot, bool counted, uint32_t *slots,
                            uint32_t *offsets, const double *models, float *shadow_compact, double *compact64,

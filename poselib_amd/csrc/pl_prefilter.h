@@ -78,6 +78,35 @@
 //    one multiplication and one FMA whose SIGN is the verdict.  Model side of that slot = -inf: NaN model (no inliers);
 //    +inf: matrix outside [1e-18, 1e18] (every point evaluated exactly).  Correspondences with a coordinate beyond 8 (or
 //    NaN) carry zero operands and the largest finite slack: never excluded.
+//  * homography, fp16 / MFMA form (k_score_mfmah, round 3; coordinates bounded by 8, thr <= 8): an inlier satisfies
+//    |h_c - b_c h_2| < thr |h_2| for c = 0, 1 (h = H (a, 1)).  |h_2| has no fixed sign over an image - for 55 % of the
+//    4-point hypotheses of BASELINE config 3 the vanishing line crosses the correspondences' bounding box, with 20 % of them
+//    on the minority side - so the inlier region is the union of two opposite cones and no set of half-planes (the P3P form)
+//    can bound it.  The matrix pipe delivers, per (hypothesis, correspondence), FOUR linear forms of the nine monomials
+//    phi = 2^8 (a0, a1, 1, b0 a0, b0 a1, b0, b1 a0, b1 a1, b1)  of the correspondence and a slack - two chained
+//    v_mfma_f32_32x32x16_f16 (32 k slots) for 8 hypotheses x 32 correspondences:
+//        V_c = H~_c . phi_a - H~_2 . phi_(b_c a)      ( = 2^8 cH (h_c - b_c h_2),  cH the power of two with max|H~| in [2^9, 2^10) )
+//        U   = thr H~_2 . phi_a                       ( = 2^8 cH thr h_2 )
+//        S   = g w + wa                               ( g = 2^-16.5 max|H~| per hypothesis (stored x 4);  w = 2^8 na (nb + thr)
+//                                                       (stored / 4), wa = 2^-5 na (nb + 1) + 3.8 per correspondence; rounded UP )
+//    and the vector ALU keeps the sign of  (|U| + S) - max(|V_0|, |V_1|)  (4 instructions per pair: v_med3 with |.| modifiers,
+//    add, subtract, v_alignbit).  The first cut of this form rounded every factor to ONE fp16 number: an error of 2^-10 of the
+//    sum of magnitudes, i.e. a band of 16 thresholds at thr = 1 px / f = 1000 - and the hypotheses of a RANSAC run are not
+//    random matrices: a homography through two or three inliers maps hundreds of correspondences to within a few pixels,
+//    which all survived (894 survivors per hypothesis against 211 of the fp32 form; measured slower than the fp32 form).  So
+//    both factors are split into fp16 high / low parts like the Sampson form's C~, and three of the four partial products are
+//    kept: k slots 0..8 hi*hi, 9..17 lo(coefficient)*hi, 18..26 hi*lo(monomial), 27 / 28 the slack.  Error budget: the dropped
+//    lo*lo product and the two splits <= 3 * 2^-22 |alpha phi|, products exact in fp32, 29 accumulations at <= 2^-23 each
+//    (truncation assumed): 2^-17.86 of the sum of magnitudes; operands below the fp16 normal range cost <= 2^-14 of the
+//    other factor each (also when the matrix pipe flushes them - low parts of small coefficients are subnormal):
+//        |V^_c - V_c| <= 2^-17.86 2^8 Hm na nb'  +  2^-14 (2 + 2^-11) (2^8 na nb' + 6 * 2^10)     (nb' = 1 + max |b_c|)
+//        |U^ - U|     <= 2^-17.86 2^8 thr Hm na  +  2^-14 (2 + 2^-11) (2^8 na + 3 * 2^10 thr)     (thr <= 8)
+//    g w = 2^-16.5 2^8 Hm na (nb' + thr) covers the relative parts 2.5 times over (which also pays for the fp32 roundings of
+//    the tail), wa >= 2^-5 (1 + 2^-10) na (nb' + 1) + 0.7503 + 3.0015 the absolute ones.  max |V^_c| > |U^| + S  then implies
+//    max |V_c| > |U|, a certain outlier; h_2 = 0 (never an inlier: the reference divides by it) needs no special case.  At
+//    thr = 1e-3 on normalised coordinates the band is 1.1 thresholds wide.  Model side of the slack slot = -inf: NaN model (no
+//    inliers); +inf: matrix outside [1e-18, 1e18] (every point evaluated exactly).  Correspondences with a coordinate beyond
+//    8 (or NaN) carry zero operands and the largest finite slack: never excluded.
 //  * models with a NaN entry have no inliers at all (see store_shadow); models or thresholds outside the range in
 //    which fp32 keeps its relative accuracy (max-abs entry outside [1e-18, 1e18]) get an infinite slack, i.e. every
 //    point is evaluated exactly.
@@ -100,6 +129,7 @@ struct PrefilterArgs {
     float t1;      // Sampson, one-comparison form: (16/15) (1 + 1/64) thr2 (1 + 96u), rounded up
     float w252;    //   and (16/15) (1 + 96u) 60, rounded up (factor of (na nb)^2 in the per-point term w)
     float t16;     // Sampson, fp16 / MFMA form: (16/15) 2^15 thr2 (1 + 256u), rounded up; 0 = that form is not available
+    float h16;     // homography, fp16 / MFMA form: the threshold, rounded up; 0 = that form is not available
 };
 
 PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-negative bound upwards
@@ -109,7 +139,7 @@ PL_HD float pf_up(float v) { return v * 1.000001f + 1e-30f; } // pads a non-nega
 // the range fp32 can carry.
 inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) {
     PrefilterArgs a;
-    a.thr = a.gx = a.thr2_up = a.g16 = a.c16 = a.t1 = a.w252 = a.t16 = 0.f;
+    a.thr = a.gx = a.thr2_up = a.g16 = a.c16 = a.t1 = a.w252 = a.t16 = a.h16 = 0.f;
     a.enabled = 0;
     if (!(thr2 >= 1e-30 && thr2 <= 1e30))
         return a;
@@ -135,6 +165,12 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
         // thr2 range: t16 and 16 E_C^2 / t16 have to stay inside fp32 / fp16 with room to spare
         if (xy_absmax <= 8.0f && thr2 >= 1e-12 && thr2 <= 1e4)
             a.t16 = nextafterf((float)((16.0 / 15.0) * 32768.0 * thr2 * (1.0 + 256.0 * u)), inf);
+    }
+    if (est == 3) {
+        // homography on the matrix cores: coordinates bounded by 8 (xy_absmax of a two-view problem, see above), thr <= 8
+        // (the coefficient thr H~_2j has to stay inside fp16) and not absurdly small
+        if (xy_absmax <= 8.0f && thr >= 1e-9 && thr <= 8.0)
+            a.h16 = a.thr;
     }
     a.enabled = 1;
     return a;
@@ -463,6 +499,100 @@ PL_HD bool pf16_abs_outlier(const Abs16Model &m, const Abs16Point &p, const int 
             sign |= bits;
         }
     return (sign >> 31) != 0u;
+}
+
+
+// ---- homography, fp16 / MFMA form: operands (header comment).  Monomials m = (a0, a1, 1, b0 a0, b0 a1, b0, b1 a0, b1 a1, b1);
+// k slots 0..8: coefficient_hi * m_hi, 9..17: coefficient_lo * m_hi, 18..26: coefficient_hi * m_lo, 27: slack (relative
+// part), 28: slack (absolute part), 29..31 unused.  Rows of a hypothesis: V_0, V_1, U, S ------------------------------------
+struct Hom16Model {
+    uint16_t r[4][32];
+};
+struct Hom16Point {
+    uint16_t k[32];
+};
+constexpr double kH16PointMax = 8.0;
+// H: row-major 3x3; nan_model: the record's NaN flag; thr: PrefilterArgs.h16
+PL_HD void pf16_hom_model(const double *H, bool nan_model, float thr, Hom16Model &o) {
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 32; ++k)
+            o.r[r][k] = 0;
+    double hm = 0.0;
+    bool bad = nan_model;
+    for (int k = 0; k < 9; ++k) {
+        const double a = fabs(H[k]);
+        bad |= (a != a);
+        hm = a > hm ? a : hm;
+    }
+    if (bad) {
+        o.r[3][28] = 0xfc00u; // -inf (times the correspondence's positive wa): no inliers
+        return;
+    }
+    if (!(hm >= 1e-18 && hm <= 1e18)) {
+        o.r[3][28] = 0x7c00u; // +inf: every correspondence is evaluated exactly
+        return;
+    }
+    int e;
+    (void)frexp(hm, &e);                  // hm in [2^(e-1), 2^e)
+    const double cH = ldexp(1.0, 10 - e); // max |H~| in [2^9, 2^10)
+    // coefficient of monomial m in row r (zero where the row does not use it)
+    double coef[3][9];
+    for (int m = 0; m < 9; ++m)
+        coef[0][m] = coef[1][m] = coef[2][m] = 0.0;
+    for (int j = 0; j < 3; ++j) {
+        coef[0][j] = H[j] * cH;          // V_0 = H~_0 . (a, 1) - b0 H~_2 . (a, 1)
+        coef[0][3 + j] = -(H[6 + j] * cH);
+        coef[1][j] = H[3 + j] * cH;      // V_1 = H~_1 . (a, 1) - b1 H~_2 . (a, 1)
+        coef[1][6 + j] = -(H[6 + j] * cH);
+        coef[2][j] = (double)thr * (H[6 + j] * cH); // U = thr H~_2 . (a, 1)
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int m = 0; m < 9; ++m) {
+            uint16_t h, l;
+            pf_split16(coef[r][m], h, l);
+            o.r[r][m] = h, o.r[r][9 + m] = l, o.r[r][18 + m] = h;
+        }
+    o.r[3][27] = pf_half_up((float)(hm * cH * 4.3158e-5) * 1.000001f); // 4 * 2^-16.5 (the correspondence carries w / 4)
+    o.r[3][28] = 0x3c00u;                                              // 1.0
+}
+// returns false (zero operands, largest finite slack) for correspondences the operands cannot carry
+PL_HD bool pf16_hom_point(double a0, double a1, double b0, double b1, bool valid, float thr, Hom16Point &o) {
+    for (int k = 0; k < 32; ++k)
+        o.k[k] = 0;
+    const double m = fmax(fmax(fabs(a0), fabs(a1)), fmax(fabs(b0), fabs(b1)));
+    const bool finite = (a0 == a0) & (a1 == a1) & (b0 == b0) & (b1 == b1);
+    if (!(valid && finite && m <= kH16PointMax)) {
+        o.k[28] = 0x7bffu; // 65504 (times the hypothesis' 1.0)
+        return false;
+    }
+    const double al[3] = {a0, a1, 1.0}, be[3] = {1.0, b0, b1};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            uint16_t h, l;
+            pf_split16(be[i] * al[j] * 256.0, h, l);
+            o.k[3 * i + j] = h, o.k[9 + 3 * i + j] = h, o.k[18 + 3 * i + j] = l;
+        }
+    const double na = 1.0 + fabs(a0) + fabs(a1), nb = 1.0 + fmax(fabs(b0), fabs(b1));
+    o.k[27] = pf_half_up((float)(64.0 * na * (nb + (double)thr) * 1.000001) * 1.000001f); // w / 4 <= 18496
+    o.k[28] = pf_half_up((float)((0.03125 * na * (nb + 1.0) * 1.001 + 3.8) * 1.000001) * 1.000001f);
+    return true;
+}
+// The verdict as the kernel computes it (one particular accumulation order; `order` permutes it): true = certainly not an
+// inlier.  Test-only host build and documentation of the device tail.
+PL_HD bool pf16_hom_outlier(const Hom16Model &m, const Hom16Point &p, const int *order /* 32 slots or nullptr */) {
+    float acc[4];
+    for (int r = 0; r < 4; ++r) {
+        acc[r] = 0.f;
+        for (int q = 0; q < 32; ++q) {
+            const int k = order ? order[q] : q;
+            acc[r] = fmaf(pf_half_to_float(m.r[r][k]), pf_half_to_float(p.k[k]), acc[r]);
+        }
+    }
+    const float t = fmaxf(fabsf(acc[0]), fabsf(acc[1]));
+    const float d = (fabsf(acc[2]) + acc[3]) - t;
+    uint32_t bits;
+    __builtin_memcpy(&bits, &d, 4);
+    return (bits >> 31) != 0u;
 }
 
 } // namespace pl

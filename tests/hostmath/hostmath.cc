@@ -383,6 +383,37 @@ int hm_prefilter16_abs(const double *rec, const double *const *pa, uint32_t n, d
     return 1;
 }
 
+// The homography pre-filter in its fp16 / matrix-core form (k_hom16 + k_score_mfmah; pl_prefilter.h): the same operand
+// builders as the kernels, the four linear forms accumulated in fp32 in k-slot order or (random_order != 0) in a
+// pseudo-random order.  Returns 0 when that form is not available (coordinates beyond 8, threshold out of range).
+int hm_prefilter16_hom(const double *rec, const double *const *pa, uint32_t n, double thr2, float uv_absmax,
+                       uint32_t random_order, uint8_t *out) {
+    const PrefilterArgs pf = make_prefilter_args(EST_HOM, thr2, uv_absmax);
+    std::memset(out, 0, n);
+    if (!pf.enabled || !(pf.h16 > 0.f))
+        return 0;
+    const float *r = reinterpret_cast<const float *>(rec + kShadowOff);
+    uint32_t flag;
+    std::memcpy(&flag, &r[13], 4);
+    Hom16Model m;
+    pf16_hom_model(rec + kMatOff, flag != 0u, pf.h16, m);
+    uint64_t rng = 0x9e3779b97f4a7c15ull * (random_order + 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        Hom16Point p;
+        pf16_hom_point(pa[0][i], pa[1][i], pa[2][i], pa[3][i], true, pf.h16, p);
+        int order[32];
+        for (int k = 0; k < 32; ++k)
+            order[k] = k;
+        if (random_order)
+            for (int k = 31; k > 0; --k) {
+                rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17;
+                std::swap(order[k], order[(rng >> 33) % (uint64_t)(k + 1)]);
+            }
+        out[i] = pf16_hom_outlier(m, p, random_order ? order : nullptr);
+    }
+    return 1;
+}
+
 // fp16 conversions of pl_prefilter.h (checked against numpy's float16 by the tests)
 void hm_half_rn(const float *v, uint64_t n, uint16_t *bits, float *back) {
     for (uint64_t i = 0; i < n; ++i) {

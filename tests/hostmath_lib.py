@@ -146,6 +146,17 @@ def prefilter16_abs(rec, cols, thr2, xy_absmax, random_order=0):
     return bool(en), out.astype(bool)
 
 
+def prefilter16_hom(rec, cols, thr2, uv_absmax, random_order=0):
+    """the homography pre-filter in its fp16 / matrix-core form: (available, mask of PROVEN non-inliers)"""
+    arrs, ptrs = _soa(cols)
+    n = arrs[0].shape[0]
+    out = np.zeros(n, dtype=np.uint8)
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    en = lib().hm_prefilter16_hom(_p(rec), ptrs, C.c_uint32(n), C.c_double(thr2), C.c_float(uv_absmax),
+                                  C.c_uint32(random_order), _p(out))
+    return bool(en), out.astype(bool)
+
+
 def half_rn(v):
     """pl_prefilter.h's float -> fp16 conversion: (bits, value of those bits as float32)"""
     v = np.ascontiguousarray(v, dtype=np.float32)

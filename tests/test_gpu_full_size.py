@@ -236,7 +236,8 @@ def test_fp32_filters_never_drop_an_inlier_on_the_device(gpu, kind):
             prob = gpu.Problem(kind, x1, x2)
             cnt, sc, path = prob.score_stream(M, thr)
             prob.close()
-            assert path == (2 if (kind != 3 and not pixel and npts >= 1024) else 1), (kind, pixel, npts, thr, path)
+            # (round 3: the homography scorer has a matrix-core form as well - normalised coordinates, >= 1024 correspondences)
+            assert path == (2 if (not pixel and npts >= 1024) else 1), (kind, pixel, npts, thr, path)
             for k in range(len(M)):
                 osc, ocnt = O.score(okind, M[k], x1, x2, thr * thr)
                 pairs += len(x1)
@@ -333,6 +334,76 @@ def test_matrix_core_sampson_filter_never_drops_an_inlier_on_the_device(gpu, kin
                     assert abs(scv[k] - osc) <= 1e-9 * abs(osc) + 1e-300
     print(f"kind {kind}: {pairs} pairs through the matrix-core Sampson filter, count differences {diff}")
     assert pairs >= 2_000_000 and diff == 0
+
+
+def test_matrix_core_homography_filter_never_drops_an_inlier_on_the_device(gpu):
+    """k_score_mfmah (round 3): four linear forms per pair out of the matrix pipe, verdict max(|V_0|, |V_1|) > |U| + S
+    (pl_prefilter.h).  Correspondences planted around the decision boundary, coordinate scales up to the operand bound of 8,
+    matrices rescaled over 27 decades and negated, vanishing lines THROUGH the correspondences (the sign of h_2 changes among
+    them), denominators of exactly zero, NaN / zero / inf models; counts must equal the oracle's exact evaluation."""
+    rs = np.random.RandomState(97)
+    pairs = diff = 0
+    for trial in range(10):
+        d = synth.homography_scene(4000, 0.5, 6500 + trial)
+        sc = [1.0, 1.0, 7.5, 3.0, 0.05][trial % 5]
+        x1, x2 = (np.asarray(d["x1"], float) - 500.0) / FOCAL * sc, (np.asarray(d["x2"], float) - 500.0) / FOCAL * sc
+        inl = np.flatnonzero(d["inlier_gt"])[:40]
+        rows = []
+        for (u0, v0), (u1, v1) in zip(x1[inl], x2[inl]):
+            p = np.array([u0, v0, 1.0])
+            rows.append(np.r_[p, 0, 0, 0, -u1 * p])
+            rows.append(np.r_[0, 0, 0, p, -v1 * p])
+        gt = np.linalg.svd(np.array(rows))[2][-1].reshape(3, 3)
+        models = []
+        for k in range(14):
+            if k == 0:
+                Mk = gt
+            elif k < 6:
+                Mk = gt + 10.0 ** (-2 * k) * np.abs(gt).max() * rs.randn(3, 3)
+            elif k < 9:
+                Mk = rs.randn(3, 3) * (1e-3 ** rs.randint(0, 3, (3, 3)))
+            elif k == 9:  # the vanishing line runs through the correspondences
+                Mk = gt.copy()
+                Mk[2] = np.array([1.0, -1.0, 1e-9]) * np.abs(gt).max()
+            elif k == 10:  # ... through correspondence `trial` exactly: a denominator of 0
+                Mk = gt.copy()
+                Mk[2] = [1.0, 0.0, -x1[trial, 0]]
+            elif k == 11:
+                Mk = gt.copy()
+                Mk[1, 1] = np.nan
+            elif k == 12:
+                Mk = np.zeros((3, 3))
+            else:
+                Mk = np.diag([1.0, 1.0, np.inf])
+            models.append(Mk * 10.0 ** rs.choice([-12, -3, 0, 0, 4, 15]) * rs.choice([-1.0, 1.0]))
+        M = np.array(models)
+        a = np.c_[x1, np.ones(len(x1))]
+        h = a @ gt.T
+        proj = h[:, :2] / h[:, 2:3]
+        for thr in (1e-5 * sc, 1e-3 * sc, 3e-3 * sc, 0.1 * sc, 1.0, 8.0):
+            eps = 10.0 ** rs.uniform(-9, -3, len(x2)) * rs.choice([-1, 1], len(x2))
+            ang = rs.uniform(0, 2 * np.pi, len(x2))
+            planted = proj + (thr * (1 + eps))[:, None] * np.c_[np.cos(ang), np.sin(ang)]
+            b = x2.copy()
+            sel = (rs.rand(len(x2)) < 0.5) & (np.abs(planted).max(1) < 7.99)
+            b[sel] = planted[sel]
+            if trial == 1:
+                b[::9] *= 30.0  # correspondences beyond the operand bound: the problem falls back to the fp32 form
+            prob = gpu.Problem(3, x1, b)
+            cnt, scv, path = prob.score_stream(M, thr)
+            prob.close()
+            in_range = max(np.abs(x1).max(), np.abs(b).max()) <= 8.0
+            assert path == (2 if in_range else 1), (trial, thr, path)
+            for k in range(len(M)):
+                osc, ocnt = O.score("homography", M[k], x1, b, thr * thr)
+                pairs += len(x1)
+                if cnt[k] != ocnt:
+                    diff += abs(int(cnt[k]) - int(ocnt))
+                    print("MISMATCH trial", trial, "thr", thr, "model", k, cnt[k], ocnt)
+                elif np.isfinite(osc):
+                    assert abs(scv[k] - osc) <= 1e-9 * abs(osc) + 1e-300
+    print(f"homography: {pairs} pairs through the matrix-core filter, count differences {diff}")
+    assert pairs >= 3_000_000 and diff == 0
 
 
 # ------------------------------------------------------------------------------------------ concurrency of the batch entry

@@ -402,3 +402,83 @@ def test_absolute_pose_fp16_form_never_drops_an_inlier():
     assert stats[1] < 0.05 * stats[0]
     # above thr = 1 the form hands over to the fp32 one
     assert not HM.prefilter16_abs(HM.pose_record(q, t), cols, 1.0000001 ** 2, 0.5)[0]
+
+
+def _check16_hom(rec, cols, thr2, uv, stats=None, order=0):
+    _, _, inl, _ = HM.score("hom", rec, cols, thr2)
+    en, out = HM.prefilter16_hom(rec, cols, thr2, uv, order)
+    bad = inl & out
+    assert not bad.any(), (thr2, np.flatnonzero(bad)[:5])
+    if stats is not None and en:
+        stats[0] += int((~inl).sum())
+        stats[1] += int((~inl & ~out).sum())
+    return en
+
+
+def _fit_homography(cols, inl):
+    a = np.c_[cols[0][inl], cols[1][inl], np.ones(len(inl))]
+    b = np.c_[cols[2][inl], cols[3][inl]]
+    A = []
+    for p, (u, v) in zip(a, b):
+        A.append(np.r_[p, 0, 0, 0, -u * p])
+        A.append(np.r_[0, 0, 0, p, -v * p])
+    return np.linalg.svd(np.array(A))[2][-1].reshape(3, 3)
+
+
+def test_homography_fp16_form_never_drops_an_inlier():
+    """The four linear forms of k_score_mfmah's filter (round 3), built by the very operand functions the kernels call
+    (pf16_hom_model / pf16_hom_point) and accumulated in fp32 in several orders: coordinate scales 1e-3 .. 7.9, thresholds
+    1e-5 .. 8, matrices rescaled by 1e-12 .. 1e15 and negated, third rows whose form h_2 changes sign inside the image
+    (|h_2| has no fixed sign: the inlier region is two opposite cones), denominators around zero, correspondences planted at
+    the decision boundary thr (1 +- 1e-9 .. 1e-3), NaN / inf / zero matrices, NaN points, coordinates beyond the bound."""
+    rs = np.random.RandomState(31)
+    stats = [0, 0]
+    enabled = 0
+    for trial in range(40):
+        d = synth.homography_scene(1500, 0.5, 900 + trial)
+        cols = _two_view_cols(d, False)
+        sc = [1.0, 1.0, 7.9, 1e-3, 3.0][trial % 5]
+        cols = [np.asarray(c, float) * sc for c in cols]
+        uv = float(max(np.abs(c).max() for c in cols))
+        Hgt = _fit_homography(cols, np.flatnonzero(d["inlier_gt"])[:40])
+        for thr in (1e-5 * sc, 1e-3 * sc, 3e-3 * sc, 0.1 * sc, 1.0, 8.0):
+            # half of the correspondences planted at the decision boundary of the first model: b = H a + thr (1 +- eps) dir
+            a = np.c_[cols[0], cols[1], np.ones(len(cols[0]))]
+            h = a @ Hgt.T
+            proj = h[:, :2] / h[:, 2:3]
+            ang = rs.uniform(0, 2 * np.pi, len(a))
+            eps = rs.choice([1e-9, 1e-6, 1e-3], len(a)) * rs.choice([-1, 1], len(a))
+            planted = proj + (thr * (1 + eps))[:, None] * np.c_[np.cos(ang), np.sin(ang)]
+            sel = (rs.rand(len(a)) < 0.5) & (np.abs(planted).max(1) < 7.99)
+            cc = [cols[0], cols[1], np.where(sel, planted[:, 0], cols[2]), np.where(sel, planted[:, 1], cols[3])]
+            uvc = float(max(np.abs(c).max() for c in cc))
+            for model in range(7):
+                if model == 0:
+                    Hm = Hgt
+                elif model < 3:
+                    Hm = Hgt + 10.0 ** -(2 * model) * np.abs(Hgt).max() * rs.randn(3, 3)
+                elif model == 3:
+                    Hm = rs.randn(3, 3)
+                elif model == 4:  # the vanishing line runs through the correspondences: h_2 changes sign among them
+                    Hm = Hgt.copy()
+                    Hm[2] = np.array([1.0, -1.0, 1e-9]) * np.abs(Hgt).max()
+                elif model == 5:  # ... and through a planted correspondence exactly: denominators of 0, 1e-300, 1e-17
+                    Hm = Hgt.copy()
+                    Hm[2] = [1.0, 0.0, -cols[0][trial] + [0.0, 1e-300, 1e-17][trial % 3]]
+                else:
+                    Hm = np.array([[np.nan, 0, 0], [0, 1, 0], [0, 0, 1.0]]) if trial % 3 == 0 else (
+                        np.zeros((3, 3)) if trial % 3 == 1 else np.diag([1.0, 1.0, np.inf]))
+                Hm = Hm * 10.0 ** rs.choice([-12, -3, 0, 0, 4, 15]) * rs.choice([-1, 1])
+                typical = model == 3 and sc in (1.0, 3.0) and 1e-3 * sc <= thr <= 0.1 * sc
+                enabled += _check16_hom(HM.matrix_record(Hm), cc, thr * thr, uvc, stats if typical else None, order=trial % 3)
+    assert enabled > 500
+    print(f"hom (fp16 form): {stats[1]}/{stats[0]} non-inliers pass the filter ({100.0 * stats[1] / stats[0]:.3f} %)")
+    assert stats[1] < 0.05 * stats[0]
+    # NaN points and coordinates beyond the bound are never excluded; thresholds above 8 / coordinates above 8 hand over
+    cols2 = [c.copy() for c in cols]
+    cols2[0][::5] = np.nan
+    cols2[3][1::5] = 8.5
+    en, out = HM.prefilter16_hom(HM.matrix_record(Hgt), cols2, 1e-6, 7.0)
+    assert en and not out[::5].any() and not out[1::5].any()
+    assert not HM.prefilter16_hom(HM.matrix_record(Hgt), cols, 8.0000001 ** 2, 1.0)[0]
+    assert not HM.prefilter16_hom(HM.matrix_record(Hgt), cols, 1e-6, 8.5)[0]
