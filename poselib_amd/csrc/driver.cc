@@ -2778,13 +2778,18 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
         else
             solo.push_back(i);
     }
+    static const size_t group_max = [] { // problems per launch sequence (POSELIB_AMD_BATCH_GROUP: experiments)
+        const char *e = std::getenv("POSELIB_AMD_BATCH_GROUP");
+        const long v = e ? std::atol(e) : (long)kGroupMax;
+        return (size_t)std::min<long>(std::max<long>(v, 1), 1024);
+    }();
     std::vector<std::vector<GroupItem>> groups;
     for (int k = 0; k < 4; ++k) {
         std::vector<size_t> &v = by_kind[k];
         std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].n > items[b].n; });
-        for (size_t at = 0; at < v.size(); at += kGroupMax) {
+        for (size_t at = 0; at < v.size(); at += group_max) {
             groups.emplace_back();
-            for (size_t j = at; j < std::min(v.size(), at + kGroupMax); ++j) {
+            for (size_t j = at; j < std::min(v.size(), at + group_max); ++j) {
                 GroupItem g;
                 g.item = &items[v[j]];
                 g.kind = k;

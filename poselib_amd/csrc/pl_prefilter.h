@@ -42,13 +42,16 @@
 //             +- rn16(R_2) ((p X)_hi + (p X)_lo) +- rn16(t_2) rn16(p)
 //    (X_hi = rn16(X), X_lo = rn16(X - X_hi); the products p X are formed in fp64 and split the same way; p itself enters
 //    with its high part only).  |R_ck| <= 1 and thr <= 1 give coefficients bounded by 1 + thr, rounded with relative error
-//    2^-12; the splits leave 2^-22 (+ 6.1e-5 absolute once a part is subnormal - also when the matrix pipe flushes it);
-//    products are exact in fp32 and sixteen accumulations add <= 2^-19 of the sum of magnitudes:
-//        |F^ - F| <= 2^-12 (1 + thr + |p|) |X|_1 (1 + 2^-6)  +  2^-12 (2 |p| + 2^-7 (1 + thr)) max|t_c|  +  absolute terms
+//    2^-11 (the unit roundoff of fp16; round 2 wrote 2^-12 here and had no margin left for the terms that follow - ADVICE r2);
+//    the splits leave 2^-22 (+ 6.1e-5 absolute once a part is subnormal - also when the matrix pipe flushes it); products
+//    are exact in fp32 and sixteen accumulations add <= 2^-19 of the sum of magnitudes:
+//        |F^ - F| <= (2^-11 + 2^-19 + 2^-21) (1 + thr + |p|) |X|_1  +  2^-11 (2 |p| + (1 + thr)) max|t_c| (1 + 2^-8)  +  absolute terms
 //    (the 2 |p|: rounded t_2 and the dropped low part of p).  With  g = G max|t_c| + c,  w = G |X|_1 + 1.3e-4,
-//    G = 2^-11 (1 + max|x|,|y| + thr),  c = 4e-4 (1 + max|x|,|y| + thr) + 6e-5 (every factor rounded up; the absolute
-//    parts cover the subnormal operands: six low parts and p per row, and coefficients below 6.1e-5 against the margin
-//    of G) the slack exceeds the error with a factor of two to spare, and the constant is rounded towards +inf, so
+//    G = 2^-11 (1 + 2^-6) (1 + max|x|,|y| + thr),  c = 4e-4 (1 + max|x|,|y| + thr) + 6e-5 (every factor rounded up): the
+//    factor 1 + 2^-6 of G pays for the accumulation and split terms of the X part (2^-8 + 2^-10 of the leading term) whatever
+//    the field of view and the threshold; the translation part needs 2 |p| + 1 + thr <= 2 (1 + max|p| + thr) - i.e. G covers
+//    it with a factor of two to spare -, and the absolute parts cover the subnormal operands: six low parts and p per row,
+//    and coefficients below 6.1e-5.  The constant is rounded towards +inf, so
 //    F^ >= F:  a NEGATIVE F^ proves |z_a - p z_2| > thr z_2, i.e. an outlier (z_2 <= 0: not an inlier either way).  The
 //    kernel ORs the four sign bits.  Points or translations beyond 3e4 (fp16 range; also |p| |X|_1) and rotation rows that
 //    are not unit-bounded get an infinite slack (always evaluated exactly), NaN models -inf (never).
@@ -124,7 +127,7 @@ struct PrefilterArgs {
     float gx;      // absolute pose: 32u (1 + max|x|,|y| + thr), rounded up
     float thr2_up; // Sampson: thr2 (1 + 64u), rounded up
     int enabled;   // 0: exact evaluation of every point
-    float g16;     // absolute pose, fp16 / MFMA form of the filter: 2^-11 (1 + max|x|,|y| + thr), rounded up
+    float g16;     // absolute pose, fp16 / MFMA form of the filter: 2^-11 (1 + 2^-6) (1 + max|x|,|y| + thr), rounded up
     float c16;     //   and the absolute part (2e-7 + 2.5e-4) (1 + max|x|,|y| + thr)
     float t1;      // Sampson, one-comparison form: (16/15) (1 + 1/64) thr2 (1 + 96u), rounded up
     float w252;    //   and (16/15) (1 + 96u) 60, rounded up (factor of (na nb)^2 in the per-point term w)
@@ -154,7 +157,7 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
     a.w252 = nextafterf((float)((16.0 / 15.0) * (1.0 + 96.0 * u) * 60.0), inf);
     if (est == 0) {
         a.gx = nextafterf((float)(32.0 * u * (1.0 + (double)xy_absmax + thr)), inf);
-        a.g16 = nextafterf((float)(4.8828125e-4 * (1.0 + (double)xy_absmax + thr)), inf); // 2^-11
+        a.g16 = nextafterf((float)(4.8828125e-4 * 1.015625 * (1.0 + (double)xy_absmax + thr)), inf); // 2^-11 (1 + 2^-6)
         // 2e-7: fp32 accumulation; 2.5e-4: four fp16 inputs per row (X_lo, t) may be subnormal, i.e. below 6.1e-5 - the
         // bound holds even if the matrix pipe flushes them to zero
         // (round 2, half-plane rows: six low parts - X_lo, (x X)_lo - and x itself may be subnormal per row: 4e-4)

@@ -265,17 +265,21 @@ template <int K> PL_HD void accumulate1(double *acc, const Loss &loss, double r,
 // (2 rho - 1)^3 of the Nielsen update (lm_impl.h:124: std::pow(2.0 * rho - 1.0, 3)), see the note at lm_update
 // The reference calls the host's libm here - glibc's pow, whose result for the exponent 3 is the correctly rounded cube
 // for 99.9 % of the arguments (measured: 183 exceptions in 2*10^5; the device library's pow differs from it for 23 %).  The
-// device therefore forms the correctly rounded cube itself: x^2 = hi + lo and hi x = p + e exactly (FMA residuals), then
+// device therefore forms the (nearly) correctly rounded cube itself: x^2 = hi + lo and hi x = p + e exactly (FMA residuals), then
 // one rounding of p + (e + lo x).  The value only matters for mediocre steps (factor = 1 - cube > 1/3, i.e. rho < 0.94).
-PL_HD double lm_cube(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+// (the FMA form is a plain function so that the host test build can compare it with glibc's pow: tests/test_libm_vs_glibc.py)
+PL_HD double lm_cube_fma(double x) {
     if (!(fabs(x) < 1e100) || fabs(x) < 1e-100)
         return x * x * x; // inf / NaN / overflow / underflow: as pow
     const double hi = x * x;
     const double lo = __builtin_fma(x, x, -hi);
     const double p = hi * x;
     const double e = __builtin_fma(hi, x, -p);
-    return p + (e + lo * x);
+    return p + (e + lo * x); // (lo x and the inner sum round once each: NEARLY correctly rounded, see above)
+}
+PL_HD double lm_cube(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return lm_cube_fma(x);
 #else
     return pow(x, 3);
 #endif

@@ -414,6 +414,12 @@ int hm_prefilter16_hom(const double *rec, const double *const *pa, uint32_t n, d
     return 1;
 }
 
+// the device form of the Nielsen update's cube (pl_refine.h lm_cube_fma), for the comparison with glibc's pow(x, 3)
+void hm_lm_cube(const double *x, uint64_t n, double *out) {
+    for (uint64_t i = 0; i < n; ++i)
+        out[i] = lm_cube_fma(x[i]);
+}
+
 // fp16 conversions of pl_prefilter.h (checked against numpy's float16 by the tests)
 void hm_half_rn(const float *v, uint64_t n, uint16_t *bits, float *back) {
     for (uint64_t i = 0; i < n; ++i) {

@@ -50,3 +50,23 @@ def test_acos_cos_sin_are_bit_identical_to_glibc():
         bad_x = C.c_double(0.0)
         bad = L.hm_libm_mismatches(which, count, 3 + which, C.byref(bad_x))
         assert bad == 0, (name, bad, bad_x.value.hex())
+
+
+def test_device_form_of_the_nielsen_cube_against_glibc_pow():
+    """pl_refine.h lm_cube_fma - what the DEVICE computes for std::pow(2 rho - 1, 3) of the LM's Nielsen update
+    (lm_impl.h:124); the host test build calls pow itself.  Two-product FMA form, nearly correctly rounded: it must equal
+    glibc's pow(x, 3) for >= 99.9 % of the arguments the update can see (|2 rho - 1| <= a few) and never be off by more than
+    one ulp (the form used to be exercised on the GPU only)."""
+    import numpy as np
+
+    L = HM.lib()
+    rs = np.random.RandomState(12)
+    x = np.r_[rs.uniform(-1.0, 1.0, 1_000_000), rs.uniform(-4.0, 4.0, 500_000), 10.0 ** rs.uniform(-8, 3, 200_000) * rs.choice([-1, 1], 200_000),
+              [0.0, 1.0, -1.0, 0.5, 1 / 3, np.inf, -np.inf, 1e200, 1e-200]]
+    out = np.zeros_like(x)
+    L.hm_lm_cube(x.ctypes.data_as(C.c_void_p), C.c_uint64(x.size), out.ctypes.data_as(C.c_void_p))
+    want = np.array([math.pow(v, 3) if abs(v) < 1e100 else v * v * v for v in x])
+    same = out == want
+    assert same.mean() > 0.999, same.mean()
+    bad = ~same & np.isfinite(want)
+    assert (np.abs(out[bad] - want[bad]) <= np.spacing(np.abs(want[bad]))).all()

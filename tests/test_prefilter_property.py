@@ -482,3 +482,31 @@ def test_homography_fp16_form_never_drops_an_inlier():
     assert en and not out[::5].any() and not out[1::5].any()
     assert not HM.prefilter16_hom(HM.matrix_record(Hgt), cols, 8.0000001 ** 2, 1.0)[0]
     assert not HM.prefilter16_hom(HM.matrix_record(Hgt), cols, 1e-6, 8.5)[0]
+
+
+def test_absolute_pose_fp16_form_narrow_field_of_view_tiny_threshold():
+    """with a narrow field of view (|x|, |y| <= 1e-3) and thresholds <= 1e-4 the relative part of the fp16 form's
+    slack, G = 2^-11 (1 + 2^-6) (1 + max|x|,|y| + thr), is all that covers the rounding of coefficients just above 1 times
+    |X|_1 ~ 1e4 - the regime where a missing margin would show.  Correspondences planted at thr (1 +- 1e-9 .. 1e-3); rotations
+    whose third row is close to a coordinate axis (coefficients thr R_2 -+ R_a next to 1), all accumulation orders."""
+    rs = np.random.RandomState(77)
+    enabled = 0
+    for trial in range(60):
+        n = 1500
+        depth = rs.uniform(3e3, 2.5e4, n)
+        X = np.c_[rs.uniform(-1e-3, 1e-3, n) * depth, rs.uniform(-1e-3, 1e-3, n) * depth, depth]
+        # camera looking down +Z, rotated by a small angle so that R_2 ~ (eps, eps, 1) and the rows R_0, R_1 stay near axes
+        w = rs.randn(3) * [1e-4, 1e-4, 0.7][trial % 3]
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        q = _quat(R)
+        t = np.r_[rs.uniform(-1, 1, 2), rs.uniform(-100, 100)]
+        Xw = (X - t) @ R  # world points such that R Xw + t = X
+        rec = HM.pose_record(q, t)
+        for thr in (1e-6, 1e-5, 1e-4):
+            xp, Xp = _plant_at_threshold_abs(rec, Xw, thr, rs)
+            cols = [xp[:, 0], xp[:, 1], Xp[:, 0], Xp[:, 1], Xp[:, 2]]
+            for order in range(3):
+                enabled += _check16_abs(rec, cols, thr * thr, float(np.abs(xp).max()), None, order=order)
+    assert enabled > 400
