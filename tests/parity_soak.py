@@ -16,14 +16,13 @@ import poselib_amd as P  # noqa: E402
 from poselib_amd import synth  # noqa: E402
 
 
-REL_DT_LEN_BOUND = 10.0 * __import__("json").load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                                                                       "relpose_gauge_v1.json")))["measured"]["max_dt_len"]
+from golden.make_gauge import DT_LEN_BOUND as REL_DT_LEN_BOUND  # noqa: E402  (|t| gauge: guarded at 1e-3)
 
 
 def model_diff(kind, a, b):
     """Poses: quaternion and translation; relative poses: R and the DIRECTION of t are held to the tolerance, the LENGTH
     of t - a gauge of the reference's LM (it steps t in its tangent plane and never renormalises; the reference does not
-    reproduce |t| across its own builds: tests/golden/make_gauge.py) - to 10 x the frozen reference-vs-reference spread.
+    reproduce |t| across its own builds: tests/golden/make_gauge.py) - only to the guard of 1e-3.
     Returned: the largest of the components, each divided by its bound and scaled back to the 1e-6 tolerance."""
     if kind in ("abs", "rel"):
         qa, qb = np.asarray(a.q), np.asarray(b[:4])
