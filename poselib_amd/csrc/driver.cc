@@ -2787,9 +2787,12 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     for (int k = 0; k < 4; ++k) {
         std::vector<size_t> &v = by_kind[k];
         std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].n > items[b].n; });
-        for (size_t at = 0; at < v.size(); at += group_max) {
+        // equal shares: ceil(n / group_max) groups of (almost) the same size instead of full groups and a small last one
+        const size_t ngrp = (v.size() + group_max - 1) / group_max;
+        const size_t gsize = ngrp ? (v.size() + ngrp - 1) / ngrp : 1;
+        for (size_t at = 0; at < v.size(); at += gsize) {
             groups.emplace_back();
-            for (size_t j = at; j < std::min(v.size(), at + group_max); ++j) {
+            for (size_t j = at; j < std::min(v.size(), at + gsize); ++j) {
                 GroupItem g;
                 g.item = &items[v[j]];
                 g.kind = k;
