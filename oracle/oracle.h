@@ -31,7 +31,7 @@ typedef struct {
     int32_t loss_type; /* 0 TRIVIAL 1 TRUNCATED 2 HUBER 3 CAUCHY 4 TRUNCATED_CAUCHY 5 TRUNCATED_LE_ZACH */
     int32_t lambda_update; /* 0 NIELSEN 1 FIXED_FACTOR */
     int32_t damping;       /* 0 LEVENBERG 1 MARQUARDT */
-    int32_t reserved;
+    int32_t refine_flags;  /* bit 0 refine_focal_length, bit 1 refine_principal_point, bit 2 refine_extra_params (types.h:92-94) */
     double loss_scale, gradient_tol, step_tol, relative_cost_tol, initial_lambda, min_lambda, max_lambda, lambda_factor;
 } orc_bundle_opt;
 
@@ -105,6 +105,9 @@ void orc_unproject(const orc_camera *cam, const double *xp, size_t n, double *ou
 /* ---- refinement ---- */
 void orc_bundle_adjust(const double *x, const double *X, size_t n, const orc_camera *cam, double *pose7,
                        const orc_bundle_opt *opt, orc_bundle_stats *st);
+/* the same with the camera in / out: the parameters opt->refine_flags names are refined along with the pose */
+void orc_bundle_adjust_camera(const double *x, const double *X, size_t n, orc_camera *cam, double *pose7,
+                              const orc_bundle_opt *opt, orc_bundle_stats *st);
 void orc_refine_relpose(const double *x1, const double *x2, size_t n, double *pose7, const orc_bundle_opt *opt,
                         orc_bundle_stats *st);
 void orc_refine_homography(const double *x1, const double *x2, size_t n, double *H9, const orc_bundle_opt *opt,

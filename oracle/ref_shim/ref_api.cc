@@ -92,6 +92,9 @@ BundleOptions bopt(const orc_bundle_opt &o) {
     b.lambda_update = static_cast<BundleOptions::LambdaUpdateType>(o.lambda_update);
     b.lambda_factor = o.lambda_factor;
     b.damping = static_cast<BundleOptions::DampingType>(o.damping);
+    b.refine_focal_length = (o.refine_flags & 1) != 0;
+    b.refine_principal_point = (o.refine_flags & 2) != 0;
+    b.refine_extra_params = (o.refine_flags & 4) != 0;
     return b;
 }
 void bstats_out(const BundleStats &s, orc_bundle_stats *o) {
@@ -318,6 +321,16 @@ void ref_bundle_adjust(const double *x, const double *X, size_t n, const orc_cam
     image.camera = cam_in(cam);
     bstats_out(bundle_adjust(pts2(x, n), pts3(X, n), &image, bopt(*opt)), st);
     pose_out(image.pose, pose7);
+}
+void ref_bundle_adjust_camera(const double *x, const double *X, size_t n, orc_camera *cam, double *pose7,
+                              const orc_bundle_opt *opt, orc_bundle_stats *st) {
+    Image image;
+    image.pose = pose_in(pose7);
+    image.camera = cam_in(cam);
+    bstats_out(bundle_adjust(pts2(x, n), pts3(X, n), &image, bopt(*opt)), st);
+    pose_out(image.pose, pose7);
+    for (size_t i = 0; i < image.camera.params.size(); ++i)
+        cam->params[i] = image.camera.params[i];
 }
 void ref_refine_relpose(const double *x1, const double *x2, size_t n, double *pose7, const orc_bundle_opt *opt,
                         orc_bundle_stats *st) {

@@ -74,6 +74,9 @@ BundleOptions bopt(const orc_bundle_opt &o) {
     b.lambda_update = o.lambda_update;
     b.lambda_factor = o.lambda_factor;
     b.damping = o.damping;
+    b.refine_focal_length = (o.refine_flags & 1) != 0;
+    b.refine_principal_point = (o.refine_flags & 2) != 0;
+    b.refine_extra_params = (o.refine_flags & 4) != 0;
     return b;
 }
 Camera cam_in(const orc_camera *c) {
@@ -289,6 +292,16 @@ void orc_bundle_adjust(const double *x, const double *X, size_t n, const orc_cam
     im.camera = cam_in(cam);
     const BundleStats s = bundle_adjust(pts2(x, n), pts3(X, n), &im, bopt(*opt));
     pose_out(im.pose, pose7);
+    bstats_out(s, st);
+}
+void orc_bundle_adjust_camera(const double *x, const double *X, size_t n, orc_camera *cam, double *pose7,
+                              const orc_bundle_opt *opt, orc_bundle_stats *st) {
+    Image im;
+    im.pose = pose_in(pose7);
+    im.camera = cam_in(cam);
+    const BundleStats s = bundle_adjust(pts2(x, n), pts3(X, n), &im, bopt(*opt));
+    pose_out(im.pose, pose7);
+    cam_out(im.camera, cam);
     bstats_out(s, st);
 }
 void orc_refine_relpose(const double *x1, const double *x2, size_t n, double *pose7, const orc_bundle_opt *opt,

@@ -117,7 +117,37 @@ V2 Camera::project(const V3 &Z) const {
         throw std::runtime_error("NYI");
     }
 }
-V2 Camera::project_with_jac(const V3 &Z, double J[2][3]) const {
+std::vector<size_t> Camera::refinement_idx(bool focal, bool principal_point, bool extra) const {
+    // focal_idx / principal_point_idx / extra_idx of the models (camera_models.cc:708-710, 759-761, 1036-1038)
+    std::vector<size_t> idx;
+    auto add = [&](std::initializer_list<size_t> v) { idx.insert(idx.end(), v.begin(), v.end()); };
+    switch (model_id) {
+    case CAM_SIMPLE_PINHOLE:
+        if (focal)
+            add({0});
+        if (principal_point)
+            add({1, 2});
+        break;
+    case CAM_PINHOLE:
+        if (focal)
+            add({0, 1});
+        if (principal_point)
+            add({2, 3});
+        break;
+    case CAM_OPENCV:
+        if (focal)
+            add({0, 1});
+        if (principal_point)
+            add({2, 3});
+        if (extra)
+            add({4, 5, 6, 7});
+        break;
+    default: // NULL camera: no parameters
+        break;
+    }
+    return idx;
+}
+V2 Camera::project_with_jac(const V3 &Z, double J[2][3], double (*Jp)[12]) const {
     switch (model_id) {
     case CAM_NULL: {
         const V2 xp{Z.x / Z.z, Z.y / Z.z};
@@ -135,6 +165,18 @@ V2 Camera::project_with_jac(const V3 &Z, double J[2][3]) const {
         const double px = fx * Z.x * zi, py = fy * Z.y * zi;
         J[0][0] = fx * zi, J[0][1] = 0.0, J[0][2] = -px * zi;
         J[1][0] = 0.0, J[1][1] = fy * zi, J[1][2] = -py * zi;
+        if (Jp) { // camera_models.cc:688-698, 739-747
+            if (simple) {
+                Jp[0][0] = Z.x * zi, Jp[1][0] = Z.y * zi;
+                Jp[0][1] = 1.0, Jp[1][1] = 0.0;
+                Jp[0][2] = 0.0, Jp[1][2] = 1.0;
+            } else {
+                Jp[0][0] = Z.x * zi, Jp[1][0] = 0.0;
+                Jp[0][1] = 0.0, Jp[1][1] = Z.y * zi;
+                Jp[0][2] = 1.0, Jp[1][2] = 0.0;
+                Jp[0][3] = 0.0, Jp[1][3] = 1.0;
+            }
+        }
         return V2{px + cx, py + cy};
     }
     case CAM_OPENCV: {
@@ -148,6 +190,18 @@ V2 Camera::project_with_jac(const V3 &Z, double J[2][3]) const {
         for (int b = 0; b < 3; ++b) {
             J[0][b] *= params[0];
             J[1][b] *= params[1];
+        }
+        if (Jp) { // camera_models.cc:953-965 (d distortion / d (k1, k2, p1, p2)), :1005-1021
+            const double u2 = u * u, uv = u * v, v2 = v * v, r2 = u * u + v * v;
+            const double j1[2][4] = {{r2 * u, r2 * r2 * u, 2.0 * uv, (r2 + 2.0 * u2)}, {r2 * v, r2 * r2 * v, (r2 + 2.0 * v2), 2.0 * uv}};
+            Jp[0][0] = du, Jp[1][0] = 0.0;
+            Jp[0][1] = 0.0, Jp[1][1] = dv;
+            Jp[0][2] = 1.0, Jp[1][2] = 0.0;
+            Jp[0][3] = 0.0, Jp[1][3] = 1.0;
+            for (int k = 0; k < 4; ++k) {
+                Jp[0][4 + k] = params[0] * j1[0][k];
+                Jp[1][4 + k] = params[1] * j1[1][k];
+            }
         }
         return V2{params[0] * du + params[2], params[1] * dv + params[3]};
     }
@@ -212,7 +266,7 @@ struct Loss { // robust_loss.h:59-157
 };
 
 // ------------------------------------------------------------------------------------ normal equations
-constexpr int KMAX = 8;
+constexpr int KMAX = 14; // 6 pose parameters + up to 8 camera parameters (OPENCV)
 struct Normal { // jacobian_accumulator.h:46-166.  NB: ONE counter shared by both passes.
     int k;
     const Loss *loss;
@@ -340,7 +394,7 @@ struct Normal { // jacobian_accumulator.h:46-166.  NB: ONE counter shared by bot
 template <typename Problem, typename Model>
 BundleStats levenberg_marquardt(Problem &prob, Model *params, const BundleOptions &opt) { // lm_impl.h:56-140
     Loss loss(opt.loss_type, opt.loss_scale);
-    Normal acc(Problem::K, &loss);
+    Normal acc(prob.k(), &loss);
     BundleStats st;
     acc.reset_residual();
     st.cost = prob.residual(acc, *params);
@@ -362,7 +416,7 @@ BundleStats levenberg_marquardt(Problem &prob, Model *params, const BundleOption
         }
         acc.solve(st.lambda, opt.damping, sol);
         double sn = 0;
-        for (int i = 0; i < Problem::K; ++i)
+        for (int i = 0; i < prob.k(); ++i)
             sn += sol[i] * sol[i];
         st.step_norm = std::sqrt(sn);
         if (st.step_norm < opt.step_tol)
@@ -409,10 +463,11 @@ BundleStats levenberg_marquardt(Problem &prob, Model *params, const BundleOption
 }
 
 // ------------------------------------------------------------------------------------ refiners
-struct AbsProblem { // optim/absolute.h:40-171 with no intrinsics refined
-    static constexpr int K = 6;
+struct AbsProblem { // optim/absolute.h:40-171; cam_idx: the camera parameters refined along with the pose (:130-133, :163-165)
     const std::vector<V2> &x;
     const std::vector<V3> &X;
+    std::vector<size_t> cam_idx;
+    int k() const { return 6 + (int)cam_idx.size(); }
     double residual(Normal &acc, const Image &im) const {
         const M3 R = im.pose.R();
         for (size_t i = 0; i < x.size(); ++i) {
@@ -431,8 +486,8 @@ struct AbsProblem { // optim/absolute.h:40-171 with no intrinsics refined
             const V3 Z = R * Xi + im.pose.t;
             if (Z.z < 0)
                 continue;
-            double Jp[2][3];
-            const V2 p = im.camera.project_with_jac(Z, Jp);
+            double Jp[2][3], Jc[2][12];
+            const V2 p = im.camera.project_with_jac(Z, Jp, cam_idx.empty() ? nullptr : Jc);
             const double r0 = p.x - x[i].x, r1 = p.y - x[i].y;
             double dZ[2][3];
             for (int a = 0; a < 2; ++a)
@@ -446,6 +501,8 @@ struct AbsProblem { // optim/absolute.h:40-171 with no intrinsics refined
                 J[a][3] = dZ[a][0];
                 J[a][4] = dZ[a][1];
                 J[a][5] = dZ[a][2];
+                for (size_t c = 0; c < cam_idx.size(); ++c)
+                    J[a][6 + c] = Jc[a][cam_idx[c]];
             }
             acc.add_jacobian(r0, r1, J);
         }
@@ -455,6 +512,8 @@ struct AbsProblem { // optim/absolute.h:40-171 with no intrinsics refined
         out.camera = im.camera;
         out.pose.q = quat_step_post(im.pose.q, V3{dp[0], dp[1], dp[2]});
         out.pose.t = im.pose.t + im.pose.rotate(V3{dp[3], dp[4], dp[5]});
+        for (size_t c = 0; c < cam_idx.size(); ++c)
+            out.camera.params[cam_idx[c]] += dp[6 + c];
         return out;
     }
 };
@@ -503,6 +562,7 @@ inline double sampson_residual(const M3 &E, const V2 &a, const V2 &b) { // relat
 
 struct RelProblem { // optim/relative.h:86-166
     static constexpr int K = 5;
+    int k() const { return K; }
     const std::vector<V2> &x1;
     const std::vector<V2> &x2;
     V3 tb0, tb1; // tangent basis of the translation, refreshed by jacobian()
@@ -570,6 +630,7 @@ struct RelProblem { // optim/relative.h:86-166
 
 struct HomProblem { // optim/homography.h:46-178 : symmetric transfer error, first 8 entries of H (column-major)
     static constexpr int K = 8;
+    int k() const { return K; }
     const std::vector<V2> &x1;
     const std::vector<V2> &x2;
     static M3 adjugate(const M3 &H) {
@@ -658,6 +719,7 @@ struct FactF { // optim_utils.h:57-82 (Bartoli-Sturm factorisation)
 
 struct FundProblem { // optim/fundamental.h:41-121
     static constexpr int K = 7;
+    int k() const { return K; }
     const std::vector<V2> &x1;
     const std::vector<V2> &x2;
     double residual(Normal &acc, const FactF &ff) const {
@@ -768,9 +830,8 @@ void svd3(const M3 &Ain, M3 &U, double s[3], M3 &V) {
 
 // ------------------------------------------------------------------------------------ entry points
 BundleStats bundle_adjust(const std::vector<V2> &x, const std::vector<V3> &X, Image *image, const BundleOptions &opt) {
-    if (opt.refine_focal_length || opt.refine_extra_params || opt.refine_principal_point)
-        throw std::runtime_error("oracle: intrinsics refinement is outside the hot-path scope (SURVEY.md 8a)");
-    AbsProblem prob{x, X};
+    // bundle.cc:99-103: the camera parameters named by the options are refined along with the pose
+    AbsProblem prob{x, X, image->camera.refinement_idx(opt.refine_focal_length, opt.refine_principal_point, opt.refine_extra_params)};
     return levenberg_marquardt(prob, image, opt);
 }
 BundleStats bundle_adjust(const std::vector<V2> &x, const std::vector<V3> &X, Pose *pose, const BundleOptions &opt) {

@@ -58,8 +58,10 @@ struct Camera {
     V3 unproject3(const V2 &xp) const;
     // camera_models.h:98-102 : pixel -> normalised image plane point
     V2 unproject(const V2 &xp) const;
-    // projection with d(xp)/d(Z) (2x3, row-major)
-    V2 project_with_jac(const V3 &Z, double J[2][3]) const;
+    // projection with d(xp)/d(Z) (2x3, row-major) and, when Jp is given, d(xp)/d(params) (2 x num_params)
+    V2 project_with_jac(const V3 &Z, double J[2][3], double (*Jp)[12] = nullptr) const;
+    // camera_models.cc:545-560: the parameters a bundle adjustment refines (focal, principal point, extra - in this order)
+    std::vector<size_t> refinement_idx(bool focal, bool principal_point, bool extra) const;
     V2 project(const V3 &Z) const;
 };
 

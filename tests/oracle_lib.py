@@ -27,7 +27,7 @@ class RansacOpt(C.Structure):
 
 class BundleOpt(C.Structure):
     _fields_ = [("max_iterations", u64), ("loss_type", i32), ("lambda_update", i32), ("damping", i32),
-                ("reserved", i32), ("loss_scale", f64), ("gradient_tol", f64), ("step_tol", f64),
+                ("refine_flags", i32), ("loss_scale", f64), ("gradient_tol", f64), ("step_tol", f64),
                 ("relative_cost_tol", f64), ("initial_lambda", f64), ("min_lambda", f64), ("max_lambda", f64),
                 ("lambda_factor", f64)]
 
@@ -103,7 +103,8 @@ def bundle_opt(d=None) -> BundleOpt:
     d = d or {}
     lt = d.get("loss_type", "CAUCHY")
     lt = LOSS[lt] if isinstance(lt, str) else int(lt)
-    return BundleOpt(d.get("max_iterations", 100), lt, int(d.get("lambda_update", 0)), int(d.get("damping", 0)), 0,
+    flags = (1 if d.get("refine_focal_length") else 0) | (2 if d.get("refine_principal_point") else 0) | (4 if d.get("refine_extra_params") else 0)
+    return BundleOpt(d.get("max_iterations", 100), lt, int(d.get("lambda_update", 0)), int(d.get("damping", 0)), flags,
                      d.get("loss_scale", 1.0), d.get("gradient_tol", 1e-12), d.get("step_tol", 1e-8),
                      d.get("relative_cost_tol", 1e-10), d.get("initial_lambda", 1e-3), d.get("min_lambda", 1e-10),
                      d.get("max_lambda", 1e10), d.get("lambda_factor", 10.0))
@@ -253,6 +254,18 @@ def bundle_adjust(x, X, cam_dict, pose7, bopt=None):
     return p, st
 
 
+def bundle_adjust_camera(x, X, cam_dict, pose7, bopt=None):
+    """bundle_adjust with the camera in / out: bopt["refine_focal_length" / "refine_principal_point" / "refine_extra_params"]
+    name the parameters refined along with the pose.  Returns (pose, camera parameters, stats)."""
+    x, X = _f(x), _f(X)
+    p = _f(pose7).copy()
+    c = camera(cam_dict)
+    o = bundle_opt(bopt)
+    st = BundleStats()
+    lib().orc_bundle_adjust_camera(_p(x), _p(X), C.c_size_t(x.shape[0]), C.byref(c), _p(p), C.byref(o), C.byref(st))
+    return p, np.array(c.params[: c.num_params]), st
+
+
 def refine(kind, x1, x2, model, bopt=None):
     x1, x2 = _f(x1), _f(x2)
     o = bundle_opt(bopt)
@@ -310,7 +323,7 @@ def ransac_homography(x1, x2, opt=None, init=None):
     return _run_mat("orc_ransac_homography", x1, x2, opt, init)
 
 
-def estimate_absolute_pose(p2d, p3d, cam_dict, opt=None, init_pose=None):
+def estimate_absolute_pose(p2d, p3d, cam_dict, opt=None, init_pose=None, return_camera=False):
     a, b = _f(p2d), _f(p3d)
     n = a.shape[0]
     pose = np.array([1.0, 0, 0, 0, 0, 0, 0]) if init_pose is None else _f(init_pose).copy()
@@ -320,6 +333,8 @@ def estimate_absolute_pose(p2d, p3d, cam_dict, opt=None, init_pose=None):
     c = camera(cam_dict)
     lib().orc_estimate_absolute_pose(_p(a), _p(b), C.c_size_t(n), C.byref(o), C.byref(c), _p(pose), _p(mask),
                                      C.byref(st))
+    if return_camera:
+        return pose, mask[:n].astype(bool), stats_dict(st), np.array(c.params[: c.num_params])
     return pose, mask[:n].astype(bool), stats_dict(st)
 
 

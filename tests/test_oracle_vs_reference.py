@@ -325,6 +325,31 @@ BOPTS = [
 ]
 
 
+REFINE_FLAGS = [{"refine_focal_length": True},
+                {"refine_principal_point": True},
+                {"refine_focal_length": True, "refine_principal_point": True},
+                {"refine_focal_length": True, "refine_extra_params": True},
+                {"refine_focal_length": True, "refine_principal_point": True, "refine_extra_params": True}]
+
+
+def _camera_cases(d):
+    f, cx, cy = d["camera"]["params"]
+    pix = np.asarray(d["p2d"])
+    par = [f, f, cx, cy, -0.05, 0.01, 1e-3, -5e-4]
+    return [(d["camera"], pix),
+            (dict(d["camera"], model="PINHOLE", params=[f, f, cx, cy]), pix),
+            (dict(d["camera"], model="OPENCV", params=par), synth.opencv_distort_pixels(pix, par))]
+
+
+def _off_calibration(cam, rs, rel=0.03, pp=4.0):
+    """start the refinement from intrinsics that are a few per cent off"""
+    par = np.array(cam["params"], dtype=np.float64)
+    nf = {"SIMPLE_PINHOLE": 1, "PINHOLE": 2, "OPENCV": 2}[cam["model"]]
+    par[:nf] *= 1.0 + rel * rs.randn(nf)
+    par[nf:nf + 2] += pp * rs.randn(2)
+    return dict(cam, params=[float(v) for v in par])
+
+
 # ------------------------------------------------------------------------------- front-ends (the real robust.cc)
 def _opencv_scene(n, seed):
     d = synth.absolute_pose_scene(n, 0.4, seed)
@@ -368,6 +393,22 @@ def test_estimate_absolute_pose(seed):  # robust.cc estimate_absolute_pose, BASE
     st, exact = _cmp_frontend("estimate_absolute_pose", (d["p2d"], d["p3d"], d["camera"]), opt)
     assert st["num_inliers"] > 600
     print("estimate_absolute_pose bit-identical:", exact)
+
+
+@pytest.mark.parametrize("flags", REFINE_FLAGS[2:], ids=lambda f: "+".join(sorted(k[7:] for k in f)))
+def test_estimate_absolute_pose_refining_intrinsics(flags):
+    """robust.cc:36-126 with opt.bundle.refine_*: RANSAC + LO at the given calibration, the final bundle moves the camera"""
+    rs = np.random.RandomState(37)
+    d = synth.absolute_pose_scene(1200, 0.4, 811)
+    for cam, pix in _camera_cases(d):
+        cam0 = _off_calibration(cam, rs, 0.01, 2.0)
+        opt = {"max_error": 8.0, "ransac": {"seed": 3, "max_iterations": 2000}, "bundle": dict(flags)}
+        (ma, ka, sa, ca), (mb, kb, sb, cb) = both("estimate_absolute_pose", pix, d["p3d"], cam0, opt, return_camera=True)
+        for k in ("iterations", "refinements", "num_inliers"):
+            assert sa[k] == sb[k], (k, sa, sb)
+        assert np.array_equal(ka, kb) and sa["num_inliers"] > 300
+        assert np.abs(ma - mb).max() < 1e-8 and np.abs(ca - cb).max() < 1e-6 * max(1.0, np.abs(ca).max())
+        assert abs(ca[0] - d["camera"]["params"][0]) < abs(cam0["params"][0] - d["camera"]["params"][0])  # focal moved towards the truth
 
 
 @pytest.mark.parametrize("seed", [0, 1])
@@ -472,6 +513,26 @@ def test_lm_absolute_pose_through_camera_models(model):  # the final polish of e
     for bo in ({"loss_type": "TRUNCATED", "loss_scale": 2.0, "max_iterations": 25}, {"loss_type": "CAUCHY", "loss_scale": 1.0}):
         (pa, sa), (pb, sb) = both("bundle_adjust", pix, d["p3d"], cam, start, bo)
         _cmp_lm(sa, sb, pa, pb)
+
+
+@pytest.mark.parametrize("flags", REFINE_FLAGS, ids=lambda f: "+".join(sorted(k[7:] for k in f)))
+def test_lm_absolute_pose_with_intrinsics(flags):
+    """bundle_adjust with refine_focal_length / refine_principal_point / refine_extra_params (robust/bundle.cc:93-118
+    -> AbsolutePoseRefiner with Camera::get_param_refinement_idx, camera_models.cc: project_with_jac's parameter block)"""
+    rs = np.random.RandomState(36)
+    d = synth.absolute_pose_scene(500, 0.2, 745)
+    start = _perturb_pose(np.r_[d["q_gt"], d["t_gt"]], rs, 0.003)
+    for cam, pix in _camera_cases(d):
+        cam0 = _off_calibration(cam, rs)
+        for bo in ({"loss_type": "CAUCHY", "loss_scale": 1.0}, {"loss_type": "TRUNCATED", "loss_scale": 6.0, "max_iterations": 25}):
+            (pa, ca, sa), (pb, cb, sb) = both("bundle_adjust_camera", pix, d["p3d"], cam0, start, dict(bo, **flags))
+            _cmp_lm(sa, sb, np.r_[pa, ca / 1000.0], np.r_[pb, cb / 1000.0])
+            assert ca.shape == (len(cam["params"]),)
+            if not flags.get("refine_extra_params") and cam["model"] == "OPENCV":
+                assert np.array_equal(ca[4:], np.asarray(cam0["params"])[4:])   # untouched parameters pass through
+            if not flags.get("refine_principal_point"):
+                npp = {"SIMPLE_PINHOLE": 1, "PINHOLE": 2, "OPENCV": 2}[cam["model"]]
+                assert np.array_equal(ca[npp:npp + 2], np.asarray(cam0["params"])[npp:npp + 2])
 
 
 @pytest.mark.parametrize("bo", BOPTS)
