@@ -63,7 +63,10 @@ typedef struct {
     int32_t damping;         /* 0 LEVENBERG, 1 MARQUARDT */
     int32_t verbose;         /* ignored */
     double loss_scale, gradient_tol, step_tol, relative_cost_tol, initial_lambda, min_lambda, max_lambda, lambda_factor;
-    int32_t refine_focal_length, refine_extra_params, refine_principal_point; /* must be 0 (out of scope) */
+    /* types.h:92-94.  Used by pl_estimate_absolute_pose's final bundle (robust.cc:103-123), its batched form and
+     * pl_bundle_adjust_camera: the selected intrinsics of the camera move with the pose and are returned.  The two-view
+     * refiners have no camera to move: ignored there, as in the reference. */
+    int32_t refine_focal_length, refine_extra_params, refine_principal_point;
     int32_t reserved;
 } pl_bundle_options;
 
@@ -229,6 +232,12 @@ int pl_debug_device_math(int fn, const double *x, size_t n, double *out);
  * flagged correspondences only. */
 int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera *camera, const uint8_t *mask,
                     void *model, uint32_t *lm_iterations);
+
+/* bundle_adjust(points2D, points3D, Camera &, CameraPose *, BundleOptions) of robust/bundle.h:45-50 / bundle.cc:93-118 on
+ * an absolute-pose problem whose 2-D points are PIXELS: pose and, per opt->refine_focal_length / refine_principal_point /
+ * refine_extra_params, the camera's intrinsics are refined together (robust/optim/absolute.h:49-171); both in / out. */
+int pl_bundle_adjust_camera(pl_problem *p, const pl_bundle_options *opt, pl_camera *camera, const uint8_t *mask,
+                            pl_camera_pose *pose, uint32_t *lm_iterations);
 
 /* ---- minimal solvers (solvers/ headers); unit bearing vectors in, solutions out; return = #solutions or <0 ---- */
 int pl_p3p(const double *x /* 3x3 */, const double *X /* 3x3 */, pl_camera_pose *out /* 4 */);

@@ -140,6 +140,7 @@ def _declare(L):
         "pl_debug_score_stream": (cint, [vp, vp, sz, dbl, vp, vp, P(C.c_int32)]),
         "pl_debug_device_math": (cint, [cint, vp, sz, vp]),
         "pl_refine_model": (cint, [vp, P(BundleOptions), cam, vp, vp, P(C.c_uint32)]),
+        "pl_bundle_adjust_camera": (cint, [vp, P(BundleOptions), cam, vp, P(CameraPose), P(C.c_uint32)]),
         "pl_p3p": (cint, [vp, vp, P(CameraPose)]),
         "pl_relpose_5pt": (cint, [vp, vp, P(CameraPose)]),
         "pl_essential_matrix_5pt": (cint, [vp, vp, vp]),
@@ -166,7 +167,7 @@ EXPORTED_SYMBOLS = [
     "pl_default_ransac_options", "pl_default_bundle_options", "pl_default_robust_options", "pl_device_count",
     "pl_set_device", "pl_last_error", "pl_version", "pl_estimate_absolute_pose", "pl_estimate_relative_pose",
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
-    "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_p3p", "pl_relpose_5pt",
+    "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_bundle_adjust_camera", "pl_p3p", "pl_relpose_5pt",
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
     "pl_ransac_batch", "pl_debug_device_math",
 ]

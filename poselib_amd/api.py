@@ -534,6 +534,21 @@ class Problem:
         L.check(L.lib().pl_refine_model(self._h, C.byref(o), *args_tail, _ptr(M), C.byref(it)))
         return M.reshape(3, 3).T.copy(), it.value
 
+    def bundle_adjust(self, pose, camera, bundle_opt=None, mask=None):
+        """poselib.bundle_adjust(points2D, points3D, camera, pose, opt) on the resident points (2-D points in pixels):
+        refines the pose and - with refine_focal_length / refine_principal_point / refine_extra_params - the camera's
+        intrinsics (robust/bundle.cc:93-118).  Returns (pose, camera, LM iterations)."""
+        assert self.kind == KIND_ABS
+        o = _robust_options({"bundle": bundle_opt or {}}, self.kind, False).bundle
+        cam = _as_camera(camera)
+        c = cam._c()
+        it = C.c_uint32(0)
+        m8 = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        m = _cpose(pose)
+        L.check(L.lib().pl_bundle_adjust_camera(self._h, C.byref(o), C.byref(c), None if m8 is None else _ptr(m8), C.byref(m),
+                                                C.byref(it)))
+        return _pypose(m), Camera(cam.model_id, list(c.params[: c.num_params]), cam.width, cam.height), it.value
+
     def close(self):
         if self._h:
             L.lib().pl_problem_destroy(self._h)

@@ -18,6 +18,7 @@
 // There is no CPU fallback for any device stage: without a HIP device the entry points fail.
 #include "../../include/poselib_amd.h"
 #include "pl_kernels.h"
+#include "pl_refine_cam.h"
 #include "pl_sampler.h"
 
 #include <algorithm>
@@ -259,6 +260,14 @@ LMOptions to_lm(const pl_bundle_options &b) {
     o.max_lambda = b.max_lambda;
     o.lambda_factor = b.lambda_factor;
     return o;
+}
+// bundle.refine_* as CamRefineFlags, reduced to the flags that select at least one parameter of the model (0: the pose alone,
+// k_lm's case)
+int active_cam_flags(int model_id, const pl_bundle_options &b) {
+    const int flags = (b.refine_focal_length ? CAM_REFINE_FOCAL : 0) | (b.refine_principal_point ? CAM_REFINE_PRINCIPAL : 0) |
+                      (b.refine_extra_params ? CAM_REFINE_EXTRA : 0);
+    int idx[kCamMaxParams];
+    return camera_refinement_idx(model_id, flags, idx) > 0 ? flags : 0;
 }
 LMOptions lo_options(double max_error) { // estimators/absolute_pose.cc:61-64 (identical in the four estimators)
     pl_bundle_options b;
@@ -579,7 +588,9 @@ struct RefineJob {
     double point_scale = 1.0;
     double prefilter_thr2 = 0.0;
     const uint8_t *d_mask = nullptr;
+    int cam_flags = 0; // absolute pose: CamRefineFlags, the intrinsics refined with the pose (k_lm_cam)
     // outputs
+    CameraParams cam_out;
     double record_out[kModelStride];
     double params_out[kParamDoubles];
     uint32_t count = 0;
@@ -633,7 +644,12 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         max_it = std::max(max_it, jobs[j].opt.max_iterations);
     }
     const uint32_t lm2_min_points = (p->kind == EST_ABS) ? 8192u : 2560u;
-    const bool use_lm2 = latency_mode && p->kind != EST_REL && same_it && max_it >= 1 && max_it <= 32 && p->n >= lm2_min_points;
+    bool with_camera = false;
+    for (uint32_t j = 0; j < nj; ++j)
+        with_camera = with_camera || jobs[j].cam_flags != 0;
+    if (with_camera && p->kind != EST_ABS)
+        return fail(PL_ERR_INVALID, "camera intrinsics are refined with absolute poses only");
+    const bool use_lm2 = !with_camera && latency_mode && p->kind != EST_REL && same_it && max_it >= 1 && max_it <= 32 && p->n >= lm2_min_points;
     if (use_lm2)
         HIP_TRY(c->lm_tasks.ensure(stage_bytes));
     LMTask *ht = c->h_tasks.as<LMTask>();
@@ -649,6 +665,7 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         t.opt = jobs[j].opt;
         t.cam = jobs[j].cam;
         t.point_scale = jobs[j].point_scale;
+        t.cam_flags = jobs[j].cam_flags;
         t.prefilter_thr2 = jobs[j].prefilter_thr2;
         t.mask = jobs[j].d_mask;
         t.scratch = c->lm_scratch.as<uint8_t>() + (size_t)j * p->n;
@@ -669,6 +686,11 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         // upload above has read it)
         HIP_TRY(launch_task_records(p->kind, d_tasks, d_records_in, c->lm_records.as<double>(), nj,
                                     c->h_tasks.dev<LMTask>(), c->stream));
+    } else if (with_camera) { // (tasks of such a call without flags: M = 0 is not a k_lm_cam case)
+        for (uint32_t j = 0; j < nj; ++j)
+            if (!jobs[j].cam_flags)
+                return fail(PL_ERR_INVALID, "refinement jobs with and without intrinsics in one launch");
+        HIP_TRY(launch_lm_cam(d_tasks, nj, c->stream));
     } else {
         HIP_TRY(launch_lm(p->kind, p->ps, d_tasks, nj, c->stream)); // outputs + refined records: written by k_lm itself
     }
@@ -693,6 +715,7 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
     for (uint32_t j = 0; j < nj; ++j) {
         jobs[j].skipped = ht[j].skipped != 0;
         std::memcpy(jobs[j].params_out, ht[j].params, sizeof(double) * kParamDoubles);
+        jobs[j].cam_out = ht[j].cam;
         if (jobs[j].skipped) // refinement not run: model unchanged (relative_pose.cc:75-77)
             std::memcpy(jobs[j].record_out, jobs[j].record_in, sizeof(double) * kModelStride);
         else
@@ -1579,8 +1602,8 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
 int validate_options(const pl_robust_options *o) {
     if (!o)
         return fail(PL_ERR_INVALID, "options pointer is null");
-    if (o->bundle.refine_focal_length || o->bundle.refine_extra_params || o->bundle.refine_principal_point)
-        return fail(PL_ERR_UNSUPPORTED, "intrinsics refinement is outside the accelerated hot path");
+    // (bundle.refine_*: used by the absolute-pose front-end's final bundle, robust.cc:103-123; the other front-ends'
+    // refiners have no camera to move, the reference ignores the flags there and so does this library)
     if (o->tangent_sampson || o->estimate_focal_length || o->estimate_extra_params)
         return fail(PL_ERR_UNSUPPORTED, "tangent-Sampson / focal-length estimation are outside the accelerated hot path");
     return PL_OK;
@@ -1832,7 +1855,8 @@ int run_with_model(Context *c, pl_problem *p, const pl_robust_options *o, void *
 
 // Final polish on the inliers (device mask from ransac_core is still in c->mask).
 int final_refine(Context *c, pl_problem *p, const double *record_in, const LMOptions &opt, const CameraParams &cam,
-                 double point_scale, double *record_out, double *params_out) {
+                 double point_scale, double *record_out, double *params_out, int cam_flags = 0,
+                 CameraParams *cam_out = nullptr) {
     RefineJob j;
     std::memcpy(j.record_in, record_in, sizeof(j.record_in));
     j.opt = opt;
@@ -1840,10 +1864,13 @@ int final_refine(Context *c, pl_problem *p, const double *record_in, const LMOpt
     j.point_scale = point_scale;
     j.prefilter_thr2 = 0.0;
     j.d_mask = c->mask.as<uint8_t>();
+    j.cam_flags = cam_flags;
     std::vector<RefineJob> jobs{j};
     int rc = run_refinements(c, p, jobs, false, 0.0);
     if (rc != PL_OK)
         return rc;
+    if (cam_out)
+        *cam_out = jobs[0].cam_out;
     std::memcpy(record_out, jobs[0].record_out, sizeof(double) * kModelStride);
     if (params_out)
         std::memcpy(params_out, jobs[0].params_out, sizeof(double) * kParamDoubles);
@@ -2157,8 +2184,8 @@ int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera
                     void *model, uint32_t *lm_iterations) {
     if (!p || !model || !opt)
         return fail(PL_ERR_INVALID, "problem / options / model pointer is null");
-    if (opt->refine_focal_length || opt->refine_extra_params || opt->refine_principal_point)
-        return fail(PL_ERR_UNSUPPORTED, "intrinsics refinement is outside the accelerated hot path");
+    if (p->kind == EST_ABS && camera && active_cam_flags(to_cam(camera).model_id, *opt))
+        return fail(PL_ERR_INVALID, "refine_* moves the camera: call pl_bundle_adjust_camera (camera in / out)");
     if (camera && !camera_supported(camera))
         return fail(PL_ERR_UNSUPPORTED, "camera model not supported (NULL, SIMPLE_PINHOLE, PINHOLE, OPENCV)");
     Context *c;
@@ -2197,6 +2224,49 @@ int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera
             M.m[i] = jobs[0].record_out[kMatOff + i];
         mat_to_colmajor(M, static_cast<double *>(model));
     }
+    return PL_OK;
+}
+
+// bundle_adjust(points2D, points3D, Camera &, CameraPose *, BundleOptions) of robust/bundle.cc:93-118 on an absolute-pose
+// problem holding PIXEL coordinates: the pose and - per opt->refine_focal_length / refine_principal_point /
+// refine_extra_params - the camera's intrinsics, both in / out.
+int pl_bundle_adjust_camera(pl_problem *p, const pl_bundle_options *opt, pl_camera *camera, const uint8_t *mask,
+                            pl_camera_pose *pose, uint32_t *lm_iterations) {
+    if (!p || !pose || !opt || !camera)
+        return fail(PL_ERR_INVALID, "problem / options / camera / pose pointer is null");
+    if (p->kind != EST_ABS)
+        return fail(PL_ERR_INVALID, "pl_bundle_adjust_camera refines absolute poses");
+    if (!camera_supported(camera))
+        return fail(PL_ERR_UNSUPPORTED, "camera model not supported (NULL, SIMPLE_PINHOLE, PINHOLE, OPENCV)");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    if (p->device != c->device)
+        return fail(PL_ERR_INVALID, "problem lives on another device than the calling thread's");
+    RefineJob j;
+    record_from_pose(pose, false, j.record_in);
+    j.opt = to_lm(*opt);
+    j.cam = to_cam(camera);
+    j.cam_flags = active_cam_flags(j.cam.model_id, *opt);
+    j.point_scale = 1.0;
+    j.prefilter_thr2 = 0.0;
+    j.d_mask = nullptr;
+    if (mask && p->n) {
+        HIP_TRY(c->mask.ensure(p->n));
+        HIP_TRY(hipMemcpyAsync(c->mask.p, mask, p->n, hipMemcpyHostToDevice, c->stream));
+        j.d_mask = c->mask.as<uint8_t>();
+    }
+    std::vector<RefineJob> jobs{j};
+    rc = run_refinements(c, p, jobs, false, 0.0);
+    if (rc != PL_OK)
+        return rc;
+    if (lm_iterations)
+        *lm_iterations = c->h_tasks.as<LMTask>()[0].iterations;
+    pose_from_record(jobs[0].record_out, pose);
+    if (j.cam_flags)
+        for (int i = 0; i < camera->num_params && i < 12; ++i)
+            camera->params[i] = jobs[0].cam_out.p[i];
     return PL_OK;
 }
 
@@ -2280,13 +2350,16 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
         CameraParams cs = cam;
         camera_rescale(cs, scale);
         double out[kModelStride];
-        rc = final_refine(c, &pp, rec, to_lm(b), cs, scale, out, nullptr);
+        // bundle.refine_*: the intrinsics the model has among them move with the pose (bundle.cc:93-118)
+        const int cam_flags = active_cam_flags(cs.model_id, opt->bundle);
+        CameraParams refined = cs;
+        rc = final_refine(c, &pp, rec, to_lm(b), cs, scale, out, nullptr, cam_flags, &refined);
         free_problem(&pp);
         if (rc != PL_OK)
             return rc;
         pose_from_record(out, pose);
         // camera.rescale(scale) ... rescale(1/scale) round trip of the reference (robust.cc:119-121)
-        CameraParams back = cs;
+        CameraParams back = cam_flags ? refined : cs;
         camera_rescale(back, 1.0 / scale);
         for (int i = 0; i < camera->num_params && i < 12; ++i)
             camera->params[i] = back.p[i];

@@ -1,0 +1,268 @@
+// poselib_amd — k_lm_cam: Levenberg-Marquardt on (pose, camera intrinsics) for the absolute-pose bundle adjustment with
+// refine_focal_length / refine_principal_point / refine_extra_params (gfx950, wave64; -ffp-contract=off like kernels.hip).
+// Reference: robust/bundle.cc:93-118, robust/optim/absolute.h:49-171, misc/camera_models.cc (parameter Jacobians),
+// robust/optim/lm_impl.h:56-140.  The arithmetic is pl_refine_cam.h / pl_refine.h, shared with the host test build.
+//
+// One workgroup of 256 lanes per task, the whole LM loop on the device.  K = 6 + M columns, M = 1..8 refined parameters:
+// the normal equations have up to 119 entries, too many for per-lane accumulators (k_lm's way), so the two halves of a
+// Jacobian pass take turns over rounds of 256 correspondences:
+//   producers  every lane evaluates one correspondence and writes its row [w, w r0, w r1, J0[14], J1[14]] to LDS; rows of
+//              correspondences without contribution (masked out, behind the camera, weight zero) are dropped by a
+//              ballot + prefix compaction that keeps ascending order;
+//   consumers  lane e < K(K+1)/2 + K owns entry e of [JtJ lower triangle | Jtr] and adds the round's rows to it one
+//              after the other.
+// Every entry is therefore summed correspondence after correspondence - the reference's order
+// (jacobian_accumulator.h:82-97) - for EVERY n, not only up to kLMSeqPoints as in k_lm: the refined pose and camera
+// equal the oracle's to the bit whenever the robust cost does (n <= 256: summed in order as well; beyond that the cost
+// is a tree sum).  The consumer loop is LDS-bandwidth bound (5 reads of 8 bytes per entry and row: ~40 cycles per
+// correspondence); the final bundle runs once per problem, on the inliers.
+#include "pl_kernels.h"
+#include "pl_device.h"
+#include "pl_refine_cam.h"
+#include <atomic>
+
+namespace pl {
+
+namespace {
+
+constexpr int kCamThreads = 256;
+constexpr int kCamWaves = kCamThreads / 64;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+} // namespace
+
+__global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
+    extern __shared__ double s_rows[]; // kCamThreads x kCamRow
+    __shared__ LMTask s_task;
+    __shared__ LMControl ctl;
+    __shared__ double cur[kParamDoubles], trial[kParamDoubles];
+    __shared__ CameraParams cam_cur, cam_trial;
+    __shared__ double s_R[9];
+    __shared__ double normal[kCamMaxEntries];
+    __shared__ double s_wsum[kCamWaves];
+    __shared__ uint32_t s_wcnt[kCamWaves];
+    __shared__ double s_racc;
+    __shared__ uint32_t s_count;
+    __shared__ int s_idx[kCamMaxParams];
+    __shared__ int s_M;
+
+    LMTask &Tout = tasks[blockIdx.x];
+    {
+        static_assert(sizeof(LMTask) % 8 == 0, "copied as 64-bit words");
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(&Tout);
+        uint64_t *dst = reinterpret_cast<uint64_t *>(&s_task);
+        for (uint32_t w = threadIdx.x; w < sizeof(LMTask) / 8; w += kCamThreads)
+            dst[w] = src[w];
+        __syncthreads();
+    }
+    const LMTask &T = s_task;
+    const PointSet pts = T.pts;
+    const uint8_t *mask = T.mask;
+    const double pscale = T.point_scale;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < kParamDoubles; ++i)
+            cur[i] = T.params[i];
+        cam_cur = T.cam;
+        ctl.opt = T.opt;
+        ctl.loss = make_loss(T.opt.loss_type, T.opt.loss_scale);
+        ctl.done = 0;
+        int idx[kCamMaxParams];
+        const int M = camera_refinement_idx(T.cam.model_id, T.cam_flags, idx);
+        for (int m = 0; m < kCamMaxParams; ++m)
+            s_idx[m] = (m < M) ? idx[m] : 0;
+        s_M = M;
+    }
+    __syncthreads();
+    const int M = s_M, K = 6 + M;
+    const int NT = K * (K + 1) / 2 + K;
+    int ci = 0, cj = -1;
+    if ((int)threadIdx.x < NT)
+        cam_entry_columns((int)threadIdx.x, K, s_idx, ci, cj);
+
+    auto rotation_of = [&](const double *p) {
+        if (threadIdx.x == 0) {
+            Quat q;
+            q.w = p[0], q.x = p[1], q.y = p[2], q.z = p[3];
+            const Mat3 R = quat_to_rotmat(q);
+            for (int i = 0; i < 9; ++i)
+                s_R[i] = R.m[i];
+        }
+        __syncthreads();
+    };
+
+    // robust cost at (p, cam) -> s_racc, s_count
+    auto cost_pass = [&](const double *p, const CameraParams &camera) {
+        rotation_of(p);
+        const Loss loss = ctl.loss;
+        const CameraParams cam = camera;
+        if (pts.n <= (uint32_t)kCamThreads) { // in the reference's order
+            double term = 0.0;
+            bool counted = false;
+            const uint32_t i = threadIdx.x;
+            if (i < pts.n && !(mask && !mask[i]))
+                counted = abs_cam_cost(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
+                                       pts.a[4][i], term);
+            s_rows[threadIdx.x] = counted ? term : 0.0; // (x + 0.0 = x)
+            const uint64_t b = __builtin_amdgcn_ballot_w64(counted);
+            if (lane == 0)
+                s_wcnt[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tot = 0.0;
+                for (uint32_t q = 0; q < pts.n; ++q)
+                    tot += s_rows[q];
+                s_racc = tot;
+                uint32_t c = 0;
+                for (int w = 0; w < kCamWaves; ++w)
+                    c += s_wcnt[w];
+                s_count = c;
+            }
+            __syncthreads();
+            return;
+        }
+        double racc = 0.0;
+        uint32_t cnt = 0;
+        for (uint32_t i = threadIdx.x; i < pts.n; i += kCamThreads) {
+            if (mask && !mask[i])
+                continue;
+            double term;
+            if (abs_cam_cost(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i], pts.a[4][i],
+                             term)) {
+                racc += term;
+                cnt++;
+            }
+        }
+        const double ws = wave_sum_f64(racc);
+        const uint32_t wc = wave_sum_u32(cnt);
+        if (lane == 0) {
+            s_wsum[wave] = ws;
+            s_wcnt[wave] = wc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            uint32_t c = 0;
+            for (int w = 0; w < kCamWaves; ++w) {
+                tot += s_wsum[w];
+                c += s_wcnt[w];
+            }
+            s_racc = tot;
+            s_count = c;
+        }
+        __syncthreads();
+    };
+
+    // normal equations at (p, cam) -> normal[0 .. NT), s_count
+    auto jacobian_pass = [&](const double *p, const CameraParams &camera) {
+        rotation_of(p);
+        const Loss loss = ctl.loss;
+        const CameraParams cam = camera;
+        double acc = 0.0;
+        uint32_t total = 0; // (uniform)
+        for (uint32_t base = 0; base < pts.n; base += kCamThreads) {
+            const uint32_t i = base + threadIdx.x;
+            double row[kCamRow];
+            bool kept = false;
+            if (i < pts.n && !(mask && !mask[i]))
+                kept = abs_cam_row(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
+                                   pts.a[4][i], row);
+            const uint64_t b = __builtin_amdgcn_ballot_w64(kept);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (lane == 0)
+                s_wcnt[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            uint32_t off = 0, round_rows = 0;
+#pragma unroll
+            for (int w = 0; w < kCamWaves; ++w) {
+                const uint32_t c = s_wcnt[w];
+                off += (w < wave) ? c : 0u;
+                round_rows += c;
+            }
+            if (kept) {
+                double *dst = s_rows + (size_t)(off + below) * kCamRow;
+#pragma unroll
+                for (int k = 0; k < kCamRow; ++k)
+                    dst[k] = row[k];
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < NT) {
+                const double *r = s_rows;
+                for (uint32_t q = 0; q < round_rows; ++q, r += kCamRow)
+                    acc += cam_entry_term(r, ci, cj);
+            }
+            total += round_rows;
+            __syncthreads(); // (s_wcnt and the rows are rewritten by the next round)
+        }
+        if ((int)threadIdx.x < NT)
+            normal[threadIdx.x] = acc;
+        if (threadIdx.x == 0)
+            s_count = total;
+        __syncthreads();
+    };
+
+    cost_pass(cur, cam_cur);
+    if (threadIdx.x == 0)
+        lm_begin(ctl, T.opt, s_racc, s_count);
+    __syncthreads();
+
+    while (!ctl.done) {
+        const bool fresh = ctl.rejac != 0;
+        if (fresh)
+            jacobian_pass(cur, cam_cur);
+        if (threadIdx.x == 0) {
+            lm_solve_k(K, ctl, normal, fresh, s_count);
+            if (!ctl.done)
+                abs_cam_step(cur, cam_cur, ctl.sol, s_idx, M, trial, cam_trial);
+        }
+        __syncthreads();
+        if (ctl.done)
+            break;
+        cost_pass(trial, cam_trial);
+        if (threadIdx.x == 0) {
+            if (lm_update_k(K, ctl, normal, s_racc, s_count)) {
+                for (int i = 0; i < kParamDoubles; ++i)
+                    cur[i] = trial[i];
+                cam_cur = cam_trial;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < kParamDoubles; ++i)
+            Tout.params[i] = cur[i];
+        Tout.cam = cam_cur;
+        Tout.iterations = ctl.iterations;
+        Tout.skipped = 0u;
+        Tout.cost = ctl.cost;
+        Tout.initial_cost = ctl.initial_cost;
+        if (T.record_out)
+            record_from_lm_params(EST_ABS, cur, T.record_out);
+    }
+}
+
+hipError_t launch_lm_cam(LMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
+    if (num_tasks == 0)
+        return hipSuccess;
+    constexpr size_t bytes = sizeof(double) * kCamThreads * kCamRow;
+    static std::atomic<int> prepared{0};
+    if (!prepared.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm_cam), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bytes);
+        if (e != hipSuccess)
+            return e;
+        prepared.store(1, std::memory_order_release);
+    }
+    k_lm_cam<<<dim3(num_tasks), dim3(kCamThreads), bytes, stream>>>(tasks);
+    return hipGetLastError();
+}
+
+} // namespace pl

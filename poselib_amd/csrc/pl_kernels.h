@@ -87,6 +87,8 @@ struct LMTask {
     uint8_t *scratch;      // n bytes, used by the prefilter
     const double *record_in; // k_lm: the seed's model record (kept when the refinement is skipped) ...
     double *record_out;      // ... and where the refined model's record goes (device memory); nullptr: no record
+    int32_t cam_flags;       // k_lm_cam: CamRefineFlags (pl_refine_cam.h) - the intrinsics refined with the pose; `cam` is in/out
+    int32_t pad0;
     // outputs
     uint32_t iterations, skipped;
     double cost, initial_cost;
@@ -318,6 +320,8 @@ hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipSt
 hipError_t launch_group_finalize_records(const GroupArgs *args, const GroupDims &d, hipStream_t stream);
 // LM over the tasks of many problems: every task carries its own correspondences (LMTask.pts)
 hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream);
+// absolute pose + camera intrinsics (lm_cam.hip): tasks with cam_flags != 0; refined pose -> params / record_out, camera -> cam
+hipError_t launch_lm_cam(LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
 int group_points_per_lane(int est); // P of the group launches (fixed per estimator)
 
 // Bare solver entry points (one problem per lane); inputs/outputs in HBM.

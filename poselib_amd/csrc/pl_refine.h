@@ -301,7 +301,7 @@ struct LMControl {
     uint32_t count; // the accumulator's single residual counter (see header comment)
     int32_t rejac;
     int32_t done;
-    double sol[8];
+    double sol[16]; // (up to 14: pose + 8 camera parameters, pl_refine_cam.h)
 };
 
 PL_HD double lm_scale(uint32_t count) { return 1.0 / fmax(1.0, (double)count); }

@@ -7,6 +7,7 @@
 // Built by tests/hostmath/Makefile with g++ -ffp-contract=off.
 #include "../../poselib_amd/csrc/pl_prefilter.h"
 #include "../../poselib_amd/csrc/pl_refine.h"
+#include "../../poselib_amd/csrc/pl_refine_cam.h"
 #include "../../poselib_amd/csrc/pl_sampler.h"
 #include "../../poselib_amd/csrc/pl_score.h"
 #include "../../poselib_amd/csrc/pl_solver_h4.h"
@@ -453,6 +454,81 @@ void hm_lm(int est, const double *const *pa, uint32_t n, double *params, const L
     default:
         lm_serial<EST_HOM>(pa, n, params, *opt, *cam, point_scale, prefilter_thr2, mask, iterations, skipped);
     }
+}
+
+// Serial evaluation of k_lm_cam's algorithm (lm_cam.hip): the same rows, the same per-entry sums in correspondence order.
+void hm_lm_cam(const double *const *pa, uint32_t n, double *params, const LMOptions *opt, CameraParams *cam_io, int cam_flags,
+               double point_scale, const uint8_t *mask, uint32_t *iterations, double *costs /* initial, final */) {
+    LMControl ctl;
+    ctl.opt = *opt;
+    ctl.loss = make_loss(opt->loss_type, opt->loss_scale);
+    ctl.done = 0;
+    double cur[kParamDoubles], trial[kParamDoubles];
+    std::memcpy(cur, params, sizeof(cur));
+    CameraParams cam_cur = *cam_io, cam_trial = *cam_io;
+    int idx[kCamMaxParams];
+    const int M = camera_refinement_idx(cam_cur.model_id, cam_flags, idx);
+    const int K = 6 + M, NT = K * (K + 1) / 2 + K;
+    double normal[kCamMaxEntries], racc = 0;
+    uint32_t count = 0;
+    double R[9];
+    auto rotation_of = [&](const double *p) {
+        Quat q;
+        q.w = p[0], q.x = p[1], q.y = p[2], q.z = p[3];
+        const Mat3 Rm = quat_to_rotmat(q);
+        for (int i = 0; i < 9; ++i)
+            R[i] = Rm.m[i];
+    };
+    auto cost_pass = [&](const double *p, const CameraParams &cam) {
+        rotation_of(p);
+        racc = 0, count = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            double term;
+            if (mask && !mask[i])
+                continue;
+            if (abs_cam_cost(p, R, cam, ctl.loss, pa[0][i] * point_scale, pa[1][i] * point_scale, pa[2][i], pa[3][i], pa[4][i], term))
+                racc += term, count++;
+        }
+    };
+    auto jacobian_pass = [&](const double *p, const CameraParams &cam) {
+        rotation_of(p);
+        for (int e = 0; e < NT; ++e)
+            normal[e] = 0;
+        count = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            double row[kCamRow];
+            if (mask && !mask[i])
+                continue;
+            if (!abs_cam_row(p, R, cam, ctl.loss, pa[0][i] * point_scale, pa[1][i] * point_scale, pa[2][i], pa[3][i], pa[4][i], row))
+                continue;
+            for (int e = 0; e < NT; ++e) {
+                int ci, cj;
+                cam_entry_columns(e, K, idx, ci, cj);
+                normal[e] += cam_entry_term(row, ci, cj);
+            }
+            count++;
+        }
+    };
+    cost_pass(cur, cam_cur);
+    lm_begin(ctl, *opt, racc, count);
+    while (!ctl.done) {
+        const bool fresh = ctl.rejac != 0;
+        if (fresh)
+            jacobian_pass(cur, cam_cur);
+        lm_solve_k(K, ctl, normal, fresh, count);
+        if (ctl.done)
+            break;
+        abs_cam_step(cur, cam_cur, ctl.sol, idx, M, trial, cam_trial);
+        cost_pass(trial, cam_trial);
+        if (lm_update_k(K, ctl, normal, racc, count)) {
+            std::memcpy(cur, trial, sizeof(cur));
+            cam_cur = cam_trial;
+        }
+    }
+    std::memcpy(params, cur, sizeof(cur));
+    *cam_io = cam_cur;
+    *iterations = ctl.iterations;
+    costs[0] = ctl.initial_cost, costs[1] = ctl.cost;
 }
 
 void hm_factorized_F(const double *params, double *F) { factorized_F(params, F); }

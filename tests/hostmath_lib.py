@@ -207,6 +207,21 @@ def lm(est, cols, params, opt: LMOptions, cam: CameraParams = None, point_scale=
     return p, it.value, bool(sk.value)
 
 
+def lm_cam(cols, params, opt: LMOptions, cam: CameraParams, cam_flags, point_scale=1.0, mask=None):
+    """k_lm_cam's algorithm serially: (pose parameters, camera parameters, iterations, (initial cost, cost))"""
+    arrs, ptrs = _soa(cols)
+    n = arrs[0].shape[0]
+    p = np.zeros(16)
+    p[: len(params)] = params
+    c = CameraParams.from_buffer_copy(cam)
+    it = C.c_uint32(0)
+    costs = np.zeros(2)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().hm_lm_cam(ptrs, C.c_uint32(n), _p(p), C.byref(opt), C.byref(c), C.c_int(cam_flags), C.c_double(point_scale),
+                    None if m is None else _p(m), C.byref(it), _p(costs))
+    return p, np.array(c.p[: c.num_params]), it.value, costs
+
+
 def factorized_F(params):
     p = np.zeros(16)
     p[: len(params)] = params

@@ -75,7 +75,7 @@ def test_no_gpu_means_loud_failure_not_fallback():
 def test_unsupported_options_are_rejected():
     o = L.RobustOptions()
     L.lib().pl_default_robust_options(C.byref(o), 0)
-    o.bundle.refine_focal_length = 1  # intrinsics refinement is outside the accelerated path
+    o.tangent_sampson = 1  # the tangent-Sampson camera estimator is outside the accelerated path
     st = L.RansacStats()
     pose = L.CameraPose()
     rc = L.lib().pl_ransac_pnp(None, None, C.c_size_t(0), C.byref(o), C.byref(pose), None, C.byref(st))

@@ -159,3 +159,45 @@ def test_lm_refiners_bit_exact():
     got, it, skipped = HM.lm("rel", [a[:, 0], a[:, 1], b[:, 0], b[:, 1]], p0, HM.lm_options(25, 1, thr),
                              prefilter_thr2=5 * thr * thr)
     assert not skipped and it == st.iterations and (got[:7] == ref).all()
+
+
+def test_lm_with_intrinsics_bit_exact():
+    """k_lm_cam's arithmetic (pl_refine_cam.h, serial on the host) against the oracle's bundle_adjust with refine_* flags
+    (itself bit-identical with the reference sources: test_oracle_vs_reference.py): pose, camera, iterations, cost."""
+    rs = np.random.RandomState(5)
+    d = synth.absolute_pose_scene(700, 0.3, 1010)
+    f, cx, cy = d["camera"]["params"]
+    pix = np.asarray(d["p2d"])
+    par = [f, f, cx, cy, -0.05, 0.01, 1e-3, -5e-4]
+    cases = [(0, "SIMPLE_PINHOLE", [f, cx, cy], pix), (1, "PINHOLE", [f, f, cx, cy], pix),
+             (4, "OPENCV", par, synth.opencv_distort_pixels(pix, par))]
+    q = d["q_gt"] + 0.003 * rs.randn(4)
+    p0 = np.r_[q / np.linalg.norm(q), d["t_gt"] + 0.003 * rs.randn(3)]
+    m = d["inlier_gt"]
+    checked = 0
+    for mid, name, params, px in cases:
+        nf = 1 if mid == 0 else 2
+        off = np.array(params, dtype=np.float64)
+        off[:nf] *= 1.0 + 0.02 * rs.randn(nf)
+        off[nf:nf + 2] += 3.0 * rs.randn(2)
+        cols = [px[:, 0], px[:, 1], d["p3d"][:, 0], d["p3d"][:, 1], d["p3d"][:, 2]]
+        for flags in (1, 2, 3, 5, 7):
+            for loss, lscale, mi in ((3, 1.0, 100), (1, 6.0, 25), (2, 2.0, 40)):
+                bo = dict(loss_type=loss, loss_scale=lscale, max_iterations=mi, refine_focal_length=bool(flags & 1),
+                          refine_principal_point=bool(flags & 2), refine_extra_params=bool(flags & 4))
+                rp, rc, st = O.bundle_adjust_camera(px[m], d["p3d"][m], {"model": name, "params": list(off)}, p0, bo)
+                gp, gc, it, costs = HM.lm_cam(cols, p0, HM.lm_options(mi, loss, lscale), HM.camera_params(mid, list(off)), flags,
+                                              mask=m)
+                assert it == st.iterations, (name, flags, loss)
+                assert (gp[:7] == rp).all() and (gc == rc).all(), (name, flags, loss, np.abs(gp[:7] - rp).max(), np.abs(gc - rc).max())
+                assert costs[1] == st.cost and costs[0] == st.initial_cost
+                checked += 1
+    assert checked == 45
+    # the final bundle's form (robust.cc:103-123): pixels * 1/f, camera rescaled, all flags
+    scale = 1.0 / f
+    camp = [f * scale, cx * scale, cy * scale]
+    bo = dict(loss_type=3, loss_scale=scale, refine_focal_length=True, refine_principal_point=True)
+    rp, rc, st = O.bundle_adjust_camera(pix[m] * scale, d["p3d"][m], {"model": "SIMPLE_PINHOLE", "params": camp}, p0, bo)
+    cols = [pix[:, 0], pix[:, 1], d["p3d"][:, 0], d["p3d"][:, 1], d["p3d"][:, 2]]
+    gp, gc, it, _ = HM.lm_cam(cols, p0, HM.lm_options(100, 3, scale), HM.camera_params(0, camp), 3, point_scale=scale, mask=m)
+    assert it == st.iterations and (gp[:7] == rp).all() and (gc == rc).all()
