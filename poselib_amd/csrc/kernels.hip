@@ -115,10 +115,9 @@ template <int EST> __device__ __forceinline__ uint32_t generate_one(const Genera
             xb[k] = bearing(g.pts.a[0][idx[k]], g.pts.a[1][idx[k]]);
             Xp[k] = v3(g.pts.a[2][idx[k]], g.pts.a[3][idx[k]], g.pts.a[4][idx[k]]);
         }
-        P3PSolution sol[4];
-        n = p3p(xb[0], xb[1], xb[2], Xp[0], Xp[1], Xp[2], sol);
-        for (int m = 0; m < n; ++m)
-            n_nan += store_pose_model(rec + m * kModelStride, sol[m].R, sol[m].t, false) ? 1u : 0u;
+        n = p3p_emit(xb[0], xb[1], xb[2], Xp[0], Xp[1], Xp[2], [&](int m, const Mat3 &R, const Vec3 &t) {
+            n_nan += store_pose_model(rec + m * kModelStride, R, t, false) ? 1u : 0u;
+        });
     } else {
         Vec3 b1[K], b2[K];
 #pragma unroll
@@ -1301,7 +1300,9 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6,
 // minimum) and the re-scored refined models - is recomputed here exactly like the reference does it: one workgroup per
 // model; the threads evaluate the correspondences of a chunk in parallel and compact the inliers' squared residuals
 // in index order into LDS (block scan), one lane adds them sequentially.
-constexpr int kSeqThreads = 1024, kSeqPerThread = 8, kSeqChunk = kSeqThreads * kSeqPerThread; // 64 KB of LDS
+// (32 KB of LDS: the workgroup fits next to two workgroups of the streaming scorers - with 64 KB it waited for a scoring
+// launch's tail whenever another group's scorer held the device, like the orbit kernel's large build, pipeline.hip)
+constexpr int kSeqThreads = 1024, kSeqPerThread = 4, kSeqChunk = kSeqThreads * kSeqPerThread;
 
 template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScoreArgs &a) {
     constexpr int ND = point_doubles(EST);

@@ -21,6 +21,8 @@
 #include "pl_kernels.h"
 #include "pl_refine.h"
 #include "pl_sampler.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace pl {
 
@@ -97,9 +99,20 @@ template <int K> __global__ __launch_bounds__(256) void k_sample_delta_g(const G
                          reinterpret_cast<uint32_t *>(g.samp.ctl), g.samp.zero_words);
 }
 
+// Capacities of the orbit walk's LDS tables, two builds of the kernel:
+//   large  8192 flagged positions (position + delta + successor), 4096 of them followed by pointer doubling, 4096 segments:
+//          ~140 KB of LDS - the workgroup needs a CU to itself;
+//   small  2048 / 2048 / 2048: 56 KB - fits next to two workgroups of the streaming scorers (50.7 KB each, three per CU),
+//          i.e. it starts as soon as ONE scoring workgroup anywhere on the device retires.  With several groups in flight the
+//          large build waited for a whole CU to drain, which under a scoring launch of another group means waiting for that
+//          launch's tail (measured r03: 3.0 ms average in the grouped trace against 23 us alone).
+// The host picks the small build when the expected number of flagged positions (M x P[a sample of K draws out of N repeats
+// an index]) is at most kOrbitSmallExpected; more flags than the tables hold => orbit_error => the caller's fallback, as before.
 constexpr int kMaxSegments = 4096;
-constexpr int kMaxFlags = 8192;  // flagged positions kept in LDS (position + delta + successor); more => host fallback
-constexpr int kParFlags = 4096;  // up to this many flags the orbit is followed by pointer doubling (all lanes)
+constexpr int kMaxFlags = 8192;
+constexpr int kParFlags = 4096;
+constexpr int kSmallFlags = 2048;
+constexpr double kOrbitSmallExpected = 1200.0; // (Poisson: 2048 is 24 standard deviations above)
 constexpr int kOrbitWords = 4;   // bitmap words per lane and tile of phase 1
 
 __device__ __forceinline__ uint32_t div_k(uint32_t x, int K) { // constant divisors compile to a multiply-high
@@ -115,19 +128,20 @@ __device__ __forceinline__ uint32_t div_k(uint32_t x, int K) { // constant divis
     }
 }
 
+template <int MAXF, int PARF, int MAXSEG>
 __device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const uint64_t *flagbits, uint32_t M, int K,
                                                   uint32_t B, uint64_t pos_base, uint32_t *positions, BatchCtl *ctl) {
     __shared__ uint32_t wave_tot[16], wave_off[16];
-    __shared__ uint32_t flag_pos[kMaxFlags];
-    __shared__ uint8_t flag_delta[kMaxFlags];
-    __shared__ uint16_t flag_next[kMaxFlags]; // next flag on the orbit that passes through this flag (0xffff: none)
-    __shared__ uint32_t seg_iter[kMaxSegments];
-    __shared__ uint32_t seg_pos[kMaxSegments];
+    __shared__ uint32_t flag_pos[MAXF];
+    __shared__ uint8_t flag_delta[MAXF];
+    __shared__ uint16_t flag_next[MAXF]; // next flag on the orbit that passes through this flag (0xffff: none)
+    __shared__ uint32_t seg_iter[MAXSEG];
+    __shared__ uint32_t seg_pos[MAXSEG];
     __shared__ uint32_t s_nseg, s_nflags, s_error, s_entry;
     // pointer doubling over the flags (phase 2b, parallel form)
-    __shared__ uint32_t pj_w[kParFlags], pj_rank[kParFlags];
-    __shared__ uint16_t pj_next[kParFlags], pj_hops[kParFlags];
-    __shared__ uint8_t pj_mark[kParFlags];
+    __shared__ uint32_t pj_w[PARF], pj_rank[PARF];
+    __shared__ uint16_t pj_next[PARF], pj_hops[PARF];
+    __shared__ uint8_t pj_mark[PARF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     // ---- phase 1: ordered list (in LDS) of the positions whose iteration would redraw (delta != K), from the
@@ -160,7 +174,7 @@ __device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const ui
                 s += wave_tot[w];
             }
             s_nflags = s;
-            if (s > (uint32_t)kMaxFlags)
+            if (s > (uint32_t)MAXF)
                 s_error = 1u;
         }
         __syncthreads();
@@ -206,12 +220,12 @@ __device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const ui
 
     // ---- phase 2b: the orbit through the flags, as (iteration, position) segments.  A flag j visited by the orbit
     // starts a segment at iteration it_j = it_prev + (q_j - cur_prev) / K + 1 with position cur_j = q_j + delta_j.
-    // Up to kParFlags flags the successor links are followed by POINTER DOUBLING: every flag carries its 2^k-th successor
+    // Up to PARF flags the successor links are followed by POINTER DOUBLING: every flag carries its 2^k-th successor
     // and the iterations that lie between; the flags reachable from the entry are marked round by round (after round k
     // all flags within 2^(k+1) hops) and receive their iteration index and hop count on the way - 12 rounds of all
     // lanes instead of one lane hopping ~300 times through LDS (22 us -> 4 us at config 1).  Beyond that: one lane. ----
-    if (!s_error && F <= (uint32_t)kParFlags) {
-        constexpr int kPer = kParFlags / 1024;
+    if (!s_error && F <= (uint32_t)PARF) {
+        constexpr int kPer = PARF / 1024;
         const uint32_t entry = s_entry;
         for (uint32_t j = threadIdx.x; j < F; j += 1024u) {
             const uint32_t nj = flag_next[j];
@@ -262,7 +276,7 @@ __device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const ui
             if (!pj_mark[j] || pj_rank[j] > B)
                 continue;
             const uint32_t idx = (uint32_t)pj_hops[j] + 1u;
-            if (flag_delta[j] == 255u || idx >= (uint32_t)kMaxSegments) {
+            if (flag_delta[j] == 255u || idx >= (uint32_t)MAXSEG) {
                 s_error = 1;
                 continue;
             }
@@ -292,7 +306,7 @@ __device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const ui
             if (it + before >= B)
                 break; // the batch ends before that iteration
             const uint32_t d = flag_delta[j];
-            if (d == 255u || nseg >= (uint32_t)kMaxSegments) {
+            if (d == 255u || nseg >= (uint32_t)MAXSEG) {
                 err = 1;
                 break;
             }
@@ -356,17 +370,35 @@ __device__ __forceinline__ void sample_orbit_body(const uint8_t *delta, const ui
         positions[i] = cur_pos + (i - cur_it) * (uint32_t)K;
     }
 }
+template <bool SMALL>
 __global__ __launch_bounds__(1024) void k_sample_orbit(const uint8_t *delta, const uint64_t *flagbits, uint32_t M, int K,
                                                        uint32_t B, uint64_t pos_base, uint32_t *positions,
                                                        BatchCtl *ctl) {
-    sample_orbit_body(delta, flagbits, M, K, B, pos_base, positions, ctl);
+    if constexpr (SMALL)
+        sample_orbit_body<kSmallFlags, kSmallFlags, kSmallFlags>(delta, flagbits, M, K, B, pos_base, positions, ctl);
+    else
+        sample_orbit_body<kMaxFlags, kParFlags, kMaxSegments>(delta, flagbits, M, K, B, pos_base, positions, ctl);
 }
-__global__ __launch_bounds__(1024) void k_sample_orbit_g(const GroupArgs *ga, int K) {
+template <bool SMALL> __global__ __launch_bounds__(1024) void k_sample_orbit_g(const GroupArgs *ga, int K) {
     const GroupArgs &g = ga[blockIdx.z];
     if (!g.active)
         return;
-    sample_orbit_body(g.samp.delta, g.samp.flagbits, g.samp.M, K, g.samp.B, g.samp.pos_base, g.samp.positions,
-                      g.samp.ctl);
+    if constexpr (SMALL)
+        sample_orbit_body<kSmallFlags, kSmallFlags, kSmallFlags>(g.samp.delta, g.samp.flagbits, g.samp.M, K, g.samp.B, g.samp.pos_base,
+                                                               g.samp.positions, g.samp.ctl);
+    else
+        sample_orbit_body<kMaxFlags, kParFlags, kMaxSegments>(g.samp.delta, g.samp.flagbits, g.samp.M, K, g.samp.B, g.samp.pos_base,
+                                                             g.samp.positions, g.samp.ctl);
+}
+// expected number of flagged positions among M: a position is flagged when the K draws starting there repeat an index
+static bool orbit_small_build(uint32_t M, uint64_t N, int K) {
+    static const bool off = std::getenv("POSELIB_AMD_ORBIT_LARGE") != nullptr;
+    if (off || N == 0)
+        return false;
+    double distinct = 1.0;
+    for (int i = 1; i < K; ++i)
+        distinct *= 1.0 - std::min(1.0, (double)i / (double)N);
+    return (double)M * (1.0 - distinct) <= kOrbitSmallExpected;
 }
 
 // ------------------------------------------------------------------------------------ compaction
@@ -964,7 +996,10 @@ hipError_t launch_sample_positions(int K, uint64_t seed, uint64_t pos_base, uint
     default:
         return hipErrorInvalidValue;
     }
-    k_sample_orbit<<<dim3(1), dim3(1024), 0, stream>>>(delta, flagbits, M, K, B, pos_base, positions, ctl);
+    if (orbit_small_build(M, N, K))
+        k_sample_orbit<true><<<dim3(1), dim3(1024), 0, stream>>>(delta, flagbits, M, K, B, pos_base, positions, ctl);
+    else
+        k_sample_orbit<false><<<dim3(1), dim3(1024), 0, stream>>>(delta, flagbits, M, K, B, pos_base, positions, ctl);
     return hipGetLastError();
 }
 
@@ -1046,7 +1081,10 @@ hipError_t launch_group_positions(int K, const GroupArgs *args, const GroupDims 
     default:
         return hipErrorInvalidValue;
     }
-    k_sample_orbit_g<<<dim3(1, 1, d.G), dim3(1024), 0, stream>>>(args, K);
+    if (orbit_small_build(d.max_M, d.min_n, K))
+        k_sample_orbit_g<true><<<dim3(1, 1, d.G), dim3(1024), 0, stream>>>(args, K);
+    else
+        k_sample_orbit_g<false><<<dim3(1, 1, d.G), dim3(1024), 0, stream>>>(args, K);
     return hipGetLastError();
 }
 hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {

@@ -292,6 +292,7 @@ constexpr int group_mfma2_points_per_lane(int est) { return est == EST_REL ? 5 :
 struct GroupDims { // grid extents: maxima over the active problems of the group
     uint32_t G;          // problems (grid.z)
     uint32_t max_M;      // sampler window
+    uint32_t min_n;      // fewest correspondences (most sample redraws: sizes the orbit kernel's tables)
     uint32_t max_B;      // iterations per batch
     uint32_t max_hcap;   // hypothesis slots
     uint32_t max_chunks, max_slices;

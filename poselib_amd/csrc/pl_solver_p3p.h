@@ -82,8 +82,9 @@ struct P3PSolution {
     Vec3 t;
 };
 
-// x: unit bearings, X: 3-D points.  Returns the number of solutions (<= 4).
-PL_HD int p3p(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, P3PSolution *out) {
+// x: unit bearings, X: 3-D points.  Returns the number of solutions (<= 4); every solution is handed to emit(m, R, t) as
+// soon as it is found (the generator stores it at once: an array of four solutions would cost 96 registers).
+template <typename Emit> PL_HD int p3p_emit(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, Emit &&emit) {
     Vec3 X01 = X0 - X1, X02 = X0 - X2, X12 = X1 - X2;
     double a01 = dot(X01, X01), a02 = dot(X02, X02), a12 = dot(X12, X12);
 
@@ -214,8 +215,7 @@ PL_HD int p3p(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, P3PSolution 
                 set_col(YY, 1, v2);
                 set_col(YY, 2, cross(v1, v2));
                 const Mat3 R = mul(YY, XX);
-                out[n].R = R;
-                out[n].t = d0 * x0 - mul(R, X0);
+                emit(n, R, d0 * x0 - mul(R, X0));
                 ++n;
             }
         }
@@ -223,6 +223,12 @@ PL_HD int p3p(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, P3PSolution 
             break;
     }
     return n;
+}
+PL_HD int p3p(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, P3PSolution *out) {
+    return p3p_emit(x0, x1, x2, X0, X1, X2, [&](int m, const Mat3 &R, const Vec3 &t) {
+        out[m].R = R;
+        out[m].t = t;
+    });
 }
 
 } // namespace pl
