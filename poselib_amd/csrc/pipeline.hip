@@ -421,33 +421,41 @@ __global__ __launch_bounds__(1024) void k_count_blocks(const uint32_t *num_model
 __device__ __forceinline__ void compact2_body(const uint32_t *num_models, uint32_t B, int maxm,
                                               const uint32_t *blk_tot, uint32_t *slots, uint32_t *offsets,
                                               BatchCtl *ctl, uint32_t nblocks, uint32_t *host_offsets) {
-    __shared__ uint32_t wt[16], wo[16];
+    __shared__ uint32_t wt[16], wo[16], wb[16], wn[16];
     __shared__ uint32_t s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
-        uint32_t b = 0;
-        for (uint32_t j = 0; j < blockIdx.x; ++j)
-            b += blk_tot[j];
-        s_base = b;
-    }
+    // models of the blocks before this one (and, in the last block, the generators' NaN-model counts: second table behind
+    // blk_tot, statistics): all lanes fetch, one wave sum each - one lane walking the table paid ~1 us per entry
+    uint32_t before = 0, nan_part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 1024u)
+        before += blk_tot[j];
+    const bool last = blockIdx.x == nblocks - 1;
+    if (last)
+        for (uint32_t j = threadIdx.x; j < nblocks; j += 1024u)
+            nan_part += blk_tot[nblocks + j];
+    before = wsum_u32(before);
+    nan_part = wsum_u32(nan_part);
     const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
     const uint32_t nm = (i < B) ? num_models[i] : 0u;
     const uint32_t inc = wscan_add(nm, lane);
     if (lane == 63)
         wt[wave] = inc;
+    if (lane == 0) {
+        wb[wave] = before;
+        wn[wave] = nan_part;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t s = 0;
+        uint32_t s = 0, b = 0, nan = 0;
         for (int w = 0; w < 16; ++w) {
             wo[w] = s;
             s += wt[w];
+            b += wb[w];
+            nan += wn[w];
         }
-        if (blockIdx.x == nblocks - 1) {
-            ctl->num_hyp = s_base + s;
-            uint32_t nan = 0; // the generators' NaN-model counts (second table behind blk_tot; statistics)
-            const uint32_t *blk_nan = blk_tot + nblocks;
-            for (uint32_t j = 0; j < nblocks; ++j)
-                nan += blk_nan[j];
+        s_base = b;
+        if (last) {
+            ctl->num_hyp = b + s;
             ctl->nan_hyp = nan;
         }
     }
