@@ -2469,7 +2469,12 @@ hipError_t launch_group_batch(int est, const GroupArgs *args, const GroupDims &d
     e = launch_group_finalize_records(args, d, stream);
     if (e != hipSuccess)
         return e;
-    const dim3 sgrid(128, 1, d.G), sblock(kSeqThreads);
+    // candidates per problem: a handful (improving hypotheses of the batch; more than kRecordFirst = 64 sends the problem to
+    // the single-problem path), every workgroup loops over the list with the grid's stride.  With many problems in the group
+    // fewer workgroups per problem: the empty ones still cost a dispatch of 16 wavefronts each (batch_mixed, groups of 128:
+    // 16 384 workgroups per launch, a third of the device time of that workload).
+    const uint32_t per_problem = std::max<uint32_t>(16u, std::min<uint32_t>(128u, 4096u / std::max<uint32_t>(1u, d.G)));
+    const dim3 sgrid(per_problem, 1, d.G), sblock(kSeqThreads);
     PL_DISPATCH_EST(est, k_score_seq_gb<E><<<sgrid, sblock, 0, stream>>>(args));
     return hipGetLastError();
 }
