@@ -43,8 +43,8 @@ pl_robust_options to_pl(int kind, const RansacOptions &r, const BundleOptions &b
     o.bundle.lambda_factor = b.lambda_factor;
     o.bundle.lambda_update = static_cast<int32_t>(b.lambda_update);
     o.bundle.damping = static_cast<int32_t>(b.damping);
-    o.bundle.refine_focal_length = b.refine_focal_length;       // non-zero -> PL_ERR_UNSUPPORTED: keep the CPU
-    o.bundle.refine_extra_params = b.refine_extra_params;       // branch of the reference for those
+    o.bundle.refine_focal_length = b.refine_focal_length;       // (absolute pose: the final bundle moves the camera,
+    o.bundle.refine_extra_params = b.refine_extra_params;       //  robust.cc:103-123; ignored by the two-view refiners)
     o.bundle.refine_principal_point = b.refine_principal_point;
     o.max_error = max_error;
     return o;

@@ -19,8 +19,8 @@ for w in relpose_5000 fund_10000 hom_10000; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$w -o r -- python $R/bench.py $Q --workload $w --mode streams --streams 1 --steps 3 > $O/prof_$w.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/profg_$w -o r -- python $R/bench.py $Q --workload $w --steps 3 > $O/profg_$w.log 2>&1
 done
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_batch -o r -- python $R/bench_batch.py --problems 4096 --streams 8 --steps 2 --no-cpu-baseline > $O/prof_batch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_batch -o k -- python $R/bench_batch.py --problems 4096 --streams 8 --steps 2 --no-cpu-baseline > $O/kt_batch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_batch -o r -- python $R/bench_batch.py --problems 4096 --streams 8 --steps 2 --warmup 3 --no-cpu-baseline > $O/prof_batch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_batch -o k -- python $R/bench_batch.py --problems 4096 --streams 8 --steps 2 --warmup 3 --no-cpu-baseline > $O/kt_batch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_gen -o r -- $R/scripts/exp/genbench 1600000 16 2 > $O/genbench.txt 2>&1
 for w in p3p_5000 relpose_5000 fund_10000 hom_10000; do
   B1="python $R/bench.py $Q --workload $w --mode streams --streams 1 --steps 2 --warmup 1"
