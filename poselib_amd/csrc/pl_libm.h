@@ -56,25 +56,33 @@ constexpr double kS1 = -0x1.5555555555555p-3, kS2 = 0x1.1111111110ECEp-7, kS3 = 
 constexpr double kBig = 0x1.8p45;                                        // 1.5 * 2^45: rounds to multiples of 2^-7
 constexpr double kHp0 = 0x1.921FB54442D18p0, kHp1 = 0x1.1A62633145C07p-54; // pi / 2 in two parts
 
-PL_HD double do_cos(double x, double dx) {
+// FMA = true: the operation sequence of glibc's -mfma variants (__sin_fma / __cos_fma: every mad below is ONE fused operation in
+// that binary); FMA = false: the same source without contractions (the sse2 build - what `sincos` is on x86-64: it has no FMA variant)
+template <bool FMA> PL_HD double mad(double a, double b, double c) {
+    if constexpr (FMA)
+        return pl_fma(a, b, c);
+    else
+        return a * b + c;
+}
+template <bool FMA = true> PL_HD double do_cos(double x, double dx) {
     if (x < 0)
         dx = -dx;
     const double u = kBig + fabs(x);
     const int k = (int)pl_lo(u);
     x = fabs(x) - (u - kBig) + dx;
     const double xx = x * x;
-    const double s = pl_fma(x * xx, pl_fma(xx, kSn5, kSn3), x);
-    const double c = xx * pl_fma(xx, pl_fma(xx, kCs6, kCs4), kCs2);
+    const double s = mad<FMA>(x * xx, mad<FMA>(xx, kSn5, kSn3), x);
+    const double c = xx * mad<FMA>(xx, mad<FMA>(xx, kCs6, kCs4), kCs2);
     const double sn = kSinCosTab[k][0], ssn = kSinCosTab[k][1], cs = kSinCosTab[k][2], ccs = kSinCosTab[k][3];
-    const double cor = pl_fma(-s, sn, pl_fma(-c, cs, pl_fma(-s, ssn, ccs)));
+    const double cor = mad<FMA>(-s, sn, mad<FMA>(-c, cs, mad<FMA>(-s, ssn, ccs)));
     return cs + cor;
 }
-PL_HD double do_sin(double x, double dx) {
+template <bool FMA = true> PL_HD double do_sin(double x, double dx) {
     const double xold = x;
     if (fabs(x) < 0.126) { // TAYLOR_SIN
         const double xx = x * x;
-        const double p = pl_fma(xx, pl_fma(xx, pl_fma(xx, pl_fma(xx, kS5, kS4), kS3), kS2), kS1);
-        const double t = pl_fma(xx, pl_fma(p, x, -(0.5 * dx)), dx);
+        const double p = mad<FMA>(xx, mad<FMA>(xx, mad<FMA>(xx, mad<FMA>(xx, kS5, kS4), kS3), kS2), kS1);
+        const double t = mad<FMA>(xx, mad<FMA>(p, x, -(0.5 * dx)), dx);
         return x + t;
     }
     if (x <= 0)
@@ -83,10 +91,10 @@ PL_HD double do_sin(double x, double dx) {
     const int k = (int)pl_lo(u);
     x = fabs(x) - (u - kBig);
     const double xx = x * x;
-    const double s = x + pl_fma(x * xx, pl_fma(xx, kSn5, kSn3), dx);
-    const double c = pl_fma(dx, x, xx * pl_fma(xx, pl_fma(xx, kCs6, kCs4), kCs2));
+    const double s = x + mad<FMA>(x * xx, mad<FMA>(xx, kSn5, kSn3), dx);
+    const double c = mad<FMA>(dx, x, xx * mad<FMA>(xx, mad<FMA>(xx, kCs6, kCs4), kCs2));
     const double sn = kSinCosTab[k][0], ssn = kSinCosTab[k][1], cs = kSinCosTab[k][2], ccs = kSinCosTab[k][3];
-    const double cor = pl_fma(s, cs, pl_fma(-c, sn, pl_fma(s, ccs, ssn)));
+    const double cor = mad<FMA>(s, cs, mad<FMA>(-c, sn, mad<FMA>(s, ccs, ssn)));
     return copysign(sn + cor, xold);
 }
 } // namespace libm_detail
@@ -139,6 +147,59 @@ PL_HD double pl_sin(double x) {
         return copysign(do_cos(t, kHp1), x);
     }
     return sin(x); // not reached
+}
+
+// sin and cos of the SAME argument: s_sincos.c __sincos, the sse2 build (libm exports one `sincos`, without an FMA variant).
+// quat_exp (misc/quaternion.h:73-96) calls std::cos and std::sin on theta / 2; GCC merges the two calls into one sincos()
+// at -O1 and above, so the reference's Release build - and the oracle - step their quaternions with THESE roundings, which
+// differ from sin() / cos() of the same machine in the last bit for 0.1 % (sin) and 0.03 % (cos) of the arguments below 0.86
+// (measured on 2*10^7 arguments; found by scripts/soak_intrinsics.py as a one-ulp difference of an LM step).
+// tests/test_libm_vs_glibc.py checks it bit for bit against the host's sincos().
+PL_HD void pl_sincos(double x, double &sn, double &cs) {
+    using namespace libm_detail;
+    const uint32_t k = pl_hi(x) & 0x7fffffffu;
+    if (k < 0x400368fdu) {
+        if (k < 0x3e400000u) { // |x| < 2^-27
+            sn = x;
+            cs = 1.0;
+            return;
+        }
+        if (k < 0x3feb6000u) { // |x| < 0.855469
+            sn = do_sin<false>(x, 0.0);
+            cs = do_cos<false>(x, 0.0);
+            return;
+        }
+        const double y = kHp0 - fabs(x); // |x| < 2.426265
+        const double a = y + kHp1;
+        const double da = (y - a) + kHp1;
+        sn = copysign(do_cos<false>(a, da), x);
+        cs = do_sin<false>(a, da);
+        return;
+    }
+    if (k < 0x419921FBu) { // reduce_sincos + do_sincos(n), do_sincos(n + 1)
+        constexpr double hpinv = 0x1.45F306DC9C883p-1, toint = 0x1.8p52;
+        constexpr double mp1 = 0x1.921FB58000000p0, mp2 = -0x1.DDE973C000000p-27, pp3 = -0x1.CB3B398000000p-55,
+                         pp4 = -0x1.d747f23e32ed7p-83;
+        const double t = x * hpinv + toint;
+        const double xn = t - toint;
+        const double y = (x - xn * mp1) - xn * mp2;
+        const int n = (int)(pl_lo(t) & 3u);
+        double t1 = xn * pp3;
+        const double t2 = y - t1;
+        double db = (y - t2) - t1;
+        t1 = xn * pp4;
+        const double b = t2 - t1;
+        db += (t2 - b) - t1;
+        auto pick = [&](int m) {
+            const double r = (m & 1) ? do_cos<false>(b, db) : do_sin<false>(b, db);
+            return (m & 2) ? -r : r;
+        };
+        sn = pick(n);
+        cs = pick(n + 1);
+        return;
+    }
+    sn = sin(x); // (rotation increments of an LM step never get here)
+    cs = cos(x);
 }
 
 // ---- acos (e_asin.c __ieee754_acos, FMA variant) -----------------------------------------------------------------------

@@ -185,8 +185,9 @@ PL_HD Quat quat_exp(Vec3 w) { // quaternion.h:73-96
     const double th = sqrt(th2);
     double re, im;
     if (th > 1e-6) {
-        re = pl_cos(0.5 * th); // (pl_libm.h: rounds like the reference's host libm)
-        im = pl_sin(0.5 * th) / th;
+        double sn; // (pl_libm.h pl_sincos: cos and sin of one argument are ONE sincos() call in the reference's build)
+        pl_sincos(0.5 * th, sn, re);
+        im = sn / th;
     } else {
         const double th4 = th2 * th2;
         re = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;

@@ -15,6 +15,8 @@
 #include "../../poselib_amd/csrc/pl_solver_rel.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -566,6 +568,26 @@ uint64_t hm_cbrt_mismatches(uint64_t count, uint64_t seed, int mode, double *fir
     return bad;
 }
 double hm_cbrt(double x) { return pl_cbrt(x); }
+double hm_sin(double x) { return pl_sin(x); }
+double hm_cos(double x) { return pl_cos(x); }
+// pl_sincos against the host's sincos(): number of arguments (three ranges) on which either result differs in any bit
+uint64_t hm_sincos_mismatches(uint64_t count, uint64_t seed, double *first_bad) {
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 88172645463325252ull, bad = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+        const double u = (double)(s >> 11) / 9007199254740992.0;
+        const double x = (i % 4 == 0) ? (u * 12 - 6) : (i % 4 == 1) ? u * 0.9 : (i % 4 == 2) ? (u * 4.8 - 2.4) : std::ldexp(2 * u - 1, -(int)((s >> 3) % 40));
+        double a, b, c, d;
+        pl_sincos(x, a, b);
+        sincos(x, &c, &d);
+        if (std::memcmp(&a, &c, 8) != 0 || std::memcmp(&b, &d, 8) != 0) {
+            if (!bad && first_bad)
+                *first_bad = x;
+            ++bad;
+        }
+    }
+    return bad;
+}
 
 // which: 0 acos on (-1, 1) incl. the interval edges of its piecewise expansion, 1 cos on [-6, 6] and tiny arguments,
 // 2 sin on [-2.4, 2.4] and tiny arguments: arguments on which pl_libm.h and the host's libm differ in any bit

@@ -52,6 +52,18 @@ def test_acos_cos_sin_are_bit_identical_to_glibc():
         assert bad == 0, (name, bad, bad_x.value.hex())
 
 
+def test_sincos_is_bit_identical_to_glibc():
+    """pl_sincos = what quat_exp's cos / sin pair IS in the reference's gcc build (one sincos() call; libm's sincos has no FMA
+    variant and differs from sin() / cos() of the same host in the last bit for ~0.1 % of the arguments): 2*10^7 arguments in
+    [-6, 6], [0, 0.9], [-2.4, 2.4] and down to 2^-40, every bit of both results"""
+    L = HM.lib()
+    L.hm_sincos_mismatches.restype = C.c_uint64
+    L.hm_sincos_mismatches.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
+    bad_x = C.c_double(0.0)
+    bad = L.hm_sincos_mismatches(20_000_000, 11, C.byref(bad_x))
+    assert bad == 0, (bad, bad_x.value.hex())
+
+
 def test_device_form_of_the_nielsen_cube_against_glibc_pow():
     """pl_refine.h lm_cube_fma - what the DEVICE computes for std::pow(2 rho - 1, 3) of the LM's Nielsen update
     (lm_impl.h:124); the host test build calls pow itself.  Two-product FMA form, nearly correctly rounded: it must equal
