@@ -202,7 +202,21 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // problem at a time 0.768 -> 0.743 ms per 100000-iteration P3P problem (three synchronisations each), but -13 % on the
 // grouped batch (8 host threads) and -1 % with 16 problems in flight - the runtime's own wait already polls - so it is
 // opt-in for latency-bound single-problem use.
+// POSELIB_AMD_GROUP_TIMING=1 (diagnostic): pl_estimate_batch reports where its workers' time went - waiting for the device,
+// in the per-item preparation, in fallback items - on stderr
+std::atomic<uint64_t> g_t_wait_ns{0}, g_t_group_ns{0}, g_t_prep_ns{0}, g_t_fallback_ns{0}, g_n_waits{0}, g_n_fallback{0};
+const bool g_group_timing = std::getenv("POSELIB_AMD_GROUP_TIMING") != nullptr;
+hipError_t wait_stream_impl(Context *c);
 hipError_t wait_stream(Context *c) {
+    if (!g_group_timing)
+        return wait_stream_impl(c);
+    const double t0 = now_s();
+    const hipError_t e = wait_stream_impl(c);
+    g_t_wait_ns += (uint64_t)((now_s() - t0) * 1e9);
+    ++g_n_waits;
+    return e;
+}
+hipError_t wait_stream_impl(Context *c) {
     static const bool spin = std::getenv("POSELIB_AMD_SPIN_SYNC") != nullptr;
     if (!spin || !c->h_flag.p)
         return hipStreamSynchronize(c->stream);
@@ -2745,19 +2759,29 @@ int run_item(pl_batch_item &it) {
 void run_group_job(std::vector<GroupItem> &items) {
     Context *c;
     int rc = get_context(&c);
+    const double t0 = now_s();
+    double t1 = t0;
     if (rc == PL_OK) {
         for (GroupItem &g : items)
             group_prepare_item(g);
+        t1 = now_s();
         rc = run_group(c, items.data(), (uint32_t)items.size());
     }
+    const double t2 = now_s();
     if (rc != PL_OK)
         note_worker_error(); // (the items are retried one by one below; the reason is kept for the caller)
     for (GroupItem &g : items) {
         if (rc != PL_OK || g.fallback) {
             g.item->status = run_item(*g.item);
+            ++g_n_fallback;
             if (g.item->status != PL_OK)
                 note_worker_error();
         }
+    }
+    if (g_group_timing) {
+        g_t_prep_ns += (uint64_t)((t1 - t0) * 1e9);
+        g_t_group_ns += (uint64_t)((t2 - t1) * 1e9);
+        g_t_fallback_ns += (uint64_t)((now_s() - t2) * 1e9);
     }
 }
 } // namespace
@@ -2894,7 +2918,16 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     w = (int)std::min<size_t>((size_t)w, jobs.size());
     (void)take_worker_error();
     g_group_workers.store(std::max(w, 1));
+    const double t_pool = now_s();
+    if (g_group_timing)
+        g_t_wait_ns = g_t_group_ns = g_t_prep_ns = g_t_fallback_ns = g_n_waits = g_n_fallback = 0;
     batch_pool_instance().run(jobs, w, g_requested_device);
+    if (g_group_timing)
+        std::fprintf(stderr, "poselib_amd: pl_estimate_batch %zu items, %zu groups + %zu solo, %d workers: wall %.1f ms; workers' time: prepare %.1f, "
+                             "groups %.1f (of which waiting for the device %.1f in %llu waits), fallback items %.1f ms (%llu items)\n",
+                     count, groups.size(), solo.size(), w, (now_s() - t_pool) * 1e3, g_t_prep_ns.load() * 1e-6, g_t_group_ns.load() * 1e-6,
+                     g_t_wait_ns.load() * 1e-6, (unsigned long long)g_n_waits.load(), g_t_fallback_ns.load() * 1e-6,
+                     (unsigned long long)g_n_fallback.load());
     const std::string werr = take_worker_error();
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
