@@ -147,3 +147,33 @@ def test_batched_front_end_with_and_without_intrinsics_equals_the_single_calls(g
         if not pr[4]["bundle"]:
             # (camera.rescale(1/f) ... rescale(f) round trip of the reference: equal up to that rounding)
             assert np.abs(np.asarray(img.camera.params) - np.asarray(pr[3]["params"])).max() < 1e-9
+
+
+def test_pose_refiners_bit_exact_on_rough_starts_and_all_lm_options(gpu):
+    """k_lm (pose only) in the regime that exposed the sincos difference: rough starting poses, few
+    correspondences (<= 256: sums in the reference's order), Marquardt damping, both lambda updates - bit for bit against the oracle"""
+    rs = np.random.RandomState(78)
+    for k in range(30):
+        n = int(rs.choice([8, 15, 60, 250]))
+        lu, dm = int(rs.randint(2)), int(rs.randint(2))
+        loss = ["TRIVIAL", "HUBER", "CAUCHY"][int(rs.randint(3))]
+        d = synth.absolute_pose_scene(n, 0.0, 6200 + k)
+        un = O.unproject(d["camera"], d["p2d"])
+        q = d["q_gt"] + 0.15 * rs.randn(4)
+        p0 = np.r_[q / np.linalg.norm(q), d["t_gt"] + 0.3 * rs.randn(3)]
+        bo = dict(loss_type=loss, loss_scale=0.01, max_iterations=60, lambda_update=lu, damping=dm)
+        ref, st = O.bundle_adjust(un, d["p3d"], {"model": "NULL", "params": []}, p0, bo)
+        pr = gpu.Problem(gpu.KIND_ABS, un, d["p3d"])
+        pose, it = pr.refine(gpu.CameraPose(p0[:4], p0[4:]), bo)
+        pr.close()
+        assert it == st.iterations and np.array_equal(np.r_[pose.q, pose.t], ref, equal_nan=True), ("abs", k, n, lu, dm, loss)
+        dr = synth.relative_pose_scene(n, 0.0, 6300 + k)
+        a, b = O.unproject(dr["camera1"], dr["x1"]), O.unproject(dr["camera2"], dr["x2"])
+        q = dr["q_gt"] + 0.1 * rs.randn(4)
+        p0 = np.r_[q / np.linalg.norm(q), dr["t_gt"] / np.linalg.norm(dr["t_gt"]) + 0.2 * rs.randn(3)]
+        bo = dict(loss_type=loss, loss_scale=1e-3, max_iterations=60, lambda_update=lu, damping=dm)
+        ref, st = O.refine("relpose", a, b, p0, bo)
+        pr = gpu.Problem(gpu.KIND_REL, a, b)
+        pose, it = pr.refine(gpu.CameraPose(p0[:4], p0[4:]), bo)
+        pr.close()
+        assert it == st.iterations and np.array_equal(np.r_[pose.q, pose.t], ref, equal_nan=True), ("rel", k, n, lu, dm, loss)

@@ -201,3 +201,35 @@ def test_lm_with_intrinsics_bit_exact():
     cols = [pix[:, 0], pix[:, 1], d["p3d"][:, 0], d["p3d"][:, 1], d["p3d"][:, 2]]
     gp, gc, it, _ = HM.lm_cam(cols, p0, HM.lm_options(100, 3, scale), HM.camera_params(0, camp), 3, point_scale=scale, mask=m)
     assert it == st.iterations and (gp[:7] == rp).all() and (gc == rc).all()
+
+
+def test_lm_pose_refiners_bit_exact_on_rough_starts_and_all_lm_options():
+    """Large LM steps (rough starting poses, few correspondences, Marquardt damping, both lambda updates) make every rounding of
+    the quaternion step count: this is the regime in which the device's sin / cos pair differed from the reference's sincos()
+    (DESIGN §5, round 3).  Absolute and relative pose, the device arithmetic on the host against the oracle, bit for bit."""
+    rs = np.random.RandomState(77)
+    checked = 0
+    for k in range(40):
+        n = int(rs.choice([8, 15, 60, 250]))
+        lu, dm = int(rs.randint(2)), int(rs.randint(2))
+        loss = int(rs.choice([0, 2, 3]))
+        d = synth.absolute_pose_scene(n, 0.0, 1200 + k)
+        un = O.unproject(d["camera"], d["p2d"])
+        q = d["q_gt"] + 0.15 * rs.randn(4)
+        p0 = np.r_[q / np.linalg.norm(q), d["t_gt"] + 0.3 * rs.randn(3)]
+        bo = dict(loss_type=loss, loss_scale=0.01, max_iterations=60, lambda_update=lu, damping=dm)
+        ref, st = O.bundle_adjust(un, d["p3d"], {"model": "NULL", "params": []}, p0, bo)
+        got, it, _ = HM.lm("abs", [un[:, 0], un[:, 1], d["p3d"][:, 0], d["p3d"][:, 1], d["p3d"][:, 2]], p0,
+                           HM.lm_options(60, loss, 0.01, lambda_update=lu, damping=dm))
+        assert it == st.iterations and np.array_equal(got[:7], ref, equal_nan=True), ("abs", k, n, lu, dm, loss)
+        dr = synth.relative_pose_scene(n, 0.0, 1300 + k)
+        a, b = O.unproject(dr["camera1"], dr["x1"]), O.unproject(dr["camera2"], dr["x2"])
+        q = dr["q_gt"] + 0.1 * rs.randn(4)
+        t = dr["t_gt"] / np.linalg.norm(dr["t_gt"]) + 0.2 * rs.randn(3)
+        p0 = np.r_[q / np.linalg.norm(q), t]
+        bo = dict(loss_type=loss, loss_scale=1e-3, max_iterations=60, lambda_update=lu, damping=dm)
+        ref, st = O.refine("relpose", a, b, p0, bo)
+        got, it, _ = HM.lm("rel", [a[:, 0], a[:, 1], b[:, 0], b[:, 1]], p0, HM.lm_options(60, loss, 1e-3, lambda_update=lu, damping=dm))
+        assert it == st.iterations and np.array_equal(got[:7], ref, equal_nan=True), ("rel", k, n, lu, dm, loss)
+        checked += 2
+    assert checked == 80
