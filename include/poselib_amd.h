@@ -233,7 +233,7 @@ int pl_debug_device_math(int fn, const double *x, size_t n, double *out);
 int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera *camera, const uint8_t *mask,
                     void *model, uint32_t *lm_iterations);
 
-/* bundle_adjust(points2D, points3D, Camera &, CameraPose *, BundleOptions) of robust/bundle.h:45-50 / bundle.cc:93-118 on
+/* bundle_adjust(x, X, Image *image, BundleOptions) - the Image overload of robust/bundle.h:47-49 / bundle.cc:94-113 - on
  * an absolute-pose problem whose 2-D points are PIXELS: pose and, per opt->refine_focal_length / refine_principal_point /
  * refine_extra_params, the camera's intrinsics are refined together (robust/optim/absolute.h:49-171); both in / out. */
 int pl_bundle_adjust_camera(pl_problem *p, const pl_bundle_options *opt, pl_camera *camera, const uint8_t *mask,

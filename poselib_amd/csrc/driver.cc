@@ -2241,7 +2241,7 @@ int pl_refine_model(pl_problem *p, const pl_bundle_options *opt, const pl_camera
     return PL_OK;
 }
 
-// bundle_adjust(points2D, points3D, Camera &, CameraPose *, BundleOptions) of robust/bundle.cc:93-118 on an absolute-pose
+// bundle_adjust(x, X, Image *image, BundleOptions) (the Image overload, robust/bundle.cc:94-113) on an absolute-pose
 // problem holding PIXEL coordinates: the pose and - per opt->refine_focal_length / refine_principal_point /
 // refine_extra_params - the camera's intrinsics, both in / out.
 int pl_bundle_adjust_camera(pl_problem *p, const pl_bundle_options *opt, pl_camera *camera, const uint8_t *mask,
