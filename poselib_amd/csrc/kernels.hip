@@ -94,6 +94,65 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
     return v;
 }
 // ------------------------------------------------------------------------------------ generate
+// P3P in two halves (pl_solver_p3p.h).  A wavefront = 64 iterations.  Every lane runs the first half on its own sample and
+// appends its <= 4 candidate depth triples to the wave's list in LDS; then the lanes take the CANDIDATES of the list, 64 at
+// a time - polish, R, t, record - fetching the sample's data from the lane that owns it through the cross-lane network
+// (ds_bpermute: no LDS memory).  1.3 of the 4 candidate slots are filled on average, and a wavefront executes a slot as soon as
+// one lane fills it: run per lane the second half costs four rounds, run on the list it costs two (83 candidates on average).
+// Records go to (iteration, solution index) as before: the outcome is bit-identical, only the lane that computes a solution
+// changes.  (Workgroup = one wavefront: the barrier below only orders the LDS traffic.)
+__device__ __forceinline__ double lane_fetch(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ Vec3 lane_fetch(Vec3 v, int src) {
+    return v3(lane_fetch(v.x, src), lane_fetch(v.y, src), lane_fetch(v.z, src));
+}
+__device__ __forceinline__ int generate_abs_dense(const GenerateArgs &g, uint32_t it, bool live, const Vec3 *xb, const Vec3 *Xp,
+                                                  uint32_t &n_nan) {
+    __shared__ uint8_t s_src[256];      // candidate -> owning lane | solution index << 6
+    __shared__ double s_cand[3][256];   // its depths
+    const int lane = threadIdx.x & 63;
+    P3PFront f;
+    double cand[4][3];
+    int n = 0;
+    if (live)
+        n = p3p_front(xb[0], xb[1], xb[2], Xp[0], Xp[1], Xp[2], f, cand);
+    const uint32_t incl = wave_scan_u32((uint32_t)n);
+    const uint32_t first = incl - (uint32_t)n;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (m < n) {
+            s_src[first + m] = (uint8_t)(lane | (m << 6));
+            s_cand[0][first + m] = cand[m][0];
+            s_cand[1][first + m] = cand[m][1];
+            s_cand[2][first + m] = cand[m][2];
+        }
+    __syncthreads();
+    const uint32_t it0 = it - (uint32_t)lane; // the wave's first iteration
+    for (uint32_t base = 0; base < total; base += 64u) { // (wave-uniform trip count)
+        const uint32_t e = base + (uint32_t)lane;
+        const bool act = e < total;
+        const uint32_t src = act ? (uint32_t)s_src[e] : 0u;
+        const int owner = (int)(src & 63u), m = (int)(src >> 6);
+        P3PFront o; // the owner's sample (every lane takes part in the exchange)
+        o.x0 = lane_fetch(f.x0, owner), o.x1 = lane_fetch(f.x1, owner), o.x2 = lane_fetch(f.x2, owner);
+        o.X0 = lane_fetch(f.X0, owner);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            o.XX.m[k] = lane_fetch(f.XX.m[k], owner);
+        o.a01 = lane_fetch(f.a01, owner), o.a02 = lane_fetch(f.a02, owner), o.a12 = lane_fetch(f.a12, owner);
+        o.m01 = lane_fetch(f.m01, owner), o.m02 = lane_fetch(f.m02, owner), o.m12 = lane_fetch(f.m12, owner);
+        if (act) {
+            Mat3 R;
+            Vec3 t;
+            p3p_back(o, s_cand[0][e], s_cand[1][e], s_cand[2][e], R, t);
+            double *rec = g.models + ((size_t)(it0 + (uint32_t)owner) * g.slots_per_iter + (uint32_t)m) * kModelStride;
+            n_nan += store_pose_model(rec, R, t, false) ? 1u : 0u;
+        }
+    }
+    __syncthreads(); // (the list is rewritten by the next call - solver batches run several per workgroup)
+    return n;
+}
+
 template <int EST> __device__ __forceinline__ uint32_t generate_one(const GenerateArgs &g, uint32_t it, uint32_t &n_nan) {
     constexpr int K = sample_size(EST);
     constexpr int MAXM = max_models(EST);
@@ -117,7 +176,7 @@ template <int EST> __device__ __forceinline__ uint32_t generate_one(const Genera
         }
         n = p3p_emit(xb[0], xb[1], xb[2], Xp[0], Xp[1], Xp[2], [&](int m, const Mat3 &R, const Vec3 &t) {
             n_nan += store_pose_model(rec + m * kModelStride, R, t, false) ? 1u : 0u;
-        });
+        }); // (the generator kernels take generate_abs_wave instead: the second half on full wavefronts of candidates)
     } else {
         Vec3 b1[K], b2[K];
 #pragma unroll
@@ -147,10 +206,32 @@ template <int EST> __device__ __forceinline__ uint32_t generate_one(const Genera
     g.num_models[it] = (uint32_t)n;
     return (uint32_t)n;
 }
+// absolute pose: all 64 lanes of the wavefront call (collective second half); lanes past the last iteration carry no sample
+__device__ __forceinline__ uint32_t generate_abs_wave(const GenerateArgs &g, uint32_t it, uint32_t &n_nan) {
+    const bool live = it < g.num_iters;
+    Vec3 xb[3], Xp[3];
+    if (live) {
+        uint32_t idx[3];
+        sample_of_iteration<3>(g, it, idx);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xb[k] = bearing(g.pts.a[0][idx[k]], g.pts.a[1][idx[k]]);
+            Xp[k] = v3(g.pts.a[2][idx[k]], g.pts.a[3][idx[k]], g.pts.a[4][idx[k]]);
+        }
+    }
+    const int n = generate_abs_dense(g, it, live, xb, Xp, n_nan);
+    if (live)
+        g.num_models[it] = (uint32_t)n;
+    return live ? (uint32_t)n : 0u;
+}
 template <int EST> __global__ __launch_bounds__(64) void k_generate(GenerateArgs g) {
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     uint32_t n_nan = 0;
-    const uint32_t n = (it < g.num_iters) ? generate_one<EST>(g, it, n_nan) : 0u;
+    uint32_t n;
+    if constexpr (EST == EST_ABS)
+        n = generate_abs_wave(g, it, n_nan);
+    else
+        n = (it < g.num_iters) ? generate_one<EST>(g, it, n_nan) : 0u;
     count_models_of_wave(g, it, n, n_nan); // one call site: the lanes past the last iteration take part with n = 0
 }
 
@@ -161,7 +242,11 @@ template <int EST> __global__ __launch_bounds__(64) void k_generate_g(const Grou
     const GenerateArgs &g = gg.gen;
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     uint32_t n_nan = 0;
-    const uint32_t n = (it < g.num_iters) ? generate_one<EST>(g, it, n_nan) : 0u;
+    uint32_t n;
+    if constexpr (EST == EST_ABS)
+        n = generate_abs_wave(g, it, n_nan);
+    else
+        n = (it < g.num_iters) ? generate_one<EST>(g, it, n_nan) : 0u;
     count_models_of_wave(g, it, n, n_nan);
 }
 

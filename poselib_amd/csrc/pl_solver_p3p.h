@@ -82,9 +82,20 @@ struct P3PSolution {
     Vec3 t;
 };
 
-// x: unit bearings, X: 3-D points.  Returns the number of solutions (<= 4); every solution is handed to emit(m, R, t) as
-// soon as it is found (the generator stores it at once: an array of four solutions would cost 96 registers).
-template <typename Emit> PL_HD int p3p_emit(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, Emit &&emit) {
+// The solver in two halves, so that the generator can run the second one on full wavefronts of CANDIDATES (kernels.hip):
+//   p3p_front  everything up to the candidate depth triples (d0, d1, d2) of the <= 4 solutions, in the reference's order
+//              (both lines of the degenerate conic, both roots of each line's quadratic, sign tests; p3p.cc:129-160), and
+//              what the second half needs of the sample: the relabelled bearings, X0, inverse(X01, X02, X01 x X02),
+//              the squared side lengths and the cosines;
+//   p3p_back   one candidate -> Newton polish of the depths (p3p_common.h:74-94), R = Y X^-1, t (p3p.cc:121-122, 162-164).
+// No candidate is dropped by the second half, so the first half's count is the number of solutions.
+struct P3PFront {
+    Vec3 x0, x1, x2, X0;
+    Mat3 XX;
+    double a01, a02, a12, m01, m02, m12;
+};
+
+PL_HD int p3p_front(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, P3PFront &f, double (*cand)[3]) {
     Vec3 X01 = X0 - X1, X02 = X0 - X2, X12 = X1 - X2;
     double a01 = dot(X01, X01), a02 = dot(X02, X02), a12 = dot(X12, X12);
 
@@ -166,7 +177,9 @@ template <typename Emit> PL_HD int p3p_emit(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, 
     set_col(XX, 0, X01);
     set_col(XX, 1, X02);
     set_col(XX, 2, cross(X01, X02));
-    XX = inverse3(XX);
+    f.XX = inverse3(XX);
+    f.x0 = x0, f.x1 = x1, f.x2 = x2, f.X0 = X0;
+    f.a01 = a01, f.a02 = a02, f.a12 = a12, f.m01 = m01, f.m02 = m02, f.m12 = m12;
 
     int n = 0;
     for (int i = 0; i < 2; ++i) {
@@ -207,21 +220,44 @@ template <typename Emit> PL_HD int p3p_emit(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, 
                     if (d2 < 0)
                         continue;
                 }
-                polish_depths(d0, d1, d2, a01, a02, a12, m01, m02, m12);
-                const Vec3 v1 = d0 * x0 - d1 * x1;
-                const Vec3 v2 = d0 * x0 - d2 * x2;
-                Mat3 YY;
-                set_col(YY, 0, v1);
-                set_col(YY, 1, v2);
-                set_col(YY, 2, cross(v1, v2));
-                const Mat3 R = mul(YY, XX);
-                emit(n, R, d0 * x0 - mul(R, X0));
+                PL_UNROLL
+                for (int k = 0; k < 4; ++k) // (cand[n] with a run-time n would put the array into scratch memory on the device)
+                    if (k == n)
+                        cand[k][0] = d0, cand[k][1] = d1, cand[k][2] = d2;
                 ++n;
             }
         }
         if (n > 0 && single_root)
             break;
     }
+    return n;
+}
+
+PL_HD void p3p_back(const P3PFront &f, double d0, double d1, double d2, Mat3 &R, Vec3 &t) {
+    polish_depths(d0, d1, d2, f.a01, f.a02, f.a12, f.m01, f.m02, f.m12);
+    const Vec3 v1 = d0 * f.x0 - d1 * f.x1;
+    const Vec3 v2 = d0 * f.x0 - d2 * f.x2;
+    Mat3 YY;
+    set_col(YY, 0, v1);
+    set_col(YY, 1, v2);
+    set_col(YY, 2, cross(v1, v2));
+    R = mul(YY, f.XX);
+    t = d0 * f.x0 - mul(R, f.X0);
+}
+
+// x: unit bearings, X: 3-D points.  Returns the number of solutions (<= 4), each handed to emit(m, R, t) in the reference's order.
+template <typename Emit> PL_HD int p3p_emit(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, Emit &&emit) {
+    P3PFront f;
+    double cand[4][3];
+    const int n = p3p_front(x0, x1, x2, X0, X1, X2, f, cand);
+    PL_UNROLL
+    for (int m = 0; m < 4; ++m)
+        if (m < n) {
+            Mat3 R;
+            Vec3 t;
+            p3p_back(f, cand[m][0], cand[m][1], cand[m][2], R, t);
+            emit(m, R, t);
+        }
     return n;
 }
 PL_HD int p3p(Vec3 x0, Vec3 x1, Vec3 x2, Vec3 X0, Vec3 X1, Vec3 X2, P3PSolution *out) {
