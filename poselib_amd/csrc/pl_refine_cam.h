@@ -170,9 +170,16 @@ PL_HD bool abs_cam_cost(const double *p, const double *R, const CameraParams &ca
     return true;
 }
 
-// Entry e of the packed normal equations [lower triangle row-major | Jtr] of K = 6 + M columns -> the two row columns it
-// multiplies.  Triangle entries: (ci, cj); gradient entries: (ci, -1).
-PL_HD void cam_entry_columns(int e, int K, const int *idx, int &ci, int &cj) {
+// Entry e of the packed normal equations [lower triangle row-major | Jtr] of K = 6 + M columns, as the four row offsets its
+// term multiplies and whether the weight multiplies it:  term = (tri ? w : 1) * (row[a] row[b] + row[c] row[d])
+//   triangle entry (i, j):  a, c = J0[c_i], J1[c_i];  b, d = J0[c_j], J1[c_j]      w (J0i J0j + J1i J1j)
+//   gradient entry i:       a, c = J0[c_i], J1[c_i];  b, d = w r0, w r1            J0i (w r0) + J1i (w r1)   (1.0 x is exact)
+// One shape for both kinds keeps the consumer loop of k_lm_cam free of branches: the LDS reads of several rows travel together.
+struct CamEntry {
+    int a, b, c, d;
+    bool tri;
+};
+PL_HD CamEntry cam_entry_of(int e, int K, const int *idx) {
     const int T = K * (K + 1) / 2;
     int i, j;
     if (e < T) {
@@ -184,15 +191,22 @@ PL_HD void cam_entry_columns(int e, int K, const int *idx, int &ci, int &cj) {
         i = e - T;
         j = -1;
     }
-    ci = (i < 6) ? i : 6 + idx[i - 6];
-    cj = (j < 0) ? -1 : ((j < 6) ? j : 6 + idx[j - 6]);
+    const int ci = (i < 6) ? i : 6 + idx[i - 6];
+    CamEntry en;
+    en.a = 3 + ci, en.c = 3 + kCamMaxK + ci;
+    en.tri = j >= 0;
+    if (en.tri) {
+        const int cj = (j < 6) ? j : 6 + idx[j - 6];
+        en.b = 3 + cj, en.d = 3 + kCamMaxK + cj;
+    } else {
+        en.b = 1, en.d = 2;
+    }
+    return en;
 }
 // ... and the entry's term of one row
-PL_HD double cam_entry_term(const double *row, int ci, int cj) {
-    const double *J0 = row + 3, *J1 = row + 3 + kCamMaxK;
-    if (cj >= 0)
-        return row[0] * (J0[ci] * J0[cj] + J1[ci] * J1[cj]);
-    return J0[ci] * row[1] + J1[ci] * row[2];
+PL_HD double cam_entry_term(const double *row, const CamEntry &en) {
+    const double t = row[en.a] * row[en.b] + row[en.c] * row[en.d];
+    return (en.tri ? row[0] : 1.0) * t;
 }
 
 // lm_solve / lm_update of pl_refine.h for a run-time K = 7..14 (thread 0 of the kernel; the fully unrolled Cholesky of

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised soak of the intrinsics-refining bundle (k_lm_cam) against the oracle: random sizes, camera models, flag sets,
-losses, start errors, outliers and masks.  Up to 256 correspondences the results must be bit-identical; beyond, pose / camera
+losses, start errors, outliers and masks.  Problems of up to 256 correspondences must be bit-identical; beyond, pose / camera
 to 1e-8 (relative for the camera).  usage: soak_intrinsics.py [count] [seed]"""
 import os
 import sys
@@ -57,7 +57,7 @@ for k in range(count):
     m = n if mask is None else int(mask.sum())
     same = np.array_equal(got, rp, equal_nan=True) and np.array_equal(gc, rc, equal_nan=True) and it == st.iterations
     exact += same
-    if m <= 256:
+    if n <= 256:  # (the kernel sums the robust cost in order when the PROBLEM has at most 256 correspondences)
         if not same:
             bad.append((k, n, m, model, bo, it, st.iterations, float(np.nanmax(np.abs(got - rp))), float(np.nanmax(np.abs(gc - rc)))))
     else:

@@ -503,11 +503,8 @@ void hm_lm_cam(const double *const *pa, uint32_t n, double *params, const LMOpti
                 continue;
             if (!abs_cam_row(p, R, cam, ctl.loss, pa[0][i] * point_scale, pa[1][i] * point_scale, pa[2][i], pa[3][i], pa[4][i], row))
                 continue;
-            for (int e = 0; e < NT; ++e) {
-                int ci, cj;
-                cam_entry_columns(e, K, idx, ci, cj);
-                normal[e] += cam_entry_term(row, ci, cj);
-            }
+            for (int e = 0; e < NT; ++e)
+                normal[e] += cam_entry_term(row, cam_entry_of(e, K, idx));
             count++;
         }
     };
