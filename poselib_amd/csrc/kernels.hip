@@ -1848,9 +1848,21 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                 }
                 __syncthreads();
                 const uint32_t slots = min(64u, pts.n - 64u * rd) * SUB;
-                if (jac ? threadIdx.x < NT : threadIdx.x == NT)
-                    for (uint32_t q = 0; q < slots; ++q)
+                if (jac ? threadIdx.x < NT : threadIdx.x == NT) {
+                    // (eight LDS reads travel together, the additions stay a chain in correspondence order)
+                    uint32_t q = 0;
+                    for (; q + 8u <= slots; q += 8u) {
+                        double t8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            t8[u] = s_terms[q + u][threadIdx.x];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            tot += t8[u];
+                    }
+                    for (; q < slots; ++q)
                         tot += s_terms[q][threadIdx.x];
+                }
                 __syncthreads();
             }
             if (jac) {
