@@ -115,7 +115,17 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
             __syncthreads();
             if (threadIdx.x == 0) {
                 double tot = 0.0;
-                for (uint32_t q = 0; q < pts.n; ++q)
+                uint32_t q = 0;
+                for (; q + 8u <= pts.n; q += 8u) { // (reads together, additions in order)
+                    double t8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        t8[u] = s_rows[q + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        tot += t8[u];
+                }
+                for (; q < pts.n; ++q)
                     tot += s_rows[q];
                 s_racc = tot;
                 uint32_t c = 0;
