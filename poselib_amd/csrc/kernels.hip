@@ -1651,8 +1651,11 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
     __shared__ RefineCtx ctx;
     __shared__ double scratch[kLMThreads / 64][NT + 1];
     __shared__ double normal[NT];
+    __shared__ double normal_next[NT]; // the normal equations at the trial point (fused pass), the next iteration's if the step is accepted
     __shared__ double s_racc[1];
-    __shared__ uint32_t s_count;
+    __shared__ uint32_t s_count;   // residual pass: correspondences counted (jacobian_accumulator.h's single counter after residual())
+    __shared__ uint32_t s_count_j; // Jacobian pass: correspondences with a non-zero weight (... after accumulate())
+    __shared__ int s_accepted;
     __shared__ int s_skip;
     __shared__ uint32_t s_queue[kLMThreads / 64][128]; // per wavefront: correspondences waiting for their Jacobian
     __shared__ double s_terms[128][NT + 1];           // small problems: the terms of 64 correspondences (x 2 for H) + cost
@@ -1705,8 +1708,13 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         return;
     }
 
-    // One pass over the points.  JAC = false: robust cost only.  JAC = true: normal equations.
-    auto pass = [&](const double *p, bool jac) {
+    // One pass over the points.  mode kRes: robust cost only (-> s_racc, s_count).  kJac: normal equations (-> out, s_count_j).
+    // kBoth: both at the same parameters, every sum in the order of the separate passes - the cost of a trial step and, if the
+    // step is accepted, the next iteration's normal equations from ONE sweep (lm_impl.h:88-99 then :66-76 of the next
+    // iteration evaluate the same point; k_lm2 does the same across launches).
+    enum { kRes = 0, kJac = 1, kBoth = 2 };
+    auto pass = [&](const double *p, int mode, double *out) {
+        const bool jac = mode != kRes, res = mode != kJac;
         if (threadIdx.x == 0) {
             R::prepare(p, ctx);
         }
@@ -1716,7 +1724,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         for (int i = 0; i < NT; ++i)
             acc[i] = 0.0;
         double racc = 0.0;
-        uint32_t cnt = 0;
+        uint32_t cnt = 0, cntj = 0; // residual pass's counter / Jacobian pass's counter
         const Loss loss = ctl.loss;
         // One correspondence into the normal equations (jac) or into the robust cost (!jac) of this thread's accumulators
         // (named directly - handed over as pointers they would live in scratch memory)
@@ -1733,7 +1741,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                 } else {
                     double J[2 * K];
                     if (R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J))
-                        accumulate2<K>(acc, loss, r0, r1, J, cnt);
+                        accumulate2<K>(acc, loss, r0, r1, J, cntj);
                 }
             } else if constexpr (EST == EST_HOM) {
                 const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
@@ -1746,8 +1754,8 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                 } else {
                     double Jf[2 * K], Jb[2 * K];
                     R::jacobian(ctx, a0, a1, b0, b1, f0, f1, Jf, g0, g1, Jb);
-                    accumulate2<K>(acc, loss, f0, f1, Jf, cnt);
-                    accumulate2<K>(acc, loss, g0, g1, Jb, cnt);
+                    accumulate2<K>(acc, loss, f0, f1, Jf, cntj);
+                    accumulate2<K>(acc, loss, g0, g1, Jb, cntj);
                 }
             } else {
                 const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
@@ -1758,7 +1766,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                 } else {
                     double J[K];
                     const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
-                    accumulate1<K>(acc, loss, r, J, cnt);
+                    accumulate1<K>(acc, loss, r, J, cntj);
                 }
             }
         };
@@ -1779,7 +1787,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                 for (int a = 0; a < NT; ++a)
                     term[u][a] = 0.0;
             }
-            uint32_t cn = 0;
+            uint32_t cn = 0, cnj = 0;
             // (the same expressions as `point`, into this correspondence's own terms; the homography's backward block apart)
                 auto point_terms = [&](uint32_t i, bool jacobian_pass) {
                 if constexpr (EST == EST_ABS) {
@@ -1794,7 +1802,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                     } else {
                         double J[2 * K];
                         if (R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J))
-                            accumulate2<K>(term[0], loss, r0, r1, J, cn);
+                            accumulate2<K>(term[0], loss, r0, r1, J, cnj);
                     }
                 } else if constexpr (EST == EST_HOM) {
                     const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
@@ -1807,8 +1815,8 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                     } else {
                         double Jf[2 * K], Jb[2 * K];
                         R::jacobian(ctx, a0, a1, b0, b1, f0, f1, Jf, g0, g1, Jb);
-                        accumulate2<K>(term[0], loss, f0, f1, Jf, cn);
-                        accumulate2<K>(term[SUB - 1], loss, g0, g1, Jb, cn);
+                        accumulate2<K>(term[0], loss, f0, f1, Jf, cnj);
+                        accumulate2<K>(term[SUB - 1], loss, g0, g1, Jb, cnj);
                     }
                 } else {
                     const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
@@ -1819,17 +1827,27 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                     } else {
                         double J[K];
                         const double r = R::jacobian(ctx, a0, a1, b0, b1, J);
-                        accumulate1<K>(term[0], loss, r, J, cn);
+                        accumulate1<K>(term[0], loss, r, J, cnj);
                     }
                 }
             };
-            if (threadIdx.x < pts.n && !(mask && !mask[threadIdx.x]))
-                point_terms(threadIdx.x, jac);
-            if (threadIdx.x == 0)
-                s_count = 0;
+            if (threadIdx.x < pts.n && !(mask && !mask[threadIdx.x])) {
+                if (res)
+                    point_terms(threadIdx.x, false);
+                if (jac)
+                    point_terms(threadIdx.x, true);
+            }
+            if (threadIdx.x == 0) {
+                if (res)
+                    s_count = 0;
+                if (jac)
+                    s_count_j = 0;
+            }
             __syncthreads();
             if (cn)
                 atomicAdd(&s_count, cn);
+            if (cnj)
+                atomicAdd(&s_count_j, cnj);
             double tot = 0.0;
             const uint32_t rounds = (pts.n + 63u) / 64u;
             for (uint32_t rd = 0; rd < rounds; ++rd) {
@@ -1841,14 +1859,14 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
 #pragma unroll
                             for (int a = 0; a < NT; ++a)
                                 dst[a] = term[u][a];
-                        } else {
-                            dst[NT] = cterm[u];
                         }
+                        if (res)
+                            dst[NT] = cterm[u];
                     }
                 }
                 __syncthreads();
                 const uint32_t slots = min(64u, pts.n - 64u * rd) * SUB;
-                if (jac ? threadIdx.x < NT : threadIdx.x == NT) {
+                if ((jac && threadIdx.x < NT) || (res && threadIdx.x == NT)) {
                     // (eight LDS reads travel together, the additions stay a chain in correspondence order)
                     uint32_t q = 0;
                     for (; q + 8u <= slots; q += 8u) {
@@ -1865,12 +1883,10 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                 }
                 __syncthreads();
             }
-            if (jac) {
-                if (threadIdx.x < NT)
-                    normal[threadIdx.x] = tot;
-            } else if (threadIdx.x == NT) {
+            if (jac && threadIdx.x < NT)
+                out[threadIdx.x] = tot;
+            if (res && threadIdx.x == NT)
                 s_racc[0] = tot;
-            }
             __syncthreads();
             return;
         }
@@ -1888,19 +1904,32 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
             for (uint32_t base = (threadIdx.x >> 6) * 64u; base < pts.n; base += kLMThreads) {
                 const uint32_t i = base + (uint32_t)lane;
                 bool keep = false;
-                if (i < pts.n && !(mask && !mask[i])) {
+                if (i < pts.n && !(mask && !mask[i])) { // (res: the residual pass's terms, in its per-lane order)
                     if constexpr (EST == EST_ABS) {
                         double r0, r1;
-                        keep = R::residual(p, ctx, cam, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
-                                           pts.a[4][i], r0, r1) &&
-                               loss_weight(loss, r0 * r0 + r1 * r1) != 0;
+                        const bool valid = R::residual(p, ctx, cam, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i],
+                                                       pts.a[3][i], pts.a[4][i], r0, r1);
+                        keep = valid && loss_weight(loss, r0 * r0 + r1 * r1) != 0;
+                        if (res && valid) {
+                            racc += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
+                            cnt++;
+                        }
                     } else if constexpr (EST == EST_HOM) {
                         double f0, f1, g0, g1;
                         R::residual(ctx, pts.a[0][i], pts.a[1][i], pts.a[2][i], pts.a[3][i], f0, f1, g0, g1);
                         keep = loss_weight(loss, f0 * f0 + f1 * f1) != 0 || loss_weight(loss, g0 * g0 + g1 * g1) != 0;
+                        if (res) {
+                            racc += 1.0 * loss_value(loss, f0 * f0 + f1 * f1);
+                            racc += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
+                            cnt += 2;
+                        }
                     } else {
                         const double r = R::residual(ctx, pts.a[0][i], pts.a[1][i], pts.a[2][i], pts.a[3][i]);
                         keep = loss_weight(loss, r * r) != 0;
+                        if (res) {
+                            racc += 1.0 * loss_value(loss, r * r);
+                            cnt++;
+                        }
                     }
                 }
                 const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
@@ -1928,47 +1957,70 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
             for (uint32_t i = threadIdx.x; i < pts.n; i += kLMThreads) {
                 if (mask && !mask[i])
                     continue;
-                point(i, jac);
+                if (res)
+                    point(i, false);
+                if (jac)
+                    point(i, true);
             }
         }
-        if (!jac) {
+        if (res) {
             double v[1] = {racc};
             BlockReduce<1>::run(v, cnt, reinterpret_cast<double(*)[2]>(&scratch[0][0]), s_racc, &s_count);
-        } else {
-            BlockReduce<NT>::run(acc, cnt, scratch, normal, &s_count);
         }
+        if (jac)
+            BlockReduce<NT>::run(acc, cntj, scratch, out, &s_count_j);
     };
 
-    pass(cur, false);
+    pass(cur, kRes, nullptr);
     if (threadIdx.x == 0)
         lm_begin(ctl, T.opt, s_racc[0], s_count);
     __syncthreads();
 
+    // The trial point's sweep is fused (kBoth) unless the loss changes between iterations (TRUNCATED_LE_ZACH: mu grows after
+    // every iteration, bundle.cc:52-75 - the next Jacobian would have to be evaluated with the new mu).
+    const bool fuse = T.opt.loss_type != LOSS_TRUNCATED_LE_ZACH;
+    bool have_next = false;   // `normal` already holds the normal equations at `cur` (from the accepted trial's sweep)
+    uint32_t jac_count = 0;   // the Jacobian pass's counter that belongs to `normal`
     while (!ctl.done) {
         const bool fresh = ctl.rejac != 0;
-        if (fresh) {
+        if (fresh && !have_next) {
             if constexpr (EST == EST_REL) {
                 if (threadIdx.x == 0)
                     R::prepare_params(cur);
                 __syncthreads();
             }
-            pass(cur, true);
+            pass(cur, kJac, normal);
+            jac_count = s_count_j;
         }
         if (threadIdx.x == 0) {
-            lm_solve<K>(ctl, normal, fresh, s_count);
-            if (!ctl.done)
+            lm_solve<K>(ctl, normal, fresh, jac_count);
+            if (!ctl.done) {
                 R::step(cur, ctx, ctl.sol, trial);
+                if constexpr (EST == EST_REL)
+                    if (fuse)
+                        R::prepare_params(trial); // (the tangent basis of the Jacobian at the trial point: what the next
+                                                  // iteration computes from the accepted parameters)
+            }
         }
         __syncthreads();
         if (ctl.done)
             break;
-        pass(trial, false);
+        pass(trial, fuse ? kBoth : kRes, normal_next);
         if (threadIdx.x == 0) {
-            if (lm_update<K>(ctl, normal, s_racc[0], s_count))
+            const bool accepted = lm_update<K>(ctl, normal, s_racc[0], s_count);
+            if (accepted)
                 for (int i = 0; i < kParamDoubles; ++i)
                     cur[i] = trial[i];
+            s_accepted = accepted ? 1 : 0;
         }
         __syncthreads();
+        have_next = fuse && s_accepted != 0;
+        if (have_next) {
+            if (threadIdx.x < NT)
+                normal[threadIdx.x] = normal_next[threadIdx.x];
+            jac_count = s_count_j;
+            __syncthreads();
+        }
     }
 
     if (threadIdx.x == 0)
