@@ -1971,7 +1971,14 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
             BlockReduce<NT>::run(acc, cntj, scratch, out, &s_count_j);
     };
 
-    pass(cur, kRes, nullptr);
+    // The initial cost and the first iteration's normal equations are evaluated at the same point with the same loss: one sweep.
+    if constexpr (EST == EST_REL) {
+        if (threadIdx.x == 0)
+            R::prepare_params(cur);
+        __syncthreads();
+    }
+    const bool first_needs_jacobian = T.opt.max_iterations != 0;
+    pass(cur, first_needs_jacobian ? kBoth : kRes, normal);
     if (threadIdx.x == 0)
         lm_begin(ctl, T.opt, s_racc[0], s_count);
     __syncthreads();
@@ -1979,8 +1986,8 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
     // The trial point's sweep is fused (kBoth) unless the loss changes between iterations (TRUNCATED_LE_ZACH: mu grows after
     // every iteration, bundle.cc:52-75 - the next Jacobian would have to be evaluated with the new mu).
     const bool fuse = T.opt.loss_type != LOSS_TRUNCATED_LE_ZACH;
-    bool have_next = false;   // `normal` already holds the normal equations at `cur` (from the accepted trial's sweep)
-    uint32_t jac_count = 0;   // the Jacobian pass's counter that belongs to `normal`
+    bool have_next = first_needs_jacobian; // `normal` already holds the normal equations at `cur`
+    uint32_t jac_count = s_count_j;        // the Jacobian pass's counter that belongs to `normal`
     while (!ctl.done) {
         const bool fresh = ctl.rejac != 0;
         if (fresh && !have_next) {
