@@ -1440,6 +1440,10 @@ struct RansacRun {
     // ---- host pass 2: replay the sequential loop over this batch (ransac_impl.h:180-188) with the refined and
     // re-scored models in `jobs`.  host_offsets: pinned mirror of the per-iteration hypothesis offsets of the batch (group
     // launches write one); nullptr: the one entry that is needed is fetched from the device ----
+    // (defer_offset: group launches - the caller fetches offsets[deferred_offset] of all stopping problems in one go and
+    // books it into st->hypotheses; mirroring the whole table to pinned memory cost 0.4 MB of PCIe writes per problem and batch)
+    bool defer_offset = false;
+    int64_t deferred_offset = -1;
     int replay(Batch &b, const uint32_t *host_offsets) {
         const uint32_t B = b.B, lo_g = b.lo_g, hi_g = b.hi_g, Bl = b.Bl;
         (void)B, (void)lo_g, (void)hi_g, (void)Bl;
@@ -1483,6 +1487,8 @@ struct RansacRun {
             } else if (stop_at > it + lo_g) {
                 if (host_offsets) {
                     upto = host_offsets[stop_at - it - lo_g];
+                } else if (defer_offset && !sh) {
+                    deferred_offset = (int64_t)(stop_at - it - lo_g);
                 } else {
                     HIP_TRY(hipMemcpyAsync(&upto, c->offsets.as<uint32_t>() + (stop_at - it - lo_g), sizeof(uint32_t),
                                            hipMemcpyDeviceToHost, c->stream));
