@@ -1386,8 +1386,11 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6,
 // model; the threads evaluate the correspondences of a chunk in parallel and compact the inliers' squared residuals
 // in index order into LDS (block scan), one lane adds them sequentially.
 // (32 KB of LDS: the workgroup fits next to two workgroups of the streaming scorers - with 64 KB it waited for a scoring
-// launch's tail whenever another group's scorer held the device, like the orbit kernel's large build, pipeline.hip)
-constexpr int kSeqThreads = 1024, kSeqPerThread = 4, kSeqChunk = kSeqThreads * kSeqPerThread;
+// launch's tail whenever another group's scorer held the device, like the orbit kernel's large build, pipeline.hip.
+// 512 lanes: while one lane adds, the others only hold wave slots - with 1024 lanes two workgroups filled a CU's 32 slots and
+// kept the scorers of other groups off it: batch_mixed 52.2 -> 55.6 k problems/s, hom_10000 +3 %; 256 lanes cost the
+// single-problem path 6 % in the evaluation phase.  The order of the sum does not depend on the workgroup's shape.)
+constexpr int kSeqThreads = 512, kSeqPerThread = 8, kSeqChunk = kSeqThreads * kSeqPerThread;
 
 template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScoreArgs &a) {
     constexpr int ND = point_doubles(EST);
