@@ -336,6 +336,277 @@ template <typename Derived, typename T, int RT, int CT> auto Dense<Derived, T, R
     return ShimColPivQR<T, RT, CT>(*this);
 }
 
+
+// HouseholderQR without pivoting (householderQr().householderQ(): the full R x R orthogonal factor) - the Householder
+// vectors and signs of Eigen's make_householder, applied column by column.
+template <typename T, int R, int C> class ShimHouseholderQR {
+  public:
+    template <typename D> explicit ShimHouseholderQR(const Dense<D, T, R, C> &A) {
+        rows_ = A.rows();
+        cols_ = A.cols();
+        qr_.resize(rows_, cols_);
+        for (Index j = 0; j < cols_; ++j)
+            for (Index i = 0; i < rows_; ++i)
+                qr_(i, j) = A(i, j);
+        const Index size = std::min(rows_, cols_);
+        tau_.assign(static_cast<size_t>(size), T(0));
+        for (Index k = 0; k < size; ++k) {
+            T tail_sq = T(0);
+            for (Index r = k + 1; r < rows_; ++r)
+                tail_sq += qr_(r, k) * qr_(r, k);
+            const T c0 = qr_(k, k);
+            T beta;
+            if (tail_sq <= std::numeric_limits<T>::min()) {
+                tau_[static_cast<size_t>(k)] = T(0);
+                beta = c0;
+                for (Index r = k + 1; r < rows_; ++r)
+                    qr_(r, k) = T(0);
+            } else {
+                beta = std::sqrt(c0 * c0 + tail_sq);
+                if (c0 >= T(0))
+                    beta = -beta;
+                for (Index r = k + 1; r < rows_; ++r)
+                    qr_(r, k) = qr_(r, k) / (c0 - beta);
+                tau_[static_cast<size_t>(k)] = (beta - c0) / beta;
+            }
+            qr_(k, k) = beta;
+            const T tk = tau_[static_cast<size_t>(k)];
+            if (tk != T(0))
+                for (Index c = k + 1; c < cols_; ++c) {
+                    T t = T(0);
+                    for (Index r = k + 1; r < rows_; ++r)
+                        t += qr_(r, k) * qr_(r, c);
+                    t += qr_(k, c);
+                    qr_(k, c) -= tk * t;
+                    for (Index r = k + 1; r < rows_; ++r)
+                        qr_(r, c) -= tk * qr_(r, k) * t;
+                }
+        }
+    }
+    Matrix<T, R, R> householderQ() const {
+        Matrix<T, R, R> Q;
+        Q.resize(rows_, rows_);
+        Q.setIdentity();
+        const Index size = std::min(rows_, cols_);
+        for (Index k = size - 1; k >= 0; --k) {
+            const T tk = tau_[static_cast<size_t>(k)];
+            if (tk != T(0))
+                for (Index c = k; c < rows_; ++c) {
+                    T t = T(0);
+                    for (Index r = k + 1; r < rows_; ++r)
+                        t += qr_(r, k) * Q(r, c);
+                    t += Q(k, c);
+                    Q(k, c) -= tk * t;
+                    for (Index r = k + 1; r < rows_; ++r)
+                        Q(r, c) -= tk * qr_(r, k) * t;
+                }
+        }
+        return Q;
+    }
+
+  private:
+    Index rows_, cols_;
+    Matrix<T, Dynamic, Dynamic> qr_;
+    std::vector<T> tau_;
+};
+template <typename Derived, typename T, int RT, int CT> auto Dense<Derived, T, RT, CT>::householderQr() const {
+    return ShimHouseholderQR<T, RT, CT>(*this);
+}
+
+// Eigenvalues of a real general matrix: Householder reduction to upper Hessenberg form, then the implicitly shifted
+// (Francis double-shift) QR iteration - the algorithm Eigen documents for EigenSolver / RealSchur (EISPACK orthes + hqr),
+// without eigenvectors (the reference's template solvers ask for the eigenvalues only and recover the solutions themselves).
+// Restated from the textbook form; Eigen's own shift strategy and deflation tests differ in details, so agreement with an
+// Eigen-built PoseLib is at rounding level here as everywhere in this shim.
+template <typename MatT> class EigenSolver {
+  public:
+    typedef typename MatT::Scalar T;
+    explicit EigenSolver(const MatT &A, bool compute_eigenvectors = true) {
+        (void)compute_eigenvectors; // never used by the units compiled against this shim
+        const int n = static_cast<int>(A.rows());
+        std::vector<std::vector<T>> a(static_cast<size_t>(n), std::vector<T>(static_cast<size_t>(n)));
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                a[i][j] = A(i, j);
+        hessenberg(a, n);
+        values_.resize(n, 1);
+        hqr(a, n);
+    }
+    const Matrix<std::complex<T>, MatT::RowsAtCompileTime, 1> &eigenvalues() const { return values_; }
+
+  private:
+    Matrix<std::complex<T>, MatT::RowsAtCompileTime, 1> values_;
+
+    static void hessenberg(std::vector<std::vector<T>> &a, int n) { // Householder similarity transformations
+        for (int k = 0; k + 2 < n; ++k) {
+            T tail_sq = T(0);
+            for (int r = k + 2; r < n; ++r)
+                tail_sq += a[r][k] * a[r][k];
+            if (tail_sq <= std::numeric_limits<T>::min())
+                continue;
+            const T c0 = a[k + 1][k];
+            T beta = std::sqrt(c0 * c0 + tail_sq);
+            if (c0 >= T(0))
+                beta = -beta;
+            std::vector<T> v(static_cast<size_t>(n), T(0));
+            v[k + 1] = T(1);
+            for (int r = k + 2; r < n; ++r)
+                v[r] = a[r][k] / (c0 - beta);
+            const T tau = (beta - c0) / beta;
+            for (int c = 0; c < n; ++c) { // H A   (H = I - tau v v^T)
+                T t = T(0);
+                for (int r = k + 1; r < n; ++r)
+                    t += v[r] * a[r][c];
+                for (int r = k + 1; r < n; ++r)
+                    a[r][c] -= tau * v[r] * t;
+            }
+            for (int r = 0; r < n; ++r) { // (H A) H
+                T t = T(0);
+                for (int c = k + 1; c < n; ++c)
+                    t += a[r][c] * v[c];
+                for (int c = k + 1; c < n; ++c)
+                    a[r][c] -= tau * t * v[c];
+            }
+            a[k + 1][k] = beta;
+            for (int r = k + 2; r < n; ++r)
+                a[r][k] = T(0);
+        }
+    }
+    void hqr(std::vector<std::vector<T>> &a, int n) { // eigenvalues of an upper Hessenberg matrix
+        T anorm = T(0);
+        for (int i = 0; i < n; ++i)
+            for (int j = std::max(i - 1, 0); j < n; ++j)
+                anorm += std::abs(a[i][j]);
+        int nn = n - 1;
+        T t = T(0);
+        T p = T(0), q = T(0), r = T(0), s = T(0), w = T(0), x = T(0), y = T(0), z = T(0);
+        while (nn >= 0) {
+            int its = 0, l;
+            do {
+                for (l = nn; l >= 1; --l) { // look for a small sub-diagonal element
+                    s = std::abs(a[l - 1][l - 1]) + std::abs(a[l][l]);
+                    if (s == T(0))
+                        s = anorm;
+                    if (std::abs(a[l][l - 1]) <= std::numeric_limits<T>::epsilon() * s) {
+                        a[l][l - 1] = T(0);
+                        break;
+                    }
+                }
+                x = a[nn][nn];
+                if (l == nn) { // one root
+                    values_(nn, 0) = std::complex<T>(x + t, T(0));
+                    --nn;
+                } else {
+                    y = a[nn - 1][nn - 1];
+                    w = a[nn][nn - 1] * a[nn - 1][nn];
+                    if (l == nn - 1) { // two roots
+                        p = T(0.5) * (y - x);
+                        q = p * p + w;
+                        z = std::sqrt(std::abs(q));
+                        x += t;
+                        if (q >= T(0)) { // real pair
+                            z = p + (p >= T(0) ? std::abs(z) : -std::abs(z));
+                            values_(nn - 1, 0) = std::complex<T>(x + z, T(0));
+                            values_(nn, 0) = std::complex<T>(z != T(0) ? x - w / z : x + z, T(0));
+                        } else { // complex pair
+                            values_(nn - 1, 0) = std::complex<T>(x + p, z);
+                            values_(nn, 0) = std::complex<T>(x + p, -z);
+                        }
+                        nn -= 2;
+                    } else { // no root yet: a QR step
+                        if (its == 60) { // (no convergence: report what is there, as NaN so that the callers drop it)
+                            for (int i = 0; i <= nn; ++i)
+                                values_(i, 0) = std::complex<T>(std::numeric_limits<T>::quiet_NaN(), T(0));
+                            return;
+                        }
+                        if (its == 10 || its == 20) { // exceptional shift
+                            t += x;
+                            for (int i = 0; i <= nn; ++i)
+                                a[i][i] -= x;
+                            s = std::abs(a[nn][nn - 1]) + std::abs(a[nn - 1][nn - 2]);
+                            y = x = T(0.75) * s;
+                            w = T(-0.4375) * s * s;
+                        }
+                        ++its;
+                        int m;
+                        for (m = nn - 2; m >= l; --m) { // two consecutive small sub-diagonal elements
+                            z = a[m][m];
+                            r = x - z;
+                            s = y - z;
+                            p = (r * s - w) / a[m + 1][m] + a[m][m + 1];
+                            q = a[m + 1][m + 1] - z - r - s;
+                            r = a[m + 2][m + 1];
+                            s = std::abs(p) + std::abs(q) + std::abs(r);
+                            p /= s;
+                            q /= s;
+                            r /= s;
+                            if (m == l)
+                                break;
+                            const T u = std::abs(a[m][m - 1]) * (std::abs(q) + std::abs(r));
+                            const T v = std::abs(p) * (std::abs(a[m - 1][m - 1]) + std::abs(z) + std::abs(a[m + 1][m + 1]));
+                            if (u <= std::numeric_limits<T>::epsilon() * v)
+                                break;
+                        }
+                        for (int i = m + 2; i <= nn; ++i) {
+                            a[i][i - 2] = T(0);
+                            if (i != m + 2)
+                                a[i][i - 3] = T(0);
+                        }
+                        for (int k = m; k <= nn - 1; ++k) { // double QR step on rows l..nn and columns m..nn
+                            if (k != m) {
+                                p = a[k][k - 1];
+                                q = a[k + 1][k - 1];
+                                r = T(0);
+                                if (k != nn - 1)
+                                    r = a[k + 2][k - 1];
+                                if ((x = std::abs(p) + std::abs(q) + std::abs(r)) != T(0)) {
+                                    p /= x;
+                                    q /= x;
+                                    r /= x;
+                                }
+                            }
+                            const T sq = std::sqrt(p * p + q * q + r * r);
+                            if ((s = (p >= T(0) ? sq : -sq)) != T(0)) {
+                                if (k == m) {
+                                    if (l != m)
+                                        a[k][k - 1] = -a[k][k - 1];
+                                } else {
+                                    a[k][k - 1] = -s * x;
+                                }
+                                p += s;
+                                x = p / s;
+                                y = q / s;
+                                z = r / s;
+                                q /= p;
+                                r /= p;
+                                for (int j = k; j <= nn; ++j) { // row modification
+                                    p = a[k][j] + q * a[k + 1][j];
+                                    if (k != nn - 1) {
+                                        p += r * a[k + 2][j];
+                                        a[k + 2][j] -= p * z;
+                                    }
+                                    a[k + 1][j] -= p * y;
+                                    a[k][j] -= p * x;
+                                }
+                                const int mmin = nn < k + 3 ? nn : k + 3;
+                                for (int i = l; i <= mmin; ++i) { // column modification
+                                    p = x * a[i][k] + y * a[i][k + 1];
+                                    if (k != nn - 1) {
+                                        p += z * a[i][k + 2];
+                                        a[i][k + 2] -= p * r;
+                                    }
+                                    a[i][k + 1] -= p * q;
+                                    a[i][k] -= p;
+                                }
+                            }
+                        }
+                    }
+                }
+            } while (l < nn - 1);
+        }
+    }
+};
+
 // 3x3 SVD by one-sided Jacobi (singular values descending); only the shape the reference needs
 template <typename MatT> class JacobiSVD {
   public:

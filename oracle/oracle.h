@@ -40,7 +40,8 @@ typedef struct {
     orc_bundle_opt bundle;
     double max_error;
     int32_t real_focal_check; /* fundamental only */
-    int32_t reserved;
+    int32_t estimate_focal_length; /* absolute pose: AbsolutePoseOptions::estimate_focal_length - REFERENCE BUILD ONLY (oracle/_ref):
+                                      the oracle has no restatement of the P3.5Pf template solver and ignores it */
 } orc_robust_opt;
 
 typedef struct {

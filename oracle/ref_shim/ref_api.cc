@@ -8,6 +8,7 @@
 // Only Eigen is not the real one.  Reference translation units the shim cannot carry (solver families that are
 // not on this path and need Eigen::EigenSolver etc.) are left out; the symbols they would define become traps
 // (oracle/ref_shim/make_traps.sh), which abort if anything ever calls them.
+#include <PoseLib/solvers/p35pf.h>
 #include <PoseLib/camera_pose.h>
 #include <PoseLib/misc/essential.h>
 #include <PoseLib/robust/ransac_impl.h>
@@ -124,6 +125,11 @@ template <typename Opt> Opt robust_in(const orc_robust_opt *o) {
     r.ransac = ropt(o->ransac);
     r.bundle = bopt(o->bundle);
     r.max_error = o->max_error;
+    return r;
+}
+AbsolutePoseOptions abs_in(const orc_robust_opt *o) {
+    AbsolutePoseOptions r = robust_in<AbsolutePoseOptions>(o);
+    r.estimate_focal_length = o->estimate_focal_length != 0;
     return r;
 }
 RelativePoseOptions rel_in(const orc_robust_opt *o) {
@@ -370,6 +376,32 @@ void ref_ransac_pnp(const double *x, const double *X, size_t n, const orc_robust
     stats_out(s, 0, st);
     st->seconds = call_seconds;
 }
+// ---- the focal-length estimator: the reference's own FocalAbsolutePoseEstimator with its default solver
+// P3.5Pf (robust/ransac.cc:58-75, estimators/absolute_pose.cc:73-160, solvers/p35pf.cc; Eigen::EigenSolver from the shim) ----
+int ref_p35pf(const double *x /* 4 x 2 */, const double *X /* 4 x 3 */, double *poses7 /* 10 x 7 */, double *focals /* 10 */) {
+    std::vector<CameraPose> poses;
+    std::vector<double> f;
+    const int n = p35pf(pts2(x, 4), pts3(X, 4), &poses, &f, true);
+    for (int i = 0; i < n && i < 10; ++i) {
+        pose_out(poses[i], poses7 + 7 * i);
+        focals[i] = f[i];
+    }
+    return n;
+}
+void ref_ransac_pnpf(const double *x, const double *X, size_t n, const orc_robust_opt *opt, double *pose7, double *focal,
+                     uint8_t *inliers, orc_stats *st) {
+    Image best;
+    std::vector<char> m;
+    const CallTimer timer;
+    const RansacStats s = ransac_pnpf(pts2(x, n), pts3(X, n), abs_in(opt), &best, &m);
+    const double call_seconds = timer.seconds();
+    pose_out(best.pose, pose7);
+    *focal = best.camera.focal();
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, 0, st);
+    st->seconds = call_seconds;
+}
 void ref_ransac_relpose(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *pose7,
                         uint8_t *inliers, orc_stats *st) {
     CameraPose best = pose_in(pose7);
@@ -417,7 +449,7 @@ void ref_estimate_absolute_pose(const double *p2d, const double *p3d, size_t n, 
     image.pose = pose_in(pose7);
     image.camera = cam_in(cam);
     std::vector<char> m;
-    const RansacStats s = estimate_absolute_pose(pts2(p2d, n), pts3(p3d, n), robust_in<AbsolutePoseOptions>(opt), &image, &m);
+    const RansacStats s = estimate_absolute_pose(pts2(p2d, n), pts3(p3d, n), abs_in(opt), &image, &m);
     pose_out(image.pose, pose7);
     cam->num_params = static_cast<int32_t>(image.camera.params.size());
     for (size_t i = 0; i < image.camera.params.size() && i < 12; ++i)

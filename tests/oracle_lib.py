@@ -34,7 +34,7 @@ class BundleOpt(C.Structure):
 
 class RobustOpt(C.Structure):
     _fields_ = [("ransac", RansacOpt), ("bundle", BundleOpt), ("max_error", f64), ("real_focal_check", i32),
-                ("reserved", i32)]
+                ("estimate_focal_length", i32)]
 
 
 class Stats(C.Structure):
@@ -113,7 +113,7 @@ def bundle_opt(d=None) -> BundleOpt:
 def robust_opt(d=None, default_max_error=1.0) -> RobustOpt:
     d = d or {}
     return RobustOpt(ransac_opt(d.get("ransac")), bundle_opt(d.get("bundle")), d.get("max_error", default_max_error),
-                     int(d.get("real_focal_check", False)), 0)
+                     int(d.get("real_focal_check", False)), int(d.get("estimate_focal_length", False)))
 
 
 def camera(d) -> Camera:
@@ -264,6 +264,38 @@ def bundle_adjust_camera(x, X, cam_dict, pose7, bopt=None):
     st = BundleStats()
     lib().orc_bundle_adjust_camera(_p(x), _p(X), C.c_size_t(x.shape[0]), C.byref(c), _p(p), C.byref(o), C.byref(st))
     return p, np.array(c.params[: c.num_params]), st
+
+
+def _reference_only(name):
+    fn = getattr(lib(), name, None) if not hasattr(lib(), "_cdll") else getattr(lib(), name)
+    if fn is None:
+        raise RuntimeError(f"{name}: only in the reference build (with ref_lib.reference(): ...) - the oracle has no "
+                           "restatement of the focal-length estimators (P3.5Pf is a generated elimination template)")
+    return fn
+
+
+def p35pf(x, X):
+    """solvers/p35pf.h (the REFERENCE's sources only): x 4 x 2 image points (principal point at the origin), X 4 x 3.
+    Returns (poses n x 7, focals n)."""
+    x, X = _f(x), _f(X)
+    poses = np.zeros((10, 7))
+    focals = np.zeros(10)
+    n = _reference_only("orc_p35pf")(_p(x), _p(X), _p(poses), _p(focals))
+    return poses[:n].copy(), focals[:n].copy()
+
+
+def ransac_pnpf(x, X, opt=None):
+    """robust/ransac.h ransac_pnpf (the REFERENCE's sources only): pose + focal length of a SIMPLE_PINHOLE camera with the
+    principal point at the origin.  Returns (pose7, focal, mask, stats)."""
+    x, X = _f(x), _f(X)
+    n = x.shape[0]
+    o = robust_opt(opt, 12.0)
+    pose = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    focal = C.c_double(0.0)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    st = Stats()
+    _reference_only("orc_ransac_pnpf")(_p(x), _p(X), C.c_size_t(n), C.byref(o), _p(pose), C.byref(focal), _p(mask), C.byref(st))
+    return pose, focal.value, mask[:n].astype(bool), stats_dict(st)
 
 
 def refine(kind, x1, x2, model, bopt=None):
