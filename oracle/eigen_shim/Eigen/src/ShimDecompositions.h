@@ -403,6 +403,39 @@ template <typename T, int R, int C> class ShimHouseholderQR {
         }
         return Q;
     }
+    // x = R^-1 (Q^T b) for a square (or tall, least-squares) system: the reflectors applied to b in order, back substitution
+    template <typename D, int BR, int BC> Matrix<T, C, BC> solve(const Dense<D, T, BR, BC> &b) const {
+        Matrix<T, Dynamic, Dynamic> c;
+        c.resize(b.rows(), b.cols());
+        for (Index j = 0; j < b.cols(); ++j)
+            for (Index i = 0; i < b.rows(); ++i)
+                c(i, j) = b(i, j);
+        const Index size = std::min(rows_, cols_);
+        for (Index k = 0; k < size; ++k) {
+            const T tk = tau_[static_cast<size_t>(k)];
+            if (tk == T(0))
+                continue;
+            for (Index j = 0; j < c.cols(); ++j) {
+                T t = T(0);
+                for (Index r = k + 1; r < rows_; ++r)
+                    t += qr_(r, k) * c(r, j);
+                t += c(k, j);
+                c(k, j) -= tk * t;
+                for (Index r = k + 1; r < rows_; ++r)
+                    c(r, j) -= tk * qr_(r, k) * t;
+            }
+        }
+        Matrix<T, C, BC> x;
+        x.resize(cols_, b.cols());
+        for (Index j = 0; j < b.cols(); ++j)
+            for (Index i = size - 1; i >= 0; --i) {
+                T s = c(i, j);
+                for (Index k = i + 1; k < size; ++k)
+                    s -= qr_(i, k) * x(k, j);
+                x(i, j) = s / qr_(i, i);
+            }
+        return x;
+    }
 
   private:
     Index rows_, cols_;

@@ -402,6 +402,23 @@ void ref_ransac_pnpf(const double *x, const double *X, size_t n, const orc_robus
     stats_out(s, 0, st);
     st->seconds = call_seconds;
 }
+// shared unknown focal length, two views (robust.cc:366-430, robust/ransac.cc:183-197, estimators/relative_pose.cc
+// SharedFocalRelativePoseEstimator, solvers/relpose_6pt_focal.cc): pixel coordinates, principal point pp
+void ref_estimate_shared_focal_relative_pose(const double *x1, const double *x2, size_t n, const double *pp2,
+                                             const orc_robust_opt *opt, double *pose7, double *focal, uint8_t *inliers,
+                                             orc_stats *st) {
+    ImagePair pair;
+    std::vector<char> m;
+    const CallTimer timer;
+    const RansacStats s = estimate_shared_focal_relative_pose(pts2(x1, n), pts2(x2, n), Point2D(pp2[0], pp2[1]), rel_in(opt), &pair, &m);
+    const double call_seconds = timer.seconds();
+    pose_out(pair.pose, pose7);
+    *focal = pair.camera1.focal();
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, 0, st);
+    st->seconds = call_seconds;
+}
 void ref_ransac_relpose(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *pose7,
                         uint8_t *inliers, orc_stats *st) {
     CameraPose best = pose_in(pose7);

@@ -298,6 +298,22 @@ def ransac_pnpf(x, X, opt=None):
     return pose, focal.value, mask[:n].astype(bool), stats_dict(st)
 
 
+def estimate_shared_focal_relative_pose(x1, x2, pp, opt=None):
+    """robust.h:84-87 (the REFERENCE's sources only): relative pose of two views with ONE unknown focal length; pixel points,
+    principal point pp.  Returns (pose7, focal, mask, stats)."""
+    x1, x2 = _f(x1), _f(x2)
+    n = x1.shape[0]
+    o = robust_opt(opt, 1.0)
+    pose = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    focal = C.c_double(0.0)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    st = Stats()
+    ppa = _f(pp)
+    _reference_only("orc_estimate_shared_focal_relative_pose")(_p(x1), _p(x2), C.c_size_t(n), _p(ppa), C.byref(o), _p(pose),
+                                                               C.byref(focal), _p(mask), C.byref(st))
+    return pose, focal.value, mask[:n].astype(bool), stats_dict(st)
+
+
 def refine(kind, x1, x2, model, bopt=None):
     x1, x2 = _f(x1), _f(x2)
     o = bundle_opt(bopt)

@@ -4,7 +4,8 @@
 robust/estimators/absolute_pose.h:71-113) with the rest of the reference's sources; what it needed from Eigen -
 `householderQr().householderQ()`, `EigenSolver(A, false).eigenvalues()`, linear indexing of a matrix - is in
 `oracle/eigen_shim` (Hessenberg reduction + Francis double-shift QR; agrees with LAPACK to 1e-13 on random 10 x 10
-matrices).  `ref_p35pf`, `ref_ransac_pnpf` and `estimate_absolute_pose` with `estimate_focal_length` run the REFERENCE's code
+matrices).  `ref_p35pf`, `ref_ransac_pnpf`, `estimate_absolute_pose` with `estimate_focal_length` and
+`ref_estimate_shared_focal_relative_pose` (solvers/relpose_6pt_focal.cc) run the REFERENCE's code
 (robust/ransac.cc:58-75, robust.cc:47-54, estimators/absolute_pose.cc:73-160, bundle with refine_focal_length).
 
 There is NO oracle restatement and NO device path for these estimators (P3.5Pf is a machine-generated elimination
@@ -75,3 +76,22 @@ def test_estimate_absolute_pose_with_estimate_focal_length_through_the_reference
     assert _pose_error(pose, d) < 5e-3
     assert mask.sum() >= 0.97 * d["inlier_gt"].sum()
     assert cam2[0] == pytest.approx(1.3 * f, rel=1e-12) and mask2.sum() < mask.sum()  # without the option the wrong focal stays
+
+
+@pytest.mark.parametrize("seed,outliers", [(0, 0.3), (1, 0.5)])
+def test_shared_focal_relative_pose_of_the_reference(seed, outliers):
+    """robust.cc:366-430 estimate_shared_focal_relative_pose -> ransac_shared_focal_relpose (ransac.cc:183-197) ->
+    SharedFocalRelativePoseEstimator with relpose_6pt_shared_focal (generated template + Sturm chain of degree 15) and the
+    shared-focal refiner: the reference's sources, compiled since round 3 (the shim's HouseholderQR::solve, MatrixBase, ...)"""
+    d = synth.relative_pose_scene(1200, outliers, 8400 + seed)
+    f, cx, cy = d["camera1"]["params"]
+    with ref_lib.reference():
+        pose, focal, mask, st = O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], {"max_error": 2.0, "ransac": {"seed": seed}})
+    assert abs(focal - f) / f < 5e-3
+    t_gt = d["t_gt"] / np.linalg.norm(d["t_gt"])
+    t = pose[4:] / np.linalg.norm(pose[4:])
+    assert np.abs(synth.quat_to_rotmat(pose[:4]) - synth.quat_to_rotmat(np.asarray(d["q_gt"]))).max() < 5e-3
+    assert np.abs(t - t_gt).max() < 5e-3
+    assert (mask & d["inlier_gt"]).sum() >= 0.97 * d["inlier_gt"].sum() and (mask & ~d["inlier_gt"]).sum() <= 0.02 * len(mask)
+    with pytest.raises(RuntimeError):
+        O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy])  # (the oracle has no such estimator)
