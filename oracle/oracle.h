@@ -40,8 +40,7 @@ typedef struct {
     orc_bundle_opt bundle;
     double max_error;
     int32_t real_focal_check; /* fundamental only */
-    int32_t estimate_focal_length; /* absolute pose: AbsolutePoseOptions::estimate_focal_length - REFERENCE BUILD ONLY (oracle/_ref):
-                                      the oracle has no restatement of the P3.5Pf template solver and ignores it */
+    int32_t estimate_focal_length; /* absolute pose: AbsolutePoseOptions::estimate_focal_length (robust.cc:47-54) */
 } orc_robust_opt;
 
 typedef struct {
@@ -80,6 +79,8 @@ int orc_solve_cubic_single_real(double c2, double c1, double c0, double *root);
 int orc_solve_cubic_real(double c2, double c1, double c0, double *roots);
 int orc_sturm_roots(const double *coeffs, int degree, double *roots);
 int orc_p3p(const double *x /*3x3*/, const double *X /*3x3*/, double *poses /*4x7*/);
+int orc_p35pf(const double *x /*4x2, principal point at the origin*/, const double *X /*4x3*/, double *poses /*10x7*/,
+              double *focals /*10*/);
 int orc_essential_5pt(const double *x1, const double *x2, double *E /*10x9 col-major each*/);
 int orc_relpose_5pt(const double *x1, const double *x2, double *poses /*40x7*/);
 int orc_relpose_7pt(const double *x1, const double *x2, double *F /*3x9*/);
@@ -126,6 +127,9 @@ void orc_ransac_fundamental(const double *x1, const double *x2, size_t n, const 
 void orc_ransac_homography(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *H9,
                            uint8_t *inliers, orc_stats *st);
 
+/* robust/ransac.h ransac_pnpf: pose + focal length (SIMPLE_PINHOLE, principal point at the origin) */
+void orc_ransac_pnpf(const double *x, const double *X, size_t n, const orc_robust_opt *opt, double *pose7, double *focal,
+                     uint8_t *inliers, orc_stats *st);
 void orc_estimate_absolute_pose(const double *p2d, const double *p3d, size_t n, const orc_robust_opt *opt,
                                 orc_camera *cam, double *pose7, uint8_t *inliers, orc_stats *st);
 void orc_estimate_relative_pose(const double *x1, const double *x2, size_t n, const orc_camera *cam1,

@@ -185,6 +185,19 @@ int orc_p3p(const double *x, const double *X, double *poses) {
         pose_out(out[i], poses + 7 * i);
     return n;
 }
+int orc_p35pf(const double *x, const double *X, double *poses7, double *focals) {
+    V2 xi[4];
+    V3 Xp[4];
+    for (int i = 0; i < 4; ++i) {
+        xi[i] = V2{x[2 * i], x[2 * i + 1]};
+        Xp[i] = V3{X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+    }
+    Pose out[10];
+    const int n = p35pf(xi, Xp, out, focals);
+    for (int i = 0; i < n; ++i)
+        pose_out(out[i], poses7 + 7 * i);
+    return n;
+}
 int orc_essential_5pt(const double *x1, const double *x2, double *E) {
     V3 a[5], b[5];
     bearings(x1, 5, a);
@@ -399,12 +412,31 @@ void orc_ransac_homography(const double *x1, const double *x2, size_t n, const o
     stats_out(s, tr, t1 - t0, st);
 }
 
+void orc_ransac_pnpf(const double *x, const double *X, size_t n, const orc_robust_opt *opt, double *pose7, double *focal,
+                     uint8_t *inliers, orc_stats *st) {
+    AbsolutePoseOptions o;
+    o.ransac = ropt(opt->ransac);
+    o.bundle = bopt(opt->bundle);
+    o.max_error = opt->max_error;
+    Image best;
+    std::vector<char> m;
+    LoopTrace tr;
+    const double t0 = now();
+    const RansacStats s = ransac_pnpf(pts2(x, n), pts3(X, n), o, &best, &m, &tr);
+    const double t1 = now();
+    pose_out(best.pose, pose7);
+    *focal = best.camera.focal();
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, tr, t1 - t0, st);
+}
 void orc_estimate_absolute_pose(const double *p2d, const double *p3d, size_t n, const orc_robust_opt *opt,
                                 orc_camera *cam, double *pose7, uint8_t *inliers, orc_stats *st) {
     AbsolutePoseOptions o;
     o.ransac = ropt(opt->ransac);
     o.bundle = bopt(opt->bundle);
     o.max_error = opt->max_error;
+    o.estimate_focal_length = opt->estimate_focal_length != 0;
     Image im;
     im.pose = pose_in(pose7);
     im.camera = cam_in(cam);

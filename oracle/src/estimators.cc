@@ -4,6 +4,10 @@
 #include "scoring.h"
 #include "solvers.h"
 
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
 namespace orc {
 
 namespace {
@@ -38,6 +42,108 @@ struct AbsEstimator {
     }
     double score(const Pose &p, uint64_t *cnt) const { return msac_reproj(p, x, X, opt.max_error * opt.max_error, cnt); }
     void refine(Pose *p) const { bundle_adjust(x, X, p, lo_options(opt.max_error)); }
+};
+
+// utils.cc:66-100: MSAC score through a camera (here always the SIMPLE_PINHOLE camera of the focal estimator: f x + cx)
+double msac_reproj_image(const Image &im, const std::vector<V2> &x, const std::vector<V3> &X, double sq_thr, uint64_t *inliers) {
+    *inliers = 0;
+    double score = 0.0;
+    const M3 R = im.pose.R();
+    const V3 &t = im.pose.t;
+    const double f = im.camera.params[0], cx = im.camera.params[1], cy = im.camera.params[2];
+    for (size_t k = 0; k < x.size(); ++k) {
+        const double X0 = X[k].x, X1 = X[k].y, X2 = X[k].z;
+        const double z0 = R.m[0][0] * X0 + R.m[0][1] * X1 + R.m[0][2] * X2 + t.x;
+        const double z1 = R.m[1][0] * X0 + R.m[1][1] * X1 + R.m[1][2] * X2 + t.y;
+        const double z2 = R.m[2][0] * X0 + R.m[2][1] * X1 + R.m[2][2] * X2 + t.z;
+        if (z2 <= 0.0)
+            continue;
+        const double inv_z2 = 1.0 / z2;
+        const double r0 = (f * (z0 * inv_z2) + cx) - x[k].x;
+        const double r1 = (f * (z1 * inv_z2) + cy) - x[k].y;
+        const double r_sq = r0 * r0 + r1 * r1;
+        if (r_sq < sq_thr) {
+            ++*inliers;
+            score += r_sq;
+        }
+    }
+    score += static_cast<double>(x.size() - *inliers) * sq_thr;
+    return score;
+}
+// utils.cc:385-399 (hnormalized: a division, not the reciprocal of the score above)
+void inliers_reproj_image(const Image &im, const std::vector<V2> &x, const std::vector<V3> &X, double sq_thr, std::vector<char> *mask) {
+    mask->resize(x.size());
+    const M3 R = im.pose.R();
+    const double f = im.camera.params[0], cx = im.camera.params[1], cy = im.camera.params[2];
+    for (size_t k = 0; k < x.size(); ++k) {
+        const V3 Z = R * X[k] + im.pose.t;
+        const double r0 = (f * (Z.x / Z.z) + cx) - x[k].x, r1 = (f * (Z.y / Z.z) + cy) - x[k].y;
+        const double r2 = r0 * r0 + r1 * r1;
+        (*mask)[k] = (r2 < sq_thr && Z.z > 0.0);
+    }
+}
+
+// estimators/absolute_pose.{h:69-113, cc:71-177} with the defaults of the class: solver P3.5Pf, refine_minimal_sample and
+// filter_minimal_sample off, inlier_scoring on.  The solver is the oracle's own (solvers_focal.cc) - the same solution SET as the
+// reference's generated template to ~1e-7, in ascending order of the eigenvalue instead of the order of Eigen's EigenSolver
+struct FocalAbsEstimator {
+    const AbsolutePoseOptions &opt;
+    const std::vector<V2> &x;
+    const std::vector<V3> &X;
+    Sampler sampler;
+    size_t sample_sz = 4, num_data;
+    double max_focal_length = -1.0;
+    FocalAbsEstimator(const AbsolutePoseOptions &o, const std::vector<V2> &x_, const std::vector<V3> &X_)
+        : opt(o), x(x_), X(X_), sampler(x_.size(), 4, o.ransac), num_data(x_.size()) {
+        if (o.min_fov > 0) { // absolute_pose.cc:159-177
+            double max_coord = 0.0;
+            for (const V2 &p : x) {
+                max_coord = std::max(max_coord, std::abs(p.x));
+                max_coord = std::max(max_coord, std::abs(p.y));
+            }
+            max_focal_length = max_coord / std::tan(o.min_fov * M_PI / 180.0 / 2.0);
+        }
+    }
+    void generate(std::vector<Image> *models) {
+        uint64_t s[4];
+        sampler.next(s);
+        V2 xs[4];
+        V3 Xs[4];
+        for (int k = 0; k < 4; ++k) {
+            xs[k] = x[s[k]];
+            Xs[k] = X[s[k]];
+        }
+        Pose sol[10];
+        double focals[10];
+        const int n = p35pf(xs, Xs, sol, focals);
+        models->clear();
+        for (int i = 0; i < n; ++i) {
+            if (focals[i] < 0)
+                continue;
+            if (max_focal_length >= 0 && focals[i] > max_focal_length)
+                continue;
+            Image im;
+            im.pose = sol[i];
+            im.camera.model_id = CAM_SIMPLE_PINHOLE;
+            im.camera.params = {focals[i], 0.0, 0.0};
+            models->push_back(im);
+        }
+    }
+    double score(const Image &im, uint64_t *cnt) const { // absolute_pose.cc:128-143
+        if (im.camera.focal() < 0)
+            return std::numeric_limits<double>::max();
+        double sc = msac_reproj_image(im, x, X, opt.max_error * opt.max_error, cnt);
+        // inlier_scoring (default on): the outliers are charged a second time, associated as ((n - c) e) e
+        sc += static_cast<double>(x.size() - *cnt) * opt.max_error * opt.max_error;
+        if (max_focal_length > 0 && im.camera.focal() > max_focal_length)
+            sc = std::numeric_limits<double>::max();
+        return sc;
+    }
+    void refine(Image *im) const { // absolute_pose.cc:145-157
+        BundleOptions b = lo_options(opt.max_error);
+        b.refine_focal_length = true;
+        bundle_adjust(x, X, im, b);
+    }
 };
 
 struct RelEstimator {
@@ -154,6 +260,17 @@ RansacStats ransac_pnp(const std::vector<V2> &x, const std::vector<V3> &X, const
     inliers_reproj(*best, x, X, opt.max_error * opt.max_error, inliers);
     return st;
 }
+RansacStats ransac_pnpf(const std::vector<V2> &x, const std::vector<V3> &X, const AbsolutePoseOptions &opt, Image *best,
+                        std::vector<char> *inliers, LoopTrace *trace) { // ransac.cc:58-75
+    reset_pose(&best->pose);
+    best->camera.model_id = CAM_SIMPLE_PINHOLE;
+    best->camera.width = best->camera.height = 0;
+    best->camera.params = {1.0, 0.0, 0.0};
+    FocalAbsEstimator est(opt, x, X);
+    const RansacStats st = lo_ransac(est, opt.ransac, best, trace);
+    inliers_reproj_image(*best, x, X, opt.max_error * opt.max_error, inliers);
+    return st;
+}
 RansacStats ransac_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,
                            Pose *best, std::vector<char> *inliers, LoopTrace *trace) {
     if (!opt.ransac.score_initial_model)
@@ -192,7 +309,16 @@ RansacStats estimate_absolute_pose(const std::vector<V2> &p2d, const std::vector
     double scale = 1.0 / image->camera.focal();
     scaled.max_error *= scale;
 
-    const RansacStats st = ransac_pnp(norm_pts, p3d, scaled, &image->pose, inliers);
+    RansacStats st;
+    if (opt.estimate_focal_length) { // robust.cc:47-54
+        Image img;
+        st = ransac_pnpf(norm_pts, p3d, scaled, &img, inliers);
+        image->pose = img.pose;
+        image->camera.set_focal(img.camera.focal() / scale);
+        scaled.bundle.refine_focal_length = true;
+    } else {
+        st = ransac_pnp(norm_pts, p3d, scaled, &image->pose, inliers);
+    }
 
     if (st.num_inliers > 3) {
         std::vector<V2> xin;

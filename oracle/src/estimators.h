@@ -14,10 +14,12 @@
 
 namespace orc {
 
-struct AbsolutePoseOptions { // types.h:108-126 (focal-length estimation branches are out of scope)
+struct AbsolutePoseOptions { // types.h:108-126 (estimate_extra_params - the radial-distortion branch - is out of scope)
     RansacOptions ransac;
     BundleOptions bundle;
     double max_error = 12.0;
+    bool estimate_focal_length = false;
+    double min_fov = 5.0; // degrees; bounds the focal length the focal estimator accepts (types.h:126)
 };
 struct RelativePoseOptions { // types.h:128-145
     RansacOptions ransac;
@@ -34,6 +36,10 @@ struct HomographyOptions { // types.h:170-175
 
 RansacStats ransac_pnp(const std::vector<V2> &x, const std::vector<V3> &X, const AbsolutePoseOptions &opt, Pose *best,
                        std::vector<char> *inliers, LoopTrace *trace = nullptr);
+// robust/ransac.cc:58-75 with FocalAbsolutePoseEstimator (estimators/absolute_pose.{h:69-113,cc:71-177}, solver P3.5Pf): pose and
+// focal length of a SIMPLE_PINHOLE camera whose principal point is the origin
+RansacStats ransac_pnpf(const std::vector<V2> &x, const std::vector<V3> &X, const AbsolutePoseOptions &opt, Image *best,
+                        std::vector<char> *inliers, LoopTrace *trace = nullptr);
 RansacStats ransac_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,
                            Pose *best, std::vector<char> *inliers, LoopTrace *trace = nullptr);
 RansacStats ransac_fundamental(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,

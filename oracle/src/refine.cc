@@ -11,6 +11,20 @@
 namespace orc {
 
 // ------------------------------------------------------------------------------------ camera
+void Camera::set_focal(double f) { // camera_models.cc:96-107 over focal_idx of the model
+    switch (model_id) {
+    case CAM_SIMPLE_PINHOLE:
+        params.at(0) = f;
+        break;
+    case CAM_PINHOLE:
+    case CAM_OPENCV:
+        params.at(0) = f;
+        params.at(1) = f;
+        break;
+    default:
+        break;
+    }
+}
 double Camera::focal() const { // camera_models.cc:304-323
     if (params.empty())
         return 1.0;

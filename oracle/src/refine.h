@@ -53,6 +53,7 @@ struct Camera {
     int width = 0, height = 0;
     std::vector<double> params;
     double focal() const;
+    void set_focal(double f); // camera_models.cc:96-107
     void rescale(double s);
     // unit bearing from pixel
     V3 unproject3(const V2 &xp) const;

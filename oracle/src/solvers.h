@@ -18,6 +18,9 @@ int sturm_real_roots(const double *c, int N, double *roots, double tol = 1e-10);
 
 // absolute pose: unit bearings x, 3-D points X  ->  <= 4 poses
 int p3p(const V3 x[3], const V3 X[3], Pose out[4]);
+// P3.5Pf from first principles (solvers_focal.cc; interface of solvers/p35pf.h:39-54): image points relative to the principal
+// point, at most 10 (pose, focal) solutions
+int p35pf(const V2 x[4], const V3 X[4], Pose out[10], double focals[10]);
 
 // relative pose (unit bearings)
 int essential_5pt(const V3 x1[5], const V3 x2[5], M3 E[10]);

@@ -270,22 +270,22 @@ def _reference_only(name):
     fn = getattr(lib(), name, None) if not hasattr(lib(), "_cdll") else getattr(lib(), name)
     if fn is None:
         raise RuntimeError(f"{name}: only in the reference build (with ref_lib.reference(): ...) - the oracle has no "
-                           "restatement of the focal-length estimators (P3.5Pf is a generated elimination template)")
+                           "restatement of the shared-focal relative estimator (a generated elimination template)")
     return fn
 
 
 def p35pf(x, X):
-    """solvers/p35pf.h (the REFERENCE's sources only): x 4 x 2 image points (principal point at the origin), X 4 x 3.
+    """solvers/p35pf.h: x 4 x 2 image points (principal point at the origin), X 4 x 3.
     Returns (poses n x 7, focals n)."""
     x, X = _f(x), _f(X)
     poses = np.zeros((10, 7))
     focals = np.zeros(10)
-    n = _reference_only("orc_p35pf")(_p(x), _p(X), _p(poses), _p(focals))
+    n = lib().orc_p35pf(_p(x), _p(X), _p(poses), _p(focals))
     return poses[:n].copy(), focals[:n].copy()
 
 
 def ransac_pnpf(x, X, opt=None):
-    """robust/ransac.h ransac_pnpf (the REFERENCE's sources only): pose + focal length of a SIMPLE_PINHOLE camera with the
+    """robust/ransac.h ransac_pnpf: pose + focal length of a SIMPLE_PINHOLE camera with the
     principal point at the origin.  Returns (pose7, focal, mask, stats)."""
     x, X = _f(x), _f(X)
     n = x.shape[0]
@@ -294,7 +294,7 @@ def ransac_pnpf(x, X, opt=None):
     focal = C.c_double(0.0)
     mask = np.zeros(max(n, 1), dtype=np.uint8)
     st = Stats()
-    _reference_only("orc_ransac_pnpf")(_p(x), _p(X), C.c_size_t(n), C.byref(o), _p(pose), C.byref(focal), _p(mask), C.byref(st))
+    lib().orc_ransac_pnpf(_p(x), _p(X), C.c_size_t(n), C.byref(o), _p(pose), C.byref(focal), _p(mask), C.byref(st))
     return pose, focal.value, mask[:n].astype(bool), stats_dict(st)
 
 
