@@ -77,7 +77,10 @@ typedef struct {
     double max_error;         /* 12.0 absolute pose, 1.0 otherwise */
     int32_t real_focal_check; /* fundamental only */
     int32_t tangent_sampson;  /* relative pose: must be 0 (out of scope) */
-    int32_t estimate_focal_length, estimate_extra_params; /* absolute pose: must be 0 (out of scope) */
+    int32_t estimate_focal_length; /* pl_estimate_absolute_pose: robust.cc:47-54 - RANSAC over pose AND focal length (ransac_pnpf,
+                                      P3.5Pf), the camera's focal length is replaced and refined in the final bundle; every
+                                      other entry point: must be 0 */
+    int32_t estimate_extra_params; /* must be 0 (radial distortion estimation: out of scope) */
 } pl_robust_options;
 
 /* types.h:52-58 (+ the metric numerator and timing, which the reference does not report) */
@@ -156,6 +159,11 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight);
 /* ---- RANSAC entry points on normalised points (robust/ransac.h) ---- */
 int pl_ransac_pnp(const double *x, const double *X, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
                   uint8_t *inliers, pl_ransac_stats *stats);
+/* robust/ransac.h:52-54 ransac_pnpf (FocalAbsolutePoseEstimator, estimators/absolute_pose.h:69-113): pose and focal length of a
+ * SIMPLE_PINHOLE camera whose principal point is the origin of the image points x.  The model is reset before the loop as in
+ * the reference (ransac.cc:61-66); min_fov is the reference's default (5 degrees).  PROSAC sampling: PL_ERR_UNSUPPORTED. */
+int pl_ransac_pnpf(const double *x, const double *X, size_t n, const pl_robust_options *opt, pl_camera_pose *pose, double *focal,
+                   uint8_t *inliers, pl_ransac_stats *stats);
 int pl_ransac_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
                       uint8_t *inliers, pl_ransac_stats *stats);
 int pl_ransac_fundamental(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *F,

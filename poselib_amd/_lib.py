@@ -129,6 +129,7 @@ def _declare(L):
         "pl_ransac_batch": (cint, [P(RansacItem), sz, cint, cint]),
         "pl_undistort_points": (cint, [cam, vp, sz, vp]),
         "pl_ransac_pnp": (cint, [vp, vp, sz, opt, pose, vp, stats]),
+        "pl_ransac_pnpf": (cint, [vp, vp, sz, opt, pose, P(dbl), vp, stats]),
         "pl_ransac_relpose": (cint, [vp, vp, sz, opt, pose, vp, stats]),
         "pl_ransac_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
         "pl_ransac_homography": (cint, [vp, vp, sz, opt, vp, vp, stats]),
@@ -169,5 +170,5 @@ EXPORTED_SYMBOLS = [
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
     "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_bundle_adjust_camera", "pl_p3p", "pl_relpose_5pt",
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
-    "pl_ransac_batch", "pl_debug_device_math",
+    "pl_ransac_batch", "pl_debug_device_math", "pl_ransac_pnpf",
 ]

@@ -413,6 +413,20 @@ def ransac_pnp(x, X, opt=None, initial_pose=None):
     return _ransac("pl_ransac_pnp", KIND_ABS, x, X, 3, opt, initial_pose)
 
 
+def ransac_pnpf(x, X, opt=None):
+    """robust/ransac.h ransac_pnpf: pose and focal length of a SIMPLE_PINHOLE camera whose principal point is the origin of `x`.
+    Returns (Image(pose, Camera SIMPLE_PINHOLE [f, 0, 0]), info)."""
+    x, X = _pts(x, 2), _pts(X, 3)
+    o = _robust_options(opt, KIND_ABS, False)
+    n = x.shape[0]
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    st = L.RansacStats()
+    pose = _cpose(CameraPose())
+    focal = C.c_double(1.0)
+    L.check(L.lib().pl_ransac_pnpf(_ptr(x), _ptr(X), C.c_size_t(n), C.byref(o), C.byref(pose), C.byref(focal), _ptr(inl), C.byref(st)))
+    return Image(_pypose(pose), Camera("SIMPLE_PINHOLE", [focal.value, 0.0, 0.0])), _info(st, inl[:n])
+
+
 def ransac_relpose(x1, x2, opt=None, initial_pose=None):
     return _ransac("pl_ransac_relpose", KIND_REL, x1, x2, 2, opt, initial_pose)
 

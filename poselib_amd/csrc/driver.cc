@@ -17,8 +17,10 @@
 //            reductions of normalize_points, threshold rescaling and de-normalisation; PROSAC's serial sample schedule.
 // There is no CPU fallback for any device stage: without a HIP device the entry points fail.
 #include "../../include/poselib_amd.h"
+#include "pl_focal.h"
 #include "pl_kernels.h"
 #include "pl_refine_cam.h"
+#include "pl_solver_p35pf.h"
 #include "pl_sampler.h"
 
 #include <algorithm>
@@ -319,6 +321,14 @@ double camera_focal(const pl_camera *c) { // misc/camera_models.cc:304-323
         return 0.0 + c->params[0] / 2 + c->params[1] / 2;
     default:
         return 1.0;
+    }
+}
+void camera_set_focal(pl_camera *c, double f) { // misc/camera_models.cc:96-107 over the model's focal_idx
+    if (c->model_id == CAM_SIMPLE_PINHOLE && c->num_params >= 1) {
+        c->params[0] = f;
+    } else if ((c->model_id == CAM_PINHOLE || c->model_id == CAM_OPENCV) && c->num_params >= 2) {
+        c->params[0] = f;
+        c->params[1] = f;
     }
 }
 void camera_rescale(CameraParams &c, double s) { // misc/camera_models.cc:432-455
@@ -1619,13 +1629,17 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
     return run.run();
 }
 
-int validate_options(const pl_robust_options *o) {
+int validate_options(const pl_robust_options *o, bool focal_entry = false) {
     if (!o)
         return fail(PL_ERR_INVALID, "options pointer is null");
+    // estimate_focal_length: pl_estimate_absolute_pose only (robust.cc:47-54 -> ransac_pnpf, driver_focal.inc)
+    if (focal_entry && o->estimate_focal_length && !o->tangent_sampson && !o->estimate_extra_params)
+        return PL_OK;
     // (bundle.refine_*: used by the absolute-pose front-end's final bundle, robust.cc:103-123; the other front-ends'
     // refiners have no camera to move, the reference ignores the flags there and so does this library)
     if (o->tangent_sampson || o->estimate_focal_length || o->estimate_extra_params)
-        return fail(PL_ERR_UNSUPPORTED, "tangent-Sampson / focal-length estimation are outside the accelerated hot path");
+        return fail(PL_ERR_UNSUPPORTED, "tangent-Sampson errors, estimate_extra_params and - outside pl_estimate_absolute_pose - "
+                                        "estimate_focal_length are outside the accelerated hot path");
     return PL_OK;
 }
 
@@ -1937,6 +1951,7 @@ double normalization_of(const double *x1, const double *x2, size_t n, bool centr
     return scale;
 }
 
+#include "driver_focal.inc"
 #include "driver_group.inc"
 
 } // namespace
@@ -2312,6 +2327,28 @@ int pl_ransac_pnp(const double *x, const double *X, size_t n, const pl_robust_op
                   uint8_t *inliers, pl_ransac_stats *stats) {
     return ransac_oneshot(EST_ABS, x, X, n, opt, pose, inliers, stats);
 }
+int pl_ransac_pnpf(const double *x, const double *X, size_t n, const pl_robust_options *opt, pl_camera_pose *pose, double *focal,
+                   uint8_t *inliers, pl_ransac_stats *stats) {
+    if (!opt || !pose || !focal)
+        return fail(PL_ERR_INVALID, "null argument");
+    pl_robust_options o = *opt;
+    o.estimate_focal_length = 1;
+    int rc = validate_options(&o, /*focal_entry=*/true);
+    if (rc != PL_OK)
+        return rc;
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    pl_problem p;
+    rc = make_problem(c, EST_ABS, x, X, n, &p);
+    if (rc != PL_OK)
+        return rc;
+    pl_ransac_stats local;
+    rc = run_focal(c, &p, &o, pose, focal, inliers, stats ? stats : &local);
+    free_problem(&p);
+    return rc;
+}
 int pl_ransac_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
                       uint8_t *inliers, pl_ransac_stats *stats) {
     return ransac_oneshot(EST_REL, x1, x2, n, opt, pose, inliers, stats);
@@ -2328,7 +2365,7 @@ int pl_ransac_homography(const double *x1, const double *x2, size_t n, const pl_
 // ---------------------------------------------------------------------------- front-ends (robust.cc)
 int pl_estimate_absolute_pose(const double *points2D, const double *points3D, size_t n, const pl_robust_options *opt,
                               pl_camera *camera, pl_camera_pose *pose, uint8_t *inliers, pl_ransac_stats *stats) {
-    int rc = validate_options(opt);
+    int rc = validate_options(opt, /*focal_entry=*/true);
     if (rc != PL_OK)
         return rc;
     if (!camera || !camera_supported(camera))
@@ -2338,7 +2375,7 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
     if (rc != PL_OK)
         return rc;
     // robust.cc:40-46 : un-project, rescale the threshold by 1/focal
-    const CameraParams cam = to_cam(camera);
+    CameraParams cam = to_cam(camera);
     pl_robust_options scaled = *opt;
     double scale = 1.0 / camera_focal(camera);
     scaled.max_error *= scale;
@@ -2350,10 +2387,23 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
     pl_ransac_stats local;
     pl_ransac_stats *st = stats ? stats : &local;
     double rec[kModelStride];
-    rc = run_with_model(c, &p, &scaled, pose, inliers, st, rec);
-    free_problem(&p);
-    if (rc != PL_OK)
-        return rc;
+    pl_bundle_options bundle = opt->bundle;
+    if (opt->estimate_focal_length) { // robust.cc:47-54: ransac_pnpf on the un-projected points, the camera takes its focal length
+        double focal = 1.0;
+        rc = run_focal(c, &p, &scaled, pose, &focal, inliers, st);
+        free_problem(&p);
+        if (rc != PL_OK)
+            return rc;
+        camera_set_focal(camera, focal / scale);
+        cam = to_cam(camera);
+        bundle.refine_focal_length = 1; // "force refinement of focal in this case"
+        record_from_pose(pose, false, rec);
+    } else {
+        rc = run_with_model(c, &p, &scaled, pose, inliers, st, rec);
+        free_problem(&p);
+        if (rc != PL_OK)
+            return rc;
+    }
 
     if (st->num_inliers > 3) { // robust.cc:103-123 : bundle over the inliers in focal-normalised pixels
         pl_problem pp;
@@ -2365,13 +2415,13 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
         if (rc != PL_OK)
             return rc;
         scale = 1.0 / camera_focal(camera);
-        pl_bundle_options b = opt->bundle;
+        pl_bundle_options b = bundle;
         b.loss_scale = opt->bundle.loss_scale * scale;
         CameraParams cs = cam;
         camera_rescale(cs, scale);
         double out[kModelStride];
         // bundle.refine_*: the intrinsics the model has among them move with the pose (bundle.cc:93-118)
-        const int cam_flags = active_cam_flags(cs.model_id, opt->bundle);
+        const int cam_flags = active_cam_flags(cs.model_id, bundle);
         CameraParams refined = cs;
         rc = final_refine(c, &pp, rec, to_lm(b), cs, scale, out, nullptr, cam_flags, &refined);
         free_problem(&pp);

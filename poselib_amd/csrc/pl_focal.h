@@ -1,0 +1,310 @@
+// poselib_amd - absolute pose with unknown focal length: the pieces of ransac_pnpf (PoseLib/robust/ransac.cc:58-75 with
+// FocalAbsolutePoseEstimator, robust/estimators/absolute_pose.{h:69-113, cc:71-177}) that are shared by the kernels (focal.hip),
+// the host driver (driver_focal.inc) and the test-only host build (tests/hostmath):
+//   * the model of the estimator - an Image with a SIMPLE_PINHOLE camera {f, 0, 0} - as 8 doubles (q, t, f),
+//   * the per-correspondence residual of compute_msac_score(Image, ...) (robust/utils.cc:66-98) and of get_inliers(Image, ...)
+//     (utils.cc:385-399), in the reference's association order,
+//   * the sequential loop of ransac_impl.h:157-201 replayed over batches of iterations that a back end evaluates (focal_lo_ransac).
+// The minimal solver is pl_solver_p35pf.h.  Defaults of the class that no public entry point of the reference changes:
+// solver P3.5Pf, refine_minimal_sample = filter_minimal_sample = false, inlier_scoring = true.
+#pragma once
+#include "pl_math.h"
+#include "pl_sampler.h"
+
+#include <limits>
+#include <vector>
+
+namespace pl {
+
+constexpr int kFocalSample = 4;
+constexpr int kFocalMaxModels = 10;
+struct FocalModel {
+    double q[4], t[3], f;
+};
+static_assert(sizeof(FocalModel) == 64, "8 doubles");
+
+// utils.cc:76-94 with SIMPLE_PINHOLE project (camera_models.cc: f x + cx, cx = cy = 0 here: + 0.0 changes no squared residual)
+PL_HD bool focal_reproj_inlier(const double *R, const double *t, double f, double x, double y, double X, double Y, double Z,
+                               double thr2, double &r2) {
+    const double z0 = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    const double z1 = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    const double z2 = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    const double inv = 1.0 / z2;
+    const double e0 = f * (z0 * inv) - x;
+    const double e1 = f * (z1 * inv) - y;
+    r2 = e0 * e0 + e1 * e1;
+    return (z2 > 0.0) & (r2 < thr2);
+}
+// utils.cc:385-399: hnormalized() divides
+PL_HD bool focal_reproj_mask(const double *R, const double *t, double f, double x, double y, double X, double Y, double Z,
+                             double thr2) {
+    const double z0 = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    const double z1 = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    const double z2 = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    const double e0 = f * (z0 / z2) - x;
+    const double e1 = f * (z1 / z2) - y;
+    const double r2 = e0 * e0 + e1 * e1;
+    return (r2 < thr2) & (z2 > 0.0);
+}
+PL_HD void focal_rotation(const FocalModel &m, double *R) {
+    Quat q;
+    q.w = m.q[0], q.x = m.q[1], q.y = m.q[2], q.z = m.q[3];
+    const Mat3 Rm = quat_to_rotmat(q);
+    for (int i = 0; i < 9; ++i)
+        R[i] = Rm.m[i];
+}
+
+// ---- host side ----
+// absolute_pose.cc:159-177
+inline double focal_max_focal_length(const double *x, const double *y, size_t n, double min_fov) {
+    if (min_fov <= 0)
+        return -1.0;
+    double max_coord = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        max_coord = std::max(max_coord, std::fabs(x[i]));
+        max_coord = std::max(max_coord, std::fabs(y[i]));
+    }
+    const double min_fov_radians = min_fov * M_PI / 180.0;
+    return max_coord / std::tan(min_fov_radians / 2.0);
+}
+// score_model (absolute_pose.cc:128-143) from the sum of the inliers' squared residuals and their number: the MSAC score of
+// utils.cc:95 plus the outliers once more (inlier_scoring), associated as the reference writes them
+inline double focal_finish_score(double inlier_sum, uint64_t count, uint64_t n, double max_error, double focal, double max_focal) {
+    if (focal < 0)
+        return std::numeric_limits<double>::max();
+    double score = inlier_sum;
+    score += static_cast<double>(n - count) * (max_error * max_error);
+    score += static_cast<double>(n - count) * max_error * max_error;
+    if (max_focal > 0 && focal > max_focal)
+        score = std::numeric_limits<double>::max();
+    return score;
+}
+
+struct FocalLoopOptions {
+    uint64_t max_iterations, min_iterations, seed;
+    double dyn_num_trials_mult, success_prob;
+    bool score_initial_model;
+    double max_error, max_focal;
+};
+struct FocalLoopStats {
+    uint64_t refinements = 0, iterations = 0, num_inliers = 0, hypotheses = 0, iterations_evaluated = 0;
+    double inlier_ratio = 0, model_score = std::numeric_limits<double>::max();
+};
+
+// ransac_impl.h:43-73
+inline uint64_t focal_dynamic_max_iter(uint64_t inl, uint64_t N, uint64_t K, double log_fail, double mult, uint64_t min_it,
+                                       uint64_t max_it) {
+    double p = 1.0;
+    if (inl < K || N < K) {
+        p = 0.0;
+    } else {
+        for (uint64_t i = 0; i < K; ++i)
+            p *= static_cast<double>(inl - i) / static_cast<double>(N - i);
+    }
+    if (p >= 0.9999)
+        return min_it;
+    if (p <= 0.0001)
+        return max_it;
+    const uint64_t n = static_cast<uint64_t>(std::ceil(log_fail / std::log(1.0 - p) * mult));
+    return std::max(min_it, std::min(max_it, n));
+}
+
+// draws consumed before each of `count` iterations (relative to pos), for samples of K distinct indices; returns the position
+// after the last one (sampling.cc:45-60: duplicates are redrawn)
+template <int K> inline uint64_t focal_sample_positions(uint64_t seed, uint64_t pos, uint64_t N, uint32_t count, uint32_t *out) {
+    const uint64_t base = pos;
+    for (uint32_t b = 0; b < count; ++b) {
+        out[b] = (uint32_t)(pos - base);
+        uint32_t idx[K];
+        pos += draw_sample<K>(seed, pos, N, idx);
+    }
+    return pos;
+}
+
+// The sequential LO-RANSAC loop (ransac_impl.h:106-201) over batches of iterations.  The back end evaluates
+//   int minimal(pos_base, positions, B, models [B * 10], num_models [B], counts, sums)   - generate + score a batch,
+//   int score(models, counts, sums)                                                     - score given models,
+//   int refine(seeds, refined)                                                          - refine_model() of every seed;
+// counts / sums: inliers and the sum of their squared residuals in correspondence order, per model slot.  All decisions are
+// taken here, in the reference's order: which hypotheses improve best_minimal_*, which of them seed a local optimisation
+// (the last improving one of an iteration), the incumbent, the dynamic iteration bound and the stop rule.
+template <class Backend>
+int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalModel *best, FocalLoopStats *stats) {
+    FocalLoopStats &st = *stats;
+    st = FocalLoopStats();
+    if (N < (uint64_t)kFocalSample)
+        return 0;
+    uint64_t best_min_inl = 0;
+    double best_min_score = std::numeric_limits<double>::max();
+    uint64_t dyn_max = o.max_iterations;
+    const double log_fail = std::log(1.0 - o.success_prob);
+
+    std::vector<FocalModel> models, seeds, refined;
+    std::vector<uint32_t> num_models, counts, rcounts, positions;
+    std::vector<double> sums, rsums;
+    struct Improving {
+        uint32_t iter, slot;
+        uint64_t count;
+        double score;
+        int job; // index into seeds / refined, -1: not the iteration's last improving hypothesis
+    };
+    std::vector<Improving> imps;
+
+    // candidates of one "iteration" whose minimal scores are known: ransac_impl.h:106-154
+    auto after_lo = [&](const FocalModel &ref, uint64_t rcnt, double rsum) {
+        st.refinements++;
+        const double rsc = focal_finish_score(rsum, rcnt, N, o.max_error, ref.f, o.max_focal);
+        if (rsc < st.model_score) {
+            st.model_score = rsc;
+            st.num_inliers = rcnt;
+            *best = ref;
+        }
+        st.inlier_ratio = static_cast<double>(st.num_inliers) / static_cast<double>(N);
+        dyn_max = focal_dynamic_max_iter(st.num_inliers, N, kFocalSample, log_fail, o.dyn_num_trials_mult, o.min_iterations,
+                                         o.max_iterations);
+    };
+
+    if (o.score_initial_model) {
+        models.assign(1, *best);
+        int rc = be.score(models, counts, sums);
+        if (rc)
+            return rc;
+        const double sc = focal_finish_score(sums[0], counts[0], N, o.max_error, best->f, o.max_focal);
+        const bool more = counts[0] > best_min_inl, better = sc < best_min_score;
+        if (more || better) {
+            if (more)
+                best_min_inl = counts[0];
+            if (better)
+                best_min_score = sc;
+            if (sc < st.model_score) {
+                st.model_score = sc;
+                st.num_inliers = counts[0];
+            }
+            seeds.assign(1, *best);
+            rc = be.refine(seeds, refined);
+            if (rc)
+                return rc;
+            rc = be.score(refined, rcounts, rsums);
+            if (rc)
+                return rc;
+            after_lo(refined[0], rcounts[0], rsums[0]);
+        }
+    }
+
+    uint64_t pos = 0;
+    bool stopped = false;
+    while (!stopped && st.iterations < o.max_iterations) {
+        // the loop cannot stop before iteration max(min_iterations, dyn_max) + 1
+        const uint64_t it0 = st.iterations;
+        const uint64_t horizon = std::max(o.min_iterations, dyn_max) + 1;
+        uint64_t want = horizon > it0 ? horizon - it0 : 1;
+        want = std::min<uint64_t>(std::max<uint64_t>(want, 256), 4096);
+        const uint32_t B = (uint32_t)std::min<uint64_t>(want, o.max_iterations - it0);
+        positions.resize(B);
+        const uint64_t pos_after = focal_sample_positions<kFocalSample>(o.seed, pos, N, B, positions.data());
+        int rc = be.minimal(pos, positions.data(), B, models, num_models, counts, sums);
+        if (rc)
+            return rc;
+        st.iterations_evaluated += B;
+        // pass 1: the hypotheses that improve best_minimal_* (independent of the local optimisations)
+        imps.clear();
+        seeds.clear();
+        for (uint32_t b = 0; b < B; ++b) {
+            int last = -1;
+            for (uint32_t m = 0; m < num_models[b]; ++m) {
+                const size_t h = (size_t)b * kFocalMaxModels + m;
+                const double sc = focal_finish_score(sums[h], counts[h], N, o.max_error, models[h].f, o.max_focal);
+                const bool more = counts[h] > best_min_inl, better = sc < best_min_score;
+                if (!(more || better))
+                    continue;
+                if (more)
+                    best_min_inl = counts[h];
+                if (better)
+                    best_min_score = sc;
+                imps.push_back(Improving{b, m, counts[h], sc, -1});
+                last = (int)imps.size() - 1;
+            }
+            if (last >= 0) {
+                imps[last].job = (int)seeds.size();
+                seeds.push_back(models[(size_t)b * kFocalMaxModels + imps[last].slot]);
+            }
+        }
+        if (!seeds.empty()) {
+            rc = be.refine(seeds, refined);
+            if (rc)
+                return rc;
+            rc = be.score(refined, rcounts, rsums);
+            if (rc)
+                return rc;
+        }
+        // pass 2: the loop itself
+        size_t a = 0;
+        for (uint32_t b = 0; b < B; ++b) {
+            if (st.iterations > o.min_iterations && st.iterations > dyn_max) {
+                stopped = true;
+                break;
+            }
+            st.hypotheses += num_models[b];
+            for (; a < imps.size() && imps[a].iter == b; ++a) {
+                const Improving &im = imps[a];
+                if (im.score < st.model_score) {
+                    st.model_score = im.score;
+                    *best = models[(size_t)b * kFocalMaxModels + im.slot];
+                    st.num_inliers = im.count;
+                }
+                if (im.job >= 0)
+                    after_lo(refined[im.job], rcounts[im.job], rsums[im.job]);
+            }
+            st.iterations++;
+        }
+        pos = pos_after;
+    }
+    // final polish (ransac_impl.h:190-198): model_score is not updated
+    seeds.assign(1, *best);
+    int rc = be.refine(seeds, refined);
+    if (rc)
+        return rc;
+    rc = be.score(refined, rcounts, rsums);
+    if (rc)
+        return rc;
+    st.refinements++;
+    const double rsc = focal_finish_score(rsums[0], rcounts[0], N, o.max_error, refined[0].f, o.max_focal);
+    if (rsc < st.model_score) {
+        *best = refined[0];
+        st.num_inliers = rcounts[0];
+    }
+    return 0;
+}
+
+// ---- kernels (focal.hip) ----
+struct FocalGenArgs {
+    const double *a[5]; // x, y, X, Y, Z
+    uint32_t n;
+    uint64_t seed, pos_base;
+    const uint32_t *positions;
+    uint32_t num_iters;
+    double max_focal;     // < 0: no bound
+    FocalModel *models;   // [num_iters * kFocalMaxModels]
+    uint32_t *num_models; // [num_iters]
+    double *work;         // kP35WorkDoubles * work_stride doubles
+    uint32_t work_stride; // >= num_iters
+};
+struct FocalScoreArgs {
+    const double *a[5];
+    uint32_t n;
+    const FocalModel *models;
+    const uint32_t *num_models; // per group of kFocalMaxModels slots; nullptr: every slot holds a model
+    uint32_t num_slots;
+    double thr2;
+    uint32_t *counts; // [num_slots]
+    double *sums;     // [num_slots]
+};
+
+#if defined(__HIPCC__)
+hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream);
+hipError_t launch_focal_score(const FocalScoreArgs &a, hipStream_t stream);
+hipError_t launch_focal_mask(const double *const *a, uint32_t n, const FocalModel &m, double thr2, uint8_t *mask, uint8_t *host_mask,
+                             hipStream_t stream);
+#endif
+
+} // namespace pl

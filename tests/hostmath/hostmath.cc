@@ -5,12 +5,14 @@
 // GPU minutes are spent.  It is NOT a CPU fallback: nothing in poselib_amd/ loads it, the C-ABI
 // (include/poselib_amd.h) has no code path into it, and the product fails loudly without a GPU.
 // Built by tests/hostmath/Makefile with g++ -ffp-contract=off.
+#include "../../poselib_amd/csrc/pl_focal.h"
 #include "../../poselib_amd/csrc/pl_prefilter.h"
 #include "../../poselib_amd/csrc/pl_refine.h"
 #include "../../poselib_amd/csrc/pl_refine_cam.h"
 #include "../../poselib_amd/csrc/pl_sampler.h"
 #include "../../poselib_amd/csrc/pl_score.h"
 #include "../../poselib_amd/csrc/pl_solver_h4.h"
+#include "../../poselib_amd/csrc/pl_solver_p35pf.h"
 #include "../../poselib_amd/csrc/pl_solver_p3p.h"
 #include "../../poselib_amd/csrc/pl_solver_rel.h"
 
@@ -218,6 +220,21 @@ int hm_essential_5pt(const double *in, double *E /* 10 x 9 row-major */) {
     return n;
 }
 
+// P3.5Pf (pl_solver_p35pf.h) with the workspace at a stride, like the device lays it out
+int hm_p35pf(const double *x /* 4 x 2 */, const double *X /* 4 x 3 */, uint32_t stride, double *poses7, double *focals) {
+    std::vector<double> work((size_t)kP35WorkDoubles * stride, 0.0);
+    Vec3 Xs[4];
+    for (int i = 0; i < 4; ++i)
+        Xs[i] = v3(X[3 * i], X[3 * i + 1], X[3 * i + 2]);
+    P35Solution sol[10];
+    const int n = p35pf(x, Xs, P35Work{work.data() + (stride - 1), stride}, sol);
+    for (int i = 0; i < n; ++i) {
+        const double o[7] = {sol[i].q.w, sol[i].q.x, sol[i].q.y, sol[i].q.z, sol[i].t.x, sol[i].t.y, sol[i].t.z};
+        std::memcpy(poses7 + 7 * i, o, sizeof(o));
+        focals[i] = sol[i].focal;
+    }
+    return n;
+}
 int hm_sturm10(const double *coef, double *roots) { return sturm_roots_deg10(coef, roots); }
 
 // Build a model record from (q,t) or a row-major 3x3, as the generate kernel stores it.
@@ -638,3 +655,119 @@ uint64_t hm_libm_mismatches(int which, uint64_t count, uint64_t seed, double *fi
 }
 
 } // extern "C"
+
+// ---- ransac_pnpf: the product's loop (pl_focal.h focal_lo_ransac) over a back end that evaluates the device functions serially -
+// the generator's and the scorer's per-lane code, hm_lm_cam for the local optimisation.  What this checks on the CPU: the
+// decisions of the loop against the oracle's ransac_pnpf; what it cannot check: the kernels' indexing and memory traffic. ----
+namespace {
+struct HostFocalBackend {
+    const double *const *pa;
+    uint32_t n;
+    uint64_t seed;
+    double thr2, max_error, max_focal;
+    std::vector<double> work = std::vector<double>(kP35WorkDoubles);
+
+    void score_one(const FocalModel &m, uint32_t &count, double &sum) const {
+        double R[9];
+        focal_rotation(m, R);
+        count = 0, sum = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            double r2;
+            if (focal_reproj_inlier(R, m.t, m.f, pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], thr2, r2))
+                count++, sum += r2;
+        }
+    }
+    int minimal(uint64_t pos_base, const uint32_t *positions, uint32_t B, std::vector<FocalModel> &models,
+                std::vector<uint32_t> &num_models, std::vector<uint32_t> &counts, std::vector<double> &sums) {
+        models.assign((size_t)B * kFocalMaxModels, FocalModel());
+        num_models.assign(B, 0);
+        counts.assign((size_t)B * kFocalMaxModels, 0);
+        sums.assign((size_t)B * kFocalMaxModels, 0.0);
+        for (uint32_t it = 0; it < B; ++it) {
+            uint32_t idx[kFocalSample];
+            draw_sample<kFocalSample>(seed, pos_base + positions[it], n, idx);
+            double xs[8];
+            Vec3 X[4];
+            for (int k = 0; k < 4; ++k) {
+                xs[2 * k] = pa[0][idx[k]], xs[2 * k + 1] = pa[1][idx[k]];
+                X[k] = v3(pa[2][idx[k]], pa[3][idx[k]], pa[4][idx[k]]);
+            }
+            P35Solution sol[kFocalMaxModels];
+            const int ns = p35pf(xs, X, P35Work{work.data(), 1}, sol);
+            uint32_t m = 0;
+            for (int i = 0; i < ns; ++i) {
+                if (sol[i].focal < 0 || (max_focal >= 0 && sol[i].focal > max_focal))
+                    continue;
+                const size_t h = (size_t)it * kFocalMaxModels + m;
+                FocalModel &o = models[h];
+                o.q[0] = sol[i].q.w, o.q[1] = sol[i].q.x, o.q[2] = sol[i].q.y, o.q[3] = sol[i].q.z;
+                o.t[0] = sol[i].t.x, o.t[1] = sol[i].t.y, o.t[2] = sol[i].t.z;
+                o.f = sol[i].focal;
+                score_one(o, counts[h], sums[h]);
+                ++m;
+            }
+            num_models[it] = m;
+        }
+        return 0;
+    }
+    int score(const std::vector<FocalModel> &models, std::vector<uint32_t> &counts, std::vector<double> &sums) {
+        counts.assign(models.size(), 0);
+        sums.assign(models.size(), 0.0);
+        for (size_t i = 0; i < models.size(); ++i)
+            score_one(models[i], counts[i], sums[i]);
+        return 0;
+    }
+    int refine(const std::vector<FocalModel> &seeds, std::vector<FocalModel> &refined) {
+        refined = seeds;
+        LMOptions lo;
+        lo.max_iterations = 25, lo.loss_type = LOSS_TRUNCATED, lo.lambda_update = 0, lo.damping = 0;
+        lo.loss_scale = max_error, lo.gradient_tol = 1e-12, lo.step_tol = 1e-8, lo.relative_cost_tol = 1e-10;
+        lo.initial_lambda = 1e-3, lo.min_lambda = 1e-10, lo.max_lambda = 1e10, lo.lambda_factor = 10.0;
+        for (FocalModel &m : refined) {
+            double params[kParamDoubles] = {0};
+            for (int i = 0; i < 4; ++i)
+                params[i] = m.q[i];
+            for (int i = 0; i < 3; ++i)
+                params[4 + i] = m.t[i];
+            CameraParams cam;
+            std::memset(&cam, 0, sizeof(cam));
+            cam.model_id = CAM_SIMPLE_PINHOLE, cam.num_params = 3, cam.p[0] = m.f;
+            uint32_t its;
+            double costs[2];
+            hm_lm_cam(pa, n, params, &lo, &cam, CAM_REFINE_FOCAL, 1.0, nullptr, &its, costs);
+            for (int i = 0; i < 4; ++i)
+                m.q[i] = params[i];
+            for (int i = 0; i < 3; ++i)
+                m.t[i] = params[4 + i];
+            m.f = cam.p[0];
+        }
+        return 0;
+    }
+};
+} // namespace
+
+extern "C" void hm_ransac_pnpf(const double *const *pa, uint32_t n, uint64_t max_iterations, uint64_t min_iterations, uint64_t seed,
+                               double dyn_mult, double success_prob, int score_initial, double max_error, double min_fov, double *pose7,
+                               double *focal, uint8_t *mask, uint64_t *stats5 /* refinements, iterations, num_inliers, hypotheses, evaluated */,
+                               double *model_score) {
+    FocalLoopOptions o;
+    o.max_iterations = max_iterations, o.min_iterations = min_iterations, o.seed = seed;
+    o.dyn_num_trials_mult = dyn_mult, o.success_prob = success_prob, o.score_initial_model = score_initial != 0;
+    o.max_error = max_error;
+    o.max_focal = focal_max_focal_length(pa[0], pa[1], n, min_fov);
+    HostFocalBackend be{pa, n, seed, max_error * max_error, max_error, o.max_focal};
+    FocalModel best;
+    std::memset(&best, 0, sizeof(best));
+    best.q[0] = 1.0, best.f = 1.0;
+    FocalLoopStats st;
+    focal_lo_ransac(be, n, o, &best, &st);
+    std::memcpy(pose7, best.q, sizeof(double) * 4);
+    std::memcpy(pose7 + 4, best.t, sizeof(double) * 3);
+    *focal = best.f;
+    double R[9];
+    focal_rotation(best, R);
+    for (uint32_t i = 0; i < n; ++i)
+        mask[i] = focal_reproj_mask(R, best.t, best.f, pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], max_error * max_error) ? 1 : 0;
+    stats5[0] = st.refinements, stats5[1] = st.iterations, stats5[2] = st.num_inliers, stats5[3] = st.hypotheses, stats5[4] = st.iterations_evaluated;
+    *model_score = st.model_score;
+}

@@ -228,3 +228,34 @@ def factorized_F(params):
     F = np.zeros(9)
     lib().hm_factorized_F(_p(p), _p(F))
     return F.reshape(3, 3)
+
+
+def p35pf(x, X, stride=1):
+    """pl_solver_p35pf.h on the host; the elimination matrix at `stride` doubles between elements, as on the device"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    poses = np.zeros((10, 7))
+    focals = np.zeros(10)
+    n = lib().hm_p35pf(_p(x), _p(X), C.c_uint32(stride), _p(poses), _p(focals))
+    return poses[:n].copy(), focals[:n].copy()
+
+
+def ransac_pnpf(x, X, max_error=12.0, seed=0, max_iterations=100000, min_iterations=1000, dyn_mult=3.0, success_prob=0.9999,
+                score_initial=False, min_fov=5.0):
+    """the product's ransac_pnpf loop (pl_focal.h) over a serial evaluation of the device functions.
+    Returns (pose7, focal, mask, stats dict)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n = x.shape[0]
+    cols, ptrs = _soa([x[:, 0], x[:, 1], X[:, 0], X[:, 1], X[:, 2]])
+    pose = np.zeros(7)
+    focal = C.c_double(0.0)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    st = np.zeros(5, dtype=np.uint64)
+    score = C.c_double(0.0)
+    lib().hm_ransac_pnpf(ptrs, C.c_uint32(n), C.c_uint64(max_iterations), C.c_uint64(min_iterations), C.c_uint64(seed),
+                         C.c_double(dyn_mult), C.c_double(success_prob), C.c_int(int(score_initial)), C.c_double(max_error),
+                         C.c_double(min_fov), _p(pose), C.byref(focal), _p(mask), _p(st), C.byref(score))
+    return pose, focal.value, mask[:n].astype(bool), {"refinements": int(st[0]), "iterations": int(st[1]), "num_inliers": int(st[2]),
+                                                     "hypotheses": int(st[3]), "iterations_evaluated": int(st[4]),
+                                                     "model_score": score.value}

@@ -233,3 +233,57 @@ def test_lm_pose_refiners_bit_exact_on_rough_starts_and_all_lm_options():
         assert it == st.iterations and np.array_equal(got[:7], ref, equal_nan=True), ("rel", k, n, lu, dm, loss)
         checked += 2
     assert checked == 80
+
+
+def _centered(d):
+    f, cx, cy = d["camera"]["params"]
+    return np.asarray(d["p2d"]) - np.array([cx, cy])
+
+
+def test_p35pf_device_header_bit_exact():
+    """pl_solver_p35pf.h (the generator kernel's per-lane code, its elimination matrix at a stride like on the device) against
+    the oracle's statement of the same algorithm: the same solutions, bit for bit, on exact and noisy minimal problems"""
+    total = 0
+    for seed in range(300):
+        d = synth.absolute_pose_scene(4, 0.0, 9000 + seed, noise_px=0.0 if seed % 2 else 1.0)
+        x = _centered(d)
+        op, of = O.p35pf(x, d["p3d"])
+        hp, hf = HM.p35pf(x, d["p3d"], stride=1 + seed % 3)
+        assert len(hf) == len(of) and np.array_equal(hp, op) and np.array_equal(hf, of), seed
+        total += len(of)
+    assert total > 1000
+    # degenerate input (two identical correspondences): whatever comes out is the same on both sides
+    d = synth.absolute_pose_scene(4, 0.0, 1)
+    x, X = _centered(d), np.array(d["p3d"])
+    x[1], X[1] = x[0], X[0]
+    op, of = O.p35pf(x, X)
+    hp, hf = HM.p35pf(x, X)
+    assert len(hf) == len(of) and np.array_equal(hp, op, equal_nan=True) and np.array_equal(hf, of, equal_nan=True)
+
+
+def test_ransac_pnpf_loop_of_the_product_takes_the_oracles_decisions():
+    """pl_focal.h focal_lo_ransac - the loop the device driver runs - over a serial evaluation of the device functions
+    (generator, scorer, k_lm_cam's algorithm): every decision and the returned model equal the oracle's ransac_pnpf"""
+    for seed in range(8):
+        n = [800, 300, 2000, 60][seed % 4]
+        d = synth.absolute_pose_scene(n, [0.3, 0.5, 0.6][seed % 3], 8200 + seed, noise_px=0.5)
+        x = _centered(d)
+        op, of, om, ost = O.ransac_pnpf(x, d["p3d"], {"max_error": 4.0, "ransac": {"seed": seed}})
+        hp, hf, hm, hst = HM.ransac_pnpf(x, d["p3d"], max_error=4.0, seed=seed)
+        for k in ("iterations", "refinements", "num_inliers", "hypotheses", "model_score"):
+            assert hst[k] == ost[k], (seed, k, hst[k], ost[k])
+        assert np.array_equal(hm, om) and np.array_equal(hp, op) and hf == of, seed
+        assert hst["iterations_evaluated"] >= hst["iterations"]
+    # early stop inside a batch, a small iteration budget and fewer points than a sample
+    d = synth.absolute_pose_scene(500, 0.1, 8300, noise_px=0.3)
+    x = _centered(d)
+    for ro in ({"min_iterations": 10, "max_iterations": 5000, "seed": 5}, {"min_iterations": 0, "max_iterations": 37, "seed": 6},
+               {"min_iterations": 300, "max_iterations": 300, "seed": 7}):
+        op, of, om, ost = O.ransac_pnpf(x, d["p3d"], {"max_error": 3.0, "ransac": ro})
+        hp, hf, hm, hst = HM.ransac_pnpf(x, d["p3d"], max_error=3.0, seed=ro["seed"], max_iterations=ro["max_iterations"],
+                                         min_iterations=ro["min_iterations"])
+        assert hst["iterations"] == ost["iterations"] and hst["refinements"] == ost["refinements"], (ro, hst, ost)
+        assert np.array_equal(hm, om) and np.array_equal(hp, op) and hf == of, ro
+    op, of, om, ost = O.ransac_pnpf(x[:3], d["p3d"][:3], {"max_error": 3.0})
+    hp, hf, hm, hst = HM.ransac_pnpf(x[:3], d["p3d"][:3], max_error=3.0)
+    assert hst["iterations"] == ost["iterations"] == 0 and np.array_equal(hp, op) and hf == of == 1.0 and np.array_equal(hm, om)
