@@ -81,6 +81,8 @@ int orc_sturm_roots(const double *coeffs, int degree, double *roots);
 int orc_p3p(const double *x /*3x3*/, const double *X /*3x3*/, double *poses /*4x7*/);
 int orc_p35pf(const double *x /*4x2, principal point at the origin*/, const double *X /*4x3*/, double *poses /*10x7*/,
               double *focals /*10*/);
+int orc_relpose_6pt_shared_focal(const double *x1 /*6x3 unit bearings*/, const double *x2, double *poses /*60x7*/,
+                                 double *focals /*60*/);
 int orc_essential_5pt(const double *x1, const double *x2, double *E /*10x9 col-major each*/);
 int orc_relpose_5pt(const double *x1, const double *x2, double *poses /*40x7*/);
 int orc_relpose_7pt(const double *x1, const double *x2, double *F /*3x9*/);
@@ -128,6 +130,14 @@ void orc_ransac_homography(const double *x1, const double *x2, size_t n, const o
                            uint8_t *inliers, orc_stats *st);
 
 /* robust/ransac.h ransac_pnpf: pose + focal length (SIMPLE_PINHOLE, principal point at the origin) */
+/* shared unknown focal length, two views (robust.h:84-90, ransac.h:71-73, bundle.h:108-111): pose7 / focal in-out */
+void orc_refine_shared_focal_relpose(const double *x1, const double *x2, size_t n, double *pose7, double *focal,
+                                     const orc_bundle_opt *opt, orc_bundle_stats *st);
+void orc_ransac_shared_focal_relpose(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *pose7,
+                                     double *focal, uint8_t *inliers, orc_stats *st);
+void orc_estimate_shared_focal_relative_pose(const double *x1, const double *x2, size_t n, const double *pp2,
+                                             const orc_robust_opt *opt, double *pose7, double *focal, uint8_t *inliers,
+                                             orc_stats *st);
 void orc_ransac_pnpf(const double *x, const double *X, size_t n, const orc_robust_opt *opt, double *pose7, double *focal,
                      uint8_t *inliers, orc_stats *st);
 void orc_estimate_absolute_pose(const double *p2d, const double *p3d, size_t n, const orc_robust_opt *opt,

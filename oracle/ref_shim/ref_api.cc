@@ -9,6 +9,7 @@
 // not on this path and need Eigen::EigenSolver etc.) are left out; the symbols they would define become traps
 // (oracle/ref_shim/make_traps.sh), which abort if anything ever calls them.
 #include <PoseLib/solvers/p35pf.h>
+#include <PoseLib/solvers/relpose_6pt_focal.h>
 #include <PoseLib/camera_pose.h>
 #include <PoseLib/misc/essential.h>
 #include <PoseLib/robust/ransac_impl.h>
@@ -408,6 +409,9 @@ void ref_estimate_shared_focal_relative_pose(const double *x1, const double *x2,
                                              const orc_robust_opt *opt, double *pose7, double *focal, uint8_t *inliers,
                                              orc_stats *st) {
     ImagePair pair;
+    pair.pose = pose_in(pose7);
+    pair.camera1 = Camera(SimplePinholeCameraModel::model_id, std::vector<double>{*focal, 0.0, 0.0}, -1, -1);
+    pair.camera2 = pair.camera1;
     std::vector<char> m;
     const CallTimer timer;
     const RansacStats s = estimate_shared_focal_relative_pose(pts2(x1, n), pts2(x2, n), Point2D(pp2[0], pp2[1]), rel_in(opt), &pair, &m);
@@ -418,6 +422,51 @@ void ref_estimate_shared_focal_relative_pose(const double *x1, const double *x2,
     mask_out(m, inliers);
     stats_out(s, 0, st);
     st->seconds = call_seconds;
+}
+// the minimal solver alone (solvers/relpose_6pt_focal.cc:1083-1144): six pairs of unit bearings (principal point at the origin,
+// unit focal length), up to 15 * 4 (pose, focal) models in the solver's order
+int ref_relpose_6pt_shared_focal(const double *x1 /* 6 x 3 */, const double *x2, double *poses7 /* 60 x 7 */, double *focals /* 60 */) {
+    std::vector<Eigen::Vector3d> a(6), b(6);
+    for (int i = 0; i < 6; ++i) {
+        a[i] = Eigen::Vector3d(x1[3 * i], x1[3 * i + 1], x1[3 * i + 2]);
+        b[i] = Eigen::Vector3d(x2[3 * i], x2[3 * i + 1], x2[3 * i + 2]);
+    }
+    ImagePairVector models;
+    const int n = relpose_6pt_shared_focal(a, b, &models);
+    for (int i = 0; i < n && i < 60; ++i) {
+        pose_out(models[i].pose, poses7 + 7 * i);
+        focals[i] = models[i].camera1.focal();
+    }
+    return n;
+}
+// ransac_shared_focal_relpose (robust/ransac.cc:182-203) on points relative to the principal point
+void ref_ransac_shared_focal_relpose(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *pose7,
+                                     double *focal, uint8_t *inliers, orc_stats *st) {
+    ImagePair best;
+    best.pose = pose_in(pose7);
+    best.camera1 = Camera(SimplePinholeCameraModel::model_id, std::vector<double>{*focal, 0.0, 0.0}, -1, -1);
+    best.camera2 = best.camera1;
+    std::vector<char> m;
+    const CallTimer timer;
+    const RansacStats s = ransac_shared_focal_relpose(pts2(x1, n), pts2(x2, n), rel_in(opt), &best, &m);
+    const double call_seconds = timer.seconds();
+    pose_out(best.pose, pose7);
+    *focal = best.camera1.focal();
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, 0, st);
+    st->seconds = call_seconds;
+}
+// refine_shared_focal_relpose (robust/bundle.cc:277-297, SharedFocalRelativePoseRefiner of optim/relative.h)
+void ref_refine_shared_focal_relpose(const double *x1, const double *x2, size_t n, double *pose7, double *focal,
+                                     const orc_bundle_opt *opt, orc_bundle_stats *st) {
+    ImagePair pair;
+    pair.pose = pose_in(pose7);
+    pair.camera1 = Camera(SimplePinholeCameraModel::model_id, std::vector<double>{*focal, 0.0, 0.0}, -1, -1);
+    pair.camera2 = pair.camera1;
+    bstats_out(refine_shared_focal_relpose(pts2(x1, n), pts2(x2, n), &pair, bopt(*opt)), st);
+    pose_out(pair.pose, pose7);
+    *focal = pair.camera1.focal();
 }
 void ref_ransac_relpose(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *pose7,
                         uint8_t *inliers, orc_stats *st) {

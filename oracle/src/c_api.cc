@@ -198,6 +198,18 @@ int orc_p35pf(const double *x, const double *X, double *poses7, double *focals) 
         pose_out(out[i], poses7 + 7 * i);
     return n;
 }
+int orc_relpose_6pt_shared_focal(const double *x1, const double *x2, double *poses7, double *focals) {
+    V3 a[6], b[6];
+    for (int i = 0; i < 6; ++i) { // unit bearings as they are (the estimator normalises, relative_pose.cc:157-160)
+        a[i] = V3{x1[3 * i], x1[3 * i + 1], x1[3 * i + 2]};
+        b[i] = V3{x2[3 * i], x2[3 * i + 1], x2[3 * i + 2]};
+    }
+    Pose out[60];
+    const int n = relpose_6pt_shared_focal(a, b, out, focals);
+    for (int i = 0; i < n; ++i)
+        pose_out(out[i], poses7 + 7 * i);
+    return n;
+}
 int orc_essential_5pt(const double *x1, const double *x2, double *E) {
     V3 a[5], b[5];
     bearings(x1, 5, a);
@@ -324,6 +336,16 @@ void orc_refine_relpose(const double *x1, const double *x2, size_t n, double *po
     pose_out(p, pose7);
     bstats_out(s, st);
 }
+void orc_refine_shared_focal_relpose(const double *x1, const double *x2, size_t n, double *pose7, double *focal,
+                                     const orc_bundle_opt *opt, orc_bundle_stats *st) {
+    ImagePair p;
+    p.pose = pose_in(pose7);
+    p.focal = *focal;
+    const BundleStats s = refine_shared_focal_relpose(pts2(x1, n), pts2(x2, n), &p, bopt(*opt));
+    pose_out(p.pose, pose7);
+    *focal = p.focal;
+    bstats_out(s, st);
+}
 void orc_refine_homography(const double *x1, const double *x2, size_t n, double *H9, const orc_bundle_opt *opt,
                            orc_bundle_stats *st) {
     M3 H = mat_in(H9);
@@ -384,6 +406,40 @@ void orc_ransac_relpose(const double *x1, const double *x2, size_t n, const orc_
     pose_out(p, pose7);
     mask_out(m, inliers);
     stats_out(s, tr, t1 - t0, st);
+}
+void orc_ransac_shared_focal_relpose(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *pose7,
+                                     double *focal, uint8_t *inliers, orc_stats *st) {
+    const std::vector<V2> a = pts2(x1, n), b = pts2(x2, n);
+    ImagePair p;
+    p.pose = pose_in(pose7);
+    p.focal = *focal;
+    std::vector<char> m;
+    LoopTrace tr;
+    const double t0 = now();
+    const RansacStats s = ransac_shared_focal_relpose(a, b, relopt(opt), &p, &m, &tr);
+    const double t1 = now();
+    pose_out(p.pose, pose7);
+    *focal = p.focal;
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, tr, t1 - t0, st);
+}
+void orc_estimate_shared_focal_relative_pose(const double *x1, const double *x2, size_t n, const double *pp2,
+                                             const orc_robust_opt *opt, double *pose7, double *focal, uint8_t *inliers,
+                                             orc_stats *st) {
+    const std::vector<V2> a = pts2(x1, n), b = pts2(x2, n);
+    ImagePair p;
+    p.pose = pose_in(pose7);
+    p.focal = *focal;
+    std::vector<char> m;
+    const double t0 = now();
+    const RansacStats s = estimate_shared_focal_relative_pose(a, b, V2{pp2[0], pp2[1]}, relopt(opt), &p, &m);
+    const double t1 = now();
+    pose_out(p.pose, pose7);
+    *focal = p.focal;
+    m.resize(n, 0);
+    mask_out(m, inliers);
+    stats_out(s, LoopTrace(), t1 - t0, st);
 }
 void orc_ransac_fundamental(const double *x1, const double *x2, size_t n, const orc_robust_opt *opt, double *F9,
                             uint8_t *inliers, orc_stats *st) {

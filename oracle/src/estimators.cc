@@ -186,6 +186,67 @@ struct RelEstimator {
     }
 };
 
+// F = K_inv * (E * K_inv), K_inv = diag(1, 1, f), as the estimator and ransac_shared_focal_relpose associate it
+// (relative_pose.cc:165-168, :179-182, ransac.cc:194-198)
+M3 shared_focal_fundamental(const ImagePair &p) {
+    const M3 E = essential_from_motion(p.pose);
+    M3 F = E;
+    for (int i = 0; i < 3; ++i)
+        F.m[i][2] = F.m[i][2] * p.focal;
+    for (int j = 0; j < 3; ++j)
+        F.m[2][j] = p.focal * F.m[2][j];
+    return F;
+}
+
+// estimators/relative_pose.{h:148-175, cc:154-203}.  The solver is the oracle's own (solvers_focal.cc, polynomial eigenvalue
+// problem) - the reference's solutions where its template is accurate, in the reference's order
+struct SharedFocalRelEstimator {
+    const RelativePoseOptions &opt;
+    const std::vector<V2> &x1;
+    const std::vector<V2> &x2;
+    Sampler sampler;
+    size_t sample_sz = 6, num_data;
+    SharedFocalRelEstimator(const RelativePoseOptions &o, const std::vector<V2> &a, const std::vector<V2> &b)
+        : opt(o), x1(a), x2(b), sampler(a.size(), 6, o.ransac), num_data(a.size()) {}
+    void generate(std::vector<ImagePair> *models) {
+        uint64_t s[6];
+        sampler.next(s);
+        V3 a[6], b[6];
+        for (int k = 0; k < 6; ++k) {
+            a[k] = bearing(x1[s[k]]);
+            b[k] = bearing(x2[s[k]]);
+        }
+        Pose sol[60];
+        double focals[60];
+        const int n = relpose_6pt_shared_focal(a, b, sol, focals);
+        models->clear();
+        for (int i = 0; i < n; ++i) {
+            ImagePair m;
+            m.pose = sol[i];
+            m.focal = focals[i];
+            models->push_back(m);
+        }
+    }
+    double score(const ImagePair &p, uint64_t *cnt) const { // relative_pose.cc:164-171
+        return msac_sampson_F(shared_focal_fundamental(p), x1, x2, opt.max_error * opt.max_error, cnt);
+    }
+    void refine(ImagePair *p) const { // relative_pose.cc:173-203
+        std::vector<char> mask;
+        const int n = inliers_sampson_F(shared_focal_fundamental(*p), x1, x2, 5 * (opt.max_error * opt.max_error), &mask);
+        if (n <= 6)
+            return;
+        std::vector<V2> a, b;
+        a.reserve(n);
+        b.reserve(n);
+        for (size_t k = 0; k < x1.size(); ++k)
+            if (mask[k]) {
+                a.push_back(x1[k]);
+                b.push_back(x2[k]);
+            }
+        refine_shared_focal_relpose(a, b, p, lo_options(opt.max_error));
+    }
+};
+
 struct FundEstimator {
     const RelativePoseOptions &opt;
     const std::vector<V2> &x1;
@@ -280,6 +341,17 @@ RansacStats ransac_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2,
     inliers_sampson_pose(*best, x1, x2, opt.max_error * opt.max_error, inliers);
     return st;
 }
+RansacStats ransac_shared_focal_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,
+                                        ImagePair *best, std::vector<char> *inliers, LoopTrace *trace) { // ransac.cc:182-203
+    if (!opt.ransac.score_initial_model) {
+        reset_pose(&best->pose);
+        best->focal = 1.0;
+    }
+    SharedFocalRelEstimator est(opt, x1, x2);
+    const RansacStats st = lo_ransac(est, opt.ransac, best, trace);
+    inliers_sampson_F(shared_focal_fundamental(*best), x1, x2, opt.max_error * opt.max_error, inliers);
+    return st;
+}
 RansacStats ransac_fundamental(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,
                                M3 *best, std::vector<char> *inliers, LoopTrace *trace) {
     if (!opt.ransac.score_initial_model)
@@ -366,6 +438,38 @@ RansacStats estimate_relative_pose(const std::vector<V2> &x1, const std::vector<
             }
         refine_relpose(ai, bi, pose, scaled.bundle);
     }
+    return st;
+}
+
+RansacStats estimate_shared_focal_relative_pose(const std::vector<V2> &x1, const std::vector<V2> &x2, const V2 &pp,
+                                                const RelativePoseOptions &opt, ImagePair *pair,
+                                                std::vector<char> *inliers) { // robust.cc:366-424
+    const size_t n = x1.size();
+    M3 T1, T2;
+    std::vector<V2> a = x1, b = x2;
+    for (size_t k = 0; k < n; ++k) {
+        a[k] = a[k] - pp;
+        b[k] = b[k] - pp;
+    }
+    const double scale = normalize_points(a, b, T1, T2, true, false, true);
+    RelativePoseOptions scaled = opt;
+    scaled.max_error /= scale;
+    scaled.bundle.loss_scale /= scale;
+    if (opt.ransac.score_initial_model)
+        pair->focal = pair->focal / scale;
+    const RansacStats st = ransac_shared_focal_relpose(a, b, scaled, pair, inliers);
+    if (st.num_inliers > 6) {
+        std::vector<V2> ai, bi;
+        ai.reserve(st.num_inliers);
+        bi.reserve(st.num_inliers);
+        for (size_t k = 0; k < n; ++k)
+            if ((*inliers)[k]) {
+                ai.push_back(a[k]);
+                bi.push_back(b[k]);
+            }
+        refine_shared_focal_relpose(ai, bi, pair, scaled.bundle);
+    }
+    pair->focal *= scale;
     return st;
 }
 

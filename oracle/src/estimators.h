@@ -42,6 +42,10 @@ RansacStats ransac_pnpf(const std::vector<V2> &x, const std::vector<V3> &X, cons
                         std::vector<char> *inliers, LoopTrace *trace = nullptr);
 RansacStats ransac_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,
                            Pose *best, std::vector<char> *inliers, LoopTrace *trace = nullptr);
+// robust/ransac.cc:182-203 with SharedFocalRelativePoseEstimator (estimators/relative_pose.{h:148-175,cc:154-203}): relative pose and
+// the focal length shared by both views; points relative to the principal point
+RansacStats ransac_shared_focal_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,
+                                        ImagePair *best, std::vector<char> *inliers, LoopTrace *trace = nullptr);
 RansacStats ransac_fundamental(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,
                                M3 *best, std::vector<char> *inliers, LoopTrace *trace = nullptr);
 RansacStats ransac_homography(const std::vector<V2> &x1, const std::vector<V2> &x2, const HomographyOptions &opt,
@@ -52,6 +56,8 @@ RansacStats estimate_absolute_pose(const std::vector<V2> &p2d, const std::vector
 RansacStats estimate_relative_pose(const std::vector<V2> &x1, const std::vector<V2> &x2, const Camera &cam1,
                                    const Camera &cam2, const RelativePoseOptions &opt, Pose *pose,
                                    std::vector<char> *inliers);
+RansacStats estimate_shared_focal_relative_pose(const std::vector<V2> &x1, const std::vector<V2> &x2, const V2 &pp,
+                                                const RelativePoseOptions &opt, ImagePair *pair, std::vector<char> *inliers);
 RansacStats estimate_fundamental(const std::vector<V2> &x1, const std::vector<V2> &x2, const RelativePoseOptions &opt,
                                  M3 *F, std::vector<char> *inliers);
 RansacStats estimate_homography(const std::vector<V2> &x1, const std::vector<V2> &x2, const HomographyOptions &opt,

@@ -642,6 +642,102 @@ struct RelProblem { // optim/relative.h:86-166
     }
 };
 
+// F = K_inv * E * K_inv with K_inv = diag(1, 1, f), evaluated left to right as the refiner does (relative.h:499-500, :519-520)
+inline M3 focal_fundamental_lr(const M3 &E, double f) {
+    M3 F = E;
+    for (int j = 0; j < 3; ++j)
+        F.m[2][j] = f * F.m[2][j];
+    for (int i = 0; i < 3; ++i)
+        F.m[i][2] = F.m[i][2] * f;
+    return F;
+}
+
+struct SharedFocalProblem { // optim/relative.h:488-592 : rotation (3), translation tangent (2), shared focal length (1)
+    static constexpr int K = 6;
+    int k() const { return K; }
+    const std::vector<V2> &x1;
+    const std::vector<V2> &x2;
+    V3 tb0, tb1;
+    double residual(Normal &acc, const ImagePair &p) const { // :496-510
+        const M3 F = focal_fundamental_lr(essential_from_motion(p.pose), p.focal);
+        for (size_t k = 0; k < x1.size(); ++k)
+            acc.add_residual(sampson_residual(F, x1[k], x2[k]));
+        return acc.residual();
+    }
+    void jacobian(Normal &acc, const ImagePair &p) { // :512-575
+        const M3 R = p.pose.R();
+        const M3 E = essential_from_motion(p.pose);
+        const double focal = p.focal;
+        const M3 F = focal_fundamental_lr(E, focal);
+        const V3 t = p.pose.t; // relative.h:63-83
+        const V3 ex{1, 0, 0}, ey{0, 1, 0}, ez{0, 0, 1};
+        if (std::abs(t.x) < std::abs(t.y))
+            tb0 = normalized(cross(t, (std::abs(t.x) < std::abs(t.z)) ? ex : ez));
+        else
+            tb0 = normalized(cross(t, (std::abs(t.y) < std::abs(t.z)) ? ey : ez));
+        tb1 = normalized(cross(tb0, t));
+        double dR[9][3], dt[9][2]; // relative.h:39-61
+        const V3 e0 = E.col(0), e1 = E.col(1), e2 = E.col(2);
+        auto put = [](double (*M)[3], int r0, int c, const V3 &v) {
+            M[r0][c] = v.x;
+            M[r0 + 1][c] = v.y;
+            M[r0 + 2][c] = v.z;
+        };
+        const V3 zero{0, 0, 0};
+        put(dR, 0, 0, zero), put(dR, 0, 1, -e2), put(dR, 0, 2, e1);
+        put(dR, 3, 0, e2), put(dR, 3, 1, zero), put(dR, 3, 2, -e0);
+        put(dR, 6, 0, -e1), put(dR, 6, 1, e0), put(dR, 6, 2, zero);
+        for (int c = 0; c < 3; ++c) {
+            const V3 a = cross(tb0, R.col(c)), b = cross(tb1, R.col(c));
+            dt[3 * c][0] = a.x, dt[3 * c + 1][0] = a.y, dt[3 * c + 2][0] = a.z;
+            dt[3 * c][1] = b.x, dt[3 * c + 1][1] = b.y, dt[3 * c + 2][1] = b.z;
+        }
+        const double ff = focal * focal; // :527-537
+        const int once[4] = {2, 5, 6, 7};
+        for (int m = 0; m < 4; ++m) {
+            for (int c = 0; c < 3; ++c)
+                dR[once[m]][c] *= focal;
+            for (int c = 0; c < 2; ++c)
+                dt[once[m]][c] *= focal;
+        }
+        for (int c = 0; c < 3; ++c)
+            dR[8][c] *= ff;
+        for (int c = 0; c < 2; ++c)
+            dt[8][c] *= ff;
+        const double df[9] = {0.0, 0.0, E.m[2][0], 0.0, 0.0, E.m[2][1], E.m[0][2], E.m[1][2], 2 * E.m[2][2] * focal}; // :540
+        for (size_t k = 0; k < x1.size(); ++k) {
+            double dF[9];
+            const double r = sampson_residual_and_grad(F, x1[k], x2[k], dF);
+            double J[KMAX];
+            for (int c = 0; c < 3; ++c) {
+                double s = 0;
+                for (int m = 0; m < 9; ++m)
+                    s += dF[m] * dR[m][c];
+                J[c] = s;
+            }
+            for (int c = 0; c < 2; ++c) {
+                double s = 0;
+                for (int m = 0; m < 9; ++m)
+                    s += dF[m] * dt[m][c];
+                J[3 + c] = s;
+            }
+            double s = 0;
+            for (int m = 0; m < 9; ++m)
+                s += dF[m] * df[m];
+            J[5] = s;
+            acc.add_jacobian(r, J);
+        }
+    }
+    ImagePair step(const double *dp, const ImagePair &p) const { // :577-585
+        ImagePair out;
+        out.pose.q = quat_step_post(p.pose.q, V3{dp[0], dp[1], dp[2]});
+        out.pose.t = V3{p.pose.t.x + (tb0.x * dp[3] + tb1.x * dp[4]), p.pose.t.y + (tb0.y * dp[3] + tb1.y * dp[4]),
+                        p.pose.t.z + (tb0.z * dp[3] + tb1.z * dp[4])};
+        out.focal = p.focal + dp[5];
+        return out;
+    }
+};
+
 struct HomProblem { // optim/homography.h:46-178 : symmetric transfer error, first 8 entries of H (column-major)
     static constexpr int K = 8;
     int k() const { return K; }
@@ -859,6 +955,11 @@ BundleStats bundle_adjust(const std::vector<V2> &x, const std::vector<V3> &X, Po
 BundleStats refine_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, Pose *pose, const BundleOptions &opt) {
     RelProblem prob{x1, x2, {}, {}};
     return levenberg_marquardt(prob, pose, opt);
+}
+BundleStats refine_shared_focal_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, ImagePair *pair,
+                                        const BundleOptions &opt) { // bundle.cc:281-297
+    SharedFocalProblem prob{x1, x2, {}, {}};
+    return levenberg_marquardt(prob, pair, opt);
 }
 BundleStats refine_homography(const std::vector<V2> &x1, const std::vector<V2> &x2, M3 *H, const BundleOptions &opt) {
     HomProblem prob{x1, x2};

@@ -74,6 +74,13 @@ struct Image {
 BundleStats bundle_adjust(const std::vector<V2> &x, const std::vector<V3> &X, Image *image, const BundleOptions &opt);
 BundleStats bundle_adjust(const std::vector<V2> &x, const std::vector<V3> &X, Pose *pose, const BundleOptions &opt);
 BundleStats refine_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, Pose *pose, const BundleOptions &opt);
+// two views of one SIMPLE_PINHOLE camera with the principal point at the origin (types.h ImagePair with camera1 == camera2)
+struct ImagePair {
+    Pose pose;
+    double focal = 1.0;
+};
+BundleStats refine_shared_focal_relpose(const std::vector<V2> &x1, const std::vector<V2> &x2, ImagePair *pair,
+                                        const BundleOptions &opt);
 BundleStats refine_homography(const std::vector<V2> &x1, const std::vector<V2> &x2, M3 *H, const BundleOptions &opt);
 BundleStats refine_fundamental(const std::vector<V2> &x1, const std::vector<V2> &x2, M3 *F, const BundleOptions &opt);
 

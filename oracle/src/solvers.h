@@ -23,6 +23,8 @@ int p3p(const V3 x[3], const V3 X[3], Pose out[4]);
 int p35pf(const V2 x[4], const V3 X[4], Pose out[10], double focals[10]);
 
 // relative pose (unit bearings)
+// shared unknown focal length from six correspondences (solvers_focal.cc; interface of solvers/relpose_6pt_focal.h:12-13)
+int relpose_6pt_shared_focal(const V3 x1[6], const V3 x2[6], Pose out[60], double focals[60]);
 int essential_5pt(const V3 x1[5], const V3 x2[5], M3 E[10]);
 int relpose_5pt(const V3 x1[5], const V3 x2[5], Pose out[40]);
 int relpose_7pt(const V3 x1[7], const V3 x2[7], M3 F[3]);

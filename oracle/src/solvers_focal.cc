@@ -478,4 +478,303 @@ int p35pf(const V2 x_in[4], const V3 X[4], Pose out[10], double focals[10]) {
     return n;
 }
 
+
+// =====================================================================================================================
+// Relative pose with one unknown focal length shared by both cameras, from six correspondences - the problem the reference solves
+// in solvers/relpose_6pt_focal.cc with a generated 31 x 46 elimination template and a Sturm chain of degree 15.  Restated FROM
+// FIRST PRINCIPLES as a polynomial eigenvalue problem (hidden variable w = 1 / f^2); nothing of the template is used.  Taken from
+// the reference: the interface and its conventions (relpose_6pt_focal.cc:1083-1144: unit bearings, null space of the six epipolar
+// constraints from a full-pivoting Householder QR, F = N0 + x N1 + y N2, solutions with w < 1e-8 dropped, focal = sqrt(1 / w),
+// E = K F K, motion_from_essential on the bearings at that focal length) and the ORDER of the solutions (ascending in y: the
+// reference's action variable, found by Sturm bisection from left to right, :1071-1078).
+//
+// Derivation.  With Q = diag(1, 1, w) the fundamental matrix of two cameras K = diag(f, f, 1) satisfies
+//     det F = 0,        2 (F Q F^T) Q F - trace(F Q F^T Q) F = 0                          (the trace constraint of E = K F K)
+// - ten equations, cubic in (x, y), the nine of the trace constraint quadratic in w: (C0 + w C1 + w^2 C2) m = 0 with m the ten
+// monomials of degree <= 3 in (x, y).  Every entry of the w^2 part carries the factor F33 (a linear form), so C2 has rank <= 6:
+// Gaussian elimination on C2 leaves six equations of degree 2 in w, three of degree 1 and the determinant of degree 0 - the row
+// degrees add up to 15, the number of solutions, so with L the matrix of the leading row coefficients and u = L m
+//     w^2 u_i + w (a1_i . u) + a0_i . u = 0  (i < 6),     w u_j + b0_j . u = 0  (j = 6..8),     u_9 = 0
+// is a 15 x 15 standard eigenvalue problem in the state (u_0..u_8, w u_0..w u_5).  Its real eigenvalues w >= 1e-8 are the
+// solutions; (x, y) come from the null vector of C0 + w C1 + w^2 C2.  scripts/exp/sixpt_focal_polyeig.py is the numpy experiment.
+namespace {
+
+constexpr int kIdx6[4][4] = {{9, 8, 6, 3}, {7, 5, 2, -1}, {4, 1, -1, -1}, {0, -1, -1, -1}}; // x^a y^b -> column (graded)
+constexpr int kExp6[10][2] = {{3, 0}, {2, 1}, {1, 2}, {0, 3}, {2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+
+struct P6 {
+    double c[10];
+    P6() { std::memset(c, 0, sizeof(c)); }
+};
+P6 mul6(const P6 &p, const P6 &q) {
+    P6 r;
+    for (int i = 0; i < 10; ++i)
+        if (p.c[i] != 0)
+            for (int j = 0; j < 10; ++j)
+                if (q.c[j] != 0)
+                    r.c[kIdx6[kExp6[i][0] + kExp6[j][0]][kExp6[i][1] + kExp6[j][1]]] += p.c[i] * q.c[j];
+    return r;
+}
+P6 add6(const P6 &p, const P6 &q) {
+    P6 r;
+    for (int i = 0; i < 10; ++i)
+        r.c[i] = p.c[i] + q.c[i];
+    return r;
+}
+P6 sub6(const P6 &p, const P6 &q) {
+    P6 r;
+    for (int i = 0; i < 10; ++i)
+        r.c[i] = p.c[i] - q.c[i];
+    return r;
+}
+P6 twice_minus(const P6 &p, const P6 &q) { // 2 p - q
+    P6 r;
+    for (int i = 0; i < 10; ++i)
+        r.c[i] = 2.0 * p.c[i] - q.c[i];
+    return r;
+}
+
+} // namespace
+
+// The polynomial eigenvalue problem of a sample: C[k] (10 x 10, row-major), k = power of w; row 0 = det F, rows 1 + 3 i + j = entry
+// (i, j) of the trace constraint; every row scaled to unit maximum over the three matrices.  nb: 9 x 3 null-space basis.
+static void sixpt_equations(const double *nb, double C[3][100]) {
+    P6 F[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int e = 3 * j + i; // column-major F
+            F[i][j].c[9] = nb[0 * 9 + e];
+            F[i][j].c[7] = nb[1 * 9 + e];
+            F[i][j].c[8] = nb[2 * 9 + e];
+        }
+    P6 G0[3][3], G1[3][3]; // F Q F^T = G0 + w G1
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            G0[i][j] = add6(mul6(F[i][0], F[j][0]), mul6(F[i][1], F[j][1]));
+            G1[i][j] = mul6(F[i][2], F[j][2]);
+        }
+    const P6 tr0 = add6(G0[0][0], G0[1][1]);
+    const P6 tr1 = add6(add6(G1[0][0], G1[1][1]), G0[2][2]);
+    const P6 tr2 = G1[2][2];
+    P6 eq[10][3];
+    eq[0][0] = add6(sub6(mul6(F[0][0], sub6(mul6(F[1][1], F[2][2]), mul6(F[1][2], F[2][1]))),
+                         mul6(F[0][1], sub6(mul6(F[1][0], F[2][2]), mul6(F[1][2], F[2][0])))),
+                    mul6(F[0][2], sub6(mul6(F[1][0], F[2][1]), mul6(F[1][1], F[2][0]))));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const P6 p0 = add6(mul6(G0[i][0], F[0][j]), mul6(G0[i][1], F[1][j]));
+            const P6 p1 = add6(add6(mul6(G1[i][0], F[0][j]), mul6(G1[i][1], F[1][j])), mul6(G0[i][2], F[2][j]));
+            const P6 p2 = mul6(G1[i][2], F[2][j]);
+            P6 *e = eq[1 + 3 * i + j];
+            e[0] = twice_minus(p0, mul6(tr0, F[i][j]));
+            e[1] = twice_minus(p1, mul6(tr1, F[i][j]));
+            e[2] = twice_minus(p2, mul6(tr2, F[i][j]));
+        }
+    for (int r = 0; r < 10; ++r) {
+        double mx = 0;
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 10; ++c)
+                mx = std::fmax(mx, std::fabs(eq[r][k].c[c]));
+        const double s = mx > 0 ? 1.0 / mx : 0.0;
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 10; ++c)
+                C[k][r * 10 + c] = eq[r][k].c[c] * s;
+    }
+}
+
+// Parlett-Reinsch balancing (EISPACK balanc without the permutation step): similarity scaling by powers of two until the row and
+// column 1-norms of every index are within a factor of two - exact in floating point, eigenvalues unchanged
+static void balance_pow2(double *a, int n) {
+    for (bool done = false; !done;) {
+        done = true;
+        for (int i = 0; i < n; ++i) {
+            double c = 0, r = 0;
+            for (int j = 0; j < n; ++j)
+                if (j != i) {
+                    c += std::fabs(a[j * n + i]);
+                    r += std::fabs(a[i * n + j]);
+                }
+            if (c == 0 || r == 0)
+                continue;
+            double g = r / 2.0, f = 1.0;
+            const double s = c + r;
+            while (c < g) {
+                f *= 2.0;
+                c *= 4.0;
+            }
+            g = r * 2.0;
+            while (c >= g) {
+                f /= 2.0;
+                c /= 4.0;
+            }
+            if ((c + r) / f < 0.95 * s) {
+                done = false;
+                g = 1.0 / f;
+                for (int j = 0; j < n; ++j)
+                    a[i * n + j] *= g;
+                for (int j = 0; j < n; ++j)
+                    a[j * n + i] *= f;
+            }
+        }
+    }
+}
+
+// 15 x 15 companion matrix T (row-major) of the row-reduced problem; false for a degenerate sample.  C is destroyed.
+static bool sixpt_companion(double C[3][100], double *T) {
+    auto c = [&](int k, int r, int col) -> double & { return C[k][r * 10 + col]; };
+    // rows 1..9: six steps of Gaussian elimination with complete pivoting on C2, the row operations applied to C0 and C1 as well
+    for (int k = 0; k < 6; ++k) {
+        int pr = -1, pc = -1;
+        double best = 0;
+        for (int r = 1 + k; r < 10; ++r)
+            for (int col = 0; col < 10; ++col)
+                if (std::fabs(c(2, r, col)) > best)
+                    best = std::fabs(c(2, r, col)), pr = r, pc = col;
+        if (pr < 0)
+            return false;
+        if (pr != 1 + k)
+            for (int m = 0; m < 3; ++m)
+                for (int col = 0; col < 10; ++col)
+                    std::swap(c(m, 1 + k, col), c(m, pr, col));
+        for (int r = 2 + k; r < 10; ++r) {
+            const double f = c(2, r, pc) / c(2, 1 + k, pc);
+            if (f == 0)
+                continue;
+            for (int m = 0; m < 3; ++m)
+                for (int col = 0; col < 10; ++col)
+                    c(m, r, col) -= f * c(m, 1 + k, col);
+            c(2, r, pc) = 0;
+        }
+    }
+    // L: leading row coefficients, rows (C2[1..6], C1[7..9], C0[0]); X L = R for the 15 right-hand rows R = (C0[1..6], C1[1..6],
+    // C0[7..9]) by LU with partial pivoting on L^T
+    double A[10][10], B[10][15]; // A = L^T, B = R^T
+    for (int col = 0; col < 10; ++col) {
+        for (int i = 0; i < 6; ++i)
+            A[col][i] = c(2, 1 + i, col);
+        for (int j = 0; j < 3; ++j)
+            A[col][6 + j] = c(1, 7 + j, col);
+        A[col][9] = c(0, 0, col);
+        for (int i = 0; i < 6; ++i) {
+            B[col][i] = c(0, 1 + i, col);
+            B[col][6 + i] = c(1, 1 + i, col);
+        }
+        for (int j = 0; j < 3; ++j)
+            B[col][12 + j] = c(0, 7 + j, col);
+    }
+    for (int k = 0; k < 10; ++k) {
+        int pr = k;
+        double best = std::fabs(A[k][k]);
+        for (int r = k + 1; r < 10; ++r)
+            if (std::fabs(A[r][k]) > best)
+                best = std::fabs(A[r][k]), pr = r;
+        if (best == 0)
+            return false;
+        if (pr != k) {
+            for (int col = 0; col < 10; ++col)
+                std::swap(A[k][col], A[pr][col]);
+            for (int col = 0; col < 15; ++col)
+                std::swap(B[k][col], B[pr][col]);
+        }
+        for (int r = k + 1; r < 10; ++r) {
+            const double f = A[r][k] / A[k][k];
+            if (f == 0)
+                continue;
+            for (int col = k + 1; col < 10; ++col)
+                A[r][col] -= f * A[k][col];
+            for (int col = 0; col < 15; ++col)
+                B[r][col] -= f * B[k][col];
+        }
+    }
+    for (int col = 0; col < 15; ++col) // back substitution: B[.][col] becomes the row `col` of R L^-1
+        for (int r = 9; r >= 0; --r) {
+            double s = B[r][col];
+            for (int m = r + 1; m < 10; ++m)
+                s -= A[r][m] * B[m][col];
+            B[r][col] = s / A[r][r];
+        }
+    // a0_i = B[.][i], a1_i = B[.][6 + i] (i < 6), b0_j = B[.][12 + j] (j < 3); state z = (u_0..u_8, w u_0..w u_5)
+    std::memset(T, 0, sizeof(double) * 225);
+    for (int i = 0; i < 6; ++i)
+        T[i * 15 + 9 + i] = 1.0;
+    for (int j = 0; j < 3; ++j)
+        for (int m = 0; m < 9; ++m)
+            T[(6 + j) * 15 + m] = -B[m][12 + j];
+    for (int i = 0; i < 6; ++i) {
+        double *row = T + (9 + i) * 15;
+        for (int m = 0; m < 6; ++m)
+            row[9 + m] = -B[m][6 + i];
+        for (int m = 0; m < 9; ++m) {
+            double s = -B[m][i];
+            for (int j = 0; j < 3; ++j)
+                s += B[6 + j][6 + i] * B[m][12 + j];
+            row[m] = s;
+        }
+    }
+    return true;
+}
+
+// Interface of solvers/relpose_6pt_focal.h:12-13.  At most 15 solutions x 4 poses.
+int relpose_6pt_shared_focal(const V3 x1[6], const V3 x2[6], Pose out[60], double focals[60]) {
+    double A[54];
+    for (int i = 0; i < 6; ++i) // relpose_6pt_focal.cc:1087-1090: column i = (x1_0 x2, x1_1 x2, x1_2 x2)
+        for (int j = 0; j < 3; ++j) {
+            A[i * 9 + 3 * j + 0] = x1[i][j] * x2[i].x;
+            A[i * 9 + 3 * j + 1] = x1[i][j] * x2[i].y;
+            A[i * 9 + 3 * j + 2] = x1[i][j] * x2[i].z;
+        }
+    double nb[27]; // 9 x 3, column-major
+    householder_complement(A, 9, 6, nb);
+    double C[3][100], Cw[3][100], T[225], ev[15];
+    sixpt_equations(nb, C);
+    std::memcpy(Cw, C, sizeof(C));
+    if (!sixpt_companion(Cw, T))
+        return 0;
+    balance_pow2(T, 15);
+    const int nroots = real_eigenvalues(T, 15, ev, 1e-8);
+    struct Sol {
+        double x, y, w;
+    } sols[15];
+    int ns = 0;
+    for (int s = 0; s < nroots; ++s) {
+        const double w = ev[s];
+        if (w < 1e-8) // relpose_6pt_focal.cc:1106
+            continue;
+        double M[100], v[10];
+        for (int i = 0; i < 100; ++i)
+            M[i] = C[0][i] + w * (C[1][i] + w * C[2][i]);
+        null_vector(M, 10, v);
+        if (v[9] == 0)
+            continue;
+        sols[ns++] = Sol{v[7] / v[9], v[8] / v[9], w};
+    }
+    std::stable_sort(sols, sols + ns, [](const Sol &a, const Sol &b) { return a.y < b.y; });
+    int n = 0;
+    for (int s = 0; s < ns; ++s) {
+        const double focal = std::sqrt(1.0 / sols[s].w);
+        double Fv[9], nrm = 0;
+        for (int e = 0; e < 9; ++e) {
+            Fv[e] = nb[e] + sols[s].x * nb[9 + e] + sols[s].y * nb[18 + e];
+            nrm += Fv[e] * Fv[e];
+        }
+        nrm = std::sqrt(nrm);
+        M3 E;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const double ki = i < 2 ? focal : 1.0, kj = j < 2 ? focal : 1.0;
+                E.m[i][j] = ki * ((Fv[3 * j + i] / nrm) * kj); // K * (F * K), relpose_6pt_focal.cc:1122
+            }
+        V3 u1[6], u2[6];
+        for (int i = 0; i < 6; ++i) {
+            u1[i] = normalized(V3{x1[i].x / focal, x1[i].y / focal, x1[i].z});
+            u2[i] = normalized(V3{x2[i].x / focal, x2[i].y / focal, x2[i].z});
+        }
+        const int m = motion_from_essential(E, u1, u2, 6, out + n);
+        for (int i = 0; i < m; ++i)
+            focals[n + i] = focal;
+        n += m;
+    }
+    return n;
+}
+
 } // namespace orc

@@ -266,14 +266,6 @@ def bundle_adjust_camera(x, X, cam_dict, pose7, bopt=None):
     return p, np.array(c.params[: c.num_params]), st
 
 
-def _reference_only(name):
-    fn = getattr(lib(), name, None) if not hasattr(lib(), "_cdll") else getattr(lib(), name)
-    if fn is None:
-        raise RuntimeError(f"{name}: only in the reference build (with ref_lib.reference(): ...) - the oracle has no "
-                           "restatement of the shared-focal relative estimator (a generated elimination template)")
-    return fn
-
-
 def p35pf(x, X):
     """solvers/p35pf.h: x 4 x 2 image points (principal point at the origin), X 4 x 3.
     Returns (poses n x 7, focals n)."""
@@ -281,6 +273,16 @@ def p35pf(x, X):
     poses = np.zeros((10, 7))
     focals = np.zeros(10)
     n = lib().orc_p35pf(_p(x), _p(X), _p(poses), _p(focals))
+    return poses[:n].copy(), focals[:n].copy()
+
+
+def relpose_6pt_shared_focal(b1, b2):
+    """solvers/relpose_6pt_focal.h: six pairs of unit bearings (principal point at the origin, unit focal length).
+    Returns (poses n x 7, focals n) in the solver's order."""
+    b1, b2 = _f(b1), _f(b2)
+    poses = np.zeros((60, 7))
+    focals = np.zeros(60)
+    n = lib().orc_relpose_6pt_shared_focal(_p(b1), _p(b2), _p(poses), _p(focals))
     return poses[:n].copy(), focals[:n].copy()
 
 
@@ -298,20 +300,46 @@ def ransac_pnpf(x, X, opt=None):
     return pose, focal.value, mask[:n].astype(bool), stats_dict(st)
 
 
-def estimate_shared_focal_relative_pose(x1, x2, pp, opt=None):
-    """robust.h:84-87 (the REFERENCE's sources only): relative pose of two views with ONE unknown focal length; pixel points,
-    principal point pp.  Returns (pose7, focal, mask, stats)."""
+def estimate_shared_focal_relative_pose(x1, x2, pp, opt=None, init_pose=None, init_focal=1.0):
+    """robust.h:84-87: relative pose of two views with ONE unknown focal length; pixel points, principal point pp.
+    Returns (pose7, focal, mask, stats)."""
     x1, x2 = _f(x1), _f(x2)
     n = x1.shape[0]
     o = robust_opt(opt, 1.0)
-    pose = np.array([1.0, 0, 0, 0, 0, 0, 0])
-    focal = C.c_double(0.0)
+    pose = np.array([1.0, 0, 0, 0, 0, 0, 0]) if init_pose is None else _f(init_pose).copy()
+    focal = C.c_double(init_focal)
     mask = np.zeros(max(n, 1), dtype=np.uint8)
     st = Stats()
     ppa = _f(pp)
-    _reference_only("orc_estimate_shared_focal_relative_pose")(_p(x1), _p(x2), C.c_size_t(n), _p(ppa), C.byref(o), _p(pose),
-                                                               C.byref(focal), _p(mask), C.byref(st))
+    lib().orc_estimate_shared_focal_relative_pose(_p(x1), _p(x2), C.c_size_t(n), _p(ppa), C.byref(o), _p(pose), C.byref(focal),
+                                                  _p(mask), C.byref(st))
     return pose, focal.value, mask[:n].astype(bool), stats_dict(st)
+
+
+def ransac_shared_focal_relpose(x1, x2, opt=None, init_pose=None, init_focal=1.0):
+    """robust/ransac.h:71-73 ransac_shared_focal_relpose: points relative to the principal point.
+    Returns (pose7, focal, mask, stats)."""
+    x1, x2 = _f(x1), _f(x2)
+    n = x1.shape[0]
+    o = robust_opt(opt, 1.0)
+    pose = np.array([1.0, 0, 0, 0, 0, 0, 0]) if init_pose is None else _f(init_pose).copy()
+    focal = C.c_double(init_focal)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    st = Stats()
+    lib().orc_ransac_shared_focal_relpose(_p(x1), _p(x2), C.c_size_t(n), C.byref(o), _p(pose), C.byref(focal), _p(mask),
+                                          C.byref(st))
+    return pose, focal.value, mask[:n].astype(bool), stats_dict(st)
+
+
+def refine_shared_focal_relpose(x1, x2, pose, focal, bopt=None):
+    """robust/bundle.h:108-111.  Returns (pose7, focal, BundleStats)."""
+    x1, x2 = _f(x1), _f(x2)
+    o = bundle_opt(bopt)
+    st = BundleStats()
+    p = _f(pose).copy()
+    f = C.c_double(focal)
+    lib().orc_refine_shared_focal_relpose(_p(x1), _p(x2), C.c_size_t(x1.shape[0]), _p(p), C.byref(f), C.byref(o), C.byref(st))
+    return p, f.value, st
 
 
 def refine(kind, x1, x2, model, bopt=None):

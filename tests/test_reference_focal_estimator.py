@@ -144,5 +144,90 @@ def test_shared_focal_relative_pose_of_the_reference(seed, outliers):
     assert np.abs(synth.quat_to_rotmat(pose[:4]) - synth.quat_to_rotmat(np.asarray(d["q_gt"]))).max() < 5e-3
     assert np.abs(t - t_gt).max() < 5e-3
     assert (mask & d["inlier_gt"]).sum() >= 0.97 * d["inlier_gt"].sum() and (mask & ~d["inlier_gt"]).sum() <= 0.02 * len(mask)
-    with pytest.raises(RuntimeError):
-        O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy])  # (the oracle has no such estimator)
+
+
+# ---- the shared-focal estimator of the ORACLE (solvers_focal.cc: polynomial eigenvalue problem, no template) against the reference's
+def _six_bearings(rng):
+    from scipy.spatial.transform import Rotation
+    f = rng.uniform(300, 3000)
+    X = rng.uniform(-1, 1, (6, 3)) * [2, 2, 1] + [0, 0, 5]
+    R = Rotation.from_rotvec(rng.normal(size=3) * 0.2).as_matrix()
+    t = rng.normal(size=3)
+    t /= np.linalg.norm(t)
+    X2 = X @ R.T + t
+    s = rng.uniform(400, 2500)  # the estimator works on normalised pixels: focal lengths of order 1
+    b1 = np.c_[f * X[:, :2] / X[:, 2:] / s, np.ones(6)]
+    b2 = np.c_[f * X2[:, :2] / X2[:, 2:] / s, np.ones(6)]
+    return f / s, b1 / np.linalg.norm(b1, axis=1)[:, None], b2 / np.linalg.norm(b2, axis=1)[:, None]
+
+
+def test_six_point_shared_focal_solver_against_the_reference():
+    """relpose_6pt_shared_focal (solvers/relpose_6pt_focal.cc:1083-1144).  The oracle's formulation is not the reference's
+    template, so the two are compared as SOLVERS: on exact data the oracle finds the true focal length more often than the
+    reference's template does (which loses it in ~13 % of the samples to 1e-6), it reproduces >= 80 % of the reference's models
+    to 1e-6 (the rest are the template's inaccurate ones), and whenever both return the same set the ORDER is the same
+    (ascending in the coefficient of the third null-space vector - the reference's action variable)."""
+    rng = np.random.default_rng(7)
+    tot = match = gt_o = gt_r = same_set = same_order = 0
+    trials = 400
+    for _ in range(trials):
+        f, b1, b2 = _six_bearings(rng)
+        pm, fm = O.relpose_6pt_shared_focal(b1, b2)
+        with ref_lib.reference():
+            pr, fr = O.relpose_6pt_shared_focal(b1, b2)
+        gt_o += any(abs(v - f) < 1e-6 * f for v in fm)
+        gt_r += any(abs(v - f) < 1e-6 * f for v in fr)
+        M = [np.r_[pm[i], fm[i]] for i in range(len(fm))]
+        R = [np.r_[pr[i], fr[i]] for i in range(len(fr))]
+        hits = [any(np.abs(r - m).max() < 1e-6 for m in M) for r in R]
+        tot += len(R)
+        match += sum(hits)
+        if len(M) == len(R) and len(M) > 1 and all(hits):
+            same_set += 1
+            same_order += all(np.abs(a - b).max() < 1e-6 for a, b in zip(M, R))
+    assert gt_o >= 0.97 * trials and gt_o > gt_r
+    assert match >= 0.8 * tot
+    assert same_set > 100 and same_order == same_set
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_shared_focal_refiner_bit_exact_with_the_reference(seed):
+    """refine_shared_focal_relpose (bundle.cc:281-297, SharedFocalRelativePoseRefiner optim/relative.h:488-592)"""
+    d = synth.relative_pose_scene(300, 0.2, 100 + seed, focal=900.0)
+    f, cx, cy = d["camera1"]["params"]
+    a, b = (d["x1"] - [cx, cy]) / 700.0, (d["x2"] - [cx, cy]) / 700.0
+    q = np.r_[d["q_gt"], d["t_gt"]] + 0.01 * np.random.default_rng(seed).normal(size=7)
+    q[:4] /= np.linalg.norm(q[:4])
+    for loss in (0, 1, 2, 3, 4, 5):
+        bo = {"loss_type": loss, "loss_scale": 0.003, "max_iterations": 30}
+        po, fo, so = O.refine_shared_focal_relpose(a, b, q, 1.1 * f / 700.0, bo)
+        with ref_lib.reference():
+            pr, fr, sr = O.refine_shared_focal_relpose(a, b, q, 1.1 * f / 700.0, bo)
+        assert np.array_equal(po, pr) and fo == fr
+        assert (so.iterations, so.cost, so.initial_cost, so.invalid_steps) == (sr.iterations, sr.cost, sr.initial_cost, sr.invalid_steps)
+
+
+@pytest.mark.parametrize("seed,outliers,n", [(0, 0.3, 1200), (1, 0.5, 1200), (2, 0.2, 400), (3, 0.4, 2500), (4, 0.1, 60)])
+def test_shared_focal_estimator_of_the_oracle_takes_the_references_decisions(seed, outliers, n):
+    """estimate_shared_focal_relative_pose / ransac_shared_focal_relpose: same iterations, refinements, inliers and mask as the
+    reference's sources on the pinned scenes; focal length to 1e-10, rotation / direction to 1e-9 (|t| is a gauge).
+    Over random problems 116 of 120 runs take identical decisions (the other four differ by ONE local optimisation where one
+    solver finds a model the other's misses) - scripts/soak_shared_focal.py."""
+    d = synth.relative_pose_scene(n, outliers, 8400 + seed)
+    f, cx, cy = d["camera1"]["params"]
+    opt = {"max_error": 2.0, "ransac": {"seed": seed}}
+    po, fo, mo, so = O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], opt)
+    with ref_lib.reference():
+        pr, fr, mr, sr = O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], opt)
+    assert (so["iterations"], so["refinements"], so["num_inliers"]) == (sr["iterations"], sr["refinements"], sr["num_inliers"])
+    assert np.array_equal(mo, mr)
+    assert abs(fo - fr) <= 1e-10 * fr and abs(fo - f) / f < 1e-2
+    assert np.abs(po[:4] - pr[:4]).max() < 1e-9
+    assert np.abs(po[4:] / np.linalg.norm(po[4:]) - pr[4:] / np.linalg.norm(pr[4:])).max() < 1e-9
+    a, b = d["x1"] - [cx, cy], d["x2"] - [cx, cy]
+    opt2 = {"max_error": 2.0, "ransac": {"seed": seed + 10, "max_iterations": 3000}}
+    po, fo, mo, so = O.ransac_shared_focal_relpose(a / 500.0, b / 500.0, dict(opt2, max_error=2.0 / 500.0))
+    with ref_lib.reference():
+        pr, fr, mr, sr = O.ransac_shared_focal_relpose(a / 500.0, b / 500.0, dict(opt2, max_error=2.0 / 500.0))
+    assert (so["iterations"], so["refinements"], so["num_inliers"]) == (sr["iterations"], sr["refinements"], sr["num_inliers"])
+    assert np.array_equal(mo, mr) and abs(fo - fr) <= 1e-6 * fr  # (the LO stops at its step tolerance from slightly different starts)
