@@ -124,6 +124,12 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
 int pl_estimate_relative_pose(const double *points2D_1, const double *points2D_2, size_t n, const pl_camera *camera1,
                               const pl_camera *camera2, const pl_robust_options *opt, pl_camera_pose *pose,
                               uint8_t *inliers, pl_ransac_stats *stats);
+/* robust.h:84-90 estimate_shared_focal_relative_pose (robust.cc:366-424): pixel coordinates, principal point pp[2]; the image pair
+ * of the reference is (pose, SIMPLE_PINHOLE {focal, pp[0], pp[1]} for both cameras).  focal is read only with
+ * ransac.score_initial_model (image_pair->camera1.focal()). */
+int pl_estimate_shared_focal_relative_pose(const double *points2D_1, const double *points2D_2, size_t n, const double *pp,
+                                           const pl_robust_options *opt, pl_camera_pose *pose, double *focal, uint8_t *inliers,
+                                           pl_ransac_stats *stats);
 int pl_estimate_fundamental(const double *points2D_1, const double *points2D_2, size_t n, const pl_robust_options *opt,
                             double *F /* 9, column-major */, uint8_t *inliers, pl_ransac_stats *stats);
 int pl_estimate_homography(const double *points2D_1, const double *points2D_2, size_t n, const pl_robust_options *opt,
@@ -166,6 +172,17 @@ int pl_ransac_pnpf(const double *x, const double *X, size_t n, const pl_robust_o
                    uint8_t *inliers, pl_ransac_stats *stats);
 int pl_ransac_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
                       uint8_t *inliers, pl_ransac_stats *stats);
+/* robust/ransac.h:71-73 ransac_shared_focal_relpose (SharedFocalRelativePoseEstimator, estimators/relative_pose.h:148-175; solver:
+ * the 6-point shared-focal problem of solvers/relpose_6pt_focal.h): relative pose of two views of ONE camera with unknown focal
+ * length; x1, x2 relative to the principal point.  pose / focal: the initial model when ransac.score_initial_model is set (otherwise
+ * reset as in ransac.cc:185-190), the result on return.  PROSAC sampling: PL_ERR_UNSUPPORTED. */
+int pl_ransac_shared_focal_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
+                                   double *focal, uint8_t *inliers, pl_ransac_stats *stats);
+/* robust/bundle.h:108-111 refine_shared_focal_relpose (SharedFocalRelativePoseRefiner, optim/relative.h:488-592): pose and the
+ * shared focal length refined on all n correspondences (Sampson error of F = K^-1 E K^-1); both in / out. */
+int pl_refine_shared_focal_relpose(const double *x1, const double *x2, size_t n, const pl_bundle_options *opt, pl_camera_pose *pose,
+                                   double *focal, uint32_t *lm_iterations);
+
 int pl_ransac_fundamental(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *F,
                           uint8_t *inliers, pl_ransac_stats *stats);
 int pl_ransac_homography(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *H,

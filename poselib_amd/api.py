@@ -427,6 +427,62 @@ def ransac_pnpf(x, X, opt=None):
     return Image(_pypose(pose), Camera("SIMPLE_PINHOLE", [focal.value, 0.0, 0.0])), _info(st, inl[:n])
 
 
+class ImagePair:
+    """poselib.ImagePair {pose, camera1, camera2} (types.h / pybind types.cc): here always two copies of one SIMPLE_PINHOLE camera"""
+
+    def __init__(self, pose=None, camera1=None, camera2=None):
+        self.pose = pose or CameraPose()
+        self.camera1 = camera1 or Camera("SIMPLE_PINHOLE", [1.0, 0.0, 0.0])
+        self.camera2 = camera2 or Camera("SIMPLE_PINHOLE", list(self.camera1.params))
+
+
+def _shared_focal_pair(pose, focal, pp):
+    return ImagePair(_pypose(pose), Camera("SIMPLE_PINHOLE", [focal, pp[0], pp[1]]), Camera("SIMPLE_PINHOLE", [focal, pp[0], pp[1]]))
+
+
+def ransac_shared_focal_relpose(x1, x2, opt=None, initial_pair=None):
+    """robust/ransac.h:71-73 ransac_shared_focal_relpose: relative pose and the focal length both views share; x1, x2 relative
+    to the principal point.  Returns (ImagePair, info)."""
+    x1, x2 = _pts(x1, 2), _pts(x2, 2)
+    o = _robust_options(opt, KIND_REL, initial_pair is not None)
+    n = x1.shape[0]
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    st = L.RansacStats()
+    pose = _cpose(initial_pair.pose if initial_pair is not None else CameraPose())
+    focal = C.c_double(initial_pair.camera1.focal() if initial_pair is not None else 1.0)
+    L.check(L.lib().pl_ransac_shared_focal_relpose(_ptr(x1), _ptr(x2), C.c_size_t(n), C.byref(o), C.byref(pose), C.byref(focal),
+                                                   _ptr(inl), C.byref(st)))
+    return _shared_focal_pair(pose, focal.value, (0.0, 0.0)), _info(st, inl[:n])
+
+
+def estimate_shared_focal_relative_pose(points2D_1, points2D_2, pp, opt=None, initial_pair=None):
+    """robust.h:84-90 estimate_shared_focal_relative_pose: pixel coordinates, principal point pp.  Returns (ImagePair, info)."""
+    x1, x2 = _pts(points2D_1, 2), _pts(points2D_2, 2)
+    o = _robust_options(opt, KIND_REL, initial_pair is not None)
+    n = x1.shape[0]
+    inl = np.zeros(max(n, 1), dtype=np.uint8)
+    st = L.RansacStats()
+    pose = _cpose(initial_pair.pose if initial_pair is not None else CameraPose())
+    focal = C.c_double(initial_pair.camera1.focal() if initial_pair is not None else 1.0)
+    ppa = np.ascontiguousarray(pp, dtype=np.float64)
+    L.check(L.lib().pl_estimate_shared_focal_relative_pose(_ptr(x1), _ptr(x2), C.c_size_t(n), _ptr(ppa), C.byref(o), C.byref(pose),
+                                                           C.byref(focal), _ptr(inl), C.byref(st)))
+    return _shared_focal_pair(pose, focal.value, ppa), _info(st, inl[:n])
+
+
+def refine_shared_focal_relpose(x1, x2, pair, bundle=None):
+    """robust/bundle.h:108-111 refine_shared_focal_relpose on all correspondences (relative to the principal point).
+    Returns (ImagePair, LM iterations)."""
+    x1, x2 = _pts(x1, 2), _pts(x2, 2)
+    o = _robust_options({"bundle": bundle or {}}, KIND_REL, False)
+    pose = _cpose(pair.pose)
+    focal = C.c_double(pair.camera1.focal())
+    its = C.c_uint32(0)
+    L.check(L.lib().pl_refine_shared_focal_relpose(_ptr(x1), _ptr(x2), C.c_size_t(x1.shape[0]), C.byref(o.bundle), C.byref(pose),
+                                                   C.byref(focal), C.byref(its)))
+    return _shared_focal_pair(pose, focal.value, (0.0, 0.0)), its.value
+
+
 def ransac_relpose(x1, x2, opt=None, initial_pose=None):
     return _ransac("pl_ransac_relpose", KIND_REL, x1, x2, 2, opt, initial_pose)
 

@@ -20,6 +20,8 @@
 #include "pl_focal.h"
 #include "pl_kernels.h"
 #include "pl_refine_cam.h"
+#include "pl_sfocal.h"
+#include "pl_solver_6ptf.h"
 #include "pl_solver_p35pf.h"
 #include "pl_sampler.h"
 
@@ -1952,6 +1954,7 @@ double normalization_of(const double *x1, const double *x2, size_t n, bool centr
 }
 
 #include "driver_focal.inc"
+#include "driver_sfocal.inc"
 #include "driver_group.inc"
 
 } // namespace
@@ -2349,6 +2352,42 @@ int pl_ransac_pnpf(const double *x, const double *X, size_t n, const pl_robust_o
     free_problem(&p);
     return rc;
 }
+int pl_ransac_shared_focal_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
+                                   double *focal, uint8_t *inliers, pl_ransac_stats *stats) {
+    if (!opt || !pose || !focal)
+        return fail(PL_ERR_INVALID, "null argument");
+    int rc = validate_options(opt);
+    if (rc != PL_OK)
+        return rc;
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    pl_problem p;
+    rc = make_problem(c, EST_FUND, x1, x2, n, &p); // (two-view layout: x1, y1, x2, y2)
+    if (rc != PL_OK)
+        return rc;
+    pl_ransac_stats local;
+    rc = run_shared_focal(c, &p, opt, pose, focal, inliers, stats ? stats : &local);
+    free_problem(&p);
+    return rc;
+}
+int pl_refine_shared_focal_relpose(const double *x1, const double *x2, size_t n, const pl_bundle_options *opt, pl_camera_pose *pose,
+                                   double *focal, uint32_t *lm_iterations) {
+    if (!opt || !pose || !focal)
+        return fail(PL_ERR_INVALID, "null argument");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    pl_problem p;
+    rc = make_problem(c, EST_FUND, x1, x2, n, &p);
+    if (rc != PL_OK)
+        return rc;
+    rc = refine_shared_focal(c, &p, to_lm(*opt), nullptr, pose, focal, lm_iterations);
+    free_problem(&p);
+    return rc;
+}
 int pl_ransac_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
                       uint8_t *inliers, pl_ransac_stats *stats) {
     return ransac_oneshot(EST_REL, x1, x2, n, opt, pose, inliers, stats);
@@ -2474,6 +2513,42 @@ int pl_estimate_relative_pose(const double *x1, const double *x2, size_t n, cons
     }
     free_problem(&p);
     return rc;
+}
+
+int pl_estimate_shared_focal_relative_pose(const double *x1, const double *x2, size_t n, const double *pp, const pl_robust_options *opt,
+                                           pl_camera_pose *pose, double *focal, uint8_t *inliers, pl_ransac_stats *stats) {
+    if (!pp || !pose || !focal)
+        return fail(PL_ERR_INVALID, "null argument");
+    int rc = validate_options(opt);
+    if (rc != PL_OK)
+        return rc;
+    Context *c;
+    rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    pl_ransac_stats local;
+    pl_ransac_stats *st = stats ? stats : &local;
+    // robust.cc:373-390
+    PrepareArgs prep;
+    const double scale = normalization_about(x1, x2, n, pp[0], pp[1], prep);
+    pl_robust_options scaled = *opt;
+    scaled.max_error /= scale;
+    scaled.bundle.loss_scale /= scale;
+    double f = *focal;
+    if (opt->ransac.score_initial_model) // :392-397
+        f = f / scale;
+    pl_problem p;
+    rc = make_problem_prepared(c, EST_FUND, x1, x2, n, prep, &p, false, /*lm_only=*/true);
+    if (rc != PL_OK)
+        return rc;
+    rc = run_shared_focal(c, &p, &scaled, pose, &f, inliers, st);
+    if (rc == PL_OK && st->num_inliers > 6) // :401-415: refine_shared_focal_relpose over the inliers (c->mask: the device mask)
+        rc = refine_shared_focal(c, &p, to_lm(scaled.bundle), c->mask.as<uint8_t>(), pose, &f, nullptr);
+    free_problem(&p);
+    if (rc != PL_OK)
+        return rc;
+    *focal = f * scale; // :417 (the caller's cameras: SIMPLE_PINHOLE {focal, pp[0], pp[1]}, :418-421)
+    return PL_OK;
 }
 
 int pl_estimate_fundamental(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, double *F,

@@ -128,11 +128,13 @@ template <int K> inline uint64_t focal_sample_positions(uint64_t seed, uint64_t 
 // counts / sums: inliers and the sum of their squared residuals in correspondence order, per model slot.  All decisions are
 // taken here, in the reference's order: which hypotheses improve best_minimal_*, which of them seed a local optimisation
 // (the last improving one of an iteration), the incumbent, the dynamic iteration bound and the stop rule.
-template <class Backend>
-int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalModel *best, FocalLoopStats *stats) {
+// Traits: kSample (sample size), kMaxModels (model slots per iteration), finish(sum, count, N, options, focal) -> score_model().
+template <class Traits, class Backend>
+int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalModel *best, FocalLoopStats *stats) {
+    constexpr int kSample = Traits::kSample, kMaxModels = Traits::kMaxModels;
     FocalLoopStats &st = *stats;
     st = FocalLoopStats();
-    if (N < (uint64_t)kFocalSample)
+    if (N < (uint64_t)kSample)
         return 0;
     uint64_t best_min_inl = 0;
     double best_min_score = std::numeric_limits<double>::max();
@@ -153,14 +155,14 @@ int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalMod
     // candidates of one "iteration" whose minimal scores are known: ransac_impl.h:106-154
     auto after_lo = [&](const FocalModel &ref, uint64_t rcnt, double rsum) {
         st.refinements++;
-        const double rsc = focal_finish_score(rsum, rcnt, N, o.max_error, ref.f, o.max_focal);
+        const double rsc = Traits::finish(rsum, rcnt, N, o, ref.f);
         if (rsc < st.model_score) {
             st.model_score = rsc;
             st.num_inliers = rcnt;
             *best = ref;
         }
         st.inlier_ratio = static_cast<double>(st.num_inliers) / static_cast<double>(N);
-        dyn_max = focal_dynamic_max_iter(st.num_inliers, N, kFocalSample, log_fail, o.dyn_num_trials_mult, o.min_iterations,
+        dyn_max = focal_dynamic_max_iter(st.num_inliers, N, kSample, log_fail, o.dyn_num_trials_mult, o.min_iterations,
                                          o.max_iterations);
     };
 
@@ -169,7 +171,7 @@ int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalMod
         int rc = be.score(models, counts, sums);
         if (rc)
             return rc;
-        const double sc = focal_finish_score(sums[0], counts[0], N, o.max_error, best->f, o.max_focal);
+        const double sc = Traits::finish(sums[0], counts[0], N, o, best->f);
         const bool more = counts[0] > best_min_inl, better = sc < best_min_score;
         if (more || better) {
             if (more)
@@ -201,7 +203,7 @@ int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalMod
         want = std::min<uint64_t>(std::max<uint64_t>(want, 256), 4096);
         const uint32_t B = (uint32_t)std::min<uint64_t>(want, o.max_iterations - it0);
         positions.resize(B);
-        const uint64_t pos_after = focal_sample_positions<kFocalSample>(o.seed, pos, N, B, positions.data());
+        const uint64_t pos_after = focal_sample_positions<kSample>(o.seed, pos, N, B, positions.data());
         int rc = be.minimal(pos, positions.data(), B, models, num_models, counts, sums);
         if (rc)
             return rc;
@@ -212,8 +214,8 @@ int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalMod
         for (uint32_t b = 0; b < B; ++b) {
             int last = -1;
             for (uint32_t m = 0; m < num_models[b]; ++m) {
-                const size_t h = (size_t)b * kFocalMaxModels + m;
-                const double sc = focal_finish_score(sums[h], counts[h], N, o.max_error, models[h].f, o.max_focal);
+                const size_t h = (size_t)b * kMaxModels + m;
+                const double sc = Traits::finish(sums[h], counts[h], N, o, models[h].f);
                 const bool more = counts[h] > best_min_inl, better = sc < best_min_score;
                 if (!(more || better))
                     continue;
@@ -226,7 +228,7 @@ int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalMod
             }
             if (last >= 0) {
                 imps[last].job = (int)seeds.size();
-                seeds.push_back(models[(size_t)b * kFocalMaxModels + imps[last].slot]);
+                seeds.push_back(models[(size_t)b * kMaxModels + imps[last].slot]);
             }
         }
         if (!seeds.empty()) {
@@ -249,7 +251,7 @@ int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalMod
                 const Improving &im = imps[a];
                 if (im.score < st.model_score) {
                     st.model_score = im.score;
-                    *best = models[(size_t)b * kFocalMaxModels + im.slot];
+                    *best = models[(size_t)b * kMaxModels + im.slot];
                     st.num_inliers = im.count;
                 }
                 if (im.job >= 0)
@@ -268,12 +270,24 @@ int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalMod
     if (rc)
         return rc;
     st.refinements++;
-    const double rsc = focal_finish_score(rsums[0], rcounts[0], N, o.max_error, refined[0].f, o.max_focal);
+    const double rsc = Traits::finish(rsums[0], rcounts[0], N, o, refined[0].f);
     if (rsc < st.model_score) {
         *best = refined[0];
         st.num_inliers = rcounts[0];
     }
     return 0;
+}
+
+// ransac_pnpf: FocalAbsolutePoseEstimator
+struct PnpfTraits {
+    static constexpr int kSample = kFocalSample, kMaxModels = kFocalMaxModels;
+    static double finish(double inlier_sum, uint64_t count, uint64_t n, const FocalLoopOptions &o, double focal) {
+        return focal_finish_score(inlier_sum, count, n, o.max_error, focal, o.max_focal);
+    }
+};
+template <class Backend>
+int focal_lo_ransac(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalModel *best, FocalLoopStats *stats) {
+    return focal_lo_ransac_t<PnpfTraits>(be, N, o, best, stats);
 }
 
 // ---- kernels (focal.hip) ----

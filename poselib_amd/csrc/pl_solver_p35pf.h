@@ -217,11 +217,10 @@ template <int ROWS, int COLS> PL_HD void complement_basis_indexed(double *qr /* 
     }
 }
 
-// Real eigenvalues of a 10 x 10 matrix (row-major, destroyed), ascending: Householder reduction to Hessenberg form, then the
+// Real eigenvalues of an n x n matrix (row-major, destroyed; Arr: a pointer or anything indexable that yields double&), ascending: Householder reduction to Hessenberg form, then the
 // Francis double-shift QR iteration in its textbook form; an eigenvalue counts as real when |imag| <= tol (1 + |real|).
 // No convergence after 60 sweeps on one block: no eigenvalues (the sample is dropped).
-PL_HD int p35_real_eigenvalues(double *a_, double *out, double tol) {
-    constexpr int n = 10;
+template <int n, class Arr> PL_HD int pl_real_eigenvalues(Arr a_, double *out, double tol) {
 #define PL_A(i, j) a_[(i) * n + (j)]
     for (int k = 0; k + 2 < n; ++k) {
         double tail = 0;
@@ -396,10 +395,11 @@ PL_HD int p35_real_eigenvalues(double *a_, double *out, double tol) {
     return m;
 }
 
-// null vector of the singular 10 x 10 matrix B (row-major, destroyed): Gaussian elimination with complete pivoting, the last
+PL_HD int p35_real_eigenvalues(double *a_, double *out, double tol) { return pl_real_eigenvalues<10, double *>(a_, out, tol); }
+
+// null vector of the singular n x n matrix B (row-major, destroyed): Gaussian elimination with complete pivoting, the last
 // permuted unknown set to 1
-PL_HD void p35_null_vector(double *B, double *v) {
-    constexpr int n = 10;
+template <int n, class Arr> PL_HD void pl_null_vector(Arr B, double *v) {
     int colperm[n];
     for (int i = 0; i < n; ++i)
         colperm[i] = i;
@@ -444,6 +444,7 @@ PL_HD void p35_null_vector(double *B, double *v) {
     for (int i = 0; i < n; ++i)
         v[colperm[i]] = y[i];
 }
+PL_HD void p35_null_vector(double *B, double *v) { pl_null_vector<10, double *>(B, v); }
 
 struct P35Solution {
     Quat q;

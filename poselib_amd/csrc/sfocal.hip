@@ -1,0 +1,347 @@
+// poselib_amd - kernels of the shared-focal relative pose estimator (ransac_shared_focal_relpose: robust/ransac.cc:182-203,
+// SharedFocalRelativePoseEstimator robust/estimators/relative_pose.cc:154-203, refiner robust/optim/relative.h:488-592).
+//
+//   k_sfocal_generate  one lane = one RANSAC iteration: the sample of six correspondences from the iteration's position in the
+//                      splitmix64 stream, unit bearings, the 6-point solver (pl_solver_6ptf.h).  The solver's matrices
+//                      (kSixWorkDoubles per sample) live in a workspace in HBM, element-major (consecutive lanes = consecutive
+//                      doubles).
+//   k_sfocal_score     one wavefront = one model: compute_sampson_msac_score (utils.cc:204-239) of F = K_inv (E K_inv) - inlier
+//                      count and the score IN CORRESPONDENCE ORDER (r2 of an inlier, the threshold of an outlier, one after the
+//                      other: the score decides comparisons in the loop, so it has to be the sequential sum).  The lanes evaluate
+//                      64 correspondences at a time; their terms are then added in lane order through v_readlane.
+//   k_sfocal_mask      get_inliers(F, ...) (utils.cc:401-419), one thread per correspondence.
+//   k_sfocal_lm        one workgroup = one refinement, the whole Levenberg-Marquardt loop on the device: refine_model's
+//                      pre-filter (Sampson error below 5 thr^2, nothing to do when <= 6 survive), then cost and normal equations
+//                      summed correspondence after correspondence - rounds of 256 rows in LDS, lane e < 27 owns entry e of
+//                      [JtJ | Jtr] (k_lm_cam's scheme; rows without contribution are zero rows: x + 0.0 = x) - so that the refined
+//                      model equals the oracle's to the bit for every n.
+// A first, correct device path for this estimator (like focal.hip): none of the kernels is tuned; DESIGN 4 has the numbers.
+#include "pl_kernels.h"
+#include "pl_device.h"
+#include "pl_sfocal.h"
+#include "pl_solver_6ptf.h"
+
+namespace pl {
+
+namespace {
+
+__global__ __launch_bounds__(64) void k_sfocal_generate(SFocalGenArgs g) {
+    const uint32_t it = blockIdx.x * 64u + threadIdx.x;
+    if (it >= g.num_iters)
+        return;
+    uint32_t idx[kSFocalSample];
+    draw_sample<kSFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
+    Vec3 x1[6], x2[6];
+    for (int k = 0; k < 6; ++k) { // relative_pose.cc:157-160: homogeneous().normalized()
+        x1[k] = bearing(g.a[0][idx[k]], g.a[1][idx[k]]);
+        x2[k] = bearing(g.a[2][idx[k]], g.a[3][idx[k]]);
+    }
+    uint32_t m = 0;
+    FocalModel *out = g.models + (size_t)it * kSFocalMaxModels;
+    relpose_6pt_shared_focal(x1, x2, SixWork{g.work + it, (size_t)g.work_stride}, [&](Quat q, Vec3 t, double f) {
+        FocalModel &o = out[m];
+        o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
+        o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
+        o.f = f;
+        ++m;
+    });
+    g.num_models[it] = m;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kSFocalScoreThreads = 256;
+
+__global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score(SFocalScoreArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t slot = blockIdx.x * (kSFocalScoreThreads / 64) + (threadIdx.x >> 6);
+    if (slot >= a.num_slots)
+        return;
+    if (a.num_models && (slot % kSFocalMaxModels) >= a.num_models[slot / kSFocalMaxModels])
+        return; // (wave-uniform)
+    const FocalModel m = a.models[slot];
+    double F[9];
+    sfocal_F_score(m, F);
+    uint32_t count = 0;
+    double score = 0.0;
+    for (uint32_t base = 0; base < a.n; base += 64u) {
+        const uint32_t i = base + lane;
+        double term = 0.0;
+        bool in = false;
+        if (i < a.n) {
+            const double r2 = sampson_sq(F, a.a[0][i], a.a[1][i], a.a[2][i], a.a[3][i]);
+            in = r2 < a.thr2;
+            term = in ? r2 : a.thr2;
+        }
+        count += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+        const int valid = (int)min(64u, a.n - base);
+        for (int l = 0; l < valid; ++l) // utils.cc:226-236, one correspondence after the other
+            score += readlane_f64(term, l);
+    }
+    if (lane == 0) {
+        a.counts[slot] = count;
+        a.scores[slot] = score;
+    }
+}
+
+__global__ void k_sfocal_mask(const double *x1, const double *y1, const double *x2, const double *y2, uint32_t n, FocalModel m,
+                              double thr2, uint8_t *mask, uint8_t *host_mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double F[9];
+    sfocal_F_score(m, F);
+    const uint8_t v = sampson_sq(F, x1[i], y1[i], x2[i], y2[i]) < thr2 ? 1 : 0;
+    mask[i] = v;
+    if (host_mask)
+        host_mask[i] = v;
+}
+
+constexpr int kSfLMThreads = 256;
+constexpr int kSfLMWaves = kSfLMThreads / 64;
+
+__global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks) {
+    __shared__ double s_rows[kSfLMThreads * kSFocalRow];
+    __shared__ SFocalLMTask s_task;
+    __shared__ LMControl ctl;
+    __shared__ double cur[kParamDoubles], trial[kParamDoubles];
+    __shared__ SFocalCtx ctx;
+    __shared__ double normal[kSFocalEntries];
+    __shared__ uint32_t s_wcnt[kSfLMWaves];
+    __shared__ double s_racc;
+    __shared__ uint32_t s_count;
+    __shared__ double s_F[9];
+
+    SFocalLMTask &Tout = tasks[blockIdx.x];
+    {
+        static_assert(sizeof(SFocalLMTask) % 8 == 0, "copied as 64-bit words");
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(&Tout);
+        uint64_t *dst = reinterpret_cast<uint64_t *>(&s_task);
+        for (uint32_t w = threadIdx.x; w < sizeof(SFocalLMTask) / 8; w += kSfLMThreads)
+            dst[w] = src[w];
+        __syncthreads();
+    }
+    const SFocalLMTask &T = s_task;
+    const uint32_t n = T.n;
+    const double *x1 = T.a[0], *y1 = T.a[1], *x2 = T.a[2], *y2 = T.a[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t *mask = T.mask;
+
+    auto block_count = [&](uint32_t mine) -> uint32_t { // sum over the workgroup, returned to every lane
+        const uint32_t ws = wave_sum_u32(mine);
+        __syncthreads();
+        if (lane == 0)
+            s_wcnt[wave] = ws;
+        __syncthreads();
+        uint32_t tot = 0;
+        for (int w = 0; w < kSfLMWaves; ++w)
+            tot += s_wcnt[w];
+        return tot;
+    };
+
+    if (T.prefilter_thr2 > 0) { // relative_pose.cc:179-190
+        if (threadIdx.x == 0) {
+            FocalModel m;
+            for (int i = 0; i < 4; ++i)
+                m.q[i] = T.params[i];
+            for (int i = 0; i < 3; ++i)
+                m.t[i] = T.params[4 + i];
+            m.f = T.params[kSFocalFocalSlot];
+            sfocal_F_score(m, s_F);
+        }
+        __syncthreads();
+        double F[9];
+        for (int i = 0; i < 9; ++i)
+            F[i] = s_F[i];
+        uint32_t kept = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += kSfLMThreads) {
+            const uint8_t v = sampson_sq(F, x1[i], y1[i], x2[i], y2[i]) < T.prefilter_thr2 ? 1 : 0;
+            T.scratch[i] = v;
+            kept += v;
+        }
+        const uint32_t total = block_count(kept);
+        if (total <= 6) {
+            if (threadIdx.x == 0) {
+                Tout.iterations = 0;
+                Tout.skipped = 1u;
+                Tout.cost = Tout.initial_cost = 0.0;
+            }
+            return;
+        }
+        mask = T.scratch;
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < kParamDoubles; ++i)
+            cur[i] = T.params[i];
+        ctl.opt = T.opt;
+        ctl.loss = make_loss(T.opt.loss_type, T.opt.loss_scale);
+        ctl.done = 0;
+    }
+    __syncthreads();
+
+    // robust cost at p -> s_racc, s_count
+    auto cost_pass = [&](const double *p) {
+        if (threadIdx.x == 0)
+            sfocal_prepare(p, ctx, false);
+        __syncthreads();
+        const Loss loss = ctl.loss;
+        double racc = 0.0; // (thread 0)
+        uint32_t mine = 0;
+        for (uint32_t base = 0; base < n; base += kSfLMThreads) {
+            const uint32_t i = base + threadIdx.x;
+            double term = 0.0;
+            if (i < n && !(mask && !mask[i])) {
+                const double r = sfocal_residual(ctx, x1[i], y1[i], x2[i], y2[i]);
+                term = 1.0 * loss_value(loss, r * r);
+                mine++;
+            }
+            s_rows[threadIdx.x] = term; // (x + 0.0 = x for the correspondences that are not part of the problem)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t rows = min((uint32_t)kSfLMThreads, n - base);
+                uint32_t q = 0;
+                for (; q + 8u <= rows; q += 8u) { // (reads together, additions in order)
+                    double t8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        t8[u] = s_rows[q + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        racc += t8[u];
+                }
+                for (; q < rows; ++q)
+                    racc += s_rows[q];
+            }
+            __syncthreads();
+        }
+        const uint32_t total = block_count(mine);
+        if (threadIdx.x == 0) {
+            s_racc = racc;
+            s_count = total;
+        }
+        __syncthreads();
+    };
+
+    // normal equations at p -> normal[0 .. 27), s_count.  p's tangent basis is refreshed first (relative.h:513).
+    auto jacobian_pass = [&](double *p) {
+        if (threadIdx.x == 0) {
+            Refiner<EST_REL>::prepare_params(p);
+            sfocal_prepare(p, ctx, true);
+        }
+        __syncthreads();
+        const Loss loss = ctl.loss;
+        double acc = 0.0;
+        uint32_t mine = 0;
+        for (uint32_t base = 0; base < n; base += kSfLMThreads) {
+            const uint32_t i = base + threadIdx.x;
+            double row[kSFocalRow];
+#pragma unroll
+            for (int k = 0; k < kSFocalRow; ++k)
+                row[k] = 0.0;
+            if (i < n && !(mask && !mask[i]))
+                mine += sfocal_row(ctx, loss, x1[i], y1[i], x2[i], y2[i], row) ? 1u : 0u;
+            double *dst = s_rows + (size_t)threadIdx.x * kSFocalRow;
+#pragma unroll
+            for (int k = 0; k < kSFocalRow; ++k)
+                dst[k] = row[k];
+            __syncthreads();
+            if ((int)threadIdx.x < kSFocalEntries) {
+                const uint32_t rows = min((uint32_t)kSfLMThreads, n - base);
+                const double *r = s_rows;
+                uint32_t q = 0;
+                for (; q + 8u <= rows; q += 8u, r += 8 * kSFocalRow) {
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        t[u] = sfocal_entry_term(r + u * kSFocalRow, (int)threadIdx.x);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        acc += t[u];
+                }
+                for (; q < rows; ++q, r += kSFocalRow)
+                    acc += sfocal_entry_term(r, (int)threadIdx.x);
+            }
+            __syncthreads();
+        }
+        const uint32_t total = block_count(mine);
+        if ((int)threadIdx.x < kSFocalEntries)
+            normal[threadIdx.x] = acc;
+        if (threadIdx.x == 0)
+            s_count = total;
+        __syncthreads();
+    };
+
+    cost_pass(cur);
+    if (threadIdx.x == 0)
+        lm_begin(ctl, T.opt, s_racc, s_count);
+    __syncthreads();
+
+    while (!ctl.done) {
+        const bool fresh = ctl.rejac != 0;
+        if (fresh)
+            jacobian_pass(cur);
+        if (threadIdx.x == 0) {
+            lm_solve<6>(ctl, normal, fresh, s_count);
+            if (!ctl.done)
+                sfocal_step(cur, ctl.sol, trial);
+        }
+        __syncthreads();
+        if (ctl.done)
+            break;
+        cost_pass(trial);
+        if (threadIdx.x == 0) {
+            if (lm_update<6>(ctl, normal, s_racc, s_count)) {
+                for (int i = 0; i < kParamDoubles; ++i)
+                    cur[i] = trial[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < kParamDoubles; ++i)
+            Tout.params[i] = cur[i];
+        Tout.iterations = ctl.iterations;
+        Tout.skipped = 0u;
+        Tout.cost = ctl.cost;
+        Tout.initial_cost = ctl.initial_cost;
+    }
+}
+
+} // namespace
+
+hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
+    if (g.num_iters == 0)
+        return hipSuccess;
+    k_sfocal_generate<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
+    return hipGetLastError();
+}
+hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream) {
+    if (a.num_slots == 0)
+        return hipSuccess;
+    constexpr uint32_t per_block = kSFocalScoreThreads / 64;
+    k_sfocal_score<<<dim3((a.num_slots + per_block - 1) / per_block), dim3(kSFocalScoreThreads), 0, stream>>>(a);
+    return hipGetLastError();
+}
+hipError_t launch_sfocal_mask(const double *const *a, uint32_t n, const FocalModel &m, double thr2, uint8_t *mask, uint8_t *host_mask,
+                              hipStream_t stream) {
+    if (n == 0)
+        return hipSuccess;
+    k_sfocal_mask<<<dim3((n + 255u) / 256u), dim3(256), 0, stream>>>(a[0], a[1], a[2], a[3], n, m, thr2, mask, host_mask);
+    return hipGetLastError();
+}
+hipError_t launch_sfocal_lm(SFocalLMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
+    if (num_tasks == 0)
+        return hipSuccess;
+    k_sfocal_lm<<<dim3(num_tasks), dim3(kSfLMThreads), 0, stream>>>(tasks);
+    return hipGetLastError();
+}
+
+} // namespace pl

@@ -10,9 +10,11 @@
 #include "../../poselib_amd/csrc/pl_refine.h"
 #include "../../poselib_amd/csrc/pl_refine_cam.h"
 #include "../../poselib_amd/csrc/pl_sampler.h"
+#include "../../poselib_amd/csrc/pl_sfocal.h"
 #include "../../poselib_amd/csrc/pl_score.h"
 #include "../../poselib_amd/csrc/pl_solver_h4.h"
 #include "../../poselib_amd/csrc/pl_solver_p35pf.h"
+#include "../../poselib_amd/csrc/pl_solver_6ptf.h"
 #include "../../poselib_amd/csrc/pl_solver_p3p.h"
 #include "../../poselib_amd/csrc/pl_solver_rel.h"
 
@@ -233,6 +235,23 @@ int hm_p35pf(const double *x /* 4 x 2 */, const double *X /* 4 x 3 */, uint32_t 
         std::memcpy(poses7 + 7 * i, o, sizeof(o));
         focals[i] = sol[i].focal;
     }
+    return n;
+}
+// the 6-point shared-focal solver (pl_solver_6ptf.h) with the workspace at a stride, like the device lays it out
+int hm_relpose_6pt_shared_focal(const double *b1 /* 6 x 3 unit bearings */, const double *b2, uint32_t stride, double *poses7,
+                                double *focals) {
+    std::vector<double> work((size_t)kSixWorkDoubles * stride, 0.0);
+    Vec3 a[6], b[6];
+    for (int i = 0; i < 6; ++i) {
+        a[i] = v3(b1[3 * i], b1[3 * i + 1], b1[3 * i + 2]);
+        b[i] = v3(b2[3 * i], b2[3 * i + 1], b2[3 * i + 2]);
+    }
+    int n = 0;
+    relpose_6pt_shared_focal(a, b, SixWork{work.data() + (stride - 1), stride}, [&](Quat q, Vec3 t, double f) {
+        const double o[7] = {q.w, q.x, q.y, q.z, t.x, t.y, t.z};
+        std::memcpy(poses7 + 7 * n, o, sizeof(o));
+        focals[n++] = f;
+    });
     return n;
 }
 int hm_sturm10(const double *coef, double *roots) { return sturm_roots_deg10(coef, roots); }
@@ -547,6 +566,87 @@ void hm_lm_cam(const double *const *pa, uint32_t n, double *params, const LMOpti
     costs[0] = ctl.initial_cost, costs[1] = ctl.cost;
 }
 
+// The shared-focal refiner as k_sfocal_lm runs it (sfocal.hip): every sum correspondence after correspondence.  prefilter_thr2 > 0:
+// refine_model of the estimator (relative_pose.cc:173-203) - the correspondences with Sampson error below it, nothing when <= 6.
+// Returns 1 when the refinement was skipped.
+int hm_sfocal_lm(const double *const *pa, uint32_t n, double *pose7, double *focal, const LMOptions *opt, double prefilter_thr2,
+                 const uint8_t *mask_in, uint32_t *iterations, double *costs /* initial, final */) {
+    std::vector<uint8_t> keep(n, 1);
+    if (prefilter_thr2 > 0) {
+        FocalModel m;
+        std::memcpy(m.q, pose7, sizeof(double) * 4);
+        std::memcpy(m.t, pose7 + 4, sizeof(double) * 3);
+        m.f = *focal;
+        double F[9];
+        sfocal_F_score(m, F);
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            keep[i] = sampson_sq(F, pa[0][i], pa[1][i], pa[2][i], pa[3][i]) < prefilter_thr2;
+            cnt += keep[i];
+        }
+        if (cnt <= 6)
+            return 1;
+    } else if (mask_in) {
+        for (uint32_t i = 0; i < n; ++i)
+            keep[i] = mask_in[i] != 0;
+    }
+    LMControl ctl;
+    ctl.opt = *opt;
+    ctl.loss = make_loss(opt->loss_type, opt->loss_scale);
+    ctl.done = 0;
+    double cur[kParamDoubles] = {0}, trial[kParamDoubles];
+    std::memcpy(cur, pose7, sizeof(double) * 7);
+    cur[kSFocalFocalSlot] = *focal;
+    double normal[kSFocalEntries], racc = 0;
+    uint32_t count = 0;
+    SFocalCtx ctx;
+    auto cost_pass = [&](const double *p) {
+        sfocal_prepare(p, ctx, false);
+        racc = 0, count = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!keep[i])
+                continue;
+            const double r = sfocal_residual(ctx, pa[0][i], pa[1][i], pa[2][i], pa[3][i]);
+            racc += 1.0 * loss_value(ctl.loss, r * r);
+            count++;
+        }
+    };
+    auto jacobian_pass = [&](double *p) {
+        Refiner<EST_REL>::prepare_params(p);
+        sfocal_prepare(p, ctx, true);
+        for (int e = 0; e < kSFocalEntries; ++e)
+            normal[e] = 0;
+        count = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            double row[kSFocalRow];
+            if (!keep[i] || !sfocal_row(ctx, ctl.loss, pa[0][i], pa[1][i], pa[2][i], pa[3][i], row))
+                continue;
+            for (int e = 0; e < kSFocalEntries; ++e)
+                normal[e] += sfocal_entry_term(row, e);
+            count++;
+        }
+    };
+    cost_pass(cur);
+    lm_begin(ctl, *opt, racc, count);
+    while (!ctl.done) {
+        const bool fresh = ctl.rejac != 0;
+        if (fresh)
+            jacobian_pass(cur);
+        lm_solve<6>(ctl, normal, fresh, count);
+        if (ctl.done)
+            break;
+        sfocal_step(cur, ctl.sol, trial);
+        cost_pass(trial);
+        if (lm_update<6>(ctl, normal, racc, count))
+            std::memcpy(cur, trial, sizeof(cur));
+    }
+    std::memcpy(pose7, cur, sizeof(double) * 7);
+    *focal = cur[kSFocalFocalSlot];
+    *iterations = ctl.iterations;
+    costs[0] = ctl.initial_cost, costs[1] = ctl.cost;
+    return 0;
+}
+
 void hm_factorized_F(const double *params, double *F) { factorized_F(params, F); }
 
 // pl_libm.h against the host's libm (glibc): number of arguments on which pl_cbrt and cbrt differ in any bit.
@@ -768,6 +868,111 @@ extern "C" void hm_ransac_pnpf(const double *const *pa, uint32_t n, uint64_t max
     focal_rotation(best, R);
     for (uint32_t i = 0; i < n; ++i)
         mask[i] = focal_reproj_mask(R, best.t, best.f, pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], max_error * max_error) ? 1 : 0;
+    stats5[0] = st.refinements, stats5[1] = st.iterations, stats5[2] = st.num_inliers, stats5[3] = st.hypotheses, stats5[4] = st.iterations_evaluated;
+    *model_score = st.model_score;
+}
+
+// ---- ransac_shared_focal_relpose: pl_focal.h's loop template with SharedFocalTraits over a serial evaluation of the device
+// functions (6-point generator, in-order MSAC score, hm_sfocal_lm) ----
+namespace {
+struct HostSFocalBackend {
+    const double *const *pa;
+    uint32_t n;
+    uint64_t seed;
+    double thr2, max_error;
+    std::vector<double> work = std::vector<double>(kSixWorkDoubles);
+
+    void score_one(const FocalModel &m, uint32_t &count, double &score) const {
+        double F[9];
+        sfocal_F_score(m, F);
+        count = 0, score = 0.0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double r2 = sampson_sq(F, pa[0][i], pa[1][i], pa[2][i], pa[3][i]);
+            if (r2 < thr2)
+                count++, score += r2;
+            else
+                score += thr2;
+        }
+    }
+    int minimal(uint64_t pos_base, const uint32_t *positions, uint32_t B, std::vector<FocalModel> &models,
+                std::vector<uint32_t> &num_models, std::vector<uint32_t> &counts, std::vector<double> &sums) {
+        models.assign((size_t)B * kSFocalMaxModels, FocalModel());
+        num_models.assign(B, 0);
+        counts.assign((size_t)B * kSFocalMaxModels, 0);
+        sums.assign((size_t)B * kSFocalMaxModels, 0.0);
+        for (uint32_t it = 0; it < B; ++it) {
+            uint32_t idx[kSFocalSample];
+            draw_sample<kSFocalSample>(seed, pos_base + positions[it], n, idx);
+            Vec3 a[6], b[6];
+            for (int k = 0; k < 6; ++k) {
+                a[k] = bearing(pa[0][idx[k]], pa[1][idx[k]]);
+                b[k] = bearing(pa[2][idx[k]], pa[3][idx[k]]);
+            }
+            uint32_t m = 0;
+            relpose_6pt_shared_focal(a, b, SixWork{work.data(), 1}, [&](Quat q, Vec3 t, double f) {
+                const size_t h = (size_t)it * kSFocalMaxModels + m;
+                FocalModel &o = models[h];
+                o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
+                o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
+                o.f = f;
+                score_one(o, counts[h], sums[h]);
+                ++m;
+            });
+            num_models[it] = m;
+        }
+        return 0;
+    }
+    int score(const std::vector<FocalModel> &models, std::vector<uint32_t> &counts, std::vector<double> &sums) {
+        counts.assign(models.size(), 0);
+        sums.assign(models.size(), 0.0);
+        for (size_t i = 0; i < models.size(); ++i)
+            score_one(models[i], counts[i], sums[i]);
+        return 0;
+    }
+    int refine(const std::vector<FocalModel> &seeds, std::vector<FocalModel> &refined) {
+        refined = seeds;
+        LMOptions lo;
+        lo.max_iterations = 25, lo.loss_type = LOSS_TRUNCATED, lo.lambda_update = 0, lo.damping = 0;
+        lo.loss_scale = max_error, lo.gradient_tol = 1e-12, lo.step_tol = 1e-8, lo.relative_cost_tol = 1e-10;
+        lo.initial_lambda = 1e-3, lo.min_lambda = 1e-10, lo.max_lambda = 1e10, lo.lambda_factor = 10.0;
+        for (FocalModel &m : refined) {
+            uint32_t its;
+            double costs[2];
+            hm_sfocal_lm(pa, n, m.q, &m.f, &lo, 5 * thr2, nullptr, &its, costs); // (q and t are adjacent: 7 doubles)
+        }
+        return 0;
+    }
+};
+} // namespace
+
+extern "C" void hm_ransac_shared_focal(const double *const *pa, uint32_t n, uint64_t max_iterations, uint64_t min_iterations,
+                                       uint64_t seed, double dyn_mult, double success_prob, int score_initial, double max_error,
+                                       double *pose7, double *focal, uint8_t *mask,
+                                       uint64_t *stats5 /* refinements, iterations, num_inliers, hypotheses, evaluated */,
+                                       double *model_score) {
+    FocalLoopOptions o;
+    o.max_iterations = max_iterations, o.min_iterations = min_iterations, o.seed = seed;
+    o.dyn_num_trials_mult = dyn_mult, o.success_prob = success_prob, o.score_initial_model = score_initial != 0;
+    o.max_error = max_error;
+    o.max_focal = -1.0;
+    HostSFocalBackend be{pa, n, seed, max_error * max_error, max_error};
+    FocalModel best;
+    std::memcpy(best.q, pose7, sizeof(double) * 4);
+    std::memcpy(best.t, pose7 + 4, sizeof(double) * 3);
+    best.f = *focal;
+    if (!score_initial) {
+        std::memset(&best, 0, sizeof(best));
+        best.q[0] = 1.0, best.f = 1.0;
+    }
+    FocalLoopStats st;
+    focal_lo_ransac_t<SharedFocalTraits>(be, n, o, &best, &st);
+    std::memcpy(pose7, best.q, sizeof(double) * 4);
+    std::memcpy(pose7 + 4, best.t, sizeof(double) * 3);
+    *focal = best.f;
+    double F[9];
+    sfocal_F_score(best, F);
+    for (uint32_t i = 0; i < n; ++i)
+        mask[i] = sampson_sq(F, pa[0][i], pa[1][i], pa[2][i], pa[3][i]) < max_error * max_error ? 1 : 0;
     stats5[0] = st.refinements, stats5[1] = st.iterations, stats5[2] = st.num_inliers, stats5[3] = st.hypotheses, stats5[4] = st.iterations_evaluated;
     *model_score = st.model_score;
 }

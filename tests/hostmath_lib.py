@@ -240,6 +240,54 @@ def p35pf(x, X, stride=1):
     return poses[:n].copy(), focals[:n].copy()
 
 
+def relpose_6pt_shared_focal(b1, b2, stride=1):
+    """pl_solver_6ptf.h on the host; the workspace at `stride` doubles between elements, as on the device"""
+    b1 = np.ascontiguousarray(b1, dtype=np.float64)
+    b2 = np.ascontiguousarray(b2, dtype=np.float64)
+    poses = np.zeros((60, 7))
+    focals = np.zeros(60)
+    n = lib().hm_relpose_6pt_shared_focal(_p(b1), _p(b2), C.c_uint32(stride), _p(poses), _p(focals))
+    return poses[:n].copy(), focals[:n].copy()
+
+
+def sfocal_lm(x1, x2, pose, focal, opt, prefilter_thr2=0.0, mask=None):
+    """the shared-focal refiner as k_sfocal_lm runs it.  Returns (pose7, focal, iterations, (initial cost, cost), skipped)"""
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    x2 = np.ascontiguousarray(x2, dtype=np.float64)
+    n = x1.shape[0]
+    cols, ptrs = _soa([x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1]])
+    p = np.ascontiguousarray(pose, dtype=np.float64).copy()
+    f = C.c_double(focal)
+    its = C.c_uint32(0)
+    costs = np.zeros(2)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().hm_sfocal_lm.restype = C.c_int
+    skipped = lib().hm_sfocal_lm(ptrs, C.c_uint32(n), _p(p), C.byref(f), C.byref(opt), C.c_double(prefilter_thr2),
+                                 None if m is None else _p(m), C.byref(its), _p(costs))
+    return p, f.value, its.value, costs, bool(skipped)
+
+
+def ransac_shared_focal(x1, x2, max_error=1.0, seed=0, max_iterations=100000, min_iterations=1000, dyn_mult=3.0,
+                        success_prob=0.9999, init_pose=None, init_focal=1.0):
+    """the product's ransac_shared_focal_relpose loop (pl_focal.h + pl_sfocal.h) over a serial evaluation of the device
+    functions.  Returns (pose7, focal, mask, stats dict)."""
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    x2 = np.ascontiguousarray(x2, dtype=np.float64)
+    n = x1.shape[0]
+    cols, ptrs = _soa([x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1]])
+    pose = np.array([1.0, 0, 0, 0, 0, 0, 0]) if init_pose is None else np.ascontiguousarray(init_pose, dtype=np.float64).copy()
+    focal = C.c_double(init_focal)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    st = np.zeros(5, dtype=np.uint64)
+    score = C.c_double(0.0)
+    lib().hm_ransac_shared_focal(ptrs, C.c_uint32(n), C.c_uint64(max_iterations), C.c_uint64(min_iterations), C.c_uint64(seed),
+                                 C.c_double(dyn_mult), C.c_double(success_prob), C.c_int(int(init_pose is not None)),
+                                 C.c_double(max_error), _p(pose), C.byref(focal), _p(mask), _p(st), C.byref(score))
+    return pose, focal.value, mask[:n].astype(bool), {"refinements": int(st[0]), "iterations": int(st[1]), "num_inliers": int(st[2]),
+                                                     "hypotheses": int(st[3]), "iterations_evaluated": int(st[4]),
+                                                     "model_score": score.value}
+
+
 def ransac_pnpf(x, X, max_error=12.0, seed=0, max_iterations=100000, min_iterations=1000, dyn_mult=3.0, success_prob=0.9999,
                 score_initial=False, min_fov=5.0):
     """the product's ransac_pnpf loop (pl_focal.h) over a serial evaluation of the device functions.

@@ -3,6 +3,7 @@ build of the very same headers hipcc compiles into the kernels), against the ora
 kernel arithmetic is validated without a GPU.  With the same libm both sides must agree to the bit for
 everything except the 5-point solver (different, but equivalent, summation order of the constraint rows)."""
 import numpy as np
+import pytest
 
 import hostmath_lib as HM
 import oracle_lib as O
@@ -287,3 +288,78 @@ def test_ransac_pnpf_loop_of_the_product_takes_the_oracles_decisions():
     op, of, om, ost = O.ransac_pnpf(x[:3], d["p3d"][:3], {"max_error": 3.0})
     hp, hf, hm, hst = HM.ransac_pnpf(x[:3], d["p3d"][:3], max_error=3.0)
     assert hst["iterations"] == ost["iterations"] == 0 and np.array_equal(hp, op) and hf == of == 1.0 and np.array_equal(hm, om)
+
+
+# ---- the shared-focal relative pose estimator: pl_solver_6ptf.h, pl_sfocal.h and pl_focal.h's loop template ----
+def _six_bearings(rng):
+    from scipy.spatial.transform import Rotation
+    f = rng.uniform(300, 3000)
+    X = rng.uniform(-1, 1, (6, 3)) * [2, 2, 1] + [0, 0, 5]
+    R = Rotation.from_rotvec(rng.normal(size=3) * 0.2).as_matrix()
+    t = rng.normal(size=3)
+    X2 = X @ R.T + t / np.linalg.norm(t)
+    s = rng.uniform(400, 2500)
+    b1 = np.c_[f * X[:, :2] / X[:, 2:] / s, np.ones(6)]
+    b2 = np.c_[f * X2[:, :2] / X2[:, 2:] / s, np.ones(6)]
+    return b1 / np.linalg.norm(b1, axis=1)[:, None], b2 / np.linalg.norm(b2, axis=1)[:, None]
+
+
+def test_six_point_shared_focal_device_header_bit_exact():
+    """pl_solver_6ptf.h (the generator kernel's per-lane code, its workspace at a stride like on the device) against the oracle's
+    statement of the same algorithm (solvers_focal.cc, dense arrays): poses, focal lengths and their order, bit for bit"""
+    rng = np.random.default_rng(3)
+    total = 0
+    for k in range(300):
+        b1, b2 = _six_bearings(rng)
+        po, fo = O.relpose_6pt_shared_focal(b1, b2)
+        ph, fh = HM.relpose_6pt_shared_focal(b1, b2, stride=1 + k % 3)
+        assert po.shape == ph.shape and np.array_equal(po, ph) and np.array_equal(fo, fh), k
+        total += len(fo)
+    assert total > 300
+    # degenerate input: all six correspondences equal
+    b = np.tile(np.array([[0.1, 0.2, 1.0]]) / np.linalg.norm([0.1, 0.2, 1.0]), (6, 1))
+    po, fo = O.relpose_6pt_shared_focal(b, b)
+    ph, fh = HM.relpose_6pt_shared_focal(b, b)
+    assert po.shape == ph.shape and np.array_equal(po, ph, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_shared_focal_refiner_of_the_product_bit_exact(seed):
+    """pl_sfocal.h's residual / Jacobian row / step under pl_refine.h's LM control, summed in k_sfocal_lm's order, against the
+    oracle's refine_shared_focal_relpose (itself bit-exact with the reference's sources) - every loss"""
+    d = synth.relative_pose_scene(300, 0.2, 100 + seed, focal=900.0)
+    f, cx, cy = d["camera1"]["params"]
+    a, b = (d["x1"] - [cx, cy]) / 700.0, (d["x2"] - [cx, cy]) / 700.0
+    q = np.r_[d["q_gt"], d["t_gt"]] + 0.01 * np.random.default_rng(seed).normal(size=7)
+    q[:4] /= np.linalg.norm(q[:4])
+    for loss in range(6):
+        po, fo, so = O.refine_shared_focal_relpose(a, b, q, 1.1 * f / 700, {"loss_type": loss, "loss_scale": 0.003, "max_iterations": 30})
+        ph, fh, its, costs, skipped = HM.sfocal_lm(a, b, q, 1.1 * f / 700, HM.lm_options(30, loss, 0.003))
+        assert not skipped and np.array_equal(po, ph) and fo == fh and its == so.iterations
+        assert costs[0] == so.initial_cost and costs[1] == so.cost
+
+
+def test_ransac_shared_focal_loop_of_the_product_takes_the_oracles_decisions():
+    """pl_focal.h's loop template with SharedFocalTraits over the device functions evaluated serially: every decision, the score
+    and the returned model equal the oracle's ransac_shared_focal_relpose"""
+    for seed, outl, n in [(0, 0.3, 1200), (1, 0.5, 1200), (2, 0.2, 400), (3, 0.4, 2500), (4, 0.3, 40)]:
+        d = synth.relative_pose_scene(n, outl, 8400 + seed)
+        f, cx, cy = d["camera1"]["params"]
+        a, b = (d["x1"] - [cx, cy]) / 500.0, (d["x2"] - [cx, cy]) / 500.0
+        ro = {"seed": seed, "max_iterations": 3000} if seed != 2 else {"seed": 2, "min_iterations": 20, "success_prob": 0.95}
+        po, fo, mo, so = O.ransac_shared_focal_relpose(a, b, {"max_error": 2.0 / 500, "ransac": ro})
+        ph, fh, mh, sh = HM.ransac_shared_focal(a, b, max_error=2.0 / 500, seed=seed, max_iterations=ro.get("max_iterations", 100000),
+                                                min_iterations=ro.get("min_iterations", 1000), success_prob=ro.get("success_prob", 0.9999))
+        assert np.array_equal(po, ph) and fo == fh and np.array_equal(mo, mh), seed
+        for k in ("iterations", "refinements", "num_inliers", "model_score"):
+            assert so[k] == sh[k], (seed, k)
+    # an initial model (score_initial_model)
+    d = synth.relative_pose_scene(500, 0.3, 8500)
+    f, cx, cy = d["camera1"]["params"]
+    a, b = (d["x1"] - [cx, cy]) / 500.0, (d["x2"] - [cx, cy]) / 500.0
+    init = np.r_[d["q_gt"], d["t_gt"]]
+    po, fo, mo, so = O.ransac_shared_focal_relpose(a, b, {"max_error": 2.0 / 500, "ransac": {"seed": 9, "max_iterations": 1500, "score_initial_model": True}},
+                                                   init_pose=init, init_focal=1.1 * f / 500)
+    ph, fh, mh, sh = HM.ransac_shared_focal(a, b, max_error=2.0 / 500, seed=9, max_iterations=1500, init_pose=init, init_focal=1.1 * f / 500)
+    assert np.array_equal(po, ph) and fo == fh and np.array_equal(mo, mh)
+    assert (so["iterations"], so["refinements"], so["model_score"]) == (sh["iterations"], sh["refinements"], sh["model_score"])

@@ -1,0 +1,117 @@
+"""GPU parity (-m gpu) of the shared-focal relative pose estimator - SURVEY §8 (f4): pl_ransac_shared_focal_relpose,
+pl_estimate_shared_focal_relative_pose (robust.cc:366-424 -> ransac.cc:182-203 -> SharedFocalRelativePoseEstimator) and
+pl_refine_shared_focal_relpose (bundle.cc:281-297) through the C-ABI against the oracle.
+
+The chain of evidence: the oracle's estimator takes the decisions of the REFERENCE's on the pinned scenes and its refiner equals
+the reference's bit for bit (tests/test_reference_focal_estimator.py; the 6-point solver is this project's own formulation); the
+device functions equal the oracle bit for bit on the host (tests/test_hostmath_vs_oracle.py: solver, refiner, loop); here the
+kernels themselves.  k_sfocal_score and k_sfocal_lm add every sum correspondence after correspondence, so EVERYTHING is demanded
+bit for bit at every size: decisions, score, inlier mask, pose, focal length.
+
+(The file name sorts last on purpose: a failure in this new path must not hide the rest of the suite behind -x.)
+"""
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from poselib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _centered(d, s=1.0):
+    f, cx, cy = d["camera1"]["params"]
+    return (np.asarray(d["x1"]) - [cx, cy]) / s, (np.asarray(d["x2"]) - [cx, cy]) / s, f / s
+
+
+def _check(tag, pair, info, ref, decisions_only=False):
+    rpose, rfocal, rmask, rst = ref
+    for k in ("iterations", "refinements", "num_inliers"):
+        assert info[k] == rst[k], (tag, k, info[k], rst[k])
+    assert np.array_equal(np.asarray(info["inliers"], dtype=bool), rmask), tag
+    assert info["model_score"] == rst["model_score"], (tag, info["model_score"], rst["model_score"])
+    pose = np.r_[pair.pose.q, pair.pose.t]
+    assert np.array_equal(pose, rpose), (tag, np.abs(pose - rpose).max())
+    assert pair.camera1.params[0] == rfocal and pair.camera2.params[0] == rfocal, (tag, pair.camera1.params[0] - rfocal)
+
+
+@pytest.mark.parametrize("n", [30, 200, 256, 700, 2000])
+def test_ransac_shared_focal_relpose_bit_exact(gpu, n):
+    for k in range(3):
+        d = synth.relative_pose_scene(n, [0.2, 0.4, 0.5][k], 8800 + 10 * n + k, noise_px=0.5)
+        a, b, f = _centered(d, 500.0)
+        opt = {"max_error": 2.0 / 500.0, "ransac": {"seed": 5 + k, "max_iterations": 4000}}
+        ref = O.ransac_shared_focal_relpose(a, b, opt)
+        pair, info = gpu.ransac_shared_focal_relpose(a, b, opt)
+        _check((n, k), pair, info, ref)
+        if k < 2 and n >= 200:
+            assert abs(pair.camera1.params[0] - f) / f < 0.05
+
+
+def test_ransac_shared_focal_options_and_initial_model(gpu):
+    d = synth.relative_pose_scene(600, 0.3, 8900, noise_px=0.7)
+    a, b, f = _centered(d, 400.0)
+    for ro in ({"seed": 3, "max_iterations": 700, "min_iterations": 50}, {"seed": 4, "min_iterations": 10, "success_prob": 0.9, "dyn_num_trials_mult": 1.0},
+               {"seed": 5, "max_iterations": 2000, "min_iterations": 1500}):
+        opt = {"max_error": 1.5 / 400.0, "ransac": ro}
+        ref = O.ransac_shared_focal_relpose(a, b, opt)
+        pair, info = gpu.ransac_shared_focal_relpose(a, b, opt)
+        _check(("opt", ro["seed"]), pair, info, ref)
+    # score_initial_model: a model near the truth, the focal length 10 % off
+    init = gpu.ImagePair(gpu.CameraPose(d["q_gt"], d["t_gt"]), gpu.Camera("SIMPLE_PINHOLE", [1.1 * f, 0.0, 0.0]))
+    opt = {"max_error": 1.5 / 400.0, "ransac": {"seed": 8, "max_iterations": 1200, "score_initial_model": True}}
+    ref = O.ransac_shared_focal_relpose(a, b, opt, init_pose=np.r_[d["q_gt"], d["t_gt"]], init_focal=1.1 * f)
+    pair, info = gpu.ransac_shared_focal_relpose(a, b, {"max_error": 1.5 / 400.0, "ransac": {"seed": 8, "max_iterations": 1200}}, initial_pair=init)
+    _check("initial", pair, info, ref)
+    # fewer correspondences than a sample: nothing runs (ransac_impl.h:87-91)
+    pair, info = gpu.ransac_shared_focal_relpose(a[:5], b[:5], {"max_error": 0.01})
+    ref = O.ransac_shared_focal_relpose(a[:5], b[:5], {"max_error": 0.01})
+    assert info["iterations"] == ref[3]["iterations"] == 0 and info["num_inliers"] == 0
+
+
+@pytest.mark.parametrize("seed,outliers,n", [(0, 0.3, 1200), (1, 0.5, 1200), (2, 0.2, 300), (3, 0.4, 3000)])
+def test_estimate_shared_focal_relative_pose_front_end(gpu, seed, outliers, n):
+    """robust.cc:366-424: principal point removed, shared scale normalisation, RANSAC, final refinement on the inliers, focal
+    length back in pixels"""
+    d = synth.relative_pose_scene(n, outliers, 8400 + seed)
+    f, cx, cy = d["camera1"]["params"]
+    opt = {"max_error": 2.0, "ransac": {"seed": seed}}
+    t0 = time.perf_counter()
+    pair, info = gpu.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], opt)
+    t_dev = time.perf_counter() - t0
+    ref = O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], opt)
+    _check(("front", seed), pair, info, ref)
+    assert pair.camera1.params[1:] == [cx, cy]
+    assert abs(pair.camera1.params[0] - f) / f < 1e-2
+    print(f"\n[shared focal] n={n}, {info['iterations']} iterations, {info['hypotheses']} hypotheses: device {1e3 * t_dev:.1f} ms, "
+          f"oracle {1e3 * ref[3]['seconds']:.1f} ms")
+    # the LOSS options of the final bundle reach the refiner
+    for loss in ("HUBER", "TRUNCATED_LE_ZACH"):
+        o2 = dict(opt, bundle={"loss_type": loss, "loss_scale": 1.5, "max_iterations": 40})
+        pair, info = gpu.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], o2)
+        _check(("front", seed, loss), pair, info, O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], o2))
+
+
+@pytest.mark.parametrize("n", [20, 256, 1500])
+def test_refine_shared_focal_relpose_bit_exact(gpu, n):
+    d = synth.relative_pose_scene(n, 0.15, 9100 + n, focal=900.0)
+    a, b, f = _centered(d, 700.0)
+    q = np.r_[d["q_gt"], d["t_gt"]] + 0.01 * np.random.default_rng(n).normal(size=7)
+    q[:4] /= np.linalg.norm(q[:4])
+    for loss in ("TRIVIAL", "TRUNCATED", "HUBER", "CAUCHY", "TRUNCATED_CAUCHY", "TRUNCATED_LE_ZACH"):
+        bo = {"loss_type": loss, "loss_scale": 0.003, "max_iterations": 30}
+        po, fo, so = O.refine_shared_focal_relpose(a, b, q, 1.1 * f, bo)
+        pair, its = gpu.refine_shared_focal_relpose(a, b, gpu.ImagePair(gpu.CameraPose(q[:4], q[4:]), gpu.Camera("SIMPLE_PINHOLE", [1.1 * f, 0, 0])), bo)
+        assert its == so.iterations, (n, loss, its, so.iterations)
+        assert np.array_equal(np.r_[pair.pose.q, pair.pose.t], po) and pair.camera1.params[0] == fo, (n, loss)
+
+
+def test_shared_focal_rejections(gpu):
+    d = synth.relative_pose_scene(100, 0.2, 9200)
+    a, b, f = _centered(d, 500.0)
+    with pytest.raises(gpu.PoseLibAmdError):
+        gpu.ransac_shared_focal_relpose(a, b, {"max_error": 0.01, "ransac": {"progressive_sampling": True}})
+    with pytest.raises(gpu.PoseLibAmdError):
+        gpu.ransac_shared_focal_relpose(a, b, {"max_error": 0.01, "tangent_sampson": True})
