@@ -4,6 +4,7 @@
 // the reference's robust.cc, so every poselib::estimate_* call below lands in libposelib_amd.so.
 //
 //   robust_amd_check <in.bin> <out.bin>
+//     (kind 4: estimate_shared_focal_relative_pose, kind 5: estimate_absolute_pose with estimate_focal_length)
 //     in : doubles [kind, n, seed, max_error, model_id, num_params, params[12], A (n x 2), B (n x 3 | n x 2)]
 //     out: doubles [iterations, refinements, num_inliers, model_score, model (7: q t | 9: column-major 3x3),
 //                   camera params[12] (kind 0), inliers (n)]
@@ -34,7 +35,8 @@ int main(int argc, char **argv) {
         return 2;
     std::fclose(f);
 
-    const int kind = (int)in[0];
+    const bool estimate_focal = (int)in[0] == 5;
+    const int kind = estimate_focal ? 0 : (int)in[0];
     const size_t n = (size_t)in[1];
     RansacOptions ransac;
     ransac.seed = (size_t)in[2];
@@ -60,6 +62,7 @@ int main(int argc, char **argv) {
         AbsolutePoseOptions opt;
         opt.ransac = ransac;
         opt.max_error = max_error;
+        opt.estimate_focal_length = estimate_focal; // (kind 5: robust.cc:47-54)
         Image image;
         image.camera = camera;
         st = estimate_absolute_pose(x1, X, opt, &image, &inliers);
@@ -79,6 +82,18 @@ int main(int argc, char **argv) {
             model.push_back(pose.q(i));
         for (int i = 0; i < 3; ++i)
             model.push_back(pose.t(i));
+    } else if (kind == 4) { // two views sharing one unknown focal length (robust.h:84-90); principal point = camera params 1, 2
+        RelativePoseOptions opt;
+        opt.ransac = ransac;
+        opt.max_error = max_error;
+        ImagePair pair;
+        st = estimate_shared_focal_relative_pose(x1, x2d, Point2D(cam_params[1], cam_params[2]), opt, &pair, &inliers);
+        for (int i = 0; i < 4; ++i)
+            model.push_back(pair.pose.q(i));
+        for (int i = 0; i < 3; ++i)
+            model.push_back(pair.pose.t(i));
+        for (size_t i = 0; i < pair.camera1.params.size() && i < 12; ++i)
+            cam_out[i] = pair.camera1.params[i];
     } else if (kind == 2) {
         RelativePoseOptions opt;
         opt.ransac = ransac;

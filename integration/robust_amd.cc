@@ -1,7 +1,7 @@
 // Reference-side binding of poselib_amd: the file a PoseLib maintainer would add to the PoseLib tree (e.g. as
 // PoseLib/robust_amd.cc, compiled INSTEAD of robust.cc / robust/ransac.cc for the four estimators below).  It
-// defines the reference's own entry points (PoseLib/robust.h:45-46, 68-70, 112-113, 133-134; robust/ransac.h:39-40,
-// 60-61, 85-87, 99-101; solvers/p3p.h:42, relpose_5pt.h:40) by forwarding to the C-ABI of include/poselib_amd.h.
+// defines the reference's own entry points (PoseLib/robust.h:45-46, 68-70, 84-90, 112-113, 133-134; robust/ransac.h:39-40,
+// 52-54, 60-61, 71-73, 85-87, 99-101; solvers/p3p.h:42, relpose_5pt.h:40) by forwarding to the C-ABI of include/poselib_amd.h.
 // std::vector<Eigen::Vector2d/3d> is contiguous AoS doubles - exactly the layout the C-ABI takes - and
 // Eigen::Matrix3d::data() is column-major like the double[9] arguments, so only options and the camera are copied.
 //
@@ -70,6 +70,20 @@ pl_camera to_pl(const Camera &c) {
     return cam;
 }
 
+// The SIMPLE_PINHOLE camera {f, cx, cy} the focal-length estimators return (fields set directly: nothing of camera_models.cc is
+// needed to link this file)
+void set_simple_pinhole(Camera *c, double f, double cx, double cy) {
+    c->model_id = SimplePinholeCameraModel::model_id;
+    c->width = c->height = -1;
+    c->params = {f, cx, cy};
+}
+// Camera::focal() of a camera these entry points can receive
+double focal_of(const Camera &c) {
+    if (c.params.empty())
+        return 1.0;
+    return c.model_id == SimplePinholeCameraModel::model_id ? c.params[0] : 0.5 * (c.params[0] + c.params[1]);
+}
+
 pl_camera_pose to_pl(const CameraPose &p) {
     pl_camera_pose q;
     for (int i = 0; i < 4; ++i)
@@ -105,7 +119,7 @@ const double *raw(const std::vector<Point3D> &v) { return v.empty() ? nullptr : 
 RansacStats estimate_absolute_pose(const std::vector<Point2D> &points2D, const std::vector<Point3D> &points3D,
                                    AbsolutePoseOptions opt, Image *image, std::vector<char> *inliers) {
     pl_robust_options o = to_pl(0, opt.ransac, opt.bundle, opt.max_error);
-    o.estimate_focal_length = opt.estimate_focal_length; // -> PL_ERR_UNSUPPORTED (focal-length branches are CPU)
+    o.estimate_focal_length = opt.estimate_focal_length; // robust.cc:47-54: ransac_pnpf on the device since round 3
     o.estimate_extra_params = opt.estimate_extra_params;
     pl_camera cam = to_pl(image->camera);
     pl_camera_pose pose = to_pl(image->pose);
@@ -128,6 +142,24 @@ RansacStats estimate_relative_pose(const std::vector<Point2D> &points2D_1, const
     check(pl_estimate_relative_pose(raw(points2D_1), raw(points2D_2), points2D_1.size(), &c1, &c2, &o, &pose,
                                     mask_of(inliers, points2D_1.size()), &st));
     from_pl(pose, relative_pose);
+    return from_pl(st);
+}
+
+// robust.h:84-90
+RansacStats estimate_shared_focal_relative_pose(const std::vector<Point2D> &points2D_1, const std::vector<Point2D> &points2D_2,
+                                                const Point2D &pp, const RelativePoseOptions &opt, ImagePair *image_pair,
+                                                std::vector<char> *inliers) {
+    pl_robust_options o = to_pl(1, opt.ransac, opt.bundle, opt.max_error);
+    o.tangent_sampson = opt.tangent_sampson; // -> PL_ERR_UNSUPPORTED
+    pl_camera_pose pose = to_pl(image_pair->pose);
+    double focal = focal_of(image_pair->camera1); // read with ransac.score_initial_model only (robust.cc:392-397)
+    const double pp2[2] = {pp(0), pp(1)};
+    pl_ransac_stats st;
+    check(pl_estimate_shared_focal_relative_pose(raw(points2D_1), raw(points2D_2), points2D_1.size(), pp2, &o, &pose, &focal,
+                                                 mask_of(inliers, points2D_1.size()), &st));
+    from_pl(pose, &image_pair->pose);
+    set_simple_pinhole(&image_pair->camera1, focal, pp(0), pp(1)); // :417-421
+    image_pair->camera2 = image_pair->camera1;
     return from_pl(st);
 }
 
@@ -158,6 +190,33 @@ RansacStats ransac_pnp(const std::vector<Point2D> &x, const std::vector<Point3D>
     pl_ransac_stats st;
     check(pl_ransac_pnp(raw(x), raw(X), x.size(), &o, &pose, mask_of(best_inliers, x.size()), &st));
     from_pl(pose, best_model);
+    return from_pl(st);
+}
+
+// ransac.h:52-54
+RansacStats ransac_pnpf(const std::vector<Point2D> &x, const std::vector<Point3D> &X, const AbsolutePoseOptions &opt, Image *best_model,
+                        std::vector<char> *best_inliers) {
+    const pl_robust_options o = to_pl(0, opt.ransac, opt.bundle, opt.max_error);
+    pl_camera_pose pose = to_pl(best_model->pose);
+    double focal = 1.0;
+    pl_ransac_stats st;
+    check(pl_ransac_pnpf(raw(x), raw(X), x.size(), &o, &pose, &focal, mask_of(best_inliers, x.size()), &st));
+    from_pl(pose, &best_model->pose);
+    set_simple_pinhole(&best_model->camera, focal, 0.0, 0.0);
+    return from_pl(st);
+}
+
+// ransac.h:71-73
+RansacStats ransac_shared_focal_relpose(const std::vector<Point2D> &x1, const std::vector<Point2D> &x2, const RelativePoseOptions &opt,
+                                        ImagePair *best_model, std::vector<char> *best_inliers) {
+    const pl_robust_options o = to_pl(1, opt.ransac, opt.bundle, opt.max_error);
+    pl_camera_pose pose = to_pl(best_model->pose);
+    double focal = focal_of(best_model->camera1);
+    pl_ransac_stats st;
+    check(pl_ransac_shared_focal_relpose(raw(x1), raw(x2), x1.size(), &o, &pose, &focal, mask_of(best_inliers, x1.size()), &st));
+    from_pl(pose, &best_model->pose);
+    set_simple_pinhole(&best_model->camera1, focal, 0.0, 0.0);
+    best_model->camera2 = best_model->camera1;
     return from_pl(st);
 }
 

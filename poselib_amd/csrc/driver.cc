@@ -122,7 +122,7 @@ struct Context {
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
     HostBuf h_rec_meta;
     HostBuf h_absmax, h_positions, h_num_models, h_count, h_score, h_tasks, h_gather_idx, h_gather_out, h_mask,
-        h_small;
+        h_small, h_models;
     HostBuf h_flag;        // completion flag of wait_stream(): the stream writes a sequence number, the host spins on it
     uint32_t flag_seq = 0;
 };

@@ -3,24 +3,28 @@
 //   k_focal_generate   one lane = one RANSAC iteration: draw the sample of four correspondences from the iteration's position in
 //                      the splitmix64 stream, solve P3.5Pf (pl_solver_p35pf.h), keep the solutions the estimator keeps
 //                      (focal >= 0, focal <= max_focal_length: absolute_pose.cc:89-95).  The 29 x 35 elimination matrices live in
-//                      a workspace in HBM, element-major (consecutive lanes = consecutive doubles).
+//                      LDS, element-major, 16 samples per workgroup (one workgroup per CU) - in HBM (first version: 5.5 ms per
+//                      batch of 4096 samples) every step of the elimination paid the memory latency.
 //   k_focal_score      one wavefront = one model: compute_msac_score(Image, ...) (utils.cc:66-98) - inlier count and the sum of
 //                      the inliers' squared residuals IN CORRESPONDENCE ORDER (the score decides comparisons in the loop, so
 //                      it has to be the sequential sum): the lanes evaluate 64 correspondences at a time, the inliers' residuals
 //                      are then added one by one in lane order (wave-uniform loop over the ballot).
 //   k_focal_mask       get_inliers(Image, ...) (utils.cc:385-399), one thread per correspondence.
-// A first, correct device path for this estimator: neither kernel is tuned (no pre-filter, no LDS staging; the generator keeps
-// its matrices in HBM), DESIGN §4 has the measured numbers and what bounds them.
+// A first, correct device path for this estimator: neither kernel is tuned (no pre-filter, one lane per sample), DESIGN §4 has the measured numbers and what bounds them.
 #include "pl_focal.h"
 #include "pl_kernels.h"
 #include "pl_solver_p35pf.h"
+#include <atomic>
 
 namespace pl {
 
 namespace {
 
+// kGenLanes samples per workgroup: their elimination matrices (8.1 KB each) fill the CU's LDS
+constexpr int kGenLanes = 16;
 __global__ __launch_bounds__(64) void k_focal_generate(FocalGenArgs g) {
-    const uint32_t it = blockIdx.x * 64u + threadIdx.x;
+    extern __shared__ double s_work[]; // kP35WorkDoubles x kGenLanes, element-major
+    const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
     if (it >= g.num_iters)
         return;
     uint32_t idx[kFocalSample];
@@ -33,7 +37,7 @@ __global__ __launch_bounds__(64) void k_focal_generate(FocalGenArgs g) {
         X[k] = v3(g.a[2][idx[k]], g.a[3][idx[k]], g.a[4][idx[k]]);
     }
     P35Solution sol[kFocalMaxModels];
-    const int n = p35pf(xs, X, P35Work{g.work + it, (size_t)g.work_stride}, sol);
+    const int n = p35pf(xs, X, P35Work{s_work + threadIdx.x, (size_t)kGenLanes}, sol);
     uint32_t m = 0;
     for (int i = 0; i < n; ++i) {
         if (sol[i].focal < 0)
@@ -101,7 +105,16 @@ __global__ void k_focal_mask(const double *x, const double *y, const double *X, 
 hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
         return hipSuccess;
-    k_focal_generate<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
+    constexpr size_t bytes = sizeof(double) * kP35WorkDoubles * kGenLanes; // 129.9 KB of the CU's 160 KB
+    static std::atomic<int> prepared{0};
+    if (!prepared.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_focal_generate),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess)
+            return e;
+        prepared.store(1, std::memory_order_release);
+    }
+    k_focal_generate<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
     return hipGetLastError();
 }
 hipError_t launch_focal_score(const FocalScoreArgs &a, hipStream_t stream) {

@@ -300,8 +300,6 @@ struct FocalGenArgs {
     double max_focal;     // < 0: no bound
     FocalModel *models;   // [num_iters * kFocalMaxModels]
     uint32_t *num_models; // [num_iters]
-    double *work;         // kP35WorkDoubles * work_stride doubles
-    uint32_t work_stride; // >= num_iters
 };
 struct FocalScoreArgs {
     const double *a[5];

@@ -117,18 +117,31 @@ PL_HD bool sfocal_row(const SFocalCtx &c, const Loss &loss, double a0, double a1
         row[2 + k] = J[k];
     return true;
 }
-// entry e of [lower triangle row-major (21) | Jtr (6)]: JtJ(i, j) += w (J_i J_j), Jtr(i) += (w r) J_i
+// entry e of [lower triangle row-major (21) | Jtr (6)]: JtJ(i, j) += w (J_i J_j), Jtr(i) += (w r) J_i - one shape for both kinds
+// (term = (tri ? w : 1) * (row[a] row[b]); 1.0 x is exact, the product commutes), so that the consumer loop of k_sfocal_lm is free
+// of branches and of index arithmetic
 constexpr int kSFocalEntries = 27;
-PL_HD double sfocal_entry_term(const double *row, int e) {
+struct SFocalEntry {
+    int a, b;
+    bool tri;
+};
+PL_HD SFocalEntry sfocal_entry_of(int e) {
+    SFocalEntry en;
     if (e < 21) {
         int i = 0;
         while ((i + 1) * (i + 2) / 2 <= e)
             ++i;
-        const int j = e - i * (i + 1) / 2;
-        return row[0] * (row[2 + i] * row[2 + j]);
+        en.a = 2 + i, en.b = 2 + (e - i * (i + 1) / 2), en.tri = true;
+    } else {
+        en.a = 1, en.b = 2 + (e - 21), en.tri = false;
     }
-    return row[1] * row[2 + (e - 21)];
+    return en;
 }
+PL_HD double sfocal_entry_term(const double *row, const SFocalEntry &en) {
+    const double t = row[en.a] * row[en.b];
+    return (en.tri ? row[0] : 1.0) * t;
+}
+PL_HD double sfocal_entry_term(const double *row, int e) { return sfocal_entry_term(row, sfocal_entry_of(e)); }
 
 // ---- the loop: score_model is the plain MSAC score of the Sampson error (relative_pose.cc:164-171) - the back end returns it
 // whole (inliers' residuals and the outliers' thresholds added in correspondence order, utils.cc:226-236) ----
@@ -146,8 +159,8 @@ struct SFocalGenArgs {
     uint32_t num_iters;
     FocalModel *models;   // [num_iters * kSFocalMaxModels]
     uint32_t *num_models; // [num_iters]
-    double *work;         // kSixWorkDoubles * work_stride doubles
-    uint32_t work_stride; // >= num_iters
+    FocalModel *host_models;   // optional mirrors in pinned host memory (same layout): only the models found are written
+    uint32_t *host_num_models;
 };
 struct SFocalScoreArgs {
     const double *a[4];

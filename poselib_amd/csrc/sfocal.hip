@@ -3,8 +3,9 @@
 //
 //   k_sfocal_generate  one lane = one RANSAC iteration: the sample of six correspondences from the iteration's position in the
 //                      splitmix64 stream, unit bearings, the 6-point solver (pl_solver_6ptf.h).  The solver's matrices
-//                      (kSixWorkDoubles per sample) live in a workspace in HBM, element-major (consecutive lanes = consecutive
-//                      doubles).
+//                      (kSixWorkDoubles = 8.6 KB per sample) live in LDS, element-major: 16 samples per workgroup fill a CU's
+//                      160 KB, one workgroup per CU - the solver is a chain of dependent accesses to those matrices, and in HBM
+//                      (first version: 10.4 ms per batch of 4096 samples) every step paid the memory latency.
 //   k_sfocal_score     one wavefront = one model: compute_sampson_msac_score (utils.cc:204-239) of F = K_inv (E K_inv) - inlier
 //                      count and the score IN CORRESPONDENCE ORDER (r2 of an inlier, the threshold of an outlier, one after the
 //                      other: the score decides comparisons in the loop, so it has to be the sequential sum).  The lanes evaluate
@@ -13,20 +14,24 @@
 //   k_sfocal_lm        one workgroup = one refinement, the whole Levenberg-Marquardt loop on the device: refine_model's
 //                      pre-filter (Sampson error below 5 thr^2, nothing to do when <= 6 survive), then cost and normal equations
 //                      summed correspondence after correspondence - rounds of 256 rows in LDS, lane e < 27 owns entry e of
-//                      [JtJ | Jtr] (k_lm_cam's scheme; rows without contribution are zero rows: x + 0.0 = x) - so that the refined
+//                      [JtJ | Jtr] (k_lm_cam's scheme: rows without contribution are dropped by a ballot + prefix compaction that keeps the order) - so that the refined
 //                      model equals the oracle's to the bit for every n.
 // A first, correct device path for this estimator (like focal.hip): none of the kernels is tuned; DESIGN 4 has the numbers.
 #include "pl_kernels.h"
 #include "pl_device.h"
 #include "pl_sfocal.h"
 #include "pl_solver_6ptf.h"
+#include <atomic>
 
 namespace pl {
 
 namespace {
 
+// kGenLanes samples per workgroup: their solver workspaces (8.6 KB each) fill the CU's LDS
+constexpr int kGenLanes = 16;
 __global__ __launch_bounds__(64) void k_sfocal_generate(SFocalGenArgs g) {
-    const uint32_t it = blockIdx.x * 64u + threadIdx.x;
+    extern __shared__ double s_work[]; // kSixWorkDoubles x kGenLanes, element-major
+    const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
     if (it >= g.num_iters)
         return;
     uint32_t idx[kSFocalSample];
@@ -38,14 +43,19 @@ __global__ __launch_bounds__(64) void k_sfocal_generate(SFocalGenArgs g) {
     }
     uint32_t m = 0;
     FocalModel *out = g.models + (size_t)it * kSFocalMaxModels;
-    relpose_6pt_shared_focal(x1, x2, SixWork{g.work + it, (size_t)g.work_stride}, [&](Quat q, Vec3 t, double f) {
-        FocalModel &o = out[m];
+    relpose_6pt_shared_focal(x1, x2, SixWork{s_work + threadIdx.x, (size_t)kGenLanes}, [&](Quat q, Vec3 t, double f) {
+        FocalModel o;
         o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
         o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
         o.f = f;
+        out[m] = o;
+        if (g.host_models)
+            g.host_models[(size_t)it * kSFocalMaxModels + m] = o;
         ++m;
     });
     g.num_models[it] = m;
+    if (g.host_num_models)
+        g.host_num_models[it] = m;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-uniform
@@ -186,6 +196,25 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
     }
     __syncthreads();
 
+    // rows of a round are compacted in ascending order (ballot + prefix over the waves): the sums below run over the
+    // correspondences that contribute, one after the other, as the reference adds them
+    auto compact_slot = [&](bool kept, uint32_t &round_rows) -> uint32_t {
+        const uint64_t b = __builtin_amdgcn_ballot_w64(kept);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        if (lane == 0)
+            s_wcnt[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t off = 0;
+        round_rows = 0;
+#pragma unroll
+        for (int w = 0; w < kSfLMWaves; ++w) {
+            const uint32_t c = s_wcnt[w];
+            off += (w < wave) ? c : 0u;
+            round_rows += c;
+        }
+        return off + below;
+    };
+
     // robust cost at p -> s_racc, s_count
     auto cost_pass = [&](const double *p) {
         if (threadIdx.x == 0)
@@ -193,19 +222,21 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
         __syncthreads();
         const Loss loss = ctl.loss;
         double racc = 0.0; // (thread 0)
-        uint32_t mine = 0;
+        uint32_t total = 0;
         for (uint32_t base = 0; base < n; base += kSfLMThreads) {
             const uint32_t i = base + threadIdx.x;
             double term = 0.0;
-            if (i < n && !(mask && !mask[i])) {
+            const bool kept = i < n && !(mask && !mask[i]);
+            if (kept) {
                 const double r = sfocal_residual(ctx, x1[i], y1[i], x2[i], y2[i]);
                 term = 1.0 * loss_value(loss, r * r);
-                mine++;
             }
-            s_rows[threadIdx.x] = term; // (x + 0.0 = x for the correspondences that are not part of the problem)
+            uint32_t rows;
+            const uint32_t slot = compact_slot(kept, rows);
+            if (kept)
+                s_rows[slot] = term;
             __syncthreads();
             if (threadIdx.x == 0) {
-                const uint32_t rows = min((uint32_t)kSfLMThreads, n - base);
                 uint32_t q = 0;
                 for (; q + 8u <= rows; q += 8u) { // (reads together, additions in order)
                     double t8[8];
@@ -219,9 +250,9 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
                 for (; q < rows; ++q)
                     racc += s_rows[q];
             }
+            total += rows;
             __syncthreads();
         }
-        const uint32_t total = block_count(mine);
         if (threadIdx.x == 0) {
             s_racc = racc;
             s_count = total;
@@ -230,6 +261,7 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
     };
 
     // normal equations at p -> normal[0 .. 27), s_count.  p's tangent basis is refreshed first (relative.h:513).
+    const SFocalEntry entry = sfocal_entry_of(min((int)threadIdx.x, kSFocalEntries - 1));
     auto jacobian_pass = [&](double *p) {
         if (threadIdx.x == 0) {
             Refiner<EST_REL>::prepare_params(p);
@@ -238,39 +270,40 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
         __syncthreads();
         const Loss loss = ctl.loss;
         double acc = 0.0;
-        uint32_t mine = 0;
+        uint32_t total = 0;
         for (uint32_t base = 0; base < n; base += kSfLMThreads) {
             const uint32_t i = base + threadIdx.x;
             double row[kSFocalRow];
-#pragma unroll
-            for (int k = 0; k < kSFocalRow; ++k)
-                row[k] = 0.0;
+            bool kept = false;
             if (i < n && !(mask && !mask[i]))
-                mine += sfocal_row(ctx, loss, x1[i], y1[i], x2[i], y2[i], row) ? 1u : 0u;
-            double *dst = s_rows + (size_t)threadIdx.x * kSFocalRow;
+                kept = sfocal_row(ctx, loss, x1[i], y1[i], x2[i], y2[i], row);
+            uint32_t rows;
+            const uint32_t slot = compact_slot(kept, rows);
+            if (kept) {
+                double *dst = s_rows + (size_t)slot * kSFocalRow;
 #pragma unroll
-            for (int k = 0; k < kSFocalRow; ++k)
-                dst[k] = row[k];
+                for (int k = 0; k < kSFocalRow; ++k)
+                    dst[k] = row[k];
+            }
             __syncthreads();
             if ((int)threadIdx.x < kSFocalEntries) {
-                const uint32_t rows = min((uint32_t)kSfLMThreads, n - base);
                 const double *r = s_rows;
                 uint32_t q = 0;
                 for (; q + 8u <= rows; q += 8u, r += 8 * kSFocalRow) {
                     double t[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        t[u] = sfocal_entry_term(r + u * kSFocalRow, (int)threadIdx.x);
+                        t[u] = sfocal_entry_term(r + u * kSFocalRow, entry);
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
                         acc += t[u];
                 }
                 for (; q < rows; ++q, r += kSFocalRow)
-                    acc += sfocal_entry_term(r, (int)threadIdx.x);
+                    acc += sfocal_entry_term(r, entry);
             }
+            total += rows;
             __syncthreads();
         }
-        const uint32_t total = block_count(mine);
         if ((int)threadIdx.x < kSFocalEntries)
             normal[threadIdx.x] = acc;
         if (threadIdx.x == 0)
@@ -320,7 +353,16 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
 hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
         return hipSuccess;
-    k_sfocal_generate<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
+    constexpr size_t bytes = sizeof(double) * kSixWorkDoubles * kGenLanes; // 137.6 KB of the CU's 160 KB
+    static std::atomic<int> prepared{0};
+    if (!prepared.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_generate),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess)
+            return e;
+        prepared.store(1, std::memory_order_release);
+    }
+    k_sfocal_generate<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
     return hipGetLastError();
 }
 hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream) {

@@ -48,7 +48,7 @@ def test_check_program_builds():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5])
 def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_path, kind):
     """A program written against the REFERENCE'S C++ API (std::vector<Eigen::Vector2d>, Image, Camera, CameraPose,
     *Options; robust.h:45-46, 68-70, 112-113, 133-134) and linked with integration/robust_amd.cc runs on the GPU and
@@ -59,23 +59,30 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
 
     assert os.path.exists(CHECK_BIN), "integration/_build/robust_amd_check was not built (python __graft_entry__.py)"
     seed = 3 + kind
-    if kind == 0:
+    if kind in (0, 5):
         d = synth.absolute_pose_scene(1500, 0.4, 4100)
         a, b, cam = d["p2d"], d["p3d"], d["camera"]
+        if kind == 5:  # estimate_focal_length: the camera's focal length is 20 % off, the estimator must not care
+            cam = dict(cam, params=[1.2 * cam["params"][0]] + list(cam["params"][1:]))
     else:
-        gen = {1: synth.relative_pose_scene, 2: synth.fundamental_scene, 3: synth.homography_scene}[kind]
+        gen = {1: synth.relative_pose_scene, 2: synth.fundamental_scene, 3: synth.homography_scene, 4: synth.relative_pose_scene}[kind]
         d = gen(1500, 0.4, 4100 + kind)
         a, b = d["x1"], d["x2"]
         cam = d.get("camera1", {"model": "SIMPLE_PINHOLE", "params": [1000.0, 500.0, 500.0]})
-    max_error = 12.0 if kind == 0 else 1.0
+    max_error = 12.0 if kind in (0, 5) else 1.0
     opt = {"max_error": max_error, "ransac": {"seed": seed}}
-    if kind == 0:
+    if kind in (0, 5):
+        if kind == 5:
+            opt["estimate_focal_length"] = True
         img, info = gpu.estimate_absolute_pose(a, b, cam, opt)
         model = np.r_[img.pose.q, img.pose.t]
         cam_out = list(img.camera.params)
     elif kind == 1:
         pose, info = gpu.estimate_relative_pose(a, b, cam, cam, opt)
         model, cam_out = np.r_[pose.q, pose.t], []
+    elif kind == 4:
+        pair, info = gpu.estimate_shared_focal_relative_pose(a, b, cam["params"][1:3], opt)
+        model, cam_out = np.r_[pair.pose.q, pair.pose.t], list(pair.camera1.params)
     elif kind == 2:
         F, info = gpu.estimate_fundamental(a, b, opt)
         model, cam_out = F.T.reshape(-1), []  # column-major like Eigen::Matrix3d::data()
@@ -96,7 +103,9 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
     assert out[0] == info["iterations"] and out[1] == info["refinements"] and out[2] == info["num_inliers"]
     assert out[3] == info["model_score"]
     assert np.array_equal(out[4:4 + nm], model)  # bit for bit
-    if kind == 0:
+    if kind in (0, 4, 5):
         assert np.array_equal(out[4 + nm:4 + nm + len(cam_out)], np.array(cam_out))
+    if kind == 4:
+        assert abs(cam_out[0] - cam["params"][0]) < 1e-2 * cam["params"][0]
     assert np.array_equal(out[4 + nm + 12:].astype(bool), np.array(info["inliers"]))
     assert info["num_inliers"] > 500
