@@ -627,6 +627,69 @@ def run_undistort_stage(args, ranks, P, synth):
     return rep, ok
 
 
+def run_focal_estimators(args, ranks, P, synth):
+    """the two focal-length estimators through their front-ends - estimate_absolute_pose with
+    estimate_focal_length (ransac_pnpf, P3.5Pf) and estimate_shared_focal_relative_pose (6-point shared-focal solver) - on
+    2000 correspondences, 40 % outliers, one problem after the other (a first device path: no problems in flight, no
+    grouping).  Host-resident inputs, PCIe-inclusive.  Parity: every problem of the step against the oracle (decisions, mask,
+    focal length bit for bit); CPU baseline: the oracle on the same problems (its solvers are this project's own formulations)."""
+    n, reps = 2000, max(4, args.steps)
+    da = [synth.absolute_pose_scene(n, 0.4, 7100 + 8 * ranks.rank + k) for k in range(4)]
+    dr = [synth.relative_pose_scene(n, 0.4, 7000 + 8 * ranks.rank + k) for k in range(4)]
+    oa = lambda s: {"max_error": 4.0, "estimate_focal_length": True, "ransac": {"seed": s}}
+    orl = lambda s: {"max_error": 2.0, "ransac": {"seed": s}}
+    pp = lambda d: d["camera1"]["params"][1:3]
+
+    def run_abs(j):
+        d = da[j % 4]
+        return P.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], oa(j))
+
+    def run_rel(j):
+        d = dr[j % 4]
+        return P.estimate_shared_focal_relative_pose(d["x1"], d["x2"], pp(d), orl(j))
+
+    rep, ok = {}, True
+    for name, run in (("pnpf_2000", run_abs), ("shared_focal_2000", run_rel)):
+        for j in range(2):
+            run(j)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        outs = [run(j) for j in range(reps)]
+        ranks.barrier()
+        elapsed = time.perf_counter() - t0
+        table = ranks.gather([elapsed, float(sum(o[1]["hypotheses"] for o in outs))])
+        if ranks.rank != 0:
+            continue
+        t_max = float(table[:, 0].max())
+        r = {"problems_per_s": ranks.world * reps / t_max, "ms_per_problem": 1e3 * t_max / reps,
+             "hyp_per_s": float(table[:, 1].sum()) / t_max, "problems": reps, "correspondences": n}
+        if not args.no_parity:
+            import oracle_lib as O
+
+            good, t_cpu = 0, 0.0
+            for j, (model, info) in enumerate(outs):
+                t1 = time.perf_counter()
+                if name == "pnpf_2000":
+                    d = da[j % 4]
+                    pose, mask, st, cam = O.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], oa(j), return_camera=True)
+                    # (k_lm_cam sums its cost in order up to 256 correspondences, as a tree beyond: model to 1e-9, decisions exact)
+                    same = abs(cam[0] - model.camera.params[0]) <= 1e-9 * cam[0] and np.abs(pose - np.r_[model.pose.q, model.pose.t]).max() < 1e-9
+                else:
+                    d = dr[j % 4]
+                    pose, focal, mask, st = O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], pp(d), orl(j))
+                    same = focal == model.camera1.params[0] and np.array_equal(pose, np.r_[model.pose.q, model.pose.t])
+                t_cpu += time.perf_counter() - t1
+                good += bool(same and st["iterations"] == info["iterations"] and st["refinements"] == info["refinements"]
+                             and np.array_equal(mask, np.asarray(info["inliers"], dtype=bool)))
+            r["parity"] = {"problems": reps, "identical": good, "ok": good == reps,
+                           "what": "iterations, refinements and inlier mask equal the oracle's; pose and focal length bit for bit "
+                                   "(shared focal) / to 1e-9 (pnpf: tree-summed LM cost above 256 correspondences)"}
+            r["cpu_port_problems_per_s"] = reps / t_cpu
+            ok = ok and good == reps
+        rep[name] = r
+    return (rep if ranks.rank == 0 else None), ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -695,6 +758,12 @@ def main():
             reports["opencv_undistort"] = rep
             names = names + ["opencv_undistort"]
             all_ok = all_ok and ok
+    focal_rep = None
+    if not args.no_secondary and not args.shard_problem:
+        focal_rep, ok = run_focal_estimators(args, ranks, P, synth)
+        if ranks.rank == 0:
+            reports["focal_estimators"] = focal_rep
+            all_ok = all_ok and ok
     if args.batch_problems > 0 and not args.no_secondary and not args.shard_problem:
         rep, ok = run_batch_mixed(args, ranks, P, synth)
         if ranks.rank == 0:
@@ -738,6 +807,12 @@ def main():
                 cfg["batch_mixed_parity_ok"] = r.get("parity", {}).get("ok")
                 if "cpu_baseline" in r:
                     cfg["batch_mixed_cpu_" + r["cpu_baseline"]["kind"] + "_problems_per_s"] = r["cpu_baseline"]["value"]
+        for n, r in (focal_rep or {}).items():
+            cfg[n + "_problems_per_s"] = r["problems_per_s"]
+            cfg[n + "_ms_per_problem"] = r["ms_per_problem"]
+            cfg[n + "_parity_ok"] = r.get("parity", {}).get("ok")
+            if "cpu_port_problems_per_s" in r:
+                cfg[n + "_cpu_port_problems_per_s"] = r["cpu_port_problems_per_s"]
         short = lambda d, drop: {k: v for k, v in d.items() if k not in drop}
         out = {
             "metric": "scored RANSAC hypotheses/sec (P3P@5k corrs, 5pt@5k corrs)",

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
+import ref_lib  # noqa: E402
 import poselib_amd as P  # noqa: E402
 from poselib_amd import synth  # noqa: E402
 
@@ -30,7 +31,13 @@ def main():
         ref = O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], dict(opt, ransac={"seed": reps}))
         t_cpu = time.perf_counter() - t0
         ok = info["iterations"] == ref[3]["iterations"] and pair.camera1.params[0] == ref[1]
-        print(f"shared_focal n={n}: device {1e3 * t_dev:.2f} ms/problem, oracle {1e3 * t_cpu:.2f} ms, iterations {info['iterations']}, "
+        t_ref = float("nan")
+        if ref_lib.available():
+            t0 = time.perf_counter()
+            with ref_lib.reference():
+                O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], dict(opt, ransac={"seed": reps}))
+            t_ref = time.perf_counter() - t0
+        print(f"shared_focal n={n}: device {1e3 * t_dev:.2f} ms/problem, oracle {1e3 * t_cpu:.2f} ms, reference sources {1e3 * t_ref:.2f} ms, iterations {info['iterations']}, "
               f"evaluated {info['iterations_evaluated']}, parity {ok}")
         d = synth.absolute_pose_scene(n, 0.4, 7100 + n)
         opt = {"max_error": 4.0, "estimate_focal_length": True, "ransac": {"seed": 1}}
@@ -42,7 +49,13 @@ def main():
         t0 = time.perf_counter()
         pose, mask, st, cam = O.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], dict(opt, ransac={"seed": reps}), return_camera=True)
         t_cpu = time.perf_counter() - t0
-        print(f"pnpf n={n}: device {1e3 * t_dev:.2f} ms/problem, oracle {1e3 * t_cpu:.2f} ms, iterations {info['iterations']}, "
+        t_ref = float("nan")
+        if ref_lib.available():
+            t0 = time.perf_counter()
+            with ref_lib.reference():
+                O.estimate_absolute_pose(d["p2d"], d["p3d"], d["camera"], dict(opt, ransac={"seed": reps}))
+            t_ref = time.perf_counter() - t0
+        print(f"pnpf n={n}: device {1e3 * t_dev:.2f} ms/problem, oracle {1e3 * t_cpu:.2f} ms, reference sources {1e3 * t_ref:.2f} ms, iterations {info['iterations']}, "
               f"evaluated {info['iterations_evaluated']}, parity {info['iterations'] == st['iterations']}")
 
 
