@@ -657,11 +657,22 @@ def run_focal_estimators(args, ranks, P, synth):
         outs = [run(j) for j in range(reps)]
         ranks.barrier()
         elapsed = time.perf_counter() - t0
-        table = ranks.gather([elapsed, float(sum(o[1]["hypotheses"] for o in outs))])
+        # the same problems from 8 host threads (one HIP stream and context each): what a caller's thread pool gets
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(8) as pool:
+            list(pool.map(run, range(8)))  # (every thread's context exists)
+            ranks.barrier()
+            t0 = time.perf_counter()
+            outs8 = list(pool.map(run, range(4 * reps)))
+            ranks.barrier()
+            elapsed8 = time.perf_counter() - t0
+        table = ranks.gather([elapsed, float(sum(o[1]["hypotheses"] for o in outs)), elapsed8])
         if ranks.rank != 0:
             continue
         t_max = float(table[:, 0].max())
         r = {"problems_per_s": ranks.world * reps / t_max, "ms_per_problem": 1e3 * t_max / reps,
+             "problems_per_s_8_threads": ranks.world * 4 * reps / float(table[:, 2].max()),
              "hyp_per_s": float(table[:, 1].sum()) / t_max, "problems": reps, "correspondences": n}
         if not args.no_parity:
             import oracle_lib as O
@@ -810,6 +821,7 @@ def main():
         for n, r in (focal_rep or {}).items():
             cfg[n + "_problems_per_s"] = r["problems_per_s"]
             cfg[n + "_ms_per_problem"] = r["ms_per_problem"]
+            cfg[n + "_problems_per_s_8_threads"] = r["problems_per_s_8_threads"]
             cfg[n + "_parity_ok"] = r.get("parity", {}).get("ok")
             if "cpu_port_problems_per_s" in r:
                 cfg[n + "_cpu_port_problems_per_s"] = r["cpu_port_problems_per_s"]

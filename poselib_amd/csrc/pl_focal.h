@@ -200,6 +200,11 @@ int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalM
         const uint64_t it0 = st.iterations;
         const uint64_t horizon = std::max(o.min_iterations, dyn_max) + 1;
         uint64_t want = horizon > it0 ? horizon - it0 : 1;
+        // no model has bounded the run yet (dyn_max is still the iteration limit): evaluate up to the earliest possible stop,
+        // then double - a typical run ends at min_iterations + 1, and a batch that is four times that only occupies the device
+        // (the decisions do not depend on how the iterations are cut into batches)
+        if (dyn_max >= o.max_iterations)
+            want = std::min<uint64_t>(want, std::max<uint64_t>(o.min_iterations + 1 > it0 ? o.min_iterations + 1 - it0 : 0, it0));
         want = std::min<uint64_t>(std::max<uint64_t>(want, 256), 4096);
         const uint32_t B = (uint32_t)std::min<uint64_t>(want, o.max_iterations - it0);
         positions.resize(B);

@@ -26,7 +26,7 @@ def main(path):
         gy = r[ix["grid_y"]] if "grid_y" in ix else 1
         wy = r[ix["workgroup_y"]] if "workgroup_y" in ix else 1
         blocks = (gx // max(wx, 1)) * (gy // max(wy, 1))
-        short = name.split("(")[0].replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         key = (short, "full batch" if blocks >= 512 else "small") if "k_score" in short or "k_lm" in short else (short, "")
         groups.setdefault(key, []).append((dur, blocks, r[ix["vgpr_count"]] if "vgpr_count" in ix else None,
                                            r[ix["sgpr_count"]] if "sgpr_count" in ix else None,
