@@ -196,6 +196,10 @@ int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalM
     uint64_t pos = 0;
     bool stopped = false;
     while (!stopped && st.iterations < o.max_iterations) {
+        // ransac_impl.h:109-111 at the head of the next iteration: the run may be over exactly at a batch boundary - do not
+        // evaluate another batch to find that out
+        if (st.iterations > o.min_iterations && st.iterations > dyn_max)
+            break;
         // the loop cannot stop before iteration max(min_iterations, dyn_max) + 1
         const uint64_t it0 = st.iterations;
         const uint64_t horizon = std::max(o.min_iterations, dyn_max) + 1;
