@@ -730,6 +730,9 @@ int relpose_6pt_shared_focal(const V3 x1[6], const V3 x2[6], Pose out[60], doubl
     std::memcpy(Cw, C, sizeof(C));
     if (!sixpt_companion(Cw, T))
         return 0;
+    for (int e = 0; e < 225; ++e)
+        if (!std::isfinite(T[e]))
+            return 0; // (a vanishing pivot: the balancing below would not terminate on an infinite entry)
     balance_pow2(T, 15);
     const int nroots = real_eigenvalues(T, 15, ev, 1e-8);
     struct Sol {

@@ -311,6 +311,9 @@ template <class Emit> PL_HD int relpose_6pt_shared_focal(const Vec3 *x1, const V
         Cw[e] = C[e];
     if (!six_companion(Cw, T, A, B))
         return 0;
+    for (int e = 0; e < 225; ++e)
+        if (!isfinite(T[e]))
+            return 0; // (a vanishing pivot: the balancing below would not terminate on an infinite entry)
     pl_balance_pow2<15>(T);
     double ev[15];
     const int nroots = pl_real_eigenvalues<15>(T, ev, 1e-8);

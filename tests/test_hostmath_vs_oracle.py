@@ -363,3 +363,40 @@ def test_ransac_shared_focal_loop_of_the_product_takes_the_oracles_decisions():
     ph, fh, mh, sh = HM.ransac_shared_focal(a, b, max_error=2.0 / 500, seed=9, max_iterations=1500, init_pose=init, init_focal=1.1 * f / 500)
     assert np.array_equal(po, ph) and fo == fh and np.array_equal(mo, mh)
     assert (so["iterations"], so["refinements"], so["model_score"]) == (sh["iterations"], sh["refinements"], sh["model_score"])
+
+
+def test_six_point_shared_focal_degenerate_and_hostile_inputs_terminate_and_agree():
+    """planar scene, pure rotation, identical views, repeated / collinear correspondences, zero / NaN / huge / tiny bearings and
+    random garbage: the device header and the oracle return the same models (usually none) - and RETURN (the eigenvalue
+    iteration gives up after 60 sweeps, the balancing is not entered with a non-finite matrix: a hang on the device is a lost GPU)"""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(5)
+
+    def unit(b):
+        return b / np.linalg.norm(b, axis=1)[:, None]
+
+    R = Rotation.from_rotvec([0.1, -0.2, 0.05]).as_matrix()
+    X = np.c_[rng.uniform(-1, 1, (6, 2)), np.full(6, 4.0)]
+    X2 = X @ R.T + [0.3, 0.1, 0.05]
+    planar = (unit(np.c_[X[:, :2] / X[:, 2:], np.ones(6)]), unit(np.c_[X2[:, :2] / X2[:, 2:], np.ones(6)]))
+    Y = rng.uniform(-1, 1, (6, 3)) + [0, 0, 4]
+    Y2 = Y @ R.T
+    rep1, rep2 = planar[0].copy(), planar[1].copy()
+    rep1[5], rep2[5] = rep1[0], rep2[0]
+    line = np.c_[np.linspace(-0.5, 0.5, 6), np.zeros(6), np.ones(6)]
+    h = unit(rng.normal(size=(6, 3)))
+    cases = [planar, (unit(np.c_[Y[:, :2] / Y[:, 2:], np.ones(6)]), unit(np.c_[Y2[:, :2] / Y2[:, 2:], np.ones(6)])), (planar[0], planar[0]),
+             (rep1, rep2), (unit(line), unit(line + [0.01, 0, 0])), (np.zeros((6, 3)), np.zeros((6, 3))),
+             (np.full((6, 3), np.nan), np.full((6, 3), np.nan)), (h * 1e200, h * 1e200), (h * 1e-200, unit(rng.normal(size=(6, 3))) * 1e-200),
+             (np.tile([[0, 0, 1.0]], (6, 1)), np.tile([[0, 0, 1.0]], (6, 1)))]
+    for k in range(400):  # garbage of every magnitude, some entries infinite or NaN
+        a = rng.normal(size=(6, 3)) * 10.0 ** rng.integers(-300, 300, size=(6, 3))
+        b = rng.normal(size=(6, 3)) * 10.0 ** rng.integers(-30, 30, size=(6, 3))
+        if k % 7 == 0:
+            a[rng.integers(6), rng.integers(3)] = [np.inf, -np.inf, np.nan][k % 3]
+        cases.append((a, b))
+    with np.errstate(all="ignore"):
+        for i, (b1, b2) in enumerate(cases):
+            po, fo = O.relpose_6pt_shared_focal(b1, b2)
+            ph, fh = HM.relpose_6pt_shared_focal(b1, b2, stride=1 + i % 2)
+            assert po.shape == ph.shape and np.array_equal(po, ph, equal_nan=True) and np.array_equal(fo, fh, equal_nan=True), i
