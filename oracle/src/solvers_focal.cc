@@ -585,7 +585,8 @@ static void sixpt_equations(const double *nb, double C[3][100]) {
 // Parlett-Reinsch balancing (EISPACK balanc without the permutation step): similarity scaling by powers of two until the row and
 // column 1-norms of every index are within a factor of two - exact in floating point, eigenvalues unchanged
 static void balance_pow2(double *a, int n) {
-    for (bool done = false; !done;) {
+    bool done = false;
+    for (int sweep = 0; sweep < 64 && !done; ++sweep) { // (typically 3 - 6 sweeps; the cap bounds the loop on overflowing input)
         done = true;
         for (int i = 0; i < n; ++i) {
             double c = 0, r = 0;

@@ -254,7 +254,8 @@ PL_HD bool six_companion(const SixWork &Cw, const SixWork &T, const SixWork &A, 
 
 // Parlett-Reinsch balancing without the permutation step: similarity scaling by powers of two (exact)
 template <int n, class Arr> PL_HD void pl_balance_pow2(Arr a) {
-    for (bool done = false; !done;) {
+    bool done = false;
+    for (int sweep = 0; sweep < 64 && !done; ++sweep) { // (typically 3 - 6 sweeps; the cap bounds the loop on overflowing input)
         done = true;
         for (int i = 0; i < n; ++i) {
             double c = 0, r = 0;

@@ -115,3 +115,39 @@ def test_shared_focal_rejections(gpu):
         gpu.ransac_shared_focal_relpose(a, b, {"max_error": 0.01, "ransac": {"progressive_sampling": True}})
     with pytest.raises(gpu.PoseLibAmdError):
         gpu.ransac_shared_focal_relpose(a, b, {"max_error": 0.01, "tangent_sampson": True})
+
+
+def test_front_end_with_an_initial_pair_and_minimal_inputs(gpu):
+    """robust.cc:392-397: with score_initial_model the pair's focal length is divided by the normalisation scale before the
+    RANSAC and the initial model competes; 6, 7 and 10 correspondences (a sample is 6)"""
+    d = synth.relative_pose_scene(800, 0.3, 9300, noise_px=0.6)
+    f, cx, cy = d["camera1"]["params"]
+    init = gpu.ImagePair(gpu.CameraPose(d["q_gt"], d["t_gt"]), gpu.Camera("SIMPLE_PINHOLE", [1.1 * f, cx, cy]))
+    ro = {"seed": 21, "max_iterations": 1500}
+    ref = O.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], {"max_error": 2.0, "ransac": dict(ro, score_initial_model=True)},
+                                                init_pose=np.r_[d["q_gt"], d["t_gt"]], init_focal=1.1 * f)
+    pair, info = gpu.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], {"max_error": 2.0, "ransac": ro}, initial_pair=init)
+    _check("front initial", pair, info, ref)
+    for n in (6, 7, 10):
+        opt = {"max_error": 2.0, "ransac": {"seed": n, "max_iterations": 300, "min_iterations": 20}}
+        pair, info = gpu.estimate_shared_focal_relative_pose(d["x1"][:n], d["x2"][:n], [cx, cy], opt)
+        _check(("front", n), pair, info, O.estimate_shared_focal_relative_pose(d["x1"][:n], d["x2"][:n], [cx, cy], opt))
+
+
+def test_hostile_inputs_return(gpu):
+    """NaN / infinite coordinates, every correspondence the same point, a planar scene: the calls return (bounded loops everywhere:
+    a hang would cost the GPU) and take the oracle's decisions"""
+    d = synth.relative_pose_scene(300, 0.2, 9400)
+    f, cx, cy = d["camera1"]["params"]
+    a, b = (np.asarray(d["x1"]) - [cx, cy]) / 500.0, (np.asarray(d["x2"]) - [cx, cy]) / 500.0
+    opt = {"max_error": 0.004, "ransac": {"seed": 2, "max_iterations": 400, "min_iterations": 50}}
+    hostile = {"nan": (np.where(np.arange(300)[:, None] % 7 == 0, np.nan, a), b), "inf": (a, np.where(np.arange(300)[:, None] % 11 == 0, np.inf, b)),
+               "one point": (np.tile(a[:1], (300, 1)), np.tile(b[:1], (300, 1))), "identical views": (a, a)}
+    h = synth.homography_scene(300, 0.1, 9401)
+    hostile["planar"] = ((np.asarray(h["x1"]) - 500.0) / 500.0, (np.asarray(h["x2"]) - 500.0) / 500.0)
+    with np.errstate(all="ignore"):
+        for name, (x1, x2) in hostile.items():
+            pair, info = gpu.ransac_shared_focal_relpose(x1, x2, opt)
+            ref = O.ransac_shared_focal_relpose(x1, x2, opt)
+            assert info["iterations"] == ref[3]["iterations"] and info["num_inliers"] == ref[3]["num_inliers"], (name, info["iterations"], ref[3])
+            assert np.array_equal(np.asarray(info["inliers"], dtype=bool), ref[2]), name
