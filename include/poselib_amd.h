@@ -147,15 +147,17 @@ int pl_undistort_points(const pl_camera *camera, const double *points2D, size_t 
  * calling thread selected with pl_set_device().  The reference has no such call: a PoseLib user loops over
  * estimate_*() (robust.h) from a thread pool, the Python wrappers release the GIL for that purpose. */
 typedef struct {
-    int32_t kind;            /* 0 absolute pose, 1 relative pose, 2 fundamental, 3 homography */
+    int32_t kind;            /* 0 absolute pose, 1 relative pose, 2 fundamental, 3 homography, 4 relative pose with a shared
+                              * unknown focal length (pl_estimate_shared_focal_relative_pose; served by the pool one problem at a time,
+                              * like kind-0 items with estimate_focal_length) */
     int32_t status;          /* out: PL_OK or the error of this item */
     const double *a;         /* points2D (kind 0) / points2D_1: N x 2 */
     const double *b;         /* points3D: N x 3 (kind 0) / points2D_2: N x 2 */
     size_t n;
     const pl_robust_options *opt;
-    pl_camera *camera1;      /* kind 0: in/out camera; kind 1: first camera; otherwise NULL */
+    pl_camera *camera1;      /* kind 0: in/out camera; kind 1: first camera; kind 4: SIMPLE_PINHOLE {focal, cx, cy} in/out; otherwise NULL */
     const pl_camera *camera2; /* kind 1: second camera; otherwise NULL */
-    void *model;             /* in/out: pl_camera_pose (kinds 0, 1) or double[9] column-major (kinds 2, 3) */
+    void *model;             /* in/out: pl_camera_pose (kinds 0, 1, 4) or double[9] column-major (kinds 2, 3) */
     uint8_t *inliers;        /* n bytes */
     pl_ransac_stats *stats;
 } pl_batch_item;

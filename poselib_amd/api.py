@@ -28,6 +28,7 @@ LOSS_TYPES = {"TRIVIAL": 0, "TRUNCATED": 1, "HUBER": 2, "CAUCHY": 3, "TRUNCATED_
 CAMERA_MODEL_IDS = {"NULL": -1, "SIMPLE_PINHOLE": 0, "PINHOLE": 1, "OPENCV": 4}
 _CAMERA_NAMES = {v: k for k, v in CAMERA_MODEL_IDS.items()}
 KIND_ABS, KIND_REL, KIND_FUND, KIND_HOM = 0, 1, 2, 3
+KIND_SHARED_FOCAL = 4  # pl_batch_item only: estimate_shared_focal_relative_pose
 
 
 # ------------------------------------------------------------------------------------------ types
@@ -252,7 +253,7 @@ class Batch:
     single-problem functions return."""
 
     def __init__(self, problems):
-        kinds = {"abs": KIND_ABS, "rel": KIND_REL, "fund": KIND_FUND, "hom": KIND_HOM}
+        kinds = {"abs": KIND_ABS, "rel": KIND_REL, "fund": KIND_FUND, "hom": KIND_HOM, "shared_focal": KIND_SHARED_FOCAL}
         self.items = (L.BatchItem * len(problems))()
         self.keep = []
         for it, pr in zip(self.items, problems):
@@ -270,12 +271,18 @@ class Batch:
                 cam = None
                 c1, c2 = _as_camera(cam1)._c(), _as_camera(cam2)._c()
                 model = _cpose(CameraPose())
+            elif kind == KIND_SHARED_FOCAL:
+                _, a, b, pp, opt = pr
+                a, b = _pts(a, 2), _pts(b, 2)
+                cam = Camera("SIMPLE_PINHOLE", [1.0, float(pp[0]), float(pp[1])])
+                c1, c2 = cam._c(), None
+                model = _cpose(CameraPose())
             else:
                 _, a, b, opt = pr
                 a, b = _pts(a, 2), _pts(b, 2)
                 cam, c1, c2 = None, None, None
                 model = np.ascontiguousarray(np.eye(3).reshape(9))
-            o = _robust_options(opt, kind, False)
+            o = _robust_options(opt, KIND_REL if kind == KIND_SHARED_FOCAL else kind, False)
             n = a.shape[0]
             inl = np.zeros(max(n, 1), dtype=np.uint8)
             st = L.RansacStats()
@@ -283,7 +290,7 @@ class Batch:
             it.opt = C.pointer(o)
             it.camera1 = C.pointer(c1) if c1 is not None else None
             it.camera2 = C.pointer(c2) if c2 is not None else None
-            it.model = C.cast(C.pointer(model), C.c_void_p) if kind in (KIND_ABS, KIND_REL) else _ptr(model)
+            it.model = C.cast(C.pointer(model), C.c_void_p) if kind in (KIND_ABS, KIND_REL, KIND_SHARED_FOCAL) else _ptr(model)
             it.inliers = _ptr(inl)
             it.stats = C.pointer(st)
             self.keep.append((kind, a, b, o, cam, c1, c2, model, inl, st, n))
@@ -307,6 +314,8 @@ class Batch:
                 out.append((Image(_pypose(model), out_cam), info))
             elif kind == KIND_REL:
                 out.append((_pypose(model), info))
+            elif kind == KIND_SHARED_FOCAL:
+                out.append((_shared_focal_pair(model, c1.params[0], (c1.params[1], c1.params[2])), info))
             else:
                 out.append((model.reshape(3, 3).T.copy(), info))
         return out
@@ -319,6 +328,7 @@ def estimate_batch(problems, max_in_flight=8):
         ("abs", points2D, points3D, camera, opt)            -> (Image, info)
         ("rel", points2D_1, points2D_2, camera1, camera2, opt) -> (CameraPose, info)
         ("fund", points2D_1, points2D_2, opt) / ("hom", points2D_1, points2D_2, opt) -> (3x3 ndarray, info)
+        ("shared_focal", points2D_1, points2D_2, pp, opt)   -> (ImagePair, info)
     Returns the list of results in the same order.  Problems of the same kind advance in groups through ONE launch
     sequence (the problem index is a grid dimension of every kernel); `max_in_flight` host threads inside the library
     work on groups concurrently, each with its own HIP stream."""

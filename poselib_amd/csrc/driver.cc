@@ -2880,8 +2880,15 @@ int run_item(pl_batch_item &it) {
         return pl_estimate_fundamental(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
     case EST_HOM:
         return pl_estimate_homography(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
+    case 4: { // two views sharing one unknown focal length: camera1 = SIMPLE_PINHOLE {focal, cx, cy}, in (principal point; focal
+              // length with ransac.score_initial_model) and out (both cameras of the reference's ImagePair)
+        if (!it.camera1 || it.camera1->model_id != CAM_SIMPLE_PINHOLE || it.camera1->num_params < 3)
+            return fail(PL_ERR_INVALID, "pl_batch_item kind 4 needs camera1 = SIMPLE_PINHOLE {focal, cx, cy}");
+        return pl_estimate_shared_focal_relative_pose(it.a, it.b, it.n, it.camera1->params + 1, it.opt,
+                                                      static_cast<pl_camera_pose *>(it.model), &it.camera1->params[0], it.inliers, it.stats);
+    }
     default:
-        return fail(PL_ERR_INVALID, "pl_batch_item.kind must be 0..3");
+        return fail(PL_ERR_INVALID, "pl_batch_item.kind must be 0..4");
     }
 }
 

@@ -151,3 +151,32 @@ def test_hostile_inputs_return(gpu):
             ref = O.ransac_shared_focal_relpose(x1, x2, opt)
             assert info["iterations"] == ref[3]["iterations"] and info["num_inliers"] == ref[3]["num_inliers"], (name, info["iterations"], ref[3])
             assert np.array_equal(np.asarray(info["inliers"], dtype=bool), ref[2]), name
+
+
+def test_batched_front_end_serves_both_focal_estimators(gpu):
+    """pl_estimate_batch: shared-focal pairs (item kind 4) and absolute-pose items with estimate_focal_length next to ordinary
+    items - every result equals the single-problem call's bit for bit (they are served by the pool one problem at a time)"""
+    probs, singles = [], []
+    for k in range(6):
+        d = synth.relative_pose_scene(400 + 100 * k, 0.3, 9500 + k)
+        f, cx, cy = d["camera1"]["params"]
+        opt = {"max_error": 2.0, "ransac": {"seed": k}}
+        probs.append(("shared_focal", d["x1"], d["x2"], [cx, cy], opt))
+        singles.append(gpu.estimate_shared_focal_relative_pose(d["x1"], d["x2"], [cx, cy], opt))
+        da = synth.absolute_pose_scene(300 + 100 * k, 0.3, 9600 + k)
+        oa = {"max_error": 4.0, "estimate_focal_length": True, "ransac": {"seed": k}}
+        probs.append(("abs", da["p2d"], da["p3d"], da["camera"], oa))
+        singles.append(gpu.estimate_absolute_pose(da["p2d"], da["p3d"], da["camera"], oa))
+        probs.append(("rel", d["x1"], d["x2"], d["camera1"], d["camera2"], {"max_error": 2.0, "ransac": {"seed": k}}))
+        singles.append(gpu.estimate_relative_pose(d["x1"], d["x2"], d["camera1"], d["camera2"], {"max_error": 2.0, "ransac": {"seed": k}}))
+    out = gpu.estimate_batch(probs, max_in_flight=4)
+    for (model, info), (smodel, sinfo), pr in zip(out, singles, probs):
+        for key in ("iterations", "refinements", "num_inliers", "model_score", "inliers"):
+            assert info[key] == sinfo[key], (pr[0], key)
+        if pr[0] == "shared_focal":
+            assert np.array_equal(np.r_[model.pose.q, model.pose.t], np.r_[smodel.pose.q, smodel.pose.t])
+            assert model.camera1.params == smodel.camera1.params and model.camera2.params == smodel.camera2.params
+        elif pr[0] == "abs":
+            assert np.array_equal(np.r_[model.pose.q, model.pose.t], np.r_[smodel.pose.q, smodel.pose.t]) and model.camera.params == smodel.camera.params
+        else:
+            assert np.array_equal(np.r_[model.q, model.t], np.r_[smodel.q, smodel.t])
