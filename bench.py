@@ -727,8 +727,9 @@ def main():
                          "ranks (pl_ransac_run_sharded, one all-gather per batch); default is independent problems per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle runs (profiling)")
-    ap.add_argument("--batch-problems", type=int, default=2048,
-                    help="configs[4] leg: problems per GPU and step of the mixed default-options batch (0: skip)")
+    ap.add_argument("--batch-problems", type=int, default=4096,
+                    help="configs[4] leg (\"batch of 4096 independent image pairs\"): problems per GPU and step of the mixed "
+                         "default-options batch (0: skip)")
     ap.add_argument("--batch-threads", type=int, default=8, help="host threads inside pl_estimate_batch")
     ap.add_argument("--detail-file", default="", help="complete per-workload reports (default gpurun_out/bench_detail.json)")
     ap.add_argument("--rehearse-distributed", action="store_true",
