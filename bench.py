@@ -696,6 +696,18 @@ def run_focal_estimators(args, ranks, P, synth):
                            "what": "iterations, refinements and inlier mask equal the oracle's; pose and focal length bit for bit "
                                    "(shared focal) / to 1e-9 (pnpf: tree-summed LM cost above 256 correspondences)"}
             r["cpu_port_problems_per_s"] = reps / t_cpu
+            if ranks.world == 1 and not args.no_cpu_baseline:  # the reference's own sources (oracle/_ref: generated solver templates), four problems
+                import ref_lib
+
+                if ref_lib.available():
+                    t1 = time.perf_counter()
+                    with ref_lib.reference():
+                        for j in range(4):
+                            if name == "pnpf_2000":
+                                O.estimate_absolute_pose(da[j % 4]["p2d"], da[j % 4]["p3d"], da[j % 4]["camera"], oa(j))
+                            else:
+                                O.estimate_shared_focal_relative_pose(dr[j % 4]["x1"], dr[j % 4]["x2"], pp(dr[j % 4]), orl(j))
+                    r["cpu_reference_problems_per_s"] = 4 / (time.perf_counter() - t1)
             ok = ok and good == reps
         rep[name] = r
     return (rep if ranks.rank == 0 else None), ok
@@ -826,6 +838,8 @@ def main():
             cfg[n + "_parity_ok"] = r.get("parity", {}).get("ok")
             if "cpu_port_problems_per_s" in r:
                 cfg[n + "_cpu_port_problems_per_s"] = r["cpu_port_problems_per_s"]
+            if "cpu_reference_problems_per_s" in r:
+                cfg[n + "_cpu_reference_problems_per_s"] = r["cpu_reference_problems_per_s"]
         short = lambda d, drop: {k: v for k, v in d.items() if k not in drop}
         out = {
             "metric": "scored RANSAC hypotheses/sec (P3P@5k corrs, 5pt@5k corrs)",

@@ -400,3 +400,22 @@ def test_six_point_shared_focal_degenerate_and_hostile_inputs_terminate_and_agre
             po, fo = O.relpose_6pt_shared_focal(b1, b2)
             ph, fh = HM.relpose_6pt_shared_focal(b1, b2, stride=1 + i % 2)
             assert po.shape == ph.shape and np.array_equal(po, ph, equal_nan=True) and np.array_equal(fo, fh, equal_nan=True), i
+
+
+def test_p35pf_hostile_inputs_terminate_and_agree():
+    """garbage of every magnitude, infinite / NaN coordinates, four equal 3-D points, image points at the origin: the device
+    header and the oracle return the same (usually no) solutions - and return"""
+    rng = np.random.default_rng(9)
+    with np.errstate(all="ignore"):
+        for k in range(600):
+            x = rng.normal(size=(4, 2)) * 10.0 ** rng.integers(-200, 200, size=(4, 2))
+            X = rng.normal(size=(4, 3)) * 10.0 ** rng.integers(-30, 30, size=(4, 3))
+            if k % 5 == 0:
+                X[rng.integers(4), rng.integers(3)] = [np.inf, -np.inf, np.nan][k % 3]
+            if k % 9 == 0:
+                X[:] = X[0]
+            if k % 11 == 0:
+                x[:] = 0
+            po, fo = O.p35pf(x, X)
+            ph, fh = HM.p35pf(x, X, stride=1 + k % 3)
+            assert po.shape == ph.shape and np.array_equal(po, ph, equal_nan=True) and np.array_equal(fo, fh, equal_nan=True), k
