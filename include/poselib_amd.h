@@ -272,6 +272,15 @@ int pl_relpose_5pt(const double *x1 /* 5x3 */, const double *x2 /* 5x3 */, pl_ca
 int pl_essential_matrix_5pt(const double *x1, const double *x2, double *E /* 10 x 9 column-major */);
 int pl_relpose_7pt(const double *x1 /* 7x3 */, const double *x2 /* 7x3 */, double *F /* 3 x 9 column-major */);
 int pl_homography_4pt(const double *x1 /* 4x3 */, const double *x2 /* 4x3 */, double *H /* 9 column-major */);
+/* the solvers of the two focal-length estimators (interfaces of solvers/p35pf.h:39-54 and solvers/relpose_6pt_focal.h:12-13; the
+ * algorithms are this library's own formulations).  pl_p35pf: x = four image points relative to the principal point
+ * (4 x 2; of the fourth only x is used), X = 4 x 3; out / focals: room for 10.  pl_relpose_6pt_shared_focal: six pairs of unit
+ * bearings (6 x 3 each); out / focals: room for 60, in the reference's order.  Return = #solutions or < 0. */
+int pl_p35pf(const double *x, const double *X, pl_camera_pose *out, double *focals);
+int pl_relpose_6pt_shared_focal(const double *x1, const double *x2, pl_camera_pose *out, double *focals);
+/* batched: kind 0 = P3.5Pf (in: count x [x 4 x 2 | X 4 x 3]; 10 slots), kind 1 = 6-point shared focal (in: count x [x1 6 x 3 |
+ * x2 6 x 3]; 60 slots); out_models: count x slots x 8 doubles (q[4] t[3] focal), out_counts: count. */
+int pl_solve_focal_batch(int kind, const double *in, size_t count, double *out_models, uint32_t *out_counts);
 /* batched form: `count` independent minimal problems, one GPU lane each.
  * in: count x (2*K*3) doubles ([first set K x 3][second set K x 3]); out_models: count x max_models x 24 doubles
  * (model records of 24 doubles: q[4] t[3] M[9 row-major] + 8 doubles of internal fp32 shadow, see

@@ -132,6 +132,9 @@ def _declare(L):
         "pl_ransac_pnpf": (cint, [vp, vp, sz, opt, pose, P(dbl), vp, stats]),
         "pl_ransac_relpose": (cint, [vp, vp, sz, opt, pose, vp, stats]),
         "pl_ransac_shared_focal_relpose": (cint, [vp, vp, sz, opt, pose, P(dbl), vp, stats]),
+        "pl_solve_focal_batch": (cint, [cint, vp, sz, vp, vp]),
+        "pl_p35pf": (cint, [vp, vp, vp, vp]),
+        "pl_relpose_6pt_shared_focal": (cint, [vp, vp, vp, vp]),
         "pl_refine_shared_focal_relpose": (cint, [vp, vp, sz, P(BundleOptions), pose, P(dbl), P(C.c_uint32)]),
         "pl_estimate_shared_focal_relative_pose": (cint, [vp, vp, sz, vp, opt, pose, P(dbl), vp, stats]),
         "pl_ransac_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
@@ -174,5 +177,5 @@ EXPORTED_SYMBOLS = [
     "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_bundle_adjust_camera", "pl_p3p", "pl_relpose_5pt",
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
     "pl_ransac_batch", "pl_debug_device_math", "pl_ransac_pnpf", "pl_ransac_shared_focal_relpose", "pl_refine_shared_focal_relpose",
-    "pl_estimate_shared_focal_relative_pose",
+    "pl_estimate_shared_focal_relative_pose", "pl_solve_focal_batch", "pl_p35pf", "pl_relpose_6pt_shared_focal",
 ]

@@ -493,6 +493,32 @@ def refine_shared_focal_relpose(x1, x2, pair, bundle=None):
     return _shared_focal_pair(pose, focal.value, (0.0, 0.0)), its.value
 
 
+def solve_focal_batch(kind, inputs):
+    """pl_solve_focal_batch: kind "p35pf" (inputs count x 20: x 4 x 2 | X 4 x 3) or "relpose_6pt_shared_focal" (count x 36: unit
+    bearings x1 6 x 3 | x2 6 x 3).  Returns (models count x slots x 8 [q t focal], counts)."""
+    k = {"p35pf": 0, "relpose_6pt_shared_focal": 1}[kind]
+    a = np.ascontiguousarray(inputs, dtype=np.float64)
+    per, slots = (20, 10) if k == 0 else (36, 60)
+    if a.ndim != 2 or a.shape[1] != per:
+        raise ValueError(f"expected a (count, {per}) array")
+    models = np.zeros((a.shape[0], slots, 8))
+    counts = np.zeros(max(a.shape[0], 1), dtype=np.uint32)
+    L.check(L.lib().pl_solve_focal_batch(C.c_int(k), _ptr(a), C.c_size_t(a.shape[0]), _ptr(models), _ptr(counts)))
+    return models, counts[: a.shape[0]]
+
+
+def p35pf(x, X):
+    """solvers/p35pf.h:39-54: four image points relative to the principal point and their 3-D points -> [(CameraPose, focal)]"""
+    models, counts = solve_focal_batch("p35pf", np.r_[_pts(x, 2).reshape(-1), _pts(X, 3).reshape(-1)][None, :])
+    return [(CameraPose(m[:4], m[4:7]), float(m[7])) for m in models[0, : counts[0]]]
+
+
+def relpose_6pt_shared_focal(x1, x2):
+    """solvers/relpose_6pt_focal.h:12-13: six pairs of unit bearings -> [(CameraPose, focal)] in the reference's order"""
+    models, counts = solve_focal_batch("relpose_6pt_shared_focal", np.r_[_pts(x1, 3).reshape(-1), _pts(x2, 3).reshape(-1)][None, :])
+    return [(CameraPose(m[:4], m[4:7]), float(m[7])) for m in models[0, : counts[0]]]
+
+
 def ransac_relpose(x1, x2, opt=None, initial_pose=None):
     return _ransac("pl_ransac_relpose", KIND_REL, x1, x2, 2, opt, initial_pose)
 

@@ -2715,6 +2715,63 @@ int pl_solve_batch(int kind, const double *in, size_t count, double *out_models,
     return PL_OK;
 }
 
+// the two focal-length solvers: kind 0 P3.5Pf (in: x 4 x 2, X 4 x 3 per problem; <= 10 models), kind 1 the 6-point shared-focal
+// solver (in: x1 6 x 3, x2 6 x 3 unit bearings per problem; <= 60 models); out_models: 8 doubles (q, t, focal) per slot
+int pl_solve_focal_batch(int kind, const double *in, size_t count, double *out_models, uint32_t *out_counts) {
+    if (kind < 0 || kind > 1)
+        return fail(PL_ERR_INVALID, "unknown focal solver kind");
+    if ((!in || !out_models || !out_counts) && count)
+        return fail(PL_ERR_INVALID, "null argument");
+    Context *c;
+    int rc = get_context(&c);
+    if (rc != PL_OK)
+        return rc;
+    if (count == 0)
+        return PL_OK;
+    if (count > 0x7fffffffu / 64u)
+        return fail(PL_ERR_INVALID, "too many problems");
+    const size_t per_in = kind == 0 ? 20 : 36, slots = kind == 0 ? (size_t)kFocalMaxModels : (size_t)kSFocalMaxModels;
+    const size_t in_bytes = sizeof(double) * per_in * count, out_bytes = sizeof(FocalModel) * slots * count;
+    HIP_TRY(c->solve_in.ensure(in_bytes));
+    HIP_TRY(c->solve_out.ensure(out_bytes));
+    HIP_TRY(c->solve_cnt.ensure(sizeof(uint32_t) * count));
+    HIP_TRY(hipMemcpyAsync(c->solve_in.p, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->solve_out.p, 0, out_bytes, c->stream));
+    if (kind == 0)
+        HIP_TRY(launch_focal_solve(c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<FocalModel>(), c->solve_cnt.as<uint32_t>(), c->stream));
+    else
+        HIP_TRY(launch_sfocal_solve(c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<FocalModel>(), c->solve_cnt.as<uint32_t>(), c->stream));
+    HIP_TRY(hipMemcpyAsync(out_models, c->solve_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_counts, c->solve_cnt.p, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(wait_stream(c));
+    return PL_OK;
+}
+static int focal_solve_one(int kind, const double *a, size_t na, const double *b, size_t nb, pl_camera_pose *out, double *focals) {
+    if (!a || !b || !out || !focals)
+        return fail(PL_ERR_INVALID, "null argument");
+    std::vector<double> in(na + nb);
+    std::memcpy(in.data(), a, sizeof(double) * na);
+    std::memcpy(in.data() + na, b, sizeof(double) * nb);
+    const size_t slots = kind == 0 ? (size_t)kFocalMaxModels : (size_t)kSFocalMaxModels;
+    std::vector<double> models(8 * slots);
+    uint32_t n = 0;
+    int rc = pl_solve_focal_batch(kind, in.data(), 1, models.data(), &n);
+    if (rc != PL_OK)
+        return rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 4; ++k)
+            out[i].q[k] = models[8 * i + k];
+        for (int k = 0; k < 3; ++k)
+            out[i].t[k] = models[8 * i + 4 + k];
+        focals[i] = models[8 * i + 7];
+    }
+    return (int)n;
+}
+int pl_p35pf(const double *x, const double *X, pl_camera_pose *out, double *focals) { return focal_solve_one(0, x, 8, X, 12, out, focals); }
+int pl_relpose_6pt_shared_focal(const double *x1, const double *x2, pl_camera_pose *out, double *focals) {
+    return focal_solve_one(1, x1, 18, x2, 18, out, focals);
+}
+
 static int solve_one(int kind, const double *a, const double *b, double *records, uint32_t *cnt) {
     const int K = sample_size(kind);
     std::vector<double> in(6 * K);

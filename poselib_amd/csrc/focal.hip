@@ -53,6 +53,30 @@ __global__ __launch_bounds__(64) void k_focal_generate(FocalGenArgs g) {
     g.num_models[it] = m;
 }
 
+// minimal problems given explicitly (pl_p35pf, pl_solve_focal_batch): in = count x [x 4 x 2 | X 4 x 3]; every solution is kept
+__global__ __launch_bounds__(64) void k_focal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models) {
+    extern __shared__ double s_work[];
+    const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
+    if (it >= count)
+        return;
+    const double *p = in + (size_t)it * 20;
+    double xs[8];
+    Vec3 X[4];
+    for (int k = 0; k < 8; ++k)
+        xs[k] = p[k];
+    for (int k = 0; k < 4; ++k)
+        X[k] = v3(p[8 + 3 * k], p[9 + 3 * k], p[10 + 3 * k]);
+    P35Solution sol[kFocalMaxModels];
+    const int n = p35pf(xs, X, P35Work{s_work + threadIdx.x, (size_t)kGenLanes}, sol);
+    for (int i = 0; i < n; ++i) {
+        FocalModel &o = models[(size_t)it * kFocalMaxModels + i];
+        o.q[0] = sol[i].q.w, o.q[1] = sol[i].q.x, o.q[2] = sol[i].q.y, o.q[3] = sol[i].q.z;
+        o.t[0] = sol[i].t.x, o.t[1] = sol[i].t.y, o.t[2] = sol[i].t.z;
+        o.f = sol[i].focal;
+    }
+    num_models[it] = (uint32_t)n;
+}
+
 constexpr int kFocalScoreThreads = 256;
 
 __global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score(FocalScoreArgs a) {
@@ -115,6 +139,21 @@ hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
         prepared.store(1, std::memory_order_release);
     }
     k_focal_generate<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
+    return hipGetLastError();
+}
+hipError_t launch_focal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, hipStream_t stream) {
+    if (count == 0)
+        return hipSuccess;
+    constexpr size_t bytes = sizeof(double) * kP35WorkDoubles * kGenLanes;
+    static std::atomic<int> prepared{0};
+    if (!prepared.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_focal_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bytes);
+        if (e != hipSuccess)
+            return e;
+        prepared.store(1, std::memory_order_release);
+    }
+    k_focal_solve<<<dim3((count + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(in, count, models, num_models);
     return hipGetLastError();
 }
 hipError_t launch_focal_score(const FocalScoreArgs &a, hipStream_t stream) {

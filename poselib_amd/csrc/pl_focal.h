@@ -324,6 +324,7 @@ struct FocalScoreArgs {
 #if defined(__HIPCC__)
 hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream);
 hipError_t launch_focal_score(const FocalScoreArgs &a, hipStream_t stream);
+hipError_t launch_focal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, hipStream_t stream);
 hipError_t launch_focal_mask(const double *const *a, uint32_t n, const FocalModel &m, double thr2, uint8_t *mask, uint8_t *host_mask,
                              hipStream_t stream);
 #endif

@@ -188,6 +188,7 @@ struct SFocalLMTask {
 #if defined(__HIPCC__)
 hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream);
 hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream);
+hipError_t launch_sfocal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, hipStream_t stream);
 hipError_t launch_sfocal_mask(const double *const *a, uint32_t n, const FocalModel &m, double thr2, uint8_t *mask, uint8_t *host_mask,
                               hipStream_t stream);
 hipError_t launch_sfocal_lm(SFocalLMTask *tasks, uint32_t num_tasks, hipStream_t stream);

@@ -58,6 +58,30 @@ __global__ __launch_bounds__(64) void k_sfocal_generate(SFocalGenArgs g) {
         g.host_num_models[it] = m;
 }
 
+// minimal problems given explicitly (pl_relpose_6pt_shared_focal, pl_solve_focal_batch): in = count x [x1 6 x 3 | x2 6 x 3]
+__global__ __launch_bounds__(64) void k_sfocal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models) {
+    extern __shared__ double s_work[];
+    const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
+    if (it >= count)
+        return;
+    const double *p = in + (size_t)it * 36;
+    Vec3 x1[6], x2[6];
+    for (int k = 0; k < 6; ++k) {
+        x1[k] = v3(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+        x2[k] = v3(p[18 + 3 * k], p[19 + 3 * k], p[20 + 3 * k]);
+    }
+    uint32_t m = 0;
+    FocalModel *out = models + (size_t)it * kSFocalMaxModels;
+    relpose_6pt_shared_focal(x1, x2, SixWork{s_work + threadIdx.x, (size_t)kGenLanes}, [&](Quat q, Vec3 t, double f) {
+        FocalModel o;
+        o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
+        o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
+        o.f = f;
+        out[m++] = o;
+    });
+    num_models[it] = m;
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -363,6 +387,21 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
         prepared.store(1, std::memory_order_release);
     }
     k_sfocal_generate<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
+    return hipGetLastError();
+}
+hipError_t launch_sfocal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, hipStream_t stream) {
+    if (count == 0)
+        return hipSuccess;
+    constexpr size_t bytes = sizeof(double) * kSixWorkDoubles * kGenLanes;
+    static std::atomic<int> prepared{0};
+    if (!prepared.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bytes);
+        if (e != hipSuccess)
+            return e;
+        prepared.store(1, std::memory_order_release);
+    }
+    k_sfocal_solve<<<dim3((count + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(in, count, models, num_models);
     return hipGetLastError();
 }
 hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream) {

@@ -180,3 +180,63 @@ def test_batched_front_end_serves_both_focal_estimators(gpu):
             assert np.array_equal(np.r_[model.pose.q, model.pose.t], np.r_[smodel.pose.q, smodel.pose.t]) and model.camera.params == smodel.camera.params
         else:
             assert np.array_equal(np.r_[model.q, model.t], np.r_[smodel.q, smodel.t])
+
+
+def test_both_focal_solvers_on_the_device_equal_the_oracle_bit_for_bit(gpu):
+    """pl_solve_focal_batch / pl_p35pf / pl_relpose_6pt_shared_focal: the generator kernels' solvers on explicit minimal problems -
+    every pose, every focal length and their order equal the oracle's (which is pinned against the reference's solvers); the golden
+    solver vectors included"""
+    import json
+    import os
+
+    from golden.make_golden_focal import minimal_inputs
+
+    rng = np.random.default_rng(17)
+    # 6-point: random two-view geometry at normalised focal lengths
+    from scipy.spatial.transform import Rotation
+
+    six = []
+    for _ in range(600):
+        f = rng.uniform(0.3, 3.0)
+        X = rng.uniform(-1, 1, (6, 3)) * [2, 2, 1] + [0, 0, 5]
+        R = Rotation.from_rotvec(rng.normal(size=3) * 0.2).as_matrix()
+        t = rng.normal(size=3)
+        X2 = X @ R.T + t / np.linalg.norm(t)
+        b1 = np.c_[f * X[:, :2] / X[:, 2:], np.ones(6)]
+        b2 = np.c_[f * X2[:, :2] / X2[:, 2:], np.ones(6)]
+        six.append(np.r_[(b1 / np.linalg.norm(b1, axis=1)[:, None]).reshape(-1), (b2 / np.linalg.norm(b2, axis=1)[:, None]).reshape(-1)])
+    six = np.array(six)
+    models, counts = gpu.solve_focal_batch("relpose_6pt_shared_focal", six)
+    total = 0
+    for k in range(len(six)):
+        po, fo = O.relpose_6pt_shared_focal(six[k, :18].reshape(6, 3), six[k, 18:].reshape(6, 3))
+        assert counts[k] == len(fo), k
+        assert np.array_equal(models[k, : counts[k], :7], po) and np.array_equal(models[k, : counts[k], 7], fo), k
+        total += len(fo)
+    assert total > 600
+    # P3.5Pf: samples of noisy absolute-pose scenes
+    p35 = []
+    for k in range(150):
+        d = synth.absolute_pose_scene(4 * 4, 0.0, 9700 + k, noise_px=[0.0, 1.0][k % 2], focal=float(rng.uniform(500, 2500)))
+        fcam, cx, cy = d["camera"]["params"]
+        x = np.asarray(d["p2d"]) - [cx, cy]
+        for j in range(4):
+            p35.append(np.r_[x[4 * j:4 * j + 4].reshape(-1), np.asarray(d["p3d"])[4 * j:4 * j + 4].reshape(-1)])
+    p35 = np.array(p35)
+    models, counts = gpu.solve_focal_batch("p35pf", p35)
+    total = 0
+    for k in range(len(p35)):
+        po, fo = O.p35pf(p35[k, :8].reshape(4, 2), p35[k, 8:].reshape(4, 3))
+        assert counts[k] == len(fo), k
+        assert np.array_equal(models[k, : counts[k], :7], po) and np.array_equal(models[k, : counts[k], 7], fo), k
+        total += len(fo)
+    assert total > 600
+    # single-problem entry points on the golden vectors
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_focal_v1.json")))
+    g35, g6 = minimal_inputs()
+    for (x, X), want in zip(g35, G["p35pf"]):
+        sols = gpu.p35pf(x, X)
+        assert [[repr(float(v)) for v in np.r_[p.q, p.t]] for p, _ in sols] == want["poses"] and [repr(f) for _, f in sols] == want["focals"]
+    for (a, b), want in zip(g6, G["six_point"]):
+        sols = gpu.relpose_6pt_shared_focal(a, b)
+        assert [[repr(float(v)) for v in np.r_[p.q, p.t]] for p, _ in sols] == want["poses"] and [repr(f) for _, f in sols] == want["focals"]
