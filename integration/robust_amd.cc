@@ -9,6 +9,7 @@
 // and links it with libposelib_amd.so, so the binding shown in INTEGRATION.md is known to build.
 #include <PoseLib/robust.h>
 #include <PoseLib/robust/ransac.h>
+#include <PoseLib/solvers/p35pf.h>
 #include <PoseLib/solvers/p3p.h>
 #include <PoseLib/solvers/relpose_5pt.h>
 
@@ -260,6 +261,21 @@ int p3p(const std::vector<Eigen::Vector3d> &x, const std::vector<Eigen::Vector3d
     output->assign(n, CameraPose());
     for (int i = 0; i < n; ++i)
         from_pl(sols[i], &(*output)[i]);
+    return n;
+}
+
+// solvers/p35pf.h:39-54 (normalize_input only changes the scaling inside the reference's solver; this one always normalises)
+int p35pf(const std::vector<Eigen::Vector2d> &points2d, const std::vector<Eigen::Vector3d> &points3d,
+          std::vector<CameraPose> *output_poses, std::vector<double> *output_focals, bool /*normalize_input*/) {
+    pl_camera_pose sols[10];
+    double focals[10];
+    const int n = pl_p35pf(points2d[0].data(), points3d[0].data(), sols, focals);
+    if (n < 0)
+        throw std::runtime_error(pl_last_error());
+    output_poses->assign(n, CameraPose());
+    output_focals->assign(focals, focals + n);
+    for (int i = 0; i < n; ++i)
+        from_pl(sols[i], &(*output_poses)[i]);
     return n;
 }
 
