@@ -52,12 +52,7 @@ constexpr int kSixT = 600;      // 15 x 15 companion
 constexpr int kSixA = 825;      // 10 x 10: L^T, later C0 + w C1 + w^2 C2
 constexpr int kSixB = 925;      // 10 x 15 right-hand sides
 constexpr int kSixWorkDoubles = 1075;
-struct SixWork {
-    double *base;
-    size_t stride;
-    PL_HD double &operator[](int e) const { return base[(size_t)e * stride]; }
-    PL_HD SixWork at(int off) const { return SixWork{base + (size_t)off * stride, stride}; }
-};
+typedef StridedArr SixWork; // (pl_solver_p35pf.h)
 
 // C[k][r * 10 + c]: coefficient of monomial c in the w^k part of equation r (0: det F, 1 + 3 i + j: entry (i, j) of the trace
 // constraint), every equation scaled to unit maximum.  nb: 9 x 3 null-space basis, column-major, vec index e = 3 col + row.

@@ -107,10 +107,18 @@ PL_HD void p35_cross(const P35Lin *a, const P35Lin *b, P35Quad *out) {
     }
 }
 
+// element e of a per-sample array that lives in a strided workspace (LDS on the device: element-major over the samples)
+struct StridedArr {
+    double *base;
+    size_t stride;
+    PL_HD double &operator[](int e) const { return base[(size_t)e * stride]; }
+    PL_HD StridedArr at(int off) const { return StridedArr{base + (size_t)off * stride, stride}; }
+};
 struct P35Work {
     double *base;
     size_t stride;
     PL_HD double &at(int r, int c) const { return base[(size_t)(r * kP35Cols + c) * stride]; }
+    PL_HD StridedArr region(int off) const { return StridedArr{base + (size_t)off * stride, stride}; }
 };
 // row r of the elimination matrix = eq scaled to unit maximum
 PL_HD void p35_store_row(const P35Work &w, int r, const P35Cubic &eq) {
@@ -577,25 +585,24 @@ PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P
         for (int j = 0; j < 10; ++j)
             AM[k * 10 + j] = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -w.at(pivot_row[-sh - 1], kP35Basis[j]);
     }
+    // the elimination matrix is consumed: its storage (the workspace: LDS on the device) now holds the action matrix and the
+    // working copies of the eigenvalue iteration and of the null-vector eliminations (in the first version these were local
+    // arrays, i.e. scratch memory behind the vector memory path)
+    const StridedArr am = w.region(0), wk = w.region(100);
+    for (int i = 0; i < 100; ++i)
+        am[i] = AM[i];
     double ev[10];
-    int nroots;
-    {
-        double work[100];
-        for (int i = 0; i < 100; ++i)
-            work[i] = AM[i];
-        nroots = p35_real_eigenvalues(work, ev, 1e-8);
-    }
+    for (int i = 0; i < 100; ++i)
+        wk[i] = AM[i];
+    const int nroots = pl_real_eigenvalues<10>(wk, ev, 1e-8);
     int n = 0;
     for (int s = 0; s < nroots; ++s) {
         double v[10];
-        {
-            double B[100];
-            for (int i = 0; i < 100; ++i)
-                B[i] = AM[i];
-            for (int i = 0; i < 10; ++i)
-                B[i * 10 + i] -= ev[s];
-            p35_null_vector(B, v);
-        }
+        for (int i = 0; i < 100; ++i)
+            wk[i] = am[i];
+        for (int i = 0; i < 10; ++i)
+            wk[i * 10 + i] -= ev[s];
+        pl_null_vector<10>(wk, v);
         if (v[9] == 0)
             continue;
         const double al[5] = {v[5] / v[9], v[6] / v[9], v[7] / v[9], v[8] / v[9], 1.0};
