@@ -81,6 +81,9 @@ typedef struct {
                                       P3.5Pf), the camera's focal length is replaced and refined in the final bundle; every
                                       other entry point: must be 0 */
     int32_t estimate_extra_params; /* must be 0 (radial distortion estimation: out of scope) */
+    double min_fov;           /* types.h:126 AbsolutePoseOptions::min_fov, degrees (5.0): with estimate_focal_length / pl_ransac_pnpf the
+                                 largest focal length a hypothesis may have is max|x| / tan(min_fov / 2) (absolute_pose.cc:159-177);
+                                 <= 0 disables the bound.  Ignored by every other entry point, like in the reference. */
 } pl_robust_options;
 
 /* types.h:52-58 (+ the metric numerator and timing, which the reference does not report) */
@@ -169,7 +172,7 @@ int pl_ransac_pnp(const double *x, const double *X, size_t n, const pl_robust_op
                   uint8_t *inliers, pl_ransac_stats *stats);
 /* robust/ransac.h:52-54 ransac_pnpf (FocalAbsolutePoseEstimator, estimators/absolute_pose.h:69-113): pose and focal length of a
  * SIMPLE_PINHOLE camera whose principal point is the origin of the image points x.  The model is reset before the loop as in
- * the reference (ransac.cc:61-66); min_fov is the reference's default (5 degrees).  PROSAC sampling: PL_ERR_UNSUPPORTED. */
+ * the reference (ransac.cc:61-66); opt->min_fov bounds the focal length (absolute_pose.h:78).  PROSAC sampling: samples drawn on the host. */
 int pl_ransac_pnpf(const double *x, const double *X, size_t n, const pl_robust_options *opt, pl_camera_pose *pose, double *focal,
                    uint8_t *inliers, pl_ransac_stats *stats);
 int pl_ransac_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,

@@ -122,6 +122,7 @@ RansacStats estimate_absolute_pose(const std::vector<Point2D> &points2D, const s
     pl_robust_options o = to_pl(0, opt.ransac, opt.bundle, opt.max_error);
     o.estimate_focal_length = opt.estimate_focal_length; // robust.cc:47-54: ransac_pnpf on the device since round 3
     o.estimate_extra_params = opt.estimate_extra_params;
+    o.min_fov = opt.min_fov; // types.h:126, absolute_pose.h:78
     pl_camera cam = to_pl(image->camera);
     pl_camera_pose pose = to_pl(image->pose);
     pl_ransac_stats st;

@@ -35,7 +35,7 @@ class BundleOptions(C.Structure):
 
 class RobustOptions(C.Structure):
     _fields_ = [("ransac", RansacOptions), ("bundle", BundleOptions), ("max_error", f64), ("real_focal_check", i32),
-                ("tangent_sampson", i32), ("estimate_focal_length", i32), ("estimate_extra_params", i32)]
+                ("tangent_sampson", i32), ("estimate_focal_length", i32), ("estimate_extra_params", i32), ("min_fov", f64)]
 
 
 class RansacStats(C.Structure):

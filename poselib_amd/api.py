@@ -167,6 +167,8 @@ def _robust_options(opt, kind: int, score_initial: bool) -> L.RobustOptions:
     for k in ("real_focal_check", "tangent_sampson", "estimate_focal_length", "estimate_extra_params"):
         if k in opt:
             setattr(o, k, int(bool(opt[k])))
+    if "min_fov" in opt:  # types.h:126; read by the focal-length estimator only (absolute_pose.h:78)
+        o.min_fov = float(opt["min_fov"])
     return o
 
 

@@ -1995,6 +1995,7 @@ void pl_default_robust_options(pl_robust_options *o, int kind) {
     pl_default_ransac_options(&o->ransac);
     pl_default_bundle_options(&o->bundle);
     o->max_error = (kind == 0) ? 12.0 : 1.0;
+    o->min_fov = 5.0; // types.h:126
 }
 
 int pl_device_count(void) {
