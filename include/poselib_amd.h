@@ -120,6 +120,12 @@ int pl_device_count(void);
 int pl_set_device(int device);      /* device used by the calling thread from now on */
 const char *pl_last_error(void);    /* thread-local description of the last failure */
 const char *pl_version(void);
+/* Summation order of the non-linear refinements (optim/jacobian_accumulator.h:82-97 adds correspondence after correspondence).
+ * 0 (default): problems up to 256 correspondences are summed in the reference's order (refined models bit-identical), larger ones in
+ * tree order (refined models 1e-13 off; the decisions were identical in every test and soak).  1: EVERY sum of every refinement in
+ * the reference's order at every size (k_lm_ordered) - refined models bit-identical at every n at 1.3 - 2 x the refinement time (6 x for
+ * homographies beyond 5000 correspondences).  Process-wide; also POSELIB_AMD_LM_ORDERED=1.  Returns the previous mode. */
+int pl_set_lm_mode(int ordered);
 
 /* ---- robust front-ends (robust.h) ---- */
 int pl_estimate_absolute_pose(const double *points2D, const double *points3D, size_t n, const pl_robust_options *opt,

@@ -13,6 +13,8 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "lib", "libposelib_amd.so")
+if os.environ.get("POSELIB_AMD_LIB"):  # development: another build of the same C-ABI (A/B timing of kernel variants)
+    LIB_PATH = os.environ["POSELIB_AMD_LIB"]
 
 u64, i32, u32, f64 = C.c_uint64, C.c_int32, C.c_uint32, C.c_double
 
@@ -118,6 +120,7 @@ def _declare(L):
         "pl_default_bundle_options": (None, [P(BundleOptions)]),
         "pl_default_robust_options": (None, [opt, cint]),
         "pl_device_count": (cint, []),
+        "pl_set_lm_mode": (cint, [cint]),
         "pl_set_device": (cint, [cint]),
         "pl_last_error": (C.c_char_p, []),
         "pl_version": (C.c_char_p, []),
@@ -177,5 +180,5 @@ EXPORTED_SYMBOLS = [
     "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_bundle_adjust_camera", "pl_p3p", "pl_relpose_5pt",
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
     "pl_ransac_batch", "pl_debug_device_math", "pl_ransac_pnpf", "pl_ransac_shared_focal_relpose", "pl_refine_shared_focal_relpose",
-    "pl_estimate_shared_focal_relative_pose", "pl_solve_focal_batch", "pl_p35pf", "pl_relpose_6pt_shared_focal",
+    "pl_estimate_shared_focal_relative_pose", "pl_solve_focal_batch", "pl_p35pf", "pl_relpose_6pt_shared_focal", "pl_set_lm_mode",
 ]

@@ -746,3 +746,9 @@ def device_count() -> int:
 
 def set_device(i: int):
     L.check(L.lib().pl_set_device(int(i)))
+
+
+def set_lm_mode(ordered: bool) -> bool:
+    """Summation order of the non-linear refinements: False (default) = the reference's order up to 256 correspondences, tree order
+    beyond; True = the reference's order at every size (bit-identical refined models, slower).  Returns the previous mode."""
+    return bool(L.lib().pl_set_lm_mode(int(bool(ordered))))

@@ -197,6 +197,14 @@ int get_context(Context **out) {
     return PL_OK;
 }
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and kernels of streams
+// that share a queue run one after the other.  The batch entry points keep 8 ... 16 launch chains in flight, one stream each: with
+// the default, three of eight streams shared a queue and ran at half the rate of the two that had one to themselves
+// (profiles/r04_batch_chain_4_queues.md).  The variable is read when the runtime initialises, i.e. at the process's first HIP
+// call - so it is set (never overwritten) when this library is loaded.  A host application that initialised HIP earlier keeps
+// whatever it had; INTEGRATION.md says so.
+__attribute__((constructor)) static void default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Wait for everything enqueued on the context's stream.  Default: hipStreamSynchronize.  POSELIB_AMD_SPIN_SYNC=1: the
@@ -1998,6 +2006,12 @@ void pl_default_robust_options(pl_robust_options *o, int kind) {
     o->min_fov = 5.0; // types.h:126
 }
 
+int pl_set_lm_mode(int ordered) {
+    const int prev = pl::get_lm_mode();
+    pl::set_lm_mode(ordered);
+    return prev;
+}
+
 int pl_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess)
@@ -3075,7 +3089,7 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     // device fed while groups finish at different times, larger groups amortise the per-launch host work.  Measured on
     // MI355X, config 4, 8 workers: 2048 problems per call - groups of 128: 49.2 k, 192: 46.7 k, 256: 42.3 k problems/s;
     // 4096 per call - 128: 49.4 k, 256: 54.8 k, 384: 51.0 k, 512: 48.4 k.  (A problem's result does not depend on its group.)
-    static const long group_env = [] { // POSELIB_AMD_BATCH_GROUP: fixed size (experiments)
+    const long group_env = [] { // POSELIB_AMD_BATCH_GROUP: fixed size (experiments; read per call so that one process can sweep it)
         const char *e = std::getenv("POSELIB_AMD_BATCH_GROUP");
         return e ? std::min<long>(std::max<long>(std::atol(e), 1), 1024) : 0L;
     }();
@@ -3102,8 +3116,20 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
             }
         }
     }
-    for (auto &grp : groups) // (the long jobs first)
-        jobs.emplace_back([&grp] { run_group_job(grp); });
+    // the long jobs first: a group's time grows with its correspondences, and a 5-point problem costs about twice a P3P or
+    // homography problem of the same size (generator + Sampson scorer + LO with a pre-filter; profiles/r03_bench_batch_mixed_*)
+    std::vector<size_t> order(groups.size());
+    std::vector<double> cost(groups.size(), 0.0);
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        order[gi] = gi;
+        for (const GroupItem &g : groups[gi])
+            cost[gi] += (double)g.item->n * (g.kind == EST_REL ? 2.0 : (g.kind == EST_HOM ? 1.2 : 1.0));
+    }
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+    for (size_t gi : order) {
+        std::vector<GroupItem> *grp = &groups[gi];
+        jobs.emplace_back([grp] { run_group_job(*grp); });
+    }
     for (size_t i : solo)
         jobs.emplace_back([items, i] {
             items[i].status = run_item(items[i]);

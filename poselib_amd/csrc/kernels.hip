@@ -29,6 +29,7 @@
 // Exact arithmetic (fp64, reference association order) never runs on the matrix cores; only the filters' linear and
 // quadratic forms do.
 #include "pl_kernels.h"
+#include "pl_lm_chain.inc"
 #include "pl_device.h"
 #include <atomic>
 #include "pl_prefilter.h"
@@ -2037,6 +2038,357 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         finish(cur, false, ctl.iterations, ctl.cost, ctl.initial_cost);
 }
 
+// ---- k_lm_ordered: the same refinement with EVERY sum in the reference's order, for every n (round 4) -------------------
+// k_lm above adds the normal equations and the robust cost of problems beyond 256 correspondences in tree order (per-lane partial
+// sums, wave and block reduction): refined models 1e-13 off the reference's, which decides a comparison only when two values tie
+// to that level - never observed, but not excluded.  This kernel excludes it: the opt-in exact mode (pl_set_lm_mode(1) /
+// POSELIB_AMD_LM_ORDERED=1) routes every task through it.  Cost and floor (measured, DESIGN 4 "Ordered sums at every n"): a
+// sequential fp64 sum is a chain of dependent additions, 9.3 cycles each on gfx950; the consumer below reaches 11.7 cycles per row in
+// isolation and ~21 inside the kernel, i.e. 44 us per LM iteration at n = 5000 against 22 us for the tree form.
+#ifndef PL_LM_WAVES
+#define PL_LM_WAVES 2 // wavefronts per SIMD the register allocation of k_lm aims at (2: one workgroup per CU, no spills)
+#endif
+template <int EST> __global__ __launch_bounds__(kLMThreads, (EST == EST_HOM ? 2 : PL_LM_WAVES)) void k_lm_ordered(LMTask *tasks, uint32_t lds_bytes) {
+    using R = Refiner<EST>;
+    constexpr int K = R::K;
+    constexpr int NT = NormalSize<K>::kTotal;
+    constexpr int ND = point_doubles(EST);
+    // The task may live in pinned host memory the device reads over the bus (no upload dispatch): ONE cooperative
+    // fetch into LDS; the outputs go back to the task (and the refined model's record to device memory) at the end.
+    __shared__ LMTask s_task;
+    LMTask &Tout = tasks[blockIdx.x];
+    {
+        static_assert(sizeof(LMTask) % 8 == 0, "copied as 64-bit words");
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(&Tout);
+        uint64_t *dst = reinterpret_cast<uint64_t *>(&s_task);
+        for (uint32_t w = threadIdx.x; w < sizeof(LMTask) / 8; w += kLMThreads)
+            dst[w] = src[w];
+        __syncthreads();
+    }
+    const LMTask &T = s_task;
+    auto finish = [&](const double *params, bool skipped, uint32_t iterations, double cost, double initial_cost) {
+        // (thread 0 only)
+        for (int i = 0; i < kParamDoubles; ++i)
+            Tout.params[i] = params[i];
+        Tout.iterations = iterations;
+        Tout.skipped = skipped ? 1u : 0u;
+        Tout.cost = cost;
+        Tout.initial_cost = initial_cost;
+        if (T.record_out) {
+            if (skipped) { // refinement not run: model unchanged (relative_pose.cc:75-77)
+                for (int i = 0; i < kModelStride; ++i)
+                    T.record_out[i] = T.record_in[i];
+            } else {
+                record_from_lm_params(EST, params, T.record_out);
+            }
+        }
+    };
+    extern __shared__ double s_lm_points[];
+    const PointSet pts_global = T.pts;
+    PointSet pts = pts_global;
+    // (tasks of several problems may share a launch: each stages its own points if they fit the launch's dynamic LDS)
+    const bool lds_points = sizeof(double) * ND * (size_t)pts_global.n <= (size_t)lds_bytes;
+    if (lds_points) {
+        for (int d = 0; d < ND; ++d) {
+            for (uint32_t i = threadIdx.x; i < pts_global.n; i += kLMThreads)
+                s_lm_points[(size_t)d * pts_global.n + i] = pts_global.a[d][i];
+            pts.a[d] = s_lm_points + (size_t)d * pts_global.n;
+        }
+    }
+
+    __shared__ LMControl ctl;
+    __shared__ double cur[kParamDoubles], trial[kParamDoubles];
+    __shared__ RefineCtx ctx;
+    __shared__ double normal[NT];
+    __shared__ double normal_next[NT]; // the normal equations at the trial point (fused pass), the next iteration's if the step is accepted
+    __shared__ double s_racc[1];
+    __shared__ uint32_t s_count;   // residual pass: correspondences counted (jacobian_accumulator.h's single counter after residual())
+    __shared__ uint32_t s_count_j; // Jacobian pass: correspondences with a non-zero weight (... after accumulate())
+    __shared__ int s_accepted;
+    __shared__ int s_skip;
+    // Ring of term rows between the producer wavefronts (1 .. 7) and the consumer (wavefront 0), see `pass`: one slot = the rows of
+    // 64 correspondences (x 2 for the homography's forward / backward blocks), a row = the NT entries of [J^T J lower triangle | J^T r]
+    // followed by the correspondence's robust-cost term.
+    constexpr int SUB = (EST == EST_HOM) ? 2 : 1;
+    constexpr int kRingSlots = (EST == EST_HOM) ? 2 : 3;
+    // column-major: s_ring[slot][entry][row] - the consumer lane of an entry reads ITS rows as adjacent doubles (two per ds_read_b128);
+    // the column stride 64 SUB + 2 doubles keeps the producers' row writes and the consumer's reads spread over the banks
+    constexpr int kRows = 64 * SUB;
+    constexpr int kColStride = kRows + 2;
+    __shared__ __attribute__((aligned(16))) double s_ring[kRingSlots][NT + 1][kColStride];
+    __shared__ uint32_t s_ready[kRingSlots]; // sequence number of the batch a slot holds
+    __shared__ uint32_t s_consumed;          // sequence number of the last batch the consumer has added
+    if (threadIdx.x < kRingSlots)
+        s_ready[threadIdx.x] = 0;
+    if (threadIdx.x == 0)
+        s_consumed = 0;
+    uint32_t seq_base = 0; // batches handed through the ring so far (the same in every thread)
+
+    const uint8_t *mask = T.mask;
+    const double pscale = T.point_scale;
+    const CameraParams cam = T.cam;
+
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < kParamDoubles; ++i)
+            cur[i] = T.params[i];
+        ctl.opt = T.opt;
+        ctl.loss = make_loss(T.opt.loss_type, T.opt.loss_scale);
+        ctl.done = 0;
+        s_skip = 0;
+    }
+    __syncthreads();
+
+    // ---- relative-pose LO: restrict to approximate inliers (relative_pose.cc:62-86) ----
+    if constexpr (EST == EST_REL) {
+        if (T.prefilter_thr2 > 0) {
+            double M[kModelStride];
+            {
+                Quat q;
+                q.w = cur[0], q.x = cur[1], q.y = cur[2], q.z = cur[3];
+                store_pose_model_q(M, q, v3(cur[4], cur[5], cur[6]), true);
+            }
+            uint32_t c = 0;
+            for (uint32_t i = threadIdx.x; i < pts.n; i += kLMThreads) {
+                double r2;
+                const bool in = sampson_pose_inlier(M, pts.a[0][i], pts.a[1][i], pts.a[2][i], pts.a[3][i],
+                                                    T.prefilter_thr2, r2);
+                T.scratch[i] = in ? 1 : 0;
+                c += in;
+            }
+            double dummy[1] = {0.0};
+            __shared__ double pre_scratch[kLMThreads / 64][2];
+            __shared__ double pre_out[1];
+            BlockReduce<1>::run(dummy, c, pre_scratch, pre_out, &s_count);
+            if (threadIdx.x == 0 && s_count <= 5)
+                s_skip = 1;
+            __threadfence_block();
+            __syncthreads();
+            mask = T.scratch;
+        }
+    }
+    if (s_skip) {
+        if (threadIdx.x == 0)
+            finish(cur, true, 0u, 0.0, 0.0);
+        return;
+    }
+
+    // One pass over the points.  mode kRes: robust cost only (-> s_racc, s_count).  kJac: normal equations (-> out, s_count_j).
+    // kBoth: both at the same parameters - the cost of a trial step and, if the step is accepted, the next iteration's normal
+    // equations from ONE sweep (lm_impl.h:88-99 then :66-76 of the next iteration evaluate the same point; k_lm2 does the same
+    // across launches).
+    //
+    // EVERY sum is formed in the reference's order, for every n (round 4; up to round 3 only for n <= 256).  The reference adds
+    // correspondence after correspondence (jacobian_accumulator.h:82-97: one `+=` per entry and correspondence), and which of two
+    // tied or nearly tied refinements wins is decided by the last bits of those sums.  A sequential sum of n terms is a chain of
+    // n dependent additions whatever the hardware, so the pass is a PIPELINE: wavefronts 1 .. 7 (producers) take the batches of
+    // 64 consecutive correspondences round robin, evaluate residual / Jacobian and the entry TERMS of their correspondence in
+    // registers, and hand them over as rows of an LDS ring; wavefront 0 (consumer) owns one entry per lane - lane a < NT entry a
+    // of [J^T J | J^T r], lane NT the robust cost - and adds the rows of batch 0, 1, 2, ... one after the other (eight LDS reads
+    // travel together, the additions stay a chain).  The producers' arithmetic hides behind the chain: ~10 cycles per
+    // correspondence, 21 us per sweep at n = 5000.  Terms of skipped correspondences (masked out, behind the camera, weight
+    // zero) are zeros: x + 0.0 = x.  Flags: s_ready[slot] = sequence number of the batch the slot holds (release / acquire at
+    // workgroup scope), s_consumed = last batch added; a producer writes a slot once the batch `slots` earlier is consumed.
+    enum { kRes = 0, kJac = 1, kBoth = 2 };
+    constexpr uint32_t kProducers = kLMThreads / 64 - 1;
+    auto pass = [&](const double *p, int mode, double *out) {
+        const bool jac = mode != kRes, res = mode != kJac;
+        if (threadIdx.x == 0) {
+            R::prepare(p, ctx);
+            if (res)
+                s_count = 0;
+            if (jac)
+                s_count_j = 0;
+        }
+        __syncthreads();
+        const Loss loss = ctl.loss;
+        const int lane = threadIdx.x & 63;
+        const uint32_t wave = threadIdx.x >> 6;
+        const uint32_t n = pts.n;
+        const uint32_t nbatch = (n + 63u) / 64u;
+        if (wave == 0) {
+            // ---- consumer ----
+            const bool mine = (jac && lane < NT) || (res && lane == NT);
+            const int col = mine ? lane : 0;
+            double tot = 0.0;
+            for (uint32_t j = 0; j < nbatch; ++j) {
+                const uint32_t g = seq_base + j + 1u;
+                const uint32_t slot = g % (uint32_t)kRingSlots;
+                while (__hip_atomic_load(&s_ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != g)
+                    __builtin_amdgcn_s_sleep(1);
+                // every slot holds 64 * SUB rows (the lanes beyond n write zero rows: x + 0.0 = x), so the loop has a fixed trip
+                // count: one inline-asm statement per slot (pl_lm_chain.inc, generated by scripts/gen_lm_chain.py) - the row reads
+                // run six pairs ahead of the additions, 11.7 cycles per row against 9.3 for the bare chain of dependent additions
+                // and 17 - 25 for hipcc's schedule of the same loop (scripts/exp/chain_add.cc)
+                const uint32_t col_addr = (uint32_t)(uintptr_t)&s_ring[slot][col][0];
+                if constexpr (SUB == 1)
+                    PL_LM_CHAIN64(tot, col_addr);
+                else
+                    PL_LM_CHAIN128(tot, col_addr);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0)
+                    __hip_atomic_store(&s_consumed, g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (jac && lane < NT)
+                out[lane] = tot;
+            if (res && lane == NT)
+                s_racc[0] = tot;
+        } else {
+            // ---- producers ----
+            uint32_t cn = 0, cnj = 0;
+            for (uint32_t j = wave - 1u; j < nbatch; j += kProducers) {
+                const uint32_t g = seq_base + j + 1u;
+                const uint32_t slot = g % (uint32_t)kRingSlots;
+                const uint32_t i = 64u * j + (uint32_t)lane;
+                const bool live = i < n && !(mask && !mask[i]);
+                double cterm[SUB];
+                double r0 = 0, r1 = 0, g0 = 0, g1 = 0;
+                double J[(EST == EST_ABS || EST == EST_HOM) ? 2 * K : K], Jb[(EST == EST_HOM) ? 2 * K : 1];
+                bool have = false; // this correspondence contributes a Jacobian row
+#pragma unroll
+                for (int u = 0; u < SUB; ++u)
+                    cterm[u] = 0.0;
+                if (live) {
+                    if constexpr (EST == EST_ABS) {
+                        const double x = pts.a[0][i] * pscale, y = pts.a[1][i] * pscale;
+                        const double X = pts.a[2][i], Y = pts.a[3][i], Z = pts.a[4][i];
+                        if (res) {
+                            if (R::residual(p, ctx, cam, x, y, X, Y, Z, r0, r1)) {
+                                cterm[0] += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
+                                cn++;
+                            }
+                        }
+                        if (jac)
+                            have = R::jacobian(p, ctx, cam, x, y, X, Y, Z, r0, r1, J);
+                    } else if constexpr (EST == EST_HOM) {
+                        const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
+                        if (res) {
+                            R::residual(ctx, a0, a1, b0, b1, r0, r1, g0, g1);
+                            cterm[0] += 1.0 * loss_value(loss, r0 * r0 + r1 * r1);
+                            cterm[SUB - 1] += 1.0 * loss_value(loss, g0 * g0 + g1 * g1);
+                            cn += 2;
+                        }
+                        if (jac) {
+                            R::jacobian(ctx, a0, a1, b0, b1, r0, r1, J, g0, g1, Jb);
+                            have = true;
+                        }
+                    } else {
+                        const double a0 = pts.a[0][i], a1 = pts.a[1][i], b0 = pts.a[2][i], b1 = pts.a[3][i];
+                        if (res) {
+                            const double r = R::residual(ctx, a0, a1, b0, b1);
+                            cterm[0] += 1.0 * loss_value(loss, r * r);
+                            cn++;
+                        }
+                        if (jac) {
+                            r0 = R::jacobian(ctx, a0, a1, b0, b1, J);
+                            have = true;
+                        }
+                    }
+                }
+                // the slot is free once the batch `kRingSlots` earlier has been added
+                if (g > (uint32_t)kRingSlots) {
+                    while (__hip_atomic_load(&s_consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + (uint32_t)kRingSlots < g)
+                        __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int u = 0; u < SUB; ++u) {
+                    const int row = SUB * lane + u;
+                    if (jac) {
+                        auto store = [&](int a, double v) { s_ring[slot][a][row] = v; };
+                        if (have) {
+                            if constexpr (EST == EST_ABS)
+                                terms2<K>(loss, r0, r1, J, cnj, store);
+                            else if constexpr (EST == EST_HOM) {
+                                if (u == 0)
+                                    terms2<K>(loss, r0, r1, J, cnj, store);
+                                else
+                                    terms2<K>(loss, g0, g1, Jb, cnj, store);
+                            } else
+                                terms1<K>(loss, r0, J, cnj, store);
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < NT; ++a)
+                                store(a, 0.0);
+                        }
+                    }
+                    if (res)
+                        s_ring[slot][NT][row] = cterm[u];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0)
+                    __hip_atomic_store(&s_ready[slot], g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (cn)
+                atomicAdd(&s_count, cn);
+            if (cnj)
+                atomicAdd(&s_count_j, cnj);
+        }
+        seq_base += nbatch;
+        __syncthreads();
+    };
+
+    // The initial cost and the first iteration's normal equations are evaluated at the same point with the same loss: one sweep.
+    if constexpr (EST == EST_REL) {
+        if (threadIdx.x == 0)
+            R::prepare_params(cur);
+        __syncthreads();
+    }
+    const bool first_needs_jacobian = T.opt.max_iterations != 0;
+    pass(cur, first_needs_jacobian ? kBoth : kRes, normal);
+    if (threadIdx.x == 0)
+        lm_begin(ctl, T.opt, s_racc[0], s_count);
+    __syncthreads();
+
+    // The trial point's sweep is fused (kBoth) unless the loss changes between iterations (TRUNCATED_LE_ZACH: mu grows after
+    // every iteration, bundle.cc:52-75 - the next Jacobian would have to be evaluated with the new mu).
+    const bool fuse = T.opt.loss_type != LOSS_TRUNCATED_LE_ZACH;
+    bool have_next = first_needs_jacobian; // `normal` already holds the normal equations at `cur`
+    uint32_t jac_count = s_count_j;        // the Jacobian pass's counter that belongs to `normal`
+    while (!ctl.done) {
+        const bool fresh = ctl.rejac != 0;
+        if (fresh && !have_next) {
+            if constexpr (EST == EST_REL) {
+                if (threadIdx.x == 0)
+                    R::prepare_params(cur);
+                __syncthreads();
+            }
+            pass(cur, kJac, normal);
+            jac_count = s_count_j;
+        }
+        if (threadIdx.x == 0) {
+            lm_solve<K>(ctl, normal, fresh, jac_count);
+            if (!ctl.done) {
+                R::step(cur, ctx, ctl.sol, trial);
+                if constexpr (EST == EST_REL)
+                    if (fuse)
+                        R::prepare_params(trial); // (the tangent basis of the Jacobian at the trial point: what the next
+                                                  // iteration computes from the accepted parameters)
+            }
+        }
+        __syncthreads();
+        if (ctl.done)
+            break;
+        pass(trial, fuse ? kBoth : kRes, normal_next);
+        if (threadIdx.x == 0) {
+            const bool accepted = lm_update<K>(ctl, normal, s_racc[0], s_count);
+            if (accepted)
+                for (int i = 0; i < kParamDoubles; ++i)
+                    cur[i] = trial[i];
+            s_accepted = accepted ? 1 : 0;
+        }
+        __syncthreads();
+        have_next = fuse && s_accepted != 0;
+        if (have_next) {
+            if (threadIdx.x < NT)
+                normal[threadIdx.x] = normal_next[threadIdx.x];
+            jac_count = s_count_j;
+            __syncthreads();
+        }
+    }
+
+    if (threadIdx.x == 0)
+        finish(cur, false, ctl.iterations, ctl.cost, ctl.initial_cost);
+}
+
 // ---- LM across several workgroups ---------------------------------------------------------------------------------
 // k_lm keeps one refinement task on one CU; at N = 10^4 with 7 or 8 parameters that CU is VALU-saturated for ~70 us per
 // LM iteration.  k_lm2 spreads the point range of every task over gridDim.x workgroups and turns the LM loop inside
@@ -2485,36 +2837,63 @@ hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_t
     const size_t want = sizeof(double) * point_doubles(est) * (size_t)pts.n;
     return launch_lm_tasks(est, tasks, num_tasks, want <= 128 * 1024 ? pts.n : 0u, stream);
 }
+// 0: k_lm (tree sums beyond 256 correspondences), 1: k_lm_ordered (every sum in the reference's order); -1: not set yet
+// (POSELIB_AMD_LM_ORDERED decides at the first launch).  pl_set_lm_mode() in the C-ABI.
+static std::atomic<int> g_lm_mode{-1};
+void set_lm_mode(int ordered) { g_lm_mode.store(ordered ? 1 : 0, std::memory_order_release); }
+int get_lm_mode() {
+    int m = g_lm_mode.load(std::memory_order_acquire);
+    if (m < 0) {
+        const char *e = std::getenv("POSELIB_AMD_LM_ORDERED");
+        m = (e && e[0] && e[0] != '0') ? 1 : 0;
+        g_lm_mode.store(m, std::memory_order_release);
+    }
+    return m;
+}
 hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
     if (est < 0 || est > 3)
         return hipErrorInvalidValue;
+    const int ordered = get_lm_mode();
     // stage the points in LDS when they fit next to the kernel's static LDS (160 KB per CU, one workgroup per CU); tasks
     // of a mixed launch whose points do not fit the launch's dynamic LDS read them from L2
     // (a request the points do not fit into would only keep every other workgroup off the CU: no staging then)
-    static std::atomic<int> dyn_limit[4] = {{-1}, {-1}, {-1}, {-1}}; // bytes of dynamic LDS the kernel may ask for
-    int limit = dyn_limit[est].load(std::memory_order_acquire);
+    static std::atomic<int> dyn_limit[2][4] = {{{-1}, {-1}, {-1}, {-1}}, {{-1}, {-1}, {-1}, {-1}}}; // bytes of dynamic LDS the kernel may ask for
+    int limit = dyn_limit[ordered][est].load(std::memory_order_acquire);
     if (limit < 0) {
         hipFuncAttributes fa;
         hipError_t e = hipSuccess;
-        PL_DISPATCH_EST(est, e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_lm<E>)));
+        if (ordered) {
+            PL_DISPATCH_EST(est, e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_lm_ordered<E>)));
+        } else {
+            PL_DISPATCH_EST(est, e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_lm<E>)));
+        }
         if (e != hipSuccess)
             return e;
         limit = std::max<int>(0, 160 * 1024 - (int)fa.sharedSizeBytes - 1024);
         limit = std::min<int>(limit, 128 * 1024);
         if (limit > 48 * 1024) {
-            PL_DISPATCH_EST(est, e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm<E>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, limit));
+            if (ordered) {
+                PL_DISPATCH_EST(est, e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm_ordered<E>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, limit));
+            } else {
+                PL_DISPATCH_EST(est, e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm<E>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, limit));
+            }
             if (e != hipSuccess)
                 return e;
         }
-        dyn_limit[est].store(limit, std::memory_order_release);
+        dyn_limit[ordered][est].store(limit, std::memory_order_release);
     }
     const size_t want = sizeof(double) * point_doubles(est) * (size_t)max_points;
     const bool lds = std::getenv("POSELIB_AMD_LM_NO_LDS") == nullptr;
     const size_t bytes = (lds && want <= (size_t)limit) ? want : 0;
-    PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), bytes, stream>>>(tasks, (uint32_t)bytes));
+    if (ordered) {
+        PL_DISPATCH_EST(est, k_lm_ordered<E><<<dim3(num_tasks), dim3(kLMThreads), bytes, stream>>>(tasks, (uint32_t)bytes));
+    } else {
+        PL_DISPATCH_EST(est, k_lm<E><<<dim3(num_tasks), dim3(kLMThreads), bytes, stream>>>(tasks, (uint32_t)bytes));
+    }
     return hipGetLastError();
 }
 
@@ -2552,6 +2931,8 @@ __global__ void k_select_record_g(const SelectArgs *arr) {
     const double *src = (*a.score_refined < a.incumbent_score) ? a.rec_refined : a.rec_incumbent;
     if (threadIdx.x < kModelStride)
         a.out[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x == 63 && a.fetch_src)
+        *a.fetch_dst = *a.fetch_src;
 }
 hipError_t launch_group_select(const SelectArgs *args, uint32_t G, hipStream_t stream) {
     if (G == 0)

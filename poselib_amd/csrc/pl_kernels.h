@@ -21,7 +21,10 @@ struct PointSet {
 
 constexpr int kScoreThreads = 256; // 4 wavefronts per workgroup
 constexpr int kLMSeqPoints = 256; // up to this many correspondences k_lm sums in the reference's order (one thread per correspondence)
-constexpr int kLMThreads = 512;    // 8 wavefronts (2 per SIMD => 256 VGPRs each: the k(k+1)/2+k accumulators stay in registers)
+#ifndef PL_LM_THREADS
+#define PL_LM_THREADS 512
+#endif
+constexpr int kLMThreads = PL_LM_THREADS; // k_lm: wavefront 0 adds the term rows in order, the others produce them (kernels.hip)
 
 PL_HD constexpr int sample_size(int est) { return est == EST_ABS ? 3 : est == EST_REL ? 5 : est == EST_FUND ? 7 : 4; }
 PL_HD constexpr int max_models(int est) { return est == EST_ABS ? 4 : est == EST_REL ? 40 : est == EST_FUND ? 3 : 1; }
@@ -275,6 +278,8 @@ struct SelectArgs {
     double incumbent_score;
     const double *rec_refined, *rec_incumbent;
     double *out;
+    const uint32_t *fetch_src; // optional: one device word (a stopped problem's hypothesis offset) ...
+    uint32_t *fetch_dst;       // ... copied to this (pinned host) address by the same launch
 };
 struct GroupArgs { // everything the kernels of one batch step need for ONE problem of the group
     uint32_t active;   // 0: the slot takes no part in this step
@@ -321,6 +326,9 @@ hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipSt
 hipError_t launch_group_finalize_records(const GroupArgs *args, const GroupDims &d, hipStream_t stream);
 // LM over the tasks of many problems: every task carries its own correspondences (LMTask.pts)
 hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream);
+// k_lm (0: tree sums beyond 256 correspondences, the default) or k_lm_ordered (1: every sum in the reference's order at every n)
+void set_lm_mode(int ordered);
+int get_lm_mode();
 // absolute pose + camera intrinsics (lm_cam.hip): tasks with cam_flags != 0; refined pose -> params / record_out, camera -> cam
 hipError_t launch_lm_cam(LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
 int group_points_per_lane(int est); // P of the group launches (fixed per estimator)

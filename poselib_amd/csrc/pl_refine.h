@@ -262,6 +262,51 @@ template <int K> PL_HD void accumulate1(double *acc, const Loss &loss, double r,
     count++;
 }
 
+// The same terms as accumulate2 / accumulate1, handed to `store(entry, value)` instead of added to an accumulator: k_lm's producers
+// write them as a row of the term ring and the consumer adds row after row (the reference's `+=` per entry and correspondence,
+// jacobian_accumulator.h:82-97).  `acc += v` with the value written here equals the reference's `acc += v` bit for bit; a
+// correspondence with weight zero contributes nothing there (early return) and a row of zeros here (x + 0.0 = x).
+template <int K, class Store> PL_HD void terms2(const Loss &loss, double r0, double r1, const double *J /*2xK*/, uint32_t &count, Store store) {
+    const double w = 1.0 * loss_weight(loss, r0 * r0 + r1 * r1);
+    if (w == 0) {
+        PL_UNROLL
+        for (int o = 0; o < NormalSize<K>::kTotal; ++o)
+            store(o, 0.0);
+        return;
+    }
+    int o = 0;
+    PL_UNROLL
+    for (int i = 0; i < K; ++i)
+        PL_UNROLL
+        for (int j = 0; j <= i; ++j)
+            store(o++, w * (J[i] * J[j] + J[K + i] * J[K + j]));
+    const double wr0 = w * r0, wr1 = w * r1;
+    PL_UNROLL
+    for (int i = 0; i < K; ++i)
+        store(o + i, J[i] * wr0 + J[K + i] * wr1);
+    count++;
+}
+template <int K, class Store> PL_HD void terms1(const Loss &loss, double r, const double *J /*K*/, uint32_t &count, Store store) {
+    const double w = 1.0 * loss_weight(loss, r * r);
+    if (w == 0) {
+        PL_UNROLL
+        for (int o = 0; o < NormalSize<K>::kTotal; ++o)
+            store(o, 0.0);
+        return;
+    }
+    int o = 0;
+    PL_UNROLL
+    for (int i = 0; i < K; ++i)
+        PL_UNROLL
+        for (int j = 0; j <= i; ++j)
+            store(o++, w * (J[i] * J[j]));
+    const double wr = w * r;
+    PL_UNROLL
+    for (int i = 0; i < K; ++i)
+        store(o + i, wr * J[i]);
+    count++;
+}
+
 // (2 rho - 1)^3 of the Nielsen update (lm_impl.h:124: std::pow(2.0 * rho - 1.0, 3)), see the note at lm_update
 // The reference calls the host's libm here - glibc's pow, whose result for the exponent 3 is the correctly rounded cube
 // for 99.9 % of the arguments (measured: 183 exceptions in 2*10^5; the device library's pow differs from it for 23 %).  The

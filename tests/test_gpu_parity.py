@@ -773,3 +773,64 @@ def test_decision_scores_and_small_problem_refinements_equal_the_oracle_bit_for_
             assert exact >= total - 1, (n, exact, total)
         pr.close(), pf.close(), ph.close()
     assert checked > 500
+
+
+def test_ordered_lm_mode_refines_bit_for_bit_at_every_size(gpu):
+    """pl_set_lm_mode(1) routes every refinement through k_lm_ordered: the normal equations and the robust cost are added
+    correspondence after correspondence like optim/jacobian_accumulator.h:82-97 - for EVERY n, not only up to 256 (the producers
+    hand the entry terms of 64 correspondences at a time through an LDS ring to one wavefront that adds them in order).  Refined
+    models, iteration counts and - through ransac_* - complete runs must EQUAL the oracle's (the exception budget is the cube
+    of the Nielsen update, 0.08 % of the arguments, as in the 256-correspondence test)."""
+    rs = np.random.RandomState(23)
+    prev = gpu.set_lm_mode(True)
+    try:
+        exact = total = 0
+        for trial, n in enumerate([257, 300, 1000, 2750, 5000, 10000, 12000]):
+            outl = [0.3, 0.6][trial % 2]
+            d = synth.absolute_pose_scene(n, outl, 7400 + trial)
+            par = d["camera"]["params"]
+            x = (np.asarray(d["p2d"]) - np.array(par[-2:])) / par[0]
+            X = np.asarray(d["p3d"])
+            r = synth.relative_pose_scene(n, outl, 7500 + trial)
+            x1, x2 = (np.asarray(r["x1"]) - 500.0) / 1000.0, (np.asarray(r["x2"]) - 500.0) / 1000.0
+            h = synth.homography_scene(n, outl, 7600 + trial)
+            y1, y2 = (np.asarray(h["x1"]) - 500.0) / 1000.0, (np.asarray(h["x2"]) - 500.0) / 1000.0
+            pa, pr, pf, ph = (gpu.Problem(gpu.KIND_ABS, x, X), gpu.Problem(gpu.KIND_REL, x1, x2), gpu.Problem(gpu.KIND_FUND, x1, x2),
+                              gpu.Problem(gpu.KIND_HOM, y1, y2))
+            Hm, _ = gpu.ransac_homography(y1, y2, {"max_error": 1e-3, "ransac": {"seed": trial, "max_iterations": 300}})
+            Fm, _ = gpu.ransac_fundamental(x1, x2, {"max_error": 1e-3, "ransac": {"seed": trial, "max_iterations": 300}})
+            for loss in ("TRUNCATED", "CAUCHY", "HUBER"):
+                bo = {"loss_type": loss, "loss_scale": 1e-3, "max_iterations": 25}
+                q = np.asarray(d["q_gt"]) + 1e-3 * rs.randn(4)
+                q /= np.linalg.norm(q)
+                t = np.asarray(d["t_gt"]) + 1e-3 * rs.randn(3)
+                got, it = pa.refine(gpu.CameraPose(q, t), dict(bo, loss_scale=0.012))
+                want, st = O.bundle_adjust(x, X, {"model": "NULL", "width": 0, "height": 0, "params": []}, np.r_[q, t], dict(bo, loss_scale=0.012))
+                exact += int((np.r_[got.q, got.t] == want).all() and it == st.iterations)
+                q = np.asarray(r["q_gt"]) + 1e-3 * rs.randn(4)
+                q /= np.linalg.norm(q)
+                t = np.asarray(r["t_gt"]) + 1e-3 * rs.randn(3)
+                got, it = pr.refine(gpu.CameraPose(q, t), bo)
+                want, st = O.refine("relpose", x1, x2, np.r_[q, t], bo)
+                exact += int((np.r_[got.q, got.t] == want).all() and it == st.iterations)
+                M = Hm + 1e-4 * np.abs(Hm).max() * rs.randn(3, 3)
+                got, it = ph.refine(M, bo)
+                want, st = O.refine("homography", y1, y2, M, bo)
+                exact += int((np.ravel(got) == np.ravel(want)).all() and it == st.iterations)
+                got, it = pf.refine(Fm, bo)
+                want, st = O.refine("fundamental", x1, x2, Fm, bo)
+                exact += int((np.ravel(got) == np.ravel(want)).all() and it == st.iterations)
+                total += 4
+            # a complete run: every LO and the final refinement in the reference's order
+            opt = {"max_error": 0.012, "ransac": {"seed": 5 + trial, "max_iterations": 2000, "min_iterations": 200}}
+            pose, info = gpu.ransac_pnp(x, X, opt)
+            ref, mask, st = O.ransac_pnp(x, X, opt)
+            assert (info["iterations"], info["refinements"], info["num_inliers"]) == (st["iterations"], st["refinements"], st["num_inliers"])
+            assert (np.array(info["inliers"], dtype=bool) == mask).all()
+            exact += int((np.r_[pose.q, pose.t] == np.asarray(ref)).all())
+            total += 1
+            for p in (pa, pr, pf, ph):
+                p.close()
+        assert exact >= total - 2, (exact, total)
+    finally:
+        gpu.set_lm_mode(prev)
