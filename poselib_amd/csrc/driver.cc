@@ -1542,6 +1542,12 @@ struct RansacRun {
         if (prosac)
             prosac_sampler.init(ro.seed, N, K, ro.max_prosac_iterations);
     }
+    // iterations the loop is known to need at least from here (plan_batch's bound, without its side effects)
+    uint64_t needed_now() const {
+        uint64_t needed = std::max<uint64_t>(ro.min_iterations, dyn_max) + 1;
+        needed = std::min<uint64_t>(needed, ro.max_iterations);
+        return (needed > it) ? needed - it : 1;
+    }
     bool plan_batch(Batch &b) {
         if (stopped || it >= ro.max_iterations)
             return false;
@@ -2966,25 +2972,35 @@ int run_item(pl_batch_item &it) {
 
 // one group of same-kind problems through the group launches; whatever it could not finish goes through the
 // single-problem entry points
-void run_group_job(std::vector<GroupItem> &items) {
+// POSELIB_AMD_GROUP_STEPS: batch steps a group of pl_estimate_batch runs before its unfinished problems are regrouped (0: never)
+uint32_t group_step_budget() {
+    const char *e = std::getenv("POSELIB_AMD_GROUP_STEPS");
+    return e ? (uint32_t)std::max<long>(std::atol(e), 0) : 2u;
+}
+void run_group_job(std::vector<GroupItem *> &items, bool resume) {
     Context *c;
     int rc = get_context(&c);
     const double t0 = now_s();
     double t1 = t0;
     if (rc == PL_OK) {
-        for (GroupItem &g : items)
-            group_prepare_item(g);
+        if (!resume)
+            for (GroupItem *g : items)
+                group_prepare_item(*g);
         t1 = now_s();
-        rc = run_group(c, items.data(), (uint32_t)items.size());
+        rc = run_group(c, items.data(), (uint32_t)items.size(), false, resume ? 0u : group_step_budget(), resume);
     }
     const double t2 = now_s();
     if (rc != PL_OK)
         note_worker_error(); // (the items are retried one by one below; the reason is kept for the caller)
-    for (GroupItem &g : items) {
-        if (rc != PL_OK || g.fallback) {
-            g.item->status = run_item(*g.item);
+    for (GroupItem *g : items) {
+        if (rc != PL_OK)
+            g->deferred = false;
+        if (rc != PL_OK || g->fallback) {
+            delete g->run;
+            g->run = nullptr;
+            g->item->status = run_item(*g->item);
             ++g_n_fallback;
-            if (g.item->status != PL_OK)
+            if (g->item->status != PL_OK)
                 note_worker_error();
         }
     }
@@ -3042,7 +3058,10 @@ int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int 
             if (r == PL_OK) {
                 for (GroupItem &g : grp)
                     group_prepare_resident(g);
-                r = run_group(cc, grp.data(), (uint32_t)grp.size(), true);
+                std::vector<GroupItem *> ptrs;
+                for (GroupItem &g : grp)
+                    ptrs.push_back(&g);
+                r = run_group(cc, ptrs.data(), (uint32_t)ptrs.size(), true);
             }
             if (r != PL_OK)
                 note_worker_error();
@@ -3126,9 +3145,13 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
             cost[gi] += (double)g.item->n * (g.kind == EST_REL ? 2.0 : (g.kind == EST_HOM ? 1.2 : 1.0));
     }
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+    std::vector<std::vector<GroupItem *>> group_ptrs(groups.size());
+    for (size_t gi = 0; gi < groups.size(); ++gi)
+        for (GroupItem &g : groups[gi])
+            group_ptrs[gi].push_back(&g);
     for (size_t gi : order) {
-        std::vector<GroupItem> *grp = &groups[gi];
-        jobs.emplace_back([grp] { run_group_job(*grp); });
+        std::vector<GroupItem *> *grp = &group_ptrs[gi];
+        jobs.emplace_back([grp] { run_group_job(*grp, false); });
     }
     for (size_t i : solo)
         jobs.emplace_back([items, i] {
@@ -3144,6 +3167,37 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     if (g_group_timing)
         g_t_wait_ns = g_t_group_ns = g_t_prep_ns = g_t_fallback_ns = g_n_waits = g_n_fallback = 0;
     batch_pool_instance().run(jobs, w, g_requested_device);
+    // ---- second round: the problems that were still running when their group's step budget ended (the long runs: 5-point problems
+    // with 60 - 70 % outliers need ~10^4 iterations), regrouped by kind, every step as large as the loop is known to need ----
+    {
+        std::vector<GroupItem *> late[4];
+        for (auto &grp : groups)
+            for (GroupItem &g : grp)
+                if (g.deferred)
+                    late[g.kind].push_back(&g);
+        std::vector<std::vector<GroupItem *>> late_groups;
+        for (int k = 0; k < 4; ++k) {
+            std::stable_sort(late[k].begin(), late[k].end(), [](const GroupItem *a, const GroupItem *b) { return a->n > b->n; });
+            const size_t per = 64; // (long batches: 32768 iterations x 16 slots of a 5-point problem are 100 MB of records)
+            for (size_t at = 0; at < late[k].size(); at += per)
+                late_groups.emplace_back(late[k].begin() + at, late[k].begin() + std::min(late[k].size(), at + per));
+        }
+        if (!late_groups.empty()) {
+            std::vector<std::function<void()>> late_jobs;
+            for (auto &grp : late_groups) {
+                std::vector<GroupItem *> *gp = &grp;
+                late_jobs.emplace_back([gp] { run_group_job(*gp, true); });
+            }
+            const int w2 = (int)std::min<size_t>((size_t)w, late_jobs.size());
+            g_group_workers.store(std::max(w2, 1));
+            batch_pool_instance().run(late_jobs, w2, g_requested_device);
+        }
+        for (auto &grp : groups)
+            for (GroupItem &g : grp) {
+                delete g.run; // (only after an error: every finished problem's run has been released by its group)
+                g.run = nullptr;
+            }
+    }
     if (g_group_timing)
         std::fprintf(stderr, "poselib_amd: pl_estimate_batch %zu items, %zu groups + %zu solo, %d workers: wall %.1f ms; workers' time: prepare %.1f, "
                              "groups %.1f (of which waiting for the device %.1f in %llu waits), fallback items %.1f ms (%llu items)\n",

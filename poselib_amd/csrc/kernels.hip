@@ -1395,7 +1395,7 @@ constexpr int kSeqThreads = 512, kSeqPerThread = 8, kSeqChunk = kSeqThreads * kS
 
 template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScoreArgs &a) {
     constexpr int ND = point_doubles(EST);
-    __shared__ double s_list[kSeqChunk + 32];
+    __shared__ __attribute__((aligned(16))) double s_list[kSeqChunk + 64];
     __shared__ uint32_t s_wave_tot[kSeqThreads / 64], s_total;
     __shared__ double s_sum;
     __shared__ uint32_t s_inliers;
@@ -1459,33 +1459,19 @@ template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScore
                     s_list[off++] = r2v[j];
             if (threadIdx.x == kSeqThreads - 1) {
                 s_total = off;
-                for (int z = 0; z < 32; ++z) // pad with +0.0 (x + 0.0 == x: the sum never is -0.0)
+                for (int z = 0; z < 64; ++z) // pad with +0.0 to the next multiple of 64 (x + 0.0 == x: the sum never is -0.0)
                     s_list[off + z] = 0.0;
             }
             __syncthreads();
             if (threadIdx.x == 0) {
                 const uint32_t total = s_total;
                 double sum = s_sum;
-                // utils.cc:59 / :193 / :233 / :323, in correspondence order; eight values per step so that the LDS reads
-                // of the next step travel while this step's dependent additions run
-                // (the reads of the next eight values are issued before this step's dependent additions)
-                double v[8], w[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    v[t] = s_list[t];
-                for (uint32_t j = 0; j < total; j += 16) {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        w[t] = s_list[j + 8 + t];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        sum += v[t];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        v[t] = s_list[j + 16 + t];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        sum += w[t]; // (+0.0 beyond `total`)
+                // utils.cc:59 / :193 / :233 / :323, in correspondence order: a chain of dependent additions.  64 terms per inline-asm
+                // statement (pl_lm_chain.inc: two terms per ds_read_b128, the reads six pairs ahead of the additions): 11.7 cycles
+                // per term against 17 - 32 for the compiler's schedule of the same loop (scripts/exp/chain_add.cc)
+                for (uint32_t j = 0; j < total; j += 64) {
+                    const uint32_t addr = (uint32_t)(uintptr_t)&s_list[j];
+                    PL_LM_CHAIN64(sum, addr); // (+0.0 beyond `total`)
                 }
                 s_sum = sum;
                 if constexpr (EST == EST_ABS)

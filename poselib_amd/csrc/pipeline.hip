@@ -1098,8 +1098,10 @@ hipError_t launch_group_positions(int K, const GroupArgs *args, const GroupDims 
 hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipStream_t stream) {
     k_compact2_g<<<dim3((d.max_B + 1023) / 1024, 1, d.G), dim3(1024), 0, stream>>>(args);
     // bounded grids (see k_gather_shadow16_g): at most 1024 + 512 workgroups per problem, none where nobody needs them
-    const uint32_t gblocks = d.any_queue ? (uint32_t)std::min<uint64_t>(((uint64_t)d.max_hcap * 12u + 255) / 256, 1024u) : 0u;
-    const uint32_t sblocks = d.any_mfma ? std::min<uint32_t>((((d.max_hcap + 15u) & ~15u) + (uint32_t)kSampson16Pad + 255) / 256, 512u) : 0u;
+    // (sized by ITERATIONS, not by record capacity: the lists hold 0.6 (5-point) ... 2.5 (7-point) hypotheses per iteration, the
+    // kernels stride over the device-side count - by capacity a group of 228 5-point problems dispatched 180 k empty workgroups)
+    const uint32_t gblocks = d.any_queue ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4u, ((uint64_t)d.max_B * 12u + 255) / 256), 1024u) : 0u;
+    const uint32_t sblocks = d.any_mfma ? std::min<uint32_t>(std::max<uint32_t>(4u, (d.max_B * 2u + 255u) / 256u), 512u) : 0u;
     if (gblocks + sblocks)
         k_gather_shadow16_g<<<dim3(gblocks + sblocks, 1, d.G), dim3(256), 0, stream>>>(args, gblocks);
     return hipGetLastError();

@@ -28,7 +28,12 @@ for i in range(n_prob):
 print(f"{n_prob} problems generated in {time.perf_counter() - t0:.1f} s", flush=True)
 batch = P.Batch(problems)
 ref = None
-for threads, group in settings:
+for cfg in settings:
+    threads, group = cfg[0], cfg[1]
+    if len(cfg) > 2:
+        os.environ["POSELIB_AMD_GROUP_STEPS"] = str(cfg[2])
+    else:
+        os.environ.pop("POSELIB_AMD_GROUP_STEPS", None)
     if group:
         os.environ["POSELIB_AMD_BATCH_GROUP"] = str(group)
     else:
@@ -43,4 +48,4 @@ for threads, group in settings:
     same = "first" if ref is None else str(all(bool((a == b).all()) for a, b in zip(ref, key)))
     if ref is None:
         ref = key
-    print(f"threads {threads:3d} group {group:4d}: {n_prob / np.median(ts):9.0f} problems/s (median of 4: {1e3 * np.median(ts):.1f} ms, min {1e3 * min(ts):.1f}); same results: {same}", flush=True)
+    print(f"threads {threads:3d} group {group:4d} steps {cfg[2] if len(cfg) > 2 else -1:2d}: {n_prob / np.median(ts):9.0f} problems/s (median of 4: {1e3 * np.median(ts):.1f} ms, min {1e3 * min(ts):.1f}); same results: {same}", flush=True)
