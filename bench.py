@@ -61,8 +61,38 @@ ITERATIONS = 100000
 FOCAL = 1000.0
 HBM_PEAK_GBS = 8000.0
 SIMDS = 1024            # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
-PEAK_CLOCK_GHZ = 2.4    # peak engine clock; a wave64 VALU instruction occupies its SIMD for 4 cycles
-VALU_PEAK_GINST_S = SIMDS * PEAK_CLOCK_GHZ / 4.0  # 614.4 G wave-instructions / s
+PEAK_CLOCK_GHZ = 2.4    # peak engine clock
+# A wave64 vector instruction occupies its SIMD's issue port for 2.3 cycles (full-rate class: v_mul/add_f32, v_add/sub_u32, v_and/or/xor,
+# v_mov, v_fma_f32 with <= 1 VGPR source) or 4.2 cycles (everything else: packed, fp64, DPP, 3-operand integer, compares, conversions);
+# a v_mfma_f32_32x32x16_f16 costs 8.4 issue cycles (measured: profiles/r04_valu_issue.md, scripts/exp/valu_issue.cc, overlap.cc).  The
+# peak of a kernel is priced at ITS instruction mix (profiles/valu_mix.json, scripts/valu_mix.py); the all-half-rate and all-full-rate
+# readings are reported next to it.
+VALU_PEAK_GINST_S = SIMDS * PEAK_CLOCK_GHZ / 4.0  # 614.4 G wave-instructions / s: every instruction at the nominal half rate (rounds 1-3)
+VALU_PEAK_FULL_RATE_GINST_S = SIMDS * PEAK_CLOCK_GHZ / 2.0
+
+
+def kernel_issue_cycles(kernel_name, per_hc):
+    """issue-port cycles per VALU instruction of `kernel_name` at its own mix (MFMA issue cycles included in the numerator), and how it
+    was derived; None when profiles/valu_mix.json has no entry"""
+    try:
+        vm = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+    except Exception:
+        return None, None
+    k = vm.get(kernel_name) or vm.get(kernel_name.replace(" ", ""))
+    cyc = vm.get("_class_cycles", {})
+    if not k or not cyc:
+        return None, None
+    price = lambda m: (m["full"] * cyc["full"] + m["half"] * cyc["half"] + m["quarter"] * cyc["quarter"] + m["f64_trans"] * cyc["f64_trans"])
+    whole = k["whole_kernel_static"]
+    if per_hc and "hot_loop_hypotheses_per_iteration" in k and "hot_loop" in k:
+        hl, rest = k["hot_loop"], k["outside_hot_loop_static"]
+        f = k["hot_loop_iterations_per_chunk"] / k["hot_loop_hypotheses_per_iteration"]
+        loop_valu = hl["valu"] * f
+        loop_cycles = (price(hl) + hl["mfma"] * cyc["mfma_issue"]) * f
+        rest_valu = max(0.0, per_hc - loop_valu)
+        total = loop_cycles + rest_valu * price(rest) / max(1, rest["valu"])
+        return total / per_hc, "tile loop counted exactly (%.1f of %.1f instructions per hypothesis and chunk), the rest at the static mix outside the loop" % (loop_valu, per_hc)
+    return (price(whole) + whole["mfma"] * cyc["mfma_issue"]) / max(1, whole["valu"]), "whole-kernel static mix"
 PARITY_SEEDS = 8
 POSE_TOL = 1e-6
 # workload -> (kind, N, outlier ratio, max_error [px], data seed, bytes per correspondence, problems per step and
@@ -74,6 +104,19 @@ WORKLOADS = {
     "hom_10000": (3, 10000, 0.5, 1.0, 1003, 32, 32, "4-point homography LO-RANSAC (ransac_homography), BASELINE configs[3]"),
 }
 SECONDARY = ["relpose_5000", "fund_10000", "hom_10000"]
+
+
+def cpu_info():
+    """host CPU of the box the baselines were timed on"""
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
 
 
 def free_port() -> int:
@@ -213,8 +256,9 @@ def run_workload(name, args, ranks, P, synth, pool_factory, primary):
     thr = MAX_ERROR_PX / FOCAL
     S = 1 if shard_problem else max(1, args.streams)  # collectives of one process group must be issued in one order
     pool = pool_factory(S)
-    # DISTINCT image pairs: problem j of a step works on scene j mod NS (RANSAC seeds 0..7 - the parity sample - on
-    # scene 0), so the 16 problems of a lock-step group are 16 different scenes, not 16 copies of one cache-resident set.
+    # DISTINCT image pairs: problem j of a step works on scene j mod NS (the parity sample - RANSAC seeds 0..7 of the first
+    # timed step - therefore covers scenes 0..7), so the 16 problems of a lock-step group are 16 different scenes, not 16
+    # copies of one cache-resident set.
     # The front-end's O(N) pre-processing (robust.cc:40-46) and the upload are done once, outside the timed region.
     NS = 1 if shard_problem else max(1, args.scenes)
     scenes = [make_scene(k) for k in range(NS)]
@@ -222,7 +266,7 @@ def run_workload(name, args, ranks, P, synth, pool_factory, primary):
     probs = list(pool.map(lambda k: P.Problem(KIND, scenes[k][0], scenes[k][1]), range(NS)))  # SoA in HBM, resident from here on
 
     def prob_of(j):
-        return probs[0] if j < PARITY_SEEDS else probs[j % NS]
+        return probs[j % NS]  # (the parity seeds 0..7 too: seed j on scene j mod NS - the oracle below runs the same pairing)
 
     exchange = None
     if shard_problem and ranks.dist is not None:
@@ -301,22 +345,22 @@ def run_workload(name, args, ranks, P, synth, pool_factory, primary):
     if grouped:
         first = batches[0].results(PARITY_SEEDS)
     else:
-        first = [pool.submit(run_one, (probs[0], j)).result() for j in range(PARITY_SEEDS)] if first_streams is not None else None
+        first = [pool.submit(run_one, (prob_of(j), j)).result() for j in range(PARITY_SEEDS)] if first_streams is not None else None
     batches.clear()
     for pr in probs:
         pr.close()
     pool.shutdown()
     rec = [elapsed, float(hyp), kern_ms, float(launches), float(last_inliers), float(nan_hyp), solo_ms,
            float(solo_launches), float(solo_hyp)]
-    ctx = {"A": A, "B": Bpts, "thr": thr, "first": first, "PPS": PPS, "S": S, "kind": KIND, "n": N_POINTS,
+    ctx = {"A": A, "B": Bpts, "parity_scenes": [scenes[j % NS] for j in range(PARITY_SEEDS)], "thr": thr, "first": first, "PPS": PPS, "S": S, "kind": KIND, "n": N_POINTS,
            "bytes_per_corr": BYTES_PER_CORR, "descr": DESCR, "outliers": OUTLIER_RATIO, "max_error_px": MAX_ERROR_PX,
            "shard_problem": shard_problem, "grouped": grouped, "G": G, "T": T, "scenes": NS}
     return rec, ctx
 
 
-def cpu_runs(kind, A, Bpts, thr, iterations, nseeds, use_reference):
-    """RANSAC seeds 0..nseeds-1 of the workload on the host: single-threaded per problem like the reference, the
-    problems on separate cores (ctypes releases the GIL).  use_reference: oracle/_ref/libposelib_ref.so (the reference's
+def cpu_runs(kind, scenes, thr, iterations, nseeds, use_reference):
+    """RANSAC seed j of the workload on scene j (j = 0..nseeds-1: what problem j of the first timed step ran) on the host:
+    single-threaded per problem like the reference, the problems on separate cores (ctypes releases the GIL).  use_reference: oracle/_ref/libposelib_ref.so (the reference's
     own sources) instead of the oracle restatement.  Test infrastructure used as the CHECKER and the CPU baseline only."""
     from concurrent.futures import ThreadPoolExecutor
 
@@ -326,7 +370,7 @@ def cpu_runs(kind, A, Bpts, thr, iterations, nseeds, use_reference):
 
     def one(seed):
         o = {"max_error": thr, "ransac": {"max_iterations": iterations, "min_iterations": iterations, "seed": seed}}
-        return getattr(O, fn_name)(A, Bpts, o)
+        return getattr(O, fn_name)(scenes[seed][0], scenes[seed][1], o)
 
     def run_all():
         workers = max(1, min(nseeds, (os.cpu_count() or 2) // 2))
@@ -360,7 +404,7 @@ def parity_block(kind, gpu_first, cpu_out):
     out = {"checked": checked, "identical_iterations": same["iterations"], "identical_refinements": same["refinements"],
            "identical_hypotheses": same["hypotheses"], "identical_inlier_counts": same["num_inliers"],
            "identical_masks": same["masks"], "max_model_diff": top, "tolerance": POSE_TOL, "ok": bool(ok),
-           "against": "oracle, RANSAC seeds 0..%d of the first timed step, %d iterations" % (checked - 1, ITERATIONS)}
+           "against": "oracle, RANSAC seeds 0..%d of the first timed step (seed j on scene j), %d iterations" % (checked - 1, ITERATIONS)}
     for k, v in worst.items():
         out["max_" + k] = v
     return out
@@ -405,14 +449,20 @@ def report_workload(name, table, ctx, args, world):
         insts_solo = per_hc * (solo_hyp / max(solo_launches, 1)) * chunks
         achieved = insts_solo / solo_launch_s / 1e9
         insts_all = per_hc * hyp0 * chunks  # every scoring launch of the timed region on rank 0
-        roof.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINST_S,
+        cyc_per_inst, cyc_basis = kernel_issue_cycles(kernel_name, per_hc)
+        peak = SIMDS * PEAK_CLOCK_GHZ / cyc_per_inst if cyc_per_inst else VALU_PEAK_GINST_S
+        roof.update({"achieved": achieved, "peak": peak, "frac": achieved / peak,
+                     "issue_cycles_per_instruction": cyc_per_inst or 4.0,
+                     "peak_basis": (f"{SIMDS} SIMDs x {PEAK_CLOCK_GHZ} GHz / {cyc_per_inst:.2f} issue cycles per wave64 VALU instruction at this kernel's mix "
+                                    f"({cyc_basis}; class costs measured: profiles/r04_valu_issue.md)") if cyc_per_inst else roof["peak_basis"],
+                     "frac_if_all_half_rate": achieved / VALU_PEAK_GINST_S, "frac_if_all_full_rate": achieved / VALU_PEAK_FULL_RATE_GINST_S,
                      "frac_basis": "the kernel with the device to itself (4 problems one after the other right before "
                                    "the timed region; HIP events on the launching stream) - in the timed region "
                                    "several launches share the device (grouped mode: every launch serves a group of "
                                    "problems, avg_launch_ms is one problem's share), see device_frac_timed_region",
                      "valu_insts_per_hypothesis_chunk": per_hc, "points_per_chunk": chunk_pts,
                      "valu_insts_per_launch": insts_solo,
-                     "device_frac_timed_region": insts_all / 1e9 / VALU_PEAK_GINST_S / float(table[0, 0]),
+                     "device_frac_timed_region": insts_all / 1e9 / peak / float(table[0, 0]),
                      "valu_busy_pmc": pmc.get("valu_busy"), "mfma_busy_pmc": pmc.get("mfma_busy")})
     else:
         roof.update({"achieved": None, "frac": None,
@@ -438,7 +488,7 @@ def report_workload(name, table, ctx, args, world):
     # ---- the oracle on RANSAC seeds 0..7 of the same problem: parity of the timed configuration + CPU baseline ----
     ok = True
     if not args.no_parity and not shard_problem:
-        cpu_out, wall, workers, fn_name = cpu_runs(kind, ctx["A"], ctx["B"], ctx["thr"], ITERATIONS, PARITY_SEEDS, False)
+        cpu_out, wall, workers, fn_name = cpu_runs(kind, ctx["parity_scenes"], ctx["thr"], ITERATIONS, PARITY_SEEDS, False)
         out["parity"] = parity_block(kind, ctx["first"], cpu_out)
         ok = out["parity"]["ok"]
         if world == 1 and not args.no_cpu_baseline:
@@ -454,7 +504,7 @@ def report_workload(name, table, ctx, args, world):
             base = port
             if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libposelib_ref.so")):
                 try:
-                    ref_out, rwall, rworkers, _ = cpu_runs(kind, ctx["A"], ctx["B"], ctx["thr"], ITERATIONS, PARITY_SEEDS, True)
+                    ref_out, rwall, rworkers, _ = cpu_runs(kind, ctx["parity_scenes"], ctx["thr"], ITERATIONS, PARITY_SEEDS, True)
                     # (ransac_* does not report its model count; the oracle's run of the same seed counts the same
                     # sample stream and agrees in iterations / inliers / mask, see agrees_with_port)
                     hyp_r = hyp_c
@@ -627,6 +677,64 @@ def run_undistort_stage(args, ranks, P, synth):
     return rep, ok
 
 
+def run_p3p_200_default(args, ranks, P, synth):
+    """BASELINE configs[0]: estimate_absolute_pose (P3P, SIMPLE_PINHOLE) on 200 synthetic 2D-3D correspondences, 50 % outliers,
+    DEFAULT options (robust.cc:36-126; the reference stops after ~1000 iterations) - the one BASELINE config that is a LATENCY
+    workload: one front-end call after the other from host-resident inputs, milliseconds per call, next to the reference's own
+    sources (oracle/_ref) on one host core.  A chain of ~15 small dispatches and three synchronisations does not beat one CPU
+    core on a problem this small - the number is reported as it is."""
+    n, calls = 200, max(64, 8 * args.steps)
+    ds = [synth.absolute_pose_scene(n, 0.5, 4200 + 16 * ranks.rank + k) for k in range(8)]
+    opt = lambda j: {"ransac": {"seed": j}}
+    run = lambda j: P.estimate_absolute_pose(ds[j % 8]["p2d"], ds[j % 8]["p3d"], ds[j % 8]["camera"], opt(j))
+    for j in range(8):
+        run(j)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    outs = [run(j) for j in range(calls)]
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    table = ranks.gather([elapsed])
+    if ranks.rank != 0:
+        return None, True
+    t_max = float(table[:, 0].max())
+    rep = {"ms_per_call": 1e3 * t_max / calls, "calls": calls, "correspondences": n, "outlier_ratio": 0.5,
+           "mean_iterations": float(np.mean([o[1]["iterations"] for o in outs])),
+           "problem": "BASELINE configs[0]: estimate_absolute_pose, SIMPLE_PINHOLE, default options, one call at a time, host-resident inputs"}
+    ok = True
+    if not args.no_parity:
+        import oracle_lib as O
+
+        def cpu_all():
+            t1 = time.perf_counter()
+            res = [O.estimate_absolute_pose(ds[j % 8]["p2d"], ds[j % 8]["p3d"], ds[j % 8]["camera"], opt(j)) for j in range(calls)]
+            return res, time.perf_counter() - t1
+
+        res, t_port = cpu_all()
+        same, worst = 0, 0.0
+        for (img, info), (pose, mask, st) in zip(outs, res):
+            same += int(info["iterations"] == st["iterations"] and info["num_inliers"] == st["num_inliers"] and info["refinements"] == st["refinements"]
+                        and bool((np.array(info["inliers"], dtype=bool) == mask).all()))
+            worst = max(worst, model_diff(0, np.r_[img.pose.q, img.pose.t], np.asarray(pose, dtype=np.float64)))
+        ok = same == calls and worst <= POSE_TOL
+        rep["parity"] = {"checked": calls, "identical_iterations_refinements_inliers_masks": same, "max_model_diff": worst, "ok": ok,
+                         "against": "oracle estimate_absolute_pose, every call of the timed region"}
+        if ranks.world == 1 and not args.no_cpu_baseline:
+            rep["cpu_port_ms_per_call"] = 1e3 * t_port / calls
+            try:
+                import ref_lib
+
+                if ref_lib.available():
+                    with ref_lib.reference():
+                        rres, t_ref = cpu_all()
+                    rep["cpu_reference_ms_per_call"] = 1e3 * t_ref / calls
+                    rep["cpu_reference_agrees"] = sum(int(a[2]["iterations"] == b[2]["iterations"] and a[2]["num_inliers"] == b[2]["num_inliers"]
+                                                          and bool((a[1] == b[1]).all())) for a, b in zip(rres, res))
+            except Exception as e:
+                rep["reference_error"] = str(e)[:200]
+    return rep, ok
+
+
 def run_focal_estimators(args, ranks, P, synth):
     """the two focal-length estimators through their front-ends - estimate_absolute_pose with
     estimate_focal_length (ransac_pnpf, P3.5Pf) and estimate_shared_focal_relative_pose (6-point shared-focal solver) - on
@@ -693,21 +801,32 @@ def run_focal_estimators(args, ranks, P, synth):
                 good += bool(same and st["iterations"] == info["iterations"] and st["refinements"] == info["refinements"]
                              and np.array_equal(mask, np.asarray(info["inliers"], dtype=bool)))
             r["parity"] = {"problems": reps, "identical": good, "ok": good == reps,
-                           "what": "iterations, refinements and inlier mask equal the oracle's; pose and focal length bit for bit "
-                                   "(shared focal) / to 1e-9 (pnpf: tree-summed LM cost above 256 correspondences)"}
+                           "what": "against the ORACLE (whose minimal solvers are this project's formulations, not the reference's templates): "
+                                   "iterations, refinements and inlier mask equal; pose and focal length bit for bit (shared focal) / to 1e-9 "
+                                   "(pnpf: tree-summed LM cost above 256 correspondences).  Agreement with the reference's own sources: "
+                                   "device_vs_reference_sources"}
             r["cpu_port_problems_per_s"] = reps / t_cpu
-            if ranks.world == 1 and not args.no_cpu_baseline:  # the reference's own sources (oracle/_ref: generated solver templates), four problems
+            if ranks.world == 1 and not args.no_cpu_baseline:
+                # the reference's own sources (oracle/_ref: ITS solvers are machine-generated elimination templates, the oracle's and
+                # the device's are this project's own formulations): every problem of the step - the CPU baseline and the measured
+                # agreement of the DEVICE with the reference (decisions and mask; DESIGN 5: 589 of 600 random problems for the oracle)
                 import ref_lib
 
                 if ref_lib.available():
-                    t1 = time.perf_counter()
+                    agree, t_ref = 0, 0.0
                     with ref_lib.reference():
-                        for j in range(4):
+                        for j, (model, info) in enumerate(outs):
+                            t1 = time.perf_counter()
                             if name == "pnpf_2000":
-                                O.estimate_absolute_pose(da[j % 4]["p2d"], da[j % 4]["p3d"], da[j % 4]["camera"], oa(j))
+                                _, rmask, rst = O.estimate_absolute_pose(da[j % 4]["p2d"], da[j % 4]["p3d"], da[j % 4]["camera"], oa(j))
                             else:
-                                O.estimate_shared_focal_relative_pose(dr[j % 4]["x1"], dr[j % 4]["x2"], pp(dr[j % 4]), orl(j))
-                    r["cpu_reference_problems_per_s"] = 4 / (time.perf_counter() - t1)
+                                _, _, rmask, rst = O.estimate_shared_focal_relative_pose(dr[j % 4]["x1"], dr[j % 4]["x2"], pp(dr[j % 4]), orl(j))
+                            t_ref += time.perf_counter() - t1
+                            agree += bool(rst["iterations"] == info["iterations"] and rst["refinements"] == info["refinements"]
+                                          and np.array_equal(rmask, np.asarray(info["inliers"], dtype=bool)))
+                    r["cpu_reference_problems_per_s"] = reps / t_ref
+                    r["identical_to_reference"] = agree
+                    r["parity"]["device_vs_reference_sources"] = f"{agree}/{reps} problems: same iterations, refinements and inlier mask as oracle/_ref"
             ok = ok and good == reps
         rep[name] = r
     return (rep if ranks.rank == 0 else None), ok
@@ -742,7 +861,7 @@ def main():
     ap.add_argument("--batch-problems", type=int, default=4096,
                     help="configs[4] leg (\"batch of 4096 independent image pairs\"): problems per GPU and step of the mixed "
                          "default-options batch (0: skip)")
-    ap.add_argument("--batch-threads", type=int, default=8, help="host threads inside pl_estimate_batch")
+    ap.add_argument("--batch-threads", type=int, default=10, help="host threads inside pl_estimate_batch (8 - 12 measure alike)")
     ap.add_argument("--detail-file", default="", help="complete per-workload reports (default gpurun_out/bench_detail.json)")
     ap.add_argument("--rehearse-distributed", action="store_true",
                     help="launch / rendezvous / gather path only, no GPU work, prints no measurement (CPU test)")
@@ -782,6 +901,12 @@ def main():
             reports["opencv_undistort"] = rep
             names = names + ["opencv_undistort"]
             all_ok = all_ok and ok
+    if not args.no_secondary and not args.shard_problem:
+        rep, ok = run_p3p_200_default(args, ranks, P, synth)
+        if ranks.rank == 0:
+            reports["p3p_200_default"] = rep
+            names = names + ["p3p_200_default"]
+            all_ok = all_ok and ok
     focal_rep = None
     if not args.no_secondary and not args.shard_problem:
         focal_rep, ok = run_focal_estimators(args, ranks, P, synth)
@@ -805,7 +930,8 @@ def main():
                **{k: prim[k] for k in ("correspondences", "outlier_ratio", "max_iterations", "min_iterations", "max_error_px",
                                        "problems_per_gpu_per_step", "problems_in_flight_per_gpu", "distinct_scenes",
                                        "timed_region_s", "hypotheses_per_step", "iterations_per_s", "nan_model_share")},
-               "sharding": "one problem over the ranks" if args.shard_problem else "independent problems per rank, RCCL: barrier + final gather"}
+               "sharding": "one problem over the ranks" if args.shard_problem else "independent problems per rank, RCCL: barrier + final gather",
+               "lm_sums": "reference order at every n (k_lm_ordered)" if os.environ.get("POSELIB_AMD_LM_ORDERED", "0") not in ("", "0") else "reference order up to 256 correspondences, tree beyond (default; pl_set_lm_mode(1) = every n)"}
         for n in names[1:]:
             r = reports[n]
             if n in WORKLOADS:
@@ -814,6 +940,9 @@ def main():
                 cfg[n + "_frac"] = r["roofline"].get("frac")
                 cfg[n + "_device_frac"] = r["roofline"].get("device_frac_timed_region")
                 cfg[n + "_kernel"] = r["roofline"].get("kernel")
+                cfg[n + "_issue_cycles_per_instruction"] = r["roofline"].get("issue_cycles_per_instruction")
+                cfg[n + "_frac_if_all_half_rate"] = r["roofline"].get("frac_if_all_half_rate")
+                cfg[n + "_counters"] = r["roofline"].get("traffic_source")
                 if "parity" in r:
                     cfg[n + "_parity_ok"] = r["parity"]["ok"]
                     cfg[n + "_max_model_diff"] = r["parity"]["max_model_diff"]
@@ -822,6 +951,12 @@ def main():
                             cfg[n + "_" + k] = r["parity"][k]
                 if "cpu_baseline" in r:
                     cfg[n + "_cpu_" + r["cpu_baseline"]["kind"] + "_hyp_per_s"] = r["cpu_baseline"]["value"]
+            elif n == "p3p_200_default":
+                cfg["p3p_200_default_ms_per_call"] = r["ms_per_call"]
+                cfg["p3p_200_default_parity_ok"] = r.get("parity", {}).get("ok")
+                for k in ("cpu_reference_ms_per_call", "cpu_port_ms_per_call"):
+                    if k in r:
+                        cfg["p3p_200_default_" + k] = r[k]
             elif n == "opencv_undistort":
                 cfg["opencv_undistort_points_per_s"] = r["value"]
                 cfg["opencv_undistort_parity_ok"] = r.get("parity", {}).get("ok")
@@ -840,6 +975,10 @@ def main():
                 cfg[n + "_cpu_port_problems_per_s"] = r["cpu_port_problems_per_s"]
             if "cpu_reference_problems_per_s" in r:
                 cfg[n + "_cpu_reference_problems_per_s"] = r["cpu_reference_problems_per_s"]
+            if "identical_to_reference" in r:
+                cfg[n + "_decisions_identical_to_reference"] = f"{r['identical_to_reference']}/{r['problems']}"
+        if focal_rep:
+            cfg["focal_oracle_vs_reference_soak"] = "589/600 random problems: identical decisions (profiles/r03_soak_focal_oracle_vs_reference.md)"
         short = lambda d, drop: {k: v for k, v in d.items() if k not in drop}
         out = {
             "metric": "scored RANSAC hypotheses/sec (P3P@5k corrs, 5pt@5k corrs)",
@@ -861,7 +1000,7 @@ def main():
         if "cpu_baseline" in prim:
             cb = prim["cpu_baseline"]
             out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                                   "sample": cb.get("sample_short", cb["sample"][:160])}
+                                   "sample": cb.get("sample_short", cb["sample"][:160]), **cpu_info()}
             if "port" in cb:
                 out["cpu_baseline"]["port_value"] = cb["port"]["value"]
         detail = args.detail_file or os.path.join(ROOT, "gpurun_out", "bench_detail.json")

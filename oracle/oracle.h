@@ -41,6 +41,7 @@ typedef struct {
     double max_error;
     int32_t real_focal_check; /* fundamental only */
     int32_t estimate_focal_length; /* absolute pose: AbsolutePoseOptions::estimate_focal_length (robust.cc:47-54) */
+    double min_fov;                /* absolute pose: AbsolutePoseOptions::min_fov, degrees (types.h:126; 5.0) */
 } orc_robust_opt;
 
 typedef struct {

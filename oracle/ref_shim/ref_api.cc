@@ -131,6 +131,7 @@ template <typename Opt> Opt robust_in(const orc_robust_opt *o) {
 AbsolutePoseOptions abs_in(const orc_robust_opt *o) {
     AbsolutePoseOptions r = robust_in<AbsolutePoseOptions>(o);
     r.estimate_focal_length = o->estimate_focal_length != 0;
+    r.min_fov = o->min_fov;
     return r;
 }
 RelativePoseOptions rel_in(const orc_robust_opt *o) {

@@ -474,6 +474,7 @@ void orc_ransac_pnpf(const double *x, const double *X, size_t n, const orc_robus
     o.ransac = ropt(opt->ransac);
     o.bundle = bopt(opt->bundle);
     o.max_error = opt->max_error;
+    o.min_fov = opt->min_fov;
     Image best;
     std::vector<char> m;
     LoopTrace tr;
@@ -493,6 +494,7 @@ void orc_estimate_absolute_pose(const double *p2d, const double *p3d, size_t n, 
     o.bundle = bopt(opt->bundle);
     o.max_error = opt->max_error;
     o.estimate_focal_length = opt->estimate_focal_length != 0;
+    o.min_fov = opt->min_fov;
     Image im;
     im.pose = pose_in(pose7);
     im.camera = cam_in(cam);

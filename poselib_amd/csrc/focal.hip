@@ -28,7 +28,12 @@ __global__ __launch_bounds__(64) void k_focal_generate(FocalGenArgs g) {
     if (it >= g.num_iters)
         return;
     uint32_t idx[kFocalSample];
-    draw_sample<kFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
+    if (g.samples) { // PROSAC: drawn on the host
+        for (int k = 0; k < kFocalSample; ++k)
+            idx[k] = g.samples[(size_t)it * kFocalSample + k];
+    } else {
+        draw_sample<kFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
+    }
     double xs[8];
     Vec3 X[4];
     for (int k = 0; k < 4; ++k) {

@@ -85,6 +85,8 @@ struct FocalLoopOptions {
     double dyn_num_trials_mult, success_prob;
     bool score_initial_model;
     double max_error, max_focal;
+    bool progressive_sampling = false;      // PROSAC (sampling.cc:85-136): the samples are drawn on the host, one ProsacSampler per run
+    uint64_t max_prosac_iterations = 100000;
 };
 struct FocalLoopStats {
     uint64_t refinements = 0, iterations = 0, num_inliers = 0, hypotheses = 0, iterations_evaluated = 0;
@@ -122,7 +124,8 @@ template <int K> inline uint64_t focal_sample_positions(uint64_t seed, uint64_t 
 }
 
 // The sequential LO-RANSAC loop (ransac_impl.h:106-201) over batches of iterations.  The back end evaluates
-//   int minimal(pos_base, positions, B, models [B * 10], num_models [B], counts, sums)   - generate + score a batch,
+//   int minimal(pos_base, positions, B, models [B * 10], num_models [B], counts, sums, samples)   - generate + score a batch
+//                                                          (samples != nullptr: B x kSample explicit indices - PROSAC),
 //   int score(models, counts, sums)                                                     - score given models,
 //   int refine(seeds, refined)                                                          - refine_model() of every seed;
 // counts / sums: inliers and the sum of their squared residuals in correspondence order, per model slot.  All decisions are
@@ -142,7 +145,10 @@ int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalM
     const double log_fail = std::log(1.0 - o.success_prob);
 
     std::vector<FocalModel> models, seeds, refined;
-    std::vector<uint32_t> num_models, counts, rcounts, positions;
+    std::vector<uint32_t> num_models, counts, rcounts, positions, prosac_samples;
+    ProsacSampler prosac;
+    if (o.progressive_sampling)
+        prosac.init(o.seed, N, kSample, o.max_prosac_iterations);
     std::vector<double> sums, rsums;
     struct Improving {
         uint32_t iter, slot;
@@ -212,8 +218,19 @@ int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalM
         want = std::min<uint64_t>(std::max<uint64_t>(want, 256), 4096);
         const uint32_t B = (uint32_t)std::min<uint64_t>(want, o.max_iterations - it0);
         positions.resize(B);
-        const uint64_t pos_after = focal_sample_positions<kSample>(o.seed, pos, N, B, positions.data());
-        int rc = be.minimal(pos, positions.data(), B, models, num_models, counts, sums);
+        uint64_t pos_after = pos;
+        const uint32_t *explicit_samples = nullptr;
+        if (o.progressive_sampling) { // the subset-size recurrence is serial: B samples from the host
+            prosac_samples.resize((size_t)B * kSample);
+            for (uint32_t b = 0; b < B; ++b) {
+                positions[b] = 0;
+                prosac.generate(&prosac_samples[(size_t)b * kSample]);
+            }
+            explicit_samples = prosac_samples.data();
+        } else {
+            pos_after = focal_sample_positions<kSample>(o.seed, pos, N, B, positions.data());
+        }
+        int rc = be.minimal(pos, positions.data(), B, models, num_models, counts, sums, explicit_samples);
         if (rc)
             return rc;
         st.iterations_evaluated += B;
@@ -305,6 +322,7 @@ struct FocalGenArgs {
     uint32_t n;
     uint64_t seed, pos_base;
     const uint32_t *positions;
+    const uint32_t *samples; // optional: num_iters x kFocalSample explicit indices (PROSAC) instead of the counter-based draws
     uint32_t num_iters;
     double max_focal;     // < 0: no bound
     FocalModel *models;   // [num_iters * kFocalMaxModels]

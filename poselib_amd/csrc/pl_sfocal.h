@@ -158,6 +158,7 @@ struct SFocalGenArgs {
     uint32_t n;
     uint64_t seed, pos_base;
     const uint32_t *positions;
+    const uint32_t *samples; // optional: num_iters x kSFocalSample explicit indices (PROSAC)
     uint32_t num_iters;
     FocalModel *models;   // [num_iters * kSFocalMaxModels]
     uint32_t *num_models; // [num_iters]

@@ -35,7 +35,12 @@ __global__ __launch_bounds__(64) void k_sfocal_generate(SFocalGenArgs g) {
     if (it >= g.num_iters)
         return;
     uint32_t idx[kSFocalSample];
-    draw_sample<kSFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
+    if (g.samples) { // PROSAC: drawn on the host
+        for (int k = 0; k < kSFocalSample; ++k)
+            idx[k] = g.samples[(size_t)it * kSFocalSample + k];
+    } else {
+        draw_sample<kSFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
+    }
     Vec3 x1[6], x2[6];
     for (int k = 0; k < 6; ++k) { // relative_pose.cc:157-160: homogeneous().normalized()
         x1[k] = bearing(g.a[0][idx[k]], g.a[1][idx[k]]);

@@ -778,14 +778,18 @@ struct HostFocalBackend {
         }
     }
     int minimal(uint64_t pos_base, const uint32_t *positions, uint32_t B, std::vector<FocalModel> &models,
-                std::vector<uint32_t> &num_models, std::vector<uint32_t> &counts, std::vector<double> &sums) {
+                std::vector<uint32_t> &num_models, std::vector<uint32_t> &counts, std::vector<double> &sums, const uint32_t *samples = nullptr) {
         models.assign((size_t)B * kFocalMaxModels, FocalModel());
         num_models.assign(B, 0);
         counts.assign((size_t)B * kFocalMaxModels, 0);
         sums.assign((size_t)B * kFocalMaxModels, 0.0);
         for (uint32_t it = 0; it < B; ++it) {
             uint32_t idx[kFocalSample];
-            draw_sample<kFocalSample>(seed, pos_base + positions[it], n, idx);
+            if (samples)
+                for (int k = 0; k < kFocalSample; ++k)
+                    idx[k] = samples[(size_t)it * kFocalSample + k];
+            else
+                draw_sample<kFocalSample>(seed, pos_base + positions[it], n, idx);
             double xs[8];
             Vec3 X[4];
             for (int k = 0; k < 4; ++k) {
@@ -846,6 +850,11 @@ struct HostFocalBackend {
 };
 } // namespace
 
+// PROSAC for the two focal-length loops below (sampling.cc:85-136): process-wide switch of the test build
+static int g_hm_prosac = 0;
+static uint64_t g_hm_max_prosac = 100000;
+extern "C" void hm_set_prosac(int on, uint64_t max_prosac_iterations) { g_hm_prosac = on, g_hm_max_prosac = max_prosac_iterations; }
+
 extern "C" void hm_ransac_pnpf(const double *const *pa, uint32_t n, uint64_t max_iterations, uint64_t min_iterations, uint64_t seed,
                                double dyn_mult, double success_prob, int score_initial, double max_error, double min_fov, double *pose7,
                                double *focal, uint8_t *mask, uint64_t *stats5 /* refinements, iterations, num_inliers, hypotheses, evaluated */,
@@ -853,6 +862,7 @@ extern "C" void hm_ransac_pnpf(const double *const *pa, uint32_t n, uint64_t max
     FocalLoopOptions o;
     o.max_iterations = max_iterations, o.min_iterations = min_iterations, o.seed = seed;
     o.dyn_num_trials_mult = dyn_mult, o.success_prob = success_prob, o.score_initial_model = score_initial != 0;
+    o.progressive_sampling = g_hm_prosac != 0, o.max_prosac_iterations = g_hm_max_prosac;
     o.max_error = max_error;
     o.max_focal = focal_max_focal_length(pa[0], pa[1], n, min_fov);
     HostFocalBackend be{pa, n, seed, max_error * max_error, max_error, o.max_focal};
@@ -895,14 +905,18 @@ struct HostSFocalBackend {
         }
     }
     int minimal(uint64_t pos_base, const uint32_t *positions, uint32_t B, std::vector<FocalModel> &models,
-                std::vector<uint32_t> &num_models, std::vector<uint32_t> &counts, std::vector<double> &sums) {
+                std::vector<uint32_t> &num_models, std::vector<uint32_t> &counts, std::vector<double> &sums, const uint32_t *samples = nullptr) {
         models.assign((size_t)B * kSFocalMaxModels, FocalModel());
         num_models.assign(B, 0);
         counts.assign((size_t)B * kSFocalMaxModels, 0);
         sums.assign((size_t)B * kSFocalMaxModels, 0.0);
         for (uint32_t it = 0; it < B; ++it) {
             uint32_t idx[kSFocalSample];
-            draw_sample<kSFocalSample>(seed, pos_base + positions[it], n, idx);
+            if (samples)
+                for (int k = 0; k < kSFocalSample; ++k)
+                    idx[k] = samples[(size_t)it * kSFocalSample + k];
+            else
+                draw_sample<kSFocalSample>(seed, pos_base + positions[it], n, idx);
             Vec3 a[6], b[6];
             for (int k = 0; k < 6; ++k) {
                 a[k] = bearing(pa[0][idx[k]], pa[1][idx[k]]);
@@ -953,6 +967,7 @@ extern "C" void hm_ransac_shared_focal(const double *const *pa, uint32_t n, uint
     FocalLoopOptions o;
     o.max_iterations = max_iterations, o.min_iterations = min_iterations, o.seed = seed;
     o.dyn_num_trials_mult = dyn_mult, o.success_prob = success_prob, o.score_initial_model = score_initial != 0;
+    o.progressive_sampling = g_hm_prosac != 0, o.max_prosac_iterations = g_hm_max_prosac;
     o.max_error = max_error;
     o.max_focal = -1.0;
     HostSFocalBackend be{pa, n, seed, max_error * max_error, max_error};

@@ -288,6 +288,11 @@ def ransac_shared_focal(x1, x2, max_error=1.0, seed=0, max_iterations=100000, mi
                                                      "model_score": score.value}
 
 
+def set_prosac(on: bool, max_prosac_iterations: int = 100000):
+    """PROSAC sampling (sampling.cc:85-136) for ransac_pnpf / ransac_shared_focal below"""
+    lib().hm_set_prosac(C.c_int(int(bool(on))), C.c_uint64(max_prosac_iterations))
+
+
 def ransac_pnpf(x, X, max_error=12.0, seed=0, max_iterations=100000, min_iterations=1000, dyn_mult=3.0, success_prob=0.9999,
                 score_initial=False, min_fov=5.0):
     """the product's ransac_pnpf loop (pl_focal.h) over a serial evaluation of the device functions.

@@ -34,7 +34,7 @@ class BundleOpt(C.Structure):
 
 class RobustOpt(C.Structure):
     _fields_ = [("ransac", RansacOpt), ("bundle", BundleOpt), ("max_error", f64), ("real_focal_check", i32),
-                ("estimate_focal_length", i32)]
+                ("estimate_focal_length", i32), ("min_fov", f64)]
 
 
 class Stats(C.Structure):
@@ -113,7 +113,7 @@ def bundle_opt(d=None) -> BundleOpt:
 def robust_opt(d=None, default_max_error=1.0) -> RobustOpt:
     d = d or {}
     return RobustOpt(ransac_opt(d.get("ransac")), bundle_opt(d.get("bundle")), d.get("max_error", default_max_error),
-                     int(d.get("real_focal_check", False)), int(d.get("estimate_focal_length", False)))
+                     int(d.get("real_focal_check", False)), int(d.get("estimate_focal_length", False)), float(d.get("min_fov", 5.0)))
 
 
 def camera(d) -> Camera:

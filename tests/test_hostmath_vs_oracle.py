@@ -419,3 +419,41 @@ def test_p35pf_hostile_inputs_terminate_and_agree():
             po, fo = O.p35pf(x, X)
             ph, fh = HM.p35pf(x, X, stride=1 + k % 3)
             assert po.shape == ph.shape and np.array_equal(po, ph, equal_nan=True) and np.array_equal(fo, fh, equal_nan=True), k
+
+
+def test_focal_loops_with_prosac_sampling_take_the_oracles_decisions():
+    """progressive_sampling (sampling.cc:85-136) in the two focal-length estimators: the reference constructs their sampler from
+    opt.ransac like every other estimator's (absolute_pose.h:80, relative_pose.h:155).  The product's loop template draws the PROSAC
+    samples on the host (pl_sampler.h ProsacSampler) and hands them to the generators explicitly; decisions and models equal the
+    oracle's, including the cross-over to uniform sampling after max_prosac_iterations."""
+    HM.set_prosac(True, 100000)
+    try:
+        for seed in range(4):
+            n = [600, 250, 1500, 50][seed]
+            d = synth.absolute_pose_scene(n, [0.3, 0.5, 0.4, 0.2][seed], 8600 + seed, noise_px=0.5)
+            x = _centered(d)
+            ro = {"seed": seed, "progressive_sampling": True}
+            op, of, om, ost = O.ransac_pnpf(x, d["p3d"], {"max_error": 4.0, "ransac": ro})
+            hp, hf, hm, hst = HM.ransac_pnpf(x, d["p3d"], max_error=4.0, seed=seed)
+            for k in ("iterations", "refinements", "num_inliers", "hypotheses", "model_score"):
+                assert hst[k] == ost[k], (seed, k, hst[k], ost[k])
+            assert np.array_equal(hm, om) and np.array_equal(hp, op) and hf == of, seed
+        for seed, n in [(0, 800), (1, 300)]:
+            d = synth.relative_pose_scene(n, 0.3, 8700 + seed)
+            f, cx, cy = d["camera1"]["params"]
+            a, b = (d["x1"] - [cx, cy]) / 500.0, (d["x2"] - [cx, cy]) / 500.0
+            po, fo, mo, so = O.ransac_shared_focal_relpose(a, b, {"max_error": 2.0 / 500, "ransac": {"seed": seed, "max_iterations": 3000, "progressive_sampling": True}})
+            ph, fh, mh, sh = HM.ransac_shared_focal(a, b, max_error=2.0 / 500, seed=seed, max_iterations=3000)
+            assert np.array_equal(po, ph) and fo == fh and np.array_equal(mo, mh), seed
+            for k in ("iterations", "refinements", "num_inliers", "model_score"):
+                assert so[k] == sh[k], (seed, k)
+        # the cross-over: uniform sampling after max_prosac_iterations
+        HM.set_prosac(True, 400)
+        d = synth.absolute_pose_scene(700, 0.5, 8650, noise_px=0.5)
+        x = _centered(d)
+        op, of, om, ost = O.ransac_pnpf(x, d["p3d"], {"max_error": 4.0, "ransac": {"seed": 3, "progressive_sampling": True, "max_prosac_iterations": 400}})
+        hp, hf, hm, hst = HM.ransac_pnpf(x, d["p3d"], max_error=4.0, seed=3)
+        assert hst["iterations"] == ost["iterations"] and hst["refinements"] == ost["refinements"] and hst["model_score"] == ost["model_score"]
+        assert np.array_equal(hm, om) and np.array_equal(hp, op) and hf == of
+    finally:
+        HM.set_prosac(False)

@@ -76,8 +76,18 @@ def test_ransac_pnpf_iteration_budgets_and_degenerate_sizes(gpu):
     img, info = gpu.ransac_pnpf(x[:3], d["p3d"][:3], {"max_error": 3.0})
     assert info["iterations"] == 0 and img.camera.params[0] == 1.0 and np.array_equal(np.r_[img.pose.q, img.pose.t], ref[0])
     assert np.array_equal(np.asarray(info["inliers"], dtype=bool), ref[2])
-    with pytest.raises(gpu.PoseLibAmdError):
-        gpu.ransac_pnpf(x, d["p3d"], {"ransac": {"progressive_sampling": True}})
+    # PROSAC (sampling.cc:85-136; absolute_pose.h:80 constructs the sampler from opt.ransac): host-drawn samples, the oracle's decisions
+    for ro in ({"seed": 2, "progressive_sampling": True}, {"seed": 3, "progressive_sampling": True, "max_prosac_iterations": 300}):
+        opt = {"max_error": 3.0, "ransac": ro}
+        ref = O.ransac_pnpf(x, d["p3d"], opt)
+        img, info = gpu.ransac_pnpf(x, d["p3d"], opt)
+        _check(ro, img, info, ref, exact=True)
+    # min_fov (types.h:126, absolute_pose.h:78): the bound on the focal length is an option, not a constant; <= 0 disables it
+    for fov in (5.0, 40.0, 0.0):
+        opt = {"max_error": 3.0, "min_fov": fov, "ransac": {"seed": 11}}
+        ref = O.ransac_pnpf(x, d["p3d"], opt)
+        img, info = gpu.ransac_pnpf(x, d["p3d"], opt)
+        _check(("min_fov", fov), img, info, ref, exact=True)
     with pytest.raises(gpu.PoseLibAmdError):  # the calibrated entry point does not estimate focal lengths
         gpu.ransac_pnp(x, d["p3d"], {"estimate_focal_length": True})
 

@@ -111,8 +111,13 @@ def test_refine_shared_focal_relpose_bit_exact(gpu, n):
 def test_shared_focal_rejections(gpu):
     d = synth.relative_pose_scene(100, 0.2, 9200)
     a, b, f = _centered(d, 500.0)
-    with pytest.raises(gpu.PoseLibAmdError):
-        gpu.ransac_shared_focal_relpose(a, b, {"max_error": 0.01, "ransac": {"progressive_sampling": True}})
+    # PROSAC is served (host-drawn samples, relative_pose.h:155): the oracle's run bit for bit
+    opt = {"max_error": 0.01, "ransac": {"progressive_sampling": True, "seed": 4, "max_iterations": 2000}}
+    po, fo, mo, so = O.ransac_shared_focal_relpose(a, b, opt)
+    pair, info = gpu.ransac_shared_focal_relpose(a, b, opt)
+    assert (info["iterations"], info["refinements"], info["num_inliers"]) == (so["iterations"], so["refinements"], so["num_inliers"])
+    assert np.array_equal(np.r_[pair.pose.q, pair.pose.t], po) and pair.camera1.params[0] == fo
+    assert np.array_equal(np.asarray(info["inliers"], dtype=bool), mo)
     with pytest.raises(gpu.PoseLibAmdError):
         gpu.ransac_shared_focal_relpose(a, b, {"max_error": 0.01, "tangent_sampson": True})
 
