@@ -78,12 +78,9 @@ void set_simple_pinhole(Camera *c, double f, double cx, double cy) {
     c->width = c->height = -1;
     c->params = {f, cx, cy};
 }
-// Camera::focal() of a camera these entry points can receive
-double focal_of(const Camera &c) {
-    if (c.params.empty())
-        return 1.0;
-    return c.model_id == SimplePinholeCameraModel::model_id ? c.params[0] : 0.5 * (c.params[0] + c.params[1]);
-}
+// Camera::focal() itself (misc/camera_models.cc is compiled into the binding: the model's own focal_idx decides, e.g. params[0] alone
+// for SIMPLE_RADIAL / SIMPLE_DIVISION - ADVICE r3)
+double focal_of(const Camera &c) { return c.params.empty() ? 1.0 : c.focal(); }
 
 pl_camera_pose to_pl(const CameraPose &p) {
     pl_camera_pose q;

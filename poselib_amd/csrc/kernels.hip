@@ -1469,10 +1469,12 @@ template <int EST> __device__ __forceinline__ void score_seq_body(const SeqScore
                 // utils.cc:59 / :193 / :233 / :323, in correspondence order: a chain of dependent additions.  64 terms per inline-asm
                 // statement (pl_lm_chain.inc: two terms per ds_read_b128, the reads six pairs ahead of the additions): 11.7 cycles
                 // per term against 17 - 32 for the compiler's schedule of the same loop (scripts/exp/chain_add.cc)
+                __builtin_amdgcn_s_setprio(3); // (a chain of dependent additions: first in line for the SIMD's issue port)
                 for (uint32_t j = 0; j < total; j += 64) {
                     const uint32_t addr = (uint32_t)(uintptr_t)&s_list[j];
                     PL_LM_CHAIN64(sum, addr); // (+0.0 beyond `total`)
                 }
+                __builtin_amdgcn_s_setprio(0);
                 s_sum = sum;
                 if constexpr (EST == EST_ABS)
                     count += total;
@@ -1989,6 +1991,10 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
             pass(cur, kJac, normal);
             jac_count = s_count_j;
         }
+        // (the one lane that solves is a chain of dependent fp64 operations: with other kernels' wavefronts on the SIMD it gets an issue slot
+        // every few instructions only - priority 3 for the serial sections, measured on the mixed batch)
+        if (threadIdx.x < 64)
+            __builtin_amdgcn_s_setprio(3);
         if (threadIdx.x == 0) {
             lm_solve<K>(ctl, normal, fresh, jac_count);
             if (!ctl.done) {
@@ -1999,10 +2005,14 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                                                   // iteration computes from the accepted parameters)
             }
         }
+        if (threadIdx.x < 64)
+            __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (ctl.done)
             break;
         pass(trial, fuse ? kBoth : kRes, normal_next);
+        if (threadIdx.x < 64)
+            __builtin_amdgcn_s_setprio(3);
         if (threadIdx.x == 0) {
             const bool accepted = lm_update<K>(ctl, normal, s_racc[0], s_count);
             if (accepted)
@@ -2010,6 +2020,8 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                     cur[i] = trial[i];
             s_accepted = accepted ? 1 : 0;
         }
+        if (threadIdx.x < 64)
+            __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         have_next = fuse && s_accepted != 0;
         if (have_next) {
@@ -2196,6 +2208,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads, (EST == EST_HOM ? 2 
             const bool mine = (jac && lane < NT) || (res && lane == NT);
             const int col = mine ? lane : 0;
             double tot = 0.0;
+            __builtin_amdgcn_s_setprio(3); // (the chain of dependent additions is the critical path of the pass)
             for (uint32_t j = 0; j < nbatch; ++j) {
                 const uint32_t g = seq_base + j + 1u;
                 const uint32_t slot = g % (uint32_t)kRingSlots;
@@ -2214,6 +2227,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads, (EST == EST_HOM ? 2 
                 if (lane == 0)
                     __hip_atomic_store(&s_consumed, g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            __builtin_amdgcn_s_setprio(0);
             if (jac && lane < NT)
                 out[lane] = tot;
             if (res && lane == NT)
@@ -2340,6 +2354,10 @@ template <int EST> __global__ __launch_bounds__(kLMThreads, (EST == EST_HOM ? 2 
             pass(cur, kJac, normal);
             jac_count = s_count_j;
         }
+        // (the one lane that solves is a chain of dependent fp64 operations: with other kernels' wavefronts on the SIMD it gets an issue slot
+        // every few instructions only - priority 3 for the serial sections, measured on the mixed batch)
+        if (threadIdx.x < 64)
+            __builtin_amdgcn_s_setprio(3);
         if (threadIdx.x == 0) {
             lm_solve<K>(ctl, normal, fresh, jac_count);
             if (!ctl.done) {
@@ -2350,10 +2368,14 @@ template <int EST> __global__ __launch_bounds__(kLMThreads, (EST == EST_HOM ? 2 
                                                   // iteration computes from the accepted parameters)
             }
         }
+        if (threadIdx.x < 64)
+            __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (ctl.done)
             break;
         pass(trial, fuse ? kBoth : kRes, normal_next);
+        if (threadIdx.x < 64)
+            __builtin_amdgcn_s_setprio(3);
         if (threadIdx.x == 0) {
             const bool accepted = lm_update<K>(ctl, normal, s_racc[0], s_count);
             if (accepted)
@@ -2361,6 +2383,8 @@ template <int EST> __global__ __launch_bounds__(kLMThreads, (EST == EST_HOM ? 2 
                     cur[i] = trial[i];
             s_accepted = accepted ? 1 : 0;
         }
+        if (threadIdx.x < 64)
+            __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         have_next = fuse && s_accepted != 0;
         if (have_next) {

@@ -383,7 +383,10 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
         return hipSuccess;
     constexpr size_t bytes = sizeof(double) * kSixWorkDoubles * kGenLanes; // 137.6 KB of the CU's 160 KB
-    static std::atomic<int> prepared{0};
+    static std::atomic<int> prepared_dev[64]; // per device ordinal: the attribute is per-device state on some runtimes
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    std::atomic<int> &prepared = prepared_dev[dev_ & 63];
     if (!prepared.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_generate),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -398,7 +401,10 @@ hipError_t launch_sfocal_solve(const double *in, uint32_t count, FocalModel *mod
     if (count == 0)
         return hipSuccess;
     constexpr size_t bytes = sizeof(double) * kSixWorkDoubles * kGenLanes;
-    static std::atomic<int> prepared{0};
+    static std::atomic<int> prepared_dev[64]; // per device ordinal: the attribute is per-device state on some runtimes
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    std::atomic<int> &prepared = prepared_dev[dev_ & 63];
     if (!prepared.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)bytes);
