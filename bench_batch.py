@@ -18,6 +18,10 @@ import os
 import sys
 import time
 
+# one HIP stream per worker of pl_estimate_batch: 16 hardware queues instead of the runtime's default 4 (read when HIP initialises -
+# torch does that below, before the library's own default at load time could apply); see bench.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -71,8 +75,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--problems", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=3, help="untimed calls (the workers' device arenas grow during the first two)")
+    ap.add_argument("--streams", type=int, default=10, help="host threads inside pl_estimate_batch")
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -117,7 +121,6 @@ def main():
         """the whole shard in ONE library call: problems of the same kind advance in groups through one launch sequence,
         S host threads inside the library work on groups concurrently"""
         batch.run(max_in_flight=S)
-        return int(batch.stats()[2].sum())
 
     def records():
         out = []
@@ -144,10 +147,11 @@ def main():
     t0 = time.perf_counter()
     hyp = 0
     res = None
-    for _ in range(args.steps):
-        hyp += run_shard()
+    for _ in range(args.steps):  # (nothing but the C-ABI call in the timed loop)
+        run_shard()
     sync()
     elapsed = time.perf_counter() - t0
+    hyp = args.steps * int(batch.stats()[2].sum())  # every step runs the same problems with the same seeds
     res = records()
 
     local = np.stack([r[0] for r in res]) if res else np.zeros((0, sharding.RECORD_DOUBLES))

@@ -1,0 +1,60 @@
+# Round-4 evidence run (MI355X box).  Outputs under gpurun_out/evidence_r04; scripts/make_profiles_r04.py turns them into profiles/r04_*.
+#   part 1 (this file, argument "a"): GPU suite, the contract bench line + detail, batch trace (configs[4]) with occupancy, LM timings in
+#           both summation modes, the micro-experiments (VALU issue table is committed separately: profiles/r04_valu_issue.md)
+#   part 2 (argument "b"): kernel traces of the four throughput workloads (grouped and one problem at a time), PMC passes of the dominant kernels
+cd $GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/evidence_r04
+mkdir -p $O
+PART=${1:-a}
+cd /tmp && export TMPDIR=/tmp
+Q="--no-parity --no-cpu-baseline --no-secondary --detail-file /tmp/_detail.json"
+if [ "$PART" = "a" ]; then
+  cd $R
+  timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu.log
+  timeout 900 python bench.py --steps 20 --warmup 5 --detail-file $O/detail_default.json > $O/bench_default.json 2> $O/bench_default.err
+  timeout 300 python bench.py --mode streams --streams 1 --no-secondary --no-cpu-baseline --steps 10 --detail-file $O/detail_s1.json > $O/bench_s1.json 2> $O/bench_s1.err
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_batch -o r -- python $R/bench_batch.py --problems 4096 --streams 10 --steps 4 --warmup 3 --no-cpu-baseline > $O/prof_batch.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_batch -o k -- python $R/bench_batch.py --problems 4096 --streams 10 --steps 4 --warmup 3 --no-cpu-baseline > $O/kt_batch.log 2>&1
+  cd $R
+  timeout 300 python scripts/batch_sweep.py 4096 8:0:0 8:0:3 10:0:3 12:0:3 16:128:3 > $O/batch_sweep.log 2>&1
+  POSELIB_AMD_LM_ORDERED=1 timeout 300 python scripts/batch_sweep.py 4096 10:0:3 > $O/batch_sweep_ordered.log 2>&1
+  POSELIB_AMD_GROUP_TIMING=1 timeout 200 python scripts/batch_sweep.py 4096 10:0:3 2>&1 | tail -3 > $O/batch_timing.log
+  for l in truncated cauchy; do
+    timeout 300 python scripts/time_lm.py $l > $O/time_lm_tree_$l.log 2>&1
+    POSELIB_AMD_LM_ORDERED=1 timeout 300 python scripts/time_lm.py $l > $O/time_lm_ordered_$l.log 2>&1
+  done
+  timeout 100 scripts/exp/chain_add > $O/chain_add.log 2>&1
+  timeout 100 scripts/exp/mfma_f64_order > $O/mfma_f64_order.log 2>&1
+  timeout 120 python scripts/time_focal_estimators.py 5 > $O/focal_timing.log 2>&1
+  f=$(find $O/prof_batch -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/prof_batch.md
+  python scripts/busy.py $(find $O/kt_batch -name "*kernel_trace.csv") 0.45 > $O/busy_batch.txt
+  python scripts/chain_view.py $(find $O/kt_batch -name "*kernel_trace.csv") > $O/chain_batch.txt
+  find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+  cat $O/pytest_gpu.log; tail -c 900 $O/bench_default.json; tail -3 $O/bench_default.err; head -3 $O/busy_batch.txt; cat $O/batch_sweep.log
+else
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_default -o r -- python $R/bench.py $Q --steps 5 > $O/prof_default.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_s1 -o r -- python $R/bench.py $Q --mode streams --streams 1 --steps 5 > $O/prof_s1.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_default -o k -- python $R/bench.py $Q --steps 3 > $O/kt_default.log 2>&1
+  for w in relpose_5000 fund_10000 hom_10000; do
+    timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$w -o r -- python $R/bench.py $Q --workload $w --mode streams --streams 1 --steps 3 > $O/prof_$w.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --stats -d $O/profg_$w -o r -- python $R/bench.py $Q --workload $w --steps 3 > $O/profg_$w.log 2>&1
+  done
+  for w in p3p_5000 relpose_5000 fund_10000 hom_10000; do
+    B1="python $R/bench.py $Q --workload $w --mode streams --streams 1 --steps 2 --warmup 1"
+    timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq_$w -o p -- $B1 > $O/pmc_sq_$w.log 2>&1
+    timeout 300 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq2_$w -o p -- $B1 > $O/pmc_sq2_$w.log 2>&1
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$w -o p -- $B1 > $O/pmc_fetch_$w.log 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$w -o p -- $B1 > $O/pmc_write_$w.log 2>&1
+  done
+  cd $R
+  for d in prof_default prof_s1 prof_relpose_5000 prof_fund_10000 prof_hom_10000 profg_relpose_5000 profg_fund_10000 profg_hom_10000; do f=$(find $O/$d -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/$d.md; done
+  python scripts/busy.py $(find $O/kt_default -name "*kernel_trace.csv") > $O/busy_default.txt
+  for w in p3p_5000 relpose_5000 fund_10000 hom_10000; do
+    python scripts/pmc_summary.py $(find $O/pmc_sq_$w $O/pmc_sq2_$w $O/pmc_fetch_$w $O/pmc_write_$w -name "*counter_collection.csv") > $O/pmc_$w.md
+  done
+  find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
+  head -8 $O/prof_default.md | cut -c1-170; head -3 $O/busy_default.txt; head -5 $O/pmc_p3p_5000.md | cut -c1-300
+fi
