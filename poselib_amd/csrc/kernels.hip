@@ -2106,7 +2106,11 @@ template <int EST> __global__ __launch_bounds__(kLMThreads, (EST == EST_HOM ? 2 
     __shared__ int s_skip;
     // Ring of term rows between the producer wavefronts (1 .. 7) and the consumer (wavefront 0), see `pass`: one slot = the rows of
     // 64 correspondences (x 2 for the homography's forward / backward blocks), a row = the NT entries of [J^T J lower triangle | J^T r]
-    // followed by the correspondence's robust-cost term.
+    // followed by the correspondence's robust-cost term.  Measured and dropped (n = 5000, us per LM iteration; this form: 44): slots
+    // of 128 rows filled in two producer rounds (55.6: a producer holds its slot twice as long, the consumer waits), the next
+    // slot's flag read inside the consumer's asm block (47.5: the flag is rarely ahead), 15 producers (46.6), two workgroups per
+    // CU at 128 registers (44.2).  With producers that only write zero rows the pass still takes 37 us: the consumer's 17.8
+    // cycles per row inside the workgroup (11.7 alone on a CU) are the bound, the producers' arithmetic adds 7.
     constexpr int SUB = (EST == EST_HOM) ? 2 : 1;
     constexpr int kRingSlots = (EST == EST_HOM) ? 2 : 3;
     // column-major: s_ring[slot][entry][row] - the consumer lane of an entry reads ITS rows as adjacent doubles (two per ds_read_b128);
