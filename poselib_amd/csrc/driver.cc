@@ -219,7 +219,14 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 std::atomic<uint64_t> g_t_wait_ns{0}, g_t_group_ns{0}, g_t_prep_ns{0}, g_t_fallback_ns{0}, g_n_waits{0}, g_n_fallback{0};
 const bool g_group_timing = std::getenv("POSELIB_AMD_GROUP_TIMING") != nullptr;
 hipError_t wait_stream_impl(Context *c);
+// host work a worker of pl_estimate_batch does INSTEAD of idling at its next wait (staging the next group's inputs); one shot
+thread_local std::function<void()> g_wait_hook;
 hipError_t wait_stream(Context *c) {
+    if (g_wait_hook) {
+        std::function<void()> h;
+        h.swap(g_wait_hook);
+        h();
+    }
     if (!g_group_timing)
         return wait_stream_impl(c);
     const double t0 = now_s();
@@ -2835,6 +2842,7 @@ struct BatchPool {
     std::vector<std::thread> threads;
     // current batch: a list of jobs (a group of problems, or one problem on its own)
     std::vector<std::function<void()>> *jobs = nullptr;
+    std::vector<std::function<void()>> *stages = nullptr; // optional, per job: its host-side staging, run ahead by the worker that claims it
     std::atomic<size_t> next{0};
     int device = 0;
     uint64_t generation = 0;
@@ -2855,11 +2863,24 @@ struct BatchPool {
                 mine = jobs;
             }
             g_requested_device = device;
+            std::vector<std::function<void()>> *mine_stages = stages;
+            size_t claimed = (size_t)-1; // a job this worker claimed (and staged) while waiting for the device with the previous one
             for (;;) {
-                const size_t i = next.fetch_add(1);
+                const size_t i = claimed != (size_t)-1 ? claimed : next.fetch_add(1);
+                claimed = (size_t)-1;
                 if (i >= mine->size())
                     break;
+                if (mine_stages) // at this job's first wait: claim the next one and do its staging
+                    g_wait_hook = [this, mine, mine_stages, &claimed] {
+                        const size_t i2 = next.fetch_add(1);
+                        if (i2 < mine->size()) {
+                            claimed = i2;
+                            if ((*mine_stages)[i2])
+                                (*mine_stages)[i2]();
+                        }
+                    };
                 (*mine)[i]();
+                g_wait_hook = nullptr;
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -2868,7 +2889,7 @@ struct BatchPool {
             }
         }
     }
-    int run(std::vector<std::function<void()>> &js, int in_flight, int dev) {
+    int run(std::vector<std::function<void()>> &js, int in_flight, int dev, std::vector<std::function<void()>> *stage_fns = nullptr) {
         // `mu` alone is not enough: done.wait() releases it, and a second caller would overwrite the job state while
         // the first batch's workers are still running
         std::lock_guard<std::mutex> one_batch(run_mu);
@@ -2878,12 +2899,14 @@ struct BatchPool {
             threads.back().detach();
         }
         jobs = &js, device = dev;
+        stages = (stage_fns && stage_fns->size() == js.size()) ? stage_fns : nullptr;
         next.store(0);
         wanted = in_flight, joined = 0, running = 0;
         generation++;
         wake.notify_all();
         done.wait(lk, [&] { return joined == wanted && running == 0; });
         jobs = nullptr;
+        stages = nullptr;
         wanted = 0;
         return PL_OK;
     }
@@ -2932,7 +2955,8 @@ void run_group_job(std::vector<GroupItem *> &items, bool resume) {
     if (rc == PL_OK) {
         if (!resume)
             for (GroupItem *g : items)
-                group_prepare_item(*g);
+                if (!g->prepared)
+                    group_prepare_item(*g);
         t1 = now_s();
         rc = run_group(c, items.data(), (uint32_t)items.size(), false, resume ? 0u : group_step_budget(), resume);
     }
@@ -3066,21 +3090,45 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     const size_t group_max = group_env ? (size_t)group_env
                                        : std::min<size_t>(kGroupMaxAuto, std::max<size_t>(kGroupMax / 2, (eligible + 2 * workers - 1) / (2 * workers)));
     std::vector<std::vector<GroupItem>> groups;
+    // A first round of SMALL groups, one per worker, taken from the small end of every kind's list: a group starts with the copy of its
+    // raw correspondences into pinned memory (0.1 MB per problem) during which the device has nothing to do - 2.5 ms for a group of
+    // 230 problems at the start of every call.  From its second group on a worker copies the NEXT group's points while it waits
+    // for the device (group_stage_in); the first round makes that start after ~0.6 ms instead.
+    const size_t first_sz = 64;
+    size_t n_first_groups = 0;
+    auto emit = [&](int k, const std::vector<size_t> &v, size_t lo, size_t hi) {
+        groups.emplace_back();
+        for (size_t j = lo; j < hi; ++j) {
+            GroupItem g;
+            g.item = &items[v[j]];
+            g.kind = k;
+            groups.back().push_back(g);
+        }
+    };
+    std::vector<size_t> rest_lo(4, 0), rest_hi(4, 0);
+    const bool first_round = !group_env && eligible >= 4 * workers * first_sz;
     for (int k = 0; k < 4; ++k) {
         std::vector<size_t> &v = by_kind[k];
         std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].n > items[b].n; });
-        // equal shares: ceil(n / group_max) groups of (almost) the same size instead of full groups and a small last one
-        const size_t ngrp = (v.size() + group_max - 1) / group_max;
-        const size_t gsize = ngrp ? (v.size() + ngrp - 1) / ngrp : 1;
-        for (size_t at = 0; at < v.size(); at += gsize) {
-            groups.emplace_back();
-            for (size_t j = at; j < std::min(v.size(), at + gsize); ++j) {
-                GroupItem g;
-                g.item = &items[v[j]];
-                g.kind = k;
-                groups.back().push_back(g);
+        size_t hi = v.size();
+        if (first_round && eligible) {
+            const size_t want = (workers * v.size() + eligible / 2) / eligible; // this kind's share of the first round
+            for (size_t f = 0; f < want && hi >= 2 * first_sz; ++f) {
+                emit(k, v, hi - first_sz, hi);
+                hi -= first_sz;
+                ++n_first_groups;
             }
         }
+        rest_hi[k] = hi;
+    }
+    for (int k = 0; k < 4; ++k) {
+        std::vector<size_t> &v = by_kind[k];
+        const size_t cnt = rest_hi[k];
+        // equal shares: ceil(n / group_max) groups of (almost) the same size instead of full groups and a small last one
+        const size_t ngrp = (cnt + group_max - 1) / group_max;
+        const size_t gsize = ngrp ? (cnt + ngrp - 1) / ngrp : 1;
+        for (size_t at = 0; at < cnt; at += gsize)
+            emit(k, v, at, std::min(cnt, at + gsize));
     }
     // the long jobs first: a group's time grows with its correspondences, and a 5-point problem costs about twice a P3P or
     // homography problem of the same size (generator + Sampson scorer + LO with a pre-filter; profiles/r03_bench_batch_mixed_*)
@@ -3091,29 +3139,33 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
         for (const GroupItem &g : groups[gi])
             cost[gi] += (double)g.item->n * (g.kind == EST_REL ? 2.0 : (g.kind == EST_HOM ? 1.2 : 1.0));
     }
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+    std::stable_sort(order.begin() + (std::ptrdiff_t)n_first_groups, order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
     std::vector<std::vector<GroupItem *>> group_ptrs(groups.size());
     for (size_t gi = 0; gi < groups.size(); ++gi)
         for (GroupItem &g : groups[gi])
             group_ptrs[gi].push_back(&g);
+    std::vector<std::function<void()>> stage_fns;
     for (size_t gi : order) {
         std::vector<GroupItem *> *grp = &group_ptrs[gi];
         jobs.emplace_back([grp] { run_group_job(*grp, false); });
+        stage_fns.emplace_back([grp] { group_stage_in(grp->data(), (uint32_t)grp->size()); });
     }
-    for (size_t i : solo)
+    for (size_t i : solo) {
         jobs.emplace_back([items, i] {
             items[i].status = run_item(items[i]);
             if (items[i].status != PL_OK)
                 note_worker_error();
         });
+        stage_fns.emplace_back(); // (nothing to stage)
+    }
     int w = max_in_flight <= 0 ? 8 : std::min(max_in_flight, 64);
     w = (int)std::min<size_t>((size_t)w, jobs.size());
     (void)take_worker_error();
     g_group_workers.store(std::max(w, 1));
     const double t_pool = now_s();
     if (g_group_timing)
-        g_t_wait_ns = g_t_group_ns = g_t_prep_ns = g_t_fallback_ns = g_n_waits = g_n_fallback = 0;
-    batch_pool_instance().run(jobs, w, g_requested_device);
+        g_t_wait_ns = g_t_group_ns = g_t_prep_ns = g_t_fallback_ns = g_n_waits = g_n_fallback = 0, g_t_stageA = g_t_args = g_t_imp = g_t_lmtasks = g_t_replay = g_t_tail = 0;
+    batch_pool_instance().run(jobs, w, g_requested_device, &stage_fns);
     // ---- second round: the problems that were still running when their group's step budget ended (the long runs: 5-point problems
     // with 60 - 70 % outliers need ~10^4 iterations), regrouped by kind, every step as large as the loop is known to need ----
     {
@@ -3151,6 +3203,10 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
                      count, groups.size(), solo.size(), w, (now_s() - t_pool) * 1e3, g_t_prep_ns.load() * 1e-6, g_t_group_ns.load() * 1e-6,
                      g_t_wait_ns.load() * 1e-6, (unsigned long long)g_n_waits.load(), g_t_fallback_ns.load() * 1e-6,
                      (unsigned long long)g_n_fallback.load());
+    if (g_group_timing)
+        std::fprintf(stderr, "poselib_amd:   host phases incl. their waits (ms): stage A %.1f, step arguments %.1f, records -> jobs %.1f, LM tasks %.1f, replay (+ what follows in the step) %.1f, "
+                             "stages D + E %.1f\n", g_t_stageA.load() * 1e-6, g_t_args.load() * 1e-6, g_t_imp.load() * 1e-6, g_t_lmtasks.load() * 1e-6,
+                     g_t_replay.load() * 1e-6, g_t_tail.load() * 1e-6);
     const std::string werr = take_worker_error();
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
