@@ -78,9 +78,24 @@ void set_simple_pinhole(Camera *c, double f, double cx, double cy) {
     c->width = c->height = -1;
     c->params = {f, cx, cy};
 }
-// Camera::focal() itself (misc/camera_models.cc is compiled into the binding: the model's own focal_idx decides, e.g. params[0] alone
-// for SIMPLE_RADIAL / SIMPLE_DIVISION - ADVICE r3)
-double focal_of(const Camera &c) { return c.params.empty() ? 1.0 : c.focal(); }
+// Camera::focal() (misc/camera_models.cc:304-321: the mean of the parameters at the model's focal_idx) without linking the camera
+// models: models with ONE focal length (focal_idx = {0}: SIMPLE_PINHOLE, SIMPLE_RADIAL, RADIAL, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE,
+// SIMPLE_DIVISION) return params[0], models without one (1D_RADIAL, SPHERICAL) 1, all others fx and fy (focal_idx = {0, 1}).  ADVICE r3:
+// the round-3 form averaged f and cx for the single-focal models other than SIMPLE_PINHOLE.
+double focal_of(const Camera &c) {
+    if (c.params.empty())
+        return 1.0;
+    const int id = c.model_id;
+    if (id == SimplePinholeCameraModel::model_id || id == SimpleRadialCameraModel::model_id || id == RadialCameraModel::model_id ||
+        id == SimpleRadialFisheyeCameraModel::model_id || id == RadialFisheyeCameraModel::model_id || id == SimpleDivisionCameraModel::model_id)
+        return c.params[0];
+    if (id == Radial1DCameraModel::model_id || id == SphericalCameraModel::model_id)
+        return 1.0;
+    double f = 0.0; // (the reference's association: 0 + p0 / 2 + p1 / 2)
+    f += c.params.at(0) / 2;
+    f += c.params.at(1) / 2;
+    return f;
+}
 
 pl_camera_pose to_pl(const CameraPose &p) {
     pl_camera_pose q;
