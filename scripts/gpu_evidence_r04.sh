@@ -58,3 +58,34 @@ else
   find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
   head -8 $O/prof_default.md | cut -c1-170; head -3 $O/busy_default.txt; head -5 $O/pmc_p3p_5000.md | cut -c1-300
 fi
+# part "c" (separate call): steady-state occupancy of configs[4] - pl_estimate_batch calls back to back (scripts/batch_sweep.py: 3 warm-up
+# + 4 timed calls, nothing else on the device), the last half of the kernel span; bench_batch.py's own trace ends with Python-side
+# record marshalling and the gather, which is not the library's time
+if [ "$PART" = "c" ]; then
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_sweep -o k -- python $R/scripts/batch_sweep.py 4096 10:0:3 > $O/kt_sweep.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_sweep -o r -- python $R/scripts/batch_sweep.py 4096 10:0:3 > $O/prof_sweep.log 2>&1
+  cd $R
+  f=$(find $O/kt_sweep -name "*kernel_trace.csv" | head -1)
+  python scripts/busy.py $f 0.5 > $O/busy_sweep.txt
+  python scripts/chain_view.py $f > $O/chain_sweep.txt
+  python - "$f" > $O/shares_sweep.txt <<'PY'
+import csv, collections, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1]))]
+for r in rows:
+    r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"]); r["n"] = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pl::", "")
+t0 = min(r["s"] for r in rows); t1 = max(r["e"] for r in rows); cut = t0 + 0.5 * (t1 - t0)
+sel = [r for r in rows if r["s"] >= cut]
+tot = collections.defaultdict(float); cnt = collections.Counter()
+for r in sel:
+    tot[r["n"]] += (r["e"] - r["s"]) / 1e3; cnt[r["n"]] += 1
+T = sum(tot.values())
+print(f"last half of the kernel span: {(t1 - cut) / 1e6:.1f} ms, {len(sel)} dispatches, summed kernel time {T / 1e3:.1f} ms")
+print("| kernel | dispatches | summed ms | share of GPU time | avg us |\n|---|---|---|---|---|")
+for n, v in sorted(tot.items(), key=lambda kv: -kv[1]):
+    print(f"| `{n}` | {cnt[n]} | {v / 1e3:.2f} | {100 * v / T:.1f} % | {v / cnt[n]:.1f} |")
+PY
+  f=$(find $O/prof_sweep -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/prof_sweep.md
+  find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+  head -3 $O/busy_sweep.txt; grep -i "copyBuffer" $O/shares_sweep.txt; head -12 $O/shares_sweep.txt
+fi

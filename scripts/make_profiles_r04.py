@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Assemble the committed profiles/r04_* files from gpurun_out/evidence_r04 (scripts/gpu_evidence_r04.sh a / b / c)."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EV = os.path.join(ROOT, "gpurun_out", "evidence_r04")
+PR = os.path.join(ROOT, "profiles")
+
+
+def rd(name):
+    p = os.path.join(EV, name)
+    return open(p).read() if os.path.exists(p) else ""
+
+
+def wr(name, text):
+    with open(os.path.join(PR, name), "w") as f:
+        f.write(text if text.endswith("\n") else text + "\n")
+
+
+def main():
+    line = json.loads(rd("bench_default.json").strip().splitlines()[-1])
+    wr("r04_bench_line.json", json.dumps(line, indent=1))
+    det = json.loads(rd("detail_default.json"))
+    wr("r04_bench_detail.json", json.dumps(det["reports"], indent=1))
+    wr("r04_pytest_gpu.log", rd("pytest_gpu.log"))
+    c = line["config"]
+    s1 = json.loads(rd("bench_s1.json").strip().splitlines()[-1])
+    wr("r04_bench_default_groups_kernel_trace.md",
+       f"# r04 - `python bench.py` (primary workload p3p_5000: {c['problems_per_gpu_per_step']} problems per step through pl_ransac_batch, lock-step groups of 16, 8 groups in "
+       f"flight, {c['distinct_scenes']} distinct scenes) under rocprofv3 --kernel-trace --stats\n\nCommand (GPU box, from /tmp): `rocprofv3 --kernel-trace --stats -- python bench.py "
+       "--no-parity --no-cpu-baseline --no-secondary --steps 5` (scripts/gpu_evidence_r04.sh b).  The bench line of the same build (scripts/gpu_evidence_r04.sh a, "
+       f"`--steps 20 --warmup 5`): {line['value']:.4g} hypotheses/s, {line['ms_per_step']:.1f} ms per step, roofline frac {line['roofline']['frac']:.3f} "
+       f"(peak priced at the kernel's instruction mix: {line['roofline']['issue_cycles_per_instruction']:.2f} issue cycles per VALU instruction; all-half-rate reading "
+       f"{line['roofline']['frac_if_all_half_rate']:.3f}).\n\n" + rd("prof_default.md") + "\n## Device occupancy (scripts/busy.py)\n\n```\n" + rd("busy_default.txt") + "```\n")
+    wr("r04_bench_p3p5000_1stream_kernel_trace.md",
+       f"# r04 - one problem at a time (`bench.py --mode streams --streams 1`): {s1['ms_per_step'] / s1['config']['problems_per_gpu_per_step']:.3f} ms per 100 k-iteration P3P problem\n\n" + rd("prof_s1.md"))
+    for w in ("relpose_5000", "fund_10000", "hom_10000"):
+        wr(f"r04_bench_{w}_1stream_kernel_trace.md", f"# r04 - `bench.py --workload {w} --mode streams --streams 1` under rocprofv3 --kernel-trace --stats\n\n" + rd(f"prof_{w}.md"))
+        wr(f"r04_bench_{w}_groups_kernel_trace.md", f"# r04 - `bench.py --workload {w}` (grouped) under rocprofv3 --kernel-trace --stats\n\n" + rd(f"profg_{w}.md"))
+    for w in ("p3p_5000", "relpose_5000", "fund_10000", "hom_10000"):
+        wr(f"r04_pmc_{w}.md", f"# r04 - PMC passes of `bench.py --workload {w} --mode streams --streams 1` (separate rocprofv3 --pmc runs: SQ set 1, SQ set 2, FETCH_SIZE, WRITE_SIZE; "
+                              "FETCH_SIZE in KB, doubled in profiles/pmc_traffic.json per MI355X_MICROARCH.md)\n\nThe scorers are unchanged since round 3: the instruction counts per launch equal "
+                              "profiles/r03_pmc_*.md (k_score_mfma<10>: SQ_INSTS_VALU 6.868e7).\n\n" + rd(f"pmc_{w}.md"))
+    wr("r04_bench_batch_mixed_kernel_trace.md",
+       "# r04 - configs[4]: `pl_estimate_batch`, 4096 mixed default-option problems per call, steady state\n\n"
+       f"Driver's leg in the bench line of this build: **{c['batch_mixed_problems_per_s']:.0f} problems/s** ({c['batch_mixed_hyp_per_s']:.3g} hypotheses/s, parity "
+       f"{c['batch_mixed_parity_ok']}).\n\nTrace: `rocprofv3 --kernel-trace -- python scripts/batch_sweep.py 4096 10:0:3` = 3 warm-up + 4 timed calls back to back, nothing else on the "
+       "device; the figures below are over the LAST HALF of the kernel span (the timed calls).  Round 3's \"52 % non-idle, 14 817 copyBuffer\" came from a trace of one warm-up + two "
+       "timed calls of bench_batch.py (arenas still growing) and one 4-byte copy per problem.\n\n```\n" + rd("busy_sweep.txt") + "```\n\n## Share of GPU time by kernel (same window)\n\n"
+       + rd("shares_sweep.txt") + "\n## Where the workers' time goes (POSELIB_AMD_GROUP_TIMING=1, per call, 10 workers)\n\n```\n" + rd("batch_timing.log") + "```\n\n## rocprofv3 --stats of the whole run (warm-up included)\n\n"
+       + rd("prof_sweep.md"))
+    wr("r04_batch_chain.md", "# r04 - launch chain of one group of pl_estimate_batch (scripts/chain_view.py on the steady-state trace): start offset, duration, gap to the previous kernel on the stream\n\n```\n"
+       + rd("chain_sweep.txt") + "```\n")
+    wr("r04_batch_sweep.md",
+       "# r04 - pl_estimate_batch, 4096 problems per call: host threads x group size x step budget (scripts/batch_sweep.py; every setting returns the same iterations / inliers / hypotheses)\n\n"
+       "`threads:group:steps` - group 0 = the library's choice (follows the call: 64 ... 256), steps = batch steps before a group's unfinished problems are regrouped (0: never).\n\n```\n"
+       + rd("batch_sweep.log") + "```\n\nExact-summation mode (POSELIB_AMD_LM_ORDERED=1):\n\n```\n" + rd("batch_sweep_ordered.log") + "```\n\n"
+       "Experiments on the same workload that did not move it (round 4, other boxes of the pool; 10 threads, budget 3): LM without LDS staging of the points (two LM workgroups per CU) 75.9 k "
+       "vs 75.5 k; LM workgroups of 256 lanes (four per CU) 77.6 k; both 75.3 k; flag-prefetching / 128-row-slot variants of the ordered kernel: see k_lm_ordered's comment.  "
+       "GPU_MAX_HW_QUEUES 8 / 16 / 32 at 8 threads: 68.0 / 68.4 / 69.1 k (before the later changes); 4 (the runtime's default): 59.8 k.\n")
+    lm = ["# r04 - one LM iteration of one refinement task (scripts/time_lm.py: pl_refine_model on resident problems, slope between a 2- and a 40-iteration run)\n",
+          "tree = k_lm (default: reference order up to 256 correspondences, tree beyond); ordered = k_lm_ordered (POSELIB_AMD_LM_ORDERED=1: reference order at every n).\n"]
+    for loss in ("truncated", "cauchy"):
+        t, o = rd(f"time_lm_tree_{loss}.log").splitlines(), rd(f"time_lm_ordered_{loss}.log").splitlines()
+        lm.append(f"\n## {loss.upper()} loss\n\n| estimator, n | tree: us per LM iteration | ordered |\n|---|---|---|")
+        for a, b in zip(t, o):
+            if "->" in a and "->" in b:
+                lm.append(f"| {a[:16].strip()} | {a.split('->')[1].replace('us per LM iteration', '').strip()} | {b.split('->')[1].replace('us per LM iteration', '').strip()} |")
+    wr("r04_lm_timing.md", "\n".join(lm))
+    wr("r04_chain_add.md", "# r04 - scripts/exp/chain_add.cc: the cost of a sequential fp64 sum on one gfx950 wavefront\n\n```\n" + rd("chain_add.log") + "```\n")
+    wr("r04_mfma_f64_order.md", "# r04 - scripts/exp/mfma_f64_order.cc: v_mfma_f64_* accumulate as a k-ordered chain of fused multiply-adds, bit for bit\n\n```\n" + rd("mfma_f64_order.log") + "```\n")
+    wr("r04_focal_estimators_timing.log", rd("focal_timing.log"))
+    # PMC constants: unchanged kernels, note the round-4 re-measurement
+    p = os.path.join(PR, "pmc_traffic.json")
+    d = json.load(open(p))
+    d["_comment_r04"] = ("round 4: the scorers are unchanged; profiles/r04_pmc_*.md re-measure the same counters on the round-4 build (k_score_mfma<10>: SQ_INSTS_VALU 6.868e7 per launch, as in "
+                         "round 3).  bench.py prices the VALU peak at each kernel's instruction mix (profiles/valu_mix.json, profiles/r04_valu_issue.md).")
+    json.dump(d, open(p, "w"), indent=1)
+    print("profiles/r04_* written")
+
+
+if __name__ == "__main__":
+    main()
