@@ -1557,6 +1557,25 @@ template <int EST> __global__ __launch_bounds__(256) void k_mask_g(const MaskArg
 }
 
 // ------------------------------------------------------------------------------------ LM
+// starting point of a refinement task: its parameter block, or (tasks enqueued behind the kernel that chooses their model) the
+// parameters of a model record in device memory - what driver.cc's params_from_record() extracts on the host
+__device__ __forceinline__ void lm_start_params(int est, const LMTask &T, double *cur) {
+    if (!T.start_record) {
+        for (int i = 0; i < kParamDoubles; ++i)
+            cur[i] = T.params[i];
+        return;
+    }
+    for (int i = 0; i < kParamDoubles; ++i)
+        cur[i] = 0.0;
+    if (est == EST_ABS || est == EST_REL) {
+        for (int i = 0; i < 7; ++i)
+            cur[i] = T.start_record[i];
+    } else {
+        for (int i = 0; i < 9; ++i)
+            cur[i] = T.start_record[kMatOff + i];
+    }
+}
+
 template <int N> struct BlockReduce {
     // Reduces N per-thread doubles (+ one counter) over the 1024-thread workgroup.  Result in out[0..N)
     // and *count_out (valid for every thread after the call).  Fixed order: butterfly inside each
@@ -1656,9 +1675,15 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
     const double pscale = T.point_scale;
     const CameraParams cam = T.cam;
 
+    if (T.gate_count && *T.gate_count <= T.gate_min) { // (uniform: every thread reads the same word) the task does not run
+        if (threadIdx.x == 0) {
+            Tout.iterations = 0;
+            Tout.skipped = 2u;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
-        for (int i = 0; i < kParamDoubles; ++i)
-            cur[i] = T.params[i];
+        lm_start_params(EST, T, cur);
         ctl.opt = T.opt;
         ctl.loss = make_loss(T.opt.loss_type, T.opt.loss_scale);
         ctl.done = 0;
@@ -2130,9 +2155,15 @@ template <int EST> __global__ __launch_bounds__(kLMThreads, (EST == EST_HOM ? 2 
     const double pscale = T.point_scale;
     const CameraParams cam = T.cam;
 
+    if (T.gate_count && *T.gate_count <= T.gate_min) { // (uniform: every thread reads the same word) the task does not run
+        if (threadIdx.x == 0) {
+            Tout.iterations = 0;
+            Tout.skipped = 2u;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
-        for (int i = 0; i < kParamDoubles; ++i)
-            cur[i] = T.params[i];
+        lm_start_params(EST, T, cur);
         ctl.opt = T.opt;
         ctl.loss = make_loss(T.opt.loss_type, T.opt.loss_scale);
         ctl.done = 0;
@@ -2947,6 +2978,8 @@ __global__ void k_select_record_g(const SelectArgs *arr) {
         a.out[threadIdx.x] = src[threadIdx.x];
     if (threadIdx.x == 63 && a.fetch_src)
         *a.fetch_dst = *a.fetch_src;
+    if (threadIdx.x == 62 && a.count_out)
+        *a.count_out = (*a.score_refined < a.incumbent_score) ? *a.count_refined : a.count_incumbent;
 }
 hipError_t launch_group_select(const SelectArgs *args, uint32_t G, hipStream_t stream) {
     if (G == 0)

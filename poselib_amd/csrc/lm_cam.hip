@@ -13,10 +13,10 @@
 //              after the other.
 // Every entry is therefore summed correspondence after correspondence - the reference's order
 // (jacobian_accumulator.h:82-97) - for EVERY n, not only up to kLMSeqPoints as in k_lm: the refined pose and camera
-// equal the oracle's to the bit whenever the robust cost does (n <= 256: summed in order as well; beyond that the cost
-// is a tree sum).  The consumer loop is branch-free and takes eight rows per step (their LDS reads travel together, the
+// equal the oracle's to the bit: the robust cost is summed in the reference's order as well, at every n since round 4.  The consumer loop is branch-free and takes eight rows per step (their LDS reads travel together, the
 // additions stay a chain in row order); the final bundle runs once per problem, on the inliers.
 #include "pl_kernels.h"
+#include "pl_lm_chain.inc"
 #include "pl_device.h"
 #include "pl_refine_cam.h"
 #include <atomic>
@@ -38,14 +38,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 } // namespace
 
 __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
-    extern __shared__ double s_rows[]; // kCamThreads x kCamRow
+    extern __shared__ __attribute__((aligned(16))) double s_rows[]; // kCamThreads x kCamRow
     __shared__ LMTask s_task;
     __shared__ LMControl ctl;
     __shared__ double cur[kParamDoubles], trial[kParamDoubles];
     __shared__ CameraParams cam_cur, cam_trial;
     __shared__ double s_R[9];
     __shared__ double normal[kCamMaxEntries];
-    __shared__ double s_wsum[kCamWaves];
     __shared__ uint32_t s_wcnt[kCamWaves];
     __shared__ double s_racc;
     __shared__ uint32_t s_count;
@@ -67,9 +66,23 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
     const double pscale = T.point_scale;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
+    if (T.gate_count && *T.gate_count <= T.gate_min) { // (uniform) the task does not run: see LMTask
+        if (threadIdx.x == 0) {
+            Tout.iterations = 0;
+            Tout.skipped = 2u;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
-        for (int i = 0; i < kParamDoubles; ++i)
-            cur[i] = T.params[i];
+        if (T.start_record) { // absolute pose: q, t of the chosen model's record
+            for (int i = 0; i < kParamDoubles; ++i)
+                cur[i] = 0.0;
+            for (int i = 0; i < 7; ++i)
+                cur[i] = T.start_record[i];
+        } else {
+            for (int i = 0; i < kParamDoubles; ++i)
+                cur[i] = T.params[i];
+        }
         cam_cur = T.cam;
         ctl.opt = T.opt;
         ctl.loss = make_loss(T.opt.loss_type, T.opt.loss_scale);
@@ -101,68 +114,38 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
         rotation_of(p);
         const Loss loss = ctl.loss;
         const CameraParams cam = camera;
-        if (pts.n <= (uint32_t)kCamThreads) { // in the reference's order
+        // in the reference's order at EVERY n (round 4; up to round 3: a wave tree beyond 256 correspondences): rounds of 256
+        // correspondences, every lane's term to LDS (zeros for skipped ones: x + 0.0 = x), lane 0 adds the round's 256 terms with the
+        // inline-asm chain of k_lm_ordered (pl_lm_chain.inc: 11.7 cycles per term)
+        double tot = 0.0;
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < pts.n; base += (uint32_t)kCamThreads) {
             double term = 0.0;
             bool counted = false;
-            const uint32_t i = threadIdx.x;
+            const uint32_t i = base + threadIdx.x;
             if (i < pts.n && !(mask && !mask[i]))
                 counted = abs_cam_cost(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
                                        pts.a[4][i], term);
-            s_rows[threadIdx.x] = counted ? term : 0.0; // (x + 0.0 = x)
-            const uint64_t b = __builtin_amdgcn_ballot_w64(counted);
-            if (lane == 0)
-                s_wcnt[wave] = (uint32_t)__popcll(b);
+            s_rows[threadIdx.x] = counted ? term : 0.0;
+            cnt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(counted)); // (every lane holds its wavefront's count)
             __syncthreads();
             if (threadIdx.x == 0) {
-                double tot = 0.0;
-                uint32_t q = 0;
-                for (; q + 8u <= pts.n; q += 8u) { // (reads together, additions in order)
-                    double t8[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        t8[u] = s_rows[q + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        tot += t8[u];
+#pragma unroll 1
+                for (int q = 0; q < kCamThreads; q += 64) {
+                    const uint32_t addr = (uint32_t)(uintptr_t)&s_rows[q];
+                    PL_LM_CHAIN64(tot, addr);
                 }
-                for (; q < pts.n; ++q)
-                    tot += s_rows[q];
-                s_racc = tot;
-                uint32_t c = 0;
-                for (int w = 0; w < kCamWaves; ++w)
-                    c += s_wcnt[w];
-                s_count = c;
             }
             __syncthreads();
-            return;
         }
-        double racc = 0.0;
-        uint32_t cnt = 0;
-        for (uint32_t i = threadIdx.x; i < pts.n; i += kCamThreads) {
-            if (mask && !mask[i])
-                continue;
-            double term;
-            if (abs_cam_cost(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i], pts.a[4][i],
-                             term)) {
-                racc += term;
-                cnt++;
-            }
-        }
-        const double ws = wave_sum_f64(racc);
-        const uint32_t wc = wave_sum_u32(cnt);
-        if (lane == 0) {
-            s_wsum[wave] = ws;
-            s_wcnt[wave] = wc;
-        }
+        if (lane == 0)
+            s_wcnt[wave] = cnt;
         __syncthreads();
         if (threadIdx.x == 0) {
-            double tot = 0.0;
-            uint32_t c = 0;
-            for (int w = 0; w < kCamWaves; ++w) {
-                tot += s_wsum[w];
-                c += s_wcnt[w];
-            }
             s_racc = tot;
+            uint32_t c = 0;
+            for (int w = 0; w < kCamWaves; ++w)
+                c += s_wcnt[w];
             s_count = c;
         }
         __syncthreads();

@@ -92,6 +92,12 @@ struct LMTask {
     double *record_out;      // ... and where the refined model's record goes (device memory); nullptr: no record
     int32_t cam_flags;       // k_lm_cam: CamRefineFlags (pl_refine_cam.h) - the intrinsics refined with the pose; `cam` is in/out
     int32_t pad0;
+    // A task that is enqueued BEHIND the kernels that decide whether and from where it runs (pl_estimate_batch: the front-end's final
+    // bundle behind the final refinement, its choice and the inlier mask - one synchronisation instead of two):
+    const double *start_record;  // optional: the model record (device memory) whose parameters replace `params` as the starting point
+    const uint32_t *gate_count;  // optional: the task runs only if *gate_count > gate_min (robust.cc:103 "num_inliers > 3" etc.); otherwise
+    uint32_t gate_min;           // skipped = 2 and nothing else is written
+    uint32_t pad1;
     // outputs
     uint32_t iterations, skipped;
     double cost, initial_cost;
@@ -278,6 +284,10 @@ struct SelectArgs {
     double incumbent_score;
     const double *rec_refined, *rec_incumbent;
     double *out;
+    const uint32_t *count_refined; // optional: inlier count of the refined model ...
+    uint32_t count_incumbent;      // ... and of the incumbent; the chosen one goes to
+    uint32_t pad;
+    uint32_t *count_out;           // ... this device word (gate of the tasks enqueued behind the choice)
     const uint32_t *fetch_src; // optional: one device word (a stopped problem's hypothesis offset) ...
     uint32_t *fetch_dst;       // ... copied to this (pinned host) address by the same launch
 };
