@@ -29,6 +29,9 @@
 // Exact arithmetic (fp64, reference association order) never runs on the matrix cores; only the filters' linear and
 // quadratic forms do.
 #include "pl_kernels.h"
+#ifndef PL_XCD_MAP
+#define PL_XCD_MAP 1
+#endif
 #include "pl_lm_chain.inc"
 #include "pl_device.h"
 #include <atomic>
@@ -701,6 +704,30 @@ constexpr int kMfmaQueueCap = 1024; // >= 63 waiting + 64 lanes * 10 point group
 #endif
 constexpr int kMfmaThreads = PL_MFMA_THREADS; // 8 wavefronts share one chunk of correspondences (LDS: 20 KB shared + 2.8 KB per wave)
 
+// Workgroup -> (hypothesis slice, chunk of correspondences) of the matrix-core scorers.  The operands of a hypothesis slice are
+// streamed by the workgroups of ALL chunks of correspondences, and the hardware deals workgroups to the 8 XCDs - each with an L2
+// of its own - round robin in linear order: with slice = blockIdx.x, chunk = blockIdx.y a slice's operands went through every
+// L2, once per chunk (k_score_mfma2<2, 12>, 10 000 correspondences: 27 x 18 MB, FETCH_SIZE 285 MB per launch).  Here the
+// (slice, chunk) pairs are numbered slice-major and XCD x (= linear workgroup index mod 8) takes the x-th eighth of them: an XCD
+// sees 2 - 3 slices per launch (1 MB each, resident in its 4 MB L2 while their chunks' workgroups stream them).  Measured on one
+// box, same build otherwise (PL_XCD_MAP = 0 / 1): FETCH_SIZE of the 7-point scorer 285 -> 61 MB per launch, of k_score_mfma<10>
+// 20.9 -> 16.4 MB; grouped throughput 7-point 3.18 -> 3.41e8, P3P 7.38 -> 7.56e8, 5-point 1.61 -> 1.64e8 hypotheses/s,
+// homography unchanged; a single problem's launch (all workgroups resident at once, not bandwidth bound) is unchanged.
+__device__ __forceinline__ bool slice_chunk_of_workgroup(uint32_t slices, uint32_t chunks, uint32_t &slice, uint32_t &chunk) {
+#if PL_XCD_MAP == 0
+    slice = blockIdx.x, chunk = blockIdx.y;
+    return slice < slices && chunk < chunks;
+#else
+    const uint32_t T = slices * chunks, L = blockIdx.x + gridDim.x * blockIdx.y;
+    if (L >= T)
+        return false;
+    const uint32_t x = L & 7u, p = x * (T >> 3) + min(x, T & 7u) + (L >> 3);
+    slice = p / chunks;
+    chunk = p - slice * chunks;
+    return true;
+#endif
+}
+
 template <int PG>
 __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4 *__restrict__ shadow16,
                                                 const double *__restrict__ models, const uint32_t *__restrict__ slots,
@@ -869,22 +896,35 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
             for (int r = 0; r < 8; ++r) {
                 const uint32_t slot = hg * 16u + 4u * (uint32_t)(r >> 1) + 2u * (uint32_t)half + (uint32_t)(r & 1); // hypothesis index inside the unit
                 uint32_t bits = ~out[r] & validbits;
-                if (slot >= gn)
+                if (hg * 16u + 16u > gn && slot >= gn) // (only the last, partial group of a short unit has slots without a hypothesis: a scalar test in front)
                     bits = 0u;
-                if (__builtin_amdgcn_ballot_w64(bits != 0u)) { // wave-uniform
+                const uint64_t anyb = __builtin_amdgcn_ballot_w64(bits != 0u);
+                if (anyb) { // wave-uniform
                     const uint32_t cnt = (uint32_t)__popc(bits);
-                    const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    uint32_t pos = qtail + incl - cnt;
-                    uint32_t rest = bits;
-                    while (rest) { // point groups in ascending order = bits from the top
-                        const int hi = 31 - __clz((int)rest);
-                        rest &= ~(1u << hi);
-                        const uint32_t g = (uint32_t)(PG - 1 - hi);
-                        queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
-                        ++pos;
+                    if (!__builtin_amdgcn_ballot_w64(cnt > 1u)) {
+                        // the usual case (1 % of the pairs survive: 0.1 bits per lane): at most ONE survivor per lane - its queue
+                        // position is the number of lower lanes with a survivor (v_mbcnt, 2 instructions) instead of a DPP prefix
+                        // sum over the lanes (12), and the bit loop is straight-line.  Same positions as the general path.
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(anyb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)anyb, 0u));
+                        if (bits) {
+                            const uint32_t g = (uint32_t)(PG - 1 - (31 - __clz((int)bits)));
+                            queue[(qtail + below) & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
+                        }
+                        qtail += (uint32_t)__popcll(anyb);
+                    } else {
+                        const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        uint32_t pos = qtail + incl - cnt;
+                        uint32_t rest = bits;
+                        while (rest) { // point groups in ascending order = bits from the top
+                            const int hi = 31 - __clz((int)rest);
+                            rest &= ~(1u << hi);
+                            const uint32_t g = (uint32_t)(PG - 1 - hi);
+                            queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
+                            ++pos;
+                        }
+                        qtail += total;
                     }
-                    qtail += total;
                     while (qtail - qhead >= 64u)
                         drain(64u);
                 }
@@ -912,17 +952,20 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6,
                                                                double *__restrict__ part_score,
                                                                uint32_t *__restrict__ tickets) {
     (void)tickets;
-    score_mfma_body<PG>(pts, shadow16, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score,
-                        blockIdx.x, blockIdx.y, gridDim.x);
+    uint32_t slice, chunk;
+    slice_chunk_of_workgroup(gridDim.x, gridDim.y, slice, chunk);
+    score_mfma_body<PG>(pts, shadow16, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score, slice, chunk,
+                        gridDim.x);
 }
 template <int PG>
 __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_score_mfma_g(const GroupArgs *ga) {
     const GroupArgs &g = ga[blockIdx.z];
-    if (!g.active || !g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
+    uint32_t slice, chunk;
+    if (!g.active || !g.use_mfma || !slice_chunk_of_workgroup(g.slices, g.chunks, slice, chunk))
         return;
     const ScoreArgs &a = g.score;
     score_mfma_body<PG>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,
-                        a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
+                        a.pf, a.part_count, a.part_score, slice, chunk, g.slices);
 }
 
 // ---- two-view Sampson scores: the pre-filter on the matrix cores ----------------------------------------------------
@@ -1113,22 +1156,35 @@ __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint
             for (int v = 0; v < 16; ++v) {
                 const uint32_t slot = hg * 32u + 8u * (uint32_t)(v >> 2) + 4u * (uint32_t)half + (uint32_t)(v & 3);
                 uint32_t bits = ~out[v] & validbits;
-                if (slot >= gn)
+                if (hg * 32u + 32u > gn && slot >= gn)
                     bits = 0u;
-                if (__builtin_amdgcn_ballot_w64(bits != 0u)) { // wave-uniform
+                const uint64_t anyb = __builtin_amdgcn_ballot_w64(bits != 0u);
+                if (anyb) { // wave-uniform
                     const uint32_t cnt = (uint32_t)__popc(bits);
-                    const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    uint32_t pos = qtail + incl - cnt;
-                    uint32_t rest = bits;
-                    while (rest) { // point groups in ascending order = bits from the top
-                        const int hi = 31 - __clz((int)rest);
-                        rest &= ~(1u << hi);
-                        const uint32_t g = (uint32_t)(PG - 1 - hi);
-                        queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
-                        ++pos;
+                    if (!__builtin_amdgcn_ballot_w64(cnt > 1u)) {
+                        // the usual case (1 % of the pairs survive: 0.1 bits per lane): at most ONE survivor per lane - its queue
+                        // position is the number of lower lanes with a survivor (v_mbcnt, 2 instructions) instead of a DPP prefix
+                        // sum over the lanes (12), and the bit loop is straight-line.  Same positions as the general path.
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(anyb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)anyb, 0u));
+                        if (bits) {
+                            const uint32_t g = (uint32_t)(PG - 1 - (31 - __clz((int)bits)));
+                            queue[(qtail + below) & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
+                        }
+                        qtail += (uint32_t)__popcll(anyb);
+                    } else {
+                        const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        uint32_t pos = qtail + incl - cnt;
+                        uint32_t rest = bits;
+                        while (rest) { // point groups in ascending order = bits from the top
+                            const int hi = 31 - __clz((int)rest);
+                            rest &= ~(1u << hi);
+                            const uint32_t g = (uint32_t)(PG - 1 - hi);
+                            queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
+                            ++pos;
+                        }
+                        qtail += total;
                     }
-                    qtail += total;
                     while (qtail - qhead >= 64u)
                         drain(64u);
                 }
@@ -1154,17 +1210,20 @@ __global__ __launch_bounds__(kMfmaThreads) void k_score_mfma2(PointSet pts, cons
                                                               uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
                                                               uint32_t *__restrict__ part_count,
                                                               double *__restrict__ part_score) {
-    score_mfma2_body<EST, PG>(pts, hypop, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score,
-                              blockIdx.x, blockIdx.y, gridDim.x);
+    uint32_t slice, chunk;
+    slice_chunk_of_workgroup(gridDim.x, gridDim.y, slice, chunk);
+    score_mfma2_body<EST, PG>(pts, hypop, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score, slice,
+                              chunk, gridDim.x);
 }
 
 template <int EST, int PG> __global__ __launch_bounds__(kMfmaThreads) void k_score_mfma2_g(const GroupArgs *ga) {
     const GroupArgs &g = ga[blockIdx.z];
-    if (!g.active || !g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
+    uint32_t slice, chunk;
+    if (!g.active || !g.use_mfma || !slice_chunk_of_workgroup(g.slices, g.chunks, slice, chunk))
         return;
     const ScoreArgs &a = g.score;
     score_mfma2_body<EST, PG>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models, a.slots, a.num_hyp, a.hyp_capacity,
-                              a.thr2, a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
+                              a.thr2, a.pf, a.part_count, a.part_score, slice, chunk, g.slices);
 }
 
 // ---- homography: the pre-filter on the matrix cores (round 3) ------------------------------------------------------------
@@ -1328,22 +1387,35 @@ __device__ __forceinline__ void score_mfmah_body(const PointSet &pts, const uint
             for (int q = 0; q < 4; ++q) {
                 const uint32_t slot = hg * 8u + 2u * (uint32_t)q + (uint32_t)half; // hypothesis index inside the unit
                 uint32_t bits = ~out[q] & validbits;
-                if (slot >= gn)
+                if (hg * 8u + 8u > gn && slot >= gn)
                     bits = 0u;
-                if (__builtin_amdgcn_ballot_w64(bits != 0u)) { // wave-uniform
+                const uint64_t anyb = __builtin_amdgcn_ballot_w64(bits != 0u);
+                if (anyb) { // wave-uniform
                     const uint32_t cnt = (uint32_t)__popc(bits);
-                    const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    uint32_t pos = qtail + incl - cnt;
-                    uint32_t rest = bits;
-                    while (rest) { // point groups in ascending order = bits from the top
-                        const int hi = 31 - __clz((int)rest);
-                        rest &= ~(1u << hi);
-                        const uint32_t g = (uint32_t)(PG - 1 - hi);
-                        queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
-                        ++pos;
+                    if (!__builtin_amdgcn_ballot_w64(cnt > 1u)) {
+                        // the usual case (1 % of the pairs survive: 0.1 bits per lane): at most ONE survivor per lane - its queue
+                        // position is the number of lower lanes with a survivor (v_mbcnt, 2 instructions) instead of a DPP prefix
+                        // sum over the lanes (12), and the bit loop is straight-line.  Same positions as the general path.
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(anyb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)anyb, 0u));
+                        if (bits) {
+                            const uint32_t g = (uint32_t)(PG - 1 - (31 - __clz((int)bits)));
+                            queue[(qtail + below) & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
+                        }
+                        qtail += (uint32_t)__popcll(anyb);
+                    } else {
+                        const uint32_t incl = wave_scan_u32(cnt); // inclusive prefix (lanes 0..31 = their hypothesis first)
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        uint32_t pos = qtail + incl - cnt;
+                        uint32_t rest = bits;
+                        while (rest) { // point groups in ascending order = bits from the top
+                            const int hi = 31 - __clz((int)rest);
+                            rest &= ~(1u << hi);
+                            const uint32_t g = (uint32_t)(PG - 1 - hi);
+                            queue[pos & (kMfmaQueueCap - 1)] = (uint16_t)((slot << 9) | (g * 32u + (uint32_t)col));
+                            ++pos;
+                        }
+                        qtail += total;
                     }
-                    qtail += total;
                     while (qtail - qhead >= 64u)
                         drain(64u);
                 }
@@ -1365,17 +1437,20 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6,
     PointSet pts, const uint4 *__restrict__ hypop, const double *__restrict__ models, const uint32_t *__restrict__ slots,
     const uint32_t *__restrict__ num_hyp_ptr, uint32_t hyp_capacity, double thr2, PrefilterArgs pf,
     uint32_t *__restrict__ part_count, double *__restrict__ part_score) {
-    score_mfmah_body<PG>(pts, hypop, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score, blockIdx.x,
-                         blockIdx.y, gridDim.x);
+    uint32_t slice, chunk;
+    slice_chunk_of_workgroup(gridDim.x, gridDim.y, slice, chunk);
+    score_mfmah_body<PG>(pts, hypop, models, slots, num_hyp_ptr, hyp_capacity, thr2, pf, part_count, part_score, slice, chunk,
+                         gridDim.x);
 }
 template <int PG>
 __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_score_mfmah_g(const GroupArgs *ga) {
     const GroupArgs &g = ga[blockIdx.z];
-    if (!g.active || !g.use_mfma || blockIdx.y >= g.chunks || blockIdx.x >= g.slices)
+    uint32_t slice, chunk;
+    if (!g.active || !g.use_mfma || !slice_chunk_of_workgroup(g.slices, g.chunks, slice, chunk))
         return;
     const ScoreArgs &a = g.score;
     score_mfmah_body<PG>(a.pts, static_cast<const uint4 *>(a.shadow16), a.models, a.slots, a.num_hyp, a.hyp_capacity, a.thr2,
-                         a.pf, a.part_count, a.part_score, blockIdx.x, blockIdx.y, g.slices);
+                         a.pf, a.part_count, a.part_score, slice, chunk, g.slices);
 }
 
 // ---- MSAC score in the reference's summation order ------------------------------------------------------------------
@@ -2759,6 +2834,9 @@ uint32_t score_chunks(int est, uint32_t n, bool streaming, bool mfma) {
     return c;
 }
 
+// slice count of a matrix-core scorer launch: a multiple of 8 from 8 on (slice_chunk_of_workgroup keeps a slice on one XCD)
+static uint32_t xcd_slices(uint32_t s) { return std::max<uint32_t>(1u, s); }
+
 template <int E>
 static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStream_t stream) {
     uint32_t chunks;
@@ -2772,7 +2850,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
             // as much as the first, and every workgroup pays the fp16 split of its chunk before its first hypothesis
             const uint32_t mslices = std::min<uint32_t>(slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads,
                                                         std::max<uint32_t>(1u, 512u / chunks));
-            const dim3 mgrid(std::max<uint32_t>(1u, mslices), chunks);
+            const dim3 mgrid(xcd_slices(mslices), chunks);
             const dim3 mblock(kMfmaThreads);
 #define PL_M2_CASE(PP)                                                                                                 \
     case PP:                                                                                                           \
@@ -2796,7 +2874,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     }
     if constexpr (E == EST_HOM) {
         if (streaming && a.shadow16) { // homography pre-filter on the matrix cores (PG = 2 P groups of 32 points per chunk)
-            const dim3 mgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
+            const dim3 mgrid(xcd_slices(slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
             const dim3 mblock(kMfmaThreads);
 #define PL_MH_CASE(PP)                                                                                                 \
     case PP:                                                                                                           \
@@ -2819,7 +2897,7 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     }
     if constexpr (E == EST_ABS) {
         if (streaming && a.shadow16) { // pre-filter on the matrix cores (PG = 2 P groups of 32 points per wave)
-            const dim3 mgrid(std::max<uint32_t>(1u, slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
+            const dim3 mgrid(xcd_slices(slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
             const dim3 mblock(kMfmaThreads);
 #define PL_M_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \

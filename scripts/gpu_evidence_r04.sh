@@ -46,6 +46,7 @@ else
     B1="python $R/bench.py $Q --workload $w --mode streams --streams 1 --steps 2 --warmup 1"
     timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq_$w -o p -- $B1 > $O/pmc_sq_$w.log 2>&1
     timeout 300 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq2_$w -o p -- $B1 > $O/pmc_sq2_$w.log 2>&1
+    timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_grbm_$w -o p -- $B1 > $O/pmc_grbm_$w.log 2>&1
     timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$w -o p -- $B1 > $O/pmc_fetch_$w.log 2>&1
     timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$w -o p -- $B1 > $O/pmc_write_$w.log 2>&1
   done
@@ -53,7 +54,7 @@ else
   for d in prof_default prof_s1 prof_relpose_5000 prof_fund_10000 prof_hom_10000 profg_relpose_5000 profg_fund_10000 profg_hom_10000; do f=$(find $O/$d -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/$d.md; done
   python scripts/busy.py $(find $O/kt_default -name "*kernel_trace.csv") > $O/busy_default.txt
   for w in p3p_5000 relpose_5000 fund_10000 hom_10000; do
-    python scripts/pmc_summary.py $(find $O/pmc_sq_$w $O/pmc_sq2_$w $O/pmc_fetch_$w $O/pmc_write_$w -name "*counter_collection.csv") > $O/pmc_$w.md
+    python scripts/pmc_summary.py $(find $O/pmc_sq_$w $O/pmc_sq2_$w $O/pmc_grbm_$w $O/pmc_fetch_$w $O/pmc_write_$w -name "*counter_collection.csv") > $O/pmc_$w.md
   done
   find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
   head -8 $O/prof_default.md | cut -c1-170; head -3 $O/busy_default.txt; head -5 $O/pmc_p3p_5000.md | cut -c1-300

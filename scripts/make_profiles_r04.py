@@ -40,8 +40,8 @@ def main():
         wr(f"r04_bench_{w}_groups_kernel_trace.md", f"# r04 - `bench.py --workload {w}` (grouped) under rocprofv3 --kernel-trace --stats\n\n" + rd(f"profg_{w}.md"))
     for w in ("p3p_5000", "relpose_5000", "fund_10000", "hom_10000"):
         wr(f"r04_pmc_{w}.md", f"# r04 - PMC passes of `bench.py --workload {w} --mode streams --streams 1` (separate rocprofv3 --pmc runs: SQ set 1, SQ set 2, FETCH_SIZE, WRITE_SIZE; "
-                              "FETCH_SIZE in KB, doubled in profiles/pmc_traffic.json per MI355X_MICROARCH.md)\n\nThe scorers are unchanged since round 3: the instruction counts per launch equal "
-                              "profiles/r03_pmc_*.md (k_score_mfma<10>: SQ_INSTS_VALU 6.868e7).\n\n" + rd(f"pmc_{w}.md"))
+                              "FETCH_SIZE in KB, doubled in profiles/pmc_traffic.json per MI355X_MICROARCH.md)\n\nRound 3 for comparison: profiles/r03_pmc_*.md (k_score_mfma<10>: "
+                              "SQ_INSTS_VALU 6.868e7 per launch before the one-survivor-per-lane expansion path).\n\n" + rd(f"pmc_{w}.md"))
     wr("r04_bench_batch_mixed_kernel_trace.md",
        "# r04 - configs[4]: `pl_estimate_batch`, 4096 mixed default-option problems per call, steady state\n\n"
        f"Driver's leg in the bench line of this build: **{c['batch_mixed_problems_per_s']:.0f} problems/s** ({c['batch_mixed_hyp_per_s']:.3g} hypotheses/s, parity "
@@ -71,12 +71,41 @@ def main():
     wr("r04_chain_add.md", "# r04 - scripts/exp/chain_add.cc: the cost of a sequential fp64 sum on one gfx950 wavefront\n\n```\n" + rd("chain_add.log") + "```\n")
     wr("r04_mfma_f64_order.md", "# r04 - scripts/exp/mfma_f64_order.cc: v_mfma_f64_* accumulate as a k-ordered chain of fused multiply-adds, bit for bit\n\n```\n" + rd("mfma_f64_order.log") + "```\n")
     wr("r04_focal_estimators_timing.log", rd("focal_timing.log"))
-    # PMC constants: unchanged kernels, note the round-4 re-measurement
+    # PMC constants of the dominant kernels (the expansion of the survivor bits changed in round 4: fewer instructions per hypothesis)
+    WORK = {"p3p_5000": ("k_score_mfma<10>", 320, 5000), "relpose_5000": ("k_score_mfma2<1, 10>", 320, 5000),
+            "fund_10000": ("k_score_mfma2<2, 12>", 384, 10000), "hom_10000": ("k_score_mfmah<10>", 320, 10000)}
+
+    def rows(md):
+        lines = [ln for ln in md.splitlines() if ln.startswith("|")]
+        cols = [c.strip() for c in lines[0].strip().strip("|").split("|")]
+        return [dict(zip(cols, [c.strip() for c in ln.strip().strip("|").split("|")])) for ln in lines[2:]]
+
     p = os.path.join(PR, "pmc_traffic.json")
-    d = json.load(open(p))
-    d["_comment_r04"] = ("round 4: the scorers are unchanged; profiles/r04_pmc_*.md re-measure the same counters on the round-4 build (k_score_mfma<10>: SQ_INSTS_VALU 6.868e7 per launch, as in "
-                         "round 3).  bench.py prices the VALU peak at each kernel's instruction mix (profiles/valu_mix.json, profiles/r04_valu_issue.md).")
-    json.dump(d, open(p, "w"), indent=1)
+    old = json.load(open(p))
+    traffic = {"_comment": old.get("_comment", "") + "  Round 4: re-measured (scripts/gpu_evidence_r04.sh b, profiles/r04_pmc_*.md) after the survivor-bit "
+               "expansion of the three matrix-core scorers got its one-survivor-per-lane path; bench.py prices the VALU peak at each kernel's instruction mix "
+               "(profiles/valu_mix.json, profiles/r04_valu_issue.md)."}
+    for w, (kernel, chunk_pts, n) in WORK.items():
+        md = rd(f"pmc_{w}.md")
+        grbm = [ln for ln in rd(f"pmc_grbm_{w}.log").splitlines() if ln.startswith("{")]
+        r = next((x for x in rows(md) if x["kernel"].strip("`").replace("pl::", "") == kernel and x.get("launches") == "full batch"), None) if md else None
+        if not r or not grbm or "GRBM_GUI_ACTIVE" not in r or not r["GRBM_GUI_ACTIVE"]:
+            traffic[w] = old[w]  # (this evidence run has no complete PMC set for the workload: keep the committed constants)
+            continue
+        f = lambda k: float(r[k])
+        hyp = json.loads(grbm[-1])["roofline"]["hypotheses_per_launch"]
+        chunks = (n + chunk_pts - 1) // chunk_pts
+        cycles = f("GRBM_GUI_ACTIVE") / 8
+        traffic[w] = {"kernel": kernel, "fetch_size_kb": f("FETCH_SIZE"), "write_size_kb": f("WRITE_SIZE"),
+                      "traffic_bytes_per_launch": (2 * f("FETCH_SIZE") + f("WRITE_SIZE")) * 1024.0, "hypotheses_per_launch": hyp,
+                      "points_per_chunk": chunk_pts, "valu_insts_per_launch": f("SQ_INSTS_VALU"),
+                      "valu_insts_per_hypothesis_chunk": f("SQ_INSTS_VALU") / (hyp * chunks),
+                      "valu_busy": round(f("SQ_ACTIVE_INST_VALU") * 4 / 1024 / cycles, 3),
+                      "mfma_busy": round(f("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / cycles, 3), "kernel_cycles": cycles,
+                      "source": f"profiles/r04_pmc_{w}.md"}
+        print(w, "valu/hyp-chunk", round(traffic[w]["valu_insts_per_hypothesis_chunk"], 2), "(r03:", round(old[w]["valu_insts_per_hypothesis_chunk"], 2), ") valu_busy",
+              traffic[w]["valu_busy"], "traffic MB", round(traffic[w]["traffic_bytes_per_launch"] / 1e6, 1))
+    json.dump(traffic, open(p, "w"), indent=1)
     print("profiles/r04_* written")
 
 
