@@ -119,8 +119,8 @@ struct Context {
     DevBuf offsets, ctl, blk_best, rec_meta, rec_models, delta, flags;
     DevBuf gen_stage; // workspace of the staged 5-point generator
     DevBuf iota; // iota[i] = i: a device-resident "number of hypotheses" for launches whose count the host knows
-    DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt;
-    HostBuf h_rec_meta;
+    DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt, focal_stage;
+    HostBuf h_rec_meta, h_focal, h_in;
     HostBuf h_absmax, h_positions, h_num_models, h_count, h_score, h_tasks, h_gather_idx, h_gather_out, h_mask,
         h_small, h_models;
     HostBuf h_flag;        // completion flag of wait_stream(): the stream writes a sequence number, the host spins on it
@@ -1735,8 +1735,18 @@ int make_problem_prepared(Context *c, int kind, const double *a, const double *b
     HIP_TRY(c->h_absmax.ensure(sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->absmax.p, 0, sizeof(unsigned long long), c->stream));
     if (!resident) {
-        HIP_TRY(hipMemcpyAsync(c->raw_a.p, a, sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->raw_b.p, b, sizeof(double) * db * n, hipMemcpyHostToDevice, c->stream));
+        const size_t bytes_a = sizeof(double) * 2 * n, bytes_b = sizeof(double) * db * n;
+        const void *src_a = a, *src_b = b;
+        if (bytes_a + bytes_b <= ((size_t)8 << 20)) {
+            // through a pinned block: a copy from pageable memory pins and unpins the caller's buffer under the process's
+            // memory-map lock, which is what front-end calls from many host threads queued on (focal estimators)
+            HIP_TRY(c->h_in.ensure(bytes_a + bytes_b));
+            std::memcpy(c->h_in.p, a, bytes_a);
+            std::memcpy(c->h_in.as<char>() + bytes_a, b, bytes_b);
+            src_a = c->h_in.p, src_b = c->h_in.as<char>() + bytes_a;
+        }
+        HIP_TRY(hipMemcpyAsync(c->raw_a.p, src_a, bytes_a, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->raw_b.p, src_b, bytes_b, hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(launch_prepare(c->raw_a.as<double>(), c->raw_b.as<double>(), (uint32_t)n, pa, c->pts_arena.as<double>(),
                            c->absmax.as<unsigned long long>(), c->stream));
@@ -2712,8 +2722,12 @@ int pl_solve_focal_batch(int kind, const double *in, size_t count, double *out_m
     HIP_TRY(c->solve_cnt.ensure(sizeof(uint32_t) * count));
     HIP_TRY(hipMemcpyAsync(c->solve_in.p, in, in_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->solve_out.p, 0, out_bytes, c->stream));
-    if (kind == 0)
-        HIP_TRY(launch_focal_solve(c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<FocalModel>(), c->solve_cnt.as<uint32_t>(), c->stream));
+    if (kind == 0) {
+        const uint32_t per_pass = (uint32_t)std::min<size_t>(count, 8192);
+        HIP_TRY(c->focal_stage.ensure(focal_stage_bytes(per_pass)));
+        HIP_TRY(launch_focal_solve(c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<FocalModel>(), c->solve_cnt.as<uint32_t>(),
+                                   c->focal_stage.as<double>(), per_pass, c->stream));
+    }
     else
         HIP_TRY(launch_sfocal_solve(c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<FocalModel>(), c->solve_cnt.as<uint32_t>(), c->stream));
     HIP_TRY(hipMemcpyAsync(out_models, c->solve_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));

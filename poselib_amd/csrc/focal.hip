@@ -14,72 +14,170 @@
 #include "pl_focal.h"
 #include "pl_kernels.h"
 #include "pl_solver_p35pf.h"
+#include <algorithm>
 #include <atomic>
 
 namespace pl {
 
 namespace {
 
-// kGenLanes samples per workgroup: their elimination matrices (8.1 KB each) fill the CU's LDS
-constexpr int kGenLanes = 16;
-__global__ __launch_bounds__(64) void k_focal_generate(FocalGenArgs g) {
-    extern __shared__ double s_work[]; // kP35WorkDoubles x kGenLanes, element-major
-    const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
+// ---- the generator: three kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ----------------------
+//   k_focal_setup      one lane = one sample: draw (or read) the sample, null space of the linear constraints, the 29 equations
+//                      -> rows of the elimination matrix (coalesced: consecutive lanes = consecutive samples), N, f0
+//   k_focal_eliminate  one WAVEFRONT = one sample: lane c holds column c of the 29 x 35 matrix in registers (58 VGPRs); per pivot
+//                      every lane searches its own column, the pivot's lane decides (v_readlane), the factors f_r = entry (r, col)
+//                      come from the pivot's lane one v_readlane pair each, and all 35 columns are updated at once - element for
+//                      element the operations of p35pf_eliminate (pl_solver_p35pf.h), so the results are the same bits
+//   k_focal_finish     one lane = one sample: action matrix, eigenvalues, null vectors, poses; its two 10 x 10 workspaces in LDS
+//                      (1.6 KB per sample: 32 samples per workgroup, three workgroups per CU)
+// Round 3's single kernel (one lane per sample, 8.1 KB of LDS per sample: 16 lanes per CU whatever the phase) took 1.5 ms per
+// launch and occupied 63 CUs for a batch of 1001 samples, which is what bounded the throughput of several problems in flight.
+constexpr int kStageN = kP35WorkDoubles, kStageF0 = kStageN + 60, kStageE = kStageF0 + 1, kStageOk = kStageE + kP35ActionDoubles,
+              kStageDoubles = kStageOk + 1;
+
+__global__ __launch_bounds__(64) void k_focal_setup(FocalGenArgs g) {
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     if (it >= g.num_iters)
         return;
-    uint32_t idx[kFocalSample];
-    if (g.samples) { // PROSAC: drawn on the host
-        for (int k = 0; k < kFocalSample; ++k)
-            idx[k] = g.samples[(size_t)it * kFocalSample + k];
-    } else {
-        draw_sample<kFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
-    }
     double xs[8];
     Vec3 X[4];
-    for (int k = 0; k < 4; ++k) {
-        xs[2 * k] = g.a[0][idx[k]];
-        xs[2 * k + 1] = g.a[1][idx[k]];
-        X[k] = v3(g.a[2][idx[k]], g.a[3][idx[k]], g.a[4][idx[k]]);
+    if (g.explicit_in) { // minimal problems given explicitly: [x 4 x 2 | X 4 x 3]
+        const double *p = g.explicit_in + (size_t)it * 20;
+        for (int k = 0; k < 8; ++k)
+            xs[k] = p[k];
+        for (int k = 0; k < 4; ++k)
+            X[k] = v3(p[8 + 3 * k], p[9 + 3 * k], p[10 + 3 * k]);
+    } else {
+        uint32_t idx[kFocalSample];
+        if (g.samples) { // PROSAC: drawn on the host
+            for (int k = 0; k < kFocalSample; ++k)
+                idx[k] = g.samples[(size_t)it * kFocalSample + k];
+        } else {
+            draw_sample<kFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
+        }
+        for (int k = 0; k < 4; ++k) {
+            xs[2 * k] = g.a[0][idx[k]];
+            xs[2 * k + 1] = g.a[1][idx[k]];
+            X[k] = v3(g.a[2][idx[k]], g.a[3][idx[k]], g.a[4][idx[k]]);
+        }
     }
-    P35Solution sol[kFocalMaxModels];
-    const int n = p35pf(xs, X, P35Work{s_work + threadIdx.x, (size_t)kGenLanes}, sol);
-    uint32_t m = 0;
-    for (int i = 0; i < n; ++i) {
-        if (sol[i].focal < 0)
-            continue;
-        if (g.max_focal >= 0 && sol[i].focal > g.max_focal)
-            continue;
-        FocalModel &o = g.models[(size_t)it * kFocalMaxModels + m];
-        o.q[0] = sol[i].q.w, o.q[1] = sol[i].q.x, o.q[2] = sol[i].q.y, o.q[3] = sol[i].q.z;
-        o.t[0] = sol[i].t.x, o.t[1] = sol[i].t.y, o.t[2] = sol[i].t.z;
-        o.f = sol[i].focal;
-        ++m;
-    }
-    g.num_models[it] = m;
+    const size_t B = g.num_iters;
+    double N[60], f0;
+    p35pf_setup(xs, X, P35Work{g.stage + it, B}, N, f0);
+    for (int e = 0; e < 60; ++e)
+        g.stage[(size_t)(kStageN + e) * B + it] = N[e];
+    g.stage[(size_t)kStageF0 * B + it] = f0;
 }
 
-// minimal problems given explicitly (pl_p35pf, pl_solve_focal_batch): in = count x [x 4 x 2 | X 4 x 3]; every solution is kept
-__global__ __launch_bounds__(64) void k_focal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models) {
-    extern __shared__ double s_work[];
-    const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
-    if (it >= count)
+__device__ __forceinline__ double readlane_f64(double v, int l) { // (l uniform)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kElimWaves = 4;
+__global__ __launch_bounds__(64 * kElimWaves) void k_focal_eliminate(double *stage, uint32_t B) {
+    const uint32_t it = blockIdx.x * kElimWaves + (threadIdx.x >> 6); // (wave-uniform)
+    if (it >= B)
         return;
-    const double *p = in + (size_t)it * 20;
-    double xs[8];
-    Vec3 X[4];
-    for (int k = 0; k < 8; ++k)
-        xs[k] = p[k];
-    for (int k = 0; k < 4; ++k)
-        X[k] = v3(p[8 + 3 * k], p[9 + 3 * k], p[10 + 3 * k]);
-    P35Solution sol[kFocalMaxModels];
-    const int n = p35pf(xs, X, P35Work{s_work + threadIdx.x, (size_t)kGenLanes}, sol);
-    for (int i = 0; i < n; ++i) {
-        FocalModel &o = models[(size_t)it * kFocalMaxModels + i];
-        o.q[0] = sol[i].q.w, o.q[1] = sol[i].q.x, o.q[2] = sol[i].q.y, o.q[3] = sol[i].q.z;
-        o.t[0] = sol[i].t.x, o.t[1] = sol[i].t.y, o.t[2] = sol[i].t.z;
-        o.f = sol[i].focal;
+    const int lane = threadIdx.x & 63;
+    const int c = lane < kP35Cols ? lane : kP35Cols - 1; // (lanes 35..63 shadow the last column: no divergence, never read)
+    double w[kP35Rows];
+#pragma unroll
+    for (int r = 0; r < kP35Rows; ++r)
+        w[r] = stage[(size_t)(r * kP35Cols + c) * B + it];
+    uint32_t used = 0;   // (uniform)
+    int pivot_of = 0;    // lane k: pivot row of eliminated monomial k
+    bool ok = true;
+#pragma unroll 1
+    for (int k = 0; k < 25; ++k) {
+        const int col = k < 23 ? k : k + 1; // kP35Elim
+        int pr = -1;
+        double best = 0;
+#pragma unroll
+        for (int r = 0; r < kP35Rows; ++r) {
+            const double v = fabs(w[r]);
+            if (!((used >> r) & 1u) && v > best)
+                best = v, pr = r;
+        }
+        pr = __builtin_amdgcn_readlane(pr, col);
+        best = readlane_f64(best, col);
+        if (pr < 0 || best < 1e-13) { // degenerate sample
+            ok = false;
+            break;
+        }
+        used |= 1u << pr;
+        pivot_of = lane == k ? pr : pivot_of;
+        double mine = w[0]; // w[pr] of this lane's column
+#pragma unroll
+        for (int r = 1; r < kP35Rows; ++r)
+            mine = r == pr ? w[r] : mine;
+        const double inv = 1.0 / readlane_f64(mine, col);
+        const double prow = mine * inv;
+#pragma unroll
+        for (int r = 0; r < kP35Rows; ++r) {
+            const double f = readlane_f64(w[r], col); // entry (r, col) before this pivot's update
+            if (r == pr)
+                w[r] = prow;
+            else if (f != 0)
+                w[r] -= f * prow;
+        }
     }
-    num_models[it] = (uint32_t)n;
+    if (lane == 0)
+        stage[(size_t)kStageOk * B + it] = ok ? 1.0 : 0.0;
+    if (!ok)
+        return;
+    // E[i][j] = entry (pivot row of monomial kP35ActionPivot[i], basis column j): lane kP35Basis[j] holds the column
+    const int j = lane >= 30 ? lane - 25 : lane == 27 ? 0 : lane == 23 ? 1 : lane == 26 ? 2 : lane == 28 ? 3 : lane == 29 ? 4 : -1;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int row = __builtin_amdgcn_readlane(pivot_of, kP35ActionPivot[i]);
+        double v = w[0];
+#pragma unroll
+        for (int r = 1; r < kP35Rows; ++r)
+            v = r == row ? w[r] : v;
+        if (j >= 0 && lane < kP35Cols)
+            stage[(size_t)(kStageE + i * 10 + j) * B + it] = v;
+    }
+}
+
+constexpr int kFinLanes = 32;
+__global__ __launch_bounds__(64) void k_focal_finish(FocalGenArgs g) {
+    __shared__ double s_work[200 * kFinLanes]; // action matrix + working copy per sample, element-major
+    const uint32_t it = blockIdx.x * kFinLanes + threadIdx.x;
+    if (threadIdx.x >= kFinLanes || it >= g.num_iters)
+        return;
+    const size_t B = g.num_iters;
+    uint32_t m = 0;
+    if (g.stage[(size_t)kStageOk * B + it] != 0.0) {
+        double E[kP35ActionDoubles], N[60];
+        for (int e = 0; e < kP35ActionDoubles; ++e)
+            E[e] = g.stage[(size_t)(kStageE + e) * B + it];
+        for (int e = 0; e < 60; ++e)
+            N[e] = g.stage[(size_t)(kStageN + e) * B + it];
+        const double f0 = g.stage[(size_t)kStageF0 * B + it];
+        P35Solution sol[kFocalMaxModels];
+        const StridedArr am{s_work + threadIdx.x, (size_t)kFinLanes};
+        const int n = p35pf_finish(E, N, f0, am, am.at(100), sol);
+        for (int i = 0; i < n; ++i) {
+            if (!g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
+                if (sol[i].focal < 0)
+                    continue;
+                if (g.max_focal >= 0 && sol[i].focal > g.max_focal)
+                    continue;
+            }
+            FocalModel o;
+            o.q[0] = sol[i].q.w, o.q[1] = sol[i].q.x, o.q[2] = sol[i].q.y, o.q[3] = sol[i].q.z;
+            o.t[0] = sol[i].t.x, o.t[1] = sol[i].t.y, o.t[2] = sol[i].t.z;
+            o.f = sol[i].focal;
+            g.models[(size_t)it * kFocalMaxModels + m] = o;
+            if (g.host_models)
+                g.host_models[(size_t)it * kFocalMaxModels + m] = o;
+            ++m;
+        }
+    }
+    g.num_models[it] = m;
+    if (g.host_num_models)
+        g.host_num_models[it] = m;
 }
 
 constexpr int kFocalScoreThreads = 256;
@@ -89,9 +187,24 @@ __global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score(FocalScoreAr
     const uint32_t slot = blockIdx.x * (kFocalScoreThreads / 64) + (threadIdx.x >> 6);
     if (slot >= a.num_slots)
         return;
-    if (a.num_models && (slot % kFocalMaxModels) >= a.num_models[slot / kFocalMaxModels])
-        return; // (wave-uniform)
-    const FocalModel m = a.models[slot];
+    if (a.num_models && (slot % kFocalMaxModels) >= a.num_models[slot / kFocalMaxModels]) { // (wave-uniform)
+        if (lane == 0) { // (the host never reads garbage - and no fill dispatches in front of this kernel)
+            a.counts[slot] = 0;
+            a.sums[slot] = 0.0;
+        }
+        return;
+    }
+    FocalModel m;
+    if (a.lm_tasks) { // the refined pose and focal length of k_lm_cam's task
+        const LMTask &t = a.lm_tasks[slot];
+        for (int i = 0; i < 4; ++i)
+            m.q[i] = t.params[i];
+        for (int i = 0; i < 3; ++i)
+            m.t[i] = t.params[4 + i];
+        m.f = t.cam.p[0];
+    } else {
+        m = a.models[slot];
+    }
     double R[9];
     focal_rotation(m, R);
     uint32_t count = 0;
@@ -131,41 +244,38 @@ __global__ void k_focal_mask(const double *x, const double *y, const double *X, 
 
 } // namespace
 
+size_t focal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)kStageDoubles * num_iters; }
+
 hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
         return hipSuccess;
-    constexpr size_t bytes = sizeof(double) * kP35WorkDoubles * kGenLanes; // 129.9 KB of the CU's 160 KB
-    static std::atomic<int> prepared_dev[64]; // per device ordinal: the attribute is per-device state on some runtimes
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    std::atomic<int> &prepared = prepared_dev[dev_ & 63];
-    if (!prepared.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_focal_generate),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess)
-            return e;
-        prepared.store(1, std::memory_order_release);
-    }
-    k_focal_generate<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
+    if (!g.stage)
+        return hipErrorInvalidValue;
+    k_focal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
+    k_focal_eliminate<<<dim3((g.num_iters + kElimWaves - 1) / kElimWaves), dim3(64 * kElimWaves), 0, stream>>>(g.stage, g.num_iters);
+    k_focal_finish<<<dim3((g.num_iters + kFinLanes - 1) / kFinLanes), dim3(64), 0, stream>>>(g);
     return hipGetLastError();
 }
-hipError_t launch_focal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, hipStream_t stream) {
-    if (count == 0)
-        return hipSuccess;
-    constexpr size_t bytes = sizeof(double) * kP35WorkDoubles * kGenLanes;
-    static std::atomic<int> prepared_dev[64]; // per device ordinal: the attribute is per-device state on some runtimes
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    std::atomic<int> &prepared = prepared_dev[dev_ & 63];
-    if (!prepared.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_focal_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)bytes);
+// minimal problems given explicitly (pl_p35pf, pl_solve_focal_batch): in = count x [x 4 x 2 | X 4 x 3]; every solution is kept.
+// stage: focal_stage_bytes(stage_samples) bytes; the problems go through it stage_samples at a time.
+hipError_t launch_focal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, double *stage,
+                              uint32_t stage_samples, hipStream_t stream) {
+    if (stage_samples == 0)
+        return hipErrorInvalidValue;
+    for (uint32_t first = 0; first < count; first += stage_samples) {
+        FocalGenArgs g{};
+        g.explicit_in = in + (size_t)first * 20;
+        g.num_iters = std::min(stage_samples, count - first);
+        g.keep_all = 1;
+        g.max_focal = -1.0;
+        g.models = models + (size_t)first * kFocalMaxModels;
+        g.num_models = num_models + first;
+        g.stage = stage;
+        hipError_t e = launch_focal_generate(g, stream);
         if (e != hipSuccess)
             return e;
-        prepared.store(1, std::memory_order_release);
     }
-    k_focal_solve<<<dim3((count + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(in, count, models, num_models);
-    return hipGetLastError();
+    return hipSuccess;
 }
 hipError_t launch_focal_score(const FocalScoreArgs &a, hipStream_t stream) {
     if (a.num_slots == 0)

@@ -189,10 +189,7 @@ int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalM
                 st.num_inliers = counts[0];
             }
             seeds.assign(1, *best);
-            rc = be.refine(seeds, refined);
-            if (rc)
-                return rc;
-            rc = be.score(refined, rcounts, rsums);
+            rc = be.refine_score(seeds, refined, rcounts, rsums);
             if (rc)
                 return rc;
             after_lo(refined[0], rcounts[0], rsums[0]);
@@ -257,11 +254,8 @@ int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalM
                 seeds.push_back(models[(size_t)b * kMaxModels + imps[last].slot]);
             }
         }
-        if (!seeds.empty()) {
-            rc = be.refine(seeds, refined);
-            if (rc)
-                return rc;
-            rc = be.score(refined, rcounts, rsums);
+        if (!seeds.empty()) { // the local optimisations of the batch and the scores of their results: one device round trip
+            rc = be.refine_score(seeds, refined, rcounts, rsums);
             if (rc)
                 return rc;
         }
@@ -289,10 +283,7 @@ int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalM
     }
     // final polish (ransac_impl.h:190-198): model_score is not updated
     seeds.assign(1, *best);
-    int rc = be.refine(seeds, refined);
-    if (rc)
-        return rc;
-    rc = be.score(refined, rcounts, rsums);
+    int rc = be.refine_score(seeds, refined, rcounts, rsums);
     if (rc)
         return rc;
     st.refinements++;
@@ -327,22 +318,30 @@ struct FocalGenArgs {
     double max_focal;     // < 0: no bound
     FocalModel *models;   // [num_iters * kFocalMaxModels]
     uint32_t *num_models; // [num_iters]
+    double *stage;              // focal_stage_bytes(num_iters): workspace of the three generator kernels (focal.hip)
+    const double *explicit_in;  // optional: num_iters x 20 minimal problems [x 4 x 2 | X 4 x 3] instead of samples of the points
+    uint32_t keep_all;          // 1: every solution (the solver's interface), 0: the estimator's focal-length filter
+    FocalModel *host_models;    // optional (pinned, mapped): the models and counts once more, for the host loop - no copy dispatches
+    uint32_t *host_num_models;
 };
 struct FocalScoreArgs {
     const double *a[5];
     uint32_t n;
     const FocalModel *models;
     const uint32_t *num_models; // per group of kFocalMaxModels slots; nullptr: every slot holds a model
+    const struct LMTask *lm_tasks; // optional: slot s = the pose and focal length k_lm_cam left in task s (instead of models)
     uint32_t num_slots;
     double thr2;
-    uint32_t *counts; // [num_slots]
+    uint32_t *counts; // [num_slots]  (slots without a model: 0)
     double *sums;     // [num_slots]
 };
 
 #if defined(__HIPCC__)
 hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream);
 hipError_t launch_focal_score(const FocalScoreArgs &a, hipStream_t stream);
-hipError_t launch_focal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, hipStream_t stream);
+size_t focal_stage_bytes(uint32_t num_iters);
+hipError_t launch_focal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, double *stage,
+                              uint32_t stage_samples, hipStream_t stream);
 hipError_t launch_focal_mask(const double *const *a, uint32_t n, const FocalModel &m, double thr2, uint8_t *mask, uint8_t *host_mask,
                              hipStream_t stream);
 #endif

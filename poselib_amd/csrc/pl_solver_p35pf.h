@@ -228,6 +228,9 @@ template <int ROWS, int COLS> PL_HD void complement_basis_indexed(double *qr /* 
 // Real eigenvalues of an n x n matrix (row-major, destroyed; Arr: a pointer or anything indexable that yields double&), ascending: Householder reduction to Hessenberg form, then the
 // Francis double-shift QR iteration in its textbook form; an eigenvalue counts as real when |imag| <= tol (1 + |real|).
 // No convergence after 60 sweeps on one block: no eigenvalues (the sample is dropped).
+#ifndef PL_EIG_MARK
+#define PL_EIG_MARK() // (scripts/exp/p35_phases.cc: cycle counter between the Hessenberg reduction and the QR iteration)
+#endif
 template <int n, class Arr> PL_HD int pl_real_eigenvalues(Arr a_, double *out, double tol) {
 #define PL_A(i, j) a_[(i) * n + (j)]
     for (int k = 0; k + 2 < n; ++k) {
@@ -265,6 +268,7 @@ template <int n, class Arr> PL_HD int pl_real_eigenvalues(Arr a_, double *out, d
         for (int r = k + 2; r < n; ++r)
             PL_A(r, k) = 0;
     }
+    PL_EIG_MARK();
     double wr[n], wi[n];
     for (int i = 0; i < n; ++i)
         wr[i] = wi[i] = 0.0;
@@ -462,17 +466,28 @@ struct P35Solution {
 
 // x: four image points (x, y) relative to the principal point - of the fourth only x is used -, X: the 3-D points.
 // Returns the number of solutions (<= 10), ascending in the eigenvalue.
-PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P35Solution *out) {
+#ifndef PL_P35_MARK
+#define PL_P35_MARK(i) // (scripts/exp/p35_phases.cc: cycle counter at the phase boundaries)
+#endif
+// The solver in three stages - on the device three kernels (focal.hip: one lane per sample / one WAVEFRONT per sample with the
+// matrix in registers / one lane per sample again), on the host and in p35pf() below one after the other.  Measured shares of the
+// one-lane-per-sample form, matrices in LDS (scripts/exp/p35_phases.cc): null space 3 %, equations 9 %, elimination 27 %,
+// eigenvalues 37 %, null vectors + poses 24 % of 1.5 ms.
+//
+// Stage 1: null space N (12 x 5, column k at N[12 k ..]) of the seven linear constraints, scale f0 of the image points, and the 29
+// equations as the rows of the elimination matrix w.
+PL_HD void p35pf_setup(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, double *N /* 60 */, double &f0_out) {
+    PL_P35_MARK(0);
     double f0 = 0;
     for (int i = 0; i < 4; ++i)
         f0 += sqrt(xs[2 * i] * xs[2 * i] + xs[2 * i + 1] * xs[2 * i + 1]);
     f0 /= 4;
+    f0_out = f0;
     double x[8];
     for (int i = 0; i < 8; ++i)
         x[i] = xs[i] / f0;
 
     // the 7 linear constraints on the 12 entries of P (row-major) as the columns of a 12 x 7 matrix
-    double N[12 * 5];
     {
         double A[12 * 7];
         for (int i = 0; i < 12 * 7; ++i)
@@ -495,6 +510,7 @@ PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P
         }
         complement_basis_indexed<12, 7>(A, N);
     }
+    PL_P35_MARK(1);
     {
         // rows of the left 3 x 3 block as vectors of linear polynomials: a[r][i] = sum_k N(4 r + i, k) x_k + N(4 r + i, 4)
         P35Lin a[3][3];
@@ -542,7 +558,17 @@ PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P
                 p35_store_row(w, ne++, eq);
             }
     }
-    // Gauss-Jordan over the 25 eliminated monomials: pivot = the largest remaining entry of the column among the unused rows
+    PL_P35_MARK(2);
+}
+
+// the five rows of the action matrix that come out of the elimination: row i of the action matrix = - (reduced row of the pivot of
+// eliminated monomial kP35ActionPivot[i]) restricted to the basis columns (kP35Shifted < 0: -sh - 1)
+static constexpr uint8_t kP35ActionPivot[5] = {17, 9, 15, 18, 19};
+constexpr int kP35ActionDoubles = 50; // E[i * 10 + j] = w.at(pivot_row[kP35ActionPivot[i]], kP35Basis[j])
+
+// Stage 2: Gauss-Jordan over the 25 eliminated monomials: pivot = the largest remaining entry of the column among the unused rows
+// (the first of equals).  false: degenerate sample.  E: the 50 entries stage 3 needs.
+PL_HD bool p35pf_eliminate(const P35Work &w, double *E /* 50 */) {
     uint32_t used = 0;
     uint8_t pivot_row[25];
     for (int k = 0; k < 25; ++k) {
@@ -555,7 +581,7 @@ PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P
                 best = v, pr = r;
         }
         if (pr < 0 || best < 1e-13)
-            return 0; // degenerate sample
+            return false; // degenerate sample
         used |= 1u << pr;
         pivot_row[k] = (uint8_t)pr;
         const double inv = 1.0 / w.at(pr, col);
@@ -565,7 +591,6 @@ PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P
             prow[c] = w.at(pr, c) * inv;
             w.at(pr, c) = prow[c];
         }
-        const double pcol = prow[col];
         for (int r = 0; r < kP35Rows; ++r) {
             if (r == pr)
                 continue;
@@ -576,25 +601,29 @@ PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P
                     w.at(r, c) -= f * prow[c];
             }
         }
-        (void)pcol;
     }
-    // action matrix of x4 on the standard monomials
-    double AM[100];
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 10; ++j)
+            E[i * 10 + j] = w.at(pivot_row[kP35ActionPivot[i]], kP35Basis[j]);
+    PL_P35_MARK(3);
+    return true;
+}
+
+// Stage 3: action matrix of x4 on the standard monomials, its real eigenvalues, the null vectors, the poses.  am, wk: two
+// workspaces of 100 doubles (LDS on the device: as local arrays they were scratch memory behind the vector memory path).
+// Returns the number of solutions (<= 10), ascending in the eigenvalue.
+PL_HD int p35pf_finish(const double *E /* 50 */, const double *N /* 60 */, double f0, const StridedArr &am, const StridedArr &wk,
+                       P35Solution *out) {
     for (int k = 0; k < 10; ++k) {
         const int sh = kP35Shifted[k];
         for (int j = 0; j < 10; ++j)
-            AM[k * 10 + j] = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -w.at(pivot_row[-sh - 1], kP35Basis[j]);
+            am[k * 10 + j] = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[k * 10 + j];
     }
-    // the elimination matrix is consumed: its storage (the workspace: LDS on the device) now holds the action matrix and the
-    // working copies of the eigenvalue iteration and of the null-vector eliminations (in the first version these were local
-    // arrays, i.e. scratch memory behind the vector memory path)
-    const StridedArr am = w.region(0), wk = w.region(100);
-    for (int i = 0; i < 100; ++i)
-        am[i] = AM[i];
     double ev[10];
     for (int i = 0; i < 100; ++i)
-        wk[i] = AM[i];
+        wk[i] = am[i];
     const int nroots = pl_real_eigenvalues<10>(wk, ev, 1e-8);
+    PL_P35_MARK(4);
     int n = 0;
     for (int s = 0; s < nroots; ++s) {
         double v[10];
@@ -643,7 +672,19 @@ PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P
         out[n].focal = focal * f0;
         ++n;
     }
+    PL_P35_MARK(5);
     return n;
+}
+
+// x: four image points (x, y) relative to the principal point - of the fourth only x is used -, X: the 3-D points; w: workspace of
+// kP35WorkDoubles.  Returns the number of solutions (<= 10), ascending in the eigenvalue.
+PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P35Solution *out) {
+    double N[12 * 5], f0, E[kP35ActionDoubles];
+    p35pf_setup(xs, X, w, N, f0);
+    if (!p35pf_eliminate(w, E))
+        return 0;
+    // the elimination matrix is consumed: its storage holds the action matrix and the working copy of stage 3
+    return p35pf_finish(E, N, f0, w.region(0), w.region(100), out);
 }
 
 } // namespace pl

@@ -821,6 +821,11 @@ struct HostFocalBackend {
             score_one(models[i], counts[i], sums[i]);
         return 0;
     }
+    int refine_score(const std::vector<FocalModel> &seeds, std::vector<FocalModel> &refined, std::vector<uint32_t> &counts,
+                     std::vector<double> &sums) {
+        int rc = refine(seeds, refined);
+        return rc ? rc : score(refined, counts, sums);
+    }
     int refine(const std::vector<FocalModel> &seeds, std::vector<FocalModel> &refined) {
         refined = seeds;
         LMOptions lo;
@@ -942,6 +947,11 @@ struct HostSFocalBackend {
         for (size_t i = 0; i < models.size(); ++i)
             score_one(models[i], counts[i], sums[i]);
         return 0;
+    }
+    int refine_score(const std::vector<FocalModel> &seeds, std::vector<FocalModel> &refined, std::vector<uint32_t> &counts,
+                     std::vector<double> &sums) {
+        int rc = refine(seeds, refined);
+        return rc ? rc : score(refined, counts, sums);
     }
     int refine(const std::vector<FocalModel> &seeds, std::vector<FocalModel> &refined) {
         refined = seeds;
