@@ -2728,8 +2728,12 @@ int pl_solve_focal_batch(int kind, const double *in, size_t count, double *out_m
         HIP_TRY(launch_focal_solve(c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<FocalModel>(), c->solve_cnt.as<uint32_t>(),
                                    c->focal_stage.as<double>(), per_pass, c->stream));
     }
-    else
-        HIP_TRY(launch_sfocal_solve(c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<FocalModel>(), c->solve_cnt.as<uint32_t>(), c->stream));
+    else {
+        const uint32_t per_pass = (uint32_t)std::min<size_t>(count, 8192);
+        HIP_TRY(c->focal_stage.ensure(sfocal_stage_bytes(per_pass)));
+        HIP_TRY(launch_sfocal_solve(c->solve_in.as<double>(), (uint32_t)count, c->solve_out.as<FocalModel>(), c->solve_cnt.as<uint32_t>(),
+                                    c->focal_stage.as<double>(), per_pass, c->stream));
+    }
     HIP_TRY(hipMemcpyAsync(out_models, c->solve_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out_counts, c->solve_cnt.p, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(wait_stream(c));

@@ -14,6 +14,7 @@
 #include "pl_focal.h"
 #include "pl_kernels.h"
 #include "pl_solver_p35pf.h"
+#include "pl_eigen_wave.h"
 #include <algorithm>
 #include <atomic>
 
@@ -28,12 +29,13 @@ namespace {
 //                      every lane searches its own column, the pivot's lane decides (v_readlane), the factors f_r = entry (r, col)
 //                      come from the pivot's lane one v_readlane pair each, and all 35 columns are updated at once - element for
 //                      element the operations of p35pf_eliminate (pl_solver_p35pf.h), so the results are the same bits
-//   k_focal_finish     one lane = one sample: action matrix, eigenvalues, null vectors, poses; its two 10 x 10 workspaces in LDS
-//                      (1.6 KB per sample: 32 samples per workgroup, three workgroups per CU)
+//   k_focal_eigen      one WAVEFRONT = one sample: the real eigenvalues of the 10 x 10 action matrix (pl_eigen_wave.h)
+//   k_focal_finish     one lane = one sample: null vectors, poses; its two 10 x 10 workspaces in LDS (1.6 KB per sample: 32
+//                      samples per workgroup, three workgroups per CU)
 // Round 3's single kernel (one lane per sample, 8.1 KB of LDS per sample: 16 lanes per CU whatever the phase) took 1.5 ms per
 // launch and occupied 63 CUs for a batch of 1001 samples, which is what bounded the throughput of several problems in flight.
 constexpr int kStageN = kP35WorkDoubles, kStageF0 = kStageN + 60, kStageE = kStageF0 + 1, kStageOk = kStageE + kP35ActionDoubles,
-              kStageDoubles = kStageOk + 1;
+              kStageEv = kStageOk + 1, kStageRoots = kStageEv + 10, kStageDoubles = kStageRoots + 1;
 
 __global__ __launch_bounds__(64) void k_focal_setup(FocalGenArgs g) {
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
@@ -140,6 +142,30 @@ __global__ __launch_bounds__(64 * kElimWaves) void k_focal_eliminate(double *sta
     }
 }
 
+// one wavefront = one sample: the 10 x 10 action matrix in LDS, its real eigenvalues by the lanes together (pl_eigen_wave.h)
+constexpr int kEigWaves = 4;
+__global__ __launch_bounds__(64 * kEigWaves) void k_focal_eigen(double *stage, uint32_t B) {
+    __shared__ double s_eig[kEigWaves][eig_wave_doubles(10)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blockIdx.x * kEigWaves + wave; // (wave-uniform)
+    if (it >= B)
+        return;
+    double *a = s_eig[wave];
+    int nroots = 0;
+    if (stage[(size_t)kStageOk * B + it] != 0.0) {
+        for (int e = lane; e < 100; e += 64) {
+            const int k = e / 10, j = e - 10 * k;
+            const int sh = kP35Shifted[k];
+            a[e] = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -stage[(size_t)(kStageE + e) * B + it]; // p35pf_action_entry
+        }
+        nroots = pl_real_eigenvalues_wave<10>(a, 1e-8, lane);
+        if (lane < nroots)
+            stage[(size_t)(kStageEv + lane) * B + it] = a[100 + 30 + lane];
+    }
+    if (lane == 0)
+        stage[(size_t)kStageRoots * B + it] = (double)nroots;
+}
+
 constexpr int kFinLanes = 32;
 __global__ __launch_bounds__(64) void k_focal_finish(FocalGenArgs g) {
     __shared__ double s_work[200 * kFinLanes]; // action matrix + working copy per sample, element-major
@@ -155,9 +181,16 @@ __global__ __launch_bounds__(64) void k_focal_finish(FocalGenArgs g) {
         for (int e = 0; e < 60; ++e)
             N[e] = g.stage[(size_t)(kStageN + e) * B + it];
         const double f0 = g.stage[(size_t)kStageF0 * B + it];
+        const int nroots = (int)g.stage[(size_t)kStageRoots * B + it];
+        double ev[10];
+        for (int r = 0; r < nroots; ++r)
+            ev[r] = g.stage[(size_t)(kStageEv + r) * B + it];
         P35Solution sol[kFocalMaxModels];
         const StridedArr am{s_work + threadIdx.x, (size_t)kFinLanes};
-        const int n = p35pf_finish(E, N, f0, am, am.at(100), sol);
+        for (int k = 0; k < 10; ++k)
+            for (int j = 0; j < 10; ++j)
+                am[k * 10 + j] = p35pf_action_entry(E, k, j);
+        const int n = p35pf_poses(am, am.at(100), ev, nroots, N, f0, sol);
         for (int i = 0; i < n; ++i) {
             if (!g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
                 if (sol[i].focal < 0)
@@ -253,6 +286,7 @@ hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
         return hipErrorInvalidValue;
     k_focal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
     k_focal_eliminate<<<dim3((g.num_iters + kElimWaves - 1) / kElimWaves), dim3(64 * kElimWaves), 0, stream>>>(g.stage, g.num_iters);
+    k_focal_eigen<<<dim3((g.num_iters + kEigWaves - 1) / kEigWaves), dim3(64 * kEigWaves), 0, stream>>>(g.stage, g.num_iters);
     k_focal_finish<<<dim3((g.num_iters + kFinLanes - 1) / kFinLanes), dim3(64), 0, stream>>>(g);
     return hipGetLastError();
 }

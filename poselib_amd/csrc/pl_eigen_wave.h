@@ -1,0 +1,282 @@
+// poselib_amd - real eigenvalues of a small matrix by ONE WAVEFRONT (device only): pl_real_eigenvalues / pl_balance_pow2 of
+// pl_solver_p35pf.h / pl_solver_6ptf.h with the matrix of one sample in LDS and the 64 lanes working on it together.
+//
+// The serial routines run one sample per lane; 16 - 32 samples share a wavefront, every lane somewhere else in its own iteration
+// (the wavefront executes the union of their paths), every access to the matrix a round trip to LDS: 2.1 ms per batch for the
+// 15 x 15 companion matrices of the shared-focal solver, 0.45 ms for the 10 x 10 action matrices of P3.5Pf.  Here the control flow
+// is the sample's own (wave-uniform: scalar branches, no divergence), the scalars of the iteration (shifts, reflectors) are
+// computed by every lane alike from broadcast reads, and the three inner loops of the algorithm - a reflector applied to its rows
+// over the columns j, to its columns over the rows i, the Householder updates of the Hessenberg reduction - run one column / row per
+// lane.  Every matrix element sees the operations of the serial routine in the serial routine's order (an update of element (i, j)
+// never depends on which lane performs it), so the eigenvalues are the same bits (tests/test_zz_gpu_focal.py,
+// tests/test_zz_gpu_shared_focal.py: the estimators' results against the oracle's).
+//
+// LDS per wavefront: kEigWaveDoubles(n) = n * n (matrix, row-major) + 4 n (Householder vector, wr, wi, out).
+#pragma once
+#include "pl_math.h"
+
+namespace pl {
+
+constexpr int eig_wave_doubles(int n) { return n * n + 4 * n; }
+
+// orders the LDS accesses of the lanes of one wavefront (the hardware executes a wavefront's LDS instructions in order; this keeps the
+// compiler from moving or caching accesses across the phases of the algorithm)
+#define PL_WAVE_SYNC()                                                                                                 \
+    do {                                                                                                               \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                                         \
+        __builtin_amdgcn_wave_barrier();                                                                               \
+    } while (0)
+
+// pl_balance_pow2<n> (pl_solver_6ptf.h): Parlett-Reinsch balancing without the permutation step
+template <int n> __device__ void pl_balance_pow2_wave(double *a, int lane) {
+    bool done = false;
+    for (int sweep = 0; sweep < 64 && !done; ++sweep) {
+        done = true;
+        for (int i = 0; i < n; ++i) {
+            double c = 0, r = 0;
+            for (int j = 0; j < n; ++j)
+                if (j != i) {
+                    c += fabs(a[j * n + i]);
+                    r += fabs(a[i * n + j]);
+                }
+            if (c == 0 || r == 0)
+                continue;
+            double g = r / 2.0, f = 1.0;
+            const double s = c + r;
+            while (c < g) {
+                f *= 2.0;
+                c *= 4.0;
+            }
+            g = r * 2.0;
+            while (c >= g) {
+                f /= 2.0;
+                c /= 4.0;
+            }
+            if ((c + r) / f < 0.95 * s) {
+                done = false;
+                g = 1.0 / f;
+                PL_WAVE_SYNC();
+                if (lane < n)
+                    a[i * n + lane] *= g;
+                PL_WAVE_SYNC();
+                if (lane < n)
+                    a[lane * n + i] *= f;
+                PL_WAVE_SYNC();
+            }
+        }
+    }
+}
+
+// pl_real_eigenvalues<n> (pl_solver_p35pf.h): Householder reduction to Hessenberg form, Francis double-shift QR iteration.
+// a: the matrix (LDS, row-major, destroyed), followed by 4 n doubles of workspace; the eigenvalues that count as real are left,
+// ascending, in a[n * n + 3 n ...]; returns their number (every lane the same).
+template <int n> __device__ int pl_real_eigenvalues_wave(double *a, double tol, int lane) {
+    double *const hv = a + n * n, *const wr = hv + n, *const wi = wr + n, *const out = wi + n;
+#define PL_A(i, j) a[(i) * n + (j)]
+    PL_WAVE_SYNC();
+    for (int k = 0; k + 2 < n; ++k) {
+        double tail = 0;
+        for (int r = k + 2; r < n; ++r)
+            tail += PL_A(r, k) * PL_A(r, k);
+        if (tail <= 1e-300)
+            continue;
+        const double c0 = PL_A(k + 1, k);
+        double beta = sqrt(c0 * c0 + tail);
+        if (c0 >= 0)
+            beta = -beta;
+        if (lane < n) // the Householder vector: lane r its entry
+            hv[lane] = lane <= k ? 0.0 : lane == k + 1 ? 1.0 : PL_A(lane, k) / (c0 - beta);
+        const double tau = (beta - c0) / beta;
+        PL_WAVE_SYNC();
+        if (lane < n) { // column c = lane
+            const int c = lane;
+            double t = 0;
+            for (int r = k + 1; r < n; ++r)
+                t += hv[r] * PL_A(r, c);
+            for (int r = k + 1; r < n; ++r)
+                PL_A(r, c) -= tau * hv[r] * t;
+        }
+        PL_WAVE_SYNC();
+        if (lane < n) { // row r = lane
+            const int r = lane;
+            double t = 0;
+            for (int c = k + 1; c < n; ++c)
+                t += PL_A(r, c) * hv[c];
+            for (int c = k + 1; c < n; ++c)
+                PL_A(r, c) -= tau * t * hv[c];
+        }
+        PL_WAVE_SYNC();
+        if (lane == k + 1)
+            PL_A(k + 1, k) = beta;
+        if (lane >= k + 2 && lane < n)
+            PL_A(lane, k) = 0;
+        PL_WAVE_SYNC();
+    }
+    if (lane < n)
+        wr[lane] = wi[lane] = 0.0;
+    const double eps = 2.220446049250313e-16;
+    double anorm = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = (i - 1 > 0 ? i - 1 : 0); j < n; ++j)
+            anorm += fabs(PL_A(i, j));
+    int nn = n - 1;
+    double t = 0, p = 0, q = 0, r = 0, s = 0, w = 0, x = 0, y = 0, z = 0;
+    while (nn >= 0) {
+        int its = 0, l;
+        do {
+            PL_WAVE_SYNC();
+            for (l = nn; l >= 1; --l) {
+                s = fabs(PL_A(l - 1, l - 1)) + fabs(PL_A(l, l));
+                if (s == 0)
+                    s = anorm;
+                if (fabs(PL_A(l, l - 1)) <= eps * s) {
+                    PL_WAVE_SYNC();
+                    if (lane == 0)
+                        PL_A(l, l - 1) = 0;
+                    PL_WAVE_SYNC();
+                    break;
+                }
+            }
+            x = PL_A(nn, nn);
+            if (l == nn) {
+                if (lane == 0) {
+                    wr[nn] = x + t;
+                    wi[nn] = 0;
+                }
+                --nn;
+            } else {
+                y = PL_A(nn - 1, nn - 1);
+                w = PL_A(nn, nn - 1) * PL_A(nn - 1, nn);
+                if (l == nn - 1) {
+                    p = 0.5 * (y - x);
+                    q = p * p + w;
+                    z = sqrt(fabs(q));
+                    x += t;
+                    if (q >= 0) {
+                        z = p + (p >= 0 ? fabs(z) : -fabs(z));
+                        double w1 = x + z, w2 = x + z;
+                        if (z != 0)
+                            w2 = x - w / z;
+                        if (lane == 0) {
+                            wr[nn - 1] = w1, wr[nn] = w2;
+                            wi[nn - 1] = wi[nn] = 0;
+                        }
+                    } else {
+                        if (lane == 0) {
+                            wr[nn - 1] = wr[nn] = x + p;
+                            wi[nn - 1] = z;
+                            wi[nn] = -z;
+                        }
+                    }
+                    nn -= 2;
+                } else {
+                    if (its == 60)
+                        return 0;
+                    if (its == 10 || its == 20) {
+                        t += x;
+                        PL_WAVE_SYNC();
+                        if (lane <= nn)
+                            PL_A(lane, lane) -= x;
+                        PL_WAVE_SYNC();
+                        s = fabs(PL_A(nn, nn - 1)) + fabs(PL_A(nn - 1, nn - 2));
+                        y = x = 0.75 * s;
+                        w = -0.4375 * s * s;
+                    }
+                    ++its;
+                    int m;
+                    for (m = nn - 2; m >= l; --m) {
+                        z = PL_A(m, m);
+                        r = x - z;
+                        s = y - z;
+                        p = (r * s - w) / PL_A(m + 1, m) + PL_A(m, m + 1);
+                        q = PL_A(m + 1, m + 1) - z - r - s;
+                        r = PL_A(m + 2, m + 1);
+                        s = fabs(p) + fabs(q) + fabs(r);
+                        p /= s, q /= s, r /= s;
+                        if (m == l)
+                            break;
+                        const double u = fabs(PL_A(m, m - 1)) * (fabs(q) + fabs(r));
+                        const double v = fabs(p) * (fabs(PL_A(m - 1, m - 1)) + fabs(z) + fabs(PL_A(m + 1, m + 1)));
+                        if (u <= eps * v)
+                            break;
+                    }
+                    PL_WAVE_SYNC();
+                    if (lane >= m + 2 && lane <= nn) { // i = lane
+                        PL_A(lane, lane - 2) = 0;
+                        if (lane != m + 2)
+                            PL_A(lane, lane - 3) = 0;
+                    }
+                    PL_WAVE_SYNC();
+                    for (int k = m; k <= nn - 1; ++k) {
+                        if (k != m) {
+                            p = PL_A(k, k - 1);
+                            q = PL_A(k + 1, k - 1);
+                            r = (k != nn - 1) ? PL_A(k + 2, k - 1) : 0.0;
+                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0)
+                                p /= x, q /= x, r /= x;
+                        }
+                        const double sq = sqrt(p * p + q * q + r * r);
+                        if ((s = (p >= 0 ? sq : -sq)) != 0) {
+                            PL_WAVE_SYNC();
+                            if (lane == 0) {
+                                if (k == m) {
+                                    if (l != m)
+                                        PL_A(k, k - 1) = -PL_A(k, k - 1);
+                                } else {
+                                    PL_A(k, k - 1) = -s * x;
+                                }
+                            }
+                            p += s;
+                            x = p / s, y = q / s, z = r / s;
+                            q /= p, r /= p;
+                            PL_WAVE_SYNC();
+                            if (lane >= k && lane <= nn) { // the reflector on rows k .. k + 2: column j = lane
+                                const int j = lane;
+                                double pp = PL_A(k, j) + q * PL_A(k + 1, j);
+                                if (k != nn - 1) {
+                                    pp += r * PL_A(k + 2, j);
+                                    PL_A(k + 2, j) -= pp * z;
+                                }
+                                PL_A(k + 1, j) -= pp * y;
+                                PL_A(k, j) -= pp * x;
+                            }
+                            PL_WAVE_SYNC();
+                            const int mmin = nn < k + 3 ? nn : k + 3;
+                            if (lane >= l && lane <= mmin) { // on columns k .. k + 2: row i = lane
+                                const int i = lane;
+                                double pp = x * PL_A(i, k) + y * PL_A(i, k + 1);
+                                if (k != nn - 1) {
+                                    pp += z * PL_A(i, k + 2);
+                                    PL_A(i, k + 2) -= pp * r;
+                                }
+                                PL_A(i, k + 1) -= pp * q;
+                                PL_A(i, k) -= pp;
+                            }
+                            PL_WAVE_SYNC();
+                        }
+                    }
+                }
+            }
+        } while (l < nn - 1);
+    }
+#undef PL_A
+    PL_WAVE_SYNC();
+    int m = 0; // (every lane walks the same list; lane 0 writes it)
+    for (int i = 0; i < n; ++i)
+        if (fabs(wi[i]) <= tol * (1.0 + fabs(wr[i]))) { // insertion into the ascending list
+            int j = m++;
+            const double v = wr[i];
+            PL_WAVE_SYNC();
+            if (lane == 0) {
+                while (j > 0 && out[j - 1] > v) {
+                    out[j] = out[j - 1];
+                    --j;
+                }
+                out[j] = v;
+            }
+            PL_WAVE_SYNC();
+        }
+    return m;
+}
+
+} // namespace pl

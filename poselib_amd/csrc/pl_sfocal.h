@@ -164,6 +164,8 @@ struct SFocalGenArgs {
     uint32_t *num_models; // [num_iters]
     FocalModel *host_models;   // optional mirrors in pinned host memory (same layout): only the models found are written
     uint32_t *host_num_models;
+    double *stage;             // sfocal_stage_bytes(num_iters): workspace of the three generator kernels (sfocal.hip)
+    const double *explicit_in; // optional: num_iters x 36 minimal problems [x1 6 x 3 | x2 6 x 3] instead of samples of the points
 };
 struct SFocalScoreArgs {
     const double *a[4];
@@ -191,7 +193,9 @@ struct SFocalLMTask {
 #if defined(__HIPCC__)
 hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream);
 hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream);
-hipError_t launch_sfocal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, hipStream_t stream);
+size_t sfocal_stage_bytes(uint32_t num_iters);
+hipError_t launch_sfocal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, double *stage,
+                               uint32_t stage_samples, hipStream_t stream);
 hipError_t launch_sfocal_mask(const double *const *a, uint32_t n, const FocalModel &m, double thr2, uint8_t *mask, uint8_t *host_mask,
                               hipStream_t stream);
 hipError_t launch_sfocal_lm(SFocalLMTask *tasks, uint32_t num_tasks, hipStream_t stream);

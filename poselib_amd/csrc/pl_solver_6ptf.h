@@ -286,9 +286,12 @@ template <int n, class Arr> PL_HD void pl_balance_pow2(Arr a) {
 
 constexpr int kSixMaxModels = 60; // 15 solutions x 4 poses (relpose_6pt_focal.cc:1101)
 
-// x1, x2: six unit bearings.  emit(q, t, focal) is called for every model, in the reference's order.  Returns their number.
-template <class Emit> PL_HD int relpose_6pt_shared_focal(const Vec3 *x1, const Vec3 *x2, const SixWork &w, Emit &&emit) {
-    double nb[27];
+// The solver in three stages - on the device three kernels with three different footprints (sfocal.hip), on the host and in
+// relpose_6pt_shared_focal() below one after the other.
+//
+// Stage 1: null space nb (9 x 3) of the six epipolar constraints, the ten equations C (kept for stage 3) and the 15 x 15 companion
+// matrix T.  false: a vanishing pivot in the row reduction (no models).  Needs the whole workspace w.
+PL_HD bool six_setup(const Vec3 *x1, const Vec3 *x2, const SixWork &w, double *nb /* 27 */) {
     {
         double A[54];
         for (int i = 0; i < 6; ++i) {
@@ -305,14 +308,21 @@ template <class Emit> PL_HD int relpose_6pt_shared_focal(const Vec3 *x1, const V
     six_equations(nb, C);
     for (int e = 0; e < 300; ++e)
         Cw[e] = C[e];
-    if (!six_companion(Cw, T, A, B))
-        return 0;
+    return six_companion(Cw, T, A, B);
+}
+// Stage 2: the real eigenvalues w = 1 / f^2 of the companion matrix T (15 x 15, destroyed), ascending.  Needs T only.
+PL_HD int six_eigenvalues(const SixWork &T, double *ev /* 15 */) {
     for (int e = 0; e < 225; ++e)
         if (!isfinite(T[e]))
             return 0; // (a vanishing pivot: the balancing below would not terminate on an infinite entry)
     pl_balance_pow2<15>(T);
-    double ev[15];
-    const int nroots = pl_real_eigenvalues<15>(T, ev, 1e-8);
+    return pl_real_eigenvalues<15>(T, ev, 1e-8);
+}
+// Stage 3: (x, y) of every root from the null vector of C0 + w C1 + w^2 C2, the essential matrices, the poses.  C: the equations
+// of stage 1 (read only), A: a workspace of 100 doubles.  emit(q, t, focal) is called for every model, in the reference's order.
+template <class Emit>
+PL_HD int six_finish(const Vec3 *x1, const Vec3 *x2, const double *nb, const SixWork &C, const SixWork &A, const double *ev, int nroots,
+                     Emit &&emit) {
     double sx[15], sy[15], sw[15];
     int ns = 0;
     for (int s = 0; s < nroots; ++s) {
@@ -360,6 +370,15 @@ template <class Emit> PL_HD int relpose_6pt_shared_focal(const Vec3 *x1, const V
         });
     }
     return n;
+}
+
+// x1, x2: six unit bearings.  emit(q, t, focal) is called for every model, in the reference's order.  Returns their number.
+template <class Emit> PL_HD int relpose_6pt_shared_focal(const Vec3 *x1, const Vec3 *x2, const SixWork &w, Emit &&emit) {
+    double nb[27], ev[15];
+    if (!six_setup(x1, x2, w, nb))
+        return 0;
+    const int nroots = six_eigenvalues(w.at(kSixT), ev);
+    return six_finish(x1, x2, nb, w.at(kSixC), w.at(kSixA), ev, nroots, emit);
 }
 
 } // namespace pl

@@ -609,21 +609,30 @@ PL_HD bool p35pf_eliminate(const P35Work &w, double *E /* 50 */) {
     return true;
 }
 
-// Stage 3: action matrix of x4 on the standard monomials, its real eigenvalues, the null vectors, the poses.  am, wk: two
+// Stage 3: action matrix of x4 on the standard monomials (am), its real eigenvalues, the null vectors, the poses.  am, wk: two
 // workspaces of 100 doubles (LDS on the device: as local arrays they were scratch memory behind the vector memory path).
+PL_HD double p35pf_action_entry(const double *E /* 50 */, int k, int j) {
+    const int sh = kP35Shifted[k];
+    return sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[k * 10 + j];
+}
+PL_HD int p35pf_poses(const StridedArr &am, const StridedArr &wk, const double *ev, int nroots, const double *N /* 60 */, double f0,
+                      P35Solution *out);
 // Returns the number of solutions (<= 10), ascending in the eigenvalue.
 PL_HD int p35pf_finish(const double *E /* 50 */, const double *N /* 60 */, double f0, const StridedArr &am, const StridedArr &wk,
                        P35Solution *out) {
-    for (int k = 0; k < 10; ++k) {
-        const int sh = kP35Shifted[k];
+    for (int k = 0; k < 10; ++k)
         for (int j = 0; j < 10; ++j)
-            am[k * 10 + j] = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[k * 10 + j];
-    }
+            am[k * 10 + j] = p35pf_action_entry(E, k, j);
     double ev[10];
     for (int i = 0; i < 100; ++i)
         wk[i] = am[i];
     const int nroots = pl_real_eigenvalues<10>(wk, ev, 1e-8);
     PL_P35_MARK(4);
+    return p35pf_poses(am, wk, ev, nroots, N, f0, out);
+}
+// the null vector of (action matrix - eigenvalue) for every root, P = sum alpha_k N_k, the pose and focal length
+PL_HD int p35pf_poses(const StridedArr &am, const StridedArr &wk, const double *ev, int nroots, const double *N /* 60 */, double f0,
+                      P35Solution *out) {
     int n = 0;
     for (int s = 0; s < nroots; ++s) {
         double v[10];

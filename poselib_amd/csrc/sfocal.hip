@@ -21,70 +21,145 @@
 #include "pl_device.h"
 #include "pl_sfocal.h"
 #include "pl_solver_6ptf.h"
+#include "pl_eigen_wave.h"
+#include <algorithm>
 #include <atomic>
 
 namespace pl {
 
 namespace {
 
-// kGenLanes samples per workgroup: their solver workspaces (8.6 KB each) fill the CU's LDS
-constexpr int kGenLanes = 16;
-__global__ __launch_bounds__(64) void k_sfocal_generate(SFocalGenArgs g) {
+// ---- the generator: three kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ----------------------
+//   k_sfocal_setup   one lane = one sample, the solver's whole workspace (8.6 KB per sample) in LDS: 16 samples per workgroup, one
+//                    workgroup per CU - null space, equations, row reduction to the 15 x 15 companion matrix; T, C, nb and the
+//                    bearings go to the stage
+//   k_sfocal_eigen   one WAVEFRONT = one sample: balancing + Hessenberg + Francis QR of T by the 64 lanes together (pl_eigen_wave.h) -
+//                    as one lane per sample this stage took 2.1 ms per batch
+//   k_sfocal_finish  one lane = one sample, C and the 10 x 10 matrix of the null vectors in LDS (3.2 KB per sample): null vectors,
+//                    essential matrices, poses
+// Round 3's single kernel held 8.6 KB of LDS per sample through all three (2.86 ms on 63 CUs per batch of 1001 samples: four
+// problems filled the device, which bounded the throughput of several host threads at 1.4 k problems/s).
+constexpr int kGenLanes = 16; // stage 1: samples per workgroup (their workspaces fill the CU's LDS)
+constexpr int kStT = 0, kStC = 225, kStNb = 525, kStX = 552, kStOk = 588, kStEv = 589, kStRoots = 604, kStDoubles = 605;
+
+__global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
     extern __shared__ double s_work[]; // kSixWorkDoubles x kGenLanes, element-major
     const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
     if (it >= g.num_iters)
         return;
-    uint32_t idx[kSFocalSample];
-    if (g.samples) { // PROSAC: drawn on the host
-        for (int k = 0; k < kSFocalSample; ++k)
-            idx[k] = g.samples[(size_t)it * kSFocalSample + k];
-    } else {
-        draw_sample<kSFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
-    }
     Vec3 x1[6], x2[6];
-    for (int k = 0; k < 6; ++k) { // relative_pose.cc:157-160: homogeneous().normalized()
-        x1[k] = bearing(g.a[0][idx[k]], g.a[1][idx[k]]);
-        x2[k] = bearing(g.a[2][idx[k]], g.a[3][idx[k]]);
+    if (g.explicit_in) { // minimal problems given explicitly: [x1 6 x 3 | x2 6 x 3] unit bearings
+        const double *p = g.explicit_in + (size_t)it * 36;
+        for (int k = 0; k < 6; ++k) {
+            x1[k] = v3(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+            x2[k] = v3(p[18 + 3 * k], p[19 + 3 * k], p[20 + 3 * k]);
+        }
+    } else {
+        uint32_t idx[kSFocalSample];
+        if (g.samples) { // PROSAC: drawn on the host
+            for (int k = 0; k < kSFocalSample; ++k)
+                idx[k] = g.samples[(size_t)it * kSFocalSample + k];
+        } else {
+            draw_sample<kSFocalSample>(g.seed, g.pos_base + g.positions[it], g.n, idx);
+        }
+        for (int k = 0; k < 6; ++k) { // relative_pose.cc:157-160: homogeneous().normalized()
+            x1[k] = bearing(g.a[0][idx[k]], g.a[1][idx[k]]);
+            x2[k] = bearing(g.a[2][idx[k]], g.a[3][idx[k]]);
+        }
     }
+    const size_t B = g.num_iters;
+    double *st = g.stage + it;
+    const SixWork w{s_work + threadIdx.x, (size_t)kGenLanes};
+    double nb[27];
+    const bool ok = six_setup(x1, x2, w, nb);
+    st[(size_t)kStOk * B] = ok ? 1.0 : 0.0;
+    if (!ok)
+        return;
+    const SixWork T = w.at(kSixT), C = w.at(kSixC);
+    for (int e = 0; e < 225; ++e)
+        st[(size_t)(kStT + e) * B] = T[e];
+    for (int e = 0; e < 300; ++e)
+        st[(size_t)(kStC + e) * B] = C[e];
+    for (int e = 0; e < 27; ++e)
+        st[(size_t)(kStNb + e) * B] = nb[e];
+    for (int k = 0; k < 6; ++k) {
+        st[(size_t)(kStX + 3 * k) * B] = x1[k].x, st[(size_t)(kStX + 3 * k + 1) * B] = x1[k].y, st[(size_t)(kStX + 3 * k + 2) * B] = x1[k].z;
+        st[(size_t)(kStX + 18 + 3 * k) * B] = x2[k].x, st[(size_t)(kStX + 19 + 3 * k) * B] = x2[k].y,
+                                     st[(size_t)(kStX + 20 + 3 * k) * B] = x2[k].z;
+    }
+}
+
+// one wavefront = one sample: the 15 x 15 companion matrix in LDS, balanced and reduced by the lanes together (pl_eigen_wave.h:
+// six_eigenvalues of pl_solver_6ptf.h, the same operations on every element)
+constexpr int kEigWaves = 4;
+__global__ __launch_bounds__(64 * kEigWaves) void k_sfocal_eigen(double *stage, uint32_t num_iters) {
+    __shared__ double s_eig[kEigWaves][eig_wave_doubles(15)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blockIdx.x * kEigWaves + wave; // (wave-uniform)
+    if (it >= num_iters)
+        return;
+    const size_t B = num_iters;
+    double *st = stage + it;
+    double *a = s_eig[wave];
+    int nroots = 0;
+    if (st[(size_t)kStOk * B] != 0.0) {
+        bool finite = true;
+        for (int e = lane; e < 225; e += 64) {
+            const double v = st[(size_t)(kStT + e) * B];
+            a[e] = v;
+            finite = finite && isfinite(v);
+        }
+        if (!__builtin_amdgcn_ballot_w64(!finite)) { // (a vanishing pivot: the balancing would not terminate on an infinite entry)
+            PL_WAVE_SYNC();
+            pl_balance_pow2_wave<15>(a, lane);
+            nroots = pl_real_eigenvalues_wave<15>(a, 1e-8, lane);
+            if (lane < nroots)
+                st[(size_t)(kStEv + lane) * B] = a[225 + 45 + lane];
+        }
+    }
+    if (lane == 0)
+        st[(size_t)kStRoots * B] = (double)nroots;
+}
+
+constexpr int kFinLanes = 16;
+__global__ __launch_bounds__(64) void k_sfocal_finish(SFocalGenArgs g) {
+    __shared__ double s_A[400 * kFinLanes]; // per sample: the 10 x 10 matrix of the null vectors, then C (3 x 100)
+    const uint32_t it = blockIdx.x * kFinLanes + threadIdx.x;
+    if (threadIdx.x >= kFinLanes || it >= g.num_iters)
+        return;
+    const size_t B = g.num_iters;
+    const double *st = g.stage + it;
     uint32_t m = 0;
-    FocalModel *out = g.models + (size_t)it * kSFocalMaxModels;
-    relpose_6pt_shared_focal(x1, x2, SixWork{s_work + threadIdx.x, (size_t)kGenLanes}, [&](Quat q, Vec3 t, double f) {
-        FocalModel o;
-        o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
-        o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
-        o.f = f;
-        out[m] = o;
-        if (g.host_models)
-            g.host_models[(size_t)it * kSFocalMaxModels + m] = o;
-        ++m;
-    });
+    const int nroots = (int)st[(size_t)kStRoots * B];
+    if (nroots > 0) {
+        double ev[15], nb[27];
+        for (int s = 0; s < nroots; ++s)
+            ev[s] = st[(size_t)(kStEv + s) * B];
+        for (int e = 0; e < 27; ++e)
+            nb[e] = st[(size_t)(kStNb + e) * B];
+        Vec3 x1[6], x2[6];
+        for (int k = 0; k < 6; ++k) {
+            x1[k] = v3(st[(size_t)(kStX + 3 * k) * B], st[(size_t)(kStX + 3 * k + 1) * B], st[(size_t)(kStX + 3 * k + 2) * B]);
+            x2[k] = v3(st[(size_t)(kStX + 18 + 3 * k) * B], st[(size_t)(kStX + 19 + 3 * k) * B], st[(size_t)(kStX + 20 + 3 * k) * B]);
+        }
+        FocalModel *out = g.models + (size_t)it * kSFocalMaxModels;
+        const SixWork A{s_A + threadIdx.x, (size_t)kFinLanes}, C = A.at(100);
+        for (int e = 0; e < 300; ++e)
+            C[e] = st[(size_t)(kStC + e) * B];
+        six_finish(x1, x2, nb, C, A, ev, nroots, [&](Quat q, Vec3 t, double f) {
+            FocalModel o;
+            o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
+            o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
+            o.f = f;
+            out[m] = o;
+            if (g.host_models)
+                g.host_models[(size_t)it * kSFocalMaxModels + m] = o;
+            ++m;
+        });
+    }
     g.num_models[it] = m;
     if (g.host_num_models)
         g.host_num_models[it] = m;
-}
-
-// minimal problems given explicitly (pl_relpose_6pt_shared_focal, pl_solve_focal_batch): in = count x [x1 6 x 3 | x2 6 x 3]
-__global__ __launch_bounds__(64) void k_sfocal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models) {
-    extern __shared__ double s_work[];
-    const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
-    if (it >= count)
-        return;
-    const double *p = in + (size_t)it * 36;
-    Vec3 x1[6], x2[6];
-    for (int k = 0; k < 6; ++k) {
-        x1[k] = v3(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
-        x2[k] = v3(p[18 + 3 * k], p[19 + 3 * k], p[20 + 3 * k]);
-    }
-    uint32_t m = 0;
-    FocalModel *out = models + (size_t)it * kSFocalMaxModels;
-    relpose_6pt_shared_focal(x1, x2, SixWork{s_work + threadIdx.x, (size_t)kGenLanes}, [&](Quat q, Vec3 t, double f) {
-        FocalModel o;
-        o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
-        o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
-        o.f = f;
-        out[m++] = o;
-    });
-    num_models[it] = m;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-uniform
@@ -379,41 +454,48 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
 
 } // namespace
 
+size_t sfocal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)kStDoubles * num_iters; }
+
 hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
         return hipSuccess;
+    if (!g.stage)
+        return hipErrorInvalidValue;
     constexpr size_t bytes = sizeof(double) * kSixWorkDoubles * kGenLanes; // 137.6 KB of the CU's 160 KB
     static std::atomic<int> prepared_dev[64]; // per device ordinal: the attribute is per-device state on some runtimes
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     std::atomic<int> &prepared = prepared_dev[dev_ & 63];
     if (!prepared.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_generate),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess)
-            return e;
-        prepared.store(1, std::memory_order_release);
-    }
-    k_sfocal_generate<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
-    return hipGetLastError();
-}
-hipError_t launch_sfocal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, hipStream_t stream) {
-    if (count == 0)
-        return hipSuccess;
-    constexpr size_t bytes = sizeof(double) * kSixWorkDoubles * kGenLanes;
-    static std::atomic<int> prepared_dev[64]; // per device ordinal: the attribute is per-device state on some runtimes
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    std::atomic<int> &prepared = prepared_dev[dev_ & 63];
-    if (!prepared.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_setup), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)bytes);
         if (e != hipSuccess)
             return e;
         prepared.store(1, std::memory_order_release);
     }
-    k_sfocal_solve<<<dim3((count + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(in, count, models, num_models);
+    k_sfocal_setup<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
+    k_sfocal_eigen<<<dim3((g.num_iters + kEigWaves - 1) / kEigWaves), dim3(64 * kEigWaves), 0, stream>>>(g.stage, g.num_iters);
+    k_sfocal_finish<<<dim3((g.num_iters + kFinLanes - 1) / kFinLanes), dim3(64), 0, stream>>>(g);
     return hipGetLastError();
+}
+// minimal problems given explicitly (pl_relpose_6pt_shared_focal, pl_solve_focal_batch): in = count x [x1 6 x 3 | x2 6 x 3].
+// stage: sfocal_stage_bytes(stage_samples) bytes; the problems go through it stage_samples at a time.
+hipError_t launch_sfocal_solve(const double *in, uint32_t count, FocalModel *models, uint32_t *num_models, double *stage,
+                               uint32_t stage_samples, hipStream_t stream) {
+    if (stage_samples == 0)
+        return hipErrorInvalidValue;
+    for (uint32_t first = 0; first < count; first += stage_samples) {
+        SFocalGenArgs g{};
+        g.explicit_in = in + (size_t)first * 36;
+        g.num_iters = std::min(stage_samples, count - first);
+        g.models = models + (size_t)first * kSFocalMaxModels;
+        g.num_models = num_models + first;
+        g.stage = stage;
+        hipError_t e = launch_sfocal_generate(g, stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
 }
 hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream) {
     if (a.num_slots == 0)
