@@ -22,20 +22,13 @@ namespace pl {
 
 namespace {
 
-// ---- the generator: three kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ----------------------
-//   k_focal_setup      one lane = one sample: draw (or read) the sample, null space of the linear constraints, the 29 equations
-//                      -> rows of the elimination matrix (coalesced: consecutive lanes = consecutive samples), N, f0
-//   k_focal_eliminate  one WAVEFRONT = one sample: lane c holds column c of the 29 x 35 matrix in registers (58 VGPRs); per pivot
-//                      every lane searches its own column, the pivot's lane decides (v_readlane), the factors f_r = entry (r, col)
-//                      come from the pivot's lane one v_readlane pair each, and all 35 columns are updated at once - element for
-//                      element the operations of p35pf_eliminate (pl_solver_p35pf.h), so the results are the same bits
-//   k_focal_eigen      one WAVEFRONT = one sample: the real eigenvalues of the 10 x 10 action matrix (pl_eigen_wave.h)
-//   k_focal_finish     one lane = one sample: null vectors, poses; its two 10 x 10 workspaces in LDS (1.6 KB per sample: 32
-//                      samples per workgroup, three workgroups per CU)
+// ---- the generator: two kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ------------------------
+//   k_focal_setup   one lane = one sample: draw (or read) the sample, null space of the linear constraints, the 29 equations
+//                   -> rows of the elimination matrix (coalesced: consecutive lanes = consecutive samples), N, f0
+//   k_focal_solve   one WAVEFRONT = one sample: elimination in registers, eigenvalues and roots by the lanes together (below)
 // Round 3's single kernel (one lane per sample, 8.1 KB of LDS per sample: 16 lanes per CU whatever the phase) took 1.5 ms per
-// launch and occupied 63 CUs for a batch of 1001 samples, which is what bounded the throughput of several problems in flight.
-constexpr int kStageN = kP35WorkDoubles, kStageF0 = kStageN + 60, kStageE = kStageF0 + 1, kStageOk = kStageE + kP35ActionDoubles,
-              kStageEv = kStageOk + 1, kStageRoots = kStageEv + 10, kStageDoubles = kStageRoots + 1;
+// launch and occupied 63 CUs for a batch of 1001 samples; the two kernels take 0.21 + 0.33 ms.
+constexpr int kStageN = kP35WorkDoubles, kStageF0 = kStageN + 60, kStageDoubles = kStageF0 + 1;
 
 __global__ __launch_bounds__(64) void k_focal_setup(FocalGenArgs g) {
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
@@ -76,141 +69,134 @@ __device__ __forceinline__ double readlane_f64(double v, int l) { // (l uniform)
     return __hiloint2double(hi, lo);
 }
 
-constexpr int kElimWaves = 4;
-__global__ __launch_bounds__(64 * kElimWaves) void k_focal_eliminate(double *stage, uint32_t B) {
-    const uint32_t it = blockIdx.x * kElimWaves + (threadIdx.x >> 6); // (wave-uniform)
-    if (it >= B)
-        return;
-    const int lane = threadIdx.x & 63;
-    const int c = lane < kP35Cols ? lane : kP35Cols - 1; // (lanes 35..63 shadow the last column: no divergence, never read)
-    double w[kP35Rows];
-#pragma unroll
-    for (int r = 0; r < kP35Rows; ++r)
-        w[r] = stage[(size_t)(r * kP35Cols + c) * B + it];
-    uint32_t used = 0;   // (uniform)
-    int pivot_of = 0;    // lane k: pivot row of eliminated monomial k
-    bool ok = true;
-#pragma unroll 1
-    for (int k = 0; k < 25; ++k) {
-        const int col = k < 23 ? k : k + 1; // kP35Elim
-        int pr = -1;
-        double best = 0;
-#pragma unroll
-        for (int r = 0; r < kP35Rows; ++r) {
-            const double v = fabs(w[r]);
-            if (!((used >> r) & 1u) && v > best)
-                best = v, pr = r;
-        }
-        pr = __builtin_amdgcn_readlane(pr, col);
-        best = readlane_f64(best, col);
-        if (pr < 0 || best < 1e-13) { // degenerate sample
-            ok = false;
-            break;
-        }
-        used |= 1u << pr;
-        pivot_of = lane == k ? pr : pivot_of;
-        double mine = w[0]; // w[pr] of this lane's column
-#pragma unroll
-        for (int r = 1; r < kP35Rows; ++r)
-            mine = r == pr ? w[r] : mine;
-        const double inv = 1.0 / readlane_f64(mine, col);
-        const double prow = mine * inv;
-#pragma unroll
-        for (int r = 0; r < kP35Rows; ++r) {
-            const double f = readlane_f64(w[r], col); // entry (r, col) before this pivot's update
-            if (r == pr)
-                w[r] = prow;
-            else if (f != 0)
-                w[r] -= f * prow;
-        }
-    }
-    if (lane == 0)
-        stage[(size_t)kStageOk * B + it] = ok ? 1.0 : 0.0;
-    if (!ok)
-        return;
-    // E[i][j] = entry (pivot row of monomial kP35ActionPivot[i], basis column j): lane kP35Basis[j] holds the column
-    const int j = lane >= 30 ? lane - 25 : lane == 27 ? 0 : lane == 23 ? 1 : lane == 26 ? 2 : lane == 28 ? 3 : lane == 29 ? 4 : -1;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int row = __builtin_amdgcn_readlane(pivot_of, kP35ActionPivot[i]);
-        double v = w[0];
-#pragma unroll
-        for (int r = 1; r < kP35Rows; ++r)
-            v = r == row ? w[r] : v;
-        if (j >= 0 && lane < kP35Cols)
-            stage[(size_t)(kStageE + i * 10 + j) * B + it] = v;
-    }
-}
-
-// one wavefront = one sample: the 10 x 10 action matrix in LDS, its real eigenvalues by the lanes together (pl_eigen_wave.h)
-constexpr int kEigWaves = 4;
-__global__ __launch_bounds__(64 * kEigWaves) void k_focal_eigen(double *stage, uint32_t B) {
-    __shared__ double s_eig[kEigWaves][eig_wave_doubles(10)];
+// k_focal_solve: one WAVEFRONT = one sample, three stages in one launch (as three kernels they cost two more dispatches per batch,
+// which is what several problems in flight on the device's hardware queues pay for: ~60 us each under 16 streams).
+//   elimination   lane c holds column c of the 29 x 35 matrix in registers (58 VGPRs); per pivot every lane searches its own column,
+//                 the pivot's lane decides (v_readlane), the factors f_r = entry (r, col) come from the pivot's lane one v_readlane
+//                 pair each, and all 35 columns are updated at once - element for element the operations of p35pf_eliminate
+//                 (pl_solver_p35pf.h), so the results are the same bits (as one lane per sample, matrices in LDS: 0.43 ms)
+//   eigenvalues   of the 10 x 10 action matrix by the lanes together (pl_eigen_wave.h; one lane per sample: 0.55 ms)
+//   roots         lane s = root s: null vector (its own 10 x 10 working copy in LDS), pose and focal length at once
+//                 (p35pf_pose_of_root; one lane per sample, root after root: 0.41 ms); the solutions leave in the order of the roots
+//                 (ballot + v_mbcnt)
+constexpr int kSolveWaves = 4, kFinRoots = 16;
+constexpr int kSolveLds = 100 + 100 * kFinRoots; // action matrix | working copies of the roots, element-major over the roots
+static_assert(eig_wave_doubles(10) + kP35ActionDoubles <= 100 * kFinRoots, "the eigenvalue workspace and E live in the roots' region");
+__global__ __launch_bounds__(64 * kSolveWaves) void k_focal_solve(FocalGenArgs g) {
+    __shared__ double s_solve[kSolveWaves][kSolveLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blockIdx.x * kEigWaves + wave; // (wave-uniform)
-    if (it >= B)
+    const uint32_t it = blockIdx.x * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
         return;
-    double *a = s_eig[wave];
-    int nroots = 0;
-    if (stage[(size_t)kStageOk * B + it] != 0.0) {
+    const size_t B = g.num_iters;
+    const double *stage = g.stage;
+    double *base = s_solve[wave], *eig = base + 100, *E = eig + eig_wave_doubles(10);
+    uint32_t m = 0;
+    bool ok = true;
+    { // ---- elimination
+        const int c = lane < kP35Cols ? lane : kP35Cols - 1; // (lanes 35..63 shadow the last column: no divergence, never read)
+        double w[kP35Rows];
+#pragma unroll
+        for (int r = 0; r < kP35Rows; ++r)
+            w[r] = stage[(size_t)(r * kP35Cols + c) * B + it];
+        uint32_t used = 0; // (uniform)
+        int pivot_of = 0;  // lane k: pivot row of eliminated monomial k
+#pragma unroll 1
+        for (int k = 0; k < 25; ++k) {
+            const int col = k < 23 ? k : k + 1; // kP35Elim
+            int pr = -1;
+            double best = 0;
+#pragma unroll
+            for (int r = 0; r < kP35Rows; ++r) {
+                const double v = fabs(w[r]);
+                if (!((used >> r) & 1u) && v > best)
+                    best = v, pr = r;
+            }
+            pr = __builtin_amdgcn_readlane(pr, col);
+            best = readlane_f64(best, col);
+            if (pr < 0 || best < 1e-13) { // degenerate sample
+                ok = false;
+                break;
+            }
+            used |= 1u << pr;
+            pivot_of = lane == k ? pr : pivot_of;
+            double mine = w[0]; // w[pr] of this lane's column
+#pragma unroll
+            for (int r = 1; r < kP35Rows; ++r)
+                mine = r == pr ? w[r] : mine;
+            const double inv = 1.0 / readlane_f64(mine, col);
+            const double prow = mine * inv;
+#pragma unroll
+            for (int r = 0; r < kP35Rows; ++r) {
+                const double f = readlane_f64(w[r], col); // entry (r, col) before this pivot's update
+                if (r == pr)
+                    w[r] = prow;
+                else if (f != 0)
+                    w[r] -= f * prow;
+            }
+        }
+        if (ok) {
+            // E[i][j] = entry (pivot row of monomial kP35ActionPivot[i], basis column j): lane kP35Basis[j] holds the column
+            const int j = lane >= 30 ? lane - 25 : lane == 27 ? 0 : lane == 23 ? 1 : lane == 26 ? 2 : lane == 28 ? 3 : lane == 29 ? 4 : -1;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int row = __builtin_amdgcn_readlane(pivot_of, kP35ActionPivot[i]);
+                double v = w[0];
+#pragma unroll
+                for (int r = 1; r < kP35Rows; ++r)
+                    v = r == row ? w[r] : v;
+                if (j >= 0 && lane < kP35Cols)
+                    E[i * 10 + j] = v;
+            }
+        }
+    }
+    if (ok) {
+        // ---- action matrix (kept for the roots) and a copy for the eigenvalue iteration, which destroys it
+        PL_WAVE_SYNC();
         for (int e = lane; e < 100; e += 64) {
             const int k = e / 10, j = e - 10 * k;
             const int sh = kP35Shifted[k];
-            a[e] = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -stage[(size_t)(kStageE + e) * B + it]; // p35pf_action_entry
+            const double v = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[e]; // p35pf_action_entry
+            base[e] = v;
+            eig[e] = v;
         }
-        nroots = pl_real_eigenvalues_wave<10>(a, 1e-8, lane);
-        if (lane < nroots)
-            stage[(size_t)(kStageEv + lane) * B + it] = a[100 + 30 + lane];
-    }
-    if (lane == 0)
-        stage[(size_t)kStageRoots * B + it] = (double)nroots;
-}
-
-constexpr int kFinLanes = 32;
-__global__ __launch_bounds__(64) void k_focal_finish(FocalGenArgs g) {
-    __shared__ double s_work[200 * kFinLanes]; // action matrix + working copy per sample, element-major
-    const uint32_t it = blockIdx.x * kFinLanes + threadIdx.x;
-    if (threadIdx.x >= kFinLanes || it >= g.num_iters)
-        return;
-    const size_t B = g.num_iters;
-    uint32_t m = 0;
-    if (g.stage[(size_t)kStageOk * B + it] != 0.0) {
-        double E[kP35ActionDoubles], N[60];
-        for (int e = 0; e < kP35ActionDoubles; ++e)
-            E[e] = g.stage[(size_t)(kStageE + e) * B + it];
-        for (int e = 0; e < 60; ++e)
-            N[e] = g.stage[(size_t)(kStageN + e) * B + it];
-        const double f0 = g.stage[(size_t)kStageF0 * B + it];
-        const int nroots = (int)g.stage[(size_t)kStageRoots * B + it];
-        double ev[10];
-        for (int r = 0; r < nroots; ++r)
-            ev[r] = g.stage[(size_t)(kStageEv + r) * B + it];
-        P35Solution sol[kFocalMaxModels];
-        const StridedArr am{s_work + threadIdx.x, (size_t)kFinLanes};
-        for (int k = 0; k < 10; ++k)
-            for (int j = 0; j < 10; ++j)
-                am[k * 10 + j] = p35pf_action_entry(E, k, j);
-        const int n = p35pf_poses(am, am.at(100), ev, nroots, N, f0, sol);
-        for (int i = 0; i < n; ++i) {
-            if (!g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
-                if (sol[i].focal < 0)
-                    continue;
-                if (g.max_focal >= 0 && sol[i].focal > g.max_focal)
-                    continue;
+        const int nroots = pl_real_eigenvalues_wave<10>(eig, 1e-8, lane);
+        const double ev = lane < nroots ? eig[100 + 30 + lane] : 0.0;
+        PL_WAVE_SYNC();
+        // ---- roots
+        bool valid = false;
+        P35Solution sol;
+        if (lane < nroots) {
+            double N[60];
+            for (int e = 0; e < 60; ++e)
+                N[e] = stage[(size_t)(kStageN + e) * B + it];
+            const double f0 = stage[(size_t)kStageF0 * B + it];
+            valid = p35pf_pose_of_root(StridedArr{base, 1}, StridedArr{base + 100 + lane, (size_t)kFinRoots}, ev, N, f0, sol);
+            if (valid && !g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
+                if (sol.focal < 0)
+                    valid = false;
+                if (g.max_focal >= 0 && sol.focal > g.max_focal)
+                    valid = false;
             }
+        }
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
+        m = (uint32_t)__popcll(mask);
+        if (valid) {
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             FocalModel o;
-            o.q[0] = sol[i].q.w, o.q[1] = sol[i].q.x, o.q[2] = sol[i].q.y, o.q[3] = sol[i].q.z;
-            o.t[0] = sol[i].t.x, o.t[1] = sol[i].t.y, o.t[2] = sol[i].t.z;
-            o.f = sol[i].focal;
-            g.models[(size_t)it * kFocalMaxModels + m] = o;
+            o.q[0] = sol.q.w, o.q[1] = sol.q.x, o.q[2] = sol.q.y, o.q[3] = sol.q.z;
+            o.t[0] = sol.t.x, o.t[1] = sol.t.y, o.t[2] = sol.t.z;
+            o.f = sol.focal;
+            g.models[(size_t)it * kFocalMaxModels + pos] = o;
             if (g.host_models)
-                g.host_models[(size_t)it * kFocalMaxModels + m] = o;
-            ++m;
+                g.host_models[(size_t)it * kFocalMaxModels + pos] = o;
         }
     }
-    g.num_models[it] = m;
-    if (g.host_num_models)
-        g.host_num_models[it] = m;
+    if (lane == 0) {
+        g.num_models[it] = m;
+        if (g.host_num_models)
+            g.host_num_models[it] = m;
+    }
 }
 
 constexpr int kFocalScoreThreads = 256;
@@ -285,9 +271,7 @@ hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
     if (!g.stage)
         return hipErrorInvalidValue;
     k_focal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
-    k_focal_eliminate<<<dim3((g.num_iters + kElimWaves - 1) / kElimWaves), dim3(64 * kElimWaves), 0, stream>>>(g.stage, g.num_iters);
-    k_focal_eigen<<<dim3((g.num_iters + kEigWaves - 1) / kEigWaves), dim3(64 * kEigWaves), 0, stream>>>(g.stage, g.num_iters);
-    k_focal_finish<<<dim3((g.num_iters + kFinLanes - 1) / kFinLanes), dim3(64), 0, stream>>>(g);
+    k_focal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     return hipGetLastError();
 }
 // minimal problems given explicitly (pl_p35pf, pl_solve_focal_batch): in = count x [x 4 x 2 | X 4 x 3]; every solution is kept.

@@ -319,56 +319,70 @@ PL_HD int six_eigenvalues(const SixWork &T, double *ev /* 15 */) {
     return pl_real_eigenvalues<15>(T, ev, 1e-8);
 }
 // Stage 3: (x, y) of every root from the null vector of C0 + w C1 + w^2 C2, the essential matrices, the poses.  C: the equations
-// of stage 1 (read only), A: a workspace of 100 doubles.  emit(q, t, focal) is called for every model, in the reference's order.
+// of stage 1 (read only), A: a workspace of 100 doubles.
+// one root w: false when it is dropped (w < 1e-8: focal length beyond 1e4; no null vector)
+PL_HD bool six_root_xy(const SixWork &C, const SixWork &A, double wv, double &x, double &y) {
+    if (wv < 1e-8)
+        return false;
+    double v[10];
+    for (int e = 0; e < 100; ++e)
+        A[e] = C[e] + wv * (C[100 + e] + wv * C[200 + e]);
+    pl_null_vector<10>(A, v);
+    if (v[9] == 0)
+        return false;
+    x = v[7] / v[9], y = v[8] / v[9];
+    return true;
+}
+// stable insertion of (x, y, w) into the list of ns solutions, ascending in y
+PL_HD void six_insert_solution(double *sx, double *sy, double *sw, int &ns, double x, double y, double wv) {
+    int j = ns++;
+    while (j > 0 && sy[j - 1] > y) {
+        sx[j] = sx[j - 1], sy[j] = sy[j - 1], sw[j] = sw[j - 1];
+        --j;
+    }
+    sx[j] = x, sy[j] = y, sw[j] = wv;
+}
+// the poses of one solution: emit(q, t, focal) for every one of them (<= 4), in the reference's order
+template <class Emit>
+PL_HD void six_solution_poses(const Vec3 *x1, const Vec3 *x2, const double *nb, double sx, double sy, double sw, Emit &&emit) {
+    const double focal = sqrt(1.0 / sw);
+    double Fv[9], nrm = 0;
+    for (int e = 0; e < 9; ++e) {
+        Fv[e] = nb[e] + sx * nb[9 + e] + sy * nb[18 + e];
+        nrm += Fv[e] * Fv[e];
+    }
+    nrm = sqrt(nrm);
+    Mat3 E;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double ki = i < 2 ? focal : 1.0, kj = j < 2 ? focal : 1.0;
+            E(i, j) = ki * ((Fv[3 * j + i] / nrm) * kj);
+        }
+    Vec3 u1[6], u2[6];
+    for (int i = 0; i < 6; ++i) {
+        u1[i] = normalized(v3(x1[i].x / focal, x1[i].y / focal, x1[i].z));
+        u2[i] = normalized(v3(x2[i].x / focal, x2[i].y / focal, x2[i].z));
+    }
+    motion_from_essential_emit<6>(E, u1, u2, [&](Quat q, Vec3 t) { emit(q, t, focal); });
+}
+// emit(q, t, focal) is called for every model, in the reference's order (on the device the roots, then the solutions, of a sample
+// go to the lanes of its wavefront: sfocal.hip k_sfocal_finish)
 template <class Emit>
 PL_HD int six_finish(const Vec3 *x1, const Vec3 *x2, const double *nb, const SixWork &C, const SixWork &A, const double *ev, int nroots,
                      Emit &&emit) {
     double sx[15], sy[15], sw[15];
     int ns = 0;
     for (int s = 0; s < nroots; ++s) {
-        const double wv = ev[s];
-        if (wv < 1e-8)
-            continue;
-        double v[10];
-        for (int e = 0; e < 100; ++e)
-            A[e] = C[e] + wv * (C[100 + e] + wv * C[200 + e]);
-        pl_null_vector<10>(A, v);
-        if (v[9] == 0)
-            continue;
-        // stable insertion, ascending in y
-        const double x = v[7] / v[9], y = v[8] / v[9];
-        int j = ns++;
-        while (j > 0 && sy[j - 1] > y) {
-            sx[j] = sx[j - 1], sy[j] = sy[j - 1], sw[j] = sw[j - 1];
-            --j;
-        }
-        sx[j] = x, sy[j] = y, sw[j] = wv;
+        double x, y;
+        if (six_root_xy(C, A, ev[s], x, y))
+            six_insert_solution(sx, sy, sw, ns, x, y, ev[s]);
     }
     int n = 0;
-    for (int s = 0; s < ns; ++s) {
-        const double focal = sqrt(1.0 / sw[s]);
-        double Fv[9], nrm = 0;
-        for (int e = 0; e < 9; ++e) {
-            Fv[e] = nb[e] + sx[s] * nb[9 + e] + sy[s] * nb[18 + e];
-            nrm += Fv[e] * Fv[e];
-        }
-        nrm = sqrt(nrm);
-        Mat3 E;
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                const double ki = i < 2 ? focal : 1.0, kj = j < 2 ? focal : 1.0;
-                E(i, j) = ki * ((Fv[3 * j + i] / nrm) * kj);
-            }
-        Vec3 u1[6], u2[6];
-        for (int i = 0; i < 6; ++i) {
-            u1[i] = normalized(v3(x1[i].x / focal, x1[i].y / focal, x1[i].z));
-            u2[i] = normalized(v3(x2[i].x / focal, x2[i].y / focal, x2[i].z));
-        }
-        motion_from_essential_emit<6>(E, u1, u2, [&](Quat q, Vec3 t) {
+    for (int s = 0; s < ns; ++s)
+        six_solution_poses(x1, x2, nb, sx[s], sy[s], sw[s], [&](Quat q, Vec3 t, double focal) {
             emit(q, t, focal);
             ++n;
         });
-    }
     return n;
 }
 

@@ -630,57 +630,62 @@ PL_HD int p35pf_finish(const double *E /* 50 */, const double *N /* 60 */, doubl
     PL_P35_MARK(4);
     return p35pf_poses(am, wk, ev, nroots, N, f0, out);
 }
-// the null vector of (action matrix - eigenvalue) for every root, P = sum alpha_k N_k, the pose and focal length
+// one root: the null vector of (action matrix - eigenvalue), P = sum alpha_k N_k, the pose and focal length.  false: no solution
+PL_HD bool p35pf_pose_of_root(const StridedArr &am, const StridedArr &wk, double ev, const double *N /* 60 */, double f0,
+                              P35Solution &out) {
+    double v[10];
+    for (int i = 0; i < 100; ++i)
+        wk[i] = am[i];
+    for (int i = 0; i < 10; ++i)
+        wk[i * 10 + i] -= ev;
+    pl_null_vector<10>(wk, v);
+    if (v[9] == 0)
+        return false;
+    const double al[5] = {v[5] / v[9], v[6] / v[9], v[7] / v[9], v[8] / v[9], 1.0};
+    double P[12];
+    for (int i = 0; i < 12; ++i) {
+        double sum = 0;
+        for (int k = 0; k < 5; ++k)
+            sum += N[k * 12 + i] * al[k];
+        P[i] = sum;
+    }
+    Mat3 R;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            R.m[3 * r + c] = P[4 * r + c];
+    double t[3] = {P[3], P[7], P[11]};
+    const double det = R.m[0] * (R.m[4] * R.m[8] - R.m[5] * R.m[7]) - R.m[1] * (R.m[3] * R.m[8] - R.m[5] * R.m[6]) +
+                       R.m[2] * (R.m[3] * R.m[7] - R.m[4] * R.m[6]);
+    const double sgn = det < 0 ? -1.0 : 1.0;
+    const double n3 = sqrt(R.m[6] * R.m[6] + R.m[7] * R.m[7] + R.m[8] * R.m[8]);
+    if (!(n3 > 0))
+        return false;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            R.m[3 * r + c] *= sgn / n3;
+        t[r] *= sgn / n3;
+    }
+    const double n1 = sqrt(R.m[0] * R.m[0] + R.m[1] * R.m[1] + R.m[2] * R.m[2]);
+    const double n2 = sqrt(R.m[3] * R.m[3] + R.m[4] * R.m[4] + R.m[5] * R.m[5]);
+    const double focal = 0.5 * (n1 + n2);
+    for (int c = 0; c < 3; ++c) {
+        R.m[c] /= focal;
+        R.m[3 + c] /= focal;
+    }
+    t[0] /= focal;
+    t[1] /= focal;
+    out.q = rotmat_to_quat(R);
+    out.t = v3(t[0], t[1], t[2]);
+    out.focal = focal * f0;
+    return true;
+}
+// every root, ascending (on the device the roots of a sample go to the lanes of its wavefront, focal.hip k_focal_finish)
 PL_HD int p35pf_poses(const StridedArr &am, const StridedArr &wk, const double *ev, int nroots, const double *N /* 60 */, double f0,
                       P35Solution *out) {
     int n = 0;
-    for (int s = 0; s < nroots; ++s) {
-        double v[10];
-        for (int i = 0; i < 100; ++i)
-            wk[i] = am[i];
-        for (int i = 0; i < 10; ++i)
-            wk[i * 10 + i] -= ev[s];
-        pl_null_vector<10>(wk, v);
-        if (v[9] == 0)
-            continue;
-        const double al[5] = {v[5] / v[9], v[6] / v[9], v[7] / v[9], v[8] / v[9], 1.0};
-        double P[12];
-        for (int i = 0; i < 12; ++i) {
-            double sum = 0;
-            for (int k = 0; k < 5; ++k)
-                sum += N[k * 12 + i] * al[k];
-            P[i] = sum;
-        }
-        Mat3 R;
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c)
-                R.m[3 * r + c] = P[4 * r + c];
-        double t[3] = {P[3], P[7], P[11]};
-        const double det = R.m[0] * (R.m[4] * R.m[8] - R.m[5] * R.m[7]) - R.m[1] * (R.m[3] * R.m[8] - R.m[5] * R.m[6]) +
-                           R.m[2] * (R.m[3] * R.m[7] - R.m[4] * R.m[6]);
-        const double sgn = det < 0 ? -1.0 : 1.0;
-        const double n3 = sqrt(R.m[6] * R.m[6] + R.m[7] * R.m[7] + R.m[8] * R.m[8]);
-        if (!(n3 > 0))
-            continue;
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c)
-                R.m[3 * r + c] *= sgn / n3;
-            t[r] *= sgn / n3;
-        }
-        const double n1 = sqrt(R.m[0] * R.m[0] + R.m[1] * R.m[1] + R.m[2] * R.m[2]);
-        const double n2 = sqrt(R.m[3] * R.m[3] + R.m[4] * R.m[4] + R.m[5] * R.m[5]);
-        const double focal = 0.5 * (n1 + n2);
-        for (int c = 0; c < 3; ++c) {
-            R.m[c] /= focal;
-            R.m[3 + c] /= focal;
-        }
-        t[0] /= focal;
-        t[1] /= focal;
-        out[n].q = rotmat_to_quat(R);
-        out[n].t = v3(t[0], t[1], t[2]);
-        out[n].focal = focal * f0;
-        ++n;
-    }
+    for (int s = 0; s < nroots; ++s)
+        if (p35pf_pose_of_root(am, wk, ev[s], N, f0, out[n]))
+            ++n;
     PL_P35_MARK(5);
     return n;
 }

@@ -29,18 +29,16 @@ namespace pl {
 
 namespace {
 
-// ---- the generator: three kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ----------------------
+// ---- the generator: two kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ------------------------
 //   k_sfocal_setup   one lane = one sample, the solver's whole workspace (8.6 KB per sample) in LDS: 16 samples per workgroup, one
 //                    workgroup per CU - null space, equations, row reduction to the 15 x 15 companion matrix; T, C, nb and the
 //                    bearings go to the stage
-//   k_sfocal_eigen   one WAVEFRONT = one sample: balancing + Hessenberg + Francis QR of T by the 64 lanes together (pl_eigen_wave.h) -
-//                    as one lane per sample this stage took 2.1 ms per batch
-//   k_sfocal_finish  one lane = one sample, C and the 10 x 10 matrix of the null vectors in LDS (3.2 KB per sample): null vectors,
-//                    essential matrices, poses
-// Round 3's single kernel held 8.6 KB of LDS per sample through all three (2.86 ms on 63 CUs per batch of 1001 samples: four
-// problems filled the device, which bounded the throughput of several host threads at 1.4 k problems/s).
+//   k_sfocal_solve   one WAVEFRONT = one sample: eigenvalues and roots by the lanes together (below)
+// Round 3's single kernel held 8.6 KB of LDS per sample through all stages (2.86 ms on 63 CUs per batch of 1001 samples: four
+// problems filled the device, which bounded the throughput of several host threads at 1.4 k problems/s); the two kernels take
+// 0.22 + 0.5 ms.
 constexpr int kGenLanes = 16; // stage 1: samples per workgroup (their workspaces fill the CU's LDS)
-constexpr int kStT = 0, kStC = 225, kStNb = 525, kStX = 552, kStOk = 588, kStEv = 589, kStRoots = 604, kStDoubles = 605;
+constexpr int kStT = 0, kStC = 225, kStNb = 525, kStX = 552, kStOk = 588, kStDoubles = 589;
 
 __global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
     extern __shared__ double s_work[]; // kSixWorkDoubles x kGenLanes, element-major
@@ -89,20 +87,33 @@ __global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
     }
 }
 
-// one wavefront = one sample: the 15 x 15 companion matrix in LDS, balanced and reduced by the lanes together (pl_eigen_wave.h:
-// six_eigenvalues of pl_solver_6ptf.h, the same operations on every element)
-constexpr int kEigWaves = 4;
-__global__ __launch_bounds__(64 * kEigWaves) void k_sfocal_eigen(double *stage, uint32_t num_iters) {
-    __shared__ double s_eig[kEigWaves][eig_wave_doubles(15)];
+// k_sfocal_solve: one WAVEFRONT = one sample, two stages in one launch.
+//   eigenvalues  the 15 x 15 companion matrix in LDS, balanced and reduced by the lanes together (pl_eigen_wave.h: six_eigenvalues of
+//                pl_solver_6ptf.h, the same operations on every element; as one lane per sample: 2.1 ms per batch)
+//   roots        phase 1, lane s = root s: (x, y) from the null vector of C0 + w C1 + w^2 C2 (its own 10 x 10 matrix in LDS).  Lane 0
+//                then builds the list of solutions ascending in y exactly as the serial routine inserts them.  Phase 2, lane s =
+//                solution s: essential matrix, up to four poses; the models leave in the order of the solutions (prefix sum of the
+//                counts).  As one lane per sample (root after root, solution after solution): 0.79 ms per batch.
+constexpr int kSolveWaves = 2, kFinRoots = 16;
+constexpr int kFinC = 0, kFinA = 300, kFinNb = kFinA + 100 * kFinRoots, kFinX = kFinNb + 27, kFinTmp = kFinX + 36,
+              kFinDoubles = kFinTmp + 7 * kFinRoots;
+static_assert(eig_wave_doubles(15) <= 100 * kFinRoots, "the eigenvalue workspace lives in the roots' region");
+__global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve(SFocalGenArgs g) {
+    __shared__ double s_fin[kSolveWaves][kFinDoubles];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blockIdx.x * kEigWaves + wave; // (wave-uniform)
-    if (it >= num_iters)
+    const uint32_t it = blockIdx.x * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
         return;
-    const size_t B = num_iters;
-    double *st = stage + it;
-    double *a = s_eig[wave];
+    const size_t B = g.num_iters;
+    const double *st = g.stage + it;
+    double *base = s_fin[wave];
+    double *rx = base + kFinTmp, *ry = rx + kFinRoots, *rw = ry + kFinRoots, *sx = rw + kFinRoots, *sy = sx + kFinRoots,
+           *sw = sy + kFinRoots, *cnt = sw + kFinRoots;
+    uint32_t m = 0;
     int nroots = 0;
+    double wv = 0.0;
     if (st[(size_t)kStOk * B] != 0.0) {
+        double *a = base + kFinA; // T, then the workspace of the iteration
         bool finite = true;
         for (int e = lane; e < 225; e += 64) {
             const double v = st[(size_t)(kStT + e) * B];
@@ -114,52 +125,75 @@ __global__ __launch_bounds__(64 * kEigWaves) void k_sfocal_eigen(double *stage, 
             pl_balance_pow2_wave<15>(a, lane);
             nroots = pl_real_eigenvalues_wave<15>(a, 1e-8, lane);
             if (lane < nroots)
-                st[(size_t)(kStEv + lane) * B] = a[225 + 45 + lane];
+                wv = a[225 + 45 + lane];
         }
+        PL_WAVE_SYNC();
     }
-    if (lane == 0)
-        st[(size_t)kStRoots * B] = (double)nroots;
-}
-
-constexpr int kFinLanes = 16;
-__global__ __launch_bounds__(64) void k_sfocal_finish(SFocalGenArgs g) {
-    __shared__ double s_A[400 * kFinLanes]; // per sample: the 10 x 10 matrix of the null vectors, then C (3 x 100)
-    const uint32_t it = blockIdx.x * kFinLanes + threadIdx.x;
-    if (threadIdx.x >= kFinLanes || it >= g.num_iters)
-        return;
-    const size_t B = g.num_iters;
-    const double *st = g.stage + it;
-    uint32_t m = 0;
-    const int nroots = (int)st[(size_t)kStRoots * B];
     if (nroots > 0) {
-        double ev[15], nb[27];
-        for (int s = 0; s < nroots; ++s)
-            ev[s] = st[(size_t)(kStEv + s) * B];
-        for (int e = 0; e < 27; ++e)
-            nb[e] = st[(size_t)(kStNb + e) * B];
-        Vec3 x1[6], x2[6];
-        for (int k = 0; k < 6; ++k) {
-            x1[k] = v3(st[(size_t)(kStX + 3 * k) * B], st[(size_t)(kStX + 3 * k + 1) * B], st[(size_t)(kStX + 3 * k + 2) * B]);
-            x2[k] = v3(st[(size_t)(kStX + 18 + 3 * k) * B], st[(size_t)(kStX + 19 + 3 * k) * B], st[(size_t)(kStX + 20 + 3 * k) * B]);
+        for (int e = lane; e < 300; e += 64)
+            base[kFinC + e] = st[(size_t)(kStC + e) * B];
+        if (lane < 27)
+            base[kFinNb + lane] = st[(size_t)(kStNb + lane) * B];
+        if (lane < 36)
+            base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
+        PL_WAVE_SYNC();
+        bool found = false;
+        if (lane < nroots) {
+            double x = 0, y = 0;
+            found = six_root_xy(SixWork{base + kFinC, 1}, SixWork{base + kFinA + lane, (size_t)kFinRoots}, wv, x, y);
+            rx[lane] = x, ry[lane] = y, rw[lane] = wv;
+        }
+        const uint64_t fmask = __builtin_amdgcn_ballot_w64(found);
+        PL_WAVE_SYNC();
+        int ns = 0;
+        if (lane == 0)
+            for (int s = 0; s < nroots; ++s)
+                if ((fmask >> s) & 1u)
+                    six_insert_solution(sx, sy, sw, ns, rx[s], ry[s], rw[s]);
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        PL_WAVE_SYNC();
+        FocalModel mine[4];
+        uint32_t c = 0;
+        if (lane < ns) {
+            Vec3 x1[6], x2[6];
+            double nb[27];
+            for (int e = 0; e < 27; ++e)
+                nb[e] = base[kFinNb + e];
+            for (int k = 0; k < 6; ++k) {
+                x1[k] = v3(base[kFinX + 3 * k], base[kFinX + 3 * k + 1], base[kFinX + 3 * k + 2]);
+                x2[k] = v3(base[kFinX + 18 + 3 * k], base[kFinX + 19 + 3 * k], base[kFinX + 20 + 3 * k]);
+            }
+            six_solution_poses(x1, x2, nb, sx[lane], sy[lane], sw[lane], [&](Quat q, Vec3 t, double f) {
+                FocalModel o;
+                o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
+                o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
+                o.f = f;
+                if (c < 4u)
+                    mine[c] = o;
+                ++c;
+            });
+        }
+        if (lane < kFinRoots)
+            cnt[lane] = (double)c;
+        PL_WAVE_SYNC();
+        uint32_t off = 0;
+        for (int s = 0; s < ns; ++s) {
+            const uint32_t cs = (uint32_t)cnt[s];
+            off += s < lane ? cs : 0u;
+            m += cs;
         }
         FocalModel *out = g.models + (size_t)it * kSFocalMaxModels;
-        const SixWork A{s_A + threadIdx.x, (size_t)kFinLanes}, C = A.at(100);
-        for (int e = 0; e < 300; ++e)
-            C[e] = st[(size_t)(kStC + e) * B];
-        six_finish(x1, x2, nb, C, A, ev, nroots, [&](Quat q, Vec3 t, double f) {
-            FocalModel o;
-            o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
-            o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
-            o.f = f;
-            out[m] = o;
+        for (uint32_t i = 0; i < c && i < 4u; ++i) {
+            out[off + i] = mine[i];
             if (g.host_models)
-                g.host_models[(size_t)it * kSFocalMaxModels + m] = o;
-            ++m;
-        });
+                g.host_models[(size_t)it * kSFocalMaxModels + off + i] = mine[i];
+        }
     }
-    g.num_models[it] = m;
-    if (g.host_num_models)
-        g.host_num_models[it] = m;
+    if (lane == 0) {
+        g.num_models[it] = m;
+        if (g.host_num_models)
+            g.host_num_models[it] = m;
+    }
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-uniform
@@ -474,8 +508,7 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
         prepared.store(1, std::memory_order_release);
     }
     k_sfocal_setup<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
-    k_sfocal_eigen<<<dim3((g.num_iters + kEigWaves - 1) / kEigWaves), dim3(64 * kEigWaves), 0, stream>>>(g.stage, g.num_iters);
-    k_sfocal_finish<<<dim3((g.num_iters + kFinLanes - 1) / kFinLanes), dim3(64), 0, stream>>>(g);
+    k_sfocal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     return hipGetLastError();
 }
 // minimal problems given explicitly (pl_relpose_6pt_shared_focal, pl_solve_focal_batch): in = count x [x1 6 x 3 | x2 6 x 3].
