@@ -2333,7 +2333,7 @@ int pl_ransac_pnpf(const double *x, const double *X, size_t n, const pl_robust_o
     if (rc != PL_OK)
         return rc;
     pl_ransac_stats local;
-    rc = run_focal(c, &p, &o, pose, focal, inliers, stats ? stats : &local);
+    rc = run_focal(c, &p, &o, pose, focal, inliers, stats ? stats : &local, x, nullptr);
     free_problem(&p);
     return rc;
 }
@@ -2414,7 +2414,7 @@ int pl_estimate_absolute_pose(const double *points2D, const double *points3D, si
     pl_bundle_options bundle = opt->bundle;
     if (opt->estimate_focal_length) { // robust.cc:47-54: ransac_pnpf on the un-projected points, the camera takes its focal length
         double focal = 1.0;
-        rc = run_focal(c, &p, &scaled, pose, &focal, inliers, st);
+        rc = run_focal(c, &p, &scaled, pose, &focal, inliers, st, points2D, &cam);
         free_problem(&p);
         if (rc != PL_OK)
             return rc;

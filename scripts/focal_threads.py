@@ -37,3 +37,13 @@ for T in [int(a) for a in sys.argv[1:]] or [1, 8, 16, 32]:
         for t in th: t.join()
         dt = time.perf_counter() - t0
         print(f"{name:18s} {T:3d} threads: {N / dt:8.0f} problems/s ({1e3 * dt / N * T:6.2f} ms per problem and thread)", flush=True)
+# the same problems as items of ONE pl_estimate_batch call (the library's own worker threads, one HIP stream each)
+for T in (8, 16):
+    for name, mk in (("pnpf_2000", lambda j: ("abs", da[j % 4]["p2d"], da[j % 4]["p3d"], da[j % 4]["camera"], {"max_error": 4.0, "estimate_focal_length": True, "ransac": {"seed": j}})),
+                     ("shared_focal_2000", lambda j: ("shared_focal", dr[j % 4]["x1"], dr[j % 4]["x2"], pp(dr[j % 4]), {"max_error": 2.0, "ransac": {"seed": j}}))):
+        b = P.Batch([mk(j) for j in range(512)])
+        b.run(T)
+        t0 = time.perf_counter()
+        b.run(T)
+        dt = time.perf_counter() - t0
+        print(f"{name:18s} pl_estimate_batch, 512 items, {T:2d} workers: {512 / dt:8.0f} problems/s", flush=True)
