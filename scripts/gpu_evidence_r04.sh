@@ -28,6 +28,11 @@ if [ "$PART" = "a" ]; then
   timeout 100 scripts/exp/chain_add > $O/chain_add.log 2>&1
   timeout 100 scripts/exp/mfma_f64_order > $O/mfma_f64_order.log 2>&1
   timeout 120 python scripts/time_focal_estimators.py 5 > $O/focal_timing.log 2>&1
+  timeout 300 python scripts/focal_threads.py 1 4 8 16 24 > $O/focal_threads.log 2>&1
+  timeout 200 scripts/exp/focal_threads 1 8 16 >> $O/focal_threads.log 2>&1
+  timeout 100 scripts/exp/p35_phases > $O/p35_phases.log 2>&1
+  (cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_focal -o r -- python $R/scripts/focal_threads.py 1 > $O/prof_focal.log 2>&1)
+  f=$(find $O/prof_focal -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/prof_focal.md
   f=$(find $O/prof_batch -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/prof_batch.md
   python scripts/busy.py $(find $O/kt_batch -name "*kernel_trace.csv") 0.45 > $O/busy_batch.txt
   python scripts/chain_view.py $(find $O/kt_batch -name "*kernel_trace.csv") > $O/chain_batch.txt

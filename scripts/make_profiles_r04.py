@@ -71,6 +71,10 @@ def main():
     wr("r04_chain_add.md", "# r04 - scripts/exp/chain_add.cc: the cost of a sequential fp64 sum on one gfx950 wavefront\n\n```\n" + rd("chain_add.log") + "```\n")
     wr("r04_mfma_f64_order.md", "# r04 - scripts/exp/mfma_f64_order.cc: v_mfma_f64_* accumulate as a k-ordered chain of fused multiply-adds, bit for bit\n\n```\n" + rd("mfma_f64_order.log") + "```\n")
     wr("r04_focal_estimators_timing.log", rd("focal_timing.log"))
+    for src, dst in (("focal_threads.log", "r04_focal_estimators_threads.log"), ("p35_phases.log", "r04_p35pf_phases_one_lane_per_sample.log"),
+                     ("prof_focal.md", "r04_focal_estimators_kernel_trace.md")):
+        if rd(src):
+            wr(dst, rd(src))
     # PMC constants of the dominant kernels (the expansion of the survivor bits changed in round 4: fewer instructions per hypothesis)
     WORK = {"p3p_5000": ("k_score_mfma<10>", 320, 5000), "relpose_5000": ("k_score_mfma2<1, 10>", 320, 5000),
             "fund_10000": ("k_score_mfma2<2, 12>", 384, 10000), "hom_10000": ("k_score_mfmah<10>", 320, 10000)}
