@@ -27,6 +27,7 @@ namespace {
 
 constexpr int kCamThreads = 256;
 constexpr int kCamWaves = kCamThreads / 64;
+constexpr int kProd = kCamThreads - 64; // correspondences per round: wavefronts 1 .. 3 produce, wavefront 0 adds
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -38,14 +39,14 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 } // namespace
 
 __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
-    extern __shared__ __attribute__((aligned(16))) double s_rows[]; // kCamThreads x kCamRow
+    extern __shared__ __attribute__((aligned(16))) double s_rows[]; // 2 buffers x kProd rows x kCamRow
     __shared__ LMTask s_task;
     __shared__ LMControl ctl;
     __shared__ double cur[kParamDoubles], trial[kParamDoubles];
     __shared__ CameraParams cam_cur, cam_trial;
     __shared__ double s_R[9];
     __shared__ double normal[kCamMaxEntries];
-    __shared__ uint32_t s_wcnt[kCamWaves];
+    __shared__ uint32_t s_wcnt[2][kCamWaves]; // rows a producer wavefront left in its third of buffer 0 / 1
     __shared__ double s_racc;
     __shared__ uint32_t s_count;
     __shared__ int s_idx[kCamMaxParams];
@@ -96,7 +97,9 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
     __syncthreads();
     const int M = s_M, K = 6 + M;
     const int NT = K * (K + 1) / 2 + K;
-    const CamEntry entry = cam_entry_of(min((int)threadIdx.x, NT - 1), K, s_idx);
+    // the consumer (wavefront 0): lane e owns entry e of [JtJ lower triangle | Jtr] and, beyond 64 entries (K >= 10), entry e + 64 as well
+    const CamEntry entry = cam_entry_of(min(lane, NT - 1), K, s_idx), entry_hi = cam_entry_of(min(lane + 64, NT - 1), K, s_idx);
+    const bool own_lo = wave == 0 && lane < NT, own_hi = wave == 0 && lane + 64 < NT;
 
     auto rotation_of = [&](const double *p) {
         if (threadIdx.x == 0) {
@@ -109,43 +112,53 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
         __syncthreads();
     };
 
-    // robust cost at (p, cam) -> s_racc, s_count
+    // Both passes are a two-stage pipeline over rounds of kProd = 192 correspondences (round 4; up to then every wavefront
+    // produced a round of 256, waited, and watched wavefront 0 add): wavefronts 1 .. 3 evaluate round r into buffer r & 1 while
+    // wavefront 0 adds round r - 1 from the other buffer; ONE barrier per round.  Each producer wavefront compacts ITS 64
+    // correspondences into its own third of the buffer (ballot + v_mbcnt: no count has to cross wavefronts before the rows are
+    // written), the consumer walks the thirds in order - ascending correspondences, as before.
+    const uint32_t rounds = (pts.n + (uint32_t)kProd - 1u) / (uint32_t)kProd;
+    const int pw = wave - 1; // producer wavefront 0 .. 2 (wavefront 0: consumer)
+
+    // robust cost at (p, cam) -> s_racc, s_count: the terms in the reference's order at EVERY n - every correspondence's term to
+    // LDS (zeros for skipped ones: x + 0.0 = x), lane 0 adds a round's 192 terms with the inline-asm chain of k_lm_ordered
+    // (pl_lm_chain.inc: 11.7 cycles per term)
     auto cost_pass = [&](const double *p, const CameraParams &camera) {
         rotation_of(p);
         const Loss loss = ctl.loss;
         const CameraParams cam = camera;
-        // in the reference's order at EVERY n (round 4; up to round 3: a wave tree beyond 256 correspondences): rounds of 256
-        // correspondences, every lane's term to LDS (zeros for skipped ones: x + 0.0 = x), lane 0 adds the round's 256 terms with the
-        // inline-asm chain of k_lm_ordered (pl_lm_chain.inc: 11.7 cycles per term)
+        double *const terms = s_rows; // [2][kProd]
         double tot = 0.0;
         uint32_t cnt = 0;
-        for (uint32_t base = 0; base < pts.n; base += (uint32_t)kCamThreads) {
-            double term = 0.0;
-            bool counted = false;
-            const uint32_t i = base + threadIdx.x;
-            if (i < pts.n && !(mask && !mask[i]))
-                counted = abs_cam_cost(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
-                                       pts.a[4][i], term);
-            s_rows[threadIdx.x] = counted ? term : 0.0;
-            cnt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(counted)); // (every lane holds its wavefront's count)
-            __syncthreads();
-            if (threadIdx.x == 0) {
+        for (uint32_t r = 0; r <= rounds; ++r) {
+            if (wave > 0) {
+                if (r < rounds) {
+                    double term = 0.0;
+                    bool counted = false;
+                    const uint32_t i = r * (uint32_t)kProd + (uint32_t)(pw * 64 + lane);
+                    if (i < pts.n && !(mask && !mask[i]))
+                        counted = abs_cam_cost(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
+                                               pts.a[4][i], term);
+                    terms[(r & 1u) * kProd + pw * 64 + lane] = counted ? term : 0.0;
+                    cnt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(counted)); // (every lane holds its wavefront's count)
+                }
+            } else if (r > 0 && threadIdx.x == 0) {
 #pragma unroll 1
-                for (int q = 0; q < kCamThreads; q += 64) {
-                    const uint32_t addr = (uint32_t)(uintptr_t)&s_rows[q];
+                for (int q = 0; q < kProd; q += 64) {
+                    const uint32_t addr = (uint32_t)(uintptr_t)&terms[((r - 1u) & 1u) * kProd + q];
                     PL_LM_CHAIN64(tot, addr);
                 }
             }
             __syncthreads();
         }
         if (lane == 0)
-            s_wcnt[wave] = cnt;
+            s_wcnt[0][wave] = cnt;
         __syncthreads();
         if (threadIdx.x == 0) {
             s_racc = tot;
             uint32_t c = 0;
-            for (int w = 0; w < kCamWaves; ++w)
-                c += s_wcnt[w];
+            for (int w = 1; w < kCamWaves; ++w)
+                c += s_wcnt[0][w];
             s_count = c;
         }
         __syncthreads();
@@ -156,56 +169,63 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
         rotation_of(p);
         const Loss loss = ctl.loss;
         const CameraParams cam = camera;
-        double acc = 0.0;
-        uint32_t total = 0; // (uniform)
-        for (uint32_t base = 0; base < pts.n; base += kCamThreads) {
-            const uint32_t i = base + threadIdx.x;
-            double row[kCamRow];
-            bool kept = false;
-            if (i < pts.n && !(mask && !mask[i]))
-                kept = abs_cam_row(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
-                                   pts.a[4][i], row);
-            const uint64_t b = __builtin_amdgcn_ballot_w64(kept);
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-            if (lane == 0)
-                s_wcnt[wave] = (uint32_t)__popcll(b);
-            __syncthreads();
-            uint32_t off = 0, round_rows = 0;
+        double acc = 0.0, acc_hi = 0.0;
+        uint32_t total = 0; // (consumer)
+        for (uint32_t r = 0; r <= rounds; ++r) {
+            if (wave > 0) {
+                if (r < rounds) {
+                    const uint32_t i = r * (uint32_t)kProd + (uint32_t)(pw * 64 + lane);
+                    double row[kCamRow];
+                    bool kept = false;
+                    if (i < pts.n && !(mask && !mask[i]))
+                        kept = abs_cam_row(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
+                                           pts.a[4][i], row);
+                    const uint64_t b = __builtin_amdgcn_ballot_w64(kept);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                    if (lane == 0)
+                        s_wcnt[r & 1u][wave] = (uint32_t)__popcll(b);
+                    if (kept) {
+                        double *dst = s_rows + ((size_t)(r & 1u) * kProd + (size_t)pw * 64 + below) * kCamRow;
 #pragma unroll
-            for (int w = 0; w < kCamWaves; ++w) {
-                const uint32_t c = s_wcnt[w];
-                off += (w < wave) ? c : 0u;
-                round_rows += c;
-            }
-            if (kept) {
-                double *dst = s_rows + (size_t)(off + below) * kCamRow;
-#pragma unroll
-                for (int k = 0; k < kCamRow; ++k)
-                    dst[k] = row[k];
-            }
-            __syncthreads();
-            if ((int)threadIdx.x < NT) {
-                // eight rows per step: their LDS reads and products are independent and travel together, only the additions
-                // into the entry are a chain - in row order, as the reference adds them (measured: 320 -> 40 cycles per row)
-                const double *r = s_rows;
-                uint32_t q = 0;
-                for (; q + 8u <= round_rows; q += 8u, r += 8 * kCamRow) {
-                    double t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        t[u] = cam_entry_term(r + u * kCamRow, entry);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        acc += t[u];
+                        for (int k = 0; k < kCamRow; ++k)
+                            dst[k] = row[k];
+                    }
                 }
-                for (; q < round_rows; ++q, r += kCamRow)
-                    acc += cam_entry_term(r, entry);
+            } else if (r > 0) {
+                const uint32_t buf = (r - 1u) & 1u;
+                for (int w = 1; w < kCamWaves; ++w) { // the three thirds in order
+                    const uint32_t rows = s_wcnt[buf][w];
+                    const double *const r0 = s_rows + ((size_t)buf * kProd + (size_t)(w - 1) * 64) * kCamRow;
+                    // eight rows per step: their LDS reads and products are independent and travel together, only the additions
+                    // into the entry are a chain - in row order, as the reference adds them (measured: 320 -> 40 cycles per row)
+                    auto add_rows = [&](const CamEntry &en, double &a) {
+                        const double *rp = r0;
+                        uint32_t q = 0;
+                        for (; q + 8u <= rows; q += 8u, rp += 8 * kCamRow) {
+                            double t[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                t[u] = cam_entry_term(rp + u * kCamRow, en);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                a += t[u];
+                        }
+                        for (; q < rows; ++q, rp += kCamRow)
+                            a += cam_entry_term(rp, en);
+                    };
+                    if (own_lo)
+                        add_rows(entry, acc);
+                    if (own_hi)
+                        add_rows(entry_hi, acc_hi);
+                    total += rows;
+                }
             }
-            total += round_rows;
-            __syncthreads(); // (s_wcnt and the rows are rewritten by the next round)
+            __syncthreads(); // (the buffer of round r - 1 is rewritten by round r + 1)
         }
-        if ((int)threadIdx.x < NT)
-            normal[threadIdx.x] = acc;
+        if (own_lo)
+            normal[lane] = acc;
+        if (own_hi)
+            normal[lane + 64] = acc_hi;
         if (threadIdx.x == 0)
             s_count = total;
         __syncthreads();
@@ -255,7 +275,7 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
 hipError_t launch_lm_cam(LMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
-    constexpr size_t bytes = sizeof(double) * kCamThreads * kCamRow;
+    constexpr size_t bytes = sizeof(double) * 2 * kProd * kCamRow; // 95 KB
     static std::atomic<int> prepared{0};
     if (!prepared.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm_cam), hipFuncAttributeMaxDynamicSharedMemorySize,

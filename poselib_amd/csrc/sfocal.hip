@@ -22,6 +22,7 @@
 #include "pl_sfocal.h"
 #include "pl_solver_6ptf.h"
 #include "pl_eigen_wave.h"
+#include "pl_lm_chain.inc"
 #include <algorithm>
 #include <atomic>
 
@@ -251,15 +252,17 @@ __global__ void k_sfocal_mask(const double *x1, const double *y1, const double *
 
 constexpr int kSfLMThreads = 256;
 constexpr int kSfLMWaves = kSfLMThreads / 64;
+constexpr int kSfProd = kSfLMThreads - 64; // correspondences per round: wavefronts 1 .. 3 produce, wavefront 0 adds
 
 __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks) {
-    __shared__ double s_rows[kSfLMThreads * kSFocalRow];
+    __shared__ __attribute__((aligned(16))) double s_rows[2 * kSfProd * kSFocalRow]; // two buffers of a round's rows
     __shared__ SFocalLMTask s_task;
     __shared__ LMControl ctl;
     __shared__ double cur[kParamDoubles], trial[kParamDoubles];
     __shared__ SFocalCtx ctx;
     __shared__ double normal[kSFocalEntries];
     __shared__ uint32_t s_wcnt[kSfLMWaves];
+    __shared__ uint32_t s_rcnt[2][kSfLMWaves]; // rows a producer wavefront left in its third of buffer 0 / 1
     __shared__ double s_racc;
     __shared__ uint32_t s_count;
     __shared__ double s_F[9];
@@ -334,66 +337,54 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
     }
     __syncthreads();
 
-    // rows of a round are compacted in ascending order (ballot + prefix over the waves): the sums below run over the
-    // correspondences that contribute, one after the other, as the reference adds them
-    auto compact_slot = [&](bool kept, uint32_t &round_rows) -> uint32_t {
-        const uint64_t b = __builtin_amdgcn_ballot_w64(kept);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        if (lane == 0)
-            s_wcnt[wave] = (uint32_t)__popcll(b);
-        __syncthreads();
-        uint32_t off = 0;
-        round_rows = 0;
-#pragma unroll
-        for (int w = 0; w < kSfLMWaves; ++w) {
-            const uint32_t c = s_wcnt[w];
-            off += (w < wave) ? c : 0u;
-            round_rows += c;
-        }
-        return off + below;
-    };
+    // Both passes are a two-stage pipeline over rounds of kSfProd = 192 correspondences (round 4, like k_lm_cam; up to then every
+    // wavefront produced a round of 256, waited, and watched wavefront 0 add): wavefronts 1 .. 3 evaluate round r into buffer r & 1
+    // while wavefront 0 adds round r - 1 from the other buffer; ONE barrier per round.  The sums run over the correspondences one
+    // after the other, as the reference adds them: each producer wavefront compacts the rows of ITS 64 correspondences into its own
+    // third of the buffer (ballot + v_mbcnt), the consumer walks the thirds in order.
+    const uint32_t rounds = (n + (uint32_t)kSfProd - 1u) / (uint32_t)kSfProd;
+    const int pw = wave - 1; // producer wavefront 0 .. 2
 
-    // robust cost at p -> s_racc, s_count
+    // robust cost at p -> s_racc, s_count: every correspondence's term (zeros for skipped ones: x + 0.0 = x), lane 0 adds a round's
+    // 192 terms with the inline-asm chain of k_lm_ordered (pl_lm_chain.inc)
     auto cost_pass = [&](const double *p) {
         if (threadIdx.x == 0)
             sfocal_prepare(p, ctx, false);
         __syncthreads();
         const Loss loss = ctl.loss;
         double racc = 0.0; // (thread 0)
-        uint32_t total = 0;
-        for (uint32_t base = 0; base < n; base += kSfLMThreads) {
-            const uint32_t i = base + threadIdx.x;
-            double term = 0.0;
-            const bool kept = i < n && !(mask && !mask[i]);
-            if (kept) {
-                const double r = sfocal_residual(ctx, x1[i], y1[i], x2[i], y2[i]);
-                term = 1.0 * loss_value(loss, r * r);
-            }
-            uint32_t rows;
-            const uint32_t slot = compact_slot(kept, rows);
-            if (kept)
-                s_rows[slot] = term;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t q = 0;
-                for (; q + 8u <= rows; q += 8u) { // (reads together, additions in order)
-                    double t8[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        t8[u] = s_rows[q + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        racc += t8[u];
+        uint32_t cnt = 0;
+        for (uint32_t r = 0; r <= rounds; ++r) {
+            if (wave > 0) {
+                if (r < rounds) {
+                    const uint32_t i = r * (uint32_t)kSfProd + (uint32_t)(pw * 64 + lane);
+                    double term = 0.0;
+                    const bool kept = i < n && !(mask && !mask[i]);
+                    if (kept) {
+                        const double res = sfocal_residual(ctx, x1[i], y1[i], x2[i], y2[i]);
+                        term = 1.0 * loss_value(loss, res * res);
+                    }
+                    s_rows[(r & 1u) * kSfProd + pw * 64 + lane] = term;
+                    cnt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(kept)); // (every lane holds its wavefront's count)
                 }
-                for (; q < rows; ++q)
-                    racc += s_rows[q];
+            } else if (r > 0 && threadIdx.x == 0) {
+#pragma unroll 1
+                for (int q = 0; q < kSfProd; q += 64) {
+                    const uint32_t addr = (uint32_t)(uintptr_t)&s_rows[((r - 1u) & 1u) * kSfProd + q];
+                    PL_LM_CHAIN64(racc, addr);
+                }
             }
-            total += rows;
             __syncthreads();
         }
+        if (lane == 0)
+            s_wcnt[wave] = cnt;
+        __syncthreads();
         if (threadIdx.x == 0) {
             s_racc = racc;
-            s_count = total;
+            uint32_t c = 0;
+            for (int w = 1; w < kSfLMWaves; ++w)
+                c += s_wcnt[w];
+            s_count = c;
         }
         __syncthreads();
     };
@@ -408,39 +399,49 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
         __syncthreads();
         const Loss loss = ctl.loss;
         double acc = 0.0;
-        uint32_t total = 0;
-        for (uint32_t base = 0; base < n; base += kSfLMThreads) {
-            const uint32_t i = base + threadIdx.x;
-            double row[kSFocalRow];
-            bool kept = false;
-            if (i < n && !(mask && !mask[i]))
-                kept = sfocal_row(ctx, loss, x1[i], y1[i], x2[i], y2[i], row);
-            uint32_t rows;
-            const uint32_t slot = compact_slot(kept, rows);
-            if (kept) {
-                double *dst = s_rows + (size_t)slot * kSFocalRow;
+        uint32_t total = 0; // (consumer)
+        for (uint32_t r = 0; r <= rounds; ++r) {
+            if (wave > 0) {
+                if (r < rounds) {
+                    const uint32_t i = r * (uint32_t)kSfProd + (uint32_t)(pw * 64 + lane);
+                    double row[kSFocalRow];
+                    bool kept = false;
+                    if (i < n && !(mask && !mask[i]))
+                        kept = sfocal_row(ctx, loss, x1[i], y1[i], x2[i], y2[i], row);
+                    const uint64_t b = __builtin_amdgcn_ballot_w64(kept);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                    if (lane == 0)
+                        s_rcnt[r & 1u][wave] = (uint32_t)__popcll(b);
+                    if (kept) {
+                        double *dst = s_rows + ((size_t)(r & 1u) * kSfProd + (size_t)pw * 64 + below) * kSFocalRow;
 #pragma unroll
-                for (int k = 0; k < kSFocalRow; ++k)
-                    dst[k] = row[k];
-            }
-            __syncthreads();
-            if ((int)threadIdx.x < kSFocalEntries) {
-                const double *r = s_rows;
-                uint32_t q = 0;
-                for (; q + 8u <= rows; q += 8u, r += 8 * kSFocalRow) {
-                    double t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        t[u] = sfocal_entry_term(r + u * kSFocalRow, entry);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        acc += t[u];
+                        for (int k = 0; k < kSFocalRow; ++k)
+                            dst[k] = row[k];
+                    }
                 }
-                for (; q < rows; ++q, r += kSFocalRow)
-                    acc += sfocal_entry_term(r, entry);
+            } else if (r > 0) {
+                const uint32_t buf = (r - 1u) & 1u;
+                for (int w = 1; w < kSfLMWaves; ++w) { // the three thirds in order
+                    const uint32_t rows = s_rcnt[buf][w];
+                    if ((int)threadIdx.x < kSFocalEntries) {
+                        const double *rp = s_rows + ((size_t)buf * kSfProd + (size_t)(w - 1) * 64) * kSFocalRow;
+                        uint32_t q = 0;
+                        for (; q + 8u <= rows; q += 8u, rp += 8 * kSFocalRow) { // (reads together, additions in order)
+                            double t[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                t[u] = sfocal_entry_term(rp + u * kSFocalRow, entry);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                acc += t[u];
+                        }
+                        for (; q < rows; ++q, rp += kSFocalRow)
+                            acc += sfocal_entry_term(rp, entry);
+                    }
+                    total += rows;
+                }
             }
-            total += rows;
-            __syncthreads();
+            __syncthreads(); // (the buffer of round r - 1 is rewritten by round r + 1)
         }
         if ((int)threadIdx.x < kSFocalEntries)
             normal[threadIdx.x] = acc;
