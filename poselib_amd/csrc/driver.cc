@@ -121,6 +121,7 @@ struct Context {
     DevBuf iota; // iota[i] = i: a device-resident "number of hypotheses" for launches whose count the host knows
     DevBuf lm_tasks, lm_records, gather_idx, gather_out, mask, lm_scratch, tmp_model, solve_in, solve_out, solve_cnt, focal_stage;
     HostBuf h_rec_meta, h_focal, h_in;
+    const double *raw_src_a = nullptr, *raw_src_b = nullptr; // where the raw correspondences of the last make_problem_prepared live (device-visible)
     HostBuf h_absmax, h_positions, h_num_models, h_count, h_score, h_tasks, h_gather_idx, h_gather_out, h_mask,
         h_small, h_models;
     HostBuf h_flag;        // completion flag of wait_stream(): the stream writes a sequence number, the host spins on it
@@ -1728,27 +1729,37 @@ int make_problem_prepared(Context *c, int kind, const double *a, const double *b
         return PL_OK;
     const int nd = point_doubles(kind);
     const int db = (kind == EST_ABS) ? 3 : 2;
-    HIP_TRY(c->raw_a.ensure(sizeof(double) * 2 * n));
-    HIP_TRY(c->raw_b.ensure(sizeof(double) * db * n));
     HIP_TRY(c->pts_arena.ensure(sizeof(double) * nd * n));
     HIP_TRY(c->absmax.ensure(sizeof(unsigned long long)));
     HIP_TRY(c->h_absmax.ensure(sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->absmax.p, 0, sizeof(unsigned long long), c->stream));
+    // max|x| of the prepared points is read back only for absolute-pose problems of non-linear cameras (below): no fill dispatch
+    // in front of the others (k_prepare's atomic max then lands on a word nobody reads)
+    const bool reads_absmax = !(lm_only || kind != EST_ABS) && !(pa.mode == 0 && pa.cam1.model_id != CAM_OPENCV);
+    if (reads_absmax)
+        HIP_TRY(hipMemsetAsync(c->absmax.p, 0, sizeof(unsigned long long), c->stream));
     if (!resident) {
         const size_t bytes_a = sizeof(double) * 2 * n, bytes_b = sizeof(double) * db * n;
-        const void *src_a = a, *src_b = b;
         if (bytes_a + bytes_b <= ((size_t)8 << 20)) {
-            // through a pinned block: a copy from pageable memory pins and unpins the caller's buffer under the process's
-            // memory-map lock, which is what front-end calls from many host threads queued on (focal estimators)
+            // through a pinned, mapped block k_prepare reads directly: no copy dispatches, and no copy from pageable memory (which pins
+            // and unpins the caller's buffer under the process's memory-map lock - what front-end calls from many host threads
+            // queued on, DESIGN 4 "focal estimators")
             HIP_TRY(c->h_in.ensure(bytes_a + bytes_b));
             std::memcpy(c->h_in.p, a, bytes_a);
             std::memcpy(c->h_in.as<char>() + bytes_a, b, bytes_b);
-            src_a = c->h_in.p, src_b = c->h_in.as<char>() + bytes_a;
+            c->raw_src_a = c->h_in.dev<double>();
+            c->raw_src_b = reinterpret_cast<const double *>(c->h_in.dev<char>() + bytes_a);
+        } else {
+            HIP_TRY(c->raw_a.ensure(bytes_a));
+            HIP_TRY(c->raw_b.ensure(bytes_b));
+            HIP_TRY(hipMemcpyAsync(c->raw_a.p, a, bytes_a, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->raw_b.p, b, bytes_b, hipMemcpyHostToDevice, c->stream));
+            c->raw_src_a = c->raw_a.as<double>();
+            c->raw_src_b = c->raw_b.as<double>();
         }
-        HIP_TRY(hipMemcpyAsync(c->raw_a.p, src_a, bytes_a, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->raw_b.p, src_b, bytes_b, hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(launch_prepare(c->raw_a.as<double>(), c->raw_b.as<double>(), (uint32_t)n, pa, c->pts_arena.as<double>(),
+    if (!c->raw_src_a || !c->raw_src_b)
+        return fail(PL_ERR_INVALID, "second preparation without a first");
+    HIP_TRY(launch_prepare(c->raw_src_a, c->raw_src_b, (uint32_t)n, pa, c->pts_arena.as<double>(),
                            c->absmax.as<unsigned long long>(), c->stream));
     p->d_pts = c->pts_arena.as<double>();
     for (int d = 0; d < nd; ++d)
