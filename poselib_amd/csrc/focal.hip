@@ -15,6 +15,7 @@
 #include "pl_kernels.h"
 #include "pl_solver_p35pf.h"
 #include "pl_eigen_wave.h"
+#include "pl_lm_chain.inc"
 #include <algorithm>
 #include <atomic>
 
@@ -248,6 +249,72 @@ __global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score(FocalScoreAr
     }
 }
 
+// The same score by ONE WORKGROUP per model (round 4): wavefronts 1 .. 3 evaluate rounds of 192 correspondences into one of two LDS
+// buffers (the inliers' squared residuals, zeros for the others: x + 0.0 = x), lane 0 of wavefront 0 adds the previous round with the
+// inline-asm chain of k_lm_ordered (pl_lm_chain.inc: 11.7 cycles per term) - a model with 1200 inliers takes 18 us instead of 65
+// (one wavefront evaluating 64 correspondences at a time and adding its inliers through v_readlane), which is the length of the
+// launches that score the few refined models of a local optimisation.
+constexpr int kScoreProd = kFocalScoreThreads - 64;
+__global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score_wg(FocalScoreArgs a) {
+    __shared__ __attribute__((aligned(16))) double s_terms[2][kScoreProd];
+    __shared__ uint32_t s_cnt[kFocalScoreThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x;
+    if (a.num_models && (slot % kFocalMaxModels) >= a.num_models[slot / kFocalMaxModels]) { // (uniform)
+        if (threadIdx.x == 0) { // (the host never reads garbage - and no fill dispatches in front of this kernel)
+            a.counts[slot] = 0;
+            a.sums[slot] = 0.0;
+        }
+        return;
+    }
+    FocalModel m;
+    if (a.lm_tasks) { // the refined pose and focal length of k_lm_cam's task
+        const LMTask &t = a.lm_tasks[slot];
+        for (int i = 0; i < 4; ++i)
+            m.q[i] = t.params[i];
+        for (int i = 0; i < 3; ++i)
+            m.t[i] = t.params[4 + i];
+        m.f = t.cam.p[0];
+    } else {
+        m = a.models[slot];
+    }
+    double R[9];
+    focal_rotation(m, R);
+    const uint32_t rounds = (a.n + (uint32_t)kScoreProd - 1u) / (uint32_t)kScoreProd;
+    uint32_t count = 0;
+    double sum = 0.0;
+    for (uint32_t r = 0; r <= rounds; ++r) {
+        if (wave > 0) {
+            if (r < rounds) {
+                const uint32_t i = r * (uint32_t)kScoreProd + (uint32_t)((wave - 1) * 64 + lane);
+                double r2 = 0.0;
+                bool in = false;
+                if (i < a.n)
+                    in = focal_reproj_inlier(R, m.t, m.f, a.a[0][i], a.a[1][i], a.a[2][i], a.a[3][i], a.a[4][i], a.thr2, r2);
+                s_terms[r & 1u][(wave - 1) * 64 + lane] = in ? r2 : 0.0;
+                count += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in)); // (every lane holds its wavefront's count)
+            }
+        } else if (r > 0 && threadIdx.x == 0) {
+#pragma unroll 1
+            for (int q = 0; q < kScoreProd; q += 64) {
+                const uint32_t addr = (uint32_t)(uintptr_t)&s_terms[(r - 1u) & 1u][q];
+                PL_LM_CHAIN64(sum, addr);
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0)
+        s_cnt[wave] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (int w = 1; w < kFocalScoreThreads / 64; ++w)
+            c += s_cnt[w];
+        a.counts[slot] = c;
+        a.sums[slot] = sum;
+    }
+}
+
 __global__ void k_focal_mask(const double *x, const double *y, const double *X, const double *Y, const double *Z, uint32_t n,
                              FocalModel m, double thr2, uint8_t *mask, uint8_t *host_mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,6 +365,10 @@ hipError_t launch_focal_solve(const double *in, uint32_t count, FocalModel *mode
 hipError_t launch_focal_score(const FocalScoreArgs &a, hipStream_t stream) {
     if (a.num_slots == 0)
         return hipSuccess;
+    if (a.num_slots <= 1024u) { // the refined models of a local optimisation: one workgroup per model
+        k_focal_score_wg<<<dim3(a.num_slots), dim3(kFocalScoreThreads), 0, stream>>>(a);
+        return hipGetLastError();
+    }
     constexpr uint32_t per_block = kFocalScoreThreads / 64;
     k_focal_score<<<dim3((a.num_slots + per_block - 1) / per_block), dim3(kFocalScoreThreads), 0, stream>>>(a);
     return hipGetLastError();

@@ -237,6 +237,59 @@ __global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score(SFocalScor
     }
 }
 
+// The same score by ONE WORKGROUP per model (round 4; used for the few refined models of a local optimisation - a batch of
+// iterations has 60 slots per iteration of which 0.3 hold a model): wavefronts 1 .. 3 evaluate rounds of 192 correspondences into one
+// of two LDS buffers, lane 0 of wavefront 0 adds the previous round's terms with the inline-asm chain of k_lm_ordered
+// (pl_lm_chain.inc; zeros beyond n: x + 0.0 = x).
+constexpr int kSfScoreProd = kSFocalScoreThreads - 64;
+__global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score_wg(SFocalScoreArgs a) {
+    __shared__ __attribute__((aligned(16))) double s_terms[2][kSfScoreProd];
+    __shared__ uint32_t s_cnt[kSFocalScoreThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x;
+    if (a.num_models && (slot % kSFocalMaxModels) >= a.num_models[slot / kSFocalMaxModels])
+        return; // (uniform)
+    const FocalModel m = a.models[slot];
+    double F[9];
+    sfocal_F_score(m, F);
+    const uint32_t rounds = (a.n + (uint32_t)kSfScoreProd - 1u) / (uint32_t)kSfScoreProd;
+    uint32_t count = 0;
+    double score = 0.0;
+    for (uint32_t r = 0; r <= rounds; ++r) {
+        if (wave > 0) {
+            if (r < rounds) {
+                const uint32_t i = r * (uint32_t)kSfScoreProd + (uint32_t)((wave - 1) * 64 + lane);
+                double term = 0.0;
+                bool in = false;
+                if (i < a.n) {
+                    const double r2 = sampson_sq(F, a.a[0][i], a.a[1][i], a.a[2][i], a.a[3][i]);
+                    in = r2 < a.thr2;
+                    term = in ? r2 : a.thr2;
+                }
+                s_terms[r & 1u][(wave - 1) * 64 + lane] = term;
+                count += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in));
+            }
+        } else if (r > 0 && threadIdx.x == 0) {
+#pragma unroll 1
+            for (int q = 0; q < kSfScoreProd; q += 64) {
+                const uint32_t addr = (uint32_t)(uintptr_t)&s_terms[(r - 1u) & 1u][q];
+                PL_LM_CHAIN64(score, addr);
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0)
+        s_cnt[wave] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (int w = 1; w < kSFocalScoreThreads / 64; ++w)
+            c += s_cnt[w];
+        a.counts[slot] = c;
+        a.scores[slot] = score;
+    }
+}
+
 __global__ void k_sfocal_mask(const double *x1, const double *y1, const double *x2, const double *y2, uint32_t n, FocalModel m,
                               double thr2, uint8_t *mask, uint8_t *host_mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -534,6 +587,10 @@ hipError_t launch_sfocal_solve(const double *in, uint32_t count, FocalModel *mod
 hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream) {
     if (a.num_slots == 0)
         return hipSuccess;
+    if (a.num_slots <= 1024u) { // the refined models of a local optimisation: one workgroup per model
+        k_sfocal_score_wg<<<dim3(a.num_slots), dim3(kSFocalScoreThreads), 0, stream>>>(a);
+        return hipGetLastError();
+    }
     constexpr uint32_t per_block = kSFocalScoreThreads / 64;
     k_sfocal_score<<<dim3((a.num_slots + per_block - 1) / per_block), dim3(kSFocalScoreThreads), 0, stream>>>(a);
     return hipGetLastError();
