@@ -80,10 +80,10 @@ __device__ __forceinline__ double readlane_f64(double v, int l) { // (l uniform)
 //   roots         lane s = root s: null vector (its own 10 x 10 working copy in LDS), pose and focal length at once
 //                 (p35pf_pose_of_root; one lane per sample, root after root: 0.41 ms); the solutions leave in the order of the roots
 //                 (ballot + v_mbcnt)
-constexpr int kSolveWaves = 4, kFinRoots = 16;
+constexpr int kSolveWaves = 4, kFinRoots = 10; // (the action matrix is 10 x 10: at most 10 roots)
 constexpr int kSolveLds = 100 + 100 * kFinRoots; // action matrix | working copies of the roots, element-major over the roots
 static_assert(eig_wave_doubles(10) + kP35ActionDoubles <= 100 * kFinRoots, "the eigenvalue workspace and E live in the roots' region");
-__global__ __launch_bounds__(64 * kSolveWaves) void k_focal_solve(FocalGenArgs g) {
+__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_focal_solve(FocalGenArgs g) {
     __shared__ double s_solve[kSolveWaves][kSolveLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blockIdx.x * kSolveWaves + wave; // (wave-uniform)

@@ -95,11 +95,11 @@ __global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
 //                then builds the list of solutions ascending in y exactly as the serial routine inserts them.  Phase 2, lane s =
 //                solution s: essential matrix, up to four poses; the models leave in the order of the solutions (prefix sum of the
 //                counts).  As one lane per sample (root after root, solution after solution): 0.79 ms per batch.
-constexpr int kSolveWaves = 2, kFinRoots = 16;
+constexpr int kSolveWaves = 2, kFinRoots = 8, kMaxRoots = 16; // the roots go through the lanes kFinRoots at a time (a second pass is rare)
 constexpr int kFinC = 0, kFinA = 300, kFinNb = kFinA + 100 * kFinRoots, kFinX = kFinNb + 27, kFinTmp = kFinX + 36,
-              kFinDoubles = kFinTmp + 7 * kFinRoots;
+              kFinDoubles = kFinTmp + 7 * kMaxRoots;
 static_assert(eig_wave_doubles(15) <= 100 * kFinRoots, "the eigenvalue workspace lives in the roots' region");
-__global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve(SFocalGenArgs g) {
+__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sfocal_solve(SFocalGenArgs g) {
     __shared__ double s_fin[kSolveWaves][kFinDoubles];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blockIdx.x * kSolveWaves + wave; // (wave-uniform)
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve(SFocalGenArgs
     const size_t B = g.num_iters;
     const double *st = g.stage + it;
     double *base = s_fin[wave];
-    double *rx = base + kFinTmp, *ry = rx + kFinRoots, *rw = ry + kFinRoots, *sx = rw + kFinRoots, *sy = sx + kFinRoots,
-           *sw = sy + kFinRoots, *cnt = sw + kFinRoots;
+    double *rx = base + kFinTmp, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots,
+           *sw = sy + kMaxRoots, *cnt = sw + kMaxRoots;
     uint32_t m = 0;
     int nroots = 0;
     double wv = 0.0;
@@ -138,14 +138,19 @@ __global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve(SFocalGenArgs
         if (lane < 36)
             base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
         PL_WAVE_SYNC();
-        bool found = false;
-        if (lane < nroots) {
-            double x = 0, y = 0;
-            found = six_root_xy(SixWork{base + kFinC, 1}, SixWork{base + kFinA + lane, (size_t)kFinRoots}, wv, x, y);
-            rx[lane] = x, ry[lane] = y, rw[lane] = wv;
+        // root s = pass * kFinRoots + lane: its eigenvalue sits in lane s
+        uint64_t fmask = 0;
+        for (int first = 0; first < nroots; first += kFinRoots) {
+            const double w_s = __shfl(wv, first + (lane < kFinRoots ? lane : 0), 64);
+            bool found = false;
+            if (lane < kFinRoots && first + lane < nroots) {
+                double x = 0, y = 0;
+                found = six_root_xy(SixWork{base + kFinC, 1}, SixWork{base + kFinA + lane, (size_t)kFinRoots}, w_s, x, y);
+                rx[first + lane] = x, ry[first + lane] = y, rw[first + lane] = w_s;
+            }
+            fmask |= __builtin_amdgcn_ballot_w64(found) << first;
+            PL_WAVE_SYNC();
         }
-        const uint64_t fmask = __builtin_amdgcn_ballot_w64(found);
-        PL_WAVE_SYNC();
         int ns = 0;
         if (lane == 0)
             for (int s = 0; s < nroots; ++s)
@@ -156,14 +161,9 @@ __global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve(SFocalGenArgs
         FocalModel mine[4];
         uint32_t c = 0;
         if (lane < ns) {
-            Vec3 x1[6], x2[6];
-            double nb[27];
-            for (int e = 0; e < 27; ++e)
-                nb[e] = base[kFinNb + e];
-            for (int k = 0; k < 6; ++k) {
-                x1[k] = v3(base[kFinX + 3 * k], base[kFinX + 3 * k + 1], base[kFinX + 3 * k + 2]);
-                x2[k] = v3(base[kFinX + 18 + 3 * k], base[kFinX + 19 + 3 * k], base[kFinX + 20 + 3 * k]);
-            }
+            // (bearings and null space are read from LDS where they are used: as local copies they cost 126 registers)
+            const Vec3 *x1 = reinterpret_cast<const Vec3 *>(base + kFinX), *x2 = x1 + 6;
+            const double *nb = base + kFinNb;
             six_solution_poses(x1, x2, nb, sx[lane], sy[lane], sw[lane], [&](Quat q, Vec3 t, double f) {
                 FocalModel o;
                 o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve(SFocalGenArgs
                 ++c;
             });
         }
-        if (lane < kFinRoots)
+        if (lane < kMaxRoots)
             cnt[lane] = (double)c;
         PL_WAVE_SYNC();
         uint32_t off = 0;
