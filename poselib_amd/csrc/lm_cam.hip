@@ -19,6 +19,7 @@
 #include "pl_lm_chain.inc"
 #include "pl_device.h"
 #include "pl_refine_cam.h"
+#include <algorithm>
 #include <atomic>
 
 namespace pl {
@@ -231,6 +232,90 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
         __syncthreads();
     };
 
+    // The same pass for ONE refined camera parameter (K = 7: pose + focal length, the LO and bundle of ransac_pnpf): measured with a
+    // cycle counter in the kernel, the consumer of the general form spends 91 cycles per row (five LDS reads and the products of its
+    // entry, next to three producer wavefronts writing rows of 31 doubles) and the producers wait for it four fifths of the pass.
+    // Here the PRODUCERS form the 35 entry terms of their correspondence - the products cam_entry_term would form, in its operand
+    // order - and store them column-major, [entry][row]; a third is padded with zero rows to 64 (the lanes without a row write
+    // them: x + 0.0 = x), so the consumer lane of an entry adds a third with ONE inline-asm chain (pl_lm_chain.inc: 11.7 cycles
+    // per row).  35 x 194 doubles per buffer.
+    constexpr int kTermCols = 35, kTermStride = kProd + 2;
+    auto jacobian_pass_m1 = [&](const double *p, const CameraParams &camera) {
+        rotation_of(p);
+        const Loss loss = ctl.loss;
+        const CameraParams cam = camera;
+        const int c6 = 6 + s_idx[0]; // the refined parameter's column of the row
+        double acc = 0.0;
+        uint32_t total = 0; // (consumer)
+        for (uint32_t r = 0; r <= rounds; ++r) {
+            if (wave > 0) {
+                if (r < rounds) {
+                    const uint32_t i = r * (uint32_t)kProd + (uint32_t)(pw * 64 + lane);
+                    double row[kCamRow];
+                    bool kept = false;
+                    if (i < pts.n && !(mask && !mask[i]))
+                        kept = abs_cam_row(p, s_R, cam, loss, pts.a[0][i] * pscale, pts.a[1][i] * pscale, pts.a[2][i], pts.a[3][i],
+                                           pts.a[4][i], row);
+                    const uint64_t b = __builtin_amdgcn_ballot_w64(kept);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                    const uint32_t rows = (uint32_t)__popcll(b);
+                    if (lane == 0)
+                        s_wcnt[r & 1u][wave] = rows;
+                    // kept rows in ascending order at 0 .. rows - 1, zero rows behind them
+                    const uint32_t pos = kept ? below : rows + ((uint32_t)lane - below);
+                    double *dst = s_rows + (size_t)(r & 1u) * kTermCols * kTermStride + (size_t)pw * 64 + pos;
+                    if (kept) {
+                        double J0[7], J1[7];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+                            J0[k] = row[3 + k], J1[k] = row[3 + kCamMaxK + k];
+                        J0[6] = row[3 + 6], J1[6] = row[3 + kCamMaxK + 6];
+#pragma unroll
+                        for (int m = 1; m < kCamMaxParams; ++m) { // (c6 is uniform)
+                            J0[6] = c6 == 6 + m ? row[3 + 6 + m] : J0[6];
+                            J1[6] = c6 == 6 + m ? row[3 + kCamMaxK + 6 + m] : J1[6];
+                        }
+                        const double w = row[0], wr0 = row[1], wr1 = row[2];
+                        int e = 0;
+#pragma unroll
+                        for (int a = 0; a < 7; ++a)
+#pragma unroll
+                            for (int c = 0; c <= a; ++c, ++e) { // cam_entry_term, triangle entry (a, c)
+                                const double t = J0[a] * J0[c] + J1[a] * J1[c];
+                                dst[(size_t)e * kTermStride] = w * t;
+                            }
+#pragma unroll
+                        for (int a = 0; a < 7; ++a, ++e) { // gradient entry a
+                            const double t = J0[a] * wr0 + J1[a] * wr1;
+                            dst[(size_t)e * kTermStride] = 1.0 * t;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < kTermCols; ++e)
+                            dst[(size_t)e * kTermStride] = 0.0;
+                    }
+                }
+            } else if (r > 0) {
+                const uint32_t buf = (r - 1u) & 1u;
+                if (lane < kTermCols) {
+#pragma unroll 1
+                    for (int w = 0; w < kCamWaves - 1; ++w) { // the three thirds in order
+                        const uint32_t addr = (uint32_t)(uintptr_t)(s_rows + (size_t)buf * kTermCols * kTermStride + (size_t)lane * kTermStride + (size_t)w * 64);
+                        PL_LM_CHAIN64(acc, addr);
+                    }
+                }
+                for (int w = 1; w < kCamWaves; ++w)
+                    total += s_wcnt[buf][w];
+            }
+            __syncthreads(); // (the buffer of round r - 1 is rewritten by round r + 1)
+        }
+        if (own_lo)
+            normal[lane] = acc;
+        if (threadIdx.x == 0)
+            s_count = total;
+        __syncthreads();
+    };
+
     cost_pass(cur, cam_cur);
     if (threadIdx.x == 0)
         lm_begin(ctl, T.opt, s_racc, s_count);
@@ -238,8 +323,12 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
 
     while (!ctl.done) {
         const bool fresh = ctl.rejac != 0;
-        if (fresh)
-            jacobian_pass(cur, cam_cur);
+        if (fresh) {
+            if (M == 1)
+                jacobian_pass_m1(cur, cam_cur);
+            else
+                jacobian_pass(cur, cam_cur);
+        }
         if (threadIdx.x == 0) {
             lm_solve_k(K, ctl, normal, fresh, s_count);
             if (!ctl.done)
@@ -275,7 +364,7 @@ __global__ __launch_bounds__(kCamThreads) void k_lm_cam(LMTask *tasks) {
 hipError_t launch_lm_cam(LMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
-    constexpr size_t bytes = sizeof(double) * 2 * kProd * kCamRow; // 95 KB
+    constexpr size_t bytes = sizeof(double) * 2 * std::max(kProd * kCamRow, 35 * (kProd + 2)); // 109 KB: two buffers of rows resp. of entry terms (one refined parameter)
     static std::atomic<int> prepared{0};
     if (!prepared.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lm_cam), hipFuncAttributeMaxDynamicSharedMemorySize,
