@@ -306,9 +306,10 @@ __global__ void k_sfocal_mask(const double *x1, const double *y1, const double *
 constexpr int kSfLMThreads = 256;
 constexpr int kSfLMWaves = kSfLMThreads / 64;
 constexpr int kSfProd = kSfLMThreads - 64; // correspondences per round: wavefronts 1 .. 3 produce, wavefront 0 adds
+constexpr int kSfTermStride = kSfProd + 2; // column stride of the entry terms (16-byte aligned columns)
 
 __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks) {
-    __shared__ __attribute__((aligned(16))) double s_rows[2 * kSfProd * kSFocalRow]; // two buffers of a round's rows
+    extern __shared__ __attribute__((aligned(16))) double s_rows[]; // two buffers of a round's entry terms: 2 x kSFocalEntries x kSfTermStride (cost pass: 2 x kSfProd terms)
     __shared__ SFocalLMTask s_task;
     __shared__ LMControl ctl;
     __shared__ double cur[kParamDoubles], trial[kParamDoubles];
@@ -443,7 +444,10 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
     };
 
     // normal equations at p -> normal[0 .. 27), s_count.  p's tangent basis is refreshed first (relative.h:513).
-    const SFocalEntry entry = sfocal_entry_of(min((int)threadIdx.x, kSFocalEntries - 1));
+    // The PRODUCERS form the 27 entry terms of their correspondence (the products sfocal_entry_term forms, in its operand order)
+    // and store them column-major, [entry][row]; every third is padded with zero rows to 64 (the lanes without a row write them:
+    // x + 0.0 = x), so the consumer lane of an entry adds a third with ONE inline-asm chain (pl_lm_chain.inc: 11.7 cycles per row;
+    // k_lm_cam's cycle counters showed the consumer of the row form - LDS reads and products per entry and row - as the bound).
     auto jacobian_pass = [&](double *p) {
         if (threadIdx.x == 0) {
             Refiner<EST_REL>::prepare_params(p);
@@ -463,36 +467,43 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
                         kept = sfocal_row(ctx, loss, x1[i], y1[i], x2[i], y2[i], row);
                     const uint64_t b = __builtin_amdgcn_ballot_w64(kept);
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                    const uint32_t rows = (uint32_t)__popcll(b);
                     if (lane == 0)
-                        s_rcnt[r & 1u][wave] = (uint32_t)__popcll(b);
+                        s_rcnt[r & 1u][wave] = rows;
+                    // kept rows in ascending order at 0 .. rows - 1, zero rows behind them
+                    const uint32_t pos = kept ? below : rows + ((uint32_t)lane - below);
+                    double *dst = s_rows + (size_t)(r & 1u) * kSFocalEntries * kSfTermStride + (size_t)pw * 64 + pos;
                     if (kept) {
-                        double *dst = s_rows + ((size_t)(r & 1u) * kSfProd + (size_t)pw * 64 + below) * kSFocalRow;
+                        int e = 0;
 #pragma unroll
-                        for (int k = 0; k < kSFocalRow; ++k)
-                            dst[k] = row[k];
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int c = 0; c <= a; ++c, ++e) { // sfocal_entry_term, triangle entry (a, c)
+                                const double t = row[2 + a] * row[2 + c];
+                                dst[(size_t)e * kSfTermStride] = row[0] * t;
+                            }
+#pragma unroll
+                        for (int k = 0; k < 6; ++k, ++e) { // gradient entry k
+                            const double t = row[1] * row[2 + k];
+                            dst[(size_t)e * kSfTermStride] = 1.0 * t;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < kSFocalEntries; ++e)
+                            dst[(size_t)e * kSfTermStride] = 0.0;
                     }
                 }
             } else if (r > 0) {
                 const uint32_t buf = (r - 1u) & 1u;
-                for (int w = 1; w < kSfLMWaves; ++w) { // the three thirds in order
-                    const uint32_t rows = s_rcnt[buf][w];
-                    if ((int)threadIdx.x < kSFocalEntries) {
-                        const double *rp = s_rows + ((size_t)buf * kSfProd + (size_t)(w - 1) * 64) * kSFocalRow;
-                        uint32_t q = 0;
-                        for (; q + 8u <= rows; q += 8u, rp += 8 * kSFocalRow) { // (reads together, additions in order)
-                            double t[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u)
-                                t[u] = sfocal_entry_term(rp + u * kSFocalRow, entry);
-#pragma unroll
-                            for (int u = 0; u < 8; ++u)
-                                acc += t[u];
-                        }
-                        for (; q < rows; ++q, rp += kSFocalRow)
-                            acc += sfocal_entry_term(rp, entry);
+                if (lane < kSFocalEntries) {
+#pragma unroll 1
+                    for (int w = 0; w < kSfLMWaves - 1; ++w) { // the three thirds in order
+                        const uint32_t addr = (uint32_t)(uintptr_t)(s_rows + (size_t)buf * kSFocalEntries * kSfTermStride + (size_t)lane * kSfTermStride + (size_t)w * 64);
+                        PL_LM_CHAIN64(acc, addr);
                     }
-                    total += rows;
                 }
+                for (int w = 1; w < kSfLMWaves; ++w)
+                    total += s_rcnt[buf][w];
             }
             __syncthreads(); // (the buffer of round r - 1 is rewritten by round r + 1)
         }
@@ -605,7 +616,18 @@ hipError_t launch_sfocal_mask(const double *const *a, uint32_t n, const FocalMod
 hipError_t launch_sfocal_lm(SFocalLMTask *tasks, uint32_t num_tasks, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
-    k_sfocal_lm<<<dim3(num_tasks), dim3(kSfLMThreads), 0, stream>>>(tasks);
+    constexpr size_t bytes = sizeof(double) * 2 * kSFocalEntries * kSfTermStride; // 84 KB
+    static std::atomic<int> prepared_dev[64]; // per device ordinal: the attribute is per-device state on some runtimes
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    std::atomic<int> &prepared = prepared_dev[dev_ & 63];
+    if (!prepared.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess)
+            return e;
+        prepared.store(1, std::memory_order_release);
+    }
+    k_sfocal_lm<<<dim3(num_tasks), dim3(kSfLMThreads), bytes, stream>>>(tasks);
     return hipGetLastError();
 }
 
