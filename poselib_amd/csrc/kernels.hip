@@ -1744,7 +1744,7 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
     __shared__ int s_accepted;
     __shared__ int s_skip;
     __shared__ uint32_t s_queue[kLMThreads / 64][128]; // per wavefront: correspondences waiting for their Jacobian
-    __shared__ double s_terms[128][NT + 1];           // small problems: the terms of 64 correspondences (x 2 for H) + cost
+    __shared__ __attribute__((aligned(16))) double s_terms[132][NT + 1]; // small problems: the terms of 64 correspondences (x 2 for H) + cost; two column-major buffers of 64 rows for the others
 
     const uint8_t *mask = T.mask;
     const double pscale = T.point_scale;
@@ -1942,6 +1942,40 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                 atomicAdd(&s_count_j, cnj);
             double tot = 0.0;
             const uint32_t rounds = (pts.n + 63u) / 64u;
+            if constexpr (SUB == 1) {
+                // Two buffers of 64 rows, column-major [entry][row] (stride 66: the adders' columns spread over the banks): wavefront rd
+                // writes its correspondences' terms while the adder lanes of wavefront 0 add round rd - 1 with the inline-asm chain of
+                // k_lm_ordered (pl_lm_chain.inc: 11.7 cycles per row; the rows beyond n are zeros: x + 0.0 = x) - one barrier per round.
+                // Before (cycle counters, n = 200): write, barrier, 64 rows at ~20 cycles, barrier: 14.4 k cycles per pass, 58 % of an LM
+                // iteration of the latency configuration (BASELINE configs[0]).
+                constexpr int kSeqStride = 66;
+                double *const tb = &s_terms[0][0];
+                static_assert(2 * (NT + 1) * kSeqStride <= (int)(sizeof(s_terms) / sizeof(double)), "two buffers of 64 rows");
+                const bool adder = (jac && threadIdx.x < NT) || (res && threadIdx.x == NT);
+                for (uint32_t rd = 0; rd <= rounds; ++rd) {
+                    if (rd < rounds && (threadIdx.x >> 6) == rd) {
+                        double *dst = tb + (size_t)(rd & 1u) * (NT + 1) * kSeqStride + (threadIdx.x & 63);
+                        if (jac) {
+#pragma unroll
+                            for (int a = 0; a < NT; ++a)
+                                dst[a * kSeqStride] = term[0][a];
+                        }
+                        if (res)
+                            dst[NT * kSeqStride] = cterm[0];
+                    }
+                    if (rd > 0 && adder) {
+                        const uint32_t addr = (uint32_t)(uintptr_t)(tb + (size_t)((rd - 1u) & 1u) * (NT + 1) * kSeqStride + (size_t)threadIdx.x * kSeqStride);
+                        PL_LM_CHAIN64(tot, addr);
+                    }
+                    __syncthreads();
+                }
+                if (jac && threadIdx.x < NT)
+                    out[threadIdx.x] = tot;
+                if (res && threadIdx.x == NT)
+                    s_racc[0] = tot;
+                __syncthreads();
+                return;
+            }
             for (uint32_t rd = 0; rd < rounds; ++rd) {
                 if ((threadIdx.x >> 6) == rd) {
 #pragma unroll
