@@ -424,31 +424,36 @@ template <int K> PL_HD void lm_solve(LMControl &c, const double *normal, bool fr
             A[r * K + col] = s / d;
         }
     }
+    // (the solves run on a local copy: c lives in LDS on the device, and a read-modify-write chain on c.sol was a chain of LDS round
+    // trips - cycle counters in k_lm: solve + step 29 % of an LM iteration of a small problem)
+    double x[K];
     PL_UNROLL
     for (int i = 0; i < K; ++i)
-        c.sol[i] = b[i];
+        x[i] = b[i];
     PL_UNROLL
     for (int i = 0; i < K; ++i) {
-        c.sol[i] /= A[i * K + i];
+        x[i] /= A[i * K + i];
         PL_UNROLL
         for (int r = i + 1; r < K; ++r)
-            c.sol[r] -= c.sol[i] * A[r * K + i];
+            x[r] -= x[i] * A[r * K + i];
     }
     PL_UNROLL
     for (int i = K - 1; i >= 0; --i) {
         if (i + 1 < K) {
-            double dot = A[(i + 1) * K + i] * c.sol[i + 1];
+            double dot = A[(i + 1) * K + i] * x[i + 1];
             PL_UNROLL
             for (int j = i + 2; j < K; ++j)
-                dot += A[j * K + i] * c.sol[j];
-            c.sol[i] -= dot;
+                dot += A[j * K + i] * x[j];
+            x[i] -= dot;
         }
-        c.sol[i] /= A[i * K + i];
+        x[i] /= A[i * K + i];
     }
     double sn = 0;
     PL_UNROLL
-    for (int i = 0; i < K; ++i)
-        sn += c.sol[i] * c.sol[i];
+    for (int i = 0; i < K; ++i) {
+        c.sol[i] = x[i];
+        sn += x[i] * x[i];
+    }
     c.step_norm = sqrt(sn);
     if (c.step_norm < c.opt.step_tol)
         c.done = 1;
@@ -570,7 +575,7 @@ template <> struct Refiner<EST_ABS> {
         }
         return true;
     }
-    PL_HD static void step(const double *p, const RefineCtx &, const double *dp, double *out) {
+    PL_HD static void step(const double *__restrict__ p, const RefineCtx &, const double *__restrict__ dp, double *__restrict__ out) { // (cur, the LM step, trial: never the same storage)
         Quat q;
         q.w = p[0], q.x = p[1], q.y = p[2], q.z = p[3];
         const Quat qn = quat_step_post(q, v3(dp[0], dp[1], dp[2]));
@@ -684,7 +689,7 @@ template <> struct Refiner<EST_REL> {
         }
         return r;
     }
-    PL_HD static void step(const double *p, const RefineCtx &, const double *dp, double *out) {
+    PL_HD static void step(const double *__restrict__ p, const RefineCtx &, const double *__restrict__ dp, double *__restrict__ out) { // (cur, the LM step, trial: never the same storage)
         Quat q;
         q.w = p[0], q.x = p[1], q.y = p[2], q.z = p[3];
         const Quat qn = quat_step_post(q, v3(dp[0], dp[1], dp[2]));
@@ -768,7 +773,7 @@ template <> struct Refiner<EST_HOM> {
         for (int i = 0; i < 16; ++i)
             Jb[i] = jb[i] * ginv;
     }
-    PL_HD static void step(const double *p, const RefineCtx &, const double *dp, double *out) {
+    PL_HD static void step(const double *__restrict__ p, const RefineCtx &, const double *__restrict__ dp, double *__restrict__ out) { // (cur, the LM step, trial: never the same storage)
         PL_UNROLL
         for (int i = 0; i < kParamDoubles; ++i)
             out[i] = p[i];
@@ -845,7 +850,7 @@ template <> struct Refiner<EST_FUND> {
         }
         return r;
     }
-    PL_HD static void step(const double *p, const RefineCtx &, const double *dp, double *out) {
+    PL_HD static void step(const double *__restrict__ p, const RefineCtx &, const double *__restrict__ dp, double *__restrict__ out) { // (cur, the LM step, trial: never the same storage)
         Quat qU, qV;
         qU.w = p[0], qU.x = p[1], qU.y = p[2], qU.z = p[3];
         qV.w = p[4], qV.x = p[5], qV.y = p[6], qV.z = p[7];
