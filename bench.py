@@ -794,7 +794,7 @@ def run_focal_estimators(args, ranks, P, synth):
             ranks.barrier()
             return time.perf_counter() - t1
 
-        n8, n16 = max(64, 4 * reps), max(256, 8 * reps)
+        n8, n16 = max(256, 16 * reps), max(768, 32 * reps)  # (0.1 - 0.2 s each: a shorter run measures the threads' start-up)
         elapsed8, elapsed16 = threaded(8, n8), threaded(16, n16)
         table = ranks.gather([elapsed, float(sum(o[1]["hypotheses"] for o in outs)), elapsed8, elapsed16])
         if ranks.rank != 0:
