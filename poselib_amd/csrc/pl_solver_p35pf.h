@@ -72,17 +72,22 @@ template <int F> struct P35Poly {
     double c[35 - F];
 };
 template <int F> PL_HD void p35_zero(P35Poly<F> &p) {
+    PL_UNROLL
     for (int i = 0; i < 35 - F; ++i)
         p.c[i] = 0.0;
 }
-// r += p * q, term by term in ascending (i, j) - zero coefficients are skipped (as the oracle's dense product does)
+// r += p * q, term by term in ascending (i, j) - zero coefficients are skipped (as the oracle's dense product does).
+// (unrolled: kP35Prod folds to constants and the coefficients stay in registers - a run-time index puts them into scratch memory)
 template <int FR, int FP, int FQ> PL_HD void p35_mul(const P35Poly<FP> &p, const P35Poly<FQ> &q, P35Poly<FR> &r) {
     p35_zero(r);
+    PL_UNROLL
     for (int i = FP; i < 35; ++i)
-        if (p.c[i - FP] != 0)
+        if (p.c[i - FP] != 0) {
+            PL_UNROLL
             for (int j = FQ; j < 35; ++j)
                 if (q.c[j - FQ] != 0)
                     r.c[kP35Prod[i][j] - FR] += p.c[i - FP] * q.c[j - FQ];
+        }
 }
 typedef P35Poly<30> P35Lin;
 typedef P35Poly<20> P35Quad;
@@ -93,15 +98,18 @@ PL_HD void p35_dot(const P35Lin *a, const P35Lin *b, P35Quad &out) { // (a0 b0 +
     p35_mul(a[0], b[0], m0);
     p35_mul(a[1], b[1], m1);
     p35_mul(a[2], b[2], m2);
+    PL_UNROLL
     for (int i = 0; i < 15; ++i)
         out.c[i] = (m0.c[i] + m1.c[i]) + m2.c[i];
 }
 PL_HD void p35_cross(const P35Lin *a, const P35Lin *b, P35Quad *out) {
     P35Quad m0, m1;
+    PL_UNROLL
     for (int k = 0; k < 3; ++k) {
         const int i = (k + 1) % 3, j = (k + 2) % 3;
         p35_mul(a[i], b[j], m0);
         p35_mul(a[j], b[i], m1);
+        PL_UNROLL
         for (int t = 0; t < 15; ++t)
             out[k].c[t] = m0.c[t] - m1.c[t];
     }
@@ -123,8 +131,10 @@ struct P35Work {
 // row r of the elimination matrix = eq scaled to unit maximum
 PL_HD void p35_store_row(const P35Work &w, int r, const P35Cubic &eq) {
     double mx = 0;
+    PL_UNROLL
     for (int c = 0; c < 35; ++c)
         mx = fmax(mx, fabs(eq.c[c]));
+    PL_UNROLL
     for (int c = 0; c < 35; ++c)
         w.at(r, c) = mx > 0 ? eq.c[c] / mx : 0.0;
 }
@@ -514,28 +524,38 @@ PL_HD void p35pf_setup(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Wor
     {
         // rows of the left 3 x 3 block as vectors of linear polynomials: a[r][i] = sum_k N(4 r + i, k) x_k + N(4 r + i, 4)
         P35Lin a[3][3];
-        for (int r = 0; r < 3; ++r)
-            for (int i = 0; i < 3; ++i)
+        PL_UNROLL
+        for (int r = 0; r < 3; ++r) {
+            PL_UNROLL
+            for (int i = 0; i < 3; ++i) {
+                PL_UNROLL
                 for (int k = 0; k < 5; ++k)
                     a[r][i].c[k] = N[k * 12 + 4 * r + i];
+            }
+        }
         P35Cubic eq;
         int ne = 0;
         {
             P35Quad quad, d1;
-            for (int qn = 0; qn < 4; ++qn) {
+            PL_UNROLL
+            for (int qn = 0; qn < 4; ++qn) { // (unrolled throughout: every coefficient index is a constant, the polynomials stay in registers)
                 if (qn < 3) {
                     p35_dot(a[qn == 2 ? 1 : 0], a[qn == 0 ? 1 : 2], quad);
                 } else {
                     p35_dot(a[0], a[0], quad);
                     p35_dot(a[1], a[1], d1);
+                    PL_UNROLL
                     for (int i = 0; i < 15; ++i)
                         quad.c[i] = quad.c[i] - d1.c[i];
                 }
+                PL_UNROLL
                 for (int i = 0; i < 20; ++i)
                     eq.c[i] = 0.0;
+                PL_UNROLL
                 for (int i = 0; i < 15; ++i)
                     eq.c[20 + i] = quad.c[i];
                 p35_store_row(w, ne++, eq);
+                PL_UNROLL
                 for (int k = 0; k < 4; ++k) {
                     P35Lin shift;
                     p35_zero(shift);
@@ -548,15 +568,19 @@ PL_HD void p35pf_setup(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Wor
         P35Quad c23[3], c31[3];
         p35_cross(a[1], a[2], c23);
         p35_cross(a[2], a[0], c31);
-        for (int i = 0; i < 3; ++i)
+        PL_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            PL_UNROLL
             for (int j = 0; j < 3; ++j) {
                 P35Cubic m1;
                 p35_mul(c23[i], a[1][j], eq);
                 p35_mul(c31[j], a[0][i], m1);
+                PL_UNROLL
                 for (int c = 0; c < 35; ++c)
                     eq.c[c] = eq.c[c] - m1.c[c];
                 p35_store_row(w, ne++, eq);
             }
+        }
     }
     PL_P35_MARK(2);
 }
