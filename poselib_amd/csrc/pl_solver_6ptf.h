@@ -38,11 +38,16 @@ struct SixPoly { // dense over the ten monomials
 };
 // r = p * q, products added in ascending (i, j); FP / FQ: first monomial a factor can hold (7: linear, 4: quadratic)
 template <int FP, int FQ> PL_HD void six_mul(const SixPoly &p, const SixPoly &q, SixPoly &r) {
+    // (unrolled: kSixProd folds to constants and the coefficients stay in registers - a run-time index puts them into scratch memory)
+    PL_UNROLL
     for (int i = 0; i < 10; ++i)
         r.c[i] = 0.0;
-    for (int i = FP; i < 10; ++i)
+    PL_UNROLL
+    for (int i = FP; i < 10; ++i) {
+        PL_UNROLL
         for (int j = FQ; j < 10; ++j)
             r.c[kSixProd[i][j]] += p.c[i] * q.c[j];
+    }
 }
 
 // workspace of one sample
@@ -58,9 +63,12 @@ typedef StridedArr SixWork; // (pl_solver_p35pf.h)
 // constraint), every equation scaled to unit maximum.  nb: 9 x 3 null-space basis, column-major, vec index e = 3 col + row.
 PL_HD void six_equations(const double *nb, const SixWork &C) {
     SixPoly F[3][3];
+    PL_UNROLL
     for (int i = 0; i < 3; ++i)
+        PL_UNROLL
         for (int j = 0; j < 3; ++j) {
             const int e = 3 * j + i;
+            PL_UNROLL
             for (int k = 0; k < 7; ++k)
                 F[i][j].c[k] = 0.0;
             F[i][j].c[9] = nb[e];
@@ -68,15 +76,19 @@ PL_HD void six_equations(const double *nb, const SixWork &C) {
             F[i][j].c[8] = nb[18 + e];
         }
     SixPoly G0[3][3], G1[3][3], a, b, c;
+    PL_UNROLL
     for (int i = 0; i < 3; ++i)
+        PL_UNROLL
         for (int j = 0; j < 3; ++j) {
             six_mul<7, 7>(F[i][0], F[j][0], a);
             six_mul<7, 7>(F[i][1], F[j][1], b);
+            PL_UNROLL
             for (int k = 0; k < 10; ++k)
                 G0[i][j].c[k] = a.c[k] + b.c[k];
             six_mul<7, 7>(F[i][2], F[j][2], G1[i][j]);
         }
     SixPoly tr0, tr1, tr2;
+    PL_UNROLL
     for (int k = 0; k < 10; ++k) {
         tr0.c[k] = G0[0][0].c[k] + G0[1][1].c[k];
         tr1.c[k] = (G1[0][0].c[k] + G1[1][1].c[k]) + G0[2][2].c[k];
@@ -84,11 +96,15 @@ PL_HD void six_equations(const double *nb, const SixWork &C) {
     }
     auto store = [&](int r, const SixPoly *e) { // one equation: scale and store
         double mx = 0;
+        PL_UNROLL
         for (int k = 0; k < 3; ++k)
+            PL_UNROLL
             for (int m = 0; m < 10; ++m)
                 mx = fmax(mx, fabs(e[k].c[m]));
         const double s = mx > 0 ? 1.0 / mx : 0.0;
+        PL_UNROLL
         for (int k = 0; k < 3; ++k)
+            PL_UNROLL
             for (int m = 0; m < 10; ++m)
                 C[k * 100 + r * 10 + m] = e[k].c[m] * s;
     };
@@ -98,6 +114,7 @@ PL_HD void six_equations(const double *nb, const SixWork &C) {
         auto minor = [&](int r0, int c0, int r1, int c1, SixPoly &out) { // F[r0][c0] F[r1][c1] - F[r0][c1] F[r1][c0]
             six_mul<7, 7>(F[r0][c0], F[r1][c1], m0);
             six_mul<7, 7>(F[r0][c1], F[r1][c0], m1);
+            PL_UNROLL
             for (int k = 0; k < 10; ++k)
                 out.c[k] = m0.c[k] - m1.c[k];
         };
@@ -107,6 +124,7 @@ PL_HD void six_equations(const double *nb, const SixWork &C) {
         six_mul<7, 4>(F[0][1], a, d1);
         minor(1, 0, 2, 1, a);
         six_mul<7, 4>(F[0][2], a, d2);
+        PL_UNROLL
         for (int k = 0; k < 10; ++k) {
             eq[0].c[k] = (d0.c[k] - d1.c[k]) + d2.c[k];
             eq[1].c[k] = 0.0;
@@ -114,13 +132,16 @@ PL_HD void six_equations(const double *nb, const SixWork &C) {
         }
         store(0, eq);
     }
+    PL_UNROLL
     for (int i = 0; i < 3; ++i)
+        PL_UNROLL
         for (int j = 0; j < 3; ++j) {
             SixPoly t;
             // w^0: 2 (G0_i0 F_0j + G0_i1 F_1j) - tr0 F_ij
             six_mul<4, 7>(G0[i][0], F[0][j], a);
             six_mul<4, 7>(G0[i][1], F[1][j], b);
             six_mul<4, 7>(tr0, F[i][j], t);
+            PL_UNROLL
             for (int k = 0; k < 10; ++k)
                 eq[0].c[k] = 2.0 * (a.c[k] + b.c[k]) - t.c[k];
             // w^1: 2 ((G1_i0 F_0j + G1_i1 F_1j) + G0_i2 F_2j) - tr1 F_ij
@@ -128,11 +149,13 @@ PL_HD void six_equations(const double *nb, const SixWork &C) {
             six_mul<4, 7>(G1[i][1], F[1][j], b);
             six_mul<4, 7>(G0[i][2], F[2][j], c);
             six_mul<4, 7>(tr1, F[i][j], t);
+            PL_UNROLL
             for (int k = 0; k < 10; ++k)
                 eq[1].c[k] = 2.0 * ((a.c[k] + b.c[k]) + c.c[k]) - t.c[k];
             // w^2: 2 G1_i2 F_2j - tr2 F_ij
             six_mul<4, 7>(G1[i][2], F[2][j], a);
             six_mul<4, 7>(tr2, F[i][j], t);
+            PL_UNROLL
             for (int k = 0; k < 10; ++k)
                 eq[2].c[k] = 2.0 * a.c[k] - t.c[k];
             store(1 + 3 * i + j, eq);
