@@ -27,6 +27,14 @@ constexpr int eig_wave_doubles(int n) { return n * n + 4 * n; }
         __builtin_amdgcn_wave_barrier();                                                                               \
     } while (0)
 
+// a / b, c / d, e / f ... at once: the divisions of a reflector are independent of one another, and an fp64 division is ~35
+// instructions that every lane would issue alike - lane i forms quotient i, the others read it (v_readlane).  The same IEEE
+// operation on the same operands in another lane: the same bits.
+__device__ __forceinline__ double eig_bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 // pl_balance_pow2<n> (pl_solver_6ptf.h): Parlett-Reinsch balancing without the permutation step
 template <int n> __device__ void pl_balance_pow2_wave(double *a, int lane) {
     bool done = false;
@@ -192,7 +200,10 @@ template <int n> __device__ int pl_real_eigenvalues_wave(double *a, double tol, 
                         q = PL_A(m + 1, m + 1) - z - r - s;
                         r = PL_A(m + 2, m + 1);
                         s = fabs(p) + fabs(q) + fabs(r);
-                        p /= s, q /= s, r /= s;
+                        {
+                            const double quo = (lane == 0 ? p : lane == 1 ? q : r) / s; // p /= s, q /= s, r /= s
+                            p = eig_bcast(quo, 0), q = eig_bcast(quo, 1), r = eig_bcast(quo, 2);
+                        }
                         if (m == l)
                             break;
                         const double u = fabs(PL_A(m, m - 1)) * (fabs(q) + fabs(r));
@@ -212,8 +223,10 @@ template <int n> __device__ int pl_real_eigenvalues_wave(double *a, double tol, 
                             p = PL_A(k, k - 1);
                             q = PL_A(k + 1, k - 1);
                             r = (k != nn - 1) ? PL_A(k + 2, k - 1) : 0.0;
-                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0)
-                                p /= x, q /= x, r /= x;
+                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0) {
+                                const double quo = (lane == 0 ? p : lane == 1 ? q : r) / x; // p /= x, q /= x, r /= x
+                                p = eig_bcast(quo, 0), q = eig_bcast(quo, 1), r = eig_bcast(quo, 2);
+                            }
                         }
                         const double sq = sqrt(p * p + q * q + r * r);
                         if ((s = (p >= 0 ? sq : -sq)) != 0) {
@@ -227,8 +240,12 @@ template <int n> __device__ int pl_real_eigenvalues_wave(double *a, double tol, 
                                 }
                             }
                             p += s;
-                            x = p / s, y = q / s, z = r / s;
-                            q /= p, r /= p;
+                            {   // x = p / s, y = q / s, z = r / s; q /= p, r /= p
+                                const double num = lane == 0 ? p : (lane == 1 || lane == 3) ? q : r, den = lane < 3 ? s : p;
+                                const double quo = num / den;
+                                x = eig_bcast(quo, 0), y = eig_bcast(quo, 1), z = eig_bcast(quo, 2);
+                                q = eig_bcast(quo, 3), r = eig_bcast(quo, 4);
+                            }
                             PL_WAVE_SYNC();
                             if (lane >= k && lane <= nn) { // the reflector on rows k .. k + 2: column j = lane
                                 const int j = lane;
