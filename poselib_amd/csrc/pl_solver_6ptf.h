@@ -314,6 +314,22 @@ constexpr int kSixMaxModels = 60; // 15 solutions x 4 poses (relpose_6pt_focal.c
 //
 // Stage 1: null space nb (9 x 3) of the six epipolar constraints, the ten equations C (kept for stage 3) and the 15 x 15 companion
 // matrix T.  false: a vanishing pivot in the row reduction (no models).  Needs the whole workspace w.
+// (the first half of stage 1 alone: null space and equations - on the device the row reduction is done by a wavefront, sfocal.hip)
+PL_HD void six_nullspace_equations(const Vec3 *x1, const Vec3 *x2, const SixWork &C, double *nb /* 27 */) {
+    {
+        double A[54];
+        for (int i = 0; i < 6; ++i) {
+            const double a[3] = {x1[i].x, x1[i].y, x1[i].z};
+            for (int j = 0; j < 3; ++j) {
+                A[i * 9 + 3 * j + 0] = a[j] * x2[i].x;
+                A[i * 9 + 3 * j + 1] = a[j] * x2[i].y;
+                A[i * 9 + 3 * j + 2] = a[j] * x2[i].z;
+            }
+        }
+        complement_basis_indexed<9, 6>(A, nb);
+    }
+    six_equations(nb, C);
+}
 PL_HD bool six_setup(const Vec3 *x1, const Vec3 *x2, const SixWork &w, double *nb /* 27 */) {
     {
         double A[54];

@@ -31,19 +31,16 @@ namespace pl {
 namespace {
 
 // ---- the generator: two kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ------------------------
-//   k_sfocal_setup   one lane = one sample, the solver's whole workspace (8.6 KB per sample) in LDS: 16 samples per workgroup, one
-//                    workgroup per CU - null space, equations, row reduction to the 15 x 15 companion matrix; T, C, nb and the
-//                    bearings go to the stage
-//   k_sfocal_solve   one WAVEFRONT = one sample: eigenvalues and roots by the lanes together (below)
+//   k_sfocal_setup   one lane = one sample: null space of the epipolar constraints and the ten equations C (written straight into the
+//                    stage, coalesced), the bearings
+//   k_sfocal_solve   one WAVEFRONT = one sample: row reduction of the equations to the 15 x 15 companion matrix, its eigenvalues
+//                    and the roots by the lanes together (below)
 // Round 3's single kernel held 8.6 KB of LDS per sample through all stages (2.86 ms on 63 CUs per batch of 1001 samples: four
-// problems filled the device, which bounded the throughput of several host threads at 1.4 k problems/s); the two kernels take
-// 0.22 + 0.5 ms.
-constexpr int kGenLanes = 16; // stage 1: samples per workgroup (their workspaces fill the CU's LDS)
-constexpr int kStT = 0, kStC = 225, kStNb = 525, kStX = 552, kStOk = 588, kStDoubles = 589;
+// problems filled the device, which bounded the throughput of several host threads at 1.4 k problems/s).
+constexpr int kStC = 0, kStNb = 300, kStX = 327, kStDoubles = 363;
 
 __global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
-    extern __shared__ double s_work[]; // kSixWorkDoubles x kGenLanes, element-major
-    const uint32_t it = blockIdx.x * kGenLanes + threadIdx.x;
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
     if (it >= g.num_iters)
         return;
     Vec3 x1[6], x2[6];
@@ -68,17 +65,8 @@ __global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
     }
     const size_t B = g.num_iters;
     double *st = g.stage + it;
-    const SixWork w{s_work + threadIdx.x, (size_t)kGenLanes};
     double nb[27];
-    const bool ok = six_setup(x1, x2, w, nb);
-    st[(size_t)kStOk * B] = ok ? 1.0 : 0.0;
-    if (!ok)
-        return;
-    const SixWork T = w.at(kSixT), C = w.at(kSixC);
-    for (int e = 0; e < 225; ++e)
-        st[(size_t)(kStT + e) * B] = T[e];
-    for (int e = 0; e < 300; ++e)
-        st[(size_t)(kStC + e) * B] = C[e];
+    six_nullspace_equations(x1, x2, SixWork{st + (size_t)kStC * B, B}, nb); // (the equations straight into the stage: coalesced)
     for (int e = 0; e < 27; ++e)
         st[(size_t)(kStNb + e) * B] = nb[e];
     for (int k = 0; k < 6; ++k) {
@@ -88,7 +76,10 @@ __global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
     }
 }
 
-// k_sfocal_solve: one WAVEFRONT = one sample, two stages in one launch.
+// k_sfocal_solve: one WAVEFRONT = one sample, three stages in one launch.
+//   companion    six_companion_wave (pl_eigen_wave.h): Gaussian elimination of the w^2 part with complete pivoting, the 10 x 10 system
+//                with 15 right-hand sides, the companion matrix (one lane per sample, matrices in LDS: 360 k cycles, 81 % of the old
+//                setup kernel)
 //   eigenvalues  the 15 x 15 companion matrix in LDS, balanced and reduced by the lanes together (pl_eigen_wave.h: six_eigenvalues of
 //                pl_solver_6ptf.h, the same operations on every element; as one lane per sample: 2.1 ms per batch)
 //   roots        phase 1, lane s = root s: (x, y) from the null vector of C0 + w C1 + w^2 C2 (its own 10 x 10 matrix in LDS).  Lane 0
@@ -98,7 +89,7 @@ __global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
 constexpr int kSolveWaves = 2, kFinRoots = 8, kMaxRoots = 16; // the roots go through the lanes kFinRoots at a time (a second pass is rare)
 constexpr int kFinC = 0, kFinA = 300, kFinNb = kFinA + 100 * kFinRoots, kFinX = kFinNb + 27, kFinTmp = kFinX + 36,
               kFinDoubles = kFinTmp + 7 * kMaxRoots;
-static_assert(eig_wave_doubles(15) <= 100 * kFinRoots, "the eigenvalue workspace lives in the roots' region");
+static_assert(eig_wave_doubles(15) <= 100 * kFinRoots && 225 + 300 + 100 + 150 + 16 <= 100 * kFinRoots, "the row reduction and the eigenvalue workspace live in the roots' region");
 __global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sfocal_solve(SFocalGenArgs g) {
     __shared__ double s_fin[kSolveWaves][kFinDoubles];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -113,31 +104,32 @@ __global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_e
     uint32_t m = 0;
     int nroots = 0;
     double wv = 0.0;
-    if (st[(size_t)kStOk * B] != 0.0) {
-        double *a = base + kFinA; // T, then the workspace of the iteration
-        bool finite = true;
-        for (int e = lane; e < 225; e += 64) {
-            const double v = st[(size_t)(kStT + e) * B];
-            a[e] = v;
-            finite = finite && isfinite(v);
+    {
+        // the equations: C stays (the roots' null vectors), a copy is row-reduced to the companion matrix by the wavefront
+        double *reg = base + kFinA; // T (225) | Cw (300) | A (100) | B (150) | factors (16): dead before the roots use the region
+        for (int e = lane; e < 300; e += 64) {
+            const double v = st[(size_t)(kStC + e) * B];
+            base[kFinC + e] = v;
+            reg[225 + e] = v;
         }
-        if (!__builtin_amdgcn_ballot_w64(!finite)) { // (a vanishing pivot: the balancing would not terminate on an infinite entry)
-            PL_WAVE_SYNC();
-            pl_balance_pow2_wave<15>(a, lane);
-            nroots = pl_real_eigenvalues_wave<15>(a, 1e-8, lane);
-            if (lane < nroots)
-                wv = a[225 + 45 + lane];
-        }
-        PL_WAVE_SYNC();
-    }
-    if (nroots > 0) {
-        for (int e = lane; e < 300; e += 64)
-            base[kFinC + e] = st[(size_t)(kStC + e) * B];
         if (lane < 27)
             base[kFinNb + lane] = st[(size_t)(kStNb + lane) * B];
         if (lane < 36)
             base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
+        if (six_companion_wave(reg + 225, reg, reg + 525, reg + 625, reg + 775, lane)) {
+            bool finite = true;
+            for (int e = lane; e < 225; e += 64)
+                finite = finite && isfinite(reg[e]);
+            if (!__builtin_amdgcn_ballot_w64(!finite)) { // (a vanishing pivot: the balancing would not terminate on an infinite entry)
+                pl_balance_pow2_wave<15>(reg, lane);
+                nroots = pl_real_eigenvalues_wave<15>(reg, 1e-8, lane);
+                if (lane < nroots)
+                    wv = reg[225 + 45 + lane];
+            }
+        }
         PL_WAVE_SYNC();
+    }
+    if (nroots > 0) {
         // root s = pass * kFinRoots + lane: its eigenvalue sits in lane s
         uint64_t fmask = 0;
         for (int first = 0; first < nroots; first += kFinRoots) {
@@ -560,19 +552,7 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
         return hipSuccess;
     if (!g.stage)
         return hipErrorInvalidValue;
-    constexpr size_t bytes = sizeof(double) * kSixWorkDoubles * kGenLanes; // 137.6 KB of the CU's 160 KB
-    static std::atomic<int> prepared_dev[64]; // per device ordinal: the attribute is per-device state on some runtimes
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    std::atomic<int> &prepared = prepared_dev[dev_ & 63];
-    if (!prepared.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sfocal_setup), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)bytes);
-        if (e != hipSuccess)
-            return e;
-        prepared.store(1, std::memory_order_release);
-    }
-    k_sfocal_setup<<<dim3((g.num_iters + kGenLanes - 1) / kGenLanes), dim3(kGenLanes), bytes, stream>>>(g);
+    k_sfocal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
     k_sfocal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     return hipGetLastError();
 }
