@@ -29,7 +29,7 @@ namespace {
 //   k_focal_solve   one WAVEFRONT = one sample: elimination in registers, eigenvalues and roots by the lanes together (below)
 // Round 3's single kernel (one lane per sample, 8.1 KB of LDS per sample: 16 lanes per CU whatever the phase) took 1.5 ms per
 // launch and occupied 63 CUs for a batch of 1001 samples; the two kernels take 0.21 + 0.33 ms.
-constexpr int kStageN = kP35WorkDoubles, kStageF0 = kStageN + 60, kStageDoubles = kStageF0 + 1;
+constexpr int kStageN = kP35WorkDoubles, kStageF0 = kStageN + 60, kStageMx = kStageF0 + 1, kStageDoubles = kStageMx + kP35Rows;
 
 __global__ __launch_bounds__(64) void k_focal_setup(FocalGenArgs g) {
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
@@ -59,7 +59,19 @@ __global__ __launch_bounds__(64) void k_focal_setup(FocalGenArgs g) {
     }
     const size_t B = g.num_iters;
     double N[60], f0;
-    p35pf_setup(xs, X, P35Work{g.stage + it, B}, N, f0);
+    // the rows unscaled, their maxima beside them: the 35 divisions of a row are done by the 35 lanes of k_focal_solve that hold its
+    // columns (p35_store_row's operations, one lane per column instead of one lane for 1015 divisions)
+    double *const st = g.stage + it;
+    p35pf_setup_t(xs, X, [&](int r, const P35Cubic &eq) {
+        double mx = 0;
+#pragma unroll
+        for (int c = 0; c < kP35Cols; ++c)
+            mx = fmax(mx, fabs(eq.c[c]));
+#pragma unroll
+        for (int c = 0; c < kP35Cols; ++c)
+            st[(size_t)(r * kP35Cols + c) * B] = eq.c[c];
+        st[(size_t)(kStageMx + r) * B] = mx;
+    }, N, f0);
     for (int e = 0; e < 60; ++e)
         g.stage[(size_t)(kStageN + e) * B + it] = N[e];
     g.stage[(size_t)kStageF0 * B + it] = f0;
@@ -98,8 +110,11 @@ __global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_e
         const int c = lane < kP35Cols ? lane : kP35Cols - 1; // (lanes 35..63 shadow the last column: no divergence, never read)
         double w[kP35Rows];
 #pragma unroll
-        for (int r = 0; r < kP35Rows; ++r)
-            w[r] = stage[(size_t)(r * kP35Cols + c) * B + it];
+        for (int r = 0; r < kP35Rows; ++r) { // p35_store_row: the row scaled to unit maximum
+            const double mx = stage[(size_t)(kStageMx + r) * B + it];
+            const double raw = stage[(size_t)(r * kP35Cols + c) * B + it];
+            w[r] = mx > 0 ? raw / mx : 0.0;
+        }
         uint32_t used = 0; // (uniform)
         int pivot_of = 0;  // lane k: pivot row of eliminated monomial k
 #pragma unroll 1

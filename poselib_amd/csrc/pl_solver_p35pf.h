@@ -486,7 +486,10 @@ struct P35Solution {
 //
 // Stage 1: null space N (12 x 5, column k at N[12 k ..]) of the seven linear constraints, scale f0 of the image points, and the 29
 // equations as the rows of the elimination matrix w.
-PL_HD void p35pf_setup(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, double *N /* 60 */, double &f0_out) {
+// sink(r, eq): takes equation r (on the host and in p35pf(): p35_store_row - the row scaled to unit maximum; on the device the raw
+// coefficients and the maximum, the 35 divisions of a row are then done by the 35 lanes that hold its columns, focal.hip)
+template <class Sink>
+PL_HD void p35pf_setup_t(const double *xs /* 4 x 2 */, const Vec3 *X, Sink &&sink, double *N /* 60 */, double &f0_out) {
     PL_P35_MARK(0);
     double f0 = 0;
     for (int i = 0; i < 4; ++i)
@@ -554,14 +557,14 @@ PL_HD void p35pf_setup(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Wor
                 PL_UNROLL
                 for (int i = 0; i < 15; ++i)
                     eq.c[20 + i] = quad.c[i];
-                p35_store_row(w, ne++, eq);
+                sink(ne++, eq);
                 PL_UNROLL
                 for (int k = 0; k < 4; ++k) {
                     P35Lin shift;
                     p35_zero(shift);
                     shift.c[k] = 1.0;
                     p35_mul(quad, shift, eq);
-                    p35_store_row(w, ne++, eq);
+                    sink(ne++, eq);
                 }
             }
         }
@@ -578,11 +581,14 @@ PL_HD void p35pf_setup(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Wor
                 PL_UNROLL
                 for (int c = 0; c < 35; ++c)
                     eq.c[c] = eq.c[c] - m1.c[c];
-                p35_store_row(w, ne++, eq);
+                sink(ne++, eq);
             }
         }
     }
     PL_P35_MARK(2);
+}
+PL_HD void p35pf_setup(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, double *N /* 60 */, double &f0_out) {
+    p35pf_setup_t(xs, X, [&](int r, const P35Cubic &eq) { p35_store_row(w, r, eq); }, N, f0_out);
 }
 
 // the five rows of the action matrix that come out of the elimination: row i of the action matrix = - (reduced row of the pivot of
