@@ -1,16 +1,19 @@
 // poselib_amd - kernels of the focal-length estimator (ransac_pnpf: robust/ransac.cc:58-75, FocalAbsolutePoseEstimator).
 //
-//   k_focal_generate   one lane = one RANSAC iteration: draw the sample of four correspondences from the iteration's position in
-//                      the splitmix64 stream, solve P3.5Pf (pl_solver_p35pf.h), keep the solutions the estimator keeps
-//                      (focal >= 0, focal <= max_focal_length: absolute_pose.cc:89-95).  The 29 x 35 elimination matrices live in
-//                      LDS, element-major, 16 samples per workgroup (one workgroup per CU) - in HBM (first version: 5.5 ms per
-//                      batch of 4096 samples) every step of the elimination paid the memory latency.
+//   k_focal_setup      one lane = one RANSAC iteration: draw the sample of four correspondences from the iteration's position in
+//                      the splitmix64 stream (or take the host's PROSAC sample), null space and equations of P3.5Pf
+//                      (pl_solver_p35pf.h) -> the 29 x 35 elimination matrix, unscaled, into a workspace in HBM
+//   k_focal_solve      one WAVEFRONT = one iteration: row scaling, elimination with a matrix column per lane in registers,
+//                      eigenvalues of the action matrix by the lanes together (pl_eigen_wave.h), one lane per root; keeps the
+//                      solutions the estimator keeps (focal >= 0, focal <= max_focal_length: absolute_pose.cc:89-95)
 //   k_focal_score      one wavefront = one model: compute_msac_score(Image, ...) (utils.cc:66-98) - inlier count and the sum of
 //                      the inliers' squared residuals IN CORRESPONDENCE ORDER (the score decides comparisons in the loop, so
 //                      it has to be the sequential sum): the lanes evaluate 64 correspondences at a time, the inliers' residuals
 //                      are then added one by one in lane order (wave-uniform loop over the ballot).
+//   k_focal_score_wg   the same score by one workgroup per model (producers / ordered chain): the few refined models of a local
+//                      optimisation
 //   k_focal_mask       get_inliers(Image, ...) (utils.cc:385-399), one thread per correspondence.
-// A first, correct device path for this estimator: neither kernel is tuned (no pre-filter, one lane per sample), DESIGN §4 has the measured numbers and what bounds them.
+// Round 3's form (one kernel, one lane per sample, matrices in LDS) and what each step of round 4 bought: DESIGN 4, "The focal-length estimators".
 #include "pl_focal.h"
 #include "pl_kernels.h"
 #include "pl_solver_p35pf.h"

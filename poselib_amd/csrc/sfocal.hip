@@ -1,22 +1,23 @@
 // poselib_amd - kernels of the shared-focal relative pose estimator (ransac_shared_focal_relpose: robust/ransac.cc:182-203,
 // SharedFocalRelativePoseEstimator robust/estimators/relative_pose.cc:154-203, refiner robust/optim/relative.h:488-592).
 //
-//   k_sfocal_generate  one lane = one RANSAC iteration: the sample of six correspondences from the iteration's position in the
-//                      splitmix64 stream, unit bearings, the 6-point solver (pl_solver_6ptf.h).  The solver's matrices
-//                      (kSixWorkDoubles = 8.6 KB per sample) live in LDS, element-major: 16 samples per workgroup fill a CU's
-//                      160 KB, one workgroup per CU - the solver is a chain of dependent accesses to those matrices, and in HBM
-//                      (first version: 10.4 ms per batch of 4096 samples) every step paid the memory latency.
+//   k_sfocal_setup     one lane = one RANSAC iteration: the sample of six correspondences from the iteration's position in the
+//                      splitmix64 stream (or the host's PROSAC sample), unit bearings, null space and the ten equations of the
+//                      6-point solver (pl_solver_6ptf.h) into a workspace in HBM
+//   k_sfocal_solve     one WAVEFRONT = one iteration: row reduction to the 15 x 15 companion matrix, its eigenvalues (pl_eigen_wave.h),
+//                      one lane per root, then one lane per solution
 //   k_sfocal_score     one wavefront = one model: compute_sampson_msac_score (utils.cc:204-239) of F = K_inv (E K_inv) - inlier
 //                      count and the score IN CORRESPONDENCE ORDER (r2 of an inlier, the threshold of an outlier, one after the
 //                      other: the score decides comparisons in the loop, so it has to be the sequential sum).  The lanes evaluate
 //                      64 correspondences at a time; their terms are then added in lane order through v_readlane.
+//   k_sfocal_score_wg  the same score by one workgroup per model (producers / ordered chain): the refined models of a local optimisation
 //   k_sfocal_mask      get_inliers(F, ...) (utils.cc:401-419), one thread per correspondence.
 //   k_sfocal_lm        one workgroup = one refinement, the whole Levenberg-Marquardt loop on the device: refine_model's
 //                      pre-filter (Sampson error below 5 thr^2, nothing to do when <= 6 survive), then cost and normal equations
-//                      summed correspondence after correspondence - rounds of 256 rows in LDS, lane e < 27 owns entry e of
-//                      [JtJ | Jtr] (k_lm_cam's scheme: rows without contribution are dropped by a ballot + prefix compaction that keeps the order) - so that the refined
-//                      model equals the oracle's to the bit for every n.
-// A first, correct device path for this estimator (like focal.hip): none of the kernels is tuned; DESIGN 4 has the numbers.
+//                      summed correspondence after correspondence - wavefronts 1 .. 3 produce the entry terms of a round of 192
+//                      correspondences, lane e < 27 of wavefront 0 adds entry e of [JtJ | Jtr] with the inline-asm chain - so that the
+//                      refined model equals the oracle's to the bit for every n.
+// Round 3's form (one lane per sample throughout) and what each step of round 4 bought: DESIGN 4, "The focal-length estimators".
 #include "pl_kernels.h"
 #include "pl_device.h"
 #include "pl_sfocal.h"
