@@ -148,7 +148,7 @@ def model_vec(kind, model):
 
 
 def model_diff(kind, got, ref):
-    """rotation + translation difference for poses (BASELINE: 1e-6 each), sign-free normalised difference for F / H"""
+    """rotation + translation difference for poses (BASELINE: 1e-6 each), sign-SENSITIVE normalised difference for F / H"""
     return max(model_diff_parts(kind, got, ref).values())
 
 
@@ -169,7 +169,7 @@ def model_diff_parts(kind, got, ref):
             parts["dt_len"] = abs(ng - nr)
         return parts
     a, b = got / np.linalg.norm(got), ref / np.linalg.norm(ref)
-    return {"dM": float(min(np.linalg.norm(a - b), np.linalg.norm(a + b)))}
+    return {"dM": float(np.linalg.norm(a - b))}
 
 
 class Ranks:
@@ -953,7 +953,8 @@ def main():
                                        "problems_per_gpu_per_step", "problems_in_flight_per_gpu", "distinct_scenes",
                                        "timed_region_s", "hypotheses_per_step", "iterations_per_s", "nan_model_share")},
                "sharding": "one problem over the ranks" if args.shard_problem else "independent problems per rank, RCCL: barrier + final gather",
-               "lm_sums": "reference order at every n (k_lm_ordered)" if os.environ.get("POSELIB_AMD_LM_ORDERED", "0") not in ("", "0") else "reference order up to 256 correspondences, tree beyond (default; pl_set_lm_mode(1) = every n)"}
+               "lm_sums": {"1": "reference order at every n (k_lm_ordered)", "2": "tree beyond 256 correspondences, every estimator"}.get(
+                   os.environ.get("POSELIB_AMD_LM_ORDERED", "0"), "poses / H: reference order up to 256 correspondences, tree beyond; F: reference order at every n (default)")}
         for n in names[1:]:
             r = reports[n]
             if n in WORKLOADS:

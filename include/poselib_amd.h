@@ -83,7 +83,12 @@ typedef struct {
     int32_t estimate_extra_params; /* must be 0 (radial distortion estimation: out of scope) */
     double min_fov;           /* types.h:126 AbsolutePoseOptions::min_fov, degrees (5.0): with estimate_focal_length / pl_ransac_pnpf the
                                  largest focal length a hypothesis may have is max|x| / tan(min_fov / 2) (absolute_pose.cc:159-177);
-                                 <= 0 disables the bound.  Ignored by every other entry point, like in the reference. */
+                                 <= 0 disables the bound; NaN is rejected (PL_ERR_INVALID).  Ignored by every other entry
+                                 point, like in the reference.
+                                 ABI note: this field was appended in PL_ABI_VERSION 4.  A caller must fill the record with
+                                 pl_default_robust_options() and then change what it needs - a zero-initialised record
+                                 means min_fov = 0 (NO bound) where the reference defaults to 5 degrees - and must be built
+                                 against the header of the library it loads: check pl_abi_version() == PL_ABI_VERSION once. */
 } pl_robust_options;
 
 /* types.h:52-58 (+ the metric numerator and timing, which the reference does not report) */
@@ -120,12 +125,23 @@ int pl_device_count(void);
 int pl_set_device(int device);      /* device used by the calling thread from now on */
 const char *pl_last_error(void);    /* thread-local description of the last failure */
 const char *pl_version(void);
+/* Layout version of the records in this header (bumped whenever a struct gains, loses or moves a field): 4 = round 4's
+ * pl_robust_options.min_fov, 5 = round 5 (pl_set_lm_mode takes a mode 0 / 1 / 2, records unchanged).  A binding - C++, ctypes, cgo -
+ * compares pl_abi_version() with the PL_ABI_VERSION it was written against before the first call that passes a record. */
+#define PL_ABI_VERSION 5
+int pl_abi_version(void);
 /* Summation order of the non-linear refinements (optim/jacobian_accumulator.h:82-97 adds correspondence after correspondence).
- * 0 (default): problems up to 256 correspondences are summed in the reference's order (refined models bit-identical), larger ones in
- * tree order (refined models 1e-13 off; the decisions were identical in every test and soak).  1: EVERY sum of every refinement in
- * the reference's order at every size (k_lm_ordered) - refined models bit-identical at every n at 1.3 - 2 x the refinement time (6 x for
- * homographies beyond 5000 correspondences).  Process-wide; also POSELIB_AMD_LM_ORDERED=1.  Returns the previous mode. */
-int pl_set_lm_mode(int ordered);
+ * 0 (default): poses and homographies - problems up to 256 correspondences are summed in the reference's order (refined models
+ *    bit-identical), larger ones in tree order (refined models 1e-13 off; the decisions were identical in every test and soak);
+ *    FUNDAMENTAL matrices - every sum in the reference's order at every size: FactorizedFundamentalMatrix (optim_utils.h:57-72)
+ *    enters each refinement through an SVD and negates U / V by their determinants, so the SIGN of the F that is returned is the
+ *    sign of a rounding-level singular value of the refinement's input - only bit-identical intermediate models give the
+ *    reference's sign (1.8 x the refinement time at 10^4 correspondences with the truncated loss, none with Cauchy's).
+ * 1: EVERY sum of every refinement in the reference's order at every size (k_lm_ordered) - refined models bit-identical at every
+ *    n at 1.3 - 2 x the refinement time (6 x for homographies beyond 5000 correspondences).
+ * 2: tree sums beyond 256 correspondences for every estimator, fundamental matrices included (their sign is then unpinned).
+ * Process-wide; also POSELIB_AMD_LM_ORDERED = 0 / 1 / 2.  Returns the previous mode. */
+int pl_set_lm_mode(int mode);
 
 /* ---- robust front-ends (robust.h) ---- */
 int pl_estimate_absolute_pose(const double *points2D, const double *points3D, size_t n, const pl_robust_options *opt,
@@ -186,7 +202,7 @@ int pl_ransac_relpose(const double *x1, const double *x2, size_t n, const pl_rob
 /* robust/ransac.h:71-73 ransac_shared_focal_relpose (SharedFocalRelativePoseEstimator, estimators/relative_pose.h:148-175; solver:
  * the 6-point shared-focal problem of solvers/relpose_6pt_focal.h): relative pose of two views of ONE camera with unknown focal
  * length; x1, x2 relative to the principal point.  pose / focal: the initial model when ransac.score_initial_model is set (otherwise
- * reset as in ransac.cc:185-190), the result on return.  PROSAC sampling: PL_ERR_UNSUPPORTED. */
+ * reset as in ransac.cc:185-190), the result on return.  PROSAC sampling (sampling.cc:85-136): samples drawn on the host, as for pl_ransac_pnpf. */
 int pl_ransac_shared_focal_relpose(const double *x1, const double *x2, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
                                    double *focal, uint8_t *inliers, pl_ransac_stats *stats);
 /* robust/bundle.h:108-111 refine_shared_focal_relpose (SharedFocalRelativePoseRefiner, optim/relative.h:488-592): pose and the

@@ -4,7 +4,8 @@
 // the reference's robust.cc, so every poselib::estimate_* call below lands in libposelib_amd.so.
 //
 //   robust_amd_check <in.bin> <out.bin>
-//     (kind 4: estimate_shared_focal_relative_pose, kind 5: estimate_absolute_pose with estimate_focal_length)
+//     (kind 4: estimate_shared_focal_relative_pose, kind 5: estimate_absolute_pose with estimate_focal_length,
+//      kind 6: ransac_pnpf on points relative to the principal point, AbsolutePoseOptions::min_fov = params[11])
 //     in : doubles [kind, n, seed, max_error, model_id, num_params, params[12], A (n x 2), B (n x 3 | n x 2)]
 //     out: doubles [iterations, refinements, num_inliers, model_score, model (7: q t | 9: column-major 3x3),
 //                   camera params[12] (kind 0), inliers (n)]
@@ -12,6 +13,7 @@
 // ctypes path bit for bit.  Built by integration/Makefile against the reference's headers (oracle/eigen_shim stands in
 // for Eigen, which this image lacks) where /root/reference exists; the binary travels to the GPU box.
 #include <PoseLib/robust.h>
+#include <PoseLib/robust/ransac.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -36,11 +38,13 @@ int main(int argc, char **argv) {
     std::fclose(f);
 
     const bool estimate_focal = (int)in[0] == 5;
-    const int kind = estimate_focal ? 0 : (int)in[0];
+    const bool pnpf = (int)in[0] == 6;
+    const int kind = (estimate_focal || pnpf) ? 0 : (int)in[0];
     const size_t n = (size_t)in[1];
     RansacOptions ransac;
     ransac.seed = (size_t)in[2];
     const double max_error = in[3];
+    const double min_fov = in[17]; // (kind 6 only)
     std::vector<double> cam_params(in.begin() + 6, in.begin() + 6 + (size_t)in[5]);
     const Camera camera((int)in[4], cam_params);
     const double *a = in.data() + 18, *b = a + 2 * n;
@@ -58,7 +62,20 @@ int main(int argc, char **argv) {
     RansacStats st;
     std::vector<double> model;
     std::vector<double> cam_out(12, 0.0);
-    if (kind == 0) {
+    if (pnpf) { // robust/ransac.h:52-54 with a non-default field-of-view bound (absolute_pose.h:78)
+        AbsolutePoseOptions opt;
+        opt.ransac = ransac;
+        opt.max_error = max_error;
+        opt.min_fov = min_fov;
+        Image image;
+        st = ransac_pnpf(x1, X, opt, &image, &inliers);
+        for (int i = 0; i < 4; ++i)
+            model.push_back(image.pose.q(i));
+        for (int i = 0; i < 3; ++i)
+            model.push_back(image.pose.t(i));
+        for (size_t i = 0; i < image.camera.params.size() && i < 12; ++i)
+            cam_out[i] = image.camera.params[i];
+    } else if (kind == 0) {
         AbsolutePoseOptions opt;
         opt.ransac = ransac;
         opt.max_error = max_error;

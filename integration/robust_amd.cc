@@ -210,7 +210,8 @@ RansacStats ransac_pnp(const std::vector<Point2D> &x, const std::vector<Point3D>
 // ransac.h:52-54
 RansacStats ransac_pnpf(const std::vector<Point2D> &x, const std::vector<Point3D> &X, const AbsolutePoseOptions &opt, Image *best_model,
                         std::vector<char> *best_inliers) {
-    const pl_robust_options o = to_pl(0, opt.ransac, opt.bundle, opt.max_error);
+    pl_robust_options o = to_pl(0, opt.ransac, opt.bundle, opt.max_error);
+    o.min_fov = opt.min_fov; // absolute_pose.h:78: FocalAbsolutePoseEstimator bounds f by compute_max_focal_length(opt.min_fov)
     pl_camera_pose pose = to_pl(best_model->pose);
     double focal = 1.0;
     pl_ransac_stats st;

@@ -3,6 +3,7 @@
 // same arithmetic as oracle/src/solvers_rel.cc and refine.cc.
 #ifndef ORACLE_EIGEN_SHIM_DECOMP
 #define ORACLE_EIGEN_SHIM_DECOMP
+#include "JacobiSVD3x3.h"
 
 namespace Eigen {
 
@@ -640,62 +641,21 @@ template <typename MatT> class EigenSolver {
     }
 };
 
-// 3x3 SVD by one-sided Jacobi (singular values descending); only the shape the reference needs
+// 3x3 SVD: Eigen's two-sided Jacobi iteration in Eigen's operation order (src/JacobiSVD3x3.h says why the order
+// matters: the sign of every LO-refined fundamental matrix hangs on it).  Only the shape the reference needs.
 template <typename MatT> class JacobiSVD {
   public:
     typedef typename MatT::Scalar T;
     JacobiSVD(const MatT &A, unsigned int = 0) {
-        MatT B = A;
-        V_.setIdentity();
-        for (int sweep = 0; sweep < 60; ++sweep) {
-            T off = T(0);
-            for (int p = 0; p < 2; ++p)
-                for (int q = p + 1; q < 3; ++q) {
-                    T alpha = 0, beta = 0, gamma = 0;
-                    for (int i = 0; i < 3; ++i) {
-                        alpha += B(i, p) * B(i, p);
-                        beta += B(i, q) * B(i, q);
-                        gamma += B(i, p) * B(i, q);
-                    }
-                    if (gamma == T(0))
-                        continue;
-                    off = std::max(off, std::abs(gamma) / std::sqrt(std::max(alpha * beta, T(1e-300))));
-                    const T zeta = (beta - alpha) / (T(2) * gamma);
-                    const T t = ((zeta >= 0) ? T(1) : T(-1)) / (std::abs(zeta) + std::sqrt(T(1) + zeta * zeta));
-                    const T c = T(1) / std::sqrt(T(1) + t * t), s = c * t;
-                    for (int i = 0; i < 3; ++i) {
-                        const T bp = B(i, p), bq = B(i, q);
-                        B(i, p) = c * bp - s * bq;
-                        B(i, q) = s * bp + c * bq;
-                        const T vp = V_(i, p), vq = V_(i, q);
-                        V_(i, p) = c * vp - s * vq;
-                        V_(i, q) = s * vp + c * vq;
-                    }
-                }
-            if (off < T(1e-15))
-                break;
-        }
-        int order[3] = {0, 1, 2};
-        T sv[3];
-        for (int j = 0; j < 3; ++j)
-            sv[j] = std::sqrt(B(0, j) * B(0, j) + B(1, j) * B(1, j) + B(2, j) * B(2, j));
-        std::sort(order, order + 3, [&](int a, int b) { return sv[a] > sv[b]; });
-        MatT Vs, Bs;
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) {
-                Vs(i, j) = V_(i, order[j]);
-                Bs(i, j) = B(i, order[j]);
-            }
-        V_ = Vs;
-        for (int j = 0; j < 3; ++j)
-            s_(j) = sv[order[j]];
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i)
-                U_(i, j) = (s_(j) > T(1e-14) * s_(0)) ? Bs(i, j) / s_(j) : T(0);
-        if (!(s_(2) > T(1e-14) * s_(0))) { // complete the basis
-            U_(0, 2) = U_(1, 0) * U_(2, 1) - U_(2, 0) * U_(1, 1);
-            U_(1, 2) = U_(2, 0) * U_(0, 1) - U_(0, 0) * U_(2, 1);
-            U_(2, 2) = U_(0, 0) * U_(1, 1) - U_(1, 0) * U_(0, 1);
+        T a[3][3], u[3][3], v[3][3], s[3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                a[i][j] = A(i, j);
+        eigen_shim_detail::jacobi_svd3(a, u, s, v);
+        for (int i = 0; i < 3; ++i) {
+            s_(i) = s[i];
+            for (int j = 0; j < 3; ++j)
+                U_(i, j) = u[i][j], V_(i, j) = v[i][j];
         }
     }
     const MatT &matrixU() const { return U_; }

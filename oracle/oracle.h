@@ -117,6 +117,7 @@ void orc_refine_relpose(const double *x1, const double *x2, size_t n, double *po
                         orc_bundle_stats *st);
 void orc_refine_homography(const double *x1, const double *x2, size_t n, double *H9, const orc_bundle_opt *opt,
                            orc_bundle_stats *st);
+void orc_svd3(const double *A9_rowmajor, double *U9, double *s3, double *V9);
 void orc_refine_fundamental(const double *x1, const double *x2, size_t n, double *F9, const orc_bundle_opt *opt,
                             orc_bundle_stats *st);
 

@@ -361,6 +361,18 @@ void orc_refine_fundamental(const double *x1, const double *x2, size_t n, double
     bstats_out(s, st);
 }
 
+// The SVD at the entry of the fundamental-matrix refinement (optim_utils.h:60), row-major 3x3 in and out.
+void orc_svd3(const double *A9, double *U9, double *s3, double *V9) {
+    M3 A, U, V;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            A.m[i][j] = A9[3 * i + j];
+    svd3(A, U, s3, V);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            U9[3 * i + j] = U.m[i][j], V9[3 * i + j] = V.m[i][j];
+}
+
 void orc_ransac_pnp(const double *x, const double *X, size_t n, const orc_robust_opt *opt, double *pose7,
                     uint8_t *inliers, orc_stats *st) {
     AbsolutePoseOptions o;

@@ -3,6 +3,8 @@
 
 #include "solvers.h"
 
+#include "../eigen_shim/Eigen/src/JacobiSVD3x3.h"
+
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -888,54 +890,12 @@ struct FundProblem { // optim/fundamental.h:41-121
 
 // ------------------------------------------------------------------------------------ SVD
 void svd3(const M3 &Ain, M3 &U, double s[3], M3 &V) {
-    // One-sided Jacobi on the columns of A: A V = B with orthogonal columns, sigma_i = |B_i|.
-    M3 B = Ain;
-    V = M3::identity();
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                const V3 bp = B.col(p), bq = B.col(q);
-                const double alpha = sqnorm(bp), beta = sqnorm(bq), gamma = dot(bp, bq);
-                if (gamma == 0.0)
-                    continue;
-                off = std::max(off, std::abs(gamma) / std::sqrt(std::max(alpha * beta, 1e-300)));
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = ((zeta >= 0) ? 1.0 : -1.0) / (std::abs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
-                B.set_col(p, c * bp - sn * bq);
-                B.set_col(q, sn * bp + c * bq);
-                const V3 vp = V.col(p), vq = V.col(q);
-                V.set_col(p, c * vp - sn * vq);
-                V.set_col(q, sn * vp + c * vq);
-            }
-        if (off < 1e-15)
-            break;
-    }
-    int order[3] = {0, 1, 2};
-    double sv[3] = {norm(B.col(0)), norm(B.col(1)), norm(B.col(2))};
-    std::sort(order, order + 3, [&](int a, int b) { return sv[a] > sv[b]; });
-    M3 Vs;
-    V3 u[3];
-    for (int i = 0; i < 3; ++i) {
-        s[i] = sv[order[i]];
-        Vs.set_col(i, V.col(order[i]));
-        u[i] = B.col(order[i]);
-    }
-    u[0] = u[0] / s[0];
-    if (s[1] > 1e-14 * s[0]) {
-        u[1] = u[1] / s[1];
-    } else { // rank <= 1: any unit vector orthogonal to u0
-        const V3 a = (std::abs(u[0].x) < 0.9) ? V3{1, 0, 0} : V3{0, 1, 0};
-        u[1] = normalized(cross(u[0], a));
-    }
-    if (s[2] > 1e-14 * s[0])
-        u[2] = u[2] / s[2];
-    else
-        u[2] = cross(u[0], u[1]);
-    for (int i = 0; i < 3; ++i)
-        U.set_col(i, u[i]);
-    V = Vs;
+    // Eigen::JacobiSVD<Matrix3d>(F, ComputeFullU | ComputeFullV) of optim_utils.h:60: the two-sided Jacobi iteration
+    // in Eigen's operation order - the same routine the shim's JacobiSVD (reference sources) runs; the sign of the
+    // refined F depends on it (JacobiSVD3x3.h).
+    double sv[3];
+    eigen_shim_detail::jacobi_svd3(Ain.m, U.m, sv, V.m);
+    s[0] = sv[0], s[1] = sv[1], s[2] = sv[2];
 }
 
 // ------------------------------------------------------------------------------------ entry points

@@ -688,29 +688,28 @@ int relpose_7pt(const V3 x1[7], const V3 x2[7], M3 F[3]) { // relpose_7pt.cc:10-
     householder_complement(A, 9, 2 + 5, nb);
     const double *n0 = nb, *n1 = nb + 9;
 
-    // det(x*F0 + F1) as a cubic in x, by polynomial arithmetic on the column-major 3x3
-    // (reference: expanded closed form :22-37).  Entry (i,j) <-> index 3*j + i.
-    auto ent = [&](int i, int j, UPoly &p) {
-        p.deg = 1;
-        p.c[0] = n1[3 * j + i];
-        p.c[1] = n0[3 * j + i];
-    };
-    UPoly e[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            ent(i, j, e[i][j]);
+    // det(x*F0 + F1) as a cubic in x (:22-37).  The reference spells the 48 monomials out in the lexicographic
+    // order of a computer-algebra expansion - factor 1 from matrix column 0 (vector entries 0..2), factor 2 from
+    // column 1 (3..5), factor 3 from column 2 (6..8), each with its null-vector index 0 (the x part) before 1 -
+    // every product evaluated left to right and every coefficient summed in that order.  The order is part of the
+    // result: the roots, hence F, hence the rounding-level det(F) that decides the sign of the refined F
+    // (eigen_shim/Eigen/src/JacobiSVD3x3.h) depend on the last bits of c3..c0.  Generated here by the loop nest
+    // that enumerates the same order.
     double c[4] = {0, 0, 0, 0};
-    auto add3 = [&](double sgn, const UPoly &a, const UPoly &b, const UPoly &d) {
-        const UPoly t = umul(umul(a, b), d);
-        for (int k = 0; k <= 3; ++k)
-            c[k] += sgn * t.c[k];
-    };
-    add3(+1, e[0][0], e[1][1], e[2][2]);
-    add3(-1, e[0][0], e[1][2], e[2][1]);
-    add3(-1, e[0][1], e[1][0], e[2][2]);
-    add3(+1, e[0][1], e[1][2], e[2][0]);
-    add3(+1, e[0][2], e[1][0], e[2][1]);
-    add3(-1, e[0][2], e[1][1], e[2][0]);
+    for (int ra = 0; ra < 3; ++ra)
+        for (int ka = 0; ka < 2; ++ka)
+            for (int rb = 0; rb < 3; ++rb) {
+                if (rb == ra)
+                    continue;
+                const int rc = 3 - ra - rb;
+                const bool even = (ra == 0 && rb == 1) || (ra == 1 && rb == 2) || (ra == 2 && rb == 0);
+                for (int kb = 0; kb < 2; ++kb)
+                    for (int kc = 0; kc < 2; ++kc) {
+                        const double t = nb[9 * ka + ra] * nb[9 * kb + 3 + rb] * nb[9 * kc + 6 + rc];
+                        const int deg = 3 - (ka + kb + kc);
+                        c[deg] = even ? c[deg] + t : c[deg] - t;
+                    }
+            }
 
     double roots[3];
     int nr;

@@ -103,6 +103,12 @@ def lib():
             raise PoseLibAmdError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import poselib_amd; poselib_amd.build()'` "
                 "(there is no CPU fallback)")
+        # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default; streams that share
+        # a queue run one after the other) and reads the variable at its first call.  The batch entry points keep 8 - 16
+        # streams in flight, so this binding - the application layer of a Python process - asks for 16 unless the user
+        # chose a value or opted out (POSELIB_AMD_KEEP_ENV=1).  The C library itself never touches the environment.
+        if not os.environ.get("POSELIB_AMD_KEEP_ENV"):
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         L = C.CDLL(LIB_PATH)
         _declare(L)
         _lib = L
@@ -124,6 +130,7 @@ def _declare(L):
         "pl_set_device": (cint, [cint]),
         "pl_last_error": (C.c_char_p, []),
         "pl_version": (C.c_char_p, []),
+        "pl_abi_version": (cint, []),
         "pl_estimate_absolute_pose": (cint, [vp, vp, sz, opt, cam, pose, vp, stats]),
         "pl_estimate_relative_pose": (cint, [vp, vp, sz, cam, cam, opt, pose, vp, stats]),
         "pl_estimate_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
@@ -164,6 +171,9 @@ def _declare(L):
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    # the ctypes mirrors of this module restate the records of include/poselib_amd.h at PL_ABI_VERSION 5
+    if L.pl_abi_version() != ABI_VERSION:
+        raise PoseLibAmdError(f"{LIB_PATH} has record layout version {L.pl_abi_version()}, this binding was written for {ABI_VERSION}: rebuild")
 
 
 def check(rc: int):
@@ -173,6 +183,7 @@ def check(rc: int):
     return rc
 
 
+ABI_VERSION = 5  # PL_ABI_VERSION of include/poselib_amd.h
 EXPORTED_SYMBOLS = [
     "pl_default_ransac_options", "pl_default_bundle_options", "pl_default_robust_options", "pl_device_count",
     "pl_set_device", "pl_last_error", "pl_version", "pl_estimate_absolute_pose", "pl_estimate_relative_pose",
@@ -181,4 +192,5 @@ EXPORTED_SYMBOLS = [
     "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
     "pl_ransac_batch", "pl_debug_device_math", "pl_ransac_pnpf", "pl_ransac_shared_focal_relpose", "pl_refine_shared_focal_relpose",
     "pl_estimate_shared_focal_relative_pose", "pl_solve_focal_batch", "pl_p35pf", "pl_relpose_6pt_shared_focal", "pl_set_lm_mode",
+    "pl_abi_version",
 ]

@@ -748,7 +748,9 @@ def set_device(i: int):
     L.check(L.lib().pl_set_device(int(i)))
 
 
-def set_lm_mode(ordered: bool) -> bool:
-    """Summation order of the non-linear refinements: False (default) = the reference's order up to 256 correspondences, tree order
-    beyond; True = the reference's order at every size (bit-identical refined models, slower).  Returns the previous mode."""
-    return bool(L.lib().pl_set_lm_mode(int(bool(ordered))))
+def set_lm_mode(mode) -> int:
+    """Summation order of the non-linear refinements.  0 / False (default): the reference's order up to 256 correspondences and
+    tree order beyond for poses and homographies, the reference's order at every size for fundamental matrices (the sign of a
+    refined F hangs on the bits of the refinement's input); 1 / True: the reference's order at every size for every estimator
+    (bit-identical refined models, slower); 2: tree order beyond 256 correspondences for every estimator.  Returns the previous mode."""
+    return int(L.lib().pl_set_lm_mode(int(mode)))

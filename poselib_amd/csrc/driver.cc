@@ -24,6 +24,7 @@
 #include "pl_solver_6ptf.h"
 #include "pl_solver_p35pf.h"
 #include "pl_sampler.h"
+#include "pl_svd3.h"
 
 #include <algorithm>
 #include <atomic>
@@ -201,10 +202,10 @@ int get_context(Context **out) {
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and kernels of streams
 // that share a queue run one after the other.  The batch entry points keep 8 ... 16 launch chains in flight, one stream each: with
 // the default, three of eight streams shared a queue and ran at half the rate of the two that had one to themselves
-// (profiles/r04_batch_chain_4_queues.md).  The variable is read when the runtime initialises, i.e. at the process's first HIP
-// call - so it is set (never overwritten) when this library is loaded.  A host application that initialised HIP earlier keeps
-// whatever it had; INTEGRATION.md says so.
-__attribute__((constructor)) static void default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// (profiles/r04_batch_chain_4_queues.md; pl_estimate_batch 59.8 k -> 68 k problems/s).  The variable is read when the runtime
+// initialises, i.e. at the process's first HIP call, and it belongs to the HOST APPLICATION: this library does not touch the
+// process environment (round 4 set it from a constructor).  poselib_amd/_lib.py (the Python binding), bench.py and
+// the reference-side binding's documentation set / recommend GPU_MAX_HW_QUEUES=16.
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -372,60 +373,6 @@ void params_from_record(int kind, const double *rec, double *params) {
         for (int i = 0; i < 9; ++i)
             params[i] = rec[kMatOff + i];
     }
-}
-
-// One-sided Jacobi SVD of a 3x3 (row-major), A = U diag(s) V^T, s descending.  Used once per
-// fundamental-matrix refinement to enter the Bartoli-Sturm factorisation
-// (PoseLib/robust/optim/optim_utils.h:57-72 uses Eigen::JacobiSVD).
-void svd3(const Mat3 &A, Mat3 &U, double s[3], Mat3 &V) {
-    Mat3 B = A;
-    for (int i = 0; i < 9; ++i)
-        V.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                const Vec3 bp = col(B, p), bq = col(B, q);
-                const double alpha = dot(bp, bp), beta = dot(bq, bq), gamma = dot(bp, bq);
-                if (gamma == 0.0)
-                    continue;
-                off = std::max(off, std::fabs(gamma) / std::sqrt(std::max(alpha * beta, 1e-300)));
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = ((zeta >= 0) ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
-                set_col(B, p, c * bp - sn * bq);
-                set_col(B, q, sn * bp + c * bq);
-                const Vec3 vp = col(V, p), vq = col(V, q);
-                set_col(V, p, c * vp - sn * vq);
-                set_col(V, q, sn * vp + c * vq);
-            }
-        if (off < 1e-15)
-            break;
-    }
-    int order[3] = {0, 1, 2};
-    double sv[3];
-    for (int i = 0; i < 3; ++i)
-        sv[i] = std::sqrt(dot(col(B, i), col(B, i)));
-    std::sort(order, order + 3, [&](int a, int b) { return sv[a] > sv[b]; });
-    Mat3 Vs;
-    Vec3 u[3];
-    for (int i = 0; i < 3; ++i) {
-        s[i] = sv[order[i]];
-        set_col(Vs, i, col(V, order[i]));
-        u[i] = col(B, order[i]);
-    }
-    u[0] = u[0] / s[0];
-    if (s[1] > 1e-14 * s[0])
-        u[1] = u[1] / s[1];
-    else
-        u[1] = normalized(cross(u[0], (std::fabs(u[0].x) < 0.9) ? v3(1, 0, 0) : v3(0, 1, 0)));
-    if (s[2] > 1e-14 * s[0])
-        u[2] = u[2] / s[2];
-    else
-        u[2] = cross(u[0], u[1]);
-    for (int i = 0; i < 3; ++i)
-        set_col(U, i, u[i]);
-    V = Vs;
 }
 
 // Parameter block that enters k_lm for a model given as record.
@@ -638,7 +585,7 @@ int run_refinements(Context *c, const pl_problem *p, std::vector<RefineJob> &job
         with_camera = with_camera || jobs[j].cam_flags != 0;
     if (with_camera && p->kind != EST_ABS)
         return fail(PL_ERR_INVALID, "camera intrinsics are refined with absolute poses only");
-    const bool use_lm2 = !with_camera && latency_mode && p->kind != EST_REL && same_it && max_it >= 1 && max_it <= 32 && p->n >= lm2_min_points;
+    const bool use_lm2 = !with_camera && latency_mode && p->kind != EST_REL && !lm_sums_ordered(p->kind) && same_it && max_it >= 1 && max_it <= 32 && p->n >= lm2_min_points;
     if (use_lm2)
         HIP_TRY(c->lm_tasks.ensure(stage_bytes));
     LMTask *ht = c->h_tasks.as<LMTask>();
@@ -1603,6 +1550,8 @@ int ransac_core(Context *c, const pl_problem *p, const pl_robust_options *o, dou
 int validate_options(const pl_robust_options *o, bool focal_entry = false) {
     if (!o)
         return fail(PL_ERR_INVALID, "options pointer is null");
+    if (o->min_fov != o->min_fov) // (a record shorter than this library's - built against an older header - reads garbage here)
+        return fail(PL_ERR_INVALID, "min_fov is NaN (options record not filled by pl_default_robust_options, or built against another PL_ABI_VERSION?)");
     // estimate_focal_length: pl_estimate_absolute_pose only (robust.cc:47-54 -> ransac_pnpf, driver_focal.inc)
     if (focal_entry && o->estimate_focal_length && !o->tangent_sampson && !o->estimate_extra_params)
         return PL_OK;
@@ -1952,6 +1901,7 @@ double normalization_of(const double *x1, const double *x2, size_t n, bool centr
 extern "C" {
 
 const char *pl_version(void) { return "poselib_amd 0.1 (gfx950)"; }
+int pl_abi_version(void) { return PL_ABI_VERSION; }
 const char *pl_last_error(void) { return g_err.c_str(); }
 
 void pl_default_ransac_options(pl_ransac_options *o) {
@@ -1987,9 +1937,9 @@ void pl_default_robust_options(pl_robust_options *o, int kind) {
     o->min_fov = 5.0; // types.h:126
 }
 
-int pl_set_lm_mode(int ordered) {
+int pl_set_lm_mode(int mode) {
     const int prev = pl::get_lm_mode();
-    pl::set_lm_mode(ordered);
+    pl::set_lm_mode(mode);
     return prev;
 }
 

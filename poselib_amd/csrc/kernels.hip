@@ -2994,25 +2994,35 @@ hipError_t launch_lm(int est, const PointSet &pts, LMTask *tasks, uint32_t num_t
     const size_t want = sizeof(double) * point_doubles(est) * (size_t)pts.n;
     return launch_lm_tasks(est, tasks, num_tasks, want <= 128 * 1024 ? pts.n : 0u, stream);
 }
-// 0: k_lm (tree sums beyond 256 correspondences), 1: k_lm_ordered (every sum in the reference's order); -1: not set yet
-// (POSELIB_AMD_LM_ORDERED decides at the first launch).  pl_set_lm_mode() in the C-ABI.
+// 0 (default): k_lm - tree sums beyond 256 correspondences - for poses and homographies, k_lm_ordered for FUNDAMENTAL
+//    matrices: every refinement of an F enters through an SVD whose third singular value is at rounding level, and the
+//    sign of the F that comes back hangs on that value's sign (pl_svd3.h) - the refined F that feeds the next refinement
+//    (local optimisation -> final refinement of the loop -> the front-end's bundle) has to carry the reference's BITS,
+//    not only its value to 1e-13, or the caller gets -F in half of the runs;
+// 1: k_lm_ordered for every estimator (every sum in the reference's order at every n);
+// 2: k_lm for every estimator (fastest; the sign of F is then unpinned above 256 correspondences);
+// -1: not set yet (POSELIB_AMD_LM_ORDERED = 0 / 1 / 2 decides at the first launch).  pl_set_lm_mode() in the C-ABI.
 static std::atomic<int> g_lm_mode{-1};
-void set_lm_mode(int ordered) { g_lm_mode.store(ordered ? 1 : 0, std::memory_order_release); }
+void set_lm_mode(int mode) { g_lm_mode.store((mode == 1 || mode == 2) ? mode : 0, std::memory_order_release); }
 int get_lm_mode() {
     int m = g_lm_mode.load(std::memory_order_acquire);
     if (m < 0) {
         const char *e = std::getenv("POSELIB_AMD_LM_ORDERED");
-        m = (e && e[0] && e[0] != '0') ? 1 : 0;
+        m = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 0;
         g_lm_mode.store(m, std::memory_order_release);
     }
     return m;
+}
+bool lm_sums_ordered(int est) {
+    const int m = get_lm_mode();
+    return m == 1 || (m == 0 && est == EST_FUND);
 }
 hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
     if (est < 0 || est > 3)
         return hipErrorInvalidValue;
-    const int ordered = get_lm_mode();
+    const int ordered = lm_sums_ordered(est) ? 1 : 0;
     // stage the points in LDS when they fit next to the kernel's static LDS (160 KB per CU, one workgroup per CU); tasks
     // of a mixed launch whose points do not fit the launch's dynamic LDS read them from L2
     // (a request the points do not fit into would only keep every other workgroup off the CU: no staging then)

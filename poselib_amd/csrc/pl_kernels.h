@@ -336,9 +336,12 @@ hipError_t launch_group_compact(const GroupArgs *args, const GroupDims &d, hipSt
 hipError_t launch_group_finalize_records(const GroupArgs *args, const GroupDims &d, hipStream_t stream);
 // LM over the tasks of many problems: every task carries its own correspondences (LMTask.pts)
 hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream);
-// k_lm (0: tree sums beyond 256 correspondences, the default) or k_lm_ordered (1: every sum in the reference's order at every n)
-void set_lm_mode(int ordered);
+// Summation order of the refinements.  0 (default): k_lm - reference order up to 256 correspondences, tree beyond - for poses and
+// homographies, k_lm_ordered for fundamental matrices (the sign of a refined F hangs on the bits of its input, pl_svd3.h);
+// 1: k_lm_ordered for every estimator; 2: k_lm for every estimator
+void set_lm_mode(int mode);
 int get_lm_mode();
+bool lm_sums_ordered(int est); // what launch_lm_tasks will pick for this estimator
 // absolute pose + camera intrinsics (lm_cam.hip): tasks with cam_flags != 0; refined pose -> params / record_out, camera -> cam
 hipError_t launch_lm_cam(LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
 int group_points_per_lane(int est); // P of the group launches (fixed per estimator)

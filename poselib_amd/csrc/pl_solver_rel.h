@@ -1039,26 +1039,33 @@ PL_HD int relpose_7pt(const Vec3 *x1, const Vec3 *x2, Mat3 *Fout) {
     double nb[18];
     complement_basis9_indexed<7>(A, nb);
     const double *n0 = nb, *n1 = nb + 9;
-    // det(x F0 + F1), entries (i,j) <-> vec index 3j+i; each entry = n1 + n0 x (ascending)
+    // det(x F0 + F1), entries (i,j) <-> vec index 3j+i.  relpose_7pt.cc:22-37 writes the 48 monomials in the
+    // lexicographic order of a symbolic expansion (factor 1 from vector entries 0..2, factor 2 from 3..5, factor 3
+    // from 6..8, null vector 0 - the x part - before null vector 1), products left to right, coefficients summed
+    // in that order.  The last bits of c3..c0 reach the roots, F, and through the rounding-level det(F) the SIGN
+    // of every refined F (pl_svd3.h), so the order is kept: this loop nest enumerates it.
     double c[4] = {0, 0, 0, 0};
-    const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
-    const double sgn[6] = {1, -1, -1, 1, 1, -1};
-    for (int t = 0; t < 6; ++t) {
-        const int e0 = 3 * perm[t][0] + 0, e1 = 3 * perm[t][1] + 1, e2 = 3 * perm[t][2] + 2;
-        const double a0 = n1[e0], a1 = n0[e0], b0 = n1[e1], b1 = n0[e1], d0 = n1[e2], d1 = n0[e2];
-        // (a0 + a1 x)(b0 + b1 x)
-        double q[3] = {0, 0, 0};
-        q[0] += a0 * b0;
-        q[1] += a0 * b1;
-        q[1] += a1 * b0;
-        q[2] += a1 * b1;
-        double p[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 3; ++i) {
-            p[i] += q[i] * d0;
-            p[i + 1] += q[i] * d1;
+    PL_UNROLL
+    for (int ra = 0; ra < 3; ++ra) {
+    PL_UNROLL
+        for (int ka = 0; ka < 2; ++ka) {
+    PL_UNROLL
+            for (int rb = 0; rb < 3; ++rb) {
+                if (rb == ra)
+                    continue;
+                const int rc = 3 - ra - rb;
+                const bool even = (ra == 0 && rb == 1) || (ra == 1 && rb == 2) || (ra == 2 && rb == 0);
+    PL_UNROLL
+                for (int kb = 0; kb < 2; ++kb) {
+    PL_UNROLL
+                    for (int kc = 0; kc < 2; ++kc) {
+                        const double t = nb[9 * ka + ra] * nb[9 * kb + 3 + rb] * nb[9 * kc + 6 + rc];
+                        const int deg = 3 - (ka + kb + kc);
+                        c[deg] = even ? c[deg] + t : c[deg] - t;
+                    }
+                }
+            }
         }
-        for (int k = 0; k < 4; ++k)
-            c[k] += sgn[t] * p[k];
     }
     double roots[3];
     int nr;

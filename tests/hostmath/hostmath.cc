@@ -17,6 +17,7 @@
 #include "../../poselib_amd/csrc/pl_solver_6ptf.h"
 #include "../../poselib_amd/csrc/pl_solver_p3p.h"
 #include "../../poselib_amd/csrc/pl_solver_rel.h"
+#include "../../poselib_amd/csrc/pl_svd3.h"
 
 #include <cmath>
 #include <cstdio>
@@ -1000,4 +1001,13 @@ extern "C" void hm_ransac_shared_focal(const double *const *pa, uint32_t n, uint
         mask[i] = sampson_sq(F, pa[0][i], pa[1][i], pa[2][i], pa[3][i]) < max_error * max_error ? 1 : 0;
     stats5[0] = st.refinements, stats5[1] = st.iterations, stats5[2] = st.num_inliers, stats5[3] = st.hypotheses, stats5[4] = st.iterations_evaluated;
     *model_score = st.model_score;
+}
+
+// The product's host-side SVD at the entry of the fundamental-matrix refinement (pl_svd3.h), row-major in and out.
+extern "C" void hm_svd3(const double *A9, double *U9, double *s3, double *V9) {
+    Mat3 A, U, V;
+    std::memcpy(A.m, A9, sizeof(A.m));
+    svd3(A, U, s3, V);
+    std::memcpy(U9, U.m, sizeof(U.m));
+    std::memcpy(V9, V.m, sizeof(V.m));
 }

@@ -35,7 +35,7 @@ def model_diff(kind, a, b):
             return max(dq, d_dir, d_len * (1e-6 / REL_DT_LEN_BOUND))
         return max(dq, np.abs(ta - tb).max())
     A, B = np.asarray(a) / np.linalg.norm(a), np.asarray(b) / np.linalg.norm(b)
-    return min(np.abs(A - B).max(), np.abs(A + B).max())
+    return np.abs(A - B).max()  # sign included
 
 
 def degrade(rng, d, keys):

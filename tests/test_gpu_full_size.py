@@ -43,7 +43,7 @@ def _model_diff(kind, got, ref):
         dr = np.linalg.norm(synth.quat_to_rotmat(g[:4]) - synth.quat_to_rotmat(ref[:4]))
         return max(dr, np.linalg.norm(g[4:] - ref[4:]))
     a, b = np.ravel(got) / np.linalg.norm(got), np.ravel(ref) / np.linalg.norm(ref)
-    return min(np.linalg.norm(a - b), np.linalg.norm(a + b))
+    return np.linalg.norm(a - b)  # sign included
 
 
 @pytest.mark.parametrize("name,kind,n,outl,err,dseed", FULL, ids=[f[0] for f in FULL])

@@ -130,6 +130,42 @@ print("RESULT " + json.dumps([[repr(float(v)) for v in T._flat(pr, m)] + [i["ite
     assert outs[0] == outs[1]
 
 
+def test_staged_points_survive_a_raised_high_water_mark(gpu):
+    """a worker stages its NEXT group's raw points into an alternate pinned block sized to the process-wide
+    high-water mark of that moment; if another worker raises the mark before the group runs, HostBuf::ensure re-allocates
+    the block and the staged points were lost (uninitialised memory uploaded, every problem of the group wrong, status OK).
+    POSELIB_AMD_DEBUG_RAISE_RAW_HW makes "another worker raised the mark" happen for EVERY staged group of a fresh process,
+    first calls included: the results must be those of the run without the hook, and the oracle's decisions."""
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import poselib_amd as P
+import test_gpu_group as T
+probs = T._problems(144, 35000, [{}])
+out = []
+for call in range(2):
+    res = P.estimate_batch(probs, max_in_flight=4)
+    out.append([[repr(float(v)) for v in T._flat(pr, m)] + [i["iterations"], i["num_inliers"]] for (m, i), pr in zip(res, probs)])
+assert out[0] == out[1]
+print("RESULT " + json.dumps(out[0]))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ({}, {"POSELIB_AMD_DEBUG_RAISE_RAW_HW": str(3 << 20)}):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, **extra), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1])
+    assert outs[0] == outs[1]
+    probs = _problems(144, 35000, [{}])
+    import json
+    got = json.loads(outs[1][len("RESULT "):])
+    for g, pr in list(zip(got, probs))[::7]:
+        ref = {"abs": O.estimate_absolute_pose, "rel": O.estimate_relative_pose, "hom": O.estimate_homography,
+               "fund": O.estimate_fundamental}[pr[0]](*pr[1:])
+        assert (g[-2], g[-1]) == (ref[2]["iterations"], ref[2]["num_inliers"]), (pr[0], len(pr[1]))
+
+
 # ---- pl_ransac_batch: device-resident problems in lock-step groups ------------------------------------------------------
 def _resident_set(gpu, base):
     """(Problem, options) pairs of all four kinds: default-length runs, long fixed-length runs (several batches of a group

@@ -457,3 +457,41 @@ def test_focal_loops_with_prosac_sampling_take_the_oracles_decisions():
         assert np.array_equal(hm, om) and np.array_equal(hp, op) and hf == of
     finally:
         HM.set_prosac(False)
+
+
+def test_entry_svd_of_the_fundamental_refinement_bit_exact():
+    """poselib_amd/csrc/pl_svd3.h (the product's host-side SVD in front of every fundamental-matrix refinement) against the
+    oracle's svd3 = the routine the reference sources run through the Eigen stand-in: U, singular values and V bit for bit,
+    on full-rank, rank-2 (the fundamental matrices of the path) and degenerate inputs; and the factors are an SVD."""
+    import ctypes as C
+
+    rs = np.random.RandomState(99)
+    ol, hl = O.lib(), HM.lib()
+
+    def run(lib, fn, A):
+        U, s, V = np.zeros(9), np.zeros(3), np.zeros(9)
+        getattr(lib, fn)(*(a.ctypes.data_as(C.c_void_p) for a in (A, U, s, V)))
+        return U.reshape(3, 3), s, V.reshape(3, 3)
+
+    cases = []
+    for i in range(3000):
+        A = rs.randn(3, 3) * 10.0 ** rs.uniform(-6, 6)
+        if i % 3 == 1:  # rank 2 up to rounding, like every F of the path
+            u, s, vt = np.linalg.svd(A)
+            A = (u[:, :2] * s[:2]) @ vt[:2]
+        elif i % 3 == 2:  # a normalised fundamental matrix [t]_x R
+            t = rs.randn(3)
+            q = rs.randn(4)
+            A = np.cross(np.eye(3), t) @ synth.quat_to_rotmat(q / np.linalg.norm(q))
+            A /= np.linalg.norm(A)
+        cases.append(np.ascontiguousarray(A).ravel())
+    cases += [np.zeros(9), np.eye(3).ravel(), np.diag([3.0, -2.0, 0.0]).ravel(), np.outer([1.0, 2, 3], [4.0, 5, 6]).ravel(),
+              np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]], dtype=np.float64).ravel(), np.full(9, 1e-310)]
+    for A in cases:
+        a, b = run(ol, "orc_svd3", A), run(hl, "hm_svd3", A)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        U, s, V = a
+        scale = max(np.abs(A).max(), 1e-300)
+        assert np.abs((U * s) @ V.T - A.reshape(3, 3)).max() <= 1e-13 * scale
+        assert s[0] >= s[1] >= s[2] >= 0
+        assert np.abs(U.T @ U - np.eye(3)).max() < 1e-13 and np.abs(V.T @ V - np.eye(3)).max() < 1e-13

@@ -48,7 +48,7 @@ def test_check_program_builds():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6])
 def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_path, kind):
     """A program written against the REFERENCE'S C++ API (std::vector<Eigen::Vector2d>, Image, Camera, CameraPose,
     *Options; robust.h:45-46, 68-70, 112-113, 133-134) and linked with integration/robust_amd.cc runs on the GPU and
@@ -59,9 +59,13 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
 
     assert os.path.exists(CHECK_BIN), "integration/_build/robust_amd_check was not built (python __graft_entry__.py)"
     seed = 3 + kind
-    if kind in (0, 5):
+    min_fov = 0.0
+    if kind in (0, 5, 6):
         d = synth.absolute_pose_scene(1500, 0.4, 4100)
         a, b, cam = d["p2d"], d["p3d"], d["camera"]
+        if kind == 6:  # ransac_pnpf: points relative to the principal point; a field-of-view bound ABOVE the camera's 53 degrees
+            a = a - np.asarray(cam["params"][1:3])  # (the binding dropped opt.min_fov - the bound must be seen to act)
+            min_fov = 90.0
         if kind == 5:  # estimate_focal_length: the camera's focal length is 20 % off, the estimator must not care
             cam = dict(cam, params=[1.2 * cam["params"][0]] + list(cam["params"][1:]))
     else:
@@ -69,9 +73,17 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
         d = gen(1500, 0.4, 4100 + kind)
         a, b = d["x1"], d["x2"]
         cam = d.get("camera1", {"model": "SIMPLE_PINHOLE", "params": [1000.0, 500.0, 500.0]})
-    max_error = 12.0 if kind in (0, 5) else 1.0
+    max_error = 12.0 if kind in (0, 5, 6) else 1.0
     opt = {"max_error": max_error, "ransac": {"seed": seed}}
-    if kind in (0, 5):
+    if kind == 6:
+        opt["min_fov"] = min_fov
+        img, info = gpu.ransac_pnpf(a, b, opt)
+        model = np.r_[img.pose.q, img.pose.t]
+        cam_out = list(img.camera.params)
+        _, info_default = gpu.ransac_pnpf(a, b, {"max_error": max_error, "ransac": {"seed": seed}})
+        assert info_default["num_inliers"] > 500  # the default bound (5 degrees) lets the true focal length through ...
+        assert info["num_inliers"] < info_default["num_inliers"]  # ... 90 degrees cuts it off: the option reaches the estimator
+    elif kind in (0, 5):
         if kind == 5:
             opt["estimate_focal_length"] = True
         img, info = gpu.estimate_absolute_pose(a, b, cam, opt)
@@ -92,6 +104,7 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
     n = a.shape[0]
     model_id = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "OPENCV": 4}[cam["model"]]
     params = list(cam["params"]) + [0.0] * (12 - len(cam["params"]))
+    params[11] = min_fov
     blob = np.r_[float(kind), float(n), float(seed), max_error, float(model_id), float(len(cam["params"])), params,
                  np.ascontiguousarray(a, dtype=np.float64).reshape(-1), np.ascontiguousarray(b, dtype=np.float64).reshape(-1)]
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
@@ -103,9 +116,9 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
     assert out[0] == info["iterations"] and out[1] == info["refinements"] and out[2] == info["num_inliers"]
     assert out[3] == info["model_score"]
     assert np.array_equal(out[4:4 + nm], model)  # bit for bit
-    if kind in (0, 4, 5):
+    if kind in (0, 4, 5, 6):
         assert np.array_equal(out[4 + nm:4 + nm + len(cam_out)], np.array(cam_out))
     if kind == 4:
         assert abs(cam_out[0] - cam["params"][0]) < 1e-2 * cam["params"][0]
     assert np.array_equal(out[4 + nm + 12:].astype(bool), np.array(info["inliers"]))
-    assert info["num_inliers"] > 500
+    assert info["num_inliers"] > 500 or kind == 6
