@@ -40,6 +40,8 @@
 #include "pl_device.h"
 #include "pl_solver_rel.h"
 
+#include <cstdlib>
+
 namespace pl {
 
 // ---- workspace ------------------------------------------------------------------------------------------------------
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(64) void k_rel_front_g(const GroupArgs *ga) {
 
 // ---- stage 2 --------------------------------------------------------------------------------------------------------
 struct SturmWorkDev { // deferred halves: one column per lane of [slot][64] LDS arrays; leaves: the workspace
+    static constexpr int kStackCap = kSturmSlots;
     double *sa, *sb;  // LDS
     unsigned *si;     // LDS
     double *leaves;   // global, [2 * slot + {0, 1}][P], this iteration's column
@@ -119,7 +122,7 @@ struct SturmWorkDev { // deferred halves: one column per lane of [slot][64] LDS 
     __device__ void leaf_set(int i, double a, double b) { leaves[(size_t)(2 * i) * P] = a, leaves[(size_t)(2 * i + 1) * P] = b; }
     __device__ void leaf_get(int i, double &a, double &b) const { a = leaves[(size_t)(2 * i) * P], b = leaves[(size_t)(2 * i + 1) * P]; }
 };
-__device__ __forceinline__ void rel_roots_body(uint32_t num_iters, const RelStage &w) {
+__device__ __forceinline__ void rel_roots_body_v1(uint32_t num_iters, const RelStage &w) {
     __shared__ double s_stack_a[kSturmSlots][64], s_stack_b[kSturmSlots][64];
     __shared__ unsigned s_stack_i[kSturmSlots][64];
     const uint32_t it = blockIdx.x * 64 + threadIdx.x;
@@ -135,13 +138,124 @@ __device__ __forceinline__ void rel_roots_body(uint32_t num_iters, const RelStag
     rel5_poly(Az, c);
     double roots[10];
     SturmWorkDev work{&s_stack_a[0][threadIdx.x], &s_stack_b[0][threadIdx.x], &s_stack_i[0][threadIdx.x], w.leaves + it, w.P};
+#if defined(PL_ROOTS_STOP) && PL_ROOTS_STOP == 3 // experiment builds (scripts/exp): time the stages of the kernel
+    {
+        Sturm10 S_;
+        double bound_;
+        int sa_, sb_;
+        w.nroots[it] = (uint32_t)sturm_prepare(c, S_, bound_, sa_, sb_);
+        return;
+    }
+    const int n = 0;
+#elif defined(PL_ROOTS_STOP) && PL_ROOTS_STOP == 4
+    w.nroots[it] = (uint32_t)(c[0] + c[5] + c[10] > 0);
+    return;
+    const int n = 0;
+#elif defined(PL_ROOTS_STOP) && PL_ROOTS_STOP == 1
+    unsigned tiny_;
+    const int n = sturm_isolate(c, work, tiny_);
+    w.nroots[it] = (uint32_t)n;
+    return;
+#else
     const int n = sturm_roots_deg10(c, roots, work);
+    w.nroots[it] = (uint32_t)n;
+#if defined(PL_ROOTS_STOP) && PL_ROOTS_STOP == 2
+    for (int r = 0; r < n; ++r)
+        w.roots[(size_t)r * w.P + it] = roots[r];
+    return;
+#endif
+    if (n == 0)
+        return;
+#endif
+    // back substitution and the essential matrix of every root (relpose_5pt.cc:355-392).  Two passes, so that the
+    // polynomial matrix (39 doubles) and the null-space basis (36) are never live together: the kernel keeps the
+    // register budget of the root finder.
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 13; ++k)
+            Az[i][k] = w.az[(size_t)(i * 13 + k) * w.P + it];
+    double xs[10], ys[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r)
+        if (r < n)
+            rel5_xy_at_root(Az, roots[r], xs[r], ys[r]);
+    double nb[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e)
+        nb[e] = w.nb[(size_t)e * w.P + it];
+#pragma unroll
+    for (int r = 0; r < 10; ++r)
+        if (r < n) {
+            Mat3 E;
+            rel5_essential_from_xyz(nb, xs[r], ys[r], roots[r], E);
+            double *oe = w.ess + (size_t)(9 * r) * w.P + it;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                oe[(size_t)k * w.P] = E.m[k];
+        }
+}
+__global__ __launch_bounds__(64) void k_rel_roots_v1(uint32_t num_iters, void *stage) { rel_roots_body_v1(num_iters, rel_stage(stage, num_iters)); }
+__global__ __launch_bounds__(64) void k_rel_roots_v1_g(const GroupArgs *ga) {
+    const GroupArgs &gg = ga[blockIdx.z];
+    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
+        return;
+    rel_roots_body_v1(gg.gen.num_iters, rel_stage(gg.gen.stage, gg.gen.num_iters));
+}
+
+// ---- stage 2, round 5 ---------------------------------------------------------------------------------------------------
+// Where the time of the round-4 kernel (k_rel_roots_v1, kept for A/B: POSELIB_AMD_REL_ROOTS_V1=1) went, measured on a
+// full device with builds that return after a stage (1.6 M iterations, profiles/r05_generator_roots_stages.md):
+// determinant polynomial + Sturm chain 147 us, ISOLATION 730 us, Ridders + Newton 635 us, back substitution + essential
+// matrices 271 us = 1783 us.  The isolation loop is not issue bound: 122 vector and 83 scalar instructions per round, 13
+// branches, an LDS round trip per pop - ~2000 SIMD cycles per round at two wavefronts per SIMD - and the recursion-shaped
+// loop spends a round on every VISIT (bisections, leaves, empty halves).  sturm_isolate_flat (pl_solver_rel.h) spends a
+// round only on a Sturm evaluation and is straight-line inside; the leaves come out of order and are ranked afterwards.
+// Also measured this round, and dropped (same checksums):
+//   * 256 iterations per workgroup, the LEAVES counting-sorted by bracket width and dealt to the lanes (the Ridders loop
+//     stops on the bracket's width: 7.2 steps on average, up to 30; host model 10.8 k -> 5.8 k instructions per 64
+//     iterations): the polish stage went 635 -> 480 us, but four wavefronts that wait for each other at barriers made
+//     the isolation stage 27 % slower (877 -> 1114 us): 1826 us in all;
+//   * in addition the ROOTS dealt to the lanes for the back substitution: a lane then gathers Az and the null-space basis
+//     of its root's iteration (75 loads over ~16 cache lines each): bound by the texture path, generator 3.56 -> 3.81 ms;
+//   * -amdgpu-sched-strategy=max-ilp for this file: 3.616 against 3.610 ms.
+struct SturmWorkFlat { // intervals to bisect and the leaves as found: one column per lane of LDS arrays; ordered leaves: workspace
+    static constexpr int kPendCap = 6, kLeafCap = kSturmSlots;
+    double *pa, *pb, *ua, *ub; // LDS
+    unsigned *pi;              // LDS
+    double *leaves;            // global, [2 * slot + {0, 1}][P], this iteration's column
+    size_t P;
+    __device__ void pend_push(int i, double a, double b, unsigned info) { pa[i * 64] = a, pb[i * 64] = b, pi[i * 64] = info; }
+    __device__ void pend_pop(int i, double &a, double &b, unsigned &info) const { a = pa[i * 64], b = pb[i * 64], info = pi[i * 64]; }
+    __device__ void uleaf_set(int i, double a, double b) { ua[i * 64] = a, ub[i * 64] = b; }
+    __device__ void uleaf_get(int i, double &a, double &b) const { a = ua[i * 64], b = ub[i * 64]; }
+    __device__ void leaf_set(int i, double a, double b) { leaves[(size_t)(2 * i) * P] = a, leaves[(size_t)(2 * i + 1) * P] = b; }
+    __device__ void leaf_get(int i, double &a, double &b) const { a = leaves[(size_t)(2 * i) * P], b = leaves[(size_t)(2 * i + 1) * P]; }
+};
+__device__ __forceinline__ void rel_roots_body(uint32_t num_iters, const RelStage &w) {
+    __shared__ double s_pend_a[SturmWorkFlat::kPendCap][64], s_pend_b[SturmWorkFlat::kPendCap][64];
+    __shared__ unsigned s_pend_i[SturmWorkFlat::kPendCap][64];
+    __shared__ double s_leaf_a[SturmWorkFlat::kLeafCap][64], s_leaf_b[SturmWorkFlat::kLeafCap][64];
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= num_iters)
+        return;
+    double Az[3][13];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 13; ++k)
+            Az[i][k] = w.az[(size_t)(i * 13 + k) * w.P + it];
+    double c[11];
+    rel5_poly(Az, c);
+    double roots[10];
+    SturmWorkFlat work{&s_pend_a[0][threadIdx.x], &s_pend_b[0][threadIdx.x], &s_leaf_a[0][threadIdx.x], &s_leaf_b[0][threadIdx.x],
+                       &s_pend_i[0][threadIdx.x], w.leaves + it, w.P};
+    const int n = sturm_roots_deg10_flat(c, roots, work);
     w.nroots[it] = (uint32_t)n;
     if (n == 0)
         return;
     // back substitution and the essential matrix of every root (relpose_5pt.cc:355-392).  Two passes, so that the
-    // polynomial matrix (39 doubles) and the null-space basis (36) are never live together: the kernel keeps the
-    // register budget of the root finder.
+    // polynomial matrix (39 doubles) and the null-space basis (36) are never live together.
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -287,16 +401,30 @@ __global__ __launch_bounds__(kPosesThreads) void k_rel_poses_g(const GroupArgs *
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
+// POSELIB_AMD_REL_ROOTS_V1=1 (diagnostic, A/B): the leaf-after-leaf root kernel of rounds 2 - 4; same bits
+static bool rel_roots_v1() {
+    static const bool v = [] {
+        const char *e = std::getenv("POSELIB_AMD_REL_ROOTS_V1");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
 hipError_t launch_generate_rel(const GenerateArgs &a, hipStream_t stream) {
     const uint32_t B = a.num_iters;
     k_rel_front<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(a);
-    k_rel_roots<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(B, a.stage);
+    if (rel_roots_v1())
+        k_rel_roots_v1<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(B, a.stage);
+    else
+        k_rel_roots<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(B, a.stage);
     k_rel_poses<<<dim3((B + kPosesThreads - 1) / kPosesThreads), dim3(kPosesThreads), 0, stream>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_group_generate_rel(const GroupArgs *args, uint32_t max_B, uint32_t G, hipStream_t stream) {
     k_rel_front_g<<<dim3((max_B + 63) / 64, 1, G), dim3(64), 0, stream>>>(args);
-    k_rel_roots_g<<<dim3((max_B + 63) / 64, 1, G), dim3(64), 0, stream>>>(args);
+    if (rel_roots_v1())
+        k_rel_roots_v1_g<<<dim3((max_B + 63) / 64, 1, G), dim3(64), 0, stream>>>(args);
+    else
+        k_rel_roots_g<<<dim3((max_B + 63) / 64, 1, G), dim3(64), 0, stream>>>(args);
     k_rel_poses_g<<<dim3((max_B + kPosesThreads - 1) / kPosesThreads, 1, G), dim3(kPosesThreads), 0, stream>>>(args);
     return hipGetLastError();
 }

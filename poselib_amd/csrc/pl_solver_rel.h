@@ -170,12 +170,20 @@ PL_HD void sturm_polish(const Sturm10 &S, double a, double b, double *roots, int
 // (kernels.hip), so that nothing of the root finder lives in scratch memory.
 constexpr int kSturmSlots = 12;
 struct SturmWorkLocal {
+    static constexpr int kStackCap = kSturmSlots; // deferred halves that can be alive (see sturm_isolate_chain)
     double sa[kSturmSlots], sb[kSturmSlots], la[kSturmSlots], lb[kSturmSlots];
     unsigned si[kSturmSlots];
     PL_HD void push(int i, double a, double b, unsigned info) { sa[i] = a, sb[i] = b, si[i] = info; }
     PL_HD void pop(int i, double &a, double &b, unsigned &info) const { a = sa[i], b = sb[i], info = si[i]; }
     PL_HD void leaf_set(int i, double a, double b) { la[i] = a, lb[i] = b; }
     PL_HD void leaf_get(int i, double &a, double &b) const { a = la[i], b = lb[i]; }
+    // flat isolation (sturm_isolate_flat): intervals to bisect share the stack arrays, leaves as found their own
+    static constexpr int kPendCap = kSturmSlots, kLeafCap = 16;
+    double ua[kLeafCap], ub[kLeafCap];
+    PL_HD void pend_push(int i, double a, double b, unsigned info) { push(i, a, b, info); }
+    PL_HD void pend_pop(int i, double &a, double &b, unsigned &info) const { pop(i, a, b, info); }
+    PL_HD void uleaf_set(int i, double a, double b) { ua[i] = a, ub[i] = b; }
+    PL_HD void uleaf_get(int i, double &a, double &b) const { a = ua[i], b = ub[i]; }
 };
 
 // Real roots of c[0] + c[1] z + ... + c[10] z^10, in the order the reference's recursion emits them (depth first,
@@ -241,7 +249,10 @@ template <class Work> PL_HD int sturm_isolate_chain(const Sturm10 &S, double bou
                 if (k > 1) {
                     const double mid = (a + b) * 0.5;
                     const int sm = sturm_variations(S, mid);
-                    if ((sm - sb >= 1 || b - mid < tol) && sp < kSturmSlots) { // right half (mid, b): later
+                    // (at most TEN deferred halves are ever alive: a half is deferred with >= 1 sign variation - at most 8 of
+                    // those next to the current interval's >= 2 - or as a narrow one, which happens at the bottom of a descent
+                    // and is popped right after the narrow left leaf; Work::kStackCap >= 10 therefore never drops one)
+                    if ((sm - sb >= 1 || b - mid < tol) && sp < Work::kStackCap) { // right half (mid, b): later
                         w.push(sp, mid, b, (unsigned)sm | ((unsigned)sb << 4) | ((unsigned)(depth + 1) << 8));
                         ++sp;
                     }
@@ -280,6 +291,77 @@ template <class Work> PL_HD int sturm_isolate(const double *coef, Work &w, unsig
     return sturm_isolate_chain(S, bound, sa0, sb0, w, tiny);
 }
 
+// phase 1, flat form (round 5; the batched generator): the same leaves from a loop whose EVERY round is one Sturm
+// evaluation.  The recursion visits an interval (narrow -> leaf; more than one sign variation -> bisect; exactly one ->
+// leaf; none -> nothing) and a visit costs nothing but comparisons - only the bisection evaluates the chain.  So the work
+// list holds just the intervals that still have to be bisected (each carries >= 2 roots: at most five are alive), a round
+// pops one, evaluates the chain at its midpoint and visits both halves at once (the right half under the reference's
+// condition: it holds a sign variation or is narrow).  The recursion's loop needed a round for every visit - bisections,
+// leaves, empty halves: about 3.3 per leaf on top of the evaluations - each with its own branches; here a wavefront runs
+// max-over-lanes(evaluations) rounds of straight-line code.  The leaves are found in a different ORDER (depth first,
+// left first = ascending interval order in the recursion); they are disjoint intervals, so their rank by left end
+// restores the recursion's order: sturm_rank_leaves.  Work: pend_push / pend_pop (intervals to bisect), uleaf_set /
+// uleaf_get (leaves as found), leaf_set (leaves in the recursion's order).
+template <class Work> PL_HD int sturm_isolate_flat(const Sturm10 &S, double bound, int sa0, int sb0, Work &w, unsigned &tiny_found) {
+    const double tol = 1e-10;
+    tiny_found = 0;
+    int np = 0, nl = 0;
+    auto visit = [&](double a, double b, int sa, int sb, int depth) {
+        if (depth > 300) // MAX_STURM_RECURSION_DEPTH_LIMIT
+            return;
+        const int k = sa - sb;
+        const bool narrow = b - a < tol;
+        if (narrow || k == 1) {
+            if (nl < Work::kLeafCap) {
+                w.uleaf_set(nl, a, b);
+                tiny_found |= narrow ? (1u << nl) : 0u;
+                ++nl;
+            }
+        } else if (k > 1 && np < Work::kPendCap) {
+            w.pend_push(np, a, b, (unsigned)sa | ((unsigned)sb << 4) | ((unsigned)depth << 8));
+            ++np;
+        }
+    };
+    visit(-bound, bound, sa0, sb0, 0);
+    while (np > 0) {
+        --np;
+        double a, b;
+        unsigned info;
+        w.pend_pop(np, a, b, info);
+        const int sa = (int)(info & 0xfu), sb = (int)((info >> 4) & 0xfu), depth = (int)(info >> 8);
+        const double mid = (a + b) * 0.5;
+        const int sm = sturm_variations(S, mid);
+        // (the right half first: it is pushed BELOW the left one, so the left subtree is bisected first like in the
+        // recursion - not needed for the result, but it keeps the list as short as the recursion's stack)
+        if (sm - sb >= 1 || b - mid < tol)
+            visit(mid, b, sm, sb, depth + 1);
+        visit(a, mid, sa, sm, depth + 1);
+    }
+    return nl;
+}
+// Leaves as found -> the recursion's order (ascending left end; the intervals are disjoint).  Keeps the first
+// kSturmSlots of them like the recursion's list; bit i of `tiny`: leaf i (in order) is narrower than tol.
+template <class Work> PL_HD int sturm_rank_leaves(int nl, unsigned tiny_found, Work &w, unsigned &tiny) {
+    tiny = 0;
+    int kept = 0;
+    for (int i = 0; i < nl; ++i) {
+        double ai, bi;
+        w.uleaf_get(i, ai, bi);
+        int rank = 0;
+        for (int j = 0; j < nl; ++j) {
+            double aj, bj;
+            w.uleaf_get(j, aj, bj);
+            rank += (aj < ai) ? 1 : 0;
+        }
+        if (rank < kSturmSlots) {
+            w.leaf_set(rank, ai, bi);
+            tiny |= ((tiny_found >> i) & 1u) << rank;
+            ++kept;
+        }
+    }
+    return kept;
+}
+
 // phase 2, one leaf: its root (the right end of a narrow leaf; Ridders + Newton on an isolating one, which reports
 // nothing when the end points do not bracket a sign change).  Returns the number of roots written (0 or 1).
 PL_HD int sturm_leaf_root(const Sturm10 &S, double la, double lb, bool is_tiny, double *root) {
@@ -312,6 +394,26 @@ template <class Work> PL_HD int sturm_roots_deg10(const double *coef, double *ro
 PL_HD int sturm_roots_deg10(const double *coef, double *roots) {
     SturmWorkLocal w;
     return sturm_roots_deg10(coef, roots, w);
+}
+// the same roots through the flat isolation (what the batched generator runs; tests compare the two bit for bit)
+template <class Work> PL_HD int sturm_roots_deg10_flat(const double *coef, double *roots, Work &w) {
+    constexpr int N = 10;
+    Sturm10 S;
+    double bound;
+    int sa0, sb0;
+    if (sturm_prepare(coef, S, bound, sa0, sb0) == 0)
+        return 0;
+    unsigned tiny_found, tiny;
+    const int nl = sturm_isolate_flat(S, bound, sa0, sb0, w, tiny_found);
+    const int nleaf = sturm_rank_leaves(nl, tiny_found, w, tiny);
+    int n = 0;
+    for (int i = 0; i < nleaf; ++i) {
+        double la, lb;
+        w.leaf_get(i, la, lb);
+        if (n < N)
+            n += sturm_leaf_root(S, la, lb, (tiny >> i) & 1u, roots + n);
+    }
+    return n;
 }
 
 // =============================================================================== null space

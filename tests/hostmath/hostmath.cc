@@ -256,6 +256,10 @@ int hm_relpose_6pt_shared_focal(const double *b1 /* 6 x 3 unit bearings */, cons
     return n;
 }
 int hm_sturm10(const double *coef, double *roots) { return sturm_roots_deg10(coef, roots); }
+int hm_sturm10_flat(const double *coef, double *roots) { // the batched generator's isolation (sturm_isolate_flat)
+    SturmWorkLocal w;
+    return sturm_roots_deg10_flat(coef, roots, w);
+}
 
 // Build a model record from (q,t) or a row-major 3x3, as the generate kernel stores it.
 void hm_pose_record(const double *q4, const double *t3, int essential, double *rec) {

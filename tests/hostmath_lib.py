@@ -92,10 +92,11 @@ def essential_5pt(x1, x2):
     return [out[i].reshape(3, 3).copy() for i in range(n)]
 
 
-def sturm10(coef):
+def sturm10(coef, flat=False):
+    """real roots of a degree-10 polynomial; flat=True: through the batched generator's isolation (sturm_isolate_flat)"""
     c = np.ascontiguousarray(coef, dtype=np.float64)
     out = np.zeros(10)
-    n = lib().hm_sturm10(_p(c), _p(out))
+    n = (lib().hm_sturm10_flat if flat else lib().hm_sturm10)(_p(c), _p(out))
     return out[:n]
 
 
