@@ -2819,7 +2819,11 @@ static void score_shape(int est, uint32_t n, bool streaming, bool mfma, uint32_t
     if (streaming && mfma && (est == EST_REL || est == EST_FUND)) {
         // k_score_mfma2: PG = 2 P groups of 32 correspondences per chunk; relative pose keeps the bearings in LDS as
         // well and stops at 320 correspondences per workgroup (two workgroups per CU)
-        const uint32_t per_chunk_max = lanes * (est == EST_REL ? 5u : 6u);
+        static const uint32_t m2p = [] { // POSELIB_AMD_M2_P (experiment): point groups of 64 per chunk of the Sampson matrix-core scorer
+            const char *e = std::getenv("POSELIB_AMD_M2_P");
+            return e ? (uint32_t)std::max(1, std::min(6, std::atoi(e))) : 0u;
+        }();
+        const uint32_t per_chunk_max = lanes * (m2p ? std::min<uint32_t>(m2p, est == EST_REL ? 5u : 6u) : (est == EST_REL ? 5u : 6u));
         chunks = std::max<uint32_t>(1u, (n + per_chunk_max - 1) / per_chunk_max);
         P = std::max<int>(1, (int)((n + lanes * chunks - 1) / (lanes * chunks)));
         return;
