@@ -93,7 +93,8 @@ def kernel_issue_cycles(kernel_name, per_hc):
         total = loop_cycles + rest_valu * price(rest) / max(1, rest["valu"])
         return total / per_hc, "tile loop counted exactly (%.1f of %.1f instructions per hypothesis and chunk), the rest at the static mix outside the loop" % (loop_valu, per_hc)
     return (price(whole) + whole["mfma"] * cyc["mfma_issue"]) / max(1, whole["valu"]), "whole-kernel static mix"
-PARITY_SEEDS = 8
+PARITY_SEEDS = 64   # problems of the first timed step checked against the oracle (seed j on scene j; VERDICT r4: 8 was 0.03 % of a step)
+BASELINE_SEEDS = 8  # of those, the runs that are timed as the CPU baseline (oracle and reference sources: ~12 core-seconds each)
 POSE_TOL = 1e-6
 # workload -> (kind, N, outlier ratio, max_error [px], data seed, bytes per correspondence, problems per step and
 #              in-flight stream, description)
@@ -433,7 +434,10 @@ def report_workload(name, table, ctx, args, world):
     traffic = pmc.get("traffic_bytes_per_launch")
     roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST_S,
             "peak_basis": f"{SIMDS} SIMDs x {PEAK_CLOCK_GHZ} GHz / 4 cycles per wave64 VALU instruction",
-            "kernel": kernel_name, "launches": k_launch,
+            # the timed region runs the GROUP form of the kernel (blockIdx.z = problem of the group, same body); `achieved` /
+            # `frac` are priced on the solo launches of the single-problem form measured right before the timed region
+            "kernel": (kernel_name.replace("<", "_g<", 1) if ctx["grouped"] else kernel_name), "solo_kernel": kernel_name,
+            "launches": k_launch,
             "launches_in_flight": ctx["T"] if ctx["grouped"] else ctx["S"],
             "avg_launch_ms": 1e3 * avg_launch_s, "solo_avg_launch_ms": 1e3 * solo_launch_s,
             "hypotheses_per_launch": hyp_per_launch,
@@ -492,33 +496,34 @@ def report_workload(name, table, ctx, args, world):
         out["parity"] = parity_block(kind, ctx["first"], cpu_out)
         ok = out["parity"]["ok"]
         if world == 1 and not args.no_cpu_baseline:
-            hyp_c = sum(c[2]["hypotheses"] for c in cpu_out)
-            sec_c = sum(c[2]["seconds"] for c in cpu_out)
+            cpu_base = cpu_out[:BASELINE_SEEDS]
+            hyp_c = sum(c[2]["hypotheses"] for c in cpu_base)
+            sec_c = sum(c[2]["seconds"] for c in cpu_base)
             port = {"value": hyp_c / sec_c, "unit": "hypotheses/s", "cores": 1, "kind": "port",
-                    "sample_short": f"oracle {fn_name}, seeds 0..{PARITY_SEEDS - 1}, {ITERATIONS} it each, {hyp_c} hyp, "
+                    "sample_short": f"oracle {fn_name}, seeds 0..{BASELINE_SEEDS - 1}, {ITERATIONS} it each, {hyp_c} hyp, "
                                     f"{sec_c:.1f} core-s, rate per core",
-                    "sample": f"oracle {fn_name}, RANSAC seeds 0..{PARITY_SEEDS - 1} of the same workload ({ITERATIONS} "
+                    "sample": f"oracle {fn_name}, RANSAC seeds 0..{BASELINE_SEEDS - 1} of the same workload ({ITERATIONS} "
                               f"iterations each, {hyp_c} hypotheses, {sec_c:.1f} core-seconds; {workers} problems at a "
                               f"time on separate cores, {wall:.1f} s wall), g++ -O3 no -march, rate per core, "
                               f"{os.cpu_count()} host cores"}
             base = port
             if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libposelib_ref.so")):
                 try:
-                    ref_out, rwall, rworkers, _ = cpu_runs(kind, ctx["parity_scenes"], ctx["thr"], ITERATIONS, PARITY_SEEDS, True)
+                    ref_out, rwall, rworkers, _ = cpu_runs(kind, ctx["parity_scenes"], ctx["thr"], ITERATIONS, BASELINE_SEEDS, True)
                     # (ransac_* does not report its model count; the oracle's run of the same seed counts the same
                     # sample stream and agrees in iterations / inliers / mask, see agrees_with_port)
                     hyp_r = hyp_c
                     sec_r = sum(c[2]["seconds"] for c in ref_out)
                     same = sum(int(r[2]["iterations"] == c[2]["iterations"] and r[2]["num_inliers"] == c[2]["num_inliers"]
-                                   and bool((r[1] == c[1]).all())) for r, c in zip(ref_out, cpu_out))
+                                   and bool((r[1] == c[1]).all())) for r, c in zip(ref_out, cpu_base))
                     base = {"value": hyp_r / sec_r, "unit": "hypotheses/s", "cores": 1, "kind": "reference",
                             "sample_short": f"oracle/_ref (reference sources, g++ -O3, eigen shim) {fn_name}, seeds 0.."
-                                            f"{PARITY_SEEDS - 1}, {ITERATIONS} it each, {hyp_r} hyp, {sec_r:.1f} core-s, "
+                                            f"{BASELINE_SEEDS - 1}, {ITERATIONS} it each, {hyp_r} hyp, {sec_r:.1f} core-s, "
                                             f"rate per core; {same}/{len(ref_out)} runs = port",
                             "sample": f"oracle/_ref/libposelib_ref.so = the reference's own sources (robust/ransac.cc, "
                                       f"ransac_impl.h, estimators, solvers, utils.cc, bundle.cc, ...) compiled in place "
                                       f"against oracle/eigen_shim (real Eigen is not in this image): {fn_name}, RANSAC "
-                                      f"seeds 0..{PARITY_SEEDS - 1} of the same workload ({ITERATIONS} iterations each, "
+                                      f"seeds 0..{BASELINE_SEEDS - 1} of the same workload ({ITERATIONS} iterations each, "
                                       f"{hyp_r} hypotheses as counted by the oracle's runs of the same seeds, {sec_r:.1f} core-seconds; {rworkers} problems at a time on "
                                       f"separate cores, {rwall:.1f} s wall), g++ -O3 (the reference's Release flags, CMakeLists.txt:18-33), rate per core, {os.cpu_count()} host cores",
                             "agrees_with_port": f"{same}/{len(ref_out)} runs identical in iterations / inliers / mask",
@@ -536,8 +541,11 @@ def run_batch_mixed(args, ranks, P, synth):
     front-end-inclusive).  Problem i of the global batch lives on rank i mod world (sharding.owned)."""
     from poselib_amd import sharding
 
-    per_rank = args.batch_problems
-    total = per_rank * ranks.world
+    # two ways to size the global batch: --batch-total T (BASELINE configs[4] as worded: 4096 problems SHARDED over the
+    # N ranks - strong scaling, rank r gets the problems i = r mod N, 512 each at N = 8) or --batch-problems per rank
+    # (weak scaling: the default of the N = 1 line, where both mean 4096 problems per call)
+    total = args.batch_total if args.batch_total > 0 else args.batch_problems * ranks.world
+    per_rank = (total + ranks.world - 1) // ranks.world
     mine = sharding.owned(total, ranks.rank, ranks.world)
     kinds = ("abs", "rel", "hom")
     problems = {}
@@ -568,6 +576,18 @@ def run_batch_mixed(args, ranks, P, synth):
     ranks.barrier()
     elapsed = time.perf_counter() - t0
     hyp = args.steps * int(batch.stats()[2].sum())  # every step runs the same problems with the same seeds: the same hypotheses
+    # what ONE of eight ranks sees when 4096 problems are sharded over a node: 512 problems per call (the first 512 of this
+    # rank's list; N = 1 line only - VERDICT r4 next 4)
+    small = None
+    if ranks.world == 1 and len(mine) > 512:
+        b512 = P.Batch([problems[i] for i in mine[:512]])
+        for _ in range(max(3, args.warmup)):
+            b512.run(max_in_flight=args.batch_threads)
+        ts = time.perf_counter()
+        reps512 = 4 * args.steps
+        for _ in range(reps512):
+            b512.run(max_in_flight=args.batch_threads)
+        small = 512.0 * reps512 / (time.perf_counter() - ts)
     table = ranks.gather([elapsed, float(hyp), float(len(mine))])
     if ranks.rank != 0:
         return None, True
@@ -577,7 +597,10 @@ def run_batch_mixed(args, ranks, P, synth):
            "problem": "BASELINE configs[4]: P3P / 5-point / homography cycling, N in [500,5000], 30-70 % outliers, default "
                       "options, host-resident inputs (PCIe- and front-end-inclusive), one pl_estimate_batch call per step",
            "problems_per_gpu_per_step": per_rank, "host_threads_per_gpu": args.batch_threads, "timed_region_s": t_max,
+           "global_batch": total, "batch_scaling": "strong (--batch-total)" if args.batch_total > 0 else "weak (--batch-problems per rank)",
            "sharding": "problem i on rank i mod world; RCCL for the barrier and the final gather only"}
+    if small is not None:
+        out["problems_per_s_at_512_per_call"] = small
     ok = True
     if not args.no_parity:  # a sample of rank 0's problems against the oracle's front-ends
         from concurrent.futures import ThreadPoolExecutor
@@ -883,6 +906,9 @@ def main():
     ap.add_argument("--batch-problems", type=int, default=4096,
                     help="configs[4] leg (\"batch of 4096 independent image pairs\"): problems per GPU and step of the mixed "
                          "default-options batch (0: skip)")
+    ap.add_argument("--batch-total", type=int, default=0,
+                    help="BASELINE configs[4] as worded: this many problems in all, sharded over the ranks (problem i on rank i mod N; "
+                         "strong scaling).  0 (default): --batch-problems per rank (weak scaling)")
     ap.add_argument("--batch-threads", type=int, default=10, help="host threads inside pl_estimate_batch (8 - 12 measure alike)")
     ap.add_argument("--detail-file", default="", help="complete per-workload reports (default gpurun_out/bench_detail.json)")
     ap.add_argument("--rehearse-distributed", action="store_true",
@@ -985,6 +1011,10 @@ def main():
                 cfg["opencv_undistort_parity_ok"] = r.get("parity", {}).get("ok")
             elif n == "batch_mixed":
                 cfg["batch_mixed_problems_per_s"] = r["problems_per_s"]
+                cfg["batch_mixed_global_batch"] = r["global_batch"]
+                cfg["batch_mixed_scaling"] = r["batch_scaling"]
+                if "problems_per_s_at_512_per_call" in r:  # what one of eight ranks sees of a 4096-problem batch
+                    cfg["batch_mixed_512_problems_per_s"] = r["problems_per_s_at_512_per_call"]
                 cfg["batch_mixed_hyp_per_s"] = r["value"]
                 cfg["batch_mixed_parity_ok"] = r.get("parity", {}).get("ok")
                 if "cpu_baseline" in r:

@@ -124,3 +124,18 @@ def test_thread_allgather():
     for t in ts:
         t.join(timeout=60)
     assert all(g is not None for g in got)
+
+
+def test_configs4_strong_split_of_4096_problems_over_a_node():
+    """BASELINE configs[4] as worded (bench.py --batch-total 4096): ONE batch of 4096 problems sharded over the N ranks of a
+    node, problem i on rank i mod N - every problem on exactly one rank, 512 per rank at N = 8, and the three problem kinds of
+    the mix (i mod 3) evenly on every rank."""
+    from poselib_amd import sharding
+
+    for world in (1, 2, 4, 8):
+        parts = [sharding.owned(4096, r, world) for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(4096))
+        assert all(len(p) == 4096 // world for p in parts)
+        for p in parts:
+            kinds = [sum(1 for i in p if i % 3 == k) for k in range(3)]
+            assert max(kinds) - min(kinds) <= 1
