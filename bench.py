@@ -588,6 +588,26 @@ def run_batch_mixed(args, ranks, P, synth):
         for _ in range(reps512):
             b512.run(max_in_flight=args.batch_threads)
         small = 512.0 * reps512 / (time.perf_counter() - ts)
+        # ... and the same shard size with FOUR calls in flight from four host threads (pl_estimate_batch is re-entrant and leases
+        # one of its worker pools per call since round 5): a rank that works through a stream of 512-problem shards
+        import threading
+
+        kf = 4
+        shards = [P.Batch([problems[i] for i in mine[j * 512:(j + 1) * 512]]) for j in range(kf) if len(mine) >= (j + 1) * 512]
+        small_inflight = None
+        if len(shards) == kf:
+            wk = max(2, args.batch_threads * 2 // 5)
+
+            def spin(b, reps):
+                for _ in range(reps):
+                    b.run(max_in_flight=wk)
+
+            for reps in (4, reps512):  # (an untimed round first: every pool's workers grow their arenas)
+                ts = time.perf_counter()
+                th = [threading.Thread(target=spin, args=(b, reps)) for b in shards]
+                [t.start() for t in th]
+                [t.join() for t in th]
+                small_inflight = 512.0 * kf * reps / (time.perf_counter() - ts)
     table = ranks.gather([elapsed, float(hyp), float(len(mine))])
     if ranks.rank != 0:
         return None, True
@@ -601,6 +621,8 @@ def run_batch_mixed(args, ranks, P, synth):
            "sharding": "problem i on rank i mod world; RCCL for the barrier and the final gather only"}
     if small is not None:
         out["problems_per_s_at_512_per_call"] = small
+        if small_inflight is not None:
+            out["problems_per_s_at_512_per_call_4_calls_in_flight"] = small_inflight
     ok = True
     if not args.no_parity:  # a sample of rank 0's problems against the oracle's front-ends
         from concurrent.futures import ThreadPoolExecutor
@@ -1015,6 +1037,8 @@ def main():
                 cfg["batch_mixed_scaling"] = r["batch_scaling"]
                 if "problems_per_s_at_512_per_call" in r:  # what one of eight ranks sees of a 4096-problem batch
                     cfg["batch_mixed_512_problems_per_s"] = r["problems_per_s_at_512_per_call"]
+                    if "problems_per_s_at_512_per_call_4_calls_in_flight" in r:
+                        cfg["batch_mixed_512_x4_in_flight_problems_per_s"] = r["problems_per_s_at_512_per_call_4_calls_in_flight"]
                 cfg["batch_mixed_hyp_per_s"] = r["value"]
                 cfg["batch_mixed_parity_ok"] = r.get("parity", {}).get("ok")
                 if "cpu_baseline" in r:

@@ -2868,10 +2868,9 @@ struct BatchPool {
             }
         }
     }
+    // (the caller holds run_mu through a PoolLease: `mu` alone is not enough - done.wait() releases it, and a second caller would
+    // overwrite the job state while the first batch's workers are still running)
     int run(std::vector<std::function<void()>> &js, int in_flight, int dev, std::vector<std::function<void()>> *stage_fns = nullptr) {
-        // `mu` alone is not enough: done.wait() releases it, and a second caller would overwrite the job state while
-        // the first batch's workers are still running
-        std::lock_guard<std::mutex> one_batch(run_mu);
         std::unique_lock<std::mutex> lk(mu);
         while ((int)threads.size() < in_flight) {
             threads.emplace_back([this] { worker(); });
@@ -2890,9 +2889,25 @@ struct BatchPool {
         return PL_OK;
     }
 };
-static BatchPool &batch_pool_instance() {
-    static BatchPool *pool = new BatchPool(); // never destroyed: its detached workers may outlive static destructors
-    return *pool;
+// A batch call leases one of kBatchPools worker pools for its whole duration (both rounds of pl_estimate_batch).  Round 4 had ONE pool and
+// one batch at a time per process; a call of a few hundred problems is a handful of launch chains whose length is latency (512 problems:
+// 11 ms against 51 ms for 4096: 57 % of the large call's rate), and a caller that has several such batches - the ranks of a node working
+// through a stream of 512-problem shards - can now keep two or three calls in flight from as many host threads: their chains interleave on
+// the device.  Every pool has its own persistent workers (thread-local contexts and arenas); a caller takes the first free pool and waits
+// for pool 0 when all are busy.
+constexpr int kBatchPools = 4;
+struct PoolLease {
+    BatchPool *pool;
+    std::unique_lock<std::mutex> held;
+};
+static PoolLease lease_batch_pool() {
+    static BatchPool *pools = new BatchPool[kBatchPools]; // never destroyed: the detached workers may outlive static destructors
+    for (int i = 0; i < kBatchPools; ++i) {
+        std::unique_lock<std::mutex> lk(pools[i].run_mu, std::try_to_lock);
+        if (lk.owns_lock())
+            return PoolLease{&pools[i], std::move(lk)};
+    }
+    return PoolLease{&pools[0], std::unique_lock<std::mutex>(pools[0].run_mu)};
 }
 
 int run_item(pl_batch_item &it) {
@@ -3025,7 +3040,10 @@ int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int 
     w = (int)std::min<size_t>((size_t)w, jobs.size());
     (void)take_worker_error();
     g_group_workers.store(std::max(w, 1));
-    batch_pool_instance().run(jobs, w, g_requested_device);
+    {
+        PoolLease lease = lease_batch_pool();
+        lease.pool->run(jobs, w, g_requested_device);
+    }
     const std::string werr = take_worker_error();
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
@@ -3144,7 +3162,8 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     const double t_pool = now_s();
     if (g_group_timing)
         g_t_wait_ns = g_t_group_ns = g_t_prep_ns = g_t_fallback_ns = g_n_waits = g_n_fallback = 0, g_t_stageA = g_t_args = g_t_imp = g_t_lmtasks = g_t_replay = g_t_tail = 0;
-    batch_pool_instance().run(jobs, w, g_requested_device, &stage_fns);
+    PoolLease lease = lease_batch_pool();
+    lease.pool->run(jobs, w, g_requested_device, &stage_fns);
     // ---- second round: the problems that were still running when their group's step budget ended (the long runs: 5-point problems
     // with 60 - 70 % outliers need ~10^4 iterations), regrouped by kind, every step as large as the loop is known to need ----
     {
@@ -3168,7 +3187,7 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
             }
             const int w2 = (int)std::min<size_t>((size_t)w, late_jobs.size());
             g_group_workers.store(std::max(w2, 1));
-            batch_pool_instance().run(late_jobs, w2, g_requested_device);
+            lease.pool->run(late_jobs, w2, g_requested_device);
         }
         for (auto &grp : groups)
             for (GroupItem &g : grp) {
