@@ -1658,13 +1658,39 @@ template <int N> struct BlockReduce {
     __device__ static void run(const double *v, uint32_t cnt, double (*scratch)[N + 1], double *out,
                                uint32_t *count_out) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // Round 5 (cycle counters, scripts/lm_profile.py): this was 43 % of an LM iteration of a small problem - 10.8 k cycles for
+        // the 28 values of a pose, 16.2 k for the 45 of a homography: written value by value (reduce, then a lane-0 store) the
+        // stores' EXEC changes kept the N dependent DPP chains (6 steps of two cross-lane moves and an addition, ~400 cycles
+        // each) from overlapping.  Now step by step over all values - the same operations on every value, so the same bits -
+        // with the N chains independent inside a step, and ONE lane-0 block of stores at the end.
+        double s[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const double s = wave_sum_dpp(v[i]);
-            if (lane == 0)
-                scratch[wave][i] = s;
-        }
+        for (int i = 0; i < N; ++i)
+            s[i] = v[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            s[i] += dpp_move<0xB1>(s[i]); // quad_perm [1,0,3,2]
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            s[i] += dpp_move<0x4E>(s[i]); // quad_perm [2,3,0,1]
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            s[i] += dpp_move<0x141>(s[i]); // row_half_mirror
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            s[i] += dpp_move<0x140>(s[i]); // row_mirror
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            s[i] += dpp_move<0x142, 0xa>(s[i]); // row_bcast:15 into rows 1 and 3
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            s[i] += dpp_move<0x143, 0xc>(s[i]); // row_bcast:31 into rows 2 and 3: lane 63 holds the total (wave_sum_dpp)
         const uint32_t c = wave_sum_u32(cnt);
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                scratch[wave][i] = s[i];
+        }
         if (lane == 0)
             scratch[wave][N] = (double)c;
         __syncthreads();
@@ -1681,9 +1707,124 @@ template <int N> struct BlockReduce {
     }
 };
 
+// ---- the block reduction of k_lm, transposed (round 5) --------------------------------------------------------------------
+// Cycle counters (scripts/lm_profile.py, profiles/r05_lm_profile.md): BlockReduce above was 43 % of an LM iteration of a small
+// problem - 10.8 k cycles for the 28 sums of a pose, 16.2 k for the 46 of a homography - because every lane carries EVERY sum through
+// all six butterfly steps (28 x 6 x 5 instructions), although only one lane's result is used.  Here a butterfly step HALVES the list
+// a lane carries: lanes whose step bit is 0 keep the first half of the current list, lanes whose bit is 1 the second half, and each
+// sends the other half to its partner (lane ^ 1, ^ 2, ^ 4, ^ 8 - quad_perm and banked row shifts): 28 -> 14 -> 7 -> 4 -> 2 values
+// per lane after the four steps inside a row of 16 lanes, 27 exchanged pairs instead of 112.  The row sums go to LDS, and the
+// thread that owns a sum adds its four rows as the butterfly's last two steps would - (R3 + R2) + (R1 + R0) - and then the
+// wavefronts in sequence.  Every sum is built from the same partial sums in the same tree as before (additions commute bit for
+// bit), so the results are the old bits; the counters take the old path.
+template <int N> struct BlockReduceT {
+    static constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2; // list length after each step
+    static constexpr int kStageDoubles = (kLMThreads / 64) * n4 * 64;
+    // exchange of one double with the lane `lane ^ (1 << STEP)`
+    template <int STEP> __device__ static __forceinline__ double xchg(double v) {
+        const uint64_t b = (uint64_t)__double_as_longlong(v);
+        int lo = (int)(uint32_t)b, hi = (int)(uint32_t)(b >> 32);
+        if constexpr (STEP == 0) {
+            lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+            hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, false);
+        } else if constexpr (STEP == 1) {
+            lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+            hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xf, 0xf, false);
+        } else if constexpr (STEP == 2) { // banks 0, 2 read four lanes up (row_shl:4), banks 1, 3 four lanes down (row_shr:4)
+            int l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xf, 0x5, false);
+            l2 = __builtin_amdgcn_update_dpp(l2, lo, 0x114, 0xf, 0xa, false);
+            int h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xf, 0x5, false);
+            h2 = __builtin_amdgcn_update_dpp(h2, hi, 0x114, 0xf, 0xa, false);
+            lo = l2, hi = h2;
+        } else { // banks 0, 1 read eight lanes up, banks 2, 3 eight lanes down
+            int l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x108, 0xf, 0x3, false);
+            l2 = __builtin_amdgcn_update_dpp(l2, lo, 0x118, 0xf, 0xc, false);
+            int h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x108, 0xf, 0x3, false);
+            h2 = __builtin_amdgcn_update_dpp(h2, hi, 0x118, 0xf, 0xc, false);
+            lo = l2, hi = h2;
+        }
+        return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+    }
+    template <int STEP, int NCUR> __device__ static __forceinline__ void halve(double *s, int lane) {
+        constexpr int NN = (NCUR + 1) / 2;
+        const bool upper = (lane >> STEP) & 1;
+#pragma unroll
+        for (int i = 0; i < NN; ++i) {
+            const double a = s[i];
+            const double b = (i + NN < NCUR) ? s[i + NN] : 0.0; // (a list of odd length: the missing partner is a zero nobody reads)
+            const double keep = upper ? b : a, send = upper ? a : b;
+            s[i] = keep + xchg<STEP>(send);
+        }
+    }
+    // where sum v sits after the four steps: lane of the row (bits = the halves it went into), slot of that lane's list
+    __device__ static __forceinline__ void home(int v, int &lane16, int &slot) {
+        int idx = v, l = 0;
+        if (idx >= n1)
+            idx -= n1, l |= 1;
+        if (idx >= n2)
+            idx -= n2, l |= 2;
+        if (idx >= n3)
+            idx -= n3, l |= 4;
+        if (idx >= n4)
+            idx -= n4, l |= 8;
+        lane16 = l, slot = idx;
+    }
+    // v[0 .. N): this thread's partial sums; the totals go to out[0 .. N - 1) and *out_last (sum N - 1), the counters' totals to
+    // *count_a_out / *count_b_out.  stage: kStageDoubles doubles of LDS, cstage: [wavefronts][2] doubles.
+    __device__ static void run(const double *v, uint32_t cnt_a, uint32_t cnt_b, double *stage, double (*cstage)[2], double *out,
+                               double *out_last, uint32_t *count_a_out, uint32_t *count_b_out) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double s[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            s[i] = v[i];
+        halve<0, N>(s, lane);
+        halve<1, n1>(s, lane);
+        halve<2, n2>(s, lane);
+        halve<3, n3>(s, lane);
+#pragma unroll
+        for (int i = 0; i < n4; ++i)
+            stage[(wave * n4 + i) * 64 + lane] = s[i];
+        const uint32_t ca = wave_sum_u32(cnt_a), cb = wave_sum_u32(cnt_b);
+        if (lane == 0) {
+            cstage[wave][0] = (double)ca;
+            cstage[wave][1] = (double)cb;
+        }
+        __syncthreads();
+        if (threadIdx.x < N) {
+            int l16, slot;
+            home((int)threadIdx.x, l16, slot);
+            double t = 0;
+            for (int w = 0; w < kLMThreads / 64; ++w) {
+                const double *r = stage + (w * n4 + slot) * 64 + l16;
+                t += (r[48] + r[32]) + (r[16] + r[0]); // rows 3 + 2, rows 1 + 0: the butterfly's row_bcast:15 / :31 steps
+            }
+            if (threadIdx.x < N - 1 || !out_last)
+                out[threadIdx.x] = t;
+            else
+                *out_last = t;
+        } else if (threadIdx.x < N + 2) {
+            const int k = (int)threadIdx.x - N;
+            double t = 0;
+            for (int w = 0; w < kLMThreads / 64; ++w)
+                t += cstage[w][k];
+            *(k == 0 ? count_a_out : count_b_out) = (uint32_t)t;
+        }
+        __syncthreads();
+    }
+};
+
 // `lds_points` != 0: the correspondences are staged once into dynamic LDS (nd * n doubles) and every residual /
 // Jacobian pass reads them from there - a task makes 30..50 passes over the same points, and for the small problems
 // of the default-options regime the L2 round trip of every pass is a visible part of the 8 us an LM iteration takes.
+#ifdef PL_LM_PROFILE // experiment builds (scripts/exp): cycles of thread 0 per phase of k_lm, summed over tasks; read by pl_debug_lm_profile
+__device__ unsigned long long g_lm_prof[16];
+#define PL_PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
+#define PL_PROF_ADD(slot, t0) do { if (threadIdx.x == 0) atomicAdd(&g_lm_prof[slot], __builtin_readcyclecounter() - (t0)); } while (0)
+#else
+#define PL_PROF_T0() do { } while (0)
+#define PL_PROF_ADD(slot, t0) do { } while (0)
+#endif
 template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *tasks, uint32_t lds_bytes) {
     using R = Refiner<EST>;
     constexpr int K = R::K;
@@ -1736,6 +1877,8 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
     __shared__ double cur[kParamDoubles], trial[kParamDoubles];
     __shared__ RefineCtx ctx;
     __shared__ double scratch[kLMThreads / 64][NT + 1];
+    __shared__ double tr_stage[BlockReduceT<NT + 1>::kStageDoubles];
+    __shared__ double tr_counts[kLMThreads / 64][2];
     __shared__ double normal[NT];
     __shared__ double normal_next[NT]; // the normal equations at the trial point (fused pass), the next iteration's if the step is accepted
     __shared__ double s_racc[1];
@@ -1807,10 +1950,17 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
     enum { kRes = 0, kJac = 1, kBoth = 2 };
     auto pass = [&](const double *p, int mode, double *out) {
         const bool jac = mode != kRes, res = mode != kJac;
+#ifdef PL_LM_PROFILE
+        const unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
         if (threadIdx.x == 0) {
             R::prepare(p, ctx);
         }
         __syncthreads();
+#ifdef PL_LM_PROFILE
+        const unsigned long long pt1 = __builtin_readcyclecounter();
+        PL_PROF_ADD(0, pt0); // prepare + barrier
+#endif
         double acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -2089,12 +2239,32 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
                     point(i, true);
             }
         }
-        if (res) {
+#ifdef PL_LM_PROFILE
+        const unsigned long long pt2 = __builtin_readcyclecounter();
+        PL_PROF_ADD(1, pt1); // the sweep over the points (thread 0's share)
+        __syncthreads();
+        const unsigned long long pt3 = __builtin_readcyclecounter();
+        PL_PROF_ADD(2, pt2); // waiting for the slowest wavefront of the sweep
+#endif
+        if (res && jac) { // the fused sweep: the NT sums of the normal equations and the cost through one reduction
+            double v[NT + 1];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                v[i] = acc[i];
+            v[NT] = racc;
+            BlockReduceT<NT + 1>::run(v, cntj, cnt, tr_stage, tr_counts, out, &s_racc[0], &s_count_j, &s_count);
+        } else if (res) {
             double v[1] = {racc};
             BlockReduce<1>::run(v, cnt, reinterpret_cast<double(*)[2]>(&scratch[0][0]), s_racc, &s_count);
+        } else if (jac) {
+            uint32_t unused;
+            BlockReduceT<NT>::run(acc, cntj, 0u, tr_stage, tr_counts, out, nullptr, &s_count_j, &unused);
         }
-        if (jac)
-            BlockReduce<NT>::run(acc, cntj, scratch, out, &s_count_j);
+#ifdef PL_LM_PROFILE
+        PL_PROF_ADD(3, pt3); // block reductions
+        if (threadIdx.x == 0)
+            atomicAdd(&g_lm_prof[8], 1ull); // passes
+#endif
     };
 
     // The initial cost and the first iteration's normal equations are evaluated at the same point with the same loss: one sweep.
@@ -2127,10 +2297,16 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         }
         // (the one lane that solves is a chain of dependent fp64 operations: with other kernels' wavefronts on the SIMD it gets an issue slot
         // every few instructions only - priority 3 for the serial sections, measured on the mixed batch)
+#ifdef PL_LM_PROFILE
+        const unsigned long long st0 = __builtin_readcyclecounter();
+#endif
         if (threadIdx.x < 64)
             __builtin_amdgcn_s_setprio(3);
         if (threadIdx.x == 0) {
             lm_solve<K>(ctl, normal, fresh, jac_count);
+#ifdef PL_LM_PROFILE
+            atomicAdd(&g_lm_prof[4], __builtin_readcyclecounter() - st0); // lm_solve alone
+#endif
             if (!ctl.done) {
                 R::step(cur, ctx, ctl.sol, trial);
                 if constexpr (EST == EST_REL)
@@ -2142,9 +2318,15 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         if (threadIdx.x < 64)
             __builtin_amdgcn_s_setprio(0);
         __syncthreads();
+#ifdef PL_LM_PROFILE
+        PL_PROF_ADD(5, st0); // solve + step (+ prepare_params) + barrier
+#endif
         if (ctl.done)
             break;
         pass(trial, fuse ? kBoth : kRes, normal_next);
+#ifdef PL_LM_PROFILE
+        const unsigned long long ut0 = __builtin_readcyclecounter();
+#endif
         if (threadIdx.x < 64)
             __builtin_amdgcn_s_setprio(3);
         if (threadIdx.x == 0) {
@@ -2164,6 +2346,11 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
             jac_count = s_count_j;
             __syncthreads();
         }
+#ifdef PL_LM_PROFILE
+        PL_PROF_ADD(6, ut0); // update + copy + barriers
+        if (threadIdx.x == 0)
+            atomicAdd(&g_lm_prof[9], 1ull); // iterations
+#endif
     }
 
     if (threadIdx.x == 0)
@@ -3021,6 +3208,18 @@ bool lm_sums_ordered(int est) {
     const int m = get_lm_mode();
     return m == 1 || (m == 0 && est == EST_FUND);
 }
+#ifdef PL_LM_PROFILE
+extern "C" int pl_debug_lm_profile(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_prof), sizeof(unsigned long long) * 16) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lm_prof), z, sizeof(z)) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#endif
 hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t max_points, hipStream_t stream) {
     if (num_tasks == 0)
         return hipSuccess;
