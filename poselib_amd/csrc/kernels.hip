@@ -1794,11 +1794,16 @@ template <int N> struct BlockReduceT {
         if (threadIdx.x < N) {
             int l16, slot;
             home((int)threadIdx.x, l16, slot);
-            double t = 0;
-            for (int w = 0; w < kLMThreads / 64; ++w) {
+            double wv[kLMThreads / 64];
+#pragma unroll
+            for (int w = 0; w < kLMThreads / 64; ++w) { // (all loads first: the rows of the wavefronts are independent)
                 const double *r = stage + (w * n4 + slot) * 64 + l16;
-                t += (r[48] + r[32]) + (r[16] + r[0]); // rows 3 + 2, rows 1 + 0: the butterfly's row_bcast:15 / :31 steps
+                wv[w] = (r[48] + r[32]) + (r[16] + r[0]); // rows 3 + 2, rows 1 + 0: the butterfly's row_bcast:15 / :31 steps
             }
+            double t = 0;
+#pragma unroll
+            for (int w = 0; w < kLMThreads / 64; ++w)
+                t += wv[w];
             if (threadIdx.x < N - 1 || !out_last)
                 out[threadIdx.x] = t;
             else
