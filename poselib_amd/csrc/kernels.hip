@@ -1769,16 +1769,25 @@ template <int N> struct BlockReduceT {
             idx -= n4, l |= 8;
         lane16 = l, slot = idx;
     }
-    // v[0 .. N): this thread's partial sums; the totals go to out[0 .. N - 1) and *out_last (sum N - 1), the counters' totals to
-    // *count_a_out / *count_b_out.  stage: kStageDoubles doubles of LDS, cstage: [wavefronts][2] doubles.
-    __device__ static void run(const double *v, uint32_t cnt_a, uint32_t cnt_b, double *stage, double (*cstage)[2], double *out,
+    // v[0 .. N - 1) and `last` (sum N - 1; with out_last == nullptr v holds all N and `last` is ignored): this thread's partial
+    // sums; the totals go to out[0 .. N - 1) and *out_last, the counters' totals to *count_a_out / *count_b_out.
+    // stage: kStageDoubles doubles of LDS, cstage: [wavefronts][2] doubles.  (The first step reads the caller's accumulators
+    // and writes a list of half the length: no second copy of the N accumulators is alive - with 46 of them, a homography's,
+    // a copy cost the sweep of k_lm<3> its registers: +33 % on its point loop, measured.)
+    __device__ static void run(const double *v, double last, uint32_t cnt_a, uint32_t cnt_b, double *stage, double (*cstage)[2], double *out,
                                double *out_last, uint32_t *count_a_out, uint32_t *count_b_out) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        double s[N];
+        double s[n1];
+        {
+            const bool upper = lane & 1;
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-            s[i] = v[i];
-        halve<0, N>(s, lane);
+            for (int i = 0; i < n1; ++i) {
+                const double a = v[i];
+                const double b = (i + n1 < N) ? ((i + n1 == N - 1 && out_last) ? last : v[i + n1]) : 0.0;
+                const double keep = upper ? b : a, send = upper ? a : b;
+                s[i] = keep + xchg<0>(send);
+            }
+        }
         halve<1, n1>(s, lane);
         halve<2, n2>(s, lane);
         halve<3, n3>(s, lane);
@@ -2251,20 +2260,24 @@ template <int EST> __global__ __launch_bounds__(kLMThreads) void k_lm(LMTask *ta
         const unsigned long long pt3 = __builtin_readcyclecounter();
         PL_PROF_ADD(2, pt2); // waiting for the slowest wavefront of the sweep
 #endif
+#ifdef PL_LM_OLD_REDUCE // experiment builds: round 4's reductions (A/B on one box)
+        if (res) {
+            double v[1] = {racc};
+            BlockReduce<1>::run(v, cnt, reinterpret_cast<double(*)[2]>(&scratch[0][0]), s_racc, &s_count);
+        }
+        if (jac)
+            BlockReduce<NT>::run(acc, cntj, scratch, out, &s_count_j);
+#else
         if (res && jac) { // the fused sweep: the NT sums of the normal equations and the cost through one reduction
-            double v[NT + 1];
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-                v[i] = acc[i];
-            v[NT] = racc;
-            BlockReduceT<NT + 1>::run(v, cntj, cnt, tr_stage, tr_counts, out, &s_racc[0], &s_count_j, &s_count);
+            BlockReduceT<NT + 1>::run(acc, racc, cntj, cnt, tr_stage, tr_counts, out, &s_racc[0], &s_count_j, &s_count);
         } else if (res) {
             double v[1] = {racc};
             BlockReduce<1>::run(v, cnt, reinterpret_cast<double(*)[2]>(&scratch[0][0]), s_racc, &s_count);
         } else if (jac) {
             uint32_t unused;
-            BlockReduceT<NT>::run(acc, cntj, 0u, tr_stage, tr_counts, out, nullptr, &s_count_j, &unused);
+            BlockReduceT<NT>::run(acc, 0.0, cntj, 0u, tr_stage, tr_counts, out, nullptr, &s_count_j, &unused);
         }
+#endif
 #ifdef PL_LM_PROFILE
         PL_PROF_ADD(3, pt3); // block reductions
         if (threadIdx.x == 0)

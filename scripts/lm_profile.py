@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from poselib_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "scripts", "exp", "variants", "lmprof", "libposelib_amd.so")
+_lib.LIB_PATH = os.path.join(ROOT, "scripts", "exp", "variants", os.environ.get("LM_PROFILE_VARIANT", "lmprof"), "libposelib_amd.so")
 import poselib_amd as P
 from poselib_amd import synth
 L = _lib.lib()
