@@ -892,11 +892,14 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
                 }
             }
             // ---- expansion: eight rounds, round (q, e) = hypothesis 4 q + e (lanes 0..31) and 4 q + 2 + e (lanes 32..63) ----
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            // (only the last, partial group of a short unit has slots without a hypothesis: the per-lane test "slot < gn" - three
+            // vector instructions per round, 1.5 of the 30.7 per hypothesis and 320 correspondences - runs behind a SCALAR branch
+            // for that group only; round 5)
+            const bool partial_group = hg * 16u + 16u > gn;
+            auto expand_round = [&](int r, bool check_slot) {
                 const uint32_t slot = hg * 16u + 4u * (uint32_t)(r >> 1) + 2u * (uint32_t)half + (uint32_t)(r & 1); // hypothesis index inside the unit
                 uint32_t bits = ~out[r] & validbits;
-                if (hg * 16u + 16u > gn && slot >= gn) // (only the last, partial group of a short unit has slots without a hypothesis: a scalar test in front)
+                if (check_slot && slot >= gn)
                     bits = 0u;
                 const uint64_t anyb = __builtin_amdgcn_ballot_w64(bits != 0u);
                 if (anyb) { // wave-uniform
@@ -928,6 +931,15 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
                     while (qtail - qhead >= 64u)
                         drain(64u);
                 }
+            };
+            if (partial_group) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    expand_round(r, true);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    expand_round(r, false);
             }
         }
         while (qtail != qhead)
@@ -1152,11 +1164,11 @@ __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint
                 }
             }
             // ---- expansion: register v = hypothesis rows 8 (v / 4) + v % 4 (lanes 0..31) and + 4 (lanes 32..63) ----
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
+            const bool partial_group = hg * 32u + 32u > gn; // (the slot test behind a scalar branch: k_score_mfma's expansion says why)
+            auto expand_round = [&](int v, bool check_slot) {
                 const uint32_t slot = hg * 32u + 8u * (uint32_t)(v >> 2) + 4u * (uint32_t)half + (uint32_t)(v & 3);
                 uint32_t bits = ~out[v] & validbits;
-                if (hg * 32u + 32u > gn && slot >= gn)
+                if (check_slot && slot >= gn)
                     bits = 0u;
                 const uint64_t anyb = __builtin_amdgcn_ballot_w64(bits != 0u);
                 if (anyb) { // wave-uniform
@@ -1188,6 +1200,15 @@ __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint
                     while (qtail - qhead >= 64u)
                         drain(64u);
                 }
+            };
+            if (partial_group) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    expand_round(v, true);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    expand_round(v, false);
             }
         }
         while (qtail != qhead)
@@ -1383,11 +1404,11 @@ __device__ __forceinline__ void score_mfmah_body(const PointSet &pts, const uint
                 }
             }
             // ---- expansion: four rounds, round q = hypothesis 2 q (lanes 0..31) and 2 q + 1 (lanes 32..63) ----
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            const bool partial_group = hg * 8u + 8u > gn; // (the slot test behind a scalar branch: k_score_mfma's expansion says why)
+            auto expand_round = [&](int q, bool check_slot) {
                 const uint32_t slot = hg * 8u + 2u * (uint32_t)q + (uint32_t)half; // hypothesis index inside the unit
                 uint32_t bits = ~out[q] & validbits;
-                if (hg * 8u + 8u > gn && slot >= gn)
+                if (check_slot && slot >= gn)
                     bits = 0u;
                 const uint64_t anyb = __builtin_amdgcn_ballot_w64(bits != 0u);
                 if (anyb) { // wave-uniform
@@ -1419,6 +1440,15 @@ __device__ __forceinline__ void score_mfmah_body(const PointSet &pts, const uint
                     while (qtail - qhead >= 64u)
                         drain(64u);
                 }
+            };
+            if (partial_group) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    expand_round(q, true);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    expand_round(q, false);
             }
         }
         while (qtail != qhead)
