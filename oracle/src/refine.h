@@ -84,7 +84,7 @@ BundleStats refine_shared_focal_relpose(const std::vector<V2> &x1, const std::ve
 BundleStats refine_homography(const std::vector<V2> &x1, const std::vector<V2> &x2, M3 *H, const BundleOptions &opt);
 BundleStats refine_fundamental(const std::vector<V2> &x1, const std::vector<V2> &x2, M3 *F, const BundleOptions &opt);
 
-// 3x3 SVD helper (one-sided Jacobi); singular values descending, A = U diag(s) V^T.
+// 3x3 SVD: Eigen's two-sided Jacobi in Eigen's operation order (eigen_shim/Eigen/src/JacobiSVD3x3.h: the sign of a refined F depends on it); singular values descending, A = U diag(s) V^T.
 void svd3(const M3 &A, M3 &U, double s[3], M3 &V);
 
 } // namespace orc

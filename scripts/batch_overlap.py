@@ -28,14 +28,15 @@ for b in batches:
         b.run(max_in_flight=threads)
 ref = [tuple(np.asarray(x).copy() for x in b.stats()[:3]) for b in batches]
 for inflight in (1, 2, 3, 4):
-    reps = 12
-    def worker(k):
+    wk = max(2, threads * 2 // (inflight + 1)) if inflight > 1 else threads
+    def worker(k, reps):
         for _ in range(reps):
-            batches[k].run(max_in_flight=max(2, threads // inflight))
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(inflight)]
-    [t.start() for t in th]; [t.join() for t in th]
-    dt = time.perf_counter() - t0
+            batches[k].run(max_in_flight=wk)
+    for reps in (4, 12):  # (an untimed round first: the pools' workers grow their arenas)
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(k, reps)) for k in range(inflight)]
+        [t.start() for t in th]; [t.join() for t in th]
+        dt = time.perf_counter() - t0
     same = all(all(bool((a == np.asarray(b)).all()) for a, b in zip(ref[k], batches[k].stats()[:3])) for k in range(inflight))
-    print(f"{n_call} problems per call, {inflight} call(s) in flight x {max(2, threads // inflight)} workers: {inflight * reps * n_call / dt:9.0f} problems/s"
+    print(f"{n_call} problems per call, {inflight} call(s) in flight x {wk} workers: {inflight * reps * n_call / dt:9.0f} problems/s"
           f" ({1e3 * dt / reps:.1f} ms per round of calls); same results: {same}", flush=True)
