@@ -76,20 +76,34 @@ if [ "$PART" = "c" ]; then
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_sweep -o r -- python $R/scripts/batch_sweep.py 4096 10:0:3 > $O/prof_sweep.log 2>&1
   cd $R
   f=$(find $O/kt_sweep -name "*kernel_trace.csv" | head -1)
-  python scripts/busy.py $f 0.5 > $O/busy_sweep.txt
+  # the window = the four TIMED calls at the end of the run (the warm-up calls grow the workers' arenas and can take seconds under the tracer):
+  # the last 4 x (median call time printed by batch_sweep.py) of the kernel span
+  FR=$(python - "$f" "$O/kt_sweep.log" <<'PY'
+import csv, re, sys
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(sys.argv[1]))]
+t0, t1 = min(r[0] for r in rows), max(r[1] for r in rows)
+m = re.search(r"median of 4: ([0-9.]+) ms", open(sys.argv[2]).read())
+ms = float(m.group(1)) if m else 52.0
+print(f"{max(0.0, 1.0 - 4.0 * ms * 1e6 / (t1 - t0)):.6f}")
+PY
+)
+  echo "window: last $(python -c "print(round((1-$FR)*100,2))") % of the kernel span = the four timed calls" > $O/busy_sweep.txt
+  python scripts/busy.py $f $FR >> $O/busy_sweep.txt
+  export PL_SHARES_CUT=$FR
   python scripts/chain_view.py $f > $O/chain_sweep.txt
   python - "$f" > $O/shares_sweep.txt <<'PY'
 import csv, collections, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 for r in rows:
     r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"]); r["n"] = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pl::", "")
-t0 = min(r["s"] for r in rows); t1 = max(r["e"] for r in rows); cut = t0 + 0.5 * (t1 - t0)
+import os
+t0 = min(r["s"] for r in rows); t1 = max(r["e"] for r in rows); cut = t0 + float(os.environ.get("PL_SHARES_CUT", "0.5")) * (t1 - t0)
 sel = [r for r in rows if r["s"] >= cut]
 tot = collections.defaultdict(float); cnt = collections.Counter()
 for r in sel:
     tot[r["n"]] += (r["e"] - r["s"]) / 1e3; cnt[r["n"]] += 1
 T = sum(tot.values())
-print(f"last half of the kernel span: {(t1 - cut) / 1e6:.1f} ms, {len(sel)} dispatches, summed kernel time {T / 1e3:.1f} ms")
+print(f"the four timed calls at the end of the kernel span: {(t1 - cut) / 1e6:.1f} ms, {len(sel)} dispatches, summed kernel time {T / 1e3:.1f} ms")
 print("| kernel | dispatches | summed ms | share of GPU time | avg us |\n|---|---|---|---|---|")
 for n, v in sorted(tot.items(), key=lambda kv: -kv[1]):
     print(f"| `{n}` | {cnt[n]} | {v / 1e3:.2f} | {100 * v / T:.1f} % | {v / cnt[n]:.1f} |")

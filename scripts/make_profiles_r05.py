@@ -61,7 +61,7 @@ def main():
        "GPU_MAX_HW_QUEUES 8 / 16 / 32 at 8 threads: 68.0 / 68.4 / 69.1 k (before the later changes); 4 (the runtime's default): 59.8 k.\n")
     wr("r05_batch_sizes.md",
        "# r05 - configs[4] as BASELINE words it: 4096 problems sharded over 8 ranks = 512 per call.  pl_estimate_batch at 256 ... 4096 problems per call (scripts/batch_sweep.py, 10 workers)\n\n```\n"
-       + rd("batch_sizes.log") + rd("batch_sweep.log") + "```\n\nSeveral calls in flight from as many host threads (scripts/batch_overlap.py; pl_estimate_batch leases one of four worker pools per call since round 5):\n\n```\n"
+       + "".join(f"{n:5d} problems per call: {ln.strip()}\n" for n, ln in zip((256, 512, 1024, 2048), rd("batch_sizes.log").splitlines())) + rd("batch_sweep.log") + "```\n\nSeveral calls in flight from as many host threads (scripts/batch_overlap.py; pl_estimate_batch leases one of four worker pools per call since round 5):\n\n```\n"
        + rd("batch_overlap.log") + "```\n\nbench.py (N = 1 line of the same build): batch_mixed_problems_per_s " + f"{c['batch_mixed_problems_per_s']:.0f}" + " at 4096 per call, batch_mixed_512_problems_per_s "
        + f"{c.get('batch_mixed_512_problems_per_s', float('nan')):.0f}" + " (calls one after the other), batch_mixed_512_x4_in_flight_problems_per_s " + f"{c.get('batch_mixed_512_x4_in_flight_problems_per_s', float('nan')):.0f}" + ".\n\n"
        "A call is a handful of launch chains whose LENGTH is latency (per group ~6 waits of ~0.9 ms: ~15 dependent launches, the LO's up to 25 and the final bundle's up to 100 LM iterations at 8 us): "
@@ -69,7 +69,9 @@ def main():
     wr("r05_generator_full_device.md", "# r05 - the 5-point generator on a FULL device: `scripts/exp/genbench 1600000 16 3` (16 problems x 100 k iterations), flat root isolation (default) against round 4's kernel "
        "(POSELIB_AMD_REL_ROOTS_V1=1), same box\n\n```\n" + rd("genbench_roots_ab.log") + "```\n\n## rocprofv3 --kernel-trace --stats, default build\n\n" + rd("prof_gen_v3.md") + "\n## ... round 4's root kernel\n\n" + rd("prof_gen_v1.md"))
     lm = ["# r05 - one LM iteration of one refinement task (scripts/time_lm.py: pl_refine_model on resident problems, slope between a 2- and a 40-iteration run)\n",
-          "tree = k_lm (default: reference order up to 256 correspondences, tree beyond); ordered = k_lm_ordered (POSELIB_AMD_LM_ORDERED=1: reference order at every n).\n"]
+          "tree = k_lm (default for poses and homographies: reference order up to 256 correspondences, tree beyond); ordered = k_lm_ordered (POSELIB_AMD_LM_ORDERED=1: reference order at every n).  "
+          "Fundamental matrices take k_lm_ordered in BOTH columns (their default since round 5: the sign of a refined F needs bit-identical sums; round 4's tree kernel: 13.5 / 17.1 / 21.4 / 31.1 / 47.3 us).  "
+          "Round 4 for comparison (tree): abs 10.0 / 12.7 / 15.5 / 22.0 / 35.2, rel 9.6 / 12.1 / 14.6 / 20.7 / 32.3, hom 13.6 / 17.2 / 19.4 / 27.0 / 40.3 us - the difference is the block reduction (BlockReduceT, r05_lm_profile.md).\n"]
     for loss in ("truncated", "cauchy"):
         t, o = rd(f"time_lm_tree_{loss}.log").splitlines(), rd(f"time_lm_ordered_{loss}.log").splitlines()
         lm.append(f"\n## {loss.upper()} loss\n\n| estimator, n | tree: us per LM iteration | ordered |\n|---|---|---|")
