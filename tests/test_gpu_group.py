@@ -166,6 +166,35 @@ print("RESULT " + json.dumps(out[0]))
         assert (g[-2], g[-1]) == (ref[2]["iterations"], ref[2]["num_inliers"]), (pr[0], len(pr[1]))
 
 
+def test_batches_in_flight_from_several_threads_return_what_they_return_alone(gpu):
+    """Round 5: pl_estimate_batch leases one of four worker pools per call (round 4: one batch at a time per process), so several
+    host threads can keep a call each in flight and their launch chains interleave on the device.  A problem's result must not
+    depend on it: four different batches, run alone and then concurrently (twice: the second round reuses warm pools), bit for bit."""
+    import threading
+
+    sets = [_problems(60, 36000 + 1000 * k, [{}]) for k in range(4)]
+    alone = [[(_flat(pr, m), i["iterations"], i["num_inliers"], i["inliers"]) for (m, i), pr in zip(gpu.estimate_batch(ps, max_in_flight=4), ps)]
+             for ps in sets]
+    for _ in range(2):
+        out = [None] * 4
+        err = []
+
+        def run(k):
+            try:
+                res = gpu.estimate_batch(sets[k], max_in_flight=3)
+                out[k] = [(_flat(pr, m), i["iterations"], i["num_inliers"], i["inliers"]) for (m, i), pr in zip(res, sets[k])]
+            except Exception as e:  # noqa: BLE001
+                err.append(repr(e))
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not err, err
+        for k in range(4):
+            for (ma, ia, na, ka), (mb, ib, nb, kb) in zip(alone[k], out[k]):
+                assert np.array_equal(ma, mb) and ia == ib and na == nb and ka == kb
+
+
 # ---- pl_ransac_batch: device-resident problems in lock-step groups ------------------------------------------------------
 def _resident_set(gpu, base):
     """(Problem, options) pairs of all four kinds: default-length runs, long fixed-length runs (several batches of a group
