@@ -73,8 +73,12 @@ __host__ __device__ inline RelStage rel_stage(void *stage, uint32_t num_iters) {
 }
 
 // ---- stage 1 --------------------------------------------------------------------------------------------------------
+#ifndef PL_FRONT_THREADS
+#define PL_FRONT_THREADS 64
+#endif
+constexpr int kFrontThreads = PL_FRONT_THREADS;
 __device__ __forceinline__ void rel_front_body(const GenerateArgs &g, const RelStage &w) {
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t it = blockIdx.x * kFrontThreads + threadIdx.x;
     if (it >= g.num_iters)
         return;
     uint32_t idx[5];
@@ -93,6 +97,21 @@ __device__ __forceinline__ void rel_front_body(const GenerateArgs &g, const RelS
     }
     double nb[36], Az[3][13];
     rel5_front(b1, b2, nb, Az);
+#ifdef PL_FRONT_NOSTORE // experiment builds: the arithmetic without its 75 result stores (box-state hunt, profiles/r05_box_state.md)
+    {
+        double chk = 0.0; // (depends on every result: nothing of the arithmetic is dead)
+#pragma unroll
+        for (int e = 0; e < 36; ++e)
+            chk += nb[e];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 13; ++k)
+                chk += Az[i][k];
+        if (chk != 12345.678)
+            return;
+    }
+#endif
 #pragma unroll
     for (int e = 0; e < 36; ++e)
         w.nb[(size_t)e * w.P + it] = nb[e];
@@ -102,10 +121,10 @@ __device__ __forceinline__ void rel_front_body(const GenerateArgs &g, const RelS
         for (int k = 0; k < 13; ++k)
             w.az[(size_t)(i * 13 + k) * w.P + it] = Az[i][k];
 }
-__global__ __launch_bounds__(64) void k_rel_front(GenerateArgs g) { rel_front_body(g, rel_stage(g.stage, g.num_iters)); }
-__global__ __launch_bounds__(64) void k_rel_front_g(const GroupArgs *ga) {
+__global__ __launch_bounds__(kFrontThreads) void k_rel_front(GenerateArgs g) { rel_front_body(g, rel_stage(g.stage, g.num_iters)); }
+__global__ __launch_bounds__(kFrontThreads) void k_rel_front_g(const GroupArgs *ga) {
     const GroupArgs &gg = ga[blockIdx.z];
-    if (!gg.active || blockIdx.x * 64u >= gg.gen.num_iters)
+    if (!gg.active || blockIdx.x * (uint32_t)kFrontThreads >= gg.gen.num_iters)
         return;
     rel_front_body(gg.gen, rel_stage(gg.gen.stage, gg.gen.num_iters));
 }
@@ -411,7 +430,7 @@ static bool rel_roots_v1() {
 }
 hipError_t launch_generate_rel(const GenerateArgs &a, hipStream_t stream) {
     const uint32_t B = a.num_iters;
-    k_rel_front<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(a);
+    k_rel_front<<<dim3((B + kFrontThreads - 1) / kFrontThreads), dim3(kFrontThreads), 0, stream>>>(a);
     if (rel_roots_v1())
         k_rel_roots_v1<<<dim3((B + 63) / 64), dim3(64), 0, stream>>>(B, a.stage);
     else
@@ -420,7 +439,7 @@ hipError_t launch_generate_rel(const GenerateArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 hipError_t launch_group_generate_rel(const GroupArgs *args, uint32_t max_B, uint32_t G, hipStream_t stream) {
-    k_rel_front_g<<<dim3((max_B + 63) / 64, 1, G), dim3(64), 0, stream>>>(args);
+    k_rel_front_g<<<dim3((max_B + kFrontThreads - 1) / kFrontThreads, 1, G), dim3(kFrontThreads), 0, stream>>>(args);
     if (rel_roots_v1())
         k_rel_roots_v1_g<<<dim3((max_B + 63) / 64, 1, G), dim3(64), 0, stream>>>(args);
     else
