@@ -123,43 +123,211 @@ template <int K> inline uint64_t focal_sample_positions(uint64_t seed, uint64_t 
     return pos;
 }
 
-// The sequential LO-RANSAC loop (ransac_impl.h:106-201) over batches of iterations.  The back end evaluates
-//   int minimal(pos_base, positions, B, models [B * 10], num_models [B], counts, sums, samples)   - generate + score a batch
-//                                                          (samples != nullptr: B x kSample explicit indices - PROSAC),
-//   int score(models, counts, sums)                                                     - score given models,
-//   int refine(seeds, refined)                                                          - refine_model() of every seed;
+// The sequential LO-RANSAC loop (ransac_impl.h:106-201) over batches of iterations, as a STATE MACHINE: advance() runs the loop up to
+// the next thing only a back end can evaluate and returns what that is; the caller evaluates it (for one problem on its stream -
+// focal_lo_ransac_t below - or for the members of a group with ONE launch sequence, driver_focal_group.inc), leaves the results in
+// the response fields and calls advance() again.  Requests:
+//   kMinimal      generate + score the batch [pos, positions[0 .. B)) (explicit_samples: B x kSample indices drawn here - PROSAC)
+//                 -> models [B * kMaxModels], num_models [B], counts, sums (per model slot)
+//   kScore        score `seeds` -> counts, sums
+//   kRefineScore  refine_model() of every seed and the scores of the results -> refined, rcounts, rsums
 // counts / sums: inliers and the sum of their squared residuals in correspondence order, per model slot.  All decisions are
 // taken here, in the reference's order: which hypotheses improve best_minimal_*, which of them seed a local optimisation
 // (the last improving one of an iteration), the incumbent, the dynamic iteration bound and the stop rule.
 // Traits: kSample (sample size), kMaxModels (model slots per iteration), finish(sum, count, N, options, focal) -> score_model().
-template <class Traits, class Backend>
-int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalModel *best, FocalLoopStats *stats) {
-    constexpr int kSample = Traits::kSample, kMaxModels = Traits::kMaxModels;
-    FocalLoopStats &st = *stats;
-    st = FocalLoopStats();
-    if (N < (uint64_t)kSample)
-        return 0;
-    uint64_t best_min_inl = 0;
-    double best_min_score = std::numeric_limits<double>::max();
-    uint64_t dyn_max = o.max_iterations;
-    const double log_fail = std::log(1.0 - o.success_prob);
+template <class Traits> struct FocalLoop {
+    static constexpr int kSample = Traits::kSample, kMaxModels = Traits::kMaxModels;
+    enum Request { kDone = 0, kMinimal, kScore, kRefineScore };
 
-    std::vector<FocalModel> models, seeds, refined;
-    std::vector<uint32_t> num_models, counts, rcounts, positions, prosac_samples;
-    ProsacSampler prosac;
-    if (o.progressive_sampling)
-        prosac.init(o.seed, N, kSample, o.max_prosac_iterations);
+    // ---- the request (valid after advance() returned it) ----
+    uint64_t pos = 0;  // sampler draws consumed before the batch
+    uint32_t B = 0;    // iterations of the batch
+    std::vector<uint32_t> positions, prosac_samples;
+    bool explicit_samples = false;
+    std::vector<FocalModel> seeds;
+    // ---- the response (filled by the caller before the next advance()) ----
+    std::vector<FocalModel> models, refined;
+    std::vector<uint32_t> num_models, counts, rcounts;
     std::vector<double> sums, rsums;
+
+    FocalLoop(uint64_t N_, const FocalLoopOptions &o_, FocalModel *best_, FocalLoopStats *stats_)
+        : N(N_), o(o_), best(best_), st(*stats_), dyn_max(o_.max_iterations), log_fail(std::log(1.0 - o_.success_prob)) {
+        st = FocalLoopStats();
+        if (o.progressive_sampling && N >= (uint64_t)kSample)
+            prosac.init(o.seed, N, kSample, o.max_prosac_iterations);
+    }
+
+    Request advance() {
+        for (;;) {
+            switch (phase) {
+            case Phase::kStart:
+                if (N < (uint64_t)kSample) {
+                    phase = Phase::kFinished;
+                    return kDone;
+                }
+                if (o.score_initial_model) {
+                    seeds.assign(1, *best);
+                    phase = Phase::kInitialScored;
+                    return kScore;
+                }
+                phase = Phase::kLoopHead;
+                break;
+            case Phase::kInitialScored: {
+                const double sc = Traits::finish(sums[0], counts[0], N, o, best->f);
+                const bool more = counts[0] > best_min_inl, better = sc < best_min_score;
+                phase = Phase::kLoopHead;
+                if (more || better) {
+                    if (more)
+                        best_min_inl = counts[0];
+                    if (better)
+                        best_min_score = sc;
+                    if (sc < st.model_score) {
+                        st.model_score = sc;
+                        st.num_inliers = counts[0];
+                    }
+                    seeds.assign(1, *best);
+                    phase = Phase::kInitialRefined;
+                    return kRefineScore;
+                }
+                break;
+            }
+            case Phase::kInitialRefined:
+                after_lo(refined[0], rcounts[0], rsums[0]);
+                phase = Phase::kLoopHead;
+                break;
+            case Phase::kLoopHead: {
+                // ransac_impl.h:109-111 at the head of the next iteration: the run may be over exactly at a batch boundary - do not
+                // evaluate another batch to find that out
+                if (stopped || st.iterations >= o.max_iterations || (st.iterations > o.min_iterations && st.iterations > dyn_max)) {
+                    phase = Phase::kFinal;
+                    break;
+                }
+                // the loop cannot stop before iteration max(min_iterations, dyn_max) + 1
+                const uint64_t it0 = st.iterations;
+                const uint64_t horizon = std::max(o.min_iterations, dyn_max) + 1;
+                uint64_t want = horizon > it0 ? horizon - it0 : 1;
+                // no model has bounded the run yet (dyn_max is still the iteration limit): evaluate up to the earliest possible stop,
+                // then double - a typical run ends at min_iterations + 1, and a batch that is four times that only occupies the device
+                // (the decisions do not depend on how the iterations are cut into batches)
+                if (dyn_max >= o.max_iterations)
+                    want = std::min<uint64_t>(want, std::max<uint64_t>(o.min_iterations + 1 > it0 ? o.min_iterations + 1 - it0 : 0, it0));
+                want = std::min<uint64_t>(std::max<uint64_t>(want, 256), 4096);
+                B = (uint32_t)std::min<uint64_t>(want, o.max_iterations - it0);
+                positions.resize(B);
+                pos_after = pos;
+                explicit_samples = false;
+                if (o.progressive_sampling) { // the subset-size recurrence is serial: B samples from the host
+                    prosac_samples.resize((size_t)B * kSample);
+                    for (uint32_t b = 0; b < B; ++b) {
+                        positions[b] = 0;
+                        prosac.generate(&prosac_samples[(size_t)b * kSample]);
+                    }
+                    explicit_samples = true;
+                } else {
+                    pos_after = focal_sample_positions<kSample>(o.seed, pos, N, B, positions.data());
+                }
+                phase = Phase::kBatchScored;
+                return kMinimal;
+            }
+            case Phase::kBatchScored: {
+                st.iterations_evaluated += B;
+                // pass 1: the hypotheses that improve best_minimal_* (independent of the local optimisations)
+                imps.clear();
+                seeds.clear();
+                for (uint32_t b = 0; b < B; ++b) {
+                    int last = -1;
+                    for (uint32_t m = 0; m < num_models[b]; ++m) {
+                        const size_t h = (size_t)b * kMaxModels + m;
+                        const double sc = Traits::finish(sums[h], counts[h], N, o, models[h].f);
+                        const bool more = counts[h] > best_min_inl, better = sc < best_min_score;
+                        if (!(more || better))
+                            continue;
+                        if (more)
+                            best_min_inl = counts[h];
+                        if (better)
+                            best_min_score = sc;
+                        imps.push_back(Improving{b, m, counts[h], sc, -1});
+                        last = (int)imps.size() - 1;
+                    }
+                    if (last >= 0) {
+                        imps[last].job = (int)seeds.size();
+                        seeds.push_back(models[(size_t)b * kMaxModels + imps[last].slot]);
+                    }
+                }
+                phase = Phase::kBatchRefined;
+                if (!seeds.empty()) // the local optimisations of the batch and the scores of their results: one device round trip
+                    return kRefineScore;
+                break;
+            }
+            case Phase::kBatchRefined: {
+                // pass 2: the loop itself
+                size_t a = 0;
+                for (uint32_t b = 0; b < B; ++b) {
+                    if (st.iterations > o.min_iterations && st.iterations > dyn_max) {
+                        stopped = true;
+                        break;
+                    }
+                    st.hypotheses += num_models[b];
+                    for (; a < imps.size() && imps[a].iter == b; ++a) {
+                        const Improving &im = imps[a];
+                        if (im.score < st.model_score) {
+                            st.model_score = im.score;
+                            *best = models[(size_t)b * kMaxModels + im.slot];
+                            st.num_inliers = im.count;
+                        }
+                        if (im.job >= 0)
+                            after_lo(refined[im.job], rcounts[im.job], rsums[im.job]);
+                    }
+                    st.iterations++;
+                }
+                pos = pos_after;
+                phase = Phase::kLoopHead;
+                break;
+            }
+            case Phase::kFinal: // final polish (ransac_impl.h:190-198): model_score is not updated
+                seeds.assign(1, *best);
+                phase = Phase::kFinalRefined;
+                return kRefineScore;
+            case Phase::kFinalRefined: {
+                st.refinements++;
+                const double rsc = Traits::finish(rsums[0], rcounts[0], N, o, refined[0].f);
+                if (rsc < st.model_score) {
+                    *best = refined[0];
+                    st.num_inliers = rcounts[0];
+                }
+                phase = Phase::kFinished;
+                return kDone;
+            }
+            case Phase::kFinished:
+                return kDone;
+            }
+        }
+    }
+
+  private:
+    enum class Phase { kStart, kInitialScored, kInitialRefined, kLoopHead, kBatchScored, kBatchRefined, kFinal, kFinalRefined, kFinished };
     struct Improving {
         uint32_t iter, slot;
         uint64_t count;
         double score;
         int job; // index into seeds / refined, -1: not the iteration's last improving hypothesis
     };
+    const uint64_t N;
+    const FocalLoopOptions o;
+    FocalModel *const best;
+    FocalLoopStats &st;
+    Phase phase = Phase::kStart;
+    uint64_t best_min_inl = 0;
+    double best_min_score = std::numeric_limits<double>::max();
+    uint64_t dyn_max;
+    const double log_fail;
+    uint64_t pos_after = 0;
+    bool stopped = false;
+    ProsacSampler prosac;
     std::vector<Improving> imps;
 
-    // candidates of one "iteration" whose minimal scores are known: ransac_impl.h:106-154
-    auto after_lo = [&](const FocalModel &ref, uint64_t rcnt, double rsum) {
+    // a local optimisation has returned: ransac_impl.h:124-154
+    void after_lo(const FocalModel &ref, uint64_t rcnt, double rsum) {
         st.refinements++;
         const double rsc = Traits::finish(rsum, rcnt, N, o, ref.f);
         if (rsc < st.model_score) {
@@ -168,131 +336,36 @@ int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalM
             *best = ref;
         }
         st.inlier_ratio = static_cast<double>(st.num_inliers) / static_cast<double>(N);
-        dyn_max = focal_dynamic_max_iter(st.num_inliers, N, kSample, log_fail, o.dyn_num_trials_mult, o.min_iterations,
-                                         o.max_iterations);
-    };
-
-    if (o.score_initial_model) {
-        models.assign(1, *best);
-        int rc = be.score(models, counts, sums);
-        if (rc)
-            return rc;
-        const double sc = Traits::finish(sums[0], counts[0], N, o, best->f);
-        const bool more = counts[0] > best_min_inl, better = sc < best_min_score;
-        if (more || better) {
-            if (more)
-                best_min_inl = counts[0];
-            if (better)
-                best_min_score = sc;
-            if (sc < st.model_score) {
-                st.model_score = sc;
-                st.num_inliers = counts[0];
-            }
-            seeds.assign(1, *best);
-            rc = be.refine_score(seeds, refined, rcounts, rsums);
-            if (rc)
-                return rc;
-            after_lo(refined[0], rcounts[0], rsums[0]);
-        }
+        dyn_max = focal_dynamic_max_iter(st.num_inliers, N, kSample, log_fail, o.dyn_num_trials_mult, o.min_iterations, o.max_iterations);
     }
+};
 
-    uint64_t pos = 0;
-    bool stopped = false;
-    while (!stopped && st.iterations < o.max_iterations) {
-        // ransac_impl.h:109-111 at the head of the next iteration: the run may be over exactly at a batch boundary - do not
-        // evaluate another batch to find that out
-        if (st.iterations > o.min_iterations && st.iterations > dyn_max)
+// One problem, one back end that evaluates every request synchronously:
+//   int minimal(pos_base, positions, B, models [B * 10], num_models [B], counts, sums, samples)
+//   int score(models, counts, sums)
+//   int refine_score(seeds, refined, counts, sums)
+template <class Traits, class Backend>
+int focal_lo_ransac_t(Backend &be, uint64_t N, const FocalLoopOptions &o, FocalModel *best, FocalLoopStats *stats) {
+    FocalLoop<Traits> loop(N, o, best, stats);
+    for (;;) {
+        int rc = 0;
+        switch (loop.advance()) {
+        case FocalLoop<Traits>::kDone:
+            return 0;
+        case FocalLoop<Traits>::kMinimal:
+            rc = be.minimal(loop.pos, loop.positions.data(), loop.B, loop.models, loop.num_models, loop.counts, loop.sums,
+                            loop.explicit_samples ? loop.prosac_samples.data() : nullptr);
             break;
-        // the loop cannot stop before iteration max(min_iterations, dyn_max) + 1
-        const uint64_t it0 = st.iterations;
-        const uint64_t horizon = std::max(o.min_iterations, dyn_max) + 1;
-        uint64_t want = horizon > it0 ? horizon - it0 : 1;
-        // no model has bounded the run yet (dyn_max is still the iteration limit): evaluate up to the earliest possible stop,
-        // then double - a typical run ends at min_iterations + 1, and a batch that is four times that only occupies the device
-        // (the decisions do not depend on how the iterations are cut into batches)
-        if (dyn_max >= o.max_iterations)
-            want = std::min<uint64_t>(want, std::max<uint64_t>(o.min_iterations + 1 > it0 ? o.min_iterations + 1 - it0 : 0, it0));
-        want = std::min<uint64_t>(std::max<uint64_t>(want, 256), 4096);
-        const uint32_t B = (uint32_t)std::min<uint64_t>(want, o.max_iterations - it0);
-        positions.resize(B);
-        uint64_t pos_after = pos;
-        const uint32_t *explicit_samples = nullptr;
-        if (o.progressive_sampling) { // the subset-size recurrence is serial: B samples from the host
-            prosac_samples.resize((size_t)B * kSample);
-            for (uint32_t b = 0; b < B; ++b) {
-                positions[b] = 0;
-                prosac.generate(&prosac_samples[(size_t)b * kSample]);
-            }
-            explicit_samples = prosac_samples.data();
-        } else {
-            pos_after = focal_sample_positions<kSample>(o.seed, pos, N, B, positions.data());
+        case FocalLoop<Traits>::kScore:
+            rc = be.score(loop.seeds, loop.counts, loop.sums);
+            break;
+        case FocalLoop<Traits>::kRefineScore:
+            rc = be.refine_score(loop.seeds, loop.refined, loop.rcounts, loop.rsums);
+            break;
         }
-        int rc = be.minimal(pos, positions.data(), B, models, num_models, counts, sums, explicit_samples);
         if (rc)
             return rc;
-        st.iterations_evaluated += B;
-        // pass 1: the hypotheses that improve best_minimal_* (independent of the local optimisations)
-        imps.clear();
-        seeds.clear();
-        for (uint32_t b = 0; b < B; ++b) {
-            int last = -1;
-            for (uint32_t m = 0; m < num_models[b]; ++m) {
-                const size_t h = (size_t)b * kMaxModels + m;
-                const double sc = Traits::finish(sums[h], counts[h], N, o, models[h].f);
-                const bool more = counts[h] > best_min_inl, better = sc < best_min_score;
-                if (!(more || better))
-                    continue;
-                if (more)
-                    best_min_inl = counts[h];
-                if (better)
-                    best_min_score = sc;
-                imps.push_back(Improving{b, m, counts[h], sc, -1});
-                last = (int)imps.size() - 1;
-            }
-            if (last >= 0) {
-                imps[last].job = (int)seeds.size();
-                seeds.push_back(models[(size_t)b * kMaxModels + imps[last].slot]);
-            }
-        }
-        if (!seeds.empty()) { // the local optimisations of the batch and the scores of their results: one device round trip
-            rc = be.refine_score(seeds, refined, rcounts, rsums);
-            if (rc)
-                return rc;
-        }
-        // pass 2: the loop itself
-        size_t a = 0;
-        for (uint32_t b = 0; b < B; ++b) {
-            if (st.iterations > o.min_iterations && st.iterations > dyn_max) {
-                stopped = true;
-                break;
-            }
-            st.hypotheses += num_models[b];
-            for (; a < imps.size() && imps[a].iter == b; ++a) {
-                const Improving &im = imps[a];
-                if (im.score < st.model_score) {
-                    st.model_score = im.score;
-                    *best = models[(size_t)b * kMaxModels + im.slot];
-                    st.num_inliers = im.count;
-                }
-                if (im.job >= 0)
-                    after_lo(refined[im.job], rcounts[im.job], rsums[im.job]);
-            }
-            st.iterations++;
-        }
-        pos = pos_after;
     }
-    // final polish (ransac_impl.h:190-198): model_score is not updated
-    seeds.assign(1, *best);
-    int rc = be.refine_score(seeds, refined, rcounts, rsums);
-    if (rc)
-        return rc;
-    st.refinements++;
-    const double rsc = Traits::finish(rsums[0], rcounts[0], N, o, refined[0].f);
-    if (rsc < st.model_score) {
-        *best = refined[0];
-        st.num_inliers = rcounts[0];
-    }
-    return 0;
 }
 
 // ransac_pnpf: FocalAbsolutePoseEstimator
