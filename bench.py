@@ -841,14 +841,43 @@ def run_focal_estimators(args, ranks, P, synth):
 
         n8, n16 = max(256, 16 * reps), max(768, 32 * reps)  # (0.1 - 0.2 s each: a shorter run measures the threads' start-up)
         elapsed8, elapsed16 = threaded(8, n8), threaded(16, n16)
-        table = ranks.gather([elapsed, float(sum(o[1]["hypotheses"] for o in outs)), elapsed8, elapsed16])
+
+        # the same problems through pl_estimate_batch (round 5, driver_focal_group.inc): groups of problems advance in lock-step
+        # through ONE launch sequence.  Descriptors marshalled outside the clock (the camera of a pnpf item is in / out: a fresh batch
+        # per run); the first `reps` results are compared with the single calls above - every field, bit for bit.
+        def item(j):
+            if name == "pnpf_2000":
+                d = da[j % 4]
+                return ("abs", d["p2d"], d["p3d"], d["camera"], oa(j))
+            d = dr[j % 4]
+            return ("shared_focal", d["x1"], d["x2"], pp(d), orl(j))
+
+        nb = max(1024, 48 * reps)
+        P.Batch([item(j) for j in range(nb)]).run(8)  # (the workers' buffers exist)
+        bt = P.Batch([item(j) for j in range(nb)])
+        ranks.barrier()
+        t1 = time.perf_counter()
+        bt.run(8)
+        ranks.barrier()
+        elapsed_b = time.perf_counter() - t1
+        outs_b = bt.results()
+        same_b = 0
+        for (m1, i1), (m2, i2) in zip(outs, outs_b):
+            c1, c2 = (m1.camera, m2.camera) if name == "pnpf_2000" else (m1.camera1, m2.camera1)
+            same_b += bool(all(i1[k] == i2[k] for k in ("iterations", "refinements", "num_inliers", "hypotheses", "model_score"))
+                           and np.array_equal(np.asarray(i1["inliers"]), np.asarray(i2["inliers"])) and list(c1.params) == list(c2.params)
+                           and np.array_equal(np.r_[m1.pose.q, m1.pose.t], np.r_[m2.pose.q, m2.pose.t]))
+        table = ranks.gather([elapsed, float(sum(o[1]["hypotheses"] for o in outs)), elapsed8, elapsed16, elapsed_b, float(same_b)])
         if ranks.rank != 0:
             continue
         t_max = float(table[:, 0].max())
         r = {"problems_per_s": ranks.world * reps / t_max, "ms_per_problem": 1e3 * t_max / reps,
              "problems_per_s_8_threads": ranks.world * n8 / float(table[:, 2].max()),
              "problems_per_s_16_threads": ranks.world * n16 / float(table[:, 3].max()),
+             "problems_per_s_batch": ranks.world * nb / float(table[:, 4].max()), "batch_problems": nb,
+             "batch_identical_to_single_calls": f"{int(table[:, 5].min())}/{reps}",
              "hyp_per_s": float(table[:, 1].sum()) / t_max, "problems": reps, "correspondences": n}
+        ok = ok and int(table[:, 5].min()) == reps
         if not args.no_parity:
             import oracle_lib as O
 
@@ -1048,6 +1077,8 @@ def main():
             cfg[n + "_ms_per_problem"] = r["ms_per_problem"]
             cfg[n + "_problems_per_s_8_threads"] = r["problems_per_s_8_threads"]
             cfg[n + "_problems_per_s_16_threads"] = r["problems_per_s_16_threads"]
+            cfg[n + "_problems_per_s_batch"] = r["problems_per_s_batch"]
+            cfg[n + "_batch_identical_to_single_calls"] = r["batch_identical_to_single_calls"]
             cfg[n + "_parity_ok"] = r.get("parity", {}).get("ok")
             if "cpu_port_problems_per_s" in r:
                 cfg[n + "_cpu_port_problems_per_s"] = r["cpu_port_problems_per_s"]

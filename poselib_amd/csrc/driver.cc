@@ -1894,6 +1894,7 @@ double normalization_of(const double *x1, const double *x2, size_t n, bool centr
 #include "driver_focal.inc"
 #include "driver_sfocal.inc"
 #include "driver_group.inc"
+#include "driver_focal_group.inc"
 
 } // namespace
 
@@ -2975,6 +2976,26 @@ void run_group_job(std::vector<GroupItem *> &items, bool resume) {
         g_t_fallback_ns += (uint64_t)((now_s() - t2) * 1e9);
     }
 }
+// one group of focal-length problems (driver_focal_group.inc); whatever it could not finish goes through the single-problem entry points
+void run_focal_group_job(std::vector<FocalGroupItem *> &items) {
+    Context *c;
+    int rc = get_context(&c);
+    if (rc == PL_OK)
+        rc = items[0]->est == 0 ? run_focal_group<PnpfGroupPolicy>(c, items.data(), (uint32_t)items.size())
+                                : run_focal_group<SFocalGroupPolicy>(c, items.data(), (uint32_t)items.size());
+    if (rc != PL_OK)
+        note_worker_error(); // (the items are retried one by one below; the reason is kept for the caller)
+    for (FocalGroupItem *g : items)
+        if (rc != PL_OK || g->fallback) {
+            if (g->est == 0) // (the camera is in / out: the group may have written the loop's focal length already)
+                for (int i = 0; i < g->item->camera1->num_params && i < 12; ++i)
+                    g->item->camera1->params[i] = g->cam.p[i];
+            g->item->status = run_item(*g->item);
+            ++g_n_fallback;
+            if (g->item->status != PL_OK)
+                note_worker_error();
+        }
+}
 } // namespace
 
 int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int group_size) {
@@ -3063,12 +3084,15 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     static const bool no_groups = std::getenv("POSELIB_AMD_NO_GROUPS") != nullptr; // diagnostic: every item on its own
     // problems the group launches cover, by kind and in descending size (neighbours in a group then have similar
     // grids); everything else is a job of its own
-    std::vector<size_t> by_kind[4], solo;
+    std::vector<size_t> by_kind[4], by_focal[2], solo;
     std::vector<std::function<void()>> jobs;
     for (size_t i = 0; i < count; ++i) {
         items[i].status = PL_OK;
+        int est;
         if (!no_groups && group_eligible(items[i]))
             by_kind[items[i].kind].push_back(i);
+        else if (!no_groups && (est = focal_group_estimator(items[i])) >= 0)
+            by_focal[est].push_back(i); // the two focal-length estimators: their own lock-step groups (driver_focal_group.inc)
         else
             solo.push_back(i);
     }
@@ -3146,6 +3170,39 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
         std::vector<GroupItem *> *grp = &group_ptrs[gi];
         jobs.emplace_back([grp] { run_group_job(*grp, false); });
         stage_fns.emplace_back([grp] { group_stage_in(grp->data(), (uint32_t)grp->size()); });
+    }
+    // the focal-length estimators: groups of up to kFocalGroupMax / kSFocalGroupMax problems of similar size, at least one group per worker
+    std::vector<std::vector<FocalGroupItem>> focal_groups;
+    for (int est = 0; est < 2; ++est) {
+        std::vector<size_t> &v = by_focal[est];
+        if (v.empty())
+            continue;
+        std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].n > items[b].n; });
+        const long focal_env = [] { // POSELIB_AMD_FOCAL_GROUP: fixed group size (experiments; read per call so that one process can sweep it)
+            const char *e = std::getenv("POSELIB_AMD_FOCAL_GROUP");
+            return e ? std::min<long>(std::max<long>(std::atol(e), 1), 256) : 0L;
+        }();
+        const size_t cap = focal_env ? (size_t)focal_env : (est == 0 ? kFocalGroupMax : kSFocalGroupMax);
+        const size_t per = focal_env ? cap : std::min(cap, std::max<size_t>(1, (v.size() + workers - 1) / workers));
+        const size_t ngrp = (v.size() + per - 1) / per;
+        const size_t gsize = (v.size() + ngrp - 1) / ngrp;
+        for (size_t at = 0; at < v.size(); at += gsize) {
+            focal_groups.emplace_back();
+            for (size_t j = at; j < std::min(v.size(), at + gsize); ++j) {
+                FocalGroupItem g;
+                g.item = &items[v[j]];
+                g.est = est;
+                focal_groups.back().push_back(g);
+            }
+        }
+    }
+    std::vector<std::vector<FocalGroupItem *>> focal_ptrs(focal_groups.size());
+    for (size_t gi = 0; gi < focal_groups.size(); ++gi) {
+        for (FocalGroupItem &g : focal_groups[gi])
+            focal_ptrs[gi].push_back(&g);
+        std::vector<FocalGroupItem *> *grp = &focal_ptrs[gi];
+        jobs.emplace_back([grp] { run_focal_group_job(*grp); });
+        stage_fns.emplace_back(); // (nothing to stage)
     }
     for (size_t i : solo) {
         jobs.emplace_back([items, i] {

@@ -34,8 +34,10 @@ namespace {
 // launch and occupied 63 CUs for a batch of 1001 samples; the two kernels take 0.21 + 0.33 ms.
 constexpr int kStageN = kP35WorkDoubles, kStageF0 = kStageN + 60, kStageMx = kStageF0 + 1, kStageDoubles = kStageMx + kP35Rows;
 
-__global__ __launch_bounds__(64) void k_focal_setup(FocalGenArgs g) {
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+// (the kernels' bodies are functions of (arguments, block index): the single-problem kernels pass their own argument block, the
+// group kernels - blockIdx.y = member of the group - the member's entry of a device-resident table, read before any store)
+__device__ __forceinline__ void focal_setup_body(const FocalGenArgs &g, uint32_t blk) {
+    const uint32_t it = blk * 64 + threadIdx.x;
     if (it >= g.num_iters)
         return;
     double xs[8];
@@ -79,6 +81,11 @@ __global__ __launch_bounds__(64) void k_focal_setup(FocalGenArgs g) {
         g.stage[(size_t)(kStageN + e) * B + it] = N[e];
     g.stage[(size_t)kStageF0 * B + it] = f0;
 }
+__global__ __launch_bounds__(64) void k_focal_setup(FocalGenArgs g) { focal_setup_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64) void k_focal_setup_g(const FocalGenArgs *__restrict__ gs) {
+    const FocalGenArgs g = gs[blockIdx.y];
+    focal_setup_body(g, blockIdx.x);
+}
 
 __device__ __forceinline__ double readlane_f64(double v, int l) { // (l uniform)
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -98,10 +105,10 @@ __device__ __forceinline__ double readlane_f64(double v, int l) { // (l uniform)
 constexpr int kSolveWaves = 4, kFinRoots = 10; // (the action matrix is 10 x 10: at most 10 roots)
 constexpr int kSolveLds = 100 + 100 * kFinRoots; // action matrix | working copies of the roots, element-major over the roots
 static_assert(eig_wave_doubles(10) + kP35ActionDoubles <= 100 * kFinRoots, "the eigenvalue workspace and E live in the roots' region");
-__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_focal_solve(FocalGenArgs g) {
+__device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t blk) {
     __shared__ double s_solve[kSolveWaves][kSolveLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blockIdx.x * kSolveWaves + wave; // (wave-uniform)
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
     const size_t B = g.num_iters;
@@ -217,12 +224,19 @@ __global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_e
             g.host_num_models[it] = m;
     }
 }
+__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_focal_solve(FocalGenArgs g) {
+    focal_solve_body(g, blockIdx.x);
+}
+__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_focal_solve_g(const FocalGenArgs *__restrict__ gs) {
+    const FocalGenArgs g = gs[blockIdx.y];
+    focal_solve_body(g, blockIdx.x);
+}
 
 constexpr int kFocalScoreThreads = 256;
 
-__global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score(FocalScoreArgs a) {
+__device__ __forceinline__ void focal_score_body(const FocalScoreArgs &a, uint32_t blk) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = blockIdx.x * (kFocalScoreThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t slot = blk * (kFocalScoreThreads / 64) + (threadIdx.x >> 6);
     if (slot >= a.num_slots)
         return;
     if (a.num_models && (slot % kFocalMaxModels) >= a.num_models[slot / kFocalMaxModels]) { // (wave-uniform)
@@ -266,6 +280,11 @@ __global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score(FocalScoreAr
         a.sums[slot] = sum;
     }
 }
+__global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score(FocalScoreArgs a) { focal_score_body(a, blockIdx.x); }
+__global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score_g(const FocalScoreArgs *__restrict__ as) {
+    const FocalScoreArgs a = as[blockIdx.y];
+    focal_score_body(a, blockIdx.x);
+}
 
 // The same score by ONE WORKGROUP per model (round 4): wavefronts 1 .. 3 evaluate rounds of 192 correspondences into one of two LDS
 // buffers (the inliers' squared residuals, zeros for the others: x + 0.0 = x), lane 0 of wavefront 0 adds the previous round with the
@@ -273,11 +292,12 @@ __global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score(FocalScoreAr
 // (one wavefront evaluating 64 correspondences at a time and adding its inliers through v_readlane), which is the length of the
 // launches that score the few refined models of a local optimisation.
 constexpr int kScoreProd = kFocalScoreThreads - 64;
-__global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score_wg(FocalScoreArgs a) {
+__device__ __forceinline__ void focal_score_wg_body(const FocalScoreArgs &a, uint32_t slot) {
     __shared__ __attribute__((aligned(16))) double s_terms[2][kScoreProd];
     __shared__ uint32_t s_cnt[kFocalScoreThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t slot = blockIdx.x;
+    if (slot >= a.num_slots) // (uniform; group launches: the grid is the largest member's)
+        return;
     if (a.num_models && (slot % kFocalMaxModels) >= a.num_models[slot / kFocalMaxModels]) { // (uniform)
         if (threadIdx.x == 0) { // (the host never reads garbage - and no fill dispatches in front of this kernel)
             a.counts[slot] = 0;
@@ -332,10 +352,14 @@ __global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score_wg(FocalScor
         a.sums[slot] = sum;
     }
 }
+__global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score_wg(FocalScoreArgs a) { focal_score_wg_body(a, blockIdx.x); }
+__global__ __launch_bounds__(kFocalScoreThreads) void k_focal_score_wg_g(const FocalScoreArgs *__restrict__ as) {
+    const FocalScoreArgs a = as[blockIdx.y];
+    focal_score_wg_body(a, blockIdx.x);
+}
 
-__global__ void k_focal_mask(const double *x, const double *y, const double *X, const double *Y, const double *Z, uint32_t n,
-                             FocalModel m, double thr2, uint8_t *mask, uint8_t *host_mask) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void focal_mask_body(const double *x, const double *y, const double *X, const double *Y, const double *Z, uint32_t n,
+                                                const FocalModel &m, double thr2, uint8_t *mask, uint8_t *host_mask, uint32_t i) {
     if (i >= n)
         return;
     double R[9];
@@ -344,6 +368,14 @@ __global__ void k_focal_mask(const double *x, const double *y, const double *X, 
     mask[i] = v;
     if (host_mask)
         host_mask[i] = v;
+}
+__global__ void k_focal_mask(const double *x, const double *y, const double *X, const double *Y, const double *Z, uint32_t n,
+                             FocalModel m, double thr2, uint8_t *mask, uint8_t *host_mask) {
+    focal_mask_body(x, y, X, Y, Z, n, m, thr2, mask, host_mask, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void k_focal_mask_g(const FocalMaskArgs *__restrict__ as) {
+    const FocalMaskArgs a = as[blockIdx.y];
+    focal_mask_body(a.a[0], a.a[1], a.a[2], a.a[3], a.a[4], a.n, a.model, a.thr2, a.mask, a.host_mask, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 } // namespace
@@ -357,6 +389,32 @@ hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
         return hipErrorInvalidValue;
     k_focal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
     k_focal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+    return hipGetLastError();
+}
+// ---- group launches (driver_focal_group.inc): blockIdx.y = member, the grid's x extent = the largest member's; `args` is a
+// device-resident table of G entries.  Same bodies as the single-problem kernels: a member's results do not depend on its group.
+hipError_t launch_focal_generate_g(const FocalGenArgs *args, uint32_t G, uint32_t max_iters, hipStream_t stream) {
+    if (G == 0 || max_iters == 0)
+        return hipSuccess;
+    k_focal_setup_g<<<dim3((max_iters + 63u) / 64u, G), dim3(64), 0, stream>>>(args);
+    k_focal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+    return hipGetLastError();
+}
+hipError_t launch_focal_score_g(const FocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream) {
+    if (G == 0 || max_slots == 0)
+        return hipSuccess;
+    if (workgroup_per_model) {
+        k_focal_score_wg_g<<<dim3(max_slots, G), dim3(kFocalScoreThreads), 0, stream>>>(args);
+        return hipGetLastError();
+    }
+    constexpr uint32_t per_block = kFocalScoreThreads / 64;
+    k_focal_score_g<<<dim3((max_slots + per_block - 1) / per_block, G), dim3(kFocalScoreThreads), 0, stream>>>(args);
+    return hipGetLastError();
+}
+hipError_t launch_focal_mask_g(const FocalMaskArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream) {
+    if (G == 0 || max_n == 0)
+        return hipSuccess;
+    k_focal_mask_g<<<dim3((max_n + 255u) / 256u, G), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
 // minimal problems given explicitly (pl_p35pf, pl_solve_focal_batch): in = count x [x 4 x 2 | X 4 x 3]; every solution is kept.

@@ -409,7 +409,18 @@ struct FocalScoreArgs {
     double *sums;     // [num_slots]
 };
 
+struct FocalMaskArgs { // get_inliers of one member of a group (k_focal_mask_g)
+    const double *a[5];
+    uint32_t n, pad;
+    FocalModel model;
+    double thr2;
+    uint8_t *mask, *host_mask; // device mask (the final bundle reads it) and its pinned mirror (optional)
+};
+
 #if defined(__HIPCC__)
+hipError_t launch_focal_generate_g(const FocalGenArgs *args, uint32_t G, uint32_t max_iters, hipStream_t stream);
+hipError_t launch_focal_score_g(const FocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream);
+hipError_t launch_focal_mask_g(const FocalMaskArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream);
 hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream);
 hipError_t launch_focal_score(const FocalScoreArgs &a, hipStream_t stream);
 size_t focal_stage_bytes(uint32_t num_iters);

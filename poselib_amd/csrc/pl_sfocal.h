@@ -167,11 +167,13 @@ struct SFocalGenArgs {
     double *stage;             // sfocal_stage_bytes(num_iters): workspace of the three generator kernels (sfocal.hip)
     const double *explicit_in; // optional: num_iters x 36 minimal problems [x1 6 x 3 | x2 6 x 3] instead of samples of the points
 };
+struct SFocalLMTask;
 struct SFocalScoreArgs {
     const double *a[4];
     uint32_t n;
     const FocalModel *models;
     const uint32_t *num_models; // per group of kSFocalMaxModels slots; nullptr: every slot holds a model
+    const SFocalLMTask *lm_tasks; // optional: slot s = the model k_sfocal_lm left in task s (a skipped task still holds its seed) instead of models
     uint32_t num_slots;
     double thr2;
     uint32_t *counts; // [num_slots]
@@ -191,6 +193,9 @@ struct SFocalLMTask {
 };
 
 #if defined(__HIPCC__)
+hipError_t launch_sfocal_generate_g(const SFocalGenArgs *args, uint32_t G, uint32_t max_iters, hipStream_t stream);
+hipError_t launch_sfocal_score_g(const SFocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream);
+hipError_t launch_sfocal_mask_g(const FocalMaskArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream); // (FocalMaskArgs.a[4] unused)
 hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream);
 hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream);
 size_t sfocal_stage_bytes(uint32_t num_iters);

@@ -40,8 +40,10 @@ namespace {
 // problems filled the device, which bounded the throughput of several host threads at 1.4 k problems/s).
 constexpr int kStC = 0, kStNb = 300, kStX = 327, kStDoubles = 363;
 
-__global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+// (the kernels' bodies are functions of (arguments, block index): the single-problem kernels pass their own argument block, the
+// group kernels - blockIdx.y = member of the group - the member's entry of a device-resident table, read before any store)
+__device__ __forceinline__ void sfocal_setup_body(const SFocalGenArgs &g, uint32_t blk) {
+    const uint32_t it = blk * 64 + threadIdx.x;
     if (it >= g.num_iters)
         return;
     Vec3 x1[6], x2[6];
@@ -76,6 +78,11 @@ __global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) {
                                      st[(size_t)(kStX + 20 + 3 * k) * B] = x2[k].z;
     }
 }
+__global__ __launch_bounds__(64) void k_sfocal_setup(SFocalGenArgs g) { sfocal_setup_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64) void k_sfocal_setup_g(const SFocalGenArgs *__restrict__ gs) {
+    const SFocalGenArgs g = gs[blockIdx.y];
+    sfocal_setup_body(g, blockIdx.x);
+}
 
 // k_sfocal_solve: one WAVEFRONT = one sample, three stages in one launch.
 //   companion    six_companion_wave (pl_eigen_wave.h): Gaussian elimination of the w^2 part with complete pivoting, the 10 x 10 system
@@ -91,10 +98,10 @@ constexpr int kSolveWaves = 2, kFinRoots = 8, kMaxRoots = 16; // the roots go th
 constexpr int kFinC = 0, kFinA = 300, kFinNb = kFinA + 100 * kFinRoots, kFinX = kFinNb + 27, kFinTmp = kFinX + 36,
               kFinDoubles = kFinTmp + 7 * kMaxRoots;
 static_assert(eig_wave_doubles(15) <= 100 * kFinRoots && 225 + 300 + 100 + 150 + 16 <= 100 * kFinRoots, "the row reduction and the eigenvalue workspace live in the roots' region");
-__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sfocal_solve(SFocalGenArgs g) {
+__device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32_t blk) {
     __shared__ double s_fin[kSolveWaves][kFinDoubles];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blockIdx.x * kSolveWaves + wave; // (wave-uniform)
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
     const size_t B = g.num_iters;
@@ -189,6 +196,13 @@ __global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_e
             g.host_num_models[it] = m;
     }
 }
+__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sfocal_solve(SFocalGenArgs g) {
+    sfocal_solve_body(g, blockIdx.x);
+}
+__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sfocal_solve_g(const SFocalGenArgs *__restrict__ gs) {
+    const SFocalGenArgs g = gs[blockIdx.y];
+    sfocal_solve_body(g, blockIdx.x);
+}
 
 __device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -198,14 +212,29 @@ __device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-unif
 
 constexpr int kSFocalScoreThreads = 256;
 
-__global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score(SFocalScoreArgs a) {
+// the model of a score slot: models[slot], or the parameters k_sfocal_lm left in task `slot` (refined - or the seed it was given when
+// refine_model returned without touching the model, relative_pose.cc:187-189)
+__device__ __forceinline__ FocalModel sfocal_score_model(const SFocalScoreArgs &a, uint32_t slot) {
+    if (!a.lm_tasks)
+        return a.models[slot];
+    const SFocalLMTask &t = a.lm_tasks[slot];
+    FocalModel m;
+    for (int i = 0; i < 4; ++i)
+        m.q[i] = t.params[i];
+    for (int i = 0; i < 3; ++i)
+        m.t[i] = t.params[4 + i];
+    m.f = t.params[kSFocalFocalSlot];
+    return m;
+}
+
+__device__ __forceinline__ void sfocal_score_body(const SFocalScoreArgs &a, uint32_t blk) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = blockIdx.x * (kSFocalScoreThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t slot = blk * (kSFocalScoreThreads / 64) + (threadIdx.x >> 6);
     if (slot >= a.num_slots)
         return;
     if (a.num_models && (slot % kSFocalMaxModels) >= a.num_models[slot / kSFocalMaxModels])
         return; // (wave-uniform)
-    const FocalModel m = a.models[slot];
+    const FocalModel m = sfocal_score_model(a, slot);
     double F[9];
     sfocal_F_score(m, F);
     uint32_t count = 0;
@@ -229,20 +258,26 @@ __global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score(SFocalScor
         a.scores[slot] = score;
     }
 }
+__global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score(SFocalScoreArgs a) { sfocal_score_body(a, blockIdx.x); }
+__global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score_g(const SFocalScoreArgs *__restrict__ as) {
+    const SFocalScoreArgs a = as[blockIdx.y];
+    sfocal_score_body(a, blockIdx.x);
+}
 
 // The same score by ONE WORKGROUP per model (round 4; used for the few refined models of a local optimisation - a batch of
 // iterations has 60 slots per iteration of which 0.3 hold a model): wavefronts 1 .. 3 evaluate rounds of 192 correspondences into one
 // of two LDS buffers, lane 0 of wavefront 0 adds the previous round's terms with the inline-asm chain of k_lm_ordered
 // (pl_lm_chain.inc; zeros beyond n: x + 0.0 = x).
 constexpr int kSfScoreProd = kSFocalScoreThreads - 64;
-__global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score_wg(SFocalScoreArgs a) {
+__device__ __forceinline__ void sfocal_score_wg_body(const SFocalScoreArgs &a, uint32_t slot) {
     __shared__ __attribute__((aligned(16))) double s_terms[2][kSfScoreProd];
     __shared__ uint32_t s_cnt[kSFocalScoreThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t slot = blockIdx.x;
+    if (slot >= a.num_slots) // (uniform; group launches: the grid is the largest member's)
+        return;
     if (a.num_models && (slot % kSFocalMaxModels) >= a.num_models[slot / kSFocalMaxModels])
         return; // (uniform)
-    const FocalModel m = a.models[slot];
+    const FocalModel m = sfocal_score_model(a, slot);
     double F[9];
     sfocal_F_score(m, F);
     const uint32_t rounds = (a.n + (uint32_t)kSfScoreProd - 1u) / (uint32_t)kSfScoreProd;
@@ -282,10 +317,14 @@ __global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score_wg(SFocalS
         a.scores[slot] = score;
     }
 }
+__global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score_wg(SFocalScoreArgs a) { sfocal_score_wg_body(a, blockIdx.x); }
+__global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score_wg_g(const SFocalScoreArgs *__restrict__ as) {
+    const SFocalScoreArgs a = as[blockIdx.y];
+    sfocal_score_wg_body(a, blockIdx.x);
+}
 
-__global__ void k_sfocal_mask(const double *x1, const double *y1, const double *x2, const double *y2, uint32_t n, FocalModel m,
-                              double thr2, uint8_t *mask, uint8_t *host_mask) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void sfocal_mask_body(const double *x1, const double *y1, const double *x2, const double *y2, uint32_t n, const FocalModel &m,
+                                                 double thr2, uint8_t *mask, uint8_t *host_mask, uint32_t i) {
     if (i >= n)
         return;
     double F[9];
@@ -294,6 +333,14 @@ __global__ void k_sfocal_mask(const double *x1, const double *y1, const double *
     mask[i] = v;
     if (host_mask)
         host_mask[i] = v;
+}
+__global__ void k_sfocal_mask(const double *x1, const double *y1, const double *x2, const double *y2, uint32_t n, FocalModel m,
+                              double thr2, uint8_t *mask, uint8_t *host_mask) {
+    sfocal_mask_body(x1, y1, x2, y2, n, m, thr2, mask, host_mask, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void k_sfocal_mask_g(const FocalMaskArgs *__restrict__ as) {
+    const FocalMaskArgs a = as[blockIdx.y];
+    sfocal_mask_body(a.a[0], a.a[1], a.a[2], a.a[3], a.n, a.model, a.thr2, a.mask, a.host_mask, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 constexpr int kSfLMThreads = 256;
@@ -555,6 +602,32 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
         return hipErrorInvalidValue;
     k_sfocal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
     k_sfocal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+    return hipGetLastError();
+}
+// ---- group launches (driver_focal_group.inc): blockIdx.y = member, the grid's x extent = the largest member's; `args` is a
+// device-resident table of G entries.  Same bodies as the single-problem kernels: a member's results do not depend on its group.
+hipError_t launch_sfocal_generate_g(const SFocalGenArgs *args, uint32_t G, uint32_t max_iters, hipStream_t stream) {
+    if (G == 0 || max_iters == 0)
+        return hipSuccess;
+    k_sfocal_setup_g<<<dim3((max_iters + 63u) / 64u, G), dim3(64), 0, stream>>>(args);
+    k_sfocal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+    return hipGetLastError();
+}
+hipError_t launch_sfocal_score_g(const SFocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream) {
+    if (G == 0 || max_slots == 0)
+        return hipSuccess;
+    if (workgroup_per_model) {
+        k_sfocal_score_wg_g<<<dim3(max_slots, G), dim3(kSFocalScoreThreads), 0, stream>>>(args);
+        return hipGetLastError();
+    }
+    constexpr uint32_t per_block = kSFocalScoreThreads / 64;
+    k_sfocal_score_g<<<dim3((max_slots + per_block - 1) / per_block, G), dim3(kSFocalScoreThreads), 0, stream>>>(args);
+    return hipGetLastError();
+}
+hipError_t launch_sfocal_mask_g(const FocalMaskArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream) {
+    if (G == 0 || max_n == 0)
+        return hipSuccess;
+    k_sfocal_mask_g<<<dim3((max_n + 255u) / 256u, G), dim3(256), 0, stream>>>(args);
     return hipGetLastError();
 }
 // minimal problems given explicitly (pl_relpose_6pt_shared_focal, pl_solve_focal_batch): in = count x [x1 6 x 3 | x2 6 x 3].

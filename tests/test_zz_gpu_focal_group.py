@@ -1,0 +1,157 @@
+"""GPU (-m gpu): the two focal-length estimators as citizens of pl_estimate_batch (driver_focal_group.inc):
+robust.cc:47-54 (estimate_absolute_pose with estimate_focal_length) and robust.cc:366-424 (estimate_shared_focal_relative_pose)
+through ONE launch sequence per group of problems.
+
+The contract: every member's result - pose, focal length / camera, inlier mask, every field of the statistics - equals the
+single-problem entry point's BIT FOR BIT (same kernel bodies, same loop code: pl_focal.h FocalLoop), whatever the group is made
+of; the single-problem entry points are the ones tests/test_zz_gpu_focal.py / test_zz_gpu_shared_focal.py hold against the oracle.
+Items the group path does not take (PROSAC, warm starts) run on the single-problem path inside the same call.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from poselib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+STAT_KEYS = ("iterations", "refinements", "num_inliers", "hypotheses", "model_score", "inlier_ratio")
+
+
+def _same_info(tag, a, b):
+    for k in STAT_KEYS:
+        assert a[k] == b[k], (tag, k, a[k], b[k])
+    assert np.array_equal(np.asarray(a["inliers"]), np.asarray(b["inliers"])), (tag, "mask")
+
+
+def _pnpf_problem(k, n, outliers, model="SIMPLE_PINHOLE", **ransac):
+    focal = 600.0 + 37.0 * (k % 11)
+    d = synth.absolute_pose_scene(n, outliers, 21000 + k, focal=focal, noise_px=0.6)
+    f, cx, cy = d["camera"]["params"]
+    params = [1.25 * f, cx, cy] if model == "SIMPLE_PINHOLE" else [1.25 * f, 1.25 * f, cx, cy]
+    cam = {"model": model, "width": d["camera"]["width"], "height": d["camera"]["height"], "params": params}
+    opt = {"max_error": 3.0 + (k % 3), "estimate_focal_length": True, "ransac": dict({"seed": k}, **ransac)}
+    if k % 4 == 1:
+        opt["min_fov"] = 20.0
+    return ("abs", d["p2d"], d["p3d"], cam, opt)
+
+
+def _sfocal_problem(k, n, outliers, **ransac):
+    focal = 700.0 + 29.0 * (k % 13)
+    d = synth.relative_pose_scene(n, outliers, 22000 + k, focal=focal, noise_px=0.4)
+    pp = d["camera1"]["params"][1:3]
+    opt = {"max_error": 1.0 + 0.5 * (k % 3), "ransac": dict({"seed": k}, **ransac)}
+    return ("shared_focal", d["x1"], d["x2"], pp, opt)
+
+
+def _single(gpu, pr):
+    if pr[0] == "abs":
+        return gpu.estimate_absolute_pose(pr[1], pr[2], pr[3], pr[4])
+    return gpu.estimate_shared_focal_relative_pose(pr[1], pr[2], pr[3], pr[4])
+
+
+def _check_equal(tag, pr, got, ref):
+    (gm, gi), (rm, ri) = got, ref
+    _same_info(tag, gi, ri)
+    if pr[0] == "abs":
+        assert np.array_equal(np.r_[gm.pose.q, gm.pose.t], np.r_[rm.pose.q, rm.pose.t]), (tag, "pose")
+        assert list(gm.camera.params) == list(rm.camera.params), (tag, gm.camera.params, rm.camera.params)
+    else:
+        assert np.array_equal(np.r_[gm.pose.q, gm.pose.t], np.r_[rm.pose.q, rm.pose.t]), (tag, "pose")
+        assert list(gm.camera1.params) == list(rm.camera1.params) and list(gm.camera2.params) == list(rm.camera2.params), (tag, gm.camera1.params, rm.camera1.params)
+
+
+def test_pnpf_group_equals_single_calls(gpu):
+    """20 problems of 12 ... 3000 correspondences, 10 - 60 % outliers, both pinhole models, with and without min_fov, short and long runs"""
+    sizes = [12, 40, 64, 150, 256, 257, 400, 640, 900, 1200, 1500, 2000, 2000, 2500, 3000, 333, 777, 1024, 90, 1800]
+    problems = []
+    for k, n in enumerate(sizes):
+        ransac = {}
+        if k % 5 == 2:
+            ransac = {"min_iterations": 100, "max_iterations": 700}
+        if k % 5 == 4:
+            ransac = {"min_iterations": 2000}
+        problems.append(_pnpf_problem(k, n, [0.1, 0.3, 0.5, 0.6][k % 4], "PINHOLE" if k % 3 == 0 else "SIMPLE_PINHOLE", **ransac))
+    got = gpu.estimate_batch(problems, max_in_flight=2)
+    for k, pr in enumerate(problems):
+        _check_equal(("pnpf", k), pr, got[k], _single(gpu, pr))
+    # the estimate is an estimate: the focal length came in 25 % off
+    good = sum(abs(g[0].camera.params[0] - (600.0 + 37.0 * (k % 11))) < 0.05 * (600.0 + 37.0 * (k % 11)) for k, g in enumerate(got))
+    assert good >= 16, good
+
+
+def test_shared_focal_group_equals_single_calls(gpu):
+    sizes = [12, 30, 64, 150, 256, 400, 640, 900, 1200, 1500, 2000, 2000, 2500, 3000, 333, 777]
+    problems = []
+    for k, n in enumerate(sizes):
+        ransac = {}
+        if k % 5 == 2:
+            ransac = {"min_iterations": 100, "max_iterations": 900}
+        if k % 5 == 4:
+            ransac = {"min_iterations": 1500}
+        problems.append(_sfocal_problem(k, n, [0.1, 0.25, 0.4, 0.5][k % 4], **ransac))
+    got = gpu.estimate_batch(problems, max_in_flight=2)
+    for k, pr in enumerate(problems):
+        _check_equal(("sfocal", k), pr, got[k], _single(gpu, pr))
+
+
+def test_mixed_call_with_items_the_group_path_does_not_take(gpu):
+    """focal items next to the four north-star kinds, a PROSAC item and a degenerate one in the same call: everything equals its single call"""
+    problems = []
+    for k in range(6):
+        problems.append(_pnpf_problem(100 + k, 500 + 100 * k, 0.4))
+        problems.append(_sfocal_problem(100 + k, 400 + 100 * k, 0.3))
+    problems.append(_pnpf_problem(200, 600, 0.3, progressive_sampling=True))  # PROSAC: single-problem path
+    problems.append(_sfocal_problem(200, 600, 0.3, progressive_sampling=True))
+    problems.append(_pnpf_problem(201, 6, 0.0))  # fewer than sample + 4 correspondences: single-problem path
+    d = synth.absolute_pose_scene(800, 0.4, 23000)
+    problems.append(("abs", d["p2d"], d["p3d"], d["camera"], {"ransac": {"seed": 5}}))
+    d = synth.homography_scene(700, 0.4, 23001) if hasattr(synth, "homography_scene") else None
+    if d is not None:
+        problems.append(("hom", d["x1"], d["x2"], {"max_error": 2.0, "ransac": {"seed": 6}}))
+    got = gpu.estimate_batch(problems, max_in_flight=4)
+    for k, pr in enumerate(problems):
+        if pr[0] in ("abs", "shared_focal") and (pr[0] == "shared_focal" or pr[4].get("estimate_focal_length")):
+            _check_equal(("mixed", k), pr, got[k], _single(gpu, pr))
+        elif pr[0] == "abs":
+            ref = gpu.estimate_absolute_pose(pr[1], pr[2], pr[3], pr[4])
+            _same_info(("mixed", k), got[k][1], ref[1])
+        else:
+            ref = gpu.estimate_homography(pr[1], pr[2], pr[3])
+            _same_info(("mixed", k), got[k][1], ref[1])
+            assert np.array_equal(got[k][0], ref[0])
+
+
+def test_group_size_does_not_change_results(gpu):
+    """the same 24 problems in one call with 1 worker (one group of 24) and with 8 workers (groups of 3): identical"""
+    problems = [_pnpf_problem(300 + k, 300 + 70 * k, [0.2, 0.5][k % 2]) for k in range(24)]
+    a = gpu.estimate_batch(problems, max_in_flight=1)
+    b = gpu.estimate_batch(problems, max_in_flight=8)
+    for k in range(24):
+        _same_info(("size", k), a[k][1], b[k][1])
+        assert list(a[k][0].camera.params) == list(b[k][0].camera.params)
+        assert np.array_equal(np.r_[a[k][0].pose.q, a[k][0].pose.t], np.r_[b[k][0].pose.q, b[k][0].pose.t])
+
+
+def test_no_groups_switch_takes_the_single_problem_path():
+    """POSELIB_AMD_NO_GROUPS=1 (diagnostic) in a fresh process: same results as the grouped call of this process"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, poselib_amd as P\n"
+        "from test_zz_gpu_focal_group import _pnpf_problem, _sfocal_problem\n"
+        "pr = [_pnpf_problem(400 + k, 500 + 50 * k, 0.4) for k in range(4)] + [_sfocal_problem(400 + k, 500 + 50 * k, 0.3) for k in range(4)]\n"
+        "got = P.estimate_batch(pr)\n"
+        "print(json.dumps([[g[1][k] for k in ('iterations', 'refinements', 'num_inliers', 'model_score')] + [float(x) for x in (g[0].camera.params if hasattr(g[0], 'camera') else g[0].camera1.params)] for g in got]))\n"
+    ) % (root, os.path.join(root, "tests"))
+    outs = []
+    for env_extra in ({}, {"POSELIB_AMD_NO_GROUPS": "1"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
