@@ -18,6 +18,7 @@
 #include "pl_kernels.h"
 #include "pl_solver_p35pf.h"
 #include "pl_eigen_wave.h"
+#include "pl_eigen_packed.h"
 #include "pl_lm_chain.inc"
 #include <algorithm>
 #include <atomic>
@@ -105,16 +106,29 @@ __device__ __forceinline__ double readlane_f64(double v, int l) { // (l uniform)
 constexpr int kSolveWaves = 4, kFinRoots = 10; // (the action matrix is 10 x 10: at most 10 roots)
 constexpr int kSolveLds = 100 + 100 * kFinRoots; // action matrix | working copies of the roots, element-major over the roots
 static_assert(eig_wave_doubles(10) + kP35ActionDoubles <= 100 * kFinRoots, "the eigenvalue workspace and E live in the roots' region");
-__device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_solve[kSolveWaves][kSolveLds];
+// Round 5: the solve stage as THREE kernels over a per-sample record in the workspace (sample-major, behind the element-major rows):
+//   [action matrix 100 | eigenvalues 10 | ok | number of real eigenvalues]
+//   k_focal_elim    one wavefront = one sample: the elimination, the action matrix
+//   k_focal_eig     one wavefront = FOUR samples, 16 lanes each: the eigenvalues (pl_eigen_packed.h).  Inside one kernel every wavefront
+//                   iterated on its own matrix with <= 10 lanes at work and every scalar of the iteration computed 64 times - 41 % of the
+//                   kernel's time, its vector ALUs 70 % busy; giving the four matrices of a workgroup to one of its wavefronts (three
+//                   waiting at a barrier) was slower still (5.8 -> 7.0 ms per 64 k samples): the packed iteration wants many
+//                   wavefronts per SIMD, which a kernel of its own has (18 KB of LDS per 16 samples)
+//   k_focal_roots   one wavefront = one sample, one lane per root: null vector, pose, focal length; the estimator's filter
+constexpr int kActDoubles = 112, kActEv = 100, kActOk = 110, kActRoots = 111;
+__device__ __forceinline__ double *focal_act(const FocalGenArgs &g, uint32_t it) {
+    return g.stage + (size_t)kStageDoubles * g.num_iters + (size_t)it * kActDoubles;
+}
+__device__ __forceinline__ void focal_elim_body(const FocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_E[kSolveWaves][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
     const size_t B = g.num_iters;
     const double *stage = g.stage;
-    double *base = s_solve[wave], *eig = base + 100, *E = eig + eig_wave_doubles(10);
-    uint32_t m = 0;
+    double *E = s_E[wave];
+    double *act = focal_act(g, it);
     bool ok = true;
     { // ---- elimination
         const int c = lane < kP35Cols ? lane : kP35Cols - 1; // (lanes 35..63 shadow the last column: no divergence, never read)
@@ -176,18 +190,53 @@ __device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t
             }
         }
     }
-    if (ok) {
-        // ---- action matrix (kept for the roots) and a copy for the eigenvalue iteration, which destroys it
+    if (ok) { // ---- the action matrix
         PL_WAVE_SYNC();
         for (int e = lane; e < 100; e += 64) {
             const int k = e / 10, j = e - 10 * k;
             const int sh = kP35Shifted[k];
-            const double v = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[e]; // p35pf_action_entry
-            base[e] = v;
-            eig[e] = v;
+            act[e] = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[e]; // p35pf_action_entry
         }
-        const int nroots = pl_real_eigenvalues_wave<10>(eig, 1e-8, lane);
-        const double ev = lane < nroots ? eig[100 + 30 + lane] : 0.0;
+    }
+    if (lane == 0)
+        act[kActOk] = ok ? 1.0 : 0.0;
+}
+constexpr int kEigWaves = 4, kEigLds = 144; // (eig_wave_doubles(10) = 140, padded)
+static_assert(eig_wave_doubles(10) <= kEigLds, "a group's matrix and workspace");
+__device__ __forceinline__ void focal_eig_body(const FocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_eig[kEigWaves][4][kEigLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+    const uint32_t it = (blk * kEigWaves + wave) * 4u + grp;
+    const bool alive = it < g.num_iters;
+    double *act = focal_act(g, alive ? it : 0u);
+    const bool ok = alive && act[kActOk] != 0.0;
+    double *mine = s_eig[wave][grp];
+    if (ok)
+        for (int e = gl; e < 100; e += 16)
+            mine[e] = act[e];
+    EigWave4<10> cx{mine, gl, lane};
+    const int nr = pl_real_eigenvalues_packed<10>(cx, ok, 1e-8);
+    if (ok && gl < nr)
+        act[kActEv + gl] = cx.out(gl);
+    if (alive && gl == 0)
+        act[kActRoots] = ok ? (double)nr : 0.0;
+}
+__device__ __forceinline__ void focal_roots_body(const FocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_solve[kSolveWaves][kSolveLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
+        return;
+    const size_t B = g.num_iters;
+    const double *stage = g.stage;
+    const double *act = focal_act(g, it);
+    double *base = s_solve[wave];
+    uint32_t m = 0;
+    const int nroots = (int)act[kActRoots]; // (0: degenerate sample, or no real eigenvalue)
+    if (nroots > 0) {
+        for (int e = lane; e < 100; e += 64)
+            base[e] = act[e];
+        const double ev = lane < nroots ? act[kActEv + lane] : 0.0;
         PL_WAVE_SYNC();
         // ---- roots
         bool valid = false;
@@ -224,12 +273,21 @@ __device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t
             g.host_num_models[it] = m;
     }
 }
-__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_focal_solve(FocalGenArgs g) {
-    focal_solve_body(g, blockIdx.x);
-}
-__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_focal_solve_g(const FocalGenArgs *__restrict__ gs) {
+#define PL_SOLVE_ATTR __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ PL_SOLVE_ATTR void k_focal_elim(FocalGenArgs g) { focal_elim_body(g, blockIdx.x); }
+__global__ PL_SOLVE_ATTR void k_focal_elim_g(const FocalGenArgs *__restrict__ gs) {
     const FocalGenArgs g = gs[blockIdx.y];
-    focal_solve_body(g, blockIdx.x);
+    focal_elim_body(g, blockIdx.x);
+}
+__global__ __launch_bounds__(64 * kEigWaves) void k_focal_eig(FocalGenArgs g) { focal_eig_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64 * kEigWaves) void k_focal_eig_g(const FocalGenArgs *__restrict__ gs) {
+    const FocalGenArgs g = gs[blockIdx.y];
+    focal_eig_body(g, blockIdx.x);
+}
+__global__ PL_SOLVE_ATTR void k_focal_roots(FocalGenArgs g) { focal_roots_body(g, blockIdx.x); }
+__global__ PL_SOLVE_ATTR void k_focal_roots_g(const FocalGenArgs *__restrict__ gs) {
+    const FocalGenArgs g = gs[blockIdx.y];
+    focal_roots_body(g, blockIdx.x);
 }
 
 constexpr int kFocalScoreThreads = 256;
@@ -380,7 +438,7 @@ __global__ void k_focal_mask_g(const FocalMaskArgs *__restrict__ as) {
 
 } // namespace
 
-size_t focal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)kStageDoubles * num_iters; }
+size_t focal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)(kStageDoubles + kActDoubles) * num_iters; }
 
 hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
@@ -388,7 +446,9 @@ hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
     if (!g.stage)
         return hipErrorInvalidValue;
     k_focal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
-    k_focal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+    k_focal_elim<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+    k_focal_eig<<<dim3((g.num_iters + 4 * kEigWaves - 1) / (4 * kEigWaves)), dim3(64 * kEigWaves), 0, stream>>>(g);
+    k_focal_roots<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     return hipGetLastError();
 }
 // ---- group launches (driver_focal_group.inc): blockIdx.y = member, the grid's x extent = the largest member's; `args` is a
@@ -397,7 +457,9 @@ hipError_t launch_focal_generate_g(const FocalGenArgs *args, uint32_t G, uint32_
     if (G == 0 || max_iters == 0)
         return hipSuccess;
     k_focal_setup_g<<<dim3((max_iters + 63u) / 64u, G), dim3(64), 0, stream>>>(args);
-    k_focal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+    k_focal_elim_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+    k_focal_eig_g<<<dim3((max_iters + 4 * kEigWaves - 1) / (4 * kEigWaves), G), dim3(64 * kEigWaves), 0, stream>>>(args);
+    k_focal_roots_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
     return hipGetLastError();
 }
 hipError_t launch_focal_score_g(const FocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream) {

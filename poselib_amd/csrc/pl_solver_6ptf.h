@@ -354,6 +354,22 @@ PL_HD int six_eigenvalues(const SixWork &T, double *ev /* 15 */) {
     for (int e = 0; e < 225; ++e)
         if (!isfinite(T[e]))
             return 0; // (a vanishing pivot: the balancing below would not terminate on an infinite entry)
+#if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
+    { // tests/hostmath: the packed balancing (pl_eigen_packed.h) on a copy, every element compared
+        double shadow[225 + 60];
+        for (int e = 0; e < 225; ++e)
+            shadow[e] = T[e];
+        EigFlatHost<15> cx{shadow};
+        pl_balance_pow2_packed<15>(cx, true);
+        pl_balance_pow2<15>(T);
+        bool same = true;
+        for (int e = 0; e < 225; ++e)
+            same = same && std::memcmp(&shadow[e], &T[e], sizeof(double)) == 0;
+        pl_eig_shadow_counters[2]++;
+        pl_eig_shadow_counters[3] += same ? 0 : 1;
+        return pl_real_eigenvalues<15>(T, ev, 1e-8);
+    }
+#endif
     pl_balance_pow2<15>(T);
     return pl_real_eigenvalues<15>(T, ev, 1e-8);
 }

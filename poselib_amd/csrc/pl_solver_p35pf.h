@@ -241,7 +241,35 @@ template <int ROWS, int COLS> PL_HD void complement_basis_indexed(double *qr /* 
 #ifndef PL_EIG_MARK
 #define PL_EIG_MARK() // (scripts/exp/p35_phases.cc: cycle counter between the Hessenberg reduction and the QR iteration)
 #endif
-template <int n, class Arr> PL_HD int pl_real_eigenvalues(Arr a_, double *out, double tol) {
+#if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
+// tests/hostmath: every matrix the solvers hand to this routine also goes through the packed form of pl_eigen_packed.h (the device's
+// routine since round 5, here with the lane loops as loops); calls and disagreements (count or any bit of an eigenvalue) are counted
+} // namespace pl
+#include "pl_eigen_packed.h"
+namespace pl {
+extern unsigned long long pl_eig_shadow_counters[4]; // [eigenvalue calls, disagreements, balancing calls, disagreements]
+template <int n, class Arr> inline int pl_real_eigenvalues_serial(Arr a_, double *out, double tol);
+template <int n, class Arr> inline int pl_real_eigenvalues(Arr a_, double *out, double tol) {
+    double shadow[n * n + 4 * n];
+    for (int e = 0; e < n * n; ++e)
+        shadow[e] = a_[e];
+    for (int e = n * n; e < n * n + 4 * n; ++e)
+        shadow[e] = 0.0;
+    const int m = pl_real_eigenvalues_serial<n, Arr>(a_, out, tol);
+    EigFlatHost<n> cx{shadow};
+    const int m2 = pl_real_eigenvalues_packed<n>(cx, true, tol);
+    bool same = m == m2;
+    for (int i = 0; same && i < m; ++i)
+        same = std::memcmp(&out[i], &cx.out(i), sizeof(double)) == 0;
+    pl_eig_shadow_counters[0]++;
+    pl_eig_shadow_counters[1] += same ? 0 : 1;
+    return m;
+}
+#define pl_real_eigenvalues_impl pl_real_eigenvalues_serial
+#else
+#define pl_real_eigenvalues_impl pl_real_eigenvalues
+#endif
+template <int n, class Arr> PL_HD int pl_real_eigenvalues_impl(Arr a_, double *out, double tol) {
 #define PL_A(i, j) a_[(i) * n + (j)]
     for (int k = 0; k + 2 < n; ++k) {
         double tail = 0;

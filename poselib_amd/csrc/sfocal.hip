@@ -23,6 +23,7 @@
 #include "pl_sfocal.h"
 #include "pl_solver_6ptf.h"
 #include "pl_eigen_wave.h"
+#include "pl_eigen_packed.h"
 #include "pl_lm_chain.inc"
 #include <algorithm>
 #include <atomic>
@@ -94,47 +95,95 @@ __global__ __launch_bounds__(64) void k_sfocal_setup_g(const SFocalGenArgs *__re
 //                then builds the list of solutions ascending in y exactly as the serial routine inserts them.  Phase 2, lane s =
 //                solution s: essential matrix, up to four poses; the models leave in the order of the solutions (prefix sum of the
 //                counts).  As one lane per sample (root after root, solution after solution): 0.79 ms per batch.
-constexpr int kSolveWaves = 2, kFinRoots = 8, kMaxRoots = 16; // the roots go through the lanes kFinRoots at a time (a second pass is rare)
+constexpr int kSolveWaves = 4, kFinRoots = 8, kMaxRoots = 16; // the roots go through the lanes kFinRoots at a time (a second pass is rare)
 constexpr int kFinC = 0, kFinA = 300, kFinNb = kFinA + 100 * kFinRoots, kFinX = kFinNb + 27, kFinTmp = kFinX + 36,
               kFinDoubles = kFinTmp + 7 * kMaxRoots;
-static_assert(eig_wave_doubles(15) <= 100 * kFinRoots && 225 + 300 + 100 + 150 + 16 <= 100 * kFinRoots, "the row reduction and the eigenvalue workspace live in the roots' region");
-__device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_fin[kSolveWaves][kFinDoubles];
+static_assert(eig_wave_doubles(15) <= 100 * kFinRoots, "the eigenvalue workspace lives in the roots' region");
+// Round 5: the solve stage as THREE kernels over a per-sample record in the workspace (sample-major, behind the element-major rows):
+//   [companion matrix 225 | eigenvalues 15 | ok | number of real eigenvalues]
+//   k_sfocal_comp    one wavefront = one sample: the row reduction to the companion matrix (six_companion_wave)
+//   k_sfocal_eig     one wavefront = FOUR samples, 16 lanes each: balancing and eigenvalues (pl_eigen_packed.h).  Inside one kernel every
+//                    wavefront iterated on its own matrix with <= 15 lanes at work and every scalar of the iteration computed 64 times:
+//                    63 % of the kernel's time (profiles/r05_focal_batch.md)
+//   k_sfocal_roots   one wavefront = one sample: one lane per root, then one lane per solution
+constexpr int kSfActDoubles = 244, kSfActEv = 225, kSfActOk = 240, kSfActRoots = 241;
+__device__ __forceinline__ double *sfocal_act(const SFocalGenArgs &g, uint32_t it) {
+    return g.stage + (size_t)kStDoubles * g.num_iters + (size_t)it * kSfActDoubles;
+}
+constexpr int kCompLds = 792; // T (225) | Cw (300) | A (100) | B (150) | factors (16)
+__device__ __forceinline__ void sfocal_comp_body(const SFocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_comp[kSolveWaves][kCompLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
     const size_t B = g.num_iters;
     const double *st = g.stage + it;
+    double *reg = s_comp[wave];
+    double *act = sfocal_act(g, it);
+    for (int e = lane; e < 300; e += 64)
+        reg[225 + e] = st[(size_t)(kStC + e) * B];
+    bool have_T = false; // (uniform) the companion matrix stands in reg[0 .. 225), all entries finite
+    if (six_companion_wave(reg + 225, reg, reg + 525, reg + 625, reg + 775, lane)) {
+        bool finite = true;
+        for (int e = lane; e < 225; e += 64)
+            finite = finite && isfinite(reg[e]);
+        have_T = !__builtin_amdgcn_ballot_w64(!finite); // (a vanishing pivot: the balancing would not terminate on an infinite entry)
+    }
+    if (have_T)
+        for (int e = lane; e < 225; e += 64)
+            act[e] = reg[e];
+    if (lane == 0)
+        act[kSfActOk] = have_T ? 1.0 : 0.0;
+}
+constexpr int kEigWaves = 4, kEigLds = 288; // (eig_wave_doubles(15) = 285, padded)
+static_assert(eig_wave_doubles(15) <= kEigLds, "a group's matrix and workspace");
+__device__ __forceinline__ void sfocal_eig_body(const SFocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_eig[kEigWaves][4][kEigLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+    const uint32_t it = (blk * kEigWaves + wave) * 4u + grp;
+    const bool alive = it < g.num_iters;
+    double *act = sfocal_act(g, alive ? it : 0u);
+    const bool ok = alive && act[kSfActOk] != 0.0;
+    double *mine = s_eig[wave][grp];
+    if (ok)
+        for (int e = gl; e < 225; e += 16)
+            mine[e] = act[e];
+    EigWave4<15> cx{mine, gl, lane};
+    cx.sync();
+    pl_balance_pow2_packed<15>(cx, ok);
+    const int nr = pl_real_eigenvalues_packed<15>(cx, ok, 1e-8);
+    if (ok && gl < nr)
+        act[kSfActEv + gl] = cx.out(gl);
+    if (alive && gl == 0)
+        act[kSfActRoots] = ok ? (double)nr : 0.0;
+}
+__device__ __forceinline__ void sfocal_roots_body(const SFocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_fin[kSolveWaves][kFinDoubles];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
+        return;
+    const bool alive = true;
+    const size_t B = g.num_iters;
+    const double *st = g.stage + it;
+    const double *act = sfocal_act(g, it);
     double *base = s_fin[wave];
     double *rx = base + kFinTmp, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots,
            *sw = sy + kMaxRoots, *cnt = sw + kMaxRoots;
     uint32_t m = 0;
-    int nroots = 0;
+    const int nroots = (int)act[kSfActRoots]; // (0: no companion matrix, or no real eigenvalue)
     double wv = 0.0;
-    {
-        // the equations: C stays (the roots' null vectors), a copy is row-reduced to the companion matrix by the wavefront
-        double *reg = base + kFinA; // T (225) | Cw (300) | A (100) | B (150) | factors (16): dead before the roots use the region
-        for (int e = lane; e < 300; e += 64) {
-            const double v = st[(size_t)(kStC + e) * B];
-            base[kFinC + e] = v;
-            reg[225 + e] = v;
-        }
+    if (nroots > 0) {
+        // the equations (the roots' null vectors), the null space and the bearings (the poses)
+        for (int e = lane; e < 300; e += 64)
+            base[kFinC + e] = st[(size_t)(kStC + e) * B];
         if (lane < 27)
             base[kFinNb + lane] = st[(size_t)(kStNb + lane) * B];
         if (lane < 36)
             base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
-        if (six_companion_wave(reg + 225, reg, reg + 525, reg + 625, reg + 775, lane)) {
-            bool finite = true;
-            for (int e = lane; e < 225; e += 64)
-                finite = finite && isfinite(reg[e]);
-            if (!__builtin_amdgcn_ballot_w64(!finite)) { // (a vanishing pivot: the balancing would not terminate on an infinite entry)
-                pl_balance_pow2_wave<15>(reg, lane);
-                nroots = pl_real_eigenvalues_wave<15>(reg, 1e-8, lane);
-                if (lane < nroots)
-                    wv = reg[225 + 45 + lane];
-            }
-        }
+        if (lane < nroots)
+            wv = act[kSfActEv + lane];
         PL_WAVE_SYNC();
     }
     if (nroots > 0) {
@@ -190,18 +239,27 @@ __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32
                 g.host_models[(size_t)it * kSFocalMaxModels + off + i] = mine[i];
         }
     }
-    if (lane == 0) {
+    if (alive && lane == 0) {
         g.num_models[it] = m;
         if (g.host_num_models)
             g.host_num_models[it] = m;
     }
 }
-__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sfocal_solve(SFocalGenArgs g) {
-    sfocal_solve_body(g, blockIdx.x);
-}
-__global__ __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_sfocal_solve_g(const SFocalGenArgs *__restrict__ gs) {
+#define PL_SOLVE_ATTR __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ PL_SOLVE_ATTR void k_sfocal_comp(SFocalGenArgs g) { sfocal_comp_body(g, blockIdx.x); }
+__global__ PL_SOLVE_ATTR void k_sfocal_comp_g(const SFocalGenArgs *__restrict__ gs) {
     const SFocalGenArgs g = gs[blockIdx.y];
-    sfocal_solve_body(g, blockIdx.x);
+    sfocal_comp_body(g, blockIdx.x);
+}
+__global__ __launch_bounds__(64 * kEigWaves) void k_sfocal_eig(SFocalGenArgs g) { sfocal_eig_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64 * kEigWaves) void k_sfocal_eig_g(const SFocalGenArgs *__restrict__ gs) {
+    const SFocalGenArgs g = gs[blockIdx.y];
+    sfocal_eig_body(g, blockIdx.x);
+}
+__global__ PL_SOLVE_ATTR void k_sfocal_roots(SFocalGenArgs g) { sfocal_roots_body(g, blockIdx.x); }
+__global__ PL_SOLVE_ATTR void k_sfocal_roots_g(const SFocalGenArgs *__restrict__ gs) {
+    const SFocalGenArgs g = gs[blockIdx.y];
+    sfocal_roots_body(g, blockIdx.x);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-uniform
@@ -593,7 +651,7 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
 
 } // namespace
 
-size_t sfocal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)kStDoubles * num_iters; }
+size_t sfocal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)(kStDoubles + kSfActDoubles) * num_iters; }
 
 hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
@@ -601,7 +659,9 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     if (!g.stage)
         return hipErrorInvalidValue;
     k_sfocal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
-    k_sfocal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+    k_sfocal_comp<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+    k_sfocal_eig<<<dim3((g.num_iters + 4 * kEigWaves - 1) / (4 * kEigWaves)), dim3(64 * kEigWaves), 0, stream>>>(g);
+    k_sfocal_roots<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     return hipGetLastError();
 }
 // ---- group launches (driver_focal_group.inc): blockIdx.y = member, the grid's x extent = the largest member's; `args` is a
@@ -610,7 +670,9 @@ hipError_t launch_sfocal_generate_g(const SFocalGenArgs *args, uint32_t G, uint3
     if (G == 0 || max_iters == 0)
         return hipSuccess;
     k_sfocal_setup_g<<<dim3((max_iters + 63u) / 64u, G), dim3(64), 0, stream>>>(args);
-    k_sfocal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+    k_sfocal_comp_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+    k_sfocal_eig_g<<<dim3((max_iters + 4 * kEigWaves - 1) / (4 * kEigWaves), G), dim3(64 * kEigWaves), 0, stream>>>(args);
+    k_sfocal_roots_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
     return hipGetLastError();
 }
 hipError_t launch_sfocal_score_g(const SFocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream) {

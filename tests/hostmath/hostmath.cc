@@ -1008,6 +1008,34 @@ extern "C" void hm_ransac_shared_focal(const double *const *pa, uint32_t n, uint
 }
 
 // The product's host-side SVD at the entry of the fundamental-matrix refinement (pl_svd3.h), row-major in and out.
+// ---- the packed eigenvalue routines (pl_eigen_packed.h) against the serial ones: shadow counters of this build (Makefile), and the
+// routines on matrices given explicitly (n = 10: plain; n = 15: balanced first, as six_eigenvalues does)
+namespace pl {
+unsigned long long pl_eig_shadow_counters[4] = {0, 0, 0, 0};
+}
+extern "C" void hm_eig_shadow_counters(unsigned long long *out4) {
+    for (int i = 0; i < 4; ++i)
+        out4[i] = pl::pl_eig_shadow_counters[i];
+}
+extern "C" int hm_real_eigenvalues(int n, const double *mats, int count, double *ev_out, int *m_out) {
+    for (int k = 0; k < count; ++k) {
+        double a[225], ev[15];
+        for (int e = 0; e < n * n; ++e)
+            a[e] = mats[(size_t)k * n * n + e];
+        int m;
+        if (n == 10) {
+            m = pl_real_eigenvalues<10, double *>(a, ev, 1e-8);
+        } else if (n == 15) {
+            m = six_eigenvalues(SixWork{a, 1}, ev);
+        } else {
+            return -1;
+        }
+        m_out[k] = m;
+        for (int i = 0; i < m; ++i)
+            ev_out[(size_t)k * 15 + i] = ev[i];
+    }
+    return 0;
+}
 extern "C" void hm_svd3(const double *A9, double *U9, double *s3, double *V9) {
     Mat3 A, U, V;
     std::memcpy(A.m, A9, sizeof(A.m));

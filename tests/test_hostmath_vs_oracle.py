@@ -533,3 +533,81 @@ def test_flat_root_isolation_finds_the_recursions_leaves_bit_for_bit():
         differ += not (len(o) == len(a) and np.array_equal(np.asarray(o), a))
     assert with_roots > 1200
     assert differ == 0  # (the oracle has no slot limits: equal wherever neither list overflows - everywhere here)
+
+
+# ---- the packed eigenvalue routines of round 5 (pl_eigen_packed.h: four matrices per wavefront on the device) ----
+def _eig_counters():
+    import ctypes as C
+
+    out = (C.c_ulonglong * 4)()
+    HM.lib().hm_eig_shadow_counters(out)
+    return list(out)
+
+
+def _real_eigenvalues(n, mats):
+    import ctypes as C
+
+    mats = np.ascontiguousarray(mats, dtype=np.float64)
+    count = mats.shape[0]
+    ev = np.zeros((count, 15))
+    m = np.zeros(count, dtype=np.int32)
+    rc = HM.lib().hm_real_eigenvalues(C.c_int(n), mats.ctypes.data_as(C.c_void_p), C.c_int(count), ev.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return ev, m
+
+
+def test_packed_eigenvalues_equal_the_serial_routines_bit_for_bit():
+    """tests/hostmath is built with PL_EIG_SHADOW_CHECK: every matrix that reaches pl_real_eigenvalues<10 | 15> / pl_balance_pow2<15> also goes
+    through the packed forms (the device's routines since round 5, lane loops as loops) and is compared bit for bit.  Here: the
+    matrices of the two minimal solvers on random samples, random dense matrices of several scalings, and the special ones
+    (zero, identity, triangular, already Hessenberg, exact deflations, rotations with complex pairs, repeated eigenvalues,
+    non-finite entries)."""
+    before = _eig_counters()
+    rng = np.random.default_rng(12)
+    # the solvers' own matrices
+    for k in range(300):
+        d = synth.absolute_pose_scene(4, 0.0, 31000 + k, noise_px=0.3)
+        f, cx, cy = d["camera"]["params"]
+        HM.p35pf((np.asarray(d["p2d"]) - [cx, cy]) / f, d["p3d"])
+    for k in range(300):
+        d = synth.relative_pose_scene(6, 0.0, 32000 + k, noise_px=0.3)
+        f, cx, cy = d["camera1"]["params"]
+        b1 = np.c_[(np.asarray(d["x1"]) - [cx, cy]) / f, np.ones(6)]
+        b2 = np.c_[(np.asarray(d["x2"]) - [cx, cy]) / f, np.ones(6)]
+        HM.relpose_6pt_shared_focal(b1 / np.linalg.norm(b1, axis=1, keepdims=True), b2 / np.linalg.norm(b2, axis=1, keepdims=True))
+    mid = _eig_counters()
+    assert mid[0] - before[0] >= 500 and mid[2] - before[2] >= 250, (before, mid)
+    for n in (10, 15):
+        mats = [rng.normal(size=(n, n)) * 10.0 ** rng.integers(-6, 7) for _ in range(1500)]
+        mats += [np.zeros((n, n)), np.eye(n), np.triu(rng.normal(size=(n, n))), np.tril(rng.normal(size=(n, n))),
+                 np.triu(rng.normal(size=(n, n)), -1), np.diag(np.arange(1.0, n + 1)), np.ones((n, n)), np.diag(np.ones(n - 1), 1)]
+        for _ in range(200):  # block structures: exact deflations, 2 x 2 rotations (complex pairs), repeated eigenvalues
+            M = np.zeros((n, n))
+            i = 0
+            while i < n:
+                if i + 1 < n and rng.random() < 0.5:
+                    a, b = rng.normal(), rng.normal()
+                    M[i:i + 2, i:i + 2] = [[a, -b], [b, a]]
+                    i += 2
+                else:
+                    M[i, i] = rng.choice([1.0, 2.0, rng.normal()])
+                    i += 1
+            if rng.random() < 0.5:
+                Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+                M = Q @ M @ Q.T
+            mats.append(M)
+        for _ in range(100):  # sparse, graded
+            M = rng.normal(size=(n, n)) * (rng.random((n, n)) < 0.3) * 2.0 ** rng.integers(-30, 30, size=(n, n))
+            mats.append(M)
+        bad = rng.normal(size=(n, n))
+        bad[3, 4] = np.nan
+        mats.append(bad)
+        ev, m = _real_eigenvalues(n, np.array(mats))
+        # and the values themselves are eigenvalues (numpy, on the well-conditioned dense ones)
+        for k in range(0, 200, 20):
+            ref = np.linalg.eigvals(mats[k])
+            real = np.sort(ref[np.abs(ref.imag) <= 1e-8 * (1 + np.abs(ref.real))].real)
+            assert m[k] == len(real) and np.allclose(ev[k, :m[k]], real, rtol=1e-7, atol=1e-9 * np.abs(mats[k]).max()), (n, k, ev[k, :m[k]], real)
+    after = _eig_counters()
+    assert after[0] - mid[0] >= 3600, (mid, after)
+    assert after[1] == 0 and after[3] == 0, f"packed != serial: {after[1]} of {after[0]} eigenvalue calls, {after[3]} of {after[2]} balancing calls"
