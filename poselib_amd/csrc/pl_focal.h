@@ -128,7 +128,9 @@ template <int K> inline uint64_t focal_sample_positions(uint64_t seed, uint64_t 
 // focal_lo_ransac_t below - or for the members of a group with ONE launch sequence, driver_focal_group.inc), leaves the results in
 // the response fields and calls advance() again.  Requests:
 //   kMinimal      generate + score the batch [pos, positions[0 .. B)) (explicit_samples: B x kSample indices drawn here - PROSAC)
-//                 -> models [B * kMaxModels], num_models [B], counts, sums (per model slot)
+//                 -> num_models [B]; models, counts, sums COMPACT: one entry per model, in (iteration, slot) order (a dense
+//                 [B * kMaxModels] response - 60 slots per iteration of the shared-focal solver, 0.2 of them used - was 3.8 MB of
+//                 zero-filled vector per batch and problem)
 //   kScore        score `seeds` -> counts, sums
 //   kRefineScore  refine_model() of every seed and the scores of the results -> refined, rcounts, rsums
 // counts / sums: inliers and the sum of their squared residuals in correspondence order, per model slot.  All decisions are
@@ -234,10 +236,10 @@ template <class Traits> struct FocalLoop {
                 // pass 1: the hypotheses that improve best_minimal_* (independent of the local optimisations)
                 imps.clear();
                 seeds.clear();
+                size_t h = 0; // (compact index: the models of the batch in (iteration, slot) order)
                 for (uint32_t b = 0; b < B; ++b) {
                     int last = -1;
-                    for (uint32_t m = 0; m < num_models[b]; ++m) {
-                        const size_t h = (size_t)b * kMaxModels + m;
+                    for (uint32_t m = 0; m < num_models[b]; ++m, ++h) {
                         const double sc = Traits::finish(sums[h], counts[h], N, o, models[h].f);
                         const bool more = counts[h] > best_min_inl, better = sc < best_min_score;
                         if (!(more || better))
@@ -246,12 +248,12 @@ template <class Traits> struct FocalLoop {
                             best_min_inl = counts[h];
                         if (better)
                             best_min_score = sc;
-                        imps.push_back(Improving{b, m, counts[h], sc, -1});
+                        imps.push_back(Improving{b, (uint32_t)h, counts[h], sc, -1});
                         last = (int)imps.size() - 1;
                     }
                     if (last >= 0) {
                         imps[last].job = (int)seeds.size();
-                        seeds.push_back(models[(size_t)b * kMaxModels + imps[last].slot]);
+                        seeds.push_back(models[imps[last].slot]);
                     }
                 }
                 phase = Phase::kBatchRefined;
@@ -272,7 +274,7 @@ template <class Traits> struct FocalLoop {
                         const Improving &im = imps[a];
                         if (im.score < st.model_score) {
                             st.model_score = im.score;
-                            *best = models[(size_t)b * kMaxModels + im.slot];
+                            *best = models[im.slot];
                             st.num_inliers = im.count;
                         }
                         if (im.job >= 0)
@@ -307,7 +309,7 @@ template <class Traits> struct FocalLoop {
   private:
     enum class Phase { kStart, kInitialScored, kInitialRefined, kLoopHead, kBatchScored, kBatchRefined, kFinal, kFinalRefined, kFinished };
     struct Improving {
-        uint32_t iter, slot;
+        uint32_t iter, slot; // iteration of the batch, compact index of the model
         uint64_t count;
         double score;
         int job; // index into seeds / refined, -1: not the iteration's last improving hypothesis
@@ -341,7 +343,7 @@ template <class Traits> struct FocalLoop {
 };
 
 // One problem, one back end that evaluates every request synchronously:
-//   int minimal(pos_base, positions, B, models [B * 10], num_models [B], counts, sums, samples)
+//   int minimal(pos_base, positions, B, models, num_models [B], counts, sums, samples)   (models, counts, sums: compact)
 //   int score(models, counts, sums)
 //   int refine_score(seeds, refined, counts, sums)
 template <class Traits, class Backend>

@@ -784,10 +784,8 @@ struct HostFocalBackend {
     }
     int minimal(uint64_t pos_base, const uint32_t *positions, uint32_t B, std::vector<FocalModel> &models,
                 std::vector<uint32_t> &num_models, std::vector<uint32_t> &counts, std::vector<double> &sums, const uint32_t *samples = nullptr) {
-        models.assign((size_t)B * kFocalMaxModels, FocalModel());
+        models.clear(), counts.clear(), sums.clear(); // (compact: one entry per model, in (iteration, slot) order)
         num_models.assign(B, 0);
-        counts.assign((size_t)B * kFocalMaxModels, 0);
-        sums.assign((size_t)B * kFocalMaxModels, 0.0);
         for (uint32_t it = 0; it < B; ++it) {
             uint32_t idx[kFocalSample];
             if (samples)
@@ -807,12 +805,14 @@ struct HostFocalBackend {
             for (int i = 0; i < ns; ++i) {
                 if (sol[i].focal < 0 || (max_focal >= 0 && sol[i].focal > max_focal))
                     continue;
-                const size_t h = (size_t)it * kFocalMaxModels + m;
-                FocalModel &o = models[h];
+                FocalModel o;
                 o.q[0] = sol[i].q.w, o.q[1] = sol[i].q.x, o.q[2] = sol[i].q.y, o.q[3] = sol[i].q.z;
                 o.t[0] = sol[i].t.x, o.t[1] = sol[i].t.y, o.t[2] = sol[i].t.z;
                 o.f = sol[i].focal;
-                score_one(o, counts[h], sums[h]);
+                uint32_t cnt = 0;
+                double sum = 0.0;
+                score_one(o, cnt, sum);
+                models.push_back(o), counts.push_back(cnt), sums.push_back(sum);
                 ++m;
             }
             num_models[it] = m;
@@ -916,10 +916,8 @@ struct HostSFocalBackend {
     }
     int minimal(uint64_t pos_base, const uint32_t *positions, uint32_t B, std::vector<FocalModel> &models,
                 std::vector<uint32_t> &num_models, std::vector<uint32_t> &counts, std::vector<double> &sums, const uint32_t *samples = nullptr) {
-        models.assign((size_t)B * kSFocalMaxModels, FocalModel());
+        models.clear(), counts.clear(), sums.clear(); // (compact: one entry per model, in (iteration, slot) order)
         num_models.assign(B, 0);
-        counts.assign((size_t)B * kSFocalMaxModels, 0);
-        sums.assign((size_t)B * kSFocalMaxModels, 0.0);
         for (uint32_t it = 0; it < B; ++it) {
             uint32_t idx[kSFocalSample];
             if (samples)
@@ -934,12 +932,14 @@ struct HostSFocalBackend {
             }
             uint32_t m = 0;
             relpose_6pt_shared_focal(a, b, SixWork{work.data(), 1}, [&](Quat q, Vec3 t, double f) {
-                const size_t h = (size_t)it * kSFocalMaxModels + m;
-                FocalModel &o = models[h];
+                FocalModel o;
                 o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
                 o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
                 o.f = f;
-                score_one(o, counts[h], sums[h]);
+                uint32_t cnt = 0;
+                double sum = 0.0;
+                score_one(o, cnt, sum);
+                models.push_back(o), counts.push_back(cnt), sums.push_back(sum);
                 ++m;
             });
             num_models[it] = m;
