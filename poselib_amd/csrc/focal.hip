@@ -115,20 +115,13 @@ static_assert(eig_wave_doubles(10) + kP35ActionDoubles <= 100 * kFinRoots, "the 
 //                   waiting at a barrier) was slower still (5.8 -> 7.0 ms per 64 k samples): the packed iteration wants many
 //                   wavefronts per SIMD, which a kernel of its own has (18 KB of LDS per 16 samples)
 //   k_focal_roots   one wavefront = one sample, one lane per root: null vector, pose, focal length; the estimator's filter
+constexpr uint32_t kSplitSamples = 4096; // launches of at least so many samples take the three kernels, smaller ones the single kernel
 constexpr int kActDoubles = 112, kActEv = 100, kActOk = 110, kActRoots = 111;
 __device__ __forceinline__ double *focal_act(const FocalGenArgs &g, uint32_t it) {
     return g.stage + (size_t)kStageDoubles * g.num_iters + (size_t)it * kActDoubles;
 }
-__device__ __forceinline__ void focal_elim_body(const FocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_E[kSolveWaves][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
-    if (it >= g.num_iters)
-        return;
-    const size_t B = g.num_iters;
-    const double *stage = g.stage;
-    double *E = s_E[wave];
-    double *act = focal_act(g, it);
+// the elimination of sample `it` by its wavefront; E (50 doubles of LDS): the rows of the action matrix that are not shifts.  false: degenerate
+__device__ __forceinline__ bool focal_eliminate(const double *stage, size_t B, uint32_t it, int lane, double *E) {
     bool ok = true;
     { // ---- elimination
         const int c = lane < kP35Cols ? lane : kP35Cols - 1; // (lanes 35..63 shadow the last column: no divergence, never read)
@@ -190,13 +183,26 @@ __device__ __forceinline__ void focal_elim_body(const FocalGenArgs &g, uint32_t 
             }
         }
     }
+    return ok;
+}
+__device__ __forceinline__ double focal_action_entry(const double *E, int e) { // p35pf_action_entry
+    const int k = e / 10, j = e - 10 * k;
+    const int sh = kP35Shifted[k];
+    return sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[e];
+}
+__device__ __forceinline__ void focal_elim_body(const FocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_E[kSolveWaves][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
+        return;
+    double *E = s_E[wave];
+    double *act = focal_act(g, it);
+    const bool ok = focal_eliminate(g.stage, g.num_iters, it, lane, E);
     if (ok) { // ---- the action matrix
         PL_WAVE_SYNC();
-        for (int e = lane; e < 100; e += 64) {
-            const int k = e / 10, j = e - 10 * k;
-            const int sh = kP35Shifted[k];
-            act[e] = sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[e]; // p35pf_action_entry
-        }
+        for (int e = lane; e < 100; e += 64)
+            act[e] = focal_action_entry(E, e);
     }
     if (lane == 0)
         act[kActOk] = ok ? 1.0 : 0.0;
@@ -221,14 +227,75 @@ __device__ __forceinline__ void focal_eig_body(const FocalGenArgs &g, uint32_t b
     if (alive && gl == 0)
         act[kActRoots] = ok ? (double)nr : 0.0;
 }
+// lane s = root s of sample `it`: null vector (its own 10 x 10 working copy in LDS behind the action matrix `base`), pose and focal length;
+// the solutions the estimator keeps leave in the order of the roots.  Returns their number (every lane).
+__device__ __forceinline__ uint32_t focal_emit_roots(const FocalGenArgs &g, uint32_t it, int lane, double *base, int nroots, double ev) {
+    const size_t B = g.num_iters;
+    const double *stage = g.stage;
+    bool valid = false;
+    P35Solution sol;
+    if (lane < nroots) {
+        double N[60];
+        for (int e = 0; e < 60; ++e)
+            N[e] = stage[(size_t)(kStageN + e) * B + it];
+        const double f0 = stage[(size_t)kStageF0 * B + it];
+        valid = p35pf_pose_of_root(StridedArr{base, 1}, StridedArr{base + 100 + lane, (size_t)kFinRoots}, ev, N, f0, sol);
+        if (valid && !g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
+            if (sol.focal < 0)
+                valid = false;
+            if (g.max_focal >= 0 && sol.focal > g.max_focal)
+                valid = false;
+        }
+    }
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
+    if (valid) {
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        FocalModel o;
+        o.q[0] = sol.q.w, o.q[1] = sol.q.x, o.q[2] = sol.q.y, o.q[3] = sol.q.z;
+        o.t[0] = sol.t.x, o.t[1] = sol.t.y, o.t[2] = sol.t.z;
+        o.f = sol.focal;
+        g.models[(size_t)it * kFocalMaxModels + pos] = o;
+        if (g.host_models)
+            g.host_models[(size_t)it * kFocalMaxModels + pos] = o;
+    }
+    return (uint32_t)__popcll(mask);
+}
+// The solve stage in ONE kernel (rounds 4 - 5: small launches - a single problem's batch of ~10^3 samples does not fill the device, and
+// what counts is the length of the chain: one wavefront per sample through all three stages, its eigenvalues by itself (pl_eigen_wave.h),
+// is 0.44 ms; the three kernels below are 0.53 ms for such a launch and 20 % faster for the 64 k samples of a group)
+__device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_solve[kSolveWaves][kSolveLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
+        return;
+    double *base = s_solve[wave], *eig = base + 100, *E = eig + eig_wave_doubles(10);
+    uint32_t m = 0;
+    if (focal_eliminate(g.stage, g.num_iters, it, lane, E)) {
+        // ---- action matrix (kept for the roots) and a copy for the eigenvalue iteration, which destroys it
+        PL_WAVE_SYNC();
+        for (int e = lane; e < 100; e += 64) {
+            const double v = focal_action_entry(E, e);
+            base[e] = v;
+            eig[e] = v;
+        }
+        const int nroots = pl_real_eigenvalues_wave<10>(eig, 1e-8, lane);
+        const double ev = lane < nroots ? eig[100 + 30 + lane] : 0.0;
+        PL_WAVE_SYNC();
+        m = focal_emit_roots(g, it, lane, base, nroots, ev);
+    }
+    if (lane == 0) {
+        g.num_models[it] = m;
+        if (g.host_num_models)
+            g.host_num_models[it] = m;
+    }
+}
 __device__ __forceinline__ void focal_roots_body(const FocalGenArgs &g, uint32_t blk) {
     __shared__ double s_solve[kSolveWaves][kSolveLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
-    const size_t B = g.num_iters;
-    const double *stage = g.stage;
     const double *act = focal_act(g, it);
     double *base = s_solve[wave];
     uint32_t m = 0;
@@ -238,34 +305,7 @@ __device__ __forceinline__ void focal_roots_body(const FocalGenArgs &g, uint32_t
             base[e] = act[e];
         const double ev = lane < nroots ? act[kActEv + lane] : 0.0;
         PL_WAVE_SYNC();
-        // ---- roots
-        bool valid = false;
-        P35Solution sol;
-        if (lane < nroots) {
-            double N[60];
-            for (int e = 0; e < 60; ++e)
-                N[e] = stage[(size_t)(kStageN + e) * B + it];
-            const double f0 = stage[(size_t)kStageF0 * B + it];
-            valid = p35pf_pose_of_root(StridedArr{base, 1}, StridedArr{base + 100 + lane, (size_t)kFinRoots}, ev, N, f0, sol);
-            if (valid && !g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
-                if (sol.focal < 0)
-                    valid = false;
-                if (g.max_focal >= 0 && sol.focal > g.max_focal)
-                    valid = false;
-            }
-        }
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
-        m = (uint32_t)__popcll(mask);
-        if (valid) {
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            FocalModel o;
-            o.q[0] = sol.q.w, o.q[1] = sol.q.x, o.q[2] = sol.q.y, o.q[3] = sol.q.z;
-            o.t[0] = sol.t.x, o.t[1] = sol.t.y, o.t[2] = sol.t.z;
-            o.f = sol.focal;
-            g.models[(size_t)it * kFocalMaxModels + pos] = o;
-            if (g.host_models)
-                g.host_models[(size_t)it * kFocalMaxModels + pos] = o;
-        }
+        m = focal_emit_roots(g, it, lane, base, nroots, ev);
     }
     if (lane == 0) {
         g.num_models[it] = m;
@@ -274,6 +314,11 @@ __device__ __forceinline__ void focal_roots_body(const FocalGenArgs &g, uint32_t
     }
 }
 #define PL_SOLVE_ATTR __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ PL_SOLVE_ATTR void k_focal_solve(FocalGenArgs g) { focal_solve_body(g, blockIdx.x); }
+__global__ PL_SOLVE_ATTR void k_focal_solve_g(const FocalGenArgs *__restrict__ gs) {
+    const FocalGenArgs g = gs[blockIdx.y];
+    focal_solve_body(g, blockIdx.x);
+}
 __global__ PL_SOLVE_ATTR void k_focal_elim(FocalGenArgs g) { focal_elim_body(g, blockIdx.x); }
 __global__ PL_SOLVE_ATTR void k_focal_elim_g(const FocalGenArgs *__restrict__ gs) {
     const FocalGenArgs g = gs[blockIdx.y];
@@ -446,6 +491,10 @@ hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
     if (!g.stage)
         return hipErrorInvalidValue;
     k_focal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
+    if (g.num_iters < kSplitSamples) {
+        k_focal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+        return hipGetLastError();
+    }
     k_focal_elim<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     k_focal_eig<<<dim3((g.num_iters + 4 * kEigWaves - 1) / (4 * kEigWaves)), dim3(64 * kEigWaves), 0, stream>>>(g);
     k_focal_roots<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
@@ -457,6 +506,10 @@ hipError_t launch_focal_generate_g(const FocalGenArgs *args, uint32_t G, uint32_
     if (G == 0 || max_iters == 0)
         return hipSuccess;
     k_focal_setup_g<<<dim3((max_iters + 63u) / 64u, G), dim3(64), 0, stream>>>(args);
+    if ((size_t)max_iters * G < kSplitSamples) { // (the same bits either way: tests/test_zz_gpu_focal_group.py)
+        k_focal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+        return hipGetLastError();
+    }
     k_focal_elim_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
     k_focal_eig_g<<<dim3((max_iters + 4 * kEigWaves - 1) / (4 * kEigWaves), G), dim3(64 * kEigWaves), 0, stream>>>(args);
     k_focal_roots_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);

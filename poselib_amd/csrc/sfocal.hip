@@ -106,30 +106,41 @@ static_assert(eig_wave_doubles(15) <= 100 * kFinRoots, "the eigenvalue workspace
 //                    wavefront iterated on its own matrix with <= 15 lanes at work and every scalar of the iteration computed 64 times:
 //                    63 % of the kernel's time (profiles/r05_focal_batch.md)
 //   k_sfocal_roots   one wavefront = one sample: one lane per root, then one lane per solution
+constexpr uint32_t kSplitSamples = 4096; // launches of at least so many samples take the three kernels, smaller ones the single kernel
 constexpr int kSfActDoubles = 244, kSfActEv = 225, kSfActOk = 240, kSfActRoots = 241;
 __device__ __forceinline__ double *sfocal_act(const SFocalGenArgs &g, uint32_t it) {
     return g.stage + (size_t)kStDoubles * g.num_iters + (size_t)it * kSfActDoubles;
 }
 constexpr int kCompLds = 792; // T (225) | Cw (300) | A (100) | B (150) | factors (16)
-__device__ __forceinline__ void sfocal_comp_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_comp[kSolveWaves][kCompLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
-    if (it >= g.num_iters)
-        return;
+// the equations of sample `it` (element-major rows of the workspace) row-reduced to the companion matrix by the wavefront.
+// reg: T (225) | Cw (300) | A (100) | B (150) | factors (16) of LDS.  true (uniform): T stands in reg[0 .. 225), all entries finite
+__device__ __forceinline__ bool sfocal_companion(const SFocalGenArgs &g, uint32_t it, int lane, double *reg, double *keep_C) {
     const size_t B = g.num_iters;
     const double *st = g.stage + it;
-    double *reg = s_comp[wave];
-    double *act = sfocal_act(g, it);
-    for (int e = lane; e < 300; e += 64)
-        reg[225 + e] = st[(size_t)(kStC + e) * B];
-    bool have_T = false; // (uniform) the companion matrix stands in reg[0 .. 225), all entries finite
+    for (int e = lane; e < 300; e += 64) {
+        const double v = st[(size_t)(kStC + e) * B];
+        if (keep_C) // (the roots' null vectors read the equations again)
+            keep_C[e] = v;
+        reg[225 + e] = v;
+    }
+    bool have_T = false;
     if (six_companion_wave(reg + 225, reg, reg + 525, reg + 625, reg + 775, lane)) {
         bool finite = true;
         for (int e = lane; e < 225; e += 64)
             finite = finite && isfinite(reg[e]);
         have_T = !__builtin_amdgcn_ballot_w64(!finite); // (a vanishing pivot: the balancing would not terminate on an infinite entry)
     }
+    return have_T;
+}
+__device__ __forceinline__ void sfocal_comp_body(const SFocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_comp[kSolveWaves][kCompLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
+        return;
+    double *reg = s_comp[wave];
+    double *act = sfocal_act(g, it);
+    const bool have_T = sfocal_companion(g, it, lane, reg, nullptr);
     if (have_T)
         for (int e = lane; e < 225; e += 64)
             act[e] = reg[e];
@@ -158,35 +169,15 @@ __device__ __forceinline__ void sfocal_eig_body(const SFocalGenArgs &g, uint32_t
     if (alive && gl == 0)
         act[kSfActRoots] = ok ? (double)nr : 0.0;
 }
-__device__ __forceinline__ void sfocal_roots_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_fin[kSolveWaves][kFinDoubles];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
-    if (it >= g.num_iters)
-        return;
-    const bool alive = true;
-    const size_t B = g.num_iters;
-    const double *st = g.stage + it;
-    const double *act = sfocal_act(g, it);
-    double *base = s_fin[wave];
+// phase 1, lane s = root s: (x, y) from the null vector of C0 + w C1 + w^2 C2 (its own 10 x 10 matrix in LDS); lane 0 builds the list of
+// solutions ascending in y as the serial routine inserts them; phase 2, lane s = solution s: essential matrix, up to four poses; the
+// models leave in the order of the solutions.  base: the wavefront's LDS block (equations, null space and bearings in place).  Returns
+// the number of models (every lane).
+__device__ __forceinline__ uint32_t sfocal_emit_roots(const SFocalGenArgs &g, uint32_t it, int lane, double *base, int nroots, double wv) {
     double *rx = base + kFinTmp, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots,
            *sw = sy + kMaxRoots, *cnt = sw + kMaxRoots;
     uint32_t m = 0;
-    const int nroots = (int)act[kSfActRoots]; // (0: no companion matrix, or no real eigenvalue)
-    double wv = 0.0;
-    if (nroots > 0) {
-        // the equations (the roots' null vectors), the null space and the bearings (the poses)
-        for (int e = lane; e < 300; e += 64)
-            base[kFinC + e] = st[(size_t)(kStC + e) * B];
-        if (lane < 27)
-            base[kFinNb + lane] = st[(size_t)(kStNb + lane) * B];
-        if (lane < 36)
-            base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
-        if (lane < nroots)
-            wv = act[kSfActEv + lane];
-        PL_WAVE_SYNC();
-    }
-    if (nroots > 0) {
+    {
         // root s = pass * kFinRoots + lane: its eigenvalue sits in lane s
         uint64_t fmask = 0;
         for (int first = 0; first < nroots; first += kFinRoots) {
@@ -239,6 +230,66 @@ __device__ __forceinline__ void sfocal_roots_body(const SFocalGenArgs &g, uint32
                 g.host_models[(size_t)it * kSFocalMaxModels + off + i] = mine[i];
         }
     }
+    return m;
+}
+// The solve stage in ONE kernel (small launches: see focal.hip - the chain of a single problem's batch is shorter this way; the same bits)
+__device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_fin[kSolveWaves][kFinDoubles];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
+        return;
+    const size_t B = g.num_iters;
+    const double *st = g.stage + it;
+    double *base = s_fin[wave];
+    double *reg = base + kFinA; // T (225) | Cw (300) | A (100) | B (150) | factors (16): dead before the roots use the region
+    uint32_t m = 0;
+    if (lane < 27)
+        base[kFinNb + lane] = st[(size_t)(kStNb + lane) * B];
+    if (lane < 36)
+        base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
+    if (sfocal_companion(g, it, lane, reg, base + kFinC)) {
+        pl_balance_pow2_wave<15>(reg, lane);
+        const int nroots = pl_real_eigenvalues_wave<15>(reg, 1e-8, lane);
+        const double wv = lane < nroots ? reg[225 + 45 + lane] : 0.0;
+        PL_WAVE_SYNC();
+        if (nroots > 0)
+            m = sfocal_emit_roots(g, it, lane, base, nroots, wv);
+    }
+    if (lane == 0) {
+        g.num_models[it] = m;
+        if (g.host_num_models)
+            g.host_num_models[it] = m;
+    }
+}
+__device__ __forceinline__ void sfocal_roots_body(const SFocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_fin[kSolveWaves][kFinDoubles];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
+    if (it >= g.num_iters)
+        return;
+    const bool alive = true;
+    const size_t B = g.num_iters;
+    const double *st = g.stage + it;
+    const double *act = sfocal_act(g, it);
+    double *base = s_fin[wave];
+    uint32_t m = 0;
+    const int nroots = (int)act[kSfActRoots]; // (0: no companion matrix, or no real eigenvalue)
+    double wv = 0.0;
+    if (nroots > 0) {
+        // the equations (the roots' null vectors), the null space and the bearings (the poses)
+        for (int e = lane; e < 300; e += 64)
+            base[kFinC + e] = st[(size_t)(kStC + e) * B];
+        if (lane < 27)
+            base[kFinNb + lane] = st[(size_t)(kStNb + lane) * B];
+        if (lane < 36)
+            base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
+        if (lane < nroots)
+            wv = act[kSfActEv + lane];
+        PL_WAVE_SYNC();
+    }
+    if (nroots > 0)
+        m = sfocal_emit_roots(g, it, lane, base, nroots, wv);
     if (alive && lane == 0) {
         g.num_models[it] = m;
         if (g.host_num_models)
@@ -246,6 +297,11 @@ __device__ __forceinline__ void sfocal_roots_body(const SFocalGenArgs &g, uint32
     }
 }
 #define PL_SOLVE_ATTR __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ PL_SOLVE_ATTR void k_sfocal_solve(SFocalGenArgs g) { sfocal_solve_body(g, blockIdx.x); }
+__global__ PL_SOLVE_ATTR void k_sfocal_solve_g(const SFocalGenArgs *__restrict__ gs) {
+    const SFocalGenArgs g = gs[blockIdx.y];
+    sfocal_solve_body(g, blockIdx.x);
+}
 __global__ PL_SOLVE_ATTR void k_sfocal_comp(SFocalGenArgs g) { sfocal_comp_body(g, blockIdx.x); }
 __global__ PL_SOLVE_ATTR void k_sfocal_comp_g(const SFocalGenArgs *__restrict__ gs) {
     const SFocalGenArgs g = gs[blockIdx.y];
@@ -659,6 +715,10 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     if (!g.stage)
         return hipErrorInvalidValue;
     k_sfocal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
+    if (g.num_iters < kSplitSamples) {
+        k_sfocal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+        return hipGetLastError();
+    }
     k_sfocal_comp<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     k_sfocal_eig<<<dim3((g.num_iters + 4 * kEigWaves - 1) / (4 * kEigWaves)), dim3(64 * kEigWaves), 0, stream>>>(g);
     k_sfocal_roots<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
@@ -670,6 +730,10 @@ hipError_t launch_sfocal_generate_g(const SFocalGenArgs *args, uint32_t G, uint3
     if (G == 0 || max_iters == 0)
         return hipSuccess;
     k_sfocal_setup_g<<<dim3((max_iters + 63u) / 64u, G), dim3(64), 0, stream>>>(args);
+    if ((size_t)max_iters * G < kSplitSamples) { // (the same bits either way: tests/test_zz_gpu_focal_group.py)
+        k_sfocal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+        return hipGetLastError();
+    }
     k_sfocal_comp_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
     k_sfocal_eig_g<<<dim3((max_iters + 4 * kEigWaves - 1) / (4 * kEigWaves), G), dim3(64 * kEigWaves), 0, stream>>>(args);
     k_sfocal_roots_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
