@@ -173,8 +173,9 @@ int pl_undistort_points(const pl_camera *camera, const double *points2D, size_t 
  * estimate_*() (robust.h) from a thread pool, the Python wrappers release the GIL for that purpose. */
 typedef struct {
     int32_t kind;            /* 0 absolute pose, 1 relative pose, 2 fundamental, 3 homography, 4 relative pose with a shared
-                              * unknown focal length (pl_estimate_shared_focal_relative_pose; served by the pool one problem at a time,
-                              * like kind-0 items with estimate_focal_length) */
+                              * unknown focal length (pl_estimate_shared_focal_relative_pose).  Kind-4 items and kind-0 items with
+                              * estimate_focal_length advance in lock-step groups of their own since round 5 (one launch sequence per
+                              * group, every item bit-identical to its single call); PROSAC or warm-started ones one at a time */
     int32_t status;          /* out: PL_OK or the error of this item */
     const double *a;         /* points2D (kind 0) / points2D_1: N x 2 */
     const double *b;         /* points3D: N x 3 (kind 0) / points2D_2: N x 2 */
