@@ -341,13 +341,8 @@ __device__ __forceinline__ FocalModel sfocal_score_model(const SFocalScoreArgs &
     return m;
 }
 
-__device__ __forceinline__ void sfocal_score_body(const SFocalScoreArgs &a, uint32_t blk) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = blk * (kSFocalScoreThreads / 64) + (threadIdx.x >> 6);
-    if (slot >= a.num_slots)
-        return;
-    if (a.num_models && (slot % kSFocalMaxModels) >= a.num_models[slot / kSFocalMaxModels])
-        return; // (wave-uniform)
+// one wavefront = the model of slot `slot`
+__device__ __forceinline__ void sfocal_score_slot(const SFocalScoreArgs &a, uint32_t slot, uint32_t lane) {
     const FocalModel m = sfocal_score_model(a, slot);
     double F[9];
     sfocal_F_score(m, F);
@@ -371,6 +366,23 @@ __device__ __forceinline__ void sfocal_score_body(const SFocalScoreArgs &a, uint
         a.counts[slot] = count;
         a.scores[slot] = score;
     }
+}
+// A batch of iterations (num_models given): one WORKGROUP = one iteration, its models over the workgroup's wavefronts - an iteration has
+// 60 slots of which 0.2 hold a model, and a wavefront per slot was 3.8 M wavefronts per group launch to score 14 k models (0.75 ms, of
+// which the scoring is half).  Models given one by one (num_models == nullptr): one wavefront per slot.
+__device__ __forceinline__ void sfocal_score_body(const SFocalScoreArgs &a, uint32_t blk) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (a.num_models) {
+        if ((size_t)blk * kSFocalMaxModels >= a.num_slots) // (group launches: the grid is the largest member's)
+            return;
+        const uint32_t nm = a.num_models[blk];
+        for (uint32_t m = wave; m < nm; m += kSFocalScoreThreads / 64)
+            sfocal_score_slot(a, blk * (uint32_t)kSFocalMaxModels + m, lane);
+        return;
+    }
+    const uint32_t slot = blk * (kSFocalScoreThreads / 64) + wave;
+    if (slot < a.num_slots)
+        sfocal_score_slot(a, slot, lane);
 }
 __global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score(SFocalScoreArgs a) { sfocal_score_body(a, blockIdx.x); }
 __global__ __launch_bounds__(kSFocalScoreThreads) void k_sfocal_score_g(const SFocalScoreArgs *__restrict__ as) {
@@ -746,8 +758,8 @@ hipError_t launch_sfocal_score_g(const SFocalScoreArgs *args, uint32_t G, uint32
         k_sfocal_score_wg_g<<<dim3(max_slots, G), dim3(kSFocalScoreThreads), 0, stream>>>(args);
         return hipGetLastError();
     }
-    constexpr uint32_t per_block = kSFocalScoreThreads / 64;
-    k_sfocal_score_g<<<dim3((max_slots + per_block - 1) / per_block, G), dim3(kSFocalScoreThreads), 0, stream>>>(args);
+    // (a batch of iterations - every member's num_models is set: one workgroup per iteration)
+    k_sfocal_score_g<<<dim3((max_slots + kSFocalMaxModels - 1) / kSFocalMaxModels, G), dim3(kSFocalScoreThreads), 0, stream>>>(args);
     return hipGetLastError();
 }
 hipError_t launch_sfocal_mask_g(const FocalMaskArgs *args, uint32_t G, uint32_t max_n, hipStream_t stream) {
@@ -783,7 +795,8 @@ hipError_t launch_sfocal_score(const SFocalScoreArgs &a, hipStream_t stream) {
         return hipGetLastError();
     }
     constexpr uint32_t per_block = kSFocalScoreThreads / 64;
-    k_sfocal_score<<<dim3((a.num_slots + per_block - 1) / per_block), dim3(kSFocalScoreThreads), 0, stream>>>(a);
+    const uint32_t blocks = a.num_models ? (a.num_slots + kSFocalMaxModels - 1) / kSFocalMaxModels : (a.num_slots + per_block - 1) / per_block;
+    k_sfocal_score<<<dim3(blocks), dim3(kSFocalScoreThreads), 0, stream>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_sfocal_mask(const double *const *a, uint32_t n, const FocalModel &m, double thr2, uint8_t *mask, uint8_t *host_mask,
