@@ -18,6 +18,9 @@
 // wavefront touch consecutive doubles.
 #pragma once
 #include "pl_math.h"
+#if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
+#include "pl_eigen_packed.h" // (tests/hostmath: the packed eigenvalue routines shadow the serial ones, below)
+#endif
 
 namespace pl {
 
@@ -244,9 +247,6 @@ template <int ROWS, int COLS> PL_HD void complement_basis_indexed(double *qr /* 
 #if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
 // tests/hostmath: every matrix the solvers hand to this routine also goes through the packed form of pl_eigen_packed.h (the device's
 // routine since round 5, here with the lane loops as loops); calls and disagreements (count or any bit of an eigenvalue) are counted
-} // namespace pl
-#include "pl_eigen_packed.h"
-namespace pl {
 extern unsigned long long pl_eig_shadow_counters[4]; // [eigenvalue calls, disagreements, balancing calls, disagreements]
 template <int n, class Arr> inline int pl_real_eigenvalues_serial(Arr a_, double *out, double tol);
 template <int n, class Arr> inline int pl_real_eigenvalues(Arr a_, double *out, double tol) {
