@@ -19,6 +19,7 @@
 #include "pl_solver_p35pf.h"
 #include "pl_eigen_wave.h"
 #include "pl_eigen_packed.h"
+#include "pl_nullvec_packed.h"
 #include "pl_lm_chain.inc"
 #include <algorithm>
 #include <atomic>
@@ -114,7 +115,7 @@ static_assert(eig_wave_doubles(10) + kP35ActionDoubles <= 100 * kFinRoots, "the 
 //                   kernel's time, its vector ALUs 70 % busy; giving the four matrices of a workgroup to one of its wavefronts (three
 //                   waiting at a barrier) was slower still (5.8 -> 7.0 ms per 64 k samples): the packed iteration wants many
 //                   wavefronts per SIMD, which a kernel of its own has (18 KB of LDS per 16 samples)
-//   k_focal_roots   one wavefront = one sample, one lane per root: null vector, pose, focal length; the estimator's filter
+//   k_focal_roots   one wavefront = one sample, 16 lanes per root: null vector (pl_nullvec_packed.h), pose, focal length; the estimator's filter
 constexpr uint32_t kSplitSamples = 4096; // launches of at least so many samples take the three kernels, smaller ones the single kernel
 constexpr int kActDoubles = 112, kActEv = 100, kActOk = 110, kActRoots = 111;
 __device__ __forceinline__ double *focal_act(const FocalGenArgs &g, uint32_t it) {
@@ -290,22 +291,75 @@ __device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t
             g.host_num_models[it] = m;
     }
 }
+// k_focal_roots (round 5, second form): one wavefront = one sample, its roots FOUR at a time - 16 lanes per root, lane j of a group holds
+// column j of (action matrix - eigenvalue) in registers and the group finds the null vector together (pl_nullvec_packed.h: positions
+// instead of swaps, one division per lane, the serial routine's bits); lane 0 of the group turns it into pose and focal length.
+// One lane per root on a working copy in LDS (focal_emit_roots: the single kernel's form) was ~2500 LDS round trips per root.
+constexpr int kRootsLds = 100 + 60 + 4 * 10 + 10 * 8 + 10; // action matrix | N | null vectors of a pass | solutions | valid
 __device__ __forceinline__ void focal_roots_body(const FocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_solve[kSolveWaves][kSolveLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double s_roots[kSolveWaves][kRootsLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
+    const size_t B = g.num_iters;
     const double *act = focal_act(g, it);
-    double *base = s_solve[wave];
+    double *am = s_roots[wave], *Ns = am + 100, *vs = Ns + 60, *sols = vs + 40, *valid_s = sols + 80;
     uint32_t m = 0;
     const int nroots = (int)act[kActRoots]; // (0: degenerate sample, or no real eigenvalue)
     if (nroots > 0) {
         for (int e = lane; e < 100; e += 64)
-            base[e] = act[e];
-        const double ev = lane < nroots ? act[kActEv + lane] : 0.0;
+            am[e] = act[e];
+        if (lane < 60)
+            Ns[lane] = g.stage[(size_t)(kStageN + lane) * B + it];
+        const double f0 = g.stage[(size_t)kStageF0 * B + it];
         PL_WAVE_SYNC();
-        m = focal_emit_roots(g, it, lane, base, nroots, ev);
+        for (int first = 0; first < nroots; first += 4) { // (uniform)
+            const int root = first + grp;
+            const bool on = root < nroots;
+            const double ev = act[kActEv + (on ? root : 0)];
+            NullWave4<10> cx;
+            cx.gl = gl, cx.lane = lane, cx.cp = 0, cx.yv = 0, cx.t1 = 0, cx.t2 = 0;
+#pragma unroll
+            for (int r = 0; r < 10; ++r) { // column gl of wk = am - ev I (p35pf_pose_of_root)
+                const double a = gl < 10 ? am[r * 10 + gl] : 0.0;
+                cx.c[r] = r == gl ? a - ev : a;
+            }
+            pl_null_vector_packed<10>(cx, on);
+            if (gl < 10)
+                vs[grp * 10 + gl] = cx.yv;
+            PL_WAVE_SYNC();
+            if (gl == 0 && on) {
+                P35Solution sol;
+                bool valid = p35pf_pose_from_null_vector(vs + grp * 10, Ns, f0, sol);
+                if (valid && !g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
+                    if (sol.focal < 0)
+                        valid = false;
+                    if (g.max_focal >= 0 && sol.focal > g.max_focal)
+                        valid = false;
+                }
+                double *o = sols + root * 8;
+                o[0] = sol.q.w, o[1] = sol.q.x, o[2] = sol.q.y, o[3] = sol.q.z;
+                o[4] = sol.t.x, o[5] = sol.t.y, o[6] = sol.t.z, o[7] = sol.focal;
+                valid_s[root] = valid ? 1.0 : 0.0;
+            }
+            PL_WAVE_SYNC();
+        }
+        // the solutions leave in the order of the roots
+        const bool valid = lane < nroots && valid_s[lane < nroots ? lane : 0] != 0.0;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
+        m = (uint32_t)__popcll(mask);
+        if (valid) {
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            FocalModel o;
+            const double *sv = sols + lane * 8;
+            o.q[0] = sv[0], o.q[1] = sv[1], o.q[2] = sv[2], o.q[3] = sv[3];
+            o.t[0] = sv[4], o.t[1] = sv[5], o.t[2] = sv[6];
+            o.f = sv[7];
+            g.models[(size_t)it * kFocalMaxModels + pos] = o;
+            if (g.host_models)
+                g.host_models[(size_t)it * kFocalMaxModels + pos] = o;
+        }
     }
     if (lane == 0) {
         g.num_models[it] = m;
@@ -329,8 +383,8 @@ __global__ __launch_bounds__(64 * kEigWaves) void k_focal_eig_g(const FocalGenAr
     const FocalGenArgs g = gs[blockIdx.y];
     focal_eig_body(g, blockIdx.x);
 }
-__global__ PL_SOLVE_ATTR void k_focal_roots(FocalGenArgs g) { focal_roots_body(g, blockIdx.x); }
-__global__ PL_SOLVE_ATTR void k_focal_roots_g(const FocalGenArgs *__restrict__ gs) {
+__global__ __launch_bounds__(64 * kSolveWaves) void k_focal_roots(FocalGenArgs g) { focal_roots_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64 * kSolveWaves) void k_focal_roots_g(const FocalGenArgs *__restrict__ gs) {
     const FocalGenArgs g = gs[blockIdx.y];
     focal_roots_body(g, blockIdx.x);
 }

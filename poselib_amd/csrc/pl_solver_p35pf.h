@@ -19,7 +19,8 @@
 #pragma once
 #include "pl_math.h"
 #if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
-#include "pl_eigen_packed.h" // (tests/hostmath: the packed eigenvalue routines shadow the serial ones, below)
+#include "pl_eigen_packed.h" // (tests/hostmath: the packed eigenvalue / null-vector routines shadow the serial ones, below)
+#include "pl_nullvec_packed.h"
 #endif
 
 namespace pl {
@@ -247,7 +248,7 @@ template <int ROWS, int COLS> PL_HD void complement_basis_indexed(double *qr /* 
 #if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
 // tests/hostmath: every matrix the solvers hand to this routine also goes through the packed form of pl_eigen_packed.h (the device's
 // routine since round 5, here with the lane loops as loops); calls and disagreements (count or any bit of an eigenvalue) are counted
-extern unsigned long long pl_eig_shadow_counters[4]; // [eigenvalue calls, disagreements, balancing calls, disagreements]
+extern unsigned long long pl_eig_shadow_counters[6]; // [eigenvalue calls, disagreements, balancing calls, disagreements, null-vector calls, disagreements]
 template <int n, class Arr> inline int pl_real_eigenvalues_serial(Arr a_, double *out, double tol);
 template <int n, class Arr> inline int pl_real_eigenvalues(Arr a_, double *out, double tol) {
     double shadow[n * n + 4 * n];
@@ -449,7 +450,28 @@ PL_HD int p35_real_eigenvalues(double *a_, double *out, double tol) { return pl_
 
 // null vector of the singular n x n matrix B (row-major, destroyed): Gaussian elimination with complete pivoting, the last
 // permuted unknown set to 1
-template <int n, class Arr> PL_HD void pl_null_vector(Arr B, double *v) {
+#if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
+// tests/hostmath: every matrix also goes through the packed form (pl_nullvec_packed.h: 16 lanes per matrix on the device, here with the
+// lane loops as loops); calls and disagreements (any bit of the null vector) are counted in pl_eig_shadow_counters[4], [5]
+template <int n, class Arr> inline void pl_null_vector_serial(Arr B, double *v);
+template <int n, class Arr> inline void pl_null_vector(Arr B, double *v) {
+    NullFlatHost<n> cx;
+    for (int r = 0; r < n; ++r)
+        for (int j = 0; j < n; ++j)
+            cx.b[r][j] = B[r * n + j];
+    pl_null_vector_serial<n, Arr>(B, v);
+    pl_null_vector_packed<n>(cx, true);
+    bool same = true;
+    for (int j = 0; j < n; ++j)
+        same = same && std::memcmp(&v[j], &cx.yv[j], sizeof(double)) == 0;
+    pl_eig_shadow_counters[4]++;
+    pl_eig_shadow_counters[5] += same ? 0 : 1;
+}
+#define pl_null_vector_impl pl_null_vector_serial
+#else
+#define pl_null_vector_impl pl_null_vector
+#endif
+template <int n, class Arr> PL_HD void pl_null_vector_impl(Arr B, double *v) {
     int colperm[n];
     for (int i = 0; i < n; ++i)
         colperm[i] = i;
@@ -689,6 +711,8 @@ PL_HD int p35pf_finish(const double *E /* 50 */, const double *N /* 60 */, doubl
     return p35pf_poses(am, wk, ev, nroots, N, f0, out);
 }
 // one root: the null vector of (action matrix - eigenvalue), P = sum alpha_k N_k, the pose and focal length.  false: no solution
+// the pose and focal length that belong to the null vector v of (action matrix - eigenvalue): P = sum alpha_k N_k
+PL_HD bool p35pf_pose_from_null_vector(const double *v /* 10 */, const double *N /* 60 */, double f0, P35Solution &out);
 PL_HD bool p35pf_pose_of_root(const StridedArr &am, const StridedArr &wk, double ev, const double *N /* 60 */, double f0,
                               P35Solution &out) {
     double v[10];
@@ -697,6 +721,9 @@ PL_HD bool p35pf_pose_of_root(const StridedArr &am, const StridedArr &wk, double
     for (int i = 0; i < 10; ++i)
         wk[i * 10 + i] -= ev;
     pl_null_vector<10>(wk, v);
+    return p35pf_pose_from_null_vector(v, N, f0, out);
+}
+PL_HD bool p35pf_pose_from_null_vector(const double *v, const double *N, double f0, P35Solution &out) {
     if (v[9] == 0)
         return false;
     const double al[5] = {v[5] / v[9], v[6] / v[9], v[7] / v[9], v[8] / v[9], 1.0};

@@ -24,6 +24,7 @@
 #include "pl_solver_6ptf.h"
 #include "pl_eigen_wave.h"
 #include "pl_eigen_packed.h"
+#include "pl_nullvec_packed.h"
 #include "pl_lm_chain.inc"
 #include <algorithm>
 #include <atomic>
@@ -100,14 +101,16 @@ constexpr int kFinC = 0, kFinA = 300, kFinNb = kFinA + 100 * kFinRoots, kFinX = 
               kFinDoubles = kFinTmp + 7 * kMaxRoots;
 static_assert(eig_wave_doubles(15) <= 100 * kFinRoots, "the eigenvalue workspace lives in the roots' region");
 // Round 5: the solve stage as THREE kernels over a per-sample record in the workspace (sample-major, behind the element-major rows):
-//   [companion matrix 225 | eigenvalues 15 | ok | number of real eigenvalues]
+//   [companion matrix 225 (later: the solutions) | eigenvalues 15 | ok | number of real eigenvalues | number of solutions]
 //   k_sfocal_comp    one wavefront = one sample: the row reduction to the companion matrix (six_companion_wave)
 //   k_sfocal_eig     one wavefront = FOUR samples, 16 lanes each: balancing and eigenvalues (pl_eigen_packed.h).  Inside one kernel every
 //                    wavefront iterated on its own matrix with <= 15 lanes at work and every scalar of the iteration computed 64 times:
 //                    63 % of the kernel's time (profiles/r05_focal_batch.md)
-//   k_sfocal_roots   one wavefront = one sample: one lane per root, then one lane per solution
+//   k_sfocal_roots   one wavefront = one sample, 16 lanes per root: (x, y) from the null vector of C0 + w C1 + w^2 C2 (pl_nullvec_packed.h), the list of solutions
+//   k_sfocal_poses   one wavefront = FOUR samples, one lane per solution: essential matrix, up to four poses; the models in order
 constexpr uint32_t kSplitSamples = 4096; // launches of at least so many samples take the three kernels, smaller ones the single kernel
-constexpr int kSfActDoubles = 244, kSfActEv = 225, kSfActOk = 240, kSfActRoots = 241;
+constexpr int kSfActDoubles = 244, kSfActEv = 225, kSfActOk = 240, kSfActRoots = 241, kSfActNs = 242,
+              kSfActSol = 0; // (the solutions sx | sy | sw, 16 each, take the companion matrix's place once the eigenvalues are known)
 __device__ __forceinline__ double *sfocal_act(const SFocalGenArgs &g, uint32_t it) {
     return g.stage + (size_t)kStDoubles * g.num_iters + (size_t)it * kSfActDoubles;
 }
@@ -170,67 +173,77 @@ __device__ __forceinline__ void sfocal_eig_body(const SFocalGenArgs &g, uint32_t
         act[kSfActRoots] = ok ? (double)nr : 0.0;
 }
 // phase 1, lane s = root s: (x, y) from the null vector of C0 + w C1 + w^2 C2 (its own 10 x 10 matrix in LDS); lane 0 builds the list of
-// solutions ascending in y as the serial routine inserts them; phase 2, lane s = solution s: essential matrix, up to four poses; the
-// models leave in the order of the solutions.  base: the wavefront's LDS block (equations, null space and bearings in place).  Returns
-// the number of models (every lane).
-__device__ __forceinline__ uint32_t sfocal_emit_roots(const SFocalGenArgs &g, uint32_t it, int lane, double *base, int nroots, double wv) {
+// solutions ascending in y as the serial routine inserts them.  base: the wavefront's LDS block (equations in place).  The list is left
+// in LDS (sx, sy, sw behind kFinTmp); returns its length (uniform).
+__device__ __forceinline__ int sfocal_root_solutions(int lane, double *base, int nroots, double wv) {
     double *rx = base + kFinTmp, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots,
-           *sw = sy + kMaxRoots, *cnt = sw + kMaxRoots;
-    uint32_t m = 0;
-    {
-        // root s = pass * kFinRoots + lane: its eigenvalue sits in lane s
-        uint64_t fmask = 0;
-        for (int first = 0; first < nroots; first += kFinRoots) {
-            const double w_s = __shfl(wv, first + (lane < kFinRoots ? lane : 0), 64);
-            bool found = false;
-            if (lane < kFinRoots && first + lane < nroots) {
-                double x = 0, y = 0;
-                found = six_root_xy(SixWork{base + kFinC, 1}, SixWork{base + kFinA + lane, (size_t)kFinRoots}, w_s, x, y);
-                rx[first + lane] = x, ry[first + lane] = y, rw[first + lane] = w_s;
-            }
-            fmask |= __builtin_amdgcn_ballot_w64(found) << first;
-            PL_WAVE_SYNC();
+           *sw = sy + kMaxRoots;
+    // root s = pass * kFinRoots + lane: its eigenvalue sits in lane s
+    uint64_t fmask = 0;
+    for (int first = 0; first < nroots; first += kFinRoots) {
+        const double w_s = __shfl(wv, first + (lane < kFinRoots ? lane : 0), 64);
+        bool found = false;
+        if (lane < kFinRoots && first + lane < nroots) {
+            double x = 0, y = 0;
+            found = six_root_xy(SixWork{base + kFinC, 1}, SixWork{base + kFinA + lane, (size_t)kFinRoots}, w_s, x, y);
+            rx[first + lane] = x, ry[first + lane] = y, rw[first + lane] = w_s;
         }
-        int ns = 0;
-        if (lane == 0)
-            for (int s = 0; s < nroots; ++s)
-                if ((fmask >> s) & 1u)
-                    six_insert_solution(sx, sy, sw, ns, rx[s], ry[s], rw[s]);
-        ns = __builtin_amdgcn_readfirstlane(ns);
+        fmask |= __builtin_amdgcn_ballot_w64(found) << first;
         PL_WAVE_SYNC();
-        FocalModel mine[4];
-        uint32_t c = 0;
-        if (lane < ns) {
-            // (bearings and null space are read from LDS where they are used: as local copies they cost 126 registers)
-            const Vec3 *x1 = reinterpret_cast<const Vec3 *>(base + kFinX), *x2 = x1 + 6;
-            const double *nb = base + kFinNb;
-            six_solution_poses(x1, x2, nb, sx[lane], sy[lane], sw[lane], [&](Quat q, Vec3 t, double f) {
-                FocalModel o;
-                o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
-                o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
-                o.f = f;
-                if (c < 4u)
-                    mine[c] = o;
-                ++c;
-            });
-        }
-        if (lane < kMaxRoots)
-            cnt[lane] = (double)c;
-        PL_WAVE_SYNC();
-        uint32_t off = 0;
-        for (int s = 0; s < ns; ++s) {
-            const uint32_t cs = (uint32_t)cnt[s];
-            off += s < lane ? cs : 0u;
-            m += cs;
-        }
-        FocalModel *out = g.models + (size_t)it * kSFocalMaxModels;
-        for (uint32_t i = 0; i < c && i < 4u; ++i) {
-            out[off + i] = mine[i];
-            if (g.host_models)
-                g.host_models[(size_t)it * kSFocalMaxModels + off + i] = mine[i];
-        }
+    }
+    int ns = 0;
+    if (lane == 0)
+        for (int s = 0; s < nroots; ++s)
+            if ((fmask >> s) & 1u)
+                six_insert_solution(sx, sy, sw, ns, rx[s], ry[s], rw[s]);
+    ns = __builtin_amdgcn_readfirstlane(ns);
+    PL_WAVE_SYNC();
+    return ns;
+}
+// phase 2, lane gl (< 16) of a group of 16 lanes = solution gl of sample `it`: essential matrix, up to four poses; the models leave in
+// the order of the solutions (prefix sum of the counts over the group).  x1 / x2 / nb: the sample's bearings and null space, cnt: 16
+// doubles of scratch - LDS of the group.  One group per wavefront (the single kernel) or four (k_sfocal_poses).  Returns the number of
+// models of the sample (every lane of the group).
+__device__ __forceinline__ uint32_t sfocal_emit_poses(const SFocalGenArgs &g, uint32_t it, int gl, int ns, double sxv, double syv, double swv,
+                                                      const Vec3 *x1, const Vec3 *x2, const double *nb, double *cnt) {
+    FocalModel mine[4];
+    uint32_t c = 0;
+    if (gl < ns) {
+        // (bearings and null space are read from LDS where they are used: as local copies they cost 126 registers)
+        six_solution_poses(x1, x2, nb, sxv, syv, swv, [&](Quat q, Vec3 t, double f) {
+            FocalModel o;
+            o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
+            o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
+            o.f = f;
+            if (c < 4u)
+                mine[c] = o;
+            ++c;
+        });
+    }
+    if (gl < kMaxRoots)
+        cnt[gl] = (double)c;
+    PL_WAVE_SYNC();
+    uint32_t off = 0, m = 0;
+    for (int s = 0; s < ns; ++s) {
+        const uint32_t cs = (uint32_t)cnt[s];
+        off += s < gl ? cs : 0u;
+        m += cs;
+    }
+    FocalModel *out = g.models + (size_t)it * kSFocalMaxModels;
+    for (uint32_t i = 0; i < c && i < 4u; ++i) {
+        out[off + i] = mine[i];
+        if (g.host_models)
+            g.host_models[(size_t)it * kSFocalMaxModels + off + i] = mine[i];
     }
     return m;
+}
+// both phases by the sample's own wavefront (the single kernel)
+__device__ __forceinline__ uint32_t sfocal_emit_roots(const SFocalGenArgs &g, uint32_t it, int lane, double *base, int nroots, double wv) {
+    const int ns = sfocal_root_solutions(lane, base, nroots, wv);
+    double *sx = base + kFinTmp + 3 * kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots, *cnt = sw + kMaxRoots;
+    const int s = lane < kMaxRoots ? lane : 0;
+    const Vec3 *x1 = reinterpret_cast<const Vec3 *>(base + kFinX);
+    return sfocal_emit_poses(g, it, lane < kMaxRoots ? lane : kMaxRoots, ns, sx[s], sy[s], sw[s], x1, x1 + 6, base + kFinNb, cnt);
 }
 // The solve stage in ONE kernel (small launches: see focal.hip - the chain of a single problem's batch is shorter this way; the same bits)
 __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32_t blk) {
@@ -262,35 +275,84 @@ __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32
             g.host_num_models[it] = m;
     }
 }
+// k_sfocal_roots (round 5, second form): one wavefront = one sample, its roots FOUR at a time - 16 lanes per root, lane j of a group forms
+// column j of C0 + w C1 + w^2 C2 in registers and the group finds the null vector together (pl_nullvec_packed.h); (x, y) of the root
+// from its entries 7, 8, 9.  Lane 0 of the wavefront then builds the list of solutions ascending in y as the serial routine inserts
+// them.  (One lane per root on a working copy in LDS - sfocal_root_solutions, the single kernel's form - was ~2800 LDS round trips per root.)
+constexpr int kSfRootsLds = 300 + 6 * kMaxRoots; // equations | rx ry rw | sx sy sw
 __device__ __forceinline__ void sfocal_roots_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_fin[kSolveWaves][kFinDoubles];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double s_fin[kSolveWaves][kSfRootsLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
-    const bool alive = true;
     const size_t B = g.num_iters;
     const double *st = g.stage + it;
-    const double *act = sfocal_act(g, it);
-    double *base = s_fin[wave];
-    uint32_t m = 0;
+    double *act = sfocal_act(g, it);
+    double *C = s_fin[wave];
+    double *rx = C + 300, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots;
     const int nroots = (int)act[kSfActRoots]; // (0: no companion matrix, or no real eigenvalue)
-    double wv = 0.0;
+    int ns = 0;
     if (nroots > 0) {
-        // the equations (the roots' null vectors), the null space and the bearings (the poses)
-        for (int e = lane; e < 300; e += 64)
-            base[kFinC + e] = st[(size_t)(kStC + e) * B];
-        if (lane < 27)
-            base[kFinNb + lane] = st[(size_t)(kStNb + lane) * B];
-        if (lane < 36)
-            base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
-        if (lane < nroots)
-            wv = act[kSfActEv + lane];
+        for (int e = lane; e < 300; e += 64) // the equations
+            C[e] = st[(size_t)(kStC + e) * B];
         PL_WAVE_SYNC();
+        uint32_t fmask = 0; // (uniform) bit s: root s has a solution
+        for (int first = 0; first < nroots; first += 4) { // (uniform)
+            const int root = first + grp;
+            const double wv = act[kSfActEv + (root < nroots ? root : 0)];
+            const bool on = root < nroots && !(wv < 1e-8); // six_root_xy: focal lengths beyond 1e4 are dropped
+            NullWave4<10> cx;
+            cx.gl = gl, cx.lane = lane, cx.cp = 0, cx.yv = 0, cx.t1 = 0, cx.t2 = 0;
+#pragma unroll
+            for (int r = 0; r < 10; ++r) { // column gl of A = C0 + w (C1 + w C2)
+                const int e = r * 10 + (gl < 10 ? gl : 0);
+                cx.c[r] = C[e] + wv * (C[100 + e] + wv * C[200 + e]);
+            }
+            pl_null_vector_packed<10>(cx, on);
+            const double v7 = null_row_bcast<7>(cx.yv), v8 = null_row_bcast<8>(cx.yv), v9 = null_row_bcast<9>(cx.yv);
+            const bool found = on && !(v9 == 0);
+            if (gl == 0 && found)
+                rx[root] = v7 / v9, ry[root] = v8 / v9, rw[root] = wv;
+            const uint64_t b = __builtin_amdgcn_ballot_w64(gl == 0 && found);
+            fmask |= ((uint32_t)(b & 1u) | (uint32_t)((b >> 16) & 1u) << 1 | (uint32_t)((b >> 32) & 1u) << 2 | (uint32_t)((b >> 48) & 1u) << 3) << first;
+            PL_WAVE_SYNC();
+        }
+        if (lane == 0)
+            for (int s = 0; s < nroots; ++s)
+                if ((fmask >> s) & 1u)
+                    six_insert_solution(sx, sy, sw, ns, rx[s], ry[s], rw[s]);
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        PL_WAVE_SYNC();
+        if (lane < ns) // the list of solutions: into the record (the companion matrix's place - dead since the eigenvalue kernel)
+            act[kSfActSol + lane] = sx[lane], act[kSfActSol + kMaxRoots + lane] = sy[lane], act[kSfActSol + 2 * kMaxRoots + lane] = sw[lane];
     }
-    if (nroots > 0)
-        m = sfocal_emit_roots(g, it, lane, base, nroots, wv);
-    if (alive && lane == 0) {
+    if (lane == 0)
+        act[kSfActNs] = (double)ns;
+}
+// k_sfocal_poses: one wavefront = FOUR samples, lane 16 g + s = solution s of sample g (a sample has <= 15 solutions and typically
+// one to three: as one wavefront per sample the poses were 18 % of the solve stage with a handful of lanes at work)
+constexpr int kPoseWaves = 4, kPoseLds = 80; // per group: null space 27 | bearings 36 | counts 16
+__device__ __forceinline__ void sfocal_poses_body(const SFocalGenArgs &g, uint32_t blk) {
+    __shared__ double s_pose[kPoseWaves][4][kPoseLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+    const uint32_t it = (blk * kPoseWaves + wave) * 4u + grp;
+    const bool alive = it < g.num_iters;
+    const size_t B = g.num_iters;
+    const double *st = g.stage + (alive ? it : 0u);
+    const double *act = sfocal_act(g, alive ? it : 0u);
+    const int ns = alive ? (int)act[kSfActNs] : 0;
+    double *mine = s_pose[wave][grp];
+    if (ns > 0)
+        for (int e = gl; e < 63; e += 16)
+            mine[e] = e < 27 ? st[(size_t)(kStNb + e) * B] : st[(size_t)(kStX + (e - 27)) * B];
+    PL_WAVE_SYNC();
+    const int s = gl < ns ? gl : 0;
+    const double sxv = ns > 0 ? act[kSfActSol + s] : 0.0, syv = ns > 0 ? act[kSfActSol + kMaxRoots + s] : 0.0,
+                 swv = ns > 0 ? act[kSfActSol + 2 * kMaxRoots + s] : 1.0;
+    const Vec3 *x1 = reinterpret_cast<const Vec3 *>(mine + 27);
+    const uint32_t m = sfocal_emit_poses(g, alive ? it : 0u, gl, ns, sxv, syv, swv, x1, x1 + 6, mine, mine + 63);
+    if (alive && gl == 0) {
         g.num_models[it] = m;
         if (g.host_num_models)
             g.host_num_models[it] = m;
@@ -312,8 +374,13 @@ __global__ __launch_bounds__(64 * kEigWaves) void k_sfocal_eig_g(const SFocalGen
     const SFocalGenArgs g = gs[blockIdx.y];
     sfocal_eig_body(g, blockIdx.x);
 }
-__global__ PL_SOLVE_ATTR void k_sfocal_roots(SFocalGenArgs g) { sfocal_roots_body(g, blockIdx.x); }
-__global__ PL_SOLVE_ATTR void k_sfocal_roots_g(const SFocalGenArgs *__restrict__ gs) {
+__global__ __launch_bounds__(64 * kPoseWaves) void k_sfocal_poses(SFocalGenArgs g) { sfocal_poses_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64 * kPoseWaves) void k_sfocal_poses_g(const SFocalGenArgs *__restrict__ gs) {
+    const SFocalGenArgs g = gs[blockIdx.y];
+    sfocal_poses_body(g, blockIdx.x);
+}
+__global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_roots(SFocalGenArgs g) { sfocal_roots_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_roots_g(const SFocalGenArgs *__restrict__ gs) {
     const SFocalGenArgs g = gs[blockIdx.y];
     sfocal_roots_body(g, blockIdx.x);
 }
@@ -734,6 +801,7 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     k_sfocal_comp<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     k_sfocal_eig<<<dim3((g.num_iters + 4 * kEigWaves - 1) / (4 * kEigWaves)), dim3(64 * kEigWaves), 0, stream>>>(g);
     k_sfocal_roots<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+    k_sfocal_poses<<<dim3((g.num_iters + 4 * kPoseWaves - 1) / (4 * kPoseWaves)), dim3(64 * kPoseWaves), 0, stream>>>(g);
     return hipGetLastError();
 }
 // ---- group launches (driver_focal_group.inc): blockIdx.y = member, the grid's x extent = the largest member's; `args` is a
@@ -749,6 +817,7 @@ hipError_t launch_sfocal_generate_g(const SFocalGenArgs *args, uint32_t G, uint3
     k_sfocal_comp_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
     k_sfocal_eig_g<<<dim3((max_iters + 4 * kEigWaves - 1) / (4 * kEigWaves), G), dim3(64 * kEigWaves), 0, stream>>>(args);
     k_sfocal_roots_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+    k_sfocal_poses_g<<<dim3((max_iters + 4 * kPoseWaves - 1) / (4 * kPoseWaves), G), dim3(64 * kPoseWaves), 0, stream>>>(args);
     return hipGetLastError();
 }
 hipError_t launch_sfocal_score_g(const SFocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream) {

@@ -1011,11 +1011,20 @@ extern "C" void hm_ransac_shared_focal(const double *const *pa, uint32_t n, uint
 // ---- the packed eigenvalue routines (pl_eigen_packed.h) against the serial ones: shadow counters of this build (Makefile), and the
 // routines on matrices given explicitly (n = 10: plain; n = 15: balanced first, as six_eigenvalues does)
 namespace pl {
-unsigned long long pl_eig_shadow_counters[4] = {0, 0, 0, 0};
+unsigned long long pl_eig_shadow_counters[6] = {0, 0, 0, 0, 0, 0};
 }
-extern "C" void hm_eig_shadow_counters(unsigned long long *out4) {
-    for (int i = 0; i < 4; ++i)
-        out4[i] = pl::pl_eig_shadow_counters[i];
+extern "C" void hm_eig_shadow_counters(unsigned long long *out6) {
+    for (int i = 0; i < 6; ++i)
+        out6[i] = pl::pl_eig_shadow_counters[i];
+}
+// pl_null_vector<10> on matrices given explicitly (the shadow check of this build compares the packed form on each)
+extern "C" void hm_null_vectors(const double *mats, int count, double *v_out) {
+    for (int k = 0; k < count; ++k) {
+        double a[100];
+        for (int e = 0; e < 100; ++e)
+            a[e] = mats[(size_t)k * 100 + e];
+        pl_null_vector<10, double *>(a, v_out + (size_t)k * 10);
+    }
 }
 extern "C" int hm_real_eigenvalues(int n, const double *mats, int count, double *ev_out, int *m_out) {
     for (int k = 0; k < count; ++k) {

@@ -539,7 +539,7 @@ def test_flat_root_isolation_finds_the_recursions_leaves_bit_for_bit():
 def _eig_counters():
     import ctypes as C
 
-    out = (C.c_ulonglong * 4)()
+    out = (C.c_ulonglong * 6)()
     HM.lib().hm_eig_shadow_counters(out)
     return list(out)
 
@@ -611,3 +611,66 @@ def test_packed_eigenvalues_equal_the_serial_routines_bit_for_bit():
     after = _eig_counters()
     assert after[0] - mid[0] >= 3600, (mid, after)
     assert after[1] == 0 and after[3] == 0, f"packed != serial: {after[1]} of {after[0]} eigenvalue calls, {after[3]} of {after[2]} balancing calls"
+
+
+def test_packed_null_vector_equals_the_serial_routine_bit_for_bit():
+    """pl_nullvec_packed.h (16 lanes per matrix on the device) against pl_null_vector<10> through the shadow check of the tests/hostmath
+    build: the solvers' own matrices (every root of 300 + 300 minimal problems), random singular and non-singular matrices of several
+    scalings, and the cases that exercise the tie rule of the complete pivoting (equal magnitudes: +-1 matrices, permutations, repeated
+    rows and columns), early termination (zero blocks, rank 1 ... 8) and non-finite entries."""
+    import ctypes as C
+
+    before = _eig_counters()
+    rng = np.random.default_rng(21)
+    for k in range(300):
+        d = synth.absolute_pose_scene(4, 0.0, 33000 + k, noise_px=0.3)
+        f, cx, cy = d["camera"]["params"]
+        HM.p35pf((np.asarray(d["p2d"]) - [cx, cy]) / f, d["p3d"])
+        d = synth.relative_pose_scene(6, 0.0, 34000 + k, noise_px=0.3)
+        f, cx, cy = d["camera1"]["params"]
+        b1 = np.c_[(np.asarray(d["x1"]) - [cx, cy]) / f, np.ones(6)]
+        b2 = np.c_[(np.asarray(d["x2"]) - [cx, cy]) / f, np.ones(6)]
+        HM.relpose_6pt_shared_focal(b1 / np.linalg.norm(b1, axis=1, keepdims=True), b2 / np.linalg.norm(b2, axis=1, keepdims=True))
+    mid = _eig_counters()
+    assert mid[4] - before[4] >= 1000, (before, mid)
+    mats = []
+    for _ in range(1500):
+        A = rng.normal(size=(10, 10)) * 10.0 ** rng.integers(-6, 7)
+        if rng.random() < 0.7:  # singular: rank 9 (the case the routine is made for) or less
+            rank = int(rng.choice([9, 9, 9, 8, 5, 2, 1]))
+            U, S, Vt = np.linalg.svd(A)
+            S[rank:] = 0
+            A = (U * S) @ Vt
+        mats.append(A)
+    for _ in range(600):  # equal magnitudes everywhere: the scan order decides the pivot
+        A = rng.choice([-1.0, 1.0, 0.0, 2.0, -2.0], size=(10, 10), p=[0.3, 0.3, 0.2, 0.1, 0.1])
+        mats.append(A)
+    for _ in range(200):
+        A = np.eye(10)[rng.permutation(10)] * rng.choice([-1.0, 1.0, 3.0], size=10)
+        if rng.random() < 0.5:
+            A[rng.integers(10)] = 0
+        mats.append(A)
+    for _ in range(200):  # repeated rows / columns, zero blocks
+        A = rng.integers(-3, 4, size=(10, 10)).astype(float)
+        A[rng.integers(10)] = A[rng.integers(10)]
+        A[:, rng.integers(10)] = A[:, rng.integers(10)]
+        if rng.random() < 0.3:
+            A[5:, 5:] = 0
+        mats.append(A)
+    mats += [np.zeros((10, 10)), np.ones((10, 10)), np.eye(10), np.triu(np.ones((10, 10))), np.tril(np.ones((10, 10)))]
+    bad = rng.normal(size=(10, 10))
+    bad[2, 7] = np.nan
+    mats.append(bad)
+    bad = rng.normal(size=(10, 10))
+    bad[4, 4] = np.inf
+    mats.append(bad)
+    M = np.ascontiguousarray(np.array(mats), dtype=np.float64)
+    v = np.zeros((len(mats), 10))
+    HM.lib().hm_null_vectors(M.ctypes.data_as(C.c_void_p), C.c_int(len(mats)), v.ctypes.data_as(C.c_void_p))
+    # and it is a null vector (rank-9 matrices)
+    for k in range(0, 1500, 50):
+        if np.linalg.matrix_rank(mats[k]) == 9:
+            assert np.abs(mats[k] @ v[k]).max() <= 1e-8 * np.abs(mats[k]).max() * np.abs(v[k]).max(), k
+    after = _eig_counters()
+    assert after[4] - mid[4] == len(mats), (mid, after)
+    assert after[5] == 0, f"packed != serial null vector: {after[5]} of {after[4]} calls"
