@@ -101,12 +101,12 @@ __device__ __forceinline__ double readlane_f64(double v, int l) { // (l uniform)
 //                 pair each, and all 35 columns are updated at once - element for element the operations of p35pf_eliminate
 //                 (pl_solver_p35pf.h), so the results are the same bits (as one lane per sample, matrices in LDS: 0.43 ms)
 //   eigenvalues   of the 10 x 10 action matrix by the lanes together (pl_eigen_wave.h; one lane per sample: 0.55 ms)
-//   roots         lane s = root s: null vector (its own 10 x 10 working copy in LDS), pose and focal length at once
-//                 (p35pf_pose_of_root; one lane per sample, root after root: 0.41 ms); the solutions leave in the order of the roots
-//                 (ballot + v_mbcnt)
-constexpr int kSolveWaves = 4, kFinRoots = 10; // (the action matrix is 10 x 10: at most 10 roots)
-constexpr int kSolveLds = 100 + 100 * kFinRoots; // action matrix | working copies of the roots, element-major over the roots
-static_assert(eig_wave_doubles(10) + kP35ActionDoubles <= 100 * kFinRoots, "the eigenvalue workspace and E live in the roots' region");
+//   roots         four at a time, 16 lanes per root: null vector with a matrix column per lane in registers (pl_nullvec_packed.h;
+//                 round 4: lane s = root s on its own 10 x 10 working copy in LDS), pose and focal length by the group's first lane;
+//                 the solutions leave in the order of the roots (ballot + v_mbcnt)
+constexpr int kSolveWaves = 4;
+constexpr int kSolveLds = 100 + eig_wave_doubles(10) + 190; // action matrix | eigenvalue workspace | E (50), later the roots' scratch (kRootsScratch)
+static_assert(kP35ActionDoubles <= 190, "E and the roots' scratch share a region");
 // Round 5: the solve stage as THREE kernels over a per-sample record in the workspace (sample-major, behind the element-major rows):
 //   [action matrix 100 | eigenvalues 10 | ok | number of real eigenvalues]
 //   k_focal_elim    one wavefront = one sample: the elimination, the action matrix
@@ -228,33 +228,62 @@ __device__ __forceinline__ void focal_eig_body(const FocalGenArgs &g, uint32_t b
     if (alive && gl == 0)
         act[kActRoots] = ok ? (double)nr : 0.0;
 }
-// lane s = root s of sample `it`: null vector (its own 10 x 10 working copy in LDS behind the action matrix `base`), pose and focal length;
-// the solutions the estimator keeps leave in the order of the roots.  Returns their number (every lane).
-__device__ __forceinline__ uint32_t focal_emit_roots(const FocalGenArgs &g, uint32_t it, int lane, double *base, int nroots, double ev) {
+// The roots of sample `it`, FOUR at a time: 16 lanes per root, lane j of a group holds column j of (action matrix - eigenvalue) in
+// registers and the group finds the null vector together (pl_nullvec_packed.h: positions instead of swaps, one division per lane, the
+// serial routine's bits); lane 0 of the group turns it into pose and focal length; the solutions the estimator keeps leave in the order of
+// the roots.  am: the action matrix (LDS, 100), ev: the eigenvalues (nroots, ascending), ws: kRootsScratch doubles of LDS.  Returns the
+// number of solutions (every lane).  (Rounds 3 - 4: one lane per root on a 10 x 10 working copy in LDS, ~2500 LDS round trips per root.)
+constexpr int kRootsScratch = 60 + 4 * 10 + 10 * 8 + 10; // N | null vectors of a pass | solutions | valid
+static_assert(kRootsScratch <= 190, "the single kernel's LDS block (kSolveLds)");
+__device__ __forceinline__ uint32_t focal_emit_roots(const FocalGenArgs &g, uint32_t it, int lane, const double *am, const double *ev, int nroots,
+                                                     double *ws) {
     const size_t B = g.num_iters;
-    const double *stage = g.stage;
-    bool valid = false;
-    P35Solution sol;
-    if (lane < nroots) {
-        double N[60];
-        for (int e = 0; e < 60; ++e)
-            N[e] = stage[(size_t)(kStageN + e) * B + it];
-        const double f0 = stage[(size_t)kStageF0 * B + it];
-        valid = p35pf_pose_of_root(StridedArr{base, 1}, StridedArr{base + 100 + lane, (size_t)kFinRoots}, ev, N, f0, sol);
-        if (valid && !g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
-            if (sol.focal < 0)
-                valid = false;
-            if (g.max_focal >= 0 && sol.focal > g.max_focal)
-                valid = false;
+    const int grp = lane >> 4, gl = lane & 15;
+    double *Ns = ws, *vs = Ns + 60, *sols = vs + 40, *valid_s = sols + 80;
+    if (lane < 60)
+        Ns[lane] = g.stage[(size_t)(kStageN + lane) * B + it];
+    const double f0 = g.stage[(size_t)kStageF0 * B + it];
+    PL_WAVE_SYNC();
+    for (int first = 0; first < nroots; first += 4) { // (uniform)
+        const int root = first + grp;
+        const bool on = root < nroots;
+        const double e = ev[on ? root : 0];
+        NullWave4<10> cx;
+        cx.gl = gl, cx.lane = lane, cx.cp = 0, cx.yv = 0, cx.t1 = 0, cx.t2 = 0;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { // column gl of wk = am - ev I (p35pf_pose_of_root)
+            const double a = gl < 10 ? am[r * 10 + gl] : 0.0;
+            cx.c[r] = r == gl ? a - e : a;
         }
+        pl_null_vector_packed<10>(cx, on);
+        if (gl < 10)
+            vs[grp * 10 + gl] = cx.yv;
+        PL_WAVE_SYNC();
+        if (gl == 0 && on) {
+            P35Solution sol;
+            bool valid = p35pf_pose_from_null_vector(vs + grp * 10, Ns, f0, sol);
+            if (valid && !g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
+                if (sol.focal < 0)
+                    valid = false;
+                if (g.max_focal >= 0 && sol.focal > g.max_focal)
+                    valid = false;
+            }
+            double *o = sols + root * 8;
+            o[0] = sol.q.w, o[1] = sol.q.x, o[2] = sol.q.y, o[3] = sol.q.z;
+            o[4] = sol.t.x, o[5] = sol.t.y, o[6] = sol.t.z, o[7] = sol.focal;
+            valid_s[root] = valid ? 1.0 : 0.0;
+        }
+        PL_WAVE_SYNC();
     }
+    const bool valid = lane < nroots && valid_s[lane < nroots ? lane : 0] != 0.0;
     const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
     if (valid) {
         const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         FocalModel o;
-        o.q[0] = sol.q.w, o.q[1] = sol.q.x, o.q[2] = sol.q.y, o.q[3] = sol.q.z;
-        o.t[0] = sol.t.x, o.t[1] = sol.t.y, o.t[2] = sol.t.z;
-        o.f = sol.focal;
+        const double *sv = sols + lane * 8;
+        o.q[0] = sv[0], o.q[1] = sv[1], o.q[2] = sv[2], o.q[3] = sv[3];
+        o.t[0] = sv[4], o.t[1] = sv[5], o.t[2] = sv[6];
+        o.f = sv[7];
         g.models[(size_t)it * kFocalMaxModels + pos] = o;
         if (g.host_models)
             g.host_models[(size_t)it * kFocalMaxModels + pos] = o;
@@ -281,9 +310,9 @@ __device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t
             eig[e] = v;
         }
         const int nroots = pl_real_eigenvalues_wave<10>(eig, 1e-8, lane);
-        const double ev = lane < nroots ? eig[100 + 30 + lane] : 0.0;
         PL_WAVE_SYNC();
-        m = focal_emit_roots(g, it, lane, base, nroots, ev);
+        // (the eigenvalues stand at eig[130 ...], the roots' scratch behind the eigenvalue workspace)
+        m = focal_emit_roots(g, it, lane, base, eig + 100 + 30, nroots, eig + eig_wave_doubles(10));
     }
     if (lane == 0) {
         g.num_models[it] = m;
@@ -291,75 +320,22 @@ __device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t
             g.host_num_models[it] = m;
     }
 }
-// k_focal_roots (round 5, second form): one wavefront = one sample, its roots FOUR at a time - 16 lanes per root, lane j of a group holds
-// column j of (action matrix - eigenvalue) in registers and the group finds the null vector together (pl_nullvec_packed.h: positions
-// instead of swaps, one division per lane, the serial routine's bits); lane 0 of the group turns it into pose and focal length.
-// One lane per root on a working copy in LDS (focal_emit_roots: the single kernel's form) was ~2500 LDS round trips per root.
-constexpr int kRootsLds = 100 + 60 + 4 * 10 + 10 * 8 + 10; // action matrix | N | null vectors of a pass | solutions | valid
+// k_focal_roots: one wavefront = one sample - the action matrix and the eigenvalues from the sample's record, then focal_emit_roots
+constexpr int kRootsLds = 100 + 10 + kRootsScratch; // action matrix | eigenvalues | scratch
 __device__ __forceinline__ void focal_roots_body(const FocalGenArgs &g, uint32_t blk) {
     __shared__ double s_roots[kSolveWaves][kRootsLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
-    const size_t B = g.num_iters;
     const double *act = focal_act(g, it);
-    double *am = s_roots[wave], *Ns = am + 100, *vs = Ns + 60, *sols = vs + 40, *valid_s = sols + 80;
+    double *am = s_roots[wave], *ev = am + 100;
     uint32_t m = 0;
     const int nroots = (int)act[kActRoots]; // (0: degenerate sample, or no real eigenvalue)
     if (nroots > 0) {
-        for (int e = lane; e < 100; e += 64)
+        for (int e = lane; e < 110; e += 64) // (the record: action matrix 100 | eigenvalues 10)
             am[e] = act[e];
-        if (lane < 60)
-            Ns[lane] = g.stage[(size_t)(kStageN + lane) * B + it];
-        const double f0 = g.stage[(size_t)kStageF0 * B + it];
-        PL_WAVE_SYNC();
-        for (int first = 0; first < nroots; first += 4) { // (uniform)
-            const int root = first + grp;
-            const bool on = root < nroots;
-            const double ev = act[kActEv + (on ? root : 0)];
-            NullWave4<10> cx;
-            cx.gl = gl, cx.lane = lane, cx.cp = 0, cx.yv = 0, cx.t1 = 0, cx.t2 = 0;
-#pragma unroll
-            for (int r = 0; r < 10; ++r) { // column gl of wk = am - ev I (p35pf_pose_of_root)
-                const double a = gl < 10 ? am[r * 10 + gl] : 0.0;
-                cx.c[r] = r == gl ? a - ev : a;
-            }
-            pl_null_vector_packed<10>(cx, on);
-            if (gl < 10)
-                vs[grp * 10 + gl] = cx.yv;
-            PL_WAVE_SYNC();
-            if (gl == 0 && on) {
-                P35Solution sol;
-                bool valid = p35pf_pose_from_null_vector(vs + grp * 10, Ns, f0, sol);
-                if (valid && !g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
-                    if (sol.focal < 0)
-                        valid = false;
-                    if (g.max_focal >= 0 && sol.focal > g.max_focal)
-                        valid = false;
-                }
-                double *o = sols + root * 8;
-                o[0] = sol.q.w, o[1] = sol.q.x, o[2] = sol.q.y, o[3] = sol.q.z;
-                o[4] = sol.t.x, o[5] = sol.t.y, o[6] = sol.t.z, o[7] = sol.focal;
-                valid_s[root] = valid ? 1.0 : 0.0;
-            }
-            PL_WAVE_SYNC();
-        }
-        // the solutions leave in the order of the roots
-        const bool valid = lane < nroots && valid_s[lane < nroots ? lane : 0] != 0.0;
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
-        m = (uint32_t)__popcll(mask);
-        if (valid) {
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            FocalModel o;
-            const double *sv = sols + lane * 8;
-            o.q[0] = sv[0], o.q[1] = sv[1], o.q[2] = sv[2], o.q[3] = sv[3];
-            o.t[0] = sv[4], o.t[1] = sv[5], o.t[2] = sv[6];
-            o.f = sv[7];
-            g.models[(size_t)it * kFocalMaxModels + pos] = o;
-            if (g.host_models)
-                g.host_models[(size_t)it * kFocalMaxModels + pos] = o;
-        }
+        m = focal_emit_roots(g, it, lane, am, ev, nroots, ev + 10);
     }
     if (lane == 0) {
         g.num_models[it] = m;
@@ -368,8 +344,9 @@ __device__ __forceinline__ void focal_roots_body(const FocalGenArgs &g, uint32_t
     }
 }
 #define PL_SOLVE_ATTR __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
-__global__ PL_SOLVE_ATTR void k_focal_solve(FocalGenArgs g) { focal_solve_body(g, blockIdx.x); }
-__global__ PL_SOLVE_ATTR void k_focal_solve_g(const FocalGenArgs *__restrict__ gs) {
+// (the single kernel serves launches that do not fill the device: no register cap - the packed null vectors want ~150)
+__global__ __launch_bounds__(64 * kSolveWaves) void k_focal_solve(FocalGenArgs g) { focal_solve_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64 * kSolveWaves) void k_focal_solve_g(const FocalGenArgs *__restrict__ gs) {
     const FocalGenArgs g = gs[blockIdx.y];
     focal_solve_body(g, blockIdx.x);
 }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_sfocal_setup_g(const SFocalGenArgs *__re
 //                then builds the list of solutions ascending in y exactly as the serial routine inserts them.  Phase 2, lane s =
 //                solution s: essential matrix, up to four poses; the models leave in the order of the solutions (prefix sum of the
 //                counts).  As one lane per sample (root after root, solution after solution): 0.79 ms per batch.
-constexpr int kSolveWaves = 4, kFinRoots = 8, kMaxRoots = 16; // the roots go through the lanes kFinRoots at a time (a second pass is rare)
+constexpr int kSolveWaves = 4, kFinRoots = 8, kMaxRoots = 16; // (kFinRoots: sizes the single kernel's row-reduction region - rounds 3 - 4: per-root working copies)
 constexpr int kFinC = 0, kFinA = 300, kFinNb = kFinA + 100 * kFinRoots, kFinX = kFinNb + 27, kFinTmp = kFinX + 36,
               kFinDoubles = kFinTmp + 7 * kMaxRoots;
 static_assert(eig_wave_doubles(15) <= 100 * kFinRoots, "the eigenvalue workspace lives in the roots' region");
@@ -172,23 +172,33 @@ __device__ __forceinline__ void sfocal_eig_body(const SFocalGenArgs &g, uint32_t
     if (alive && gl == 0)
         act[kSfActRoots] = ok ? (double)nr : 0.0;
 }
-// phase 1, lane s = root s: (x, y) from the null vector of C0 + w C1 + w^2 C2 (its own 10 x 10 matrix in LDS); lane 0 builds the list of
-// solutions ascending in y as the serial routine inserts them.  base: the wavefront's LDS block (equations in place).  The list is left
-// in LDS (sx, sy, sw behind kFinTmp); returns its length (uniform).
-__device__ __forceinline__ int sfocal_root_solutions(int lane, double *base, int nroots, double wv) {
-    double *rx = base + kFinTmp, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots,
-           *sw = sy + kMaxRoots;
-    // root s = pass * kFinRoots + lane: its eigenvalue sits in lane s
-    uint64_t fmask = 0;
-    for (int first = 0; first < nroots; first += kFinRoots) {
-        const double w_s = __shfl(wv, first + (lane < kFinRoots ? lane : 0), 64);
-        bool found = false;
-        if (lane < kFinRoots && first + lane < nroots) {
-            double x = 0, y = 0;
-            found = six_root_xy(SixWork{base + kFinC, 1}, SixWork{base + kFinA + lane, (size_t)kFinRoots}, w_s, x, y);
-            rx[first + lane] = x, ry[first + lane] = y, rw[first + lane] = w_s;
+// phase 1, the roots of a sample FOUR at a time: 16 lanes per root, lane j of a group forms column j of C0 + w C1 + w^2 C2 in registers
+// and the group finds the null vector together (pl_nullvec_packed.h); (x, y) of the root from its entries 7, 8, 9.  Lane 0 of the
+// wavefront then builds the list of solutions ascending in y as the serial routine inserts them.  C: the equations (LDS, 300), ev: the
+// eigenvalues (nroots), ws: 6 x kMaxRoots doubles of LDS - the list is left in its second half (sx | sy | sw); returns its length (uniform).
+// (Rounds 3 - 4: one lane per root on a 10 x 10 working copy in LDS, ~2800 LDS round trips per root.)
+__device__ __forceinline__ int sfocal_root_solutions(int lane, const double *C, const double *ev, int nroots, double *ws) {
+    const int grp = lane >> 4, gl = lane & 15;
+    double *rx = ws, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots;
+    uint32_t fmask = 0; // (uniform) bit s: root s has a solution
+    for (int first = 0; first < nroots; first += 4) { // (uniform)
+        const int root = first + grp;
+        const double wv = ev[root < nroots ? root : 0];
+        const bool on = root < nroots && !(wv < 1e-8); // six_root_xy: focal lengths beyond 1e4 are dropped
+        NullWave4<10> cx;
+        cx.gl = gl, cx.lane = lane, cx.cp = 0, cx.yv = 0, cx.t1 = 0, cx.t2 = 0;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { // column gl of A = C0 + w (C1 + w C2)
+            const int e = r * 10 + (gl < 10 ? gl : 0);
+            cx.c[r] = C[e] + wv * (C[100 + e] + wv * C[200 + e]);
         }
-        fmask |= __builtin_amdgcn_ballot_w64(found) << first;
+        pl_null_vector_packed<10>(cx, on);
+        const double v7 = null_row_bcast<7>(cx.yv), v8 = null_row_bcast<8>(cx.yv), v9 = null_row_bcast<9>(cx.yv);
+        const bool found = on && !(v9 == 0);
+        if (gl == 0 && found)
+            rx[root] = v7 / v9, ry[root] = v8 / v9, rw[root] = wv;
+        const uint64_t b = __builtin_amdgcn_ballot_w64(gl == 0 && found);
+        fmask |= ((uint32_t)(b & 1u) | (uint32_t)((b >> 16) & 1u) << 1 | (uint32_t)((b >> 32) & 1u) << 2 | (uint32_t)((b >> 48) & 1u) << 3) << first;
         PL_WAVE_SYNC();
     }
     int ns = 0;
@@ -238,8 +248,8 @@ __device__ __forceinline__ uint32_t sfocal_emit_poses(const SFocalGenArgs &g, ui
     return m;
 }
 // both phases by the sample's own wavefront (the single kernel)
-__device__ __forceinline__ uint32_t sfocal_emit_roots(const SFocalGenArgs &g, uint32_t it, int lane, double *base, int nroots, double wv) {
-    const int ns = sfocal_root_solutions(lane, base, nroots, wv);
+__device__ __forceinline__ uint32_t sfocal_emit_roots(const SFocalGenArgs &g, uint32_t it, int lane, double *base, const double *ev, int nroots) {
+    const int ns = sfocal_root_solutions(lane, base + kFinC, ev, nroots, base + kFinTmp);
     double *sx = base + kFinTmp + 3 * kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots, *cnt = sw + kMaxRoots;
     const int s = lane < kMaxRoots ? lane : 0;
     const Vec3 *x1 = reinterpret_cast<const Vec3 *>(base + kFinX);
@@ -264,10 +274,9 @@ __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32
     if (sfocal_companion(g, it, lane, reg, base + kFinC)) {
         pl_balance_pow2_wave<15>(reg, lane);
         const int nroots = pl_real_eigenvalues_wave<15>(reg, 1e-8, lane);
-        const double wv = lane < nroots ? reg[225 + 45 + lane] : 0.0;
         PL_WAVE_SYNC();
-        if (nroots > 0)
-            m = sfocal_emit_roots(g, it, lane, base, nroots, wv);
+        if (nroots > 0) // (the eigenvalues stand at reg[270 ...])
+            m = sfocal_emit_roots(g, it, lane, base, reg + 225 + 45, nroots);
     }
     if (lane == 0) {
         g.num_models[it] = m;
@@ -275,55 +284,29 @@ __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32
             g.host_num_models[it] = m;
     }
 }
-// k_sfocal_roots (round 5, second form): one wavefront = one sample, its roots FOUR at a time - 16 lanes per root, lane j of a group forms
-// column j of C0 + w C1 + w^2 C2 in registers and the group finds the null vector together (pl_nullvec_packed.h); (x, y) of the root
-// from its entries 7, 8, 9.  Lane 0 of the wavefront then builds the list of solutions ascending in y as the serial routine inserts
-// them.  (One lane per root on a working copy in LDS - sfocal_root_solutions, the single kernel's form - was ~2800 LDS round trips per root.)
-constexpr int kSfRootsLds = 300 + 6 * kMaxRoots; // equations | rx ry rw | sx sy sw
+// k_sfocal_roots: one wavefront = one sample - the equations from the workspace, the eigenvalues from the sample's record, then
+// sfocal_root_solutions; the list of solutions goes into the record
+constexpr int kSfRootsLds = 300 + kMaxRoots + 6 * kMaxRoots; // equations | eigenvalues | rx ry rw | sx sy sw
 __device__ __forceinline__ void sfocal_roots_body(const SFocalGenArgs &g, uint32_t blk) {
     __shared__ double s_fin[kSolveWaves][kSfRootsLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
     const size_t B = g.num_iters;
     const double *st = g.stage + it;
     double *act = sfocal_act(g, it);
-    double *C = s_fin[wave];
-    double *rx = C + 300, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots;
+    double *C = s_fin[wave], *ev = C + 300, *ws = ev + kMaxRoots;
     const int nroots = (int)act[kSfActRoots]; // (0: no companion matrix, or no real eigenvalue)
     int ns = 0;
     if (nroots > 0) {
         for (int e = lane; e < 300; e += 64) // the equations
             C[e] = st[(size_t)(kStC + e) * B];
+        if (lane < nroots)
+            ev[lane] = act[kSfActEv + lane];
         PL_WAVE_SYNC();
-        uint32_t fmask = 0; // (uniform) bit s: root s has a solution
-        for (int first = 0; first < nroots; first += 4) { // (uniform)
-            const int root = first + grp;
-            const double wv = act[kSfActEv + (root < nroots ? root : 0)];
-            const bool on = root < nroots && !(wv < 1e-8); // six_root_xy: focal lengths beyond 1e4 are dropped
-            NullWave4<10> cx;
-            cx.gl = gl, cx.lane = lane, cx.cp = 0, cx.yv = 0, cx.t1 = 0, cx.t2 = 0;
-#pragma unroll
-            for (int r = 0; r < 10; ++r) { // column gl of A = C0 + w (C1 + w C2)
-                const int e = r * 10 + (gl < 10 ? gl : 0);
-                cx.c[r] = C[e] + wv * (C[100 + e] + wv * C[200 + e]);
-            }
-            pl_null_vector_packed<10>(cx, on);
-            const double v7 = null_row_bcast<7>(cx.yv), v8 = null_row_bcast<8>(cx.yv), v9 = null_row_bcast<9>(cx.yv);
-            const bool found = on && !(v9 == 0);
-            if (gl == 0 && found)
-                rx[root] = v7 / v9, ry[root] = v8 / v9, rw[root] = wv;
-            const uint64_t b = __builtin_amdgcn_ballot_w64(gl == 0 && found);
-            fmask |= ((uint32_t)(b & 1u) | (uint32_t)((b >> 16) & 1u) << 1 | (uint32_t)((b >> 32) & 1u) << 2 | (uint32_t)((b >> 48) & 1u) << 3) << first;
-            PL_WAVE_SYNC();
-        }
-        if (lane == 0)
-            for (int s = 0; s < nroots; ++s)
-                if ((fmask >> s) & 1u)
-                    six_insert_solution(sx, sy, sw, ns, rx[s], ry[s], rw[s]);
-        ns = __builtin_amdgcn_readfirstlane(ns);
-        PL_WAVE_SYNC();
+        ns = sfocal_root_solutions(lane, C, ev, nroots, ws);
+        const double *sx = ws + 3 * kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots;
         if (lane < ns) // the list of solutions: into the record (the companion matrix's place - dead since the eigenvalue kernel)
             act[kSfActSol + lane] = sx[lane], act[kSfActSol + kMaxRoots + lane] = sy[lane], act[kSfActSol + 2 * kMaxRoots + lane] = sw[lane];
     }
@@ -359,8 +342,9 @@ __device__ __forceinline__ void sfocal_poses_body(const SFocalGenArgs &g, uint32
     }
 }
 #define PL_SOLVE_ATTR __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
-__global__ PL_SOLVE_ATTR void k_sfocal_solve(SFocalGenArgs g) { sfocal_solve_body(g, blockIdx.x); }
-__global__ PL_SOLVE_ATTR void k_sfocal_solve_g(const SFocalGenArgs *__restrict__ gs) {
+// (the single kernel serves launches that do not fill the device: no register cap - the packed null vectors want ~140)
+__global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve(SFocalGenArgs g) { sfocal_solve_body(g, blockIdx.x); }
+__global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve_g(const SFocalGenArgs *__restrict__ gs) {
     const SFocalGenArgs g = gs[blockIdx.y];
     sfocal_solve_body(g, blockIdx.x);
 }
