@@ -123,6 +123,28 @@ def test_mixed_call_with_items_the_group_path_does_not_take(gpu):
             assert np.array_equal(got[k][0], ref[0])
 
 
+def test_opencv_cameras_in_a_group(gpu):
+    """distorted pixels, OPENCV camera with a focal length that is 25 % off: un-projection (k_prepare_g), the bound of compute_max_focal_length
+    (host, the same camera_unproject) and the bundle with the focal lengths free run inside the group - every member equals its single call"""
+    problems = []
+    for k in range(8):
+        focal = 700.0 + 50.0 * k
+        d = synth.absolute_pose_scene(300 + 150 * k, [0.2, 0.4][k % 2], 24000 + k, focal=focal, noise_px=0.5)
+        f, cx, cy = d["camera"]["params"]
+        dist = [f, f, cx, cy, -0.08 + 0.01 * k, 0.02, 0.001, -0.0005]
+        pix = synth.opencv_distort_pixels(np.asarray(d["p2d"]), dist)
+        cam = {"model": "OPENCV", "width": d["camera"]["width"], "height": d["camera"]["height"], "params": [1.25 * f, 1.25 * f] + dist[2:]}
+        opt = {"max_error": 4.0, "estimate_focal_length": True, "ransac": {"seed": k}}
+        if k % 2:
+            opt["min_fov"] = 15.0
+        if k % 3 == 0:
+            opt["bundle"] = {"refine_principal_point": True}
+        problems.append(("abs", pix, d["p3d"], cam, opt))
+    got = gpu.estimate_batch(problems, max_in_flight=2)
+    for k, pr in enumerate(problems):
+        _check_equal(("opencv", k), pr, got[k], _single(gpu, pr))
+
+
 def test_group_size_does_not_change_results(gpu):
     """the same 24 problems in one call with 1 worker (one group of 24) and with 8 workers (groups of 3): identical"""
     problems = [_pnpf_problem(300 + k, 300 + 70 * k, [0.2, 0.5][k % 2]) for k in range(24)]
