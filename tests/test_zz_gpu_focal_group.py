@@ -145,6 +145,33 @@ def test_opencv_cameras_in_a_group(gpu):
         _check_equal(("opencv", k), pr, got[k], _single(gpu, pr))
 
 
+def test_concurrent_batch_calls_with_focal_items(gpu):
+    """three host threads, each with its own pl_estimate_batch call of focal items in flight (the calls lease different worker pools; the
+    group contexts are per worker thread): every result equals its single call"""
+    import threading
+
+    calls = [[_pnpf_problem(500 + 10 * t + k, 400 + 60 * k, 0.4) for k in range(6)] + [_sfocal_problem(500 + 10 * t + k, 350 + 50 * k, 0.3) for k in range(6)]
+             for t in range(3)]
+    out, errs = [None] * 3, []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                out[t] = gpu.estimate_batch(calls[t], max_in_flight=3)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(3):
+        for k, pr in enumerate(calls[t]):
+            _check_equal(("concurrent", t, k), pr, out[t][k], _single(gpu, pr))
+
+
 def test_group_size_does_not_change_results(gpu):
     """the same 24 problems in one call with 1 worker (one group of 24) and with 8 workers (groups of 3): identical"""
     problems = [_pnpf_problem(300 + k, 300 + 70 * k, [0.2, 0.5][k % 2]) for k in range(24)]
