@@ -183,6 +183,30 @@ def test_group_size_does_not_change_results(gpu):
         assert np.array_equal(np.r_[a[k][0].pose.q, a[k][0].pose.t], np.r_[b[k][0].pose.q, b[k][0].pose.t])
 
 
+def test_mirror_budget_defers_batches_without_changing_results():
+    """POSELIB_AMD_FOCAL_MIRROR_MB=1 in a fresh process: a round serves only the batches whose pinned mirrors fit (one or two members),
+    the others wait for the next round - same results as the default budget"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, poselib_amd as P\n"
+        "from test_zz_gpu_focal_group import _pnpf_problem, _sfocal_problem\n"
+        "pr = [_pnpf_problem(600 + k, 400 + 90 * k, 0.45) for k in range(12)] + [_sfocal_problem(600 + k, 400 + 90 * k, 0.35) for k in range(12)]\n"
+        "got = P.estimate_batch(pr, 2)\n"
+        "print(json.dumps([[g[1][k] for k in ('iterations', 'refinements', 'num_inliers', 'model_score')] + [float(x) for x in (g[0].camera.params if hasattr(g[0], 'camera') else g[0].camera1.params)] + [float(x) for x in g[0].pose.q] for g in got]))\n"
+    ) % (root, os.path.join(root, "tests"))
+    outs = []
+    for env_extra in ({}, {"POSELIB_AMD_FOCAL_MIRROR_MB": "1"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
+
+
 def test_no_groups_switch_takes_the_single_problem_path():
     """POSELIB_AMD_NO_GROUPS=1 (diagnostic) in a fresh process: same results as the grouped call of this process"""
     import subprocess
