@@ -236,6 +236,31 @@ def test_both_focal_solvers_on_the_device_equal_the_oracle_bit_for_bit(gpu):
         assert np.array_equal(models[k, : counts[k], :7], po) and np.array_equal(models[k, : counts[k], 7], fo), k
         total += len(fo)
     assert total > 600
+    # launches of >= 4096 samples run the three-kernel form of the solve stage (elimination / row reduction, FOUR matrices per wavefront in
+    # the eigenvalue kernels, 16 lanes per null vector, the shared-focal poses four samples per wavefront): the same problems, the
+    # p35 samples re-drawn from their scenes, 4608 of each in one call - against the oracle again
+    big6 = np.concatenate([six] * 8)[:4608]
+    models, counts = gpu.solve_focal_batch("relpose_6pt_shared_focal", big6)
+    ref6 = [O.relpose_6pt_shared_focal(six[k, :18].reshape(6, 3), six[k, 18:].reshape(6, 3)) for k in range(len(six))]
+    for k in range(len(big6)):
+        po, fo = ref6[k % len(six)]
+        assert counts[k] == len(fo), k
+        assert np.array_equal(models[k, : counts[k], :7], po) and np.array_equal(models[k, : counts[k], 7], fo), k
+    big35 = []
+    for k in range(144):
+        d = synth.absolute_pose_scene(16, 0.0, 9700 + k, noise_px=[0.0, 1.0][k % 2], focal=float(rng.uniform(500, 2500)))
+        fcam, cx, cy = d["camera"]["params"]
+        x = np.asarray(d["p2d"]) - [cx, cy]
+        for j in range(32):
+            idx = rng.choice(16, 4, replace=False)
+            big35.append(np.r_[x[idx].reshape(-1), np.asarray(d["p3d"])[idx].reshape(-1)])
+    big35 = np.array(big35)
+    assert len(big35) == 4608
+    models, counts = gpu.solve_focal_batch("p35pf", big35)
+    for k in range(len(big35)):
+        po, fo = O.p35pf(big35[k, :8].reshape(4, 2), big35[k, 8:].reshape(4, 3))
+        assert counts[k] == len(fo), k
+        assert np.array_equal(models[k, : counts[k], :7], po) and np.array_equal(models[k, : counts[k], 7], fo), k
     # single-problem entry points on the golden vectors
     G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_focal_v1.json")))
     g35, g6 = minimal_inputs()
