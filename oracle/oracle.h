@@ -79,11 +79,15 @@ void orc_mock_ransac(uint64_t num_data, uint64_t sample_sz, uint64_t inlier_coun
 int orc_solve_cubic_single_real(double c2, double c1, double c0, double *root);
 int orc_solve_cubic_real(double c2, double c1, double c0, double *roots);
 int orc_sturm_roots(const double *coeffs, int degree, double *roots);
+int orc_sturm_roots_tol(const double *coeffs, int degree, double tol, double *roots);
 int orc_p3p(const double *x /*3x3*/, const double *X /*3x3*/, double *poses /*4x7*/);
 int orc_p35pf(const double *x /*4x2, principal point at the origin*/, const double *X /*4x3*/, double *poses /*10x7*/,
               double *focals /*10*/);
 int orc_relpose_6pt_shared_focal(const double *x1 /*6x3 unit bearings*/, const double *x2, double *poses /*60x7*/,
                                  double *focals /*60*/);
+/* the cubes in the six-point solver's coefficients: 1 = correctly rounded (default; what the device computes), 0 = std::pow(d, 3)
+   as the reference calls it (bit parity with oracle/_ref on the same host); process-wide, test use only */
+void orc_set_exact_cubes(int on);
 int orc_essential_5pt(const double *x1, const double *x2, double *E /*10x9 col-major each*/);
 int orc_relpose_5pt(const double *x1, const double *x2, double *poses /*40x7*/);
 int orc_relpose_7pt(const double *x1, const double *x2, double *F /*3x9*/);

@@ -174,6 +174,7 @@ int orc_solve_cubic_single_real(double c2, double c1, double c0, double *root) {
 }
 int orc_solve_cubic_real(double c2, double c1, double c0, double *roots) { return cubic_real_roots(c2, c1, c0, roots); }
 int orc_sturm_roots(const double *coeffs, int degree, double *roots) { return sturm_real_roots(coeffs, degree, roots); }
+int orc_sturm_roots_tol(const double *coeffs, int degree, double tol, double *roots) { return sturm_real_roots(coeffs, degree, roots, tol); }
 
 int orc_p3p(const double *x, const double *X, double *poses) {
     V3 xb[3], Xp[3];
@@ -210,6 +211,7 @@ int orc_relpose_6pt_shared_focal(const double *x1, const double *x2, double *pos
         pose_out(out[i], poses7 + 7 * i);
     return n;
 }
+void orc_set_exact_cubes(int on) { set_exact_cubes(on != 0); }
 int orc_essential_5pt(const double *x1, const double *x2, double *E) {
     V3 a[5], b[5];
     bearings(x1, 5, a);

@@ -18,13 +18,15 @@ int sturm_real_roots(const double *c, int N, double *roots, double tol = 1e-10);
 
 // absolute pose: unit bearings x, 3-D points X  ->  <= 4 poses
 int p3p(const V3 x[3], const V3 X[3], Pose out[4]);
-// P3.5Pf from first principles (solvers_focal.cc; interface of solvers/p35pf.h:39-54): image points relative to the principal
-// point, at most 10 (pose, focal) solutions
+// P3.5Pf (solvers_focal.cc restates solvers/p35pf.cc; interface solvers/p35pf.h:39-54): image points relative to the principal
+// point, at most 10 (pose, focal) solutions in the reference's order
 int p35pf(const V2 x[4], const V3 X[4], Pose out[10], double focals[10]);
 
 // relative pose (unit bearings)
 // shared unknown focal length from six correspondences (solvers_focal.cc; interface of solvers/relpose_6pt_focal.h:12-13)
 int relpose_6pt_shared_focal(const V3 x1[6], const V3 x2[6], Pose out[60], double focals[60]);
+// the cubes of the six-point coefficients: correctly rounded like the device (default) or std::pow(d, 3) like the reference
+void set_exact_cubes(bool on);
 int essential_5pt(const V3 x1[5], const V3 x2[5], M3 E[10]);
 int relpose_5pt(const V3 x1[5], const V3 x2[5], Pose out[40]);
 int relpose_7pt(const V3 x1[7], const V3 x2[7], M3 F[3]);

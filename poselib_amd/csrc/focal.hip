@@ -1,11 +1,13 @@
 // poselib_amd - kernels of the focal-length estimator (ransac_pnpf: robust/ransac.cc:58-75, FocalAbsolutePoseEstimator).
 //
 //   k_focal_setup      one lane = one RANSAC iteration: draw the sample of four correspondences from the iteration's position in
-//                      the splitmix64 stream (or take the host's PROSAC sample), null space and equations of P3.5Pf
-//                      (pl_solver_p35pf.h) -> the 29 x 35 elimination matrix, unscaled, into a workspace in HBM
-//   k_focal_solve      one WAVEFRONT = one iteration: row scaling, elimination with a matrix column per lane in registers,
-//                      eigenvalues of the action matrix by the lanes together (pl_eigen_wave.h), one lane per root; keeps the
-//                      solutions the estimator keeps (focal >= 0, focal <= max_focal_length: absolute_pose.cc:89-95)
+//                      the splitmix64 stream (or take the host's PROSAC sample), the null space of P3.5Pf's linear constraints
+//                      (pl_solver_p35pf.h, step 1) -> N (12 x 5) and the scale of the image points into a workspace in HBM
+//   k_focal_solve      one WAVEFRONT = one iteration, the matrices in LDS: the 235 coefficients (four per lane), the 25 x 35
+//                      template, LU with partial pivoting with a column per lane, the 10 x 10 action matrix, its eigenvalues by
+//                      the lanes together (pl_eigen_wave.h), one lane per real eigenvalue for the 5 x 4 least-squares system and
+//                      the pose; keeps the solutions the estimator keeps (focal >= 0, focal <= max_focal_length:
+//                      absolute_pose.cc:89-95) in the order of the eigenvalues
 //   k_focal_score      one wavefront = one model: compute_msac_score(Image, ...) (utils.cc:66-98) - inlier count and the sum of
 //                      the inliers' squared residuals IN CORRESPONDENCE ORDER (the score decides comparisons in the loop, so
 //                      it has to be the sequential sum): the lanes evaluate 64 correspondences at a time, the inliers' residuals
@@ -13,13 +15,13 @@
 //   k_focal_score_wg   the same score by one workgroup per model (producers / ordered chain): the few refined models of a local
 //                      optimisation
 //   k_focal_mask       get_inliers(Image, ...) (utils.cc:385-399), one thread per correspondence.
-// Round 3's form (one kernel, one lane per sample, matrices in LDS) and what each step of round 4 bought: DESIGN 4, "The focal-length estimators".
+// Rounds 3 - 5 solved P3.5Pf in a formulation of this project's own (29 x 35 Gauss-Jordan elimination in registers, packed
+// eigenvalue / null-vector kernels for large launches; CHANGELOG.md); round 6 restates the reference's action-matrix template so
+// that the solver returns the reference's roots bit for bit ("The focal-length estimators").
 #include "pl_focal.h"
 #include "pl_kernels.h"
 #include "pl_solver_p35pf.h"
 #include "pl_eigen_wave.h"
-#include "pl_eigen_packed.h"
-#include "pl_nullvec_packed.h"
 #include "pl_lm_chain.inc"
 #include <algorithm>
 #include <atomic>
@@ -29,12 +31,7 @@ namespace pl {
 namespace {
 
 // ---- the generator: two kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ------------------------
-//   k_focal_setup   one lane = one sample: draw (or read) the sample, null space of the linear constraints, the 29 equations
-//                   -> rows of the elimination matrix (coalesced: consecutive lanes = consecutive samples), N, f0
-//   k_focal_solve   one WAVEFRONT = one sample: elimination in registers, eigenvalues and roots by the lanes together (below)
-// Round 3's single kernel (one lane per sample, 8.1 KB of LDS per sample: 16 lanes per CU whatever the phase) took 1.5 ms per
-// launch and occupied 63 CUs for a batch of 1001 samples; the two kernels take 0.21 + 0.33 ms.
-constexpr int kStageN = kP35WorkDoubles, kStageF0 = kStageN + 60, kStageMx = kStageF0 + 1, kStageDoubles = kStageMx + kP35Rows;
+constexpr int kStageN = 0, kStageF0 = 60, kStageDoubles = 61;
 
 // (the kernels' bodies are functions of (arguments, block index): the single-problem kernels pass their own argument block, the
 // group kernels - blockIdx.y = member of the group - the member's entry of a device-resident table, read before any store)
@@ -66,19 +63,7 @@ __device__ __forceinline__ void focal_setup_body(const FocalGenArgs &g, uint32_t
     }
     const size_t B = g.num_iters;
     double N[60], f0;
-    // the rows unscaled, their maxima beside them: the 35 divisions of a row are done by the 35 lanes of k_focal_solve that hold its
-    // columns (p35_store_row's operations, one lane per column instead of one lane for 1015 divisions)
-    double *const st = g.stage + it;
-    p35pf_setup_t(xs, X, [&](int r, const P35Cubic &eq) {
-        double mx = 0;
-#pragma unroll
-        for (int c = 0; c < kP35Cols; ++c)
-            mx = fmax(mx, fabs(eq.c[c]));
-#pragma unroll
-        for (int c = 0; c < kP35Cols; ++c)
-            st[(size_t)(r * kP35Cols + c) * B] = eq.c[c];
-        st[(size_t)(kStageMx + r) * B] = mx;
-    }, N, f0);
+    p35pf_nullspace(xs, X, N, f0);
     for (int e = 0; e < 60; ++e)
         g.stage[(size_t)(kStageN + e) * B + it] = N[e];
     g.stage[(size_t)kStageF0 * B + it] = f0;
@@ -89,281 +74,80 @@ __global__ __launch_bounds__(64) void k_focal_setup_g(const FocalGenArgs *__rest
     focal_setup_body(g, blockIdx.x);
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int l) { // (l uniform)
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-// k_focal_solve: one WAVEFRONT = one sample, three stages in one launch (as three kernels they cost two more dispatches per batch,
-// which is what several problems in flight on the device's hardware queues pay for: ~60 us each under 16 streams).
-//   elimination   lane c holds column c of the 29 x 35 matrix in registers (58 VGPRs); per pivot every lane searches its own column,
-//                 the pivot's lane decides (v_readlane), the factors f_r = entry (r, col) come from the pivot's lane one v_readlane
-//                 pair each, and all 35 columns are updated at once - element for element the operations of p35pf_eliminate
-//                 (pl_solver_p35pf.h), so the results are the same bits (as one lane per sample, matrices in LDS: 0.43 ms)
-//   eigenvalues   of the 10 x 10 action matrix by the lanes together (pl_eigen_wave.h; one lane per sample: 0.55 ms)
-//   roots         four at a time, 16 lanes per root: null vector with a matrix column per lane in registers (pl_nullvec_packed.h;
-//                 round 4: lane s = root s on its own 10 x 10 working copy in LDS), pose and focal length by the group's first lane;
-//                 the solutions leave in the order of the roots (ballot + v_mbcnt)
+// k_focal_solve: one WAVEFRONT = one sample.  LDS of a wavefront (doubles):
+//   [0, 60) N | [60, 296) the coefficients, later the action matrix (100) | [296, 296 + 25 * 36) the template, row-major at a row
+//   stride of 36 (consecutive lanes = consecutive columns: no bank conflicts), later the eigenvalue workspace (130)
 constexpr int kSolveWaves = 4;
-constexpr int kSolveLds = 100 + eig_wave_doubles(10) + 190; // action matrix | eigenvalue workspace | E (50), later the roots' scratch (kRootsScratch)
-static_assert(kP35ActionDoubles <= 190, "E and the roots' scratch share a region");
-// Round 5: the solve stage as THREE kernels over a per-sample record in the workspace (sample-major, behind the element-major rows):
-//   [action matrix 100 | eigenvalues 10 | ok | number of real eigenvalues]
-//   k_focal_elim    one wavefront = one sample: the elimination, the action matrix
-//   k_focal_eig     one wavefront = FOUR samples, 16 lanes each: the eigenvalues (pl_eigen_packed.h).  Inside one kernel every wavefront
-//                   iterated on its own matrix with <= 10 lanes at work and every scalar of the iteration computed 64 times - 41 % of the
-//                   kernel's time, its vector ALUs 70 % busy; giving the four matrices of a workgroup to one of its wavefronts (three
-//                   waiting at a barrier) was slower still (5.8 -> 7.0 ms per 64 k samples): the packed iteration wants many
-//                   wavefronts per SIMD, which a kernel of its own has (18 KB of LDS per 16 samples)
-//   k_focal_roots   one wavefront = one sample, 16 lanes per root: null vector (pl_nullvec_packed.h), pose, focal length; the estimator's filter
-constexpr uint32_t kSplitSamples = 4096; // launches of at least so many samples take the three kernels, smaller ones the single kernel
-constexpr int kActDoubles = 112, kActEv = 100, kActOk = 110, kActRoots = 111;
-__device__ __forceinline__ double *focal_act(const FocalGenArgs &g, uint32_t it) {
-    return g.stage + (size_t)kStageDoubles * g.num_iters + (size_t)it * kActDoubles;
-}
-// the elimination of sample `it` by its wavefront; E (50 doubles of LDS): the rows of the action matrix that are not shifts.  false: degenerate
-__device__ __forceinline__ bool focal_eliminate(const double *stage, size_t B, uint32_t it, int lane, double *E) {
-    bool ok = true;
-    { // ---- elimination
-        const int c = lane < kP35Cols ? lane : kP35Cols - 1; // (lanes 35..63 shadow the last column: no divergence, never read)
-        double w[kP35Rows];
-#pragma unroll
-        for (int r = 0; r < kP35Rows; ++r) { // p35_store_row: the row scaled to unit maximum
-            const double mx = stage[(size_t)(kStageMx + r) * B + it];
-            const double raw = stage[(size_t)(r * kP35Cols + c) * B + it];
-            w[r] = mx > 0 ? raw / mx : 0.0;
-        }
-        uint32_t used = 0; // (uniform)
-        int pivot_of = 0;  // lane k: pivot row of eliminated monomial k
-#pragma unroll 1
-        for (int k = 0; k < 25; ++k) {
-            const int col = k < 23 ? k : k + 1; // kP35Elim
-            int pr = -1;
-            double best = 0;
-#pragma unroll
-            for (int r = 0; r < kP35Rows; ++r) {
-                const double v = fabs(w[r]);
-                if (!((used >> r) & 1u) && v > best)
-                    best = v, pr = r;
-            }
-            pr = __builtin_amdgcn_readlane(pr, col);
-            best = readlane_f64(best, col);
-            if (pr < 0 || best < 1e-13) { // degenerate sample
-                ok = false;
-                break;
-            }
-            used |= 1u << pr;
-            pivot_of = lane == k ? pr : pivot_of;
-            double mine = w[0]; // w[pr] of this lane's column
-#pragma unroll
-            for (int r = 1; r < kP35Rows; ++r)
-                mine = r == pr ? w[r] : mine;
-            const double inv = 1.0 / readlane_f64(mine, col);
-            const double prow = mine * inv;
-#pragma unroll
-            for (int r = 0; r < kP35Rows; ++r) {
-                const double f = readlane_f64(w[r], col); // entry (r, col) before this pivot's update
-                if (r == pr)
-                    w[r] = prow;
-                else if (f != 0)
-                    w[r] -= f * prow;
-            }
-        }
-        if (ok) {
-            // E[i][j] = entry (pivot row of monomial kP35ActionPivot[i], basis column j): lane kP35Basis[j] holds the column
-            const int j = lane >= 30 ? lane - 25 : lane == 27 ? 0 : lane == 23 ? 1 : lane == 26 ? 2 : lane == 28 ? 3 : lane == 29 ? 4 : -1;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int row = __builtin_amdgcn_readlane(pivot_of, kP35ActionPivot[i]);
-                double v = w[0];
-#pragma unroll
-                for (int r = 1; r < kP35Rows; ++r)
-                    v = r == row ? w[r] : v;
-                if (j >= 0 && lane < kP35Cols)
-                    E[i * 10 + j] = v;
-            }
-        }
-    }
-    return ok;
-}
-__device__ __forceinline__ double focal_action_entry(const double *E, int e) { // p35pf_action_entry
-    const int k = e / 10, j = e - 10 * k;
-    const int sh = kP35Shifted[k];
-    return sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[e];
-}
-__device__ __forceinline__ void focal_elim_body(const FocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_E[kSolveWaves][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
-    if (it >= g.num_iters)
-        return;
-    double *E = s_E[wave];
-    double *act = focal_act(g, it);
-    const bool ok = focal_eliminate(g.stage, g.num_iters, it, lane, E);
-    if (ok) { // ---- the action matrix
-        PL_WAVE_SYNC();
-        for (int e = lane; e < 100; e += 64)
-            act[e] = focal_action_entry(E, e);
-    }
-    if (lane == 0)
-        act[kActOk] = ok ? 1.0 : 0.0;
-}
-constexpr int kEigWaves = 4, kEigLds = 144; // (eig_wave_doubles(10) = 140, padded)
-static_assert(eig_wave_doubles(10) <= kEigLds, "a group's matrix and workspace");
-__device__ __forceinline__ void focal_eig_body(const FocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_eig[kEigWaves][4][kEigLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
-    const uint32_t it = (blk * kEigWaves + wave) * 4u + grp;
-    const bool alive = it < g.num_iters;
-    double *act = focal_act(g, alive ? it : 0u);
-    const bool ok = alive && act[kActOk] != 0.0;
-    double *mine = s_eig[wave][grp];
-    if (ok)
-        for (int e = gl; e < 100; e += 16)
-            mine[e] = act[e];
-    EigWave4<10> cx{mine, gl, lane};
-    const int nr = pl_real_eigenvalues_packed<10>(cx, ok, 1e-8);
-    if (ok && gl < nr)
-        act[kActEv + gl] = cx.out(gl);
-    if (alive && gl == 0)
-        act[kActRoots] = ok ? (double)nr : 0.0;
-}
-// The roots of sample `it`, FOUR at a time: 16 lanes per root, lane j of a group holds column j of (action matrix - eigenvalue) in
-// registers and the group finds the null vector together (pl_nullvec_packed.h: positions instead of swaps, one division per lane, the
-// serial routine's bits); lane 0 of the group turns it into pose and focal length; the solutions the estimator keeps leave in the order of
-// the roots.  am: the action matrix (LDS, 100), ev: the eigenvalues (nroots, ascending), ws: kRootsScratch doubles of LDS.  Returns the
-// number of solutions (every lane).  (Rounds 3 - 4: one lane per root on a 10 x 10 working copy in LDS, ~2500 LDS round trips per root.)
-constexpr int kRootsScratch = 60 + 4 * 10 + 10 * 8 + 10; // N | null vectors of a pass | solutions | valid
-static_assert(kRootsScratch <= 190, "the single kernel's LDS block (kSolveLds)");
-__device__ __forceinline__ uint32_t focal_emit_roots(const FocalGenArgs &g, uint32_t it, int lane, const double *am, const double *ev, int nroots,
-                                                     double *ws) {
-    const size_t B = g.num_iters;
-    const int grp = lane >> 4, gl = lane & 15;
-    double *Ns = ws, *vs = Ns + 60, *sols = vs + 40, *valid_s = sols + 80;
-    if (lane < 60)
-        Ns[lane] = g.stage[(size_t)(kStageN + lane) * B + it];
-    const double f0 = g.stage[(size_t)kStageF0 * B + it];
-    PL_WAVE_SYNC();
-    for (int first = 0; first < nroots; first += 4) { // (uniform)
-        const int root = first + grp;
-        const bool on = root < nroots;
-        const double e = ev[on ? root : 0];
-        NullWave4<10> cx;
-        cx.gl = gl, cx.lane = lane, cx.cp = 0, cx.yv = 0, cx.t1 = 0, cx.t2 = 0;
-#pragma unroll
-        for (int r = 0; r < 10; ++r) { // column gl of wk = am - ev I (p35pf_pose_of_root)
-            const double a = gl < 10 ? am[r * 10 + gl] : 0.0;
-            cx.c[r] = r == gl ? a - e : a;
-        }
-        pl_null_vector_packed<10>(cx, on);
-        if (gl < 10)
-            vs[grp * 10 + gl] = cx.yv;
-        PL_WAVE_SYNC();
-        if (gl == 0 && on) {
-            P35Solution sol;
-            bool valid = p35pf_pose_from_null_vector(vs + grp * 10, Ns, f0, sol);
-            if (valid && !g.keep_all) { // the estimator's filter (absolute_pose.cc:89-95)
-                if (sol.focal < 0)
-                    valid = false;
-                if (g.max_focal >= 0 && sol.focal > g.max_focal)
-                    valid = false;
-            }
-            double *o = sols + root * 8;
-            o[0] = sol.q.w, o[1] = sol.q.x, o[2] = sol.q.y, o[3] = sol.q.z;
-            o[4] = sol.t.x, o[5] = sol.t.y, o[6] = sol.t.z, o[7] = sol.focal;
-            valid_s[root] = valid ? 1.0 : 0.0;
-        }
-        PL_WAVE_SYNC();
-    }
-    const bool valid = lane < nroots && valid_s[lane < nroots ? lane : 0] != 0.0;
-    const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
-    if (valid) {
-        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        FocalModel o;
-        const double *sv = sols + lane * 8;
-        o.q[0] = sv[0], o.q[1] = sv[1], o.q[2] = sv[2], o.q[3] = sv[3];
-        o.t[0] = sv[4], o.t[1] = sv[5], o.t[2] = sv[6];
-        o.f = sv[7];
-        g.models[(size_t)it * kFocalMaxModels + pos] = o;
-        if (g.host_models)
-            g.host_models[(size_t)it * kFocalMaxModels + pos] = o;
-    }
-    return (uint32_t)__popcll(mask);
-}
-// The solve stage in ONE kernel (rounds 4 - 5: small launches - a single problem's batch of ~10^3 samples does not fill the device, and
-// what counts is the length of the chain: one wavefront per sample through all three stages, its eigenvalues by itself (pl_eigen_wave.h),
-// is 0.44 ms; the three kernels below are 0.53 ms for such a launch and 20 % faster for the 64 k samples of a group)
+constexpr int kLuStride = 36, kLdsN = 0, kLdsCoef = 60, kLdsC = 296, kSolveLds = kLdsC + 25 * kLuStride;
+static_assert(kP35Coeffs <= kLdsC - kLdsCoef && kP35Cols <= kLuStride, "regions");
+static_assert(eig_wave_doubles(10) <= 25 * kLuStride, "the eigenvalue workspace takes the template's place");
 __device__ __forceinline__ void focal_solve_body(const FocalGenArgs &g, uint32_t blk) {
     __shared__ double s_solve[kSolveWaves][kSolveLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
-    double *base = s_solve[wave], *eig = base + 100, *E = eig + eig_wave_doubles(10);
-    uint32_t m = 0;
-    if (focal_eliminate(g.stage, g.num_iters, it, lane, E)) {
-        // ---- action matrix (kept for the roots) and a copy for the eigenvalue iteration, which destroys it
-        PL_WAVE_SYNC();
-        for (int e = lane; e < 100; e += 64) {
-            const double v = focal_action_entry(E, e);
-            base[e] = v;
-            eig[e] = v;
+    const size_t B = g.num_iters;
+    double *base = s_solve[wave], *Ns = base + kLdsN, *coef = base + kLdsCoef, *C = base + kLdsC;
+    if (lane < 60)
+        Ns[lane] = g.stage[(size_t)(kStageN + lane) * B + it];
+    const double f0 = g.stage[(size_t)kStageF0 * B + it];
+    PL_WAVE_SYNC();
+    // ---- coefficients, template, the last five rows of C0^-1 C1 (p35pf.cc:86-871)
+    template_coefficients_wave<false, kP35Coeffs>(Ns, kP35TermStart, kP35TermPacked, coef, lane);
+    PL_WAVE_SYNC();
+    template_fill_wave<25, kP35Cols, kLuStride>(coef, kP35ColStart, kP35EntryRow, kP35EntryCoeff, C, lane);
+    lu_solve_tail_wave<25, kP35Cols, kLuStride, 5>(C, lane);
+    // ---- the action matrix (p35pf.cc:873-885): kept in the coefficients' place for the roots, a copy for the eigenvalue iteration
+    double am0, am1;
+    {
+        auto tail = [&](int r, int j) { return C[(20 + r) * kLuStride + 25 + j]; };
+        am0 = p35pf_action_entry(tail, lane / 10, lane % 10);
+        am1 = lane + 64 < 100 ? p35pf_action_entry(tail, (lane + 64) / 10, (lane + 64) % 10) : 0.0;
+    }
+    PL_WAVE_SYNC();
+    double *am = coef, *eig = C;
+    am[lane] = am0, eig[lane] = am0;
+    if (lane + 64 < 100)
+        am[lane + 64] = am1, eig[lane + 64] = am1;
+    pl_general_eigenvalues_wave<10>(eig, lane);
+    // ---- one lane per real eigenvalue (|imag| < 1e-6, in the routine's order: p35pf.cc:890-896), the estimator's filter
+    const double *wr = eig + 100 + 10, *wi = wr + 10;
+    const bool real = lane < 10 && fabs(wi[lane < 10 ? lane : 0]) < 1e-6;
+    bool valid = false;
+    P35Solution sol;
+    if (real) {
+        p35pf_root_solution((const double *)am, wr[lane], (const double *)Ns, f0, sol);
+        valid = true;
+        if (!g.keep_all) { // absolute_pose.cc:89-95
+            if (sol.focal < 0)
+                valid = false;
+            if (g.max_focal >= 0 && sol.focal > g.max_focal)
+                valid = false;
         }
-        const int nroots = pl_real_eigenvalues_wave<10>(eig, 1e-8, lane);
-        PL_WAVE_SYNC();
-        // (the eigenvalues stand at eig[130 ...], the roots' scratch behind the eigenvalue workspace)
-        m = focal_emit_roots(g, it, lane, base, eig + 100 + 30, nroots, eig + eig_wave_doubles(10));
+    }
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
+    if (valid) {
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        FocalModel o;
+        o.q[0] = sol.q.w, o.q[1] = sol.q.x, o.q[2] = sol.q.y, o.q[3] = sol.q.z;
+        o.t[0] = sol.t.x, o.t[1] = sol.t.y, o.t[2] = sol.t.z;
+        o.f = sol.focal;
+        g.models[(size_t)it * kFocalMaxModels + pos] = o;
+        if (g.host_models)
+            g.host_models[(size_t)it * kFocalMaxModels + pos] = o;
     }
     if (lane == 0) {
+        const uint32_t m = (uint32_t)__popcll(mask);
         g.num_models[it] = m;
         if (g.host_num_models)
             g.host_num_models[it] = m;
     }
 }
-// k_focal_roots: one wavefront = one sample - the action matrix and the eigenvalues from the sample's record, then focal_emit_roots
-constexpr int kRootsLds = 100 + 10 + kRootsScratch; // action matrix | eigenvalues | scratch
-__device__ __forceinline__ void focal_roots_body(const FocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_roots[kSolveWaves][kRootsLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
-    if (it >= g.num_iters)
-        return;
-    const double *act = focal_act(g, it);
-    double *am = s_roots[wave], *ev = am + 100;
-    uint32_t m = 0;
-    const int nroots = (int)act[kActRoots]; // (0: degenerate sample, or no real eigenvalue)
-    if (nroots > 0) {
-        for (int e = lane; e < 110; e += 64) // (the record: action matrix 100 | eigenvalues 10)
-            am[e] = act[e];
-        m = focal_emit_roots(g, it, lane, am, ev, nroots, ev + 10);
-    }
-    if (lane == 0) {
-        g.num_models[it] = m;
-        if (g.host_num_models)
-            g.host_num_models[it] = m;
-    }
-}
-#define PL_SOLVE_ATTR __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
-// (the single kernel serves launches that do not fill the device: no register cap - the packed null vectors want ~150)
 __global__ __launch_bounds__(64 * kSolveWaves) void k_focal_solve(FocalGenArgs g) { focal_solve_body(g, blockIdx.x); }
 __global__ __launch_bounds__(64 * kSolveWaves) void k_focal_solve_g(const FocalGenArgs *__restrict__ gs) {
     const FocalGenArgs g = gs[blockIdx.y];
     focal_solve_body(g, blockIdx.x);
-}
-__global__ PL_SOLVE_ATTR void k_focal_elim(FocalGenArgs g) { focal_elim_body(g, blockIdx.x); }
-__global__ PL_SOLVE_ATTR void k_focal_elim_g(const FocalGenArgs *__restrict__ gs) {
-    const FocalGenArgs g = gs[blockIdx.y];
-    focal_elim_body(g, blockIdx.x);
-}
-__global__ __launch_bounds__(64 * kEigWaves) void k_focal_eig(FocalGenArgs g) { focal_eig_body(g, blockIdx.x); }
-__global__ __launch_bounds__(64 * kEigWaves) void k_focal_eig_g(const FocalGenArgs *__restrict__ gs) {
-    const FocalGenArgs g = gs[blockIdx.y];
-    focal_eig_body(g, blockIdx.x);
-}
-__global__ __launch_bounds__(64 * kSolveWaves) void k_focal_roots(FocalGenArgs g) { focal_roots_body(g, blockIdx.x); }
-__global__ __launch_bounds__(64 * kSolveWaves) void k_focal_roots_g(const FocalGenArgs *__restrict__ gs) {
-    const FocalGenArgs g = gs[blockIdx.y];
-    focal_roots_body(g, blockIdx.x);
 }
 
 constexpr int kFocalScoreThreads = 256;
@@ -514,7 +298,7 @@ __global__ void k_focal_mask_g(const FocalMaskArgs *__restrict__ as) {
 
 } // namespace
 
-size_t focal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)(kStageDoubles + kActDoubles) * num_iters; }
+size_t focal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)kStageDoubles * num_iters; }
 
 hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
@@ -522,13 +306,7 @@ hipError_t launch_focal_generate(const FocalGenArgs &g, hipStream_t stream) {
     if (!g.stage)
         return hipErrorInvalidValue;
     k_focal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
-    if (g.num_iters < kSplitSamples) {
-        k_focal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
-        return hipGetLastError();
-    }
-    k_focal_elim<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
-    k_focal_eig<<<dim3((g.num_iters + 4 * kEigWaves - 1) / (4 * kEigWaves)), dim3(64 * kEigWaves), 0, stream>>>(g);
-    k_focal_roots<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
+    k_focal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     return hipGetLastError();
 }
 // ---- group launches (driver_focal_group.inc): blockIdx.y = member, the grid's x extent = the largest member's; `args` is a
@@ -537,13 +315,7 @@ hipError_t launch_focal_generate_g(const FocalGenArgs *args, uint32_t G, uint32_
     if (G == 0 || max_iters == 0)
         return hipSuccess;
     k_focal_setup_g<<<dim3((max_iters + 63u) / 64u, G), dim3(64), 0, stream>>>(args);
-    if ((size_t)max_iters * G < kSplitSamples) { // (the same bits either way: tests/test_zz_gpu_focal_group.py)
-        k_focal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
-        return hipGetLastError();
-    }
-    k_focal_elim_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
-    k_focal_eig_g<<<dim3((max_iters + 4 * kEigWaves - 1) / (4 * kEigWaves), G), dim3(64 * kEigWaves), 0, stream>>>(args);
-    k_focal_roots_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
+    k_focal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
     return hipGetLastError();
 }
 hipError_t launch_focal_score_g(const FocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream) {

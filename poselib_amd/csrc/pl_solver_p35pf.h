@@ -1,147 +1,24 @@
 // poselib_amd - P3.5Pf: absolute pose and focal length from three 2D-3D correspondences and the x coordinate of a fourth.
 //
-// Interface of the reference's solver (PoseLib/solvers/p35pf.h:39-54: image points relative to the principal point; the image
-// points are scaled by their mean norm, p35pf.cc:45-58; solutions with det > 0, |third row| = 1, focal = mean norm of the first
-// two rows, p35pf.cc:903-921).  The ALGORITHM is not the reference's generated elimination template but this project's own,
-// derived from first principles (FocalAbsolutePoseEstimator): P = sum alpha_k N_k over the 5-dimensional null space
-// of the seven linear constraints, alpha_5 = 1; with a1, a2, a3 the rows of the left 3 x 3 block of P
-//     a1.a2 = a1.a3 = a2.a3 = 0, |a1|^2 = |a2|^2                              (4 quadrics, each also times x1..x4)
-//     (a2 x a3)_i (a2)_j = (a3 x a1)_j (a1)_i,  i, j = 1..3                    (9 cubics: they remove the six f = 0 roots)
-// are 29 equations, linear in the 35 monomials of degree <= 3 in (x1..x4); one Gauss-Jordan elimination of 25 monomials leaves
-// the multiplication by x4 on the standard monomials {x3^2, x1 x4, x2 x4, x3 x4, x4^2, x1, x2, x3, x4, 1} as a 10 x 10 matrix,
-// whose real eigenvalues (Hessenberg + Francis QR) and null vectors give the solutions, ascending in x4.
-// Operation for operation the same as the oracle's statement of this algorithm (oracle/src/solvers_focal.cc - written
-// independently of this file's storage layout); tests/test_hostmath_vs_oracle.py compares the two bit for bit on the host.
-//
-// Storage: the 29 x 35 elimination matrix of a sample (8 KB) lives in a workspace the caller provides - element (r, c) at
-// work[(r * 35 + c) * stride]: on the device one lane = one sample and stride = samples of the launch, so that the 64 lanes of a
-// wavefront touch consecutive doubles.
+// The reference's solver restated (PoseLib/solvers/p35pf.cc:42-925; interface solvers/p35pf.h:39-54: image points relative to the
+// principal point, scaled by their mean norm) so that it returns the reference's solutions - the same roots in the same order, to
+// the last bit of oracle/_ref's build:
+//   1. the seven linear constraints on P (3 x 4) as the columns of a 12 x 7 matrix, its null space N (12 x 5) from the Q of an
+//      unpivoted Householder QR (p35pf.cc:68-84)                                                    p35pf_nullspace
+//   2. 235 coefficients of four quadrics and five cubics in the null-space coordinates, the 25 x 35 template [C0 | C1], the last
+//      five rows of C0^-1 C1 (p35pf.cc:86-871)                              pl_action_template.h + pl_focal_templates.h
+//   3. the 10 x 10 action matrix of the multiplication by alpha_3 on the basis {1, x, xw, y, yw, z, zz, zw, w, ww}, its
+//      eigenvalues (Hessenberg + Francis QR: EigenSolver), the real ones |imag| < 1e-6 in the routine's order (p35pf.cc:873-896)
+//   4. per eigenvalue the other three unknowns from a 5 x 4 least-squares problem (p35pf.cc:7-40), P = N v, the pose and the focal
+//      length (p35pf.cc:903-921)                                                                    p35pf_root_solution
+// On the device: step 1 one lane per sample (k_focal_setup), steps 2 - 3 one wavefront per sample with the matrices in LDS, step 4
+// one lane per root (focal.hip).  p35pf() below is the serial statement of the whole solver: the host build of tests/hostmath
+// holds it against the oracle (oracle/src/solvers_focal.cc, written independently of this file) bit for bit.
 #pragma once
+#include "pl_action_template.h"
 #include "pl_math.h"
-#if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
-#include "pl_eigen_packed.h" // (tests/hostmath: the packed eigenvalue / null-vector routines shadow the serial ones, below)
-#include "pl_nullvec_packed.h"
-#endif
 
 namespace pl {
-
-// monomials of degree <= 3 in x1..x4, graded: 0..19 cubic, 20..29 quadratic, 30..33 = x1..x4, 34 = 1
-// kP35Prod[i][j]: index of monomial i * monomial j (-1: degree > 3)
-static constexpr int8_t kP35Prod[35][35] = {
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 1},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 2},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 3},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 4},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 5},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 6},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 7},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 8},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 9},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 10},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 11},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 13},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 14},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 15},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 16},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 17},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 18},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 19},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 1, 2, 3, 20},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 1, 4, 5, 6, 21},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 2, 5, 7, 8, 22},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 3, 6, 8, 9, 23},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 4, 10, 11, 12, 24},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 5, 11, 13, 14, 25},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 6, 12, 14, 15, 26},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 7, 13, 16, 17, 27},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 8, 14, 17, 18, 28},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 9, 15, 18, 19, 29},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 30},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 1, 4, 5, 6, 10, 11, 12, 13, 14, 15, 21, 24, 25, 26, 31},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 2, 5, 7, 8, 11, 13, 14, 16, 17, 18, 22, 25, 27, 28, 32},
-    {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 3, 6, 8, 9, 12, 14, 15, 17, 18, 19, 23, 26, 28, 29, 33},
-    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34},
-};
-static constexpr uint8_t kP35Basis[10] = {27, 23, 26, 28, 29, 30, 31, 32, 33, 34};
-static constexpr uint8_t kP35Elim[25] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24, 25};
-static constexpr int8_t kP35Shifted[10] = {-18, -10, -16, -19, -20, 1, 2, 3, 4, 8};
-
-constexpr int kP35Rows = 29, kP35Cols = 35;
-constexpr int kP35WorkDoubles = kP35Rows * kP35Cols; // per sample
-
-// polynomial with coefficients of the monomials F..34 only (F = 30: linear, 20: quadratic, 0: cubic)
-template <int F> struct P35Poly {
-    double c[35 - F];
-};
-template <int F> PL_HD void p35_zero(P35Poly<F> &p) {
-    PL_UNROLL
-    for (int i = 0; i < 35 - F; ++i)
-        p.c[i] = 0.0;
-}
-// r += p * q, term by term in ascending (i, j) - zero coefficients are skipped (as the oracle's dense product does).
-// (unrolled: kP35Prod folds to constants and the coefficients stay in registers - a run-time index puts them into scratch memory)
-template <int FR, int FP, int FQ> PL_HD void p35_mul(const P35Poly<FP> &p, const P35Poly<FQ> &q, P35Poly<FR> &r) {
-    p35_zero(r);
-    PL_UNROLL
-    for (int i = FP; i < 35; ++i)
-        if (p.c[i - FP] != 0) {
-            PL_UNROLL
-            for (int j = FQ; j < 35; ++j)
-                if (q.c[j - FQ] != 0)
-                    r.c[kP35Prod[i][j] - FR] += p.c[i - FP] * q.c[j - FQ];
-        }
-}
-typedef P35Poly<30> P35Lin;
-typedef P35Poly<20> P35Quad;
-typedef P35Poly<0> P35Cubic;
-
-PL_HD void p35_dot(const P35Lin *a, const P35Lin *b, P35Quad &out) { // (a0 b0 + a1 b1) + a2 b2, coefficient by coefficient
-    P35Quad m0, m1, m2;
-    p35_mul(a[0], b[0], m0);
-    p35_mul(a[1], b[1], m1);
-    p35_mul(a[2], b[2], m2);
-    PL_UNROLL
-    for (int i = 0; i < 15; ++i)
-        out.c[i] = (m0.c[i] + m1.c[i]) + m2.c[i];
-}
-PL_HD void p35_cross(const P35Lin *a, const P35Lin *b, P35Quad *out) {
-    P35Quad m0, m1;
-    PL_UNROLL
-    for (int k = 0; k < 3; ++k) {
-        const int i = (k + 1) % 3, j = (k + 2) % 3;
-        p35_mul(a[i], b[j], m0);
-        p35_mul(a[j], b[i], m1);
-        PL_UNROLL
-        for (int t = 0; t < 15; ++t)
-            out[k].c[t] = m0.c[t] - m1.c[t];
-    }
-}
-
-// element e of a per-sample array that lives in a strided workspace (LDS on the device: element-major over the samples)
-struct StridedArr {
-    double *base;
-    size_t stride;
-    PL_HD double &operator[](int e) const { return base[(size_t)e * stride]; }
-    PL_HD StridedArr at(int off) const { return StridedArr{base + (size_t)off * stride, stride}; }
-};
-struct P35Work {
-    double *base;
-    size_t stride;
-    PL_HD double &at(int r, int c) const { return base[(size_t)(r * kP35Cols + c) * stride]; }
-    PL_HD StridedArr region(int off) const { return StridedArr{base + (size_t)off * stride, stride}; }
-};
-// row r of the elimination matrix = eq scaled to unit maximum
-PL_HD void p35_store_row(const P35Work &w, int r, const P35Cubic &eq) {
-    double mx = 0;
-    PL_UNROLL
-    for (int c = 0; c < 35; ++c)
-        mx = fmax(mx, fabs(eq.c[c]));
-    PL_UNROLL
-    for (int c = 0; c < 35; ++c)
-        w.at(r, c) = mx > 0 ? eq.c[c] / mx : 0.0;
-}
 
 // Orthonormal basis of the complement of span(columns of A), A ROWS x COLS column-major: full-pivoting Householder QR, then the
 // last ROWS - COLS columns of Q - pl_solver_rel.h complement_basis9_indexed with the row count as a parameter
@@ -239,44 +116,18 @@ template <int ROWS, int COLS> PL_HD void complement_basis_indexed(double *qr /* 
     }
 }
 
-// Real eigenvalues of an n x n matrix (row-major, destroyed; Arr: a pointer or anything indexable that yields double&), ascending: Householder reduction to Hessenberg form, then the
-// Francis double-shift QR iteration in its textbook form; an eigenvalue counts as real when |imag| <= tol (1 + |real|).
-// No convergence after 60 sweeps on one block: no eigenvalues (the sample is dropped).
-#ifndef PL_EIG_MARK
-#define PL_EIG_MARK() // (scripts/exp/p35_phases.cc: cycle counter between the Hessenberg reduction and the QR iteration)
-#endif
-#if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
-// tests/hostmath: every matrix the solvers hand to this routine also goes through the packed form of pl_eigen_packed.h (the device's
-// routine since round 5, here with the lane loops as loops); calls and disagreements (count or any bit of an eigenvalue) are counted
-extern unsigned long long pl_eig_shadow_counters[6]; // [eigenvalue calls, disagreements, balancing calls, disagreements, null-vector calls, disagreements]
-template <int n, class Arr> inline int pl_real_eigenvalues_serial(Arr a_, double *out, double tol);
-template <int n, class Arr> inline int pl_real_eigenvalues(Arr a_, double *out, double tol) {
-    double shadow[n * n + 4 * n];
-    for (int e = 0; e < n * n; ++e)
-        shadow[e] = a_[e];
-    for (int e = n * n; e < n * n + 4 * n; ++e)
-        shadow[e] = 0.0;
-    const int m = pl_real_eigenvalues_serial<n, Arr>(a_, out, tol);
-    EigFlatHost<n> cx{shadow};
-    const int m2 = pl_real_eigenvalues_packed<n>(cx, true, tol);
-    bool same = m == m2;
-    for (int i = 0; same && i < m; ++i)
-        same = std::memcmp(&out[i], &cx.out(i), sizeof(double)) == 0;
-    pl_eig_shadow_counters[0]++;
-    pl_eig_shadow_counters[1] += same ? 0 : 1;
-    return m;
-}
-#define pl_real_eigenvalues_impl pl_real_eigenvalues_serial
-#else
-#define pl_real_eigenvalues_impl pl_real_eigenvalues
-#endif
-template <int n, class Arr> PL_HD int pl_real_eigenvalues_impl(Arr a_, double *out, double tol) {
+
+// EigenSolver(A, false).eigenvalues() (what the reference's template solvers call) in the operation order of oracle/eigen_shim:
+// Householder reduction to Hessenberg form, Francis double-shift QR iteration with exceptional shifts after 10 and 20 sweeps.
+// a_: n x n row-major (Arr: a pointer or anything indexable that yields double&), destroyed.  wr / wi: real and imaginary parts
+// in the order the deflation leaves them.
+template <int n, class Arr> PL_HD void pl_general_eigenvalues(Arr a_, double *wr, double *wi) {
 #define PL_A(i, j) a_[(i) * n + (j)]
     for (int k = 0; k + 2 < n; ++k) {
         double tail = 0;
         for (int r = k + 2; r < n; ++r)
             tail += PL_A(r, k) * PL_A(r, k);
-        if (tail <= 1e-300)
+        if (tail <= 2.2250738585072014e-308)
             continue;
         const double c0 = PL_A(k + 1, k);
         double beta = sqrt(c0 * c0 + tail);
@@ -307,8 +158,6 @@ template <int n, class Arr> PL_HD int pl_real_eigenvalues_impl(Arr a_, double *o
         for (int r = k + 2; r < n; ++r)
             PL_A(r, k) = 0;
     }
-    PL_EIG_MARK();
-    double wr[n], wi[n];
     for (int i = 0; i < n; ++i)
         wr[i] = wi[i] = 0.0;
     const double eps = 2.220446049250313e-16;
@@ -355,8 +204,13 @@ template <int n, class Arr> PL_HD int pl_real_eigenvalues_impl(Arr a_, double *o
                     }
                     nn -= 2;
                 } else {
-                    if (its == 60)
-                        return 0;
+                    if (its == 60) { // no convergence: what is left counts as NaN (and passes the reference's filter as such)
+                        for (int i = 0; i <= nn; ++i) {
+                            wr[i] = __builtin_nan("");
+                            wi[i] = 0;
+                        }
+                        return;
+                    }
                     if (its == 10 || its == 20) {
                         t += x;
                         for (int i = 0; i <= nn; ++i)
@@ -433,90 +287,7 @@ template <int n, class Arr> PL_HD int pl_real_eigenvalues_impl(Arr a_, double *o
         } while (l < nn - 1);
     }
 #undef PL_A
-    int m = 0;
-    for (int i = 0; i < n; ++i)
-        if (fabs(wi[i]) <= tol * (1.0 + fabs(wr[i]))) { // insertion into the ascending list
-            int j = m++;
-            while (j > 0 && out[j - 1] > wr[i]) {
-                out[j] = out[j - 1];
-                --j;
-            }
-            out[j] = wr[i];
-        }
-    return m;
 }
-
-PL_HD int p35_real_eigenvalues(double *a_, double *out, double tol) { return pl_real_eigenvalues<10, double *>(a_, out, tol); }
-
-// null vector of the singular n x n matrix B (row-major, destroyed): Gaussian elimination with complete pivoting, the last
-// permuted unknown set to 1
-#if defined(PL_EIG_SHADOW_CHECK) && !defined(__HIPCC__)
-// tests/hostmath: every matrix also goes through the packed form (pl_nullvec_packed.h: 16 lanes per matrix on the device, here with the
-// lane loops as loops); calls and disagreements (any bit of the null vector) are counted in pl_eig_shadow_counters[4], [5]
-template <int n, class Arr> inline void pl_null_vector_serial(Arr B, double *v);
-template <int n, class Arr> inline void pl_null_vector(Arr B, double *v) {
-    NullFlatHost<n> cx;
-    for (int r = 0; r < n; ++r)
-        for (int j = 0; j < n; ++j)
-            cx.b[r][j] = B[r * n + j];
-    pl_null_vector_serial<n, Arr>(B, v);
-    pl_null_vector_packed<n>(cx, true);
-    bool same = true;
-    for (int j = 0; j < n; ++j)
-        same = same && std::memcmp(&v[j], &cx.yv[j], sizeof(double)) == 0;
-    pl_eig_shadow_counters[4]++;
-    pl_eig_shadow_counters[5] += same ? 0 : 1;
-}
-#define pl_null_vector_impl pl_null_vector_serial
-#else
-#define pl_null_vector_impl pl_null_vector
-#endif
-template <int n, class Arr> PL_HD void pl_null_vector_impl(Arr B, double *v) {
-    int colperm[n];
-    for (int i = 0; i < n; ++i)
-        colperm[i] = i;
-    for (int k = 0; k < n - 1; ++k) {
-        int pr = k, pc = k;
-        double best = 0;
-        for (int i = k; i < n; ++i)
-            for (int j = k; j < n; ++j)
-                if (fabs(B[i * n + j]) > best)
-                    best = fabs(B[i * n + j]), pr = i, pc = j;
-        if (best == 0)
-            break;
-        for (int j = 0; j < n; ++j) {
-            const double t = B[k * n + j];
-            B[k * n + j] = B[pr * n + j];
-            B[pr * n + j] = t;
-        }
-        for (int i = 0; i < n; ++i) {
-            const double t = B[i * n + k];
-            B[i * n + k] = B[i * n + pc];
-            B[i * n + pc] = t;
-        }
-        const int tc = colperm[k];
-        colperm[k] = colperm[pc];
-        colperm[pc] = tc;
-        for (int i = k + 1; i < n; ++i) {
-            const double f = B[i * n + k] / B[k * n + k];
-            for (int j = k; j < n; ++j)
-                B[i * n + j] -= f * B[k * n + j];
-        }
-    }
-    double y[n];
-    for (int i = 0; i < n; ++i)
-        y[i] = 0.0;
-    y[n - 1] = 1.0;
-    for (int i = n - 2; i >= 0; --i) {
-        double s = 0;
-        for (int j = i + 1; j < n; ++j)
-            s += B[i * n + j] * y[j];
-        y[i] = -s / B[i * n + i];
-    }
-    for (int i = 0; i < n; ++i)
-        v[colperm[i]] = y[i];
-}
-PL_HD void p35_null_vector(double *B, double *v) { pl_null_vector<10, double *>(B, v); }
 
 struct P35Solution {
     Quat q;
@@ -524,266 +295,178 @@ struct P35Solution {
     double focal;
 };
 
-// x: four image points (x, y) relative to the principal point - of the fourth only x is used -, X: the 3-D points.
-// Returns the number of solutions (<= 10), ascending in the eigenvalue.
-#ifndef PL_P35_MARK
-#define PL_P35_MARK(i) // (scripts/exp/p35_phases.cc: cycle counter at the phase boundaries)
-#endif
-// The solver in three stages - on the device three kernels (focal.hip: one lane per sample / one WAVEFRONT per sample with the
-// matrix in registers / one lane per sample again), on the host and in p35pf() below one after the other.  Measured shares of the
-// one-lane-per-sample form, matrices in LDS (scripts/exp/p35_phases.cc): null space 3 %, equations 9 %, elimination 27 %,
-// eigenvalues 37 %, null vectors + poses 24 % of 1.5 ms.
-//
-// Stage 1: null space N (12 x 5, column k at N[12 k ..]) of the seven linear constraints, scale f0 of the image points, and the 29
-// equations as the rows of the elimination matrix w.
-// sink(r, eq): takes equation r (on the host and in p35pf(): p35_store_row - the row scaled to unit maximum; on the device the raw
-// coefficients and the maximum, the 35 divisions of a row are then done by the 35 lanes that hold its columns, focal.hip)
-template <class Sink>
-PL_HD void p35pf_setup_t(const double *xs /* 4 x 2 */, const Vec3 *X, Sink &&sink, double *N /* 60 */, double &f0_out) {
-    PL_P35_MARK(0);
+// Step 1.  xs: four image points (x, y) relative to the principal point; N: 12 x 5 column-major (column k at N[12 k ..], each
+// column a 3 x 4 matrix, column-major); f0: the scale of the image points.
+PL_HD void p35pf_nullspace(const double *xs /* 4 x 2 */, const Vec3 *X, double *N /* 60 */, double &f0_out) {
     double f0 = 0;
     for (int i = 0; i < 4; ++i)
         f0 += sqrt(xs[2 * i] * xs[2 * i] + xs[2 * i + 1] * xs[2 * i + 1]);
     f0 /= 4;
     f0_out = f0;
-    double x[8];
-    for (int i = 0; i < 8; ++i)
-        x[i] = xs[i] / f0;
-
-    // the 7 linear constraints on the 12 entries of P (row-major) as the columns of a 12 x 7 matrix
-    {
-        double A[12 * 7];
-        for (int i = 0; i < 12 * 7; ++i)
-            A[i] = 0.0;
-        int row = 0;
-        for (int i = 0; i < 4; ++i) {
-            const double Xh[4] = {X[i].x, X[i].y, X[i].z, 1.0};
-            for (int k = 0; k < 4; ++k) {
-                A[row * 12 + k] = Xh[k];
-                A[row * 12 + 8 + k] = -x[2 * i] * Xh[k];
-            }
-            ++row;
-            if (i < 3) {
-                for (int k = 0; k < 4; ++k) {
-                    A[row * 12 + 4 + k] = Xh[k];
-                    A[row * 12 + 8 + k] = -x[2 * i + 1] * Xh[k];
-                }
-                ++row;
-            }
+    double M[12 * 7], tau[7];
+    for (int c = 0; c < 7; ++c) { // columns 2 i, 2 i + 1: the u and v rows of point i; column 6: the u row of the fourth point
+        const int i = c < 6 ? c / 2 : 3, is_v = c < 6 ? c & 1 : 0;
+        const double u = xs[2 * i + is_v] / f0;
+        const double Xi[3] = {X[i].x, X[i].y, X[i].z};
+        double *m = M + 12 * c;
+        for (int k = 0; k < 3; ++k) {
+            m[3 * k + 0] = is_v ? 0.0 : -Xi[k];
+            m[3 * k + 1] = is_v ? -Xi[k] : 0.0;
+            m[3 * k + 2] = Xi[k] * u;
         }
-        complement_basis_indexed<12, 7>(A, N);
+        m[9] = is_v ? 0.0 : -1.0;
+        m[10] = is_v ? -1.0 : 0.0;
+        m[11] = u;
     }
-    PL_P35_MARK(1);
-    {
-        // rows of the left 3 x 3 block as vectors of linear polynomials: a[r][i] = sum_k N(4 r + i, k) x_k + N(4 r + i, 4)
-        P35Lin a[3][3];
-        PL_UNROLL
-        for (int r = 0; r < 3; ++r) {
-            PL_UNROLL
-            for (int i = 0; i < 3; ++i) {
-                PL_UNROLL
-                for (int k = 0; k < 5; ++k)
-                    a[r][i].c[k] = N[k * 12 + 4 * r + i];
-            }
+    for (int k = 0; k < 7; ++k) { // householderQr()
+        double tail_sq = 0;
+        for (int r = k + 1; r < 12; ++r)
+            tail_sq += M[k * 12 + r] * M[k * 12 + r];
+        const double c0 = M[k * 12 + k];
+        if (tail_sq <= 2.2250738585072014e-308) {
+            tau[k] = 0;
+            for (int r = k + 1; r < 12; ++r)
+                M[k * 12 + r] = 0;
+        } else {
+            double beta = sqrt(c0 * c0 + tail_sq);
+            if (c0 >= 0)
+                beta = -beta;
+            for (int r = k + 1; r < 12; ++r)
+                M[k * 12 + r] = M[k * 12 + r] / (c0 - beta);
+            tau[k] = (beta - c0) / beta;
+            M[k * 12 + k] = beta;
         }
-        P35Cubic eq;
-        int ne = 0;
-        {
-            P35Quad quad, d1;
-            PL_UNROLL
-            for (int qn = 0; qn < 4; ++qn) { // (unrolled throughout: every coefficient index is a constant, the polynomials stay in registers)
-                if (qn < 3) {
-                    p35_dot(a[qn == 2 ? 1 : 0], a[qn == 0 ? 1 : 2], quad);
-                } else {
-                    p35_dot(a[0], a[0], quad);
-                    p35_dot(a[1], a[1], d1);
-                    PL_UNROLL
-                    for (int i = 0; i < 15; ++i)
-                        quad.c[i] = quad.c[i] - d1.c[i];
-                }
-                PL_UNROLL
-                for (int i = 0; i < 20; ++i)
-                    eq.c[i] = 0.0;
-                PL_UNROLL
-                for (int i = 0; i < 15; ++i)
-                    eq.c[20 + i] = quad.c[i];
-                sink(ne++, eq);
-                PL_UNROLL
-                for (int k = 0; k < 4; ++k) {
-                    P35Lin shift;
-                    p35_zero(shift);
-                    shift.c[k] = 1.0;
-                    p35_mul(quad, shift, eq);
-                    sink(ne++, eq);
-                }
+        if (tau[k] != 0)
+            for (int c = k + 1; c < 7; ++c) {
+                double t = 0;
+                for (int r = k + 1; r < 12; ++r)
+                    t += M[k * 12 + r] * M[c * 12 + r];
+                t += M[c * 12 + k];
+                M[c * 12 + k] -= tau[k] * t;
+                for (int r = k + 1; r < 12; ++r)
+                    M[c * 12 + r] -= tau[k] * M[k * 12 + r] * t;
             }
-        }
-        P35Quad c23[3], c31[3];
-        p35_cross(a[1], a[2], c23);
-        p35_cross(a[2], a[0], c31);
-        PL_UNROLL
-        for (int i = 0; i < 3; ++i) {
-            PL_UNROLL
-            for (int j = 0; j < 3; ++j) {
-                P35Cubic m1;
-                p35_mul(c23[i], a[1][j], eq);
-                p35_mul(c31[j], a[0][i], m1);
-                PL_UNROLL
-                for (int c = 0; c < 35; ++c)
-                    eq.c[c] = eq.c[c] - m1.c[c];
-                sink(ne++, eq);
-            }
-        }
     }
-    PL_P35_MARK(2);
-}
-PL_HD void p35pf_setup(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, double *N /* 60 */, double &f0_out) {
-    p35pf_setup_t(xs, X, [&](int r, const P35Cubic &eq) { p35_store_row(w, r, eq); }, N, f0_out);
-}
-
-// the five rows of the action matrix that come out of the elimination: row i of the action matrix = - (reduced row of the pivot of
-// eliminated monomial kP35ActionPivot[i]) restricted to the basis columns (kP35Shifted < 0: -sh - 1)
-static constexpr uint8_t kP35ActionPivot[5] = {17, 9, 15, 18, 19};
-constexpr int kP35ActionDoubles = 50; // E[i * 10 + j] = w.at(pivot_row[kP35ActionPivot[i]], kP35Basis[j])
-
-// Stage 2: Gauss-Jordan over the 25 eliminated monomials: pivot = the largest remaining entry of the column among the unused rows
-// (the first of equals).  false: degenerate sample.  E: the 50 entries stage 3 needs.
-PL_HD bool p35pf_eliminate(const P35Work &w, double *E /* 50 */) {
-    uint32_t used = 0;
-    uint8_t pivot_row[25];
-    for (int k = 0; k < 25; ++k) {
-        const int col = kP35Elim[k];
-        int pr = -1;
-        double best = 0;
-        for (int r = 0; r < kP35Rows; ++r) {
-            const double v = fabs(w.at(r, col));
-            if (!((used >> r) & 1u) && v > best)
-                best = v, pr = r;
-        }
-        if (pr < 0 || best < 1e-13)
-            return false; // degenerate sample
-        used |= 1u << pr;
-        pivot_row[k] = (uint8_t)pr;
-        const double inv = 1.0 / w.at(pr, col);
-        double prow[kP35Cols];
-        PL_UNROLL
-        for (int c = 0; c < kP35Cols; ++c) {
-            prow[c] = w.at(pr, c) * inv;
-            w.at(pr, c) = prow[c];
-        }
-        for (int r = 0; r < kP35Rows; ++r) {
-            if (r == pr)
+    for (int j = 0; j < 5; ++j) { // householderQ().rightCols(5)
+        double *q = N + 12 * j;
+        for (int r = 0; r < 12; ++r)
+            q[r] = r == 7 + j ? 1.0 : 0.0;
+        for (int k = 6; k >= 0; --k) {
+            if (tau[k] == 0)
                 continue;
-            const double f = w.at(r, col);
-            if (f != 0) {
-                PL_UNROLL
-                for (int c = 0; c < kP35Cols; ++c)
-                    w.at(r, c) -= f * prow[c];
-            }
+            double t = 0;
+            for (int r = k + 1; r < 12; ++r)
+                t += M[k * 12 + r] * q[r];
+            t += q[k];
+            q[k] -= tau[k] * t;
+            for (int r = k + 1; r < 12; ++r)
+                q[r] -= tau[k] * M[k * 12 + r] * t;
         }
     }
-    for (int i = 0; i < 5; ++i)
-        for (int j = 0; j < 10; ++j)
-            E[i * 10 + j] = w.at(pivot_row[kP35ActionPivot[i]], kP35Basis[j]);
-    PL_P35_MARK(3);
-    return true;
 }
 
-// Stage 3: action matrix of x4 on the standard monomials (am), its real eigenvalues, the null vectors, the poses.  am, wk: two
-// workspaces of 100 doubles (LDS on the device: as local arrays they were scratch memory behind the vector memory path).
-PL_HD double p35pf_action_entry(const double *E /* 50 */, int k, int j) {
-    const int sh = kP35Shifted[k];
-    return sh >= 0 ? (j == sh ? 1.0 : 0.0) : -E[k * 10 + j];
+// the rows of the action matrix that are not shifts come from rows 20 .. 24 of C0^-1 C1 (p35pf.cc:873-885)
+static constexpr int8_t kP35Reduced[5] = {2, 4, 6, 7, 9};
+// entry (k, j) of the action matrix; X(r, j): row 20 + r of column j of C0^-1 C1
+template <class Tail> PL_HD double p35pf_action_entry(const Tail &X, int k, int j) {
+    switch (k) {
+    case 0:
+        return j == 8 ? 1.0 : 0.0;
+    case 1:
+        return j == 2 ? 1.0 : 0.0;
+    case 3:
+        return j == 4 ? 1.0 : 0.0;
+    case 5:
+        return j == 7 ? 1.0 : 0.0;
+    case 8:
+        return j == 9 ? 1.0 : 0.0;
+    default:
+        return -X(k == 2 ? 0 : k == 4 ? 1 : k == 6 ? 2 : k == 7 ? 3 : 4, j);
+    }
 }
-PL_HD int p35pf_poses(const StridedArr &am, const StridedArr &wk, const double *ev, int nroots, const double *N /* 60 */, double f0,
-                      P35Solution *out);
-// Returns the number of solutions (<= 10), ascending in the eigenvalue.
-PL_HD int p35pf_finish(const double *E /* 50 */, const double *N /* 60 */, double f0, const StridedArr &am, const StridedArr &wk,
-                       P35Solution *out) {
-    for (int k = 0; k < 10; ++k)
-        for (int j = 0; j < 10; ++j)
-            am[k * 10 + j] = p35pf_action_entry(E, k, j);
-    double ev[10];
-    for (int i = 0; i < 100; ++i)
-        wk[i] = am[i];
-    const int nroots = pl_real_eigenvalues<10>(wk, ev, 1e-8);
-    PL_P35_MARK(4);
-    return p35pf_poses(am, wk, ev, nroots, N, f0, out);
-}
-// one root: the null vector of (action matrix - eigenvalue), P = sum alpha_k N_k, the pose and focal length.  false: no solution
-// the pose and focal length that belong to the null vector v of (action matrix - eigenvalue): P = sum alpha_k N_k
-PL_HD bool p35pf_pose_from_null_vector(const double *v /* 10 */, const double *N /* 60 */, double f0, P35Solution &out);
-PL_HD bool p35pf_pose_of_root(const StridedArr &am, const StridedArr &wk, double ev, const double *N /* 60 */, double f0,
-                              P35Solution &out) {
-    double v[10];
-    for (int i = 0; i < 100; ++i)
-        wk[i] = am[i];
-    for (int i = 0; i < 10; ++i)
-        wk[i * 10 + i] -= ev;
-    pl_null_vector<10>(wk, v);
-    return p35pf_pose_from_null_vector(v, N, f0, out);
-}
-PL_HD bool p35pf_pose_from_null_vector(const double *v, const double *N, double f0, P35Solution &out) {
-    if (v[9] == 0)
-        return false;
-    const double al[5] = {v[5] / v[9], v[6] / v[9], v[7] / v[9], v[8] / v[9], 1.0};
-    double P[12];
-    for (int i = 0; i < 12; ++i) {
-        double sum = 0;
-        for (int k = 0; k < 5; ++k)
-            sum += N[k * 12 + i] * al[k];
-        P[i] = sum;
+
+// Step 4 for one eigenvalue z: AM the action matrix (10 x 10 row-major), N, f0 from step 1.
+template <class Arr> PL_HD void p35pf_root_solution(const Arr &AM, double z0, const double *N, double f0, P35Solution &out) {
+    const double z1 = z0 * z0, z2 = z1 * z0;
+    double AA[25], rhs[5], s[4]; // column-major 5 x 5
+    for (int r = 0; r < 5; ++r) {
+        const int row = kP35Reduced[r] * 10;
+        AA[0 * 5 + r] = AM[row + 1] + z0 * AM[row + 2];
+        AA[1 * 5 + r] = AM[row + 3] + z0 * AM[row + 4];
+        AA[2 * 5 + r] = AM[row + 6];
+        AA[3 * 5 + r] = AM[row + 5] + z0 * AM[row + 7];
+        AA[4 * 5 + r] = AM[row + 0] + z0 * AM[row + 8] + z1 * AM[row + 9];
+    }
+    AA[0] = AA[0] - z1;
+    AA[6] = AA[6] - z1;
+    AA[12] = AA[12] - z0;
+    AA[18] = AA[18] - z1;
+    AA[24] = AA[24] - z2;
+    for (int r = 0; r < 5; ++r)
+        rhs[r] = -AA[20 + r];
+    colpiv_qr_solve<5, 4>(AA, rhs, s);
+    const double v[5] = {s[0], s[1], s[3], z0, 1.0};
+    double P[12]; // 3 x 4 column-major
+    for (int e = 0; e < 12; ++e) {
+        double sum = N[e] * v[0];
+        for (int k = 1; k < 5; ++k)
+            sum += N[k * 12 + e] * v[k];
+        P[e] = sum;
+    }
+    const double det = P[0] * (P[4] * P[8] - P[7] * P[5]) - P[3] * (P[1] * P[8] - P[7] * P[2]) + P[6] * (P[1] * P[5] - P[4] * P[2]);
+    if (det < 0)
+        for (int e = 0; e < 12; ++e)
+            P[e] = -P[e];
+    double n3 = 0;
+    for (int c = 0; c < 3; ++c)
+        n3 += P[3 * c + 2] * P[3 * c + 2];
+    n3 = sqrt(n3);
+    for (int e = 0; e < 12; ++e)
+        P[e] = P[e] / n3;
+    double n1 = 0, n2 = 0;
+    for (int c = 0; c < 3; ++c) {
+        n1 += P[3 * c] * P[3 * c];
+        n2 += P[3 * c + 1] * P[3 * c + 1];
+    }
+    const double focal = (sqrt(n1) + sqrt(n2)) / 2;
+    for (int c = 0; c < 4; ++c) {
+        P[3 * c] = P[3 * c] / focal;
+        P[3 * c + 1] = P[3 * c + 1] / focal;
     }
     Mat3 R;
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
-            R.m[3 * r + c] = P[4 * r + c];
-    double t[3] = {P[3], P[7], P[11]};
-    const double det = R.m[0] * (R.m[4] * R.m[8] - R.m[5] * R.m[7]) - R.m[1] * (R.m[3] * R.m[8] - R.m[5] * R.m[6]) +
-                       R.m[2] * (R.m[3] * R.m[7] - R.m[4] * R.m[6]);
-    const double sgn = det < 0 ? -1.0 : 1.0;
-    const double n3 = sqrt(R.m[6] * R.m[6] + R.m[7] * R.m[7] + R.m[8] * R.m[8]);
-    if (!(n3 > 0))
-        return false;
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c)
-            R.m[3 * r + c] *= sgn / n3;
-        t[r] *= sgn / n3;
-    }
-    const double n1 = sqrt(R.m[0] * R.m[0] + R.m[1] * R.m[1] + R.m[2] * R.m[2]);
-    const double n2 = sqrt(R.m[3] * R.m[3] + R.m[4] * R.m[4] + R.m[5] * R.m[5]);
-    const double focal = 0.5 * (n1 + n2);
-    for (int c = 0; c < 3; ++c) {
-        R.m[c] /= focal;
-        R.m[3 + c] /= focal;
-    }
-    t[0] /= focal;
-    t[1] /= focal;
+            R.m[3 * r + c] = P[3 * c + r];
     out.q = rotmat_to_quat(R);
-    out.t = v3(t[0], t[1], t[2]);
+    out.t = v3(P[9], P[10], P[11]);
     out.focal = focal * f0;
-    return true;
-}
-// every root, ascending (on the device the roots of a sample go to the lanes of its wavefront, focal.hip k_focal_finish)
-PL_HD int p35pf_poses(const StridedArr &am, const StridedArr &wk, const double *ev, int nroots, const double *N /* 60 */, double f0,
-                      P35Solution *out) {
-    int n = 0;
-    for (int s = 0; s < nroots; ++s)
-        if (p35pf_pose_of_root(am, wk, ev[s], N, f0, out[n]))
-            ++n;
-    PL_P35_MARK(5);
-    return n;
 }
 
-// x: four image points (x, y) relative to the principal point - of the fourth only x is used -, X: the 3-D points; w: workspace of
-// kP35WorkDoubles.  Returns the number of solutions (<= 10), ascending in the eigenvalue.
-PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, const P35Work &w, P35Solution *out) {
-    double N[12 * 5], f0, E[kP35ActionDoubles];
-    p35pf_setup(xs, X, w, N, f0);
-    if (!p35pf_eliminate(w, E))
-        return 0;
-    // the elimination matrix is consumed: its storage holds the action matrix and the working copy of stage 3
-    return p35pf_finish(E, N, f0, w.region(0), w.region(100), out);
+// The whole solver, serially (host; tests/hostmath).  Returns the number of solutions (<= 10) in the reference's order.
+PL_HD int p35pf(const double *xs /* 4 x 2 */, const Vec3 *X, P35Solution *out) {
+    double N[60], f0;
+    p35pf_nullspace(xs, X, N, f0);
+    constexpr int S = 36;
+    double coef[kP35Coeffs], C[25 * S];
+    for (int k = 0; k < kP35Coeffs; ++k)
+        coef[k] = template_coefficient<false>(N, kP35TermStart, kP35TermPacked, k);
+    for (int e = 0; e < 25 * S; ++e)
+        C[e] = 0.0;
+    for (int c = 0; c < kP35Cols; ++c)
+        for (int e = kP35ColStart[c]; e < kP35ColStart[c + 1]; ++e)
+            C[kP35EntryRow[e] * S + c] = coef[kP35EntryCoeff[e]];
+    lu_solve_tail<25, 35, S, 5>(C);
+    double AM[100], H[100], wr[10], wi[10];
+    auto tail = [&](int r, int j) { return C[(20 + r) * S + 25 + j]; };
+    for (int k = 0; k < 10; ++k)
+        for (int j = 0; j < 10; ++j)
+            H[k * 10 + j] = AM[k * 10 + j] = p35pf_action_entry(tail, k, j);
+    pl_general_eigenvalues<10, double *>(H, wr, wi);
+    int n = 0;
+    for (int i = 0; i < 10; ++i)
+        if (fabs(wi[i]) < 1e-6)
+            p35pf_root_solution(AM, wr[i], N, f0, out[n++]);
+    return n;
 }
 
 } // namespace pl

@@ -2,10 +2,12 @@
 // SharedFocalRelativePoseEstimator robust/estimators/relative_pose.cc:154-203, refiner robust/optim/relative.h:488-592).
 //
 //   k_sfocal_setup     one lane = one RANSAC iteration: the sample of six correspondences from the iteration's position in the
-//                      splitmix64 stream (or the host's PROSAC sample), unit bearings, null space and the ten equations of the
-//                      6-point solver (pl_solver_6ptf.h) into a workspace in HBM
-//   k_sfocal_solve     one WAVEFRONT = one iteration: row reduction to the 15 x 15 companion matrix, its eigenvalues (pl_eigen_wave.h),
-//                      one lane per root, then one lane per solution
+//                      splitmix64 stream (or the host's PROSAC sample), unit bearings, the null space of the epipolar constraints
+//                      (pl_solver_6ptf.h, step 1) into a workspace in HBM
+//   k_sfocal_solve     one WAVEFRONT = one iteration, the matrices in LDS: the 280 coefficients, the 31 x 46 template, LU with
+//                      partial pivoting with a column per lane, the 15 x 15 action matrix, its characteristic polynomial
+//                      (Danilevsky, a column per lane), the real roots (Sturm bisection of degree 15 by one lane), one lane per
+//                      root for the 7 x 7 system, then one lane per solution for the poses
 //   k_sfocal_score     one wavefront = one model: compute_sampson_msac_score (utils.cc:204-239) of F = K_inv (E K_inv) - inlier
 //                      count and the score IN CORRESPONDENCE ORDER (r2 of an inlier, the threshold of an outlier, one after the
 //                      other: the score decides comparisons in the loop, so it has to be the sequential sum).  The lanes evaluate
@@ -17,14 +19,12 @@
 //                      summed correspondence after correspondence - wavefronts 1 .. 3 produce the entry terms of a round of 192
 //                      correspondences, lane e < 27 of wavefront 0 adds entry e of [JtJ | Jtr] with the inline-asm chain - so that the
 //                      refined model equals the oracle's to the bit for every n.
-// Round 3's form (one lane per sample throughout) and what each step of round 4 bought: DESIGN 4, "The focal-length estimators".
+// Rounds 3 - 5 solved the six-point problem as a polynomial eigenvalue problem of this project's own (CHANGELOG.md); round 6 restates
+// the reference's template (relpose_6pt_focal.cc) so that the solver returns the reference's roots.
 #include "pl_kernels.h"
 #include "pl_device.h"
 #include "pl_sfocal.h"
 #include "pl_solver_6ptf.h"
-#include "pl_eigen_wave.h"
-#include "pl_eigen_packed.h"
-#include "pl_nullvec_packed.h"
 #include "pl_lm_chain.inc"
 #include <algorithm>
 #include <atomic>
@@ -34,13 +34,7 @@ namespace pl {
 namespace {
 
 // ---- the generator: two kernels over a workspace in HBM (element e of sample it at stage[e * B + it]) ------------------------
-//   k_sfocal_setup   one lane = one sample: null space of the epipolar constraints and the ten equations C (written straight into the
-//                    stage, coalesced), the bearings
-//   k_sfocal_solve   one WAVEFRONT = one sample: row reduction of the equations to the 15 x 15 companion matrix, its eigenvalues
-//                    and the roots by the lanes together (below)
-// Round 3's single kernel held 8.6 KB of LDS per sample through all stages (2.86 ms on 63 CUs per batch of 1001 samples: four
-// problems filled the device, which bounded the throughput of several host threads at 1.4 k problems/s).
-constexpr int kStC = 0, kStNb = 300, kStX = 327, kStDoubles = 363;
+constexpr int kStNb = 0, kStX = 27, kStDoubles = 63;
 
 // (the kernels' bodies are functions of (arguments, block index): the single-problem kernels pass their own argument block, the
 // group kernels - blockIdx.y = member of the group - the member's entry of a device-resident table, read before any store)
@@ -71,7 +65,7 @@ __device__ __forceinline__ void sfocal_setup_body(const SFocalGenArgs &g, uint32
     const size_t B = g.num_iters;
     double *st = g.stage + it;
     double nb[27];
-    six_nullspace_equations(x1, x2, SixWork{st + (size_t)kStC * B, B}, nb); // (the equations straight into the stage: coalesced)
+    six_nullspace(x1, x2, nb);
     for (int e = 0; e < 27; ++e)
         st[(size_t)(kStNb + e) * B] = nb[e];
     for (int k = 0; k < 6; ++k) {
@@ -86,134 +80,10 @@ __global__ __launch_bounds__(64) void k_sfocal_setup_g(const SFocalGenArgs *__re
     sfocal_setup_body(g, blockIdx.x);
 }
 
-// k_sfocal_solve: one WAVEFRONT = one sample, three stages in one launch.
-//   companion    six_companion_wave (pl_eigen_wave.h): Gaussian elimination of the w^2 part with complete pivoting, the 10 x 10 system
-//                with 15 right-hand sides, the companion matrix (one lane per sample, matrices in LDS: 360 k cycles, 81 % of the old
-//                setup kernel)
-//   eigenvalues  the 15 x 15 companion matrix in LDS, balanced and reduced by the lanes together (pl_eigen_wave.h: six_eigenvalues of
-//                pl_solver_6ptf.h, the same operations on every element; as one lane per sample: 2.1 ms per batch)
-//   roots        phase 1, lane s = root s: (x, y) from the null vector of C0 + w C1 + w^2 C2 (its own 10 x 10 matrix in LDS).  Lane 0
-//                then builds the list of solutions ascending in y exactly as the serial routine inserts them.  Phase 2, lane s =
-//                solution s: essential matrix, up to four poses; the models leave in the order of the solutions (prefix sum of the
-//                counts).  As one lane per sample (root after root, solution after solution): 0.79 ms per batch.
-constexpr int kSolveWaves = 4, kFinRoots = 8, kMaxRoots = 16; // (kFinRoots: sizes the single kernel's row-reduction region - rounds 3 - 4: per-root working copies)
-constexpr int kFinC = 0, kFinA = 300, kFinNb = kFinA + 100 * kFinRoots, kFinX = kFinNb + 27, kFinTmp = kFinX + 36,
-              kFinDoubles = kFinTmp + 7 * kMaxRoots;
-static_assert(eig_wave_doubles(15) <= 100 * kFinRoots, "the eigenvalue workspace lives in the roots' region");
-// Round 5: the solve stage as THREE kernels over a per-sample record in the workspace (sample-major, behind the element-major rows):
-//   [companion matrix 225 (later: the solutions) | eigenvalues 15 | ok | number of real eigenvalues | number of solutions]
-//   k_sfocal_comp    one wavefront = one sample: the row reduction to the companion matrix (six_companion_wave)
-//   k_sfocal_eig     one wavefront = FOUR samples, 16 lanes each: balancing and eigenvalues (pl_eigen_packed.h).  Inside one kernel every
-//                    wavefront iterated on its own matrix with <= 15 lanes at work and every scalar of the iteration computed 64 times:
-//                    63 % of the kernel's time (profiles/r05_focal_batch.md)
-//   k_sfocal_roots   one wavefront = one sample, 16 lanes per root: (x, y) from the null vector of C0 + w C1 + w^2 C2 (pl_nullvec_packed.h), the list of solutions
-//   k_sfocal_poses   one wavefront = FOUR samples, one lane per solution: essential matrix, up to four poses; the models in order
-constexpr uint32_t kSplitSamples = 4096; // launches of at least so many samples take the three kernels, smaller ones the single kernel
-constexpr int kSfActDoubles = 244, kSfActEv = 225, kSfActOk = 240, kSfActRoots = 241, kSfActNs = 242,
-              kSfActSol = 0; // (the solutions sx | sy | sw, 16 each, take the companion matrix's place once the eigenvalues are known)
-__device__ __forceinline__ double *sfocal_act(const SFocalGenArgs &g, uint32_t it) {
-    return g.stage + (size_t)kStDoubles * g.num_iters + (size_t)it * kSfActDoubles;
-}
-constexpr int kCompLds = 792; // T (225) | Cw (300) | A (100) | B (150) | factors (16)
-// the equations of sample `it` (element-major rows of the workspace) row-reduced to the companion matrix by the wavefront.
-// reg: T (225) | Cw (300) | A (100) | B (150) | factors (16) of LDS.  true (uniform): T stands in reg[0 .. 225), all entries finite
-__device__ __forceinline__ bool sfocal_companion(const SFocalGenArgs &g, uint32_t it, int lane, double *reg, double *keep_C) {
-    const size_t B = g.num_iters;
-    const double *st = g.stage + it;
-    for (int e = lane; e < 300; e += 64) {
-        const double v = st[(size_t)(kStC + e) * B];
-        if (keep_C) // (the roots' null vectors read the equations again)
-            keep_C[e] = v;
-        reg[225 + e] = v;
-    }
-    bool have_T = false;
-    if (six_companion_wave(reg + 225, reg, reg + 525, reg + 625, reg + 775, lane)) {
-        bool finite = true;
-        for (int e = lane; e < 225; e += 64)
-            finite = finite && isfinite(reg[e]);
-        have_T = !__builtin_amdgcn_ballot_w64(!finite); // (a vanishing pivot: the balancing would not terminate on an infinite entry)
-    }
-    return have_T;
-}
-__device__ __forceinline__ void sfocal_comp_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_comp[kSolveWaves][kCompLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
-    if (it >= g.num_iters)
-        return;
-    double *reg = s_comp[wave];
-    double *act = sfocal_act(g, it);
-    const bool have_T = sfocal_companion(g, it, lane, reg, nullptr);
-    if (have_T)
-        for (int e = lane; e < 225; e += 64)
-            act[e] = reg[e];
-    if (lane == 0)
-        act[kSfActOk] = have_T ? 1.0 : 0.0;
-}
-constexpr int kEigWaves = 4, kEigLds = 288; // (eig_wave_doubles(15) = 285, padded)
-static_assert(eig_wave_doubles(15) <= kEigLds, "a group's matrix and workspace");
-__device__ __forceinline__ void sfocal_eig_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_eig[kEigWaves][4][kEigLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
-    const uint32_t it = (blk * kEigWaves + wave) * 4u + grp;
-    const bool alive = it < g.num_iters;
-    double *act = sfocal_act(g, alive ? it : 0u);
-    const bool ok = alive && act[kSfActOk] != 0.0;
-    double *mine = s_eig[wave][grp];
-    if (ok)
-        for (int e = gl; e < 225; e += 16)
-            mine[e] = act[e];
-    EigWave4<15> cx{mine, gl, lane};
-    cx.sync();
-    pl_balance_pow2_packed<15>(cx, ok);
-    const int nr = pl_real_eigenvalues_packed<15>(cx, ok, 1e-8);
-    if (ok && gl < nr)
-        act[kSfActEv + gl] = cx.out(gl);
-    if (alive && gl == 0)
-        act[kSfActRoots] = ok ? (double)nr : 0.0;
-}
-// phase 1, the roots of a sample FOUR at a time: 16 lanes per root, lane j of a group forms column j of C0 + w C1 + w^2 C2 in registers
-// and the group finds the null vector together (pl_nullvec_packed.h); (x, y) of the root from its entries 7, 8, 9.  Lane 0 of the
-// wavefront then builds the list of solutions ascending in y as the serial routine inserts them.  C: the equations (LDS, 300), ev: the
-// eigenvalues (nroots), ws: 6 x kMaxRoots doubles of LDS - the list is left in its second half (sx | sy | sw); returns its length (uniform).
-// (Rounds 3 - 4: one lane per root on a 10 x 10 working copy in LDS, ~2800 LDS round trips per root.)
-__device__ __forceinline__ int sfocal_root_solutions(int lane, const double *C, const double *ev, int nroots, double *ws) {
-    const int grp = lane >> 4, gl = lane & 15;
-    double *rx = ws, *ry = rx + kMaxRoots, *rw = ry + kMaxRoots, *sx = rw + kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots;
-    uint32_t fmask = 0; // (uniform) bit s: root s has a solution
-    for (int first = 0; first < nroots; first += 4) { // (uniform)
-        const int root = first + grp;
-        const double wv = ev[root < nroots ? root : 0];
-        const bool on = root < nroots && !(wv < 1e-8); // six_root_xy: focal lengths beyond 1e4 are dropped
-        NullWave4<10> cx;
-        cx.gl = gl, cx.lane = lane, cx.cp = 0, cx.yv = 0, cx.t1 = 0, cx.t2 = 0;
-#pragma unroll
-        for (int r = 0; r < 10; ++r) { // column gl of A = C0 + w (C1 + w C2)
-            const int e = r * 10 + (gl < 10 ? gl : 0);
-            cx.c[r] = C[e] + wv * (C[100 + e] + wv * C[200 + e]);
-        }
-        pl_null_vector_packed<10>(cx, on);
-        const double v7 = null_row_bcast<7>(cx.yv), v8 = null_row_bcast<8>(cx.yv), v9 = null_row_bcast<9>(cx.yv);
-        const bool found = on && !(v9 == 0);
-        if (gl == 0 && found)
-            rx[root] = v7 / v9, ry[root] = v8 / v9, rw[root] = wv;
-        const uint64_t b = __builtin_amdgcn_ballot_w64(gl == 0 && found);
-        fmask |= ((uint32_t)(b & 1u) | (uint32_t)((b >> 16) & 1u) << 1 | (uint32_t)((b >> 32) & 1u) << 2 | (uint32_t)((b >> 48) & 1u) << 3) << first;
-        PL_WAVE_SYNC();
-    }
-    int ns = 0;
-    if (lane == 0)
-        for (int s = 0; s < nroots; ++s)
-            if ((fmask >> s) & 1u)
-                six_insert_solution(sx, sy, sw, ns, rx[s], ry[s], rw[s]);
-    ns = __builtin_amdgcn_readfirstlane(ns);
-    PL_WAVE_SYNC();
-    return ns;
-}
-// phase 2, lane gl (< 16) of a group of 16 lanes = solution gl of sample `it`: essential matrix, up to four poses; the models leave in
-// the order of the solutions (prefix sum of the counts over the group).  x1 / x2 / nb: the sample's bearings and null space, cnt: 16
-// doubles of scratch - LDS of the group.  One group per wavefront (the single kernel) or four (k_sfocal_poses).  Returns the number of
-// models of the sample (every lane of the group).
+constexpr int kSolveWaves = 4, kMaxRoots = 16;
+// lane gl (< 16) = solution gl of sample `it`: essential matrix, up to four poses; the models leave in the order of the solutions
+// (prefix sum of the counts).  x1 / x2 / nb: the sample's bearings and null space (LDS), cnt: 16 doubles of scratch (LDS).  Returns the
+// number of models of the sample (every lane).
 __device__ __forceinline__ uint32_t sfocal_emit_poses(const SFocalGenArgs &g, uint32_t it, int gl, int ns, double sxv, double syv, double swv,
                                                       const Vec3 *x1, const Vec3 *x2, const double *nb, double *cnt) {
     FocalModel mine[4];
@@ -247,36 +117,87 @@ __device__ __forceinline__ uint32_t sfocal_emit_poses(const SFocalGenArgs &g, ui
     }
     return m;
 }
-// both phases by the sample's own wavefront (the single kernel)
-__device__ __forceinline__ uint32_t sfocal_emit_roots(const SFocalGenArgs &g, uint32_t it, int lane, double *base, const double *ev, int nroots) {
-    const int ns = sfocal_root_solutions(lane, base + kFinC, ev, nroots, base + kFinTmp);
-    double *sx = base + kFinTmp + 3 * kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots, *cnt = sw + kMaxRoots;
-    const int s = lane < kMaxRoots ? lane : 0;
-    const Vec3 *x1 = reinterpret_cast<const Vec3 *>(base + kFinX);
-    return sfocal_emit_poses(g, it, lane < kMaxRoots ? lane : kMaxRoots, ns, sx[s], sy[s], sw[s], x1, x1 + 6, base + kFinNb, cnt);
-}
-// The solve stage in ONE kernel (small launches: see focal.hip - the chain of a single problem's batch is shorter this way; the same bits)
+
+// k_sfocal_solve: one WAVEFRONT = one sample.  LDS of a wavefront (doubles):
+//   [0, 28) null space | [28, 64) bearings | [64, 344) the coefficients, later the action matrix (225) |
+//   [344, 344 + 31 * 46) the template, row-major (consecutive lanes = consecutive columns), later: the working copy of the action
+//   matrix (225) | Danilevsky's vectors (30) | the polynomial (16) | roots (16) | solutions sx, sy, sw (48) | counts (16)
+constexpr int kSixS = 46, kLdsNb = 0, kLdsX = 28, kLdsCoef = 64, kLdsC = 344, kSolveLds = kLdsC + 31 * kSixS;
+constexpr int kLdsAmp = 0, kLdsWs = 225, kLdsPoly = 255, kLdsEv = 271, kLdsSol = 287, kLdsCnt = 335; // (offsets inside the template's region)
+static_assert(kSixCoeffs <= kLdsC - kLdsCoef && kLdsCnt + 16 <= 31 * kSixS, "regions");
 __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_fin[kSolveWaves][kFinDoubles];
+    __shared__ double s_fin[kSolveWaves][kSolveLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
     if (it >= g.num_iters)
         return;
     const size_t B = g.num_iters;
     const double *st = g.stage + it;
-    double *base = s_fin[wave];
-    double *reg = base + kFinA; // T (225) | Cw (300) | A (100) | B (150) | factors (16): dead before the roots use the region
-    uint32_t m = 0;
+    double *base = s_fin[wave], *nb = base + kLdsNb, *coef = base + kLdsCoef, *C = base + kLdsC;
     if (lane < 27)
-        base[kFinNb + lane] = st[(size_t)(kStNb + lane) * B];
+        nb[lane] = st[(size_t)(kStNb + lane) * B];
     if (lane < 36)
-        base[kFinX + lane] = st[(size_t)(kStX + lane) * B];
-    if (sfocal_companion(g, it, lane, reg, base + kFinC)) {
-        pl_balance_pow2_wave<15>(reg, lane);
-        const int nroots = pl_real_eigenvalues_wave<15>(reg, 1e-8, lane);
-        PL_WAVE_SYNC();
-        if (nroots > 0) // (the eigenvalues stand at reg[270 ...])
-            m = sfocal_emit_roots(g, it, lane, base, reg + 225 + 45, nroots);
+        base[kLdsX + lane] = st[(size_t)(kStX + lane) * B];
+    PL_WAVE_SYNC();
+    // ---- coefficients, template, the last eight rows of C0^-1 C1 (relpose_6pt_focal.cc:54-1043)
+    template_coefficients_wave<true, kSixCoeffs>(nb, kSixTermStart, kSixTermPacked, coef, lane);
+    PL_WAVE_SYNC();
+    template_fill_wave<31, kSixCols, kSixS>(coef, kSixColStart, kSixEntryRow, kSixEntryCoeff, C, lane);
+    lu_solve_tail_wave<31, kSixCols, kSixS, 8>(C, lane);
+    // ---- the action matrix (:1045-1053): kept in the coefficients' place for the roots, a working copy for the polynomial
+    double amv[4];
+    {
+        auto tail = [&](int r, int j) { return C[(23 + r) * kSixS + 31 + j]; };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = lane + 64 * k;
+            amv[k] = e < 225 ? six_action_entry(tail, e / 15, e % 15) : 0.0;
+        }
+    }
+    PL_WAVE_SYNC();
+    double *am = coef, *amp = C + kLdsAmp, *poly = C + kLdsPoly, *ev = C + kLdsEv, *sols = C + kLdsSol;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = lane + 64 * k;
+        if (e < 225)
+            am[e] = amv[k], amp[e] = amv[k];
+    }
+    PL_WAVE_SYNC();
+    // ---- characteristic polynomial, its real roots (:1069-1076)
+    danilevsky_charpoly_wave<15>(amp, C + kLdsWs, poly, lane);
+    int nroots = 0;
+    if (lane == 0) {
+        double p[16], r[15];
+        for (int i = 0; i < 16; ++i)
+            p[i] = poly[i];
+        nroots = sturm_n_roots<15>(p, r, 1e-12);
+        for (int i = 0; i < nroots; ++i)
+            ev[i] = r[i];
+    }
+    nroots = __builtin_amdgcn_readfirstlane(nroots);
+    PL_WAVE_SYNC();
+    // ---- lane s = root s: x and w (:11-52); w < 1e-8 dropped (:1105); the solutions in the order of the roots
+    bool keep = false;
+    double x = 0, w = 1;
+    const double y = ev[lane < nroots ? lane : 0];
+    if (lane < nroots) {
+        six_root_xw((const double *)am, y, x, w);
+        keep = !(w < 1e-8);
+    }
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+    const int ns = (int)__popcll(mask);
+    if (keep) {
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        sols[pos] = x, sols[kMaxRoots + pos] = y, sols[2 * kMaxRoots + pos] = w;
+    }
+    PL_WAVE_SYNC();
+    // ---- lane s = solution s: essential matrix, poses (:1107-1141)
+    uint32_t m = 0;
+    if (ns > 0) { // (uniform)
+        const int s = lane < ns ? lane : 0;
+        const Vec3 *x1 = reinterpret_cast<const Vec3 *>(base + kLdsX);
+        m = sfocal_emit_poses(g, it, lane < kMaxRoots ? lane : kMaxRoots, ns, sols[s], sols[kMaxRoots + s], sols[2 * kMaxRoots + s], x1, x1 + 6, nb,
+                              C + kLdsCnt);
     }
     if (lane == 0) {
         g.num_models[it] = m;
@@ -284,89 +205,10 @@ __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32
             g.host_num_models[it] = m;
     }
 }
-// k_sfocal_roots: one wavefront = one sample - the equations from the workspace, the eigenvalues from the sample's record, then
-// sfocal_root_solutions; the list of solutions goes into the record
-constexpr int kSfRootsLds = 300 + kMaxRoots + 6 * kMaxRoots; // equations | eigenvalues | rx ry rw | sx sy sw
-__device__ __forceinline__ void sfocal_roots_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_fin[kSolveWaves][kSfRootsLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t it = blk * kSolveWaves + wave; // (wave-uniform)
-    if (it >= g.num_iters)
-        return;
-    const size_t B = g.num_iters;
-    const double *st = g.stage + it;
-    double *act = sfocal_act(g, it);
-    double *C = s_fin[wave], *ev = C + 300, *ws = ev + kMaxRoots;
-    const int nroots = (int)act[kSfActRoots]; // (0: no companion matrix, or no real eigenvalue)
-    int ns = 0;
-    if (nroots > 0) {
-        for (int e = lane; e < 300; e += 64) // the equations
-            C[e] = st[(size_t)(kStC + e) * B];
-        if (lane < nroots)
-            ev[lane] = act[kSfActEv + lane];
-        PL_WAVE_SYNC();
-        ns = sfocal_root_solutions(lane, C, ev, nroots, ws);
-        const double *sx = ws + 3 * kMaxRoots, *sy = sx + kMaxRoots, *sw = sy + kMaxRoots;
-        if (lane < ns) // the list of solutions: into the record (the companion matrix's place - dead since the eigenvalue kernel)
-            act[kSfActSol + lane] = sx[lane], act[kSfActSol + kMaxRoots + lane] = sy[lane], act[kSfActSol + 2 * kMaxRoots + lane] = sw[lane];
-    }
-    if (lane == 0)
-        act[kSfActNs] = (double)ns;
-}
-// k_sfocal_poses: one wavefront = FOUR samples, lane 16 g + s = solution s of sample g (a sample has <= 15 solutions and typically
-// one to three: as one wavefront per sample the poses were 18 % of the solve stage with a handful of lanes at work)
-constexpr int kPoseWaves = 4, kPoseLds = 80; // per group: null space 27 | bearings 36 | counts 16
-__device__ __forceinline__ void sfocal_poses_body(const SFocalGenArgs &g, uint32_t blk) {
-    __shared__ double s_pose[kPoseWaves][4][kPoseLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
-    const uint32_t it = (blk * kPoseWaves + wave) * 4u + grp;
-    const bool alive = it < g.num_iters;
-    const size_t B = g.num_iters;
-    const double *st = g.stage + (alive ? it : 0u);
-    const double *act = sfocal_act(g, alive ? it : 0u);
-    const int ns = alive ? (int)act[kSfActNs] : 0;
-    double *mine = s_pose[wave][grp];
-    if (ns > 0)
-        for (int e = gl; e < 63; e += 16)
-            mine[e] = e < 27 ? st[(size_t)(kStNb + e) * B] : st[(size_t)(kStX + (e - 27)) * B];
-    PL_WAVE_SYNC();
-    const int s = gl < ns ? gl : 0;
-    const double sxv = ns > 0 ? act[kSfActSol + s] : 0.0, syv = ns > 0 ? act[kSfActSol + kMaxRoots + s] : 0.0,
-                 swv = ns > 0 ? act[kSfActSol + 2 * kMaxRoots + s] : 1.0;
-    const Vec3 *x1 = reinterpret_cast<const Vec3 *>(mine + 27);
-    const uint32_t m = sfocal_emit_poses(g, alive ? it : 0u, gl, ns, sxv, syv, swv, x1, x1 + 6, mine, mine + 63);
-    if (alive && gl == 0) {
-        g.num_models[it] = m;
-        if (g.host_num_models)
-            g.host_num_models[it] = m;
-    }
-}
-#define PL_SOLVE_ATTR __launch_bounds__(64 * kSolveWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
-// (the single kernel serves launches that do not fill the device: no register cap - the packed null vectors want ~140)
 __global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve(SFocalGenArgs g) { sfocal_solve_body(g, blockIdx.x); }
 __global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_solve_g(const SFocalGenArgs *__restrict__ gs) {
     const SFocalGenArgs g = gs[blockIdx.y];
     sfocal_solve_body(g, blockIdx.x);
-}
-__global__ PL_SOLVE_ATTR void k_sfocal_comp(SFocalGenArgs g) { sfocal_comp_body(g, blockIdx.x); }
-__global__ PL_SOLVE_ATTR void k_sfocal_comp_g(const SFocalGenArgs *__restrict__ gs) {
-    const SFocalGenArgs g = gs[blockIdx.y];
-    sfocal_comp_body(g, blockIdx.x);
-}
-__global__ __launch_bounds__(64 * kEigWaves) void k_sfocal_eig(SFocalGenArgs g) { sfocal_eig_body(g, blockIdx.x); }
-__global__ __launch_bounds__(64 * kEigWaves) void k_sfocal_eig_g(const SFocalGenArgs *__restrict__ gs) {
-    const SFocalGenArgs g = gs[blockIdx.y];
-    sfocal_eig_body(g, blockIdx.x);
-}
-__global__ __launch_bounds__(64 * kPoseWaves) void k_sfocal_poses(SFocalGenArgs g) { sfocal_poses_body(g, blockIdx.x); }
-__global__ __launch_bounds__(64 * kPoseWaves) void k_sfocal_poses_g(const SFocalGenArgs *__restrict__ gs) {
-    const SFocalGenArgs g = gs[blockIdx.y];
-    sfocal_poses_body(g, blockIdx.x);
-}
-__global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_roots(SFocalGenArgs g) { sfocal_roots_body(g, blockIdx.x); }
-__global__ __launch_bounds__(64 * kSolveWaves) void k_sfocal_roots_g(const SFocalGenArgs *__restrict__ gs) {
-    const SFocalGenArgs g = gs[blockIdx.y];
-    sfocal_roots_body(g, blockIdx.x);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) { // l wave-uniform
@@ -770,7 +612,7 @@ __global__ __launch_bounds__(kSfLMThreads) void k_sfocal_lm(SFocalLMTask *tasks)
 
 } // namespace
 
-size_t sfocal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)(kStDoubles + kSfActDoubles) * num_iters; }
+size_t sfocal_stage_bytes(uint32_t num_iters) { return sizeof(double) * (size_t)kStDoubles * num_iters; }
 
 hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     if (g.num_iters == 0)
@@ -778,14 +620,7 @@ hipError_t launch_sfocal_generate(const SFocalGenArgs &g, hipStream_t stream) {
     if (!g.stage)
         return hipErrorInvalidValue;
     k_sfocal_setup<<<dim3((g.num_iters + 63u) / 64u), dim3(64), 0, stream>>>(g);
-    if (g.num_iters < kSplitSamples) {
-        k_sfocal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
-        return hipGetLastError();
-    }
-    k_sfocal_comp<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
-    k_sfocal_eig<<<dim3((g.num_iters + 4 * kEigWaves - 1) / (4 * kEigWaves)), dim3(64 * kEigWaves), 0, stream>>>(g);
-    k_sfocal_roots<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
-    k_sfocal_poses<<<dim3((g.num_iters + 4 * kPoseWaves - 1) / (4 * kPoseWaves)), dim3(64 * kPoseWaves), 0, stream>>>(g);
+    k_sfocal_solve<<<dim3((g.num_iters + kSolveWaves - 1) / kSolveWaves), dim3(64 * kSolveWaves), 0, stream>>>(g);
     return hipGetLastError();
 }
 // ---- group launches (driver_focal_group.inc): blockIdx.y = member, the grid's x extent = the largest member's; `args` is a
@@ -794,14 +629,7 @@ hipError_t launch_sfocal_generate_g(const SFocalGenArgs *args, uint32_t G, uint3
     if (G == 0 || max_iters == 0)
         return hipSuccess;
     k_sfocal_setup_g<<<dim3((max_iters + 63u) / 64u, G), dim3(64), 0, stream>>>(args);
-    if ((size_t)max_iters * G < kSplitSamples) { // (the same bits either way: tests/test_zz_gpu_focal_group.py)
-        k_sfocal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
-        return hipGetLastError();
-    }
-    k_sfocal_comp_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
-    k_sfocal_eig_g<<<dim3((max_iters + 4 * kEigWaves - 1) / (4 * kEigWaves), G), dim3(64 * kEigWaves), 0, stream>>>(args);
-    k_sfocal_roots_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
-    k_sfocal_poses_g<<<dim3((max_iters + 4 * kPoseWaves - 1) / (4 * kPoseWaves), G), dim3(64 * kPoseWaves), 0, stream>>>(args);
+    k_sfocal_solve_g<<<dim3((max_iters + kSolveWaves - 1) / kSolveWaves, G), dim3(64 * kSolveWaves), 0, stream>>>(args);
     return hipGetLastError();
 }
 hipError_t launch_sfocal_score_g(const SFocalScoreArgs *args, uint32_t G, uint32_t max_slots, bool workgroup_per_model, hipStream_t stream) {

@@ -223,14 +223,13 @@ int hm_essential_5pt(const double *in, double *E /* 10 x 9 row-major */) {
     return n;
 }
 
-// P3.5Pf (pl_solver_p35pf.h) with the workspace at a stride, like the device lays it out
-int hm_p35pf(const double *x /* 4 x 2 */, const double *X /* 4 x 3 */, uint32_t stride, double *poses7, double *focals) {
-    std::vector<double> work((size_t)kP35WorkDoubles * stride, 0.0);
+// P3.5Pf (pl_solver_p35pf.h: the serial statement of the solver whose steps the kernels of focal.hip distribute)
+int hm_p35pf(const double *x /* 4 x 2 */, const double *X /* 4 x 3 */, uint32_t /*stride*/, double *poses7, double *focals) {
     Vec3 Xs[4];
     for (int i = 0; i < 4; ++i)
         Xs[i] = v3(X[3 * i], X[3 * i + 1], X[3 * i + 2]);
     P35Solution sol[10];
-    const int n = p35pf(x, Xs, P35Work{work.data() + (stride - 1), stride}, sol);
+    const int n = p35pf(x, Xs, sol);
     for (int i = 0; i < n; ++i) {
         const double o[7] = {sol[i].q.w, sol[i].q.x, sol[i].q.y, sol[i].q.z, sol[i].t.x, sol[i].t.y, sol[i].t.z};
         std::memcpy(poses7 + 7 * i, o, sizeof(o));
@@ -238,17 +237,16 @@ int hm_p35pf(const double *x /* 4 x 2 */, const double *X /* 4 x 3 */, uint32_t 
     }
     return n;
 }
-// the 6-point shared-focal solver (pl_solver_6ptf.h) with the workspace at a stride, like the device lays it out
-int hm_relpose_6pt_shared_focal(const double *b1 /* 6 x 3 unit bearings */, const double *b2, uint32_t stride, double *poses7,
+// the 6-point shared-focal solver (pl_solver_6ptf.h: the serial statement)
+int hm_relpose_6pt_shared_focal(const double *b1 /* 6 x 3 unit bearings */, const double *b2, uint32_t /*stride*/, double *poses7,
                                 double *focals) {
-    std::vector<double> work((size_t)kSixWorkDoubles * stride, 0.0);
     Vec3 a[6], b[6];
     for (int i = 0; i < 6; ++i) {
         a[i] = v3(b1[3 * i], b1[3 * i + 1], b1[3 * i + 2]);
         b[i] = v3(b2[3 * i], b2[3 * i + 1], b2[3 * i + 2]);
     }
     int n = 0;
-    relpose_6pt_shared_focal(a, b, SixWork{work.data() + (stride - 1), stride}, [&](Quat q, Vec3 t, double f) {
+    relpose_6pt_shared_focal(a, b, [&](Quat q, Vec3 t, double f) {
         const double o[7] = {q.w, q.x, q.y, q.z, t.x, t.y, t.z};
         std::memcpy(poses7 + 7 * n, o, sizeof(o));
         focals[n++] = f;
@@ -770,7 +768,6 @@ struct HostFocalBackend {
     uint32_t n;
     uint64_t seed;
     double thr2, max_error, max_focal;
-    std::vector<double> work = std::vector<double>(kP35WorkDoubles);
 
     void score_one(const FocalModel &m, uint32_t &count, double &sum) const {
         double R[9];
@@ -800,7 +797,7 @@ struct HostFocalBackend {
                 X[k] = v3(pa[2][idx[k]], pa[3][idx[k]], pa[4][idx[k]]);
             }
             P35Solution sol[kFocalMaxModels];
-            const int ns = p35pf(xs, X, P35Work{work.data(), 1}, sol);
+            const int ns = p35pf(xs, X, sol);
             uint32_t m = 0;
             for (int i = 0; i < ns; ++i) {
                 if (sol[i].focal < 0 || (max_focal >= 0 && sol[i].focal > max_focal))
@@ -900,7 +897,6 @@ struct HostSFocalBackend {
     uint32_t n;
     uint64_t seed;
     double thr2, max_error;
-    std::vector<double> work = std::vector<double>(kSixWorkDoubles);
 
     void score_one(const FocalModel &m, uint32_t &count, double &score) const {
         double F[9];
@@ -931,7 +927,7 @@ struct HostSFocalBackend {
                 b[k] = bearing(pa[2][idx[k]], pa[3][idx[k]]);
             }
             uint32_t m = 0;
-            relpose_6pt_shared_focal(a, b, SixWork{work.data(), 1}, [&](Quat q, Vec3 t, double f) {
+            relpose_6pt_shared_focal(a, b, [&](Quat q, Vec3 t, double f) {
                 FocalModel o;
                 o.q[0] = q.w, o.q[1] = q.x, o.q[2] = q.y, o.q[3] = q.z;
                 o.t[0] = t.x, o.t[1] = t.y, o.t[2] = t.z;
@@ -1008,42 +1004,25 @@ extern "C" void hm_ransac_shared_focal(const double *const *pa, uint32_t n, uint
 }
 
 // The product's host-side SVD at the entry of the fundamental-matrix refinement (pl_svd3.h), row-major in and out.
-// ---- the packed eigenvalue routines (pl_eigen_packed.h) against the serial ones: shadow counters of this build (Makefile), and the
-// routines on matrices given explicitly (n = 10: plain; n = 15: balanced first, as six_eigenvalues does)
-namespace pl {
-unsigned long long pl_eig_shadow_counters[6] = {0, 0, 0, 0, 0, 0};
-}
-extern "C" void hm_eig_shadow_counters(unsigned long long *out6) {
-    for (int i = 0; i < 6; ++i)
-        out6[i] = pl::pl_eig_shadow_counters[i];
-}
-// pl_null_vector<10> on matrices given explicitly (the shadow check of this build compares the packed form on each)
-extern "C" void hm_null_vectors(const double *mats, int count, double *v_out) {
+// ---- pl_general_eigenvalues (pl_solver_p35pf.h: Hessenberg + Francis QR, the eigenvalue routine of the P3.5Pf action matrix) on
+// matrices given explicitly: real and imaginary parts in the routine's order
+extern "C" int hm_general_eigenvalues(int n, const double *mats, int count, double *wr_out, double *wi_out) {
+    if (n != 10)
+        return -1;
     for (int k = 0; k < count; ++k) {
         double a[100];
         for (int e = 0; e < 100; ++e)
             a[e] = mats[(size_t)k * 100 + e];
-        pl_null_vector<10, double *>(a, v_out + (size_t)k * 10);
-    }
-}
-extern "C" int hm_real_eigenvalues(int n, const double *mats, int count, double *ev_out, int *m_out) {
-    for (int k = 0; k < count; ++k) {
-        double a[225], ev[15];
-        for (int e = 0; e < n * n; ++e)
-            a[e] = mats[(size_t)k * n * n + e];
-        int m;
-        if (n == 10) {
-            m = pl_real_eigenvalues<10, double *>(a, ev, 1e-8);
-        } else if (n == 15) {
-            m = six_eigenvalues(SixWork{a, 1}, ev);
-        } else {
-            return -1;
-        }
-        m_out[k] = m;
-        for (int i = 0; i < m; ++i)
-            ev_out[(size_t)k * 15 + i] = ev[i];
+        pl_general_eigenvalues<10, double *>(a, wr_out + (size_t)k * 10, wi_out + (size_t)k * 10);
     }
     return 0;
+}
+// sturm_n_roots<15> (pl_sturm_n.h) and danilevsky_charpoly<15> (pl_action_template.h)
+extern "C" int hm_sturm15(const double *coef16, double tol, double *roots) { return sturm_n_roots<15>(coef16, roots, tol); }
+extern "C" void hm_charpoly15(const double *A225, double *p16) {
+    double a[225];
+    std::memcpy(a, A225, sizeof(a));
+    danilevsky_charpoly<15>(a, p16);
 }
 extern "C" void hm_svd3(const double *A9, double *U9, double *s3, double *V9) {
     Mat3 A, U, V;

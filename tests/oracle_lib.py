@@ -185,10 +185,13 @@ def homography_4pt(x1, x2, check_cheirality=True):
     return n, out.reshape(3, 3).T.copy()
 
 
-def sturm_roots(coeffs):
+def sturm_roots(coeffs, tol=None):
     c = _f(coeffs)
     out = np.zeros(len(c))
-    n = lib().orc_sturm_roots(_p(c), len(c) - 1, _p(out))
+    if tol is None:
+        n = lib().orc_sturm_roots(_p(c), len(c) - 1, _p(out))
+    else:
+        n = lib().orc_sturm_roots_tol(_p(c), len(c) - 1, C.c_double(tol), _p(out))
     return out[:n]
 
 
@@ -284,6 +287,21 @@ def relpose_6pt_shared_focal(b1, b2):
     focals = np.zeros(60)
     n = lib().orc_relpose_6pt_shared_focal(_p(b1), _p(b2), _p(poses), _p(focals))
     return poses[:n].copy(), focals[:n].copy()
+
+
+class libm_cubes:
+    """Context: the six-point solver's cubes through std::pow(d, 3) like the reference's formulas (glibc: the correctly rounded cube
+    except for ~8 of 10^4 arguments, one unit in the last place) instead of the oracle's default, the correctly rounded cube the
+    device computes - oracle/src/solvers_focal.cc.  For comparisons with oracle/_ref (tests/ref_lib.py), which always runs the
+    reference's own call."""
+
+    def __enter__(self):
+        lib().orc_set_exact_cubes(0)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_exact_cubes(1)
+        return False
 
 
 def ransac_pnpf(x, X, opt=None):

@@ -242,8 +242,9 @@ def _centered(d):
 
 
 def test_p35pf_device_header_bit_exact():
-    """pl_solver_p35pf.h (the generator kernel's per-lane code, its elimination matrix at a stride like on the device) against
-    the oracle's statement of the same algorithm: the same solutions, bit for bit, on exact and noisy minimal problems"""
+    """pl_solver_p35pf.h (the serial statement of the solver whose steps the kernels of focal.hip distribute over lanes) against
+    the oracle's restatement of the reference's template solver: the same solutions in the same order, bit for bit, on exact and
+    noisy minimal problems"""
     total = 0
     for seed in range(300):
         d = synth.absolute_pose_scene(4, 0.0, 9000 + seed, noise_px=0.0 if seed % 2 else 1.0)
@@ -305,8 +306,9 @@ def _six_bearings(rng):
 
 
 def test_six_point_shared_focal_device_header_bit_exact():
-    """pl_solver_6ptf.h (the generator kernel's per-lane code, its workspace at a stride like on the device) against the oracle's
-    statement of the same algorithm (solvers_focal.cc, dense arrays): poses, focal lengths and their order, bit for bit"""
+    """pl_solver_6ptf.h (the serial statement of the solver whose steps the kernels of sfocal.hip distribute over lanes) against the
+    oracle's restatement of the reference's template solver (solvers_focal.cc; both with the correctly rounded cube): poses, focal
+    lengths and their order, bit for bit"""
     rng = np.random.default_rng(3)
     total = 0
     for k in range(300):
@@ -535,142 +537,51 @@ def test_flat_root_isolation_finds_the_recursions_leaves_bit_for_bit():
     assert differ == 0  # (the oracle has no slot limits: equal wherever neither list overflows - everywhere here)
 
 
-# ---- the packed eigenvalue routines of round 5 (pl_eigen_packed.h: four matrices per wavefront on the device) ----
-def _eig_counters():
+# ---- the pieces of the two template solvers (round 6: pl_action_template.h, pl_sturm_n.h, pl_general_eigenvalues) on their own ----
+def test_general_eigenvalues_of_the_device_header_against_lapack():
+    """pl_general_eigenvalues<10> (Hessenberg + Francis QR: the routine behind the P3.5Pf action matrix, serial form; the wavefront
+    form of pl_eigen_wave.h performs the same operations on every element) - the spectrum of random and of structured matrices to
+    1e-9 of LAPACK's; the bit-level check is the solver test above (the oracle runs the same iteration)"""
     import ctypes as C
 
-    out = (C.c_ulonglong * 6)()
-    HM.lib().hm_eig_shadow_counters(out)
-    return list(out)
-
-
-def _real_eigenvalues(n, mats):
-    import ctypes as C
-
-    mats = np.ascontiguousarray(mats, dtype=np.float64)
-    count = mats.shape[0]
-    ev = np.zeros((count, 15))
-    m = np.zeros(count, dtype=np.int32)
-    rc = HM.lib().hm_real_eigenvalues(C.c_int(n), mats.ctypes.data_as(C.c_void_p), C.c_int(count), ev.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p))
-    assert rc == 0
-    return ev, m
-
-
-def test_packed_eigenvalues_equal_the_serial_routines_bit_for_bit():
-    """tests/hostmath is built with PL_EIG_SHADOW_CHECK: every matrix that reaches pl_real_eigenvalues<10 | 15> / pl_balance_pow2<15> also goes
-    through the packed forms (the device's routines since round 5, lane loops as loops) and is compared bit for bit.  Here: the
-    matrices of the two minimal solvers on random samples, random dense matrices of several scalings, and the special ones
-    (zero, identity, triangular, already Hessenberg, exact deflations, rotations with complex pairs, repeated eigenvalues,
-    non-finite entries)."""
-    before = _eig_counters()
-    rng = np.random.default_rng(12)
-    # the solvers' own matrices
-    for k in range(300):
-        d = synth.absolute_pose_scene(4, 0.0, 31000 + k, noise_px=0.3)
-        f, cx, cy = d["camera"]["params"]
-        HM.p35pf((np.asarray(d["p2d"]) - [cx, cy]) / f, d["p3d"])
-    for k in range(300):
-        d = synth.relative_pose_scene(6, 0.0, 32000 + k, noise_px=0.3)
-        f, cx, cy = d["camera1"]["params"]
-        b1 = np.c_[(np.asarray(d["x1"]) - [cx, cy]) / f, np.ones(6)]
-        b2 = np.c_[(np.asarray(d["x2"]) - [cx, cy]) / f, np.ones(6)]
-        HM.relpose_6pt_shared_focal(b1 / np.linalg.norm(b1, axis=1, keepdims=True), b2 / np.linalg.norm(b2, axis=1, keepdims=True))
-    mid = _eig_counters()
-    assert mid[0] - before[0] >= 500 and mid[2] - before[2] >= 250, (before, mid)
-    for n in (10, 15):
-        mats = [rng.normal(size=(n, n)) * 10.0 ** rng.integers(-6, 7) for _ in range(1500)]
-        mats += [np.zeros((n, n)), np.eye(n), np.triu(rng.normal(size=(n, n))), np.tril(rng.normal(size=(n, n))),
-                 np.triu(rng.normal(size=(n, n)), -1), np.diag(np.arange(1.0, n + 1)), np.ones((n, n)), np.diag(np.ones(n - 1), 1)]
-        for _ in range(200):  # block structures: exact deflations, 2 x 2 rotations (complex pairs), repeated eigenvalues
-            M = np.zeros((n, n))
-            i = 0
-            while i < n:
-                if i + 1 < n and rng.random() < 0.5:
-                    a, b = rng.normal(), rng.normal()
-                    M[i:i + 2, i:i + 2] = [[a, -b], [b, a]]
-                    i += 2
-                else:
-                    M[i, i] = rng.choice([1.0, 2.0, rng.normal()])
-                    i += 1
-            if rng.random() < 0.5:
-                Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
-                M = Q @ M @ Q.T
-            mats.append(M)
-        for _ in range(100):  # sparse, graded
-            M = rng.normal(size=(n, n)) * (rng.random((n, n)) < 0.3) * 2.0 ** rng.integers(-30, 30, size=(n, n))
-            mats.append(M)
-        bad = rng.normal(size=(n, n))
-        bad[3, 4] = np.nan
-        mats.append(bad)
-        ev, m = _real_eigenvalues(n, np.array(mats))
-        # and the values themselves are eigenvalues (numpy, on the well-conditioned dense ones)
-        for k in range(0, 200, 20):
-            ref = np.linalg.eigvals(mats[k])
-            real = np.sort(ref[np.abs(ref.imag) <= 1e-8 * (1 + np.abs(ref.real))].real)
-            assert m[k] == len(real) and np.allclose(ev[k, :m[k]], real, rtol=1e-7, atol=1e-9 * np.abs(mats[k]).max()), (n, k, ev[k, :m[k]], real)
-    after = _eig_counters()
-    assert after[0] - mid[0] >= 3600, (mid, after)
-    assert after[1] == 0 and after[3] == 0, f"packed != serial: {after[1]} of {after[0]} eigenvalue calls, {after[3]} of {after[2]} balancing calls"
-
-
-def test_packed_null_vector_equals_the_serial_routine_bit_for_bit():
-    """pl_nullvec_packed.h (16 lanes per matrix on the device) against pl_null_vector<10> through the shadow check of the tests/hostmath
-    build: the solvers' own matrices (every root of 300 + 300 minimal problems), random singular and non-singular matrices of several
-    scalings, and the cases that exercise the tie rule of the complete pivoting (equal magnitudes: +-1 matrices, permutations, repeated
-    rows and columns), early termination (zero blocks, rank 1 ... 8) and non-finite entries."""
-    import ctypes as C
-
-    before = _eig_counters()
     rng = np.random.default_rng(21)
-    for k in range(300):
-        d = synth.absolute_pose_scene(4, 0.0, 33000 + k, noise_px=0.3)
-        f, cx, cy = d["camera"]["params"]
-        HM.p35pf((np.asarray(d["p2d"]) - [cx, cy]) / f, d["p3d"])
-        d = synth.relative_pose_scene(6, 0.0, 34000 + k, noise_px=0.3)
-        f, cx, cy = d["camera1"]["params"]
-        b1 = np.c_[(np.asarray(d["x1"]) - [cx, cy]) / f, np.ones(6)]
-        b2 = np.c_[(np.asarray(d["x2"]) - [cx, cy]) / f, np.ones(6)]
-        HM.relpose_6pt_shared_focal(b1 / np.linalg.norm(b1, axis=1, keepdims=True), b2 / np.linalg.norm(b2, axis=1, keepdims=True))
-    mid = _eig_counters()
-    assert mid[4] - before[4] >= 1000, (before, mid)
-    mats = []
-    for _ in range(1500):
-        A = rng.normal(size=(10, 10)) * 10.0 ** rng.integers(-6, 7)
-        if rng.random() < 0.7:  # singular: rank 9 (the case the routine is made for) or less
-            rank = int(rng.choice([9, 9, 9, 8, 5, 2, 1]))
-            U, S, Vt = np.linalg.svd(A)
-            S[rank:] = 0
-            A = (U * S) @ Vt
-        mats.append(A)
-    for _ in range(600):  # equal magnitudes everywhere: the scan order decides the pivot
-        A = rng.choice([-1.0, 1.0, 0.0, 2.0, -2.0], size=(10, 10), p=[0.3, 0.3, 0.2, 0.1, 0.1])
-        mats.append(A)
-    for _ in range(200):
-        A = np.eye(10)[rng.permutation(10)] * rng.choice([-1.0, 1.0, 3.0], size=10)
-        if rng.random() < 0.5:
-            A[rng.integers(10)] = 0
-        mats.append(A)
-    for _ in range(200):  # repeated rows / columns, zero blocks
-        A = rng.integers(-3, 4, size=(10, 10)).astype(float)
-        A[rng.integers(10)] = A[rng.integers(10)]
-        A[:, rng.integers(10)] = A[:, rng.integers(10)]
-        if rng.random() < 0.3:
-            A[5:, 5:] = 0
-        mats.append(A)
-    mats += [np.zeros((10, 10)), np.ones((10, 10)), np.eye(10), np.triu(np.ones((10, 10))), np.tril(np.ones((10, 10)))]
-    bad = rng.normal(size=(10, 10))
-    bad[2, 7] = np.nan
-    mats.append(bad)
-    bad = rng.normal(size=(10, 10))
-    bad[4, 4] = np.inf
-    mats.append(bad)
-    M = np.ascontiguousarray(np.array(mats), dtype=np.float64)
-    v = np.zeros((len(mats), 10))
-    HM.lib().hm_null_vectors(M.ctypes.data_as(C.c_void_p), C.c_int(len(mats)), v.ctypes.data_as(C.c_void_p))
-    # and it is a null vector (rank-9 matrices)
-    for k in range(0, 1500, 50):
-        if np.linalg.matrix_rank(mats[k]) == 9:
-            assert np.abs(mats[k] @ v[k]).max() <= 1e-8 * np.abs(mats[k]).max() * np.abs(v[k]).max(), k
-    after = _eig_counters()
-    assert after[4] - mid[4] == len(mats), (mid, after)
-    assert after[5] == 0, f"packed != serial null vector: {after[5]} of {after[4]} calls"
+    mats = [rng.normal(size=(10, 10)) for _ in range(200)]
+    mats += [np.diag(rng.normal(size=10)) + 1e-3 * rng.normal(size=(10, 10)) for _ in range(50)]
+    comp = np.zeros((10, 10))
+    comp[1:, :-1] = np.eye(9)
+    comp[:, -1] = rng.normal(size=10)
+    mats.append(comp)
+    M = np.ascontiguousarray(np.stack(mats))
+    wr, wi = np.zeros((len(mats), 10)), np.zeros((len(mats), 10))
+    rc = HM.lib().hm_general_eigenvalues(C.c_int(10), M.ctypes.data_as(C.c_void_p), C.c_int(len(mats)), wr.ctypes.data_as(C.c_void_p),
+                                         wi.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    for k, A in enumerate(mats):
+        got = np.sort_complex(wr[k] + 1j * wi[k])
+        want = np.sort_complex(np.linalg.eigvals(A))
+        assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max()), k
+
+
+def test_sturm_of_degree_15_and_danilevsky_of_the_device_headers():
+    """sturm_n_roots<15> (pl_sturm_n.h) against the oracle's generic Sturm bisection bit for bit at the six-point solver's tolerance;
+    danilevsky_charpoly<15> (pl_action_template.h) against numpy's characteristic polynomial"""
+    import ctypes as C
+
+    rng = np.random.default_rng(22)
+    with_roots = 0
+    for k in range(400):
+        roots_true = rng.normal(size=15) * 10.0 ** rng.integers(-2, 2)
+        c = np.poly(roots_true)[::-1].copy() if k % 2 else rng.normal(size=16)
+        c = np.ascontiguousarray(c * rng.uniform(0.5, 2.0))
+        out = np.zeros(16)
+        n = HM.lib().hm_sturm15(c.ctypes.data_as(C.c_void_p), C.c_double(1e-12), out.ctypes.data_as(C.c_void_p))
+        want = O.sturm_roots(c, tol=1e-12)
+        assert n == len(want) and np.array_equal(out[:n], np.asarray(want)), (k, out[:n], want)
+        with_roots += n > 0
+    assert with_roots > 300
+    for k in range(50):
+        A = np.ascontiguousarray(rng.normal(size=(15, 15)))
+        p = np.zeros(16)
+        HM.lib().hm_charpoly15(A.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p))
+        want = np.poly(A)[::-1]
+        assert np.abs(p - want).max() < 1e-7 * np.abs(want).max(), k
