@@ -2,14 +2,17 @@
 random problems - decisions (iterations, refinements) and inlier masks counted separately - and, for every problem on which the
 two differ, which minimal solver returned which root set at the sample where the two loops part.
 
-The estimators differ from the reference in ONE place: the minimal solvers (P3.5Pf, 6-point shared focal) are this project's own
-formulations, not the reference's generated elimination templates; everything after a sample's models is the same arithmetic.  The
-per-case analysis replays the sample stream of the problem (the sampler is counter based), calls BOTH solvers on every sample
-(oracle/_ref's and the oracle's, which the device equals bit for bit: tests/test_zz_gpu_*focal*.py), scores every model on all
-correspondences and reports the first sample at which the running best (inlier count, then MSAC score) of the two model streams
-differ.
+Rounds 3 - 5 solved the two minimal problems in formulations of this project's own (589 / 600 identical decisions in round 5: their
+root sets differed from the template solvers' on ~2 % of the samples); since round 6 the solvers restate the reference's templates
+(scripts/gen_focal_templates.py, pl_solver_p35pf.h, pl_solver_6ptf.h) and return the reference's roots bit for bit - up to the
+cubes of the six-point coefficients (std::pow in the reference, correctly rounded on the device: one unit in the last place of one
+coefficient on ~1.5 % of the samples) and the rounding-level agreement of the local optimisations.  For every problem on which
+the two still differ the per-case analysis replays the sample stream (the sampler is counter based), calls BOTH solvers on every
+sample (oracle/_ref's and the oracle's, which the device equals bit for bit: tests/test_zz_gpu_*focal*.py), scores every model on
+all correspondences and reports the first sample at which the running best (inlier count, then MSAC score) of the two model
+streams differ.
 
-    python scripts/soak_focal_device_vs_reference.py [problems per estimator=300] > profiles/r05_soak_focal_device_vs_reference.md
+    python scripts/soak_focal_device_vs_reference.py [problems per estimator=300] > profiles/r06_soak_focal_device_vs_reference.md
 """
 import os
 import sys
@@ -185,7 +188,7 @@ def main():
                              f"{'equal' if msk else 'differ in %d points' % int((md != np.asarray(mr, dtype=bool)).sum())}, focal {fd:.9g} / {fr:.9g} "
                              f"(true {focal:.9g}; in the loop's units {f_true:.6g}).  {where}")
         rows.append((name, len(fdiff), same_all, same_dec, same_mask, float(np.median(fdiff)) if fdiff else 0.0, float(np.max(fdiff)) if fdiff else 0.0, better, worse))
-    print("# r05 - the DEVICE's focal-length estimators against the reference's own sources (scripts/soak_focal_device_vs_reference.py)\n")
+    print("# r06 - the DEVICE's focal-length estimators against the reference's own sources (scripts/soak_focal_device_vs_reference.py)\n")
     print("The 600 random problems of `profiles/r03_soak_focal_oracle_vs_reference.md` (30 ... 3000 correspondences, 5 - 60 % outliers, random focal")
     print("lengths / noise / thresholds, max_iterations 5000) through `poselib_amd.estimate_*` on the GPU and through `oracle/_ref` (the reference's")
     print("sources with their generated solver templates) on the host.  device / reference in the list below.\n")
