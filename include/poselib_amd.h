@@ -175,7 +175,10 @@ typedef struct {
     int32_t kind;            /* 0 absolute pose, 1 relative pose, 2 fundamental, 3 homography, 4 relative pose with a shared
                               * unknown focal length (pl_estimate_shared_focal_relative_pose).  Kind-4 items and kind-0 items with
                               * estimate_focal_length advance in lock-step groups of their own since round 5 (one launch sequence per
-                              * group, every item bit-identical to its single call); PROSAC or warm-started ones one at a time */
+                              * group, every item bit-identical to its single call).  Kinds 0 - 3 with PROSAC, a warm start
+                              * (ransac.score_initial_model) or an OPENCV camera are group members like any other since round 6;
+                              * what still runs one at a time: min_iterations > 4096, fewer correspondences than sample size + 4,
+                              * more than 16384, PROSAC / warm starts of the focal-length kinds (pl_last_batch_report counts them) */
     int32_t status;          /* out: PL_OK or the error of this item */
     const double *a;         /* points2D (kind 0) / points2D_1: N x 2 */
     const double *b;         /* points3D: N x 3 (kind 0) / points2D_2: N x 2 */
@@ -189,6 +192,27 @@ typedef struct {
 } pl_batch_item;
 /* returns PL_OK if every item succeeded, otherwise the status of the first failing item */
 int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight);
+/* The same call over SEVERAL devices of the node from one process (north_star: independent problems round-robined across the
+ * GPUs; SURVEY 5 "one process drives <= 8 GPUs"): item i runs on devices[i mod num_devices], every entry of the list is served by
+ * a host thread and a worker pool of its own (`max_in_flight` workers each), the results land in the caller's arrays - no
+ * collective is needed inside one process.  devices == NULL or num_devices <= 0: every visible device.  An entry may repeat a
+ * device (the list {0, 0} runs two half-batches side by side on device 0); every item is bit-identical to its single call
+ * whatever the list.  The process-per-GPU form (one rank per device, RCCL gather of the result records) is the Python
+ * harness's: poselib_amd/sharding.py, bench.py --gpus N; INTEGRATION.md says which to use when. */
+int pl_estimate_batch_devices(pl_batch_item *items, size_t count, const int *devices, int num_devices, int max_in_flight);
+/* What the calling thread's last pl_estimate_batch / pl_estimate_batch_devices / pl_ransac_batch did with its items.  Items in
+ * lock-step groups share one launch sequence (the advertised rate); `solo` items were outside the group path from the start
+ * (options or sizes a group does not take - see pl_batch_item / pl_ransac_batch) and `fallback` items were handed back by their
+ * group: both kinds ran through the single-problem entry points, correct but at that path's rate - a batch that is mostly solo
+ * items runs ~20 x slower than one that is grouped, and this report is where a caller sees it. */
+typedef struct {
+    uint64_t items;         /* items of the call */
+    uint64_t grouped;       /* ... in the lock-step groups of kinds 0 - 3 */
+    uint64_t focal_grouped; /* ... in the groups of the two focal-length estimators */
+    uint64_t solo;          /* ... run one at a time from the start */
+    uint64_t fallback;      /* of the grouped ones: handed back by their group and re-run one at a time */
+} pl_batch_report;
+void pl_last_batch_report(pl_batch_report *out);
 
 /* ---- RANSAC entry points on normalised points (robust/ransac.h) ---- */
 int pl_ransac_pnp(const double *x, const double *X, size_t n, const pl_robust_options *opt, pl_camera_pose *pose,
@@ -229,8 +253,10 @@ int pl_ransac_run(pl_problem *p, const pl_robust_options *opt, void *model, uint
  * Items of the same kind advance in lock-step groups of `group_size` problems (<= 0: 16, at most 64): one launch sequence
  * per group and batch of iterations instead of one per problem, which is what keeps the device busy when thousands of
  * problems are queued (bench.py's throughput mode).  `max_in_flight` host threads (<= 0: 4), each with its own stream,
- * work on different groups.  Items a group cannot take (PROSAC, warm starts, fewer correspondences than sample size + 4,
- * more than 16384) run through pl_ransac_run. ---- */
+ * work on different groups.  Items a group cannot take (fewer correspondences than sample size + 4, more than 16384) run
+ * through pl_ransac_run; PROSAC and warm starts are group members since round 6.  The problems may live on DIFFERENT devices (pl_set_device before
+ * pl_problem_create): every item runs on the device that holds its problem, one host thread and one worker pool per device
+ * side by side (round 6). ---- */
 typedef struct {
     pl_problem *problem;
     const pl_robust_options *opt;

@@ -5,7 +5,10 @@
 //
 //   robust_amd_check <in.bin> <out.bin>
 //     (kind 4: estimate_shared_focal_relative_pose, kind 5: estimate_absolute_pose with estimate_focal_length,
-//      kind 6: ransac_pnpf on points relative to the principal point, AbsolutePoseOptions::min_fov = params[11])
+//      kind 6: ransac_pnpf on points relative to the principal point, AbsolutePoseOptions::min_fov = params[11],
+//      kind 7: estimate_absolute_pose_batch - the binding's multi-device call, not in the reference: six problems (the scene
+//              with seeds seed .. seed + 5) over the device list {0, 0}; every one must equal its single call, the first is
+//              written out)
 //     in : doubles [kind, n, seed, max_error, model_id, num_params, params[12], A (n x 2), B (n x 3 | n x 2)]
 //     out: doubles [iterations, refinements, num_inliers, model_score, model (7: q t | 9: column-major 3x3),
 //                   camera params[12] (kind 0), inliers (n)]
@@ -20,6 +23,13 @@
 #include <vector>
 
 using namespace poselib;
+
+namespace poselib { // (integration/robust_amd.cc; the reference's headers have no batched entry point)
+std::vector<RansacStats> estimate_absolute_pose_batch(const std::vector<std::vector<Point2D>> &points2D,
+                                                      const std::vector<std::vector<Point3D>> &points3D,
+                                                      const std::vector<AbsolutePoseOptions> &opts, std::vector<Image> *images,
+                                                      std::vector<std::vector<char>> *inliers, const std::vector<int> &devices);
+}
 
 int main(int argc, char **argv) {
     if (argc != 3) {
@@ -39,7 +49,8 @@ int main(int argc, char **argv) {
 
     const bool estimate_focal = (int)in[0] == 5;
     const bool pnpf = (int)in[0] == 6;
-    const int kind = (estimate_focal || pnpf) ? 0 : (int)in[0];
+    const bool multi = (int)in[0] == 7;
+    const int kind = (estimate_focal || pnpf || multi) ? 0 : (int)in[0];
     const size_t n = (size_t)in[1];
     RansacOptions ransac;
     ransac.seed = (size_t)in[2];
@@ -62,7 +73,45 @@ int main(int argc, char **argv) {
     RansacStats st;
     std::vector<double> model;
     std::vector<double> cam_out(12, 0.0);
-    if (pnpf) { // robust/ransac.h:52-54 with a non-default field-of-view bound (absolute_pose.h:78)
+    if (multi) {
+        const size_t K = 6;
+        std::vector<std::vector<Point2D>> xs(K, x1);
+        std::vector<std::vector<Point3D>> Xs(K, X);
+        std::vector<AbsolutePoseOptions> opts(K);
+        std::vector<Image> images(K);
+        std::vector<std::vector<char>> masks;
+        for (size_t j = 0; j < K; ++j) {
+            opts[j].ransac = ransac;
+            opts[j].ransac.seed = ransac.seed + j;
+            opts[j].max_error = max_error;
+            images[j].camera = camera;
+        }
+        const std::vector<RansacStats> stats = estimate_absolute_pose_batch(xs, Xs, opts, &images, &masks, {0, 0});
+        for (size_t j = 0; j < K; ++j) { // every problem against its single call: bit for bit
+            Image single;
+            single.camera = camera;
+            std::vector<char> m1;
+            const RansacStats s1 = estimate_absolute_pose(x1, X, opts[j], &single, &m1);
+            bool same = s1.iterations == stats[j].iterations && s1.refinements == stats[j].refinements && s1.num_inliers == stats[j].num_inliers &&
+                        s1.model_score == stats[j].model_score && m1 == masks[j] && single.camera.params == images[j].camera.params;
+            for (int i = 0; i < 4; ++i)
+                same = same && single.pose.q(i) == images[j].pose.q(i);
+            for (int i = 0; i < 3; ++i)
+                same = same && single.pose.t(i) == images[j].pose.t(i);
+            if (!same) {
+                std::fprintf(stderr, "estimate_absolute_pose_batch: problem %zu differs from its single call\n", j);
+                return 3;
+            }
+        }
+        st = stats[0];
+        inliers = masks[0];
+        for (int i = 0; i < 4; ++i)
+            model.push_back(images[0].pose.q(i));
+        for (int i = 0; i < 3; ++i)
+            model.push_back(images[0].pose.t(i));
+        for (size_t i = 0; i < images[0].camera.params.size() && i < 12; ++i)
+            cam_out[i] = images[0].camera.params[i];
+    } else if (pnpf) { // robust/ransac.h:52-54 with a non-default field-of-view bound (absolute_pose.h:78)
         AbsolutePoseOptions opt;
         opt.ransac = ransac;
         opt.max_error = max_error;

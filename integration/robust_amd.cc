@@ -145,6 +145,54 @@ RansacStats estimate_absolute_pose(const std::vector<Point2D> &points2D, const s
     return from_pl(st);
 }
 
+// ---- not in the reference: many independent absolute-pose problems in ONE call, spread over the GPUs of the node --------------
+// (a PoseLib user loops over estimate_absolute_pose() from a thread pool; with the device library the loop is the library's:
+// pl_estimate_batch_devices round-robins the problems over `devices` - empty: every visible GPU - from this one process, one worker
+// pool per device, and every problem's result equals its single call bit for bit.)  images: in (camera, and the pose when
+// ransac.score_initial_model is set) and out, one per problem.
+std::vector<RansacStats> estimate_absolute_pose_batch(const std::vector<std::vector<Point2D>> &points2D,
+                                                      const std::vector<std::vector<Point3D>> &points3D,
+                                                      const std::vector<AbsolutePoseOptions> &opts, std::vector<Image> *images,
+                                                      std::vector<std::vector<char>> *inliers, const std::vector<int> &devices = {}) {
+    const size_t count = points2D.size();
+    if (points3D.size() != count || opts.size() != count || images->size() != count)
+        throw std::runtime_error("estimate_absolute_pose_batch: one entry per problem in every argument");
+    inliers->resize(count);
+    std::vector<pl_robust_options> o(count);
+    std::vector<pl_camera> cams(count);
+    std::vector<pl_camera_pose> poses(count);
+    std::vector<pl_ransac_stats> st(count);
+    std::vector<pl_batch_item> items(count);
+    for (size_t i = 0; i < count; ++i) {
+        o[i] = to_pl(0, opts[i].ransac, opts[i].bundle, opts[i].max_error);
+        o[i].estimate_focal_length = opts[i].estimate_focal_length;
+        o[i].estimate_extra_params = opts[i].estimate_extra_params;
+        o[i].min_fov = opts[i].min_fov;
+        cams[i] = to_pl((*images)[i].camera);
+        poses[i] = to_pl((*images)[i].pose);
+        pl_batch_item &it = items[i];
+        it.kind = 0;
+        it.status = 0;
+        it.a = raw(points2D[i]);
+        it.b = raw(points3D[i]);
+        it.n = points2D[i].size();
+        it.opt = &o[i];
+        it.camera1 = &cams[i];
+        it.camera2 = nullptr;
+        it.model = &poses[i];
+        it.inliers = mask_of(&(*inliers)[i], points2D[i].size());
+        it.stats = &st[i];
+    }
+    check(pl_estimate_batch_devices(items.data(), count, devices.empty() ? nullptr : devices.data(), (int)devices.size(), 0));
+    std::vector<RansacStats> out(count);
+    for (size_t i = 0; i < count; ++i) {
+        from_pl(poses[i], &(*images)[i].pose);
+        std::copy(cams[i].params, cams[i].params + cams[i].num_params, (*images)[i].camera.params.begin());
+        out[i] = from_pl(st[i]);
+    }
+    return out;
+}
+
 RansacStats estimate_relative_pose(const std::vector<Point2D> &points2D_1, const std::vector<Point2D> &points2D_2,
                                    const Camera &camera1, const Camera &camera2, const RelativePoseOptions &opt,
                                    CameraPose *relative_pose, std::vector<char> *inliers) {

@@ -8,7 +8,7 @@ include/poselib_amd.h; this package only marshals numpy arrays.  No CPU fallback
 from ._lib import LIB_PATH, PoseLibAmdError, build  # noqa: F401
 from .api import (  # noqa: F401
     KIND_ABS, KIND_FUND, KIND_HOM, KIND_REL, Batch, RansacBatch, ransac_batch, device_math, BundleOptions, Camera, CameraPose, Image, Problem, RansacOptions,
-    device_count, essential_matrix_5pt, estimate_absolute_pose, estimate_batch, estimate_fundamental, estimate_homography,
+    device_count, essential_matrix_5pt, estimate_absolute_pose, estimate_batch, last_batch_report, estimate_fundamental, estimate_homography,
     estimate_relative_pose, homography_4pt, p3p, p5p, ransac_fundamental, ransac_homography, ransac_pnp, ransac_pnpf,
     ransac_relpose, ransac_shared_focal_relpose, estimate_shared_focal_relative_pose, refine_shared_focal_relpose, ImagePair, p35pf, relpose_6pt_shared_focal, solve_focal_batch, relpose_5pt, relpose_7pt, set_device, set_lm_mode, solve_batch, undistort_points,
 )

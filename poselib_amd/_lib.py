@@ -63,6 +63,11 @@ BatchItem._fields_ = [("kind", i32), ("status", i32), ("a", C.c_void_p), ("b", C
                       ("model", C.c_void_p), ("inliers", C.c_void_p), ("stats", C.POINTER(RansacStats))]
 
 
+class BatchReport(C.Structure):  # pl_batch_report
+    _fields_ = [("items", C.c_uint64), ("grouped", C.c_uint64), ("focal_grouped", C.c_uint64), ("solo", C.c_uint64),
+                ("fallback", C.c_uint64)]
+
+
 class RansacItem(C.Structure):  # pl_ransac_item
     _fields_ = [("problem", C.c_void_p), ("opt", C.POINTER(RobustOptions)), ("model", C.c_void_p), ("inliers", C.c_void_p),
                 ("stats", C.POINTER(RansacStats)), ("status", i32), ("reserved", i32)]
@@ -136,6 +141,8 @@ def _declare(L):
         "pl_estimate_fundamental": (cint, [vp, vp, sz, opt, vp, vp, stats]),
         "pl_estimate_homography": (cint, [vp, vp, sz, opt, vp, vp, stats]),
         "pl_estimate_batch": (cint, [P(BatchItem), sz, cint]),
+        "pl_estimate_batch_devices": (cint, [P(BatchItem), sz, P(C.c_int), cint, cint]),
+        "pl_last_batch_report": (None, [P(BatchReport)]),
         "pl_ransac_batch": (cint, [P(RansacItem), sz, cint, cint]),
         "pl_undistort_points": (cint, [cam, vp, sz, vp]),
         "pl_ransac_pnp": (cint, [vp, vp, sz, opt, pose, vp, stats]),
@@ -189,7 +196,7 @@ EXPORTED_SYMBOLS = [
     "pl_set_device", "pl_last_error", "pl_version", "pl_estimate_absolute_pose", "pl_estimate_relative_pose",
     "pl_estimate_fundamental", "pl_estimate_homography", "pl_ransac_pnp", "pl_ransac_relpose", "pl_ransac_fundamental",
     "pl_ransac_homography", "pl_problem_create", "pl_problem_destroy", "pl_ransac_run", "pl_ransac_run_sharded", "pl_score_model", "pl_debug_score_stream", "pl_refine_model", "pl_bundle_adjust_camera", "pl_p3p", "pl_relpose_5pt",
-    "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_undistort_points",
+    "pl_essential_matrix_5pt", "pl_relpose_7pt", "pl_homography_4pt", "pl_solve_batch", "pl_estimate_batch", "pl_estimate_batch_devices", "pl_last_batch_report", "pl_undistort_points",
     "pl_ransac_batch", "pl_debug_device_math", "pl_ransac_pnpf", "pl_ransac_shared_focal_relpose", "pl_refine_shared_focal_relpose",
     "pl_estimate_shared_focal_relative_pose", "pl_solve_focal_batch", "pl_p35pf", "pl_relpose_6pt_shared_focal", "pl_set_lm_mode",
     "pl_abi_version",

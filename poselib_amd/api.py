@@ -261,18 +261,23 @@ class Batch:
         for it, pr in zip(self.items, problems):
             kind = kinds[pr[0]]
             it.kind = kind
+            # a warm start: the options dict may carry "initial_model" (a CameraPose for "abs" / "rel", a 3 x 3 matrix for "fund" /
+            # "hom") - the initial_pose / initial_F / initial_H argument of the single-problem functions; it sets score_initial_model
+            opt = dict(pr[-1] or {})
+            init = opt.pop("initial_model", None)
+            pr = tuple(pr[:-1]) + (opt,)
             if kind == KIND_ABS:
                 _, a, b, cam, opt = pr
                 a, b = _pts(a, 2), _pts(b, 3)
                 cam = _as_camera(cam)
                 c1, c2 = cam._c(), None
-                model = _cpose(CameraPose())
+                model = _cpose(init if init is not None else CameraPose())
             elif kind == KIND_REL:
                 _, a, b, cam1, cam2, opt = pr
                 a, b = _pts(a, 2), _pts(b, 2)
                 cam = None
                 c1, c2 = _as_camera(cam1)._c(), _as_camera(cam2)._c()
-                model = _cpose(CameraPose())
+                model = _cpose(init if init is not None else CameraPose())
             elif kind == KIND_SHARED_FOCAL:
                 _, a, b, pp, opt = pr
                 a, b = _pts(a, 2), _pts(b, 2)
@@ -283,8 +288,8 @@ class Batch:
                 _, a, b, opt = pr
                 a, b = _pts(a, 2), _pts(b, 2)
                 cam, c1, c2 = None, None, None
-                model = np.ascontiguousarray(np.eye(3).reshape(9))
-            o = _robust_options(opt, KIND_REL if kind == KIND_SHARED_FOCAL else kind, False)
+                model = np.ascontiguousarray((np.eye(3) if init is None else np.asarray(init, dtype=np.float64)).T.reshape(9))
+            o = _robust_options(opt, KIND_REL if kind == KIND_SHARED_FOCAL else kind, init is not None and kind != KIND_SHARED_FOCAL)
             n = a.shape[0]
             inl = np.zeros(max(n, 1), dtype=np.uint8)
             st = L.RansacStats()
@@ -297,8 +302,16 @@ class Batch:
             it.stats = C.pointer(st)
             self.keep.append((kind, a, b, o, cam, c1, c2, model, inl, st, n))
 
-    def run(self, max_in_flight=8):
-        L.check(L.lib().pl_estimate_batch(self.items, C.c_size_t(len(self.keep)), C.c_int(int(max_in_flight))))
+    def run(self, max_in_flight=8, devices=None):
+        """devices: None = the calling thread's device (pl_estimate_batch); a list of device indices, or "all", = the items
+        round-robined over those devices from this one process (pl_estimate_batch_devices)"""
+        if devices is None:
+            L.check(L.lib().pl_estimate_batch(self.items, C.c_size_t(len(self.keep)), C.c_int(int(max_in_flight))))
+            return
+        lst = [] if isinstance(devices, str) else [int(d) for d in devices]
+        arr = (C.c_int * max(len(lst), 1))(*lst)
+        L.check(L.lib().pl_estimate_batch_devices(self.items, C.c_size_t(len(self.keep)), arr if lst else None, C.c_int(len(lst)),
+                                                  C.c_int(int(max_in_flight))))
 
     def stats(self):
         """(iterations, num_inliers, hypotheses) arrays without building the per-problem Python objects"""
@@ -323,7 +336,15 @@ class Batch:
         return out
 
 
-def estimate_batch(problems, max_in_flight=8):
+def last_batch_report():
+    """What this thread's last batch call did with its items (include/poselib_amd.h pl_batch_report): items in lock-step groups run
+    at the advertised rate, `solo` and `fallback` items one at a time."""
+    r = L.BatchReport()
+    L.lib().pl_last_batch_report(C.byref(r))
+    return {k: int(getattr(r, k)) for k in ("items", "grouped", "focal_grouped", "solo", "fallback")}
+
+
+def estimate_batch(problems, max_in_flight=8, devices=None):
     """Many independent problems in one call (include/poselib_amd.h pl_estimate_batch; BASELINE config 4).
 
     problems: list of tuples, the arguments of the single-problem functions prefixed by the kind:
@@ -333,9 +354,10 @@ def estimate_batch(problems, max_in_flight=8):
         ("shared_focal", points2D_1, points2D_2, pp, opt)   -> (ImagePair, info)
     Returns the list of results in the same order.  Problems of the same kind advance in groups through ONE launch
     sequence (the problem index is a grid dimension of every kernel); `max_in_flight` host threads inside the library
-    work on groups concurrently, each with its own HIP stream."""
+    work on groups concurrently, each with its own HIP stream.  devices: a list of device indices (or "all") spreads the problems
+    over several GPUs from this one process (problem i on devices[i mod len]); None: the calling thread's device."""
     b = Batch(problems)
-    b.run(max_in_flight)
+    b.run(max_in_flight, devices)
     return b.results()
 
 

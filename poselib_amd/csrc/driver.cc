@@ -2825,6 +2825,7 @@ struct BatchPool {
     std::vector<std::function<void()>> *stages = nullptr; // optional, per job: its host-side staging, run ahead by the worker that claims it
     std::atomic<size_t> next{0};
     int device = 0;
+    WorkerError err; // the first error of a worker of the current batch
     uint64_t generation = 0;
     int wanted = 0;   // workers that should take part in the current batch
     int joined = 0;   // workers that have picked the current batch up
@@ -2832,6 +2833,7 @@ struct BatchPool {
 
     void worker() {
         uint64_t seen = 0;
+        g_err_slot = &err;
         for (;;) {
             std::vector<std::function<void()>> *mine;
             {
@@ -2876,6 +2878,7 @@ struct BatchPool {
         while ((int)threads.size() < in_flight) {
             threads.emplace_back([this] { worker(); });
             threads.back().detach();
+            g_pool_threads[dev & (kMaxDevices - 1)].fetch_add(1); // (a pool serves one device: lease_batch_pool)
         }
         jobs = &js, device = dev;
         stages = (stage_fns && stage_fns->size() == js.size()) ? stage_fns : nullptr;
@@ -2895,14 +2898,25 @@ struct BatchPool {
 // 11 ms against 51 ms for 4096: 57 % of the large call's rate), and a caller that has several such batches - the ranks of a node working
 // through a stream of 512-problem shards - can now keep two or three calls in flight from as many host threads: their chains interleave on
 // the device.  Every pool has its own persistent workers (thread-local contexts and arenas); a caller takes the first free pool and waits
-// for pool 0 when all are busy.
+// for pool 0 when all are busy.  Round 6: the pools belong to a DEVICE (a worker's context, stream and arenas live on one device for
+// good), four per device, so that one call can drive several devices (pl_estimate_batch_devices) and calls on different devices never
+// share workers.
 constexpr int kBatchPools = 4;
 struct PoolLease {
     BatchPool *pool;
     std::unique_lock<std::mutex> held;
 };
-static PoolLease lease_batch_pool() {
-    static BatchPool *pools = new BatchPool[kBatchPools]; // never destroyed: the detached workers may outlive static destructors
+static PoolLease lease_batch_pool(int device) {
+    static std::mutex table_mu;
+    static BatchPool *table[kMaxDevices] = {}; // never destroyed: the detached workers may outlive static destructors
+    BatchPool *pools;
+    {
+        std::lock_guard<std::mutex> lk(table_mu);
+        BatchPool *&slot = table[device & (kMaxDevices - 1)];
+        if (!slot)
+            slot = new BatchPool[kBatchPools];
+        pools = slot;
+    }
     for (int i = 0; i < kBatchPools; ++i) {
         std::unique_lock<std::mutex> lk(pools[i].run_mu, std::try_to_lock);
         if (lk.owns_lock())
@@ -2966,6 +2980,7 @@ void run_group_job(std::vector<GroupItem *> &items, bool resume) {
             g->run = nullptr;
             g->item->status = run_item(*g->item);
             ++g_n_fallback;
+            note_fallback_item();
             if (g->item->status != PL_OK)
                 note_worker_error();
         }
@@ -2987,22 +3002,20 @@ void run_focal_group_job(std::vector<FocalGroupItem *> &items) {
         note_worker_error(); // (the items are retried one by one below; the reason is kept for the caller)
     for (FocalGroupItem *g : items)
         if (rc != PL_OK || g->fallback) {
-            if (g->est == 0) // (the camera is in / out: the group may have written the loop's focal length already)
+            if (g->est == 0 && g->cam_saved) // (the camera is in / out: the group may have written the loop's focal length already)
                 for (int i = 0; i < g->item->camera1->num_params && i < 12; ++i)
                     g->item->camera1->params[i] = g->cam.p[i];
             g->item->status = run_item(*g->item);
             ++g_n_fallback;
+            note_fallback_item();
             if (g->item->status != PL_OK)
                 note_worker_error();
         }
 }
 } // namespace
 
-int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int group_size) {
-    if (count == 0)
-        return PL_OK;
-    if (!items)
-        return fail(PL_ERR_INVALID, "items pointer is null");
+// pl_ransac_batch on the calling thread's device (every item's problem lives there, or runs on its own)
+static int ransac_batch_here(pl_ransac_item *items, size_t count, int max_in_flight, int group_size) {
     Context *c;
     int rc = get_context(&c);
     if (rc != PL_OK)
@@ -3052,31 +3065,109 @@ int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int 
             if (r != PL_OK)
                 note_worker_error();
             for (GroupItem &g : grp)
-                if (r != PL_OK || g.fallback)
+                if (r != PL_OK || g.fallback) {
+                    note_fallback_item();
                     run_solo(*g.ritem);
+                }
         });
     for (size_t i : solo)
         jobs.emplace_back([items, i, run_solo] { run_solo(items[i]); });
     int w = max_in_flight <= 0 ? 4 : std::min(max_in_flight, 64);
     w = (int)std::min<size_t>((size_t)w, jobs.size());
-    (void)take_worker_error();
-    g_group_workers.store(std::max(w, 1));
+    std::string werr;
     {
-        PoolLease lease = lease_batch_pool();
-        lease.pool->run(jobs, w, g_requested_device);
+        PoolLease lease = lease_batch_pool(c->device);
+        (void)lease.pool->err.take();
+        lease.pool->err.fallbacks.store(0);
+        lease.pool->run(jobs, w, c->device);
+        werr = lease.pool->err.take();
+        g_last_report = pl_batch_report{count, count - solo.size(), 0, solo.size(), lease.pool->err.fallbacks.load()};
     }
-    const std::string werr = take_worker_error();
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
             return fail(items[i].status, ("pl_ransac_batch: item " + std::to_string(i) + " failed" + (werr.empty() ? "" : ": " + werr)).c_str());
     return PL_OK;
 }
 
-int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
+// One host thread per device of a multi-device call: runs `body` with that device selected, keeps the thread's error text.
+namespace {
+struct DevicePart {
+    int device = 0;
+    std::vector<size_t> index; // positions of this device's items in the caller's array
+    int rc = PL_OK;
+    std::string err;
+    pl_batch_report report = {0, 0, 0, 0, 0};
+};
+int run_device_parts(std::vector<DevicePart> &parts, const std::function<int(DevicePart &)> &body) {
+    std::vector<std::thread> threads;
+    for (DevicePart &p : parts)
+        if (!p.index.empty())
+            threads.emplace_back([&p, &body] {
+                g_requested_device = p.device;
+                p.rc = body(p);
+                p.report = g_last_report;
+                if (p.rc != PL_OK)
+                    p.err = g_err;
+            });
+    for (std::thread &t : threads)
+        t.join();
+    g_last_report = pl_batch_report{0, 0, 0, 0, 0};
+    for (const DevicePart &p : parts) {
+        g_last_report.items += p.report.items, g_last_report.grouped += p.report.grouped, g_last_report.focal_grouped += p.report.focal_grouped;
+        g_last_report.solo += p.report.solo, g_last_report.fallback += p.report.fallback;
+    }
+    for (DevicePart &p : parts)
+        if (p.rc != PL_OK)
+            return fail(p.rc, ("device " + std::to_string(p.device) + ": " + p.err).c_str());
+    return PL_OK;
+}
+} // namespace
+
+int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int group_size) {
     if (count == 0)
         return PL_OK;
     if (!items)
         return fail(PL_ERR_INVALID, "items pointer is null");
+    Context *c;
+    int rc = get_context(&c); // fails loudly without a HIP device
+    if (rc != PL_OK)
+        return rc;
+    // the problems are device-resident: every item runs on the device that holds its problem.  All on the caller's device (the
+    // usual case): this thread's pool; otherwise one host thread and one worker pool per device, side by side, results straight
+    // into the caller's arrays - no collective inside one process (round 6; north_star: problems round-robined over the GPUs)
+    bool elsewhere = false;
+    for (size_t i = 0; i < count && !elsewhere; ++i)
+        elsewhere = items[i].problem && items[i].problem->device != c->device;
+    if (!elsewhere)
+        return ransac_batch_here(items, count, max_in_flight, group_size);
+    std::vector<DevicePart> parts;
+    for (size_t i = 0; i < count; ++i) {
+        const int dev = items[i].problem ? items[i].problem->device : c->device;
+        size_t k = 0;
+        while (k < parts.size() && parts[k].device != dev)
+            ++k;
+        if (k == parts.size()) {
+            parts.emplace_back();
+            parts.back().device = dev;
+        }
+        parts[k].index.push_back(i);
+    }
+    std::vector<std::vector<pl_ransac_item>> local(parts.size());
+    for (size_t k = 0; k < parts.size(); ++k)
+        for (size_t i : parts[k].index)
+            local[k].push_back(items[i]);
+    rc = run_device_parts(parts, [&](DevicePart &p) {
+        const size_t k = (size_t)(&p - parts.data());
+        return ransac_batch_here(local[k].data(), local[k].size(), max_in_flight, group_size);
+    });
+    for (size_t k = 0; k < parts.size(); ++k)
+        for (size_t j = 0; j < parts[k].index.size(); ++j)
+            items[parts[k].index[j]].status = local[k][j].status;
+    return rc;
+}
+
+// pl_estimate_batch on the calling thread's device
+static int estimate_batch_here(pl_batch_item *items, size_t count, int max_in_flight) {
     Context *c;
     int rc = get_context(&c); // fails loudly without a HIP device, and pins the device for the workers
     if (rc != PL_OK)
@@ -3192,6 +3283,10 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
                 FocalGroupItem g;
                 g.item = &items[v[j]];
                 g.est = est;
+                if (est == 0 && g.item->camera1) { // snapshot before any worker touches the item (an error path restores from it)
+                    g.cam = to_cam(g.item->camera1);
+                    g.cam_saved = true;
+                }
                 focal_groups.back().push_back(g);
             }
         }
@@ -3214,13 +3309,13 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
     }
     int w = max_in_flight <= 0 ? 8 : std::min(max_in_flight, 64);
     w = (int)std::min<size_t>((size_t)w, jobs.size());
-    (void)take_worker_error();
-    g_group_workers.store(std::max(w, 1));
     const double t_pool = now_s();
     if (g_group_timing)
         g_t_wait_ns = g_t_group_ns = g_t_prep_ns = g_t_fallback_ns = g_n_waits = g_n_fallback = 0, g_t_stageA = g_t_args = g_t_imp = g_t_lmtasks = g_t_replay = g_t_tail = 0;
-    PoolLease lease = lease_batch_pool();
-    lease.pool->run(jobs, w, g_requested_device, &stage_fns);
+    PoolLease lease = lease_batch_pool(c->device);
+    (void)lease.pool->err.take();
+    lease.pool->err.fallbacks.store(0);
+    lease.pool->run(jobs, w, c->device, &stage_fns);
     // ---- second round: the problems that were still running when their group's step budget ended (the long runs: 5-point problems
     // with 60 - 70 % outliers need ~10^4 iterations), regrouped by kind, every step as large as the loop is known to need ----
     {
@@ -3243,8 +3338,7 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
                 late_jobs.emplace_back([gp] { run_group_job(*gp, true); });
             }
             const int w2 = (int)std::min<size_t>((size_t)w, late_jobs.size());
-            g_group_workers.store(std::max(w2, 1));
-            lease.pool->run(late_jobs, w2, g_requested_device);
+            lease.pool->run(late_jobs, w2, c->device);
         }
         for (auto &grp : groups)
             for (GroupItem &g : grp) {
@@ -3262,11 +3356,65 @@ int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
         std::fprintf(stderr, "poselib_amd:   host phases incl. their waits (ms): stage A %.1f, step arguments %.1f, records -> jobs %.1f, LM tasks %.1f, replay (+ what follows in the step) %.1f, "
                              "stages D + E %.1f\n", g_t_stageA.load() * 1e-6, g_t_args.load() * 1e-6, g_t_imp.load() * 1e-6, g_t_lmtasks.load() * 1e-6,
                      g_t_replay.load() * 1e-6, g_t_tail.load() * 1e-6);
-    const std::string werr = take_worker_error();
+    const std::string werr = lease.pool->err.take();
+    g_last_report = pl_batch_report{count, eligible, by_focal[0].size() + by_focal[1].size(), solo.size(), lease.pool->err.fallbacks.load()};
     for (size_t i = 0; i < count; ++i)
         if (items[i].status != PL_OK)
             return fail(items[i].status, ("pl_estimate_batch: item " + std::to_string(i) + " failed" + (werr.empty() ? "" : ": " + werr)).c_str());
     return PL_OK;
+}
+
+void pl_last_batch_report(pl_batch_report *out) {
+    if (out)
+        *out = g_last_report;
+}
+
+int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
+    if (count == 0)
+        return PL_OK;
+    if (!items)
+        return fail(PL_ERR_INVALID, "items pointer is null");
+    return estimate_batch_here(items, count, max_in_flight);
+}
+
+int pl_estimate_batch_devices(pl_batch_item *items, size_t count, const int *devices, int num_devices, int max_in_flight) {
+    if (count == 0)
+        return PL_OK;
+    if (!items)
+        return fail(PL_ERR_INVALID, "items pointer is null");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(PL_ERR_NO_DEVICE, "no HIP device available (poselib_amd has no CPU fallback)", e);
+    std::vector<int> all;
+    if (!devices || num_devices <= 0) { // every visible device
+        for (int d = 0; d < ndev; ++d)
+            all.push_back(d);
+        devices = all.data();
+        num_devices = ndev;
+    }
+    for (int k = 0; k < num_devices; ++k)
+        if (devices[k] < 0 || devices[k] >= ndev)
+            return fail(PL_ERR_INVALID, "pl_estimate_batch_devices: device index out of range");
+    // item i on entry i mod num_devices of the list (an entry may repeat a device: its share of the items is a call of its own on
+    // that device, with a worker pool of its own); one host thread per entry, results straight into the caller's arrays
+    std::vector<DevicePart> parts((size_t)num_devices);
+    std::vector<std::vector<pl_batch_item>> local((size_t)num_devices);
+    for (int k = 0; k < num_devices; ++k)
+        parts[(size_t)k].device = devices[k];
+    for (size_t i = 0; i < count; ++i) {
+        const size_t k = i % (size_t)num_devices;
+        parts[k].index.push_back(i);
+        local[k].push_back(items[i]);
+    }
+    const int rc = run_device_parts(parts, [&](DevicePart &p) {
+        const size_t k = (size_t)(&p - parts.data());
+        return estimate_batch_here(local[k].data(), local[k].size(), max_in_flight);
+    });
+    for (size_t k = 0; k < parts.size(); ++k)
+        for (size_t j = 0; j < parts[k].index.size(); ++j)
+            items[parts[k].index[j]].status = local[k][j].status;
+    return rc;
 }
 
 } // extern "C"

@@ -48,7 +48,7 @@ def test_check_program_builds():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_path, kind):
     """A program written against the REFERENCE'S C++ API (std::vector<Eigen::Vector2d>, Image, Camera, CameraPose,
     *Options; robust.h:45-46, 68-70, 112-113, 133-134) and linked with integration/robust_amd.cc runs on the GPU and
@@ -60,7 +60,7 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
     assert os.path.exists(CHECK_BIN), "integration/_build/robust_amd_check was not built (python __graft_entry__.py)"
     seed = 3 + kind
     min_fov = 0.0
-    if kind in (0, 5, 6):
+    if kind in (0, 5, 6, 7):  # (7: the binding's multi-device batch call over the device list {0, 0}; its first problem is compared)
         d = synth.absolute_pose_scene(1500, 0.4, 4100)
         a, b, cam = d["p2d"], d["p3d"], d["camera"]
         if kind == 6:  # ransac_pnpf: points relative to the principal point; a field-of-view bound ABOVE the camera's 53 degrees
@@ -73,7 +73,7 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
         d = gen(1500, 0.4, 4100 + kind)
         a, b = d["x1"], d["x2"]
         cam = d.get("camera1", {"model": "SIMPLE_PINHOLE", "params": [1000.0, 500.0, 500.0]})
-    max_error = 12.0 if kind in (0, 5, 6) else 1.0
+    max_error = 12.0 if kind in (0, 5, 6, 7) else 1.0
     opt = {"max_error": max_error, "ransac": {"seed": seed}}
     if kind == 6:
         opt["min_fov"] = min_fov
@@ -83,7 +83,7 @@ def test_reference_side_binding_executes_and_equals_the_ctypes_path(gpu, tmp_pat
         _, info_default = gpu.ransac_pnpf(a, b, {"max_error": max_error, "ransac": {"seed": seed}})
         assert info_default["num_inliers"] > 500  # the default bound (5 degrees) lets the true focal length through ...
         assert info["num_inliers"] < info_default["num_inliers"]  # ... 90 degrees cuts it off: the option reaches the estimator
-    elif kind in (0, 5):
+    elif kind in (0, 5, 7):
         if kind == 5:
             opt["estimate_focal_length"] = True
         img, info = gpu.estimate_absolute_pose(a, b, cam, opt)
