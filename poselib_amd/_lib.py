@@ -86,7 +86,7 @@ class PoseLibAmdError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hip", ".cc", "Makefile"))]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hip", ".cc", ".inc", "Makefile"))]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "poselib_amd.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:

@@ -2811,610 +2811,6 @@ int pl_homography_4pt(const double *x1, const double *x2, double *H) {
     return (int)n;
 }
 
-// ---------------------------------------------------------------------------- batched front-end
-// A persistent pool of host threads (each owns a Context: HIP stream + scratch arena, created on first use and kept
-// for later batches) pulls items from a shared counter.  The threads are detached and live until the process ends.
-namespace {
-struct BatchPool {
-    std::mutex run_mu; // held for the whole of run(): one batch at a time per process (concurrent callers queue up)
-    std::mutex mu;
-    std::condition_variable wake, done;
-    std::vector<std::thread> threads;
-    // current batch: a list of jobs (a group of problems, or one problem on its own)
-    std::vector<std::function<void()>> *jobs = nullptr;
-    std::vector<std::function<void()>> *stages = nullptr; // optional, per job: its host-side staging, run ahead by the worker that claims it
-    std::atomic<size_t> next{0};
-    int device = 0;
-    WorkerError err; // the first error of a worker of the current batch
-    uint64_t generation = 0;
-    int wanted = 0;   // workers that should take part in the current batch
-    int joined = 0;   // workers that have picked the current batch up
-    int running = 0;  // workers still inside the current batch
-
-    void worker() {
-        uint64_t seen = 0;
-        g_err_slot = &err;
-        for (;;) {
-            std::vector<std::function<void()>> *mine;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                wake.wait(lk, [&] { return generation != seen && joined < wanted; });
-                seen = generation;
-                joined++;
-                running++;
-                mine = jobs;
-            }
-            g_requested_device = device;
-            std::vector<std::function<void()>> *mine_stages = stages;
-            size_t claimed = (size_t)-1; // a job this worker claimed (and staged) while waiting for the device with the previous one
-            for (;;) {
-                const size_t i = claimed != (size_t)-1 ? claimed : next.fetch_add(1);
-                claimed = (size_t)-1;
-                if (i >= mine->size())
-                    break;
-                if (mine_stages) // at this job's first wait: claim the next one and do its staging
-                    g_wait_hook = [this, mine, mine_stages, &claimed] {
-                        const size_t i2 = next.fetch_add(1);
-                        if (i2 < mine->size()) {
-                            claimed = i2;
-                            if ((*mine_stages)[i2])
-                                (*mine_stages)[i2]();
-                        }
-                    };
-                (*mine)[i]();
-                g_wait_hook = nullptr;
-            }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (--running == 0 && joined == wanted)
-                    done.notify_all();
-            }
-        }
-    }
-    // (the caller holds run_mu through a PoolLease: `mu` alone is not enough - done.wait() releases it, and a second caller would
-    // overwrite the job state while the first batch's workers are still running)
-    int run(std::vector<std::function<void()>> &js, int in_flight, int dev, std::vector<std::function<void()>> *stage_fns = nullptr) {
-        std::unique_lock<std::mutex> lk(mu);
-        while ((int)threads.size() < in_flight) {
-            threads.emplace_back([this] { worker(); });
-            threads.back().detach();
-            g_pool_threads[dev & (kMaxDevices - 1)].fetch_add(1); // (a pool serves one device: lease_batch_pool)
-        }
-        jobs = &js, device = dev;
-        stages = (stage_fns && stage_fns->size() == js.size()) ? stage_fns : nullptr;
-        next.store(0);
-        wanted = in_flight, joined = 0, running = 0;
-        generation++;
-        wake.notify_all();
-        done.wait(lk, [&] { return joined == wanted && running == 0; });
-        jobs = nullptr;
-        stages = nullptr;
-        wanted = 0;
-        return PL_OK;
-    }
-};
-// A batch call leases one of kBatchPools worker pools for its whole duration (both rounds of pl_estimate_batch).  Round 4 had ONE pool and
-// one batch at a time per process; a call of a few hundred problems is a handful of launch chains whose length is latency (512 problems:
-// 11 ms against 51 ms for 4096: 57 % of the large call's rate), and a caller that has several such batches - the ranks of a node working
-// through a stream of 512-problem shards - can now keep two or three calls in flight from as many host threads: their chains interleave on
-// the device.  Every pool has its own persistent workers (thread-local contexts and arenas); a caller takes the first free pool and waits
-// for pool 0 when all are busy.  Round 6: the pools belong to a DEVICE (a worker's context, stream and arenas live on one device for
-// good), four per device, so that one call can drive several devices (pl_estimate_batch_devices) and calls on different devices never
-// share workers.
-constexpr int kBatchPools = 4;
-struct PoolLease {
-    BatchPool *pool;
-    std::unique_lock<std::mutex> held;
-};
-static PoolLease lease_batch_pool(int device) {
-    static std::mutex table_mu;
-    static BatchPool *table[kMaxDevices] = {}; // never destroyed: the detached workers may outlive static destructors
-    BatchPool *pools;
-    {
-        std::lock_guard<std::mutex> lk(table_mu);
-        BatchPool *&slot = table[device & (kMaxDevices - 1)];
-        if (!slot)
-            slot = new BatchPool[kBatchPools];
-        pools = slot;
-    }
-    for (int i = 0; i < kBatchPools; ++i) {
-        std::unique_lock<std::mutex> lk(pools[i].run_mu, std::try_to_lock);
-        if (lk.owns_lock())
-            return PoolLease{&pools[i], std::move(lk)};
-    }
-    return PoolLease{&pools[0], std::unique_lock<std::mutex>(pools[0].run_mu)};
-}
-
-int run_item(pl_batch_item &it) {
-    switch (it.kind) {
-    case EST_ABS:
-        return pl_estimate_absolute_pose(it.a, it.b, it.n, it.opt, it.camera1, static_cast<pl_camera_pose *>(it.model),
-                                         it.inliers, it.stats);
-    case EST_REL:
-        return pl_estimate_relative_pose(it.a, it.b, it.n, it.camera1, it.camera2, it.opt,
-                                         static_cast<pl_camera_pose *>(it.model), it.inliers, it.stats);
-    case EST_FUND:
-        return pl_estimate_fundamental(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
-    case EST_HOM:
-        return pl_estimate_homography(it.a, it.b, it.n, it.opt, static_cast<double *>(it.model), it.inliers, it.stats);
-    case 4: { // two views sharing one unknown focal length: camera1 = SIMPLE_PINHOLE {focal, cx, cy}, in (principal point; focal
-              // length with ransac.score_initial_model) and out (both cameras of the reference's ImagePair)
-        if (!it.camera1 || it.camera1->model_id != CAM_SIMPLE_PINHOLE || it.camera1->num_params < 3)
-            return fail(PL_ERR_INVALID, "pl_batch_item kind 4 needs camera1 = SIMPLE_PINHOLE {focal, cx, cy}");
-        return pl_estimate_shared_focal_relative_pose(it.a, it.b, it.n, it.camera1->params + 1, it.opt,
-                                                      static_cast<pl_camera_pose *>(it.model), &it.camera1->params[0], it.inliers, it.stats);
-    }
-    default:
-        return fail(PL_ERR_INVALID, "pl_batch_item.kind must be 0..4");
-    }
-}
-
-// one group of same-kind problems through the group launches; whatever it could not finish goes through the
-// single-problem entry points
-// POSELIB_AMD_GROUP_STEPS: batch steps a group of pl_estimate_batch runs before its unfinished problems are regrouped (0: never)
-uint32_t group_step_budget() {
-    const char *e = std::getenv("POSELIB_AMD_GROUP_STEPS");
-    return e ? (uint32_t)std::max<long>(std::atol(e), 0) : 3u; // (0 / 1 / 2 / 3 / 4 steps: 69 / 70 / 72 / 73 / 71 k problems/s on config 4)
-}
-void run_group_job(std::vector<GroupItem *> &items, bool resume) {
-    Context *c;
-    int rc = get_context(&c);
-    const double t0 = now_s();
-    double t1 = t0;
-    if (rc == PL_OK) {
-        if (!resume)
-            for (GroupItem *g : items)
-                if (!g->prepared)
-                    group_prepare_item(*g);
-        t1 = now_s();
-        rc = run_group(c, items.data(), (uint32_t)items.size(), false, resume ? 0u : group_step_budget(), resume);
-    }
-    const double t2 = now_s();
-    if (rc != PL_OK)
-        note_worker_error(); // (the items are retried one by one below; the reason is kept for the caller)
-    for (GroupItem *g : items) {
-        if (rc != PL_OK)
-            g->deferred = false;
-        if (rc != PL_OK || g->fallback) {
-            delete g->run;
-            g->run = nullptr;
-            g->item->status = run_item(*g->item);
-            ++g_n_fallback;
-            note_fallback_item();
-            if (g->item->status != PL_OK)
-                note_worker_error();
-        }
-    }
-    if (g_group_timing) {
-        g_t_prep_ns += (uint64_t)((t1 - t0) * 1e9);
-        g_t_group_ns += (uint64_t)((t2 - t1) * 1e9);
-        g_t_fallback_ns += (uint64_t)((now_s() - t2) * 1e9);
-    }
-}
-// one group of focal-length problems (driver_focal_group.inc); whatever it could not finish goes through the single-problem entry points
-void run_focal_group_job(std::vector<FocalGroupItem *> &items) {
-    Context *c;
-    int rc = get_context(&c);
-    if (rc == PL_OK)
-        rc = items[0]->est == 0 ? run_focal_group<PnpfGroupPolicy>(c, items.data(), (uint32_t)items.size())
-                                : run_focal_group<SFocalGroupPolicy>(c, items.data(), (uint32_t)items.size());
-    if (rc != PL_OK)
-        note_worker_error(); // (the items are retried one by one below; the reason is kept for the caller)
-    for (FocalGroupItem *g : items)
-        if (rc != PL_OK || g->fallback) {
-            if (g->est == 0 && g->cam_saved) // (the camera is in / out: the group may have written the loop's focal length already)
-                for (int i = 0; i < g->item->camera1->num_params && i < 12; ++i)
-                    g->item->camera1->params[i] = g->cam.p[i];
-            g->item->status = run_item(*g->item);
-            ++g_n_fallback;
-            note_fallback_item();
-            if (g->item->status != PL_OK)
-                note_worker_error();
-        }
-}
-} // namespace
-
-// pl_ransac_batch on the calling thread's device (every item's problem lives there, or runs on its own)
-static int ransac_batch_here(pl_ransac_item *items, size_t count, int max_in_flight, int group_size) {
-    Context *c;
-    int rc = get_context(&c);
-    if (rc != PL_OK)
-        return rc;
-    static const bool no_groups = std::getenv("POSELIB_AMD_NO_GROUPS") != nullptr;
-    const size_t gsz = (size_t)(group_size <= 0 ? 16 : std::min<int>(group_size, (int)kGroupMax));
-    auto run_solo = [](pl_ransac_item &it) {
-        it.status = pl_ransac_run(it.problem, it.opt, it.model, it.inliers, it.stats);
-        if (it.status != PL_OK)
-            note_worker_error();
-    };
-    std::vector<size_t> by_kind[4], solo;
-    for (size_t i = 0; i < count; ++i) {
-        items[i].status = PL_OK;
-        if (!no_groups && group_eligible_resident(items[i]) && items[i].problem->device == c->device)
-            by_kind[items[i].problem->kind].push_back(i);
-        else
-            solo.push_back(i);
-    }
-    std::vector<std::vector<GroupItem>> groups;
-    for (int k = 0; k < 4; ++k) {
-        std::vector<size_t> &v = by_kind[k];
-        std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].problem->n > items[b].problem->n; });
-        for (size_t at = 0; at < v.size(); at += gsz) {
-            groups.emplace_back();
-            for (size_t j = at; j < std::min(v.size(), at + gsz); ++j) {
-                GroupItem g;
-                g.ritem = &items[v[j]];
-                g.kind = k;
-                groups.back().push_back(g);
-            }
-        }
-    }
-    std::vector<std::function<void()>> jobs;
-    for (auto &grp : groups)
-        jobs.emplace_back([&grp, run_solo] {
-            Context *cc;
-            int r = get_context(&cc);
-            if (r == PL_OK) {
-                for (GroupItem &g : grp)
-                    group_prepare_resident(g);
-                std::vector<GroupItem *> ptrs;
-                for (GroupItem &g : grp)
-                    ptrs.push_back(&g);
-                r = run_group(cc, ptrs.data(), (uint32_t)ptrs.size(), true);
-            }
-            if (r != PL_OK)
-                note_worker_error();
-            for (GroupItem &g : grp)
-                if (r != PL_OK || g.fallback) {
-                    note_fallback_item();
-                    run_solo(*g.ritem);
-                }
-        });
-    for (size_t i : solo)
-        jobs.emplace_back([items, i, run_solo] { run_solo(items[i]); });
-    int w = max_in_flight <= 0 ? 4 : std::min(max_in_flight, 64);
-    w = (int)std::min<size_t>((size_t)w, jobs.size());
-    std::string werr;
-    {
-        PoolLease lease = lease_batch_pool(c->device);
-        (void)lease.pool->err.take();
-        lease.pool->err.fallbacks.store(0);
-        lease.pool->run(jobs, w, c->device);
-        werr = lease.pool->err.take();
-        g_last_report = pl_batch_report{count, count - solo.size(), 0, solo.size(), lease.pool->err.fallbacks.load()};
-    }
-    for (size_t i = 0; i < count; ++i)
-        if (items[i].status != PL_OK)
-            return fail(items[i].status, ("pl_ransac_batch: item " + std::to_string(i) + " failed" + (werr.empty() ? "" : ": " + werr)).c_str());
-    return PL_OK;
-}
-
-// One host thread per device of a multi-device call: runs `body` with that device selected, keeps the thread's error text.
-namespace {
-struct DevicePart {
-    int device = 0;
-    std::vector<size_t> index; // positions of this device's items in the caller's array
-    int rc = PL_OK;
-    std::string err;
-    pl_batch_report report = {0, 0, 0, 0, 0};
-};
-int run_device_parts(std::vector<DevicePart> &parts, const std::function<int(DevicePart &)> &body) {
-    std::vector<std::thread> threads;
-    for (DevicePart &p : parts)
-        if (!p.index.empty())
-            threads.emplace_back([&p, &body] {
-                g_requested_device = p.device;
-                p.rc = body(p);
-                p.report = g_last_report;
-                if (p.rc != PL_OK)
-                    p.err = g_err;
-            });
-    for (std::thread &t : threads)
-        t.join();
-    g_last_report = pl_batch_report{0, 0, 0, 0, 0};
-    for (const DevicePart &p : parts) {
-        g_last_report.items += p.report.items, g_last_report.grouped += p.report.grouped, g_last_report.focal_grouped += p.report.focal_grouped;
-        g_last_report.solo += p.report.solo, g_last_report.fallback += p.report.fallback;
-    }
-    for (DevicePart &p : parts)
-        if (p.rc != PL_OK)
-            return fail(p.rc, ("device " + std::to_string(p.device) + ": " + p.err).c_str());
-    return PL_OK;
-}
-} // namespace
-
-int pl_ransac_batch(pl_ransac_item *items, size_t count, int max_in_flight, int group_size) {
-    if (count == 0)
-        return PL_OK;
-    if (!items)
-        return fail(PL_ERR_INVALID, "items pointer is null");
-    Context *c;
-    int rc = get_context(&c); // fails loudly without a HIP device
-    if (rc != PL_OK)
-        return rc;
-    // the problems are device-resident: every item runs on the device that holds its problem.  All on the caller's device (the
-    // usual case): this thread's pool; otherwise one host thread and one worker pool per device, side by side, results straight
-    // into the caller's arrays - no collective inside one process (round 6; north_star: problems round-robined over the GPUs)
-    bool elsewhere = false;
-    for (size_t i = 0; i < count && !elsewhere; ++i)
-        elsewhere = items[i].problem && items[i].problem->device != c->device;
-    if (!elsewhere)
-        return ransac_batch_here(items, count, max_in_flight, group_size);
-    std::vector<DevicePart> parts;
-    for (size_t i = 0; i < count; ++i) {
-        const int dev = items[i].problem ? items[i].problem->device : c->device;
-        size_t k = 0;
-        while (k < parts.size() && parts[k].device != dev)
-            ++k;
-        if (k == parts.size()) {
-            parts.emplace_back();
-            parts.back().device = dev;
-        }
-        parts[k].index.push_back(i);
-    }
-    std::vector<std::vector<pl_ransac_item>> local(parts.size());
-    for (size_t k = 0; k < parts.size(); ++k)
-        for (size_t i : parts[k].index)
-            local[k].push_back(items[i]);
-    rc = run_device_parts(parts, [&](DevicePart &p) {
-        const size_t k = (size_t)(&p - parts.data());
-        return ransac_batch_here(local[k].data(), local[k].size(), max_in_flight, group_size);
-    });
-    for (size_t k = 0; k < parts.size(); ++k)
-        for (size_t j = 0; j < parts[k].index.size(); ++j)
-            items[parts[k].index[j]].status = local[k][j].status;
-    return rc;
-}
-
-// pl_estimate_batch on the calling thread's device
-static int estimate_batch_here(pl_batch_item *items, size_t count, int max_in_flight) {
-    Context *c;
-    int rc = get_context(&c); // fails loudly without a HIP device, and pins the device for the workers
-    if (rc != PL_OK)
-        return rc;
-    static const bool no_groups = std::getenv("POSELIB_AMD_NO_GROUPS") != nullptr; // diagnostic: every item on its own
-    // problems the group launches cover, by kind and in descending size (neighbours in a group then have similar
-    // grids); everything else is a job of its own
-    std::vector<size_t> by_kind[4], by_focal[2], solo;
-    std::vector<std::function<void()>> jobs;
-    for (size_t i = 0; i < count; ++i) {
-        items[i].status = PL_OK;
-        int est;
-        if (!no_groups && group_eligible(items[i]))
-            by_kind[items[i].kind].push_back(i);
-        else if (!no_groups && (est = focal_group_estimator(items[i])) >= 0)
-            by_focal[est].push_back(i); // the two focal-length estimators: their own lock-step groups (driver_focal_group.inc)
-        else
-            solo.push_back(i);
-    }
-    // Problems per launch sequence.  Every group is one job of the worker pool: two rounds of jobs per worker keep the
-    // device fed while groups finish at different times, larger groups amortise the per-launch host work.  Measured on
-    // MI355X, config 4, 8 workers: 2048 problems per call - groups of 128: 49.2 k, 192: 46.7 k, 256: 42.3 k problems/s;
-    // 4096 per call - 128: 49.4 k, 256: 54.8 k, 384: 51.0 k, 512: 48.4 k.  (A problem's result does not depend on its group.)
-    const long group_env = [] { // POSELIB_AMD_BATCH_GROUP: fixed size (experiments; read per call so that one process can sweep it)
-        const char *e = std::getenv("POSELIB_AMD_BATCH_GROUP");
-        return e ? std::min<long>(std::max<long>(std::atol(e), 1), 1024) : 0L;
-    }();
-    size_t eligible = 0;
-    for (int k = 0; k < 4; ++k)
-        eligible += by_kind[k].size();
-    const size_t workers = (size_t)(max_in_flight <= 0 ? 8 : std::min(max_in_flight, 64));
-    const size_t group_max = group_env ? (size_t)group_env
-                                       : std::min<size_t>(kGroupMaxAuto, std::max<size_t>(kGroupMax / 2, (eligible + 2 * workers - 1) / (2 * workers)));
-    std::vector<std::vector<GroupItem>> groups;
-    // A first round of SMALL groups, one per worker, taken from the small end of every kind's list: a group starts with the copy of its
-    // raw correspondences into pinned memory (0.1 MB per problem) during which the device has nothing to do - 2.5 ms for a group of
-    // 230 problems at the start of every call.  From its second group on a worker copies the NEXT group's points while it waits
-    // for the device (group_stage_in); the first round makes that start after ~0.6 ms instead.
-    const size_t first_sz = 64;
-    size_t n_first_groups = 0;
-    auto emit = [&](int k, const std::vector<size_t> &v, size_t lo, size_t hi) {
-        groups.emplace_back();
-        for (size_t j = lo; j < hi; ++j) {
-            GroupItem g;
-            g.item = &items[v[j]];
-            g.kind = k;
-            groups.back().push_back(g);
-        }
-    };
-    std::vector<size_t> rest_lo(4, 0), rest_hi(4, 0);
-    const bool first_round = !group_env && eligible >= 4 * workers * first_sz;
-    for (int k = 0; k < 4; ++k) {
-        std::vector<size_t> &v = by_kind[k];
-        std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].n > items[b].n; });
-        size_t hi = v.size();
-        if (first_round && eligible) {
-            const size_t want = (workers * v.size() + eligible / 2) / eligible; // this kind's share of the first round
-            for (size_t f = 0; f < want && hi >= 2 * first_sz; ++f) {
-                emit(k, v, hi - first_sz, hi);
-                hi -= first_sz;
-                ++n_first_groups;
-            }
-        }
-        rest_hi[k] = hi;
-    }
-    for (int k = 0; k < 4; ++k) {
-        std::vector<size_t> &v = by_kind[k];
-        const size_t cnt = rest_hi[k];
-        // equal shares: ceil(n / group_max) groups of (almost) the same size instead of full groups and a small last one
-        const size_t ngrp = (cnt + group_max - 1) / group_max;
-        const size_t gsize = ngrp ? (cnt + ngrp - 1) / ngrp : 1;
-        for (size_t at = 0; at < cnt; at += gsize)
-            emit(k, v, at, std::min(cnt, at + gsize));
-    }
-    // the long jobs first: a group's time grows with its correspondences, and a 5-point problem costs about twice a P3P or
-    // homography problem of the same size (generator + Sampson scorer + LO with a pre-filter; profiles/r03_bench_batch_mixed_*)
-    std::vector<size_t> order(groups.size());
-    std::vector<double> cost(groups.size(), 0.0);
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
-        order[gi] = gi;
-        for (const GroupItem &g : groups[gi])
-            cost[gi] += (double)g.item->n * (g.kind == EST_REL ? 2.0 : (g.kind == EST_HOM ? 1.2 : 1.0));
-    }
-    std::stable_sort(order.begin() + (std::ptrdiff_t)n_first_groups, order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
-    std::vector<std::vector<GroupItem *>> group_ptrs(groups.size());
-    for (size_t gi = 0; gi < groups.size(); ++gi)
-        for (GroupItem &g : groups[gi])
-            group_ptrs[gi].push_back(&g);
-    std::vector<std::function<void()>> stage_fns;
-    for (size_t gi : order) {
-        std::vector<GroupItem *> *grp = &group_ptrs[gi];
-        jobs.emplace_back([grp] { run_group_job(*grp, false); });
-        stage_fns.emplace_back([grp] { group_stage_in(grp->data(), (uint32_t)grp->size()); });
-    }
-    // the focal-length estimators: groups of up to kFocalGroupMax / kSFocalGroupMax problems of similar size, at least one group per worker
-    std::vector<std::vector<FocalGroupItem>> focal_groups;
-    for (int est = 0; est < 2; ++est) {
-        std::vector<size_t> &v = by_focal[est];
-        if (v.empty())
-            continue;
-        std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return items[a].n > items[b].n; });
-        const long focal_env = [] { // POSELIB_AMD_FOCAL_GROUP: fixed group size (experiments; read per call so that one process can sweep it)
-            const char *e = std::getenv("POSELIB_AMD_FOCAL_GROUP");
-            return e ? std::min<long>(std::max<long>(std::atol(e), 1), 256) : 0L;
-        }();
-        const size_t cap = focal_env ? (size_t)focal_env : (est == 0 ? kFocalGroupMax : kSFocalGroupMax);
-        const size_t per = focal_env ? cap : std::min(cap, std::max<size_t>(1, (v.size() + workers - 1) / workers));
-        const size_t ngrp = (v.size() + per - 1) / per;
-        const size_t gsize = (v.size() + ngrp - 1) / ngrp;
-        for (size_t at = 0; at < v.size(); at += gsize) {
-            focal_groups.emplace_back();
-            for (size_t j = at; j < std::min(v.size(), at + gsize); ++j) {
-                FocalGroupItem g;
-                g.item = &items[v[j]];
-                g.est = est;
-                if (est == 0 && g.item->camera1) { // snapshot before any worker touches the item (an error path restores from it)
-                    g.cam = to_cam(g.item->camera1);
-                    g.cam_saved = true;
-                }
-                focal_groups.back().push_back(g);
-            }
-        }
-    }
-    std::vector<std::vector<FocalGroupItem *>> focal_ptrs(focal_groups.size());
-    for (size_t gi = 0; gi < focal_groups.size(); ++gi) {
-        for (FocalGroupItem &g : focal_groups[gi])
-            focal_ptrs[gi].push_back(&g);
-        std::vector<FocalGroupItem *> *grp = &focal_ptrs[gi];
-        jobs.emplace_back([grp] { run_focal_group_job(*grp); });
-        stage_fns.emplace_back(); // (nothing to stage)
-    }
-    for (size_t i : solo) {
-        jobs.emplace_back([items, i] {
-            items[i].status = run_item(items[i]);
-            if (items[i].status != PL_OK)
-                note_worker_error();
-        });
-        stage_fns.emplace_back(); // (nothing to stage)
-    }
-    int w = max_in_flight <= 0 ? 8 : std::min(max_in_flight, 64);
-    w = (int)std::min<size_t>((size_t)w, jobs.size());
-    const double t_pool = now_s();
-    if (g_group_timing)
-        g_t_wait_ns = g_t_group_ns = g_t_prep_ns = g_t_fallback_ns = g_n_waits = g_n_fallback = 0, g_t_stageA = g_t_args = g_t_imp = g_t_lmtasks = g_t_replay = g_t_tail = 0;
-    PoolLease lease = lease_batch_pool(c->device);
-    (void)lease.pool->err.take();
-    lease.pool->err.fallbacks.store(0);
-    lease.pool->run(jobs, w, c->device, &stage_fns);
-    // ---- second round: the problems that were still running when their group's step budget ended (the long runs: 5-point problems
-    // with 60 - 70 % outliers need ~10^4 iterations), regrouped by kind, every step as large as the loop is known to need ----
-    {
-        std::vector<GroupItem *> late[4];
-        for (auto &grp : groups)
-            for (GroupItem &g : grp)
-                if (g.deferred)
-                    late[g.kind].push_back(&g);
-        std::vector<std::vector<GroupItem *>> late_groups;
-        for (int k = 0; k < 4; ++k) {
-            std::stable_sort(late[k].begin(), late[k].end(), [](const GroupItem *a, const GroupItem *b) { return a->n > b->n; });
-            const size_t per = 64; // (long batches: 32768 iterations x 16 slots of a 5-point problem are 100 MB of records)
-            for (size_t at = 0; at < late[k].size(); at += per)
-                late_groups.emplace_back(late[k].begin() + at, late[k].begin() + std::min(late[k].size(), at + per));
-        }
-        if (!late_groups.empty()) {
-            std::vector<std::function<void()>> late_jobs;
-            for (auto &grp : late_groups) {
-                std::vector<GroupItem *> *gp = &grp;
-                late_jobs.emplace_back([gp] { run_group_job(*gp, true); });
-            }
-            const int w2 = (int)std::min<size_t>((size_t)w, late_jobs.size());
-            lease.pool->run(late_jobs, w2, c->device);
-        }
-        for (auto &grp : groups)
-            for (GroupItem &g : grp) {
-                delete g.run; // (only after an error: every finished problem's run has been released by its group)
-                g.run = nullptr;
-            }
-    }
-    if (g_group_timing)
-        std::fprintf(stderr, "poselib_amd: pl_estimate_batch %zu items, %zu groups + %zu solo, %d workers: wall %.1f ms; workers' time: prepare %.1f, "
-                             "groups %.1f (of which waiting for the device %.1f in %llu waits), fallback items %.1f ms (%llu items)\n",
-                     count, groups.size(), solo.size(), w, (now_s() - t_pool) * 1e3, g_t_prep_ns.load() * 1e-6, g_t_group_ns.load() * 1e-6,
-                     g_t_wait_ns.load() * 1e-6, (unsigned long long)g_n_waits.load(), g_t_fallback_ns.load() * 1e-6,
-                     (unsigned long long)g_n_fallback.load());
-    if (g_group_timing)
-        std::fprintf(stderr, "poselib_amd:   host phases incl. their waits (ms): stage A %.1f, step arguments %.1f, records -> jobs %.1f, LM tasks %.1f, replay (+ what follows in the step) %.1f, "
-                             "stages D + E %.1f\n", g_t_stageA.load() * 1e-6, g_t_args.load() * 1e-6, g_t_imp.load() * 1e-6, g_t_lmtasks.load() * 1e-6,
-                     g_t_replay.load() * 1e-6, g_t_tail.load() * 1e-6);
-    const std::string werr = lease.pool->err.take();
-    g_last_report = pl_batch_report{count, eligible, by_focal[0].size() + by_focal[1].size(), solo.size(), lease.pool->err.fallbacks.load()};
-    for (size_t i = 0; i < count; ++i)
-        if (items[i].status != PL_OK)
-            return fail(items[i].status, ("pl_estimate_batch: item " + std::to_string(i) + " failed" + (werr.empty() ? "" : ": " + werr)).c_str());
-    return PL_OK;
-}
-
-void pl_last_batch_report(pl_batch_report *out) {
-    if (out)
-        *out = g_last_report;
-}
-
-int pl_estimate_batch(pl_batch_item *items, size_t count, int max_in_flight) {
-    if (count == 0)
-        return PL_OK;
-    if (!items)
-        return fail(PL_ERR_INVALID, "items pointer is null");
-    return estimate_batch_here(items, count, max_in_flight);
-}
-
-int pl_estimate_batch_devices(pl_batch_item *items, size_t count, const int *devices, int num_devices, int max_in_flight) {
-    if (count == 0)
-        return PL_OK;
-    if (!items)
-        return fail(PL_ERR_INVALID, "items pointer is null");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0)
-        return fail(PL_ERR_NO_DEVICE, "no HIP device available (poselib_amd has no CPU fallback)", e);
-    std::vector<int> all;
-    if (!devices || num_devices <= 0) { // every visible device
-        for (int d = 0; d < ndev; ++d)
-            all.push_back(d);
-        devices = all.data();
-        num_devices = ndev;
-    }
-    for (int k = 0; k < num_devices; ++k)
-        if (devices[k] < 0 || devices[k] >= ndev)
-            return fail(PL_ERR_INVALID, "pl_estimate_batch_devices: device index out of range");
-    // item i on entry i mod num_devices of the list (an entry may repeat a device: its share of the items is a call of its own on
-    // that device, with a worker pool of its own); one host thread per entry, results straight into the caller's arrays
-    std::vector<DevicePart> parts((size_t)num_devices);
-    std::vector<std::vector<pl_batch_item>> local((size_t)num_devices);
-    for (int k = 0; k < num_devices; ++k)
-        parts[(size_t)k].device = devices[k];
-    for (size_t i = 0; i < count; ++i) {
-        const size_t k = i % (size_t)num_devices;
-        parts[k].index.push_back(i);
-        local[k].push_back(items[i]);
-    }
-    const int rc = run_device_parts(parts, [&](DevicePart &p) {
-        const size_t k = (size_t)(&p - parts.data());
-        return estimate_batch_here(local[k].data(), local[k].size(), max_in_flight);
-    });
-    for (size_t k = 0; k < parts.size(); ++k)
-        for (size_t j = 0; j < parts[k].index.size(); ++j)
-            items[parts[k].index[j]].status = local[k][j].status;
-    return rc;
-}
+#include "driver_batch.inc"
 
 } // extern "C"
