@@ -784,7 +784,7 @@ def run_focal_estimators(args, ranks, P, synth):
     estimate_focal_length (ransac_pnpf, P3.5Pf) and estimate_shared_focal_relative_pose (6-point shared-focal solver) - on
     2000 correspondences, 40 % outliers, one problem after the other (a first device path: no problems in flight, no
     grouping).  Host-resident inputs, PCIe-inclusive.  Parity: every problem of the step against the oracle (decisions, mask,
-    focal length bit for bit); CPU baseline: the oracle on the same problems (its solvers are this project's own formulations)."""
+    focal length bit for bit); CPU baseline: the oracle on the same problems (its solvers restate the reference's templates)."""
     n, reps = 2000, max(4, args.steps)
     da = [synth.absolute_pose_scene(n, 0.4, 7100 + 8 * ranks.rank + k) for k in range(4)]
     dr = [synth.relative_pose_scene(n, 0.4, 7000 + 8 * ranks.rank + k) for k in range(4)]
@@ -903,9 +903,9 @@ def run_focal_estimators(args, ranks, P, synth):
                                    "device_vs_reference_sources"}
             r["cpu_port_problems_per_s"] = reps / t_cpu
             if ranks.world == 1 and not args.no_cpu_baseline:
-                # the reference's own sources (oracle/_ref: ITS solvers are machine-generated elimination templates, the oracle's and
-                # the device's are this project's own formulations): every problem of the step - the CPU baseline and the measured
-                # agreement of the DEVICE with the reference (decisions and mask; DESIGN 5: 589 of 600 random problems for the oracle)
+                # the reference's own sources (oracle/_ref; the oracle's and the device's solvers restate its elimination templates since
+                # round 6): every problem of the step - the CPU baseline and the measured agreement of the DEVICE with the reference
+                # (decisions and mask; DESIGN 5: 600 of 600 random problems in the soak)
                 import ref_lib
 
                 if ref_lib.available():

@@ -325,7 +325,7 @@ int pl_essential_matrix_5pt(const double *x1, const double *x2, double *E /* 10 
 int pl_relpose_7pt(const double *x1 /* 7x3 */, const double *x2 /* 7x3 */, double *F /* 3 x 9 column-major */);
 int pl_homography_4pt(const double *x1 /* 4x3 */, const double *x2 /* 4x3 */, double *H /* 9 column-major */);
 /* the solvers of the two focal-length estimators (interfaces of solvers/p35pf.h:39-54 and solvers/relpose_6pt_focal.h:12-13; the
- * algorithms are this library's own formulations).  pl_p35pf: x = four image points relative to the principal point
+ * algorithms restate the reference's action-matrix templates since round 6 and return its roots in its order).  pl_p35pf: x = four image points relative to the principal point
  * (4 x 2; of the fourth only x is used), X = 4 x 3; out / focals: room for 10.  pl_relpose_6pt_shared_focal: six pairs of unit
  * bearings (6 x 3 each); out / focals: room for 60, in the reference's order.  Return = #solutions or < 0. */
 int pl_p35pf(const double *x, const double *X, pl_camera_pose *out, double *focals);

@@ -7,7 +7,7 @@
 //   * the Sampson residual of compute_sampson_msac_score / get_inliers (utils.cc:204-239, :401-419 - pl_score.h sampson_sq),
 //   * the refiner's residual, Jacobian row and step,
 //   * the traits that run pl_focal.h's loop template for this estimator.
-// The minimal solver is pl_solver_6ptf.h (this project's own formulation).  The refiner's residual / Jacobian and the two forms of
+// The minimal solver is pl_solver_6ptf.h (the reference's template solver restated).  The refiner's residual / Jacobian and the two forms of
 // F follow the operation order of the reference's SharedFocalRelativePoseRefiner and estimator (PoseLib, BSD-3-Clause) on purpose:
 // bit parity of the refined model with the reference's sources is the requirement, and it fixes the order of every operation.
 #pragma once

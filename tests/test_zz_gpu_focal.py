@@ -2,7 +2,8 @@
 estimate_focal_length (robust.cc:47-54 -> ransac.cc:58-75 -> FocalAbsolutePoseEstimator) through the C-ABI against the oracle.
 
 The chain of evidence: the oracle's ransac_pnpf takes the decisions of the REFERENCE's estimator on the pinned scenes
-(tests/test_reference_focal_estimator.py; its P3.5Pf is this project's own formulation, same solution set to ~1e-7); the device
+(tests/test_reference_focal_estimator.py; since round 6 its P3.5Pf restates the reference's template: the same solutions bit for
+bit); the device
 functions equal the oracle bit for bit on the host (tests/test_hostmath_vs_oracle.py: solver, loop); here the kernels themselves.
 Up to 256 correspondences k_lm_cam sums the cost in the reference's order and everything is bit for bit; beyond, its cost is
 a tree sum, so a refined model may differ in the last bits: decisions (iterations, refinements, inlier mask) are still demanded

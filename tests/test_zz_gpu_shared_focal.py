@@ -3,7 +3,8 @@ pl_estimate_shared_focal_relative_pose (robust.cc:366-424 -> ransac.cc:182-203 -
 pl_refine_shared_focal_relpose (bundle.cc:281-297) through the C-ABI against the oracle.
 
 The chain of evidence: the oracle's estimator takes the decisions of the REFERENCE's on the pinned scenes and its refiner equals
-the reference's bit for bit (tests/test_reference_focal_estimator.py; the 6-point solver is this project's own formulation); the
+the reference's bit for bit (tests/test_reference_focal_estimator.py; since round 6 the 6-point solver restates the reference's
+template: the same solutions bit for bit, up to the rounding of the cubes); the
 device functions equal the oracle bit for bit on the host (tests/test_hostmath_vs_oracle.py: solver, refiner, loop); here the
 kernels themselves.  k_sfocal_score and k_sfocal_lm add every sum correspondence after correspondence, so EVERYTHING is demanded
 bit for bit at every size: decisions, score, inlier mask, pose, focal length.
