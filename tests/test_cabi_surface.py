@@ -70,6 +70,14 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert "no HIP device" in str(e.value)
     with pytest.raises(poselib_amd.PoseLibAmdError):
         poselib_amd.p3p(np.eye(3), np.eye(3))
+    # the batch entry points, the multi-device one included (round 6): the same loud failure, and a report that says nothing ran
+    cam = {"model": "SIMPLE_PINHOLE", "params": [1.0, 0.0, 0.0]}
+    for devices in (None, [0], "all"):
+        with pytest.raises(poselib_amd.PoseLibAmdError) as e:
+            poselib_amd.estimate_batch([("abs", pts2, pts3, cam, {})], devices=devices)
+        assert "no HIP device" in str(e.value)
+    with pytest.raises(poselib_amd.PoseLibAmdError):
+        poselib_amd.p35pf(np.zeros((4, 2)), np.zeros((4, 3)))
 
 
 def test_unsupported_options_are_rejected():
