@@ -178,7 +178,7 @@ typedef struct {
                               * group, every item bit-identical to its single call).  Kinds 0 - 3 with PROSAC, a warm start
                               * (ransac.score_initial_model) or an OPENCV camera are group members like any other since round 6;
                               * what still runs one at a time: min_iterations > 4096, fewer correspondences than sample size + 4,
-                              * more than 16384, PROSAC / warm starts of the focal-length kinds (pl_last_batch_report counts them) */
+                              * more than 16384, warm starts of the focal-length kinds (pl_last_batch_report counts them) */
     int32_t status;          /* out: PL_OK or the error of this item */
     const double *a;         /* points2D (kind 0) / points2D_1: N x 2 */
     const double *b;         /* points3D: N x 3 (kind 0) / points2D_2: N x 2 */

@@ -97,13 +97,15 @@ def test_shared_focal_group_equals_single_calls(gpu):
 
 
 def test_mixed_call_with_items_the_group_path_does_not_take(gpu):
-    """focal items next to the four north-star kinds, a PROSAC item and a degenerate one in the same call: everything equals its single call"""
+    """focal items next to the four north-star kinds, PROSAC items and a degenerate one in the same call: everything equals its single call"""
     problems = []
     for k in range(6):
         problems.append(_pnpf_problem(100 + k, 500 + 100 * k, 0.4))
         problems.append(_sfocal_problem(100 + k, 400 + 100 * k, 0.3))
-    problems.append(_pnpf_problem(200, 600, 0.3, progressive_sampling=True))  # PROSAC: single-problem path
+    problems.append(_pnpf_problem(200, 600, 0.3, progressive_sampling=True))  # PROSAC: a group member since round 6 (samples drawn by the member's loop)
     problems.append(_sfocal_problem(200, 600, 0.3, progressive_sampling=True))
+    problems.append(_pnpf_problem(202, 900, 0.5, progressive_sampling=True, max_prosac_iterations=60))  # ... with the cross-over to uniform sampling
+    problems.append(_sfocal_problem(202, 900, 0.4, progressive_sampling=True, max_prosac_iterations=60))
     problems.append(_pnpf_problem(201, 6, 0.0))  # fewer than sample + 4 correspondences: single-problem path
     d = synth.absolute_pose_scene(800, 0.4, 23000)
     problems.append(("abs", d["p2d"], d["p3d"], d["camera"], {"ransac": {"seed": 5}}))
@@ -111,6 +113,8 @@ def test_mixed_call_with_items_the_group_path_does_not_take(gpu):
     if d is not None:
         problems.append(("hom", d["x1"], d["x2"], {"max_error": 2.0, "ransac": {"seed": 6}}))
     got = gpu.estimate_batch(problems, max_in_flight=4)
+    rep = gpu.last_batch_report()
+    assert rep["focal_grouped"] == 16 and rep["solo"] == 1 and rep["items"] == len(problems), rep  # (solo: the 6-correspondence problem)
     for k, pr in enumerate(problems):
         if pr[0] in ("abs", "shared_focal") and (pr[0] == "shared_focal" or pr[4].get("estimate_focal_length")):
             _check_equal(("mixed", k), pr, got[k], _single(gpu, pr))
