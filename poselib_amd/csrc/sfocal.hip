@@ -121,10 +121,12 @@ __device__ __forceinline__ uint32_t sfocal_emit_poses(const SFocalGenArgs &g, ui
 // k_sfocal_solve: one WAVEFRONT = one sample.  LDS of a wavefront (doubles):
 //   [0, 28) null space | [28, 64) bearings | [64, 344) the coefficients, later the action matrix (225) |
 //   [344, 344 + 31 * 46) the template, row-major (consecutive lanes = consecutive columns), later: the working copy of the action
-//   matrix (225) | Danilevsky's vectors (30) | the polynomial (16) | roots (16) | solutions sx, sy, sw (48) | counts (16)
+//   matrix (225) | Danilevsky's vectors (30) | the polynomial (16) | roots (16) | solutions sx, sy, sw (48) | counts (16) | the Sturm
+//   chain and the bisection's stack (175) | the leaves (60)
 constexpr int kSixS = 46, kLdsNb = 0, kLdsX = 28, kLdsCoef = 64, kLdsC = 344, kSolveLds = kLdsC + 31 * kSixS;
-constexpr int kLdsAmp = 0, kLdsWs = 225, kLdsPoly = 255, kLdsEv = 271, kLdsSol = 287, kLdsCnt = 335; // (offsets inside the template's region)
-static_assert(kSixCoeffs <= kLdsC - kLdsCoef && kLdsCnt + 16 <= 31 * kSixS, "regions");
+constexpr int kLdsAmp = 0, kLdsWs = 225, kLdsPoly = 255, kLdsEv = 271, kLdsSol = 287, kLdsCnt = 335, kLdsSturm = 352,
+              kLdsLeaves = kLdsSturm + kSturmNWork(15), kLdsLevel = kLdsLeaves + 2 * kSturmNLeaves(15); // (offsets inside the template's region)
+static_assert(kSixCoeffs <= kLdsC - kLdsCoef && kLdsLevel + kSturmNWaveWork(15) <= 31 * kSixS, "regions");
 __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32_t blk) {
     __shared__ double s_fin[kSolveWaves][kSolveLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -140,10 +142,23 @@ __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32
         base[kLdsX + lane] = st[(size_t)(kStX + lane) * B];
     PL_WAVE_SYNC();
     // ---- coefficients, template, the last eight rows of C0^-1 C1 (relpose_6pt_focal.cc:54-1043)
+#ifndef PL_SFOCAL_STOP
+#define PL_SFOCAL_STOP 99 // (experiment builds: the kernel returns after phase n - profiles/r06_sfocal_phases.md)
+#endif
+#define PL_SFOCAL_PHASE(n)                                                                                             \
+    if (PL_SFOCAL_STOP <= (n)) {                                                                                       \
+        if (lane == 0)                                                                                                 \
+            g.num_models[it] = 0;                                                                                      \
+        return;                                                                                                        \
+    }
+    PL_SFOCAL_PHASE(0)
     template_coefficients_wave<true, kSixCoeffs>(nb, kSixTermStart, kSixTermPacked, coef, lane);
     PL_WAVE_SYNC();
+    PL_SFOCAL_PHASE(1)
     template_fill_wave<31, kSixCols, kSixS>(coef, kSixColStart, kSixEntryRow, kSixEntryCoeff, C, lane);
+    PL_SFOCAL_PHASE(2)
     lu_solve_tail_wave<31, kSixCols, kSixS, 8>(C, lane);
+    PL_SFOCAL_PHASE(3)
     // ---- the action matrix (:1045-1053): kept in the coefficients' place for the roots, a working copy for the polynomial
     double amv[4];
     {
@@ -164,18 +179,33 @@ __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32
     }
     PL_WAVE_SYNC();
     // ---- characteristic polynomial, its real roots (:1069-1076)
+    PL_SFOCAL_PHASE(4)
     danilevsky_charpoly_wave<15>(amp, C + kLdsWs, poly, lane);
-    int nroots = 0;
-    if (lane == 0) {
-        double p[16], r[15];
-        for (int i = 0; i < 16; ++i)
-            p[i] = poly[i];
-        nroots = sturm_n_roots<15>(p, r, 1e-12);
-        for (int i = 0; i < nroots; ++i)
-            ev[i] = r[i];
-    }
-    nroots = __builtin_amdgcn_readfirstlane(nroots);
+    PL_SFOCAL_PHASE(5)
+    // the real roots: lane 0 builds the Sturm chain (its arrays in LDS: as private arrays they are scratch memory), the bisection
+    // runs level by level with one lane per live interval (sturm_n_isolate_wave), then ONE LANE PER LEAF polishes (Ridders +
+    // Newton) - the roots in leaf order, at most 15, as the serial routine emits them
+    int nleaf = 0;
+    unsigned tiny = 0;
+    double *leaves = C + kLdsLeaves;
+    nleaf = sturm_n_isolate_wave<15>(poly, 1e-12, C + kLdsSturm, leaves, tiny, C + kLdsLevel, lane);
+    nleaf = __builtin_amdgcn_readfirstlane(nleaf);
+    tiny = (unsigned)__builtin_amdgcn_readfirstlane((int)tiny);
     PL_WAVE_SYNC();
+    double root = 0;
+    bool has_root = false;
+    if (lane < nleaf)
+        has_root = sturm_n_leaf_root<15>(C + kLdsSturm, leaves[2 * lane], leaves[2 * lane + 1], (tiny >> lane) & 1u, 1e-12, &root) != 0;
+    const uint64_t rmask = __builtin_amdgcn_ballot_w64(has_root);
+    if (has_root) {
+        const uint32_t rpos = __builtin_amdgcn_mbcnt_hi((uint32_t)(rmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rmask, 0u));
+        if (rpos < 15u)
+            ev[rpos] = root;
+    }
+    int nroots = (int)__popcll(rmask);
+    nroots = nroots < 15 ? nroots : 15;
+    PL_WAVE_SYNC();
+    PL_SFOCAL_PHASE(6)
     // ---- lane s = root s: x and w (:11-52); w < 1e-8 dropped (:1105); the solutions in the order of the roots
     bool keep = false;
     double x = 0, w = 1;
@@ -191,6 +221,7 @@ __device__ __forceinline__ void sfocal_solve_body(const SFocalGenArgs &g, uint32
         sols[pos] = x, sols[kMaxRoots + pos] = y, sols[2 * kMaxRoots + pos] = w;
     }
     PL_WAVE_SYNC();
+    PL_SFOCAL_PHASE(7)
     // ---- lane s = solution s: essential matrix, poses (:1107-1141)
     uint32_t m = 0;
     if (ns > 0) { // (uniform)
