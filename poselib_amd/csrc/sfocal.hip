@@ -6,7 +6,8 @@
 //                      (pl_solver_6ptf.h, step 1) into a workspace in HBM
 //   k_sfocal_solve     one WAVEFRONT = one iteration, the matrices in LDS: the 280 coefficients, the 31 x 46 template, LU with
 //                      partial pivoting with a column per lane, the 15 x 15 action matrix, its characteristic polynomial
-//                      (Danilevsky, a column per lane), the real roots (Sturm bisection of degree 15 by one lane), one lane per
+//                      (Danilevsky, a column per lane), the real roots (Sturm chain by one lane, the bisection level by level with a lane
+//                      per live interval, Ridders / Newton with a lane per leaf: pl_sturm_n.h), one lane per
 //                      root for the 7 x 7 system, then one lane per solution for the poses
 //   k_sfocal_score     one wavefront = one model: compute_sampson_msac_score (utils.cc:204-239) of F = K_inv (E K_inv) - inlier
 //                      count and the score IN CORRESPONDENCE ORDER (r2 of an inlier, the threshold of an outlier, one after the
