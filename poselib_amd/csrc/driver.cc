@@ -223,6 +223,7 @@ const bool g_group_timing = std::getenv("POSELIB_AMD_GROUP_TIMING") != nullptr;
 hipError_t wait_stream_impl(Context *c);
 // host work a worker of pl_estimate_batch does INSTEAD of idling at its next wait (staging the next group's inputs); one shot
 thread_local std::function<void()> g_wait_hook;
+thread_local std::vector<double> g_wait_marks; // (diagnostic) end of every wait of this worker's current job, seconds
 hipError_t wait_stream(Context *c) {
     if (g_wait_hook) {
         std::function<void()> h;
@@ -233,8 +234,11 @@ hipError_t wait_stream(Context *c) {
         return wait_stream_impl(c);
     const double t0 = now_s();
     const hipError_t e = wait_stream_impl(c);
-    g_t_wait_ns += (uint64_t)((now_s() - t0) * 1e9);
+    const double t1 = now_s();
+    g_t_wait_ns += (uint64_t)((t1 - t0) * 1e9);
     ++g_n_waits;
+    g_wait_marks.push_back(t0);
+    g_wait_marks.push_back(t1);
     return e;
 }
 hipError_t wait_stream_impl(Context *c) {

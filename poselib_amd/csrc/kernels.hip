@@ -83,6 +83,35 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
+// The sums of the exact pass when the waiting pairs belong to several hypotheses: the pairs of one hypothesis are ONE run of
+// lanes (the queues are filled hypothesis by hypothesis), lanes past the last pair carry a key no hypothesis has.  Run starts
+// from one ballot (key against the key one lane below: DPP wave_shr:1), a lane's distance to its run's start replaces the
+// key comparison of every scan step, the inlier count of a run is a popcount of the ballot - and the segmented inclusive scan
+// of the values runs over the DPP paths (Hillis-Steele inside the rows of 16, then the row broadcasts), not over 26
+// ds_bpermute round trips as in rounds 1 - 5: a drain is a dependency chain, not work, and this was the longest link of it
+// (profiles/r06_score_phases.md).  The association of the additions differs from the shuffle form's: streaming scores are
+// compared with a 1e-9 margin and every candidate is re-scored in the reference's order (k_finalize2 / k_score_seq).
+__device__ __forceinline__ void add_run_totals(double v, uint64_t inmask, uint32_t g, bool act, int lane, double *acc_s, uint32_t *acc_c) {
+    const uint32_t gprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x138, 0xf, 0xf, false); // wave_shr:1
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(lane == 0 || gprev != g);
+    const uint64_t upto = ~0ull >> (63 - lane); // lanes 0 .. mine
+    const int start = 63 - __clzll((long long)(heads & upto));
+    const uint32_t dist = (uint32_t)(lane - start);
+    double t;
+    t = dpp_move<0x111>(v), v += dist >= 1u ? t : 0.0; // row_shr:1 (lanes whose source is outside their row of 16 receive 0)
+    t = dpp_move<0x112>(v), v += dist >= 2u ? t : 0.0;
+    t = dpp_move<0x114>(v), v += dist >= 4u ? t : 0.0;
+    t = dpp_move<0x118>(v), v += dist >= 8u ? t : 0.0;
+    // the part of the run in the rows below: lane 15 resp. 47 into rows 1 resp. 3, then lane 31 into rows 2 and 3
+    t = dpp_move<0x142, 0xa>(v), v += dist > (uint32_t)(lane & 15) ? t : 0.0;
+    t = dpp_move<0x143, 0xc>(v), v += (lane >= 32 && dist >= (uint32_t)(lane - 31)) ? t : 0.0;
+    const bool tail = act && (lane == 63 || ((heads >> (lane + 1)) & 1ull));
+    const uint32_t c = (uint32_t)__popcll(inmask & upto & (~0ull << start));
+    if (tail && c) {
+        acc_s[g] += v;
+        acc_c[g] += c;
+    }
+}
 // Inclusive prefix sum over the 64 lanes through the DPP paths (Hillis-Steele inside each row of 16 with zero fill,
 // then the row totals are broadcast downwards): no LDS round trips.
 template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ uint32_t dpp_shift_u32(uint32_t v) {
@@ -338,6 +367,7 @@ __device__ __forceinline__ v2f bc(float s) { return v2f{s, s}; }
 // cost 6 rounds, this costs 5.5; with 918 for 432 (config 2) 2.25 instead of 3.  (A counter in global memory shared by
 // the waves of all XCDs was measured: 2.2x SLOWER - contended device-scope atomics.)  Which wave evaluates a unit has
 // no influence on its results.
+template <uint32_t MINSUB = 16u>
 __device__ __forceinline__ bool unit_of_ticket(uint32_t t, uint32_t H, uint32_t waves_per_chunk, uint32_t &kb, uint32_t &gn) {
     const uint32_t G = (H + 63u) / 64u;
     const uint32_t full = (G / waves_per_chunk) * waves_per_chunk; // 64-hypothesis units of the whole rounds
@@ -347,7 +377,7 @@ __device__ __forceinline__ bool unit_of_ticket(uint32_t t, uint32_t H, uint32_t 
         return true;
     }
     const uint32_t rest = G - full; // < waves_per_chunk groups left
-    const uint32_t sub = (rest * 4u <= waves_per_chunk) ? 16u : (rest * 2u <= waves_per_chunk) ? 32u : 64u;
+    const uint32_t sub = (MINSUB <= 16u && rest * 4u <= waves_per_chunk) ? 16u : (rest * 2u <= waves_per_chunk) ? 32u : 64u;
     kb = full * 64u + (t - full) * sub;
     if (kb >= H)
         return false;
@@ -489,7 +519,6 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
                 in = eval_point<EST>(M, x, thr2, r2) && act;
             }
             double v = in ? r2 : 0.0;
-            uint32_t c = in ? 1u : 0u;
             const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
             if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) {
@@ -503,22 +532,7 @@ __device__ __forceinline__ void score_queue_body(const PointSet &pts, const floa
             } else if (inmask) {
                 // segmented inclusive scan; keys (hypothesis) ascend with the lane, so "same key `off` lanes below"
                 // implies the whole stretch in between belongs to the segment
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const double vv = __shfl_up(v, off, 64);
-                    const uint32_t cc = __shfl_up(c, off, 64);
-                    const uint32_t gg = __shfl_up(g, off, 64);
-                    if (lane >= off && gg == g) {
-                        v += vv;
-                        c += cc;
-                    }
-                }
-                const uint32_t gnext = __shfl_down(g, 1, 64);
-                const bool tail = act && ((uint32_t)lane + 1 == n || gnext != g);
-                if (tail && c) {
-                    acc_s[g] += v;
-                    acc_c[g] += c;
-                }
+                add_run_totals(v, inmask, g, act, lane, acc_s, acc_c);
             }
             qhead += n;
         };
@@ -683,24 +697,37 @@ template <int EST, int P> __global__ __launch_bounds__(kQueueThreads) void k_sco
 }
 
 // ---- absolute pose: the pre-filter on the matrix cores ----------------------------------------------------------
-// k_score_mfma: same contract and same exact pass as k_score_queue, but pass A comes out of the matrix pipe whole: the
-// reprojection test is four half-planes per pair, each linear in sixteen numbers of the correspondence (X high / low,
-// 1, slack | x X high / low, x), so two v_mfma_f32_32x32x16_f16 - one with the x-, one with the y-products - deliver
-// B - a0, B + a0, B - a1, B + a1 (B = thr z2 + slack) for 16 hypotheses x 32 correspondences (operand rows: k_shadow16 in
-// pipeline.hip; bound derivation in pl_prefilter.h).  The vector ALU ORs the four sign bits of a pair (one v_or3, one
-// v_or) and shifts the result into a per-lane, per-hypothesis bit field over the point groups (v_alignbit): 3
-// instructions per pair instead of 4 with the z rows of round 1.  After the PG tiles of a group of 16 hypotheses the bit
-// fields are expanded into the wave's LDS queue, hypothesis by hypothesis (prefix sum over the lanes), so the drain's
-// segmented scan sees every hypothesis as one run, exactly as in k_score_queue.
-// Register layout of a tile (32 rows x 32 columns, 16 accumulator registers per lane; lane l: column l % 32, rows
-// 8 (v / 4) + 4 (l / 32) + v % 4 for register v; row 2 j + f = hypothesis j of the group, f = 0: B - a, 1: B + a):
-// register 4 q + 2 e + f of a lane belongs to hypothesis 4 q + 2 (l / 32) + e.
+// k_score_mfma: same contract and same exact pass as k_score_queue, but pass A comes out of the matrix pipe whole.  An
+// inlier's residual vector is shorter than thr z_2, so its component along any direction is: three directions 120 degrees
+// apart bound the inlier disc by a triangle (round 6; rounds 2 - 5: the axis-parallel square, four half-planes), and each
+// half-plane is linear in sixteen numbers of the correspondence (X high / low, 1, slack | p X high / low, p, |p|; p = c x + s y),
+// so three v_mfma_f32_32x32x16_f16 - one per direction, 32 hypotheses x 32 correspondences each - deliver the three signed
+// distances of a pair, slack included (operand rows: k_shadow16 in pipeline.hip; bound derivation in pl_prefilter.h).  The
+// vector ALU ORs the three sign bits of a pair (one v_or3) and shifts the result into a per-lane, per-hypothesis bit field over
+// the point groups (v_alignbit): 2 instructions per pair (round 2: 3, round 1: 4); the triangle lets 1.3 x the square's pairs
+// through to the exact pass.  After the PG tiles of a group of 32 hypotheses the bit fields are expanded into the wave's LDS
+// queue, hypothesis by hypothesis (prefix sum over the lanes), so the drain's segmented scan sees every hypothesis as one
+// run, exactly as in k_score_queue.
+// Register layout of a tile (32 rows x 32 columns, 16 accumulator registers per lane): lane l = column l % 32, register v =
+// hypothesis row 8 (v / 4) + 4 (l / 32) + v % 4 - the same for the three directions.
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 constexpr int kMfmaQueueCap = 1024; // >= 63 waiting + 64 lanes * 10 point groups appended by one round
 #ifndef PL_MFMA_THREADS
 #define PL_MFMA_THREADS 512
+#endif
+#ifndef PL_ABS_TILE_UNROLL
+#define PL_ABS_TILE_UNROLL 1 // k_score_mfma's loop over the point groups of a tile
+#endif
+#ifndef PL_ABS_SCHED
+#define PL_ABS_SCHED 1 // k_score_mfma: the products of the next point group interleaved with the vector instructions of this one
+#endif
+#ifndef PL_ABS_EXP
+#define PL_ABS_EXP 0 // experiment builds of k_score_mfma (scripts/exp): 1 = no exact pass, 2 = no expansion either
+#endif
+#ifndef PL_ABS_WAVES
+#define PL_ABS_WAVES 4 // wavefronts per SIMD k_score_mfma's register allocation aims at (48 accumulators + 16 bit fields + operands)
 #endif
 constexpr int kMfmaThreads = PL_MFMA_THREADS; // 8 wavefronts share one chunk of correspondences (LDS: 20 KB shared + 2.8 KB per wave)
 
@@ -742,9 +769,8 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
     __shared__ double s_acc_s[kWaves][64];
     __shared__ uint32_t s_acc_c[kWaves][64];
     __shared__ uint32_t s_next_unit;
-    __shared__ uint4 s_b0[PG][32]; // B operands, first k block: (X_hi, X_lo, 1, w) - shared by the x- and the y-instruction
-    __shared__ uint4 s_bx[PG][32]; // second k block of the x-instruction: (x X)_hi, (x X)_lo, x, 0
-    __shared__ uint4 s_by[PG][32]; // ... of the y-instruction
+    __shared__ uint4 s_b[1 + kAbs16Dirs][PG][32]; // B operands: [0] first k block (X_hi, X_lo, 1, w), shared by the three
+                                                  // instructions; [1 + d] second k block of direction d: (p X)_hi, (p X)_lo, p, |p|
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int col = lane & 31, half = lane >> 5;
@@ -769,14 +795,15 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
             s_pts[d][j] = x[d];
         }
         Abs16Point o;
-        pf16_abs_point(x[0], x[1], x[2], x[3], x[4], valid, pf.g16, o);
+        pf16_abs_point(x[0], x[1], x[2], x[3], x[4], valid, pf.g16, pf.thr, o);
         auto row = [](const uint16_t *h) {
             return make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
                               (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
         };
-        s_b0[j >> 5][j & 31] = row(o.b0);
-        s_bx[j >> 5][j & 31] = row(o.bx);
-        s_by[j >> 5][j & 31] = row(o.by);
+        s_b[0][j >> 5][j & 31] = row(o.b0);
+#pragma unroll
+        for (int d = 0; d < kAbs16Dirs; ++d)
+            s_b[1 + d][j >> 5][j & 31] = row(o.bp[d]);
     }
     if (threadIdx.x == 0)
         s_next_unit = 0;
@@ -797,13 +824,18 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
     };
     uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)request_ticket());
     uint32_t kb, gn;
-    while (unit_of_ticket(ticket, H, waves_per_chunk, kb, gn)) {
+    while (unit_of_ticket<32u>(ticket, H, waves_per_chunk, kb, gn)) {
         const uint32_t pending = request_ticket(); // the next unit's index travels while this one is evaluated
+        const uint32_t unit_slots = slots[kb + min((uint32_t)lane, gn - 1u)]; // lane l: the record of the unit's hypothesis l
         acc_s[lane] = 0.0;
         acc_c[lane] = 0;
         uint32_t qhead = 0, qtail = 0;
 
         auto drain = [&](uint32_t n) { // identical to k_score_queue's
+#if PL_ABS_EXP == 1 // (experiment: no exact pass - timing only, results are wrong)
+            qhead += n;
+            return;
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const bool act = (uint32_t)lane < n;
             const uint32_t e = act ? (uint32_t)queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffu;
@@ -814,7 +846,10 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
                 x[d] = s_pts[d][pi];
             // the fp64 model straight from its record (hypothesis k lives in slot slots[k]; the records of consecutive
             // hypotheses are neighbours in memory): no hypothesis-ordered copy of the models is needed on this path
-            const double *Mp = models + (size_t)slots[kb + (act ? g : 0u)] * kModelStride;
+            // (the unit's slot numbers were fetched when the unit began - one lane per hypothesis -, so the record's address costs a
+            // lane permutation here instead of a second dependent trip to memory: a drain is latency, not work)
+            const uint32_t slot_g = (uint32_t)__shfl((int)unit_slots, (int)(act ? g : 0u), 64);
+            const double *Mp = models + (size_t)slot_g * kModelStride;
             double M[kModelDoubles];
 #pragma unroll
             for (int i = 0; i < kModelDoubles; ++i)
@@ -822,7 +857,6 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
             double r2;
             const bool in = eval_point<EST_ABS>(M, x, thr2, r2) && act;
             double v = in ? r2 : 0.0;
-            uint32_t c = in ? 1u : 0u;
             const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
             if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) { // one hypothesis: plain wave sum (k_score_queue)
@@ -832,73 +866,103 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
                     acc_c[g0] += (uint32_t)__popcll(inmask);
                 }
             } else if (inmask) {
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const double vv = __shfl_up(v, off, 64);
-                    const uint32_t cc = __shfl_up(c, off, 64);
-                    const uint32_t gg = __shfl_up(g, off, 64);
-                    if (lane >= off && gg == g) {
-                        v += vv;
-                        c += cc;
-                    }
-                }
-                const uint32_t gnext = __shfl_down(g, 1, 64);
-                const bool tail = act && ((uint32_t)lane + 1 == n || gnext != g);
-                if (tail && c) {
-                    acc_s[g] += v;
-                    acc_c[g] += c;
-                }
+                add_run_totals(v, inmask, g, act, lane, acc_s, acc_c);
             }
             qhead += n;
         };
 
-        const uint32_t ngroups16 = (gn + 15u) / 16u;
-        // lane l: row l % 32 of the group's blocks; lanes 0..31 carry the first k block (x rows / y rows), lanes 32..63
-        // the second one (the same for both instructions)
-        auto load_a = [&](uint32_t hg, uint4 &ax, uint4 &ay) {
-            const uint4 *grp = shadow16 + ((size_t)(kb >> 4) + hg) * 96;
-            ax = grp[(half ? 64 : 0) + col];
-            ay = grp[(half ? 64 : 32) + col];
+        const uint32_t ngroups32 = (gn + 31u) / 32u;
+        // lane l: row l % 32 of the group; lanes 0..31 carry the first k block of the direction, lanes 32..63 the second one (the
+        // same for the three instructions)
+        auto load_a = [&](uint32_t hg, uint4 (&A)[kAbs16Dirs]) {
+            const uint4 *row = shadow16 + (size_t)(kb + 32u * hg + (uint32_t)col) * 4;
+#pragma unroll
+            for (int d = 0; d < kAbs16Dirs; ++d)
+                A[d] = row[half ? 3 : d];
         };
-        uint4 Axr, Ayr;
-        load_a(0, Axr, Ayr);
-        for (uint32_t hg = 0; hg < ngroups16; ++hg) {
-            half8_t Ax, Ay;
-            __builtin_memcpy(&Ax, &Axr, 16);
-            __builtin_memcpy(&Ay, &Ayr, 16);
-            if (hg + 1 < ngroups16) // next group's operands travel while this one is evaluated
-                load_a(hg + 1, Axr, Ayr);
-            uint32_t out[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; // hypothesis 4 q + 2 half + e -> out[2 q + e]: bit (PG - 1 - g) = point group g is a proven outlier
+        uint4 Araw[kAbs16Dirs];
+        load_a(0, Araw);
+        for (uint32_t hg = 0; hg < ngroups32; ++hg) {
+            half8_t Aop[kAbs16Dirs];
+#pragma unroll
+            for (int d = 0; d < kAbs16Dirs; ++d)
+                __builtin_memcpy(&Aop[d], &Araw[d], 16);
+            if (hg + 1 < ngroups32) // next group's operands travel while this one is evaluated
+                load_a(hg + 1, Araw);
+            uint32_t out[16]; // register v: bit (PG - 1 - g) = point group g is a proven outlier of hypothesis row(v)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                out[v] = 0u;
             const float16_t kZero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-            for (int g = 0; g < PG; ++g) {
-                const uint4 bxr = half ? s_bx[g][col] : s_b0[g][col];
-                const uint4 byr = half ? s_by[g][col] : s_b0[g][col];
-                half8_t Bx, By;
-                __builtin_memcpy(&Bx, &bxr, 16);
-                __builtin_memcpy(&By, &byr, 16);
-                const float16_t Dx = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ax, Bx, kZero, 0, 0, 0);
-                const float16_t Dy = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ay, By, kZero, 0, 0, 0);
+            // The loop over the point groups, software-pipelined by hand: the three products of group g + 1 are issued BETWEEN the
+            // v_alignbit of group g (whose OR of sign bits sits in T), five or six vector instructions apart - an MFMA that has to
+            // wait for the matrix pipe (32 cycles per product) blocks the SIMD's vector issue for every wavefront
+            // (scripts/exp/overlap.cc), and three products back to back did that for 48 cycles per group.
+            auto products = [&](int g, float16_t &D0, float16_t &D1, float16_t &D2) {
+                half8_t Bop[kAbs16Dirs];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        // proven outlier <=> one of B - a0, B + a0, B - a1, B + a1 is negative: OR of the four sign bits
-                        const int b = 4 * q + 2 * e;
-                        const uint32_t sg = __float_as_uint(Dx[b]) | __float_as_uint(Dx[b + 1]) | __float_as_uint(Dy[b]) |
-                                            __float_as_uint(Dy[b + 1]);
-                        out[2 * q + e] = __builtin_amdgcn_alignbit(out[2 * q + e], sg, 31);
-                    }
+                for (int d = 0; d < kAbs16Dirs; ++d) {
+                    const uint4 braw = s_b[half ? 1 + d : 0][g][col];
+                    __builtin_memcpy(&Bop[d], &braw, 16);
                 }
+                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[0], Bop[0], kZero, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[1], Bop[1], kZero, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[2], Bop[2], kZero, 0, 0, 0);
+            };
+            float16_t D0, D1, D2;
+            products(0, D0, D1, D2);
+#pragma unroll PL_ABS_TILE_UNROLL
+            for (int g = 1; g < PG; ++g) {
+                uint32_t T[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) // proven outlier <=> one of the three signed distances is negative: OR of the sign bits (v_or3)
+                    T[v] = __float_as_uint(D0[v]) | __float_as_uint(D1[v]) | __float_as_uint(D2[v]);
+                products(g, D0, D1, D2);
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    out[v] = __builtin_amdgcn_alignbit(out[v], T[v], 31);
+#if PL_ABS_SCHED
+#if PL_ABS_SCHED == 1
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0); // the v_or3
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // the operands of the next group from LDS
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#else
+                // the four v_or3 that free the registers the operands are loaded into, the loads, the other v_or3 under the loads' latency
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#endif
+#endif
             }
-            // ---- expansion: eight rounds, round (q, e) = hypothesis 4 q + e (lanes 0..31) and 4 q + 2 + e (lanes 32..63) ----
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const uint32_t sg = __float_as_uint(D0[v]) | __float_as_uint(D1[v]) | __float_as_uint(D2[v]);
+                out[v] = __builtin_amdgcn_alignbit(out[v], sg, 31);
+            }
+            // ---- expansion: register v = hypothesis rows 8 (v / 4) + v % 4 (lanes 0..31) and + 4 (lanes 32..63) ----
             // (only the last, partial group of a short unit has slots without a hypothesis: the per-lane test "slot < gn" - three
-            // vector instructions per round, 1.5 of the 30.7 per hypothesis and 320 correspondences - runs behind a SCALAR branch
-            // for that group only; round 5)
-            const bool partial_group = hg * 16u + 16u > gn;
-            auto expand_round = [&](int r, bool check_slot) {
-                const uint32_t slot = hg * 16u + 4u * (uint32_t)(r >> 1) + 2u * (uint32_t)half + (uint32_t)(r & 1); // hypothesis index inside the unit
-                uint32_t bits = ~out[r] & validbits;
+            // vector instructions per round - runs behind a SCALAR branch for that group only; round 5)
+            const bool partial_group = hg * 32u + 32u > gn;
+            auto expand_round = [&](int v, bool check_slot) {
+#if PL_ABS_EXP == 2 // (experiment: no expansion, no exact pass - timing only, results are wrong)
+                if (out[v] == 0x12345u)
+                    qtail += 1;
+                return;
+#endif
+                const uint32_t slot = hg * 32u + 8u * (uint32_t)(v >> 2) + 4u * (uint32_t)half + (uint32_t)(v & 3); // hypothesis index inside the unit
+                uint32_t bits = ~out[v] & validbits;
                 if (check_slot && slot >= gn)
                     bits = 0u;
                 const uint64_t anyb = __builtin_amdgcn_ballot_w64(bits != 0u);
@@ -934,12 +998,12 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
             };
             if (partial_group) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    expand_round(r, true);
+                for (int v = 0; v < 16; ++v)
+                    expand_round(v, true);
             } else {
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    expand_round(r, false);
+                for (int v = 0; v < 16; ++v)
+                    expand_round(v, false);
             }
         }
         while (qtail != qhead)
@@ -955,7 +1019,7 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
 }
 
 template <int PG>
-__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_score_mfma(PointSet pts, const uint4 *__restrict__ shadow16,
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(PL_ABS_WAVES, 8))) void k_score_mfma(PointSet pts, const uint4 *__restrict__ shadow16,
                                                                const double *__restrict__ models,
                                                                const uint32_t *__restrict__ slots,
                                                                const uint32_t *__restrict__ num_hyp_ptr,
@@ -970,7 +1034,7 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6,
                         gridDim.x);
 }
 template <int PG>
-__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_score_mfma_g(const GroupArgs *ga) {
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(PL_ABS_WAVES, 8))) void k_score_mfma_g(const GroupArgs *ga) {
     const GroupArgs &g = ga[blockIdx.z];
     uint32_t slice, chunk;
     if (!g.active || !g.use_mfma || !slice_chunk_of_workgroup(g.slices, g.chunks, slice, chunk))
@@ -1094,7 +1158,6 @@ __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint
             }
             in = in && act;
             double v = in ? r2 : 0.0;
-            uint32_t c = in ? 1u : 0u;
             const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
             if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) {
@@ -1104,22 +1167,7 @@ __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint
                     acc_c[g0] += (uint32_t)__popcll(inmask);
                 }
             } else if (inmask) {
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const double vv = __shfl_up(v, off, 64);
-                    const uint32_t cc = __shfl_up(c, off, 64);
-                    const uint32_t gg = __shfl_up(g, off, 64);
-                    if (lane >= off && gg == g) {
-                        v += vv;
-                        c += cc;
-                    }
-                }
-                const uint32_t gnext = __shfl_down(g, 1, 64);
-                const bool tail = act && ((uint32_t)lane + 1 == n || gnext != g);
-                if (tail && c) {
-                    acc_s[g] += v;
-                    acc_c[g] += c;
-                }
+                add_run_totals(v, inmask, g, act, lane, acc_s, acc_c);
             }
             qhead += n;
         };
@@ -1337,7 +1385,6 @@ __device__ __forceinline__ void score_mfmah_body(const PointSet &pts, const uint
             double r2;
             const bool in = eval_point<EST_HOM>(M, x, thr2, r2) && act;
             double v = in ? r2 : 0.0;
-            uint32_t c = in ? 1u : 0u;
             const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
             if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) { // one hypothesis: plain wave sum
@@ -1347,22 +1394,7 @@ __device__ __forceinline__ void score_mfmah_body(const PointSet &pts, const uint
                     acc_c[g0] += (uint32_t)__popcll(inmask);
                 }
             } else if (inmask) {
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const double vv = __shfl_up(v, off, 64);
-                    const uint32_t cc = __shfl_up(c, off, 64);
-                    const uint32_t gg = __shfl_up(g, off, 64);
-                    if (lane >= off && gg == g) {
-                        v += vv;
-                        c += cc;
-                    }
-                }
-                const uint32_t gnext = __shfl_down(g, 1, 64);
-                const bool tail = act && ((uint32_t)lane + 1 == n || gnext != g);
-                if (tail && c) {
-                    acc_s[g] += v;
-                    acc_c[g] += c;
-                }
+                add_run_totals(v, inmask, g, act, lane, acc_s, acc_c);
             }
             qhead += n;
         };
@@ -3170,7 +3202,10 @@ static hipError_t launch_score_est(const ScoreArgs &a, uint32_t slices, hipStrea
     }
     if constexpr (E == EST_ABS) {
         if (streaming && a.shadow16) { // pre-filter on the matrix cores (PG = 2 P groups of 32 points per wave)
-            const dim3 mgrid(xcd_slices(slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads), chunks);
+            // two workgroups fit a CU (LDS, registers): one resident round of 512 workgroups, as for the Sampson form above
+            const uint32_t mslices = std::min<uint32_t>(slices * (uint32_t)kScoreThreads / (uint32_t)kMfmaThreads,
+                                                        std::max<uint32_t>(1u, 512u / chunks));
+            const dim3 mgrid(xcd_slices(mslices), chunks);
             const dim3 mblock(kMfmaThreads);
 #define PL_M_CASE(PP)                                                                                                  \
     case PP:                                                                                                           \

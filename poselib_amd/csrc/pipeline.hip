@@ -679,39 +679,36 @@ __global__ __launch_bounds__(256) void k_records_g(const GroupArgs *ga) {
 }
 
 // ------------------------------------------------------------------------------------ fp16 hypothesis operands
-// A-operand rows of v_mfma_f32_32x32x16_f16 for k_score_mfma (kernels.hip; bounds in pl_prefilter.h).  The reprojection
-// test |z0 - x z2| <= thr z2 and |z1 - y z2| <= thr z2 is four half-planes, each LINEAR in the sixteen per-correspondence
-// numbers  (X, X_lo, 1, w | xX, (xX)_lo, x, 0)  resp. the same with y:
-//     F-  =  (thr R_2 - R_a) . X  +  (thr t_2 - t_a + g)  +  x (R_2 . X)  +  x t_2  +  w      ( = B - a,  a = z_a - x z_2 )
-//     F+  =  (thr R_2 + R_a) . X  +  (thr t_2 + t_a + g)  -  x (R_2 . X)  -  x t_2  +  w      ( = B + a )
-// so the matrix pipe delivers the four signed distances of a pair directly, slack included, and the vector ALU only
-// ORs four sign bits.  One instruction = 16 hypotheses x 2 rows (F-, F+) x 32 correspondences; the x- and the y-instruction
-// share the first k block of the correspondence side and the second k block of the hypothesis side.  Stored per group of
-// 16 hypotheses as three blocks of 32 rows x 16 B:  [block 0 of the x rows][block 0 of the y rows][block 1 (both)],
-// row 2 j + f for hypothesis j of the group and f = 0 (F-) / 1 (F+):
-//     block 0 = (c_0, c_1, c_2, c_0, c_1, c_2, const, 1),  c = thr R_2 -+ R_a,  const = thr t_2 -+ t_a + g  rounded UP
-//     block 1 = +-(R_20, R_21, R_22, R_20, R_21, R_22, t_2, 0)
-// g = g16 max|t_c| + c16 is the hypothesis' share of the slack (+inf: evaluate every point exactly, -inf: NaN model, no
-// inliers; the other entries are zero then).
+// A-operand rows of v_mfma_f32_32x32x16_f16 for k_score_mfma (kernels.hip; bounds in pl_prefilter.h).  An inlier's residual
+// vector (z_0 - x z_2, z_1 - y z_2) is shorter than thr z_2, so its component along ANY unit direction d = (c, s) is: three
+// directions 120 degrees apart bound the inlier disc by a triangle, and each half-plane is LINEAR in the sixteen
+// per-correspondence numbers  (X, X_lo, 1, w | p X, (p X)_lo, p, |p|),  p = c x + s y:
+//     F  =  (thr R_2 - (c R_0 + s R_1)) . X  +  (thr t_2 - (c t_0 + s t_1) + g)  +  w  +  p (R_2 . X)  +  p t_2  +  Tm |p|
+// so the matrix pipe delivers the three signed distances of a pair directly, slack included, and the vector ALU only ORs
+// three sign bits (one v_or3).  One instruction = 32 hypotheses x 32 correspondences of ONE direction; the three
+// instructions share the first k block of the correspondence side and the second k block of the hypothesis side.  Stored per
+// hypothesis as four rows of 16 B:  [block 0 of direction 0][of direction 1][of direction 2][block 1 (all three)]
+//     block 0 = (c_0, c_1, c_2, c_0, c_1, c_2, const, 1),  c = thr R_2 - (c R_0 + s R_1),  const rounded UP
+//     block 1 = (R_20, R_21, R_22, R_20, R_21, R_22, t_2, Tm)
+// g = 2^-16 max|t_c| + c16 is the hypothesis' share of the slack (+inf: evaluate every point exactly, -inf: NaN model, no
+// inliers; the other entries are zero then), Tm = 2^-10 (1 + 2^-6) max|t_c| the factor of |p| (pl_prefilter.h).
 // shadow_of(k): the fp32 shadow (16 floats) of hypothesis k < H
 template <typename ShadowOf>
-__device__ __forceinline__ void shadow16_one(uint32_t k, uint32_t H, ShadowOf shadow_of, float g16, float c16, float thr,
+__device__ __forceinline__ void shadow16_one(uint32_t k, uint32_t H, ShadowOf shadow_of, float c16, float thr,
                                              uint4 *__restrict__ out) {
-    if (k >= ((H + 15u) & ~15u))
-        return; // groups past the last hypothesis are never read
+    if (k >= ((H + 31u) & ~31u))
+        return; // groups of 32 past the last hypothesis are never read
     Abs16Model m;
-    pf16_abs_model(k < H ? shadow_of(k) : nullptr, g16, c16, thr, m); // (pl_prefilter.h: the host test build runs the same)
-    uint4 *grp = out + (size_t)(k >> 4) * 96; // 3 blocks x 32 rows
-    const uint32_t j = k & 15u;
+    pf16_abs_model(k < H ? shadow_of(k) : nullptr, c16, thr, m); // (pl_prefilter.h: the host test build runs the same)
+    uint4 *dst = out + (size_t)k * 4;
     auto row = [](const uint16_t *h) {
         return make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
                           (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
     };
-    for (int f = 0; f < 2; ++f) {
-        grp[2 * j + f] = row(m.x0[f]);
-        grp[32 + 2 * j + f] = row(m.y0[f]);
-        grp[64 + 2 * j + f] = row(m.b1[f]);
-    }
+#pragma unroll
+    for (int d = 0; d < kAbs16Dirs; ++d)
+        dst[d] = row(m.d[d]);
+    dst[3] = row(m.b1);
 }
 
 __global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const float *__restrict__ shadow,
@@ -720,7 +717,8 @@ __global__ __launch_bounds__(256) void k_shadow16(const uint32_t *num_hyp, const
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= capacity16)
         return;
-    shadow16_one(k, *num_hyp, [&](uint32_t kk) { return shadow + (size_t)kk * 16; }, g16, c16, thr, out);
+    (void)g16;
+    shadow16_one(k, *num_hyp, [&](uint32_t kk) { return shadow + (size_t)kk * 16; }, c16, thr, out);
 }
 
 // k_gather_models and k_shadow16 as ONE launch (both only depend on k_compact2's hypothesis list): blocks below
@@ -738,7 +736,7 @@ __global__ __launch_bounds__(256) void k_gather_shadow16(BatchCtl *ctl, const ui
         return;
     shadow16_one(k, ctl->num_hyp,
                  [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
-                 g16, c16, thr, out16);
+                 c16, thr, out16);
 }
 
 // Operands of k_score_mfma2 (Sampson scores on the matrix cores): 96 B per hypothesis = six 16-byte k blocks
@@ -845,14 +843,14 @@ __global__ __launch_bounds__(256) void k_gather_shadow16_g(const GroupArgs *ga, 
             sampson16_one(k, H, capp, g.comp.slots, g.comp.models, static_cast<uint4 *>(g.comp.s16.out));
         return;
     }
-    // (shadow16_one fills the last group of 16 up and ignores everything behind it)
-    const uint32_t end = (uint32_t)std::min<uint64_t>((cap + 15u) & ~15ull, ((uint64_t)H + 15u) & ~15ull);
+    // (shadow16_one fills the last group of 32 up and ignores everything behind it)
+    const uint32_t end = (uint32_t)std::min<uint64_t>((cap + 31u) & ~31ull, ((uint64_t)H + 31u) & ~31ull);
     const uint32_t *slots = g.comp.slots;
     const double *models = g.comp.models;
     for (uint32_t k = k0; k < end; k += nb * 256)
         shadow16_one(k, H,
                      [&](uint32_t kk) { return reinterpret_cast<const float *>(models + (size_t)slots[kk] * kModelStride + kShadowOff); },
-                     g.comp.s16.g16, g.comp.s16.c16, g.comp.s16.thr, static_cast<uint4 *>(g.comp.s16.out));
+                     g.comp.s16.c16, g.comp.s16.thr, static_cast<uint4 *>(g.comp.s16.out));
 }
 
 // ------------------------------------------------------------------------------------ front-end pre-processing
@@ -967,7 +965,7 @@ hipError_t launch_undistort(const double *in, uint32_t n, const CameraParams &ca
 // ------------------------------------------------------------------------------------ launchers
 hipError_t launch_shadow16(const uint32_t *num_hyp, const float *shadow_compact, uint32_t hyp_capacity, float g16,
                            float c16, float thr, void *shadow16, hipStream_t stream) {
-    const uint32_t cap8 = (hyp_capacity + 15u) & ~15u;
+    const uint32_t cap8 = (hyp_capacity + 31u) & ~31u;
     if (cap8 == 0)
         return hipSuccess;
     k_shadow16<<<dim3((cap8 + 255) / 256), dim3(256), 0, stream>>>(num_hyp, shadow_compact, cap8, g16, c16, thr,
@@ -1029,7 +1027,7 @@ hipError_t launch_compact2(const uint32_t *num_models, uint32_t B, int maxm, uin
     } else if (s16.out) {
         // matrix-core scorer: its fp16 operand blocks are built straight from the records, and its exact pass reads the
         // fp64 models from the records as well - no hypothesis-ordered copies
-        const uint32_t cap8 = (uint32_t)(((uint64_t)B * (uint64_t)maxm + 15u) & ~15ull);
+        const uint32_t cap8 = (uint32_t)(((uint64_t)B * (uint64_t)maxm + 31u) & ~31ull);
         k_gather_shadow16<<<dim3((cap8 + 255) / 256), dim3(256), 0, stream>>>(ctl, slots, models, nullptr, nullptr, 0u, cap8,
                                                                             s16.g16, s16.c16, s16.thr,
                                                                             static_cast<uint4 *>(s16.out));

@@ -214,8 +214,8 @@ struct Shadow16Params {
                      // 2: homography, operands of k_score_mfmah (256 B per hypothesis, Hom16Model; thr = PrefilterArgs.h16)
 };
 constexpr size_t kSampson16Bytes = 96;
-constexpr size_t kAbs16Bytes = 96;  // absolute pose (k_score_mfma): 2 rows x 3 k blocks x 16 B per hypothesis
-constexpr size_t kAbs16Pad = 16;    // the last group of 16 is filled up
+constexpr size_t kAbs16Bytes = 64;  // absolute pose (k_score_mfma): 3 directions + the shared second k block, 16 B each, per hypothesis
+constexpr size_t kAbs16Pad = 32;    // the last group of 32 is filled up
 constexpr size_t kSampson16Pad = 64; // operand rows a partial group of 32 may read past the last hypothesis
 constexpr size_t kHom16Bytes = 256; // homography (k_score_mfmah): 4 rows x 4 k blocks x 16 B per hypothesis, groups of 8
 constexpr size_t kHom16Pad = 8;     // the last group of 8 is filled up

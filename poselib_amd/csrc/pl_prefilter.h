@@ -127,8 +127,8 @@ struct PrefilterArgs {
     float gx;      // absolute pose: 32u (1 + max|x|,|y| + thr), rounded up
     float thr2_up; // Sampson: thr2 (1 + 64u), rounded up
     int enabled;   // 0: exact evaluation of every point
-    float g16;     // absolute pose, fp16 / MFMA form of the filter: 2^-11 (1 + 2^-6) (1 + max|x|,|y| + thr), rounded up
-    float c16;     //   and the absolute part (2e-7 + 2.5e-4) (1 + max|x|,|y| + thr)
+    float g16;     // absolute pose, fp16 / MFMA form of the filter: 2^-11 (1 + 2^-6), rounded up (0: form not available)
+    float c16;     //   and the absolute part (2e-7 + 5e-4) (1 + 1.3661 max|x|,|y| + thr)
     float t1;      // Sampson, one-comparison form: (16/15) (1 + 1/64) thr2 (1 + 96u), rounded up
     float w252;    //   and (16/15) (1 + 96u) 60, rounded up (factor of (na nb)^2 in the per-point term w)
     float t16;     // Sampson, fp16 / MFMA form: (16/15) 2^15 thr2 (1 + 256u), rounded up; 0 = that form is not available
@@ -157,11 +157,10 @@ inline PrefilterArgs make_prefilter_args(int est, double thr2, float xy_absmax) 
     a.w252 = nextafterf((float)((16.0 / 15.0) * (1.0 + 96.0 * u) * 60.0), inf);
     if (est == 0) {
         a.gx = nextafterf((float)(32.0 * u * (1.0 + (double)xy_absmax + thr)), inf);
-        a.g16 = nextafterf((float)(4.8828125e-4 * 1.015625 * (1.0 + (double)xy_absmax + thr)), inf); // 2^-11 (1 + 2^-6)
-        // 2e-7: fp32 accumulation; 2.5e-4: four fp16 inputs per row (X_lo, t) may be subnormal, i.e. below 6.1e-5 - the
-        // bound holds even if the matrix pipe flushes them to zero
-        // (round 2, half-plane rows: six low parts - X_lo, (x X)_lo - and x itself may be subnormal per row: 4e-4)
-        a.c16 = nextafterf((float)((2e-7 + 4.0e-4) * (1.0 + (double)xy_absmax + thr)), inf);
+        // fp16 / MFMA form (round 6: three directions, p = c x + s y with |p| <= 1.3661 max(|x|, |y|); pf16_abs_model / _point)
+        a.g16 = nextafterf((float)(4.8828125e-4 * 1.015625), inf); // 2^-11 (1 + 2^-6)
+        // absolute part: operands below the fp16 normal range (also when the matrix pipe flushes them), fp32 accumulation
+        a.c16 = nextafterf((float)((2e-7 + 5.0e-4) * (1.0 + 1.3661 * (double)xy_absmax + thr)), inf);
     }
     if (est == 1 || est == 2) {
         // xy_absmax of a two-view problem: max over all four coordinates (driver.cc make_problem; +inf when unknown).
@@ -407,16 +406,43 @@ PL_HD uint16_t pf_half_toward_plus_inf(float v) { // any sign: the smallest fp16
     }
     return b;
 }
-struct Abs16Model { // rows of one hypothesis: [f = 0: B - a, f = 1: B + a][8 k slots]
-    uint16_t x0[2][8]; // first k block of the x rows:  (c_0, c_1, c_2, c_0, c_1, c_2, const, 1)
-    uint16_t y0[2][8]; // ... of the y rows
-    uint16_t b1[2][8]; // second k block (both):        +-(R_20, R_21, R_22, R_20, R_21, R_22, t_2, 0)
+// Round 6: THREE half-planes instead of four, and the slack where it arises.  An inlier's residual vector
+// a = (z_0 - x z_2, z_1 - y z_2) has |a|_2 < thr z_2 (utils.cc:36-65: the squared reprojection error against thr^2, z_2 > 0), so
+// d . a < thr z_2 for EVERY direction |d|_2 <= 1: the three directions below (0, 120, 240 degrees; the second component rounded
+// DOWN, |d| < 1) bound the inlier disc by a triangle instead of the axis-parallel square.  The triangle's area is 1.3 x the
+// square's - 30 % more pairs reach the exact pass - but a pair costs the matrix pipe three single-row products (32 hypotheses
+// per instruction) and the vector ALU one v_or3 and one v_alignbit instead of two products of two rows (16 hypotheses) and three
+// vector instructions.  Per direction (c, s), with p = c x + s y, R' = c R_0 + s R_1 (entries bounded by |c| + |s| <= 1.3661; by
+// 1 for orthonormal rows) and t' = c t_0 + s t_1, the exact form and what the matrix pipe accumulates in fp32 are
+//     F  = (thr R_2 - R') . X + (thr t_2 - t') + p (R_2 . X) + p t_2                                   ( > 0 for an inlier )
+//     F^ = rn16(thr R_2 - R') (X_hi + X_lo) + up16(thr t_2 - t' + g) + up16(w) + rn16(R_2) ((p X)_hi + (p X)_lo)
+//          + rn16(t_2) rn16(p) + up16(Tm) up16(Pa)
+// (the last product rides in the sixteenth k slot, unused until round 6).  Errors, with u16 = 2^-11 (fp16 unit roundoff), splits
+// exact to 2^-22, sixteen fp32 accumulations <= 2^-19 of the sum of magnitudes, fp32 roundings of the coefficients <= 2^-22:
+//     X part:            (u16 + 2^-19 + 2^-21) (1.3661 + thr + |p|) |X|_1       <=  w  = u16 (1 + 2^-6) (1.3661 + thr + pm) |X|_1 + 1.3e-4,
+//                                                                                   pm >= |p| of every direction: |(x, y)|_2 rounded up
+//     rn16(t_2) rn16(p): 2 u16 (1 + 2^-12) |t_2| |p|  (+ 2^-19 of it)            <=  Tm Pa,  Tm = 2 u16 (1 + 2^-6) max|t_c|,  Pa = |p|
+//     constant:          rounded UP; its fp32 roundings and 2^-19 of |constant|  <=  g  = 2^-16 max|t_c| + c
+// - round 2 .. 5 charged the translation part as G max|t_c| with G = u16 (1 + 2^-6) (1 + max|x|,|y| + thr), which covers
+// 2 u16 |p| |t_2| only while 2 |p| <= 1 + max|x|,|y| + thr, i.e. not in the corners of a field of view beyond 90 degrees; the
+// bilinear slot is exact in |p| and tighter everywhere else.  Operands below the fp16 normal range (the matrix pipe may flush
+// them): X_hi / X_lo and (p X)_hi / (p X)_lo cost <= 6.1e-5 of their coefficient each (three + three per row), the constant
+// and rn16(t_2) one unit each (x 1 resp. x |p|); coefficients below 6.1e-5 carry no rounding error, so the budget of the X part
+// pays for them; together <= 6.1e-5 (8.2 + 3 thr + max|p|) <= c = 5e-4 (1 + 1.3661 max|x|,|y| + thr).  |p| < 2^-14 enters as
+// rn16(p) = 0 and Pa = 2^-4 (Tm Pa >= |t_2| 2^-14 >= the dropped product); Tm and Pa are never below 2^-14.
+// F^ >= F then: a NEGATIVE F^ of any direction proves an outlier.
+constexpr int kAbs16Dirs = 3;
+PL_HD float pf16_abs_dir_c(int k) { return k == 0 ? 1.f : -0.5f; }
+PL_HD float pf16_abs_dir_s(int k) { return k == 0 ? 0.f : (k == 1 ? 0.8660254f : -0.8660254f); } // (0.8660254f < sqrt(3) / 2)
+struct Abs16Model {      // rows of one hypothesis
+    uint16_t d[kAbs16Dirs][8]; // first k block of direction k: (c_0, c_1, c_2, c_0, c_1, c_2, const, 1)
+    uint16_t b1[8];            // second k block (every direction): (R_20, R_21, R_22, R_20, R_21, R_22, t_2, Tm)
 };
 // shadow: the record's fp32 shadow (R row-major at 0..8, t at 9..11, padded max|t_c| at 12, NaN flag at 13) or nullptr for
-// a row that is not a hypothesis
-PL_HD void pf16_abs_model(const float *shadow, float g16, float c16, float thr, Abs16Model &o) {
+// a row that is not a hypothesis; c16: PrefilterArgs.c16
+PL_HD void pf16_abs_model(const float *shadow, float c16, float thr, Abs16Model &o) {
     const float inf = __builtin_huge_valf();
-    float R[9], t[3], slack;
+    float R[9], t[3], slack, tm = 0.f;
     for (int i = 0; i < 9; ++i)
         R[i] = 0.f;
     t[0] = t[1] = t[2] = 0.f;
@@ -431,76 +457,77 @@ PL_HD void pf16_abs_model(const float *shadow, float g16, float c16, float thr, 
         __builtin_memcpy(&nanflag, &shadow[13], 4);
         if (nanflag != 0u) {
             slack = -inf; // NaN model: no inliers
-        } else if (!(tmax < 3.0e4f) || !(rmax <= 1.0001f)) {
+        } else if (!(tmax < 2.7e4f) || !(rmax <= 1.0001f)) { // (2.7e4: |thr t_2 - t'| <= 2.37 max|t_c| stays below 65504)
             slack = inf; // outside what fp16 carries: every point is evaluated exactly
         } else {
             for (int i = 0; i < 9; ++i)
                 R[i] = shadow[i];
             for (int i = 0; i < 3; ++i)
                 t[i] = shadow[9 + i];
-            slack = fmaf(g16, tmax, c16) * 1.000001f + 6.2e-5f;
+            slack = fmaf(1.52587890625e-5f, tmax, c16) * 1.000001f + 6.2e-5f; // 2^-16 max|t_c| + c
+            tm = fmaxf(9.918212890625e-4f * tmax * 1.000001f, 6.103515625e-5f); // 2^-10 (1 + 2^-6) max|t_c|, at least 2^-14
         }
     }
     const bool finite = slack != inf && slack != -inf;
-    for (int a = 0; a < 2; ++a)
-        for (int f = 0; f < 2; ++f) {
-            const float sg = f ? 1.f : -1.f;
-            uint16_t *row = a ? o.y0[f] : o.x0[f];
-            for (int d = 0; d < 3; ++d)
-                row[d] = row[3 + d] = pf_half_rn(fmaf(thr, R[6 + d], sg * R[3 * a + d]));
-            row[6] = finite ? pf_half_toward_plus_inf(fmaf(thr, t[2], sg * t[a]) + slack) : (uint16_t)(slack > 0 ? 0x7c00u : 0xfc00u);
-            row[7] = 0x3c00u; // 1.0
-        }
-    for (int f = 0; f < 2; ++f) {
-        const float sg = f ? -1.f : 1.f;
+    for (int k = 0; k < kAbs16Dirs; ++k) {
+        const float c = pf16_abs_dir_c(k), s = pf16_abs_dir_s(k);
+        uint16_t *row = o.d[k];
         for (int d = 0; d < 3; ++d)
-            o.b1[f][d] = o.b1[f][3 + d] = pf_half_rn(sg * R[6 + d]);
-        o.b1[f][6] = pf_half_rn(sg * t[2]);
-        o.b1[f][7] = 0;
+            row[d] = row[3 + d] = pf_half_rn(fmaf(thr, R[6 + d], -fmaf(c, R[d], s * R[3 + d])));
+        row[6] = finite ? pf_half_toward_plus_inf(fmaf(thr, t[2], -fmaf(c, t[0], s * t[1])) + slack) : (uint16_t)(slack > 0 ? 0x7c00u : 0xfc00u);
+        row[7] = 0x3c00u; // 1.0
     }
+    for (int d = 0; d < 3; ++d)
+        o.b1[d] = o.b1[3 + d] = pf_half_rn(R[6 + d]);
+    o.b1[6] = pf_half_rn(t[2]);
+    o.b1[7] = finite ? pf_half_up(tm) : (uint16_t)0;
 }
 struct Abs16Point {
-    uint16_t b0[8]; // (X_hi, X_lo, 1, w)
-    uint16_t bx[8]; // ((x X)_hi, (x X)_lo, x, 0)
-    uint16_t by[8];
+    uint16_t b0[8];             // (X_hi, X_lo, 1, w)
+    uint16_t bp[kAbs16Dirs][8]; // direction k: ((p X)_hi, (p X)_lo, p, Pa),  p = c_k x + s_k y
 };
-// returns false (zero operands, largest finite slack) for correspondences the operands cannot carry
-PL_HD bool pf16_abs_point(double x, double y, double X, double Y, double Z, bool valid, float g16, Abs16Point &o) {
+// g16: PrefilterArgs.g16 = 2^-11 (1 + 2^-6), thr: PrefilterArgs.thr.  Returns false (zero operands, largest finite slack) for
+// correspondences the operands cannot carry
+PL_HD bool pf16_abs_point(double x, double y, double X, double Y, double Z, bool valid, float g16, float thr, Abs16Point &o) {
     const double n1 = fabs(X) + fabs(Y) + fabs(Z);
-    const bool use = valid && n1 < 3.0e4 && fabs(x) * n1 < 3.0e4 && fabs(y) * n1 < 3.0e4 && fabs(x) < 3.0e4 && fabs(y) < 3.0e4;
+    const double pm = fabs(x) + fabs(y); // >= |p| of every direction
+    const bool use = valid && n1 < 3.0e4 && pm * n1 < 3.0e4 && pm < 3.0e4;
     const double P[3] = {X, Y, Z};
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < 3; ++d)
         pf_split16(use ? P[d] : 0.0, o.b0[d], o.b0[3 + d]);
-        pf_split16(use ? x * P[d] : 0.0, o.bx[d], o.bx[3 + d]);
-        pf_split16(use ? y * P[d] : 0.0, o.by[d], o.by[3 + d]);
+    for (int k = 0; k < kAbs16Dirs; ++k) {
+        const double p = use ? (double)pf16_abs_dir_c(k) * x + (double)pf16_abs_dir_s(k) * y : 0.0;
+        for (int d = 0; d < 3; ++d)
+            pf_split16(p * P[d], o.bp[k][d], o.bp[k][3 + d]);
+        // the factor of t_2: below 2^-14 it enters as zero and the slack slot pays for the dropped product
+        const bool tiny = !(fabs(p) >= 6.103515625e-5);
+        o.bp[k][6] = tiny ? (uint16_t)0 : pf_half_rn((float)p);
+        o.bp[k][7] = use ? pf_half_up(tiny ? 0.0625f : (float)fabs(p) * 1.000001f) : (uint16_t)0;
     }
     // the point's share of the slack, rounded up (out of range: the largest finite fp16, not +inf - hypotheses with
     // |t| >= 3e4 carry an infinite slack of their own, so 65504 exceeds every |a| a zero operand can produce; thr <= 1)
-    const float wv = use ? fminf(pf_up(g16 * pf_up((float)n1)) + 1.3e-4f, 65504.f) : 65504.f;
+    const float p2 = pf_up((float)sqrt(x * x + y * y)); // >= |p| of every direction (|d| <= 1)
+    const float wv = use ? fminf(pf_up(g16 * pf_up(1.3661f + thr + p2) * pf_up((float)n1)) + 1.3e-4f, 65504.f) : 65504.f;
     o.b0[6] = 0x3c00u;
     o.b0[7] = pf_half_up(wv);
-    o.bx[6] = pf_half_rn(use ? (float)x : 0.f);
-    o.by[6] = pf_half_rn(use ? (float)y : 0.f);
-    o.bx[7] = o.by[7] = 0;
     return use;
 }
 // The verdict as the kernel computes it (one particular accumulation order; `order` permutes it): true = certainly not an
 // inlier.  Test-only host build and documentation of the device tail.
 PL_HD bool pf16_abs_outlier(const Abs16Model &m, const Abs16Point &p, const int *order /* 16 slots or nullptr */) {
     uint32_t sign = 0;
-    for (int a = 0; a < 2; ++a)
-        for (int f = 0; f < 2; ++f) {
-            float acc = 0.f;
-            for (int q = 0; q < 16; ++q) {
-                const int k = order ? order[q] : q;
-                const uint16_t av = k < 8 ? (a ? m.y0[f][k] : m.x0[f][k]) : m.b1[f][k - 8];
-                const uint16_t bv = k < 8 ? p.b0[k] : (a ? p.by[k - 8] : p.bx[k - 8]);
-                acc = fmaf(pf_half_to_float(av), pf_half_to_float(bv), acc);
-            }
-            uint32_t bits;
-            __builtin_memcpy(&bits, &acc, 4);
-            sign |= bits;
+    for (int a = 0; a < kAbs16Dirs; ++a) {
+        float acc = 0.f;
+        for (int q = 0; q < 16; ++q) {
+            const int k = order ? order[q] : q;
+            const uint16_t av = k < 8 ? m.d[a][k] : m.b1[k - 8];
+            const uint16_t bv = k < 8 ? p.b0[k] : p.bp[a][k - 8];
+            acc = fmaf(pf_half_to_float(av), pf_half_to_float(bv), acc);
         }
+        uint32_t bits;
+        __builtin_memcpy(&bits, &acc, 4);
+        sign |= bits;
+    }
     return (sign >> 31) != 0u;
 }
 

@@ -407,11 +407,11 @@ int hm_prefilter16_abs(const double *rec, const double *const *pa, uint32_t n, d
     if (!pf.enabled || !(pf.g16 > 0.f) || !(pf.thr <= 1.0f))
         return 0;
     Abs16Model m;
-    pf16_abs_model(reinterpret_cast<const float *>(rec + kShadowOff), pf.g16, pf.c16, pf.thr, m);
+    pf16_abs_model(reinterpret_cast<const float *>(rec + kShadowOff), pf.c16, pf.thr, m);
     uint64_t rng = 0x9e3779b97f4a7c15ull * (random_order + 1);
     for (uint32_t i = 0; i < n; ++i) {
         Abs16Point p;
-        pf16_abs_point(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], true, pf.g16, p);
+        pf16_abs_point(pa[0][i], pa[1][i], pa[2][i], pa[3][i], pa[4][i], true, pf.g16, pf.thr, p);
         int order[16];
         for (int k = 0; k < 16; ++k)
             order[k] = k;

@@ -404,6 +404,45 @@ def test_absolute_pose_fp16_form_never_drops_an_inlier():
     assert not HM.prefilter16_abs(HM.pose_record(q, t), cols, 1.0000001 ** 2, 0.5)[0]
 
 
+def test_absolute_pose_fp16_form_wide_field_of_view_and_large_translations():
+    """Round 6: image coordinates up to +-4 (a field of view far beyond 90 degrees) with inliers planted AT the threshold in the
+    corners, and world frames whose origin is far from the camera (|t| = 10 .. 2e4 with the scene next to the camera): the product
+    rn16(t_2) rn16(p) of the fp16 form then carries the largest error of the row (2^-10 |t_2| |p|), which the sixteenth k slot
+    (Tm |p|) pays for - rounds 2 - 5 charged it to a per-hypothesis slack that only covers it while 2 |p| <= 1 + max|x|,|y| + thr."""
+    rs = np.random.RandomState(77)
+    enabled = 0
+    for trial in range(40):
+        n = 1500
+        q = rs.randn(4)
+        q /= np.linalg.norm(q)
+        R = np.array(HM.pose_record(q, np.zeros(3))[HM.MAT:HM.MAT + 9]).reshape(3, 3)
+        fov = [0.5, 1.5, 4.0, 4.0][trial % 4]
+        xy = rs.uniform(-fov, fov, (n, 2))
+        if trial % 2:
+            xy[: n // 2] = np.sign(xy[: n // 2]) * fov * (1 - 1e-3 * rs.rand(n // 2, 2))  # corners
+        depth = 10.0 ** rs.uniform(-1, 1.5, n)
+        Zc = np.c_[xy * depth[:, None], depth]  # camera frame
+        tlen = [0.0, 10.0, 300.0, 5e3, 2e4][trial % 5]
+        t = rs.randn(3)
+        t *= tlen / max(np.linalg.norm(t), 1e-9)
+        X = (Zc - t) @ R  # world points: R X + t = Zc
+        keep = (np.abs(X).sum(1) < 2.5e4) & (np.abs(xy).sum(1) * np.abs(X).sum(1) < 2.9e4)
+        X, xy = X[keep], xy[keep]
+        if len(X) < 50:
+            continue
+        for thr in (1e-3, 1.2e-2, 0.3, 1.0):
+            rec = HM.pose_record(q, t)
+            xp, Xp = _plant_at_threshold_abs(rec, X, thr, rs)
+            cols = [xp[:, 0], xp[:, 1], Xp[:, 0], Xp[:, 1], Xp[:, 2]]
+            for order in range(3):
+                enabled += _check16_abs(rec, cols, thr * thr, float(np.abs(xp).max()), order=order)
+            # a second model next to the first: its inliers are a subset of the planted points
+            q2 = q + 1e-4 * rs.randn(4)
+            q2 /= np.linalg.norm(q2)
+            enabled += _check16_abs(HM.pose_record(q2, t * (1 + 1e-5)), cols, thr * thr, float(np.abs(xp).max()), order=trial % 3)
+    assert enabled > 300
+
+
 def _check16_hom(rec, cols, thr2, uv, stats=None, order=0):
     _, _, inl, _ = HM.score("hom", rec, cols, thr2)
     en, out = HM.prefilter16_hom(rec, cols, thr2, uv, order)
