@@ -713,7 +713,6 @@ template <int EST, int P> __global__ __launch_bounds__(kQueueThreads) void k_sco
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
-constexpr int kMfmaQueueCap = 1024; // >= 63 waiting + 64 lanes * 10 point groups appended by one round
 #ifndef PL_MFMA_THREADS
 #define PL_MFMA_THREADS 512
 #endif
@@ -753,6 +752,76 @@ __device__ __forceinline__ bool slice_chunk_of_workgroup(uint32_t slices, uint32
     chunk = p - slice * chunks;
     return true;
 #endif
+}
+
+// The exact pass of k_score_mfma (k_score_queue's arithmetic).  A drain is a dependency chain - queue entry, the lane
+// permutation that turns the hypothesis into its record's slot, the record's twelve doubles from L2, the evaluation, the run
+// totals -, not work: 31 of the kernel's 132 us with four wavefronts per SIMD to hide it (profiles/r06_score_phases.md).  So
+// the chain is split - `fetch` issues every load of a batch of 64 pairs, `finish` evaluates it - and the kernel drains TWO
+// batches at a time (128 waiting pairs), the second batch's loads in flight under the first one's chain (132.3 -> 129.2 us).
+// Inlined into each of the sixteen expansion rounds of a tile (110 KB of instructions): as a real call (one copy, 15 KB) the
+// saves and restores around 34 call sites cost more than the instruction cache gives back (137.9 us); one drain site behind
+// the rounds keeps the sixteen bit fields alive across it and spills them once per tile (97 registers).
+// queue: the wave's ring (kMfmaQueueCap entries: hypothesis of the unit << 9 | correspondence of the chunk); n0 (+ n1) pairs wait
+// at `first`; pts: the chunk's correspondences in LDS, [5][npw]; unit_slots: lane l = record slot of the unit's hypothesis l.
+constexpr int kMfmaQueueCap = 1024; // >= 127 waiting + 64 lanes * 10 point groups appended by one round
+__device__ __forceinline__ void abs_drain(const uint16_t *queue, uint32_t first, uint32_t n0, uint32_t n1, const double *pts, int npw,
+                                       const double *__restrict__ models, uint32_t unit_slots, double thr2, double *acc_s,
+                                       uint32_t *acc_c) {
+    const int lane = threadIdx.x & 63;
+    struct Batch {
+        uint32_t g;
+        bool act;
+        double x[5];
+        double M[kModelDoubles];
+    };
+    auto fetch = [&](uint32_t n, uint32_t at, Batch &b) {
+        b.act = (uint32_t)lane < n;
+        const uint32_t e = b.act ? (uint32_t)queue[(at + lane) & (kMfmaQueueCap - 1)] : 0xffffu;
+        const uint32_t pi = b.act ? (e & 0x1ffu) : 0u;
+        b.g = e >> 9;
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+            b.x[d] = pts[d * npw + pi];
+        // the fp64 model straight from its record (hypothesis k lives in slot slots[k]): no hypothesis-ordered copy of the
+        // models is needed on this path.  The unit's slot numbers were fetched when the unit began - one lane per
+        // hypothesis -, so the record's address costs a lane permutation here, not a second dependent trip to memory.
+        const uint32_t slot_g = (uint32_t)__shfl((int)unit_slots, (int)(b.act ? b.g : 0u), 64);
+#if PL_ABS_EXP == 4 // (experiment: every pair against the unit's first model - no scattered loads; timing only)
+        const double *Mp = models + (size_t)__builtin_amdgcn_readfirstlane((int)unit_slots) * kModelStride + (slot_g & 0u);
+#else
+        const double *Mp = models + (size_t)slot_g * kModelStride;
+#endif
+#pragma unroll
+        for (int i = 0; i < kModelDoubles; ++i)
+            b.M[i] = Mp[i];
+    };
+    auto finish = [&](const Batch &b) {
+        double r2;
+        const bool in = eval_point<EST_ABS>(b.M, b.x, thr2, r2) && b.act;
+        const double v = in ? r2 : 0.0;
+        const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.g);
+        if (inmask && !__builtin_amdgcn_ballot_w64(b.act && b.g != g0)) { // one hypothesis: plain wave sum (k_score_queue)
+            const double tot = wave_sum_dpp(v);
+            if (lane == 0) {
+                acc_s[g0] += tot;
+                acc_c[g0] += (uint32_t)__popcll(inmask);
+            }
+        } else if (inmask) {
+            add_run_totals(v, inmask, b.g, b.act, lane, acc_s, acc_c);
+        }
+    };
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    Batch b0, b1;
+    fetch(n0, first, b0);
+    if (n1) { // wave-uniform
+        fetch(n1, first + n0, b1);
+        finish(b0);
+        finish(b1);
+    } else {
+        finish(b0);
+    }
 }
 
 template <int PG>
@@ -831,43 +900,17 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
         acc_c[lane] = 0;
         uint32_t qhead = 0, qtail = 0;
 
-        auto drain = [&](uint32_t n) { // identical to k_score_queue's
-#if PL_ABS_EXP == 1 // (experiment: no exact pass - timing only, results are wrong)
-            qhead += n;
-            return;
+        // The exact pass: abs_drain above, two batches of 64 pairs at a time
+        auto drain_pair = [&](uint32_t n2) { // 64 + n2 waiting pairs (0 < n2 <= 64)
+#if PL_ABS_EXP != 1
+            abs_drain(queue, qhead, 64u, n2, &s_pts[0][0], NPW, models, unit_slots, thr2, acc_s, acc_c);
 #endif
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const bool act = (uint32_t)lane < n;
-            const uint32_t e = act ? (uint32_t)queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffu;
-            const uint32_t g = e >> 9, pi = act ? (e & 0x1ffu) : 0u;
-            double x[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d)
-                x[d] = s_pts[d][pi];
-            // the fp64 model straight from its record (hypothesis k lives in slot slots[k]; the records of consecutive
-            // hypotheses are neighbours in memory): no hypothesis-ordered copy of the models is needed on this path
-            // (the unit's slot numbers were fetched when the unit began - one lane per hypothesis -, so the record's address costs a
-            // lane permutation here instead of a second dependent trip to memory: a drain is latency, not work)
-            const uint32_t slot_g = (uint32_t)__shfl((int)unit_slots, (int)(act ? g : 0u), 64);
-            const double *Mp = models + (size_t)slot_g * kModelStride;
-            double M[kModelDoubles];
-#pragma unroll
-            for (int i = 0; i < kModelDoubles; ++i)
-                M[i] = Mp[i];
-            double r2;
-            const bool in = eval_point<EST_ABS>(M, x, thr2, r2) && act;
-            double v = in ? r2 : 0.0;
-            const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
-            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-            if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) { // one hypothesis: plain wave sum (k_score_queue)
-                const double tot = wave_sum_dpp(v);
-                if (lane == 0) {
-                    acc_s[g0] += tot;
-                    acc_c[g0] += (uint32_t)__popcll(inmask);
-                }
-            } else if (inmask) {
-                add_run_totals(v, inmask, g, act, lane, acc_s, acc_c);
-            }
+            qhead += 64u + n2;
+        };
+        auto drain = [&](uint32_t n) { // n <= 64 waiting pairs
+#if PL_ABS_EXP != 1
+            abs_drain(queue, qhead, n, 0u, &s_pts[0][0], NPW, models, unit_slots, thr2, acc_s, acc_c);
+#endif
             qhead += n;
         };
 
@@ -905,9 +948,18 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
                     const uint4 braw = s_b[half ? 1 + d : 0][g][col];
                     __builtin_memcpy(&Bop[d], &braw, 16);
                 }
+#if PL_ABS_EXP == 5 // (experiment: no matrix products - timing only, with PL_ABS_EXP == 2's missing expansion)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    D0[v] = (float)Bop[0][v & 7] + (float)Aop[0][v & 7];
+                    D1[v] = (float)Bop[1][v & 7] + (float)Aop[1][v & 7];
+                    D2[v] = (float)Bop[2][v & 7] + (float)Aop[2][v & 7];
+                }
+#else
                 D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[0], Bop[0], kZero, 0, 0, 0);
                 D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[1], Bop[1], kZero, 0, 0, 0);
                 D2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aop[2], Bop[2], kZero, 0, 0, 0);
+#endif
             };
             float16_t D0, D1, D2;
             products(0, D0, D1, D2);
@@ -956,7 +1008,7 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
             // vector instructions per round - runs behind a SCALAR branch for that group only; round 5)
             const bool partial_group = hg * 32u + 32u > gn;
             auto expand_round = [&](int v, bool check_slot) {
-#if PL_ABS_EXP == 2 // (experiment: no expansion, no exact pass - timing only, results are wrong)
+#if PL_ABS_EXP == 2 || PL_ABS_EXP == 5 // (experiment: no expansion, no exact pass - timing only, results are wrong)
                 if (out[v] == 0x12345u)
                     qtail += 1;
                 return;
@@ -992,8 +1044,8 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
                         }
                         qtail += total;
                     }
-                    while (qtail - qhead >= 64u)
-                        drain(64u);
+                    while (qtail - qhead >= 128u)
+                        drain_pair(64u);
                 }
             };
             if (partial_group) {
@@ -1006,8 +1058,10 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
                     expand_round(v, false);
             }
         }
-        while (qtail != qhead)
-            drain(min(64u, qtail - qhead));
+        if (qtail - qhead > 64u)
+            drain_pair(qtail - qhead - 64u);
+        else if (qtail != qhead)
+            drain(qtail - qhead);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if ((uint32_t)lane < gn) {
             const size_t o = (size_t)chunk * hyp_capacity + kb + lane;
