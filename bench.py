@@ -30,8 +30,9 @@ The JSON line also carries
                  register/LDS-resident, so the kernel is limited by vector-ALU issue, not by HBM.
                  achieved = VALU wave-instructions per launch (PMC-measured instructions per (hypothesis, point chunk),
                  committed in profiles/pmc_traffic.json, x hypotheses x chunks of the launch) / launch duration (HIP
-                 events, launching stream); peak = 1024 SIMDs x clock / 4 cycles per wave64 instruction; frac < 1 by
-                 construction.  The SURVEY 8d "as if streamed" byte count is kept as algorithmic_hbm_x_peak, the PMC
+                 events, launching stream); peak = 1024 SIMDs x clock / the SIMD cycles per VALU instruction at the kernel's
+                 own mix, its MFMAs charged at their 32.6 cycles in the matrix pipe (profiles/valu_mix.json, r06_overlap2.md;
+                 frac_mfma_at_issue_cost: rounds 4 - 5's pricing at 8.4 issue cycles); frac < 1 by construction.  The SURVEY 8d "as if streamed" byte count is kept as algorithmic_hbm_x_peak, the PMC
                  traffic as hbm_frac_physical.
   cpu_baseline : oracle/_ref (the reference's own sources, kind "reference") and the oracle restatement ("port") timed
                  on the same workload on this box's host cores (rank 0, N = 1 only; single-threaded per problem like the
@@ -71,9 +72,11 @@ VALU_PEAK_GINST_S = SIMDS * PEAK_CLOCK_GHZ / 4.0  # 614.4 G wave-instructions / 
 VALU_PEAK_FULL_RATE_GINST_S = SIMDS * PEAK_CLOCK_GHZ / 2.0
 
 
-def kernel_issue_cycles(kernel_name, per_hc):
-    """issue-port cycles per VALU instruction of `kernel_name` at its own mix (MFMA issue cycles included in the numerator), and how it
-    was derived; None when profiles/valu_mix.json has no entry"""
+def kernel_issue_cycles(kernel_name, per_hc, mfma_cost="mfma_pipe"):
+    """SIMD cycles per VALU instruction of `kernel_name` at its own mix, the kernel's MFMAs included in the numerator - at their
+    32.6 cycles in the matrix pipe (`mfma_pipe`, the default since round 6: profiles/r06_overlap2.md measured that the pipe's time
+    does NOT run under the vector instructions that consume its results) or at the 8.4 cycles they hold the issue port
+    (`mfma_issue`, the pricing of rounds 4 - 5) -, and how it was derived; None when profiles/valu_mix.json has no entry"""
     try:
         vm = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
     except Exception:
@@ -88,11 +91,11 @@ def kernel_issue_cycles(kernel_name, per_hc):
         hl, rest = k["hot_loop"], k["outside_hot_loop_static"]
         f = k["hot_loop_iterations_per_chunk"] / k["hot_loop_hypotheses_per_iteration"]
         loop_valu = hl["valu"] * f
-        loop_cycles = (price(hl) + hl["mfma"] * cyc["mfma_issue"]) * f
+        loop_cycles = (price(hl) + hl["mfma"] * cyc.get(mfma_cost, cyc["mfma_issue"])) * f
         rest_valu = max(0.0, per_hc - loop_valu)
         total = loop_cycles + rest_valu * price(rest) / max(1, rest["valu"])
         return total / per_hc, "tile loop counted exactly (%.1f of %.1f instructions per hypothesis and chunk), the rest at the static mix outside the loop" % (loop_valu, per_hc)
-    return (price(whole) + whole["mfma"] * cyc["mfma_issue"]) / max(1, whole["valu"]), "whole-kernel static mix"
+    return (price(whole) + whole["mfma"] * cyc.get(mfma_cost, cyc["mfma_issue"])) / max(1, whole["valu"]), "whole-kernel static mix"
 PARITY_SEEDS = 64   # problems of the first timed step checked against the oracle (seed j on scene j; VERDICT r4: 8 was 0.03 % of a step)
 BASELINE_SEEDS = 8  # of those, the runs that are timed as the CPU baseline (oracle and reference sources: ~12 core-seconds each)
 POSE_TOL = 1e-6
@@ -317,13 +320,18 @@ def run_workload(name, args, ranks, P, synth, pool_factory, primary):
     # the dominant kernel with the device to itself (4 problems one after the other, outside the timed region)
     ranks.barrier()
     solo_ms, solo_launches, solo_hyp = 0.0, 0, 0
+    # (ONE worker thread for all twelve: every host thread has a context of its own, and a context's first launch runs on freshly
+    # allocated buffers - 250 instead of 125 us for k_score_mfma<10>, scripts/exp/solo_launch_probe.py; taken from the pool's S
+    # threads as they came, the four measured launches were first launches of some threads: 0.17 - 0.23 ms in round 6's first line)
+    solo_pool = pool_factory(1)
     for j in range(12):  # the first eight only bring the clocks up (an idle device starts these launches ~10 % slower)
-        _, info = pool.submit(run_one, (probs[0], 7000 + j)).result()
+        _, info = solo_pool.submit(run_one, (probs[0], 7000 + j)).result()
         if j < 8:
             continue
         solo_ms += info["score_kernel_ms"]
         solo_launches += info["score_kernel_launches"]
         solo_hyp += info["hypotheses"]
+    solo_pool.shutdown()
     ranks.barrier()
     t0 = time.perf_counter()
     hyp = nan_hyp = launches = 0
@@ -454,11 +462,16 @@ def report_workload(name, table, ctx, args, world):
         achieved = insts_solo / solo_launch_s / 1e9
         insts_all = per_hc * hyp0 * chunks  # every scoring launch of the timed region on rank 0
         cyc_per_inst, cyc_basis = kernel_issue_cycles(kernel_name, per_hc)
+        cyc_issue_only, _ = kernel_issue_cycles(kernel_name, per_hc, "mfma_issue")
         peak = SIMDS * PEAK_CLOCK_GHZ / cyc_per_inst if cyc_per_inst else VALU_PEAK_GINST_S
         roof.update({"achieved": achieved, "peak": peak, "frac": achieved / peak,
                      "issue_cycles_per_instruction": cyc_per_inst or 4.0,
                      "peak_basis": (f"{SIMDS} SIMDs x {PEAK_CLOCK_GHZ} GHz / {cyc_per_inst:.2f} issue cycles per wave64 VALU instruction at this kernel's mix "
-                                    f"({cyc_basis}; class costs measured: profiles/r04_valu_issue.md)") if cyc_per_inst else roof["peak_basis"],
+                                    f"({cyc_basis}; class costs measured: profiles/r04_valu_issue.md; an MFMA at its 32.6 cycles in the matrix pipe: profiles/r06_overlap2.md)") if cyc_per_inst else roof["peak_basis"],
+                     # rounds 4 - 5 priced an MFMA at the 8.4 cycles it holds the issue port (scripts/exp/overlap.cc: vector instructions
+                     # that do not depend on it run under the rest of its 32.6 cycles); the scorers' vector instructions CONSUME the
+                     # products, and profiles/r06_overlap2.md measured 203 cycles for what costs 123 + 120 apart - `frac` charges the pipe's time
+                     "frac_mfma_at_issue_cost": (achieved * cyc_issue_only / (SIMDS * PEAK_CLOCK_GHZ)) if cyc_issue_only else None,
                      "frac_if_all_half_rate": achieved / VALU_PEAK_GINST_S, "frac_if_all_full_rate": achieved / VALU_PEAK_FULL_RATE_GINST_S,
                      "frac_basis": "the kernel with the device to itself (4 problems one after the other right before "
                                    "the timed region; HIP events on the launching stream) - in the timed region "

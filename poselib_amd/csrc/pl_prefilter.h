@@ -34,7 +34,9 @@
 //    forces |C^| > 3.8 e_C > e_C); the extra 32u covers the roundings of C^ C^, gf^2 w and the final FMA.  The acceptance
 //    band is 4 % wider than with the two-comparison form (h trades that against the weight of e_C, which matters for
 //    un-normalised pixel coordinates); 20 instead of 24 operations per pair.
-//  * reprojection, fp16 / MFMA form (k_score_mfma, round 2): the test is four half-planes per pair,
+//  * reprojection, fp16 / MFMA form (k_score_mfma): round 6 tests THREE half-planes of a triangle around the inlier disc and
+//    carries the slack differently - see "Round 6" at pf16_abs_model below, which builds on this derivation of the round-2 form
+//    (kept for reference): the test was four half-planes per pair,
 //        F(-+, a) = thr z_2 -+ (z_a - p z_2) + slack >= 0        a = 0, 1;  p = x (a = 0) or y (a = 1)
 //    and each is LINEAR in sixteen numbers of the correspondence, so v_mfma_f32_32x32x16_f16 evaluates, with fp32
 //    accumulation,

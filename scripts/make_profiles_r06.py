@@ -18,7 +18,55 @@ def wr(name, text):
         f.write(text if text.endswith("\n") else text + "\n")
 
 
+WORK = {"p3p_5000": ("k_score_mfma<10>", 320, 5000), "relpose_5000": ("k_score_mfma2<1, 10>", 320, 5000),
+        "fund_10000": ("k_score_mfma2<2, 12>", 384, 10000), "hom_10000": ("k_score_mfmah<10>", 320, 10000)}
+
+
+def refresh_pmc_constants():
+    """profiles/pmc_traffic.json from the PMC passes of scripts/gpu_evidence_r06.sh p (round 6: the headline scorer has a new filter,
+    all four have a new reduction in their exact pass) - run BEFORE the bench of part a, which prices its roofline with them"""
+    def rows(md):
+        lines = [ln for ln in md.splitlines() if ln.startswith("|")]
+        cols = [c.strip() for c in lines[0].strip().strip("|").split("|")]
+        return [dict(zip(cols, [c.strip() for c in ln.strip().strip("|").split("|")])) for ln in lines[2:]]
+
+    p = os.path.join(PR, "pmc_traffic.json")
+    old = json.load(open(p))
+    traffic = {"_comment": old.get("_comment", "").split("  Round 6:")[0] + "  Round 6: re-measured (scripts/gpu_evidence_r06.sh p, profiles/r06_pmc_*.md): "
+               "k_score_mfma has three half-planes per pair and 32 hypotheses per tile, every scorer sums the runs of its exact pass over DPP."}
+    for w, (kernel, chunk_pts, n) in WORK.items():
+        md = rd(f"pmc_{w}.md")
+        grbm = [ln for ln in rd(f"pmc_grbm_{w}.log").splitlines() if ln.startswith("{")]
+        r = next((x for x in rows(md) if x["kernel"].strip("`").replace("pl::", "") == kernel and x.get("launches") == "full batch"), None) if md else None
+        need = ("GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES")
+        if not r or not grbm or any(not r.get(k) for k in need):
+            traffic[w] = old[w]  # (this evidence run has no complete PMC set for the workload: keep the committed constants)
+            print(w, "kept", old[w].get("source"))
+            continue
+        f = lambda k: float(r[k])
+        hyp = json.loads(grbm[-1])["roofline"]["hypotheses_per_launch"]
+        chunks = (n + chunk_pts - 1) // chunk_pts
+        cycles = f("GRBM_GUI_ACTIVE") / 8
+        traffic[w] = {"kernel": kernel, "fetch_size_kb": f("FETCH_SIZE"), "write_size_kb": f("WRITE_SIZE"),
+                      "traffic_bytes_per_launch": (2 * f("FETCH_SIZE") + f("WRITE_SIZE")) * 1024.0, "hypotheses_per_launch": hyp,
+                      "points_per_chunk": chunk_pts, "valu_insts_per_launch": f("SQ_INSTS_VALU"),
+                      "valu_insts_per_hypothesis_chunk": f("SQ_INSTS_VALU") / (hyp * chunks),
+                      "mfma_insts_per_launch": float(r["SQ_INSTS_MFMA"]) if r.get("SQ_INSTS_MFMA") else None,
+                      "valu_busy": round(f("SQ_ACTIVE_INST_VALU") * 4 / 1024 / cycles, 3),
+                      "mfma_busy": round(f("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / cycles, 3), "kernel_cycles": cycles,
+                      "source": f"profiles/r06_pmc_{w}.md"}
+        print(w, "valu/hyp-chunk", round(traffic[w]["valu_insts_per_hypothesis_chunk"], 2), "(before:", round(old[w]["valu_insts_per_hypothesis_chunk"], 2), ") valu_busy",
+              traffic[w]["valu_busy"], "traffic MB", round(traffic[w]["traffic_bytes_per_launch"] / 1e6, 1))
+        wr(f"r06_pmc_{w}.md", f"# r06 - PMC passes of `bench.py --workload {w} --mode streams --streams 1` (separate rocprofv3 --pmc runs: SQ set 1, SQ set 2, "
+                              "GRBM, FETCH_SIZE, WRITE_SIZE; FETCH_SIZE in KB, doubled in profiles/pmc_traffic.json per MI355X_MICROARCH.md)\n\n" + md)
+    json.dump(traffic, open(p, "w"), indent=1)
+
+
 def main():
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "pmc":
+        refresh_pmc_constants()
+        return
     line = json.loads(rd("bench_default.json").strip().splitlines()[-1])
     wr("r06_bench_line.json", json.dumps(line, indent=1))
     det = json.loads(rd("detail_default.json"))
@@ -42,7 +90,9 @@ def main():
     for w in ("relpose_5000",):
         wr(f"r06_bench_{w}_1stream_kernel_trace.md", f"# r06 - `bench.py --workload {w} --mode streams --streams 1` under rocprofv3 --kernel-trace --stats\n\n" + rd(f"prof_{w}.md"))
         wr(f"r06_bench_{w}_groups_kernel_trace.md", f"# r06 - `bench.py --workload {w}` (grouped) under rocprofv3 --kernel-trace --stats\n\n" + rd(f"profg_{w}.md"))
-    for w in ("p3p_5000", "relpose_5000"):
+    for w in ("p3p_5000", "relpose_5000", "fund_10000", "hom_10000"):
+        if not rd(f"pmc_{w}.md"):
+            continue
         wr(f"r06_pmc_{w}.md", f"# r06 - PMC passes of `bench.py --workload {w} --mode streams --streams 1` (separate rocprofv3 --pmc runs: SQ set 1, SQ set 2, "
                               "GRBM, FETCH_SIZE, WRITE_SIZE; FETCH_SIZE in KB, doubled in profiles/pmc_traffic.json per MI355X_MICROARCH.md)\n\n" + rd(f"pmc_{w}.md"))
     sizes = rd("batch_sizes.log").splitlines()
