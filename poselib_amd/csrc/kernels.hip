@@ -754,7 +754,7 @@ __device__ __forceinline__ bool slice_chunk_of_workgroup(uint32_t slices, uint32
 #endif
 }
 
-// The exact pass of k_score_mfma (k_score_queue's arithmetic).  A drain is a dependency chain - queue entry, the lane
+// The exact pass of k_score_mfma and k_score_mfmah (k_score_queue's arithmetic).  A drain is a dependency chain - queue entry, the lane
 // permutation that turns the hypothesis into its record's slot, the record's twelve doubles from L2, the evaluation, the run
 // totals -, not work: 31 of the kernel's 132 us with four wavefronts per SIMD to hide it (profiles/r06_score_phases.md).  So
 // the chain is split - `fetch` issues every load of a batch of 64 pairs, `finish` evaluates it - and the kernel drains TWO
@@ -763,16 +763,17 @@ __device__ __forceinline__ bool slice_chunk_of_workgroup(uint32_t slices, uint32
 // saves and restores around 34 call sites cost more than the instruction cache gives back (137.9 us); one drain site behind
 // the rounds keeps the sixteen bit fields alive across it and spills them once per tile (97 registers).
 // queue: the wave's ring (kMfmaQueueCap entries: hypothesis of the unit << 9 | correspondence of the chunk); n0 (+ n1) pairs wait
-// at `first`; pts: the chunk's correspondences in LDS, [5][npw]; unit_slots: lane l = record slot of the unit's hypothesis l.
+// at `first`; pts: the chunk's correspondences in LDS, [5 or 4][npw]; unit_slots: lane l = record slot of the unit's hypothesis l.
 constexpr int kMfmaQueueCap = 1024; // >= 127 waiting + 64 lanes * 10 point groups appended by one round
-__device__ __forceinline__ void abs_drain(const uint16_t *queue, uint32_t first, uint32_t n0, uint32_t n1, const double *pts, int npw,
+template <int EST>
+__device__ __forceinline__ void mfma_drain(const uint16_t *queue, uint32_t first, uint32_t n0, uint32_t n1, const double *pts, int npw,
                                        const double *__restrict__ models, uint32_t unit_slots, double thr2, double *acc_s,
                                        uint32_t *acc_c) {
     const int lane = threadIdx.x & 63;
     struct Batch {
         uint32_t g;
         bool act;
-        double x[5];
+        double x[EST == EST_ABS ? 5 : 4];
         double M[kModelDoubles];
     };
     auto fetch = [&](uint32_t n, uint32_t at, Batch &b) {
@@ -781,7 +782,7 @@ __device__ __forceinline__ void abs_drain(const uint16_t *queue, uint32_t first,
         const uint32_t pi = b.act ? (e & 0x1ffu) : 0u;
         b.g = e >> 9;
 #pragma unroll
-        for (int d = 0; d < 5; ++d)
+        for (int d = 0; d < (EST == EST_ABS ? 5 : 4); ++d)
             b.x[d] = pts[d * npw + pi];
         // the fp64 model straight from its record (hypothesis k lives in slot slots[k]): no hypothesis-ordered copy of the
         // models is needed on this path.  The unit's slot numbers were fetched when the unit began - one lane per
@@ -798,7 +799,7 @@ __device__ __forceinline__ void abs_drain(const uint16_t *queue, uint32_t first,
     };
     auto finish = [&](const Batch &b) {
         double r2;
-        const bool in = eval_point<EST_ABS>(b.M, b.x, thr2, r2) && b.act;
+        const bool in = eval_point<EST>(b.M, b.x, thr2, r2) && b.act;
         const double v = in ? r2 : 0.0;
         const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.g);
@@ -900,16 +901,16 @@ __device__ __forceinline__ void score_mfma_body(const PointSet &pts, const uint4
         acc_c[lane] = 0;
         uint32_t qhead = 0, qtail = 0;
 
-        // The exact pass: abs_drain above, two batches of 64 pairs at a time
+        // The exact pass: mfma_drain above, two batches of 64 pairs at a time
         auto drain_pair = [&](uint32_t n2) { // 64 + n2 waiting pairs (0 < n2 <= 64)
 #if PL_ABS_EXP != 1
-            abs_drain(queue, qhead, 64u, n2, &s_pts[0][0], NPW, models, unit_slots, thr2, acc_s, acc_c);
+            mfma_drain<EST_ABS>(queue, qhead, 64u, n2, &s_pts[0][0], NPW, models, unit_slots, thr2, acc_s, acc_c);
 #endif
             qhead += 64u + n2;
         };
         auto drain = [&](uint32_t n) { // n <= 64 waiting pairs
 #if PL_ABS_EXP != 1
-            abs_drain(queue, qhead, n, 0u, &s_pts[0][0], NPW, models, unit_slots, thr2, acc_s, acc_c);
+            mfma_drain<EST_ABS>(queue, qhead, n, 0u, &s_pts[0][0], NPW, models, unit_slots, thr2, acc_s, acc_c);
 #endif
             qhead += n;
         };
@@ -1185,6 +1186,7 @@ __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint
     uint32_t kb, gn;
     while (unit_of_ticket(ticket, H, waves_per_chunk, kb, gn)) {
         const uint32_t pending = request_ticket();
+        const uint32_t unit_slots = slots[kb + min((uint32_t)lane, gn - 1u)]; // lane l: the record of the unit's hypothesis l (k_score_mfma)
         acc_s[lane] = 0.0;
         acc_c[lane] = 0;
         uint32_t qhead = 0, qtail = 0;
@@ -1195,7 +1197,7 @@ __device__ __forceinline__ void score_mfma2_body(const PointSet &pts, const uint
             const uint32_t e = act ? (uint32_t)queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffu;
             const uint32_t g = e >> 9, pi = act ? (e & 0x1ffu) : 0u;
             const double x0 = s_pts[0][pi], x1 = s_pts[1][pi], x2 = s_pts[2][pi], x3 = s_pts[3][pi];
-            const double *Mp = models + (size_t)slots[kb + (act ? g : 0u)] * kModelStride;
+            const double *Mp = models + (size_t)(uint32_t)__shfl((int)unit_slots, (int)(act ? g : 0u), 64) * kModelStride;
             double M[kModelDoubles];
 #pragma unroll
             for (int i = 0; i < kModelDoubles; ++i)
@@ -1418,38 +1420,15 @@ __device__ __forceinline__ void score_mfmah_body(const PointSet &pts, const uint
     uint32_t kb, gn;
     while (unit_of_ticket(ticket, H, waves_per_chunk, kb, gn)) {
         const uint32_t pending = request_ticket(); // the next unit's index travels while this one is evaluated
+        const uint32_t unit_slots = slots[kb + min((uint32_t)lane, gn - 1u)]; // lane l: the record of the unit's hypothesis l (k_score_mfma)
         acc_s[lane] = 0.0;
         acc_c[lane] = 0;
         uint32_t qhead = 0, qtail = 0;
 
-        auto drain = [&](uint32_t n) { // k_score_queue's exact pass; the fp64 models straight from their records
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const bool act = (uint32_t)lane < n;
-            const uint32_t e = act ? (uint32_t)queue[(qhead + lane) & (kMfmaQueueCap - 1)] : 0xffffu;
-            const uint32_t g = e >> 9, pi = act ? (e & 0x1ffu) : 0u;
-            double x[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                x[d] = s_pts[d][pi];
-            const double *Mp = models + (size_t)slots[kb + (act ? g : 0u)] * kModelStride;
-            double M[kModelDoubles];
-#pragma unroll
-            for (int i = 0; i < kModelDoubles; ++i)
-                M[i] = Mp[i];
-            double r2;
-            const bool in = eval_point<EST_HOM>(M, x, thr2, r2) && act;
-            double v = in ? r2 : 0.0;
-            const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
-            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-            if (inmask && !__builtin_amdgcn_ballot_w64(act && g != g0)) { // one hypothesis: plain wave sum
-                const double tot = wave_sum_dpp(v);
-                if (lane == 0) {
-                    acc_s[g0] += tot;
-                    acc_c[g0] += (uint32_t)__popcll(inmask);
-                }
-            } else if (inmask) {
-                add_run_totals(v, inmask, g, act, lane, acc_s, acc_c);
-            }
+        // the exact pass: mfma_drain (k_score_mfma's), ONE batch of 64 pairs at a time - two at a time need 16 registers more than
+        // the 84 that three workgroups per CU leave a wavefront: spilt, hom_10000 1.50 -> 1.42e8 on one box (round 6)
+        auto drain = [&](uint32_t n) { // n <= 64 waiting pairs
+            mfma_drain<EST_HOM>(queue, qhead, n, 0u, &s_pts[0][0], NPW, models, unit_slots, thr2, acc_s, acc_c);
             qhead += n;
         };
 
