@@ -155,6 +155,53 @@ def test_matrix_core_filter_never_drops_an_inlier_on_the_device(gpu):
     assert dropped == 0
 
 
+def test_matrix_core_filter_wide_field_of_view_and_far_world_frames_on_the_device(gpu):
+    """Round 6: image coordinates up to +-4 with inliers planted at the threshold in the corners, world frames whose origin is
+    10 .. 2e4 away from the camera while the scene sits next to it: the row's largest error is then the product rn16(t_2) rn16(p),
+    which the sixteenth k slot of the three-half-plane form pays for (pl_prefilter.h "Round 6").  Counts through the streaming
+    scorer must equal the oracle's exact evaluation for the planted model and for models next to it."""
+    rs = np.random.RandomState(177)
+    pairs = dropped = 0
+    for trial in range(20):
+        n = 4000
+        q = rs.randn(4)
+        q /= np.linalg.norm(q)
+        R = _rot(q)
+        fov = [0.5, 1.5, 4.0, 4.0][trial % 4]
+        xy = rs.uniform(-fov, fov, (n, 2))
+        if trial % 2:
+            xy[: n // 2] = np.sign(xy[: n // 2]) * fov * (1 - 1e-3 * rs.rand(n // 2, 2))  # corners
+        depth = 10.0 ** rs.uniform(-1, 1.5, n)
+        Zc = np.c_[xy * depth[:, None], depth]
+        tlen = [0.0, 10.0, 300.0, 5e3, 2e4][trial % 5]
+        t = rs.randn(3)
+        t *= tlen / max(np.linalg.norm(t), 1e-9)
+        X = (Zc - t) @ R  # R X + t = Zc
+        models = [np.r_[q, t]]
+        for k in (6, 5, 4, 3):
+            qq = q + 10.0 ** (-k) * rs.randn(4)
+            qq /= np.linalg.norm(qq)
+            models.append(np.r_[qq, t * (1 + 10.0 ** (-k) * rs.randn())])
+        M = np.array(models)
+        for thr in (1e-3, 0.012, 0.3, 0.99):
+            x = _plant_at_threshold(q, t, X, thr, rs)
+            prob = gpu.Problem(gpu.KIND_ABS, x, X)
+            cnt, sc, path = prob.score_stream(M, thr)
+            prob.close()
+            assert path == 2, (trial, thr, path)
+            for k in range(len(M)):
+                osc, ocnt = O.score("reproj", M[k], x, X, thr * thr)
+                pairs += n
+                if cnt[k] != ocnt:
+                    dropped += abs(int(cnt[k]) - int(ocnt))
+                    print("MISMATCH trial", trial, "fov", fov, "|t|", tlen, "thr", thr, "model", k, cnt[k], ocnt)
+                else:
+                    assert abs(sc[k] - osc) <= 1e-9 * abs(osc) + 1e-300
+    print(f"absolute pose, wide field of view: {pairs} pairs through the device filter, count differences {dropped}")
+    assert pairs >= 1_500_000
+    assert dropped == 0
+
+
 # ------------------------------------------------------------------------------------------ adversarial: two-view
 def _essential(q, t):
     R = _rot(q)
