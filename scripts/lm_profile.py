@@ -18,7 +18,7 @@ names = ["prepare+barrier", "sweep (thread 0)", "wait for slowest wave", "block 
 print("| estimator, n, loss | iterations | " + " | ".join(names) + " | sum of phases per iteration | passes per iteration |")
 print("|---|---|" + "---|" * (len(names) + 2))
 for kind, name in ((P.KIND_ABS, "abs"), (P.KIND_REL, "rel"), (P.KIND_HOM, "hom")):
-    for n in (300, 1500, 5000, 10000):
+    for n in ([int(x) for x in os.environ["LM_PROFILE_N"].split(",")] if os.environ.get("LM_PROFILE_N") else (300, 1500, 5000, 10000)):
         for loss in ("TRUNCATED", "CAUCHY"):
             if kind == P.KIND_ABS:
                 d = synth.absolute_pose_scene(n, 0.5, 77); a, b = (d["p2d"] - 500.0) / 1000.0, d["p3d"]
