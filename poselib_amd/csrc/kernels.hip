@@ -717,7 +717,9 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 #define PL_MFMA_THREADS 512
 #endif
 #ifndef PL_ABS_TILE_UNROLL
-#define PL_ABS_TILE_UNROLL 1 // k_score_mfma's loop over the point groups of a tile
+#define PL_ABS_TILE_UNROLL 16 // k_score_mfma's loop over the point groups of a tile: unrolled completely (PG - 1 <= 9 iterations) - the LDS
+                             // addresses of the operands become immediate offsets (3 of 35 vector instructions per group): 131.0 -> 126.5 us
+                             // per launch (unrolled 3 times: 125.9 / 129.1; profiles/r06_score_phases.md)
 #endif
 #ifndef PL_ABS_SCHED
 #define PL_ABS_SCHED 1 // k_score_mfma: the products of the next point group interleaved with the vector instructions of this one

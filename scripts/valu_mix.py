@@ -124,6 +124,16 @@ def analyse(obj, pattern):
         else:
             hot = max(cands, key=lambda se: sum(1 for _, m, _ in ins[se[0]:se[1] + 1] if m.startswith("v_")) / (1 + 0.01 * (se[1] - se[0])))
     res = {"kernel": name, "whole_kernel_static": mix(ins)}
+    mf = [k for k, (_, m, _) in enumerate(ins) if m.startswith("v_mfma")]
+    n_hot_mfma = sum(1 for _, m, _ in ins[hot[0]:hot[1] + 1] if m.startswith("v_mfma")) if (hot and with_mfma) else 0
+    if mf and (not with_mfma or n_hot_mfma > 12):
+        # a completely unrolled tile loop (k_score_mfma since round 6): the straight-line stretch from the first MFMA to the first
+        # branch behind the last one takes the loop's place (ONE "iteration" that holds all point groups of a tile)
+        end = mf[-1]
+        while end + 1 < len(ins) and not ins[end + 1][1].startswith("s_cbranch") and not ins[end + 1][1].startswith("s_branch"):
+            end += 1
+        hot = (mf[0], end)
+        res["hot_loop_is_unrolled_stretch"] = True
     if hot:
         res["hot_loop"] = mix(ins[hot[0]:hot[1] + 1])
         rest = ins[:hot[0]] + ins[hot[1] + 1:]
