@@ -3322,7 +3322,13 @@ int get_lm_mode() {
     }
     return m;
 }
+// (a calling thread can ask for the reference's order for the launches it makes itself: the driver re-runs a homography problem
+// that way when a decision of its loop hung on the last bits of two refined models of opposite sign - driver.cc ransac_core)
+static thread_local int tl_lm_force_ordered = 0;
+void set_lm_force_ordered(int on) { tl_lm_force_ordered = on; }
 bool lm_sums_ordered(int est) {
+    if (tl_lm_force_ordered)
+        return true;
     const int m = get_lm_mode();
     return m == 1 || (m == 0 && est == EST_FUND);
 }

@@ -342,6 +342,7 @@ hipError_t launch_lm_tasks(int est, LMTask *tasks, uint32_t num_tasks, uint32_t 
 void set_lm_mode(int mode);
 int get_lm_mode();
 bool lm_sums_ordered(int est); // what launch_lm_tasks will pick for this estimator
+void set_lm_force_ordered(int on); // this host thread's LM launches in the reference's order whatever the mode (0: back to the mode)
 // absolute pose + camera intrinsics (lm_cam.hip): tasks with cam_flags != 0; refined pose -> params / record_out, camera -> cam
 hipError_t launch_lm_cam(LMTask *tasks, uint32_t num_tasks, hipStream_t stream);
 int group_points_per_lane(int est); // P of the group launches (fixed per estimator)

@@ -341,6 +341,27 @@ def test_estimate_homography_parity(gpu, n, outl, dseed, rseed):
     assert ok, err
 
 
+def test_homography_decision_between_h_and_minus_h(gpu):
+    """Round 6 (item 1186 of tests/parity_soak_estimate_batch.py 4000 11): two local optimisations from minimal models of opposite
+    sign end in the same optimum, as H and -H, with scores that agree to the last bits; `score < best` then hangs on the bits of the
+    refined models.  With the default tree-order sums the device returned -1 x the reference's matrix (everything else identical);
+    the driver now repeats the two refinements in the reference's order when such a decision comes up (RansacRun::resolve_sign_tie).
+    Single call and batch call, sign-sensitive."""
+    n, outl = 1616, 0.12012363631497766
+    d = synth.homography_scene(n, outl, 60000 + 1186)
+    order = np.argsort(~d["inlier_gt"], kind="stable")
+    x1, x2 = np.asarray(d["x1"])[order], np.asarray(d["x2"])[order]
+    opt = {"ransac": {"seed": 579604402, "progressive_sampling": True}}
+    Hr, mask, st = O.estimate_homography(x1, x2, opt)
+    H, info = gpu.estimate_homography(x1, x2, opt)
+    (res,) = gpu.estimate_batch([("hom", x1, x2, opt)], max_in_flight=1)
+    for got, inf in ((H, info), res):
+        assert inf["iterations"] == st["iterations"] and inf["refinements"] == st["refinements"]
+        assert inf["num_inliers"] == st["num_inliers"] and (np.array(inf["inliers"]) == mask).all()
+        ok, err = mat_close(got, Hr)
+        assert ok, err
+
+
 @pytest.mark.parametrize("n,outl,dseed,rseed", [(10000, 0.5, 1004, 0), (2000, 0.3, 32, 5)])
 def test_estimate_fundamental_parity(gpu, n, outl, dseed, rseed):
     d = synth.fundamental_scene(n, outl, dseed)
