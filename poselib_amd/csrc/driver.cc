@@ -777,17 +777,19 @@ struct RansacRun {
     // the default sums run in tree order (models 1e-13 off the reference's), and in one of ~1000 default-option problems the
     // caller got -H (tests/parity_soak_estimate_batch.py 4000 11, item 1186; every other field identical).  A local
     // optimisation is a function of its seed - the minimal model, whose bits ARE the reference's - so when such a decision
-    // comes up (opposite signs, scores within 1e-13: the tree order moves a converged model's score by ulps) the two
+    // comes up (opposite signs, scores within 2e-15: the tree order moves a converged model's score by an ulp or two) the two
     // refinements are repeated with the sums in the reference's order (k_lm_ordered) and the decision is taken on those
     // results, which are the reference's bit for bit.  Up to 4096 correspondences: there the ordered kernel costs 1.3 - 2 x the
-    // tree kernel for the one or two tasks concerned (0.8 % of the default-option homography problems); at 10^4 it costs 6 x
+    // tree kernel for the one or two tasks concerned (< 0.5 % of the default-option homography problems; with a bound of 1e-13,
+    // 1.5 % of them, the synchronous launches inside the groups' replays cost a 512-problem batch call 17 %); at 10^4 it costs 6 x
     // and long runs meet such a pair about once each - that regime keeps the tree order (pl_set_lm_mode(1) pins it).
     double best_seed[kModelStride];                  // the minimal model the incumbent was refined from ...
     bool best_from_lo = false, best_exact = false;   // ... if it is a refined one / already refined in the reference's order
-    static constexpr double kSignTieGap = 1e-13;
+    static constexpr double kSignTieGap = 2e-15; // (9 ulps of the score: the tree order moves a converged model's score by an ulp or two)
     static constexpr uint32_t kSignTieMaxPoints = 4096;
     int resolve_sign_tie(RefineJob &job) {
-        if (kind != EST_HOM || sh || N <= (uint32_t)kLMSeqPoints || N > kSignTieMaxPoints || lm_sums_ordered(EST_HOM) || job.skipped ||
+        static const bool off = std::getenv("POSELIB_AMD_NO_SIGN_TIE") != nullptr; // (diagnostic: A/B of what the extra refinements cost)
+        if (off || kind != EST_HOM || sh || N <= (uint32_t)kLMSeqPoints || N > kSignTieMaxPoints || lm_sums_ordered(EST_HOM) || job.skipped ||
             !(st->model_score < std::numeric_limits<double>::max()) ||
             !(std::fabs(job.score - st->model_score) <= kSignTieGap * std::fabs(st->model_score)))
             return PL_OK;
