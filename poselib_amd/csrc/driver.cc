@@ -789,7 +789,8 @@ struct RansacRun {
     static constexpr uint32_t kSignTieMaxPoints = 4096;
     int resolve_sign_tie(RefineJob &job) {
         static const bool off = std::getenv("POSELIB_AMD_NO_SIGN_TIE") != nullptr; // (diagnostic: A/B of what the extra refinements cost)
-        if (off || kind != EST_HOM || sh || N <= (uint32_t)kLMSeqPoints || N > kSignTieMaxPoints || lm_sums_ordered(EST_HOM) || job.skipped ||
+        // (a sharded run: every rank holds the whole problem and replays the same decisions - each repeats the two refinements itself)
+        if (off || kind != EST_HOM || N <= (uint32_t)kLMSeqPoints || N > kSignTieMaxPoints || lm_sums_ordered(EST_HOM) || job.skipped ||
             !(st->model_score < std::numeric_limits<double>::max()) ||
             !(std::fabs(job.score - st->model_score) <= kSignTieGap * std::fabs(st->model_score)))
             return PL_OK;
